@@ -1,0 +1,263 @@
+"""ctypes binding of the CPU oracle (oracle/wost_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package (elaina_amd/) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+
+
+def build(force=False):
+    """Compile the oracle with gcc (plain C, seconds)."""
+    targets = [os.path.join(_BUILD, "libwost_oracle.so"), os.path.join(_BUILD, "libwost_oracle_libm.so")]
+    src = [os.path.join(_HERE, "wost_oracle.c"), os.path.join(_HERE, "wost_oracle.h")]
+    stale = force or any(
+        (not os.path.exists(t)) or os.path.getmtime(t) < max(os.path.getmtime(s) for s in src) for t in targets
+    )
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return targets[0]
+
+
+class Mesh(C.Structure):
+    _fields_ = [
+        ("n_verts", C.c_int),
+        ("n_segs", C.c_int),
+        ("verts", C.POINTER(C.c_float)),
+        ("segs", C.POINTER(C.c_int)),
+        ("colors", C.POINTER(C.c_float)),
+    ]
+
+
+class Scene(C.Structure):
+    _fields_ = [
+        ("dirichlet", Mesh),
+        ("neumann", Mesh),
+        ("dirichlet_intensity", C.c_float),
+        ("neumann_intensity", C.c_float),
+        ("probe_scale", C.c_float),
+        ("probe_pos", C.c_float * 2),
+        ("probe_up", C.c_float * 2),
+        ("mask", C.POINTER(C.c_ubyte)),
+    ]
+
+
+class Settings(C.Structure):
+    _fields_ = [
+        ("width", C.c_int),
+        ("height", C.c_int),
+        ("spp", C.c_int),
+        ("max_depth", C.c_int),
+        ("eps_shell", C.c_float),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("walk_steps", C.c_uint64),
+        ("walks_started", C.c_uint64),
+        ("walks_absorbed", C.c_uint64),
+        ("walks_truncated", C.c_uint64),
+        ("neumann_hits", C.c_uint64),
+        ("seconds", C.c_double),
+    ]
+
+
+class Pcg(C.Structure):
+    _fields_ = [("state", C.c_uint64), ("inc", C.c_uint64)]
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class Oracle:
+    def __init__(self, libm=False):
+        build()
+        name = "libwost_oracle_libm.so" if libm else "libwost_oracle.so"
+        self.lib = C.CDLL(os.path.join(_BUILD, name))
+        L = self.lib
+        L.wo_version.restype = C.c_char_p
+        L.wo_pcg_next_uint.restype = C.c_uint32
+        L.wo_pcg_next_float.restype = C.c_float
+        L.wo_pcg_next_double.restype = C.c_double
+        L.wo_interleave_32bit.restype = C.c_uint32
+        L.wo_interleave_32bit.argtypes = [C.c_uint32, C.c_uint32]
+        L.wo_pcg_set_seed.argtypes = [C.POINTER(Pcg), C.c_uint64, C.c_uint64]
+        L.wo_pcg_advance.argtypes = [C.POINTER(Pcg), C.c_int64]
+        L.wo_pcg_seed_pixel.argtypes = [C.POINTER(Pcg), C.c_int, C.c_int]
+        L.wo_logf.restype = C.c_float
+        L.wo_logf.argtypes = [C.c_float]
+        L.wo_sincos_2pi.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        self._keep = []
+
+    def version(self):
+        return self.lib.wo_version().decode()
+
+    # ---- helpers to build the C structs from numpy arrays -------------------
+    def _mesh(self, verts, segs, colors):
+        m = Mesh()
+        if verts is None or segs is None or len(segs) == 0:
+            m.n_verts = 0
+            m.n_segs = 0
+            return m
+        v = np.ascontiguousarray(verts, dtype=np.float32)
+        s = np.ascontiguousarray(segs, dtype=np.int32)
+        self._keep += [v, s]
+        m.n_verts, m.n_segs = len(v), len(s)
+        m.verts, m.segs = _fp(v), _ip(s)
+        if colors is not None:
+            c = np.ascontiguousarray(colors, dtype=np.float32)
+            assert c.shape == (len(v), 6)
+            self._keep.append(c)
+            m.colors = _fp(c)
+        return m
+
+    def make_scene(self, sd):
+        """sd: dict with d_verts,d_segs,d_colors,n_verts,n_segs,n_colors(optional),probe,
+        dirichlet_intensity, neumann_intensity, mask (optional)"""
+        self._keep = []
+        sc = Scene()
+        sc.dirichlet = self._mesh(sd.get("d_verts"), sd.get("d_segs"), sd.get("d_colors"))
+        sc.neumann = self._mesh(sd.get("n_verts"), sd.get("n_segs"), sd.get("n_colors"))
+        sc.dirichlet_intensity = float(sd.get("dirichlet_intensity", 1.0))
+        sc.neumann_intensity = float(sd.get("neumann_intensity", 1.0))
+        p = np.asarray(sd["probe"], dtype=np.float32)
+        sc.probe_scale = float(p[0])
+        sc.probe_pos[0], sc.probe_pos[1] = float(p[1]), float(p[2])
+        sc.probe_up[0], sc.probe_up[1] = float(p[3]), float(p[4])
+        mask = sd.get("mask")
+        if mask is not None:
+            mk = np.ascontiguousarray(mask, dtype=np.uint8)
+            self._keep.append(mk)
+            sc.mask = mk.ctypes.data_as(C.POINTER(C.c_ubyte))
+        return sc
+
+    # ---- solver ----------------------------------------------------------------
+    def solve(self, sd, width, height, spp, max_depth, eps, pixel_begin=0, pixel_end=None, threads=8,
+              want_steps=False, want_hist=False):
+        sc = self.make_scene(sd)
+        st = Settings(width, height, spp, max_depth, eps)
+        if pixel_end is None:
+            pixel_end = width * height
+        n = pixel_end - pixel_begin
+        field = np.zeros((n, 3), dtype=np.float32)
+        steps = np.zeros(n, dtype=np.uint32) if want_steps else None
+        hist = np.zeros(max_depth, dtype=np.uint64) if want_hist else None
+        stats = Stats()
+        rc = self.lib.wo_solve(
+            C.byref(sc), C.byref(st), pixel_begin, pixel_end, threads, _fp(field),
+            steps.ctypes.data_as(C.POINTER(C.c_uint32)) if want_steps else None,
+            hist.ctypes.data_as(C.POINTER(C.c_uint64)) if want_hist else None,
+            C.byref(stats),
+        )
+        if rc != 0:
+            raise RuntimeError("wo_solve failed: %d" % rc)
+        out = {
+            "field": field,
+            "walk_steps": int(stats.walk_steps),
+            "walks_started": int(stats.walks_started),
+            "walks_absorbed": int(stats.walks_absorbed),
+            "walks_truncated": int(stats.walks_truncated),
+            "neumann_hits": int(stats.neumann_hits),
+            "seconds": float(stats.seconds),
+        }
+        if want_steps:
+            out["steps"] = steps
+        if want_hist:
+            out["depth_hist"] = hist
+        return out
+
+    def render_dirichlet_sdf(self, sd, width, height, threads=8):
+        sc = self.make_scene(sd)
+        st = Settings(width, height, 1, 1, 1.0)
+        out = np.zeros(width * height, dtype=np.float32)
+        rc = self.lib.wo_render_dirichlet_sdf(C.byref(sc), C.byref(st), threads, _fp(out))
+        if rc != 0:
+            raise RuntimeError("wo_render_dirichlet_sdf failed: %d" % rc)
+        return out
+
+    # ---- batch queries -----------------------------------------------------------
+    def closest_point(self, verts, segs, pts, mode=1):
+        self._keep = []
+        m = self._mesh(verts, segs, None)
+        p = np.ascontiguousarray(pts, dtype=np.float32)
+        n = len(p)
+        idx = np.zeros(n, dtype=np.int32)
+        dist = np.zeros(n, dtype=np.float32)
+        uv = np.zeros(n, dtype=np.float32)
+        side = np.zeros(n, dtype=np.int32)
+        rc = self.lib.wo_closest_point_batch(C.byref(m), _fp(p), n, mode, _ip(idx), _fp(dist), _fp(uv), _ip(side))
+        if rc != 0:
+            raise RuntimeError("wo_closest_point_batch failed: %d" % rc)
+        return idx, dist, uv, side
+
+    def closest_silhouette(self, verts, segs, pts, rmax=None):
+        self._keep = []
+        m = self._mesh(verts, segs, None)
+        p = np.ascontiguousarray(pts, dtype=np.float32)
+        n = len(p)
+        out = np.zeros(n, dtype=np.float32)
+        r = None
+        if rmax is not None:
+            r = np.ascontiguousarray(rmax, dtype=np.float32)
+        rc = self.lib.wo_closest_silhouette_batch(C.byref(m), _fp(p), _fp(r) if r is not None else None, n, _fp(out))
+        if rc != 0:
+            raise RuntimeError("wo_closest_silhouette_batch failed: %d" % rc)
+        return out
+
+    def ray_intersect(self, verts, segs, origins, dirs, tmax):
+        self._keep = []
+        m = self._mesh(verts, segs, None)
+        o = np.ascontiguousarray(origins, dtype=np.float32)
+        d = np.ascontiguousarray(dirs, dtype=np.float32)
+        t = np.ascontiguousarray(tmax, dtype=np.float32)
+        n = len(o)
+        hit = np.zeros(n, dtype=np.int32)
+        tt = np.zeros(n, dtype=np.float32)
+        idx = np.zeros(n, dtype=np.int32)
+        rc = self.lib.wo_ray_intersect_batch(C.byref(m), _fp(o), _fp(d), _fp(t), n, _ip(hit), _fp(tt), _ip(idx))
+        if rc != 0:
+            raise RuntimeError("wo_ray_intersect_batch failed: %d" % rc)
+        return hit, tt, idx
+
+    # ---- scalar helpers for KATs ---------------------------------------------------
+    def pcg_seed(self, initstate, initseq):
+        r = Pcg()
+        self.lib.wo_pcg_set_seed(C.byref(r), initstate, initseq)
+        return r
+
+    def pcg_seed_pixel(self, pixel_id, width):
+        r = Pcg()
+        self.lib.wo_pcg_seed_pixel(C.byref(r), pixel_id, width)
+        return r
+
+    def pcg_uint(self, r):
+        return int(self.lib.wo_pcg_next_uint(C.byref(r)))
+
+    def pcg_float(self, r):
+        return float(self.lib.wo_pcg_next_float(C.byref(r)))
+
+    def pcg_double(self, r):
+        return float(self.lib.wo_pcg_next_double(C.byref(r)))
+
+    def pcg_advance(self, r, delta):
+        self.lib.wo_pcg_advance(C.byref(r), delta)
+
+    def sincos_2pi(self, u):
+        c, s = C.c_float(), C.c_float()
+        self.lib.wo_sincos_2pi(C.c_float(u), C.byref(c), C.byref(s))
+        return c.value, s.value
+
+    def logf(self, x):
+        return float(self.lib.wo_logf(C.c_float(x)))

@@ -1,0 +1,132 @@
+/*
+ * wost_oracle.h -- CPU oracle for the wavefront Walk-on-Stars hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under elaina_amd/ (the product) may
+ * include, link or call this.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and only as the checker / the reported
+ * host baseline.
+ *
+ * What it restates (all paths relative to /root/reference):
+ *   integrator/uniform/integrator.cu:65-100,103-212,215-232,319-445,448-526,529-623
+ *   integrator/uniform/workitem.h:12-61, workqueue.h:25-29,99-110
+ *   core/sampler.h:20-98, util/hash.h:13-28, core/evaluation_grid.h:27-33
+ *   util/sampling.h:29-42,80-94,112-115, util/green.h:15-74
+ *   util/transformation.h:30-55, util/math_utils.h:153-156,319-322
+ *   integrator/common.h:242-260, core/math/include/krrmath/functors.h:60-92
+ *
+ * PARITY STATUS: the geometric queries of the path live in the third-party
+ * submodule ext/lbvh = tyanyuy3125/snch-lbvh (.gitmodules:16-18, pinned commit
+ * unknown, directory empty in /root/reference), and the reference has no test
+ * or golden vector for the integrators.  The pieces that ARE pinned here:
+ * PCG32 against the canonical pcg32 known-answer vector (the reference's
+ * sampler is the canonical generator, core/sampler.h:20-27,65-72) and the
+ * per-pixel seeding vectors of SURVEY.md 8(c).  For the lbvh boundary the
+ * oracle implements the mathematical definition of each query (exact closest
+ * point / closest silhouette vertex / first hit) and is checked against an
+ * O(N) brute force.  => "parity unpinned" at the snch-lbvh boundary.
+ *
+ * Deterministic arithmetic (so that the HIP path can be compared bit for bit):
+ *   - fp32 everywhere except PCG32 (uint64), compiled with -ffp-contract=off;
+ *   - fmaf() only where written explicitly;
+ *   - sin/cos/log are the polynomial kernels specified in DESIGN.md
+ *     ("deterministic math"), not libm (build with -DWOST_ORACLE_LIBM to get
+ *     the literal std::cos/std::sin/std::log restatement for statistical
+ *     cross-checks).
+ */
+#ifndef WOST_ORACLE_H
+#define WOST_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wo_mesh {
+    int n_verts;
+    int n_segs;
+    const float *verts;   /* n_verts * 2 (x,y)                                  */
+    const int *segs;      /* n_segs  * 2 (i0,i1), 0-based                       */
+    const float *colors;  /* n_verts * 6 (left rgb, right rgb) or NULL = zeros  */
+} wo_mesh;
+
+typedef struct wo_scene {
+    wo_mesh dirichlet;    /* n_segs == 0  -> Dirichlet disabled */
+    wo_mesh neumann;      /* n_segs == 0  -> Neumann disabled   */
+    float dirichlet_intensity;
+    float neumann_intensity;
+    float probe_scale;
+    float probe_pos[2];
+    float probe_up[2];
+    const unsigned char *mask; /* width*height bytes (0 = masked out) or NULL   */
+} wo_scene;
+
+typedef struct wo_settings {
+    int width;
+    int height;
+    int spp;
+    int max_depth;
+    float eps_shell;
+} wo_settings;
+
+typedef struct wo_stats {
+    uint64_t walk_steps;      /* sum over depths of the size of the eval queue  */
+    uint64_t walks_started;
+    uint64_t walks_absorbed;  /* terminated in the epsilon shell                */
+    uint64_t walks_truncated; /* reached max_depth                              */
+    uint64_t neumann_hits;    /* steps that landed on the Neumann boundary      */
+    double seconds;
+} wo_stats;
+
+/* ---- PCG32 (core/sampler.h) -------------------------------------------- */
+typedef struct wo_pcg { uint64_t state, inc; } wo_pcg;
+void wo_pcg_set_seed(wo_pcg *r, uint64_t initstate, uint64_t initseq);
+uint32_t wo_pcg_next_uint(wo_pcg *r);
+float wo_pcg_next_float(wo_pcg *r);
+double wo_pcg_next_double(wo_pcg *r);
+void wo_pcg_advance(wo_pcg *r, int64_t delta);
+uint32_t wo_interleave_32bit(uint32_t x, uint32_t y);
+/* prepareSolve seeding of one pixel (integrator.cu:71-77) */
+void wo_pcg_seed_pixel(wo_pcg *r, int pixel_id, int width);
+
+/* ---- deterministic math ------------------------------------------------ */
+void wo_sincos_2pi(float u, float *c, float *s);   /* cos/sin(2*pi*u), u in [0,1) */
+float wo_logf(float x);                            /* natural log, x > 0 finite   */
+
+/* ---- evaluation grid --------------------------------------------------- */
+void wo_eval_point(const wo_scene *sc, int px, int py, int width, int height,
+                   float *x, float *y);
+
+/* ---- geometric queries (definition of the lbvh boundary) ---------------- */
+/* closest point: returns per query the winning segment (original index),
+ * the distance, the unclamped projection ratio and the side.
+ * mode 0 = brute force O(N), 1 = oracle's own BVH. */
+int wo_closest_point_batch(const wo_mesh *mesh, const float *pts, int n, int mode,
+                           int *out_idx, float *out_dist, float *out_uv, int *out_side);
+/* closest silhouette vertex distance, search radius limited to rmax
+ * (pass INFINITY for unbounded); returns INFINITY when there is none. */
+int wo_closest_silhouette_batch(const wo_mesh *mesh, const float *pts, const float *rmax,
+                                int n, float *out_dist);
+/* closest-hit ray query: hit flag, t, segment index. */
+int wo_ray_intersect_batch(const wo_mesh *mesh, const float *origins, const float *dirs,
+                           const float *tmax, int n, int *out_hit, float *out_t, int *out_idx);
+
+/* ---- the solver --------------------------------------------------------- */
+/* Solves pixels [pixel_begin, pixel_end) of the width*height frame with
+ * n_threads host threads.  field_rgb: (pixel_end-pixel_begin)*3 floats,
+ * steps_per_pixel (optional): (pixel_end-pixel_begin) uint32,
+ * depth_hist (optional): max_depth uint64 (queue size per depth, summed over spp). */
+int wo_solve(const wo_scene *sc, const wo_settings *st, int pixel_begin, int pixel_end,
+             int n_threads, float *field_rgb, uint32_t *steps_per_pixel,
+             uint64_t *depth_hist, wo_stats *stats);
+
+/* Dirichlet SDF channel (integrator/common.h:52-85): distance per pixel. */
+int wo_render_dirichlet_sdf(const wo_scene *sc, const wo_settings *st, int n_threads,
+                            float *out_dist);
+
+const char *wo_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
