@@ -1,0 +1,53 @@
+"""Build the HIP shared library (libwost_hip.so) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the build container as the
+"does it build" check and the resulting .so travels to the GPU box with the tree.
+"""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libwost_hip.so")
+HOST_EXE = os.path.join(LIB_DIR, "elaina-exec")
+
+SOURCES = ["wost_hip.hip", "lbvh_build.cpp"]
+HEADERS = ["lbvh.h", "wost_device.h", "wost_math.h", os.path.join("..", "..", "include", "wost.h")]
+
+# -ffp-contract=off is part of the arithmetic contract (DESIGN.md "deterministic math")
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP library cannot be built")
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_library(force=False, verbose=False):
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
+    if force or _stale(LIB_PATH, deps):
+        cmd = [_hipcc()] + HIPCC_FLAGS + srcs + ["-o", LIB_PATH]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

@@ -1,0 +1,125 @@
+"""ctypes binding of the C-ABI in include/wost.h (libwost_hip.so).
+
+This is the Python-side stub a maintainer would write against the boundary; it adds
+nothing to the data path.  If the library is missing it raises -- there is no CPU
+fallback in the product.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+WOST_OK = 0
+MESH_DIRICHLET = 0
+MESH_NEUMANN = 1
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [
+        ("n_verts", C.c_int32),
+        ("n_segs", C.c_int32),
+        ("verts", C.POINTER(C.c_float)),
+        ("segs", C.POINTER(C.c_int32)),
+        ("colors", C.POINTER(C.c_float)),
+    ]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("dirichlet", MeshDesc),
+        ("neumann", MeshDesc),
+        ("dirichlet_intensity", C.c_float),
+        ("neumann_intensity", C.c_float),
+        ("probe_scale", C.c_float),
+        ("probe_pos", C.c_float * 2),
+        ("probe_up", C.c_float * 2),
+        ("mask", C.POINTER(C.c_uint8)),
+    ]
+
+
+class Settings(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("spp", C.c_int32),
+        ("max_depth", C.c_int32),
+        ("eps_shell", C.c_float),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("walk_steps", C.c_uint64),
+        ("walks_started", C.c_uint64),
+        ("walks_absorbed", C.c_uint64),
+        ("walks_truncated", C.c_uint64),
+        ("neumann_hits", C.c_uint64),
+        ("solve_ms", C.c_double),
+        ("kernel_ms", C.c_double),
+        ("kernel_launches", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+EXPORTS = [
+    "wost_create", "wost_solve", "wost_solve_sharded", "wost_render_sdf", "wost_closest_point",
+    "wost_closest_silhouette", "wost_ray_intersect", "wost_set_option", "wost_destroy",
+    "wost_last_error", "wost_version",
+]
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load libwost_hip.so (built in-tree by elaina_amd.build). Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "libwost_hip.so is missing (%s): run `python -m elaina_amd.build`; "
+            "this package has no CPU fallback" % path)
+    L = C.CDLL(path)
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    L.wost_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(Settings), C.c_int, C.POINTER(C.c_void_p)]
+    L.wost_solve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, fp, C.POINTER(Stats)]
+    L.wost_solve_sharded.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    L.wost_render_sdf.argtypes = [C.c_void_p, C.c_int, fp]
+    L.wost_closest_point.argtypes = [C.c_void_p, C.c_int, fp, C.c_int32, ip, fp, fp, ip]
+    L.wost_closest_silhouette.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_int32, fp]
+    L.wost_ray_intersect.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, C.c_int32, ip, fp, ip]
+    L.wost_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    L.wost_destroy.argtypes = [C.c_void_p]
+    L.wost_last_error.restype = C.c_char_p
+    L.wost_version.restype = C.c_char_p
+    for name in EXPORTS:
+        getattr(L, name)  # fail loudly on a missing symbol
+    _lib = L
+    return L
+
+
+class WostError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != WOST_OK:
+        raise WostError("%s failed (%d): %s" % (what, rc, load().wost_last_error().decode()))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))

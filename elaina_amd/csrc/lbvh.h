@@ -1,0 +1,66 @@
+// lbvh.h -- host-side builder of the wide LBVH the HIP kernels traverse.
+//
+// Replaces (does not port) lbvh::scene<2>::build_bvh() / compute_silhouettes() of
+// the absent third-party snch-lbvh (reference call sites core/problem.cu:31-37,48-54).
+//
+// Layout, designed for per-lane gathers on gfx950 rather than for a pointer-chasing
+// binary tree:
+//   * segments are sorted by the 32-bit Morton code of their centroid;
+//   * a leaf is 4 consecutive sorted segments;
+//   * the hierarchy is an IMPLICIT complete 4-ary tree in heap order: node g has the
+//     children 4g+1..4g+4, node 0 is the root, leaves are the nodes of level `levels`.
+//     No child pointers are stored; the four child boxes of node g are the float4s
+//     boxes[4g..4g+3] = one aligned 64-byte line, fetched with one dwordx4 per child.
+//   * leaf k stores its four segments as float4 {ax, ay, ex, ey} in segA[4k..4k+3]
+//     (one 64-byte line) plus float4 segInv[k] = the four 1/|e|^2.
+// Query results do not depend on this layout: the closest-point query returns the
+// minimum distance with ties broken by the lowest ORIGINAL segment index, and node
+// boxes are padded so that pruning can never cut a segment that ties or wins.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace wost {
+
+constexpr int kLeafSize = 4;
+constexpr int kArity = 4;
+constexpr int kFarIndex = 0x7fffffff;
+constexpr float kFarCoord = 1.0e18f;
+
+// one boundary segment in ORIGINAL order, with everything the flat Neumann loops need
+struct FlatSeg {
+    float ax, ay, ex, ey;
+    float inv_len2, len, nx, ny;  // unit normal (e.y, -e.x)/|e|
+};
+
+// silhouette candidate (one per mesh vertex that has at least one incident segment)
+struct SilVertex {
+    float x, y;
+    int32_t prev, next;  // segment ending / starting at this vertex, -1 if none
+};
+
+struct HostTree {
+    int32_t n_segs = 0;
+    int32_t n_verts = 0;
+    int32_t levels = 0;        // >= 1 when n_segs > 0
+    int32_t first_leaf = 0;    // heap index of leaf 0 = (4^levels - 1) / 3
+    int32_t n_leaves_cap = 0;  // 4^levels
+    int32_t n_leaves = 0;      // leaves holding at least one real segment
+    float pad = 0.0f;
+    std::vector<float> boxes;     // 4 floats per node g >= 1, stored at [g-1]: lox, loy, hix, hiy
+    std::vector<float> segA;      // 4 floats per slot
+    std::vector<float> segInv;    // 1 float per slot
+    std::vector<int32_t> segOrig; // original index per slot (kFarIndex for padding)
+    std::vector<float> segCol;    // 12 floats per slot: left(i0) left(i1) right(i0) right(i1)
+    std::vector<int32_t> origToSlot;
+    std::vector<FlatSeg> flat;    // original order
+    std::vector<float> flatCol;   // 12 floats per original segment
+    std::vector<SilVertex> sil;   // silhouette candidates
+    float aabb[4] = {0, 0, 0, 0}; // lox, loy, hix, hiy of the mesh
+};
+
+// Returns 0 on success, negative on invalid input (index out of range).
+int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_t *segs,
+               const float *colors, HostTree *out);
+
+}  // namespace wost

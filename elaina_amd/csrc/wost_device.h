@@ -1,0 +1,322 @@
+// wost_device.h -- device-side geometry queries and the per-step walk logic (gfx950).
+//
+// Everything the wavefront loop of the reference's uniform integrator does per walk item
+// (integrator/uniform/integrator.cu:128-211 separate, :224-231 handleBoundary, :336-444
+// sampleNeumann, :465-525 oneStepWalk) is one inlined device function here, so that a walk
+// item never leaves registers between stages.  The lbvh queries it needs are written
+// against the implicit 4-ary LBVH of lbvh.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wost_math.h"
+
+namespace wost {
+
+#define WOST_R_B_FLOOR 1e-4f
+#define WOST_R_B_SHRINK 0.99f
+#define WOST_SIL_PRECISION 1e-3f
+#define WOST_FAR_INDEX 0x7fffffff
+#define WOST_INF __builtin_inff()
+
+// ---- device views ----------------------------------------------------------------------
+struct DevFlatSeg {
+    float ax, ay, ex, ey;
+    float inv_len2, len, nx, ny;
+};
+struct DevSilVertex {
+    float x, y;
+    int32_t prev, next;
+};
+
+struct DevMesh {
+    const float4 *boxes;     // [n_nodes-1], children of g at 4g..4g+3
+    const float4 *segA;      // [slots] ax, ay, ex, ey
+    const float4 *segInv;    // [leaves] 1/|e|^2 of the four slots
+    const int32_t *segOrig;  // [slots]
+    const float *segCol;     // [slots*12]
+    const DevFlatSeg *flat;  // [n_segs] original order
+    const float *flatCol;    // [n_segs*12]
+    const DevSilVertex *sil; // [n_sil]
+    int32_t n_segs;
+    int32_t n_sil;
+    int32_t levels;
+    int32_t first_leaf;
+    int32_t emissive;        // any non-zero colour
+};
+
+struct DevProbe {
+    float scale, posx, posy, upx, upy;
+};
+
+struct DevSettings {
+    int32_t width, height, spp, max_depth;
+    float eps;
+    float dirichlet_intensity, neumann_intensity;
+};
+
+// ---- evaluation grid (reference core/evaluation_grid.h:27-33) --------------------------
+__device__ __forceinline__ void eval_point(const DevProbe &p, int px, int py, int width, int height,
+                                           float &x, float &y)
+{
+    float ndcx = 2.0f * (float)px / (float)width + -1.0f;
+    float ndcy = 2.0f * (float)py / (float)height + -1.0f;
+    float ux = p.upy, uy = -p.upx;
+    float vx = p.upx, vy = p.upy;
+    x = p.scale * (ndcx * ux + ndcy * vx) + p.posx;
+    y = p.scale * (ndcx * uy + ndcy * vy) + p.posy;
+}
+
+// ---- closest point on one segment (DESIGN.md "segment distance") -----------------------
+__device__ __forceinline__ float seg_d2(float ax, float ay, float ex, float ey, float inv, float qx, float qy)
+{
+    float wx = qx - ax, wy = qy - ay;
+    float tr = dot2(wx, wy, ex, ey) * inv;
+    float t = fminf(fmaxf(tr, 0.0f), 1.0f);
+    float cx = __builtin_fmaf(t, ex, ax), cy = __builtin_fmaf(t, ey, ay);
+    float dx = qx - cx, dy = qy - cy;
+    return dot2(dx, dy, dx, dy);
+}
+
+__device__ __forceinline__ float box_d2(const float4 b, float qx, float qy)
+{
+    float dx = fmaxf(fmaxf(b.x - qx, qx - b.z), 0.0f);
+    float dy = fmaxf(fmaxf(b.y - qy, qy - b.w), 0.0f);
+    return dot2(dx, dy, dx, dy);
+}
+
+// result of a closest-point query: slot in sorted order + squared distance
+struct Closest {
+    float d2;
+    int32_t slot;
+};
+
+__device__ __forceinline__ void cswap(uint32_t &a, uint32_t &b)
+{
+    uint32_t lo = min(a, b), hi = max(a, b);
+    a = lo;
+    b = hi;
+}
+
+// Closest point on the wide LBVH.  `stack` is this lane's column of the LDS traversal
+// stack: entry i lives at stack[i * stride].  (best.d2, best.slot) may carry a valid
+// candidate on entry (temporal hint); ties are broken by the lowest original index.
+__device__ __forceinline__ Closest closest_point(const DevMesh &m, float qx, float qy, Closest best,
+                                                 uint32_t *stack, int stride)
+{
+    int sp = 0;
+    int g = 0;
+    int32_t best_orig = -1;  // loaded lazily, only when an exact tie shows up
+    const int first_leaf = m.first_leaf;
+    for (;;) {
+        const float4 *cb = m.boxes + 4 * g;
+        float4 b0 = cb[0], b1 = cb[1], b2 = cb[2], b3 = cb[3];
+        float d0 = box_d2(b0, qx, qy), d1 = box_d2(b1, qx, qy);
+        float d2 = box_d2(b2, qx, qy), d3 = box_d2(b3, qx, qy);
+        const int child0 = 4 * g + 1;
+        if (child0 >= first_leaf) {
+            // children are leaves: evaluate every leaf that can still tie or win
+            const int leaf0 = child0 - first_leaf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float dj = (j == 0) ? d0 : (j == 1) ? d1 : (j == 2) ? d2 : d3;
+                if (dj <= best.d2) {
+                    const int leaf = leaf0 + j;
+                    const float4 *sa = m.segA + 4 * leaf;
+                    float4 a0 = sa[0], a1 = sa[1], a2 = sa[2], a3 = sa[3];
+                    float4 iv = m.segInv[leaf];
+                    float e0 = seg_d2(a0.x, a0.y, a0.z, a0.w, iv.x, qx, qy);
+                    float e1 = seg_d2(a1.x, a1.y, a1.z, a1.w, iv.y, qx, qy);
+                    float e2 = seg_d2(a2.x, a2.y, a2.z, a2.w, iv.z, qx, qy);
+                    float e3 = seg_d2(a3.x, a3.y, a3.z, a3.w, iv.w, qx, qy);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float ek = (k == 0) ? e0 : (k == 1) ? e1 : (k == 2) ? e2 : e3;
+                        int slot = 4 * leaf + k;
+                        if (ek < best.d2) {
+                            best.d2 = ek;
+                            best.slot = slot;
+                            best_orig = -1;
+                        } else if (ek == best.d2 && slot != best.slot) {
+                            if (best_orig < 0) best_orig = (best.slot >= 0) ? m.segOrig[best.slot] : WOST_FAR_INDEX;
+                            int o = m.segOrig[slot];
+                            if (o < best_orig) {
+                                best.slot = slot;
+                                best_orig = o;
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            // inner children: near-first order; the child index rides in the two low
+            // mantissa bits of the (non-negative) distance so that four integer
+            // compare-exchanges sort the candidates
+            uint32_t k0 = (d0 <= best.d2) ? ((__float_as_uint(d0) & ~3u) | 0u) : 0xffffffffu;
+            uint32_t k1 = (d1 <= best.d2) ? ((__float_as_uint(d1) & ~3u) | 1u) : 0xffffffffu;
+            uint32_t k2 = (d2 <= best.d2) ? ((__float_as_uint(d2) & ~3u) | 2u) : 0xffffffffu;
+            uint32_t k3 = (d3 <= best.d2) ? ((__float_as_uint(d3) & ~3u) | 3u) : 0xffffffffu;
+            cswap(k0, k1);
+            cswap(k2, k3);
+            cswap(k0, k2);
+            cswap(k1, k3);
+            cswap(k1, k2);
+            if (k3 != 0xffffffffu) { stack[sp * stride] = child0 + (k3 & 3u); ++sp; }
+            if (k2 != 0xffffffffu) { stack[sp * stride] = child0 + (k2 & 3u); ++sp; }
+            if (k1 != 0xffffffffu) { stack[sp * stride] = child0 + (k1 & 3u); ++sp; }
+            if (k0 != 0xffffffffu) {
+                g = child0 + (k0 & 3u);
+                continue;
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        g = stack[sp * stride];
+    }
+    return best;
+}
+
+// Brute-force variant for tiny meshes (wave-uniform loop over the flat records, which the
+// compiler turns into scalar loads).  Returns the ORIGINAL index in .slot.
+__device__ __forceinline__ Closest closest_point_flat(const DevMesh &m, float qx, float qy)
+{
+    Closest best{WOST_INF, -1};
+    for (int i = 0; i < m.n_segs; ++i) {
+        const DevFlatSeg s = m.flat[i];
+        float d = seg_d2(s.ax, s.ay, s.ex, s.ey, s.inv_len2, qx, qy);
+        if (d < best.d2) {  // ascending i: strict < keeps the lowest index on ties
+            best.d2 = d;
+            best.slot = i;
+        }
+    }
+    return best;
+}
+
+// ---- closest silhouette vertex (reference call site integrator.cu:189) ------------------
+// Distance to the nearest vertex of the mesh that is a silhouette as seen from q, limited
+// to vertices within rmax; +inf when there is none.  Test = FCPW isSilhouetteVertex.
+__device__ __forceinline__ float closest_silhouette_flat(const DevMesh &m, float qx, float qy, float rmax)
+{
+    float best2 = rmax * rmax;
+    bool found = false;
+    for (int v = 0; v < m.n_sil; ++v) {
+        const DevSilVertex sv = m.sil[v];
+        float vx = qx - sv.x, vy = qy - sv.y;
+        float d2 = dot2(vx, vy, vx, vy);
+        if (d2 > best2) continue;
+        bool is_sil = (sv.prev < 0 || sv.next < 0);
+        if (!is_sil) {
+            const DevFlatSeg s0 = m.flat[sv.prev], s1 = m.flat[sv.next];
+            float d = sqrtf(d2);
+            if (d <= WOST_SIL_PRECISION) {
+                float det = cross2(s0.nx, s0.ny, s1.nx, s1.ny);
+                is_sil = (-det > WOST_SIL_PRECISION);
+            } else {
+                float ux = vx / d, uy = vy / d;
+                float dot0 = dot2(ux, uy, s0.nx, s0.ny);
+                float dot1 = dot2(ux, uy, s1.nx, s1.ny);
+                if (fabsf(dot0) <= WOST_SIL_PRECISION || fabsf(dot1) <= WOST_SIL_PRECISION) is_sil = false;
+                else is_sil = (dot0 * dot1 < 0.0f);
+            }
+        }
+        if (is_sil && (d2 < best2 || !found)) {
+            best2 = d2;
+            found = true;
+        }
+    }
+    return found ? sqrtf(best2) : WOST_INF;
+}
+
+// ---- ray / segment (reference call sites integrator.cu:385-390,500) ----------------------
+__device__ __forceinline__ bool seg_ray(const DevFlatSeg &s, float ox, float oy, float dx, float dy, float tmax,
+                                        float &t)
+{
+    float ux = s.ax - ox, uy = s.ay - oy;
+    float dv = cross2(dx, dy, s.ex, s.ey);
+    if (dv == 0.0f) return false;
+    float ud = cross2(ux, uy, dx, dy);
+    float uv = cross2(ux, uy, s.ex, s.ey);
+    float adv = fabsf(dv);
+    float sgn = (dv < 0.0f) ? -1.0f : 1.0f;
+    float ud_s = ud * sgn, uv_s = uv * sgn;
+    if (ud_s < 0.0f || ud_s > adv) return false;
+    if (uv_s < 0.0f || uv_s > tmax * adv) return false;
+    t = uv / dv;
+    return true;
+}
+
+__device__ __forceinline__ bool ray_closest_flat(const DevMesh &m, float ox, float oy, float dx, float dy, float tmax,
+                                                 float &t_out, int &idx_out)
+{
+    bool hit = false;
+    float bt = WOST_INF;
+    int bi = -1;
+    for (int i = 0; i < m.n_segs; ++i) {
+        const DevFlatSeg s = m.flat[i];
+        float t;
+        if (seg_ray(s, ox, oy, dx, dy, tmax, t)) {
+            if (!hit || t < bt) {
+                bt = t;
+                bi = i;
+                hit = true;
+            }
+        }
+    }
+    t_out = bt;
+    idx_out = bi;
+    return hit;
+}
+
+__device__ __forceinline__ bool ray_any_flat(const DevMesh &m, float ox, float oy, float dx, float dy, float tmax)
+{
+    bool hit = false;
+    for (int i = 0; i < m.n_segs; ++i) {
+        const DevFlatSeg s = m.flat[i];
+        float t;
+        hit = hit || seg_ray(s, ox, oy, dx, dy, tmax, t);
+    }
+    return hit;
+}
+
+// ---- primitive sampling in a ball (reference call site integrator.cu:349-354) ------------
+__device__ __forceinline__ int sample_in_sphere_flat(const DevMesh &m, float qx, float qy, float R, float u,
+                                                     float &pdf)
+{
+    float R2 = R * R;
+    float total = 0.0f;
+    for (int i = 0; i < m.n_segs; ++i) {
+        const DevFlatSeg s = m.flat[i];
+        float d2 = seg_d2(s.ax, s.ay, s.ex, s.ey, s.inv_len2, qx, qy);
+        if (d2 <= R2 && s.len > 0.0f) total += s.len;
+    }
+    pdf = 0.0f;
+    if (!(total > 0.0f)) return -1;
+    float target = u * total;
+    float cum = 0.0f;
+    int last = -1;
+    bool done = false;
+    for (int i = 0; i < m.n_segs; ++i) {
+        const DevFlatSeg s = m.flat[i];
+        float d2 = seg_d2(s.ax, s.ay, s.ex, s.ey, s.inv_len2, qx, qy);
+        if (!done && d2 <= R2 && s.len > 0.0f) {
+            cum += s.len;
+            last = i;
+            if (target < cum) done = true;
+        }
+    }
+    float len = m.flat[last].len;
+    pdf = (len / total) / len;
+    return last;
+}
+
+// ---- surface colour (reference integrator/common.h:242-260, functors.h:60-64) ------------
+// col12 = left(i0) left(i1) right(i0) right(i1)
+__device__ __forceinline__ void surface_color(const float *col12, int side, float uv, float &r, float &g, float &b)
+{
+    const float *c = col12 + ((side >= 0) ? 0 : 6);
+    r = c[0] * (1 - uv) + c[3] * uv;
+    g = c[1] * (1 - uv) + c[4] * uv;
+    b = c[2] * (1 - uv) + c[5] * uv;
+}
+
+}  // namespace wost

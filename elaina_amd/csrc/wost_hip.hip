@@ -1,0 +1,956 @@
+// wost_hip.hip -- walk kernels and the C-ABI of libwost_hip.so (gfx950 / MI355X only).
+//
+// Design (DESIGN.md has the long form):
+//   * one SoA walk-state queue; a queue slot is one PIXEL's walker, which carries its
+//     PCG32 state, position, partial solution and the temporal hint of the last closest
+//     segment.  A pixel's samples are strictly sequential in the reference (one RNG stream
+//     per pixel, integrator/uniform/integrator.cu:71-77, one walk in flight per pixel), so a
+//     slot restarts its next sample the moment the previous walk ends instead of idling
+//     until every other walk of that sample is done -- same per-pixel arithmetic, no
+//     starved late-depth launches.
+//   * a launch ("round") advances every slot by up to `steps_per_round` walk steps held in
+//     registers, then compacts the still-unfinished slots into the other queue with
+//     ballot/popcount + one atomic per wave, and resolves finished pixels into the field.
+//   * the per-lane LBVH traversal stack lives in LDS (one column per lane, bank = lane).
+//   * no managed memory, no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/wost.h"
+#include "lbvh.h"
+#include "wost_device.h"
+
+namespace wost {
+
+// ------------------------------------------------------------------------------------------
+// queue layout
+// ------------------------------------------------------------------------------------------
+struct WalkQueue {
+    uint32_t *pix;     // global pixel id
+    float *x0, *y0;    // evaluation point of the pixel (start of every sample)
+    float *px, *py;    // current walk position
+    uint64_t *rng;     // PCG32 state (inc == 1 for every pixel: setSeed(.., seq 0))
+    uint32_t *meta;    // sample[0:20) | depth[20:30) | onNeumann[30]
+    float *nx, *ny;    // Neumann normal at the current point (valid when onNeumann)
+    int32_t *hint;     // slot of the closest Dirichlet segment of the previous step
+    float *thp;        // throughput (scalar: all three channels are always equal)
+    float *sr, *sg, *sb;  // running solution of the pixel
+    float *d0_d2;      // cached closest-point result of the evaluation point (depth 0 of
+    int32_t *d0_slot;  //   every sample starts at the same point)
+};
+
+static const int kQueueWords = 16 + 1;  // rng counts twice
+
+struct StatsDev {
+    unsigned long long steps, started, absorbed, truncated, nhits;
+};
+
+struct RoundParams {
+    DevMesh dm, nm;
+    DevSettings st;
+    DevProbe probe;
+    WalkQueue in, out;
+    const uint32_t *count_in;
+    uint32_t *count_out;
+    float *field;        // solution/spp written at field[(pix - field_base) * 3]
+    int32_t field_base;
+    StatsDev *stats;
+    int32_t steps_per_round;
+    int32_t stack_stride;  // = blockDim.x
+};
+
+struct InitParams {
+    DevMesh dm;
+    DevSettings st;
+    DevProbe probe;
+    WalkQueue out;
+    uint32_t *count_out;
+    const uint8_t *mask;
+    float *field;
+    int32_t field_base;
+    int32_t pixel_begin, pixel_end;
+    int32_t shard_index, shard_count;
+    int32_t tiles_x, tiles_y;
+    int32_t stack_stride;
+};
+
+#define META_SAMPLE(m) ((m) & 0xfffffu)
+#define META_DEPTH(m) (((m) >> 20) & 0x3ffu)
+#define META_ONN(m) (((m) >> 30) & 1u)
+#define META_PACK(s, d, n) ((uint32_t)(s) | ((uint32_t)(d) << 20) | ((uint32_t)(n) << 30))
+
+__device__ __forceinline__ Closest hint_candidate(const DevMesh &m, int32_t slot, float qx, float qy)
+{
+    float4 a = m.segA[slot];
+    float inv = reinterpret_cast<const float *>(m.segInv)[slot];
+    return Closest{seg_d2(a.x, a.y, a.z, a.w, inv, qx, qy), slot};
+}
+
+// ------------------------------------------------------------------------------------------
+// init: seed every owned pixel, cache its depth-0 closest point, compact into the queue
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void init_kernel(InitParams P)
+{
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tile = t >> 6, i = t & 63;
+    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const int x = tx * 8 + (i & 7), y = ty * 8 + (i >> 3);
+    bool owned = (ty < P.tiles_y) && (x < P.st.width) && (y < P.st.height);
+    int pid = y * P.st.width + x;
+    owned = owned && pid >= P.pixel_begin && pid < P.pixel_end && (tile % P.shard_count) == P.shard_index;
+    bool active = owned && (P.mask == nullptr || P.mask[pid] != 0) && P.st.spp > 0;
+    if (owned && !active) {
+        // masked pixel: solution stays 0 (reference integrator.cu:92-95, :616-620)
+        float *f = P.field + 3 * (size_t)(pid - P.field_base);
+        float z = 0.0f / (float)P.st.spp;
+        f[0] = z; f[1] = z; f[2] = z;
+    }
+    float x0 = 0, y0 = 0;
+    Pcg rng{0, 1};
+    Closest c0{WOST_INF, -1};
+    if (active) {
+        eval_point(P.probe, x, y, P.st.width, P.st.height, x0, y0);
+        pcg_seed_pixel(rng, pid, P.st.width);
+        if (P.dm.n_segs > 0) c0 = closest_point(P.dm, x0, y0, hint_candidate(P.dm, 0, x0, y0), stack, P.stack_stride);
+    }
+    // wave-level compaction: one atomic per wave
+    const unsigned long long bal = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0 && bal) base = atomicAdd(P.count_out, (uint32_t)__popcll(bal));
+    base = __shfl(base, 0);
+    if (active) {
+        const uint32_t s = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        WalkQueue &q = P.out;
+        q.pix[s] = pid;
+        q.x0[s] = x0; q.y0[s] = y0;
+        q.px[s] = x0; q.py[s] = y0;
+        q.rng[s] = rng.state;
+        q.meta[s] = META_PACK(0, 0, 0);
+        q.nx[s] = 0.0f; q.ny[s] = 0.0f;
+        q.hint[s] = c0.slot;
+        q.thp[s] = 1.0f;
+        q.sr[s] = 0.0f; q.sg[s] = 0.0f; q.sb[s] = 0.0f;
+        q.d0_d2[s] = c0.d2;
+        q.d0_slot[s] = c0.slot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the walk round
+// ------------------------------------------------------------------------------------------
+struct Lane {
+    float x0, y0, px, py;
+    Pcg rng;
+    uint32_t sample, depth;
+    bool on_n;
+    float nx, ny;
+    int32_t hint;
+    float thp;
+    float sr, sg, sb;
+    float d0_d2;
+    int32_t d0_slot;
+};
+
+struct LaneStats {
+    uint32_t steps, started, absorbed, truncated, nhits;
+};
+
+// One walk step of one walker = one item consumed from the reference's evaluation-point
+// queue at one depth: separate -> handleBoundary -> sampleNeumann -> oneStepWalk
+// (reference integrator/uniform/integrator.cu:128-211, 224-231, 336-444, 465-525).
+// Returns true when the walk ended in this step.
+template <bool NEUMANN_EMISSIVE>
+__device__ __forceinline__ bool walk_step(const RoundParams &P, Lane &L, LaneStats &S, uint32_t *stack)
+{
+    const DevMesh &dm = P.dm;
+    const DevMesh &nm = P.nm;
+    const bool has_d = dm.n_segs > 0, has_n = nm.n_segs > 0;
+    const float eps = P.st.eps;
+    S.steps++;
+    const float px = L.px, py = L.py;
+
+    // ---- separateEvaluationPoint -------------------------------------------------------
+    float R_D = WOST_INF;
+    if (has_d) {
+        Closest cp;
+        if (L.depth == 0) {
+            cp = Closest{L.d0_d2, L.d0_slot};  // same point for every sample of the pixel
+        } else {
+            cp = closest_point(dm, px, py, hint_candidate(dm, L.hint, px, py), stack, P.stack_stride);
+        }
+        L.hint = cp.slot;
+        const float4 a = dm.segA[cp.slot];
+        const float inv = reinterpret_cast<const float *>(dm.segInv)[cp.slot];
+        const float wx = px - a.x, wy = py - a.y;
+        const float uv = dot2(wx, wy, a.z, a.w) * inv;       // computeProjectionRatio
+        const float cr = cross2(a.z, a.w, wx, wy);           // checkPointSide
+        const int side = (0.0f < cr) - (cr < 0.0f);
+        R_D = sqrtf(cp.d2);
+        const bool in_shell = (R_D < eps) && (uv > 0.0f && uv < 1.0f);
+        if (in_shell) {
+            // ---- handleBoundary ----
+            float r, g, b;
+            surface_color(dm.segCol + 12 * (size_t)cp.slot, side, uv, r, g, b);
+            r *= P.st.dirichlet_intensity; g *= P.st.dirichlet_intensity; b *= P.st.dirichlet_intensity;
+            r *= L.thp; g *= L.thp; b *= L.thp;
+            L.sr = r + L.sr; L.sg = g + L.sg; L.sb = b + L.sb;
+            S.absorbed++;
+            return true;
+        }
+    }
+    float R_N = WOST_INF;
+    if (has_n) R_N = closest_silhouette_flat(nm, px, py, R_D);
+    float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
+    R_B *= WOST_R_B_SHRINK;
+    if (isinf(R_B)) return true;
+
+    // ---- sampleNeumann -------------------------------------------------------------------
+    if (has_n) {
+        const float u0 = pcg_next_float(L.rng);
+        const float u1 = pcg_next_float(L.rng);
+        if (NEUMANN_EMISSIVE) {
+            float pdf;
+            const int oi = sample_in_sphere_flat(nm, px, py, R_B, u0, pdf);
+            if (oi != -1 && pdf > 0) {
+                const DevFlatSeg so = nm.flat[oi];
+                const float spx = __builtin_fmaf(u1, so.ex, so.ax), spy = __builtin_fmaf(u1, so.ey, so.ay);
+                const float rx = spx - px, ry = spy - py;
+                const float r = sqrtf(dot2(rx, ry, rx, ry));
+                if (r < R_B && r > 0) {
+                    float ox = px, oy = py;
+                    if (L.on_n) { ox += eps * L.nx; oy += eps * L.ny; }
+                    float dx = spx - ox, dy = spy - oy;
+                    const float cd = sqrtf(dot2(dx, dy, dx, dy));
+                    if (cd > 0) { dx /= cd; dy /= cd; }
+                    const bool blocked = ray_any_flat(nm, ox, oy, dx, dy, cd - eps);
+                    if (!blocked) {
+                        const float cr = cross2(so.ex, so.ey, px - so.ax, py - so.ay);
+                        int side = (0.0f < cr) - (cr < 0.0f);
+                        const float uv = dot2(spx - so.ax, spy - so.ay, so.ex, so.ey) * so.inv_len2;
+                        if (L.on_n) {
+                            const float dn = dot2(so.nx, so.ny, L.nx, L.ny);
+                            side = (0.0f < dn) - (dn < 0.0f);
+                        }
+                        if (side != 0) {
+                            float cr_, cg_, cb_;
+                            surface_color(nm.flatCol + 12 * (size_t)oi, side, uv, cr_, cg_, cb_);
+                            const float alpha = L.on_n ? 0.5f : 1.0f;
+                            const float G = det_logf(R_B / r) / WOST_2PI;
+                            const float w = L.thp * G / alpha / pdf;
+                            cr_ *= P.st.neumann_intensity; cg_ *= P.st.neumann_intensity; cb_ *= P.st.neumann_intensity;
+                            cr_ *= w; cg_ *= w; cb_ *= w;
+                            L.sr = -cr_ + L.sr; L.sg = -cg_ + L.sg; L.sb = -cb_ + L.sb;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- oneStepWalk ---------------------------------------------------------------------
+    float dirx, diry, pdf, alpha = 1.0f;
+    float cxp = px, cyp = py;
+    if (L.on_n) {
+        const float u = pcg_next_float(L.rng);
+        float lc, ls;
+        sincos_2pi(u * 0.5f, lc, ls);               // phi = pi * u
+        const float qx = -L.ny, qy = L.nx;          // frameFromNormal: T = -normalize(-n.y, n.x)
+        const float ql = sqrtf(dot2(qx, qy, qx, qy));
+        const float tx = -(qx / ql), ty = -(qy / ql);
+        dirx = tx * lc + L.nx * ls;
+        diry = ty * lc + L.ny * ls;
+        pdf = (float)(1.0 / 3.14159265358979323846);
+        alpha = 0.5f;
+        cxp += eps * L.nx;
+        cyp += eps * L.ny;
+    } else {
+        const float u = pcg_next_float(L.rng);
+        sincos_2pi(u, dirx, diry);
+        pdf = 1.0f / WOST_2PI;
+    }
+    float nxt_x = px + R_B * dirx, nxt_y = py + R_B * diry;
+    bool hit = false;
+    float hnx = 0.0f, hny = 0.0f;
+    if (has_n) {
+        float t;
+        int hi;
+        hit = ray_closest_flat(nm, cxp, cyp, dirx, diry, R_B, t, hi);
+        if (hit) {
+            hnx = nm.flat[hi].nx;
+            hny = nm.flat[hi].ny;
+            if (dot2(hnx, hny, dirx, diry) > 0) { hnx = -hnx; hny = -hny; }
+            nxt_x = cxp + t * dirx;
+            nxt_y = cyp + t * diry;
+            S.nhits++;
+        }
+    }
+    L.thp = L.thp / pdf / alpha / WOST_2PI;
+    L.px = nxt_x; L.py = nxt_y;
+    L.on_n = hit; L.nx = hnx; L.ny = hny;
+    L.depth++;
+    if (L.depth == (uint32_t)P.st.max_depth) {
+        S.truncated++;
+        return true;
+    }
+    return false;
+}
+
+template <bool NEUMANN_EMISSIVE>
+__global__ __launch_bounds__(256) void walk_round_kernel(RoundParams P)
+{
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_in = *P.count_in;
+    const bool valid = slot < n_in;
+    Lane L;
+    LaneStats S{0, 0, 0, 0, 0};
+    uint32_t pix = 0;
+    bool alive = false;
+    if (valid) {
+        const WalkQueue &q = P.in;
+        pix = q.pix[slot];
+        L.x0 = q.x0[slot]; L.y0 = q.y0[slot];
+        L.px = q.px[slot]; L.py = q.py[slot];
+        L.rng.state = q.rng[slot]; L.rng.inc = 1;
+        const uint32_t m = q.meta[slot];
+        L.sample = META_SAMPLE(m); L.depth = META_DEPTH(m); L.on_n = META_ONN(m) != 0;
+        L.nx = q.nx[slot]; L.ny = q.ny[slot];
+        L.hint = q.hint[slot];
+        L.thp = q.thp[slot];
+        L.sr = q.sr[slot]; L.sg = q.sg[slot]; L.sb = q.sb[slot];
+        L.d0_d2 = q.d0_d2[slot]; L.d0_slot = q.d0_slot[slot];
+        alive = L.sample < (uint32_t)P.st.spp;
+    }
+    for (int it = 0; it < P.steps_per_round; ++it) {
+        if (!__any(alive)) break;
+        if (alive) {
+            if (L.depth == 0) S.started++;
+            const bool ended = walk_step<NEUMANN_EMISSIVE>(P, L, S, stack);
+            if (ended) {
+                // next sample of this pixel starts right away (generateEvaluationPoints,
+                // reference integrator.cu:90-99 + workqueue.h:99-110)
+                L.sample++;
+                L.px = L.x0; L.py = L.y0;
+                L.depth = 0; L.on_n = false; L.nx = 0.0f; L.ny = 0.0f;
+                L.thp = 1.0f;
+                L.hint = L.d0_slot;
+                alive = L.sample < (uint32_t)P.st.spp;
+            }
+        }
+    }
+    // ---- resolve finished pixels (reference integrator.cu:616-620) -------------------------
+    if (valid && !alive) {
+        float *f = P.field + 3 * (size_t)((int32_t)pix - P.field_base);
+        const float spp = (float)P.st.spp;
+        f[0] = L.sr / spp; f[1] = L.sg / spp; f[2] = L.sb / spp;
+    }
+    // ---- stream compaction of the survivors: ballot + popcount, one atomic per wave -------
+    const unsigned long long bal = __ballot(alive);
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0 && bal) base = atomicAdd(P.count_out, (uint32_t)__popcll(bal));
+    base = __shfl(base, 0);
+    if (alive) {
+        const uint32_t s = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        WalkQueue &q = P.out;
+        q.pix[s] = pix;
+        q.x0[s] = L.x0; q.y0[s] = L.y0;
+        q.px[s] = L.px; q.py[s] = L.py;
+        q.rng[s] = L.rng.state;
+        q.meta[s] = META_PACK(L.sample, L.depth, L.on_n ? 1 : 0);
+        q.nx[s] = L.nx; q.ny[s] = L.ny;
+        q.hint[s] = L.hint;
+        q.thp[s] = L.thp;
+        q.sr[s] = L.sr; q.sg[s] = L.sg; q.sb[s] = L.sb;
+        q.d0_d2[s] = L.d0_d2; q.d0_slot[s] = L.d0_slot;
+    }
+    // ---- statistics: wave reduction, one atomic per counter per wave -----------------------
+    uint32_t v[5] = {S.steps, S.started, S.absorbed, S.truncated, S.nhits};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        uint32_t x = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        v[k] = x;
+    }
+    if (lane == 0) {
+        if (v[0]) atomicAdd(&P.stats->steps, (unsigned long long)v[0]);
+        if (v[1]) atomicAdd(&P.stats->started, (unsigned long long)v[1]);
+        if (v[2]) atomicAdd(&P.stats->absorbed, (unsigned long long)v[2]);
+        if (v[3]) atomicAdd(&P.stats->truncated, (unsigned long long)v[3]);
+        if (v[4]) atomicAdd(&P.stats->nhits, (unsigned long long)v[4]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// batch query kernels (the lbvh::query_device call sites, exposed for tests and SDF renders)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void closest_point_kernel(DevMesh m, const float *pts, int n, int32_t *out_idx,
+                                                            float *out_dist, float *out_uv, int32_t *out_side,
+                                                            int stack_stride)
+{
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float qx = pts[2 * i], qy = pts[2 * i + 1];
+    const Closest c = closest_point(m, qx, qy, hint_candidate(m, 0, qx, qy), stack, stack_stride);
+    const float4 a = m.segA[c.slot];
+    const float inv = reinterpret_cast<const float *>(m.segInv)[c.slot];
+    const float wx = qx - a.x, wy = qy - a.y;
+    const float cr = cross2(a.z, a.w, wx, wy);
+    if (out_idx) out_idx[i] = m.segOrig[c.slot];
+    if (out_dist) out_dist[i] = sqrtf(c.d2);
+    if (out_uv) out_uv[i] = dot2(wx, wy, a.z, a.w) * inv;
+    if (out_side) out_side[i] = (0.0f < cr) - (cr < 0.0f);
+}
+
+__global__ __launch_bounds__(256) void sdf_kernel(DevMesh m, DevProbe probe, int width, int height, int which,
+                                                  float *out, int stack_stride)
+{
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= width * height) return;
+    float x, y;
+    eval_point(probe, pid % width, pid / width, width, height, x, y);
+    float d = WOST_INF;
+    if (m.n_segs > 0) {
+        if (which == WOST_MESH_DIRICHLET) {
+            d = sqrtf(closest_point(m, x, y, hint_candidate(m, 0, x, y), stack, stack_stride).d2);
+        } else {
+            d = closest_silhouette_flat(m, x, y, WOST_INF);
+        }
+    }
+    out[pid] = d;
+}
+
+__global__ __launch_bounds__(256) void silhouette_kernel(DevMesh m, const float *pts, const float *rmax, int n,
+                                                         float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = closest_silhouette_flat(m, pts[2 * i], pts[2 * i + 1], rmax ? rmax[i] : WOST_INF);
+}
+
+__global__ __launch_bounds__(256) void ray_kernel(DevMesh m, const float *o, const float *d, const float *tmax, int n,
+                                                  int32_t *out_hit, float *out_t, int32_t *out_idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float t;
+    int idx;
+    const bool hit = ray_closest_flat(m, o[2 * i], o[2 * i + 1], d[2 * i], d[2 * i + 1], tmax[i], t, idx);
+    out_hit[i] = hit ? 1 : 0;
+    out_t[i] = t;
+    out_idx[i] = idx;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(WOST_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+struct DeviceMeshStorage {
+    DevMesh view{};
+    std::vector<void *> allocs;
+    HostTree host;
+};
+
+static const int kMaxFlatNeumann = 1024;
+
+template <class T>
+static hipError_t upload(std::vector<void *> &allocs, const T *src, size_t count, const T **dst)
+{
+    *dst = nullptr;
+    if (count == 0) return hipSuccess;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, count * sizeof(T));
+    if (e != hipSuccess) return e;
+    allocs.push_back(p);
+    e = hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+    *dst = reinterpret_cast<const T *>(p);
+    return e;
+}
+
+static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
+{
+    if (d.n_segs < 0 || d.n_verts < 0) return fail(WOST_ERR_INVALID, "negative mesh size");
+    if (build_tree(d.n_verts, d.verts, d.n_segs, d.segs, d.colors, &s.host) != 0)
+        return fail(WOST_ERR_INVALID, "mesh: segment index out of range or null arrays");
+    const HostTree &t = s.host;
+    DevMesh &v = s.view;
+    v = DevMesh{};
+    v.n_segs = t.n_segs;
+    if (t.n_segs == 0) return WOST_OK;
+    v.n_sil = (int32_t)t.sil.size();
+    v.levels = t.levels;
+    v.first_leaf = t.first_leaf;
+    v.emissive = 0;
+    for (float c : t.flatCol)
+        if (c != 0.0f) v.emissive = 1;
+    HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(t.boxes.data()), t.boxes.size() / 4, &v.boxes));
+    HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(t.segA.data()), t.segA.size() / 4, &v.segA));
+    HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(t.segInv.data()), t.segInv.size() / 4, &v.segInv));
+    HIP_TRY(upload(s.allocs, t.segOrig.data(), t.segOrig.size(), &v.segOrig));
+    HIP_TRY(upload(s.allocs, t.segCol.data(), t.segCol.size(), &v.segCol));
+    HIP_TRY(upload(s.allocs, reinterpret_cast<const DevFlatSeg *>(t.flat.data()), t.flat.size(), &v.flat));
+    HIP_TRY(upload(s.allocs, t.flatCol.data(), t.flatCol.size(), &v.flatCol));
+    HIP_TRY(upload(s.allocs, reinterpret_cast<const DevSilVertex *>(t.sil.data()), t.sil.size(), &v.sil));
+    return WOST_OK;
+}
+
+static_assert(sizeof(FlatSeg) == sizeof(DevFlatSeg), "flat segment layout");
+static_assert(sizeof(SilVertex) == sizeof(DevSilVertex), "silhouette vertex layout");
+
+}  // namespace wost
+
+using namespace wost;
+
+struct wost_context {
+    int device = 0;
+    wost_settings settings{};
+    DevSettings dst{};
+    DevProbe probe{};
+    DeviceMeshStorage dm, nm;
+    uint8_t *mask = nullptr;
+    size_t n_pixels = 0;
+    // queues
+    void *queue_mem[2] = {nullptr, nullptr};
+    WalkQueue queue[2]{};
+    uint32_t *counts = nullptr;     // [2]
+    StatsDev *stats = nullptr;
+    float *field = nullptr;         // n_pixels * 3 (used by wost_solve)
+    uint32_t *host_count = nullptr; // pinned
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // options
+    int steps_per_round = 64;
+    int block_size = 256;
+    int time_kernels = 1;
+};
+
+static void carve_queue(void *mem, size_t n, WalkQueue &q)
+{
+    // 8-byte array first, then 4-byte arrays
+    char *p = reinterpret_cast<char *>(mem);
+    q.rng = reinterpret_cast<uint64_t *>(p); p += n * 8;
+    auto take = [&](size_t bytes) { void *r = p; p += bytes; return r; };
+    q.pix = (uint32_t *)take(n * 4);
+    q.x0 = (float *)take(n * 4); q.y0 = (float *)take(n * 4);
+    q.px = (float *)take(n * 4); q.py = (float *)take(n * 4);
+    q.meta = (uint32_t *)take(n * 4);
+    q.nx = (float *)take(n * 4); q.ny = (float *)take(n * 4);
+    q.hint = (int32_t *)take(n * 4);
+    q.thp = (float *)take(n * 4);
+    q.sr = (float *)take(n * 4); q.sg = (float *)take(n * 4); q.sb = (float *)take(n * 4);
+    q.d0_d2 = (float *)take(n * 4);
+    q.d0_slot = (int32_t *)take(n * 4);
+}
+
+static void destroy_ctx(wost_context *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (void *p : c->dm.allocs) (void)hipFree(p);
+    for (void *p : c->nm.allocs) (void)hipFree(p);
+    if (c->mask) (void)hipFree(c->mask);
+    for (int i = 0; i < 2; ++i)
+        if (c->queue_mem[i]) (void)hipFree(c->queue_mem[i]);
+    if (c->counts) (void)hipFree(c->counts);
+    if (c->stats) (void)hipFree(c->stats);
+    if (c->field) (void)hipFree(c->field);
+    if (c->host_count) (void)hipHostFree(c->host_count);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" {
+
+const char *wost_version(void) { return "wost-hip 0.1 (gfx950)"; }
+
+const char *wost_last_error(void) { return g_last_error.c_str(); }
+
+int wost_create(const wost_scene_desc *scene, const wost_settings *settings, int device, wost_handle *out)
+{
+    if (!scene || !settings || !out) return fail(WOST_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (settings->width <= 0 || settings->height <= 0 || settings->spp < 0 || settings->max_depth <= 0)
+        return fail(WOST_ERR_INVALID, "bad settings");
+    if (settings->spp >= (1 << 20) || settings->max_depth >= (1 << 10))
+        return fail(WOST_ERR_UNSUPPORTED, "spp must be < 2^20 and max_depth < 2^10");
+    if ((int64_t)settings->width * settings->height > (1 << 28))
+        return fail(WOST_ERR_UNSUPPORTED, "frame too large");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(WOST_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n_dev) return fail(WOST_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    wost_context *c = new (std::nothrow) wost_context();
+    if (!c) return fail(WOST_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    c->settings = *settings;
+    c->dst = DevSettings{settings->width, settings->height, settings->spp, settings->max_depth, settings->eps_shell,
+                         scene->dirichlet_intensity, scene->neumann_intensity};
+    c->probe = DevProbe{scene->probe_scale, scene->probe_pos[0], scene->probe_pos[1], scene->probe_up[0],
+                        scene->probe_up[1]};
+    c->n_pixels = (size_t)settings->width * settings->height;
+    int rc = upload_mesh(scene->dirichlet, c->dm);
+    if (rc == WOST_OK) rc = upload_mesh(scene->neumann, c->nm);
+    if (rc == WOST_OK && c->nm.view.n_segs > kMaxFlatNeumann)
+        rc = fail(WOST_ERR_UNSUPPORTED, "Neumann meshes above 1024 segments need the BVH Neumann path (not built yet)");
+    auto bail = [&](int code) {
+        destroy_ctx(c);
+        return code;
+    };
+    if (rc != WOST_OK) return bail(rc);
+#define HIP_TRY_C(expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            fail(WOST_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+            return bail(WOST_ERR_DEVICE);                                                                \
+        }                                                                                                \
+    } while (0)
+    if (scene->mask) {
+        HIP_TRY_C(hipMalloc((void **)&c->mask, c->n_pixels));
+        HIP_TRY_C(hipMemcpy(c->mask, scene->mask, c->n_pixels, hipMemcpyHostToDevice));
+    }
+    const size_t qbytes = c->n_pixels * 4 * kQueueWords;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY_C(hipMalloc(&c->queue_mem[i], qbytes));
+        carve_queue(c->queue_mem[i], c->n_pixels, c->queue[i]);
+    }
+    HIP_TRY_C(hipMalloc((void **)&c->counts, 2 * sizeof(uint32_t)));
+    HIP_TRY_C(hipMalloc((void **)&c->stats, sizeof(StatsDev)));
+    HIP_TRY_C(hipMalloc((void **)&c->field, c->n_pixels * 3 * sizeof(float)));
+    HIP_TRY_C(hipHostMalloc((void **)&c->host_count, 2 * sizeof(uint32_t)));
+    HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY_C(hipEventCreate(&c->ev0));
+    HIP_TRY_C(hipEventCreate(&c->ev1));
+#undef HIP_TRY_C
+    *out = c;
+    return WOST_OK;
+}
+
+int wost_destroy(wost_handle h)
+{
+    destroy_ctx(h);
+    return WOST_OK;
+}
+
+int wost_set_option(wost_handle h, const char *key, double value)
+{
+    if (!h || !key) return fail(WOST_ERR_INVALID, "null argument");
+    const std::string k(key);
+    if (k == "steps_per_round") {
+        if (value < 1 || value > 1e6) return fail(WOST_ERR_INVALID, "steps_per_round out of range");
+        h->steps_per_round = (int)value;
+    } else if (k == "block_size") {
+        const int b = (int)value;
+        if (b != 64 && b != 128 && b != 256) return fail(WOST_ERR_INVALID, "block_size must be 64, 128 or 256");
+        h->block_size = b;
+    } else if (k == "time_kernels") {
+        h->time_kernels = value != 0;
+    } else {
+        return fail(WOST_ERR_INVALID, "unknown option: " + k);
+    }
+    return WOST_OK;
+}
+
+}  // extern "C"
+
+// the shared solve driver: field_dev indexed by (pix - field_base)
+static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, int32_t shard_index, int32_t shard_count,
+                     float *field_dev, int32_t field_base, hipStream_t stream, wost_stats *stats)
+{
+    const auto t_start = std::chrono::high_resolution_clock::now();
+    HIP_TRY(hipSetDevice(c->device));
+    const int bs = c->block_size;
+    const int levels = c->dm.view.n_segs > 0 ? c->dm.view.levels : 1;
+    const int stack_depth = 3 * levels + 2;
+    const size_t lds = (size_t)stack_depth * bs * sizeof(uint32_t);
+    HIP_TRY(hipMemsetAsync(c->counts, 0, 2 * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(StatsDev), stream));
+
+    const int tiles_x = (c->settings.width + 7) / 8, tiles_y = (c->settings.height + 7) / 8;
+    InitParams ip{};
+    ip.dm = c->dm.view;
+    ip.st = c->dst;
+    ip.probe = c->probe;
+    ip.out = c->queue[0];
+    ip.count_out = c->counts + 0;
+    ip.mask = c->mask;
+    ip.field = field_dev;
+    ip.field_base = field_base;
+    ip.pixel_begin = pixel_begin;
+    ip.pixel_end = pixel_end;
+    ip.shard_index = shard_index;
+    ip.shard_count = shard_count;
+    ip.tiles_x = tiles_x;
+    ip.tiles_y = tiles_y;
+    ip.stack_stride = bs;
+    const long long n_threads = (long long)tiles_x * tiles_y * 64;
+    const unsigned init_grid = (unsigned)((n_threads + bs - 1) / bs);
+    hipLaunchKernelGGL(init_kernel, dim3(init_grid), dim3(bs), lds, stream, ip);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->host_count, c->counts, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    uint32_t n_active = c->host_count[0];
+
+    double kernel_ms = 0.0;
+    uint32_t launches = 0;
+    int cur = 0;
+    const bool emissive = c->nm.view.n_segs > 0 && c->nm.view.emissive;
+    while (n_active > 0) {
+        const int nxt = cur ^ 1;
+        HIP_TRY(hipMemsetAsync(c->counts + nxt, 0, sizeof(uint32_t), stream));
+        RoundParams rp{};
+        rp.dm = c->dm.view;
+        rp.nm = c->nm.view;
+        rp.st = c->dst;
+        rp.probe = c->probe;
+        rp.in = c->queue[cur];
+        rp.out = c->queue[nxt];
+        rp.count_in = c->counts + cur;
+        rp.count_out = c->counts + nxt;
+        rp.field = field_dev;
+        rp.field_base = field_base;
+        rp.stats = c->stats;
+        rp.steps_per_round = c->steps_per_round;
+        rp.stack_stride = bs;
+        const unsigned grid = (n_active + bs - 1) / bs;
+        if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
+        if (emissive)
+            hipLaunchKernelGGL(walk_round_kernel<true>, dim3(grid), dim3(bs), lds, stream, rp);
+        else
+            hipLaunchKernelGGL(walk_round_kernel<false>, dim3(grid), dim3(bs), lds, stream, rp);
+        HIP_TRY(hipGetLastError());
+        if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev1, stream));
+        HIP_TRY(hipMemcpyAsync(c->host_count, c->counts + nxt, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c->time_kernels) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            kernel_ms += ms;
+        }
+        ++launches;
+        n_active = c->host_count[0];
+        cur = nxt;
+    }
+    StatsDev sd{};
+    HIP_TRY(hipMemcpyAsync(&sd, c->stats, sizeof(sd), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (stats) {
+        const auto t_end = std::chrono::high_resolution_clock::now();
+        stats->walk_steps = sd.steps;
+        stats->walks_started = sd.started;
+        stats->walks_absorbed = sd.absorbed;
+        stats->walks_truncated = sd.truncated;
+        stats->neumann_hits = sd.nhits;
+        stats->kernel_ms = kernel_ms;
+        stats->kernel_launches = launches;
+        stats->reserved = 0;
+        stats->solve_ms = std::chrono::duration<double, std::milli>(t_end - t_start).count();
+    }
+    return WOST_OK;
+}
+
+static DeviceMeshStorage *pick_mesh(wost_handle h, int which)
+{
+    if (which == WOST_MESH_DIRICHLET) return &h->dm;
+    if (which == WOST_MESH_NEUMANN) return &h->nm;
+    return nullptr;
+}
+
+// small RAII helper for scratch device buffers of the batch queries
+struct Scratch {
+    std::vector<void *> ptrs;
+    ~Scratch()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    hipError_t alloc(T **p, size_t count)
+    {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, count * sizeof(T) + 16);
+        if (e == hipSuccess) ptrs.push_back(q);
+        *p = reinterpret_cast<T *>(q);
+        return e;
+    }
+};
+
+extern "C" {
+
+int wost_solve(wost_handle h, int32_t pixel_begin, int32_t pixel_end, float *field_rgb, wost_stats *stats)
+{
+    if (!h || !field_rgb) return fail(WOST_ERR_INVALID, "null argument");
+    if (pixel_begin < 0 || pixel_end > (int64_t)h->n_pixels || pixel_begin > pixel_end)
+        return fail(WOST_ERR_INVALID, "pixel range outside the frame");
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    const size_t n = (size_t)(pixel_end - pixel_begin);
+    if (n == 0) {
+        if (stats) std::memset(stats, 0, sizeof(*stats));
+        return WOST_OK;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemsetAsync(h->field, 0, n * 3 * sizeof(float), h->stream));
+    int rc = run_solve(h, pixel_begin, pixel_end, 0, 1, h->field, pixel_begin, h->stream, stats);
+    if (rc != WOST_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(field_rgb, h->field, n * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (stats)
+        stats->solve_ms =
+            std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    return WOST_OK;
+}
+
+int wost_solve_sharded(wost_handle h, int32_t shard_index, int32_t shard_count, float *field_rgb_dev, void *stream,
+                       wost_stats *stats)
+{
+    if (!h || !field_rgb_dev) return fail(WOST_ERR_INVALID, "null argument");
+    if (shard_count <= 0 || shard_index < 0 || shard_index >= shard_count)
+        return fail(WOST_ERR_INVALID, "bad shard");
+    hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+    return run_solve(h, 0, (int32_t)h->n_pixels, shard_index, shard_count, field_rgb_dev, 0, s, stats);
+}
+
+int wost_render_sdf(wost_handle h, int which_mesh, float *out_dist)
+{
+    if (!h || !out_dist) return fail(WOST_ERR_INVALID, "null argument");
+    DeviceMeshStorage *m = pick_mesh(h, which_mesh);
+    if (!m) return fail(WOST_ERR_INVALID, "unknown mesh selector");
+    HIP_TRY(hipSetDevice(h->device));
+    const int bs = 256;
+    const int levels = m->view.n_segs > 0 ? m->view.levels : 1;
+    const size_t lds = (size_t)(3 * levels + 2) * bs * sizeof(uint32_t);
+    const int n = (int)h->n_pixels;
+    float *d_out = h->field;  // reuse: n_pixels floats fit in the field buffer
+    hipLaunchKernelGGL(sdf_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, h->probe,
+                       h->settings.width, h->settings.height, which_mesh, d_out, bs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_dist, d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WOST_OK;
+}
+
+int wost_closest_point(wost_handle h, int which_mesh, const float *pts, int32_t n, int32_t *out_idx, float *out_dist,
+                       float *out_uv, int32_t *out_side)
+{
+    if (!h || !pts || n < 0) return fail(WOST_ERR_INVALID, "null argument");
+    DeviceMeshStorage *m = pick_mesh(h, which_mesh);
+    if (!m || m->view.n_segs == 0) return fail(WOST_ERR_INVALID, "mesh is empty or unknown");
+    if (n == 0) return WOST_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    Scratch s;
+    float *d_pts, *d_dist, *d_uv;
+    int32_t *d_idx, *d_side;
+    HIP_TRY(s.alloc(&d_pts, (size_t)n * 2));
+    HIP_TRY(s.alloc(&d_dist, n));
+    HIP_TRY(s.alloc(&d_uv, n));
+    HIP_TRY(s.alloc(&d_idx, n));
+    HIP_TRY(s.alloc(&d_side, n));
+    HIP_TRY(hipMemcpyAsync(d_pts, pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    const int bs = 256;
+    const size_t lds = (size_t)(3 * m->view.levels + 2) * bs * sizeof(uint32_t);
+    hipLaunchKernelGGL(closest_point_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, d_pts, n,
+                       d_idx, d_dist, d_uv, d_side, bs);
+    HIP_TRY(hipGetLastError());
+    if (out_idx) HIP_TRY(hipMemcpyAsync(out_idx, d_idx, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (out_dist) HIP_TRY(hipMemcpyAsync(out_dist, d_dist, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (out_uv) HIP_TRY(hipMemcpyAsync(out_uv, d_uv, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (out_side) HIP_TRY(hipMemcpyAsync(out_side, d_side, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WOST_OK;
+}
+
+int wost_closest_silhouette(wost_handle h, int which_mesh, const float *pts, const float *rmax, int32_t n,
+                            float *out_dist)
+{
+    if (!h || !pts || !out_dist || n < 0) return fail(WOST_ERR_INVALID, "null argument");
+    DeviceMeshStorage *m = pick_mesh(h, which_mesh);
+    if (!m) return fail(WOST_ERR_INVALID, "unknown mesh selector");
+    if (m->view.n_segs > kMaxFlatNeumann)
+        return fail(WOST_ERR_UNSUPPORTED, "silhouette query is flat-loop only (<= 1024 segments) in this build");
+    if (n == 0) return WOST_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    Scratch s;
+    float *d_pts, *d_rmax = nullptr, *d_out;
+    HIP_TRY(s.alloc(&d_pts, (size_t)n * 2));
+    HIP_TRY(s.alloc(&d_out, n));
+    HIP_TRY(hipMemcpyAsync(d_pts, pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (rmax) {
+        HIP_TRY(s.alloc(&d_rmax, n));
+        HIP_TRY(hipMemcpyAsync(d_rmax, rmax, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+    const int bs = 256;
+    hipLaunchKernelGGL(silhouette_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, h->stream, m->view, d_pts, d_rmax, n,
+                       d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_dist, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WOST_OK;
+}
+
+int wost_ray_intersect(wost_handle h, int which_mesh, const float *origins, const float *dirs, const float *tmax,
+                       int32_t n, int32_t *out_hit, float *out_t, int32_t *out_idx)
+{
+    if (!h || !origins || !dirs || !tmax || !out_hit || !out_t || !out_idx || n < 0)
+        return fail(WOST_ERR_INVALID, "null argument");
+    DeviceMeshStorage *m = pick_mesh(h, which_mesh);
+    if (!m) return fail(WOST_ERR_INVALID, "unknown mesh selector");
+    if (m->view.n_segs > kMaxFlatNeumann)
+        return fail(WOST_ERR_UNSUPPORTED, "ray query is flat-loop only (<= 1024 segments) in this build");
+    if (n == 0) return WOST_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    Scratch s;
+    float *d_o, *d_d, *d_tm, *d_t;
+    int32_t *d_hit, *d_idx;
+    HIP_TRY(s.alloc(&d_o, (size_t)n * 2));
+    HIP_TRY(s.alloc(&d_d, (size_t)n * 2));
+    HIP_TRY(s.alloc(&d_tm, n));
+    HIP_TRY(s.alloc(&d_t, n));
+    HIP_TRY(s.alloc(&d_hit, n));
+    HIP_TRY(s.alloc(&d_idx, n));
+    HIP_TRY(hipMemcpyAsync(d_o, origins, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_d, dirs, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_tm, tmax, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    const int bs = 256;
+    hipLaunchKernelGGL(ray_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, h->stream, m->view, d_o, d_d, d_tm, n, d_hit,
+                       d_t, d_idx);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_hit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(out_idx, d_idx, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WOST_OK;
+}
+
+}  // extern "C"

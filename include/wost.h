@@ -1,0 +1,142 @@
+/*
+ * wost.h -- C-ABI of the MI355X-native Walk-on-Stars hot path (libwost_hip.so).
+ *
+ * This is the drop-in boundary for the ONE path this repository accelerates: the
+ * wavefront walk loop of Elaina's uniform integrator and the snch-lbvh queries it
+ * calls.  The reference has no FFI; what `run_expr` touches is the C++ class shape
+ * of `UniformIntegrator<2>` / `Problem<2>` (reference exec.cu:77-78,145-215).  The
+ * host-side mirror of those classes (elaina_amd/host/) calls only the functions
+ * declared here.  Plain pointers and sizes, no C++/torch types, no exceptions
+ * across the boundary, caller owns every host buffer, callee owns device memory,
+ * one handle per GPU, handles are independent.
+ *
+ * Every entry point returns WOST_OK (0) or a negative error code; the message of
+ * the last error on the calling thread is available from wost_last_error().
+ * There is NO CPU fallback: without a usable HIP device wost_create() fails.
+ */
+#ifndef WOST_H
+#define WOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WOST_OK 0
+#define WOST_ERR_INVALID -1      /* bad argument                                 */
+#define WOST_ERR_DEVICE -2       /* HIP runtime error / no device                */
+#define WOST_ERR_UNSUPPORTED -3  /* valid request this build does not cover      */
+#define WOST_ERR_NOMEM -4
+
+/* which mesh a query refers to */
+#define WOST_MESH_DIRICHLET 0
+#define WOST_MESH_NEUMANN 1
+
+/* Host description of one boundary mesh (2-D polylines).
+ * Replaces: lbvh::scene_loader<2> + lbvh::scene<2>(vb,ve,ib,ie) + compute_silhouettes()
+ * + build_bvh() (reference core/problem.cu:27-60) and the per-vertex colour pairs of
+ * loadVertexColorFileImpl (core/problem.cu:99-133). */
+typedef struct wost_mesh_desc {
+    int32_t n_verts;
+    int32_t n_segs;        /* 0 => this boundary type is disabled (problem.h:104-111)   */
+    const float *verts;    /* n_verts * 2, (x, y)                                        */
+    const int32_t *segs;   /* n_segs * 2, 0-based (i0, i1); direction p0 -> p1           */
+    const float *colors;   /* n_verts * 6: (left r,g,b, right r,g,b); NULL => all zero   */
+} wost_mesh_desc;
+
+/* Replaces Problem<2> as seen by the integrator (core/problem.h:104-171) and the
+ * probe EvaluationGrid<2>::ProbeData (core/evaluation_grid.h:16-23). */
+typedef struct wost_scene_desc {
+    wost_mesh_desc dirichlet;
+    wost_mesh_desc neumann;
+    float dirichlet_intensity;   /* problem.h:155 */
+    float neumann_intensity;     /* problem.h:159 */
+    float probe_scale;           /* evaluation_grid.h:18 */
+    float probe_pos[2];          /* evaluation_grid.h:19 */
+    float probe_up[2];           /* evaluation_grid.h:20 */
+    const uint8_t *mask;         /* width*height bytes, 0 = pixel masked out; NULL = all on
+                                    (problem.h:163; the reference's fixed 1024^2 default mask,
+                                    core/problem.cu:245-247, is sized to the frame here)     */
+} wost_scene_desc;
+
+/* Replaces UniformIntegratorSettings (integrator/uniform/integrator.h:27-48); the
+ * metric-dump keys are host-side concerns and do not cross the boundary. */
+typedef struct wost_settings {
+    int32_t width;         /* frameSize[0] */
+    int32_t height;        /* frameSize[1] */
+    int32_t spp;           /* samplesPerPixel */
+    int32_t max_depth;     /* maxWalkingDepth */
+    float eps_shell;       /* epsilonShell */
+} wost_settings;
+
+typedef struct wost_stats {
+    uint64_t walk_steps;       /* sum over depths of the evaluation-queue size   */
+    uint64_t walks_started;
+    uint64_t walks_absorbed;   /* ended in the epsilon shell                                  */
+    uint64_t walks_truncated;  /* reached max_depth                                           */
+    uint64_t neumann_hits;     /* steps that landed on the Neumann boundary                   */
+    double solve_ms;           /* host wall time of the call, like UniformIntegrator::solve() */
+    double kernel_ms;          /* sum of HIP-event durations of the walk kernel launches      */
+    uint32_t kernel_launches;  /* number of walk-kernel launches (rounds)                     */
+    uint32_t reserved;
+} wost_stats;
+
+typedef struct wost_context *wost_handle;
+
+/* Upload the scene, build both LBVHs, allocate walk-state queues for the frame.
+ * Replaces Problem<2>::loadConfig geometry upload + UniformIntegrator<2> ctor
+ * (integrator/uniform/integrator.cu:626-633 -> initializeImpl :18-62). */
+int wost_create(const wost_scene_desc *scene, const wost_settings *settings, int device,
+                wost_handle *out);
+
+/* UniformIntegrator<2>::solve() (integrator/uniform/integrator.cu:666-672 -> solveImpl
+ * :529-623) for the pixels [pixel_begin, pixel_end) of the frame, row-major pixelId as in
+ * the reference.  field_rgb receives (pixel_end - pixel_begin) * 3 floats = solution / spp,
+ * i.e. the RGB of the Film after the resolve pass (:614-621).  Results depend only on
+ * (pixelId, frame width, geometry, settings), never on the range, so shards concatenate
+ * to exactly the full-frame result. */
+int wost_solve(wost_handle h, int32_t pixel_begin, int32_t pixel_end, float *field_rgb,
+               wost_stats *stats);
+
+/* Same walk, sharded by 64-pixel tiles for multi-GPU load balance: this call owns the tiles
+ * t with t % shard_count == shard_index.  field_rgb_dev is a DEVICE buffer of
+ * width*height*3 floats that the caller has zero-filled; only owned pixels are written, so
+ * a sum-reduce over ranks (RCCL) yields the full field.  `stream` is a hipStream_t (NULL =
+ * default stream); the call returns after the stream work has completed. */
+int wost_solve_sharded(wost_handle h, int32_t shard_index, int32_t shard_count,
+                       float *field_rgb_dev, void *stream, wost_stats *stats);
+
+/* renderDirichletSDF / renderSilhouetteSDF (integrator/common.h:52-123): one query per
+ * pixel of the frame, out receives width*height distances. */
+int wost_render_sdf(wost_handle h, int which_mesh, float *out_dist);
+
+/* lbvh::query_device(bvh, lbvh::nearest(q), distance_calculator()) + checkPointSide +
+ * computeProjectionRatio for a batch of host points (call sites
+ * integrator/uniform/integrator.cu:138,148-149).  out_idx = original segment index. */
+int wost_closest_point(wost_handle h, int which_mesh, const float *pts, int32_t n,
+                       int32_t *out_idx, float *out_dist, float *out_uv, int32_t *out_side);
+
+/* lbvh::query_device(bvh, nearest_silhouette(q,false), silhouette_distance_calculator())
+ * (integrator.cu:189); rmax (optional, per point) bounds the search radius. */
+int wost_closest_silhouette(wost_handle h, int which_mesh, const float *pts, const float *rmax,
+                            int32_t n, float *out_dist);
+
+/* lbvh::query_device(bvh, ray_intersect(ray(o,d), tmax), intersect_test()) closest hit
+ * (integrator.cu:500-503). */
+int wost_ray_intersect(wost_handle h, int which_mesh, const float *origins, const float *dirs,
+                       const float *tmax, int32_t n, int32_t *out_hit, float *out_t,
+                       int32_t *out_idx);
+
+/* Tuning knobs ("steps_per_round", "block_size", ...); unknown keys -> WOST_ERR_INVALID. */
+int wost_set_option(wost_handle h, const char *key, double value);
+
+int wost_destroy(wost_handle h);
+
+const char *wost_last_error(void);
+const char *wost_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
