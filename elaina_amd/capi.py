@@ -84,6 +84,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7; loading it FIRST makes this library bind to the same
+    # HIP runtime (same SONAME), so one process never holds two runtimes (DESIGN.md "runtime").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise RuntimeError(

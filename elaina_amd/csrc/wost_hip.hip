@@ -838,7 +838,8 @@ int wost_solve_sharded(wost_handle h, int32_t shard_index, int32_t shard_count, 
     if (!h || !field_rgb_dev) return fail(WOST_ERR_INVALID, "null argument");
     if (shard_count <= 0 || shard_index < 0 || shard_index >= shard_count)
         return fail(WOST_ERR_INVALID, "bad shard");
-    hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->stream;
+    // NULL is the legacy default stream, which is also torch's default stream
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return run_solve(h, 0, (int32_t)h->n_pixels, shard_index, shard_count, field_rgb_dev, 0, s, stats);
 }
 

@@ -1,0 +1,69 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle.oracle import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def oracle_libm():
+    from oracle.oracle import Oracle
+    return Oracle(libm=True)
+
+
+@pytest.fixture(scope="session")
+def ladybug():
+    from elaina_amd import Problem
+    return Problem.load_scene("ladybug")
+
+
+@pytest.fixture(scope="session")
+def fille():
+    from elaina_amd import Problem
+    return Problem.load_scene("fille")
+
+
+def box_problem(lo=0.0, hi=1.0, n_per_side=8, d_sides=(0, 1, 2, 3), n_sides=(), value=None, flux=None,
+                probe=None):
+    """Axis-aligned CCW box [lo,hi]^2 split into n_per_side segments per side.
+    sides: 0 bottom (y=lo), 1 right (x=hi), 2 top (y=hi), 3 left (x=lo).
+    value(x,y) -> Dirichlet value, flux(x,y,side) -> Neumann colour."""
+    from elaina_amd import Problem
+    corners = [(lo, lo), (hi, lo), (hi, hi), (lo, hi)]
+
+    def side_mesh(sides, fn):
+        verts, segs, cols = [], [], []
+        for s in sides:
+            a, b = np.array(corners[s]), np.array(corners[(s + 1) % 4])
+            base = len(verts)
+            for k in range(n_per_side + 1):
+                p = a + (b - a) * (k / n_per_side)
+                verts.append(p)
+                v = 0.0 if fn is None else fn(float(p[0]), float(p[1]), s)
+                cols.append([v, v, v, v, v, v])
+            for k in range(n_per_side):
+                segs.append((base + k, base + k + 1))
+        if not verts:
+            return None, None, None
+        return (np.asarray(verts, np.float32), np.asarray(segs, np.int32), np.asarray(cols, np.float32))
+
+    dv, ds, dc = side_mesh(d_sides, (lambda x, y, s: value(x, y)) if value else None)
+    nv, ns, nc = side_mesh(n_sides, flux)
+    mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    if probe is None:
+        probe = (half * 0.9, mid, mid, 0.0, 1.0)
+    return Problem(d_verts=dv, d_segs=ds, d_colors=dc, n_verts=nv, n_segs=ns, n_colors=nc, probe=probe)

@@ -1,0 +1,242 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact (fp32 field, integer counters, indices)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import box_problem
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+GOLD = os.path.join(ROOT, "tests", "golden", "oracle_golden.npz")
+THREADS = os.cpu_count() or 8
+
+
+def _integrator(problem, w, h, spp, depth, eps):
+    from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+    return UniformIntegrator(problem, UniformIntegratorSettings((w, h), spp, depth, eps))
+
+
+def _assert_same_solve(oracle, problem, w, h, spp, depth, eps, **opts):
+    it = _integrator(problem, w, h, spp, depth, eps)
+    for k, v in opts.items():
+        it.set_option(k, v)
+    it.solve()
+    ref = oracle.solve(problem.as_dict(), w, h, spp, depth, eps, threads=THREADS)
+    s = it.last_stats
+    assert s["walk_steps"] == ref["walk_steps"]
+    for k in ("walks_started", "walks_absorbed", "walks_truncated", "neumann_hits"):
+        assert s[k] == ref[k], k
+    assert np.array_equal(it.solution, ref["field"]), float(np.abs(it.solution - ref["field"]).max())
+    it.close()
+    return ref
+
+
+@pytest.mark.parametrize("scene", ["ladybug", "fille"])
+def test_closest_point_matches_golden_brute_force(scene):
+    from elaina_amd import Problem
+    g = np.load(GOLD)
+    p = Problem.load_scene(scene)
+    it = _integrator(p, 16, 16, 1, 4, 1.0)
+    idx, dist, uv, side = it.closest_point(g[scene + "_cp_pts"])
+    assert np.array_equal(idx, g[scene + "_cp_idx"])
+    assert np.array_equal(dist, g[scene + "_cp_dist"])
+    assert np.array_equal(uv, g[scene + "_cp_uv"])
+    assert np.array_equal(side, g[scene + "_cp_side"].astype(np.int32))
+    it.close()
+
+
+def test_closest_point_random_mesh_and_ties(oracle):
+    from elaina_amd import Problem
+    rng = np.random.default_rng(2)
+    n = 5000
+    a = rng.uniform(0, 100, size=(n, 2))
+    verts = np.concatenate([a, a + rng.normal(0, 1, size=(n, 2))]).astype(np.float32)
+    segs = np.stack([np.arange(n), np.arange(n) + n], 1).astype(np.int32)
+    # duplicate 500 segments so exact ties occur; lowest original index must win
+    segs = np.concatenate([segs, segs[:500]])
+    p = Problem(d_verts=verts, d_segs=segs)
+    it = _integrator(p, 16, 16, 1, 4, 1.0)
+    pts = rng.uniform(-20, 120, size=(100000, 2)).astype(np.float32)
+    got = it.closest_point(pts)
+    ref = oracle.closest_point(verts, segs, pts, mode=1)
+    for x, y in zip(got, ref):
+        assert np.array_equal(x, y)
+    it.close()
+
+
+@pytest.mark.parametrize("n_segs", [1, 3, 4, 5, 16, 17, 64, 65, 257])
+def test_closest_point_tiny_meshes(oracle, n_segs):
+    # tree shapes around the leaf-size / arity boundaries, including padded (empty) leaves
+    from elaina_amd import Problem
+    rng = np.random.default_rng(n_segs)
+    verts = rng.uniform(0, 10, size=(n_segs + 1, 2)).astype(np.float32)
+    segs = np.stack([np.arange(n_segs), np.arange(n_segs) + 1], 1).astype(np.int32)
+    it = _integrator(Problem(d_verts=verts, d_segs=segs), 16, 16, 1, 4, 1.0)
+    pts = rng.uniform(-5, 15, size=(4096, 2)).astype(np.float32)
+    got = it.closest_point(pts)
+    ref = oracle.closest_point(verts, segs, pts, mode=0)
+    for x, y in zip(got, ref):
+        assert np.array_equal(x, y)
+    it.close()
+
+
+def test_silhouette_and_ray_queries(oracle, ladybug):
+    it = _integrator(ladybug, 16, 16, 1, 4, 1.0)
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-400, 900, size=(20000, 2)).astype(np.float32)
+    assert np.array_equal(it.closest_silhouette(pts), oracle.closest_silhouette(ladybug.n_verts, ladybug.n_segs, pts))
+    rmax = rng.uniform(10, 600, size=20000).astype(np.float32)
+    assert np.array_equal(it.closest_silhouette(pts, rmax),
+                          oracle.closest_silhouette(ladybug.n_verts, ladybug.n_segs, pts, rmax))
+    o = rng.uniform(-89, 589, size=(20000, 2)).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, size=20000)
+    d = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+    tmax = rng.uniform(1, 900, size=20000).astype(np.float32)
+    got = it.ray_intersect(o, d, tmax)
+    ref = oracle.ray_intersect(ladybug.n_verts, ladybug.n_segs, o, d, tmax)
+    assert np.array_equal(got[0], ref[0])
+    hit = ref[0] == 1
+    assert np.array_equal(got[1][hit], ref[1][hit]) and np.array_equal(got[2][hit], ref[2][hit])
+    it.close()
+
+
+def test_sdf_channels(oracle, ladybug):
+    it = _integrator(ladybug, 64, 64, 1, 4, 1.0)
+    assert np.array_equal(it.renderDirichletSDF(), oracle.render_dirichlet_sdf(ladybug.as_dict(), 64, 64, THREADS))
+    assert np.all(np.isinf(it.renderSilhouetteSDF()))
+    it.close()
+
+
+@pytest.mark.parametrize("scene", ["ladybug", "fille"])
+def test_config1_field_is_bit_exact_vs_golden(scene):
+    # BASELINE.json configs[0]: 128^2, 16 spp, max_depth 32, eps 1
+    from elaina_amd import Problem
+    g = np.load(GOLD)
+    it = _integrator(Problem.load_scene(scene), 128, 128, 16, 32, 1.0)
+    it.solve()
+    counts = g[scene + "_cfg1_counts"]
+    s = it.last_stats
+    assert [s["walk_steps"], s["walks_started"], s["walks_absorbed"], s["walks_truncated"], s["neumann_hits"]] == \
+        [int(c) for c in counts]
+    assert np.array_equal(it.solution, g[scene + "_cfg1_field"])
+    it.close()
+
+
+@pytest.mark.parametrize("steps_per_round", [1, 7, 64, 4096])
+def test_round_length_does_not_change_results(oracle, ladybug, steps_per_round):
+    _assert_same_solve(oracle, ladybug, 48, 40, 6, 24, 1.0, steps_per_round=steps_per_round)
+
+
+@pytest.mark.parametrize("block_size", [64, 128, 256])
+def test_block_size_does_not_change_results(oracle, ladybug, block_size):
+    _assert_same_solve(oracle, ladybug, 40, 48, 5, 24, 1.0, block_size=block_size)
+
+
+def test_ragged_frame_mask_and_ranges(oracle, ladybug):
+    from elaina_amd import Problem
+    w, h = 37, 29  # not a multiple of the 8x8 tile
+    mask = (np.random.default_rng(0).uniform(size=w * h) > 0.3).astype(np.uint8)
+    p = Problem(d_verts=ladybug.d_verts, d_segs=ladybug.d_segs, d_colors=ladybug.d_colors, n_verts=ladybug.n_verts,
+                n_segs=ladybug.n_segs, probe=ladybug.probe, mask=mask)
+    ref = _assert_same_solve(oracle, p, w, h, 5, 32, 1.0)
+    assert np.all(ref["field"][mask == 0] == 0)
+    it = _integrator(p, w, h, 5, 32, 1.0)
+    parts = []
+    for b, e in ((0, 1), (1, 500), (500, 500), (500, w * h)):
+        it.solve(b, e)
+        parts.append(it.solution.copy())
+    assert np.array_equal(np.concatenate(parts), ref["field"])
+    it.close()
+
+
+def test_edge_settings(oracle, ladybug):
+    _assert_same_solve(oracle, ladybug, 32, 32, 1, 1, 1.0)      # one step per walk
+    _assert_same_solve(oracle, ladybug, 32, 32, 3, 200, 0.01)   # thin shell, long walks
+    _assert_same_solve(oracle, ladybug, 8, 8, 40, 64, 5.0)      # fat shell
+
+
+def test_dirichlet_only_and_neumann_only(oracle, ladybug):
+    from elaina_amd import Problem
+    d_only = Problem(d_verts=ladybug.d_verts, d_segs=ladybug.d_segs, d_colors=ladybug.d_colors, probe=ladybug.probe)
+    _assert_same_solve(oracle, d_only, 32, 32, 4, 32, 1.0)
+    # no Dirichlet boundary and no silhouette: R_B is infinite, every walk is dropped at depth 0
+    n_only = Problem(n_verts=ladybug.n_verts, n_segs=ladybug.n_segs, probe=ladybug.probe)
+    ref = _assert_same_solve(oracle, n_only, 16, 16, 3, 8, 1.0)
+    assert ref["walk_steps"] == 16 * 16 * 3 and np.all(ref["field"] == 0)
+
+
+def test_emissive_neumann_boundary(oracle):
+    # non-zero Neumann colours exercise sample_object_in_sphere / shadow ray / Green's function
+    flux = lambda x, y, side: -1.0 if side == 2 else 1.0
+    p = box_problem(0.0, 100.0, 25, d_sides=(1, 3), n_sides=(0, 2), value=lambda x, y: y, flux=flux,
+                    probe=(40.0, 50.0, 50.0, 0.0, 1.0))
+    _assert_same_solve(oracle, p, 16, 16, 64, 512, 0.25)
+
+
+def test_sharded_solve_sums_to_full_field(oracle, ladybug):
+    import torch
+    w, h, spp, depth = 64, 48, 4, 32
+    ref = oracle.solve(ladybug.as_dict(), w, h, spp, depth, 1.0, threads=THREADS)
+    it = _integrator(ladybug, w, h, spp, depth, 1.0)
+    total = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    steps = 0
+    for r in range(3):
+        buf = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        st = it.solve_sharded(r, 3, buf.data_ptr())
+        steps += st["walk_steps"]
+        total += buf
+    assert steps == ref["walk_steps"]
+    assert np.array_equal(total.cpu().numpy().reshape(-1, 3), ref["field"])
+    it.close()
+
+
+def test_full_size_properties(oracle, ladybug):
+    # BASELINE.json configs[1] frame (1024^2, depth 64) at 2 spp: size-independent properties
+    w = h = 1024
+    spp = 2
+    it = _integrator(ladybug, w, h, spp, 64, 1.0)
+    it.solve()
+    s = it.last_stats
+    f = it.solution
+    assert s["walks_started"] == w * h * spp
+    assert s["walks_absorbed"] + s["walks_truncated"] == s["walks_started"]
+    assert np.isfinite(f).all() and f.min() >= 0.0 and f.max() <= 1.0
+    # a band of rows against the oracle, bit for bit
+    b, e = 500 * w, 508 * w
+    ref = oracle.solve(ladybug.as_dict(), w, h, spp, 64, 1.0, pixel_begin=b, pixel_end=e, threads=THREADS)
+    assert np.array_equal(f[b:e], ref["field"])
+    # same launch twice: identical (no dependence on atomic ordering)
+    it.solve()
+    assert np.array_equal(it.solution, f) and it.last_stats["walk_steps"] == s["walk_steps"]
+    it.close()
+
+
+def test_constant_colour_counts_absorptions_exactly(ladybug):
+    from elaina_amd import Problem
+    p = Problem(d_verts=ladybug.d_verts, d_segs=ladybug.d_segs, d_colors=np.ones_like(ladybug.d_colors),
+                n_verts=ladybug.n_verts, n_segs=ladybug.n_segs, probe=ladybug.probe)
+    spp = 16
+    it = _integrator(p, 256, 256, spp, 64, 1.0)
+    it.solve()
+    f = it.solution * spp
+    assert np.array_equal(f, np.round(f))
+    assert int(f[:, 0].sum()) == it.last_stats["walks_absorbed"]
+    it.close()
+
+
+def test_invalid_arguments_are_rejected(ladybug):
+    from elaina_amd import UniformIntegratorSettings, UniformIntegrator, capi
+    it = _integrator(ladybug, 16, 16, 1, 4, 1.0)
+    with pytest.raises(capi.WostError):
+        it.solve(-1, 10)
+    with pytest.raises(capi.WostError):
+        it.solve(0, 16 * 16 + 1)
+    with pytest.raises(capi.WostError):
+        it.set_option("no_such_option", 1)
+    it.close()
+    with pytest.raises(capi.WostError):
+        UniformIntegrator(ladybug, UniformIntegratorSettings((0, 16), 1, 4, 1.0))
