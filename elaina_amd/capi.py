@@ -56,6 +56,8 @@ class Stats(C.Structure):
         ("walks_absorbed", C.c_uint64),
         ("walks_truncated", C.c_uint64),
         ("neumann_hits", C.c_uint64),
+        ("inner_visits", C.c_uint64),
+        ("leaf_visits", C.c_uint64),
         ("solve_ms", C.c_double),
         ("kernel_ms", C.c_double),
         ("kernel_launches", C.c_uint32),

@@ -60,7 +60,10 @@ struct HostTree {
 };
 
 // Returns 0 on success, negative on invalid input (index out of range).
+// refine: true = perimeter-weighted (SAH) top-down assignment of the Morton-ordered segments
+// to the leaves of the implicit tree, false = plain LBVH (consecutive Morton groups).
+// extra_levels: grow the implicit tree beyond the minimum depth (more split freedom).
 int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_t *segs,
-               const float *colors, HostTree *out);
+               const float *colors, HostTree *out, bool refine = true, int extra_levels = 0);
 
 }  // namespace wost

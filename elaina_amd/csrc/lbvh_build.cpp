@@ -25,8 +25,9 @@ static inline uint32_t part1by1(uint32_t x)
 static inline float dot2(float ax, float ay, float bx, float by) { return std::fmaf(ax, bx, ay * by); }
 
 int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_t *segs,
-               const float *colors, HostTree *t)
+               const float *colors, HostTree *t, bool refine, int extra_levels)
 {
+    const float inf_f = std::numeric_limits<float>::infinity();
     *t = HostTree();
     t->n_segs = n_segs;
     t->n_verts = n_verts;
@@ -94,7 +95,7 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return code[a] < code[b]; });
 
-    // ---- leaves ------------------------------------------------------------------------
+    // ---- tree shape -------------------------------------------------------------------
     t->n_leaves = (n_segs + kLeafSize - 1) / kLeafSize;
     int levels = 1;
     int cap = kArity;
@@ -102,10 +103,98 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
         cap *= kArity;
         ++levels;
     }
+    levels += extra_levels;
+    for (int i = 0; i < extra_levels; ++i) cap *= kArity;
     t->levels = levels;
     t->n_leaves_cap = cap;
     t->first_leaf = (cap - 1) / (kArity - 1);
     const size_t n_slots = (size_t)cap * kLeafSize;
+
+    // ---- assignment of segments to leaves -----------------------------------------------
+    // slot_of[k] = original segment stored in slot k (-1 = padding).  Two policies:
+    //  * plain LBVH: consecutive groups of 4 in Morton order fill the leaves left to right;
+    //  * refined (default): top-down, every node splits its Morton-ordered set into four
+    //    subsets by two rounds of a perimeter-weighted sweep (the surface-area heuristic in
+    //    2-D), constrained so that each subset fits the fixed capacity of its implicit subtree.
+    std::vector<int32_t> slot_of(n_slots, -1);
+    if (!refine) {
+        for (int k = 0; k < n_segs; ++k) slot_of[k] = order[k];
+    } else {
+        struct Item { float cx, cy, lox, loy, hix, hiy; int32_t idx; };
+        std::vector<Item> items(n_segs);
+        for (int k = 0; k < n_segs; ++k) {
+            int o = order[k];
+            const FlatSeg &s = t->flat[o];
+            int i1 = segs[2 * o + 1];
+            float bx = verts[2 * i1], by = verts[2 * i1 + 1];
+            items[k] = Item{s.ax + 0.5f * s.ex, s.ay + 0.5f * s.ey, std::min(s.ax, bx), std::min(s.ay, by),
+                            std::max(s.ax, bx), std::max(s.ay, by), o};
+        }
+        std::vector<float> suffix;
+        // split items[b,e) into [b,m) and [m,e) with both sides <= cap_side items; returns m
+        auto split2 = [&](int b, int e, int cap_side) -> int {
+            const int n = e - b;
+            const int lo = std::max(0, n - cap_side), hi = std::min(n, cap_side);
+            if (n <= 1) return std::min(e, b + hi);
+            double best_cost = std::numeric_limits<double>::infinity();
+            int best_axis = 0, best_k = (lo + hi) / 2;
+            for (int axis = 0; axis < 2; ++axis) {
+                std::stable_sort(items.begin() + b, items.begin() + e, [axis](const Item &p, const Item &q) {
+                    return axis == 0 ? p.cx < q.cx : p.cy < q.cy;
+                });
+                suffix.assign(n + 1, 0.0f);
+                float lx = inf_f, ly = inf_f, hx = -inf_f, hy = -inf_f;
+                for (int i = n - 1; i >= 0; --i) {
+                    const Item &it = items[b + i];
+                    lx = std::min(lx, it.lox); ly = std::min(ly, it.loy);
+                    hx = std::max(hx, it.hix); hy = std::max(hy, it.hiy);
+                    suffix[i] = (hx - lx) + (hy - ly);
+                }
+                // cost in leaf visits: leaves needed on each side times the box perimeter;
+                // k == 0 / k == n (no split, everything in one child) compete when they fit
+                auto leaves = [](int c) { return (double)((c + kLeafSize - 1) / kLeafSize); };
+                if (axis == 0 && hi == n) {
+                    const double cost = leaves(n) * suffix[0];
+                    if (cost < best_cost) { best_cost = cost; best_axis = 0; best_k = n; }
+                }
+                lx = inf_f; ly = inf_f; hx = -inf_f; hy = -inf_f;
+                for (int k = 1; k < n; ++k) {
+                    const Item &it = items[b + k - 1];
+                    lx = std::min(lx, it.lox); ly = std::min(ly, it.loy);
+                    hx = std::max(hx, it.hix); hy = std::max(hy, it.hiy);
+                    if (k < lo || k > hi) continue;
+                    const double cost = leaves(k) * ((hx - lx) + (hy - ly)) + leaves(n - k) * suffix[k];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_k = k; }
+                }
+            }
+            if (best_axis == 0)
+                std::stable_sort(items.begin() + b, items.begin() + e,
+                                 [](const Item &p, const Item &q) { return p.cx < q.cx; });
+            return b + std::min(std::max(best_k, lo), hi);
+        };
+        // recursive descent over the implicit tree
+        struct Job { int b, e, level, pos; };
+        std::vector<Job> todo{{0, n_segs, 0, 0}};
+        while (!todo.empty()) {
+            Job j = todo.back();
+            todo.pop_back();
+            if (j.level == levels) {
+                for (int k = j.b; k < j.e; ++k) slot_of[(size_t)j.pos * kLeafSize + (k - j.b)] = items[k].idx;
+                continue;
+            }
+            int child_cap = kLeafSize;  // segments one child subtree can hold
+            for (int l = j.level + 1; l < levels; ++l) child_cap *= kArity;
+            const int m = split2(j.b, j.e, 2 * child_cap);
+            const int ml = split2(j.b, m, child_cap);
+            const int mr = split2(m, j.e, child_cap);
+            todo.push_back({j.b, ml, j.level + 1, 4 * j.pos + 0});
+            todo.push_back({ml, m, j.level + 1, 4 * j.pos + 1});
+            todo.push_back({m, mr, j.level + 1, 4 * j.pos + 2});
+            todo.push_back({mr, j.e, j.level + 1, 4 * j.pos + 3});
+        }
+    }
+
+    // ---- leaves ------------------------------------------------------------------------
     t->segA.assign(n_slots * 4, 0.0f);
     t->segInv.assign(n_slots, 0.0f);
     t->segOrig.assign(n_slots, kFarIndex);
@@ -115,17 +204,18 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
         t->segA[4 * s + 0] = kFarCoord;
         t->segA[4 * s + 1] = kFarCoord;
     }
-    for (int k = 0; k < n_segs; ++k) {
-        int o = order[k];
+    for (size_t k = 0; k < n_slots; ++k) {
+        const int o = slot_of[k];
+        if (o < 0) continue;
         const FlatSeg &s = t->flat[o];
-        t->segA[4 * (size_t)k + 0] = s.ax;
-        t->segA[4 * (size_t)k + 1] = s.ay;
-        t->segA[4 * (size_t)k + 2] = s.ex;
-        t->segA[4 * (size_t)k + 3] = s.ey;
+        t->segA[4 * k + 0] = s.ax;
+        t->segA[4 * k + 1] = s.ay;
+        t->segA[4 * k + 2] = s.ex;
+        t->segA[4 * k + 3] = s.ey;
         t->segInv[k] = s.inv_len2;
         t->segOrig[k] = o;
-        t->origToSlot[o] = k;
-        std::memcpy(&t->segCol[(size_t)k * 12], &t->flatCol[(size_t)o * 12], 12 * sizeof(float));
+        t->origToSlot[o] = (int32_t)k;
+        std::memcpy(&t->segCol[k * 12], &t->flatCol[(size_t)o * 12], 12 * sizeof(float));
     }
 
     // ---- boxes, bottom-up ----------------------------------------------------------------
@@ -144,11 +234,13 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
         nb[4 * (size_t)g + 0] = inf; nb[4 * (size_t)g + 1] = inf;
         nb[4 * (size_t)g + 2] = -inf; nb[4 * (size_t)g + 3] = -inf;
     }
-    for (int k = 0; k < n_segs; ++k) {
-        int g = t->first_leaf + k / kLeafSize;
-        const FlatSeg &s = t->flat[order[k]];
+    for (size_t k = 0; k < n_slots; ++k) {
+        const int o = slot_of[k];
+        if (o < 0) continue;
+        int g = t->first_leaf + (int)(k / kLeafSize);
+        const FlatSeg &s = t->flat[o];
         // second endpoint exactly as given (not a + e)
-        int i1 = segs[2 * order[k] + 1];
+        int i1 = segs[2 * o + 1];
         float bx = verts[2 * i1], by = verts[2 * i1 + 1];
         float *b = &nb[4 * (size_t)g];
         b[0] = std::min(b[0], std::min(s.ax, bx));

@@ -98,82 +98,138 @@ __device__ __forceinline__ void cswap(uint32_t &a, uint32_t &b)
     b = hi;
 }
 
-// Closest point on the wide LBVH.  `stack` is this lane's column of the LDS traversal
-// stack: entry i lives at stack[i * stride].  (best.d2, best.slot) may carry a valid
-// candidate on entry (temporal hint); ties are broken by the lowest original index.
-__device__ __forceinline__ Closest closest_point(const DevMesh &m, float qx, float qy, Closest best,
-                                                 uint32_t *stack, int stride)
+// Traversal state of one closest-point query on the wide LBVH.
+//
+// A node is addressed as (level, pos): heap index = first(level) + pos with
+// first(L) = (4^L - 1) / 3 = 0x55555555 >> (32 - 2L); its children are (level+1, 4*pos+j).
+// `stack` is the lane's column of the LDS traversal stack: entry i lives at stack[i*stride].
+// A stack entry is ONE 32-bit word: the child's box distance with its 6 low mantissa bits
+// replaced by (level << 2 | j).  The truncated distance is a lower bound of the true one,
+// so stale entries are dropped at pop time without touching memory, and the node position
+// is recovered from the position of the last visited node (which always lies below the
+// entry's parent in a depth-first traversal): parent pos = pos >> 2*(level - entry_level + 1).
+struct Trav {
+    int32_t level;      // level of the node to visit next; == mesh.levels means a leaf
+    int32_t pos;        // position of that node inside its level
+    int32_t sp;         // stack pointer
+    Closest best;       // may start from a valid candidate (temporal hint)
+    int32_t best_orig;  // original index of best.slot, loaded lazily when an exact tie shows up
+};
+
+__device__ __forceinline__ Trav trav_begin(Closest seed)
 {
-    int sp = 0;
-    int g = 0;
-    int32_t best_orig = -1;  // loaded lazily, only when an exact tie shows up
-    const int first_leaf = m.first_leaf;
-    for (;;) {
-        const float4 *cb = m.boxes + 4 * g;
-        float4 b0 = cb[0], b1 = cb[1], b2 = cb[2], b3 = cb[3];
-        float d0 = box_d2(b0, qx, qy), d1 = box_d2(b1, qx, qy);
-        float d2 = box_d2(b2, qx, qy), d3 = box_d2(b3, qx, qy);
-        const int child0 = 4 * g + 1;
-        if (child0 >= first_leaf) {
-            // children are leaves: evaluate every leaf that can still tie or win
-            const int leaf0 = child0 - first_leaf;
+    return Trav{0, 0, 0, seed, -1};
+}
+
+__device__ __forceinline__ uint32_t level_first(int level)
+{
+    return level == 0 ? 0u : (0x55555555u >> (32 - 2 * level));
+}
+
+// Pop the next entry that can still tie or beat the current best.  Returns false when the
+// stack is exhausted (query complete).
+__device__ __forceinline__ bool trav_pop(Trav &T, const uint32_t *stack, int stride)
+{
+    while (T.sp > 0) {
+        --T.sp;
+        const uint32_t key = stack[T.sp * stride];
+        const float dlb = __uint_as_float(key & ~0x3Fu);
+        if (dlb <= T.best.d2) {
+            const int el = (int)((key >> 2) & 15u);
+            const int parent = T.pos >> (2 * (T.level - el + 1));
+            T.pos = 4 * parent + (int)(key & 3u);
+            T.level = el;
+            return true;
+        }
+    }
+    return false;
+}
+
+// Evaluate the four segments of leaf T.pos.  Ties are broken by the lowest ORIGINAL segment
+// index, so the answer does not depend on the tree layout or the visiting order.
+__device__ __forceinline__ void trav_leaf(const DevMesh &m, float qx, float qy, Trav &T)
+{
+    const int leaf = T.pos;
+    const float4 *sa = m.segA + 4 * leaf;
+    const float4 a0 = sa[0], a1 = sa[1], a2 = sa[2], a3 = sa[3];
+    const float4 iv = m.segInv[leaf];
+    const float e0 = seg_d2(a0.x, a0.y, a0.z, a0.w, iv.x, qx, qy);
+    const float e1 = seg_d2(a1.x, a1.y, a1.z, a1.w, iv.y, qx, qy);
+    const float e2 = seg_d2(a2.x, a2.y, a2.z, a2.w, iv.z, qx, qy);
+    const float e3 = seg_d2(a3.x, a3.y, a3.z, a3.w, iv.w, qx, qy);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float dj = (j == 0) ? d0 : (j == 1) ? d1 : (j == 2) ? d2 : d3;
-                if (dj <= best.d2) {
-                    const int leaf = leaf0 + j;
-                    const float4 *sa = m.segA + 4 * leaf;
-                    float4 a0 = sa[0], a1 = sa[1], a2 = sa[2], a3 = sa[3];
-                    float4 iv = m.segInv[leaf];
-                    float e0 = seg_d2(a0.x, a0.y, a0.z, a0.w, iv.x, qx, qy);
-                    float e1 = seg_d2(a1.x, a1.y, a1.z, a1.w, iv.y, qx, qy);
-                    float e2 = seg_d2(a2.x, a2.y, a2.z, a2.w, iv.z, qx, qy);
-                    float e3 = seg_d2(a3.x, a3.y, a3.z, a3.w, iv.w, qx, qy);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float ek = (k == 0) ? e0 : (k == 1) ? e1 : (k == 2) ? e2 : e3;
-                        int slot = 4 * leaf + k;
-                        if (ek < best.d2) {
-                            best.d2 = ek;
-                            best.slot = slot;
-                            best_orig = -1;
-                        } else if (ek == best.d2 && slot != best.slot) {
-                            if (best_orig < 0) best_orig = (best.slot >= 0) ? m.segOrig[best.slot] : WOST_FAR_INDEX;
-                            int o = m.segOrig[slot];
-                            if (o < best_orig) {
-                                best.slot = slot;
-                                best_orig = o;
-                            }
-                        }
-                    }
-                }
-            }
-        } else {
-            // inner children: near-first order; the child index rides in the two low
-            // mantissa bits of the (non-negative) distance so that four integer
-            // compare-exchanges sort the candidates
-            uint32_t k0 = (d0 <= best.d2) ? ((__float_as_uint(d0) & ~3u) | 0u) : 0xffffffffu;
-            uint32_t k1 = (d1 <= best.d2) ? ((__float_as_uint(d1) & ~3u) | 1u) : 0xffffffffu;
-            uint32_t k2 = (d2 <= best.d2) ? ((__float_as_uint(d2) & ~3u) | 2u) : 0xffffffffu;
-            uint32_t k3 = (d3 <= best.d2) ? ((__float_as_uint(d3) & ~3u) | 3u) : 0xffffffffu;
-            cswap(k0, k1);
-            cswap(k2, k3);
-            cswap(k0, k2);
-            cswap(k1, k3);
-            cswap(k1, k2);
-            if (k3 != 0xffffffffu) { stack[sp * stride] = child0 + (k3 & 3u); ++sp; }
-            if (k2 != 0xffffffffu) { stack[sp * stride] = child0 + (k2 & 3u); ++sp; }
-            if (k1 != 0xffffffffu) { stack[sp * stride] = child0 + (k1 & 3u); ++sp; }
-            if (k0 != 0xffffffffu) {
-                g = child0 + (k0 & 3u);
-                continue;
+    for (int k = 0; k < 4; ++k) {
+        const float ek = (k == 0) ? e0 : (k == 1) ? e1 : (k == 2) ? e2 : e3;
+        const int slot = 4 * leaf + k;
+        if (ek < T.best.d2) {
+            T.best.d2 = ek;
+            T.best.slot = slot;
+            T.best_orig = -1;
+        } else if (ek == T.best.d2 && slot != T.best.slot) {
+            if (T.best_orig < 0) T.best_orig = (T.best.slot >= 0) ? m.segOrig[T.best.slot] : WOST_FAR_INDEX;
+            const int o = m.segOrig[slot];
+            if (o < T.best_orig) {
+                T.best.slot = slot;
+                T.best_orig = o;
             }
         }
-        if (sp == 0) break;
-        --sp;
-        g = stack[sp * stride];
     }
-    return best;
+}
+
+// Expand inner node (T.level, T.pos): test the four child boxes, push the ones that can
+// still tie or win in far-to-near order and step into the nearest.  Returns false when no
+// child qualifies (the caller then pops).
+__device__ __forceinline__ bool trav_inner(const DevMesh &m, float qx, float qy, Trav &T, uint32_t *stack, int stride)
+{
+    const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
+    const float4 *cb = m.boxes + 4 * (size_t)g;
+    const float4 b0 = cb[0], b1 = cb[1], b2 = cb[2], b3 = cb[3];
+    const float d0 = box_d2(b0, qx, qy), d1 = box_d2(b1, qx, qy);
+    const float d2 = box_d2(b2, qx, qy), d3 = box_d2(b3, qx, qy);
+    // the (non-negative) distance orders as an integer; level and child index ride in the low
+    // mantissa bits, so five integer compare-exchanges sort the candidates near-first
+    const float bd = T.best.d2;
+    const uint32_t tag = (uint32_t)(T.level + 1) << 2;
+    uint32_t k0 = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;
+    uint32_t k1 = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3Fu) | tag | 1u) : 0xffffffffu;
+    uint32_t k2 = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3Fu) | tag | 2u) : 0xffffffffu;
+    uint32_t k3 = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3Fu) | tag | 3u) : 0xffffffffu;
+    cswap(k0, k1);
+    cswap(k2, k3);
+    cswap(k0, k2);
+    cswap(k1, k3);
+    cswap(k1, k2);
+    int sp = T.sp;
+    if (k3 != 0xffffffffu) { stack[sp * stride] = k3; ++sp; }
+    if (k2 != 0xffffffffu) { stack[sp * stride] = k2; ++sp; }
+    if (k1 != 0xffffffffu) { stack[sp * stride] = k1; ++sp; }
+    T.sp = sp;
+    if (k0 != 0xffffffffu) {
+        T.pos = 4 * T.pos + (int)(k0 & 3u);
+        T.level += 1;
+        return true;
+    }
+    return false;
+}
+
+// Visit ONE node, then pick the next one.  Returns false when the query is complete.
+__device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy, Trav &T, uint32_t *stack, int stride)
+{
+    if (T.level == m.levels) {
+        trav_leaf(m, qx, qy, T);
+    } else {
+        if (trav_inner(m, qx, qy, T, stack, stride)) return true;
+    }
+    return trav_pop(T, stack, stride);
+}
+
+__device__ __forceinline__ Closest closest_point(const DevMesh &m, float qx, float qy, Closest seed,
+                                                 uint32_t *stack, int stride)
+{
+    Trav T = trav_begin(seed);
+    while (trav_visit(m, qx, qy, T, stack, stride)) {
+    }
+    return T.best;
 }
 
 // Brute-force variant for tiny meshes (wave-uniform loop over the flat records, which the

@@ -18,7 +18,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -49,7 +51,7 @@ struct WalkQueue {
 static const int kQueueWords = 16 + 1;  // rng counts twice
 
 struct StatsDev {
-    unsigned long long steps, started, absorbed, truncated, nhits;
+    unsigned long long steps, started, absorbed, truncated, nhits, inner_visits, leaf_visits;
 };
 
 struct RoundParams {
@@ -64,6 +66,7 @@ struct RoundParams {
     StatsDev *stats;
     int32_t steps_per_round;
     int32_t stack_stride;  // = blockDim.x
+    int32_t wait_weight;   // step phase runs when n_wait * wait_weight >= 8 * max(n_inner, n_leaf)
 };
 
 struct InitParams {
@@ -162,32 +165,27 @@ struct Lane {
 };
 
 struct LaneStats {
-    uint32_t steps, started, absorbed, truncated, nhits;
+    uint32_t steps, started, absorbed, truncated, nhits, inner_visits, leaf_visits;
 };
 
-// One walk step of one walker = one item consumed from the reference's evaluation-point
-// queue at one depth: separate -> handleBoundary -> sampleNeumann -> oneStepWalk
-// (reference integrator/uniform/integrator.cu:128-211, 224-231, 336-444, 465-525).
+// The part of one walk step that follows the closest-point query.  One walk step = one item
+// consumed from the reference's evaluation-point queue at one depth: separate ->
+// handleBoundary -> sampleNeumann -> oneStepWalk (reference
+// integrator/uniform/integrator.cu:128-211, 224-231, 336-444, 465-525).  `cp` is the result
+// of lbvh nearest() for L.px,L.py (ignored when there is no Dirichlet boundary).
 // Returns true when the walk ended in this step.
 template <bool NEUMANN_EMISSIVE>
-__device__ __forceinline__ bool walk_step(const RoundParams &P, Lane &L, LaneStats &S, uint32_t *stack)
+__device__ __forceinline__ bool step_finish(const RoundParams &P, Lane &L, LaneStats &S, const Closest cp)
 {
     const DevMesh &dm = P.dm;
     const DevMesh &nm = P.nm;
     const bool has_d = dm.n_segs > 0, has_n = nm.n_segs > 0;
     const float eps = P.st.eps;
-    S.steps++;
     const float px = L.px, py = L.py;
 
     // ---- separateEvaluationPoint -------------------------------------------------------
     float R_D = WOST_INF;
     if (has_d) {
-        Closest cp;
-        if (L.depth == 0) {
-            cp = Closest{L.d0_d2, L.d0_slot};  // same point for every sample of the pixel
-        } else {
-            cp = closest_point(dm, px, py, hint_candidate(dm, L.hint, px, py), stack, P.stack_stride);
-        }
         L.hint = cp.slot;
         const float4 a = dm.segA[cp.slot];
         const float inv = reinterpret_cast<const float *>(dm.segInv)[cp.slot];
@@ -314,7 +312,7 @@ __global__ __launch_bounds__(256) void walk_round_kernel(RoundParams P)
     const uint32_t n_in = *P.count_in;
     const bool valid = slot < n_in;
     Lane L;
-    LaneStats S{0, 0, 0, 0, 0};
+    LaneStats S{0, 0, 0, 0, 0, 0, 0};
     uint32_t pix = 0;
     bool alive = false;
     if (valid) {
@@ -332,20 +330,69 @@ __global__ __launch_bounds__(256) void walk_round_kernel(RoundParams P)
         L.d0_d2 = q.d0_d2[slot]; L.d0_slot = q.d0_slot[slot];
         alive = L.sample < (uint32_t)P.st.spp;
     }
-    for (int it = 0; it < P.steps_per_round; ++it) {
-        if (!__any(alive)) break;
-        if (alive) {
-            if (L.depth == 0) S.started++;
-            const bool ended = walk_step<NEUMANN_EMISSIVE>(P, L, S, stack);
-            if (ended) {
-                // next sample of this pixel starts right away (generateEvaluationPoints,
-                // reference integrator.cu:90-99 + workqueue.h:99-110)
-                L.sample++;
-                L.px = L.x0; L.py = L.y0;
-                L.depth = 0; L.on_n = false; L.nx = 0.0f; L.ny = 0.0f;
-                L.thp = 1.0f;
-                L.hint = L.d0_slot;
-                alive = L.sample < (uint32_t)P.st.spp;
+    // Per-lane state machine.  A lane either has an INNER node or a LEAF of the LBVH to visit
+    // for its current walk position, WAITs with a finished query for the step logic, or is DONE
+    // for this round.  Query lengths differ wildly between lanes, so instead of running every
+    // lane's query to completion in lock step, each trip of the loop runs ONE of the three
+    // bodies -- the one most lanes of the wave are ready for -- and the others accumulate.
+    enum { MODE_START = 0, MODE_INNER = 1, MODE_LEAF = 2, MODE_WAIT = 3, MODE_DONE = 4 };
+    const bool has_d = P.dm.n_segs > 0;
+    const int levels = P.dm.levels;
+    int mode = alive ? MODE_WAIT : MODE_DONE;
+    bool fresh = true;   // first trip: no finished step yet, only start the query
+    int budget = P.steps_per_round;
+    Trav T = trav_begin(Closest{WOST_INF, -1});
+    for (;;) {
+        const int n_inner = __popcll(__ballot(mode == MODE_INNER));
+        const int n_leaf = __popcll(__ballot(mode == MODE_LEAF));
+        const int n_wait = __popcll(__ballot(mode == MODE_WAIT));
+        if (n_inner + n_leaf + n_wait == 0) break;
+        if (n_wait * P.wait_weight >= max(n_inner, n_leaf) * 8) {
+            // ---- step phase ----
+            if (mode == MODE_WAIT) {
+                if (!fresh) {
+                    const bool ended = step_finish<NEUMANN_EMISSIVE>(P, L, S, T.best);
+                    if (ended) {
+                        // next sample of this pixel starts right away (generateEvaluationPoints,
+                        // reference integrator.cu:90-99 + workqueue.h:99-110)
+                        L.sample++;
+                        L.px = L.x0; L.py = L.y0;
+                        L.depth = 0; L.on_n = false; L.nx = 0.0f; L.ny = 0.0f;
+                        L.thp = 1.0f;
+                        L.hint = L.d0_slot;
+                        alive = L.sample < (uint32_t)P.st.spp;
+                    }
+                    --budget;
+                }
+                fresh = false;
+                if (alive && budget > 0) {
+                    S.steps++;
+                    if (L.depth == 0) S.started++;
+                    if (!has_d || L.depth == 0) {
+                        // depth 0 starts at the same point for every sample of the pixel: cached
+                        T.best = Closest{L.d0_d2, L.d0_slot};
+                        mode = MODE_WAIT;
+                    } else {
+                        T = trav_begin(hint_candidate(P.dm, L.hint, L.px, L.py));
+                        mode = MODE_INNER;  // the root is an inner node (levels >= 1)
+                    }
+                } else {
+                    mode = MODE_DONE;
+                }
+            }
+        } else if (n_inner >= n_leaf) {
+            if (mode == MODE_INNER) {
+                S.inner_visits++;
+                bool more = trav_inner(P.dm, L.px, L.py, T, stack, P.stack_stride);
+                if (!more) more = trav_pop(T, stack, P.stack_stride);
+                mode = !more ? MODE_WAIT : (T.level == levels ? MODE_LEAF : MODE_INNER);
+            }
+        } else {
+            if (mode == MODE_LEAF) {
+                S.leaf_visits++;
+                trav_leaf(P.dm, L.px, L.py, T);
+                const bool more = trav_pop(T, stack, P.stack_stride);
+                mode = !more ? MODE_WAIT : (T.level == levels ? MODE_LEAF : MODE_INNER);
             }
         }
     }
@@ -376,9 +423,9 @@ __global__ __launch_bounds__(256) void walk_round_kernel(RoundParams P)
         q.d0_d2[s] = L.d0_d2; q.d0_slot[s] = L.d0_slot;
     }
     // ---- statistics: wave reduction, one atomic per counter per wave -----------------------
-    uint32_t v[5] = {S.steps, S.started, S.absorbed, S.truncated, S.nhits};
+    uint32_t v[7] = {S.steps, S.started, S.absorbed, S.truncated, S.nhits, S.inner_visits, S.leaf_visits};
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 7; ++k) {
         uint32_t x = v[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
@@ -390,6 +437,8 @@ __global__ __launch_bounds__(256) void walk_round_kernel(RoundParams P)
         if (v[2]) atomicAdd(&P.stats->absorbed, (unsigned long long)v[2]);
         if (v[3]) atomicAdd(&P.stats->truncated, (unsigned long long)v[3]);
         if (v[4]) atomicAdd(&P.stats->nhits, (unsigned long long)v[4]);
+        if (v[5]) atomicAdd(&P.stats->inner_visits, (unsigned long long)v[5]);
+        if (v[6]) atomicAdd(&P.stats->leaf_visits, (unsigned long long)v[6]);
     }
 }
 
@@ -500,7 +549,12 @@ static hipError_t upload(std::vector<void *> &allocs, const T *src, size_t count
 static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
 {
     if (d.n_segs < 0 || d.n_verts < 0) return fail(WOST_ERR_INVALID, "negative mesh size");
-    if (build_tree(d.n_verts, d.verts, d.n_segs, d.segs, d.colors, &s.host) != 0)
+    // developer knobs for tree-quality experiments (defaults: refined, minimal depth)
+    const char *e_refine = getenv("WOST_TREE_REFINE");
+    const char *e_extra = getenv("WOST_TREE_EXTRA_LEVELS");
+    const bool refine = e_refine ? atoi(e_refine) != 0 : true;
+    const int extra = e_extra ? std::max(0, std::min(3, atoi(e_extra))) : 0;
+    if (build_tree(d.n_verts, d.verts, d.n_segs, d.segs, d.colors, &s.host, refine, extra) != 0)
         return fail(WOST_ERR_INVALID, "mesh: segment index out of range or null arrays");
     const HostTree &t = s.host;
     DevMesh &v = s.view;
@@ -551,6 +605,7 @@ struct wost_context {
     // options
     int steps_per_round = 64;
     int block_size = 256;
+    int wait_weight = 8;
     int time_kernels = 1;
 };
 
@@ -676,6 +731,9 @@ int wost_set_option(wost_handle h, const char *key, double value)
         const int b = (int)value;
         if (b != 64 && b != 128 && b != 256) return fail(WOST_ERR_INVALID, "block_size must be 64, 128 or 256");
         h->block_size = b;
+    } else if (k == "wait_weight") {
+        if (value < 1 || value > 512) return fail(WOST_ERR_INVALID, "wait_weight must be in 1..512");
+        h->wait_weight = (int)value;
     } else if (k == "time_kernels") {
         h->time_kernels = value != 0;
     } else {
@@ -745,6 +803,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         rp.stats = c->stats;
         rp.steps_per_round = c->steps_per_round;
         rp.stack_stride = bs;
+        rp.wait_weight = c->wait_weight;
         const unsigned grid = (n_active + bs - 1) / bs;
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
         if (emissive)
@@ -774,6 +833,8 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         stats->walks_absorbed = sd.absorbed;
         stats->walks_truncated = sd.truncated;
         stats->neumann_hits = sd.nhits;
+        stats->inner_visits = sd.inner_visits;
+        stats->leaf_visits = sd.leaf_visits;
         stats->kernel_ms = kernel_ms;
         stats->kernel_launches = launches;
         stats->reserved = 0;

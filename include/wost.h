@@ -76,6 +76,8 @@ typedef struct wost_stats {
     uint64_t walks_absorbed;   /* ended in the epsilon shell                                  */
     uint64_t walks_truncated;  /* reached max_depth                                           */
     uint64_t neumann_hits;     /* steps that landed on the Neumann boundary                   */
+    uint64_t inner_visits;     /* LBVH inner nodes expanded by the walk's closest-point queries */
+    uint64_t leaf_visits;      /* LBVH leaves (4 segments each) evaluated by those queries    */
     double solve_ms;           /* host wall time of the call, like UniformIntegrator::solve() */
     double kernel_ms;          /* sum of HIP-event durations of the walk kernel launches      */
     uint32_t kernel_launches;  /* number of walk-kernel launches (rounds)                     */

@@ -2,7 +2,7 @@
 # PMC passes for the walk kernel (each counter group in its own run; no trace domains mixed in)
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc
-ARGS="bench.py --steps 1 --warmup 0 --no-cpu-baseline --spp ${SPP:-32}"
+ARGS="bench.py --steps 1 --warmup 0 --no-cpu-baseline --spp ${SPP:-32} --steps-per-round ${SPR:-256}"
 rocprofv3 -L > gpurun_out/pmc/counters.txt 2>&1
 i=0
 for grp in \
