@@ -58,6 +58,18 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
             s.nx = 0.0f;
             s.ny = 0.0f;
         }
+        // distance form (DESIGN.md "segment distance")
+        s.cx = std::fmaf(0.5f, s.ex, s.ax);
+        s.cy = std::fmaf(0.5f, s.ey, s.ay);
+        if (s.len > 0.0f) {
+            s.ux = s.ex / s.len;
+            s.uy = s.ey / s.len;
+        } else {
+            s.ux = 1.0f;
+            s.uy = 0.0f;
+        }
+        s.hl = 0.5f * s.len;
+        s.pad0 = s.pad1 = s.pad2 = 0.0f;
         if (vnext[i0] < 0) vnext[i0] = i;  // lowest segment index wins
         if (vprev[i1] < 0) vprev[i1] = i;
         lox = std::min(lox, std::min(s.ax, bx));
@@ -269,6 +281,91 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
         } else {
             o[0] = b[0] - pad; o[1] = b[1] - pad; o[2] = b[2] + pad; o[3] = b[3] + pad;
         }
+    }
+    // ---- oriented child boxes for every node -------------------------------------------
+    {
+        const int n_all = t->first_leaf + cap;   // nodes that have children (leaves included)
+        t->nodes.assign((size_t)n_all * 24, 0.0f);
+        // endpoints under every node, gathered bottom-up (leaves first)
+        std::vector<std::vector<double>> pts(n_all);
+        for (int k = 0; k < cap; ++k) {
+            std::vector<double> &P = pts[t->first_leaf + k];
+            for (int j = 0; j < kLeafSize; ++j) {
+                const int o = slot_of[(size_t)k * kLeafSize + j];
+                if (o < 0) continue;
+                const int i0 = segs[2 * o], i1 = segs[2 * o + 1];
+                P.push_back(verts[2 * i0]); P.push_back(verts[2 * i0 + 1]);
+                P.push_back(verts[2 * i1]); P.push_back(verts[2 * i1 + 1]);
+            }
+        }
+        for (int g = t->first_leaf - 1; g >= 1; --g)
+            for (int j = 1; j <= kArity; ++j) {
+                const std::vector<double> &C = pts[kArity * g + j];
+                pts[g].insert(pts[g].end(), C.begin(), C.end());
+            }
+        const double obb_pad = (double)ext * 0x1p-18 + 1e-30;
+        auto set_child = [&](int parent, int j, float cx, float cy, float ux, float uy, float hl, float hw) {
+            float *nd = &t->nodes[(size_t)parent * 24];
+            nd[0 + j] = cx; nd[4 + j] = cy; nd[8 + j] = ux; nd[12 + j] = uy; nd[16 + j] = hl; nd[20 + j] = hw;
+        };
+        // inner levels: fit an oriented box around the endpoints of each child subtree
+        for (int g = 0; g < t->first_leaf; ++g) {
+            for (int j = 0; j < kArity; ++j) {
+                const std::vector<double> &P = pts[kArity * g + 1 + j];
+                const size_t n = P.size() / 2;
+                if (n == 0) {
+                    set_child(g, j, kFarCoord, kFarCoord, 1.0f, 0.0f, 0.0f, 0.0f);
+                    continue;
+                }
+                double mx = 0, my = 0;
+                for (size_t i = 0; i < n; ++i) { mx += P[2 * i]; my += P[2 * i + 1]; }
+                mx /= (double)n; my /= (double)n;
+                double sxx = 0, sxy = 0, syy = 0;
+                for (size_t i = 0; i < n; ++i) {
+                    const double x = P[2 * i] - mx, y = P[2 * i + 1] - my;
+                    sxx += x * x; sxy += x * y; syy += y * y;
+                }
+                const double pca = 0.5 * std::atan2(2.0 * sxy, sxx - syy);
+                double best = std::numeric_limits<double>::infinity();
+                float b_cx = 0, b_cy = 0, b_ux = 1, b_uy = 0, b_hl = 0, b_hw = 0;
+                const int n_ang = 16;
+                for (int a = -1; a < n_ang; ++a) {
+                    const double ang = (a < 0) ? pca : M_PI * (double)a / n_ang;
+                    // the axis as it will be stored (fp32); extents are measured in THAT frame
+                    const float uxf = (float)std::cos(ang), uyf = (float)std::sin(ang);
+                    const double ux = uxf, uy = uyf, n2 = ux * ux + uy * uy;
+                    double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+                    for (size_t i = 0; i < n; ++i) {
+                        const double u = P[2 * i] * ux + P[2 * i + 1] * uy;
+                        const double v = -P[2 * i] * uy + P[2 * i + 1] * ux;
+                        umin = std::min(umin, u); umax = std::max(umax, u);
+                        vmin = std::min(vmin, v); vmax = std::max(vmax, v);
+                    }
+                    const double score = (umax - umin) + (vmax - vmin);
+                    if (score < best) {
+                        best = score;
+                        const double uc = 0.5 * (umin + umax), vc = 0.5 * (vmin + vmax);
+                        b_cx = (float)((uc * ux - vc * uy) / n2);
+                        b_cy = (float)((uc * uy + vc * ux) / n2);
+                        b_ux = uxf; b_uy = uyf;
+                        b_hl = (float)(0.5 * (umax - umin) * (1.0 + 1e-6) + obb_pad);
+                        b_hw = (float)(0.5 * (vmax - vmin) * (1.0 + 1e-6) + obb_pad);
+                    }
+                }
+                set_child(g, j, b_cx, b_cy, b_ux, b_uy, b_hl, b_hw);
+            }
+        }
+        // last level: the children are the segments, exact records, no padding
+        for (int k = 0; k < cap; ++k)
+            for (int j = 0; j < kLeafSize; ++j) {
+                const int o = slot_of[(size_t)k * kLeafSize + j];
+                if (o < 0) {
+                    set_child(t->first_leaf + k, j, kFarCoord, kFarCoord, 1.0f, 0.0f, 0.0f, 0.0f);
+                } else {
+                    const FlatSeg &s = t->flat[o];
+                    set_child(t->first_leaf + k, j, s.cx, s.cy, s.ux, s.uy, s.hl, 0.0f);
+                }
+            }
     }
     return 0;
 }

@@ -23,6 +23,8 @@ namespace wost {
 struct DevFlatSeg {
     float ax, ay, ex, ey;
     float inv_len2, len, nx, ny;
+    float cx, cy, ux, uy;
+    float hl, pad0, pad1, pad2;
 };
 struct DevSilVertex {
     float x, y;
@@ -30,9 +32,9 @@ struct DevSilVertex {
 };
 
 struct DevMesh {
-    const float4 *boxes;     // [n_nodes-1], children of g at 4g..4g+3
+    const float4 *nodes;     // [n_nodes * 6]: cx[4] cy[4] ux[4] uy[4] hl[4] hw[4] of the children
     const float4 *segA;      // [slots] ax, ay, ex, ey
-    const float4 *segInv;    // [leaves] 1/|e|^2 of the four slots
+    const float *segInv;     // [slots] 1/|e|^2
     const int32_t *segOrig;  // [slots]
     const float *segCol;     // [slots*12]
     const DevFlatSeg *flat;  // [n_segs] original order
@@ -67,22 +69,22 @@ __device__ __forceinline__ void eval_point(const DevProbe &p, int px, int py, in
     y = p.scale * (ndcx * uy + ndcy * vy) + p.posy;
 }
 
-// ---- closest point on one segment (DESIGN.md "segment distance") -----------------------
-__device__ __forceinline__ float seg_d2(float ax, float ay, float ex, float ey, float inv, float qx, float qy)
+// ---- squared distance to an oriented box / a segment (DESIGN.md "segment distance") ------
+// Box = centre c, unit axis u, half length hl along u, half width hw across it.  A segment
+// is the box with hw = 0; for it this IS the distance of the arithmetic contract.
+__device__ __forceinline__ float obb_d2(float cx, float cy, float ux, float uy, float hl, float hw, float qx, float qy)
 {
-    float wx = qx - ax, wy = qy - ay;
-    float tr = dot2(wx, wy, ex, ey) * inv;
-    float t = fminf(fmaxf(tr, 0.0f), 1.0f);
-    float cx = __builtin_fmaf(t, ex, ax), cy = __builtin_fmaf(t, ey, ay);
-    float dx = qx - cx, dy = qy - cy;
-    return dot2(dx, dy, dx, dy);
+    const float wx = qx - cx, wy = qy - cy;
+    const float u = dot2(wx, wy, ux, uy);
+    const float v = cross2(ux, uy, wx, wy);
+    const float du = fmaxf(fabsf(u) - hl, 0.0f);
+    const float dv = fmaxf(fabsf(v) - hw, 0.0f);
+    return dot2(du, dv, du, dv);
 }
 
-__device__ __forceinline__ float box_d2(const float4 b, float qx, float qy)
+__device__ __forceinline__ float seg_d2(const DevFlatSeg &s, float qx, float qy)
 {
-    float dx = fmaxf(fmaxf(b.x - qx, qx - b.z), 0.0f);
-    float dy = fmaxf(fmaxf(b.y - qy, qy - b.w), 0.0f);
-    return dot2(dx, dy, dx, dy);
+    return obb_d2(s.cx, s.cy, s.ux, s.uy, s.hl, 0.0f, qx, qy);
 }
 
 // result of a closest-point query: slot in sorted order + squared distance
@@ -101,15 +103,17 @@ __device__ __forceinline__ void cswap(uint32_t &a, uint32_t &b)
 // Traversal state of one closest-point query on the wide LBVH.
 //
 // A node is addressed as (level, pos): heap index = first(level) + pos with
-// first(L) = (4^L - 1) / 3 = 0x55555555 >> (32 - 2L); its children are (level+1, 4*pos+j).
-// `stack` is the lane's column of the LDS traversal stack: entry i lives at stack[i*stride].
-// A stack entry is ONE 32-bit word: the child's box distance with its 6 low mantissa bits
-// replaced by (level << 2 | j).  The truncated distance is a lower bound of the true one,
-// so stale entries are dropped at pop time without touching memory, and the node position
-// is recovered from the position of the last visited node (which always lies below the
-// entry's parent in a depth-first traversal): parent pos = pos >> 2*(level - entry_level + 1).
+// first(L) = (4^L - 1) / 3 = 0x55555555 >> (32 - 2L); its children are (level+1, 4*pos+j);
+// the children of a node of the last level (level == mesh.levels) are the segment slots
+// 4*pos+j.  `stack` is the lane's column of the LDS traversal stack: entry i lives at
+// stack[i*stride].  A stack entry is ONE 32-bit word: the child's box distance with its 6
+// low mantissa bits replaced by (level << 2 | j).  The truncated distance is a lower bound
+// of the true one, so stale entries are dropped at pop time without touching memory, and
+// the node position is recovered from the position of the last visited node (which always
+// lies below the entry's parent in a depth-first traversal):
+// parent pos = pos >> 2*(level - entry_level + 1).
 struct Trav {
-    int32_t level;      // level of the node to visit next; == mesh.levels means a leaf
+    int32_t level;      // level of the node to visit next
     int32_t pos;        // position of that node inside its level
     int32_t sp;         // stack pointer
     Closest best;       // may start from a valid candidate (temporal hint)
@@ -145,22 +149,13 @@ __device__ __forceinline__ bool trav_pop(Trav &T, const uint32_t *stack, int str
     return false;
 }
 
-// Evaluate the four segments of leaf T.pos.  Ties are broken by the lowest ORIGINAL segment
-// index, so the answer does not depend on the tree layout or the visiting order.
-__device__ __forceinline__ void trav_leaf(const DevMesh &m, float qx, float qy, Trav &T)
+// rare path of a leaf visit: an exact tie between candidates; lowest ORIGINAL index wins
+__device__ __forceinline__ void trav_leaf_ties(const DevMesh &m, Trav &T, int slot0, float e0, float e1, float e2, float e3)
 {
-    const int leaf = T.pos;
-    const float4 *sa = m.segA + 4 * leaf;
-    const float4 a0 = sa[0], a1 = sa[1], a2 = sa[2], a3 = sa[3];
-    const float4 iv = m.segInv[leaf];
-    const float e0 = seg_d2(a0.x, a0.y, a0.z, a0.w, iv.x, qx, qy);
-    const float e1 = seg_d2(a1.x, a1.y, a1.z, a1.w, iv.y, qx, qy);
-    const float e2 = seg_d2(a2.x, a2.y, a2.z, a2.w, iv.z, qx, qy);
-    const float e3 = seg_d2(a3.x, a3.y, a3.z, a3.w, iv.w, qx, qy);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float ek = (k == 0) ? e0 : (k == 1) ? e1 : (k == 2) ? e2 : e3;
-        const int slot = 4 * leaf + k;
+        const int slot = slot0 + k;
         if (ek < T.best.d2) {
             T.best.d2 = ek;
             T.best.slot = slot;
@@ -176,49 +171,61 @@ __device__ __forceinline__ void trav_leaf(const DevMesh &m, float qx, float qy, 
     }
 }
 
-// Expand inner node (T.level, T.pos): test the four child boxes, push the ones that can
-// still tie or win in far-to-near order and step into the nearest.  Returns false when no
-// child qualifies (the caller then pops).
-__device__ __forceinline__ bool trav_inner(const DevMesh &m, float qx, float qy, Trav &T, uint32_t *stack, int stride)
-{
-    const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
-    const float4 *cb = m.boxes + 4 * (size_t)g;
-    const float4 b0 = cb[0], b1 = cb[1], b2 = cb[2], b3 = cb[3];
-    const float d0 = box_d2(b0, qx, qy), d1 = box_d2(b1, qx, qy);
-    const float d2 = box_d2(b2, qx, qy), d3 = box_d2(b3, qx, qy);
-    // the (non-negative) distance orders as an integer; level and child index ride in the low
-    // mantissa bits, so five integer compare-exchanges sort the candidates near-first
-    const float bd = T.best.d2;
-    const uint32_t tag = (uint32_t)(T.level + 1) << 2;
-    uint32_t k0 = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;
-    uint32_t k1 = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3Fu) | tag | 1u) : 0xffffffffu;
-    uint32_t k2 = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3Fu) | tag | 2u) : 0xffffffffu;
-    uint32_t k3 = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3Fu) | tag | 3u) : 0xffffffffu;
-    cswap(k0, k1);
-    cswap(k2, k3);
-    cswap(k0, k2);
-    cswap(k1, k3);
-    cswap(k1, k2);
-    int sp = T.sp;
-    if (k3 != 0xffffffffu) { stack[sp * stride] = k3; ++sp; }
-    if (k2 != 0xffffffffu) { stack[sp * stride] = k2; ++sp; }
-    if (k1 != 0xffffffffu) { stack[sp * stride] = k1; ++sp; }
-    T.sp = sp;
-    if (k0 != 0xffffffffu) {
-        T.pos = 4 * T.pos + (int)(k0 & 3u);
-        T.level += 1;
-        return true;
-    }
-    return false;
-}
-
-// Visit ONE node, then pick the next one.  Returns false when the query is complete.
+// Visit ONE node: measure the four children (oriented boxes, or the segments themselves on
+// the last level -- same arithmetic), then either update the best candidate (last level) or
+// push the children that can still tie or win in far-to-near order and step into the
+// nearest.  Returns false when the query is complete.  Ties between segments are broken by
+// the lowest ORIGINAL index, so the answer does not depend on the tree or the visiting order.
 __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy, Trav &T, uint32_t *stack, int stride)
 {
+    const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
+    const float4 *nd = m.nodes + 6 * (size_t)g;
+    const float4 CX = nd[0], CY = nd[1], UX = nd[2], UY = nd[3], HL = nd[4], HW = nd[5];
+    const float d0 = obb_d2(CX.x, CY.x, UX.x, UY.x, HL.x, HW.x, qx, qy);
+    const float d1 = obb_d2(CX.y, CY.y, UX.y, UY.y, HL.y, HW.y, qx, qy);
+    const float d2 = obb_d2(CX.z, CY.z, UX.z, UY.z, HL.z, HW.z, qx, qy);
+    const float d3 = obb_d2(CX.w, CY.w, UX.w, UY.w, HL.w, HW.w, qx, qy);
+    const float bd = T.best.d2;
     if (T.level == m.levels) {
-        trav_leaf(m, qx, qy, T);
+        // children are segments: exact distances
+        const float mn = fminf(fminf(d0, d1), fminf(d2, d3));
+        if (mn <= bd) {
+            const int slot0 = 4 * T.pos;
+            const int n_eq = (d0 == mn) + (d1 == mn) + (d2 == mn) + (d3 == mn);
+            const int slot = slot0 + ((d0 == mn) ? 0 : (d1 == mn) ? 1 : (d2 == mn) ? 2 : 3);
+            if (n_eq == 1 && mn < bd) {
+                T.best.d2 = mn;
+                T.best.slot = slot;
+                T.best_orig = -1;
+            } else if (n_eq == 1 && slot == T.best.slot) {
+                // the seed segment (temporal hint) met again: nothing to do
+            } else {
+                trav_leaf_ties(m, T, slot0, d0, d1, d2, d3);
+            }
+        }
     } else {
-        if (trav_inner(m, qx, qy, T, stack, stride)) return true;
+        // the (non-negative) distance orders as an integer; level and child index ride in the
+        // low mantissa bits, so five integer compare-exchanges sort the candidates near-first
+        const uint32_t tag = (uint32_t)(T.level + 1) << 2;
+        uint32_t k0 = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;
+        uint32_t k1 = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3Fu) | tag | 1u) : 0xffffffffu;
+        uint32_t k2 = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3Fu) | tag | 2u) : 0xffffffffu;
+        uint32_t k3 = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3Fu) | tag | 3u) : 0xffffffffu;
+        cswap(k0, k1);
+        cswap(k2, k3);
+        cswap(k0, k2);
+        cswap(k1, k3);
+        cswap(k1, k2);
+        int sp = T.sp;
+        if (k3 != 0xffffffffu) { stack[sp * stride] = k3; ++sp; }
+        if (k2 != 0xffffffffu) { stack[sp * stride] = k2; ++sp; }
+        if (k1 != 0xffffffffu) { stack[sp * stride] = k1; ++sp; }
+        T.sp = sp;
+        if (k0 != 0xffffffffu) {
+            T.pos = 4 * T.pos + (int)(k0 & 3u);
+            T.level += 1;
+            return true;
+        }
     }
     return trav_pop(T, stack, stride);
 }
@@ -232,6 +239,13 @@ __device__ __forceinline__ Closest closest_point(const DevMesh &m, float qx, flo
     return T.best;
 }
 
+// distance of q to the segment stored in `slot` (seed of a query: temporal hint)
+__device__ __forceinline__ Closest slot_candidate(const DevMesh &m, int32_t slot, float qx, float qy)
+{
+    const float *nd = reinterpret_cast<const float *>(m.nodes + 6 * (size_t)(m.first_leaf + (slot >> 2))) + (slot & 3);
+    return Closest{obb_d2(nd[0], nd[4], nd[8], nd[12], nd[16], 0.0f, qx, qy), slot};
+}
+
 // Brute-force variant for tiny meshes (wave-uniform loop over the flat records, which the
 // compiler turns into scalar loads).  Returns the ORIGINAL index in .slot.
 __device__ __forceinline__ Closest closest_point_flat(const DevMesh &m, float qx, float qy)
@@ -239,7 +253,7 @@ __device__ __forceinline__ Closest closest_point_flat(const DevMesh &m, float qx
     Closest best{WOST_INF, -1};
     for (int i = 0; i < m.n_segs; ++i) {
         const DevFlatSeg s = m.flat[i];
-        float d = seg_d2(s.ax, s.ay, s.ex, s.ey, s.inv_len2, qx, qy);
+        float d = seg_d2(s, qx, qy);
         if (d < best.d2) {  // ascending i: strict < keeps the lowest index on ties
             best.d2 = d;
             best.slot = i;
@@ -342,7 +356,7 @@ __device__ __forceinline__ int sample_in_sphere_flat(const DevMesh &m, float qx,
     float total = 0.0f;
     for (int i = 0; i < m.n_segs; ++i) {
         const DevFlatSeg s = m.flat[i];
-        float d2 = seg_d2(s.ax, s.ay, s.ex, s.ey, s.inv_len2, qx, qy);
+        float d2 = seg_d2(s, qx, qy);
         if (d2 <= R2 && s.len > 0.0f) total += s.len;
     }
     pdf = 0.0f;
@@ -353,7 +367,7 @@ __device__ __forceinline__ int sample_in_sphere_flat(const DevMesh &m, float qx,
     bool done = false;
     for (int i = 0; i < m.n_segs; ++i) {
         const DevFlatSeg s = m.flat[i];
-        float d2 = seg_d2(s.ax, s.ay, s.ex, s.ey, s.inv_len2, qx, qy);
+        float d2 = seg_d2(s, qx, qy);
         if (!done && d2 <= R2 && s.len > 0.0f) {
             cum += s.len;
             last = i;

@@ -66,7 +66,7 @@ struct RoundParams {
     StatsDev *stats;
     int32_t steps_per_round;
     int32_t stack_stride;  // = blockDim.x
-    int32_t wait_weight;   // step phase runs when n_wait * wait_weight >= 8 * max(n_inner, n_leaf)
+    int32_t wait_weight;   // step phase runs when n_wait * wait_weight >= 8 * n_trav
 };
 
 struct InitParams {
@@ -88,13 +88,6 @@ struct InitParams {
 #define META_DEPTH(m) (((m) >> 20) & 0x3ffu)
 #define META_ONN(m) (((m) >> 30) & 1u)
 #define META_PACK(s, d, n) ((uint32_t)(s) | ((uint32_t)(d) << 20) | ((uint32_t)(n) << 30))
-
-__device__ __forceinline__ Closest hint_candidate(const DevMesh &m, int32_t slot, float qx, float qy)
-{
-    float4 a = m.segA[slot];
-    float inv = reinterpret_cast<const float *>(m.segInv)[slot];
-    return Closest{seg_d2(a.x, a.y, a.z, a.w, inv, qx, qy), slot};
-}
 
 // ------------------------------------------------------------------------------------------
 // init: seed every owned pixel, cache its depth-0 closest point, compact into the queue
@@ -123,7 +116,7 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams P)
     if (active) {
         eval_point(P.probe, x, y, P.st.width, P.st.height, x0, y0);
         pcg_seed_pixel(rng, pid, P.st.width);
-        if (P.dm.n_segs > 0) c0 = closest_point(P.dm, x0, y0, hint_candidate(P.dm, 0, x0, y0), stack, P.stack_stride);
+        if (P.dm.n_segs > 0) c0 = closest_point(P.dm, x0, y0, slot_candidate(P.dm, 0, x0, y0), stack, P.stack_stride);
     }
     // wave-level compaction: one atomic per wave
     const unsigned long long bal = __ballot(active);
@@ -188,7 +181,7 @@ __device__ __forceinline__ bool step_finish(const RoundParams &P, Lane &L, LaneS
     if (has_d) {
         L.hint = cp.slot;
         const float4 a = dm.segA[cp.slot];
-        const float inv = reinterpret_cast<const float *>(dm.segInv)[cp.slot];
+        const float inv = dm.segInv[cp.slot];
         const float wx = px - a.x, wy = py - a.y;
         const float uv = dot2(wx, wy, a.z, a.w) * inv;       // computeProjectionRatio
         const float cr = cross2(a.z, a.w, wx, wy);           // checkPointSide
@@ -333,21 +326,20 @@ __global__ __launch_bounds__(256) void walk_round_kernel(RoundParams P)
     // Per-lane state machine.  A lane either has an INNER node or a LEAF of the LBVH to visit
     // for its current walk position, WAITs with a finished query for the step logic, or is DONE
     // for this round.  Query lengths differ wildly between lanes, so instead of running every
-    // lane's query to completion in lock step, each trip of the loop runs ONE of the three
-    // bodies -- the one most lanes of the wave are ready for -- and the others accumulate.
-    enum { MODE_START = 0, MODE_INNER = 1, MODE_LEAF = 2, MODE_WAIT = 3, MODE_DONE = 4 };
+    // lane's query to completion in lock step, each trip of the loop runs ONE of two bodies
+    // -- "visit one node" or "finish a step and start the next query" -- whichever more lanes
+    // of the wave are ready for (weighted), while the lanes of the other kind accumulate.
+    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4 };
     const bool has_d = P.dm.n_segs > 0;
-    const int levels = P.dm.levels;
     int mode = alive ? MODE_WAIT : MODE_DONE;
     bool fresh = true;   // first trip: no finished step yet, only start the query
     int budget = P.steps_per_round;
     Trav T = trav_begin(Closest{WOST_INF, -1});
     for (;;) {
-        const int n_inner = __popcll(__ballot(mode == MODE_INNER));
-        const int n_leaf = __popcll(__ballot(mode == MODE_LEAF));
+        const int n_trav = __popcll(__ballot(mode == MODE_TRAV));
         const int n_wait = __popcll(__ballot(mode == MODE_WAIT));
-        if (n_inner + n_leaf + n_wait == 0) break;
-        if (n_wait * P.wait_weight >= max(n_inner, n_leaf) * 8) {
+        if (n_trav + n_wait == 0) break;
+        if (n_wait * P.wait_weight >= n_trav * 8) {
             // ---- step phase ----
             if (mode == MODE_WAIT) {
                 if (!fresh) {
@@ -373,26 +365,18 @@ __global__ __launch_bounds__(256) void walk_round_kernel(RoundParams P)
                         T.best = Closest{L.d0_d2, L.d0_slot};
                         mode = MODE_WAIT;
                     } else {
-                        T = trav_begin(hint_candidate(P.dm, L.hint, L.px, L.py));
-                        mode = MODE_INNER;  // the root is an inner node (levels >= 1)
+                        T = trav_begin(slot_candidate(P.dm, L.hint, L.px, L.py));
+                        mode = MODE_TRAV;
                     }
                 } else {
                     mode = MODE_DONE;
                 }
             }
-        } else if (n_inner >= n_leaf) {
-            if (mode == MODE_INNER) {
-                S.inner_visits++;
-                bool more = trav_inner(P.dm, L.px, L.py, T, stack, P.stack_stride);
-                if (!more) more = trav_pop(T, stack, P.stack_stride);
-                mode = !more ? MODE_WAIT : (T.level == levels ? MODE_LEAF : MODE_INNER);
-            }
         } else {
-            if (mode == MODE_LEAF) {
-                S.leaf_visits++;
-                trav_leaf(P.dm, L.px, L.py, T);
-                const bool more = trav_pop(T, stack, P.stack_stride);
-                mode = !more ? MODE_WAIT : (T.level == levels ? MODE_LEAF : MODE_INNER);
+            // ---- traversal phase: every traversing lane visits one node ----
+            if (mode == MODE_TRAV) {
+                if (T.level == P.dm.levels) S.leaf_visits++; else S.inner_visits++;
+                if (!trav_visit(P.dm, L.px, L.py, T, stack, P.stack_stride)) mode = MODE_WAIT;
             }
         }
     }
@@ -454,9 +438,9 @@ __global__ __launch_bounds__(256) void closest_point_kernel(DevMesh m, const flo
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float qx = pts[2 * i], qy = pts[2 * i + 1];
-    const Closest c = closest_point(m, qx, qy, hint_candidate(m, 0, qx, qy), stack, stack_stride);
+    const Closest c = closest_point(m, qx, qy, slot_candidate(m, 0, qx, qy), stack, stack_stride);
     const float4 a = m.segA[c.slot];
-    const float inv = reinterpret_cast<const float *>(m.segInv)[c.slot];
+    const float inv = m.segInv[c.slot];
     const float wx = qx - a.x, wy = qy - a.y;
     const float cr = cross2(a.z, a.w, wx, wy);
     if (out_idx) out_idx[i] = m.segOrig[c.slot];
@@ -477,7 +461,7 @@ __global__ __launch_bounds__(256) void sdf_kernel(DevMesh m, DevProbe probe, int
     float d = WOST_INF;
     if (m.n_segs > 0) {
         if (which == WOST_MESH_DIRICHLET) {
-            d = sqrtf(closest_point(m, x, y, hint_candidate(m, 0, x, y), stack, stack_stride).d2);
+            d = sqrtf(closest_point(m, x, y, slot_candidate(m, 0, x, y), stack, stack_stride).d2);
         } else {
             d = closest_silhouette_flat(m, x, y, WOST_INF);
         }
@@ -567,9 +551,9 @@ static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
     v.emissive = 0;
     for (float c : t.flatCol)
         if (c != 0.0f) v.emissive = 1;
-    HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(t.boxes.data()), t.boxes.size() / 4, &v.boxes));
+    HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(t.nodes.data()), t.nodes.size() / 4, &v.nodes));
     HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(t.segA.data()), t.segA.size() / 4, &v.segA));
-    HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(t.segInv.data()), t.segInv.size() / 4, &v.segInv));
+    HIP_TRY(upload(s.allocs, t.segInv.data(), t.segInv.size(), &v.segInv));
     HIP_TRY(upload(s.allocs, t.segOrig.data(), t.segOrig.size(), &v.segOrig));
     HIP_TRY(upload(s.allocs, t.segCol.data(), t.segCol.size(), &v.segCol));
     HIP_TRY(upload(s.allocs, reinterpret_cast<const DevFlatSeg *>(t.flat.data()), t.flat.size(), &v.flat));
@@ -752,7 +736,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     HIP_TRY(hipSetDevice(c->device));
     const int bs = c->block_size;
     const int levels = c->dm.view.n_segs > 0 ? c->dm.view.levels : 1;
-    const int stack_depth = 3 * levels + 2;
+    const int stack_depth = 3 * (levels + 1) + 1;
     const size_t lds = (size_t)stack_depth * bs * sizeof(uint32_t);
     HIP_TRY(hipMemsetAsync(c->counts, 0, 2 * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(StatsDev), stream));
@@ -912,7 +896,7 @@ int wost_render_sdf(wost_handle h, int which_mesh, float *out_dist)
     HIP_TRY(hipSetDevice(h->device));
     const int bs = 256;
     const int levels = m->view.n_segs > 0 ? m->view.levels : 1;
-    const size_t lds = (size_t)(3 * levels + 2) * bs * sizeof(uint32_t);
+    const size_t lds = (size_t)(3 * (levels + 1) + 1) * bs * sizeof(uint32_t);
     const int n = (int)h->n_pixels;
     float *d_out = h->field;  // reuse: n_pixels floats fit in the field buffer
     hipLaunchKernelGGL(sdf_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, h->probe,
@@ -941,7 +925,7 @@ int wost_closest_point(wost_handle h, int which_mesh, const float *pts, int32_t 
     HIP_TRY(s.alloc(&d_side, n));
     HIP_TRY(hipMemcpyAsync(d_pts, pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
     const int bs = 256;
-    const size_t lds = (size_t)(3 * m->view.levels + 2) * bs * sizeof(uint32_t);
+    const size_t lds = (size_t)(3 * (m->view.levels + 1) + 1) * bs * sizeof(uint32_t);
     hipLaunchKernelGGL(closest_point_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, d_pts, n,
                        d_idx, d_dist, d_uv, d_side, bs);
     HIP_TRY(hipGetLastError());

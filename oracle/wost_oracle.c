@@ -224,6 +224,7 @@ void wo_eval_point(const wo_scene *sc, int px, int py, int width, int height,
 /* ------------------------------------------------------------------------ */
 typedef struct {
     float ax, ay, ex, ey, inv_len2, len, nx, ny;
+    float cx, cy, ux, uy, hl;   /* centre, unit axis, half length (distance form) */
     int i0, i1;
 } pseg;
 
@@ -260,6 +261,11 @@ static void seg_prepare(pseg *s, const float *verts, int i0, int i1)
     /* unit normal (e.y, -e.x)/|e|: outward for a CCW polygon (FCPW convention) */
     if (s->len > 0.0f) { s->nx = s->ey / s->len; s->ny = -s->ex / s->len; }
     else { s->nx = 0.0f; s->ny = 0.0f; }
+    /* distance form (DESIGN.md "segment distance"): centre, unit axis, half length */
+    s->cx = fmaf(0.5f, s->ex, s->ax); s->cy = fmaf(0.5f, s->ey, s->ay);
+    if (s->len > 0.0f) { s->ux = s->ex / s->len; s->uy = s->ey / s->len; }
+    else { s->ux = 1.0f; s->uy = 0.0f; }
+    s->hl = 0.5f * s->len;
 }
 
 /* ---- BVH build (median split; layout does not influence results) -------- */
@@ -349,13 +355,15 @@ static int pmesh_prepare(pmesh *m, const wo_mesh *in)
  *      distance_calculator at integrator.cu:138) ---------------------------- */
 static inline void seg_closest(const pseg *s, float qx, float qy, float *d2, float *t_raw)
 {
-    float wx = qx - s->ax, wy = qy - s->ay;
-    float tr = wo_dot2(wx, wy, s->ex, s->ey) * s->inv_len2;
-    float t = fminf(fmaxf(tr, 0.0f), 1.0f);
-    float cx = fmaf(t, s->ex, s->ax), cy = fmaf(t, s->ey, s->ay);
-    float dx = qx - cx, dy = qy - cy;
-    *d2 = wo_dot2(dx, dy, dx, dy);
-    *t_raw = tr;
+    /* squared distance in the segment's own frame: u along the axis, v across it */
+    float wx = qx - s->cx, wy = qy - s->cy;
+    float u = wo_dot2(wx, wy, s->ux, s->uy);
+    float v = wo_cross2(s->ux, s->uy, wx, wy);
+    float du = fmaxf(fabsf(u) - s->hl, 0.0f);
+    float dv = fabsf(v);
+    *d2 = wo_dot2(du, dv, du, dv);
+    /* unclamped projection ratio along p0 -> p1 (lbvh::computeProjectionRatio) */
+    *t_raw = wo_dot2(qx - s->ax, qy - s->ay, s->ex, s->ey) * s->inv_len2;
 }
 
 typedef struct { int idx; float d2; } cp_result;
