@@ -58,6 +58,8 @@ class Stats(C.Structure):
         ("neumann_hits", C.c_uint64),
         ("inner_visits", C.c_uint64),
         ("leaf_visits", C.c_uint64),
+        ("trav_trips", C.c_uint64),
+        ("step_trips", C.c_uint64),
         ("solve_ms", C.c_double),
         ("kernel_ms", C.c_double),
         ("kernel_launches", C.c_uint32),
@@ -78,7 +80,8 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB_PATH
+    # WOST_LIB: developer override to A/B alternative builds of the same C-ABI
+    return os.environ.get("WOST_LIB", _build.LIB_PATH)
 
 
 def load():

@@ -111,11 +111,12 @@ __device__ __forceinline__ void cswap(uint32_t &a, uint32_t &b)
 // of the true one, so stale entries are dropped at pop time without touching memory, and
 // the node position is recovered from the position of the last visited node (which always
 // lies below the entry's parent in a depth-first traversal):
-// parent pos = pos >> 2*(level - entry_level + 1).
+// parent pos = pos >> 2*(level - entry_level + 1).  Stack pointers are byte offsets and
+// the stride between entries of one lane is passed in bytes (no multiplies on push/pop).
 struct Trav {
     int32_t level;      // level of the node to visit next
     int32_t pos;        // position of that node inside its level
-    int32_t sp;         // stack pointer
+    int32_t sp;         // stack pointer as a BYTE offset into the lane's column (0 = empty)
     Closest best;       // may start from a valid candidate (temporal hint)
     int32_t best_orig;  // original index of best.slot, loaded lazily when an exact tie shows up
 };
@@ -132,11 +133,11 @@ __device__ __forceinline__ uint32_t level_first(int level)
 
 // Pop the next entry that can still tie or beat the current best.  Returns false when the
 // stack is exhausted (query complete).
-__device__ __forceinline__ bool trav_pop(Trav &T, const uint32_t *stack, int stride)
+__device__ __forceinline__ bool trav_pop(Trav &T, const uint32_t *stack, int stride_bytes)
 {
     while (T.sp > 0) {
-        --T.sp;
-        const uint32_t key = stack[T.sp * stride];
+        T.sp -= stride_bytes;
+        const uint32_t key = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(stack) + T.sp);
         const float dlb = __uint_as_float(key & ~0x3Fu);
         if (dlb <= T.best.d2) {
             const int el = (int)((key >> 2) & 15u);
@@ -176,11 +177,23 @@ __device__ __forceinline__ void trav_leaf_ties(const DevMesh &m, Trav &T, int sl
 // push the children that can still tie or win in far-to-near order and step into the
 // nearest.  Returns false when the query is complete.  Ties between segments are broken by
 // the lowest ORIGINAL index, so the answer does not depend on the tree or the visiting order.
-__device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy, Trav &T, uint32_t *stack, int stride)
+// `top` (optional) is an LDS copy of the nodes of the levels < top_levels: every query
+// starts there, and the per-CU vector L1 -- six 16-byte gathers per lane and visit -- is the
+// scarce resource of this kernel, so the top of the tree is served from LDS instead.
+template <bool USE_TOP = false>
+__device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy, Trav &T, uint32_t *stack, int stride_bytes,
+                                           const float4 *top = nullptr, int top_levels = 0)
 {
     const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
-    const float4 *nd = m.nodes + 6 * (size_t)g;
-    const float4 CX = nd[0], CY = nd[1], UX = nd[2], UY = nd[3], HL = nd[4], HW = nd[5];
+    float4 CX, CY, UX, UY, HL, HW;
+    if (USE_TOP && T.level < top_levels) {
+        const float4 *nd = top + 6 * g;
+        CX = nd[0]; CY = nd[1]; UX = nd[2]; UY = nd[3]; HL = nd[4]; HW = nd[5];
+    } else {
+        // 96-byte nodes; a 24-bit multiply is full rate and the byte offset stays below 4 GiB
+        const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+        CX = nd[0]; CY = nd[1]; UX = nd[2]; UY = nd[3]; HL = nd[4]; HW = nd[5];
+    }
     const float d0 = obb_d2(CX.x, CY.x, UX.x, UY.x, HL.x, HW.x, qx, qy);
     const float d1 = obb_d2(CX.y, CY.y, UX.y, UY.y, HL.y, HW.y, qx, qy);
     const float d2 = obb_d2(CX.z, CY.z, UX.z, UY.z, HL.z, HW.z, qx, qy);
@@ -216,10 +229,17 @@ __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy,
         cswap(k0, k2);
         cswap(k1, k3);
         cswap(k1, k2);
+        // branch-free pushes: sorted keys keep the invalid ones (0xffffffff) last, i.e. first
+        // in far-to-near push order; an invalid key is written but the pointer does not move,
+        // so the next write lands on top of it (the column has three words of slack)
+        char *col = reinterpret_cast<char *>(stack);
         int sp = T.sp;
-        if (k3 != 0xffffffffu) { stack[sp * stride] = k3; ++sp; }
-        if (k2 != 0xffffffffu) { stack[sp * stride] = k2; ++sp; }
-        if (k1 != 0xffffffffu) { stack[sp * stride] = k1; ++sp; }
+        *reinterpret_cast<uint32_t *>(col + sp) = k3;
+        sp += (k3 != 0xffffffffu) ? stride_bytes : 0;
+        *reinterpret_cast<uint32_t *>(col + sp) = k2;
+        sp += (k2 != 0xffffffffu) ? stride_bytes : 0;
+        *reinterpret_cast<uint32_t *>(col + sp) = k1;
+        sp += (k1 != 0xffffffffu) ? stride_bytes : 0;
         T.sp = sp;
         if (k0 != 0xffffffffu) {
             T.pos = 4 * T.pos + (int)(k0 & 3u);
@@ -227,14 +247,15 @@ __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy,
             return true;
         }
     }
-    return trav_pop(T, stack, stride);
+    return trav_pop(T, stack, stride_bytes);
 }
 
 __device__ __forceinline__ Closest closest_point(const DevMesh &m, float qx, float qy, Closest seed,
                                                  uint32_t *stack, int stride)
 {
     Trav T = trav_begin(seed);
-    while (trav_visit(m, qx, qy, T, stack, stride)) {
+    const int stride_bytes = stride * 4;
+    while (trav_visit(m, qx, qy, T, stack, stride_bytes)) {
     }
     return T.best;
 }

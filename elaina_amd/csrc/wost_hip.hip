@@ -51,7 +51,7 @@ struct WalkQueue {
 static const int kQueueWords = 16 + 1;  // rng counts twice
 
 struct StatsDev {
-    unsigned long long steps, started, absorbed, truncated, nhits, inner_visits, leaf_visits;
+    unsigned long long steps, started, absorbed, truncated, nhits, inner_visits, leaf_visits, trav_trips, step_trips;
 };
 
 struct RoundParams {
@@ -67,6 +67,8 @@ struct RoundParams {
     int32_t steps_per_round;
     int32_t stack_stride;  // = blockDim.x
     int32_t wait_weight;   // step phase runs when n_wait * wait_weight >= 8 * n_trav
+    int32_t top_levels;    // levels of the Dirichlet tree mirrored in LDS
+    int32_t top_nodes;     // (4^top_levels - 1) / 3
 };
 
 struct InitParams {
@@ -207,8 +209,14 @@ __device__ __forceinline__ bool step_finish(const RoundParams &P, Lane &L, LaneS
 
     // ---- sampleNeumann -------------------------------------------------------------------
     if (has_n) {
-        const float u0 = pcg_next_float(L.rng);
-        const float u1 = pcg_next_float(L.rng);
+        // the two draws happen whether or not the boundary emits (reference :343-347)
+        float u0 = 0.0f, u1 = 0.0f;
+        if (NEUMANN_EMISSIVE) {
+            u0 = pcg_next_float(L.rng);
+            u1 = pcg_next_float(L.rng);
+        } else {
+            pcg_skip2(L.rng);
+        }
         if (NEUMANN_EMISSIVE) {
             float pdf;
             const int oi = sample_in_sphere_flat(nm, px, py, R_B, u0, pdf);
@@ -285,7 +293,9 @@ __device__ __forceinline__ bool step_finish(const RoundParams &P, Lane &L, LaneS
             S.nhits++;
         }
     }
-    L.thp = L.thp / pdf / alpha / WOST_2PI;
+    // 1/pdf/alpha/2pi is exactly 1.0f in fp32 for both branches (tests/test_oracle_units.py),
+    // so a unit throughput stays a unit throughput without three IEEE divisions
+    if (L.thp != 1.0f) L.thp = L.thp / pdf / alpha / WOST_2PI;
     L.px = nxt_x; L.py = nxt_y;
     L.on_n = hit; L.nx = hnx; L.ny = hny;
     L.depth++;
@@ -297,10 +307,17 @@ __device__ __forceinline__ bool step_finish(const RoundParams &P, Lane &L, LaneS
 }
 
 template <bool NEUMANN_EMISSIVE>
-__global__ __launch_bounds__(256) void walk_round_kernel(RoundParams P)
+__global__ __launch_bounds__(256, 6) void walk_round_kernel(RoundParams P)
 {
     extern __shared__ uint32_t lds_stack[];
-    uint32_t *stack = lds_stack + threadIdx.x;
+    // LDS: [top of the tree: top_nodes * 6 float4][traversal stack columns]
+    const float4 *lds_top = reinterpret_cast<const float4 *>(lds_stack);
+    {
+        float4 *dst = reinterpret_cast<float4 *>(lds_stack);
+        for (int i = threadIdx.x; i < P.top_nodes * 6; i += blockDim.x) dst[i] = P.dm.nodes[i];
+        __syncthreads();
+    }
+    uint32_t *stack = lds_stack + P.top_nodes * 24 + threadIdx.x;
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_in = *P.count_in;
     const bool valid = slot < n_in;
@@ -335,11 +352,14 @@ __global__ __launch_bounds__(256) void walk_round_kernel(RoundParams P)
     bool fresh = true;   // first trip: no finished step yet, only start the query
     int budget = P.steps_per_round;
     Trav T = trav_begin(Closest{WOST_INF, -1});
+    uint32_t trav_trips = 0, step_trips = 0;   // wave-uniform: scheduler diagnostics
+    const int stride_bytes = P.stack_stride * 4;
     for (;;) {
         const int n_trav = __popcll(__ballot(mode == MODE_TRAV));
         const int n_wait = __popcll(__ballot(mode == MODE_WAIT));
         if (n_trav + n_wait == 0) break;
         if (n_wait * P.wait_weight >= n_trav * 8) {
+            ++step_trips;
             // ---- step phase ----
             if (mode == MODE_WAIT) {
                 if (!fresh) {
@@ -374,9 +394,10 @@ __global__ __launch_bounds__(256) void walk_round_kernel(RoundParams P)
             }
         } else {
             // ---- traversal phase: every traversing lane visits one node ----
+            ++trav_trips;
             if (mode == MODE_TRAV) {
                 if (T.level == P.dm.levels) S.leaf_visits++; else S.inner_visits++;
-                if (!trav_visit(P.dm, L.px, L.py, T, stack, P.stack_stride)) mode = MODE_WAIT;
+                if (!trav_visit<true>(P.dm, L.px, L.py, T, stack, stride_bytes, lds_top, P.top_levels)) mode = MODE_WAIT;
             }
         }
     }
@@ -423,6 +444,8 @@ __global__ __launch_bounds__(256) void walk_round_kernel(RoundParams P)
         if (v[4]) atomicAdd(&P.stats->nhits, (unsigned long long)v[4]);
         if (v[5]) atomicAdd(&P.stats->inner_visits, (unsigned long long)v[5]);
         if (v[6]) atomicAdd(&P.stats->leaf_visits, (unsigned long long)v[6]);
+        atomicAdd(&P.stats->trav_trips, (unsigned long long)trav_trips);
+        atomicAdd(&P.stats->step_trips, (unsigned long long)step_trips);
     }
 }
 
@@ -590,6 +613,7 @@ struct wost_context {
     int steps_per_round = 64;
     int block_size = 256;
     int wait_weight = 8;
+    int top_levels = 3;
     int time_kernels = 1;
 };
 
@@ -718,6 +742,9 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "wait_weight") {
         if (value < 1 || value > 512) return fail(WOST_ERR_INVALID, "wait_weight must be in 1..512");
         h->wait_weight = (int)value;
+    } else if (k == "top_levels") {
+        if (value < 0 || value > 6) return fail(WOST_ERR_INVALID, "top_levels must be in 0..6");
+        h->top_levels = (int)value;
     } else if (k == "time_kernels") {
         h->time_kernels = value != 0;
     } else {
@@ -736,7 +763,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     HIP_TRY(hipSetDevice(c->device));
     const int bs = c->block_size;
     const int levels = c->dm.view.n_segs > 0 ? c->dm.view.levels : 1;
-    const int stack_depth = 3 * (levels + 1) + 1;
+    const int stack_depth = 3 * (levels + 1) + 4;
     const size_t lds = (size_t)stack_depth * bs * sizeof(uint32_t);
     HIP_TRY(hipMemsetAsync(c->counts, 0, 2 * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(StatsDev), stream));
@@ -788,12 +815,17 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         rp.steps_per_round = c->steps_per_round;
         rp.stack_stride = bs;
         rp.wait_weight = c->wait_weight;
+        rp.top_levels = std::min(c->top_levels, levels + 1);
+        if (c->dm.view.n_segs == 0) rp.top_levels = 0;
+        rp.top_nodes = 0;
+        for (int l = 0, n = 1; l < rp.top_levels; ++l, n *= 4) rp.top_nodes += n;
+        const size_t lds_round = lds + (size_t)rp.top_nodes * 96;
         const unsigned grid = (n_active + bs - 1) / bs;
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
         if (emissive)
-            hipLaunchKernelGGL(walk_round_kernel<true>, dim3(grid), dim3(bs), lds, stream, rp);
+            hipLaunchKernelGGL(walk_round_kernel<true>, dim3(grid), dim3(bs), lds_round, stream, rp);
         else
-            hipLaunchKernelGGL(walk_round_kernel<false>, dim3(grid), dim3(bs), lds, stream, rp);
+            hipLaunchKernelGGL(walk_round_kernel<false>, dim3(grid), dim3(bs), lds_round, stream, rp);
         HIP_TRY(hipGetLastError());
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev1, stream));
         HIP_TRY(hipMemcpyAsync(c->host_count, c->counts + nxt, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -819,6 +851,8 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         stats->neumann_hits = sd.nhits;
         stats->inner_visits = sd.inner_visits;
         stats->leaf_visits = sd.leaf_visits;
+        stats->trav_trips = sd.trav_trips;
+        stats->step_trips = sd.step_trips;
         stats->kernel_ms = kernel_ms;
         stats->kernel_launches = launches;
         stats->reserved = 0;
@@ -896,7 +930,7 @@ int wost_render_sdf(wost_handle h, int which_mesh, float *out_dist)
     HIP_TRY(hipSetDevice(h->device));
     const int bs = 256;
     const int levels = m->view.n_segs > 0 ? m->view.levels : 1;
-    const size_t lds = (size_t)(3 * (levels + 1) + 1) * bs * sizeof(uint32_t);
+    const size_t lds = (size_t)(3 * (levels + 1) + 4) * bs * sizeof(uint32_t);
     const int n = (int)h->n_pixels;
     float *d_out = h->field;  // reuse: n_pixels floats fit in the field buffer
     hipLaunchKernelGGL(sdf_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, h->probe,
@@ -925,7 +959,7 @@ int wost_closest_point(wost_handle h, int which_mesh, const float *pts, int32_t 
     HIP_TRY(s.alloc(&d_side, n));
     HIP_TRY(hipMemcpyAsync(d_pts, pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
     const int bs = 256;
-    const size_t lds = (size_t)(3 * (m->view.levels + 1) + 1) * bs * sizeof(uint32_t);
+    const size_t lds = (size_t)(3 * (m->view.levels + 1) + 4) * bs * sizeof(uint32_t);
     hipLaunchKernelGGL(closest_point_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, d_pts, n,
                        d_idx, d_dist, d_uv, d_side, bs);
     HIP_TRY(hipGetLastError());

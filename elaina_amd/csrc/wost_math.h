@@ -37,6 +37,14 @@ __device__ __forceinline__ uint32_t pcg_next_uint(Pcg &r)
     return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
 }
 
+// two draws whose values are not needed: one LCG jump (x -> M^2 x + (M + 1) inc), which
+// leaves the generator in exactly the state two pcg_next_uint() calls would
+__device__ __forceinline__ void pcg_skip2(Pcg &r)
+{
+    const uint64_t m2 = WOST_PCG32_MULT * WOST_PCG32_MULT;
+    r.state = r.state * m2 + (WOST_PCG32_MULT + 1ull) * r.inc;
+}
+
 __device__ __forceinline__ float pcg_next_float(Pcg &r)
 {
     return __uint_as_float((pcg_next_uint(r) >> 9) | 0x3f800000u) - 1.0f;

@@ -78,6 +78,8 @@ typedef struct wost_stats {
     uint64_t neumann_hits;     /* steps that landed on the Neumann boundary                   */
     uint64_t inner_visits;     /* LBVH inner nodes expanded by the walk's closest-point queries */
     uint64_t leaf_visits;      /* LBVH leaves (4 segments each) evaluated by those queries    */
+    uint64_t trav_trips;       /* wave-level scheduler diagnostics: traversal-phase trips ...  */
+    uint64_t step_trips;       /* ... and step-phase trips, summed over waves                 */
     double solve_ms;           /* host wall time of the call, like UniformIntegrator::solve() */
     double kernel_ms;          /* sum of HIP-event durations of the walk kernel launches      */
     uint32_t kernel_launches;  /* number of walk-kernel launches (rounds)                     */

@@ -187,3 +187,27 @@ def test_eval_point_matches_survey_formula(oracle, ladybug):
         oracle.lib.wo_eval_point(C.byref(sc), px, py, 1024, 1024, C.byref(x), C.byref(y))
         ndcx, ndcy = 2 * px / 1024 - 1, 2 * py / 1024 - 1
         assert abs(x.value - (250 - 250 * ndcy)) < 1e-3 and abs(y.value - (250 + 250 * ndcx)) < 1e-3
+
+
+def test_unit_throughput_identity():
+    # thp' = thp / pdf / alpha / 2pi (integrator.cu:521) is exactly 1.0f for
+    # thp = 1 on both branches of the uniform path, with the constants of krrmath/constants.h
+    # and M_PI taken from <cmath> as a double.  The HIP kernel relies on this identity.
+    f = np.float32
+    two_pi = f(6.28318530717958647693)
+    sphere_pdf = f(1.0) / two_pi
+    hemi_pdf = f(np.float64(1.0) / np.float64(3.14159265358979323846))
+    assert f(f(f(1.0) / sphere_pdf) / f(1.0)) / two_pi == f(1.0)
+    assert f(f(f(1.0) / hemi_pdf) / f(0.5)) / two_pi == f(1.0)
+
+
+def test_pcg_skip2_constants(oracle):
+    # two discarded draws == one LCG jump x -> M^2 x + (M+1) inc (used by the HIP kernel when
+    # the Neumann boundary does not emit)
+    M = 0x5851F42D4C957F2D
+    mask = (1 << 64) - 1
+    r = oracle.pcg_seed(123, 0)
+    s0, inc = r.state, r.inc
+    oracle.pcg_uint(r)
+    oracle.pcg_uint(r)
+    assert r.state == ((s0 * ((M * M) & mask)) + ((M + 1) & mask) * inc) & mask

@@ -33,6 +33,10 @@ def main():
             dict(zip(keys, combo)), best["solve_ms"], best["kernel_ms"], best["kernel_launches"],
             best["walk_steps"] / best["solve_ms"] * 1e3, best["inner_visits"] / best["walk_steps"],
             best["leaf_visits"] / best["walk_steps"]), flush=True)
+        vis = best["inner_visits"] + best["leaf_visits"]
+        print("     lane utilisation: traversal phase %.3f (trips %d) step phase %.3f (trips %d)" % (
+            vis / (64.0 * max(best["trav_trips"], 1)), best["trav_trips"],
+            best["walk_steps"] / (64.0 * max(best["step_trips"], 1)), best["step_trips"]), flush=True)
     it.close()
 
 
