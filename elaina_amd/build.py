@@ -49,5 +49,29 @@ def build_library(force=False, verbose=False):
     return LIB_PATH
 
 
+HOST_DIR = os.path.join(_HERE, "host")
+HOST_SOURCES = ["main.cpp", "exec.cpp", os.path.join("core", "problem.cpp"),
+                os.path.join("integrator", "uniform", "integrator.cpp"), os.path.join("util", "json.cpp")]
+
+
+def build_host(force=False, verbose=False):
+    """elaina-exec: the C++ host mirror of the reference's entry point, linked against
+    libwost_hip.so (rpath = $ORIGIN, both live in elaina_amd/lib)."""
+    build_library(force=force, verbose=verbose)
+    srcs = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
+    deps = list(srcs)
+    for root, _, files in os.walk(HOST_DIR):
+        deps += [os.path.join(root, f) for f in files if f.endswith(".h")]
+    deps.append(LIB_PATH)
+    if force or _stale(HOST_EXE, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", HOST_DIR] + srcs + [
+            "-L", LIB_DIR, "-lwost_hip", "-Wl,-rpath,$ORIGIN", "-o", HOST_EXE]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOST_EXE
+
+
 if __name__ == "__main__":
+    print(build_host(force=True, verbose=True))
     print(build_library(force=True, verbose=True))

@@ -1,0 +1,212 @@
+#include "problem.h"
+
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace elaina {
+
+// ---- common.h helpers ---------------------------------------------------------------------
+bool parse_channel(const string &n, ExportImageChannel *out)
+{
+    if (n == "DIRICHLET_SDF") *out = ExportImageChannel::DIRICHLET_SDF;
+    else if (n == "NEUMANN_SDF") *out = ExportImageChannel::NEUMANN_SDF;
+    else if (n == "SOURCE") *out = ExportImageChannel::SOURCE;
+    else if (n == "SOLUTION") *out = ExportImageChannel::SOLUTION;
+    else return false;
+    return true;
+}
+
+bool parse_tone(const string &n, ToneMapping *out)
+{
+    if (n == "NONE") *out = ToneMapping::NONE;
+    else if (n == "NONE_NORMALIZED") *out = ToneMapping::NONE_NORMALIZED;
+    else if (n == "MATLAB_JET") *out = ToneMapping::MATLAB_JET;
+    else if (n == "MATLAB_PARULA") *out = ToneMapping::MATLAB_PARULA;
+    else if (n == "IDL_RDBU") *out = ToneMapping::IDL_RDBU;
+    else return false;
+    return true;
+}
+
+const char *channel_name(ExportImageChannel c)
+{
+    switch (c) {
+    case ExportImageChannel::DIRICHLET_SDF: return "DIRICHLET_SDF";
+    case ExportImageChannel::NEUMANN_SDF: return "NEUMANN_SDF";
+    case ExportImageChannel::SOURCE: return "SOURCE";
+    case ExportImageChannel::SOLUTION: return "SOLUTION";
+    default: return "?";
+    }
+}
+
+void log_message(LogLevel level, const char *fmt, ...)
+{
+    static const char *tag[] = {"[debug] ", "[info] ", "[ok] ", "[warning] ", "[error] "};
+    std::fputs(tag[(int)level], stderr);
+    va_list ap;
+    va_start(ap, fmt);
+    std::vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    std::fputc('\n', stderr);
+}
+
+// ---- OBJ polylines -------------------------------------------------------------------------
+SceneLoader2::SceneLoader2(const string &path)
+{
+    std::ifstream f(path);
+    if (!f.is_open()) throw std::runtime_error("Failed to open model file: " + path);
+    string line;
+    while (std::getline(f, line)) {
+        const char *p = line.c_str();
+        while (*p == ' ' || *p == '\t') ++p;
+        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+            char *e = nullptr;
+            const double x = std::strtod(p + 1, &e);
+            const double y = std::strtod(e, &e);
+            vertices.push_back((float)x);
+            vertices.push_back((float)y);
+        } else if (p[0] == 'l' && (p[1] == ' ' || p[1] == '\t')) {
+            std::vector<long> idx;
+            const char *q = p + 1;
+            while (true) {
+                char *e = nullptr;
+                const long v = std::strtol(q, &e, 10);
+                if (e == q) break;
+                idx.push_back(v);
+                q = e;
+                while (*q == '/' || (*q >= '0' && *q <= '9')) ++q;  // skip "/vt" suffixes
+            }
+            const long nv = (long)(vertices.size() / 2);
+            for (size_t i = 0; i + 1 < idx.size(); ++i) {
+                long a = idx[i] > 0 ? idx[i] - 1 : nv + idx[i];
+                long b = idx[i + 1] > 0 ? idx[i + 1] - 1 : nv + idx[i + 1];
+                indices.push_back((int32_t)a);
+                indices.push_back((int32_t)b);
+            }
+        }
+    }
+    const long nv = (long)(vertices.size() / 2);
+    for (int32_t i : indices)
+        if (i < 0 || i >= nv) throw std::runtime_error("OBJ segment references a missing vertex: " + path);
+}
+
+// ---- vertex colours ------------------------------------------------------------------------
+std::vector<float> parseVertexColorFile(const string &path)
+{
+    const json conf = load_json_file(path);
+    const json cc = json_get_or_throw<json>(conf, "ColorConfigurations");
+    if (!cc.is_array()) throw std::runtime_error("The ColorConfigurations item is not an array.");
+    std::vector<float> out(cc.size() * 6);
+    for (size_t i = 0; i < cc.size(); ++i) {
+        const json &c = cc[i];
+        if (json_get_or_throw<int>(c, "vertexID") != (int)i + 1)
+            throw std::runtime_error("The configurations should be sorted.");
+        out[6 * i + 0] = json_get_or_throw<float>(c, "leftColor/R");
+        out[6 * i + 1] = json_get_or_throw<float>(c, "leftColor/G");
+        out[6 * i + 2] = json_get_or_throw<float>(c, "leftColor/B");
+        out[6 * i + 3] = json_get_or_throw<float>(c, "rightColor/R");
+        out[6 * i + 4] = json_get_or_throw<float>(c, "rightColor/G");
+        out[6 * i + 5] = json_get_or_throw<float>(c, "rightColor/B");
+    }
+    return out;
+}
+
+// ---- Problem<2> ----------------------------------------------------------------------------
+static string resolve(const string &p, const fs::path &search_dir)
+{
+    if (fs::exists(p) || search_dir.empty()) return p;
+    const fs::path alt = search_dir / p;
+    return fs::exists(alt) ? alt.string() : p;
+}
+
+void Problem<2>::loadConfig(const json &config, const fs::path &search_dir)
+{
+    // reference core/problem.cu:152-181
+    const json probeConfig = json_get_or_throw<json>(config, "evaluation_grid");
+    const auto amin = json_get_or_throw<std::vector<float>>(config, "aabb/min");
+    const auto amax = json_get_or_throw<std::vector<float>>(config, "aabb/max");
+    if (amin.size() != 2 || amax.size() != 2) throw std::runtime_error("aabb/min and aabb/max must have 2 entries");
+    mAABB = AABB2f{{amin[0], amin[1]}, {amax[0], amax[1]}};
+    mpProbe = std::make_shared<SceneProbe>(probeConfig);
+
+    const json meshConfig = json_get_or_throw<json>(config, "mesh");
+    const auto dirichlet_path = json_get_optional<string>(meshConfig, "dirichlet_path");
+    const auto neumann_path = json_get_optional<string>(meshConfig, "neumann_path");
+    if (dirichlet_path) {
+        scene_dirichlet_loader = std::make_unique<SceneLoader2>(resolve(*dirichlet_path, search_dir));
+        enable_dirichlet = true;
+        scene_stat.dirichlet_vertices_size = scene_dirichlet_loader->vertices.size() / 2;
+        scene_stat.dirichlet_primitives_size = scene_dirichlet_loader->indices.size() / 2;
+    }
+    if (neumann_path) {
+        scene_neumann_loader = std::make_unique<SceneLoader2>(resolve(*neumann_path, search_dir));
+        enable_neumann = true;
+        scene_stat.neumann_vertices_size = scene_neumann_loader->vertices.size() / 2;
+        scene_stat.neumann_primitives_size = scene_neumann_loader->indices.size() / 2;
+    }
+    // reference core/problem.cu:99-133: absent file => all-zero colours
+    const auto cd = json_get_optional<string>(meshConfig, "vertex_color_dirichlet_path");
+    const auto cn = json_get_optional<string>(meshConfig, "vertex_color_neumann_path");
+    if (enable_dirichlet) {
+        if (cd) vertex_color_dirichlet = parseVertexColorFile(resolve(*cd, search_dir));
+        else vertex_color_dirichlet.assign(scene_stat.dirichlet_vertices_size * 6, 0.0f);
+        if (vertex_color_dirichlet.size() != scene_stat.dirichlet_vertices_size * 6)
+            throw std::runtime_error("Dirichlet colour file does not have one entry per vertex");
+    }
+    if (enable_neumann) {
+        if (cn) vertex_color_neumann = parseVertexColorFile(resolve(*cn, search_dir));
+        else vertex_color_neumann.assign(scene_stat.neumann_vertices_size * 6, 0.0f);
+        if (vertex_color_neumann.size() != scene_stat.neumann_vertices_size * 6)
+            throw std::runtime_error("Neumann colour file does not have one entry per vertex");
+    }
+    if (json_get_optional<string>(config, "source_path"))
+        throw std::runtime_error("source_path: the source term is outside this build's scope (SURVEY.md 8f.2)");
+    if (json_get_optional<string>(config, "mask_path"))
+        throw std::runtime_error("mask_path: mask images are not loaded by this build (SURVEY.md 8f.4); use set_mask()");
+    source_intensity = json_get_optional<float>(config, "source_intensity", 1.0f);
+    dirichlet_intensity = json_get_optional<float>(config, "dirichlet_intensity", 1.0f);
+    neumann_intensity = json_get_optional<float>(config, "neumann_intensity", 1.0f);
+    if (verbose) {
+        ELAINA_LOG(Success, "Problem: loadConfig is completed.");
+        if (enable_dirichlet)
+            ELAINA_LOG(Info, "Dirichlet: %zu vertices, %zu primitives, intensity %f", scene_stat.dirichlet_vertices_size,
+                       scene_stat.dirichlet_primitives_size, dirichlet_intensity);
+        if (enable_neumann)
+            ELAINA_LOG(Info, "Neumann: %zu vertices, %zu primitives, intensity %f", scene_stat.neumann_vertices_size,
+                       scene_stat.neumann_primitives_size, neumann_intensity);
+    }
+}
+
+wost_scene_desc Problem<2>::scene_desc(int width, int height) const
+{
+    wost_scene_desc d;
+    std::memset(&d, 0, sizeof(d));
+    if (enable_dirichlet) {
+        d.dirichlet.n_verts = (int32_t)scene_stat.dirichlet_vertices_size;
+        d.dirichlet.n_segs = (int32_t)scene_stat.dirichlet_primitives_size;
+        d.dirichlet.verts = scene_dirichlet_loader->vertices.data();
+        d.dirichlet.segs = scene_dirichlet_loader->indices.data();
+        d.dirichlet.colors = vertex_color_dirichlet.data();
+    }
+    if (enable_neumann) {
+        d.neumann.n_verts = (int32_t)scene_stat.neumann_vertices_size;
+        d.neumann.n_segs = (int32_t)scene_stat.neumann_primitives_size;
+        d.neumann.verts = scene_neumann_loader->vertices.data();
+        d.neumann.segs = scene_neumann_loader->indices.data();
+        d.neumann.colors = vertex_color_neumann.data();
+    }
+    d.dirichlet_intensity = dirichlet_intensity;
+    d.neumann_intensity = neumann_intensity;
+    d.probe_scale = mpProbe->mData.scale;
+    d.probe_pos[0] = mpProbe->mData.pos.x; d.probe_pos[1] = mpProbe->mData.pos.y;
+    d.probe_up[0] = mpProbe->mData.up.x; d.probe_up[1] = mpProbe->mData.up.y;
+    if (!mask.empty()) {
+        if (mask.size() != (size_t)width * height) throw std::runtime_error("mask size does not match the frame");
+        d.mask = mask.data();
+    }
+    return d;
+}
+
+}  // namespace elaina

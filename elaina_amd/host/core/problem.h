@@ -1,0 +1,74 @@
+// problem.h -- scene description, mirror of the reference's Problem<2> surface
+// (core/problem.h:54-194): loadConfig(json) plus the getters the integrator and run_expr
+// touch.  Where the reference hands out snch-lbvh device handles
+// (get_problem_*_bvh_device / get_problem_*_ptr), this class hands out the host arrays as a
+// wost_scene_desc: the LBVH lives behind the C-ABI (include/wost.h).
+#pragma once
+#include <memory>
+#include <optional>
+#include <vector>
+
+#include "../../../include/wost.h"
+#include "common.h"
+#include "evaluation_grid.h"
+
+namespace elaina {
+
+struct ProblemStatistics {
+    std::size_t dirichlet_vertices_size{0};
+    std::size_t dirichlet_primitives_size{0};
+    std::size_t neumann_vertices_size{0};
+    std::size_t neumann_primitives_size{0};
+};
+
+// OBJ polyline loader: replaces lbvh::scene_loader<2> (reference core/problem.cu:29,46).
+// Reads "v x y [z]" and "l i j k ..." (1-based, negative = relative) records.
+struct SceneLoader2 {
+    explicit SceneLoader2(const string &path);
+    std::vector<float> vertices;   // x,y per vertex
+    std::vector<int32_t> indices;  // i0,i1 per segment, 0-based
+};
+
+template <unsigned int DIM> class Problem;
+
+template <> class Problem<2> {
+public:
+    explicit Problem(const bool verbose = true) : verbose(verbose) {}
+    using SceneProbe = EvaluationGrid<2>;
+
+    void loadConfig(const json &config, const fs::path &search_dir = {});
+
+    // reference core/problem.h:104-171
+    bool isDirichletEnabled() const { return enable_dirichlet; }
+    bool isNeumannEnabled() const { return enable_neumann; }
+    bool isSourceEnabled() const { return false; }
+    const SceneProbe &getProbe() const { return *mpProbe; }
+    const AABB2f &getAABB() const { return mAABB; }
+    const ProblemStatistics &get_problem_stat() const { return scene_stat; }
+    float get_source_intensity() const { return source_intensity; }
+    float get_dirichlet_intensity() const { return dirichlet_intensity; }
+    float get_neumann_intensity() const { return neumann_intensity; }
+    const std::vector<float> &get_vertex_color_dirichlet() const { return vertex_color_dirichlet; }
+    const std::vector<float> &get_vertex_color_neumann() const { return vertex_color_neumann; }
+    const std::vector<uint8_t> &get_mask() const { return mask; }
+    void set_mask(std::vector<uint8_t> m) { mask = std::move(m); }
+
+    // what crosses the C-ABI (valid while this Problem is alive and unchanged)
+    wost_scene_desc scene_desc(int width, int height) const;
+
+private:
+    std::shared_ptr<SceneProbe> mpProbe;
+    AABB2f mAABB;
+    std::unique_ptr<SceneLoader2> scene_dirichlet_loader, scene_neumann_loader;
+    std::vector<float> vertex_color_dirichlet, vertex_color_neumann;  // 6 floats per vertex
+    bool enable_dirichlet{false}, enable_neumann{false};
+    bool verbose{false};
+    ProblemStatistics scene_stat;
+    float source_intensity{1.0f}, dirichlet_intensity{1.0f}, neumann_intensity{1.0f};
+    std::vector<uint8_t> mask;  // empty = all pixels on
+};
+
+// reference core/problem.cu:63-96: {"ColorConfigurations":[{"vertexID":i+1,"leftColor":{R,G,B},"rightColor":{R,G,B}}]}
+std::vector<float> parseVertexColorFile(const string &path);
+
+}  // namespace elaina

@@ -1,0 +1,118 @@
+// exec.cpp -- run_expr: parse the config, build the Problem, build the integrator, run the
+// requested channels, export, write result.json (reference exec.cu:39-221).  Differences,
+// on purpose: the output directory is created (the reference writes conf.json into a
+// directory it never makes, exec.cu:69); unknown channels / export entries are skipped
+// instead of dereferencing an empty optional (exec.cu:193-199); only "uniform" + 2-D is
+// built -- guided and 3-D configurations exit(1) like an unrecognised type does.
+#include "exec.h"
+
+#include <chrono>
+#include <ctime>
+#include <fstream>
+#include <set>
+
+#include "core/problem.h"
+#include "integrator/uniform/integrator.h"
+
+using namespace elaina;
+
+static std::string get_current_time()
+{
+    const std::time_t t = std::chrono::system_clock::to_time_t(std::chrono::system_clock::now());
+    char buffer[20];
+    std::strftime(buffer, sizeof(buffer), "%Y-%m-%d %H:%M:%S", std::localtime(&t));
+    return buffer;
+}
+
+void run_expr(fs::path conf_path)
+{
+    if (!fs::exists(conf_path)) {
+        ELAINA_LOG(Error, "Configuration file does not exist: %s", conf_path.c_str());
+        return;
+    }
+    json conf_json, result_json = json::object();
+    try {
+        conf_json = load_json_file(conf_path.string());
+    } catch (const std::exception &e) {
+        ELAINA_LOG(Error, "Failed to parse JSON: %s", e.what());
+        return;
+    }
+    const int dimensionality = json_get_or_throw<int>(conf_json, "dimensionality");
+    const fs::path basePath = json_get_or_throw<string>(conf_json, "base_path");
+    const std::string expName = json_get_or_throw<string>(conf_json, "exp_name");
+    const fs::path outDir = basePath / expName;
+    fs::create_directories(outDir);
+    {
+        std::ofstream confFileCopy(outDir / "conf.json");
+        confFileCopy << conf_json.dump(4) << std::endl;
+    }
+    ELAINA_LOG(Success, "Configuration file copied to %s", (outDir / "conf.json").c_str());
+
+    const json scene_section = json_get_or_throw<json>(conf_json, "scene");
+    const json integrator_section = json_get_or_throw<json>(conf_json, "integrator");
+    const string integrator_type = json_get_or_throw<string>(integrator_section, "type");
+    const json integrator_setting = json_get_or_throw<json>(integrator_section, "setting");
+    if (dimensionality != 2) {
+        ELAINA_LOG(Error, "Unsupported dimensionality (this build: 2).");
+        exit(1);
+    }
+    if (integrator_type != "uniform") {
+        ELAINA_LOG(Error, "Unrecognized integrator type (this build: uniform).");
+        exit(1);
+    }
+    Problem<2> scene;
+    scene.loadConfig(scene_section, conf_path.parent_path());
+    UniformIntegrator<2> obj(scene, UniformIntegratorSettings::from_json(integrator_setting), outDir);
+
+    const json export_section = json_get_or_throw<json>(conf_json, "export");
+    const json integrator_channels = json_get_or_throw<json>(integrator_section, "channels");
+    std::set<ExportImageChannel> channels;
+    for (const json &c : integrator_channels.items()) {
+        ExportImageChannel ch;
+        if (!parse_channel(c.get<string>(), &ch)) {
+            ELAINA_LOG(Error, "Unrecognized integrator channel, skipping...");
+            continue;
+        }
+        channels.insert(ch);
+    }
+    if (json_get_optional<bool>(conf_json, "print_network", false))
+        ELAINA_LOG(Warning, "print_network: the uniform integrator has no network");
+
+    for (const ExportImageChannel ch : channels) {
+        switch (ch) {
+        case ExportImageChannel::SOLUTION: {
+            const uint64_t duration = obj.solve();
+            result_json["duration"] = json((uint64_t)duration);
+            const wost_stats &s = obj.get_last_stats();
+            result_json["walk_steps"] = json((uint64_t)s.walk_steps);
+            result_json["walk_steps_per_second"] = json(s.solve_ms > 0 ? (double)s.walk_steps / (s.solve_ms * 1e-3) : 0.0);
+            break;
+        }
+        case ExportImageChannel::DIRICHLET_SDF: obj.renderDirichletSDF(); break;
+        case ExportImageChannel::NEUMANN_SDF: obj.renderSilhouetteSDF(); break;
+        case ExportImageChannel::SOURCE: obj.renderSource(); break;
+        default: break;
+        }
+    }
+    for (const json &m : export_section.items()) {
+        const string type = json_get_or_throw<string>(m, "type");
+        const string channel_string = json_get_or_throw<string>(m, "channel");
+        const string file_name = json_get_or_throw<string>(m, "file_name");
+        ExportImageChannel ch;
+        if (!parse_channel(channel_string, &ch)) {
+            ELAINA_LOG(Error, "Unrecognized export channel, skipping...");
+            continue;
+        }
+        if (type == "image") {
+            obj.exportImage(ch, file_name);
+        } else if (type == "energy") {
+            ToneMapping tone;
+            if (parse_tone(json_get_or_throw<string>(m, "tone"), &tone)) obj.exportEnergy(ch, tone, file_name);
+            else ELAINA_LOG(Error, "Unrecognized tone mapping method, skipping...");
+        }
+    }
+    result_json["timestamp"] = json(get_current_time());
+    std::ofstream resultFile(outDir / "result.json");
+    resultFile << result_json.dump(4) << std::endl;
+    ELAINA_LOG(Success, "Result file written to %s", (outDir / "result.json").c_str());
+}

@@ -1,0 +1,70 @@
+// main.cpp -- `elaina-exec <conf.json>` (reference main.cpp:9-19).  `--selftest` runs the
+// host-only checks (JSON, OBJ, settings binding) that need no GPU.
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+#include "core/problem.h"
+#include "exec.h"
+#include "integrator/uniform/integrator.h"
+
+using namespace elaina;
+
+static int selftest()
+{
+    int failures = 0;
+    auto expect = [&](bool ok, const char *what) {
+        if (!ok) { std::cerr << "selftest FAILED: " << what << std::endl; ++failures; }
+    };
+    const json j = json::parse(R"({"a": {"b": [1, 2.5, -3e2], "s": "x\nyé", "t": true, "n": null}, "k": 7})");
+    expect(json_get_or_throw<int>(j, "k") == 7, "int");
+    expect(json_get_or_throw<std::vector<float>>(j, "a/b")[2] == -300.0f, "array");
+    expect(json_get_or_throw<string>(j, "a/s") == "x\ny\xc3\xa9", "string escapes");
+    expect(json_get_or_throw<bool>(j, "a/t"), "bool");
+    expect(!json_get_optional<int>(j, "a/n").has_value(), "null is absent");
+    expect(json_get_optional<float>(j, "missing/path", 3.0f) == 3.0f, "optional default");
+    bool threw = false;
+    try { json_get_or_throw<int>(j, "nope"); } catch (const std::runtime_error &) { threw = true; }
+    expect(threw, "missing key throws");
+    threw = false;
+    try { json::parse("{\"a\": }"); } catch (const std::runtime_error &) { threw = true; }
+    expect(threw, "syntax error throws");
+    expect(json::parse(j.dump(2)).dump() == j.dump(), "dump/parse round trip");
+    // settings binding: every key required
+    const json st = json::parse(R"({"frameSize":[64,32],"debugPixel":0,"samplesPerPixel":4,"maxWalkingDepth":16,
+        "saveSppMetricsDuration":-1,"saveSppMetricsUntil":-1,"saveTimeMetricsDuration":-1,"epsilonShell":1})");
+    const UniformIntegratorSettings s = UniformIntegratorSettings::from_json(st);
+    expect(s.frameSize.x == 64 && s.frameSize.y == 32 && s.samplesPerPixel == 4 && s.epsilonShell == 1.0f, "settings");
+    threw = false;
+    try { UniformIntegratorSettings::from_json(json::parse("{\"frameSize\":[1,1]}")); } catch (const std::runtime_error &) { threw = true; }
+    expect(threw, "missing setting throws");
+    // OBJ polylines
+    const fs::path tmp = fs::temp_directory_path() / "elaina_selftest.obj";
+    { std::ofstream f(tmp); f << "# c\no P\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nl 1 2 3\nl -1 1\n"; }
+    SceneLoader2 ld(tmp.string());
+    expect(ld.vertices.size() == 8 && ld.indices.size() == 6, "obj counts");
+    expect(ld.indices[2] == 1 && ld.indices[3] == 2 && ld.indices[4] == 3 && ld.indices[5] == 0, "obj polyline + relative index");
+    fs::remove(tmp);
+    EvaluationGrid<2> g(json::parse(R"({"mData":{"scale":250,"pos":[250,250],"up":[-1,0]}})"));
+    const Vector2f p = g.getEvaluationPoint({0, 0}, {1024, 1024});
+    expect(std::fabs(p.x - 500.0f) < 1e-3f && std::fabs(p.y - 0.0f) < 1e-3f, "evaluation grid");
+    std::cout << (failures ? "selftest failed" : "selftest ok") << std::endl;
+    return failures ? 1 : 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) {
+        std::cerr << "Usage: " << argv[0] << " <conf_path> | --selftest" << std::endl;
+        return 1;
+    }
+    if (std::strcmp(argv[1], "--selftest") == 0) return selftest();
+    try {
+        run_expr(fs::path(argv[1]));
+    } catch (const std::exception &e) {
+        ELAINA_LOG(Error, "%s", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Write a shipped scene fixture (data/scenes/<name>.npz) as the files the JSON-driven entry
+point reads: model.obj, boundary.obj, color.json (reference schema, core/problem.cu:63-96)
+and a conf.json in the reference's layout (data/ladybug/u.json).
+
+usage: export_scene.py <scene> <out_dir> [--frame N] [--spp N] [--depth N]
+Floats are printed with 9 significant digits, which round-trips fp32 exactly."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from elaina_amd import Problem  # noqa: E402
+
+
+def write_obj(path, verts, segs):
+    with open(path, "w") as f:
+        for x, y in verts:
+            f.write("v %.9g %.9g 0\n" % (x, y))
+        for a, b in segs:
+            f.write("l %d %d\n" % (a + 1, b + 1))
+
+
+def write_colors(path, colors):
+    cfg = [{"vertexID": i + 1,
+            "leftColor": {"R": float(c[0]), "G": float(c[1]), "B": float(c[2])},
+            "rightColor": {"R": float(c[3]), "G": float(c[4]), "B": float(c[5])}} for i, c in enumerate(colors)]
+    with open(path, "w") as f:
+        json.dump({"ColorConfigurations": cfg}, f)
+
+
+def export(scene, out_dir, frame=128, spp=16, depth=32, exp_name=None):
+    p = Problem.load_scene(scene)
+    os.makedirs(out_dir, exist_ok=True)
+    write_obj(os.path.join(out_dir, "model.obj"), p.d_verts, p.d_segs)
+    write_obj(os.path.join(out_dir, "boundary.obj"), p.n_verts, p.n_segs)
+    write_colors(os.path.join(out_dir, "color.json"), p.d_colors)
+    conf = {
+        "dimensionality": 2, "base_path": os.path.join(out_dir, "exp"), "exp_name": exp_name or (scene + "_u"),
+        "integrator": {
+            "setting": {"debugPixel": 0, "frameSize": [frame, frame], "maxWalkingDepth": depth, "samplesPerPixel": spp,
+                        "saveSppMetricsDuration": -1, "saveSppMetricsUntil": -1, "saveTimeMetricsDuration": -1,
+                        "epsilonShell": float(p.default_eps)},
+            "type": "uniform", "channels": ["SOLUTION", "DIRICHLET_SDF"]},
+        "export": [{"type": "image", "channel": "SOLUTION", "file_name": "solution"},
+                   {"type": "image", "channel": "DIRICHLET_SDF", "file_name": "dirichlet_sdf"},
+                   {"type": "energy", "tone": "NONE_NORMALIZED", "channel": "SOLUTION", "file_name": "solution_energy"}],
+        "scene": {
+            "aabb": {"min": [float(p.aabb[0]), float(p.aabb[1])], "max": [float(p.aabb[2]), float(p.aabb[3])]},
+            "evaluation_grid": {"mData": {"pos": [float(p.probe[1]), float(p.probe[2])], "scale": float(p.probe[0]),
+                                          "up": [float(p.probe[3]), float(p.probe[4])]}},
+            "mesh": {"dirichlet_path": os.path.join(out_dir, "model.obj"),
+                     "vertex_color_dirichlet_path": os.path.join(out_dir, "color.json"),
+                     "neumann_path": os.path.join(out_dir, "boundary.obj")}}}
+    path = os.path.join(out_dir, "conf.json")
+    with open(path, "w") as f:
+        json.dump(conf, f, indent=4)
+    return path
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = [int(x) for x in f.readline().split()]
+        scale = float(f.readline())
+        data = np.frombuffer(f.read(), dtype="<f4" if scale < 0 else ">f4")
+    return data.reshape(h * w, 3)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("scene")
+    ap.add_argument("out_dir")
+    ap.add_argument("--frame", type=int, default=128)
+    ap.add_argument("--spp", type=int, default=16)
+    ap.add_argument("--depth", type=int, default=32)
+    a = ap.parse_args()
+    print(export(a.scene, a.out_dir, a.frame, a.spp, a.depth))
