@@ -610,7 +610,7 @@ struct wost_context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // options
-    int steps_per_round = 64;
+    int steps_per_round = 256;
     int block_size = 256;
     int wait_weight = 8;
     int top_levels = 3;
