@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--depth", type=int, default=0, help="0 = the scene's maxWalkingDepth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steps-per-round", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="key=value passed to wost_set_option")
     args = ap.parse_args()
 
     import torch
@@ -79,6 +80,9 @@ def main():
     it = UniformIntegrator(problem, UniformIntegratorSettings((frame, frame), args.spp, depth, eps), device=local)
     if args.steps_per_round:
         it.set_option("steps_per_round", args.steps_per_round)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        it.set_option(k, float(v))
     field = torch.zeros(frame * frame * 3, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
 

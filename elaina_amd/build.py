@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libwost_hip.so")
 HOST_EXE = os.path.join(LIB_DIR, "elaina-exec")
 
 SOURCES = ["wost_hip.hip", "lbvh_build.cpp"]
-HEADERS = ["lbvh.h", "wost_device.h", "wost_math.h", os.path.join("..", "..", "include", "wost.h")]
+HEADERS = ["lbvh.h", "wost_device.h", "wost_math.h", "wost_pool.h", os.path.join("..", "..", "include", "wost.h")]
 
 # -ffp-contract=off is part of the arithmetic contract (DESIGN.md "deterministic math")
 HIPCC_FLAGS = [

@@ -67,7 +67,7 @@ class Stats(C.Structure):
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 EXPORTS = [

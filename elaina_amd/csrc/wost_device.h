@@ -82,6 +82,22 @@ __device__ __forceinline__ float obb_d2(float cx, float cy, float ux, float uy, 
     return dot2(du, dv, du, dv);
 }
 
+// The same arithmetic for the four children of one node, two per instruction: gfx950 issues
+// v_pk_{add,mul,fma}_f32 at the rate of their scalar forms, and this kernel is bound by VALU
+// issue.  Component-wise IEEE operations, so the results equal four obb_d2() calls bit for bit.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 obb_d2_x2(f32x2 cx, f32x2 cy, f32x2 ux, f32x2 uy, f32x2 hl, f32x2 hw, f32x2 qx, f32x2 qy)
+{
+    const f32x2 wx = qx - cx, wy = qy - cy;
+    const f32x2 u = __builtin_elementwise_fma(wx, ux, wy * uy);
+    const f32x2 v = __builtin_elementwise_fma(ux, wy, -(uy * wx));
+    const f32x2 zero = {0.0f, 0.0f};
+    const f32x2 du = __builtin_elementwise_max(__builtin_elementwise_abs(u) - hl, zero);
+    const f32x2 dv = __builtin_elementwise_max(__builtin_elementwise_abs(v) - hw, zero);
+    return __builtin_elementwise_fma(du, du, dv * dv);
+}
+
 __device__ __forceinline__ float seg_d2(const DevFlatSeg &s, float qx, float qy)
 {
     return obb_d2(s.cx, s.cy, s.ux, s.uy, s.hl, 0.0f, qx, qy);
@@ -111,12 +127,11 @@ __device__ __forceinline__ void cswap(uint32_t &a, uint32_t &b)
 // of the true one, so stale entries are dropped at pop time without touching memory, and
 // the node position is recovered from the position of the last visited node (which always
 // lies below the entry's parent in a depth-first traversal):
-// parent pos = pos >> 2*(level - entry_level + 1).  Stack pointers are byte offsets and
-// the stride between entries of one lane is passed in bytes (no multiplies on push/pop).
+// parent pos = pos >> 2*(level - entry_level + 1).
 struct Trav {
     int32_t level;      // level of the node to visit next
     int32_t pos;        // position of that node inside its level
-    int32_t sp;         // stack pointer as a BYTE offset into the lane's column (0 = empty)
+    int32_t sp;         // number of entries on the stack
     Closest best;       // may start from a valid candidate (temporal hint)
     int32_t best_orig;  // original index of best.slot, loaded lazily when an exact tie shows up
 };
@@ -131,13 +146,41 @@ __device__ __forceinline__ uint32_t level_first(int level)
     return level == 0 ? 0u : (0x55555555u >> (32 - 2 * level));
 }
 
+// Where a traversal stack lives.  LdsColumn: entry i of this lane/walker at col[i * stride]
+// (one column per lane, bank = lane).  SplitColumn: the first `lds_entries` entries in an LDS
+// column, the rest in a global-memory column (rarely reached: deep stacks are the exception).
+struct LdsColumn {
+    uint32_t *col;
+    uint32_t stride;  // words between consecutive entries
+    __device__ __forceinline__ void put(int i, uint32_t key) const { col[__umul24((uint32_t)i, stride)] = key; }
+    __device__ __forceinline__ uint32_t get(int i) const { return col[__umul24((uint32_t)i, stride)]; }
+};
+
+struct SplitColumn {
+    uint32_t *col;
+    uint32_t stride;
+    int lds_entries;
+    uint32_t *gcol;    // global column of this walker
+    uint32_t gstride;  // words between consecutive global entries
+    __device__ __forceinline__ void put(int i, uint32_t key) const
+    {
+        if (i < lds_entries) col[__umul24((uint32_t)i, stride)] = key;
+        else gcol[(size_t)(i - lds_entries) * gstride] = key;
+    }
+    __device__ __forceinline__ uint32_t get(int i) const
+    {
+        return (i < lds_entries) ? col[__umul24((uint32_t)i, stride)] : gcol[(size_t)(i - lds_entries) * gstride];
+    }
+};
+
 // Pop the next entry that can still tie or beat the current best.  Returns false when the
 // stack is exhausted (query complete).
-__device__ __forceinline__ bool trav_pop(Trav &T, const uint32_t *stack, int stride_bytes)
+template <class STK>
+__device__ __forceinline__ bool trav_pop(Trav &T, const STK &stk)
 {
     while (T.sp > 0) {
-        T.sp -= stride_bytes;
-        const uint32_t key = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(stack) + T.sp);
+        --T.sp;
+        const uint32_t key = stk.get(T.sp);
         const float dlb = __uint_as_float(key & ~0x3Fu);
         if (dlb <= T.best.d2) {
             const int el = (int)((key >> 2) & 15u);
@@ -177,11 +220,12 @@ __device__ __forceinline__ void trav_leaf_ties(const DevMesh &m, Trav &T, int sl
 // push the children that can still tie or win in far-to-near order and step into the
 // nearest.  Returns false when the query is complete.  Ties between segments are broken by
 // the lowest ORIGINAL index, so the answer does not depend on the tree or the visiting order.
-// `top` (optional) is an LDS copy of the nodes of the levels < top_levels: every query
-// starts there, and the per-CU vector L1 -- six 16-byte gathers per lane and visit -- is the
-// scarce resource of this kernel, so the top of the tree is served from LDS instead.
-template <bool USE_TOP = false>
-__device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy, Trav &T, uint32_t *stack, int stride_bytes,
+// `top` (optional) is an LDS copy of the nodes of the levels < top_levels.
+// KIND: 0 = decide per lane from T.level, 1 = every active lane is at an inner node,
+// 2 = every active lane is at a node of the last level (children are segments); the pool
+// kernel batches lanes by kind so that only one tail is ever executed by a wave.
+template <bool USE_TOP = false, int KIND = 0, class STK = LdsColumn>
+__device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy, Trav &T, const STK &stk,
                                            const float4 *top = nullptr, int top_levels = 0)
 {
     const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
@@ -194,12 +238,15 @@ __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy,
         const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
         CX = nd[0]; CY = nd[1]; UX = nd[2]; UY = nd[3]; HL = nd[4]; HW = nd[5];
     }
-    const float d0 = obb_d2(CX.x, CY.x, UX.x, UY.x, HL.x, HW.x, qx, qy);
-    const float d1 = obb_d2(CX.y, CY.y, UX.y, UY.y, HL.y, HW.y, qx, qy);
-    const float d2 = obb_d2(CX.z, CY.z, UX.z, UY.z, HL.z, HW.z, qx, qy);
-    const float d3 = obb_d2(CX.w, CY.w, UX.w, UY.w, HL.w, HW.w, qx, qy);
+    const f32x2 q2x = {qx, qx}, q2y = {qy, qy};
+    const f32x2 d01 = obb_d2_x2(f32x2{CX.x, CX.y}, f32x2{CY.x, CY.y}, f32x2{UX.x, UX.y}, f32x2{UY.x, UY.y},
+                                f32x2{HL.x, HL.y}, f32x2{HW.x, HW.y}, q2x, q2y);
+    const f32x2 d23 = obb_d2_x2(f32x2{CX.z, CX.w}, f32x2{CY.z, CY.w}, f32x2{UX.z, UX.w}, f32x2{UY.z, UY.w},
+                                f32x2{HL.z, HL.w}, f32x2{HW.z, HW.w}, q2x, q2y);
+    const float d0 = d01.x, d1 = d01.y, d2 = d23.x, d3 = d23.y;
     const float bd = T.best.d2;
-    if (T.level == m.levels) {
+    const bool at_leaf = (KIND == 2) || (KIND == 0 && T.level == m.levels);
+    if (at_leaf) {
         // children are segments: exact distances
         const float mn = fminf(fminf(d0, d1), fminf(d2, d3));
         if (mn <= bd) {
@@ -232,14 +279,13 @@ __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy,
         // branch-free pushes: sorted keys keep the invalid ones (0xffffffff) last, i.e. first
         // in far-to-near push order; an invalid key is written but the pointer does not move,
         // so the next write lands on top of it (the column has three words of slack)
-        char *col = reinterpret_cast<char *>(stack);
         int sp = T.sp;
-        *reinterpret_cast<uint32_t *>(col + sp) = k3;
-        sp += (k3 != 0xffffffffu) ? stride_bytes : 0;
-        *reinterpret_cast<uint32_t *>(col + sp) = k2;
-        sp += (k2 != 0xffffffffu) ? stride_bytes : 0;
-        *reinterpret_cast<uint32_t *>(col + sp) = k1;
-        sp += (k1 != 0xffffffffu) ? stride_bytes : 0;
+        stk.put(sp, k3);
+        sp += (k3 != 0xffffffffu) ? 1 : 0;
+        stk.put(sp, k2);
+        sp += (k2 != 0xffffffffu) ? 1 : 0;
+        stk.put(sp, k1);
+        sp += (k1 != 0xffffffffu) ? 1 : 0;
         T.sp = sp;
         if (k0 != 0xffffffffu) {
             T.pos = 4 * T.pos + (int)(k0 & 3u);
@@ -247,15 +293,15 @@ __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy,
             return true;
         }
     }
-    return trav_pop(T, stack, stride_bytes);
+    return trav_pop(T, stk);
 }
 
 __device__ __forceinline__ Closest closest_point(const DevMesh &m, float qx, float qy, Closest seed,
                                                  uint32_t *stack, int stride)
 {
     Trav T = trav_begin(seed);
-    const int stride_bytes = stride * 4;
-    while (trav_visit(m, qx, qy, T, stack, stride_bytes)) {
+    const LdsColumn stk{stack, (uint32_t)stride};
+    while (trav_visit(m, qx, qy, T, stk)) {
     }
     return T.best;
 }

@@ -51,7 +51,7 @@ struct WalkQueue {
 static const int kQueueWords = 16 + 1;  // rng counts twice
 
 struct StatsDev {
-    unsigned long long steps, started, absorbed, truncated, nhits, inner_visits, leaf_visits, trav_trips, step_trips;
+    unsigned long long steps, started, absorbed, truncated, nhits, inner_visits, leaf_visits, trav_trips, step_trips, max_stack;
 };
 
 struct RoundParams {
@@ -170,12 +170,11 @@ struct LaneStats {
 // of lbvh nearest() for L.px,L.py (ignored when there is no Dirichlet boundary).
 // Returns true when the walk ended in this step.
 template <bool NEUMANN_EMISSIVE>
-__device__ __forceinline__ bool step_finish(const RoundParams &P, Lane &L, LaneStats &S, const Closest cp)
+__device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm, const DevSettings &st, Lane &L, LaneStats &S,
+                                            const Closest cp)
 {
-    const DevMesh &dm = P.dm;
-    const DevMesh &nm = P.nm;
     const bool has_d = dm.n_segs > 0, has_n = nm.n_segs > 0;
-    const float eps = P.st.eps;
+    const float eps = st.eps;
     const float px = L.px, py = L.py;
 
     // ---- separateEvaluationPoint -------------------------------------------------------
@@ -194,7 +193,7 @@ __device__ __forceinline__ bool step_finish(const RoundParams &P, Lane &L, LaneS
             // ---- handleBoundary ----
             float r, g, b;
             surface_color(dm.segCol + 12 * (size_t)cp.slot, side, uv, r, g, b);
-            r *= P.st.dirichlet_intensity; g *= P.st.dirichlet_intensity; b *= P.st.dirichlet_intensity;
+            r *= st.dirichlet_intensity; g *= st.dirichlet_intensity; b *= st.dirichlet_intensity;
             r *= L.thp; g *= L.thp; b *= L.thp;
             L.sr = r + L.sr; L.sg = g + L.sg; L.sb = b + L.sb;
             S.absorbed++;
@@ -246,7 +245,7 @@ __device__ __forceinline__ bool step_finish(const RoundParams &P, Lane &L, LaneS
                             const float alpha = L.on_n ? 0.5f : 1.0f;
                             const float G = det_logf(R_B / r) / WOST_2PI;
                             const float w = L.thp * G / alpha / pdf;
-                            cr_ *= P.st.neumann_intensity; cg_ *= P.st.neumann_intensity; cb_ *= P.st.neumann_intensity;
+                            cr_ *= st.neumann_intensity; cg_ *= st.neumann_intensity; cb_ *= st.neumann_intensity;
                             cr_ *= w; cg_ *= w; cb_ *= w;
                             L.sr = -cr_ + L.sr; L.sg = -cg_ + L.sg; L.sb = -cb_ + L.sb;
                         }
@@ -299,7 +298,7 @@ __device__ __forceinline__ bool step_finish(const RoundParams &P, Lane &L, LaneS
     L.px = nxt_x; L.py = nxt_y;
     L.on_n = hit; L.nx = hnx; L.ny = hny;
     L.depth++;
-    if (L.depth == (uint32_t)P.st.max_depth) {
+    if (L.depth == (uint32_t)st.max_depth) {
         S.truncated++;
         return true;
     }
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(256, 6) void walk_round_kernel(RoundParams P)
     int budget = P.steps_per_round;
     Trav T = trav_begin(Closest{WOST_INF, -1});
     uint32_t trav_trips = 0, step_trips = 0;   // wave-uniform: scheduler diagnostics
-    const int stride_bytes = P.stack_stride * 4;
+    const LdsColumn stk{stack, (uint32_t)P.stack_stride};
     for (;;) {
         const int n_trav = __popcll(__ballot(mode == MODE_TRAV));
         const int n_wait = __popcll(__ballot(mode == MODE_WAIT));
@@ -363,7 +362,7 @@ __global__ __launch_bounds__(256, 6) void walk_round_kernel(RoundParams P)
             // ---- step phase ----
             if (mode == MODE_WAIT) {
                 if (!fresh) {
-                    const bool ended = step_finish<NEUMANN_EMISSIVE>(P, L, S, T.best);
+                    const bool ended = step_finish<NEUMANN_EMISSIVE>(P.dm, P.nm, P.st, L, S, T.best);
                     if (ended) {
                         // next sample of this pixel starts right away (generateEvaluationPoints,
                         // reference integrator.cu:90-99 + workqueue.h:99-110)
@@ -397,7 +396,7 @@ __global__ __launch_bounds__(256, 6) void walk_round_kernel(RoundParams P)
             ++trav_trips;
             if (mode == MODE_TRAV) {
                 if (T.level == P.dm.levels) S.leaf_visits++; else S.inner_visits++;
-                if (!trav_visit<true>(P.dm, L.px, L.py, T, stack, stride_bytes, lds_top, P.top_levels)) mode = MODE_WAIT;
+                if (!trav_visit<true>(P.dm, L.px, L.py, T, stk, lds_top, P.top_levels)) mode = MODE_WAIT;
             }
         }
     }
@@ -448,6 +447,10 @@ __global__ __launch_bounds__(256, 6) void walk_round_kernel(RoundParams P)
         atomicAdd(&P.stats->step_trips, (unsigned long long)step_trips);
     }
 }
+
+}  // namespace wost
+#include "wost_pool.h"
+namespace wost {
 
 // ------------------------------------------------------------------------------------------
 // batch query kernels (the lbvh::query_device call sites, exposed for tests and SDF renders)
@@ -614,6 +617,13 @@ struct wost_context {
     int block_size = 256;
     int wait_weight = 8;
     int top_levels = 3;
+    int kernel = 0;        // 0 = round kernel (walker per lane), 1 = pool kernel (walkers in LDS)
+    int pool_k = 2;        // pool kernel: 64 * pool_k walkers per wave
+    int step_weight = 8;
+    int waves_per_cu = 0;  // pool kernel: 0 = as many as LDS admits
+    int pool_stack = 8;    // pool kernel: traversal stack entries kept in LDS per walker
+    uint32_t *spill = nullptr;
+    size_t spill_words = 0;
     int time_kernels = 1;
 };
 
@@ -647,6 +657,7 @@ static void destroy_ctx(wost_context *c)
     if (c->counts) (void)hipFree(c->counts);
     if (c->stats) (void)hipFree(c->stats);
     if (c->field) (void)hipFree(c->field);
+    if (c->spill) (void)hipFree(c->spill);
     if (c->host_count) (void)hipHostFree(c->host_count);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -745,6 +756,21 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "top_levels") {
         if (value < 0 || value > 6) return fail(WOST_ERR_INVALID, "top_levels must be in 0..6");
         h->top_levels = (int)value;
+    } else if (k == "kernel") {
+        if (value != 0 && value != 1) return fail(WOST_ERR_INVALID, "kernel must be 0 (round) or 1 (pool)");
+        h->kernel = (int)value;
+    } else if (k == "pool_k") {
+        if (value < 1 || value > 4) return fail(WOST_ERR_INVALID, "pool_k must be in 1..4");
+        h->pool_k = (int)value;
+    } else if (k == "step_weight") {
+        if (value < 1 || value > 512) return fail(WOST_ERR_INVALID, "step_weight must be in 1..512");
+        h->step_weight = (int)value;
+    } else if (k == "pool_stack") {
+        if (value < 3 || value > 64) return fail(WOST_ERR_INVALID, "pool_stack must be in 3..64");
+        h->pool_stack = (int)value;
+    } else if (k == "waves_per_cu") {
+        if (value < 0 || value > 32) return fail(WOST_ERR_INVALID, "waves_per_cu must be in 0..32");
+        h->waves_per_cu = (int)value;
     } else if (k == "time_kernels") {
         h->time_kernels = value != 0;
     } else {
@@ -797,6 +823,62 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     uint32_t launches = 0;
     int cur = 0;
     const bool emissive = c->nm.view.n_segs > 0 && c->nm.view.emissive;
+    if (c->kernel == 1 && n_active > 0) {
+        // ---- pool kernel: one launch walks every pixel of this call ----
+        PoolParams pp{};
+        pp.dm = c->dm.view;
+        pp.nm = c->nm.view;
+        pp.st = c->dst;
+        pp.q = c->queue[0];
+        pp.n_walkers = n_active;
+        pp.next = c->counts + 1;
+        pp.field = field_dev;
+        pp.field_base = field_base;
+        pp.stats = c->stats;
+        const int full_stack = 3 * (levels + 1) + 4;
+        pp.stack_words = std::min(full_stack, c->pool_stack);
+        pp.step_weight = c->step_weight;
+        const int K = c->pool_k;
+        const size_t pool_lds = ((size_t)(kPoolWordsPerWalker + pp.stack_words) * 64 * K + 64) * sizeof(uint32_t);
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+        int waves_per_cu = (int)((160 * 1024) / pool_lds);
+        if (waves_per_cu < 1) return fail(WOST_ERR_UNSUPPORTED, "tree too deep for the LDS walker pool");
+        if (c->waves_per_cu > 0) waves_per_cu = std::min(waves_per_cu, c->waves_per_cu);
+        const unsigned want = (n_active + 64 * K - 1) / (64 * K);
+        const unsigned grid = std::min<unsigned>(want, (unsigned)(prop.multiProcessorCount * waves_per_cu));
+        // overflow columns of the traversal stacks (entries beyond the LDS part)
+        const size_t spill_words = (size_t)std::max(1, full_stack - pp.stack_words) * grid * 64 * K;
+        if (c->spill_words < spill_words) {
+            if (c->spill) (void)hipFree(c->spill);
+            c->spill = nullptr;
+            c->spill_words = 0;
+            HIP_TRY(hipMalloc((void **)&c->spill, spill_words * sizeof(uint32_t)));
+            c->spill_words = spill_words;
+        }
+        pp.spill = c->spill;
+        HIP_TRY(hipMemsetAsync(c->counts + 1, 0, sizeof(uint32_t), stream));
+        if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
+#define WOST_LAUNCH_POOL(E, KK) hipLaunchKernelGGL((walk_pool_kernel<E, KK>), dim3(grid), dim3(64), pool_lds, stream, pp)
+        if (emissive) {
+            if (K == 1) WOST_LAUNCH_POOL(true, 1); else if (K == 2) WOST_LAUNCH_POOL(true, 2);
+            else if (K == 3) WOST_LAUNCH_POOL(true, 3); else WOST_LAUNCH_POOL(true, 4);
+        } else {
+            if (K == 1) WOST_LAUNCH_POOL(false, 1); else if (K == 2) WOST_LAUNCH_POOL(false, 2);
+            else if (K == 3) WOST_LAUNCH_POOL(false, 3); else WOST_LAUNCH_POOL(false, 4);
+        }
+#undef WOST_LAUNCH_POOL
+        HIP_TRY(hipGetLastError());
+        if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev1, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c->time_kernels) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            kernel_ms += ms;
+        }
+        launches = 1;
+        n_active = 0;
+    }
     while (n_active > 0) {
         const int nxt = cur ^ 1;
         HIP_TRY(hipMemsetAsync(c->counts + nxt, 0, sizeof(uint32_t), stream));
@@ -853,9 +935,9 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         stats->leaf_visits = sd.leaf_visits;
         stats->trav_trips = sd.trav_trips;
         stats->step_trips = sd.step_trips;
+        stats->reserved = (uint32_t)sd.max_stack;
         stats->kernel_ms = kernel_ms;
         stats->kernel_launches = launches;
-        stats->reserved = 0;
         stats->solve_ms = std::chrono::duration<double, std::milli>(t_end - t_start).count();
     }
     return WOST_OK;

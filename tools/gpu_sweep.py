@@ -37,6 +37,7 @@ def main():
         print("     lane utilisation: traversal phase %.3f (trips %d) step phase %.3f (trips %d)" % (
             vis / (64.0 * max(best["trav_trips"], 1)), best["trav_trips"],
             best["walk_steps"] / (64.0 * max(best["step_trips"], 1)), best["step_trips"]), flush=True)
+        print("     max stack depth after a visit: %d" % best["reserved"], flush=True)
     it.close()
 
 
