@@ -246,31 +246,31 @@ __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy,
     const float d0 = d01.x, d1 = d01.y, d2 = d23.x, d3 = d23.y;
     const float bd = T.best.d2;
     const bool at_leaf = (KIND == 2) || (KIND == 0 && T.level == m.levels);
-    if (at_leaf) {
-        // children are segments: exact distances
+    // ---- last level: the children are segments, the distances are exact.  Branch-free in
+    // the common case (one strict winner); exact ties take the rare path.
+    if (KIND != 1) {
         const float mn = fminf(fminf(d0, d1), fminf(d2, d3));
-        if (mn <= bd) {
-            const int slot0 = 4 * T.pos;
-            const int n_eq = (d0 == mn) + (d1 == mn) + (d2 == mn) + (d3 == mn);
-            const int slot = slot0 + ((d0 == mn) ? 0 : (d1 == mn) ? 1 : (d2 == mn) ? 2 : 3);
-            if (n_eq == 1 && mn < bd) {
-                T.best.d2 = mn;
-                T.best.slot = slot;
-                T.best_orig = -1;
-            } else if (n_eq == 1 && slot == T.best.slot) {
-                // the seed segment (temporal hint) met again: nothing to do
-            } else {
-                trav_leaf_ties(m, T, slot0, d0, d1, d2, d3);
-            }
-        }
-    } else {
-        // the (non-negative) distance orders as an integer; level and child index ride in the
-        // low mantissa bits, so five integer compare-exchanges sort the candidates near-first
+        const int n_eq = (d0 == mn) + (d1 == mn) + (d2 == mn) + (d3 == mn);
+        const int slot = 4 * T.pos + ((d0 == mn) ? 0 : (d1 == mn) ? 1 : (d2 == mn) ? 2 : 3);
+        const bool clean = (n_eq == 1);
+        const bool win = at_leaf && clean && mn < bd;
+        // same segment as the current best (the temporal hint met again) needs nothing
+        const bool tie = at_leaf && mn <= bd && !win && !(clean && slot == T.best.slot);
+        T.best.d2 = win ? mn : T.best.d2;
+        T.best.slot = win ? slot : T.best.slot;
+        T.best_orig = win ? -1 : T.best_orig;
+        if (tie) trav_leaf_ties(m, T, 4 * T.pos, d0, d1, d2, d3);
+    }
+    // ---- inner level: near-first order.  The (non-negative) distance orders as an integer;
+    // level and child index ride in the low mantissa bits, so five integer compare-exchanges
+    // sort the candidates.  Lanes at the last level simply have no valid key.
+    if (KIND != 2) {
         const uint32_t tag = (uint32_t)(T.level + 1) << 2;
-        uint32_t k0 = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;
-        uint32_t k1 = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3Fu) | tag | 1u) : 0xffffffffu;
-        uint32_t k2 = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3Fu) | tag | 2u) : 0xffffffffu;
-        uint32_t k3 = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3Fu) | tag | 3u) : 0xffffffffu;
+        const bool inner = !at_leaf;
+        uint32_t k0 = (inner && d0 <= bd) ? ((__float_as_uint(d0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;
+        uint32_t k1 = (inner && d1 <= bd) ? ((__float_as_uint(d1) & ~0x3Fu) | tag | 1u) : 0xffffffffu;
+        uint32_t k2 = (inner && d2 <= bd) ? ((__float_as_uint(d2) & ~0x3Fu) | tag | 2u) : 0xffffffffu;
+        uint32_t k3 = (inner && d3 <= bd) ? ((__float_as_uint(d3) & ~0x3Fu) | tag | 3u) : 0xffffffffu;
         cswap(k0, k1);
         cswap(k2, k3);
         cswap(k0, k2);

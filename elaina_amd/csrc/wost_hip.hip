@@ -67,6 +67,7 @@ struct RoundParams {
     int32_t steps_per_round;
     int32_t stack_stride;  // = blockDim.x
     int32_t wait_weight;   // step phase runs when n_wait * wait_weight >= 8 * n_trav
+    int32_t trav_burst;    // node visits per scheduling decision in the traversal phase
     int32_t top_levels;    // levels of the Dirichlet tree mirrored in LDS
     int32_t top_nodes;     // (4^top_levels - 1) / 3
 };
@@ -394,9 +395,11 @@ __global__ __launch_bounds__(256, 6) void walk_round_kernel(RoundParams P)
         } else {
             // ---- traversal phase: every traversing lane visits one node ----
             ++trav_trips;
-            if (mode == MODE_TRAV) {
-                if (T.level == P.dm.levels) S.leaf_visits++; else S.inner_visits++;
-                if (!trav_visit<true>(P.dm, L.px, L.py, T, stk, lds_top, P.top_levels)) mode = MODE_WAIT;
+            for (int b = 0; b < P.trav_burst; ++b) {
+                if (mode == MODE_TRAV) {
+                    if (T.level == P.dm.levels) S.leaf_visits++; else S.inner_visits++;
+                    if (!trav_visit<true>(P.dm, L.px, L.py, T, stk, lds_top, P.top_levels)) mode = MODE_WAIT;
+                }
             }
         }
     }
@@ -616,6 +619,7 @@ struct wost_context {
     int steps_per_round = 256;
     int block_size = 256;
     int wait_weight = 8;
+    int trav_burst = 3;
     int top_levels = 3;
     int kernel = 0;        // 0 = round kernel (walker per lane), 1 = pool kernel (walkers in LDS)
     int pool_k = 2;        // pool kernel: 64 * pool_k walkers per wave
@@ -753,6 +757,9 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "wait_weight") {
         if (value < 1 || value > 512) return fail(WOST_ERR_INVALID, "wait_weight must be in 1..512");
         h->wait_weight = (int)value;
+    } else if (k == "trav_burst") {
+        if (value < 1 || value > 16) return fail(WOST_ERR_INVALID, "trav_burst must be in 1..16");
+        h->trav_burst = (int)value;
     } else if (k == "top_levels") {
         if (value < 0 || value > 6) return fail(WOST_ERR_INVALID, "top_levels must be in 0..6");
         h->top_levels = (int)value;
@@ -897,6 +904,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         rp.steps_per_round = c->steps_per_round;
         rp.stack_stride = bs;
         rp.wait_weight = c->wait_weight;
+        rp.trav_burst = c->trav_burst;
         rp.top_levels = std::min(c->top_levels, levels + 1);
         if (c->dm.view.n_segs == 0) rp.top_levels = 0;
         rp.top_nodes = 0;
