@@ -530,6 +530,9 @@ static int fail(int code, const std::string &msg)
     return code;
 }
 
+// shared with the other translation units of the library (wost_vmm.hip)
+int set_error(int code, const std::string &msg) { return fail(code, msg); }
+
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \

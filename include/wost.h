@@ -132,6 +132,27 @@ int wost_ray_intersect(wost_handle h, int which_mesh, const float *origins, cons
                        const float *tmax, int32_t n, int32_t *out_hit, float *out_t,
                        int32_t *out_idx);
 
+/* ---- guided path, deterministic distribution layer (first slice of SURVEY 8a row a24) -------
+ * Batch entry points over HOST arrays; no handle, `device` selects the GPU. */
+
+/* logModifiedBesselFn(x, 0|1), VonMises::log_eval(cos), VonMises::d_log_eval_d_kappa(cos)
+ * (reference util/vonmises.h:75-93,128-163) for n (kappa, cos_theta) pairs; any output may
+ * be NULL. */
+int wost_vonmises_eval(int device, const float *kappa, const float *cos_theta, int32_t n,
+                       float *log_i0, float *log_i1, float *log_pdf, float *dlogpdf_dkappa);
+
+/* rejectionSample(kappa, proposalR, sampler) (util/vonmises.h:95-118): per point a PCG32
+ * stream setSeed(seed[i], 1) and per_point consecutive angles in theta[n*per_point]. */
+int wost_vonmises_sample(int device, const float *kappa, const uint64_t *seed, int32_t n,
+                         int32_t per_point, float *theta);
+
+/* VMM<2,8> built from 32 raw network outputs per point (integrator/guided/distribution.h:
+ * 146-168, train.h:50-79): mixture pdf at direction wi[n*2] (pdf may be NULL) and one sampled
+ * direction per point with the stream setSeed(seed[i], 1) (distribution.h:186-198;
+ * sample_dir may be NULL). */
+int wost_vmm_pdf_sample(int device, const float *raw, const float *wi, const uint64_t *seed,
+                        int32_t n, float *pdf, float *sample_dir);
+
 /* Tuning knobs ("steps_per_round", "block_size", ...); unknown keys -> WOST_ERR_INVALID. */
 int wost_set_option(wost_handle h, const char *key, double value);
 

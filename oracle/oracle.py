@@ -16,7 +16,7 @@ _BUILD = os.path.join(_HERE, "_build")
 def build(force=False):
     """Compile the oracle with gcc (plain C, seconds)."""
     targets = [os.path.join(_BUILD, "libwost_oracle.so"), os.path.join(_BUILD, "libwost_oracle_libm.so")]
-    src = [os.path.join(_HERE, "wost_oracle.c"), os.path.join(_HERE, "wost_oracle.h")]
+    src = [os.path.join(_HERE, "wost_oracle.c"), os.path.join(_HERE, "wost_oracle.h"), os.path.join(_HERE, "wost_vmm.c")]
     stale = force or any(
         (not os.path.exists(t)) or os.path.getmtime(t) < max(os.path.getmtime(s) for s in src) for t in targets
     )
@@ -261,3 +261,33 @@ class Oracle:
 
     def logf(self, x):
         return float(self.lib.wo_logf(C.c_float(x)))
+
+    # ---- guided path: von Mises / mixture --------------------------------------------------
+    def eval_poly_large0(self, y):
+        self.lib.wo_eval_poly_large0.restype = C.c_float
+        return float(self.lib.wo_eval_poly_large0(C.c_float(y)))
+
+    def vonmises_eval(self, kappa, cos_theta):
+        k = np.ascontiguousarray(kappa, dtype=np.float32)
+        c = np.ascontiguousarray(cos_theta, dtype=np.float32)
+        n = len(k)
+        out = [np.zeros(n, dtype=np.float32) for _ in range(4)]
+        self.lib.wo_vonmises_eval(_fp(k), _fp(c), n, *[_fp(o) for o in out])
+        return dict(zip(("log_i0", "log_i1", "log_pdf", "dlog_dkappa"), out))
+
+    def vonmises_sample(self, kappa, seed, per_point=1):
+        k = np.ascontiguousarray(kappa, dtype=np.float32)
+        s = np.ascontiguousarray(seed, dtype=np.uint64)
+        th = np.zeros(len(k) * per_point, dtype=np.float32)
+        self.lib.wo_vonmises_sample(_fp(k), s.ctypes.data_as(C.POINTER(C.c_uint64)), len(k), per_point, _fp(th))
+        return th.reshape(len(k), per_point)
+
+    def vmm_pdf_sample(self, raw, wi, seed):
+        r = np.ascontiguousarray(raw, dtype=np.float32)
+        w = np.ascontiguousarray(wi, dtype=np.float32)
+        s = np.ascontiguousarray(seed, dtype=np.uint64)
+        n = len(w)
+        pdf = np.zeros(n, dtype=np.float32)
+        d = np.zeros((n, 2), dtype=np.float32)
+        self.lib.wo_vmm_pdf_sample(_fp(r), _fp(w), s.ctypes.data_as(C.POINTER(C.c_uint64)), n, _fp(pdf), _fp(d))
+        return pdf, d

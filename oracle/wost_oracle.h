@@ -124,6 +124,14 @@ int wo_solve(const wo_scene *sc, const wo_settings *st, int pixel_begin, int pix
 int wo_render_dirichlet_sdf(const wo_scene *sc, const wo_settings *st, int n_threads,
                             float *out_dist);
 
+/* ---- guided path, deterministic distribution layer (oracle/wost_vmm.c) ---- */
+float wo_eval_poly_large0(float y);
+float wo_log_bessel(float x, int order);
+int wo_vonmises_eval(const float *kappa, const float *cos_theta, int n, float *log_i0, float *log_i1,
+                     float *log_pdf, float *dlog_dkappa);
+int wo_vonmises_sample(const float *kappa, const uint64_t *seed, int n, int per_point, float *theta);
+int wo_vmm_pdf_sample(const float *raw, const float *wi, const uint64_t *seed, int n, float *pdf, float *dir);
+
 const char *wo_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,209 @@
+/*
+ * wost_vmm.c -- CPU oracle for the deterministic pieces of the GUIDED path's directional
+ * distribution: polynomial log-Bessel, von Mises pdf and d/dkappa,
+ * Best-Fisher rejection sampling in double precision, and the 8-lobe mixture VMM<2,8> built
+ * from raw network outputs.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Restates (paths relative to /root/reference):
+ *   util/vonmises.h:17-93 (coefficients, evalPoly, logModifiedBesselFn), :95-118
+ *   (rejectionSample), :121-209 (VonMises), integrator/guided/distribution.h:19-45,136-198
+ *   (VMFKernel<2>, VMM<2,N>), integrator/guided/train.h:50-79 (output activations),
+ *   util/transformation.h:47-50 (frameFromTangent), core/sampler.h:74-85 (nextDouble).
+ * Pinned by the reference's own known-answer constants (test/vonmises_test.cu:5-22,57-59,
+ * 124-148, commented out there but numerically valid -- SURVEY.md section 4).
+ * Transcendentals are libm here and ocml on the GPU: parity is within the 1e-5 relative
+ * tolerance the reference's tests use, not bit-exact.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "wost_oracle.h"
+
+#define WV_2PI 6.28318530717958647693f
+#define WV_PI_D 3.14159265358979323846
+
+static const float COEF_SMALL[2][7] = {
+    {1.0f, 3.5156229f, 3.0899424f, 1.2067492f, 0.2659732f, 0.360768e-1f, 0.45813e-2f},
+    {0.5f, 0.87890594f, 0.51498869f, 0.15084934f, 0.2658733e-1f, 0.301532e-2f, 0.32411e-3f}};
+static const float COEF_LARGE[2][9] = {
+    {0.39894228f, 0.1328592e-1f, 0.225319e-2f, -0.157565e-2f, 0.916281e-2f, -0.2057706e-1f, 0.2635537e-1f,
+     -0.1647633e-1f, 0.392377e-2f},
+    {0.39894228f, -0.3988024e-1f, -0.362018e-2f, 0.163801e-2f, -0.1031555e-1f, 0.2282967e-1f, -0.2895312e-1f,
+     0.1787654e-1f, -0.420059e-2f}};
+
+float wo_eval_poly(float y, const float *coeff, int n)
+{
+    float ret = coeff[n - 1];
+    for (int i = n - 2; i >= 0; --i) ret = coeff[i] + y * ret;
+    return ret;
+}
+
+float wo_eval_poly_large0(float y) { return wo_eval_poly(y, COEF_LARGE[0], 9); }
+
+float wo_log_bessel(float x, int order)
+{
+    float y = x / 3.75f;
+    y *= y;
+    float small = wo_eval_poly(y, COEF_SMALL[order], 7);
+    if (order == 1) small = fabsf(x) * small;
+    small = logf(small);
+    y = 3.75f / x;
+    float large = x - 0.5f * logf(x) + logf(wo_eval_poly(y, COEF_LARGE[order], 9));
+    return (x < 3.75) ? small : large;
+}
+
+float wo_vm_log_eval(float kappa, float cos_theta)
+{
+    float ret = kappa * cos_theta;
+    return ret - logf(WV_2PI) - wo_log_bessel(kappa, 0);
+}
+
+float wo_vm_eval(float kappa, float cos_theta)
+{
+    if (kappa < 1e-3f) return 1.0f / WV_2PI;
+    return expf(wo_vm_log_eval(kappa, cos_theta));
+}
+
+float wo_vm_dlog_dkappa(float kappa, float cosTheta)
+{
+    if (kappa < 3.75f) {
+        const float *coeff = COEF_SMALL[0];
+        const float coef = 0.0711111111111111f, c142 = 0.142222222222222f, c010 = 0.0101135802469136f;
+        float kappa2 = kappa * kappa;
+        float term7 = coeff[6] * kappa2;
+        float term6 = coeff[5] + coef * term7;
+        float term5 = coeff[4] + coef * kappa2 * term6;
+        float term4 = coeff[3] + coef * kappa2 * term5;
+        float term3 = coeff[2] + coef * kappa2 * term4;
+        float term2 = coeff[1] + coef * kappa2 * term3;
+        float numerator = coef * kappa2 * (coef * kappa2 * (coef * kappa2 * (coef * kappa2 * (c010 * coeff[6] * kappa * kappa2 + c142 * kappa * term6) + c142 * kappa * term5) + c142 * kappa * term4) + c142 * kappa * term3) + c142 * kappa * term2;
+        float denominator = coeff[0] + coef * kappa2 * term2;
+        return cosTheta - (numerator / denominator);
+    } else {
+        /* vonmises.h:153-161: the analytic derivative of the large-argument branch; the
+         * reference spells the nested Horner form out in double constants -- same value: */
+        const float *K = COEF_LARGE[0];
+        double x = kappa, t = 3.75 / x;
+        /* P(t) = sum K_i t^i, dP/dx = -(t/x) * sum i K_i t^(i-1) */
+        double P = 0.0, dP = 0.0;
+        for (int i = 8; i >= 0; --i) P = K[i] + t * P;
+        for (int i = 8; i >= 1; --i) dP = i * (double)K[i] + t * dP;
+        dP *= -(t / x);
+        /* d/dx [x - 0.5 log x + log P] = 1 - 0.5/x + dP/P ; d log p = cos - that */
+        return (float)(cosTheta - 1.0 - dP / P + 0.5 / x);
+    }
+}
+
+double wo_vm_proposal_r(float kappa)
+{
+    double k = kappa;
+    double tau = 1.0 + sqrt(1.0 + 4.0 * k * k);
+    double rho = (tau - sqrt(2.0 * tau)) / (2.0 * k);
+    double proposalR = (1.0 + rho * rho) / (2.0 * rho);
+    double proposalRTaylor = 1.0 / k + k;
+    return (kappa < 1e-5) ? proposalRTaylor : proposalR;
+}
+
+float wo_vm_rejection_sample(float kappa, double proposal_r, wo_pcg *rng)
+{
+    if (kappa < 1e-3f) return WV_2PI * wo_pcg_next_float(rng);
+    for (;;) {
+        double u1 = wo_pcg_next_double(rng);
+        double u2 = wo_pcg_next_double(rng);
+        double u3 = wo_pcg_next_double(rng);
+        double z = cos(WV_PI_D * u1);
+        double f = (1.0 + proposal_r * z) / (proposal_r + z);
+        double c = (double)kappa * (proposal_r - f);
+        int accept = ((c * (2.0 - c) - u2) > 0.0) || (log(c / u2) + 1.0 - c >= 0.0);
+        if (accept)
+            return (float)(fmod((copysign(1.0, u3 - 0.5) * acos(f)) + WV_PI_D, 2 * WV_PI_D) - WV_PI_D);
+    }
+}
+
+/* ---- VMM<2,8> ------------------------------------------------------------------------- */
+#define WV_NCOMP 8
+
+typedef struct { float lambda, kappa, mux, muy, ox, oy; } wv_lobe;
+typedef struct { wv_lobe sg[WV_NCOMP]; float weight[WV_NCOMP]; float total; } wv_vmm;
+
+static float clampf(float v, float lo, float hi) { return fmaxf(fminf(v, hi), lo); }
+
+static void vmm_build(wv_vmm *m, const float *data)
+{
+    m->total = 0.0f;
+    for (int i = 0; i < WV_NCOMP; ++i) {
+        const float *d = data + 4 * i;
+        m->sg[i].lambda = expf(clampf(d[0], -10.0f, 15.0f));   /* train.h:60-72, Exponential */
+        m->sg[i].kappa = expf(clampf(d[1], -10.0f, 15.0f));
+        m->sg[i].ox = d[2]; m->sg[i].oy = d[3];                 /* None */
+        float n = sqrtf(d[2] * d[2] + d[3] * d[3]);
+        m->sg[i].mux = d[2] / n; m->sg[i].muy = d[3] / n;
+        m->total += m->sg[i].lambda;
+    }
+    for (int i = 0; i < WV_NCOMP; ++i) m->weight[i] = m->sg[i].lambda / m->total;
+}
+
+static float vmm_pdf(const wv_vmm *m, float wx, float wy)
+{
+    float val = 0.0f;
+    for (int i = 0; i < WV_NCOMP; ++i)
+        val += m->weight[i] * wo_vm_eval(m->sg[i].kappa, wx * m->sg[i].mux + wy * m->sg[i].muy);
+    return val;
+}
+
+static void lobe_sample(const wv_lobe *l, wo_pcg *rng, float *ox, float *oy)
+{
+    float theta = wo_vm_rejection_sample(l->kappa, wo_vm_proposal_r(l->kappa), rng);
+    float vx = cosf(theta), vy = sinf(theta);
+    /* frameFromTangent(mu): N = normalize(-mu.y, mu.x), T = mu; world = T*v.x + N*v.y */
+    float px = -l->muy, py = l->mux;
+    float pl = sqrtf(px * px + py * py);
+    px /= pl; py /= pl;
+    *ox = l->mux * vx + px * vy;
+    *oy = l->muy * vx + py * vy;
+}
+
+int wo_vonmises_eval(const float *kappa, const float *cos_theta, int n, float *log_i0, float *log_i1,
+                     float *log_pdf, float *dlog_dkappa)
+{
+    for (int i = 0; i < n; ++i) {
+        if (log_i0) log_i0[i] = wo_log_bessel(kappa[i], 0);
+        if (log_i1) log_i1[i] = wo_log_bessel(kappa[i], 1);
+        if (log_pdf) log_pdf[i] = wo_vm_log_eval(kappa[i], cos_theta[i]);
+        if (dlog_dkappa) dlog_dkappa[i] = wo_vm_dlog_dkappa(kappa[i], cos_theta[i]);
+    }
+    return 0;
+}
+
+int wo_vonmises_sample(const float *kappa, const uint64_t *seed, int n, int per_point, float *theta)
+{
+    for (int i = 0; i < n; ++i) {
+        wo_pcg rng;
+        wo_pcg_set_seed(&rng, seed[i], 1);
+        double pr = wo_vm_proposal_r(kappa[i]);
+        for (int k = 0; k < per_point; ++k) theta[(size_t)i * per_point + k] = wo_vm_rejection_sample(kappa[i], pr, &rng);
+    }
+    return 0;
+}
+
+int wo_vmm_pdf_sample(const float *raw, const float *wi, const uint64_t *seed, int n, float *pdf, float *dir)
+{
+    for (int i = 0; i < n; ++i) {
+        wv_vmm m;
+        vmm_build(&m, raw + 32 * (size_t)i);
+        if (pdf) pdf[i] = vmm_pdf(&m, wi[2 * i], wi[2 * i + 1]);
+        if (dir) {
+            wo_pcg rng;
+            wo_pcg_set_seed(&rng, seed[i], 1);
+            float u = wo_pcg_next_float(&rng);      /* distribution.h:186-198 */
+            int pick = 0, found = 0;
+            for (int k = 0; k < WV_NCOMP && !found; ++k) {
+                if (u < m.weight[k]) { pick = k; found = 1; }
+                else u -= m.weight[k];
+            }
+            lobe_sample(&m.sg[pick], &rng, &dir[2 * i], &dir[2 * i + 1]);
+        }
+    }
+    return 0;
+}

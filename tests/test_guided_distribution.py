@@ -1,0 +1,126 @@
+"""Guided path, distribution layer: the oracle against the reference's
+own known-answer constants (test/vonmises_test.cu, commented out there but numerically valid),
+and the HIP entry points against the oracle within the reference tests' 1e-5 tolerance."""
+import math
+
+import numpy as np
+import pytest
+
+REL = 1e-5  # Catch::Matchers::WithinRel(..., 1e-5f) in the reference tests
+
+
+def test_eval_poly_kat(oracle):
+    # test/vonmises_test.cu:5-9
+    assert oracle.eval_poly_large0(1.14514) == pytest.approx(0.4184690292340133, rel=REL)
+
+
+def test_log_bessel_kat(oracle):
+    # test/vonmises_test.cu:11-22
+    r = oracle.vonmises_eval([1.0, 2.0, 3.0, 4.0], [0, 0, 0, 0])
+    assert np.allclose(r["log_i0"], [0.23591432, 0.82399356, 1.58530772, 2.42497277], rtol=REL)
+
+
+def test_von_mises_log_pdf_kat(oracle):
+    # test/vonmises_test.cu:57-59 (kappa 4.2; today's API takes cos(theta): util/vonmises.h:128-133)
+    th = np.array([-2.0, -1.0, 0.0, 1.0, 2.0])
+    r = oracle.vonmises_eval([4.2] * 5, np.cos(th))
+    assert np.allclose(r["log_pdf"], [-6.18411160, -2.16702533, -0.23629522, -2.16702533, -6.18411160], rtol=REL)
+    assert np.allclose(np.exp(r["log_pdf"]), [0.00206193, 0.11451776, 0.78954756, 0.11451776, 0.00206193], rtol=1e-4)
+
+
+def test_von_mises_dlog_dkappa_kat(oracle):
+    # test/vonmises_test.cu:124-148: small-kappa and large-kappa branches
+    r = oracle.vonmises_eval([1.45, 14.5], np.cos([0.5, 0.5]))
+    assert r["dlog_dkappa"][0] == pytest.approx(0.29405486583709717, rel=REL)
+    assert r["dlog_dkappa"][1] == pytest.approx(-0.08729398250579834, rel=REL)
+
+
+@pytest.mark.parametrize("kappa,n,eps", [(1.45, 200000, 0.02), (145.0, 20000, 0.05), (1e-4, 50000, None)])
+def test_von_mises_sampling_moments(oracle, kappa, n, eps):
+    # test/vonmises_test.cu:72-122: circular mean ~ 0 and circular variance 1 - I1/I0, seed 42
+    th = oracle.vonmises_sample([kappa], [42], n)[0]
+    if eps is None:   # kappa < 1e-3: uniform on [0, 2pi)
+        assert th.min() >= 0 and th.max() < 2 * math.pi and abs(th.mean() - math.pi) < 0.05
+        return
+    assert abs(th.mean()) < 0.1
+    R = math.hypot(np.cos(th).mean(), np.sin(th).mean())
+    r = oracle.vonmises_eval([kappa], [0.0])
+    theory = 1.0 - math.exp(float(r["log_i1"][0]) - float(r["log_i0"][0]))
+    assert (1.0 - R) == pytest.approx(theory, rel=eps)
+
+
+def _random_vmm(rng, n):
+    raw = rng.normal(0, 1.5, size=(n, 32)).astype(np.float32)
+    raw[:, 1::4] = rng.uniform(-3, 5, size=(n, 8))      # log kappa
+    ang = rng.uniform(0, 2 * np.pi, size=n)
+    wi = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+    return raw, wi
+
+
+def test_vmm_pdf_integrates_to_one(oracle):
+    rng = np.random.default_rng(0)
+    raw, _ = _random_vmm(rng, 4)
+    ang = (np.arange(4096) + 0.5) * (2 * np.pi / 4096)
+    wi = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+    for k in range(4):
+        pdf, _ = oracle.vmm_pdf_sample(np.repeat(raw[k:k + 1], 4096, 0), wi, np.zeros(4096, np.uint64))
+        assert pdf.sum() * (2 * np.pi / 4096) == pytest.approx(1.0, abs=2e-3)
+
+
+def test_vmm_samples_follow_the_pdf(oracle):
+    rng = np.random.default_rng(1)
+    raw, _ = _random_vmm(rng, 1)
+    n = 60000
+    _, d = oracle.vmm_pdf_sample(np.repeat(raw, n, 0), np.zeros((n, 2), np.float32), np.arange(n, dtype=np.uint64))
+    assert np.allclose(np.hypot(d[:, 0], d[:, 1]), 1.0, atol=1e-5)
+    bins = 16
+    hist, _ = np.histogram(np.arctan2(d[:, 1], d[:, 0]), bins=bins, range=(-np.pi, np.pi))
+    ang = (np.arange(4096) + 0.5) * (2 * np.pi / 4096) - np.pi
+    wi = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+    pdf, _ = oracle.vmm_pdf_sample(np.repeat(raw, 4096, 0), wi, np.zeros(4096, np.uint64))
+    expect = pdf.reshape(bins, -1).sum(1) * (2 * np.pi / 4096) * n
+    assert np.all(np.abs(hist - expect) < 5 * np.sqrt(expect + 1) + 0.01 * n / bins)
+
+
+@pytest.mark.gpu
+def test_hip_vonmises_eval_matches_oracle_and_kats(oracle):
+    from elaina_amd import guided
+    rng = np.random.default_rng(3)
+    kappa = np.concatenate([[1.0, 2.0, 3.0, 4.0, 4.2, 1.45, 14.5], np.exp(rng.uniform(-9, 9, 20000))]).astype(np.float32)
+    cos = np.concatenate([[0, 0, 0, 0, 1, math.cos(0.5), math.cos(0.5)], rng.uniform(-1, 1, 20000)]).astype(np.float32)
+    got = guided.vonmises_eval(kappa, cos)
+    ref = oracle.vonmises_eval(kappa, cos)
+    assert np.allclose(got["log_i0"][:4], [0.23591432, 0.82399356, 1.58530772, 2.42497277], rtol=REL)
+    assert got["dlog_dkappa"][5] == pytest.approx(0.29405486583709717, rel=REL)
+    assert got["dlog_dkappa"][6] == pytest.approx(-0.08729398250579834, rel=REL)
+    for k in ("log_i0", "log_i1", "log_pdf"):
+        assert np.allclose(got[k], ref[k], rtol=REL, atol=2e-6 * np.maximum(1.0, np.abs(kappa))), k
+    # the derivative cancels to ~1/kappa^2 at large kappa: compare on the scale of its terms
+    assert np.allclose(got["dlog_dkappa"], ref["dlog_dkappa"], rtol=REL, atol=3e-6)
+
+
+@pytest.mark.gpu
+def test_hip_vonmises_sampling_matches_oracle(oracle):
+    from elaina_amd import guided
+    rng = np.random.default_rng(4)
+    kappa = np.exp(rng.uniform(-8, 7, 4000)).astype(np.float32)
+    seed = rng.integers(0, 2**62, 4000).astype(np.uint64)
+    got = guided.vonmises_sample(kappa, seed, 8)
+    ref = oracle.vonmises_sample(kappa, seed, 8)
+    # identical PCG streams and double-precision acceptance tests: the same trials are accepted
+    # except where libm/ocml differ in the last bits of a borderline comparison (vanishingly rare)
+    close = np.isclose(got, ref, rtol=0, atol=2e-6)
+    assert close.mean() > 0.9995, close.mean()
+
+
+@pytest.mark.gpu
+def test_hip_vmm_pdf_and_sample_match_oracle(oracle):
+    from elaina_amd import guided
+    rng = np.random.default_rng(5)
+    raw, wi = _random_vmm(rng, 30000)
+    seed = rng.integers(0, 2**62, 30000).astype(np.uint64)
+    gp, gd = guided.vmm_pdf_sample(raw, wi, seed)
+    rp, rd = oracle.vmm_pdf_sample(raw, wi, seed)
+    assert np.allclose(gp, rp, rtol=1e-4, atol=1e-7)     # 1e-4 agreement of the VMM sub-kernels
+    close = np.isclose(gd, rd, rtol=0, atol=1e-5).all(1)
+    assert close.mean() > 0.999, close.mean()
