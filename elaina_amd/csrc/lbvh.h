@@ -39,7 +39,7 @@ struct FlatSeg {
     float hl, pad0, pad1, pad2;   // ... and half length (64-byte record)
 };
 
-// silhouette candidate (one per mesh vertex that has at least one incident segment)
+// silhouette candidate, one per mesh vertex (indexed by vertex id)
 struct SilVertex {
     float x, y;
     int32_t prev, next;  // segment ending / starting at this vertex, -1 if none
@@ -58,6 +58,13 @@ struct HostTree {
     // boxes, SoA: cx[4] cy[4] ux[4] uy[4] hl[4] hw[4].  Children of the nodes of the last
     // level are the segments themselves (hw = 0, no padding: that distance is exact).
     std::vector<float> nodes;
+    // 20 floats per node: the SNCH normal cones of the four children, SoA:
+    // axis.x[4] axis.y[4] cos(half)[4] sin(half)[4] radius[4].  The cone of a child covers the
+    // normals of every segment incident to a vertex of its subtree; cos(half) <= 0 marks
+    // "cannot prune" (open polyline end inside, or normals spread over >= 90 degrees).  The
+    // radius bounds the subtree's vertices around the child's box centre.
+    std::vector<float> cones;
+    std::vector<int32_t> segVerts; // 2 ints per slot: the segment's vertex ids (-1 padding)
     std::vector<float> segA;      // 4 floats per slot
     std::vector<float> segInv;    // 1 float per slot
     std::vector<int32_t> segOrig; // original index per slot (kFarIndex for padding)
@@ -65,7 +72,7 @@ struct HostTree {
     std::vector<int32_t> origToSlot;
     std::vector<FlatSeg> flat;    // original order
     std::vector<float> flatCol;   // 12 floats per original segment
-    std::vector<SilVertex> sil;   // silhouette candidates
+    std::vector<SilVertex> sil;   // one per mesh vertex (prev = next = -1: no incident segment)
     float aabb[4] = {0, 0, 0, 0}; // lox, loy, hix, hiy of the mesh
 };
 

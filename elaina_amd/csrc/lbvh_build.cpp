@@ -87,10 +87,8 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
         }
     }
     t->aabb[0] = lox; t->aabb[1] = loy; t->aabb[2] = hix; t->aabb[3] = hiy;
-    for (int v = 0; v < n_verts; ++v) {
-        if (vprev[v] < 0 && vnext[v] < 0) continue;
-        t->sil.push_back(SilVertex{verts[2 * v], verts[2 * v + 1], vprev[v], vnext[v]});
-    }
+    t->sil.resize(n_verts);
+    for (int v = 0; v < n_verts; ++v) t->sil[v] = SilVertex{verts[2 * v], verts[2 * v + 1], vprev[v], vnext[v]};
 
     // ---- Morton order of centroids -----------------------------------------------------
     const double sx = (hix > lox) ? 65535.0 / ((double)hix - lox) : 0.0;
@@ -366,6 +364,77 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
                     set_child(t->first_leaf + k, j, s.cx, s.cy, s.ux, s.uy, s.hl, 0.0f);
                 }
             }
+    }
+    // ---- SNCH normal cones + per-slot vertex ids ------------------------------------------
+    {
+        const int n_all = t->first_leaf + cap;
+        t->cones.assign((size_t)n_all * 20, 0.0f);
+        t->segVerts.assign(n_slots * 2, -1);
+        for (size_t k = 0; k < n_slots; ++k) {
+            const int o = slot_of[k];
+            if (o < 0) continue;
+            t->segVerts[2 * k] = segs[2 * o];
+            t->segVerts[2 * k + 1] = segs[2 * o + 1];
+        }
+        // per node (heap index): angles of the relevant normals, "has an open end", vertices
+        struct Acc { std::vector<double> ang; bool open = false; std::vector<double> pts; };
+        std::vector<Acc> acc(n_all);
+        auto add_seg_normal = [&](Acc &a, int sidx) {
+            const FlatSeg &s = t->flat[sidx];
+            if (s.len > 0.0f) a.ang.push_back(std::atan2((double)s.ny, (double)s.nx));
+        };
+        for (int k = 0; k < cap; ++k) {
+            Acc &a = acc[t->first_leaf + k];
+            for (int j = 0; j < kLeafSize; ++j) {
+                const int o = slot_of[(size_t)k * kLeafSize + j];
+                if (o < 0) continue;
+                add_seg_normal(a, o);
+                for (int e = 0; e < 2; ++e) {
+                    const int v = segs[2 * o + e];
+                    a.pts.push_back(verts[2 * v]); a.pts.push_back(verts[2 * v + 1]);
+                    if (vprev[v] < 0 || vnext[v] < 0) a.open = true;
+                    if (vprev[v] >= 0) add_seg_normal(a, vprev[v]);
+                    if (vnext[v] >= 0) add_seg_normal(a, vnext[v]);
+                }
+            }
+        }
+        for (int g = t->first_leaf - 1; g >= 1; --g)
+            for (int j = 1; j <= kArity; ++j) {
+                const Acc &c = acc[kArity * g + j];
+                acc[g].ang.insert(acc[g].ang.end(), c.ang.begin(), c.ang.end());
+                acc[g].pts.insert(acc[g].pts.end(), c.pts.begin(), c.pts.end());
+                acc[g].open = acc[g].open || c.open;
+            }
+        auto set_cone = [&](int parent, int j, float ax, float ay, float ch, float sh, float rad) {
+            float *cn = &t->cones[(size_t)parent * 20];
+            cn[0 + j] = ax; cn[4 + j] = ay; cn[8 + j] = ch; cn[12 + j] = sh; cn[16 + j] = rad;
+        };
+        const double two_pi = 2.0 * M_PI;
+        auto fit = [&](int parent, int j, Acc &a, float cx, float cy) {
+            double rad = 0.0;
+            for (size_t i = 0; i + 1 < a.pts.size(); i += 2)
+                rad = std::max(rad, std::hypot(a.pts[i] - (double)cx, a.pts[i + 1] - (double)cy));
+            const float radf = (float)(rad * (1.0 + 1e-6) + (double)ext * 0x1p-18);
+            if (a.open || a.ang.empty()) { set_cone(parent, j, 1.0f, 0.0f, -1.0f, 0.0f, radf); return; }
+            std::sort(a.ang.begin(), a.ang.end());
+            double gap = a.ang.front() + two_pi - a.ang.back(), gap_end = a.ang.front() + two_pi;
+            for (size_t i = 1; i < a.ang.size(); ++i)
+                if (a.ang[i] - a.ang[i - 1] > gap) { gap = a.ang[i] - a.ang[i - 1]; gap_end = a.ang[i]; }
+            const double arc = two_pi - gap;              // smallest arc containing every normal
+            const double half = 0.5 * arc + 1e-4;        // padded
+            if (half >= 0.5 * M_PI - 1e-3) { set_cone(parent, j, 1.0f, 0.0f, -1.0f, 0.0f, radf); return; }
+            const double mid = gap_end + 0.5 * arc;       // arc starts where the largest gap ends
+            set_cone(parent, j, (float)std::cos(mid), (float)std::sin(mid), (float)std::cos(half), (float)std::sin(half), radf);
+        };
+        for (int g = 0; g < t->first_leaf; ++g)
+            for (int j = 0; j < kArity; ++j) {
+                const float *nd = &t->nodes[(size_t)g * 24];
+                fit(g, j, acc[kArity * g + 1 + j], nd[0 + j], nd[4 + j]);
+            }
+        // last level: the "children" are single segments; their candidates are their two
+        // endpoints, tested exactly by the query, so no cone is needed (cannot prune)
+        for (int k = 0; k < cap; ++k)
+            for (int j = 0; j < kLeafSize; ++j) set_cone(t->first_leaf + k, j, 1.0f, 0.0f, -1.0f, 0.0f, 0.0f);
     }
     return 0;
 }

@@ -39,7 +39,9 @@ struct DevMesh {
     const float *segCol;     // [slots*12]
     const DevFlatSeg *flat;  // [n_segs] original order
     const float *flatCol;    // [n_segs*12]
-    const DevSilVertex *sil; // [n_sil]
+    const DevSilVertex *sil; // [n_sil] one per mesh vertex
+    const float4 *cones;     // [n_nodes * 5]: SNCH cones of the children: ax[4] ay[4] cos[4] sin[4] rad[4]
+    const int2 *segVerts;    // [slots] vertex ids of the slot's segment
     int32_t n_segs;
     int32_t n_sil;
     int32_t levels;
@@ -338,6 +340,7 @@ __device__ __forceinline__ float closest_silhouette_flat(const DevMesh &m, float
     bool found = false;
     for (int v = 0; v < m.n_sil; ++v) {
         const DevSilVertex sv = m.sil[v];
+        if (sv.prev < 0 && sv.next < 0) continue;  // vertex without segments
         float vx = qx - sv.x, vy = qy - sv.y;
         float d2 = dot2(vx, vy, vx, vy);
         if (d2 > best2) continue;
@@ -444,6 +447,217 @@ __device__ __forceinline__ int sample_in_sphere_flat(const DevMesh &m, float qx,
     float len = m.flat[last].len;
     pdf = (len / total) / len;
     return last;
+}
+
+// ---- the same queries on the wide LBVH, for boundary meshes too large for flat loops -------
+// Results are identical to the flat loops (layout-independent definitions); the tree only
+// prunes.  `stk` is any free traversal-stack column of the lane / walker.
+
+// silhouette predicate of one vertex (FCPW isSilhouetteVertex, flipNormalOrientation = false)
+__device__ __forceinline__ bool vertex_is_silhouette(const DevMesh &m, const DevSilVertex &sv, float vx, float vy, float d2)
+{
+    if (sv.prev < 0 || sv.next < 0) return true;
+    const DevFlatSeg s0 = m.flat[sv.prev], s1 = m.flat[sv.next];
+    const float d = sqrtf(d2);
+    if (d <= WOST_SIL_PRECISION) {
+        const float det = cross2(s0.nx, s0.ny, s1.nx, s1.ny);
+        return -det > WOST_SIL_PRECISION;
+    }
+    const float ux = vx / d, uy = vy / d;
+    const float dot0 = dot2(ux, uy, s0.nx, s0.ny);
+    const float dot1 = dot2(ux, uy, s1.nx, s1.ny);
+    if (fabsf(dot0) <= WOST_SIL_PRECISION || fabsf(dot1) <= WOST_SIL_PRECISION) return false;
+    return dot0 * dot1 < 0.0f;
+}
+
+// SNCH test (Sawhney et al. 2023, "Walk on Stars", spatialized normal cone hierarchy): can the
+// subtree whose normals lie in the cone (axis, half angle) and whose vertices lie in the disc
+// (c, rad) contain a silhouette seen from q?  A silhouette needs a normal perpendicular to a
+// view direction, i.e. pi/2 inside [angle(axis, view) -/+ (half + view half angle)].
+// Trig-free and conservative: |cos(angle)| <= sin(half + viewhalf), slack added.
+__device__ __forceinline__ bool cone_may_hold_silhouette(float ax, float ay, float ch, float sh, float rad, float cx, float cy,
+                                                        float qx, float qy)
+{
+    if (ch <= 0.0f) return true;                 // marked "cannot prune"
+    const float wx = cx - qx, wy = cy - qy;
+    const float l2 = dot2(wx, wy, wx, wy);
+    if (l2 <= rad * rad * 1.0001f) return true;  // q inside the bounding disc: no view cone
+    const float inv_l = 1.0f / sqrtf(l2);
+    const float sv = fminf(rad * inv_l, 1.0f);                 // sin(view half angle)
+    const float cv = sqrtf(fmaxf(1.0f - sv * sv, 0.0f));
+    const float cos_sum = ch * cv - sh * sv;                   // cos(half + viewhalf)
+    if (cos_sum <= 1e-3f) return true;                         // sum >= ~90 degrees
+    const float sin_sum = sh * cv + ch * sv;
+    const float c = (ax * wx + ay * wy) * inv_l;               // cos(angle(axis, view axis))
+    return fabsf(c) <= sin_sum + 1e-3f;
+}
+
+template <class STK>
+__device__ __forceinline__ float closest_silhouette_tree(const DevMesh &m, float qx, float qy, float rmax, const STK &stk)
+{
+    float best2 = rmax * rmax;
+    bool found = false;
+    int sp = 0;
+    uint32_t g = 0;      // heap index of the node whose children are examined
+    for (;;) {
+        const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+        const float4 CX = nd[0], CY = nd[1], UX = nd[2], UY = nd[3], HL = nd[4], HW = nd[5];
+        const bool leaf_level = g >= (uint32_t)m.first_leaf;
+        if (leaf_level) {
+            const int slot0 = 4 * (int)(g - (uint32_t)m.first_leaf);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int2 vv = m.segVerts[slot0 + j];
+                if (vv.x < 0) continue;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const DevSilVertex sv = m.sil[e ? vv.y : vv.x];
+                    const float vx = qx - sv.x, vy = qy - sv.y;
+                    const float d2 = dot2(vx, vy, vx, vy);
+                    if (d2 > best2) continue;
+                    if (vertex_is_silhouette(m, sv, vx, vy, d2) && (d2 < best2 || !found)) {
+                        best2 = d2;
+                        found = true;
+                    }
+                }
+            }
+        } else {
+            const float4 *cn = m.cones + 5 * (size_t)g;
+            const float4 AX = cn[0], AY = cn[1], CH = cn[2], SH = cn[3], RD = cn[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float cx = j == 0 ? CX.x : j == 1 ? CX.y : j == 2 ? CX.z : CX.w;
+                const float cy = j == 0 ? CY.x : j == 1 ? CY.y : j == 2 ? CY.z : CY.w;
+                const float ux = j == 0 ? UX.x : j == 1 ? UX.y : j == 2 ? UX.z : UX.w;
+                const float uy = j == 0 ? UY.x : j == 1 ? UY.y : j == 2 ? UY.z : UY.w;
+                const float hl = j == 0 ? HL.x : j == 1 ? HL.y : j == 2 ? HL.z : HL.w;
+                const float hw = j == 0 ? HW.x : j == 1 ? HW.y : j == 2 ? HW.z : HW.w;
+                const float d = obb_d2(cx, cy, ux, uy, hl, hw, qx, qy);
+                if (!(d <= best2)) continue;
+                const float ax = j == 0 ? AX.x : j == 1 ? AX.y : j == 2 ? AX.z : AX.w;
+                const float ay = j == 0 ? AY.x : j == 1 ? AY.y : j == 2 ? AY.z : AY.w;
+                const float ch = j == 0 ? CH.x : j == 1 ? CH.y : j == 2 ? CH.z : CH.w;
+                const float sh = j == 0 ? SH.x : j == 1 ? SH.y : j == 2 ? SH.z : SH.w;
+                const float rd = j == 0 ? RD.x : j == 1 ? RD.y : j == 2 ? RD.z : RD.w;
+                if (!cone_may_hold_silhouette(ax, ay, ch, sh, rd, cx, cy, qx, qy)) continue;
+                stk.put(sp, 4u * g + 1u + (uint32_t)j);
+                ++sp;
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        g = stk.get(sp);
+    }
+    return found ? sqrtf(best2) : WOST_INF;
+}
+
+// entry distance of the ray o + t d, t in [0, tmax], into an oriented box; +inf when it misses.
+// Pruning only: slabs are widened by a relative epsilon, so a box is never missed.
+__device__ __forceinline__ float ray_obb_entry(float cx, float cy, float ux, float uy, float hl, float hw, float ox, float oy,
+                                               float dx, float dy, float tmax)
+{
+    const float wx = ox - cx, wy = oy - cy;
+    const float ou = wx * ux + wy * uy, ov = wy * ux - wx * uy;
+    const float du = dx * ux + dy * uy, dv = dy * ux - dx * uy;
+    const float slack = 1e-4f * (fabsf(ou) + fabsf(ov) + hl + hw) + 1e-30f;
+    const float hlp = hl + slack, hwp = hw + slack;
+    float t0 = 0.0f, t1 = tmax;
+    // slab along u
+    if (fabsf(du) > 1e-20f) {
+        const float inv = 1.0f / du;
+        float a = (-hlp - ou) * inv, b = (hlp - ou) * inv;
+        t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+    } else if (fabsf(ou) > hlp) return WOST_INF;
+    if (fabsf(dv) > 1e-20f) {
+        const float inv = 1.0f / dv;
+        float a = (-hwp - ov) * inv, b = (hwp - ov) * inv;
+        t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+    } else if (fabsf(ov) > hwp) return WOST_INF;
+    const float tol = 1e-4f * (fabsf(t0) + fabsf(t1)) + 1e-6f;
+    return (t0 <= t1 + tol) ? fmaxf(t0 - tol, 0.0f) : WOST_INF;
+}
+
+// closest hit (ANY_HIT = false) or any hit (true); ties in t go to the lowest ORIGINAL index
+template <bool ANY_HIT, class STK>
+__device__ __forceinline__ bool ray_tree(const DevMesh &m, float ox, float oy, float dx, float dy, float tmax, float &t_out,
+                                         int &idx_out, const STK &stk)
+{
+    bool hit = false;
+    float bt = WOST_INF;
+    int bi = -1;
+    int sp = 0;
+    uint32_t g = 0;
+    for (;;) {
+        if (g >= (uint32_t)m.first_leaf) {
+            const int slot0 = 4 * (int)(g - (uint32_t)m.first_leaf);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = m.segOrig[slot0 + j];
+                if (o == WOST_FAR_INDEX) continue;
+                const DevFlatSeg s = m.flat[o];
+                float t;
+                if (seg_ray(s, ox, oy, dx, dy, tmax, t)) {
+                    if (!hit || t < bt || (t == bt && o < bi)) {
+                        bt = t;
+                        bi = o;
+                        hit = true;
+                    }
+                }
+            }
+            if (ANY_HIT && hit) break;
+        } else {
+            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+            const float4 CX = nd[0], CY = nd[1], UX = nd[2], UY = nd[3], HL = nd[4], HW = nd[5];
+            const float lim = hit ? fminf(bt, tmax) : tmax;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float cx = j == 0 ? CX.x : j == 1 ? CX.y : j == 2 ? CX.z : CX.w;
+                const float cy = j == 0 ? CY.x : j == 1 ? CY.y : j == 2 ? CY.z : CY.w;
+                const float ux = j == 0 ? UX.x : j == 1 ? UX.y : j == 2 ? UX.z : UX.w;
+                const float uy = j == 0 ? UY.x : j == 1 ? UY.y : j == 2 ? UY.z : UY.w;
+                const float hl = j == 0 ? HL.x : j == 1 ? HL.y : j == 2 ? HL.z : HL.w;
+                const float hw = j == 0 ? HW.x : j == 1 ? HW.y : j == 2 ? HW.z : HW.w;
+                if (cx >= 1.0e17f) continue;  // empty child
+                const float te = ray_obb_entry(cx, cy, ux, uy, hl, hw, ox, oy, dx, dy, lim);
+                if (!(te <= lim)) continue;
+                stk.put(sp, 4u * g + 1u + (uint32_t)j);
+                ++sp;
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        g = stk.get(sp);
+    }
+    t_out = bt;
+    idx_out = bi;
+    return hit;
+}
+
+// a boundary mesh is walked with the flat wave-uniform loops up to this many segments
+#define WOST_FLAT_MAX 64
+
+template <class STK>
+__device__ __forceinline__ float closest_silhouette(const DevMesh &m, float qx, float qy, float rmax, const STK &stk)
+{
+    if (m.n_segs <= WOST_FLAT_MAX) return closest_silhouette_flat(m, qx, qy, rmax);
+    return closest_silhouette_tree(m, qx, qy, rmax, stk);
+}
+
+template <class STK>
+__device__ __forceinline__ bool ray_closest(const DevMesh &m, float ox, float oy, float dx, float dy, float tmax, float &t_out,
+                                            int &idx_out, const STK &stk)
+{
+    if (m.n_segs <= WOST_FLAT_MAX) return ray_closest_flat(m, ox, oy, dx, dy, tmax, t_out, idx_out);
+    return ray_tree<false>(m, ox, oy, dx, dy, tmax, t_out, idx_out, stk);
+}
+
+template <class STK>
+__device__ __forceinline__ bool ray_any(const DevMesh &m, float ox, float oy, float dx, float dy, float tmax, const STK &stk)
+{
+    if (m.n_segs <= WOST_FLAT_MAX) return ray_any_flat(m, ox, oy, dx, dy, tmax);
+    float t;
+    int i;
+    return ray_tree<true>(m, ox, oy, dx, dy, tmax, t, i, stk);
 }
 
 // ---- surface colour (reference integrator/common.h:242-260, functors.h:60-64) ------------

@@ -170,9 +170,9 @@ struct LaneStats {
 // integrator/uniform/integrator.cu:128-211, 224-231, 336-444, 465-525).  `cp` is the result
 // of lbvh nearest() for L.px,L.py (ignored when there is no Dirichlet boundary).
 // Returns true when the walk ended in this step.
-template <bool NEUMANN_EMISSIVE>
+template <bool NEUMANN_EMISSIVE, class STK>
 __device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm, const DevSettings &st, Lane &L, LaneStats &S,
-                                            const Closest cp)
+                                            const Closest cp, const STK &stk)
 {
     const bool has_d = dm.n_segs > 0, has_n = nm.n_segs > 0;
     const float eps = st.eps;
@@ -202,7 +202,7 @@ __device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm
         }
     }
     float R_N = WOST_INF;
-    if (has_n) R_N = closest_silhouette_flat(nm, px, py, R_D);
+    if (has_n) R_N = closest_silhouette(nm, px, py, R_D, stk);
     float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
     R_B *= WOST_R_B_SHRINK;
     if (isinf(R_B)) return true;
@@ -231,7 +231,7 @@ __device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm
                     float dx = spx - ox, dy = spy - oy;
                     const float cd = sqrtf(dot2(dx, dy, dx, dy));
                     if (cd > 0) { dx /= cd; dy /= cd; }
-                    const bool blocked = ray_any_flat(nm, ox, oy, dx, dy, cd - eps);
+                    const bool blocked = ray_any(nm, ox, oy, dx, dy, cd - eps, stk);
                     if (!blocked) {
                         const float cr = cross2(so.ex, so.ey, px - so.ax, py - so.ay);
                         int side = (0.0f < cr) - (cr < 0.0f);
@@ -283,7 +283,7 @@ __device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm
     if (has_n) {
         float t;
         int hi;
-        hit = ray_closest_flat(nm, cxp, cyp, dirx, diry, R_B, t, hi);
+        hit = ray_closest(nm, cxp, cyp, dirx, diry, R_B, t, hi, stk);
         if (hit) {
             hnx = nm.flat[hi].nx;
             hny = nm.flat[hi].ny;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 6) void walk_round_kernel(RoundParams P)
             // ---- step phase ----
             if (mode == MODE_WAIT) {
                 if (!fresh) {
-                    const bool ended = step_finish<NEUMANN_EMISSIVE>(P.dm, P.nm, P.st, L, S, T.best);
+                    const bool ended = step_finish<NEUMANN_EMISSIVE>(P.dm, P.nm, P.st, L, S, T.best, stk);
                     if (ended) {
                         // next sample of this pixel starts right away (generateEvaluationPoints,
                         // reference integrator.cu:90-99 + workqueue.h:99-110)
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void sdf_kernel(DevMesh m, DevProbe probe, int
         if (which == WOST_MESH_DIRICHLET) {
             d = sqrtf(closest_point(m, x, y, slot_candidate(m, 0, x, y), stack, stack_stride).d2);
         } else {
-            d = closest_silhouette_flat(m, x, y, WOST_INF);
+            d = closest_silhouette(m, x, y, WOST_INF, LdsColumn{stack, (uint32_t)stack_stride});
         }
     }
     out[pid] = d;
@@ -501,19 +501,23 @@ __global__ __launch_bounds__(256) void sdf_kernel(DevMesh m, DevProbe probe, int
 __global__ __launch_bounds__(256) void silhouette_kernel(DevMesh m, const float *pts, const float *rmax, int n,
                                                          float *out)
 {
+    extern __shared__ uint32_t lds_stack[];
+    const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)blockDim.x};
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = closest_silhouette_flat(m, pts[2 * i], pts[2 * i + 1], rmax ? rmax[i] : WOST_INF);
+    out[i] = closest_silhouette(m, pts[2 * i], pts[2 * i + 1], rmax ? rmax[i] : WOST_INF, stk);
 }
 
 __global__ __launch_bounds__(256) void ray_kernel(DevMesh m, const float *o, const float *d, const float *tmax, int n,
                                                   int32_t *out_hit, float *out_t, int32_t *out_idx)
 {
+    extern __shared__ uint32_t lds_stack[];
+    const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)blockDim.x};
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float t;
     int idx;
-    const bool hit = ray_closest_flat(m, o[2 * i], o[2 * i + 1], d[2 * i], d[2 * i + 1], tmax[i], t, idx);
+    const bool hit = ray_closest(m, o[2 * i], o[2 * i + 1], d[2 * i], d[2 * i + 1], tmax[i], t, idx, stk);
     out_hit[i] = hit ? 1 : 0;
     out_t[i] = t;
     out_idx[i] = idx;
@@ -546,7 +550,6 @@ struct DeviceMeshStorage {
     HostTree host;
 };
 
-static const int kMaxFlatNeumann = 1024;
 
 template <class T>
 static hipError_t upload(std::vector<void *> &allocs, const T *src, size_t count, const T **dst)
@@ -591,6 +594,8 @@ static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
     HIP_TRY(upload(s.allocs, reinterpret_cast<const DevFlatSeg *>(t.flat.data()), t.flat.size(), &v.flat));
     HIP_TRY(upload(s.allocs, t.flatCol.data(), t.flatCol.size(), &v.flatCol));
     HIP_TRY(upload(s.allocs, reinterpret_cast<const DevSilVertex *>(t.sil.data()), t.sil.size(), &v.sil));
+    HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(t.cones.data()), t.cones.size() / 4, &v.cones));
+    HIP_TRY(upload(s.allocs, reinterpret_cast<const int2 *>(t.segVerts.data()), t.segVerts.size() / 2, &v.segVerts));
     return WOST_OK;
 }
 
@@ -704,8 +709,6 @@ int wost_create(const wost_scene_desc *scene, const wost_settings *settings, int
     c->n_pixels = (size_t)settings->width * settings->height;
     int rc = upload_mesh(scene->dirichlet, c->dm);
     if (rc == WOST_OK) rc = upload_mesh(scene->neumann, c->nm);
-    if (rc == WOST_OK && c->nm.view.n_segs > kMaxFlatNeumann)
-        rc = fail(WOST_ERR_UNSUPPORTED, "Neumann meshes above 1024 segments need the BVH Neumann path (not built yet)");
     auto bail = [&](int code) {
         destroy_ctx(c);
         return code;
@@ -799,7 +802,8 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     HIP_TRY(hipSetDevice(c->device));
     const int bs = c->block_size;
     const int levels = c->dm.view.n_segs > 0 ? c->dm.view.levels : 1;
-    const int stack_depth = 3 * (levels + 1) + 4;
+    const int levels_any = std::max(levels, c->nm.view.n_segs > 0 ? c->nm.view.levels : 1);
+    const int stack_depth = 3 * (levels_any + 1) + 4;
     const size_t lds = (size_t)stack_depth * bs * sizeof(uint32_t);
     HIP_TRY(hipMemsetAsync(c->counts, 0, 2 * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(StatsDev), stream));
@@ -845,7 +849,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         pp.field = field_dev;
         pp.field_base = field_base;
         pp.stats = c->stats;
-        const int full_stack = 3 * (levels + 1) + 4;
+        const int full_stack = 3 * (levels_any + 1) + 4;
         pp.stack_words = std::min(full_stack, c->pool_stack);
         pp.step_weight = c->step_weight;
         const int K = c->pool_k;
@@ -1070,8 +1074,6 @@ int wost_closest_silhouette(wost_handle h, int which_mesh, const float *pts, con
     if (!h || !pts || !out_dist || n < 0) return fail(WOST_ERR_INVALID, "null argument");
     DeviceMeshStorage *m = pick_mesh(h, which_mesh);
     if (!m) return fail(WOST_ERR_INVALID, "unknown mesh selector");
-    if (m->view.n_segs > kMaxFlatNeumann)
-        return fail(WOST_ERR_UNSUPPORTED, "silhouette query is flat-loop only (<= 1024 segments) in this build");
     if (n == 0) return WOST_OK;
     HIP_TRY(hipSetDevice(h->device));
     Scratch s;
@@ -1084,7 +1086,8 @@ int wost_closest_silhouette(wost_handle h, int which_mesh, const float *pts, con
         HIP_TRY(hipMemcpyAsync(d_rmax, rmax, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     }
     const int bs = 256;
-    hipLaunchKernelGGL(silhouette_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, h->stream, m->view, d_pts, d_rmax, n,
+    const size_t lds = (size_t)(3 * ((m->view.n_segs > 0 ? m->view.levels : 1) + 1) + 4) * bs * sizeof(uint32_t);
+    hipLaunchKernelGGL(silhouette_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, d_pts, d_rmax, n,
                        d_out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_dist, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1099,8 +1102,6 @@ int wost_ray_intersect(wost_handle h, int which_mesh, const float *origins, cons
         return fail(WOST_ERR_INVALID, "null argument");
     DeviceMeshStorage *m = pick_mesh(h, which_mesh);
     if (!m) return fail(WOST_ERR_INVALID, "unknown mesh selector");
-    if (m->view.n_segs > kMaxFlatNeumann)
-        return fail(WOST_ERR_UNSUPPORTED, "ray query is flat-loop only (<= 1024 segments) in this build");
     if (n == 0) return WOST_OK;
     HIP_TRY(hipSetDevice(h->device));
     Scratch s;
@@ -1116,7 +1117,8 @@ int wost_ray_intersect(wost_handle h, int which_mesh, const float *origins, cons
     HIP_TRY(hipMemcpyAsync(d_d, dirs, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(d_tm, tmax, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     const int bs = 256;
-    hipLaunchKernelGGL(ray_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, h->stream, m->view, d_o, d_d, d_tm, n, d_hit,
+    const size_t lds = (size_t)(3 * ((m->view.n_segs > 0 ? m->view.levels : 1) + 1) + 4) * bs * sizeof(uint32_t);
+    hipLaunchKernelGGL(ray_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, d_o, d_d, d_tm, n, d_hit,
                        d_t, d_idx);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_hit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));

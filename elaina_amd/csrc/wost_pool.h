@@ -208,7 +208,11 @@ __global__ __launch_bounds__(64, 1) void walk_pool_kernel(PoolParams P)
                 A.sr = sr0; A.sg = sg0; A.sb = sb0;
                 A.hint = 0;
                 const Closest cp{L.bd2[w], L.bslot[w]};
-                const bool ended = step_finish<NEUMANN_EMISSIVE>(P.dm, P.nm, P.st, A, S, cp);
+                // the walker's traversal stack is idle between queries: the Neumann-side tree
+                // queries of the step logic use it
+                const SplitColumn stk{L.stack + w, (uint32_t)NW, P.stack_words,
+                                      P.spill + (size_t)blockIdx.x * NW + w, (uint32_t)(gridDim.x * NW)};
+                const bool ended = step_finish<NEUMANN_EMISSIVE>(P.dm, P.nm, P.st, A, S, cp, stk);
                 bool alive = true;
                 if (ended) {
                     // next sample of this pixel starts right away (generateEvaluationPoints,

@@ -67,3 +67,29 @@ def box_problem(lo=0.0, hi=1.0, n_per_side=8, d_sides=(0, 1, 2, 3), n_sides=(), 
     if probe is None:
         probe = (half * 0.9, mid, mid, 0.0, 1.0)
     return Problem(d_verts=dv, d_segs=ds, d_colors=dc, n_verts=nv, n_segs=ns, n_colors=nc, probe=probe)
+
+
+def wiggly_problem(n_neumann=3000, n_dirichlet=400, emissive=False, open_gap=0):
+    """A non-convex CCW Neumann boundary r(t) = 100 (1 + .2 sin 7t + .05 sin 31t) with
+    n_neumann segments around a Dirichlet circle of radius 15 (n_dirichlet segments).
+    open_gap > 0 removes that many Neumann segments (open polyline ends = silhouettes)."""
+    from elaina_amd import Problem
+    t = np.linspace(0.0, 2.0 * np.pi, n_neumann, endpoint=False)
+    r = 100.0 * (1.0 + 0.2 * np.sin(7 * t) + 0.05 * np.sin(31 * t))
+    nv = np.stack([r * np.cos(t), r * np.sin(t)], 1).astype(np.float32)
+    ns = np.stack([np.arange(n_neumann), (np.arange(n_neumann) + 1) % n_neumann], 1).astype(np.int32)
+    if open_gap:
+        ns = ns[:-open_gap]
+    td = np.linspace(0.0, 2.0 * np.pi, n_dirichlet, endpoint=False)
+    dv = np.stack([15.0 * np.cos(td) + 5.0, 15.0 * np.sin(td) - 3.0], 1).astype(np.float32)
+    ds = np.stack([np.arange(n_dirichlet), (np.arange(n_dirichlet) + 1) % n_dirichlet], 1).astype(np.int32)
+    dc = np.zeros((n_dirichlet, 6), np.float32)
+    dc[:, 0:3] = (0.5 + 0.5 * np.cos(td))[:, None] * np.array([1.0, 0.5, 0.25])
+    dc[:, 3:6] = 0.3
+    nc = None
+    if emissive:
+        nc = np.zeros((n_neumann, 6), np.float32)
+        nc[:, 0:3] = (0.01 * np.sin(3 * t))[:, None]
+        nc[:, 3:6] = nc[:, 0:3]
+    return Problem(d_verts=dv, d_segs=ds, d_colors=dc, n_verts=nv, n_segs=ns, n_colors=nc,
+                   probe=(110.0, 0.0, 0.0, 0.0, 1.0))

@@ -258,3 +258,43 @@ def test_invalid_arguments_are_rejected(ladybug):
     it.close()
     with pytest.raises(capi.WostError):
         UniformIntegrator(ladybug, UniformIntegratorSettings((0, 16), 1, 4, 1.0))
+
+
+# ---- boundary meshes too large for the flat loops: LBVH + SNCH cone path ------------------
+@pytest.mark.parametrize("open_gap", [0, 7])
+def test_large_neumann_mesh_silhouette_and_ray_queries(oracle, open_gap):
+    from conftest import wiggly_problem
+    p = wiggly_problem(3000, 64, open_gap=open_gap)
+    it = _integrator(p, 16, 16, 1, 4, 1.0)
+    rng = np.random.default_rng(8)
+    pts = rng.uniform(-140, 140, size=(20000, 2)).astype(np.float32)
+    ref = oracle.closest_silhouette(p.n_verts, p.n_segs, pts)
+    got = it.closest_silhouette(pts)
+    assert np.isfinite(ref).mean() > 0.3          # the wiggly boundary does have silhouettes
+    assert np.array_equal(got, ref)
+    rmax = rng.uniform(1, 60, size=20000).astype(np.float32)
+    assert np.array_equal(it.closest_silhouette(pts, rmax), oracle.closest_silhouette(p.n_verts, p.n_segs, pts, rmax))
+    o = rng.uniform(-70, 70, size=(20000, 2)).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, size=20000)
+    d = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+    tmax = rng.uniform(1, 300, size=20000).astype(np.float32)
+    gh, gt, gi = it.ray_intersect(o, d, tmax)
+    rh, rt, ri = oracle.ray_intersect(p.n_verts, p.n_segs, o, d, tmax)
+    assert np.array_equal(gh, rh) and rh.mean() > 0.2
+    hit = rh == 1
+    assert np.array_equal(gt[hit], rt[hit]) and np.array_equal(gi[hit], ri[hit])
+    it.close()
+
+
+@pytest.mark.parametrize("opts", [{"kernel": 0}, {"kernel": 1, "pool_k": 2, "pool_stack": 5}])
+def test_large_neumann_mesh_solve(oracle, opts):
+    from conftest import wiggly_problem
+    p = wiggly_problem(3000, 400)
+    ref = _assert_same_solve(oracle, p, 24, 20, 6, 96, 0.5, **opts)
+    assert ref["neumann_hits"] > 100
+
+
+def test_large_emissive_neumann_mesh_solve(oracle):
+    from conftest import wiggly_problem
+    p = wiggly_problem(600, 200, emissive=True, open_gap=3)
+    _assert_same_solve(oracle, p, 12, 10, 4, 64, 0.5)
