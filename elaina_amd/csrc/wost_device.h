@@ -636,25 +636,27 @@ __device__ __forceinline__ bool ray_tree(const DevMesh &m, float ox, float oy, f
 // a boundary mesh is walked with the flat wave-uniform loops up to this many segments
 #define WOST_FLAT_MAX 64
 
-template <class STK>
+// TREE is a compile-time choice (the host picks the kernel instantiation from the mesh size):
+// kernels for small boundary meshes carry no traversal code and keep their register budget.
+template <bool TREE, class STK>
 __device__ __forceinline__ float closest_silhouette(const DevMesh &m, float qx, float qy, float rmax, const STK &stk)
 {
-    if (m.n_segs <= WOST_FLAT_MAX) return closest_silhouette_flat(m, qx, qy, rmax);
+    if (!TREE) return closest_silhouette_flat(m, qx, qy, rmax);
     return closest_silhouette_tree(m, qx, qy, rmax, stk);
 }
 
-template <class STK>
+template <bool TREE, class STK>
 __device__ __forceinline__ bool ray_closest(const DevMesh &m, float ox, float oy, float dx, float dy, float tmax, float &t_out,
                                             int &idx_out, const STK &stk)
 {
-    if (m.n_segs <= WOST_FLAT_MAX) return ray_closest_flat(m, ox, oy, dx, dy, tmax, t_out, idx_out);
+    if (!TREE) return ray_closest_flat(m, ox, oy, dx, dy, tmax, t_out, idx_out);
     return ray_tree<false>(m, ox, oy, dx, dy, tmax, t_out, idx_out, stk);
 }
 
-template <class STK>
+template <bool TREE, class STK>
 __device__ __forceinline__ bool ray_any(const DevMesh &m, float ox, float oy, float dx, float dy, float tmax, const STK &stk)
 {
-    if (m.n_segs <= WOST_FLAT_MAX) return ray_any_flat(m, ox, oy, dx, dy, tmax);
+    if (!TREE) return ray_any_flat(m, ox, oy, dx, dy, tmax);
     float t;
     int i;
     return ray_tree<true>(m, ox, oy, dx, dy, tmax, t, i, stk);

@@ -170,7 +170,7 @@ struct LaneStats {
 // integrator/uniform/integrator.cu:128-211, 224-231, 336-444, 465-525).  `cp` is the result
 // of lbvh nearest() for L.px,L.py (ignored when there is no Dirichlet boundary).
 // Returns true when the walk ended in this step.
-template <bool NEUMANN_EMISSIVE, class STK>
+template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, class STK>
 __device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm, const DevSettings &st, Lane &L, LaneStats &S,
                                             const Closest cp, const STK &stk)
 {
@@ -202,7 +202,7 @@ __device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm
         }
     }
     float R_N = WOST_INF;
-    if (has_n) R_N = closest_silhouette(nm, px, py, R_D, stk);
+    if (has_n) R_N = closest_silhouette<NEUMANN_TREE>(nm, px, py, R_D, stk);
     float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
     R_B *= WOST_R_B_SHRINK;
     if (isinf(R_B)) return true;
@@ -231,7 +231,7 @@ __device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm
                     float dx = spx - ox, dy = spy - oy;
                     const float cd = sqrtf(dot2(dx, dy, dx, dy));
                     if (cd > 0) { dx /= cd; dy /= cd; }
-                    const bool blocked = ray_any(nm, ox, oy, dx, dy, cd - eps, stk);
+                    const bool blocked = ray_any<NEUMANN_TREE>(nm, ox, oy, dx, dy, cd - eps, stk);
                     if (!blocked) {
                         const float cr = cross2(so.ex, so.ey, px - so.ax, py - so.ay);
                         int side = (0.0f < cr) - (cr < 0.0f);
@@ -283,7 +283,7 @@ __device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm
     if (has_n) {
         float t;
         int hi;
-        hit = ray_closest(nm, cxp, cyp, dirx, diry, R_B, t, hi, stk);
+        hit = ray_closest<NEUMANN_TREE>(nm, cxp, cyp, dirx, diry, R_B, t, hi, stk);
         if (hit) {
             hnx = nm.flat[hi].nx;
             hny = nm.flat[hi].ny;
@@ -306,8 +306,8 @@ __device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm
     return false;
 }
 
-template <bool NEUMANN_EMISSIVE>
-__global__ __launch_bounds__(256, 6) void walk_round_kernel(RoundParams P)
+template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE>
+__global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(RoundParams P)
 {
     extern __shared__ uint32_t lds_stack[];
     // LDS: [top of the tree: top_nodes * 6 float4][traversal stack columns]
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 6) void walk_round_kernel(RoundParams P)
             // ---- step phase ----
             if (mode == MODE_WAIT) {
                 if (!fresh) {
-                    const bool ended = step_finish<NEUMANN_EMISSIVE>(P.dm, P.nm, P.st, L, S, T.best, stk);
+                    const bool ended = step_finish<NEUMANN_EMISSIVE, NEUMANN_TREE>(P.dm, P.nm, P.st, L, S, T.best, stk);
                     if (ended) {
                         // next sample of this pixel starts right away (generateEvaluationPoints,
                         // reference integrator.cu:90-99 + workqueue.h:99-110)
@@ -492,7 +492,8 @@ __global__ __launch_bounds__(256) void sdf_kernel(DevMesh m, DevProbe probe, int
         if (which == WOST_MESH_DIRICHLET) {
             d = sqrtf(closest_point(m, x, y, slot_candidate(m, 0, x, y), stack, stack_stride).d2);
         } else {
-            d = closest_silhouette(m, x, y, WOST_INF, LdsColumn{stack, (uint32_t)stack_stride});
+            d = (m.n_segs <= WOST_FLAT_MAX) ? closest_silhouette_flat(m, x, y, WOST_INF)
+                                             : closest_silhouette_tree(m, x, y, WOST_INF, LdsColumn{stack, (uint32_t)stack_stride});
         }
     }
     out[pid] = d;
@@ -505,7 +506,9 @@ __global__ __launch_bounds__(256) void silhouette_kernel(DevMesh m, const float 
     const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)blockDim.x};
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = closest_silhouette(m, pts[2 * i], pts[2 * i + 1], rmax ? rmax[i] : WOST_INF, stk);
+    const float r = rmax ? rmax[i] : WOST_INF;
+    out[i] = (m.n_segs <= WOST_FLAT_MAX) ? closest_silhouette_flat(m, pts[2 * i], pts[2 * i + 1], r)
+                                         : closest_silhouette_tree(m, pts[2 * i], pts[2 * i + 1], r, stk);
 }
 
 __global__ __launch_bounds__(256) void ray_kernel(DevMesh m, const float *o, const float *d, const float *tmax, int n,
@@ -517,7 +520,9 @@ __global__ __launch_bounds__(256) void ray_kernel(DevMesh m, const float *o, con
     if (i >= n) return;
     float t;
     int idx;
-    const bool hit = ray_closest(m, o[2 * i], o[2 * i + 1], d[2 * i], d[2 * i + 1], tmax[i], t, idx, stk);
+    const bool hit = (m.n_segs <= WOST_FLAT_MAX)
+                         ? ray_closest_flat(m, o[2 * i], o[2 * i + 1], d[2 * i], d[2 * i + 1], tmax[i], t, idx)
+                         : ray_tree<false>(m, o[2 * i], o[2 * i + 1], d[2 * i], d[2 * i + 1], tmax[i], t, idx, stk);
     out_hit[i] = hit ? 1 : 0;
     out_t[i] = t;
     out_idx[i] = idx;
@@ -837,6 +842,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     uint32_t launches = 0;
     int cur = 0;
     const bool emissive = c->nm.view.n_segs > 0 && c->nm.view.emissive;
+    const bool ntree = c->nm.view.n_segs > WOST_FLAT_MAX;
     if (c->kernel == 1 && n_active > 0) {
         // ---- pool kernel: one launch walks every pixel of this call ----
         PoolParams pp{};
@@ -873,14 +879,18 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         pp.spill = c->spill;
         HIP_TRY(hipMemsetAsync(c->counts + 1, 0, sizeof(uint32_t), stream));
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
-#define WOST_LAUNCH_POOL(E, KK) hipLaunchKernelGGL((walk_pool_kernel<E, KK>), dim3(grid), dim3(64), pool_lds, stream, pp)
-        if (emissive) {
-            if (K == 1) WOST_LAUNCH_POOL(true, 1); else if (K == 2) WOST_LAUNCH_POOL(true, 2);
-            else if (K == 3) WOST_LAUNCH_POOL(true, 3); else WOST_LAUNCH_POOL(true, 4);
+#define WOST_LAUNCH_POOL(E, T, KK) hipLaunchKernelGGL((walk_pool_kernel<E, T, KK>), dim3(grid), dim3(64), pool_lds, stream, pp)
+#define WOST_LAUNCH_POOL_K(E, T)                                                                              \
+    do {                                                                                                      \
+        if (K == 1) WOST_LAUNCH_POOL(E, T, 1); else if (K == 2) WOST_LAUNCH_POOL(E, T, 2);                    \
+        else if (K == 3) WOST_LAUNCH_POOL(E, T, 3); else WOST_LAUNCH_POOL(E, T, 4);                           \
+    } while (0)
+        if (ntree) {
+            if (emissive) WOST_LAUNCH_POOL_K(true, true); else WOST_LAUNCH_POOL_K(false, true);
         } else {
-            if (K == 1) WOST_LAUNCH_POOL(false, 1); else if (K == 2) WOST_LAUNCH_POOL(false, 2);
-            else if (K == 3) WOST_LAUNCH_POOL(false, 3); else WOST_LAUNCH_POOL(false, 4);
+            if (emissive) WOST_LAUNCH_POOL_K(true, false); else WOST_LAUNCH_POOL_K(false, false);
         }
+#undef WOST_LAUNCH_POOL_K
 #undef WOST_LAUNCH_POOL
         HIP_TRY(hipGetLastError());
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev1, stream));
@@ -919,10 +929,13 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         const size_t lds_round = lds + (size_t)rp.top_nodes * 96;
         const unsigned grid = (n_active + bs - 1) / bs;
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
-        if (emissive)
-            hipLaunchKernelGGL(walk_round_kernel<true>, dim3(grid), dim3(bs), lds_round, stream, rp);
-        else
-            hipLaunchKernelGGL(walk_round_kernel<false>, dim3(grid), dim3(bs), lds_round, stream, rp);
+        if (ntree) {
+            if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+            else hipLaunchKernelGGL((walk_round_kernel<false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+        } else {
+            if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, false>), dim3(grid), dim3(bs), lds_round, stream, rp);
+            else hipLaunchKernelGGL((walk_round_kernel<false, false>), dim3(grid), dim3(bs), lds_round, stream, rp);
+        }
         HIP_TRY(hipGetLastError());
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev1, stream));
         HIP_TRY(hipMemcpyAsync(c->host_count, c->counts + nxt, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

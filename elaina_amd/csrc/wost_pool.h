@@ -66,7 +66,7 @@ __device__ __forceinline__ PoolLds carve_pool(uint32_t *base, int NW)
 
 static constexpr int kPoolWordsPerWalker = 11;  // + stack_words
 
-template <bool NEUMANN_EMISSIVE, int K>
+template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, int K>
 __global__ __launch_bounds__(64, 1) void walk_pool_kernel(PoolParams P)
 {
     constexpr int NW = 64 * K;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64, 1) void walk_pool_kernel(PoolParams P)
                 // queries of the step logic use it
                 const SplitColumn stk{L.stack + w, (uint32_t)NW, P.stack_words,
                                       P.spill + (size_t)blockIdx.x * NW + w, (uint32_t)(gridDim.x * NW)};
-                const bool ended = step_finish<NEUMANN_EMISSIVE>(P.dm, P.nm, P.st, A, S, cp, stk);
+                const bool ended = step_finish<NEUMANN_EMISSIVE, NEUMANN_TREE>(P.dm, P.nm, P.st, A, S, cp, stk);
                 bool alive = true;
                 if (ended) {
                     // next sample of this pixel starts right away (generateEvaluationPoints,
