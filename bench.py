@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--depth", type=int, default=0, help="0 = the scene's maxWalkingDepth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--steps-per-round", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="key=value passed to wost_set_option")
     args = ap.parse_args()
@@ -67,9 +68,10 @@ def main():
     from elaina_amd import Problem, UniformIntegrator, UniformIntegratorSettings
     from elaina_amd import distributed as D
 
-    rank, world, local = D.init_process_group()
+    rank, world, local = D.init_process_group(args.backend)
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    local = local % max(torch.cuda.device_count(), 1)   # several ranks may share one GPU in tests
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

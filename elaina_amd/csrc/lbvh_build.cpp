@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -301,7 +302,8 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
                 const std::vector<double> &C = pts[kArity * g + j];
                 pts[g].insert(pts[g].end(), C.begin(), C.end());
             }
-        const double obb_pad = (double)ext * 0x1p-18 + 1e-30;
+        const char *e_pad = getenv("WOST_OBB_PAD_LOG2");   // developer knob: absolute pad = ext * 2^-k
+        const double obb_pad = (double)ext * std::ldexp(1.0, -(e_pad ? atoi(e_pad) : 21)) + 1e-30;
         auto set_child = [&](int parent, int j, float cx, float cy, float ux, float uy, float hl, float hw) {
             float *nd = &t->nodes[(size_t)parent * 24];
             nd[0 + j] = cx; nd[4 + j] = cy; nd[8 + j] = ux; nd[12 + j] = uy; nd[16 + j] = hl; nd[20 + j] = hw;

@@ -298,3 +298,27 @@ def test_large_emissive_neumann_mesh_solve(oracle):
     from conftest import wiggly_problem
     p = wiggly_problem(600, 200, emissive=True, open_gap=3)
     _assert_same_solve(oracle, p, 12, 10, 4, 64, 0.5)
+
+
+def test_bench_two_ranks_sharing_one_gpu():
+    # the N > 1 path of bench.py end to end (tile sharding + reduce + JSON contract) with two
+    # processes on the one GPU of the test box; gloo carries the reduce because RCCL refuses
+    # two ranks on one device
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "0", "--frame", "128", "--spp", "8", "--backend", "gloo"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["metric"] == "walk-steps/s" and r["scaling"] == "strong"
+    assert r["rel_l2_vs_oracle"] == 0.0
+    assert r["roofline"]["bound"] == "hbm" and r["cpu_baseline"]["kind"] == "port"
