@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--depth", type=int, default=0, help="0 = the scene's maxWalkingDepth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--no-1spp", action="store_true", help="skip the time-to-1spp probe (profiling runs)")
     ap.add_argument("--steps-per-round", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="key=value passed to wost_set_option")
     args = ap.parse_args()
@@ -96,8 +97,8 @@ def main():
 
     # time-to-1spp (cold first pass of a fresh handle, then steady state), outside the timed region
     it1 = UniformIntegrator(problem, UniformIntegratorSettings((frame, frame), 1, depth, eps), device=local)
-    t1 = []
-    for _ in range(4):
+    t1 = [0.0, 0.0] if args.no_1spp else []
+    for _ in range(0 if args.no_1spp else 4):
         field.zero_()
         torch.cuda.synchronize()
         t = time.perf_counter()
@@ -140,6 +141,12 @@ def main():
         # dominant kernel: walk_round_kernel.  Algorithmic bytes per launch = 98 B x the walk steps
         # that launch advanced; both summed over this rank's launches of the timed region.
         ach = (steps_local * BYTES_PER_STEP) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "walk_round_traffic.json")
+        if os.path.exists(tpath):
+            # PMC passes cannot run inside this process: the figure comes from the committed
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command (tools/gpu_round.sh)
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         out = {
             "metric": "walk-steps/s", "value": value, "unit": "walk-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -150,7 +157,8 @@ def main():
                 "walk_steps_per_pass": total_steps / args.steps},
             "time_to_1spp_ms": {"cold": t1[0], "steady": sorted(t1[1:])[len(t1[1:]) // 2]},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (profiles/walk_round_traffic.json)",
                          "kernel": "walk_round_kernel", "launches": launches,
                          "avg_launch_ms": kernel_ms / max(launches, 1),
                          "algorithmic_bytes_per_walk_step": BYTES_PER_STEP},

@@ -180,7 +180,25 @@ struct SplitColumn {
 template <class STK>
 __device__ __forceinline__ bool trav_pop(Trav &T, const STK &stk)
 {
-    while (T.sp > 0) {
+    // Divergent branches are what this kernel pays most for (scalar exec-mask traffic), so the
+    // common case -- the first or second entry is live -- runs as straight-line predicated
+    // code: the LDS read is unconditional (index clamped), everything else is a select.
+    bool need = true;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = max(T.sp - 1, 0);
+        const uint32_t key = stk.get(idx);
+        const bool can = need && T.sp > 0;
+        const float dlb = __uint_as_float(key & ~0x3Fu);
+        const bool take = can && dlb <= T.best.d2;
+        const int el = (int)((key >> 2) & 15u);
+        const int parent = T.pos >> (2 * (T.level - el + 1));
+        T.pos = take ? 4 * parent + (int)(key & 3u) : T.pos;
+        T.level = take ? el : T.level;
+        T.sp = can ? T.sp - 1 : T.sp;
+        need = need && !take;
+    }
+    while (need && T.sp > 0) {
         --T.sp;
         const uint32_t key = stk.get(T.sp);
         const float dlb = __uint_as_float(key & ~0x3Fu);
@@ -189,10 +207,10 @@ __device__ __forceinline__ bool trav_pop(Trav &T, const STK &stk)
             const int parent = T.pos >> (2 * (T.level - el + 1));
             T.pos = 4 * parent + (int)(key & 3u);
             T.level = el;
-            return true;
+            need = false;
         }
     }
-    return false;
+    return !need;
 }
 
 // rare path of a leaf visit: an exact tie between candidates; lowest ORIGINAL index wins
@@ -289,11 +307,10 @@ __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy,
         stk.put(sp, k1);
         sp += (k1 != 0xffffffffu) ? 1 : 0;
         T.sp = sp;
-        if (k0 != 0xffffffffu) {
-            T.pos = 4 * T.pos + (int)(k0 & 3u);
-            T.level += 1;
-            return true;
-        }
+        const bool descend = k0 != 0xffffffffu;
+        T.pos = descend ? 4 * T.pos + (int)(k0 & 3u) : T.pos;
+        T.level = descend ? T.level + 1 : T.level;
+        if (descend) return true;
     }
     return trav_pop(T, stk);
 }

@@ -67,7 +67,7 @@ __device__ __forceinline__ PoolLds carve_pool(uint32_t *base, int NW)
 static constexpr int kPoolWordsPerWalker = 11;  // + stack_words
 
 template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, int K>
-__global__ __launch_bounds__(64, 1) void walk_pool_kernel(PoolParams P)
+__global__ __launch_bounds__(64, 4) void walk_pool_kernel(PoolParams P)
 {
     constexpr int NW = 64 * K;
     extern __shared__ uint32_t lds_pool[];
