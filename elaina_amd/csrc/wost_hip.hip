@@ -160,8 +160,12 @@ struct Lane {
     int32_t d0_slot;
 };
 
+// Per-lane event counters of one launch, packed two 16-bit fields per register (the kernels
+// are register-bound; a lane makes at most steps_per_round <= 32767 steps per launch):
+// a = steps | started << 16, b = absorbed | truncated << 16, c = Neumann hits, visits = LBVH
+// nodes visited (32 bits).
 struct LaneStats {
-    uint32_t steps, started, absorbed, truncated, nhits, inner_visits, leaf_visits;
+    uint32_t a, b, c, visits;
 };
 
 // The part of one walk step that follows the closest-point query.  One walk step = one item
@@ -169,10 +173,14 @@ struct LaneStats {
 // handleBoundary -> sampleNeumann -> oneStepWalk (reference
 // integrator/uniform/integrator.cu:128-211, 224-231, 336-444, 465-525).  `cp` is the result
 // of lbvh nearest() for L.px,L.py (ignored when there is no Dirichlet boundary).
-// Returns true when the walk ended in this step.
+// Returns STEP_* status bits (STEP_ENDED when the walk ended in this step); the caller keeps
+// the statistics, so no counter is ever touched inside a divergent branch.
+// status bits returned by step_finish
+enum : uint32_t { STEP_ENDED = 1u, STEP_ABSORBED = 2u, STEP_TRUNCATED = 4u, STEP_NEUMANN_HIT = 8u };
+
 template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, class STK>
-__device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm, const DevSettings &st, Lane &L, LaneStats &S,
-                                            const Closest cp, const STK &stk)
+__device__ __forceinline__ uint32_t step_finish(const DevMesh &dm, const DevMesh &nm, const DevSettings &st, Lane &L,
+                                                const Closest cp, const STK &stk)
 {
     const bool has_d = dm.n_segs > 0, has_n = nm.n_segs > 0;
     const float eps = st.eps;
@@ -197,15 +205,14 @@ __device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm
             r *= st.dirichlet_intensity; g *= st.dirichlet_intensity; b *= st.dirichlet_intensity;
             r *= L.thp; g *= L.thp; b *= L.thp;
             L.sr = r + L.sr; L.sg = g + L.sg; L.sb = b + L.sb;
-            S.absorbed++;
-            return true;
+            return STEP_ENDED | STEP_ABSORBED;
         }
     }
     float R_N = WOST_INF;
     if (has_n) R_N = closest_silhouette<NEUMANN_TREE>(nm, px, py, R_D, stk);
     float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
     R_B *= WOST_R_B_SHRINK;
-    if (isinf(R_B)) return true;
+    if (isinf(R_B)) return STEP_ENDED;
 
     // ---- sampleNeumann -------------------------------------------------------------------
     if (has_n) {
@@ -279,6 +286,7 @@ __device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm
     }
     float nxt_x = px + R_B * dirx, nxt_y = py + R_B * diry;
     bool hit = false;
+    uint32_t hit_count = 0u;
     float hnx = 0.0f, hny = 0.0f;
     if (has_n) {
         float t;
@@ -290,7 +298,7 @@ __device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm
             if (dot2(hnx, hny, dirx, diry) > 0) { hnx = -hnx; hny = -hny; }
             nxt_x = cxp + t * dirx;
             nxt_y = cyp + t * diry;
-            S.nhits++;
+            hit_count = 1u;
         }
     }
     // 1/pdf/alpha/2pi is exactly 1.0f in fp32 for both branches (tests/test_oracle_units.py),
@@ -299,11 +307,8 @@ __device__ __forceinline__ bool step_finish(const DevMesh &dm, const DevMesh &nm
     L.px = nxt_x; L.py = nxt_y;
     L.on_n = hit; L.nx = hnx; L.ny = hny;
     L.depth++;
-    if (L.depth == (uint32_t)st.max_depth) {
-        S.truncated++;
-        return true;
-    }
-    return false;
+    const bool truncated = L.depth == (uint32_t)st.max_depth;
+    return (truncated ? (STEP_ENDED | STEP_TRUNCATED) : 0u) | (hit_count ? STEP_NEUMANN_HIT : 0u);
 }
 
 template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE>
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
     const uint32_t n_in = *P.count_in;
     const bool valid = slot < n_in;
     Lane L;
-    LaneStats S{0, 0, 0, 0, 0, 0, 0};
+    LaneStats S{0, 0, 0, 0};
     uint32_t pix = 0;
     bool alive = false;
     if (valid) {
@@ -363,7 +368,10 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
             // ---- step phase ----
             if (mode == MODE_WAIT) {
                 if (!fresh) {
-                    const bool ended = step_finish<NEUMANN_EMISSIVE, NEUMANN_TREE>(P.dm, P.nm, P.st, L, S, T.best, stk);
+                    const uint32_t status = step_finish<NEUMANN_EMISSIVE, NEUMANN_TREE>(P.dm, P.nm, P.st, L, T.best, stk);
+                    const bool ended = (status & STEP_ENDED) != 0u;
+                    S.b += ((status >> 1) & 1u) | (((status >> 2) & 1u) << 16);
+                    S.c += (status >> 3) & 1u;
                     if (ended) {
                         // next sample of this pixel starts right away (generateEvaluationPoints,
                         // reference integrator.cu:90-99 + workqueue.h:99-110)
@@ -378,8 +386,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
                 }
                 fresh = false;
                 if (alive && budget > 0) {
-                    S.steps++;
-                    if (L.depth == 0) S.started++;
+                    S.a += 1u + ((L.depth == 0) ? 0x10000u : 0u);
                     if (!has_d || L.depth == 0) {
                         // depth 0 starts at the same point for every sample of the pixel: cached
                         T.best = Closest{L.d0_d2, L.d0_slot};
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
             ++trav_trips;
             for (int b = 0; b < P.trav_burst; ++b) {
                 if (mode == MODE_TRAV) {
-                    if (T.level == P.dm.levels) S.leaf_visits++; else S.inner_visits++;
+                    S.visits++;
                     if (!trav_visit<true>(P.dm, L.px, L.py, T, stk, lds_top, P.top_levels)) mode = MODE_WAIT;
                 }
             }
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
         q.d0_d2[s] = L.d0_d2; q.d0_slot[s] = L.d0_slot;
     }
     // ---- statistics: wave reduction, one atomic per counter per wave -----------------------
-    uint32_t v[7] = {S.steps, S.started, S.absorbed, S.truncated, S.nhits, S.inner_visits, S.leaf_visits};
+    uint32_t v[7] = {S.a & 0xffffu, S.a >> 16, S.b & 0xffffu, S.b >> 16, S.c, S.visits, 0u};
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         uint32_t x = v[k];
@@ -445,7 +452,6 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
         if (v[3]) atomicAdd(&P.stats->truncated, (unsigned long long)v[3]);
         if (v[4]) atomicAdd(&P.stats->nhits, (unsigned long long)v[4]);
         if (v[5]) atomicAdd(&P.stats->inner_visits, (unsigned long long)v[5]);
-        if (v[6]) atomicAdd(&P.stats->leaf_visits, (unsigned long long)v[6]);
         atomicAdd(&P.stats->trav_trips, (unsigned long long)trav_trips);
         atomicAdd(&P.stats->step_trips, (unsigned long long)step_trips);
     }
@@ -759,7 +765,7 @@ int wost_set_option(wost_handle h, const char *key, double value)
     if (!h || !key) return fail(WOST_ERR_INVALID, "null argument");
     const std::string k(key);
     if (k == "steps_per_round") {
-        if (value < 1 || value > 1e6) return fail(WOST_ERR_INVALID, "steps_per_round out of range");
+        if (value < 1 || value > 32767) return fail(WOST_ERR_INVALID, "steps_per_round must be in 1..32767");
         h->steps_per_round = (int)value;
     } else if (k == "block_size") {
         const int b = (int)value;

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(64, 4) void walk_pool_kernel(PoolParams P)
     const bool has_d = P.dm.n_segs > 0;
     const int levels = P.dm.levels;
     const uint32_t spp = (uint32_t)P.st.spp;
-    LaneStats S{0, 0, 0, 0, 0, 0, 0};
+    // the pool kernel runs the whole solve in one launch: full-width counters
+    uint32_t n_steps = 0, n_started = 0, n_absorbed = 0, n_truncated = 0, n_hits = 0, n_inner = 0, n_leaf = 0;
     uint32_t trav_trips = 0, step_trips = 0;
     int max_sp = 0;
     bool exhausted = false;  // wave-uniform: the global queue has no more walkers
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(64, 4) void walk_pool_kernel(PoolParams P)
     // Start the next walk step of walker w: count it, then either use the cached depth-0
     // answer of the pixel or seed a traversal with the temporal hint.
     auto begin_step = [&](int w, uint32_t depth, float px, float py, int32_t hint, uint32_t g) {
-        S.steps++;
-        if (depth == 0) S.started++;
+        n_steps++;
+        n_started += (depth == 0) ? 1u : 0u;
         if (!has_d || depth == 0) {
             L.bd2[w] = P.q.d0_d2[g];
             L.bslot[w] = P.q.d0_slot[g];
@@ -176,10 +177,10 @@ __global__ __launch_bounds__(64, 4) void walk_pool_kernel(PoolParams P)
                                       P.spill + (size_t)blockIdx.x * NW + w, (uint32_t)(gridDim.x * NW)};
                 bool more;
                 if (kind == W_INNER) {
-                    S.inner_visits++;
+                    n_inner++;
                     more = trav_visit<false, 1>(P.dm, qx, qy, T, stk);
                 } else {
-                    S.leaf_visits++;
+                    n_leaf++;
                     more = trav_visit<false, 2>(P.dm, qx, qy, T, stk);
                 }
                 L.lvlpos[w] = ((uint32_t)T.level << 28) | (uint32_t)T.pos;
@@ -212,7 +213,11 @@ __global__ __launch_bounds__(64, 4) void walk_pool_kernel(PoolParams P)
                 // queries of the step logic use it
                 const SplitColumn stk{L.stack + w, (uint32_t)NW, P.stack_words,
                                       P.spill + (size_t)blockIdx.x * NW + w, (uint32_t)(gridDim.x * NW)};
-                const bool ended = step_finish<NEUMANN_EMISSIVE, NEUMANN_TREE>(P.dm, P.nm, P.st, A, S, cp, stk);
+                const uint32_t status = step_finish<NEUMANN_EMISSIVE, NEUMANN_TREE>(P.dm, P.nm, P.st, A, cp, stk);
+                const bool ended = (status & STEP_ENDED) != 0u;
+                n_absorbed += (status >> 1) & 1u;
+                n_truncated += (status >> 2) & 1u;
+                n_hits += (status >> 3) & 1u;
                 bool alive = true;
                 if (ended) {
                     // next sample of this pixel starts right away (generateEvaluationPoints,
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(64, 4) void walk_pool_kernel(PoolParams P)
     }
 
     // ---- statistics: wave reduction, one atomic per counter per wave ----
-    uint32_t v[7] = {S.steps, S.started, S.absorbed, S.truncated, S.nhits, S.inner_visits, S.leaf_visits};
+    uint32_t v[7] = {n_steps, n_started, n_absorbed, n_truncated, n_hits, n_inner, n_leaf};
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         uint32_t x = v[k];

@@ -125,7 +125,7 @@ def test_config1_field_is_bit_exact_vs_golden(scene):
     it.close()
 
 
-@pytest.mark.parametrize("steps_per_round", [1, 7, 64, 4096])
+@pytest.mark.parametrize("steps_per_round", [1, 7, 64, 4096, 32767])
 def test_round_length_does_not_change_results(oracle, ladybug, steps_per_round):
     _assert_same_solve(oracle, ladybug, 48, 40, 6, 24, 1.0, steps_per_round=steps_per_round)
 
