@@ -814,7 +814,10 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     const int bs = c->block_size;
     const int levels = c->dm.view.n_segs > 0 ? c->dm.view.levels : 1;
     const int levels_any = std::max(levels, c->nm.view.n_segs > 0 ? c->nm.view.levels : 1);
-    const int stack_depth = 3 * (levels_any + 1) + 4;
+    // closest point: pushes happen on the inner levels 0..L-1, at most 3 per level, and the
+    // branch-free pushes never write beyond entry 3L-1; the Neumann tree queries push up to 4
+    // and pop 1 per inner level: 3L+1 entries
+    const int stack_depth = 3 * levels_any + 1;
     const size_t lds = (size_t)stack_depth * bs * sizeof(uint32_t);
     HIP_TRY(hipMemsetAsync(c->counts, 0, 2 * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(StatsDev), stream));
@@ -861,7 +864,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         pp.field = field_dev;
         pp.field_base = field_base;
         pp.stats = c->stats;
-        const int full_stack = 3 * (levels_any + 1) + 4;
+        const int full_stack = 3 * levels_any + 1;
         pp.stack_words = std::min(full_stack, c->pool_stack);
         pp.step_weight = c->step_weight;
         const int K = c->pool_k;
@@ -1046,7 +1049,7 @@ int wost_render_sdf(wost_handle h, int which_mesh, float *out_dist)
     HIP_TRY(hipSetDevice(h->device));
     const int bs = 256;
     const int levels = m->view.n_segs > 0 ? m->view.levels : 1;
-    const size_t lds = (size_t)(3 * (levels + 1) + 4) * bs * sizeof(uint32_t);
+    const size_t lds = (size_t)(3 * levels + 1) * bs * sizeof(uint32_t);
     const int n = (int)h->n_pixels;
     float *d_out = h->field;  // reuse: n_pixels floats fit in the field buffer
     hipLaunchKernelGGL(sdf_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, h->probe,
@@ -1075,7 +1078,7 @@ int wost_closest_point(wost_handle h, int which_mesh, const float *pts, int32_t 
     HIP_TRY(s.alloc(&d_side, n));
     HIP_TRY(hipMemcpyAsync(d_pts, pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
     const int bs = 256;
-    const size_t lds = (size_t)(3 * (m->view.levels + 1) + 4) * bs * sizeof(uint32_t);
+    const size_t lds = (size_t)(3 * m->view.levels + 1) * bs * sizeof(uint32_t);
     hipLaunchKernelGGL(closest_point_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, d_pts, n,
                        d_idx, d_dist, d_uv, d_side, bs);
     HIP_TRY(hipGetLastError());
@@ -1105,7 +1108,7 @@ int wost_closest_silhouette(wost_handle h, int which_mesh, const float *pts, con
         HIP_TRY(hipMemcpyAsync(d_rmax, rmax, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     }
     const int bs = 256;
-    const size_t lds = (size_t)(3 * ((m->view.n_segs > 0 ? m->view.levels : 1) + 1) + 4) * bs * sizeof(uint32_t);
+    const size_t lds = (size_t)(3 * (m->view.n_segs > 0 ? m->view.levels : 1) + 1) * bs * sizeof(uint32_t);
     hipLaunchKernelGGL(silhouette_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, d_pts, d_rmax, n,
                        d_out);
     HIP_TRY(hipGetLastError());
@@ -1136,7 +1139,7 @@ int wost_ray_intersect(wost_handle h, int which_mesh, const float *origins, cons
     HIP_TRY(hipMemcpyAsync(d_d, dirs, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(d_tm, tmax, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     const int bs = 256;
-    const size_t lds = (size_t)(3 * ((m->view.n_segs > 0 ? m->view.levels : 1) + 1) + 4) * bs * sizeof(uint32_t);
+    const size_t lds = (size_t)(3 * (m->view.n_segs > 0 ? m->view.levels : 1) + 1) * bs * sizeof(uint32_t);
     hipLaunchKernelGGL(ray_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, d_o, d_d, d_tm, n, d_hit,
                        d_t, d_idx);
     HIP_TRY(hipGetLastError());
