@@ -73,7 +73,7 @@ class Stats(C.Structure):
 EXPORTS = [
     "wost_create", "wost_solve", "wost_solve_sharded", "wost_render_sdf", "wost_closest_point",
     "wost_closest_silhouette", "wost_ray_intersect", "wost_set_option", "wost_destroy",
-    "wost_vonmises_eval", "wost_vonmises_sample", "wost_vmm_pdf_sample",
+    "wost_vonmises_eval", "wost_vonmises_sample", "wost_vmm_pdf_sample", "wost_vmm_loss_gradients",
     "wost_last_error", "wost_version",
 ]
 
@@ -115,6 +115,7 @@ def load():
     L.wost_vonmises_eval.argtypes = [C.c_int, fp, fp, C.c_int32, fp, fp, fp, fp]
     L.wost_vonmises_sample.argtypes = [C.c_int, fp, u64p, C.c_int32, C.c_int32, fp]
     L.wost_vmm_pdf_sample.argtypes = [C.c_int, fp, fp, u64p, C.c_int32, fp, fp]
+    L.wost_vmm_loss_gradients.argtypes = [C.c_int, fp, fp, fp, fp, C.POINTER(C.c_uint8), fp, C.c_int32, C.c_float, fp, fp]
     L.wost_destroy.argtypes = [C.c_void_p]
     L.wost_last_error.restype = C.c_char_p
     L.wost_version.restype = C.c_char_p

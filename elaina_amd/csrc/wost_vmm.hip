@@ -190,6 +190,86 @@ __global__ void vmm_pdf_sample_kernel(const float *raw, const float *wi, const u
     }
 }
 
+// training-side gradient of the mixture and of the selection logit: reference
+// integrator/guided/distribution.h:201-264 (gradients_probability) + train.h:492-553
+// (compute_dL_doutput_divergence), one thread per training sample.
+__global__ void vmm_loss_gradients_kernel(const float *raw, const float *dir, const float *li, const float *dir_pdf,
+                                          const uint8_t *on_neumann, const float *normal, int n, float loss_scale,
+                                          float *dl_draw, float *likelihood)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const float eps = 1e-5f;  // M_EPSILON
+    const float scale = loss_scale / (float)n;
+    const float *d = raw + 33 * (size_t)t;
+    float *grad = dl_draw + 33 * (size_t)t;
+    float lambda[8], kap[8], mux[8], muy[8], ox[8], oy[8], pk[8], pkr[8];
+    float total = 0.0f;
+    const float wx = dir[2 * t], wy = dir[2 * t + 1];
+    const bool on_n = on_neumann && on_neumann[t] != 0;
+    float rx = 0.0f, ry = 0.0f;
+    if (on_n) {
+        const float nx = normal[2 * t], ny = normal[2 * t + 1];
+        const float dd = wx * nx + wy * ny;
+        rx = wx - 2 * dd * nx;
+        ry = wy - 2 * dd * ny;
+    }
+    for (int k = 0; k < 8; ++k) {
+        lambda[k] = expf(fmaxf(fminf(d[4 * k], 15.0f), -10.0f));
+        kap[k] = expf(fmaxf(fminf(d[4 * k + 1], 15.0f), -10.0f));
+        ox[k] = d[4 * k + 2];
+        oy[k] = d[4 * k + 3];
+        const float nn = sqrtf(ox[k] * ox[k] + oy[k] * oy[k]);
+        mux[k] = ox[k] / nn;
+        muy[k] = oy[k] / nn;
+        total += lambda[k];
+    }
+    for (int k = 0; k < 8; ++k) {
+        pk[k] = vm_eval(kap[k], wx * mux[k] + wy * muy[k]);
+        pkr[k] = on_n ? vm_eval(kap[k], rx * mux[k] + ry * muy[k]) : 0.0f;
+    }
+    float probability = 0.0f;
+    for (int sg = 0; sg < 8; ++sg) {
+        const float w = lambda[sg] / total;
+        const float vm = pk[sg], vmr = pkr[sg];
+        probability += w * vm;
+        if (on_n) probability += w * vmr;
+        float dF_dlambda = (vm + vmr) * (total - lambda[sg]) / (total * total);
+        for (int k = 0; k < 8; ++k) {
+            if (k == sg) continue;
+            const float wk = lambda[k] / total;
+            dF_dlambda -= wk / total * pk[k];
+            if (on_n) dF_dlambda -= wk / total * pkr[k];
+        }
+        float dF_dkappa = w * (vm * vm_dlog_dkappa(kap[sg], wx * mux[sg] + wy * muy[sg]));
+        if (on_n) dF_dkappa += w * (vmr * vm_dlog_dkappa(kap[sg], rx * mux[sg] + ry * muy[sg]));
+        float denom = powf(ox[sg] * ox[sg] + oy[sg] * oy[sg], 1.5f);
+        if (denom < eps) denom = eps;
+        float dF_dx = w * vm * kap[sg] * oy[sg] * (-ox[sg] * wy + oy[sg] * wx) / denom;
+        if (on_n) dF_dx += w * vmr * kap[sg] * oy[sg] * (-ox[sg] * ry + oy[sg] * rx) / denom;
+        float dF_dy = w * vm * kap[sg] * ox[sg] * (ox[sg] * wy - oy[sg] * wx) / denom;
+        if (on_n) dF_dy += w * vmr * kap[sg] * ox[sg] * (ox[sg] * ry - oy[sg] * rx) / denom;
+        grad[4 * sg + 0] = dF_dlambda;
+        grad[4 * sg + 1] = dF_dkappa;
+        grad[4 * sg + 2] = dF_dx;
+        grad[4 * sg + 3] = dF_dy;
+    }
+    const float Li = li[t];
+    const float dirPdf = dir_pdf[t] + eps;
+    const float guidePdf = probability + eps;
+    const float prefix = -Li / dirPdf / guidePdf * scale;
+    if (likelihood) likelihood[t] = -Li / dirPdf * logf(guidePdf);
+    for (int sg = 0; sg < 8; ++sg) {
+        grad[4 * sg + 0] = prefix * grad[4 * sg + 0] * expf(fmaxf(fminf(d[4 * sg], 15.0f), -10.0f));
+        grad[4 * sg + 1] = prefix * grad[4 * sg + 1] * expf(fmaxf(fminf(d[4 * sg + 1], 15.0f), -10.0f));
+        grad[4 * sg + 2] = prefix * grad[4 * sg + 2];
+        grad[4 * sg + 3] = prefix * grad[4 * sg + 3];
+    }
+    const float uni = on_n ? (float)(1.0 / VM_PI_D) : 1.0f / VM_2PI;
+    const float sgm = 1.0f / (1.0f + expf(-d[32]));
+    grad[32] = scale * (-0.2f) * Li * (guidePdf - uni) / (dirPdf * dirPdf) * (sgm * (1 - sgm));
+}
+
 struct DevBufs {
     std::vector<void *> ptrs;
     ~DevBufs()
@@ -303,6 +383,34 @@ int wost_vmm_pdf_sample(int device, const float *raw, const float *wi, const uin
     VMM_TRY(hipGetLastError());
     if (pdf) VMM_TRY(hipMemcpy(pdf, dp, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (sample_dir) VMM_TRY(hipMemcpy(sample_dir, dd, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return WOST_OK;
+}
+
+int wost_vmm_loss_gradients(int device, const float *raw, const float *dir, const float *li, const float *dir_pdf,
+                            const uint8_t *on_neumann, const float *normal, int32_t n, float loss_scale, float *dl_draw,
+                            float *likelihood)
+{
+    if (!raw || !dir || !li || !dir_pdf || !dl_draw || n < 0 || (on_neumann && !normal))
+        return set_error(WOST_ERR_INVALID, "bad argument");
+    if (n == 0) return WOST_OK;
+    int rc = pick_device(device);
+    if (rc != WOST_OK) return rc;
+    DevBufs b;
+    float *dr, *dd, *dli, *dp, *dn, *dg, *dl;
+    uint8_t *don;
+    VMM_TRY(b.in(&dr, raw, (size_t)n * 33));
+    VMM_TRY(b.in(&dd, dir, (size_t)n * 2));
+    VMM_TRY(b.in(&dli, li, n));
+    VMM_TRY(b.in(&dp, dir_pdf, n));
+    VMM_TRY(b.in(&don, on_neumann, n));
+    VMM_TRY(b.in(&dn, normal, (size_t)n * 2));
+    VMM_TRY(b.out(&dg, dl_draw, (size_t)n * 33));
+    VMM_TRY(b.out(&dl, likelihood, n));
+    hipLaunchKernelGGL(vmm_loss_gradients_kernel, dim3((n + 127) / 128), dim3(128), 0, 0, dr, dd, dli, dp, don, dn, n,
+                       loss_scale, dg, dl);
+    VMM_TRY(hipGetLastError());
+    VMM_TRY(hipMemcpy(dl_draw, dg, (size_t)n * 33 * 4, hipMemcpyDeviceToHost));
+    if (likelihood) VMM_TRY(hipMemcpy(likelihood, dl, (size_t)n * 4, hipMemcpyDeviceToHost));
     return WOST_OK;
 }
 

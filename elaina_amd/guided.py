@@ -42,3 +42,19 @@ def vmm_pdf_sample(raw, wi, seed, device=0):
     d = np.zeros((n, 2), dtype=np.float32)
     _check(lib.wost_vmm_pdf_sample(device, _fp(r), _fp(w), _u64(s), n, _fp(pdf), _fp(d)), "wost_vmm_pdf_sample")
     return pdf, d
+
+
+def vmm_loss_gradients(raw33, dirs, li, dir_pdf, on_neumann, normal, loss_scale=128.0, device=0):
+    lib = capi.load()
+    r = np.ascontiguousarray(raw33, dtype=np.float32)
+    d = np.ascontiguousarray(dirs, dtype=np.float32)
+    l = np.ascontiguousarray(li, dtype=np.float32)
+    p = np.ascontiguousarray(dir_pdf, dtype=np.float32)
+    o = np.ascontiguousarray(on_neumann, dtype=np.uint8)
+    nn = np.ascontiguousarray(normal, dtype=np.float32)
+    n = len(l)
+    g = np.zeros((n, 33), dtype=np.float32)
+    lk = np.zeros(n, dtype=np.float32)
+    _check(lib.wost_vmm_loss_gradients(device, _fp(r), _fp(d), _fp(l), _fp(p), o.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                       _fp(nn), n, C.c_float(loss_scale), _fp(g), _fp(lk)), "wost_vmm_loss_gradients")
+    return g, lk

@@ -153,6 +153,16 @@ int wost_vonmises_sample(int device, const float *kappa, const uint64_t *seed, i
 int wost_vmm_pdf_sample(int device, const float *raw, const float *wi, const uint64_t *seed,
                         int32_t n, float *pdf, float *sample_dir);
 
+/* Training-side gradients: VMM<2,8>::gradients_probability
+ * (distribution.h:201-264) chained with compute_dL_doutput_divergence (train.h:492-553) for n
+ * samples: raw[n*33] network outputs (8 lobes + selection logit), reference record per sample
+ * (dir[n*2], li = mean |solution/thp|, dir_pdf, on_neumann flags (may be NULL), normal[n*2]),
+ * loss_scale (the reference uses 128, divided by n inside).  Outputs dL/draw[n*33] and the
+ * per-sample likelihood term (may be NULL). */
+int wost_vmm_loss_gradients(int device, const float *raw, const float *dir, const float *li,
+                            const float *dir_pdf, const uint8_t *on_neumann, const float *normal,
+                            int32_t n, float loss_scale, float *dl_draw, float *likelihood);
+
 /* Tuning knobs ("steps_per_round", "block_size", ...); unknown keys -> WOST_ERR_INVALID. */
 int wost_set_option(wost_handle h, const char *key, double value);
 

@@ -282,6 +282,20 @@ class Oracle:
         self.lib.wo_vonmises_sample(_fp(k), s.ctypes.data_as(C.POINTER(C.c_uint64)), len(k), per_point, _fp(th))
         return th.reshape(len(k), per_point)
 
+    def vmm_loss_gradients(self, raw33, dirs, li, dir_pdf, on_neumann, normal, loss_scale=128.0):
+        r = np.ascontiguousarray(raw33, dtype=np.float32)
+        d = np.ascontiguousarray(dirs, dtype=np.float32)
+        l = np.ascontiguousarray(li, dtype=np.float32)
+        p = np.ascontiguousarray(dir_pdf, dtype=np.float32)
+        o = np.ascontiguousarray(on_neumann, dtype=np.uint8)
+        nn = np.ascontiguousarray(normal, dtype=np.float32)
+        n = len(l)
+        g = np.zeros((n, 33), dtype=np.float32)
+        lk = np.zeros(n, dtype=np.float32)
+        self.lib.wo_vmm_loss_gradients(_fp(r), _fp(d), _fp(l), _fp(p), o.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(nn), n,
+                                       C.c_float(loss_scale), _fp(g), _fp(lk))
+        return g, lk
+
     def vmm_pdf_sample(self, raw, wi, seed):
         r = np.ascontiguousarray(raw, dtype=np.float32)
         w = np.ascontiguousarray(wi, dtype=np.float32)

@@ -131,6 +131,9 @@ int wo_vonmises_eval(const float *kappa, const float *cos_theta, int n, float *l
                      float *log_pdf, float *dlog_dkappa);
 int wo_vonmises_sample(const float *kappa, const uint64_t *seed, int n, int per_point, float *theta);
 int wo_vmm_pdf_sample(const float *raw, const float *wi, const uint64_t *seed, int n, float *pdf, float *dir);
+int wo_vmm_loss_gradients(const float *raw, const float *dir, const float *li, const float *dir_pdf,
+                          const unsigned char *on_neumann, const float *normal, int n, float loss_scale,
+                          float *dl_draw, float *likelihood);
 
 const char *wo_version(void);
 

@@ -207,3 +207,82 @@ int wo_vmm_pdf_sample(const float *raw, const float *wi, const uint64_t *seed, i
     }
     return 0;
 }
+
+/* ---- training-side gradient of the mixture -----------------------
+ * restates integrator/guided/distribution.h:201-264 (VMM<2,N>::gradients_probability),
+ * integrator/guided/train.h:81-105 (d_network_to_d_params) and :492-553
+ * (compute_dL_doutput_divergence).  `raw`: 33 floats per sample (8 lobes x (lambda, kappa,
+ * mu.x, mu.y) + selection logit); reference record per sample: dir[2], Li, dirPdf, onNeumann,
+ * normal[2].  Outputs: dL/draw (33 per sample) and the per-sample likelihood term. */
+#define WV_EPS 1e-5f     /* M_EPSILON, core/math/include/krrmath/constants.h */
+
+static float wv_d_exp_act(float v) { return expf(clampf(v, -10.0f, 15.0f)); }
+
+int wo_vmm_loss_gradients(const float *raw, const float *dir, const float *li, const float *dir_pdf,
+                          const unsigned char *on_neumann, const float *normal, int n, float loss_scale,
+                          float *dl_draw, float *likelihood)
+{
+    const float scale = loss_scale / (float)n;                /* train.h:512 */
+    for (int t = 0; t < n; ++t) {
+        const float *data = raw + 33 * (size_t)t;
+        float *grad = dl_draw + 33 * (size_t)t;
+        wv_vmm m;
+        vmm_build(&m, data);
+        const float wx = dir[2 * t], wy = dir[2 * t + 1];
+        const int on_n = on_neumann ? on_neumann[t] : 0;
+        float rx = 0.0f, ry = 0.0f;
+        if (on_n) {   /* reflect(wi, n) = wi - 2 (wi.n) n, util/transformation.h:69-72 */
+            const float nx = normal[2 * t], ny = normal[2 * t + 1];
+            const float d = wx * nx + wy * ny;
+            rx = wx - 2 * d * nx; ry = wy - 2 * d * ny;
+        }
+        float pdf_k[WV_NCOMP], pdf_kr[WV_NCOMP];
+        for (int k = 0; k < WV_NCOMP; ++k) {
+            pdf_k[k] = wo_vm_eval(m.sg[k].kappa, wx * m.sg[k].mux + wy * m.sg[k].muy);
+            pdf_kr[k] = on_n ? wo_vm_eval(m.sg[k].kappa, rx * m.sg[k].mux + ry * m.sg[k].muy) : 0.0f;
+        }
+        float probability = 0.0f;
+        for (int sg = 0; sg < WV_NCOMP; ++sg) {
+            const float lambda = m.sg[sg].lambda, kappa = m.sg[sg].kappa;
+            const float mox = m.sg[sg].ox, moy = m.sg[sg].oy;
+            const float vm = pdf_k[sg];
+            probability += m.weight[sg] * vm;
+            float vmr = 0.0f;
+            if (on_n) { vmr = pdf_kr[sg]; probability += m.weight[sg] * vmr; }
+            float dF_dlambda = (vm + vmr) * (m.total - lambda) / (m.total * m.total);
+            for (int k = 0; k < WV_NCOMP; ++k) {
+                if (k == sg) continue;
+                dF_dlambda -= m.weight[k] / m.total * pdf_k[k];
+                if (on_n) dF_dlambda -= m.weight[k] / m.total * pdf_kr[k];
+            }
+            /* d pdf / d kappa = pdf * d log pdf / d kappa (vonmises.h:165-168) */
+            float dF_dkappa = m.weight[sg] * (vm * wo_vm_dlog_dkappa(kappa, wx * m.sg[sg].mux + wy * m.sg[sg].muy));
+            if (on_n) dF_dkappa += m.weight[sg] * (vmr * wo_vm_dlog_dkappa(kappa, rx * m.sg[sg].mux + ry * m.sg[sg].muy));
+            float denom = powf(mox * mox + moy * moy, 1.5f);
+            if (denom < WV_EPS) denom = WV_EPS;
+            float dF_dx = m.weight[sg] * vm * kappa * moy * (-mox * wy + moy * wx) / denom;
+            if (on_n) dF_dx += m.weight[sg] * vmr * kappa * moy * (-mox * ry + moy * rx) / denom;
+            float dF_dy = m.weight[sg] * vm * kappa * mox * (mox * wy - moy * wx) / denom;
+            if (on_n) dF_dy += m.weight[sg] * vmr * kappa * mox * (mox * ry - moy * rx) / denom;
+            grad[4 * sg + 0] = dF_dlambda; grad[4 * sg + 1] = dF_dkappa;
+            grad[4 * sg + 2] = dF_dx; grad[4 * sg + 3] = dF_dy;
+        }
+        const float Li = li[t];
+        const float dirPdf = dir_pdf[t] + WV_EPS;
+        const float guidePdf = probability + WV_EPS;
+        const float prefix = -Li / dirPdf / guidePdf * scale;
+        if (likelihood) likelihood[t] = -Li / dirPdf * logf(guidePdf);
+        for (int sg = 0; sg < WV_NCOMP; ++sg) {
+            grad[4 * sg + 0] = prefix * grad[4 * sg + 0] * wv_d_exp_act(data[4 * sg + 0]);
+            grad[4 * sg + 1] = prefix * grad[4 * sg + 1] * wv_d_exp_act(data[4 * sg + 1]);
+            grad[4 * sg + 2] = prefix * grad[4 * sg + 2];
+            grad[4 * sg + 3] = prefix * grad[4 * sg + 3];
+        }
+        /* selection probability (train.h:541-552): Logistic activation */
+        const float e = 0.2f;
+        const float uni = on_n ? (float)(1.0 / WV_PI_D) : 1.0f / WV_2PI;
+        const float sgm = 1.0f / (1.0f + expf(-data[32]));
+        grad[32] = scale * (-e) * Li * (guidePdf - uni) / (dirPdf * dirPdf) * (sgm * (1 - sgm));
+    }
+    return 0;
+}

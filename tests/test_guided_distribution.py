@@ -124,3 +124,46 @@ def test_hip_vmm_pdf_and_sample_match_oracle(oracle):
     assert np.allclose(gp, rp, rtol=1e-4, atol=1e-7)     # 1e-4 agreement of the VMM sub-kernels
     close = np.isclose(gd, rd, rtol=0, atol=1e-5).all(1)
     assert close.mean() > 0.999, close.mean()
+
+
+def _random_training_batch(rng, n):
+    raw = rng.normal(0, 1, size=(n, 33)).astype(np.float32)
+    raw[:, 1:32:4] = rng.uniform(-2, 4, size=(n, 8))
+    ang = rng.uniform(0, 2 * np.pi, n)
+    dirs = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+    li = rng.uniform(0.0, 1.0, n).astype(np.float32)
+    dir_pdf = rng.uniform(0.05, 0.6, n).astype(np.float32)
+    on_n = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    na = rng.uniform(0, 2 * np.pi, n)
+    normal = np.stack([np.cos(na), np.sin(na)], 1).astype(np.float32)
+    return raw, dirs, li, dir_pdf, on_n, normal
+
+
+def test_vmm_loss_gradients_are_the_gradient_of_the_likelihood(oracle):
+    # the analytic chain (distribution.h:201-264 x train.h:518-538) must equal d/draw of the
+    # likelihood term -Li/q * log p(raw) that the same kernel reports (train.h:520)
+    rng = np.random.default_rng(0)
+    n = 8
+    raw, dirs, li, dir_pdf, on_n, normal = _random_training_batch(rng, n)
+    g, _ = oracle.vmm_loss_gradients(raw, dirs, li, dir_pdf, on_n, normal, loss_scale=float(n))
+    eps = 1e-3
+    for j in range(32):
+        hi, lo = raw.copy(), raw.copy()
+        hi[:, j] += eps
+        lo[:, j] -= eps
+        _, lh = oracle.vmm_loss_gradients(hi, dirs, li, dir_pdf, on_n, normal, float(n))
+        _, ll = oracle.vmm_loss_gradients(lo, dirs, li, dir_pdf, on_n, normal, float(n))
+        num = (lh - ll) / (2 * eps)
+        assert np.allclose(num, g[:, j], rtol=3e-2, atol=3e-3), j
+
+
+@pytest.mark.gpu
+def test_hip_vmm_loss_gradients_match_oracle(oracle):
+    from elaina_amd import guided
+    rng = np.random.default_rng(6)
+    batch = _random_training_batch(rng, 20000)
+    gg, gl = guided.vmm_loss_gradients(*batch)
+    rg, rl = oracle.vmm_loss_gradients(*batch)
+    scale = np.abs(rg).max(axis=1, keepdims=True) + 1e-12
+    assert np.all(np.abs(gg - rg) <= 2e-4 * scale + 1e-9)     # 1e-4-level agreement
+    assert np.allclose(gl, rl, rtol=1e-4, atol=1e-6)
