@@ -70,10 +70,23 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class NetConfig(C.Structure):
+    """wost_net_config (include/wost.h); defaults = reference data/ladybug/n.json:49-81."""
+    _fields_ = [
+        ("n_levels", C.c_int32), ("n_features_per_level", C.c_int32), ("base_resolution", C.c_int32),
+        ("per_level_scale", C.c_float),
+        ("n_neurons", C.c_int32), ("n_hidden_layers", C.c_int32), ("n_output", C.c_int32),
+        ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float),
+        ("l2_reg", C.c_float), ("ema_decay", C.c_float),
+    ]
+
+
 EXPORTS = [
     "wost_create", "wost_solve", "wost_solve_sharded", "wost_render_sdf", "wost_closest_point",
     "wost_closest_silhouette", "wost_ray_intersect", "wost_set_option", "wost_destroy",
     "wost_vonmises_eval", "wost_vonmises_sample", "wost_vmm_pdf_sample", "wost_vmm_loss_gradients",
+    "wost_net_create", "wost_net_destroy", "wost_net_n_params", "wost_net_get_params",
+    "wost_net_set_params", "wost_net_inference", "wost_net_train_step",
     "wost_last_error", "wost_version",
 ]
 
@@ -116,6 +129,13 @@ def load():
     L.wost_vonmises_sample.argtypes = [C.c_int, fp, u64p, C.c_int32, C.c_int32, fp]
     L.wost_vmm_pdf_sample.argtypes = [C.c_int, fp, fp, u64p, C.c_int32, fp, fp]
     L.wost_vmm_loss_gradients.argtypes = [C.c_int, fp, fp, fp, fp, C.POINTER(C.c_uint8), fp, C.c_int32, C.c_float, fp, fp]
+    L.wost_net_create.argtypes = [C.c_int, C.POINTER(NetConfig), C.c_uint64, C.POINTER(C.c_void_p)]
+    L.wost_net_destroy.argtypes = [C.c_void_p]
+    L.wost_net_n_params.argtypes = [C.c_void_p, u64p, u64p]
+    L.wost_net_get_params.argtypes = [C.c_void_p, C.c_int, fp]
+    L.wost_net_set_params.argtypes = [C.c_void_p, fp]
+    L.wost_net_inference.argtypes = [C.c_void_p, fp, C.c_int32, fp, C.c_int]
+    L.wost_net_train_step.argtypes = [C.c_void_p, fp, fp, C.c_int32, C.c_float, C.c_int]
     L.wost_destroy.argtypes = [C.c_void_p]
     L.wost_last_error.restype = C.c_char_p
     L.wost_version.restype = C.c_char_p

@@ -1,0 +1,483 @@
+// wost_net.hip -- the guiding network of the guided integrator on the device (SURVEY.md 8a rows
+// a22/a23 and the optimizer of a27), behind the C-ABI: DenseGrid encoding -> bias-free ReLU MLP
+// -> raw mixture parameters; backward pass; Adam nested in a debiased EMA.  gfx950 only.
+//
+// Replaces (does not port) tiny-cuda-nn as used through the reference adapter
+// util/network.h:21-196 with the configuration of data/ladybug/n.json:49-81.  This first version
+// computes in fp32 (the reference uses half precision on tensor cores): one thread per point,
+// activations in a per-lane LDS column (bank = lane), weights read with scalar loads because
+// they are wave-uniform.  Numerically it is the stronger sibling of the reference network and
+// matches the fp32 CPU oracle to ~1e-6; the f16-MFMA fused version is future work
+// (DESIGN.md section 8).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/wost.h"
+#include "wost_math.h"
+
+namespace wost {
+
+int set_error(int code, const std::string &msg);
+
+constexpr int kNetMaxLevels = 16;
+constexpr int kNetBlock = 64;
+
+struct NetLayout {
+    int32_t res[kNetMaxLevels];
+    float scale[kNetMaxLevels];
+    uint32_t level_off[kNetMaxLevels + 1];  // entries (x n_features floats)
+    int32_t n_levels, n_features, enc, n_neurons, n_hidden, n_out, n_out_padded;
+    uint32_t n_mlp, n_grid;
+    uint32_t w_off[kNetMaxLevels];  // offset of every weight matrix in the parameter vector
+};
+
+static NetLayout make_layout(const wost_net_config &c)
+{
+    NetLayout l{};
+    const float log2s = std::log2(c.per_level_scale);
+    uint32_t off = 0;
+    for (int i = 0; i < c.n_levels; ++i) {
+        l.scale[i] = std::exp2((float)i * log2s) * (float)c.base_resolution - 1.0f;
+        l.res[i] = (int)std::ceil(l.scale[i]) + 1;
+        uint32_t n = (uint32_t)l.res[i] * (uint32_t)l.res[i];
+        n = (n + 7u) / 8u * 8u;
+        l.level_off[i] = off;
+        off += n;
+    }
+    l.level_off[c.n_levels] = off;
+    l.n_levels = c.n_levels;
+    l.n_features = c.n_features_per_level;
+    l.enc = c.n_levels * c.n_features_per_level;
+    l.n_neurons = c.n_neurons;
+    l.n_hidden = c.n_hidden_layers;
+    l.n_out = c.n_output;
+    l.n_out_padded = (c.n_output + 15) / 16 * 16;
+    l.n_grid = off * (uint32_t)c.n_features_per_level;
+    l.w_off[0] = 0;
+    l.w_off[1] = (uint32_t)(l.n_neurons * l.enc);
+    for (int i = 2; i <= l.n_hidden; ++i) l.w_off[i] = l.w_off[i - 1] + (uint32_t)(l.n_neurons * l.n_neurons);
+    l.n_mlp = l.w_off[l.n_hidden] + (uint32_t)(l.n_out_padded * l.n_neurons);
+    return l;
+}
+
+// ---- device code --------------------------------------------------------------------------
+// per-lane activation column in LDS: element k of this thread at col[k * kNetBlock]
+__device__ __forceinline__ float &act(float *col, int k) { return col[k * kNetBlock]; }
+
+// DenseGrid encoding of one point into col[0..enc) (tiny-cuda-nn grid.h: grid_scale,
+// grid_resolution, dense grid_index with wrap, linear interpolation)
+__device__ __forceinline__ void encode_point(const NetLayout &L, const float *grid, float x, float y, float *col)
+{
+    for (int lv = 0; lv < L.n_levels; ++lv) {
+        const float s = L.scale[lv];
+        const uint32_t res = (uint32_t)L.res[lv];
+        const uint32_t n_level = L.level_off[lv + 1] - L.level_off[lv];
+        float px = __builtin_fmaf(s, x, 0.5f), py = __builtin_fmaf(s, y, 0.5f);
+        const float fx = floorf(px), fy = floorf(py);
+        px -= fx;
+        py -= fy;
+        const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+        for (int q = 0; q < L.n_features; ++q) act(col, lv * L.n_features + q) = 0.0f;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
+            const float w = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
+            const uint32_t idx = (cx + cy * res) % n_level;
+            const float *g = grid + (size_t)(L.level_off[lv] + idx) * L.n_features;
+            for (int q = 0; q < L.n_features; ++q) act(col, lv * L.n_features + q) += w * g[q];
+        }
+    }
+}
+
+// out[r] = sum_k W[r][k] * in[k] (k ascending, fma chain), optional ReLU.  W is wave-uniform.
+__device__ __forceinline__ void dense_layer(const float *W, int n_out, int n_in, const float *in_col, float *out_col, bool relu)
+{
+    for (int r0 = 0; r0 < n_out; r0 += 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < n_in; ++k) {
+            const float a = in_col[k * kNetBlock];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(W[(size_t)(r0 + j) * n_in + k], a, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out_col[(r0 + j) * kNetBlock] = relu ? fmaxf(acc[j], 0.0f) : acc[j];
+    }
+}
+
+// forward; out: n x n_out (unpadded).  acts (optional): n x (enc + n_hidden * n_neurons), the
+// activations the backward pass needs.
+__global__ __launch_bounds__(kNetBlock) void net_forward_kernel(NetLayout L, const float *params, const float *xy, int n,
+                                                                float *out, float *acts)
+{
+    extern __shared__ float lds[];
+    float *col_a = lds + threadIdx.x;                       // ping
+    float *col_b = lds + 64 * kNetBlock + threadIdx.x;      // pong (widths <= 64)
+    const int p = blockIdx.x * kNetBlock + threadIdx.x;
+    const bool valid = p < n;
+    const float x = valid ? xy[2 * p] : 0.5f, y = valid ? xy[2 * p + 1] : 0.5f;
+    encode_point(L, params + L.n_mlp, x, y, col_a);
+    const int stride = L.enc + L.n_hidden * L.n_neurons;
+    if (acts && valid)
+        for (int k = 0; k < L.enc; ++k) acts[(size_t)p * stride + k] = act(col_a, k);
+    float *in = col_a, *o = col_b;
+    int n_in = L.enc;
+    for (int layer = 0; layer < L.n_hidden; ++layer) {
+        dense_layer(params + L.w_off[layer], L.n_neurons, n_in, in, o, true);
+        if (acts && valid)
+            for (int k = 0; k < L.n_neurons; ++k) acts[(size_t)p * stride + L.enc + layer * L.n_neurons + k] = act(o, k);
+        float *t = in; in = o; o = t;
+        n_in = L.n_neurons;
+    }
+    dense_layer(params + L.w_off[L.n_hidden], L.n_out_padded, n_in, in, o, false);
+    if (valid)
+        for (int k = 0; k < L.n_out; ++k) out[(size_t)p * L.n_out + k] = act(o, k);
+}
+
+// backward, one thread per point: propagates dL/dout to every layer input (kept per point in
+// `deltas`: n x (n_out_padded + n_hidden * n_neurons)), and scatters the encoding gradient into
+// the grid with float atomics.  Weight gradients are formed afterwards by weight_grad_kernel.
+__global__ __launch_bounds__(kNetBlock) void net_backward_kernel(NetLayout L, const float *params, const float *xy,
+                                                                 const float *dl_dout, const float *acts, int n, float *deltas,
+                                                                 float *grad)
+{
+    extern __shared__ float lds[];
+    float *col_a = lds + threadIdx.x;
+    float *col_b = lds + 64 * kNetBlock + threadIdx.x;
+    const int p = blockIdx.x * kNetBlock + threadIdx.x;
+    const bool valid = p < n;
+    const int astride = L.enc + L.n_hidden * L.n_neurons;
+    const int dstride = L.n_out_padded + L.n_hidden * L.n_neurons;
+    // delta of the output layer
+    for (int k = 0; k < L.n_out_padded; ++k) {
+        const float g = (valid && k < L.n_out) ? dl_dout[(size_t)p * L.n_out + k] : 0.0f;
+        act(col_a, k) = g;
+        if (valid) deltas[(size_t)p * dstride + k] = g;
+    }
+    float *d_out = col_a, *d_in = col_b;
+    int n_o = L.n_out_padded;
+    for (int layer = L.n_hidden; layer >= 1; --layer) {
+        // d_in[k] = relu'(h[k]) * sum_r W[r][k] d_out[r], h = output of hidden layer (layer-1)
+        const float *W = params + L.w_off[layer];
+        const int n_i = L.n_neurons;
+        for (int k0 = 0; k0 < n_i; k0 += 8) {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < n_o; ++r) {
+                const float g = d_out[r * kNetBlock];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(W[(size_t)r * n_i + k0 + j], g, acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float h = valid ? acts[(size_t)p * astride + L.enc + (layer - 1) * L.n_neurons + k0 + j] : 0.0f;
+                const float v = h > 0.0f ? acc[j] : 0.0f;
+                d_in[(k0 + j) * kNetBlock] = v;
+                if (valid) deltas[(size_t)p * dstride + L.n_out_padded + (layer - 1) * L.n_neurons + k0 + j] = v;
+            }
+        }
+        float *t = d_out; d_out = d_in; d_in = t;
+        n_o = L.n_neurons;
+    }
+    // encoding gradient: d_enc[k] = sum_r W1[r][k] d_out[r]
+    {
+        const float *W = params + L.w_off[0];
+        for (int k0 = 0; k0 < L.enc; k0 += 8) {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < L.n_neurons; ++r) {
+                const float g = d_out[r * kNetBlock];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(W[(size_t)r * L.enc + k0 + j], g, acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d_in[(k0 + j) * kNetBlock] = acc[j];
+        }
+    }
+    if (!valid) return;
+    const float x = xy[2 * p], y = xy[2 * p + 1];
+    float *gG = grad + L.n_mlp;
+    for (int lv = 0; lv < L.n_levels; ++lv) {
+        const float s = L.scale[lv];
+        const uint32_t res = (uint32_t)L.res[lv];
+        const uint32_t n_level = L.level_off[lv + 1] - L.level_off[lv];
+        float px = __builtin_fmaf(s, x, 0.5f), py = __builtin_fmaf(s, y, 0.5f);
+        const float fx = floorf(px), fy = floorf(py);
+        px -= fx;
+        py -= fy;
+        const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
+            const float w = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
+            const uint32_t idx = (cx + cy * res) % n_level;
+            for (int q = 0; q < L.n_features; ++q)
+                atomicAdd(gG + (size_t)(L.level_off[lv] + idx) * L.n_features + q, w * d_in[(lv * L.n_features + q) * kNetBlock]);
+        }
+    }
+}
+
+// dW[r][k] += sum_p delta[p][r] * input[p][k] for one layer: a block owns a chunk of points,
+// thread t owns the (r, k) pairs {t, t + 256, ...}; partial sums leave through float atomics.
+__global__ __launch_bounds__(256) void weight_grad_kernel(const float *delta, int dstride, int doff, const float *input,
+                                                          int istride, int ioff, int n_o, int n_i, int n, int chunk,
+                                                          float *gW)
+{
+    extern __shared__ float lds[];
+    float *sd = lds;                 // [32][n_o]
+    float *si = lds + 32 * 64;       // [32][n_i]
+    const int p0 = blockIdx.x * chunk;
+    const int p1 = min(n, p0 + chunk);
+    const int n_pairs = n_o * n_i;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    for (int pb = p0; pb < p1; pb += 32) {
+        const int cnt = min(32, p1 - pb);
+        __syncthreads();
+        for (int e = threadIdx.x; e < 32 * n_o; e += 256) {
+            const int q = e / n_o, r = e % n_o;
+            sd[q * 64 + r] = q < cnt ? delta[(size_t)(pb + q) * dstride + doff + r] : 0.0f;
+        }
+        for (int e = threadIdx.x; e < 32 * n_i; e += 256) {
+            const int q = e / n_i, k = e % n_i;
+            si[q * 64 + k] = q < cnt ? input[(size_t)(pb + q) * istride + ioff + k] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int pair = threadIdx.x + 256 * j;
+            if (pair < n_pairs) {
+                const int r = pair / n_i, k = pair % n_i;
+                float a = acc[j];
+                for (int q = 0; q < 32; ++q) a = __builtin_fmaf(sd[q * 64 + r], si[q * 64 + k], a);
+                acc[j] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int pair = threadIdx.x + 256 * j;
+        if (pair < n_pairs && acc[j] != 0.0f) atomicAdd(gW + pair, acc[j]);
+    }
+}
+
+// tiny-cuda-nn adam.h adam_step nested in ema.h (debiased): step counts from 1
+__global__ void optimizer_kernel(uint32_t n, float *params, float *m1, float *m2, float *ema_raw, float *inference,
+                                 const float *grad, float lr_t, float beta1, float beta2, float eps, float l2, float decay,
+                                 float debias, float loss_scale)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float w = params[i];
+    float g = grad[i] / loss_scale;
+    g += l2 * w;
+    const float a = m1[i] = beta1 * m1[i] + (1.0f - beta1) * g;
+    const float b = m2[i] = beta2 * m2[i] + (1.0f - beta2) * (g * g);
+    const float nw = w - (lr_t / (sqrtf(b) + eps)) * a;
+    params[i] = nw;
+    const float e = ema_raw[i] = decay * ema_raw[i] + (1.0f - decay) * nw;
+    inference[i] = e * debias;
+}
+
+}  // namespace wost
+
+using namespace wost;
+
+struct wost_net {
+    int device = 0;
+    wost_net_config cfg{};
+    NetLayout L{};
+    uint32_t n_params = 0;
+    float *params = nullptr, *inference = nullptr, *m1 = nullptr, *m2 = nullptr, *ema_raw = nullptr, *grad = nullptr;
+    int step = 0;
+    // scratch (grown on demand)
+    float *d_xy = nullptr, *d_out = nullptr, *d_dl = nullptr, *d_acts = nullptr, *d_deltas = nullptr;
+    size_t cap_points = 0;
+};
+
+#define NET_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return set_error(WOST_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static int ensure_points(wost_net *h, size_t n)
+{
+    if (n <= h->cap_points) return WOST_OK;
+    for (float **p : {&h->d_xy, &h->d_out, &h->d_dl, &h->d_acts, &h->d_deltas})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    h->cap_points = 0;
+    const NetLayout &L = h->L;
+    NET_TRY(hipMalloc((void **)&h->d_xy, n * 2 * sizeof(float)));
+    NET_TRY(hipMalloc((void **)&h->d_out, n * L.n_out * sizeof(float)));
+    NET_TRY(hipMalloc((void **)&h->d_dl, n * L.n_out * sizeof(float)));
+    NET_TRY(hipMalloc((void **)&h->d_acts, n * (size_t)(L.enc + L.n_hidden * L.n_neurons) * sizeof(float)));
+    NET_TRY(hipMalloc((void **)&h->d_deltas, n * (size_t)(L.n_out_padded + L.n_hidden * L.n_neurons) * sizeof(float)));
+    h->cap_points = n;
+    return WOST_OK;
+}
+
+static void net_free(wost_net *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (float *p : {h->params, h->inference, h->m1, h->m2, h->ema_raw, h->grad, h->d_xy, h->d_out, h->d_dl, h->d_acts, h->d_deltas})
+        if (p) (void)hipFree(p);
+    delete h;
+}
+
+extern "C" {
+
+int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_net_handle *out)
+{
+    if (!cfg || !out) return set_error(WOST_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->n_levels < 1 || cfg->n_levels > kNetMaxLevels || cfg->n_features_per_level < 1 || cfg->n_features_per_level > 8 ||
+        cfg->n_levels * cfg->n_features_per_level > 64 || (cfg->n_levels * cfg->n_features_per_level) % 8 != 0 ||
+        cfg->n_neurons < 8 || cfg->n_neurons > 64 || cfg->n_neurons % 8 != 0 || cfg->n_hidden_layers < 1 ||
+        cfg->n_hidden_layers >= kNetMaxLevels || cfg->n_output < 1 || cfg->n_output > 64 || cfg->base_resolution < 1 ||
+        !(cfg->per_level_scale >= 1.0f))
+        return set_error(WOST_ERR_UNSUPPORTED, "network shape outside this build (widths <= 64, multiples of 8)");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return set_error(WOST_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n_dev) return set_error(WOST_ERR_INVALID, "device index out of range");
+    NET_TRY(hipSetDevice(device));
+    wost_net *h = new (std::nothrow) wost_net();
+    if (!h) return set_error(WOST_ERR_NOMEM, "out of host memory");
+    h->device = device;
+    h->cfg = *cfg;
+    h->L = make_layout(*cfg);
+    h->n_params = h->L.n_mlp + h->L.n_grid;
+    // initialisation (tiny-cuda-nn defaults): MLP xavier uniform, grid uniform(-1e-4, 1e-4)
+    std::vector<float> init(h->n_params);
+    uint64_t state = 0, inc = (54u << 1u) | 1u;
+    auto next_u32 = [&]() {
+        const uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        const uint32_t x = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u);
+        return (x >> rot) | (x << ((~rot + 1u) & 31));
+    };
+    next_u32(); state += seed; next_u32();
+    auto uniform = [&]() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); };
+    const NetLayout &L = h->L;
+    for (int layer = 0; layer <= L.n_hidden; ++layer) {
+        const int n_i = layer == 0 ? L.enc : L.n_neurons, n_o = layer == L.n_hidden ? L.n_out_padded : L.n_neurons;
+        const float s = std::sqrt(6.0f / (float)(n_i + n_o));
+        for (int e = 0; e < n_i * n_o; ++e) init[L.w_off[layer] + e] = (uniform() * 2.0f - 1.0f) * s;
+    }
+    for (uint32_t e = 0; e < L.n_grid; ++e) init[L.n_mlp + e] = (uniform() * 2.0f - 1.0f) * 1e-4f;
+    const size_t bytes = (size_t)h->n_params * sizeof(float);
+    hipError_t e = hipSuccess;
+    for (float **p : {&h->params, &h->inference, &h->m1, &h->m2, &h->ema_raw, &h->grad})
+        if (e == hipSuccess) e = hipMalloc((void **)p, bytes);
+    if (e == hipSuccess) e = hipMemcpy(h->params, init.data(), bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->inference, init.data(), bytes, hipMemcpyHostToDevice);
+    for (float *p : {h->m1, h->m2, h->ema_raw, h->grad})
+        if (e == hipSuccess) e = hipMemset(p, 0, bytes);
+    if (e != hipSuccess) {
+        net_free(h);
+        return set_error(WOST_ERR_DEVICE, std::string("network allocation: ") + hipGetErrorString(e));
+    }
+    *out = h;
+    return WOST_OK;
+}
+
+int wost_net_destroy(wost_net_handle h)
+{
+    net_free(h);
+    return WOST_OK;
+}
+
+int wost_net_n_params(wost_net_handle h, uint64_t *n_total, uint64_t *n_mlp)
+{
+    if (!h || !n_total) return set_error(WOST_ERR_INVALID, "null argument");
+    *n_total = h->n_params;
+    if (n_mlp) *n_mlp = h->L.n_mlp;
+    return WOST_OK;
+}
+
+int wost_net_get_params(wost_net_handle h, int which, float *host)
+{
+    if (!h || !host || which < 0 || which > 2) return set_error(WOST_ERR_INVALID, "bad argument");
+    NET_TRY(hipSetDevice(h->device));
+    const float *src = which == 0 ? h->params : which == 1 ? h->inference : h->grad;
+    NET_TRY(hipMemcpy(host, src, (size_t)h->n_params * sizeof(float), hipMemcpyDeviceToHost));
+    return WOST_OK;
+}
+
+int wost_net_set_params(wost_net_handle h, const float *host)
+{
+    if (!h || !host) return set_error(WOST_ERR_INVALID, "null argument");
+    NET_TRY(hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->n_params * sizeof(float);
+    NET_TRY(hipMemcpy(h->params, host, bytes, hipMemcpyHostToDevice));
+    NET_TRY(hipMemcpy(h->inference, host, bytes, hipMemcpyHostToDevice));
+    for (float *p : {h->m1, h->m2, h->ema_raw}) NET_TRY(hipMemset(p, 0, bytes));
+    h->step = 0;
+    return WOST_OK;
+}
+
+int wost_net_inference(wost_net_handle h, const float *xy, int32_t n, float *out, int use_inference_params)
+{
+    if (!h || !xy || !out || n < 0) return set_error(WOST_ERR_INVALID, "bad argument");
+    if (n == 0) return WOST_OK;
+    NET_TRY(hipSetDevice(h->device));
+    int rc = ensure_points(h, (size_t)n);
+    if (rc != WOST_OK) return rc;
+    NET_TRY(hipMemcpy(h->d_xy, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice));
+    const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
+    hipLaunchKernelGGL(net_forward_kernel, dim3((n + kNetBlock - 1) / kNetBlock), dim3(kNetBlock), lds, 0, h->L,
+                       use_inference_params ? h->inference : h->params, h->d_xy, n, h->d_out, (float *)nullptr);
+    NET_TRY(hipGetLastError());
+    NET_TRY(hipMemcpy(out, h->d_out, (size_t)n * h->L.n_out * sizeof(float), hipMemcpyDeviceToHost));
+    return WOST_OK;
+}
+
+int wost_net_train_step(wost_net_handle h, const float *xy, const float *dl_dout, int32_t n, float loss_scale,
+                        int apply_update)
+{
+    if (!h || !xy || !dl_dout || n <= 0 || !(loss_scale > 0.0f)) return set_error(WOST_ERR_INVALID, "bad argument");
+    NET_TRY(hipSetDevice(h->device));
+    int rc = ensure_points(h, (size_t)n);
+    if (rc != WOST_OK) return rc;
+    const NetLayout &L = h->L;
+    NET_TRY(hipMemcpy(h->d_xy, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice));
+    NET_TRY(hipMemcpy(h->d_dl, dl_dout, (size_t)n * L.n_out * sizeof(float), hipMemcpyHostToDevice));
+    NET_TRY(hipMemset(h->grad, 0, (size_t)h->n_params * sizeof(float)));
+    const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
+    const unsigned gridp = (unsigned)((n + kNetBlock - 1) / kNetBlock);
+    hipLaunchKernelGGL(net_forward_kernel, dim3(gridp), dim3(kNetBlock), lds, 0, L, h->params, h->d_xy, n, h->d_out,
+                       h->d_acts);
+    hipLaunchKernelGGL(net_backward_kernel, dim3(gridp), dim3(kNetBlock), lds, 0, L, h->params, h->d_xy, h->d_dl, h->d_acts,
+                       n, h->d_deltas, h->grad);
+    NET_TRY(hipGetLastError());
+    const int astride = L.enc + L.n_hidden * L.n_neurons, dstride = L.n_out_padded + L.n_hidden * L.n_neurons;
+    const int chunk = 1024;
+    const unsigned gridc = (unsigned)((n + chunk - 1) / chunk);
+    const size_t lds_w = 2 * 32 * 64 * sizeof(float);
+    for (int layer = 0; layer <= L.n_hidden; ++layer) {
+        const int n_i = layer == 0 ? L.enc : L.n_neurons, n_o = layer == L.n_hidden ? L.n_out_padded : L.n_neurons;
+        const int doff = layer == L.n_hidden ? 0 : L.n_out_padded + layer * L.n_neurons;   // delta of this layer's output
+        const int ioff = layer == 0 ? 0 : L.enc + (layer - 1) * L.n_neurons;               // this layer's input
+        hipLaunchKernelGGL(weight_grad_kernel, dim3(gridc), dim3(256), lds_w, 0, h->d_deltas, dstride, doff, h->d_acts, astride,
+                           ioff, n_o, n_i, n, chunk, h->grad + L.w_off[layer]);
+    }
+    NET_TRY(hipGetLastError());
+    if (apply_update) {
+        h->step += 1;
+        const wost_net_config &c = h->cfg;
+        const float lr_t = c.learning_rate * std::sqrt(1.0f - std::pow(c.beta2, (float)h->step)) /
+                           (1.0f - std::pow(c.beta1, (float)h->step));
+        const float debias = 1.0f / (1.0f - std::pow(c.ema_decay, (float)h->step));
+        hipLaunchKernelGGL(optimizer_kernel, dim3((h->n_params + 255) / 256), dim3(256), 0, 0, h->n_params, h->params, h->m1,
+                           h->m2, h->ema_raw, h->inference, h->grad, lr_t, c.beta1, c.beta2, c.epsilon, c.l2_reg, c.ema_decay,
+                           debias, loss_scale);
+        NET_TRY(hipGetLastError());
+    }
+    NET_TRY(hipDeviceSynchronize());
+    return WOST_OK;
+}
+
+}  // extern "C"

@@ -58,3 +58,69 @@ def vmm_loss_gradients(raw33, dirs, li, dir_pdf, on_neumann, normal, loss_scale=
     _check(lib.wost_vmm_loss_gradients(device, _fp(r), _fp(d), _fp(l), _fp(p), o.ctypes.data_as(C.POINTER(C.c_uint8)),
                                        _fp(nn), n, C.c_float(loss_scale), _fp(g), _fp(lk)), "wost_vmm_loss_gradients")
     return g, lk
+
+
+def default_net_config():
+    """Network of the reference's 2-D guided integrator: data/ladybug/n.json:49-81, 33 outputs
+    (8 lobes x (kappa, mu.x, mu.y, weight) + selection logit, guided/parameters.h:16-24)."""
+    return capi.NetConfig(8, 4, 8, 1.4049999713897705, 64, 3, 33, 0.00800000037997961, 0.8999999761581421,
+                          0.9900000095367432, 1.0000000036274937e-15, 9.999999974752427e-07, 0.949999988079071)
+
+
+class GuidingNetwork:
+    """Device-resident guiding network (wost_net_* of include/wost.h): DenseGrid encoding ->
+    ReLU MLP, Adam nested in EMA.  Mirrors how integrator/guided/integrator.cu drives
+    tiny-cuda-nn: inference() (:560,:597) and one training step (:655-662)."""
+
+    def __init__(self, config=None, seed=1337, device=0):
+        self._lib = capi.load()
+        self.config = config or default_net_config()
+        self._h = C.c_void_p()
+        _check(self._lib.wost_net_create(device, C.byref(self.config), seed, C.byref(self._h)), "wost_net_create")
+        total, mlp = C.c_uint64(), C.c_uint64()
+        _check(self._lib.wost_net_n_params(self._h, C.byref(total), C.byref(mlp)), "wost_net_n_params")
+        self.n_params, self.n_mlp_params = total.value, mlp.value
+
+    def close(self):
+        if self._h:
+            self._lib.wost_net_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _get(self, which):
+        out = np.zeros(self.n_params, dtype=np.float32)
+        _check(self._lib.wost_net_get_params(self._h, which, _fp(out)), "wost_net_get_params")
+        return out
+
+    def params(self):
+        return self._get(0)
+
+    def inference_params(self):
+        return self._get(1)
+
+    def gradients(self):
+        return self._get(2)
+
+    def set_params(self, params):
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        if p.size != self.n_params:
+            raise ValueError("expected %d parameters" % self.n_params)
+        _check(self._lib.wost_net_set_params(self._h, _fp(p)), "wost_net_set_params")
+
+    def inference(self, xy, use_inference_params=True):
+        x = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        out = np.zeros((len(x), self.config.n_output), dtype=np.float32)
+        _check(self._lib.wost_net_inference(self._h, _fp(x), len(x), _fp(out), int(use_inference_params)),
+               "wost_net_inference")
+        return out
+
+    def train_step(self, xy, dl_dout, loss_scale=128.0, apply_update=True):
+        x = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        g = np.ascontiguousarray(dl_dout, dtype=np.float32).reshape(len(x), self.config.n_output)
+        _check(self._lib.wost_net_train_step(self._h, _fp(x), _fp(g), len(x), loss_scale, int(apply_update)),
+               "wost_net_train_step")

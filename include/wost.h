@@ -163,6 +163,43 @@ int wost_vmm_loss_gradients(int device, const float *raw, const float *dir, cons
                             const float *dir_pdf, const uint8_t *on_neumann, const float *normal,
                             int32_t n, float loss_scale, float *dl_draw, float *likelihood);
 
+/* ---- guiding network (SURVEY 8a rows a22/a23 + the optimizer of a27) -------------------------
+ * Replaces the tiny-cuda-nn objects of the guided integrator: the NetworkWithInputEncoding
+ * variant of util/network.h:21-196 (inference 39-47, forward 49-60, backward 62-92, parameter
+ * order 94-136), built in integrator/guided/integrator.cu:1095-1131 from the configuration of
+ * data/ladybug/n.json:49-81: DenseGrid encoding (n_levels x n_features_per_level, linear
+ * interpolation) -> bias-free ReLU MLP -> n_output raw values per point; Adam nested in a
+ * debiased EMA.  Parameter vector order as in util/network.h:99-117 (network first, encoding
+ * second): [W1 n_neurons x enc][W2..][Wout pad16(n_output) x n_neurons][grid levels].
+ * fp32 arithmetic in this version (the reference computes in half precision). */
+typedef struct wost_net_config {
+    int32_t n_levels, n_features_per_level, base_resolution;
+    float per_level_scale;
+    int32_t n_neurons, n_hidden_layers, n_output;
+    float learning_rate, beta1, beta2, epsilon, l2_reg, ema_decay;
+} wost_net_config;
+typedef struct wost_net *wost_net_handle;
+
+/* integrator/guided/integrator.cu:1095-1131 (network + optimizer + trainer construction):
+ * allocates parameters on `device` and initialises them from `seed` (util/network.h:113-136;
+ * MLP xavier-uniform, grid uniform(-1e-4, 1e-4)). */
+int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_net_handle *out);
+int wost_net_destroy(wost_net_handle h);
+int wost_net_n_params(wost_net_handle h, uint64_t *n_total, uint64_t *n_mlp);
+/* which: 0 = training parameters, 1 = inference (EMA) parameters, 2 = gradients of the last
+ * wost_net_train_step (scaled by loss_scale). */
+int wost_net_get_params(wost_net_handle h, int which, float *host);
+/* sets training and inference parameters, resets the optimizer state */
+int wost_net_set_params(wost_net_handle h, const float *host);
+/* network->inference (integrator/guided/integrator.cu:560,597; util/network.h:39-47): xy[n*2] in [0,1]^2 -> out[n*n_output];
+ * use_inference_params = 1 evaluates the EMA weights (what rendering uses), 0 the training ones. */
+int wost_net_inference(wost_net_handle h, const float *xy, int32_t n, float *out, int use_inference_params);
+/* One training step (integrator/guided/integrator.cu:655-662: network->forward, ->backward,
+ * trainer->optimizer_step(TRAIN_LOSS_SCALE)): forward with the training parameters, backward of
+ * sum_p <dl_dout[p], out[p]>, then (apply_update != 0) one Adam+EMA step on gradient/loss_scale. */
+int wost_net_train_step(wost_net_handle h, const float *xy, const float *dl_dout, int32_t n, float loss_scale,
+                        int apply_update);
+
 /* Tuning knobs ("steps_per_round", "block_size", ...); unknown keys -> WOST_ERR_INVALID. */
 int wost_set_option(wost_handle h, const char *key, double value);
 

@@ -16,7 +16,7 @@ _BUILD = os.path.join(_HERE, "_build")
 def build(force=False):
     """Compile the oracle with gcc (plain C, seconds)."""
     targets = [os.path.join(_BUILD, "libwost_oracle.so"), os.path.join(_BUILD, "libwost_oracle_libm.so")]
-    src = [os.path.join(_HERE, "wost_oracle.c"), os.path.join(_HERE, "wost_oracle.h"), os.path.join(_HERE, "wost_vmm.c")]
+    src = [os.path.join(_HERE, "wost_oracle.c"), os.path.join(_HERE, "wost_oracle.h"), os.path.join(_HERE, "wost_vmm.c"), os.path.join(_HERE, "wost_net.c")]
     stale = force or any(
         (not os.path.exists(t)) or os.path.getmtime(t) < max(os.path.getmtime(s) for s in src) for t in targets
     )
@@ -67,6 +67,21 @@ class Stats(C.Structure):
         ("neumann_hits", C.c_uint64),
         ("seconds", C.c_double),
     ]
+
+
+class NetConfig(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_int), ("n_features", C.c_int), ("base_resolution", C.c_int), ("per_level_scale", C.c_float),
+        ("n_neurons", C.c_int), ("n_hidden_layers", C.c_int), ("n_output", C.c_int), ("n_output_padded", C.c_int),
+        ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float),
+        ("l2_reg", C.c_float), ("ema_decay", C.c_float),
+    ]
+
+
+def default_net_config():
+    """data/ladybug/n.json:49-81 of the reference + guided/parameters.h:16-24"""
+    return NetConfig(8, 4, 8, 1.4049999713897705, 64, 3, 33, 48, 0.00800000037997961, 0.8999999761581421,
+                     0.9900000095367432, 1.0000000036274937e-15, 9.999999974752427e-07, 0.949999988079071)
 
 
 class Pcg(C.Structure):
@@ -261,6 +276,50 @@ class Oracle:
 
     def logf(self, x):
         return float(self.lib.wo_logf(C.c_float(x)))
+
+    # ---- guided path: network -----------------------------------------------------------------
+    def net_n_params(self, cfg):
+        self.lib.wo_net_n_params.restype = C.c_uint64
+        return int(self.lib.wo_net_n_params(C.byref(cfg)))
+
+    def net_levels(self, cfg):
+        res = np.zeros(cfg.n_levels, dtype=np.int32)
+        scale = np.zeros(cfg.n_levels, dtype=np.float32)
+        enc = self.lib.wo_net_levels(C.byref(cfg), _ip(res), _fp(scale))
+        return res, scale, enc
+
+    def net_forward(self, cfg, params, xy, want_acts=False):
+        """-> (out[n, n_output_padded], acts[n, enc + hidden*neurons] or None)"""
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        x = np.ascontiguousarray(xy, dtype=np.float32)
+        out = np.zeros((len(x), cfg.n_output_padded), dtype=np.float32)
+        acts = None
+        if want_acts:
+            acts = np.zeros((len(x), cfg.n_levels * cfg.n_features + cfg.n_hidden_layers * cfg.n_neurons), dtype=np.float32)
+        self.lib.wo_net_forward(C.byref(cfg), _fp(p), _fp(x), len(x), _fp(out), _fp(acts) if want_acts else None)
+        return out, acts
+
+    def net_backward(self, cfg, params, xy, dl_dout):
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        x = np.ascontiguousarray(xy, dtype=np.float32)
+        d = np.ascontiguousarray(dl_dout, dtype=np.float32)
+        assert d.shape == (len(x), cfg.n_output_padded)
+        g = np.zeros(len(p), dtype=np.float32)
+        self.lib.wo_net_backward(C.byref(cfg), _fp(p), _fp(x), _fp(d), len(x), _fp(g))
+        return g
+
+    def net_optimizer_state(self, cfg):
+        n = self.net_n_params(cfg)
+        return {k: np.zeros(n, dtype=np.float32) for k in ("m1", "m2", "ema_raw")}
+
+    def net_optimizer_step(self, cfg, params, state, grad, step, loss_scale):
+        """updates params and state in place, returns the inference (EMA) parameters"""
+        assert params.dtype == np.float32 and params.flags.c_contiguous
+        g = np.ascontiguousarray(grad, dtype=np.float32)
+        inf = np.zeros_like(params)
+        self.lib.wo_net_optimizer_step(C.byref(cfg), _fp(params), _fp(state["m1"]), _fp(state["m2"]), _fp(state["ema_raw"]),
+                                       _fp(inf), _fp(g), step, C.c_float(loss_scale))
+        return inf
 
     # ---- guided path: von Mises / mixture --------------------------------------------------
     def eval_poly_large0(self, y):

@@ -1,0 +1,232 @@
+/*
+ * wost_net.c -- CPU oracle of the guiding network (the optimizer of
+ * a27): DenseGrid encoding -> bias-free ReLU MLP -> raw mixture parameters, plus backward pass
+ * and the Adam-in-EMA optimizer step.  TEST INFRASTRUCTURE ONLY.
+ *
+ * The reference builds this from tiny-cuda-nn (ext/tcnn, https://github.com/NVlabs/tiny-cuda-nn,
+ * .gitmodules:1-3, pinned commit unknown, directory EMPTY in /root/reference) through the adapter
+ * util/network.h:21-196 with the configuration data/ladybug/n.json:49-81.  There is no test or
+ * golden vector for it in the reference => PARITY UNPINNED; this file restates tiny-cuda-nn's
+ * published algorithms (grid.h: grid_scale / grid_resolution / dense grid_index / linear
+ * interpolation; fully_fused_mlp.h: y = W x without bias, ReLU hidden, no output activation;
+ * adam.h adam_step; ema.h debiased exponential moving average) in plain fp32.  The reference
+ * runs the MLP in half precision on tensor cores; fp32 here is the numerically stronger
+ * stand-in the HIP path is compared against.
+ *
+ * Parameter vector order (util/network.h:99-117: network first, then encoding):
+ *   [W1: n_neurons x enc] [W(hidden-1) x: n_neurons x n_neurons] [Wout: n_out_padded x n_neurons]
+ *   [grid level 0 .. L-1: res^2 (rounded up to 8) x n_features]
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "wost_oracle.h"
+
+#define WN_MAX_LEVELS 16
+
+typedef struct {
+    int res[WN_MAX_LEVELS];
+    float scale[WN_MAX_LEVELS];
+    size_t level_off[WN_MAX_LEVELS + 1]; /* in entries (x n_features floats) */
+    int enc;        /* encoded width */
+    size_t n_mlp, n_grid;
+} wn_layout;
+
+static void layout(const wo_net_config *c, wn_layout *l)
+{
+    const float log2s = log2f(c->per_level_scale);
+    size_t off = 0;
+    for (int i = 0; i < c->n_levels; ++i) {
+        l->scale[i] = exp2f((float)i * log2s) * (float)c->base_resolution - 1.0f;   /* grid.h grid_scale */
+        l->res[i] = (int)ceilf(l->scale[i]) + 1;                                     /* grid.h grid_resolution */
+        size_t n = (size_t)l->res[i] * l->res[i];
+        n = (n + 7) / 8 * 8;
+        l->level_off[i] = off;
+        off += n;
+    }
+    l->level_off[c->n_levels] = off;
+    l->enc = c->n_levels * c->n_features;
+    l->n_grid = off * c->n_features;
+    l->n_mlp = (size_t)c->n_neurons * l->enc + (size_t)(c->n_hidden_layers - 1) * c->n_neurons * c->n_neurons +
+               (size_t)c->n_output_padded * c->n_neurons;
+}
+
+uint64_t wo_net_n_params(const wo_net_config *c)
+{
+    wn_layout l;
+    layout(c, &l);
+    return l.n_mlp + l.n_grid;
+}
+
+/* encode one point; optionally return the 4 corner indices/weights per level for backward */
+static void encode(const wo_net_config *c, const wn_layout *l, const float *grid, float x, float y, float *enc,
+                   size_t *cidx, float *cw)
+{
+    for (int lv = 0; lv < c->n_levels; ++lv) {
+        const float s = l->scale[lv];
+        const int res = l->res[lv];
+        const size_t n_level = l->level_off[lv + 1] - l->level_off[lv];
+        float px = fmaf(s, x, 0.5f), py = fmaf(s, y, 0.5f);
+        const float fx = floorf(px), fy = floorf(py);
+        px -= fx; py -= fy;
+        const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+        float f[8] = {0};
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
+            const float w = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
+            const size_t idx = ((size_t)cx + (size_t)cy * (size_t)res) % n_level;   /* dense grid_index */
+            const float *g = grid + (l->level_off[lv] + idx) * c->n_features;
+            for (int q = 0; q < c->n_features; ++q) f[q] += w * g[q];
+            if (cidx) { cidx[4 * lv + k] = l->level_off[lv] + idx; cw[4 * lv + k] = w; }
+        }
+        for (int q = 0; q < c->n_features; ++q) enc[lv * c->n_features + q] = f[q];
+    }
+}
+
+/* forward for n points; out: n x n_output_padded.  acts (optional): per point enc + hidden*n_neurons */
+int wo_net_forward(const wo_net_config *c, const float *params, const float *xy, int n, float *out, float *acts)
+{
+    wn_layout l;
+    layout(c, &l);
+    const float *grid = params + l.n_mlp;
+    const int H = c->n_neurons, E = l.enc, NL = c->n_hidden_layers;
+    const int act_stride = E + NL * H;
+    float *buf = malloc(sizeof(float) * (size_t)act_stride);
+    for (int p = 0; p < n; ++p) {
+        float *a = acts ? acts + (size_t)p * act_stride : buf;
+        encode(c, &l, grid, xy[2 * p], xy[2 * p + 1], a, NULL, NULL);
+        const float *W = params;
+        const float *in = a;
+        int n_in = E;
+        for (int layer = 0; layer < NL; ++layer) {
+            float *o = a + E + layer * H;
+            for (int r = 0; r < H; ++r) {
+                float s = 0.0f;
+                for (int k = 0; k < n_in; ++k) s = fmaf(W[(size_t)r * n_in + k], in[k], s);
+                o[r] = s > 0.0f ? s : 0.0f;
+            }
+            W += (size_t)H * n_in;
+            in = o;
+            n_in = H;
+        }
+        for (int r = 0; r < c->n_output_padded; ++r) {
+            float s = 0.0f;
+            for (int k = 0; k < H; ++k) s = fmaf(W[(size_t)r * H + k], in[k], s);
+            out[(size_t)p * c->n_output_padded + r] = s;
+        }
+    }
+    free(buf);
+    return 0;
+}
+
+/* gradient of sum_p <dl_dout[p], out[p]> w.r.t. every parameter (grad must hold n_params floats) */
+int wo_net_backward(const wo_net_config *c, const float *params, const float *xy, const float *dl_dout, int n,
+                    float *grad)
+{
+    wn_layout l;
+    layout(c, &l);
+    const int H = c->n_neurons, E = l.enc, NL = c->n_hidden_layers, NO = c->n_output_padded;
+    const int act_stride = E + NL * H;
+    memset(grad, 0, sizeof(float) * (l.n_mlp + l.n_grid));
+    float *a = malloc(sizeof(float) * (size_t)act_stride);
+    float *d = malloc(sizeof(float) * (size_t)(H > E ? H : E) * 2);
+    float *out = malloc(sizeof(float) * (size_t)NO);
+    size_t *cidx = malloc(sizeof(size_t) * 4 * c->n_levels);
+    float *cw = malloc(sizeof(float) * 4 * c->n_levels);
+    const float *grid = params + l.n_mlp;
+    /* weight block offsets */
+    size_t woff[WN_MAX_LEVELS];
+    woff[0] = 0;
+    woff[1] = (size_t)H * E;
+    for (int i = 2; i <= NL; ++i) woff[i] = woff[i - 1] + (size_t)H * H;
+    for (int p = 0; p < n; ++p) {
+        encode(c, &l, grid, xy[2 * p], xy[2 * p + 1], a, cidx, cw);
+        /* forward, keeping activations */
+        const float *in = a;
+        int n_in = E;
+        for (int layer = 0; layer < NL; ++layer) {
+            const float *W = params + woff[layer];
+            float *o = a + E + layer * H;
+            for (int r = 0; r < H; ++r) {
+                float s = 0.0f;
+                for (int k = 0; k < n_in; ++k) s = fmaf(W[(size_t)r * n_in + k], in[k], s);
+                o[r] = s > 0.0f ? s : 0.0f;
+            }
+            in = o; n_in = H;
+        }
+        /* output layer */
+        const float *dlo = dl_dout + (size_t)p * NO;
+        float *dcur = d, *dnext = d + (H > E ? H : E);
+        {
+            const float *W = params + woff[NL];
+            float *gW = grad + woff[NL];
+            const float *h = a + E + (NL - 1) * H;
+            for (int k = 0; k < H; ++k) dcur[k] = 0.0f;
+            for (int r = 0; r < NO; ++r) {
+                const float g = dlo[r];
+                if (g == 0.0f) continue;
+                for (int k = 0; k < H; ++k) {
+                    gW[(size_t)r * H + k] += g * h[k];
+                    dcur[k] = fmaf(W[(size_t)r * H + k], g, dcur[k]);
+                }
+            }
+        }
+        for (int layer = NL - 1; layer >= 0; --layer) {
+            const int nin = layer == 0 ? E : H;
+            const float *W = params + woff[layer];
+            float *gW = grad + woff[layer];
+            const float *o = a + E + layer * H;
+            const float *inp = layer == 0 ? a : a + E + (layer - 1) * H;
+            for (int k = 0; k < nin; ++k) dnext[k] = 0.0f;
+            for (int r = 0; r < H; ++r) {
+                const float g = o[r] > 0.0f ? dcur[r] : 0.0f;   /* ReLU' */
+                if (g == 0.0f) continue;
+                for (int k = 0; k < nin; ++k) {
+                    gW[(size_t)r * nin + k] += g * inp[k];
+                    dnext[k] = fmaf(W[(size_t)r * nin + k], g, dnext[k]);
+                }
+            }
+            float *t = dcur; dcur = dnext; dnext = t;
+        }
+        /* dcur = dL/d(encoded input): scatter into the grid */
+        float *gG = grad + l.n_mlp;
+        for (int lv = 0; lv < c->n_levels; ++lv)
+            for (int k = 0; k < 4; ++k)
+                for (int q = 0; q < c->n_features; ++q)
+                    gG[cidx[4 * lv + k] * c->n_features + q] += cw[4 * lv + k] * dcur[lv * c->n_features + q];
+    }
+    free(a); free(d); free(out); free(cidx); free(cw);
+    return 0;
+}
+
+/* one optimizer step (tiny-cuda-nn adam.h adam_step nested in ema.h): step counts from 1 */
+int wo_net_optimizer_step(const wo_net_config *c, float *params, float *m1, float *m2, float *ema_raw,
+                          float *inference_params, const float *grad, int step, float loss_scale)
+{
+    const uint64_t n = wo_net_n_params(c);
+    const float lr = c->learning_rate * sqrtf(1.0f - powf(c->beta2, (float)step)) / (1.0f - powf(c->beta1, (float)step));
+    const float debias = 1.0f / (1.0f - powf(c->ema_decay, (float)step));
+    for (uint64_t i = 0; i < n; ++i) {
+        const float w = params[i];
+        float g = grad[i] / loss_scale;
+        g += c->l2_reg * w;
+        const float a = m1[i] = c->beta1 * m1[i] + (1.0f - c->beta1) * g;
+        const float b = m2[i] = c->beta2 * m2[i] + (1.0f - c->beta2) * (g * g);
+        const float nw = w - (lr / (sqrtf(b) + c->epsilon)) * a;
+        params[i] = nw;
+        ema_raw[i] = c->ema_decay * ema_raw[i] + (1.0f - c->ema_decay) * nw;
+        inference_params[i] = ema_raw[i] * debias;
+    }
+    return 0;
+}
+
+int wo_net_levels(const wo_net_config *c, int *res, float *scale)
+{
+    wn_layout l;
+    layout(c, &l);
+    for (int i = 0; i < c->n_levels; ++i) { res[i] = l.res[i]; scale[i] = l.scale[i]; }
+    return l.enc;
+}

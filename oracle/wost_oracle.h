@@ -135,6 +135,21 @@ int wo_vmm_loss_gradients(const float *raw, const float *dir, const float *li, c
                           const unsigned char *on_neumann, const float *normal, int n, float loss_scale,
                           float *dl_draw, float *likelihood);
 
+/* ---- guiding network (oracle/wost_net.c) -------------------------------------------- */
+typedef struct wo_net_config {
+    int n_levels, n_features, base_resolution;
+    float per_level_scale;
+    int n_neurons, n_hidden_layers, n_output, n_output_padded;
+    float learning_rate, beta1, beta2, epsilon, l2_reg, ema_decay;
+} wo_net_config;
+uint64_t wo_net_n_params(const wo_net_config *c);
+int wo_net_levels(const wo_net_config *c, int *res, float *scale);
+int wo_net_forward(const wo_net_config *c, const float *params, const float *xy, int n, float *out, float *acts);
+int wo_net_backward(const wo_net_config *c, const float *params, const float *xy, const float *dl_dout, int n,
+                    float *grad);
+int wo_net_optimizer_step(const wo_net_config *c, float *params, float *m1, float *m2, float *ema_raw,
+                          float *inference_params, const float *grad, int step, float loss_scale);
+
 const char *wo_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,212 @@
+"""Guiding network (SURVEY.md 8a rows a22/a23 + the optimizer of a27).
+
+CPU part: the oracle (oracle/wost_net.c) against the published tiny-cuda-nn layout numbers of the
+reference configuration (data/ladybug/n.json:49-81), against finite differences and against the
+closed-form first Adam/EMA step.  GPU part: the HIP network (elaina_amd/csrc/wost_net.hip) through
+the C-ABI against the oracle.  PARITY UNPINNED w.r.t. tiny-cuda-nn itself (submodule absent)."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle, default_net_config
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+def _rand_params(orc, cfg, seed=5, wscale=0.25, gscale=0.5):
+    n = orc.net_n_params(cfg)
+    rng = np.random.default_rng(seed)
+    p = rng.uniform(-wscale, wscale, n).astype(np.float32)
+    n_mlp = 64 * 32 + 2 * 64 * 64 + 48 * 64
+    p[n_mlp:] = rng.uniform(-gscale, gscale, n - n_mlp).astype(np.float32)
+    return p
+
+
+def test_layout_matches_reference_configuration(orc):
+    cfg = default_net_config()
+    # ~13.3k MLP + ~61k grid parameters
+    n_mlp = 64 * 32 + 2 * 64 * 64 + 48 * 64
+    assert n_mlp == 13312
+    assert orc.net_n_params(cfg) == 74848
+    res, scale, enc = orc.net_levels(cfg)
+    assert enc == 32
+    assert list(res) == [8, 12, 16, 23, 32, 44, 62, 87]
+    # grid_scale = base * s^level - 1
+    np.testing.assert_allclose(scale, 8.0 * 1.405 ** np.arange(8) - 1.0, rtol=1e-5)
+
+
+def test_forward_is_bilinear_in_grid_and_relu_mlp(orc):
+    cfg = default_net_config()
+    p = _rand_params(orc, cfg)
+    rng = np.random.default_rng(1)
+    xy = rng.uniform(0, 1, (64, 2)).astype(np.float32)
+    out, acts = orc.net_forward(cfg, p, xy, want_acts=True)
+    assert out.shape == (64, 48) and acts.shape == (64, 32 + 3 * 64)
+    assert np.all(acts[:, 32:] >= 0)
+    # numpy restatement of the MLP on the oracle's own encoding
+    W1 = p[:2048].reshape(64, 32); W2 = p[2048:6144].reshape(64, 64); W3 = p[6144:10240].reshape(64, 64)
+    Wo = p[10240:13312].reshape(48, 64)
+    h = acts[:, :32].astype(np.float64)
+    for W in (W1, W2, W3):
+        h = np.maximum(h @ W.astype(np.float64).T, 0)
+    np.testing.assert_allclose(out, h @ Wo.astype(np.float64).T, rtol=2e-4, atol=2e-5)
+    # the encoding at a grid vertex of level 0 equals that vertex's features (pos = x*scale + 0.5)
+    res, scale, _ = orc.net_levels(cfg)
+    gx, gy = 3, 5
+    x = np.array([[(gx - 0.5) / scale[0], (gy - 0.5) / scale[0]]], dtype=np.float32)
+    _, a = orc.net_forward(cfg, p, x, want_acts=True)
+    grid0 = p[13312:13312 + 64 * 4].reshape(64, 4)
+    np.testing.assert_allclose(a[0, :4], grid0[gx + gy * res[0]], rtol=0, atol=2e-5)
+
+
+def test_backward_matches_finite_differences(orc):
+    cfg = default_net_config()
+    p = _rand_params(orc, cfg)
+    rng = np.random.default_rng(2)
+    xy = rng.uniform(0, 1, (16, 2)).astype(np.float32)
+    dl = rng.normal(size=(16, 48)).astype(np.float32)
+    dl[:, 33:] = 0
+    grad = orc.net_backward(cfg, p, xy, dl)
+
+    def loss(q):
+        return float(np.sum(orc.net_forward(cfg, q, xy)[0].astype(np.float64) * dl))
+
+    idx = np.concatenate([rng.integers(0, 13312, 12), 13312 + np.flatnonzero(grad[13312:])[::97][:12]])
+    bad = []
+    for i in idx:
+        h = 2e-3
+        q = p.copy(); q[i] += h; up = loss(q)
+        q[i] -= 2 * h; dn = loss(q)
+        fd = (up - dn) / (2 * h)
+        if abs(fd - grad[i]) > 2e-2 * max(abs(fd), abs(grad[i])) + 2e-3:
+            bad.append((int(i), fd, float(grad[i])))
+    # a central difference may straddle a ReLU kink of one of the 16 x 192 units: allow two
+    assert len(bad) <= 2, bad
+
+
+def test_optimizer_first_step_closed_form(orc):
+    cfg = default_net_config()
+    n = orc.net_n_params(cfg)
+    rng = np.random.default_rng(3)
+    p0 = rng.normal(size=n).astype(np.float32)
+    g = rng.normal(size=n).astype(np.float32) * 128
+    st = orc.net_optimizer_state(cfg)
+    p = p0.copy()
+    inf = orc.net_optimizer_step(cfg, p, st, g, step=1, loss_scale=128.0)
+    # step 1 of Adam with bias correction moves every weight by ~lr against the gradient sign ...
+    gg = g / 128.0 + cfg.l2_reg * p0
+    np.testing.assert_allclose(p - p0, -cfg.learning_rate * np.sign(gg), rtol=1e-3, atol=1e-7)
+    # ... and the debiased EMA of one sample is that sample
+    np.testing.assert_allclose(inf, p, rtol=1e-5, atol=1e-7)
+    p2 = p.copy()
+    inf2 = orc.net_optimizer_step(cfg, p2, st, g, step=2, loss_scale=128.0)
+    d = cfg.ema_decay
+    np.testing.assert_allclose(inf2, (d * (1 - d) * p + (1 - d) * p2) / (1 - d * d), rtol=1e-4, atol=1e-6)
+
+
+# ---- HIP network against the oracle ----------------------------------------------------------
+@pytest.fixture(scope="module")
+def net():
+    from elaina_amd.guided import GuidingNetwork
+    n = GuidingNetwork(seed=7)
+    yield n
+    n.close()
+
+
+@pytest.mark.gpu
+def test_gpu_initialisation_and_shapes(net, orc):
+    cfg = default_net_config()
+    assert net.n_params == orc.net_n_params(cfg) and net.n_mlp_params == 13312
+    p = net.params()
+    np.testing.assert_array_equal(p, net.inference_params())
+    lim = np.sqrt(6.0 / (32 + 64))
+    assert np.abs(p[:2048]).max() <= lim * 1.0001 and np.abs(p[:2048]).max() > 0.9 * lim
+    assert np.abs(p[13312:]).max() <= 1.0001e-4 and abs(float(p.mean())) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 63, 64, 1000, 65536 + 17])
+def test_gpu_inference_matches_oracle(net, orc, n):
+    cfg = default_net_config()
+    p = _rand_params(orc, cfg, seed=11)
+    net.set_params(p)
+    rng = np.random.default_rng(n)
+    xy = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    xy[0] = (0.0, 1.0)
+    want = orc.net_forward(cfg, p, xy)[0][:, :33]
+    got = net.inference(xy)
+    # same fma chains in the same order on both sides: expected bit-exact, gate at 1e-6
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(got, want), "fp32 forward drifted from the oracle's operation order"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [5, 64, 4096 + 3])
+def test_gpu_gradients_match_oracle(net, orc, n):
+    cfg = default_net_config()
+    p = _rand_params(orc, cfg, seed=13)
+    net.set_params(p)
+    rng = np.random.default_rng(100 + n)
+    xy = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    dl = rng.normal(size=(n, 33)).astype(np.float32)
+    net.train_step(xy, dl, apply_update=False)
+    got = net.gradients()
+    dl48 = np.zeros((n, 48), dtype=np.float32)
+    dl48[:, :33] = dl
+    want = orc.net_backward(cfg, p, xy, dl48)
+    scale = np.abs(want).max()
+    # float atomics reorder the sums: tolerance, not bit-exactness
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5 * scale)
+    np.testing.assert_array_equal(net.params(), p)      # apply_update=False leaves the weights alone
+
+
+@pytest.mark.gpu
+def test_gpu_training_steps_match_oracle(net, orc):
+    cfg = default_net_config()
+    p = _rand_params(orc, cfg, seed=17, gscale=0.1)
+    net.set_params(p)
+    st = orc.net_optimizer_state(cfg)
+    rng = np.random.default_rng(4)
+    po = p.copy()
+    for step in range(1, 4):
+        xy = rng.uniform(0, 1, (512, 2)).astype(np.float32)
+        dl = (rng.normal(size=(512, 33)) * 128 / 512).astype(np.float32)
+        net.train_step(xy, dl, loss_scale=128.0)
+        dl48 = np.zeros((512, 48), dtype=np.float32)
+        dl48[:, :33] = dl
+        g = orc.net_backward(cfg, po, xy, dl48)
+        inf = orc.net_optimizer_step(cfg, po, st, g, step=step, loss_scale=128.0)
+        # Adam normalises the step by sqrt(v): tiny gradient differences can flip tiny steps, so
+        # compare where the gradient is well above the atomics' noise floor
+        big = np.abs(g) > 1e-3 * np.abs(g).max()
+        np.testing.assert_allclose(net.params()[big], po[big], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(net.inference_params()[big], inf[big], rtol=0, atol=2e-4)
+        assert np.abs(net.params() - po).max() <= 2.05 * cfg.learning_rate
+        net_params = net.params()
+        po = net_params.copy()            # re-synchronise so the comparison stays per step
+        # (the oracle's moments are kept; they only differ by the same noise)
+
+
+@pytest.mark.gpu
+def test_gpu_network_learns_a_field(net):
+    """End-to-end sanity: L2 regression of a smooth 33-channel field drives the loss down and the
+    EMA weights follow (what the guided integrator relies on between training iterations)."""
+    from elaina_amd.guided import GuidingNetwork
+    n = GuidingNetwork(seed=3)
+    rng = np.random.default_rng(8)
+    freq = rng.uniform(1, 3, (33, 2))
+
+    def target(xy):
+        return np.sin(xy @ freq.T * 2 * np.pi).astype(np.float32)
+
+    test_xy = rng.uniform(0, 1, (2048, 2)).astype(np.float32)
+    first = float(np.mean((n.inference(test_xy) - target(test_xy)) ** 2))
+    for _ in range(300):
+        xy = rng.uniform(0, 1, (4096, 2)).astype(np.float32)
+        pred = n.inference(xy, use_inference_params=False)
+        n.train_step(xy, 2.0 * (pred - target(xy)) / pred.size * 128.0, loss_scale=128.0)
+    last = float(np.mean((n.inference(test_xy) - target(test_xy)) ** 2))
+    n.close()
+    assert first > 0.3 and last < 0.1 * first, (first, last)
