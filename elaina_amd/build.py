@@ -13,7 +13,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libwost_hip.so")
 HOST_EXE = os.path.join(LIB_DIR, "elaina-exec")
 
-SOURCES = ["wost_hip.hip", "wost_vmm.hip", "wost_net.hip", "lbvh_build.cpp"]
+SOURCES = ["wost_hip.hip", "wost_vmm.hip", "wost_net.hip", "wost_guided.hip", "lbvh_build.cpp"]
 HEADERS = ["lbvh.h", "wost_device.h", "wost_math.h", "wost_pool.h", os.path.join("..", "..", "include", "wost.h")]
 
 # -ffp-contract=off is part of the arithmetic contract (DESIGN.md "deterministic math")

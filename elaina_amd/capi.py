@@ -81,12 +81,39 @@ class NetConfig(C.Structure):
     ]
 
 
+class GuidedSettings(C.Structure):
+    """wost_guided_settings (include/wost.h)"""
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
+        ("eps_shell", C.c_float), ("train_spp_count", C.c_int32),
+        ("uniform_fraction_training", C.c_float), ("uniform_fraction_guiding", C.c_float),
+        ("max_guided_depth_training", C.c_int32), ("max_guided_depth_guiding", C.c_int32),
+        ("aabb_min", C.c_float * 2), ("aabb_max", C.c_float * 2),
+        ("max_train_depth", C.c_int32), ("batch_size", C.c_int32), ("min_batch_size", C.c_int32),
+        ("batches_per_spp", C.c_int32), ("train_pixel_stride", C.c_int32), ("train_pixel_offset", C.c_int32),
+        ("loss_scale", C.c_float),
+    ]
+
+
+class GuidedStats(C.Structure):
+    _fields_ = [
+        ("walk_steps", C.c_uint64), ("walks_started", C.c_uint64), ("walks_absorbed", C.c_uint64),
+        ("walks_truncated", C.c_uint64), ("neumann_hits", C.c_uint64), ("guided_steps", C.c_uint64),
+        ("train_samples", C.c_uint64), ("optimizer_steps", C.c_uint64),
+        ("solve_ms", C.c_double), ("train_ms", C.c_double), ("kernel_launches", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 EXPORTS = [
     "wost_create", "wost_solve", "wost_solve_sharded", "wost_render_sdf", "wost_closest_point",
     "wost_closest_silhouette", "wost_ray_intersect", "wost_set_option", "wost_destroy",
     "wost_vonmises_eval", "wost_vonmises_sample", "wost_vmm_pdf_sample", "wost_vmm_loss_gradients",
     "wost_net_create", "wost_net_destroy", "wost_net_n_params", "wost_net_get_params",
     "wost_net_set_params", "wost_net_inference", "wost_net_train_step",
+    "wost_guided_create", "wost_guided_network", "wost_guided_solve", "wost_guided_train_set", "wost_guided_destroy",
     "wost_last_error", "wost_version",
 ]
 
@@ -136,6 +163,12 @@ def load():
     L.wost_net_set_params.argtypes = [C.c_void_p, fp]
     L.wost_net_inference.argtypes = [C.c_void_p, fp, C.c_int32, fp, C.c_int]
     L.wost_net_train_step.argtypes = [C.c_void_p, fp, fp, C.c_int32, C.c_float, C.c_int]
+    L.wost_guided_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(GuidedSettings), C.POINTER(NetConfig), C.c_uint64,
+                                     C.c_int, C.POINTER(C.c_void_p)]
+    L.wost_guided_network.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.wost_guided_solve.argtypes = [C.c_void_p, fp, C.POINTER(GuidedStats)]
+    L.wost_guided_train_set.argtypes = [C.c_void_p, C.c_int32, ip, fp, fp, fp, fp, fp, C.POINTER(C.c_uint8)]
+    L.wost_guided_destroy.argtypes = [C.c_void_p]
     L.wost_destroy.argtypes = [C.c_void_p]
     L.wost_last_error.restype = C.c_char_p
     L.wost_version.restype = C.c_char_p

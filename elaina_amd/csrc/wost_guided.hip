@@ -1,0 +1,755 @@
+// wost_guided.hip -- the GUIDED Walk-on-Stars integrator on MI355X (SURVEY.md 8a rows a21, a22,
+// a25, a26, a27) behind the C-ABI (include/wost.h, wost_guided_*).  gfx950 only.
+//
+// Unlike the uniform integrator (wost_hip.hip), whose walkers are independent and live in
+// registers for hundreds of steps, the guided walk is synchronous per sample and per depth:
+// every pixel consults ONE guiding network that is retrained between samples (reference
+// integrator/guided/integrator.cu:968-1094).  The reference issues ~10 kernels and 2 stream
+// syncs per depth over 45-byte AoS-like work items; here one depth is three launches over a
+// compact SoA queue:
+//   separate_kernel  closest point on the Dirichlet LBVH (LDS stack, temporal hint), epsilon
+//                    shell -> boundary colour into the pixel; else closest silhouette, R_B,
+//                    Neumann sampling, normalised network input; ballot/popcount compaction
+//                    (one atomic per wave) into the out-of-shell queue
+//   net_forward      the guiding network on exactly the live entries (size read on the device)
+//   sample_kernel    routing by the learned selection probability, mixture or uniform
+//                    direction with one-sample MIS, boundary intersection, throughput, training
+//                    record; in place -- the out-of-shell queue becomes the next depth's queue
+// Free choices of the reference that made it irreproducible are fixed: the training set is
+// ordered by (pixel, record) through a prefix sum instead of by atomics, so two runs -- and the
+// CPU oracle (oracle/wost_guided.c) -- see the same batches.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/wost.h"
+#include "wost_internal.h"
+#include "wost_vmm_device.h"
+#include "wost_walk.h"
+
+namespace wost {
+
+constexpr int kMaxTrainDepth = 4;     // reference parameters.h:7 (record slots per pixel)
+constexpr int kRecFields = 12;        // sol rgb, pos xy, dir xy, pdf, thp, normal xy, onNeumann
+constexpr uint32_t kDead = 0xffffffffu;
+constexpr uint32_t kOnNeumann = 0x80000000u;
+
+struct GQueue {
+    uint32_t *pid;     // pixel id | kOnNeumann; kDead = entry dropped
+    float *x, *y, *thp, *nx, *ny, *rb;
+    int32_t *hint;     // slot of the closest Dirichlet segment of the previous step
+};
+
+struct GStatsDev {
+    unsigned long long steps, started, absorbed, truncated, nhits, guided;
+};
+
+struct GAabb {
+    float minx, miny, maxx, maxy;   // scene.aabb: contains() test (Eigen AlignedBox semantics)
+    float cx, cy, ex, ey;           // centre and extent of the box inflated by 0.5 % of its diagonal
+};
+
+__device__ __forceinline__ bool aabb_contains(const GAabb &b, float x, float y)
+{
+    return b.minx <= x && x <= b.maxx && b.miny <= y && y <= b.maxy;
+}
+
+// normalizeSpatialCoord (reference integrator/guided/train.h:149-155)
+__device__ __forceinline__ void normalize_coord(const GAabb &b, float x, float y, float &ox, float &oy)
+{
+    ox = 0.5f + (x - b.cx) / b.ex;
+    oy = 0.5f + (y - b.cy) / b.ey;
+}
+
+struct GParams {
+    DevMesh dm, nm;
+    DevSettings st;
+    DevProbe probe;
+    GAabb box;
+    const uint8_t *mask;
+    GQueue in, out;
+    const uint32_t *count_in;
+    uint32_t *count_out;
+    uint64_t *rng;            // per pixel (inc == 1)
+    float *sol;               // per pixel rgb
+    uint32_t *cur_depth;      // per pixel: training records of the current sample
+    float *rec;               // [slot][field][n_pixels]
+    int32_t *hint0;           // per pixel: closest slot of the evaluation point
+    float *net_in;            // [2 * slot]
+    const float *net_out;     // [33 * slot]
+    GStatsDev *stats;
+    int32_t n_pixels;
+    int32_t depth;
+    int32_t stack_stride;
+    // guiding state of this sample
+    int32_t training;         // trainState.enableTraining
+    int32_t guiding;          // depth < maxGuidedDepth
+    int32_t max_train_depth;
+    uint32_t train_offset, train_stride;
+    float uniform_fraction;
+    int32_t first_sample;
+    int32_t last_depth;
+};
+
+__device__ __forceinline__ bool is_training_pixel(const GParams &P, uint32_t pid)
+{
+    return P.training && ((pid - P.train_offset) % P.train_stride == 0u);
+}
+
+__device__ __forceinline__ float &rec_at(const GParams &P, int slot, int field, uint32_t pid)
+{
+    return P.rec[((size_t)slot * kRecFields + field) * (size_t)P.n_pixels + pid];
+}
+
+// recordSolution / recordSourceContribution (reference guided.h:48-68): add to every record
+// this walk has already created.  (The reference's inclusive variant also touches the slot of
+// the record not yet created, which incrementDepth then wipes: no observable effect.)
+__device__ __forceinline__ void record_solution(const GParams &P, uint32_t pid, float r, float g, float b)
+{
+    const uint32_t n = min(P.cur_depth[pid], (uint32_t)kMaxTrainDepth);
+    for (uint32_t i = 0; i < n; ++i) {
+        rec_at(P, i, 0, pid) = rec_at(P, i, 0, pid) + r;
+        rec_at(P, i, 1, pid) = rec_at(P, i, 1, pid) + g;
+        rec_at(P, i, 2, pid) = rec_at(P, i, 2, pid) + b;
+    }
+}
+
+// wave-level compaction: returns the output slot of this lane (valid when `keep`)
+__device__ __forceinline__ uint32_t wave_push(bool keep, uint32_t *counter)
+{
+    const unsigned long long bal = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0 && bal) base = atomicAdd(counter, (uint32_t)__popcll(bal));
+    base = __shfl(base, 0);
+    return base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ void wave_count(bool pred, unsigned long long *counter)
+{
+    const unsigned long long bal = __ballot(pred);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(counter, (unsigned long long)__popcll(bal));
+}
+
+// ---- start of a sample: every unmasked pixel queues its evaluation point ---------------------
+// (reference prepareSolve :112-128 on the first sample, reset + generateEvaluationPoints
+// :131-150 on every sample)
+__global__ __launch_bounds__(256) void begin_sample_kernel(GParams P)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_frame = p < P.n_pixels;
+    bool active = false;
+    float x = 0, y = 0;
+    if (in_frame) {
+        if (P.first_sample) {
+            Pcg rng;
+            pcg_seed_pixel(rng, p, P.st.width);
+            P.rng[p] = rng.state;
+            P.sol[3 * (size_t)p] = 0.0f; P.sol[3 * (size_t)p + 1] = 0.0f; P.sol[3 * (size_t)p + 2] = 0.0f;
+            P.hint0[p] = 0;
+        }
+        P.cur_depth[p] = 0;
+        active = (P.mask == nullptr || P.mask[p] != 0);
+        if (active) eval_point(P.probe, p % P.st.width, p / P.st.width, P.st.width, P.st.height, x, y);
+    }
+    const uint32_t s = wave_push(active, P.count_out);
+    wave_count(active, &P.stats->started);
+    if (active) {
+        P.out.pid[s] = (uint32_t)p;
+        P.out.x[s] = x; P.out.y[s] = y;
+        P.out.thp[s] = 1.0f;
+        P.out.nx[s] = 0.0f; P.out.ny[s] = 0.0f;
+        P.out.hint[s] = P.hint0[p];
+    }
+}
+
+// ---- separateEvaluationPoint + handleBoundary + sampleNeumann + generate_inference_data -----
+// (reference guided/integrator.cu:153-249, 252-274, 367-494; train.h:474-486)
+template <bool EMISSIVE, bool TREE>
+__global__ __launch_bounds__(256) void separate_kernel(GParams P)
+{
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const LdsColumn stk{stack, (uint32_t)P.stack_stride};
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_in = *P.count_in;
+    uint32_t pidf = kDead;
+    if (i < n_in) pidf = P.in.pid[i];
+    const bool live = pidf != kDead;
+    wave_count(live, &P.stats->steps);
+    bool keep = false;
+    bool absorbed = false;
+    float x = 0, y = 0, thp = 0, nx = 0, ny = 0, R_B = 0;
+    int32_t hint = 0;
+    const uint32_t pid = pidf & ~kOnNeumann;
+    const bool on_n = (pidf & kOnNeumann) != 0u;
+    if (live) {
+        x = P.in.x[i]; y = P.in.y[i]; thp = P.in.thp[i]; nx = P.in.nx[i]; ny = P.in.ny[i];
+        hint = P.in.hint[i];
+        const bool train_px = is_training_pixel(P, pid);
+        const float eps = P.st.eps;
+        float R_D = WOST_INF;
+        if (P.dm.n_segs > 0) {
+            const Closest cp = closest_point(P.dm, x, y, slot_candidate(P.dm, hint, x, y), stack, P.stack_stride);
+            hint = cp.slot;
+            if (P.depth == 0) P.hint0[pid] = cp.slot;
+            const float4 a = P.dm.segA[cp.slot];
+            const float inv = P.dm.segInv[cp.slot];
+            const float wx = x - a.x, wy = y - a.y;
+            const float uv = dot2(wx, wy, a.z, a.w) * inv;
+            const float cr = cross2(a.z, a.w, wx, wy);
+            const int side = (0.0f < cr) - (cr < 0.0f);
+            R_D = sqrtf(cp.d2);
+            if ((R_D < eps) && (uv > 0.0f && uv < 1.0f)) {
+                float r, g, b;
+                surface_color(P.dm.segCol + 12 * (size_t)cp.slot, side, uv, r, g, b);
+                r *= P.st.dirichlet_intensity; g *= P.st.dirichlet_intensity; b *= P.st.dirichlet_intensity;
+                r *= thp; g *= thp; b *= thp;
+                float *s = P.sol + 3 * (size_t)pid;
+                s[0] = r + s[0]; s[1] = g + s[1]; s[2] = b + s[2];
+                if (train_px) record_solution(P, pid, r, g, b);
+                absorbed = true;
+            }
+        }
+        if (!absorbed) {
+            float R_N = WOST_INF;
+            if (P.nm.n_segs > 0) R_N = closest_silhouette<TREE>(P.nm, x, y, R_D, stk);
+            R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));     // no 0.99 in the guided integrator (:238-239)
+            keep = !isinf(R_B);                              // no boundary at all: nothing to walk to
+            if (keep && P.nm.n_segs > 0) {
+                Pcg rng{P.rng[pid], 1};
+                float cr, cg, cb;
+                if (neumann_sample<EMISSIVE, TREE>(P.nm, P.st.neumann_intensity, eps, x, y, R_B, on_n, nx, ny, thp, rng, stk,
+                                                   cr, cg, cb)) {
+                    float *s = P.sol + 3 * (size_t)pid;
+                    s[0] = cr + s[0]; s[1] = cg + s[1]; s[2] = cb + s[2];
+                    if (train_px) record_solution(P, pid, cr, cg, cb);
+                }
+                P.rng[pid] = rng.state;
+            }
+        }
+    }
+    wave_count(absorbed, &P.stats->absorbed);
+    const uint32_t s = wave_push(keep, P.count_out);
+    if (keep) {
+        P.out.pid[s] = pidf;
+        P.out.x[s] = x; P.out.y[s] = y; P.out.thp[s] = thp;
+        P.out.nx[s] = nx; P.out.ny[s] = ny;
+        P.out.rb[s] = R_B;
+        P.out.hint[s] = hint;
+        float ix, iy;
+        normalize_coord(P.box, x, y, ix, iy);
+        P.net_in[2 * (size_t)s] = ix;
+        P.net_in[2 * (size_t)s + 1] = iy;
+    }
+}
+
+// ---- handleOutShellPoint + handleGuidedSampling + handleUniformSampling / oneStepWalk --------
+// (reference guided/integrator.cu:497-526, 782-880, 671-779, 883-965), in place on the queue
+template <bool TREE>
+__global__ __launch_bounds__(256) void sample_kernel(GParams P)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_in = *P.count_in;
+    const bool live = i < n_in;       // separate_kernel only pushes live entries
+    bool guided_step = false, hit_n = false, alive_after = false;
+    if (live) {
+        const uint32_t pidf = P.in.pid[i];
+        const uint32_t pid = pidf & ~kOnNeumann;
+        const bool on_n = (pidf & kOnNeumann) != 0u;
+        const float x = P.in.x[i], y = P.in.y[i], thp = P.in.thp[i], nx = P.in.nx[i], ny = P.in.ny[i];
+        const float R_B = P.in.rb[i];
+        Pcg rng{P.rng[pid], 1};
+        const bool record = is_training_pixel(P, pid) && P.depth < P.max_train_depth;
+        float dirx = 0, diry = 0, pdf = 1, alpha = 1;
+        bool dropped = false;
+        if (!P.guiding) {
+            uniform_direction(on_n, nx, ny, rng, dirx, diry, pdf, alpha);
+        } else {
+            const float *raw = P.net_out + 33 * (size_t)i;
+            const float sel = 1 / (1.f + expf(-raw[32]));                 // logistic (functors.h:182)
+            const bool inside = aabb_contains(P.box, x, y);
+            // the draw precedes the box test and is skipped for uniform fraction 0 (:518)
+            bool to_guided = (P.uniform_fraction == 0.0f) || (pcg_next_float(rng) < sel);
+            to_guided = to_guided && inside;
+            if (to_guided) {
+                if (!(P.uniform_fraction < 1.0f)) {
+                    dropped = true;                                       // kernel never launched (:1031)
+                } else {
+                    Vmm m;
+                    m.build(raw);
+                    m.sample(rng, dirx, diry);
+                    float guided_pdf = m.pdf(dirx, diry);
+                    float uniform_pdf = 1.0f / WOST_2PI;
+                    if (on_n) {
+                        uniform_pdf = (float)(1.0 / 3.14159265358979323846);
+                        alpha = 0.5f;
+                        const float dd = 2 * (dirx * nx + diry * ny);
+                        const float rx = dirx - dd * nx, ry = diry - dd * ny;
+                        if (nx * dirx + ny * diry <= 0) { dirx = rx; diry = ry; }
+                        guided_pdf += m.pdf(rx, ry);
+                    }
+                    pdf = sel * guided_pdf + (1.0f - sel) * uniform_pdf;
+                    guided_step = true;
+                }
+            } else {
+                uniform_direction(on_n, nx, ny, rng, dirx, diry, pdf, alpha);
+                if (inside) {
+                    Vmm m;
+                    m.build(raw);
+                    float guided_pdf = m.pdf(dirx, diry);
+                    if (on_n) {
+                        const float dd = 2 * (dirx * nx + diry * ny);
+                        guided_pdf += m.pdf(dirx - dd * nx, diry - dd * ny);
+                    }
+                    pdf = sel * guided_pdf + (1.0f - sel) * pdf;
+                }
+            }
+        }
+        P.rng[pid] = rng.state;
+        if (dropped) {
+            P.in.pid[i] = kDead;
+        } else {
+            float nxt_x, nxt_y, hnx, hny;
+            hit_n = walk_advance<TREE>(P.nm, P.st.eps, x, y, R_B, on_n, nx, ny, dirx, diry, stk, nxt_x, nxt_y, hnx, hny);
+            if (record) {
+                // incrementDepth (guided.h:21-46): the vertex BEFORE the step
+                const uint32_t d = P.cur_depth[pid];
+                if (d < (uint32_t)kMaxTrainDepth) {
+                    rec_at(P, d, 0, pid) = 0.0f; rec_at(P, d, 1, pid) = 0.0f; rec_at(P, d, 2, pid) = 0.0f;
+                    rec_at(P, d, 3, pid) = x; rec_at(P, d, 4, pid) = y;
+                    rec_at(P, d, 5, pid) = dirx; rec_at(P, d, 6, pid) = diry;
+                    rec_at(P, d, 7, pid) = pdf;
+                    rec_at(P, d, 8, pid) = thp;
+                    rec_at(P, d, 9, pid) = nx; rec_at(P, d, 10, pid) = ny;
+                    rec_at(P, d, 11, pid) = on_n ? 1.0f : 0.0f;
+                    P.cur_depth[pid] = d + 1;
+                }
+            }
+            P.in.pid[i] = pid | (hit_n ? kOnNeumann : 0u);
+            P.in.x[i] = nxt_x; P.in.y[i] = nxt_y;
+            P.in.thp[i] = thp / pdf / alpha / WOST_2PI;
+            P.in.nx[i] = hnx; P.in.ny[i] = hny;
+            alive_after = true;
+        }
+    }
+    wave_count(guided_step, &P.stats->guided);
+    wave_count(hit_n, &P.stats->nhits);
+    if (P.last_depth) wave_count(alive_after, &P.stats->truncated);
+}
+
+// ---- training set: generate_training_data (reference train.h:423-471), ordered ----------------
+struct TrainSet {
+    float *xy, *dir, *sol, *li, *pdf, *nrm;
+    uint8_t *onn;
+};
+
+struct TParams {
+    GAabb box;
+    const uint32_t *cur_depth;
+    const float *rec;
+    int32_t n_pixels;
+    uint32_t train_offset, train_stride;
+    int32_t n_train_pixels;
+    uint32_t *block_sums;     // [n_blocks + 1]
+    TrainSet ts;
+};
+
+__device__ __forceinline__ bool record_valid(const TParams &T, int slot, uint32_t pid, float out[kRecFields])
+{
+    for (int f = 0; f < kRecFields; ++f) out[f] = T.rec[((size_t)slot * kRecFields + f) * (size_t)T.n_pixels + pid];
+    if (!aabb_contains(T.box, out[3], out[4])) return false;
+    // |solution / thp| per channel, 0 where the throughput vanished
+    for (int c = 0; c < 3; ++c) {
+        float v = 0.0f;
+        if (fabsf(out[8]) > 1e-5f) v = out[c] / out[8];
+        out[c] = fabsf(v);
+    }
+    float ix, iy;
+    normalize_coord(T.box, out[3], out[4], ix, iy);
+    const bool bad = isnan(ix) || isnan(iy) || isnan(out[5]) || isnan(out[6]) || isnan(out[7]) || out[7] == 0 ||
+                     isnan(out[0]) || isnan(out[1]) || isnan(out[2]);
+    out[3] = ix;
+    out[4] = iy;
+    return !bad;
+}
+
+// pass 1: samples per training pixel -> per-block sums; pass 3: scatter at the scanned offsets
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void train_set_kernel(TParams T)
+{
+    __shared__ uint32_t sh[256];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    uint32_t cnt = 0;
+    uint32_t pid = 0, depth = 0;
+    if (t < T.n_train_pixels) {
+        pid = T.train_offset + (uint32_t)t * T.train_stride;
+        depth = min(T.cur_depth[pid], (uint32_t)kMaxTrainDepth);
+    }
+    float r[kMaxTrainDepth][kRecFields];
+    bool ok[kMaxTrainDepth];
+#pragma unroll
+    for (int k = 0; k < kMaxTrainDepth; ++k) {
+        ok[k] = (uint32_t)k < depth && record_valid(T, k, pid, r[k]);
+        cnt += ok[k] ? 1u : 0u;
+    }
+    // block-level exclusive scan of cnt
+    sh[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (!SCATTER) {
+        if (threadIdx.x == 255) T.block_sums[blockIdx.x] = sh[255];
+        return;
+    }
+    uint32_t o = T.block_sums[blockIdx.x] + sh[threadIdx.x] - cnt;
+#pragma unroll
+    for (int k = 0; k < kMaxTrainDepth; ++k) {
+        if (!ok[k]) continue;
+        const float *q = r[k];
+        T.ts.xy[2 * (size_t)o] = q[3]; T.ts.xy[2 * (size_t)o + 1] = q[4];
+        T.ts.dir[2 * (size_t)o] = q[5]; T.ts.dir[2 * (size_t)o + 1] = q[6];
+        T.ts.sol[3 * (size_t)o] = q[0]; T.ts.sol[3 * (size_t)o + 1] = q[1]; T.ts.sol[3 * (size_t)o + 2] = q[2];
+        T.ts.li[o] = (q[0] + q[1] + q[2]) / 3.0f;      // Color::mean() (train.h:519)
+        T.ts.pdf[o] = q[7];
+        T.ts.nrm[2 * (size_t)o] = q[9]; T.ts.nrm[2 * (size_t)o + 1] = q[10];
+        T.ts.onn[o] = q[11] != 0.0f ? 1 : 0;
+        ++o;
+    }
+}
+
+// pass 2: exclusive scan of the block sums by one block; block_sums[n_blocks] = total
+__global__ __launch_bounds__(256) void train_scan_kernel(uint32_t *block_sums, int n_blocks)
+{
+    __shared__ uint32_t sh[256];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += 256) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < n_blocks ? block_sums[i] : 0u;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            uint32_t a = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += a;
+            __syncthreads();
+        }
+        if (i < n_blocks) block_sums[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[n_blocks] = carry;
+}
+
+__global__ void resolve_kernel(const float *sol, int n, float spp, float *field)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * n) field[i] = sol[i] / spp;
+}
+
+}  // namespace wost
+
+using namespace wost;
+
+struct wost_guided {
+    int device = 0;
+    wost_guided_settings gs{};
+    wost_handle scene = nullptr;       // owns the uploaded meshes
+    wost_net_handle net = nullptr;
+    SceneView view{};
+    size_t n_pixels = 0;
+    std::vector<void *> allocs;
+    GQueue q[2]{};
+    uint32_t *counts = nullptr;        // [2]
+    uint32_t *host_counts = nullptr;   // pinned [4]
+    uint64_t *rng = nullptr;
+    float *sol = nullptr, *field = nullptr, *rec = nullptr, *net_in = nullptr, *net_out = nullptr;
+    uint32_t *cur_depth = nullptr;
+    int32_t *hint0 = nullptr;
+    GStatsDev *stats = nullptr;
+    uint32_t *block_sums = nullptr;
+    int n_train_blocks = 0, n_train_pixels = 0;
+    TrainSet ts{};
+    uint32_t last_train_n = 0;
+    GAabb box{};
+};
+
+#define G_TRY(expr)                                                                                      \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return set_error(WOST_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+static hipError_t galloc(wost_guided *g, T **p, size_t count)
+{
+    void *v = nullptr;
+    hipError_t e = hipMalloc(&v, std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) {
+        g->allocs.push_back(v);
+        *p = reinterpret_cast<T *>(v);
+    }
+    return e;
+}
+
+static void guided_free(wost_guided *g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    for (void *p : g->allocs) (void)hipFree(p);
+    if (g->host_counts) (void)hipHostFree(g->host_counts);
+    if (g->net) wost_net_destroy(g->net);
+    if (g->scene) wost_destroy(g->scene);
+    delete g;
+}
+
+extern "C" {
+
+int wost_guided_create(const wost_scene_desc *scene, const wost_guided_settings *s, const wost_net_config *net,
+                       uint64_t net_seed, int device, wost_guided_handle *out)
+{
+    if (!scene || !s || !net || !out) return set_error(WOST_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (s->width <= 0 || s->height <= 0 || s->spp < 0 || s->max_depth <= 0 || s->train_spp_count < 0 ||
+        s->max_guided_depth_training < 0 || s->max_guided_depth_guiding < 0 || s->batch_size < 128 ||
+        s->min_batch_size < 1 || s->batches_per_spp < 0 || s->train_pixel_stride < 1 || s->train_pixel_offset < 0 ||
+        s->train_pixel_offset >= s->train_pixel_stride || !(s->loss_scale > 0.0f) ||
+        !(s->aabb_min[0] < s->aabb_max[0]) || !(s->aabb_min[1] < s->aabb_max[1]))
+        return set_error(WOST_ERR_INVALID, "bad guided settings");
+    if (s->max_train_depth < 0 || s->max_train_depth > kMaxTrainDepth)
+        return set_error(WOST_ERR_UNSUPPORTED, "max_train_depth must be in 0..4 (record slots per pixel)");
+    if (net->n_output != 33) return set_error(WOST_ERR_UNSUPPORTED, "the 2-D mixture needs 33 network outputs");
+    if ((int64_t)s->width * s->height >= (1ll << 31)) return set_error(WOST_ERR_UNSUPPORTED, "frame too large");
+    wost_guided *g = new (std::nothrow) wost_guided();
+    if (!g) return set_error(WOST_ERR_NOMEM, "out of host memory");
+    g->device = device;
+    g->gs = *s;
+    auto bail = [&](int code) {
+        guided_free(g);
+        return code;
+    };
+    // the scene upload and LBVH build are the uniform integrator's (spp of the base settings is unused here)
+    wost_settings base{s->width, s->height, 1, s->max_depth, s->eps_shell};
+    int rc = wost_create(scene, &base, device, &g->scene);
+    if (rc != WOST_OK) return bail(rc);
+    rc = wost_net_create(device, net, net_seed, &g->net);
+    if (rc != WOST_OK) return bail(rc);
+    g->view = scene_view(g->scene);
+    g->n_pixels = (size_t)s->width * s->height;
+    const size_t N = g->n_pixels;
+    {
+        // normalizeSpatialCoord's inflated box, evaluated once in fp32 exactly like train.h:149-155
+        GAabb &b = g->box;
+        b.minx = s->aabb_min[0]; b.miny = s->aabb_min[1]; b.maxx = s->aabb_max[0]; b.maxy = s->aabb_max[1];
+        const float ex = b.maxx - b.minx, ey = b.maxy - b.miny;
+        const float infl = std::sqrt(ex * ex + ey * ey) * 0.005f;
+        const float lox = b.minx - infl, loy = b.miny - infl, hix = b.maxx + infl, hiy = b.maxy + infl;
+        b.cx = (lox + hix) / 2.0f; b.cy = (loy + hiy) / 2.0f;
+        b.ex = hix - lox; b.ey = hiy - loy;
+    }
+    hipError_t e = hipSuccess;
+#define GA(ptr, count) if (e == hipSuccess) e = galloc(g, &(ptr), (count))
+    for (int k = 0; k < 2; ++k) {
+        GA(g->q[k].pid, N); GA(g->q[k].x, N); GA(g->q[k].y, N); GA(g->q[k].thp, N); GA(g->q[k].nx, N); GA(g->q[k].ny, N);
+        GA(g->q[k].rb, N); GA(g->q[k].hint, N);
+    }
+    GA(g->counts, 2); GA(g->rng, N); GA(g->sol, 3 * N); GA(g->field, 3 * N);
+    GA(g->rec, (size_t)kMaxTrainDepth * kRecFields * N);
+    GA(g->net_in, 2 * N); GA(g->net_out, 33 * N); GA(g->cur_depth, N); GA(g->hint0, N); GA(g->stats, 1);
+    g->n_train_pixels = (int)((N - (size_t)s->train_pixel_offset + (size_t)s->train_pixel_stride - 1) / (size_t)s->train_pixel_stride);
+    g->n_train_blocks = (g->n_train_pixels + 255) / 256;
+    GA(g->block_sums, (size_t)g->n_train_blocks + 1);
+    const size_t M = (size_t)g->n_train_pixels * kMaxTrainDepth;
+    GA(g->ts.xy, 2 * M); GA(g->ts.dir, 2 * M); GA(g->ts.sol, 3 * M); GA(g->ts.li, M); GA(g->ts.pdf, M); GA(g->ts.nrm, 2 * M);
+    GA(g->ts.onn, M);
+#undef GA
+    if (e == hipSuccess) e = hipHostMalloc((void **)&g->host_counts, 4 * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        set_error(WOST_ERR_DEVICE, std::string("guided allocation: ") + hipGetErrorString(e));
+        return bail(WOST_ERR_DEVICE);
+    }
+    *out = g;
+    return WOST_OK;
+}
+
+int wost_guided_destroy(wost_guided_handle h)
+{
+    guided_free(h);
+    return WOST_OK;
+}
+
+int wost_guided_network(wost_guided_handle h, wost_net_handle *net)
+{
+    if (!h || !net) return set_error(WOST_ERR_INVALID, "null argument");
+    *net = h->net;
+    return WOST_OK;
+}
+
+int wost_guided_train_set(wost_guided_handle h, int32_t capacity, int32_t *n, float *xy, float *dir, float *solution,
+                          float *dir_pdf, float *normal, uint8_t *on_neumann)
+{
+    if (!h || !n || capacity < 0) return set_error(WOST_ERR_INVALID, "bad argument");
+    G_TRY(hipSetDevice(h->device));
+    *n = (int32_t)h->last_train_n;
+    const size_t m = std::min<size_t>(h->last_train_n, (size_t)capacity);
+    if (m == 0) return WOST_OK;
+    if (xy) G_TRY(hipMemcpy(xy, h->ts.xy, m * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    if (dir) G_TRY(hipMemcpy(dir, h->ts.dir, m * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    if (solution) G_TRY(hipMemcpy(solution, h->ts.sol, m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (dir_pdf) G_TRY(hipMemcpy(dir_pdf, h->ts.pdf, m * sizeof(float), hipMemcpyDeviceToHost));
+    if (normal) G_TRY(hipMemcpy(normal, h->ts.nrm, m * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    if (on_neumann) G_TRY(hipMemcpy(on_neumann, h->ts.onn, m, hipMemcpyDeviceToHost));
+    return WOST_OK;
+}
+
+int wost_guided_solve(wost_guided_handle g, float *field_rgb, wost_guided_stats *stats)
+{
+    if (!g || !field_rgb) return set_error(WOST_ERR_INVALID, "null argument");
+    const auto t_start = std::chrono::high_resolution_clock::now();
+    G_TRY(hipSetDevice(g->device));
+    const wost_guided_settings &s = g->gs;
+    const SceneView &v = g->view;
+    hipStream_t stream = v.stream;
+    const int N = (int)g->n_pixels;
+    const bool emissive = v.nm.n_segs > 0 && v.nm.emissive;
+    const bool tree = v.nm.n_segs > WOST_FLAT_MAX;
+    const int d_levels = v.dm.n_segs > 0 ? v.dm.levels : 1, n_levels = v.nm.n_segs > 0 ? v.nm.levels : 1;
+    const int stack_words = 3 * std::max(d_levels, n_levels) + 1;
+    const size_t lds = (size_t)stack_words * 256 * sizeof(uint32_t);
+    uint32_t launches = 0;
+    double train_ms = 0.0;
+    uint64_t train_samples = 0;
+    const int opt_before = net_optimizer_steps(g->net);
+
+    G_TRY(hipMemsetAsync(g->stats, 0, sizeof(GStatsDev), stream));
+    GParams P{};
+    P.dm = v.dm; P.nm = v.nm; P.st = v.st; P.probe = v.probe; P.box = g->box; P.mask = v.mask;
+    P.rng = g->rng; P.sol = g->sol; P.cur_depth = g->cur_depth; P.rec = g->rec; P.hint0 = g->hint0;
+    P.net_in = g->net_in; P.net_out = g->net_out; P.stats = g->stats; P.n_pixels = N; P.stack_stride = 256;
+    P.max_train_depth = s.max_train_depth;
+    P.train_offset = (uint32_t)s.train_pixel_offset; P.train_stride = (uint32_t)s.train_pixel_stride;
+
+    // ctor state (integrator.cu:1158-1160), prepareSolve (:125-126)
+    bool training = true;
+    float uniform_fraction = s.uniform_fraction_training;
+    int max_guided_depth = s.max_guided_depth_training;
+
+    for (int sample = 0; sample < s.spp; ++sample) {
+        if (sample == s.train_spp_count) {       // :991-996
+            training = false;
+            uniform_fraction = s.uniform_fraction_guiding;
+            max_guided_depth = s.max_guided_depth_guiding;
+        }
+        P.training = training ? 1 : 0;
+        P.uniform_fraction = uniform_fraction;
+        P.first_sample = sample == 0;
+        int cur = 0;     // queue holding the evaluation points of this depth
+        G_TRY(hipMemsetAsync(g->counts + cur, 0, sizeof(uint32_t), stream));
+        P.out = g->q[cur]; P.count_out = g->counts + cur;
+        hipLaunchKernelGGL(begin_sample_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, P);
+        ++launches;
+        uint32_t n_cur = (uint32_t)N;    // upper bound of the queue size, refined by the read-backs below
+        for (int depth = 0; depth < s.max_depth; ++depth) {
+            const int nxt = cur ^ 1;
+            P.depth = depth;
+            P.guiding = depth < max_guided_depth ? 1 : 0;
+            P.last_depth = depth == s.max_depth - 1;
+            P.in = g->q[cur]; P.count_in = g->counts + cur;
+            P.out = g->q[nxt]; P.count_out = g->counts + nxt;
+            G_TRY(hipMemsetAsync(g->counts + nxt, 0, sizeof(uint32_t), stream));
+            const unsigned grid = (n_cur + 255) / 256;
+#define LAUNCH_SEP(E, T) hipLaunchKernelGGL((separate_kernel<E, T>), dim3(grid), dim3(256), lds, stream, P)
+            if (emissive) { if (tree) LAUNCH_SEP(true, true); else LAUNCH_SEP(true, false); }
+            else          { if (tree) LAUNCH_SEP(false, true); else LAUNCH_SEP(false, false); }
+#undef LAUNCH_SEP
+            ++launches;
+            // the out-of-shell queue is the input of the network and of the sampling kernel
+            G_TRY(hipMemcpyAsync(g->host_counts, g->counts + nxt, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            G_TRY(hipStreamSynchronize(stream));
+            const uint32_t n_out = g->host_counts[0];
+            if (n_out == 0) break;
+            if (P.guiding) {
+                int rc = net_inference_dev(g->net, g->net_in, nullptr, (int)n_out, g->net_out, true, stream);
+                if (rc != WOST_OK) return rc;
+                ++launches;
+            }
+            P.in = g->q[nxt]; P.count_in = g->counts + nxt;
+            const unsigned grid2 = (n_out + 255) / 256;
+            if (tree) hipLaunchKernelGGL((sample_kernel<true>), dim3(grid2), dim3(256), lds, stream, P);
+            else hipLaunchKernelGGL((sample_kernel<false>), dim3(grid2), dim3(256), lds, stream, P);
+            ++launches;
+            G_TRY(hipGetLastError());
+            cur = nxt;
+            n_cur = n_out;
+        }
+        // ---- trainStep (:618-668) ----
+        if (training) {
+            const auto t0 = std::chrono::high_resolution_clock::now();
+            TParams T{};
+            T.box = g->box; T.cur_depth = g->cur_depth; T.rec = g->rec; T.n_pixels = N;
+            T.train_offset = (uint32_t)s.train_pixel_offset; T.train_stride = (uint32_t)s.train_pixel_stride;
+            T.n_train_pixels = g->n_train_pixels; T.block_sums = g->block_sums; T.ts = g->ts;
+            hipLaunchKernelGGL((train_set_kernel<false>), dim3(g->n_train_blocks), dim3(256), 0, stream, T);
+            hipLaunchKernelGGL(train_scan_kernel, dim3(1), dim3(256), 0, stream, g->block_sums, g->n_train_blocks);
+            hipLaunchKernelGGL((train_set_kernel<true>), dim3(g->n_train_blocks), dim3(256), 0, stream, T);
+            launches += 3;
+            G_TRY(hipMemcpyAsync(g->host_counts + 1, g->block_sums + g->n_train_blocks, sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, stream));
+            G_TRY(hipStreamSynchronize(stream));
+            const size_t n = g->host_counts[1];
+            g->last_train_n = (uint32_t)n;
+            train_samples += n;
+            const size_t bs = (size_t)s.batch_size;
+            size_t n_batches = std::min<size_t>(n / bs + 1, (size_t)s.batches_per_spp);
+            for (size_t it = 0; it < n_batches; ++it) {
+                size_t local = std::min(n - it * bs, bs);
+                local -= local % 128;
+                if (local < (size_t)s.min_batch_size) break;
+                const size_t o = it * bs;
+                float *raw = nullptr, *dl = nullptr;
+                int rc = net_forward_train_dev(g->net, g->ts.xy + 2 * o, (int)local, stream, &raw, &dl);
+                if (rc != WOST_OK) return rc;
+                launch_vmm_loss_gradients(stream, raw, g->ts.dir + 2 * o, g->ts.li + o, g->ts.pdf + o, g->ts.onn + o,
+                                          g->ts.nrm + 2 * o, (int)local, s.loss_scale, dl, nullptr);
+                rc = net_backward_update_dev(g->net, g->ts.xy + 2 * o, (int)local, s.loss_scale, 1, stream);
+                if (rc != WOST_OK) return rc;
+                launches += 8;
+            }
+            G_TRY(hipStreamSynchronize(stream));
+            train_ms += std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+        }
+    }
+    hipLaunchKernelGGL(resolve_kernel, dim3((3 * N + 255) / 256), dim3(256), 0, stream, g->sol, N, (float)s.spp, g->field);
+    G_TRY(hipGetLastError());
+    G_TRY(hipMemcpyAsync(field_rgb, g->field, (size_t)N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    GStatsDev hs{};
+    G_TRY(hipMemcpyAsync(&hs, g->stats, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    G_TRY(hipStreamSynchronize(stream));
+    if (stats) {
+        *stats = wost_guided_stats{};
+        stats->walk_steps = hs.steps; stats->walks_started = hs.started; stats->walks_absorbed = hs.absorbed;
+        stats->walks_truncated = hs.truncated; stats->neumann_hits = hs.nhits; stats->guided_steps = hs.guided;
+        stats->train_samples = train_samples;
+        stats->optimizer_steps = (uint64_t)(net_optimizer_steps(g->net) - opt_before);
+        stats->train_ms = train_ms;
+        stats->kernel_launches = launches;
+        stats->solve_ms =
+            std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_start).count();
+    }
+    return WOST_OK;
+}
+
+}  // extern "C"

@@ -28,6 +28,8 @@
 #include "../../include/wost.h"
 #include "lbvh.h"
 #include "wost_device.h"
+#include "wost_internal.h"
+#include "wost_walk.h"
 
 namespace wost {
 
@@ -216,91 +218,20 @@ __device__ __forceinline__ uint32_t step_finish(const DevMesh &dm, const DevMesh
 
     // ---- sampleNeumann -------------------------------------------------------------------
     if (has_n) {
-        // the two draws happen whether or not the boundary emits (reference :343-347)
-        float u0 = 0.0f, u1 = 0.0f;
-        if (NEUMANN_EMISSIVE) {
-            u0 = pcg_next_float(L.rng);
-            u1 = pcg_next_float(L.rng);
-        } else {
-            pcg_skip2(L.rng);
-        }
-        if (NEUMANN_EMISSIVE) {
-            float pdf;
-            const int oi = sample_in_sphere_flat(nm, px, py, R_B, u0, pdf);
-            if (oi != -1 && pdf > 0) {
-                const DevFlatSeg so = nm.flat[oi];
-                const float spx = __builtin_fmaf(u1, so.ex, so.ax), spy = __builtin_fmaf(u1, so.ey, so.ay);
-                const float rx = spx - px, ry = spy - py;
-                const float r = sqrtf(dot2(rx, ry, rx, ry));
-                if (r < R_B && r > 0) {
-                    float ox = px, oy = py;
-                    if (L.on_n) { ox += eps * L.nx; oy += eps * L.ny; }
-                    float dx = spx - ox, dy = spy - oy;
-                    const float cd = sqrtf(dot2(dx, dy, dx, dy));
-                    if (cd > 0) { dx /= cd; dy /= cd; }
-                    const bool blocked = ray_any<NEUMANN_TREE>(nm, ox, oy, dx, dy, cd - eps, stk);
-                    if (!blocked) {
-                        const float cr = cross2(so.ex, so.ey, px - so.ax, py - so.ay);
-                        int side = (0.0f < cr) - (cr < 0.0f);
-                        const float uv = dot2(spx - so.ax, spy - so.ay, so.ex, so.ey) * so.inv_len2;
-                        if (L.on_n) {
-                            const float dn = dot2(so.nx, so.ny, L.nx, L.ny);
-                            side = (0.0f < dn) - (dn < 0.0f);
-                        }
-                        if (side != 0) {
-                            float cr_, cg_, cb_;
-                            surface_color(nm.flatCol + 12 * (size_t)oi, side, uv, cr_, cg_, cb_);
-                            const float alpha = L.on_n ? 0.5f : 1.0f;
-                            const float G = det_logf(R_B / r) / WOST_2PI;
-                            const float w = L.thp * G / alpha / pdf;
-                            cr_ *= st.neumann_intensity; cg_ *= st.neumann_intensity; cb_ *= st.neumann_intensity;
-                            cr_ *= w; cg_ *= w; cb_ *= w;
-                            L.sr = -cr_ + L.sr; L.sg = -cg_ + L.sg; L.sb = -cb_ + L.sb;
-                        }
-                    }
-                }
-            }
+        float cr_, cg_, cb_;
+        if (neumann_sample<NEUMANN_EMISSIVE, NEUMANN_TREE>(nm, st.neumann_intensity, eps, px, py, R_B, L.on_n, L.nx, L.ny,
+                                                           L.thp, L.rng, stk, cr_, cg_, cb_)) {
+            L.sr = cr_ + L.sr; L.sg = cg_ + L.sg; L.sb = cb_ + L.sb;
         }
     }
 
     // ---- oneStepWalk ---------------------------------------------------------------------
-    float dirx, diry, pdf, alpha = 1.0f;
-    float cxp = px, cyp = py;
-    if (L.on_n) {
-        const float u = pcg_next_float(L.rng);
-        float lc, ls;
-        sincos_2pi(u * 0.5f, lc, ls);               // phi = pi * u
-        const float qx = -L.ny, qy = L.nx;          // frameFromNormal: T = -normalize(-n.y, n.x)
-        const float ql = sqrtf(dot2(qx, qy, qx, qy));
-        const float tx = -(qx / ql), ty = -(qy / ql);
-        dirx = tx * lc + L.nx * ls;
-        diry = ty * lc + L.ny * ls;
-        pdf = (float)(1.0 / 3.14159265358979323846);
-        alpha = 0.5f;
-        cxp += eps * L.nx;
-        cyp += eps * L.ny;
-    } else {
-        const float u = pcg_next_float(L.rng);
-        sincos_2pi(u, dirx, diry);
-        pdf = 1.0f / WOST_2PI;
-    }
-    float nxt_x = px + R_B * dirx, nxt_y = py + R_B * diry;
-    bool hit = false;
-    uint32_t hit_count = 0u;
-    float hnx = 0.0f, hny = 0.0f;
-    if (has_n) {
-        float t;
-        int hi;
-        hit = ray_closest<NEUMANN_TREE>(nm, cxp, cyp, dirx, diry, R_B, t, hi, stk);
-        if (hit) {
-            hnx = nm.flat[hi].nx;
-            hny = nm.flat[hi].ny;
-            if (dot2(hnx, hny, dirx, diry) > 0) { hnx = -hnx; hny = -hny; }
-            nxt_x = cxp + t * dirx;
-            nxt_y = cyp + t * diry;
-            hit_count = 1u;
-        }
-    }
+    float dirx, diry, pdf, alpha;
+    uniform_direction(L.on_n, L.nx, L.ny, L.rng, dirx, diry, pdf, alpha);
+    float nxt_x, nxt_y, hnx, hny;
+    const bool hit = walk_advance<NEUMANN_TREE>(nm, eps, px, py, R_B, L.on_n, L.nx, L.ny, dirx, diry, stk, nxt_x, nxt_y,
+                                                hnx, hny);
+    const uint32_t hit_count = hit ? 1u : 0u;
     // 1/pdf/alpha/2pi is exactly 1.0f in fp32 for both branches (tests/test_oracle_units.py),
     // so a unit throughput stays a unit throughput without three IEEE divisions
     if (L.thp != 1.0f) L.thp = L.thp / pdf / alpha / WOST_2PI;
@@ -649,6 +580,13 @@ struct wost_context {
     size_t spill_words = 0;
     int time_kernels = 1;
 };
+
+namespace wost {
+SceneView scene_view(wost_handle h)
+{
+    return SceneView{h->device, h->dm.view, h->nm.view, h->dst, h->probe, h->mask, h->stream};
+}
+}  // namespace wost
 
 static void carve_queue(void *mem, size_t n, WalkQueue &q)
 {

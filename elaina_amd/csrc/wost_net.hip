@@ -18,11 +18,10 @@
 #include <vector>
 
 #include "../../include/wost.h"
+#include "wost_internal.h"
 #include "wost_math.h"
 
 namespace wost {
-
-int set_error(int code, const std::string &msg);
 
 constexpr int kNetMaxLevels = 16;
 constexpr int kNetBlock = 64;
@@ -111,8 +110,10 @@ __device__ __forceinline__ void dense_layer(const float *W, int n_out, int n_in,
 // forward; out: n x n_out (unpadded).  acts (optional): n x (enc + n_hidden * n_neurons), the
 // activations the backward pass needs.
 __global__ __launch_bounds__(kNetBlock) void net_forward_kernel(NetLayout L, const float *params, const float *xy, int n,
-                                                                float *out, float *acts)
+                                                                const uint32_t *n_dev, float *out, float *acts)
 {
+    if (n_dev) n = (int)*n_dev;                              // queue size decided on the device
+    if ((int)(blockIdx.x * kNetBlock) >= n) return;
     extern __shared__ float lds[];
     float *col_a = lds + threadIdx.x;                       // ping
     float *col_b = lds + 64 * kNetBlock + threadIdx.x;      // pong (widths <= 64)
@@ -327,6 +328,75 @@ static void net_free(wost_net *h)
     delete h;
 }
 
+namespace wost {
+
+// ---- device-pointer entry points used by the guided integrator (wost_guided.hip) -----------
+int net_inference_dev(wost_net *h, const float *xy_dev, const uint32_t *count_dev, int max_n, float *out_dev,
+                      bool use_inference_params, hipStream_t stream)
+{
+    if (max_n <= 0) return WOST_OK;
+    const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
+    hipLaunchKernelGGL(net_forward_kernel, dim3((max_n + kNetBlock - 1) / kNetBlock), dim3(kNetBlock), lds, stream, h->L,
+                       use_inference_params ? h->inference : h->params, xy_dev, max_n, count_dev, out_dev, (float *)nullptr);
+    NET_TRY(hipGetLastError());
+    return WOST_OK;
+}
+
+// forward with the training parameters, keeping activations; *out_dev = raw outputs
+// (n x n_output), *dl_dev = where the caller writes dL/dout before net_backward_update_dev
+int net_forward_train_dev(wost_net *h, const float *xy_dev, int n, hipStream_t stream, float **out_dev, float **dl_dev)
+{
+    int rc = ensure_points(h, (size_t)n);
+    if (rc != WOST_OK) return rc;
+    const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
+    hipLaunchKernelGGL(net_forward_kernel, dim3((n + kNetBlock - 1) / kNetBlock), dim3(kNetBlock), lds, stream, h->L, h->params,
+                       xy_dev, n, (const uint32_t *)nullptr, h->d_out, h->d_acts);
+    NET_TRY(hipGetLastError());
+    *out_dev = h->d_out;
+    *dl_dev = h->d_dl;
+    return WOST_OK;
+}
+
+int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_scale, int apply_update, hipStream_t stream)
+{
+    const NetLayout &L = h->L;
+    NET_TRY(hipMemsetAsync(h->grad, 0, (size_t)h->n_params * sizeof(float), stream));
+    const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
+    const unsigned gridp = (unsigned)((n + kNetBlock - 1) / kNetBlock);
+    hipLaunchKernelGGL(net_backward_kernel, dim3(gridp), dim3(kNetBlock), lds, stream, L, h->params, xy_dev, h->d_dl, h->d_acts,
+                       n, h->d_deltas, h->grad);
+    NET_TRY(hipGetLastError());
+    const int astride = L.enc + L.n_hidden * L.n_neurons, dstride = L.n_out_padded + L.n_hidden * L.n_neurons;
+    const int chunk = 1024;
+    const unsigned gridc = (unsigned)((n + chunk - 1) / chunk);
+    const size_t lds_w = 2 * 32 * 64 * sizeof(float);
+    for (int layer = 0; layer <= L.n_hidden; ++layer) {
+        const int n_i = layer == 0 ? L.enc : L.n_neurons, n_o = layer == L.n_hidden ? L.n_out_padded : L.n_neurons;
+        const int doff = layer == L.n_hidden ? 0 : L.n_out_padded + layer * L.n_neurons;   // delta of this layer's output
+        const int ioff = layer == 0 ? 0 : L.enc + (layer - 1) * L.n_neurons;               // this layer's input
+        hipLaunchKernelGGL(weight_grad_kernel, dim3(gridc), dim3(256), lds_w, stream, h->d_deltas, dstride, doff, h->d_acts,
+                           astride, ioff, n_o, n_i, n, chunk, h->grad + L.w_off[layer]);
+    }
+    NET_TRY(hipGetLastError());
+    if (apply_update) {
+        h->step += 1;
+        const wost_net_config &c = h->cfg;
+        const float lr_t = c.learning_rate * std::sqrt(1.0f - std::pow(c.beta2, (float)h->step)) /
+                           (1.0f - std::pow(c.beta1, (float)h->step));
+        const float debias = 1.0f / (1.0f - std::pow(c.ema_decay, (float)h->step));
+        hipLaunchKernelGGL(optimizer_kernel, dim3((h->n_params + 255) / 256), dim3(256), 0, stream, h->n_params, h->params,
+                           h->m1, h->m2, h->ema_raw, h->inference, h->grad, lr_t, c.beta1, c.beta2, c.epsilon, c.l2_reg,
+                           c.ema_decay, debias, loss_scale);
+        NET_TRY(hipGetLastError());
+    }
+    return WOST_OK;
+}
+
+int net_optimizer_steps(const wost_net *h) { return h->step; }
+int net_n_output(const wost_net *h) { return h->L.n_out; }
+
+}  // namespace wost
+
 extern "C" {
 
 int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_net_handle *out)
@@ -429,7 +499,8 @@ int wost_net_inference(wost_net_handle h, const float *xy, int32_t n, float *out
     NET_TRY(hipMemcpy(h->d_xy, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice));
     const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
     hipLaunchKernelGGL(net_forward_kernel, dim3((n + kNetBlock - 1) / kNetBlock), dim3(kNetBlock), lds, 0, h->L,
-                       use_inference_params ? h->inference : h->params, h->d_xy, n, h->d_out, (float *)nullptr);
+                       use_inference_params ? h->inference : h->params, h->d_xy, n, (const uint32_t *)nullptr, h->d_out,
+                       (float *)nullptr);
     NET_TRY(hipGetLastError());
     NET_TRY(hipMemcpy(out, h->d_out, (size_t)n * h->L.n_out * sizeof(float), hipMemcpyDeviceToHost));
     return WOST_OK;
@@ -442,40 +513,13 @@ int wost_net_train_step(wost_net_handle h, const float *xy, const float *dl_dout
     NET_TRY(hipSetDevice(h->device));
     int rc = ensure_points(h, (size_t)n);
     if (rc != WOST_OK) return rc;
-    const NetLayout &L = h->L;
     NET_TRY(hipMemcpy(h->d_xy, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice));
-    NET_TRY(hipMemcpy(h->d_dl, dl_dout, (size_t)n * L.n_out * sizeof(float), hipMemcpyHostToDevice));
-    NET_TRY(hipMemset(h->grad, 0, (size_t)h->n_params * sizeof(float)));
-    const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
-    const unsigned gridp = (unsigned)((n + kNetBlock - 1) / kNetBlock);
-    hipLaunchKernelGGL(net_forward_kernel, dim3(gridp), dim3(kNetBlock), lds, 0, L, h->params, h->d_xy, n, h->d_out,
-                       h->d_acts);
-    hipLaunchKernelGGL(net_backward_kernel, dim3(gridp), dim3(kNetBlock), lds, 0, L, h->params, h->d_xy, h->d_dl, h->d_acts,
-                       n, h->d_deltas, h->grad);
-    NET_TRY(hipGetLastError());
-    const int astride = L.enc + L.n_hidden * L.n_neurons, dstride = L.n_out_padded + L.n_hidden * L.n_neurons;
-    const int chunk = 1024;
-    const unsigned gridc = (unsigned)((n + chunk - 1) / chunk);
-    const size_t lds_w = 2 * 32 * 64 * sizeof(float);
-    for (int layer = 0; layer <= L.n_hidden; ++layer) {
-        const int n_i = layer == 0 ? L.enc : L.n_neurons, n_o = layer == L.n_hidden ? L.n_out_padded : L.n_neurons;
-        const int doff = layer == L.n_hidden ? 0 : L.n_out_padded + layer * L.n_neurons;   // delta of this layer's output
-        const int ioff = layer == 0 ? 0 : L.enc + (layer - 1) * L.n_neurons;               // this layer's input
-        hipLaunchKernelGGL(weight_grad_kernel, dim3(gridc), dim3(256), lds_w, 0, h->d_deltas, dstride, doff, h->d_acts, astride,
-                           ioff, n_o, n_i, n, chunk, h->grad + L.w_off[layer]);
-    }
-    NET_TRY(hipGetLastError());
-    if (apply_update) {
-        h->step += 1;
-        const wost_net_config &c = h->cfg;
-        const float lr_t = c.learning_rate * std::sqrt(1.0f - std::pow(c.beta2, (float)h->step)) /
-                           (1.0f - std::pow(c.beta1, (float)h->step));
-        const float debias = 1.0f / (1.0f - std::pow(c.ema_decay, (float)h->step));
-        hipLaunchKernelGGL(optimizer_kernel, dim3((h->n_params + 255) / 256), dim3(256), 0, 0, h->n_params, h->params, h->m1,
-                           h->m2, h->ema_raw, h->inference, h->grad, lr_t, c.beta1, c.beta2, c.epsilon, c.l2_reg, c.ema_decay,
-                           debias, loss_scale);
-        NET_TRY(hipGetLastError());
-    }
+    float *out = nullptr, *dl = nullptr;
+    rc = wost::net_forward_train_dev(h, h->d_xy, n, nullptr, &out, &dl);
+    if (rc != WOST_OK) return rc;
+    NET_TRY(hipMemcpy(dl, dl_dout, (size_t)n * h->L.n_out * sizeof(float), hipMemcpyHostToDevice));
+    rc = wost::net_backward_update_dev(h, h->d_xy, n, loss_scale, apply_update, nullptr);
+    if (rc != WOST_OK) return rc;
     NET_TRY(hipDeviceSynchronize());
     return WOST_OK;
 }

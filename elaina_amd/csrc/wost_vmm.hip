@@ -11,113 +11,11 @@
 #include <vector>
 
 #include "../../include/wost.h"
+#include "wost_internal.h"
 #include "wost_math.h"
+#include "wost_vmm_device.h"
 
 namespace wost {
-
-int set_error(int code, const std::string &msg);
-
-__constant__ float VM_COEF_SMALL[2][7] = {
-    {1.0f, 3.5156229f, 3.0899424f, 1.2067492f, 0.2659732f, 0.360768e-1f, 0.45813e-2f},
-    {0.5f, 0.87890594f, 0.51498869f, 0.15084934f, 0.2658733e-1f, 0.301532e-2f, 0.32411e-3f}};
-__constant__ float VM_COEF_LARGE[2][9] = {
-    {0.39894228f, 0.1328592e-1f, 0.225319e-2f, -0.157565e-2f, 0.916281e-2f, -0.2057706e-1f, 0.2635537e-1f,
-     -0.1647633e-1f, 0.392377e-2f},
-    {0.39894228f, -0.3988024e-1f, -0.362018e-2f, 0.163801e-2f, -0.1031555e-1f, 0.2282967e-1f, -0.2895312e-1f,
-     0.1787654e-1f, -0.420059e-2f}};
-
-#define VM_2PI 6.28318530717958647693f
-#define VM_PI_D 3.14159265358979323846
-
-__device__ __forceinline__ float eval_poly(float y, const float *coeff, int n)
-{
-    float ret = coeff[n - 1];
-    for (int i = n - 2; i >= 0; --i) ret = coeff[i] + y * ret;
-    return ret;
-}
-
-__device__ __forceinline__ float log_bessel(float x, int order)
-{
-    float y = x / 3.75f;
-    y *= y;
-    float small = eval_poly(y, VM_COEF_SMALL[order], 7);
-    if (order == 1) small = fabsf(x) * small;
-    small = logf(small);
-    y = 3.75f / x;
-    const float large = x - 0.5f * logf(x) + logf(eval_poly(y, VM_COEF_LARGE[order], 9));
-    return (x < 3.75f) ? small : large;
-}
-
-__device__ __forceinline__ float vm_log_eval(float kappa, float cos_theta)
-{
-    const float ret = kappa * cos_theta;
-    return ret - logf(VM_2PI) - log_bessel(kappa, 0);
-}
-
-__device__ __forceinline__ float vm_eval(float kappa, float cos_theta)
-{
-    if (kappa < 1e-3f) return 1.0f / VM_2PI;
-    return expf(vm_log_eval(kappa, cos_theta));
-}
-
-__device__ __forceinline__ float vm_dlog_dkappa(float kappa, float cosTheta)
-{
-    if (kappa < 3.75f) {
-        const float *coeff = VM_COEF_SMALL[0];
-        const float coef = 0.0711111111111111f, c142 = 0.142222222222222f, c010 = 0.0101135802469136f;
-        const float kappa2 = kappa * kappa;
-        const float term7 = coeff[6] * kappa2;
-        const float term6 = coeff[5] + coef * term7;
-        const float term5 = coeff[4] + coef * kappa2 * term6;
-        const float term4 = coeff[3] + coef * kappa2 * term5;
-        const float term3 = coeff[2] + coef * kappa2 * term4;
-        const float term2 = coeff[1] + coef * kappa2 * term3;
-        const float numerator = coef * kappa2 * (coef * kappa2 * (coef * kappa2 * (coef * kappa2 * (c010 * coeff[6] * kappa * kappa2 + c142 * kappa * term6) + c142 * kappa * term5) + c142 * kappa * term4) + c142 * kappa * term3) + c142 * kappa * term2;
-        const float denominator = coeff[0] + coef * kappa2 * term2;
-        return cosTheta - (numerator / denominator);
-    }
-    // large-argument branch: d/dx [x - log(x)/2 + log P(3.75/x)], evaluated in double like the
-    // reference's spelled-out expression (its 3.75 literals are doubles)
-    const float *K = VM_COEF_LARGE[0];
-    const double x = kappa, t = 3.75 / x;
-    double P = 0.0, dP = 0.0;
-    for (int i = 8; i >= 0; --i) P = K[i] + t * P;
-    for (int i = 8; i >= 1; --i) dP = i * (double)K[i] + t * dP;
-    dP *= -(t / x);
-    return (float)(cosTheta - 1.0 - dP / P + 0.5 / x);
-}
-
-__device__ __forceinline__ double vm_proposal_r(float kappa)
-{
-    const double k = kappa;
-    const double tau = 1.0 + sqrt(1.0 + 4.0 * k * k);
-    const double rho = (tau - sqrt(2.0 * tau)) / (2.0 * k);
-    const double proposalR = (1.0 + rho * rho) / (2.0 * rho);
-    const double proposalRTaylor = 1.0 / k + k;
-    return (kappa < 1e-5) ? proposalRTaylor : proposalR;
-}
-
-__device__ __forceinline__ double pcg_next_double(Pcg &r)
-{
-    // reference core/sampler.h:74-85
-    const uint64_t u = ((uint64_t)pcg_next_uint(r) << 20) | 0x3ff0000000000000ULL;
-    return __longlong_as_double((long long)u) - 1.0;
-}
-
-__device__ __forceinline__ float vm_rejection_sample(float kappa, double proposal_r, Pcg &rng)
-{
-    if (kappa < 1e-3f) return VM_2PI * pcg_next_float(rng);
-    for (;;) {
-        const double u1 = pcg_next_double(rng);
-        const double u2 = pcg_next_double(rng);
-        const double u3 = pcg_next_double(rng);
-        const double z = cos(VM_PI_D * u1);
-        const double f = (1.0 + proposal_r * z) / (proposal_r + z);
-        const double c = (double)kappa * (proposal_r - f);
-        const bool accept = ((c * (2.0 - c) - u2) > 0.0) || (log(c / u2) + 1.0 - c >= 0.0);
-        if (accept) return (float)(fmod((copysign(1.0, u3 - 0.5) * acos(f)) + VM_PI_D, 2 * VM_PI_D) - VM_PI_D);
-    }
-}
 
 __global__ void vonmises_eval_kernel(const float *kappa, const float *cos_theta, int n, float *log_i0, float *log_i1,
                                      float *log_pdf, float *dlog)
@@ -140,53 +38,19 @@ __global__ void vonmises_sample_kernel(const float *kappa, const uint64_t *seed,
     for (int k = 0; k < per_point; ++k) theta[(size_t)i * per_point + k] = vm_rejection_sample(kappa[i], pr, rng);
 }
 
-// VMM<2,8>: lambda = exp(clamp(x,-10,15)), kappa likewise, mu = normalize(x,y), weights lambda/sum
+// VMM<2,8> pdf and one sample per point (stream setSeed(seed, 1))
 __global__ void vmm_pdf_sample_kernel(const float *raw, const float *wi, const uint64_t *seed, int n, float *pdf,
                                       float *dir)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float *d = raw + 32 * (size_t)i;
-    float lambda[8], kap[8], mux[8], muy[8];
-    float total = 0.0f;
-    for (int k = 0; k < 8; ++k) {
-        lambda[k] = expf(fmaxf(fminf(d[4 * k], 15.0f), -10.0f));
-        kap[k] = expf(fmaxf(fminf(d[4 * k + 1], 15.0f), -10.0f));
-        const float x = d[4 * k + 2], y = d[4 * k + 3];
-        const float nn = sqrtf(x * x + y * y);
-        mux[k] = x / nn;
-        muy[k] = y / nn;
-        total += lambda[k];
-    }
-    if (pdf) {
-        const float wx = wi[2 * i], wy = wi[2 * i + 1];
-        float val = 0.0f;
-        for (int k = 0; k < 8; ++k) val += (lambda[k] / total) * vm_eval(kap[k], wx * mux[k] + wy * muy[k]);
-        pdf[i] = val;
-    }
+    Vmm m;
+    m.build(raw + 32 * (size_t)i);
+    if (pdf) pdf[i] = m.pdf(wi[2 * i], wi[2 * i + 1]);
     if (dir) {
         Pcg rng;
         pcg_set_seed(rng, seed[i], 1);
-        float u = pcg_next_float(rng);
-        int pick = 0;
-        bool found = false;
-        for (int k = 0; k < 8; ++k) {
-            const float w = lambda[k] / total;
-            if (!found) {
-                if (u < w) { pick = k; found = true; }
-                else u -= w;
-            }
-        }
-        float pk = kap[0], pmx = mux[0], pmy = muy[0];
-        for (int k = 1; k < 8; ++k)
-            if (k == pick) { pk = kap[k]; pmx = mux[k]; pmy = muy[k]; }
-        const float theta = vm_rejection_sample(pk, vm_proposal_r(pk), rng);
-        const float vx = cosf(theta), vy = sinf(theta);
-        float px = -pmy, py = pmx;   // frameFromTangent(mu): N = normalize(-mu.y, mu.x), T = mu
-        const float pl = sqrtf(px * px + py * py);
-        px /= pl; py /= pl;
-        dir[2 * i] = pmx * vx + px * vy;
-        dir[2 * i + 1] = pmy * vx + py * vy;
+        m.sample(rng, dir[2 * i], dir[2 * i + 1]);
     }
 }
 
@@ -268,6 +132,15 @@ __global__ void vmm_loss_gradients_kernel(const float *raw, const float *dir, co
     const float uni = on_n ? (float)(1.0 / VM_PI_D) : 1.0f / VM_2PI;
     const float sgm = 1.0f / (1.0f + expf(-d[32]));
     grad[32] = scale * (-0.2f) * Li * (guidePdf - uni) / (dirPdf * dirPdf) * (sgm * (1 - sgm));
+}
+
+void launch_vmm_loss_gradients(hipStream_t stream, const float *raw, const float *dir, const float *li,
+                               const float *dir_pdf, const uint8_t *on_neumann, const float *normal, int n,
+                               float loss_scale, float *dl_draw, float *likelihood)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(vmm_loss_gradients_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, raw, dir, li, dir_pdf,
+                       on_neumann, normal, n, loss_scale, dl_draw, likelihood);
 }
 
 struct DevBufs {

@@ -1,0 +1,175 @@
+// wost_vmm_device.h -- device functions of the guided path's directional distribution
+// (SURVEY.md 8a row a24): polynomial log-Bessel, von Mises pdf and d/dkappa (reference
+// util/vonmises.h:17-93,121-172), Best-Fisher rejection sampling in double precision (:95-118)
+// and the 8-lobe mixture VMM<2,8> built from raw network outputs
+// (integrator/guided/distribution.h:136-198, train.h:50-79).  Shared by the batch entry points
+// (wost_vmm.hip) and the guided integrator kernels (wost_guided.hip).  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "wost_math.h"
+
+namespace wost {
+
+static __constant__ float VM_COEF_SMALL[2][7] = {
+    {1.0f, 3.5156229f, 3.0899424f, 1.2067492f, 0.2659732f, 0.360768e-1f, 0.45813e-2f},
+    {0.5f, 0.87890594f, 0.51498869f, 0.15084934f, 0.2658733e-1f, 0.301532e-2f, 0.32411e-3f}};
+static __constant__ float VM_COEF_LARGE[2][9] = {
+    {0.39894228f, 0.1328592e-1f, 0.225319e-2f, -0.157565e-2f, 0.916281e-2f, -0.2057706e-1f, 0.2635537e-1f,
+     -0.1647633e-1f, 0.392377e-2f},
+    {0.39894228f, -0.3988024e-1f, -0.362018e-2f, 0.163801e-2f, -0.1031555e-1f, 0.2282967e-1f, -0.2895312e-1f,
+     0.1787654e-1f, -0.420059e-2f}};
+
+#define VM_2PI 6.28318530717958647693f
+#define VM_PI_D 3.14159265358979323846
+
+__device__ __forceinline__ float eval_poly(float y, const float *coeff, int n)
+{
+    float ret = coeff[n - 1];
+    for (int i = n - 2; i >= 0; --i) ret = coeff[i] + y * ret;
+    return ret;
+}
+
+__device__ __forceinline__ float log_bessel(float x, int order)
+{
+    float y = x / 3.75f;
+    y *= y;
+    float small = eval_poly(y, VM_COEF_SMALL[order], 7);
+    if (order == 1) small = fabsf(x) * small;
+    small = logf(small);
+    y = 3.75f / x;
+    const float large = x - 0.5f * logf(x) + logf(eval_poly(y, VM_COEF_LARGE[order], 9));
+    return (x < 3.75f) ? small : large;
+}
+
+__device__ __forceinline__ float vm_log_eval(float kappa, float cos_theta)
+{
+    const float ret = kappa * cos_theta;
+    return ret - logf(VM_2PI) - log_bessel(kappa, 0);
+}
+
+__device__ __forceinline__ float vm_eval(float kappa, float cos_theta)
+{
+    if (kappa < 1e-3f) return 1.0f / VM_2PI;
+    return expf(vm_log_eval(kappa, cos_theta));
+}
+
+__device__ __forceinline__ float vm_dlog_dkappa(float kappa, float cosTheta)
+{
+    if (kappa < 3.75f) {
+        const float *coeff = VM_COEF_SMALL[0];
+        const float coef = 0.0711111111111111f, c142 = 0.142222222222222f, c010 = 0.0101135802469136f;
+        const float kappa2 = kappa * kappa;
+        const float term7 = coeff[6] * kappa2;
+        const float term6 = coeff[5] + coef * term7;
+        const float term5 = coeff[4] + coef * kappa2 * term6;
+        const float term4 = coeff[3] + coef * kappa2 * term5;
+        const float term3 = coeff[2] + coef * kappa2 * term4;
+        const float term2 = coeff[1] + coef * kappa2 * term3;
+        const float numerator = coef * kappa2 * (coef * kappa2 * (coef * kappa2 * (coef * kappa2 * (c010 * coeff[6] * kappa * kappa2 + c142 * kappa * term6) + c142 * kappa * term5) + c142 * kappa * term4) + c142 * kappa * term3) + c142 * kappa * term2;
+        const float denominator = coeff[0] + coef * kappa2 * term2;
+        return cosTheta - (numerator / denominator);
+    }
+    // large-argument branch: d/dx [x - log(x)/2 + log P(3.75/x)], evaluated in double like the
+    // reference's spelled-out expression (its 3.75 literals are doubles)
+    const float *K = VM_COEF_LARGE[0];
+    const double x = kappa, t = 3.75 / x;
+    double P = 0.0, dP = 0.0;
+    for (int i = 8; i >= 0; --i) P = K[i] + t * P;
+    for (int i = 8; i >= 1; --i) dP = i * (double)K[i] + t * dP;
+    dP *= -(t / x);
+    return (float)(cosTheta - 1.0 - dP / P + 0.5 / x);
+}
+
+__device__ __forceinline__ double vm_proposal_r(float kappa)
+{
+    const double k = kappa;
+    const double tau = 1.0 + sqrt(1.0 + 4.0 * k * k);
+    const double rho = (tau - sqrt(2.0 * tau)) / (2.0 * k);
+    const double proposalR = (1.0 + rho * rho) / (2.0 * rho);
+    const double proposalRTaylor = 1.0 / k + k;
+    return (kappa < 1e-5) ? proposalRTaylor : proposalR;
+}
+
+__device__ __forceinline__ double pcg_next_double(Pcg &r)
+{
+    // reference core/sampler.h:74-85
+    const uint64_t u = ((uint64_t)pcg_next_uint(r) << 20) | 0x3ff0000000000000ULL;
+    return __longlong_as_double((long long)u) - 1.0;
+}
+
+__device__ __forceinline__ float vm_rejection_sample(float kappa, double proposal_r, Pcg &rng)
+{
+    if (kappa < 1e-3f) return VM_2PI * pcg_next_float(rng);
+    for (;;) {
+        const double u1 = pcg_next_double(rng);
+        const double u2 = pcg_next_double(rng);
+        const double u3 = pcg_next_double(rng);
+        const double z = cos(VM_PI_D * u1);
+        const double f = (1.0 + proposal_r * z) / (proposal_r + z);
+        const double c = (double)kappa * (proposal_r - f);
+        const bool accept = ((c * (2.0 - c) - u2) > 0.0) || (log(c / u2) + 1.0 - c >= 0.0);
+        if (accept) return (float)(fmod((copysign(1.0, u3 - 0.5) * acos(f)) + VM_PI_D, 2 * VM_PI_D) - VM_PI_D);
+    }
+}
+
+// VMM<2,8>: lambda = exp(clamp(x,-10,15)), kappa likewise, mu = normalize(x,y), weights lambda/sum
+struct Vmm {
+    float weight[8], kap[8], mux[8], muy[8];
+
+    __device__ __forceinline__ void build(const float *d)
+    {
+        float lambda[8];
+        float total = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            lambda[k] = expf(fmaxf(fminf(d[4 * k], 15.0f), -10.0f));
+            kap[k] = expf(fmaxf(fminf(d[4 * k + 1], 15.0f), -10.0f));
+            const float x = d[4 * k + 2], y = d[4 * k + 3];
+            const float nn = sqrtf(x * x + y * y);
+            mux[k] = x / nn;
+            muy[k] = y / nn;
+            total += lambda[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) weight[k] = lambda[k] / total;
+    }
+
+    __device__ __forceinline__ float pdf(float wx, float wy) const
+    {
+        float val = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) val += weight[k] * vm_eval(kap[k], wx * mux[k] + wy * muy[k]);
+        return val;
+    }
+
+    // VMM::sample (distribution.h:186-198): lobe picked by one float draw, then the lobe's
+    // rejection sampler, rotated into the frame whose tangent is mu
+    __device__ __forceinline__ void sample(Pcg &rng, float &ox, float &oy) const
+    {
+        float u = pcg_next_float(rng);
+        int pick = 0;
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (!found) {
+                if (u < weight[k]) { pick = k; found = true; }
+                else u -= weight[k];
+            }
+        }
+        float pk = kap[0], pmx = mux[0], pmy = muy[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (k == pick) { pk = kap[k]; pmx = mux[k]; pmy = muy[k]; }
+        const float theta = vm_rejection_sample(pk, vm_proposal_r(pk), rng);
+        const float vx = cosf(theta), vy = sinf(theta);
+        float px = -pmy, py = pmx;   // frameFromTangent(mu): N = normalize(-mu.y, mu.x), T = mu
+        const float pl = sqrtf(px * px + py * py);
+        px /= pl; py /= pl;
+        ox = pmx * vx + px * vy;
+        oy = pmy * vx + py * vy;
+    }
+};
+
+}  // namespace wost

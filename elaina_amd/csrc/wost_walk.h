@@ -1,0 +1,113 @@
+// wost_walk.h -- the pieces of one walk step that the uniform round kernel (wost_hip.hip) and
+// the guided wavefront kernels (wost_guided.hip) share: Neumann boundary sampling, the uniform
+// star-region direction, and the boundary intersection that advances the walker.  Device code
+// for gfx950, all __forceinline__: each kernel gets its own specialised copy.
+#pragma once
+
+#include "wost_device.h"
+
+namespace wost {
+
+// sampleNeumann (reference integrator/uniform/integrator.cu:336-444, guided/integrator.cu:
+// 384-493): two draws from the pixel's stream whether or not the boundary emits (:343-347),
+// object sampling in the ball, visibility, Green's-function weight.  Returns true when the
+// sample contributes; (cr, cg, cb) is then the term to ADD to the solution (already negated).
+template <bool EMISSIVE, bool TREE, class STK>
+__device__ __forceinline__ bool neumann_sample(const DevMesh &nm, float neumann_intensity, float eps, float px, float py,
+                                               float R_B, bool on_n, float nx, float ny, float thp, Pcg &rng,
+                                               const STK &stk, float &cr, float &cg, float &cb)
+{
+    if (!EMISSIVE) {
+        pcg_skip2(rng);
+        return false;
+    }
+    const float u0 = pcg_next_float(rng);
+    const float u1 = pcg_next_float(rng);
+    float pdf;
+    const int oi = sample_in_sphere_flat(nm, px, py, R_B, u0, pdf);
+    if (!(oi != -1 && pdf > 0)) return false;
+    const DevFlatSeg so = nm.flat[oi];
+    const float spx = __builtin_fmaf(u1, so.ex, so.ax), spy = __builtin_fmaf(u1, so.ey, so.ay);
+    const float rx = spx - px, ry = spy - py;
+    const float r = sqrtf(dot2(rx, ry, rx, ry));
+    if (!(r < R_B && r > 0)) return false;
+    float ox = px, oy = py;
+    if (on_n) { ox += eps * nx; oy += eps * ny; }
+    float dx = spx - ox, dy = spy - oy;
+    const float cd = sqrtf(dot2(dx, dy, dx, dy));
+    if (cd > 0) { dx /= cd; dy /= cd; }
+    if (ray_any<TREE>(nm, ox, oy, dx, dy, cd - eps, stk)) return false;
+    const float crs = cross2(so.ex, so.ey, px - so.ax, py - so.ay);
+    int side = (0.0f < crs) - (crs < 0.0f);
+    const float uv = dot2(spx - so.ax, spy - so.ay, so.ex, so.ey) * so.inv_len2;
+    if (on_n) {
+        const float dn = dot2(so.nx, so.ny, nx, ny);
+        side = (0.0f < dn) - (dn < 0.0f);
+    }
+    if (side == 0) return false;
+    surface_color(nm.flatCol + 12 * (size_t)oi, side, uv, cr, cg, cb);
+    const float alpha = on_n ? 0.5f : 1.0f;
+    const float G = det_logf(R_B / r) / WOST_2PI;
+    const float w = thp * G / alpha / pdf;
+    cr *= neumann_intensity; cg *= neumann_intensity; cb *= neumann_intensity;
+    cr *= w; cg *= w; cb *= w;
+    cr = -cr; cg = -cg; cb = -cb;
+    return true;
+}
+
+// uniformSampleSphere<2> / uniformSampleHemisphere<2> in the frame of the Neumann normal
+// (util/sampling.h:29-33,80-85, util/transformation.h:30-55): one draw.
+__device__ __forceinline__ void uniform_direction(bool on_n, float nx, float ny, Pcg &rng, float &dirx, float &diry,
+                                                  float &pdf, float &alpha)
+{
+    const float u = pcg_next_float(rng);
+    if (on_n) {
+        float lc, ls;
+        sincos_2pi(u * 0.5f, lc, ls);               // phi = pi * u
+        const float qx = -ny, qy = nx;              // frameFromNormal: T = -normalize(-n.y, n.x)
+        const float ql = sqrtf(dot2(qx, qy, qx, qy));
+        const float tx = -(qx / ql), ty = -(qy / ql);
+        dirx = tx * lc + nx * ls;
+        diry = ty * lc + ny * ls;
+        pdf = (float)(1.0 / 3.14159265358979323846);
+        alpha = 0.5f;
+    } else {
+        sincos_2pi(u, dirx, diry);
+        pdf = 1.0f / WOST_2PI;
+        alpha = 1.0f;
+    }
+}
+
+// The tail of oneStepWalk (integrator/uniform/integrator.cu:479-513): move R_B along the
+// direction, or to the first Neumann hit of the ray started at x (+ eps n on the boundary).
+template <bool TREE, class STK>
+__device__ __forceinline__ bool walk_advance(const DevMesh &nm, float eps, float px, float py, float R_B, bool on_n,
+                                             float nx, float ny, float dirx, float diry, const STK &stk, float &nxt_x,
+                                             float &nxt_y, float &hnx, float &hny)
+{
+    float cxp = px, cyp = py;
+    if (on_n) {
+        cxp += eps * nx;
+        cyp += eps * ny;
+    }
+    nxt_x = px + R_B * dirx;
+    nxt_y = py + R_B * diry;
+    hnx = 0.0f;
+    hny = 0.0f;
+    bool hit = false;
+    if (nm.n_segs > 0) {
+        float t;
+        int hi;
+        hit = ray_closest<TREE>(nm, cxp, cyp, dirx, diry, R_B, t, hi, stk);
+        if (hit) {
+            hnx = nm.flat[hi].nx;
+            hny = nm.flat[hi].ny;
+            if (dot2(hnx, hny, dirx, diry) > 0) { hnx = -hnx; hny = -hny; }
+            nxt_x = cxp + t * dirx;
+            nxt_y = cyp + t * diry;
+        }
+    }
+    return hit;
+}
+
+}  // namespace wost

@@ -124,3 +124,124 @@ class GuidingNetwork:
         g = np.ascontiguousarray(dl_dout, dtype=np.float32).reshape(len(x), self.config.n_output)
         _check(self._lib.wost_net_train_step(self._h, _fp(x), _fp(g), len(x), loss_scale, int(apply_update)),
                "wost_net_train_step")
+
+
+class GuidedIntegratorSettings:
+    """reference integrator/guided/integrator.h:54-75; the trailing group exposes the reference's
+    compile-time training constants (parameters.h:7-14, integrator.h:237-239)"""
+
+    def __init__(self, frameSize=(800, 800), samplesPerPixel=512, trainSppCount=150,
+                 uniformFractionInTrainingPhase=0.5, uniformFractionInGuidingPhase=0.5,
+                 maxGuidedDepthInTrainingPhase=10, maxGuidedDepthInGuidingPhase=10, maxWalkingDepth=32,
+                 epsilonShell=1e-5, debugPixel=0, saveSppMetricsDuration=-1, saveSppMetricsUntil=1024,
+                 saveTimeMetricsDuration=-1,
+                 maxTrainDepth=3, batchSize=524288, minBatchSize=65536, batchPerFrame=5, trainPixelStride=1,
+                 trainPixelOffset=0, lossScale=128.0):
+        self.frameSize = (int(frameSize[0]), int(frameSize[1]))
+        self.samplesPerPixel = int(samplesPerPixel)
+        self.trainSppCount = int(trainSppCount)
+        self.uniformFractionInTrainingPhase = float(uniformFractionInTrainingPhase)
+        self.uniformFractionInGuidingPhase = float(uniformFractionInGuidingPhase)
+        self.maxGuidedDepthInTrainingPhase = int(maxGuidedDepthInTrainingPhase)
+        self.maxGuidedDepthInGuidingPhase = int(maxGuidedDepthInGuidingPhase)
+        self.maxWalkingDepth = int(maxWalkingDepth)
+        self.epsilonShell = float(epsilonShell)
+        self.debugPixel = debugPixel
+        self.saveSppMetricsDuration = saveSppMetricsDuration
+        self.saveSppMetricsUntil = saveSppMetricsUntil
+        self.saveTimeMetricsDuration = saveTimeMetricsDuration
+        self.maxTrainDepth, self.batchSize, self.minBatchSize = int(maxTrainDepth), int(batchSize), int(minBatchSize)
+        self.batchPerFrame, self.trainPixelStride, self.trainPixelOffset = int(batchPerFrame), int(trainPixelStride), int(trainPixelOffset)
+        self.lossScale = float(lossScale)
+
+
+class _BorrowedNetwork(GuidingNetwork):
+    """the integrator's own network: same methods, lifetime owned by the integrator"""
+
+    def __init__(self, lib, handle, config):
+        self._lib, self._h, self.config = lib, handle, config
+        total, mlp = C.c_uint64(), C.c_uint64()
+        _check(lib.wost_net_n_params(handle, C.byref(total), C.byref(mlp)), "wost_net_n_params")
+        self.n_params, self.n_mlp_params = total.value, mlp.value
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+class GuidedIntegrator:
+    """Mirror of GuidedIntegrator<2> (reference integrator/guided/integrator.h:77-256): ctor +
+    resetNetwork, solve(), queryNetwork(); `aabb` is scene.aabb of the JSON configuration."""
+
+    def __init__(self, problem, settings, aabb, network_config=None, seed=42, device=0):
+        from .integrator import scene_desc
+        self.lib = capi.load()
+        self.problem, self.settings = problem, settings
+        keep = []
+        w, h = settings.frameSize
+        sc = scene_desc(keep, problem, w, h)
+        gs = capi.GuidedSettings(w, h, settings.samplesPerPixel, settings.maxWalkingDepth, settings.epsilonShell,
+                                 settings.trainSppCount, settings.uniformFractionInTrainingPhase,
+                                 settings.uniformFractionInGuidingPhase, settings.maxGuidedDepthInTrainingPhase,
+                                 settings.maxGuidedDepthInGuidingPhase)
+        (gs.aabb_min[0], gs.aabb_min[1]), (gs.aabb_max[0], gs.aabb_max[1]) = aabb
+        gs.max_train_depth, gs.batch_size, gs.min_batch_size = settings.maxTrainDepth, settings.batchSize, settings.minBatchSize
+        gs.batches_per_spp, gs.train_pixel_stride = settings.batchPerFrame, settings.trainPixelStride
+        gs.train_pixel_offset, gs.loss_scale = settings.trainPixelOffset, settings.lossScale
+        self.network_config = network_config or default_net_config()
+        self._handle = C.c_void_p()
+        _check(self.lib.wost_guided_create(C.byref(sc), C.byref(gs), C.byref(self.network_config), seed, device,
+                                           C.byref(self._handle)), "wost_guided_create")
+        nh = C.c_void_p()
+        _check(self.lib.wost_guided_network(self._handle, C.byref(nh)), "wost_guided_network")
+        self.network = _BorrowedNetwork(self.lib, nh, self.network_config)
+        self.n_pixels = w * h
+        self.aabb = aabb
+        self.solution = None
+        self.last_stats = None
+
+    def close(self):
+        if self._handle:
+            self.network.close()
+            self.lib.wost_guided_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self):
+        """returns wall milliseconds like the reference; the field is in self.solution"""
+        field = np.zeros((self.n_pixels, 3), dtype=np.float32)
+        st = capi.GuidedStats()
+        _check(self.lib.wost_guided_solve(self._handle, _fp(field), C.byref(st)), "wost_guided_solve")
+        self.solution = field
+        self.last_stats = st.as_dict()
+        return int(st.solve_ms)
+
+    def train_set(self):
+        """training set of the most recent training pass, (pixel, record) order"""
+        n = C.c_int32()
+        _check(self.lib.wost_guided_train_set(self._handle, 0, C.byref(n), None, None, None, None, None, None),
+               "wost_guided_train_set")
+        m = n.value
+        out = {"xy": np.zeros((m, 2), np.float32), "dir": np.zeros((m, 2), np.float32),
+               "solution": np.zeros((m, 3), np.float32), "dir_pdf": np.zeros(m, np.float32),
+               "normal": np.zeros((m, 2), np.float32), "on_neumann": np.zeros(m, np.uint8)}
+        if m:
+            _check(self.lib.wost_guided_train_set(self._handle, m, C.byref(n), _fp(out["xy"]), _fp(out["dir"]),
+                                                  _fp(out["solution"]), _fp(out["dir_pdf"]), _fp(out["normal"]),
+                                                  out["on_neumann"].ctypes.data_as(C.POINTER(C.c_uint8))),
+                   "wost_guided_train_set")
+        return out
+
+    def queryNetwork(self, p):
+        """raw mixture parameters of the guiding network at world position p (reference
+        integrator.cu:566-615 prints the VMM built from them)"""
+        (lo, hi) = self.aabb
+        lo, hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
+        infl = np.float32(np.sqrt(np.sum((hi - lo) ** 2, dtype=np.float32))) * np.float32(0.005)
+        lo2, hi2 = lo - infl, hi + infl
+        xy = np.float32(0.5) + (np.asarray(p, np.float32) - (lo2 + hi2) / np.float32(2)) / (hi2 - lo2)
+        return self.network.inference(xy.reshape(1, 2))[0]

@@ -40,6 +40,24 @@ def _mesh_desc(keep, verts, segs, colors):
     return m
 
 
+def scene_desc(keep, problem, w, h):
+    """wost_scene_desc of a Problem; `keep` collects the arrays the descriptor points into"""
+    sc = SceneDesc()
+    sc.dirichlet = _mesh_desc(keep, problem.d_verts, problem.d_segs, problem.d_colors)
+    sc.neumann = _mesh_desc(keep, problem.n_verts, problem.n_segs, problem.n_colors)
+    sc.dirichlet_intensity = problem.dirichlet_intensity
+    sc.neumann_intensity = problem.neumann_intensity
+    sc.probe_scale = float(problem.probe[0])
+    sc.probe_pos[0], sc.probe_pos[1] = float(problem.probe[1]), float(problem.probe[2])
+    sc.probe_up[0], sc.probe_up[1] = float(problem.probe[3]), float(problem.probe[4])
+    if problem.mask is not None:
+        if problem.mask.size != w * h:
+            raise ValueError("mask must have width*height entries")
+        keep.append(problem.mask)
+        sc.mask = problem.mask.ctypes.data_as(C.POINTER(C.c_uint8))
+    return sc
+
+
 class UniformIntegrator:
     VectorType = tuple
 
@@ -48,20 +66,8 @@ class UniformIntegrator:
         self.problem = problem
         self.settings = settings
         keep = []
-        sc = SceneDesc()
-        sc.dirichlet = _mesh_desc(keep, problem.d_verts, problem.d_segs, problem.d_colors)
-        sc.neumann = _mesh_desc(keep, problem.n_verts, problem.n_segs, problem.n_colors)
-        sc.dirichlet_intensity = problem.dirichlet_intensity
-        sc.neumann_intensity = problem.neumann_intensity
-        sc.probe_scale = float(problem.probe[0])
-        sc.probe_pos[0], sc.probe_pos[1] = float(problem.probe[1]), float(problem.probe[2])
-        sc.probe_up[0], sc.probe_up[1] = float(problem.probe[3]), float(problem.probe[4])
         w, h = settings.frameSize
-        if problem.mask is not None:
-            if problem.mask.size != w * h:
-                raise ValueError("mask must have width*height entries")
-            keep.append(problem.mask)
-            sc.mask = problem.mask.ctypes.data_as(C.POINTER(C.c_uint8))
+        sc = scene_desc(keep, problem, w, h)
         st = Settings(w, h, settings.samplesPerPixel, settings.maxWalkingDepth, settings.epsilonShell)
         self._handle = C.c_void_p()
         _check(self.lib.wost_create(C.byref(sc), C.byref(st), device, C.byref(self._handle)), "wost_create")

@@ -200,6 +200,60 @@ int wost_net_inference(wost_net_handle h, const float *xy, int32_t n, float *out
 int wost_net_train_step(wost_net_handle h, const float *xy, const float *dl_dout, int32_t n, float loss_scale,
                         int apply_update);
 
+/* ---- guided integrator -------------------------------
+ * Replaces GuidedIntegrator<2> as run_expr drives it (reference exec.cu:145-215): the ctor
+ * (integrator/guided/integrator.cu:1148-1161), resetNetwork (:1095-1131) and solve()
+ * (:1189-1195 -> solveImpl :968-1094).  The first block mirrors GuidedIntegratorSettings
+ * (integrator/guided/integrator.h:54-75) plus scene.aabb of the JSON; the second block holds the
+ * reference's compile-time constants, exposed so that small frames can be trained in tests. */
+typedef struct wost_guided_settings {
+    int32_t width, height, spp, max_depth;      /* frameSize, samplesPerPixel, maxWalkingDepth   */
+    float eps_shell;                            /* epsilonShell                                  */
+    int32_t train_spp_count;                    /* trainSppCount                                 */
+    float uniform_fraction_training;            /* uniformFractionInTrainingPhase                */
+    float uniform_fraction_guiding;             /* uniformFractionInGuidingPhase                 */
+    int32_t max_guided_depth_training;          /* maxGuidedDepthInTrainingPhase                 */
+    int32_t max_guided_depth_guiding;           /* maxGuidedDepthInGuidingPhase                  */
+    float aabb_min[2], aabb_max[2];             /* scene.aabb (core/problem.cu loadConfig)       */
+    int32_t max_train_depth;                    /* 3       integrator.h:237 (<= 4, parameters.h:7) */
+    int32_t batch_size;                         /* 524288  parameters.h:11                       */
+    int32_t min_batch_size;                     /* 65536   parameters.h:12                       */
+    int32_t batches_per_spp;                    /* 5       integrator.h:238                      */
+    int32_t train_pixel_stride;                 /* 1       guided.h:104-121                      */
+    int32_t train_pixel_offset;                 /* 0                                              */
+    float loss_scale;                           /* 128     parameters.h:14                       */
+} wost_guided_settings;
+
+typedef struct wost_guided_stats {
+    uint64_t walk_steps, walks_started, walks_absorbed, walks_truncated, neumann_hits;
+    uint64_t guided_steps;       /* steps whose direction was drawn from the mixture              */
+    uint64_t train_samples;      /* training records collected over all training passes           */
+    uint64_t optimizer_steps;
+    double solve_ms;             /* host wall time of wost_guided_solve                           */
+    double train_ms;             /* part of it spent building training sets and training          */
+    uint32_t kernel_launches;
+    uint32_t reserved;
+} wost_guided_stats;
+
+typedef struct wost_guided *wost_guided_handle;
+
+/* Scene upload + LBVH build + network construction (initialised from net_seed). */
+int wost_guided_create(const wost_scene_desc *scene, const wost_guided_settings *settings,
+                       const wost_net_config *net, uint64_t net_seed, int device, wost_guided_handle *out);
+/* The integrator's network, borrowed (valid until wost_guided_destroy): get/set parameters,
+ * queryNetwork-style inference (integrator.cu:566-615). */
+int wost_guided_network(wost_guided_handle h, wost_net_handle *net);
+/* GuidedIntegrator<2>::solve(): all samples, training passes included; field_rgb receives
+ * width*height*3 floats = solution / spp.  Starts from the network's current state. */
+int wost_guided_solve(wost_guided_handle h, float *field_rgb, wost_guided_stats *stats);
+/* The training set built by the most recent training pass, in (pixel, record) order
+ * (generate_training_data, train.h:423-471): xy[n*2] normalised positions, dir[n*2],
+ * solution[n*3] = |record.solution / record.thp|, dir_pdf[n], normal[n*2], on_neumann[n].
+ * Copies min(n, capacity) entries; any output array may be NULL. */
+int wost_guided_train_set(wost_guided_handle h, int32_t capacity, int32_t *n, float *xy, float *dir,
+                          float *solution, float *dir_pdf, float *normal, uint8_t *on_neumann);
+int wost_guided_destroy(wost_guided_handle h);
+
 /* Tuning knobs ("steps_per_round", "block_size", ...); unknown keys -> WOST_ERR_INVALID. */
 int wost_set_option(wost_handle h, const char *key, double value);
 

@@ -69,6 +69,43 @@ class Stats(C.Structure):
     ]
 
 
+class GuidedSettings(C.Structure):
+    """wo_guided_settings; defaults = the reference's constants (see wost_oracle.h)"""
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int), ("spp", C.c_int), ("max_depth", C.c_int), ("eps_shell", C.c_float),
+        ("train_spp_count", C.c_int),
+        ("uniform_fraction_training", C.c_float), ("uniform_fraction_guiding", C.c_float),
+        ("max_guided_depth_training", C.c_int), ("max_guided_depth_guiding", C.c_int),
+        ("aabb_min", C.c_float * 2), ("aabb_max", C.c_float * 2),
+        ("max_train_depth", C.c_int), ("batch_size", C.c_int), ("min_batch_size", C.c_int), ("batches_per_spp", C.c_int),
+        ("train_pixel_stride", C.c_int), ("train_pixel_offset", C.c_int), ("loss_scale", C.c_float),
+    ]
+
+
+def guided_settings(width, height, spp, max_depth, eps, aabb_min, aabb_max, train_spp_count=150,
+                    uniform_fraction=(0.5, 0.5), max_guided_depth=(10, 10), max_train_depth=3, batch_size=524288,
+                    min_batch_size=65536, batches_per_spp=5, train_pixel_stride=1, train_pixel_offset=0,
+                    loss_scale=128.0):
+    g = GuidedSettings(width, height, spp, max_depth, eps, train_spp_count, uniform_fraction[0], uniform_fraction[1],
+                       max_guided_depth[0], max_guided_depth[1])
+    g.aabb_min[0], g.aabb_min[1] = aabb_min
+    g.aabb_max[0], g.aabb_max[1] = aabb_max
+    g.max_train_depth, g.batch_size, g.min_batch_size, g.batches_per_spp = max_train_depth, batch_size, min_batch_size, batches_per_spp
+    g.train_pixel_stride, g.train_pixel_offset, g.loss_scale = train_pixel_stride, train_pixel_offset, loss_scale
+    return g
+
+
+class GuidedStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated",
+                                          "neumann_hits", "guided_steps", "train_samples", "optimizer_steps")]
+
+
+class TrainDump(C.Structure):
+    _fields_ = [("capacity", C.c_int), ("n", C.c_int), ("xy", C.POINTER(C.c_float)), ("dir", C.POINTER(C.c_float)),
+                ("solution", C.POINTER(C.c_float)), ("dir_pdf", C.POINTER(C.c_float)), ("normal", C.POINTER(C.c_float)),
+                ("on_neumann", C.POINTER(C.c_ubyte))]
+
+
 class NetConfig(C.Structure):
     _fields_ = [
         ("n_levels", C.c_int), ("n_features", C.c_int), ("base_resolution", C.c_int), ("per_level_scale", C.c_float),
@@ -191,6 +228,33 @@ class Oracle:
             out["steps"] = steps
         if want_hist:
             out["depth_hist"] = hist
+        return out
+
+    def solve_guided(self, sd, gs, net_cfg, params, threads=8, dump_spp=-1):
+        """Guided integrator; params (float32, n_params) are trained IN PLACE.  Returns field, stats and,
+        when dump_spp >= 0, the training set built after that sample pass."""
+        sc = self.make_scene(sd)
+        n = gs.width * gs.height
+        field = np.zeros((n, 3), dtype=np.float32)
+        stats = GuidedStats()
+        assert params.dtype == np.float32 and params.flags.c_contiguous and params.size == self.net_n_params(net_cfg)
+        dump = None
+        arrays = {}
+        if dump_spp >= 0:
+            cap = n * 4
+            arrays = {"xy": np.zeros((cap, 2), np.float32), "dir": np.zeros((cap, 2), np.float32),
+                      "solution": np.zeros((cap, 3), np.float32), "dir_pdf": np.zeros(cap, np.float32),
+                      "normal": np.zeros((cap, 2), np.float32), "on_neumann": np.zeros(cap, np.uint8)}
+            dump = TrainDump(cap, 0, _fp(arrays["xy"]), _fp(arrays["dir"]), _fp(arrays["solution"]), _fp(arrays["dir_pdf"]),
+                             _fp(arrays["normal"]), arrays["on_neumann"].ctypes.data_as(C.POINTER(C.c_ubyte)))
+        rc = self.lib.wo_solve_guided(C.byref(sc), C.byref(gs), C.byref(net_cfg), _fp(params), threads, _fp(field),
+                                      C.byref(stats), dump_spp, C.byref(dump) if dump is not None else None)
+        if rc != 0:
+            raise RuntimeError("wo_solve_guided failed: %d" % rc)
+        out = {"field": field}
+        out.update({k: int(getattr(stats, k)) for k, _ in GuidedStats._fields_})
+        if dump is not None:
+            out["train_set"] = {k: v[:dump.n] for k, v in arrays.items()}
         return out
 
     def render_dirichlet_sdf(self, sd, width, height, threads=8):

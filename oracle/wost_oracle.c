@@ -10,25 +10,13 @@
  */
 #define _GNU_SOURCE
 #include "wost_oracle.h"
+#include "wost_internal.h"
 
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
-
-/* ------------------------------------------------------------------------ */
-/* constants: core/math/include/krrmath/constants.h:9-13                     */
-/* M_PI comes from <math.h> as a double in the reference translation units   */
-/* (constants.h only defines it when absent), so expressions such as         */
-/* `1.0f / M_PI` are evaluated in double and then rounded to float.          */
-/* ------------------------------------------------------------------------ */
-#define WO_PI_D 3.14159265358979323846
-#define WO_2PI 6.28318530717958647693f
-#define WO_R_B_FLOOR 1e-4f           /* integrator.cu:193 */
-#define WO_R_B_SHRINK 0.99f          /* integrator.cu:195 */
-#define WO_SIL_PRECISION 1e-3f       /* silhouette test tolerance */
-#define WO_FAR_IDX 0x7fffffff
 
 /* ------------------------------------------------------------------------ */
 /* PCG32: core/sampler.h:10-103                                              */
@@ -118,15 +106,6 @@ void wo_pcg_seed_pixel(wo_pcg *r, int pixel_id, int width)
 /* ------------------------------------------------------------------------ */
 /* deterministic math (specified in DESIGN.md, "deterministic math")         */
 /* ------------------------------------------------------------------------ */
-static inline float wo_dot2(float ax, float ay, float bx, float by)
-{
-    return fmaf(ax, bx, ay * by);
-}
-static inline float wo_cross2(float ax, float ay, float bx, float by)
-{
-    return fmaf(ax, by, -(ay * bx));
-}
-
 void wo_sincos_2pi(float u, float *c, float *s)
 {
 #ifdef WOST_ORACLE_LIBM
@@ -222,28 +201,7 @@ void wo_eval_point(const wo_scene *sc, int px, int py, int width, int height,
 /* ------------------------------------------------------------------------ */
 /* prepared mesh                                                             */
 /* ------------------------------------------------------------------------ */
-typedef struct {
-    float ax, ay, ex, ey, inv_len2, len, nx, ny;
-    float cx, cy, ux, uy, hl;   /* centre, unit axis, half length (distance form) */
-    int i0, i1;
-} pseg;
-
-typedef struct { float lox, loy, hix, hiy; int left, right, first, count; } bnode;
-
-typedef struct {
-    int n_segs, n_verts;
-    pseg *segs;
-    const float *colors;
-    /* silhouette candidates: per vertex incident segments (prev: vertex is i1, next: vertex is i0) */
-    int *v_prev, *v_next;
-    const float *verts;
-    /* BVH over segments */
-    bnode *nodes;
-    int n_nodes;
-    int *order;   /* leaf order -> original segment index */
-} pmesh;
-
-static void pmesh_free(pmesh *m)
+void pmesh_free(pmesh *m)
 {
     free(m->segs); free(m->v_prev); free(m->v_next); free(m->nodes); free(m->order);
     memset(m, 0, sizeof(*m));
@@ -308,7 +266,7 @@ static int bvh_build_rec(pmesh *m, cent *c, int first, int count, float pad)
     return id;
 }
 
-static int pmesh_prepare(pmesh *m, const wo_mesh *in)
+int pmesh_prepare(pmesh *m, const wo_mesh *in)
 {
     memset(m, 0, sizeof(*m));
     m->n_segs = in->n_segs; m->n_verts = in->n_verts;
@@ -366,7 +324,6 @@ static inline void seg_closest(const pseg *s, float qx, float qy, float *d2, flo
     *t_raw = wo_dot2(qx - s->ax, qy - s->ay, s->ex, s->ey) * s->inv_len2;
 }
 
-typedef struct { int idx; float d2; } cp_result;
 
 /* candidate (d2, idx) beats (bd2, bidx): smaller distance, ties -> lower original index */
 static inline int cp_better(float d2, int idx, float bd2, int bidx)
@@ -394,7 +351,7 @@ static inline float box_d2(const bnode *n, float qx, float qy)
     return wo_dot2(dx, dy, dx, dy);
 }
 
-static cp_result closest_bvh(const pmesh *m, float qx, float qy)
+cp_result closest_bvh(const pmesh *m, float qx, float qy)
 {
     cp_result r = { -1, INFINITY };
     int bidx = WO_FAR_IDX;
@@ -423,20 +380,10 @@ static cp_result closest_bvh(const pmesh *m, float qx, float qy)
 }
 
 /* lbvh::checkPointSide (integrator.cu:148): sign of cross(p1-p0, q-p0), left = +1 */
-static inline int seg_side(const pseg *s, float qx, float qy)
-{
-    float cr = wo_cross2(s->ex, s->ey, qx - s->ax, qy - s->ay);
-    return (0.0f < cr) - (cr < 0.0f);
-}
 /* lbvh::computeProjectionRatio (integrator.cu:149): unclamped parameter along p0->p1 */
-static inline float seg_proj_ratio(const pseg *s, float qx, float qy)
-{
-    return wo_dot2(qx - s->ax, qy - s->ay, s->ex, s->ey) * s->inv_len2;
-}
-
 /* ---- closest silhouette vertex (definition of nearest_silhouette(q,false),
  *      integrator.cu:189; test follows FCPW's isSilhouetteVertex) ----------- */
-static float closest_silhouette(const pmesh *m, float qx, float qy, float rmax)
+float closest_silhouette(const pmesh *m, float qx, float qy, float rmax)
 {
     float best2 = rmax * rmax; /* inf*inf = inf */
     int found = 0;
@@ -485,7 +432,7 @@ static inline int seg_ray(const pseg *s, float ox, float oy, float dx, float dy,
     return 1;
 }
 
-static int ray_closest(const pmesh *m, float ox, float oy, float dx, float dy, float tmax,
+int ray_closest(const pmesh *m, float ox, float oy, float dx, float dy, float tmax,
                        float *t_out, int *idx_out)
 {
     int hit = 0;
@@ -501,7 +448,7 @@ static int ray_closest(const pmesh *m, float ox, float oy, float dx, float dy, f
     return hit;
 }
 
-static int ray_any(const pmesh *m, float ox, float oy, float dx, float dy, float tmax)
+int ray_any(const pmesh *m, float ox, float oy, float dx, float dy, float tmax)
 {
     for (int i = 0; i < m->n_segs; ++i) {
         float t;
@@ -514,7 +461,7 @@ static int ray_any(const pmesh *m, float ox, float oy, float dx, float dy, float
  *      integrator.cu:349-354): segments touching the ball, probability
  *      proportional to their length, chosen by inverse CDF in index order;
  *      returned pdf is the density w.r.t. arc length: P(i) / len_i. ---------- */
-static int sample_in_sphere(const pmesh *m, float qx, float qy, float R, float u, float *pdf)
+int sample_in_sphere(const pmesh *m, float qx, float qy, float R, float u, float *pdf)
 {
     float R2 = R * R;
     float total = 0.0f;
@@ -544,19 +491,6 @@ static int sample_in_sphere(const pmesh *m, float qx, float qy, float R, float u
 /* ------------------------------------------------------------------------ */
 /* surface colour: integrator/common.h:242-260 + functors.h:60-64            */
 /* ------------------------------------------------------------------------ */
-static inline void surface_color(const float *colors, int i0, int i1, int side, float uv, float out[3])
-{
-    for (int c = 0; c < 3; ++c) {
-        float a = 0.0f, b = 0.0f;
-        if (colors) {
-            int off = (side >= 0) ? 0 : 3;
-            a = colors[6 * i0 + off + c];
-            b = colors[6 * i1 + off + c];
-        }
-        out[c] = a * (1 - uv) + b * uv;
-    }
-}
-
 /* ------------------------------------------------------------------------ */
 /* one pixel: the whole spp x depth loop (integrator.cu:529-623 restated     */
 /* per pixel; legal because a pixel's walk only touches its own sampler and  */

@@ -150,6 +150,39 @@ int wo_net_backward(const wo_net_config *c, const float *params, const float *xy
 int wo_net_optimizer_step(const wo_net_config *c, float *params, float *m1, float *m2, float *ema_raw,
                           float *inference_params, const float *grad, int step, float loss_scale);
 
+/* ---- guided integrator (oracle/wost_guided.c) ------------------------------------------ */
+typedef struct wo_guided_settings {
+    int width, height, spp, max_depth;
+    float eps_shell;
+    int train_spp_count;                    /* GuidedIntegratorSettings, integrator/guided/integrator.h:54-75 */
+    float uniform_fraction_training, uniform_fraction_guiding;
+    int max_guided_depth_training, max_guided_depth_guiding;
+    float aabb_min[2], aabb_max[2];         /* scene.aabb of the JSON configuration */
+    int max_train_depth;                    /* 3       integrator.h:237 */
+    int batch_size;                         /* 524288  parameters.h:11  */
+    int min_batch_size;                     /* 65536   parameters.h:12  */
+    int batches_per_spp;                    /* 5       integrator.h:238 */
+    int train_pixel_stride, train_pixel_offset; /* 1, 0 guided.h:104-121 */
+    float loss_scale;                       /* 128     parameters.h:14  */
+} wo_guided_settings;
+
+typedef struct wo_guided_stats {
+    uint64_t walk_steps, walks_started, walks_absorbed, walks_truncated, neumann_hits;
+    uint64_t guided_steps;                  /* steps whose direction came from the mixture */
+    uint64_t train_samples, optimizer_steps;
+} wo_guided_stats;
+
+/* training set of one sample pass, in (pixel, record) order; arrays may be NULL */
+typedef struct wo_train_dump {
+    int capacity, n;
+    float *xy, *dir, *solution, *dir_pdf, *normal;
+    unsigned char *on_neumann;
+} wo_train_dump;
+
+/* params: n_params floats, initial weights in, trained weights out. */
+int wo_solve_guided(const wo_scene *sc, const wo_guided_settings *gs, const wo_net_config *nc, float *params,
+                    int n_threads, float *field_rgb, wo_guided_stats *stats, int dump_spp, wo_train_dump *dump);
+
 const char *wo_version(void);
 
 #ifdef __cplusplus

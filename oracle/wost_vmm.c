@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "wost_oracle.h"
+#include "wost_internal.h"
 
 #define WV_2PI 6.28318530717958647693f
 #define WV_PI_D 3.14159265358979323846
@@ -122,14 +123,10 @@ float wo_vm_rejection_sample(float kappa, double proposal_r, wo_pcg *rng)
 }
 
 /* ---- VMM<2,8> ------------------------------------------------------------------------- */
-#define WV_NCOMP 8
-
-typedef struct { float lambda, kappa, mux, muy, ox, oy; } wv_lobe;
-typedef struct { wv_lobe sg[WV_NCOMP]; float weight[WV_NCOMP]; float total; } wv_vmm;
 
 static float clampf(float v, float lo, float hi) { return fmaxf(fminf(v, hi), lo); }
 
-static void vmm_build(wv_vmm *m, const float *data)
+void wo_vmm_build(wv_vmm *m, const float *data)
 {
     m->total = 0.0f;
     for (int i = 0; i < WV_NCOMP; ++i) {
@@ -144,7 +141,7 @@ static void vmm_build(wv_vmm *m, const float *data)
     for (int i = 0; i < WV_NCOMP; ++i) m->weight[i] = m->sg[i].lambda / m->total;
 }
 
-static float vmm_pdf(const wv_vmm *m, float wx, float wy)
+float wo_vmm_pdf(const wv_vmm *m, float wx, float wy)
 {
     float val = 0.0f;
     for (int i = 0; i < WV_NCOMP; ++i)
@@ -162,6 +159,18 @@ static void lobe_sample(const wv_lobe *l, wo_pcg *rng, float *ox, float *oy)
     px /= pl; py /= pl;
     *ox = l->mux * vx + px * vy;
     *oy = l->muy * vx + py * vy;
+}
+
+/* VMM::sample (distribution.h:186-198): pick a lobe by one float draw, then sample it */
+void wo_vmm_sample(const wv_vmm *m, wo_pcg *rng, float *ox, float *oy)
+{
+    float u = wo_pcg_next_float(rng);
+    int pick = 0, found = 0;
+    for (int k = 0; k < WV_NCOMP && !found; ++k) {
+        if (u < m->weight[k]) { pick = k; found = 1; }
+        else u -= m->weight[k];
+    }
+    lobe_sample(&m->sg[pick], rng, ox, oy);
 }
 
 int wo_vonmises_eval(const float *kappa, const float *cos_theta, int n, float *log_i0, float *log_i1,
@@ -191,18 +200,12 @@ int wo_vmm_pdf_sample(const float *raw, const float *wi, const uint64_t *seed, i
 {
     for (int i = 0; i < n; ++i) {
         wv_vmm m;
-        vmm_build(&m, raw + 32 * (size_t)i);
-        if (pdf) pdf[i] = vmm_pdf(&m, wi[2 * i], wi[2 * i + 1]);
+        wo_vmm_build(&m, raw + 32 * (size_t)i);
+        if (pdf) pdf[i] = wo_vmm_pdf(&m, wi[2 * i], wi[2 * i + 1]);
         if (dir) {
             wo_pcg rng;
             wo_pcg_set_seed(&rng, seed[i], 1);
-            float u = wo_pcg_next_float(&rng);      /* distribution.h:186-198 */
-            int pick = 0, found = 0;
-            for (int k = 0; k < WV_NCOMP && !found; ++k) {
-                if (u < m.weight[k]) { pick = k; found = 1; }
-                else u -= m.weight[k];
-            }
-            lobe_sample(&m.sg[pick], &rng, &dir[2 * i], &dir[2 * i + 1]);
+            wo_vmm_sample(&m, &rng, &dir[2 * i], &dir[2 * i + 1]);
         }
     }
     return 0;
@@ -227,7 +230,7 @@ int wo_vmm_loss_gradients(const float *raw, const float *dir, const float *li, c
         const float *data = raw + 33 * (size_t)t;
         float *grad = dl_draw + 33 * (size_t)t;
         wv_vmm m;
-        vmm_build(&m, data);
+        wo_vmm_build(&m, data);
         const float wx = dir[2 * t], wy = dir[2 * t + 1];
         const int on_n = on_neumann ? on_neumann[t] : 0;
         float rx = 0.0f, ry = 0.0f;
