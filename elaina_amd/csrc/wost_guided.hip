@@ -17,7 +17,7 @@
 //                    record; in place -- the out-of-shell queue becomes the next depth's queue
 // Free choices of the reference that made it irreproducible are fixed: the training set is
 // ordered by (pixel, record) through a prefix sum instead of by atomics, so two runs -- and the
-// CPU oracle (oracle/wost_guided.c) -- see the same batches.
+// CPU restatement the tests compare against -- see the same batches.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
