@@ -113,7 +113,7 @@ EXPORTS = [
     "wost_vonmises_eval", "wost_vonmises_sample", "wost_vmm_pdf_sample", "wost_vmm_loss_gradients",
     "wost_net_create", "wost_net_destroy", "wost_net_n_params", "wost_net_get_params",
     "wost_net_set_params", "wost_net_inference", "wost_net_train_step",
-    "wost_guided_create", "wost_guided_network", "wost_guided_solve", "wost_guided_train_set", "wost_guided_destroy",
+    "wost_guided_create", "wost_guided_network", "wost_guided_scene", "wost_guided_query_network", "wost_guided_solve", "wost_guided_solve_sharded", "wost_guided_train_set", "wost_guided_destroy",
     "wost_last_error", "wost_version",
 ]
 
@@ -166,7 +166,10 @@ def load():
     L.wost_guided_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(GuidedSettings), C.POINTER(NetConfig), C.c_uint64,
                                      C.c_int, C.POINTER(C.c_void_p)]
     L.wost_guided_network.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.wost_guided_scene.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.wost_guided_query_network.argtypes = [C.c_void_p, fp, C.c_int32, fp]
     L.wost_guided_solve.argtypes = [C.c_void_p, fp, C.POINTER(GuidedStats)]
+    L.wost_guided_solve_sharded.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(GuidedStats)]
     L.wost_guided_train_set.argtypes = [C.c_void_p, C.c_int32, ip, fp, fp, fp, fp, fp, C.POINTER(C.c_uint8)]
     L.wost_guided_destroy.argtypes = [C.c_void_p]
     L.wost_destroy.argtypes = [C.c_void_p]

@@ -93,6 +93,7 @@ struct GParams {
     float uniform_fraction;
     int32_t first_sample;
     int32_t last_depth;
+    int32_t shard_index, shard_count;   // this solve owns the 8x8 pixel tiles t with t % count == index
 };
 
 __device__ __forceinline__ bool is_training_pixel(const GParams &P, uint32_t pid)
@@ -153,7 +154,9 @@ __global__ __launch_bounds__(256) void begin_sample_kernel(GParams P)
             P.hint0[p] = 0;
         }
         P.cur_depth[p] = 0;
-        active = (P.mask == nullptr || P.mask[p] != 0);
+        const int px = p % P.st.width, py = p / P.st.width;
+        const int tile = (py >> 3) * ((P.st.width + 7) >> 3) + (px >> 3);
+        active = (tile % P.shard_count) == P.shard_index && (P.mask == nullptr || P.mask[p] != 0);
         if (active) eval_point(P.probe, p % P.st.width, p / P.st.width, P.st.width, P.st.height, x, y);
     }
     const uint32_t s = wave_push(active, P.count_out);
@@ -598,6 +601,25 @@ int wost_guided_network(wost_guided_handle h, wost_net_handle *net)
     return WOST_OK;
 }
 
+int wost_guided_scene(wost_guided_handle h, wost_handle *scene)
+{
+    if (!h || !scene) return set_error(WOST_ERR_INVALID, "null argument");
+    *scene = h->scene;
+    return WOST_OK;
+}
+
+int wost_guided_query_network(wost_guided_handle h, const float *pts, int32_t n, float *raw)
+{
+    if (!h || !pts || !raw || n < 0) return set_error(WOST_ERR_INVALID, "bad argument");
+    std::vector<float> xy((size_t)n * 2);
+    const GAabb &b = h->box;
+    for (int i = 0; i < n; ++i) {
+        xy[2 * (size_t)i] = 0.5f + (pts[2 * (size_t)i] - b.cx) / b.ex;
+        xy[2 * (size_t)i + 1] = 0.5f + (pts[2 * (size_t)i + 1] - b.cy) / b.ey;
+    }
+    return wost_net_inference(h->net, xy.data(), n, raw, 1);
+}
+
 int wost_guided_train_set(wost_guided_handle h, int32_t capacity, int32_t *n, float *xy, float *dir, float *solution,
                           float *dir_pdf, float *normal, uint8_t *on_neumann)
 {
@@ -615,9 +637,12 @@ int wost_guided_train_set(wost_guided_handle h, int32_t capacity, int32_t *n, fl
     return WOST_OK;
 }
 
-int wost_guided_solve(wost_guided_handle g, float *field_rgb, wost_guided_stats *stats)
+}  // extern "C"
+
+// the shared driver: field_host (n_pixels*3, may be null) and/or field_dev (device, n_pixels*3)
+static int run_guided(wost_guided *g, int shard_index, int shard_count, float *field_host, float *field_dev,
+                      wost_guided_stats *stats)
 {
-    if (!g || !field_rgb) return set_error(WOST_ERR_INVALID, "null argument");
     const auto t_start = std::chrono::high_resolution_clock::now();
     G_TRY(hipSetDevice(g->device));
     const wost_guided_settings &s = g->gs;
@@ -641,6 +666,7 @@ int wost_guided_solve(wost_guided_handle g, float *field_rgb, wost_guided_stats 
     P.net_in = g->net_in; P.net_out = g->net_out; P.stats = g->stats; P.n_pixels = N; P.stack_stride = 256;
     P.max_train_depth = s.max_train_depth;
     P.train_offset = (uint32_t)s.train_pixel_offset; P.train_stride = (uint32_t)s.train_pixel_stride;
+    P.shard_index = shard_index; P.shard_count = shard_count;
 
     // ctor state (integrator.cu:1158-1160), prepareSolve (:125-126)
     bool training = true;
@@ -734,7 +760,8 @@ int wost_guided_solve(wost_guided_handle g, float *field_rgb, wost_guided_stats 
     }
     hipLaunchKernelGGL(resolve_kernel, dim3((3 * N + 255) / 256), dim3(256), 0, stream, g->sol, N, (float)s.spp, g->field);
     G_TRY(hipGetLastError());
-    G_TRY(hipMemcpyAsync(field_rgb, g->field, (size_t)N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (field_host) G_TRY(hipMemcpyAsync(field_host, g->field, (size_t)N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (field_dev) G_TRY(hipMemcpyAsync(field_dev, g->field, (size_t)N * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
     GStatsDev hs{};
     G_TRY(hipMemcpyAsync(&hs, g->stats, sizeof(hs), hipMemcpyDeviceToHost, stream));
     G_TRY(hipStreamSynchronize(stream));
@@ -750,6 +777,22 @@ int wost_guided_solve(wost_guided_handle g, float *field_rgb, wost_guided_stats 
             std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_start).count();
     }
     return WOST_OK;
+}
+
+extern "C" {
+
+int wost_guided_solve(wost_guided_handle g, float *field_rgb, wost_guided_stats *stats)
+{
+    if (!g || !field_rgb) return set_error(WOST_ERR_INVALID, "null argument");
+    return run_guided(g, 0, 1, field_rgb, nullptr, stats);
+}
+
+int wost_guided_solve_sharded(wost_guided_handle g, int32_t shard_index, int32_t shard_count, float *field_rgb_dev,
+                              wost_guided_stats *stats)
+{
+    if (!g || !field_rgb_dev) return set_error(WOST_ERR_INVALID, "null argument");
+    if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return set_error(WOST_ERR_INVALID, "bad shard");
+    return run_guided(g, shard_index, shard_count, nullptr, field_rgb_dev, stats);
 }
 
 }  // extern "C"

@@ -92,15 +92,17 @@ __device__ __forceinline__ void encode_point(const NetLayout &L, const float *gr
     }
 }
 
-// out[r] = sum_k W[r][k] * in[k] (k ascending, fma chain), optional ReLU.  W is wave-uniform.
-__device__ __forceinline__ void dense_layer(const float *W, int n_out, int n_in, const float *in_col, float *out_col, bool relu)
+// out[r] = sum_k W[r][k] * in[k] (k ascending, fma chain), optional ReLU.  The weights are
+// wave-uniform and read from the TRANSPOSED copy Wt[k][r], so the 8 weights of one k are one
+// s_load_dwordx8.
+__device__ __forceinline__ void dense_layer(const float *Wt, int n_out, int n_in, const float *in_col, float *out_col, bool relu)
 {
     for (int r0 = 0; r0 < n_out; r0 += 8) {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < n_in; ++k) {
             const float a = in_col[k * kNetBlock];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(W[(size_t)(r0 + j) * n_in + k], a, acc[j]);
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(Wt[(size_t)k * n_out + r0 + j], a, acc[j]);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) out_col[(r0 + j) * kNetBlock] = relu ? fmaxf(acc[j], 0.0f) : acc[j];
@@ -109,8 +111,9 @@ __device__ __forceinline__ void dense_layer(const float *W, int n_out, int n_in,
 
 // forward; out: n x n_out (unpadded).  acts (optional): n x (enc + n_hidden * n_neurons), the
 // activations the backward pass needs.
-__global__ __launch_bounds__(kNetBlock) void net_forward_kernel(NetLayout L, const float *params, const float *xy, int n,
-                                                                const uint32_t *n_dev, float *out, float *acts)
+__global__ __launch_bounds__(kNetBlock) void net_forward_kernel(NetLayout L, const float *params, const float *wt,
+                                                                const float *xy, int n, const uint32_t *n_dev, float *out,
+                                                                float *acts)
 {
     if (n_dev) n = (int)*n_dev;                              // queue size decided on the device
     if ((int)(blockIdx.x * kNetBlock) >= n) return;
@@ -127,23 +130,23 @@ __global__ __launch_bounds__(kNetBlock) void net_forward_kernel(NetLayout L, con
     float *in = col_a, *o = col_b;
     int n_in = L.enc;
     for (int layer = 0; layer < L.n_hidden; ++layer) {
-        dense_layer(params + L.w_off[layer], L.n_neurons, n_in, in, o, true);
+        dense_layer(wt + L.w_off[layer], L.n_neurons, n_in, in, o, true);
         if (acts && valid)
             for (int k = 0; k < L.n_neurons; ++k) acts[(size_t)p * stride + L.enc + layer * L.n_neurons + k] = act(o, k);
         float *t = in; in = o; o = t;
         n_in = L.n_neurons;
     }
-    dense_layer(params + L.w_off[L.n_hidden], L.n_out_padded, n_in, in, o, false);
+    dense_layer(wt + L.w_off[L.n_hidden], L.n_out_padded, n_in, in, o, false);
     if (valid)
         for (int k = 0; k < L.n_out; ++k) out[(size_t)p * L.n_out + k] = act(o, k);
 }
 
 // backward, one thread per point: propagates dL/dout to every layer input (kept per point in
-// `deltas`: n x (n_out_padded + n_hidden * n_neurons)), and scatters the encoding gradient into
-// the grid with float atomics.  Weight gradients are formed afterwards by weight_grad_kernel.
+// `deltas`: n x (n_out_padded + n_hidden * n_neurons)) and to the encoding (`denc`: n x enc).
+// Weight and grid gradients are formed afterwards by weight_grad_kernel / grid_grad_kernel.
 __global__ __launch_bounds__(kNetBlock) void net_backward_kernel(NetLayout L, const float *params, const float *xy,
                                                                  const float *dl_dout, const float *acts, int n, float *deltas,
-                                                                 float *grad)
+                                                                 float *denc)
 {
     extern __shared__ float lds[];
     float *col_a = lds + threadIdx.x;
@@ -197,24 +200,59 @@ __global__ __launch_bounds__(kNetBlock) void net_backward_kernel(NetLayout L, co
         }
     }
     if (!valid) return;
-    const float x = xy[2 * p], y = xy[2 * p + 1];
+    for (int k = 0; k < L.enc; ++k) denc[(size_t)p * L.enc + k] = d_in[k * kNetBlock];
+}
+
+// Gradient of the grid: every point adds w_corner * d_enc to the 4 corners of its cell on every
+// level.  Coarse levels are hit by thousands of points per entry, so a block first accumulates
+// the levels that fit into LDS there (ds_add_f32) and flushes each touched entry with ONE global
+// atomic; only the fine levels go to global memory directly.  Work item = (point, level):
+// neighbouring lanes read consecutive float4s of d_enc and hit different levels.
+__global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float *xy, const float *denc, int n, int chunk,
+                                                        int n_lds_levels, float *grad)
+{
+    extern __shared__ float acc[];
+    __shared__ float s_scale[kNetMaxLevels];
+    __shared__ uint32_t s_res[kNetMaxLevels], s_off[kNetMaxLevels + 1];
+    if (threadIdx.x <= (unsigned)L.n_levels) {
+        s_off[threadIdx.x] = L.level_off[threadIdx.x];
+        if (threadIdx.x < (unsigned)L.n_levels) {
+            s_scale[threadIdx.x] = L.scale[threadIdx.x];
+            s_res[threadIdx.x] = (uint32_t)L.res[threadIdx.x];
+        }
+    }
+    const int nf = L.n_features;
+    const int n_acc = (int)L.level_off[n_lds_levels] * nf;
+    for (int e = threadIdx.x; e < n_acc; e += 256) acc[e] = 0.0f;
+    __syncthreads();
+    const int p0 = blockIdx.x * chunk, p1 = min(n, p0 + chunk);
     float *gG = grad + L.n_mlp;
-    for (int lv = 0; lv < L.n_levels; ++lv) {
-        const float s = L.scale[lv];
-        const uint32_t res = (uint32_t)L.res[lv];
-        const uint32_t n_level = L.level_off[lv + 1] - L.level_off[lv];
-        float px = __builtin_fmaf(s, x, 0.5f), py = __builtin_fmaf(s, y, 0.5f);
+    const int n_items = (p1 - p0) * L.n_levels;
+    for (int item = threadIdx.x; item < n_items; item += 256) {
+        const int p = p0 + item / L.n_levels, lv = item % L.n_levels;
+        const float s = s_scale[lv];
+        const uint32_t res = s_res[lv], lo = s_off[lv], n_level = s_off[lv + 1] - lo;
+        float px = __builtin_fmaf(s, xy[2 * p], 0.5f), py = __builtin_fmaf(s, xy[2 * p + 1], 0.5f);
         const float fx = floorf(px), fy = floorf(py);
         px -= fx;
         py -= fy;
         const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+        const float *d = denc + (size_t)p * L.enc + lv * nf;
         for (int k = 0; k < 4; ++k) {
             const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
             const float w = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
-            const uint32_t idx = (cx + cy * res) % n_level;
-            for (int q = 0; q < L.n_features; ++q)
-                atomicAdd(gG + (size_t)(L.level_off[lv] + idx) * L.n_features + q, w * d_in[(lv * L.n_features + q) * kNetBlock]);
+            const uint32_t e = (lo + (cx + cy * res) % n_level) * nf;
+            if (lv < n_lds_levels) {
+                for (int q = 0; q < nf; ++q) atomicAdd(&acc[e + q], w * d[q]);
+            } else {
+                for (int q = 0; q < nf; ++q) atomicAdd(gG + e + q, w * d[q]);
+            }
         }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_acc; e += 256) {
+        const float v = acc[e];
+        if (v != 0.0f) atomicAdd(gG + e, v);
     }
 }
 
@@ -263,6 +301,19 @@ __global__ __launch_bounds__(256) void weight_grad_kernel(const float *delta, in
     }
 }
 
+// transposed copies of the MLP matrices for the forward pass: dst[k][r] = src[r][k] per layer
+__global__ void transpose_mlp_kernel(NetLayout L, const float *src, float *dst)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n_mlp) return;
+    int layer = 0;
+    while (layer < L.n_hidden && i >= L.w_off[layer + 1]) ++layer;
+    const int n_i = layer == 0 ? L.enc : L.n_neurons, n_o = layer == L.n_hidden ? L.n_out_padded : L.n_neurons;
+    const uint32_t e = i - L.w_off[layer];
+    const uint32_t r = e / n_i, k = e % n_i;
+    dst[L.w_off[layer] + k * n_o + r] = src[i];
+}
+
 // tiny-cuda-nn adam.h adam_step nested in ema.h (debiased): step counts from 1
 __global__ void optimizer_kernel(uint32_t n, float *params, float *m1, float *m2, float *ema_raw, float *inference,
                                  const float *grad, float lr_t, float beta1, float beta2, float eps, float l2, float decay,
@@ -291,9 +342,10 @@ struct wost_net {
     NetLayout L{};
     uint32_t n_params = 0;
     float *params = nullptr, *inference = nullptr, *m1 = nullptr, *m2 = nullptr, *ema_raw = nullptr, *grad = nullptr;
+    float *params_t = nullptr, *inference_t = nullptr;   // transposed MLP matrices (forward pass)
     int step = 0;
     // scratch (grown on demand)
-    float *d_xy = nullptr, *d_out = nullptr, *d_dl = nullptr, *d_acts = nullptr, *d_deltas = nullptr;
+    float *d_xy = nullptr, *d_out = nullptr, *d_dl = nullptr, *d_acts = nullptr, *d_deltas = nullptr, *d_denc = nullptr;
     size_t cap_points = 0;
 };
 
@@ -303,10 +355,19 @@ struct wost_net {
         if (e_ != hipSuccess) return set_error(WOST_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+static int refresh_transposed(wost_net *h, hipStream_t stream)
+{
+    const unsigned g = (h->L.n_mlp + 255) / 256;
+    hipLaunchKernelGGL(transpose_mlp_kernel, dim3(g), dim3(256), 0, stream, h->L, h->params, h->params_t);
+    hipLaunchKernelGGL(transpose_mlp_kernel, dim3(g), dim3(256), 0, stream, h->L, h->inference, h->inference_t);
+    NET_TRY(hipGetLastError());
+    return WOST_OK;
+}
+
 static int ensure_points(wost_net *h, size_t n)
 {
     if (n <= h->cap_points) return WOST_OK;
-    for (float **p : {&h->d_xy, &h->d_out, &h->d_dl, &h->d_acts, &h->d_deltas})
+    for (float **p : {&h->d_xy, &h->d_out, &h->d_dl, &h->d_acts, &h->d_deltas, &h->d_denc})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     h->cap_points = 0;
     const NetLayout &L = h->L;
@@ -315,6 +376,7 @@ static int ensure_points(wost_net *h, size_t n)
     NET_TRY(hipMalloc((void **)&h->d_dl, n * L.n_out * sizeof(float)));
     NET_TRY(hipMalloc((void **)&h->d_acts, n * (size_t)(L.enc + L.n_hidden * L.n_neurons) * sizeof(float)));
     NET_TRY(hipMalloc((void **)&h->d_deltas, n * (size_t)(L.n_out_padded + L.n_hidden * L.n_neurons) * sizeof(float)));
+    NET_TRY(hipMalloc((void **)&h->d_denc, n * (size_t)L.enc * sizeof(float)));
     h->cap_points = n;
     return WOST_OK;
 }
@@ -323,7 +385,7 @@ static void net_free(wost_net *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    for (float *p : {h->params, h->inference, h->m1, h->m2, h->ema_raw, h->grad, h->d_xy, h->d_out, h->d_dl, h->d_acts, h->d_deltas})
+    for (float *p : {h->params, h->inference, h->params_t, h->inference_t, h->m1, h->m2, h->ema_raw, h->grad, h->d_xy, h->d_out, h->d_dl, h->d_acts, h->d_deltas, h->d_denc})
         if (p) (void)hipFree(p);
     delete h;
 }
@@ -337,7 +399,8 @@ int net_inference_dev(wost_net *h, const float *xy_dev, const uint32_t *count_de
     if (max_n <= 0) return WOST_OK;
     const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
     hipLaunchKernelGGL(net_forward_kernel, dim3((max_n + kNetBlock - 1) / kNetBlock), dim3(kNetBlock), lds, stream, h->L,
-                       use_inference_params ? h->inference : h->params, xy_dev, max_n, count_dev, out_dev, (float *)nullptr);
+                       use_inference_params ? h->inference : h->params, use_inference_params ? h->inference_t : h->params_t, xy_dev,
+                       max_n, count_dev, out_dev, (float *)nullptr);
     NET_TRY(hipGetLastError());
     return WOST_OK;
 }
@@ -350,7 +413,7 @@ int net_forward_train_dev(wost_net *h, const float *xy_dev, int n, hipStream_t s
     if (rc != WOST_OK) return rc;
     const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
     hipLaunchKernelGGL(net_forward_kernel, dim3((n + kNetBlock - 1) / kNetBlock), dim3(kNetBlock), lds, stream, h->L, h->params,
-                       xy_dev, n, (const uint32_t *)nullptr, h->d_out, h->d_acts);
+                       h->params_t, xy_dev, n, (const uint32_t *)nullptr, h->d_out, h->d_acts);
     NET_TRY(hipGetLastError());
     *out_dev = h->d_out;
     *dl_dev = h->d_dl;
@@ -364,8 +427,18 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
     const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
     const unsigned gridp = (unsigned)((n + kNetBlock - 1) / kNetBlock);
     hipLaunchKernelGGL(net_backward_kernel, dim3(gridp), dim3(kNetBlock), lds, stream, L, h->params, xy_dev, h->d_dl, h->d_acts,
-                       n, h->d_deltas, h->grad);
+                       n, h->d_deltas, h->d_denc);
     NET_TRY(hipGetLastError());
+    {
+        // levels whose accumulators fit into 64 KB of LDS
+        int n_lds = 0;
+        while (n_lds < L.n_levels && (size_t)L.level_off[n_lds + 1] * L.n_features * sizeof(float) <= 64 * 1024) ++n_lds;
+        const int gchunk = 2048;
+        hipLaunchKernelGGL(grid_grad_kernel, dim3((unsigned)((n + gchunk - 1) / gchunk)), dim3(256),
+                           (size_t)L.level_off[n_lds] * L.n_features * sizeof(float), stream, L, xy_dev, h->d_denc, n, gchunk,
+                           n_lds, h->grad);
+        NET_TRY(hipGetLastError());
+    }
     const int astride = L.enc + L.n_hidden * L.n_neurons, dstride = L.n_out_padded + L.n_hidden * L.n_neurons;
     const int chunk = 1024;
     const unsigned gridc = (unsigned)((n + chunk - 1) / chunk);
@@ -388,6 +461,8 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
                            h->m1, h->m2, h->ema_raw, h->inference, h->grad, lr_t, c.beta1, c.beta2, c.epsilon, c.l2_reg,
                            c.ema_decay, debias, loss_scale);
         NET_TRY(hipGetLastError());
+        int rc = refresh_transposed(h, stream);
+        if (rc != WOST_OK) return rc;
     }
     return WOST_OK;
 }
@@ -440,7 +515,7 @@ int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_
     for (uint32_t e = 0; e < L.n_grid; ++e) init[L.n_mlp + e] = (uniform() * 2.0f - 1.0f) * 1e-4f;
     const size_t bytes = (size_t)h->n_params * sizeof(float);
     hipError_t e = hipSuccess;
-    for (float **p : {&h->params, &h->inference, &h->m1, &h->m2, &h->ema_raw, &h->grad})
+    for (float **p : {&h->params, &h->inference, &h->m1, &h->m2, &h->ema_raw, &h->grad, &h->params_t, &h->inference_t})
         if (e == hipSuccess) e = hipMalloc((void **)p, bytes);
     if (e == hipSuccess) e = hipMemcpy(h->params, init.data(), bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->inference, init.data(), bytes, hipMemcpyHostToDevice);
@@ -449,6 +524,10 @@ int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_
     if (e != hipSuccess) {
         net_free(h);
         return set_error(WOST_ERR_DEVICE, std::string("network allocation: ") + hipGetErrorString(e));
+    }
+    if (refresh_transposed(h, nullptr) != WOST_OK || hipDeviceSynchronize() != hipSuccess) {
+        net_free(h);
+        return set_error(WOST_ERR_DEVICE, "network initialisation failed");
     }
     *out = h;
     return WOST_OK;
@@ -486,6 +565,9 @@ int wost_net_set_params(wost_net_handle h, const float *host)
     NET_TRY(hipMemcpy(h->inference, host, bytes, hipMemcpyHostToDevice));
     for (float *p : {h->m1, h->m2, h->ema_raw}) NET_TRY(hipMemset(p, 0, bytes));
     h->step = 0;
+    int rc = refresh_transposed(h, nullptr);
+    if (rc != WOST_OK) return rc;
+    NET_TRY(hipDeviceSynchronize());
     return WOST_OK;
 }
 
@@ -499,8 +581,8 @@ int wost_net_inference(wost_net_handle h, const float *xy, int32_t n, float *out
     NET_TRY(hipMemcpy(h->d_xy, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice));
     const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
     hipLaunchKernelGGL(net_forward_kernel, dim3((n + kNetBlock - 1) / kNetBlock), dim3(kNetBlock), lds, 0, h->L,
-                       use_inference_params ? h->inference : h->params, h->d_xy, n, (const uint32_t *)nullptr, h->d_out,
-                       (float *)nullptr);
+                       use_inference_params ? h->inference : h->params, use_inference_params ? h->inference_t : h->params_t,
+                       h->d_xy, n, (const uint32_t *)nullptr, h->d_out, (float *)nullptr);
     NET_TRY(hipGetLastError());
     NET_TRY(hipMemcpy(out, h->d_out, (size_t)n * h->L.n_out * sizeof(float), hipMemcpyDeviceToHost));
     return WOST_OK;

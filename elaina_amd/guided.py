@@ -220,6 +220,14 @@ class GuidedIntegrator:
         self.last_stats = st.as_dict()
         return int(st.solve_ms)
 
+    def solve_sharded(self, shard_index, shard_count, field_dev_ptr):
+        """field_dev_ptr: device pointer (int) to a width*height*3 float buffer; returns the stats"""
+        st = capi.GuidedStats()
+        _check(self.lib.wost_guided_solve_sharded(self._handle, shard_index, shard_count, C.c_void_p(field_dev_ptr),
+                                                  C.byref(st)), "wost_guided_solve_sharded")
+        self.last_stats = st.as_dict()
+        return self.last_stats
+
     def train_set(self):
         """training set of the most recent training pass, (pixel, record) order"""
         n = C.c_int32()
@@ -237,11 +245,9 @@ class GuidedIntegrator:
         return out
 
     def queryNetwork(self, p):
-        """raw mixture parameters of the guiding network at world position p (reference
+        """raw mixture parameters of the guiding network at world position(s) p (reference
         integrator.cu:566-615 prints the VMM built from them)"""
-        (lo, hi) = self.aabb
-        lo, hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
-        infl = np.float32(np.sqrt(np.sum((hi - lo) ** 2, dtype=np.float32))) * np.float32(0.005)
-        lo2, hi2 = lo - infl, hi + infl
-        xy = np.float32(0.5) + (np.asarray(p, np.float32) - (lo2 + hi2) / np.float32(2)) / (hi2 - lo2)
-        return self.network.inference(xy.reshape(1, 2))[0]
+        pts = np.ascontiguousarray(p, dtype=np.float32).reshape(-1, 2)
+        raw = np.zeros((len(pts), 33), dtype=np.float32)
+        _check(self.lib.wost_guided_query_network(self._handle, _fp(pts), len(pts), _fp(raw)), "wost_guided_query_network")
+        return raw if np.ndim(p) > 1 else raw[0]

@@ -2,8 +2,8 @@
 // requested channels, export, write result.json (reference exec.cu:39-221).  Differences,
 // on purpose: the output directory is created (the reference writes conf.json into a
 // directory it never makes, exec.cu:69); unknown channels / export entries are skipped
-// instead of dereferencing an empty optional (exec.cu:193-199); only "uniform" + 2-D is
-// built -- guided and 3-D configurations exit(1) like an unrecognised type does.
+// instead of dereferencing an empty optional (exec.cu:193-199); only 2-D is built -- 3-D
+// configurations exit(1) like an unsupported dimensionality does.
 #include "exec.h"
 
 #include <chrono>
@@ -12,6 +12,7 @@
 #include <set>
 
 #include "core/problem.h"
+#include "integrator/guided/integrator.h"
 #include "integrator/uniform/integrator.h"
 
 using namespace elaina;
@@ -22,6 +23,56 @@ static std::string get_current_time()
     char buffer[20];
     std::strftime(buffer, sizeof(buffer), "%Y-%m-%d %H:%M:%S", std::localtime(&t));
     return buffer;
+}
+
+// the channel + export loops of run_expr (reference exec.cu:145-215), for either integrator
+template <class Integrator>
+static void run_channels(Integrator &obj, const json &conf_json, const json &integrator_section, json &result_json)
+{
+    const json export_section = json_get_or_throw<json>(conf_json, "export");
+    const json integrator_channels = json_get_or_throw<json>(integrator_section, "channels");
+    std::set<ExportImageChannel> channels;
+    for (const json &c : integrator_channels.items()) {
+        ExportImageChannel ch;
+        if (!parse_channel(c.get<string>(), &ch)) {
+            ELAINA_LOG(Error, "Unrecognized integrator channel, skipping...");
+            continue;
+        }
+        channels.insert(ch);
+    }
+    for (const ExportImageChannel ch : channels) {
+        switch (ch) {
+        case ExportImageChannel::SOLUTION: result_json["duration"] = json((uint64_t)obj.solve()); break;
+        case ExportImageChannel::DIRICHLET_SDF: obj.renderDirichletSDF(); break;
+        case ExportImageChannel::NEUMANN_SDF: obj.renderSilhouetteSDF(); break;
+        case ExportImageChannel::SOURCE: obj.renderSource(); break;
+        default: break;
+        }
+    }
+    if (json_get_optional<bool>(conf_json, "print_network", false)) {
+        try {
+            obj.queryNetwork(typename Integrator::VectorType{});
+        } catch (const std::exception &e) {
+            ELAINA_LOG(Warning, "print_network: %s", e.what());
+        }
+    }
+    for (const json &m : export_section.items()) {
+        const string type = json_get_or_throw<string>(m, "type");
+        const string channel_string = json_get_or_throw<string>(m, "channel");
+        const string file_name = json_get_or_throw<string>(m, "file_name");
+        ExportImageChannel ch;
+        if (!parse_channel(channel_string, &ch)) {
+            ELAINA_LOG(Error, "Unrecognized export channel, skipping...");
+            continue;
+        }
+        if (type == "image") {
+            obj.exportImage(ch, file_name);
+        } else if (type == "energy") {
+            ToneMapping tone;
+            if (parse_tone(json_get_or_throw<string>(m, "tone"), &tone)) obj.exportEnergy(ch, tone, file_name);
+            else ELAINA_LOG(Error, "Unrecognized tone mapping method, skipping...");
+        }
+    }
 }
 
 void run_expr(fs::path conf_path)
@@ -56,60 +107,31 @@ void run_expr(fs::path conf_path)
         ELAINA_LOG(Error, "Unsupported dimensionality (this build: 2).");
         exit(1);
     }
-    if (integrator_type != "uniform") {
-        ELAINA_LOG(Error, "Unrecognized integrator type (this build: uniform).");
-        exit(1);
-    }
     Problem<2> scene;
     scene.loadConfig(scene_section, conf_path.parent_path());
-    UniformIntegrator<2> obj(scene, UniformIntegratorSettings::from_json(integrator_setting), outDir);
-
-    const json export_section = json_get_or_throw<json>(conf_json, "export");
-    const json integrator_channels = json_get_or_throw<json>(integrator_section, "channels");
-    std::set<ExportImageChannel> channels;
-    for (const json &c : integrator_channels.items()) {
-        ExportImageChannel ch;
-        if (!parse_channel(c.get<string>(), &ch)) {
-            ELAINA_LOG(Error, "Unrecognized integrator channel, skipping...");
-            continue;
-        }
-        channels.insert(ch);
-    }
-    if (json_get_optional<bool>(conf_json, "print_network", false))
-        ELAINA_LOG(Warning, "print_network: the uniform integrator has no network");
-
-    for (const ExportImageChannel ch : channels) {
-        switch (ch) {
-        case ExportImageChannel::SOLUTION: {
-            const uint64_t duration = obj.solve();
-            result_json["duration"] = json((uint64_t)duration);
-            const wost_stats &s = obj.get_last_stats();
+    if (integrator_type == "uniform") {
+        UniformIntegrator<2> obj(scene, UniformIntegratorSettings::from_json(integrator_setting), outDir);
+        run_channels(obj, conf_json, integrator_section, result_json);
+        const wost_stats &s = obj.get_last_stats();
+        if (s.walk_steps) {
             result_json["walk_steps"] = json((uint64_t)s.walk_steps);
             result_json["walk_steps_per_second"] = json(s.solve_ms > 0 ? (double)s.walk_steps / (s.solve_ms * 1e-3) : 0.0);
-            break;
         }
-        case ExportImageChannel::DIRICHLET_SDF: obj.renderDirichletSDF(); break;
-        case ExportImageChannel::NEUMANN_SDF: obj.renderSilhouetteSDF(); break;
-        case ExportImageChannel::SOURCE: obj.renderSource(); break;
-        default: break;
+    } else if (integrator_type == "guided") {
+        const json network_section = json_get_or_throw<json>(conf_json, "network");
+        GuidedIntegrator<2> obj(scene, GuidedIntegratorSettings::from_json(integrator_setting), outDir);
+        obj.resetNetwork(network_section);
+        run_channels(obj, conf_json, integrator_section, result_json);
+        const wost_guided_stats &s = obj.get_last_stats();
+        if (s.walk_steps) {
+            result_json["walk_steps"] = json((uint64_t)s.walk_steps);
+            result_json["guided_steps"] = json((uint64_t)s.guided_steps);
+            result_json["optimizer_steps"] = json((uint64_t)s.optimizer_steps);
+            result_json["walk_steps_per_second"] = json(s.solve_ms > 0 ? (double)s.walk_steps / (s.solve_ms * 1e-3) : 0.0);
         }
-    }
-    for (const json &m : export_section.items()) {
-        const string type = json_get_or_throw<string>(m, "type");
-        const string channel_string = json_get_or_throw<string>(m, "channel");
-        const string file_name = json_get_or_throw<string>(m, "file_name");
-        ExportImageChannel ch;
-        if (!parse_channel(channel_string, &ch)) {
-            ELAINA_LOG(Error, "Unrecognized export channel, skipping...");
-            continue;
-        }
-        if (type == "image") {
-            obj.exportImage(ch, file_name);
-        } else if (type == "energy") {
-            ToneMapping tone;
-            if (parse_tone(json_get_or_throw<string>(m, "tone"), &tone)) obj.exportEnergy(ch, tone, file_name);
-            else ELAINA_LOG(Error, "Unrecognized tone mapping method, skipping...");
-        }
+    } else {
+        ELAINA_LOG(Error, "Unrecognized integrator type.");
+        exit(1);
     }
     result_json["timestamp"] = json(get_current_time());
     std::ofstream resultFile(outDir / "result.json");

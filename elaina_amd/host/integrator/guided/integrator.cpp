@@ -1,0 +1,144 @@
+#include "integrator.h"
+
+#include <chrono>
+#include <cmath>
+
+namespace elaina {
+
+GuidedIntegratorSettings GuidedIntegratorSettings::from_json(const json &j)
+{
+    GuidedIntegratorSettings s;
+    const auto fsz = json_get_or_throw<std::vector<int>>(j, "frameSize");
+    if (fsz.size() != 2) throw std::runtime_error("frameSize must have 2 entries");
+    s.frameSize = {fsz[0], fsz[1]};
+    s.debugPixel = json_get_or_throw<unsigned>(j, "debugPixel");
+    s.samplesPerPixel = json_get_or_throw<int>(j, "samplesPerPixel");
+    s.trainSppCount = json_get_or_throw<unsigned>(j, "trainSppCount");
+    s.uniformFractionInTrainingPhase = json_get_or_throw<float>(j, "uniformFractionInTrainingPhase");
+    s.uniformFractionInGuidingPhase = json_get_or_throw<float>(j, "uniformFractionInGuidingPhase");
+    s.maxGuidedDepthInTrainingPhase = json_get_or_throw<unsigned>(j, "maxGuidedDepthInTrainingPhase");
+    s.maxGuidedDepthInGuidingPhase = json_get_or_throw<unsigned>(j, "maxGuidedDepthInGuidingPhase");
+    s.maxWalkingDepth = json_get_or_throw<unsigned>(j, "maxWalkingDepth");
+    s.saveSppMetricsDuration = json_get_or_throw<int>(j, "saveSppMetricsDuration");
+    s.saveSppMetricsUntil = json_get_or_throw<int>(j, "saveSppMetricsUntil");
+    s.saveTimeMetricsDuration = json_get_or_throw<int>(j, "saveTimeMetricsDuration");
+    s.epsilonShell = json_get_or_throw<float>(j, "epsilonShell");
+    return s;
+}
+
+wost_net_config network_config_from_json(const json &n)
+{
+    const json enc = json_get_or_throw<json>(n, "encoding");
+    const json net = json_get_or_throw<json>(n, "network");
+    const json opt = json_get_or_throw<json>(n, "optimizer");
+    if (json_get_or_throw<string>(enc, "otype") != "DenseGrid" || json_get_optional<string>(enc, "interpolation", "Linear") != "Linear")
+        throw std::runtime_error("network.encoding: this build implements DenseGrid with Linear interpolation");
+    if (json_get_optional<string>(net, "activation", "ReLU") != "ReLU" ||
+        json_get_optional<string>(net, "output_activation", "None") != "None")
+        throw std::runtime_error("network.network: this build implements ReLU hidden / None output activations");
+    if (json_get_or_throw<string>(opt, "otype") != "Ema")
+        throw std::runtime_error("network.optimizer: this build implements Ema{Adam}");
+    const json adam = json_get_or_throw<json>(opt, "nested");
+    if (json_get_or_throw<string>(adam, "otype") != "Adam") throw std::runtime_error("network.optimizer.nested: Adam expected");
+    wost_net_config c{};
+    c.n_levels = json_get_or_throw<int>(enc, "n_levels");
+    c.n_features_per_level = json_get_or_throw<int>(enc, "n_features_per_level");
+    c.base_resolution = json_get_or_throw<int>(enc, "base_resolution");
+    c.per_level_scale = json_get_or_throw<float>(enc, "per_level_scale");
+    c.n_neurons = json_get_or_throw<int>(net, "n_neurons");
+    c.n_hidden_layers = json_get_or_throw<int>(net, "n_hidden_layers");
+    c.n_output = 33;   // 8 lobes x (lambda, kappa, mu.x, mu.y) + selection logit (guided/parameters.h:16-24)
+    c.learning_rate = json_get_or_throw<float>(adam, "learning_rate");
+    c.beta1 = json_get_or_throw<float>(adam, "beta1");
+    c.beta2 = json_get_or_throw<float>(adam, "beta2");
+    c.epsilon = json_get_or_throw<float>(adam, "epsilon");
+    c.l2_reg = json_get_or_throw<float>(adam, "l2_reg");
+    c.ema_decay = json_get_or_throw<float>(opt, "decay");
+    return c;
+}
+
+GuidedIntegrator<2>::GuidedIntegrator(Problem<2> &problem_, const IntegratorSettings &settings, const fs::path &basePath_,
+                                      int device_)
+    : IntegratorOutputs(settings.frameSize, basePath_), problem(problem_), integratorSettings(settings), device(device_)
+{
+    if (settings.saveSppMetricsDuration > 0 || settings.saveTimeMetricsDuration > 0)
+        ELAINA_LOG(Warning, "periodic metric dumps are not built (SURVEY.md 8f.4); ignoring save*Metrics* settings");
+}
+
+GuidedIntegrator<2>::~GuidedIntegrator()
+{
+    if (handle) wost_guided_destroy(handle);
+}
+
+void GuidedIntegrator<2>::resetNetwork(const json &config)
+{
+    if (handle) {
+        wost_guided_destroy(handle);
+        handle = nullptr;
+    }
+    const IntegratorSettings &s = integratorSettings;
+    const wost_net_config nc = network_config_from_json(config);
+    const wost_scene_desc sd = problem.scene_desc(s.frameSize.x, s.frameSize.y);
+    wost_guided_settings gs{};
+    gs.width = s.frameSize.x; gs.height = s.frameSize.y; gs.spp = s.samplesPerPixel; gs.max_depth = (int32_t)s.maxWalkingDepth;
+    gs.eps_shell = s.epsilonShell;
+    gs.train_spp_count = (int32_t)s.trainSppCount;
+    gs.uniform_fraction_training = s.uniformFractionInTrainingPhase;
+    gs.uniform_fraction_guiding = s.uniformFractionInGuidingPhase;
+    gs.max_guided_depth_training = (int32_t)s.maxGuidedDepthInTrainingPhase;
+    gs.max_guided_depth_guiding = (int32_t)s.maxGuidedDepthInGuidingPhase;
+    const AABB2f &b = problem.getAABB();
+    gs.aabb_min[0] = b.min.x; gs.aabb_min[1] = b.min.y; gs.aabb_max[0] = b.max.x; gs.aabb_max[1] = b.max.y;
+    // the reference's compile-time training constants (parameters.h:7-14, integrator.h:237-239)
+    gs.max_train_depth = 3; gs.batch_size = 65536 * 8; gs.min_batch_size = 65536; gs.batches_per_spp = 5;
+    gs.train_pixel_stride = 1; gs.train_pixel_offset = 0; gs.loss_scale = 128.0f;
+    check_wost(wost_guided_create(&sd, &gs, &nc, /* ELAINA_DEFAULT_RNG_SEED */ 42, device, &handle), "wost_guided_create");
+}
+
+wost_handle GuidedIntegrator<2>::scene_handle()
+{
+    if (!handle) throw std::runtime_error("GuidedIntegrator: resetNetwork() has not been called");
+    wost_handle scene = nullptr;
+    check_wost(wost_guided_scene(handle, &scene), "wost_guided_scene");
+    return scene;
+}
+
+uint64_t GuidedIntegrator<2>::solve()
+{
+    if (!handle) throw std::runtime_error("GuidedIntegrator: resetNetwork() has not been called");
+    const auto start = std::chrono::high_resolution_clock::now();
+    std::vector<float> &f = channels[(size_t)ExportImageChannel::SOLUTION];
+    f.assign((size_t)frameSize_.x * frameSize_.y * 3, 0.0f);
+    check_wost(wost_guided_solve(handle, f.data(), &last_stats), "wost_guided_solve");
+    const auto end = std::chrono::high_resolution_clock::now();
+    return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count();
+}
+
+void GuidedIntegrator<2>::renderDirichletSDF() { render_sdf(scene_handle(), WOST_MESH_DIRICHLET, ExportImageChannel::DIRICHLET_SDF); }
+
+void GuidedIntegrator<2>::renderSilhouetteSDF() { render_sdf(scene_handle(), WOST_MESH_NEUMANN, ExportImageChannel::NEUMANN_SDF); }
+
+void GuidedIntegrator<2>::renderSource()
+{
+    throw std::runtime_error("renderSource: the source term is outside this build's scope (SURVEY.md 8f.2)");
+}
+
+void GuidedIntegrator<2>::queryNetwork(const VectorType &p)
+{
+    if (!handle) throw std::runtime_error("GuidedIntegrator: resetNetwork() has not been called");
+    float raw[33];
+    const float xy[2] = {p.x, p.y};
+    check_wost(wost_guided_query_network(handle, xy, 1, raw), "wost_guided_query_network");
+    ELAINA_LOG(Info, "VMM @ (%f, %f): ", p.x, p.y);
+    float total = 0.0f;
+    float lambda[8];
+    for (int k = 0; k < 8; ++k) total += lambda[k] = std::exp(std::fmin(std::fmax(raw[4 * k], -10.0f), 15.0f));
+    for (int k = 0; k < 8; ++k) {
+        const float nn = std::sqrt(raw[4 * k + 2] * raw[4 * k + 2] + raw[4 * k + 3] * raw[4 * k + 3]);
+        ELAINA_LOG(Info, "  lobe %d: weight %.4f kappa %.4f mu (%.4f, %.4f)", k, lambda[k] / total,
+                   std::exp(std::fmin(std::fmax(raw[4 * k + 1], -10.0f), 15.0f)), raw[4 * k + 2] / nn, raw[4 * k + 3] / nn);
+    }
+    ELAINA_LOG(Info, "  selection probability %.4f", 1.0f / (1.0f + std::exp(-raw[32])));
+}
+
+}  // namespace elaina

@@ -8,6 +8,7 @@
 #include "../../../../include/wost.h"
 #include "core/common.h"
 #include "core/problem.h"
+#include "integrator/common.h"
 
 namespace elaina {
 
@@ -27,7 +28,7 @@ struct UniformIntegratorSettings {
 
 template <unsigned int DIM> class UniformIntegrator;
 
-template <> class UniformIntegrator<2> {
+template <> class UniformIntegrator<2> : public IntegratorOutputs {
 public:
     using IntegratorSettings = UniformIntegratorSettings;
     using VectorType = Vector2f;
@@ -39,32 +40,20 @@ public:
     UniformIntegrator &operator=(const UniformIntegrator &) = delete;
 
     uint64_t solve();  // wall milliseconds, like the reference (integrator.cu:666-672)
-    void exportImage(ExportImageChannel imageType, const string &file_name);
-    void exportEnergy(ExportImageChannel imageType, ToneMapping tone, const string &file_name);
     void renderDirichletSDF();
     void renderSilhouetteSDF();
     void renderSource();
     void queryNetwork(const VectorType &p);
 
     const IntegratorSettings &get_integratorSettings() const { return integratorSettings; }
-    const fs::path &get_basePath() const { return basePath; }
     const Problem<2> &get_problem() const { return problem; }
     const wost_stats &get_last_stats() const { return last_stats; }
-    // RGB per pixel of a channel (empty until that channel has been produced)
-    const std::vector<float> &get_channel(ExportImageChannel c) const { return channels[(size_t)c]; }
 
 private:
     Problem<2> &problem;
     IntegratorSettings integratorSettings;
-    fs::path basePath;
     wost_handle handle{nullptr};
     wost_stats last_stats{};
-    std::vector<float> channels[(size_t)ExportImageChannel::CHANNEL_COUNT];
 };
-
-// image writers for the raw field: binary PFM (fp32, what parity is measured on) and an
-// 8-bit PPM preview.  EXR/PNG and the colormaps are "next" rows.
-void write_pfm(const fs::path &path, int width, int height, const std::vector<float> &rgb);
-void write_ppm(const fs::path &path, int width, int height, const std::vector<float> &rgb);
 
 }  // namespace elaina

@@ -7,6 +7,7 @@
 
 #include "core/problem.h"
 #include "exec.h"
+#include "integrator/guided/integrator.h"
 #include "integrator/uniform/integrator.h"
 
 using namespace elaina;
@@ -39,6 +40,28 @@ static int selftest()
     threw = false;
     try { UniformIntegratorSettings::from_json(json::parse("{\"frameSize\":[1,1]}")); } catch (const std::runtime_error &) { threw = true; }
     expect(threw, "missing setting throws");
+    // guided settings + network section binding
+    const json gst = json::parse(R"({"frameSize":[64,32],"debugPixel":0,"samplesPerPixel":4,"maxWalkingDepth":16,
+        "saveSppMetricsDuration":-1,"saveSppMetricsUntil":-1,"saveTimeMetricsDuration":-1,"epsilonShell":1,
+        "trainSppCount":2,"uniformFractionInTrainingPhase":0.5,"uniformFractionInGuidingPhase":0.25,
+        "maxGuidedDepthInTrainingPhase":10,"maxGuidedDepthInGuidingPhase":7})");
+    const GuidedIntegratorSettings g2 = GuidedIntegratorSettings::from_json(gst);
+    expect(g2.trainSppCount == 2 && g2.uniformFractionInGuidingPhase == 0.25f && g2.maxGuidedDepthInGuidingPhase == 7, "guided settings");
+    threw = false;
+    try { GuidedIntegratorSettings::from_json(st); } catch (const std::runtime_error &) { threw = true; }
+    expect(threw, "missing guided setting throws");
+    const json net = json::parse(R"({"encoding":{"otype":"DenseGrid","interpolation":"Linear","n_levels":8,
+        "n_features_per_level":4,"base_resolution":8,"per_level_scale":1.405},"loss":{"otype":"L2"},
+        "network":{"otype":"FullyFusedMLP","activation":"ReLU","output_activation":"None","n_neurons":64,"n_hidden_layers":3},
+        "optimizer":{"otype":"Ema","decay":0.95,"nested":{"otype":"Adam","beta1":0.9,"beta2":0.99,"epsilon":1e-15,
+        "l2_reg":1e-6,"learning_rate":0.008}}})");
+    const wost_net_config nc = network_config_from_json(net);
+    expect(nc.n_levels == 8 && nc.n_neurons == 64 && nc.n_hidden_layers == 3 && nc.n_output == 33 && nc.ema_decay == 0.95f &&
+               nc.learning_rate == 0.008f, "network section");
+    threw = false;
+    try { network_config_from_json(json::parse(R"({"encoding":{"otype":"HashGrid"},"network":{},"optimizer":{}})")); }
+    catch (const std::runtime_error &) { threw = true; }
+    expect(threw, "unsupported encoding throws");
     // OBJ polylines
     const fs::path tmp = fs::temp_directory_path() / "elaina_selftest.obj";
     { std::ofstream f(tmp); f << "# c\no P\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nl 1 2 3\nl -1 1\n"; }

@@ -243,9 +243,23 @@ int wost_guided_create(const wost_scene_desc *scene, const wost_guided_settings 
 /* The integrator's network, borrowed (valid until wost_guided_destroy): get/set parameters,
  * queryNetwork-style inference (integrator.cu:566-615). */
 int wost_guided_network(wost_guided_handle h, wost_net_handle *net);
+/* The uploaded scene, borrowed: SDF renders and the batched geometric queries of the guided
+ * integrator's scene go through the wost_* entry points above. */
+int wost_guided_scene(wost_guided_handle h, wost_handle *scene);
+/* queryNetwork (integrator.cu:566-615): raw[n*33] mixture parameters of the inference (EMA)
+ * network at world positions pts[n*2] (normalizeSpatialCoord applied inside). */
+int wost_guided_query_network(wost_guided_handle h, const float *pts, int32_t n, float *raw);
 /* GuidedIntegrator<2>::solve(): all samples, training passes included; field_rgb receives
  * width*height*3 floats = solution / spp.  Starts from the network's current state. */
 int wost_guided_solve(wost_guided_handle h, float *field_rgb, wost_guided_stats *stats);
+/* Same solve for the 8x8-pixel tiles t with t % shard_count == shard_index (the tiling of
+ * wost_solve_sharded).  Every shard trains its OWN copy of the guiding network on the records of
+ * its own pixels -- the estimator is unbiased for any network state, so no collective is needed
+ * on the data path.  field_rgb_dev: DEVICE buffer of width*height*3 floats; pixels of other
+ * shards are written as 0, so a sum-reduce over ranks (RCCL) yields the full field.  Returns
+ * after the work has completed. */
+int wost_guided_solve_sharded(wost_guided_handle h, int32_t shard_index, int32_t shard_count,
+                              float *field_rgb_dev, wost_guided_stats *stats);
 /* The training set built by the most recent training pass, in (pixel, record) order
  * (generate_training_data, train.h:423-471): xy[n*2] normalised positions, dir[n*2],
  * solution[n*3] = |record.solution / record.thp|, dir_pdf[n], normal[n*2], on_neumann[n].

@@ -74,3 +74,59 @@ def test_ownership_partitions_the_frame():
             assert np.all(total == 1)
             if w * h >= 64 * 64:
                 assert max(sizes) - min(sizes) <= 64 * ((h + 7) // 8)
+
+
+def _guided_worker(rank, world, port, w, h, spp, depth, q):
+    """guided integrator, BASELINE config 5 in miniature: every rank owns its tiles AND its own
+    network; with a frozen network the union is exactly the single-process field"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from conftest import box_problem
+    from elaina_amd import distributed as D
+    from oracle.oracle import Oracle, default_net_config, guided_settings
+    r, wsz, _ = D.init_process_group("gloo")
+    prob = box_problem(d_sides=(0, 2), n_sides=(1, 3), value=lambda x, y: y, flux=lambda x, y, s: 0.0, n_per_side=8)
+    sd = prob.as_dict()
+    sd["mask"] = D.owned_mask(w, h, r, wsz).astype(np.uint8)
+    o = Oracle()
+    cfg = default_net_config()
+    params = np.random.default_rng(5).uniform(-0.3, 0.3, o.net_n_params(cfg)).astype(np.float32)
+    gs = guided_settings(w, h, spp, depth, 1e-3, (-0.1, -0.1), (1.1, 1.1), train_spp_count=0)
+    res = o.solve_guided(sd, gs, cfg, params, threads=2)
+    field = torch.from_numpy(res["field"].reshape(-1).copy())
+    D.reduce_field(field, wsz)
+    steps = torch.tensor([res["walk_steps"], res["guided_steps"]], dtype=torch.int64)
+    dist.all_reduce(steps)
+    if r == 0:
+        q.put((field.numpy().reshape(-1, 3), steps.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_guided_solve_with_frozen_network(oracle):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import box_problem
+    from oracle.oracle import default_net_config, guided_settings
+    w, h, spp, depth = 24, 16, 2, 24
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guided_worker, args=(r, 2, port, w, h, spp, depth, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    field, (steps, guided) = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    prob = box_problem(d_sides=(0, 2), n_sides=(1, 3), value=lambda x, y: y, flux=lambda x, y, s: 0.0, n_per_side=8)
+    cfg = default_net_config()
+    params = np.random.default_rng(5).uniform(-0.3, 0.3, oracle.net_n_params(cfg)).astype(np.float32)
+    gs = guided_settings(w, h, spp, depth, 1e-3, (-0.1, -0.1), (1.1, 1.1), train_spp_count=0)
+    ref = oracle.solve_guided(prob.as_dict(), gs, cfg, params, threads=4)
+    assert steps == ref["walk_steps"] and guided == ref["guided_steps"]
+    assert np.array_equal(field, ref["field"])

@@ -270,3 +270,53 @@ def test_gpu_guided_on_ladybug_agrees_with_uniform(ladybug, oracle):
     assert abs(float(gi.solution.mean()) - float(ref.mean())) < 0.01 * abs(float(ref.mean())) + 1e-3
     assert rms_g < 1.5 * rms_u + 1e-3, (rms_g, rms_u)
     gi.close()
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_guided_solve(oracle):
+    """wost_guided_solve_sharded: with a frozen network the shards sum to exactly the full-frame
+    field; with training every shard fits its own network and the sum stays unbiased"""
+    import torch
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    prob = laplace_box()
+    w, h = 40, 24
+    cfg = default_net_config()
+    p = np.random.default_rng(5).uniform(-0.3, 0.3, oracle.net_n_params(cfg)).astype(np.float32)
+
+    def make(train_spp, spp):
+        st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=train_spp, maxWalkingDepth=32,
+                                      epsilonShell=EPS, batchSize=1024, minBatchSize=256)
+        gi = GuidedIntegrator(prob, st, AABB, seed=3)
+        gi.network.set_params(p)
+        return gi
+
+    full = make(0, 4)
+    full.solve()
+    total = torch.zeros(w * h * 3, device="cuda")
+    steps = 0
+    for r in range(3):
+        gi = make(0, 4)
+        buf = torch.full((w * h * 3,), 7.0, device="cuda")      # must be overwritten, other shards' pixels with 0
+        st = gi.solve_sharded(r, 3, buf.data_ptr())
+        torch.cuda.synchronize()
+        total += buf
+        steps += st["walk_steps"]
+        gi.close()
+    assert np.array_equal(total.cpu().numpy().reshape(-1, 3), full.solution)
+    assert steps == full.last_stats["walk_steps"]
+    full.close()
+    # with training: each shard trains on its own records
+    total = torch.zeros(w * h * 3, device="cuda")
+    opt = 0
+    for r in range(2):
+        gi = make(8, 16)
+        buf = torch.zeros(w * h * 3, device="cuda")
+        st = gi.solve_sharded(r, 2, buf.data_ptr())
+        torch.cuda.synchronize()
+        total += buf
+        opt += st["optimizer_steps"]
+        gi.close()
+    assert opt > 0
+    ys = eval_ys(prob, w, h)
+    f = total.cpu().numpy().reshape(-1, 3)[:, 0].reshape(h, w)
+    assert abs(float(np.mean(f - ys))) < 0.03

@@ -55,3 +55,23 @@ def test_run_expr_end_to_end_matches_oracle(tmp_path, oracle, ladybug):
     sdf = export_scene.read_pfm(exp / "dirichlet_sdf.pfm")[:, 0]
     assert np.array_equal(sdf, oracle.render_dirichlet_sdf(ladybug.as_dict(), 64, 64))
     assert os.path.exists(exp / "solution.ppm") and os.path.exists(exp / "solution_energy.pfm")
+
+
+@pytest.mark.gpu
+def test_run_expr_guided_configuration(tmp_path, ladybug):
+    """the reference's n.json shape (type "guided" + network section) through the C++ host"""
+    import export_scene
+    from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+    conf = export_scene.export("ladybug", str(tmp_path), frame=192, spp=8, depth=48, integrator="guided")
+    out = subprocess.run([_exe(), conf], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    exp = tmp_path / "exp" / "ladybug_n"
+    res = json.load(open(exp / "result.json"))
+    assert res["guided_steps"] > 0 and res["optimizer_steps"] > 0 and res["walk_steps"] > res["guided_steps"]
+    assert "selection probability" in out.stderr          # print_network -> queryNetwork
+    field = export_scene.read_pfm(exp / "solution.pfm")
+    ui = UniformIntegrator(ladybug, UniformIntegratorSettings(frameSize=(192, 192), samplesPerPixel=64, maxWalkingDepth=48,
+                                                              epsilonShell=1.0))
+    ui.solve()
+    assert abs(float(field.mean()) - float(ui.solution.mean())) < 0.02 * abs(float(ui.solution.mean()))
+    assert np.array_equal(export_scene.read_pfm(exp / "dirichlet_sdf.pfm")[:, 0], ui.renderDirichletSDF())

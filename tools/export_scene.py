@@ -32,7 +32,21 @@ def write_colors(path, colors):
         json.dump({"ColorConfigurations": cfg}, f)
 
 
-def export(scene, out_dir, frame=128, spp=16, depth=32, exp_name=None):
+# the "network" section of the reference's guided configurations (data/ladybug/n.json:49-81)
+NETWORK_SECTION = {
+    "encoding": {"otype": "DenseGrid", "interpolation": "Linear", "n_levels": 8, "n_features_per_level": 4,
+                 "base_resolution": 8, "per_level_scale": 1.4049999713897705},
+    "loss": {"otype": "L2"},
+    "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
+                "n_hidden_layers": 3},
+    "optimizer": {"otype": "Ema", "decay": 0.949999988079071,
+                  "nested": {"otype": "Adam", "adabound": False, "beta1": 0.8999999761581421, "beta2": 0.9900000095367432,
+                             "epsilon": 1.0000000036274937e-15, "l2_reg": 9.999999974752427e-07,
+                             "learning_rate": 0.00800000037997961}},
+}
+
+
+def export(scene, out_dir, frame=128, spp=16, depth=32, exp_name=None, integrator="uniform", train_spp=None):
     p = Problem.load_scene(scene)
     os.makedirs(out_dir, exist_ok=True)
     write_obj(os.path.join(out_dir, "model.obj"), p.d_verts, p.d_segs)
@@ -55,6 +69,14 @@ def export(scene, out_dir, frame=128, spp=16, depth=32, exp_name=None):
             "mesh": {"dirichlet_path": os.path.join(out_dir, "model.obj"),
                      "vertex_color_dirichlet_path": os.path.join(out_dir, "color.json"),
                      "neumann_path": os.path.join(out_dir, "boundary.obj")}}}
+    if integrator == "guided":
+        conf["exp_name"] = exp_name or (scene + "_n")
+        conf["integrator"]["type"] = "guided"
+        conf["integrator"]["setting"].update({
+            "trainSppCount": spp if train_spp is None else train_spp, "uniformFractionInTrainingPhase": 0.5,
+            "uniformFractionInGuidingPhase": 0.5, "maxGuidedDepthInTrainingPhase": 10, "maxGuidedDepthInGuidingPhase": 10})
+        conf["network"] = NETWORK_SECTION
+        conf["print_network"] = True
     path = os.path.join(out_dir, "conf.json")
     with open(path, "w") as f:
         json.dump(conf, f, indent=4)
@@ -77,5 +99,6 @@ if __name__ == "__main__":
     ap.add_argument("--frame", type=int, default=128)
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--depth", type=int, default=32)
+    ap.add_argument("--integrator", default="uniform", choices=["uniform", "guided"])
     a = ap.parse_args()
-    print(export(a.scene, a.out_dir, a.frame, a.spp, a.depth))
+    print(export(a.scene, a.out_dir, a.frame, a.spp, a.depth, integrator=a.integrator))
