@@ -11,7 +11,9 @@
 // (DESIGN.md section 8).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -139,6 +141,156 @@ __global__ __launch_bounds__(kNetBlock) void net_forward_kernel(NetLayout L, con
     dense_layer(wt + L.w_off[L.n_hidden], L.n_out_padded, n_in, in, o, false);
     if (valid)
         for (int k = 0; k < L.n_out; ++k) out[(size_t)p * L.n_out + k] = act(o, k);
+}
+
+// ---- MFMA forward -------------------------------------------------------------------------------
+// The MLP is the one dense contraction of the whole path.  v_mfma_f32_16x16x4_f32
+// is bit-for-bit a k-ordered fmaf chain, so this kernel returns exactly what net_forward_kernel
+// (and the CPU restatement) returns, at MFMA operand bandwidth instead of one LDS read per 8 FMAs.
+//
+// One wave owns 2 x 16 points.  For out[r][p] = sum_k W[r][k] in[k][p] the A operand is a
+// 16-row tile of W, the B operand the activations: lane (i = l&15, g = l>>4) supplies
+// in[4s + g][point i] at k-step s and receives D[4g + c][point i] in accumulator register c.
+// The rows of every A tile are stored PERMUTED (physical row 4a+b = logical row 4b+a), so that
+// register c of row tile rt holds logical feature 16rt + 4c + g: exactly the B operand of k-step
+// s = 4rt + c of the next layer.  Layer outputs never leave the registers and the k order stays
+// ascending.  Weight fragments (13 312 floats) sit in LDS in lane order: one conflict-free
+// ds_read_b32 per MFMA pair.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kMfmaSub = 2;   // 16-point subtiles per wave iteration
+
+// frag[w_off[layer] + (rt * S + s) * 64 + l] = W[16rt + 4((l&15)&3) + ((l&15)>>2)][4s + (l>>4)]
+__global__ void fragment_mlp_kernel(NetLayout L, const float *src, float *dst)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L.n_mlp) return;
+    int layer = 0;
+    while (layer < L.n_hidden && e >= L.w_off[layer + 1]) ++layer;
+    const int n_i = layer == 0 ? L.enc : L.n_neurons;
+    const int S = n_i / 4;
+    const uint32_t f = e - L.w_off[layer];
+    const uint32_t l = f & 63u, t = f >> 6;
+    const uint32_t rt = t / S, s = t % S;
+    const uint32_t i = l & 15u, g = l >> 4;
+    const uint32_t row = 16 * rt + 4 * (i & 3u) + (i >> 2), k = 4 * s + g;
+    dst[e] = src[L.w_off[layer] + row * n_i + k];
+}
+
+template <int S, int RT>
+__device__ __forceinline__ void mfma_layer(const float *wf, int lane, const float (&b)[kMfmaSub][16], f32x4_t (&acc)[kMfmaSub][4])
+{
+#pragma unroll
+    for (int u = 0; u < kMfmaSub; ++u)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[u][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const float a = wf[(rt * S + s) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < kMfmaSub; ++u) acc[u][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[u][s], acc[u][rt], 0, 0, 0);
+        }
+    }
+}
+
+// ENC = encoded width, H = neurons, NH = hidden layers (the first takes ENC inputs), NOP = padded outputs
+template <int ENC, int H, int NH, int NOP, bool SAVE>
+__global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, const float *params, const float *frag,
+                                                                  const float *xy, int n, const uint32_t *n_dev, float *out,
+                                                                  float *acts)
+{
+    static_assert(ENC % 4 == 0 && ENC <= 64 && H % 16 == 0 && H <= 64 && NOP % 16 == 0 && NOP <= 64, "shape");
+    extern __shared__ float lds[];
+    __shared__ float s_scale[kNetMaxLevels];
+    __shared__ uint32_t s_res[kNetMaxLevels], s_off[kNetMaxLevels + 1];
+    float *wfrag = lds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *stage = lds + L.n_mlp + wave * (kMfmaSub * 16 * ENC);
+    for (uint32_t e = threadIdx.x; e < L.n_mlp; e += 256) wfrag[e] = frag[e];
+    if (threadIdx.x <= (unsigned)L.n_levels) {
+        s_off[threadIdx.x] = L.level_off[threadIdx.x];
+        if (threadIdx.x < (unsigned)L.n_levels) {
+            s_scale[threadIdx.x] = L.scale[threadIdx.x];
+            s_res[threadIdx.x] = (uint32_t)L.res[threadIdx.x];
+        }
+    }
+    __syncthreads();
+    if (n_dev) n = (int)*n_dev;
+    const int i = lane & 15, g = lane >> 4;
+    const int n_tiles = (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
+    const float *grid = params + L.n_mlp;
+    const int astride = ENC + NH * H;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        int pt[kMfmaSub];
+        bool valid[kMfmaSub];
+        // ---- encoding: lane (i, g) interpolates the levels lv = g, g + 4, ... of its point
+#pragma unroll
+        for (int u = 0; u < kMfmaSub; ++u) {
+            pt[u] = (tile * kMfmaSub + u) * 16 + i;
+            valid[u] = pt[u] < n;
+            const float x = valid[u] ? xy[2 * (size_t)pt[u]] : 0.5f, y = valid[u] ? xy[2 * (size_t)pt[u] + 1] : 0.5f;
+            for (int lv = g; lv < L.n_levels; lv += 4) {
+                const float sc = s_scale[lv];
+                const uint32_t res = s_res[lv], lo = s_off[lv];
+                const uint32_t n_level = s_off[lv + 1] - lo;
+                float px = __builtin_fmaf(sc, x, 0.5f), py = __builtin_fmaf(sc, y, 0.5f);
+                const float fx = floorf(px), fy = floorf(py);
+                px -= fx;
+                py -= fy;
+                const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+                float f[8];
+                for (int q = 0; q < L.n_features; ++q) f[q] = 0.0f;
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
+                    const float w = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
+                    const uint32_t idx = (cx + cy * res) % n_level;
+                    const float *gp = grid + (size_t)(lo + idx) * L.n_features;
+                    for (int q = 0; q < L.n_features; ++q) f[q] += w * gp[q];
+                }
+                for (int q = 0; q < L.n_features; ++q) {
+                    stage[(u * 16 + i) * ENC + lv * L.n_features + q] = f[q];
+                    if (SAVE && valid[u]) acts[(size_t)pt[u] * astride + lv * L.n_features + q] = f[q];
+                }
+            }
+        }
+        __threadfence_block();      // the wave reads back what its own lanes wrote
+        float b[kMfmaSub][16];
+#pragma unroll
+        for (int u = 0; u < kMfmaSub; ++u)
+#pragma unroll
+            for (int s = 0; s < ENC / 4; ++s) b[u][s] = stage[(u * 16 + i) * ENC + 4 * s + g];
+        __threadfence_block();      // before the next iteration overwrites the staging area
+        f32x4_t acc[kMfmaSub][4];
+        // ---- hidden layers: ReLU, the accumulators become the next B operands
+#pragma unroll
+        for (int layer = 0; layer < NH; ++layer) {
+            if (layer == 0) mfma_layer<ENC / 4, H / 16>(wfrag + L.w_off[0], lane, b, acc);
+            else mfma_layer<H / 4, H / 16>(wfrag + L.w_off[layer], lane, b, acc);
+#pragma unroll
+            for (int u = 0; u < kMfmaSub; ++u)
+#pragma unroll
+                for (int rt = 0; rt < H / 16; ++rt)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float v = fmaxf(acc[u][rt][c], 0.0f);
+                        b[u][4 * rt + c] = v;
+                        if (SAVE && valid[u]) acts[(size_t)pt[u] * astride + ENC + layer * H + 16 * rt + 4 * c + g] = v;
+                    }
+        }
+        // ---- output layer
+        mfma_layer<H / 4, NOP / 16>(wfrag + L.w_off[NH], lane, b, acc);
+#pragma unroll
+        for (int u = 0; u < kMfmaSub; ++u)
+#pragma unroll
+            for (int rt = 0; rt < NOP / 16; ++rt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int o = 16 * rt + 4 * c + g;
+                    if (valid[u] && o < L.n_out) out[(size_t)pt[u] * L.n_out + o] = acc[u][rt][c];
+                }
+    }
 }
 
 // backward, one thread per point: propagates dL/dout to every layer input (kept per point in
@@ -342,7 +494,9 @@ struct wost_net {
     NetLayout L{};
     uint32_t n_params = 0;
     float *params = nullptr, *inference = nullptr, *m1 = nullptr, *m2 = nullptr, *ema_raw = nullptr, *grad = nullptr;
-    float *params_t = nullptr, *inference_t = nullptr;   // transposed MLP matrices (forward pass)
+    float *params_t = nullptr, *inference_t = nullptr;   // transposed MLP matrices (scalar forward pass)
+    float *params_f = nullptr, *inference_f = nullptr;   // MFMA A-fragment order (MFMA forward pass)
+    bool use_mfma = false;
     int step = 0;
     // scratch (grown on demand)
     float *d_xy = nullptr, *d_out = nullptr, *d_dl = nullptr, *d_acts = nullptr, *d_deltas = nullptr, *d_denc = nullptr;
@@ -360,6 +514,39 @@ static int refresh_transposed(wost_net *h, hipStream_t stream)
     const unsigned g = (h->L.n_mlp + 255) / 256;
     hipLaunchKernelGGL(transpose_mlp_kernel, dim3(g), dim3(256), 0, stream, h->L, h->params, h->params_t);
     hipLaunchKernelGGL(transpose_mlp_kernel, dim3(g), dim3(256), 0, stream, h->L, h->inference, h->inference_t);
+    if (h->use_mfma) {
+        hipLaunchKernelGGL(fragment_mlp_kernel, dim3(g), dim3(256), 0, stream, h->L, h->params, h->params_f);
+        hipLaunchKernelGGL(fragment_mlp_kernel, dim3(g), dim3(256), 0, stream, h->L, h->inference, h->inference_f);
+    }
+    NET_TRY(hipGetLastError());
+    return WOST_OK;
+}
+
+// forward pass on device pointers: MFMA kernel for the reference's network shape, the scalar
+// kernel otherwise (or when WOST_NET_SCALAR=1 asks for the comparison path)
+static int launch_forward(wost_net *h, bool use_inference_params, const float *xy_dev, int n, const uint32_t *n_dev,
+                          float *out_dev, float *acts_dev, hipStream_t stream)
+{
+    if (n <= 0) return WOST_OK;
+    const NetLayout &L = h->L;
+    const float *p = use_inference_params ? h->inference : h->params;
+    if (h->use_mfma) {
+        const float *f = use_inference_params ? h->inference_f : h->params_f;
+        const size_t lds = ((size_t)L.n_mlp + 4 * kMfmaSub * 16 * 32) * sizeof(float);
+        const int n_tiles = (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
+        const unsigned grid = (unsigned)std::min((n_tiles + 3) / 4, 512);
+        if (acts_dev)
+            hipLaunchKernelGGL((net_forward_mfma_kernel<32, 64, 3, 48, true>), dim3(grid), dim3(256), lds, stream, L, p, f, xy_dev,
+                               n, n_dev, out_dev, acts_dev);
+        else
+            hipLaunchKernelGGL((net_forward_mfma_kernel<32, 64, 3, 48, false>), dim3(grid), dim3(256), lds, stream, L, p, f, xy_dev,
+                               n, n_dev, out_dev, acts_dev);
+    } else {
+        const float *t = use_inference_params ? h->inference_t : h->params_t;
+        const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
+        hipLaunchKernelGGL(net_forward_kernel, dim3((n + kNetBlock - 1) / kNetBlock), dim3(kNetBlock), lds, stream, L, p, t, xy_dev,
+                           n, n_dev, out_dev, acts_dev);
+    }
     NET_TRY(hipGetLastError());
     return WOST_OK;
 }
@@ -385,7 +572,7 @@ static void net_free(wost_net *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    for (float *p : {h->params, h->inference, h->params_t, h->inference_t, h->m1, h->m2, h->ema_raw, h->grad, h->d_xy, h->d_out, h->d_dl, h->d_acts, h->d_deltas, h->d_denc})
+    for (float *p : {h->params, h->inference, h->params_t, h->inference_t, h->params_f, h->inference_f, h->m1, h->m2, h->ema_raw, h->grad, h->d_xy, h->d_out, h->d_dl, h->d_acts, h->d_deltas, h->d_denc})
         if (p) (void)hipFree(p);
     delete h;
 }
@@ -396,13 +583,7 @@ namespace wost {
 int net_inference_dev(wost_net *h, const float *xy_dev, const uint32_t *count_dev, int max_n, float *out_dev,
                       bool use_inference_params, hipStream_t stream)
 {
-    if (max_n <= 0) return WOST_OK;
-    const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
-    hipLaunchKernelGGL(net_forward_kernel, dim3((max_n + kNetBlock - 1) / kNetBlock), dim3(kNetBlock), lds, stream, h->L,
-                       use_inference_params ? h->inference : h->params, use_inference_params ? h->inference_t : h->params_t, xy_dev,
-                       max_n, count_dev, out_dev, (float *)nullptr);
-    NET_TRY(hipGetLastError());
-    return WOST_OK;
+    return launch_forward(h, use_inference_params, xy_dev, max_n, count_dev, out_dev, nullptr, stream);
 }
 
 // forward with the training parameters, keeping activations; *out_dev = raw outputs
@@ -411,10 +592,8 @@ int net_forward_train_dev(wost_net *h, const float *xy_dev, int n, hipStream_t s
 {
     int rc = ensure_points(h, (size_t)n);
     if (rc != WOST_OK) return rc;
-    const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
-    hipLaunchKernelGGL(net_forward_kernel, dim3((n + kNetBlock - 1) / kNetBlock), dim3(kNetBlock), lds, stream, h->L, h->params,
-                       h->params_t, xy_dev, n, (const uint32_t *)nullptr, h->d_out, h->d_acts);
-    NET_TRY(hipGetLastError());
+    rc = launch_forward(h, false, xy_dev, n, nullptr, h->d_out, h->d_acts, stream);
+    if (rc != WOST_OK) return rc;
     *out_dev = h->d_out;
     *dl_dev = h->d_dl;
     return WOST_OK;
@@ -495,6 +674,12 @@ int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_
     h->cfg = *cfg;
     h->L = make_layout(*cfg);
     h->n_params = h->L.n_mlp + h->L.n_grid;
+    {
+        // the MFMA forward kernel is instantiated for the reference's network shape
+        const char *scalar = getenv("WOST_NET_SCALAR");
+        h->use_mfma = h->L.enc == 32 && h->L.n_neurons == 64 && h->L.n_hidden == 3 && h->L.n_out_padded == 48 &&
+                      h->L.n_features <= 8 && !(scalar && atoi(scalar) != 0);
+    }
     // initialisation (tiny-cuda-nn defaults): MLP xavier uniform, grid uniform(-1e-4, 1e-4)
     std::vector<float> init(h->n_params);
     uint64_t state = 0, inc = (54u << 1u) | 1u;
@@ -515,7 +700,7 @@ int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_
     for (uint32_t e = 0; e < L.n_grid; ++e) init[L.n_mlp + e] = (uniform() * 2.0f - 1.0f) * 1e-4f;
     const size_t bytes = (size_t)h->n_params * sizeof(float);
     hipError_t e = hipSuccess;
-    for (float **p : {&h->params, &h->inference, &h->m1, &h->m2, &h->ema_raw, &h->grad, &h->params_t, &h->inference_t})
+    for (float **p : {&h->params, &h->inference, &h->m1, &h->m2, &h->ema_raw, &h->grad, &h->params_t, &h->inference_t, &h->params_f, &h->inference_f})
         if (e == hipSuccess) e = hipMalloc((void **)p, bytes);
     if (e == hipSuccess) e = hipMemcpy(h->params, init.data(), bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->inference, init.data(), bytes, hipMemcpyHostToDevice);
@@ -579,11 +764,8 @@ int wost_net_inference(wost_net_handle h, const float *xy, int32_t n, float *out
     int rc = ensure_points(h, (size_t)n);
     if (rc != WOST_OK) return rc;
     NET_TRY(hipMemcpy(h->d_xy, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice));
-    const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
-    hipLaunchKernelGGL(net_forward_kernel, dim3((n + kNetBlock - 1) / kNetBlock), dim3(kNetBlock), lds, 0, h->L,
-                       use_inference_params ? h->inference : h->params, use_inference_params ? h->inference_t : h->params_t,
-                       h->d_xy, n, (const uint32_t *)nullptr, h->d_out, (float *)nullptr);
-    NET_TRY(hipGetLastError());
+    rc = launch_forward(h, use_inference_params != 0, h->d_xy, n, nullptr, h->d_out, nullptr, nullptr);
+    if (rc != WOST_OK) return rc;
     NET_TRY(hipMemcpy(out, h->d_out, (size_t)n * h->L.n_out * sizeof(float), hipMemcpyDeviceToHost));
     return WOST_OK;
 }
