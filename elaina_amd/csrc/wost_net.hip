@@ -293,6 +293,119 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
     }
 }
 
+// ---- MFMA backward ------------------------------------------------------------------------------
+// d_in[k][p] = relu'(h[k][p]) * sum_r W[r][k] d_out[r][p]: the same register-resident chain as the
+// forward pass, with A = tiles of W^T (rows = k, row-permuted like the forward fragments) and the
+// deltas as B operand; sums over r ascending, i.e. bit-identical to net_backward_kernel.
+// fragb[w_off[layer] + (kt * S + s) * 64 + l] = W[4s + (l>>4)][16kt + 4((l&15)&3) + ((l&15)>>2)], S = n_o / 4
+__global__ void fragment_mlp_t_kernel(NetLayout L, const float *src, float *dst)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L.n_mlp) return;
+    int layer = 0;
+    while (layer < L.n_hidden && e >= L.w_off[layer + 1]) ++layer;
+    const int n_i = layer == 0 ? L.enc : L.n_neurons, n_o = layer == L.n_hidden ? L.n_out_padded : L.n_neurons;
+    const int S = n_o / 4;
+    const uint32_t f = e - L.w_off[layer];
+    const uint32_t l = f & 63u, t = f >> 6;
+    const uint32_t kt = t / S, s = t % S;
+    const uint32_t i = l & 15u, g = l >> 4;
+    const uint32_t k = 16 * kt + 4 * (i & 3u) + (i >> 2), r = 4 * s + g;
+    dst[e] = src[L.w_off[layer] + r * n_i + k];
+}
+
+template <int ENC, int H, int NH, int NOP>
+__global__ __launch_bounds__(256, 2) void net_backward_mfma_kernel(NetLayout L, const float *fragb, const float *dl_dout,
+                                                                   const float *acts, int n, float *deltas, float *denc)
+{
+    extern __shared__ float lds[];
+    float *wfrag = lds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t e = threadIdx.x; e < L.n_mlp; e += 256) wfrag[e] = fragb[e];
+    __syncthreads();
+    const int i = lane & 15, g = lane >> 4;
+    const int n_tiles = (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
+    const int astride = ENC + NH * H, dstride = NOP + NH * H;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        int pt[kMfmaSub];
+        bool valid[kMfmaSub];
+        float b[kMfmaSub][16];
+#pragma unroll
+        for (int u = 0; u < kMfmaSub; ++u) {
+            pt[u] = (tile * kMfmaSub + u) * 16 + i;
+            valid[u] = pt[u] < n;
+#pragma unroll
+            for (int s = 0; s < NOP / 4; ++s) {
+                const int r = 4 * s + g;
+                const float v = (valid[u] && r < L.n_out) ? dl_dout[(size_t)pt[u] * L.n_out + r] : 0.0f;
+                b[u][s] = v;
+                if (valid[u]) deltas[(size_t)pt[u] * dstride + r] = v;
+            }
+        }
+        f32x4_t acc[kMfmaSub][4];
+#pragma unroll
+        for (int layer = NH; layer >= 1; --layer) {
+            if (layer == NH) mfma_layer<NOP / 4, H / 16>(wfrag + L.w_off[layer], lane, b, acc);
+            else mfma_layer<H / 4, H / 16>(wfrag + L.w_off[layer], lane, b, acc);
+#pragma unroll
+            for (int u = 0; u < kMfmaSub; ++u)
+#pragma unroll
+                for (int kt = 0; kt < H / 16; ++kt)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int k = 16 * kt + 4 * c + g;
+                        const float h = valid[u] ? acts[(size_t)pt[u] * astride + ENC + (layer - 1) * H + k] : 0.0f;
+                        const float v = h > 0.0f ? acc[u][kt][c] : 0.0f;
+                        b[u][4 * kt + c] = v;
+                        if (valid[u]) deltas[(size_t)pt[u] * dstride + NOP + (layer - 1) * H + k] = v;
+                    }
+        }
+        mfma_layer<H / 4, ENC / 16>(wfrag + L.w_off[0], lane, b, acc);
+#pragma unroll
+        for (int u = 0; u < kMfmaSub; ++u)
+#pragma unroll
+            for (int kt = 0; kt < ENC / 16; ++kt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (valid[u]) denc[(size_t)pt[u] * ENC + 16 * kt + 4 * c + g] = acc[u][kt][c];
+    }
+}
+
+// dW[r][k] += sum_p delta[p][r] * input[p][k] as MFMA over the point index: A = delta^T tile
+// (16 rows r x 4 points), B = input tile (4 points x 16 columns k).  One block = a chunk of
+// points, wave w owns the row tiles w, w+4, .. and all column tiles; partial sums leave through
+// one float atomic per (block, weight).
+template <int N_O, int N_I>
+__global__ __launch_bounds__(256) void weight_grad_mfma_kernel(const float *delta, int dstride, int doff, const float *input,
+                                                               int istride, int ioff, int n, int chunk, float *gW)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int p0 = blockIdx.x * chunk, p1 = min(n, p0 + chunk);
+    constexpr int KT = N_I / 16;
+    for (int rt = wave; rt < N_O / 16; rt += 4) {
+        f32x4_t acc[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) acc[kt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int p = p0; p < p1; p += 4) {
+            const bool ok = p + g < p1;
+            const float a = ok ? delta[(size_t)(p + g) * dstride + doff + 16 * rt + i] : 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const float bb = ok ? input[(size_t)(p + g) * istride + ioff + 16 * kt + i] : 0.0f;
+                acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc[kt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float v = acc[kt][c];
+                if (v != 0.0f) atomicAdd(gW + (size_t)(16 * rt + 4 * g + c) * N_I + 16 * kt + i, v);
+            }
+    }
+}
+
 // backward, one thread per point: propagates dL/dout to every layer input (kept per point in
 // `deltas`: n x (n_out_padded + n_hidden * n_neurons)) and to the encoding (`denc`: n x enc).
 // Weight and grid gradients are formed afterwards by weight_grad_kernel / grid_grad_kernel.
@@ -356,12 +469,14 @@ __global__ __launch_bounds__(kNetBlock) void net_backward_kernel(NetLayout L, co
 }
 
 // Gradient of the grid: every point adds w_corner * d_enc to the 4 corners of its cell on every
-// level.  Coarse levels are hit by thousands of points per entry, so a block first accumulates
-// the levels that fit into LDS there (ds_add_f32) and flushes each touched entry with ONE global
-// atomic; only the fine levels go to global memory directly.  Work item = (point, level):
-// neighbouring lanes read consecutive float4s of d_enc and hit different levels.
+// level.  Training points arrive in pixel order, so neighbouring lanes hit the SAME entries:
+// direct global float atomics cost 39 ms per 524 288-sample batch.  Instead a launch takes a
+// group of consecutive levels [lv0, lv1) whose accumulators fit into LDS, a block accumulates its
+// chunk of points there (ds_add_f32) and flushes each touched entry with ONE global atomic.
+// Work item = (point, level): neighbouring lanes read consecutive float4s of d_enc and hit
+// different levels.  use_lds = 0 (a level too large for LDS) scatters straight to global memory.
 __global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float *xy, const float *denc, int n, int chunk,
-                                                        int n_lds_levels, float *grad)
+                                                        int lv0, int lv1, int use_lds, float *grad)
 {
     extern __shared__ float acc[];
     __shared__ float s_scale[kNetMaxLevels];
@@ -374,14 +489,16 @@ __global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float
         }
     }
     const int nf = L.n_features;
-    const int n_acc = (int)L.level_off[n_lds_levels] * nf;
+    const uint32_t base = L.level_off[lv0] * nf;                       // first float of the group
+    const int n_acc = use_lds ? (int)(L.level_off[lv1] * nf - base) : 0;
     for (int e = threadIdx.x; e < n_acc; e += 256) acc[e] = 0.0f;
     __syncthreads();
     const int p0 = blockIdx.x * chunk, p1 = min(n, p0 + chunk);
     float *gG = grad + L.n_mlp;
-    const int n_items = (p1 - p0) * L.n_levels;
+    const int n_lv = lv1 - lv0;
+    const int n_items = (p1 - p0) * n_lv;
     for (int item = threadIdx.x; item < n_items; item += 256) {
-        const int p = p0 + item / L.n_levels, lv = item % L.n_levels;
+        const int p = p0 + item / n_lv, lv = lv0 + item % n_lv;
         const float s = s_scale[lv];
         const uint32_t res = s_res[lv], lo = s_off[lv], n_level = s_off[lv + 1] - lo;
         float px = __builtin_fmaf(s, xy[2 * p], 0.5f), py = __builtin_fmaf(s, xy[2 * p + 1], 0.5f);
@@ -394,8 +511,8 @@ __global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float
             const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
             const float w = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
             const uint32_t e = (lo + (cx + cy * res) % n_level) * nf;
-            if (lv < n_lds_levels) {
-                for (int q = 0; q < nf; ++q) atomicAdd(&acc[e + q], w * d[q]);
+            if (use_lds) {
+                for (int q = 0; q < nf; ++q) atomicAdd(&acc[e - base + q], w * d[q]);
             } else {
                 for (int q = 0; q < nf; ++q) atomicAdd(gG + e + q, w * d[q]);
             }
@@ -404,7 +521,7 @@ __global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float
     __syncthreads();
     for (int e = threadIdx.x; e < n_acc; e += 256) {
         const float v = acc[e];
-        if (v != 0.0f) atomicAdd(gG + e, v);
+        if (v != 0.0f) atomicAdd(gG + base + e, v);
     }
 }
 
@@ -496,6 +613,7 @@ struct wost_net {
     float *params = nullptr, *inference = nullptr, *m1 = nullptr, *m2 = nullptr, *ema_raw = nullptr, *grad = nullptr;
     float *params_t = nullptr, *inference_t = nullptr;   // transposed MLP matrices (scalar forward pass)
     float *params_f = nullptr, *inference_f = nullptr;   // MFMA A-fragment order (MFMA forward pass)
+    float *params_fb = nullptr;                          // MFMA fragments of the transposed matrices (backward pass)
     bool use_mfma = false;
     int step = 0;
     // scratch (grown on demand)
@@ -517,6 +635,7 @@ static int refresh_transposed(wost_net *h, hipStream_t stream)
     if (h->use_mfma) {
         hipLaunchKernelGGL(fragment_mlp_kernel, dim3(g), dim3(256), 0, stream, h->L, h->params, h->params_f);
         hipLaunchKernelGGL(fragment_mlp_kernel, dim3(g), dim3(256), 0, stream, h->L, h->inference, h->inference_f);
+        hipLaunchKernelGGL(fragment_mlp_t_kernel, dim3(g), dim3(256), 0, stream, h->L, h->params, h->params_fb);
     }
     NET_TRY(hipGetLastError());
     return WOST_OK;
@@ -572,7 +691,7 @@ static void net_free(wost_net *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    for (float *p : {h->params, h->inference, h->params_t, h->inference_t, h->params_f, h->inference_f, h->m1, h->m2, h->ema_raw, h->grad, h->d_xy, h->d_out, h->d_dl, h->d_acts, h->d_deltas, h->d_denc})
+    for (float *p : {h->params, h->inference, h->params_t, h->inference_t, h->params_f, h->inference_f, h->params_fb, h->m1, h->m2, h->ema_raw, h->grad, h->d_xy, h->d_out, h->d_dl, h->d_acts, h->d_deltas, h->d_denc})
         if (p) (void)hipFree(p);
     delete h;
 }
@@ -603,19 +722,46 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
 {
     const NetLayout &L = h->L;
     NET_TRY(hipMemsetAsync(h->grad, 0, (size_t)h->n_params * sizeof(float), stream));
-    const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
-    const unsigned gridp = (unsigned)((n + kNetBlock - 1) / kNetBlock);
-    hipLaunchKernelGGL(net_backward_kernel, dim3(gridp), dim3(kNetBlock), lds, stream, L, h->params, xy_dev, h->d_dl, h->d_acts,
-                       n, h->d_deltas, h->d_denc);
+    if (h->use_mfma) {
+        const size_t lds = (size_t)L.n_mlp * sizeof(float);
+        const int n_tiles = (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
+        hipLaunchKernelGGL((net_backward_mfma_kernel<32, 64, 3, 48>), dim3((unsigned)std::min((n_tiles + 3) / 4, 512)), dim3(256), lds,
+                           stream, L, h->params_fb, h->d_dl, h->d_acts, n, h->d_deltas, h->d_denc);
+    } else {
+        const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
+        const unsigned gridp = (unsigned)((n + kNetBlock - 1) / kNetBlock);
+        hipLaunchKernelGGL(net_backward_kernel, dim3(gridp), dim3(kNetBlock), lds, stream, L, h->params, xy_dev, h->d_dl, h->d_acts,
+                           n, h->d_deltas, h->d_denc);
+    }
     NET_TRY(hipGetLastError());
     {
-        // levels whose accumulators fit into 64 KB of LDS
-        int n_lds = 0;
-        while (n_lds < L.n_levels && (size_t)L.level_off[n_lds + 1] * L.n_features * sizeof(float) <= 64 * 1024) ++n_lds;
-        const int gchunk = 2048;
-        hipLaunchKernelGGL(grid_grad_kernel, dim3((unsigned)((n + gchunk - 1) / gchunk)), dim3(256),
-                           (size_t)L.level_off[n_lds] * L.n_features * sizeof(float), stream, L, xy_dev, h->d_denc, n, gchunk,
-                           n_lds, h->grad);
+        // group consecutive levels so that each group's accumulators fit into LDS: up to 64 KB
+        // per group (two blocks per CU), a single larger level alone up to 150 KB (one block per CU)
+        const size_t small = 64 * 1024, big = 150 * 1024;
+        int lv = 0;
+        while (lv < L.n_levels) {
+            int end = lv;
+            size_t bytes = 0;
+            while (end < L.n_levels) {
+                const size_t add = (size_t)(L.level_off[end + 1] - L.level_off[end]) * L.n_features * sizeof(float);
+                if (bytes + add > small) break;
+                bytes += add;
+                ++end;
+            }
+            int use_lds = 1;
+            if (end == lv) {        // this level alone exceeds 64 KB
+                bytes = (size_t)(L.level_off[lv + 1] - L.level_off[lv]) * L.n_features * sizeof(float);
+                end = lv + 1;
+                if (bytes > big) { use_lds = 0; bytes = 0; }
+            }
+            const int gchunk = bytes > small ? 4096 : 2048;
+            if (bytes > small)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(grid_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)big);
+            hipLaunchKernelGGL(grid_grad_kernel, dim3((unsigned)((n + gchunk - 1) / gchunk)), dim3(256), bytes, stream, L, xy_dev,
+                               h->d_denc, n, gchunk, lv, end, use_lds, h->grad);
+            lv = end;
+        }
         NET_TRY(hipGetLastError());
     }
     const int astride = L.enc + L.n_hidden * L.n_neurons, dstride = L.n_out_padded + L.n_hidden * L.n_neurons;
@@ -626,8 +772,18 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
         const int n_i = layer == 0 ? L.enc : L.n_neurons, n_o = layer == L.n_hidden ? L.n_out_padded : L.n_neurons;
         const int doff = layer == L.n_hidden ? 0 : L.n_out_padded + layer * L.n_neurons;   // delta of this layer's output
         const int ioff = layer == 0 ? 0 : L.enc + (layer - 1) * L.n_neurons;               // this layer's input
-        hipLaunchKernelGGL(weight_grad_kernel, dim3(gridc), dim3(256), lds_w, stream, h->d_deltas, dstride, doff, h->d_acts,
-                           astride, ioff, n_o, n_i, n, chunk, h->grad + L.w_off[layer]);
+        float *gW = h->grad + L.w_off[layer];
+        if (h->use_mfma) {
+#define WG(NO, NI) hipLaunchKernelGGL((weight_grad_mfma_kernel<NO, NI>), dim3(gridc), dim3(256), 0, stream, h->d_deltas, dstride, \
+                                      doff, h->d_acts, astride, ioff, n, chunk, gW)
+            if (layer == 0) WG(64, 32);
+            else if (layer == L.n_hidden) WG(48, 64);
+            else WG(64, 64);
+#undef WG
+        } else {
+            hipLaunchKernelGGL(weight_grad_kernel, dim3(gridc), dim3(256), lds_w, stream, h->d_deltas, dstride, doff, h->d_acts,
+                               astride, ioff, n_o, n_i, n, chunk, gW);
+        }
     }
     NET_TRY(hipGetLastError());
     if (apply_update) {
@@ -700,7 +856,7 @@ int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_
     for (uint32_t e = 0; e < L.n_grid; ++e) init[L.n_mlp + e] = (uniform() * 2.0f - 1.0f) * 1e-4f;
     const size_t bytes = (size_t)h->n_params * sizeof(float);
     hipError_t e = hipSuccess;
-    for (float **p : {&h->params, &h->inference, &h->m1, &h->m2, &h->ema_raw, &h->grad, &h->params_t, &h->inference_t, &h->params_f, &h->inference_f})
+    for (float **p : {&h->params, &h->inference, &h->m1, &h->m2, &h->ema_raw, &h->grad, &h->params_t, &h->inference_t, &h->params_f, &h->inference_f, &h->params_fb})
         if (e == hipSuccess) e = hipMalloc((void **)p, bytes);
     if (e == hipSuccess) e = hipMemcpy(h->params, init.data(), bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->inference, init.data(), bytes, hipMemcpyHostToDevice);
