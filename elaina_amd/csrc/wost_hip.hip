@@ -72,6 +72,7 @@ struct RoundParams {
     int32_t trav_burst;    // node visits per scheduling decision in the traversal phase
     int32_t top_levels;    // levels of the Dirichlet tree mirrored in LDS
     int32_t top_nodes;     // (4^top_levels - 1) / 3
+    uint32_t *cursor;      // REFILL launches: next unread slot of the input queue
 };
 
 struct InitParams {
@@ -242,7 +243,28 @@ __device__ __forceinline__ uint32_t step_finish(const DevMesh &dm, const DevMesh
     return (truncated ? (STEP_ENDED | STEP_TRUNCATED) : 0u) | (hit_count ? STEP_NEUMANN_HIT : 0u);
 }
 
-template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE>
+__device__ __forceinline__ void load_lane(const WalkQueue &q, uint32_t slot, Lane &L, uint32_t &pix)
+{
+    pix = q.pix[slot];
+    L.x0 = q.x0[slot]; L.y0 = q.y0[slot];
+    L.px = q.px[slot]; L.py = q.py[slot];
+    L.rng.state = q.rng[slot]; L.rng.inc = 1;
+    const uint32_t m = q.meta[slot];
+    L.sample = META_SAMPLE(m); L.depth = META_DEPTH(m); L.on_n = META_ONN(m) != 0;
+    L.nx = q.nx[slot]; L.ny = q.ny[slot];
+    L.hint = q.hint[slot];
+    L.thp = q.thp[slot];
+    L.sr = q.sr[slot]; L.sg = q.sg[slot]; L.sb = q.sb[slot];
+    L.d0_d2 = q.d0_d2[slot]; L.d0_slot = q.d0_slot[slot];
+}
+
+// REFILL = false: one thread per queue slot, the round ends after steps_per_round steps and the
+// survivors are compacted (the throughput path: with many samples per pixel a slot keeps itself
+// busy by regenerating).  REFILL = true: a fixed number of resident threads; a lane whose pixel
+// is complete writes it out and takes the next unread slot of the input queue (one atomic per
+// wave), so the whole solve is ONE launch and no lane idles while work is left -- the
+// low-sample-count path (time-to-1spp), where regeneration cannot fill the lanes.
+template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, bool REFILL = false>
 __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(RoundParams P)
 {
     extern __shared__ uint32_t lds_stack[];
@@ -262,27 +284,19 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
     uint32_t pix = 0;
     bool alive = false;
     if (valid) {
-        const WalkQueue &q = P.in;
-        pix = q.pix[slot];
-        L.x0 = q.x0[slot]; L.y0 = q.y0[slot];
-        L.px = q.px[slot]; L.py = q.py[slot];
-        L.rng.state = q.rng[slot]; L.rng.inc = 1;
-        const uint32_t m = q.meta[slot];
-        L.sample = META_SAMPLE(m); L.depth = META_DEPTH(m); L.on_n = META_ONN(m) != 0;
-        L.nx = q.nx[slot]; L.ny = q.ny[slot];
-        L.hint = q.hint[slot];
-        L.thp = q.thp[slot];
-        L.sr = q.sr[slot]; L.sg = q.sg[slot]; L.sb = q.sb[slot];
-        L.d0_d2 = q.d0_d2[slot]; L.d0_slot = q.d0_slot[slot];
+        load_lane(P.in, slot, L, pix);
         alive = L.sample < (uint32_t)P.st.spp;
     }
+    bool open = valid;            // this lane holds a pixel whose result has not been written
+    uint32_t wide[6] = {0, 0, 0, 0, 0, 0};   // REFILL: 32-bit totals of the packed 16-bit lane counters
+    uint32_t pool_next = 0, pool_end = 0;    // REFILL: this wave's reserved input slots [next, end)
     // Per-lane state machine.  A lane either has an INNER node or a LEAF of the LBVH to visit
     // for its current walk position, WAITs with a finished query for the step logic, or is DONE
     // for this round.  Query lengths differ wildly between lanes, so instead of running every
     // lane's query to completion in lock step, each trip of the loop runs ONE of two bodies
     // -- "visit one node" or "finish a step and start the next query" -- whichever more lanes
     // of the wave are ready for (weighted), while the lanes of the other kind accumulate.
-    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4 };
+    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5 };
     const bool has_d = P.dm.n_segs > 0;
     int mode = alive ? MODE_WAIT : MODE_DONE;
     bool fresh = true;   // first trip: no finished step yet, only start the query
@@ -291,9 +305,53 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
     uint32_t trav_trips = 0, step_trips = 0;   // wave-uniform: scheduler diagnostics
     const LdsColumn stk{stack, (uint32_t)P.stack_stride};
     for (;;) {
+        if (REFILL) {
+            // lanes whose pixel is complete: write it, then take the next unread input slot
+            const unsigned long long need = __ballot(mode == MODE_REFILL);
+            if (need) {
+                // slots come from a wave-private reservation of 64 (one atomic on the shared cursor
+                // per 64 pixels, not per refill: same-address atomics serialise in L2)
+                const int lane_ = threadIdx.x & 63;
+                const uint32_t needed = (uint32_t)__popcll(need), avail = pool_end - pool_next;
+                uint32_t fresh_base = 0;
+                if (needed > avail) {
+                    if (lane_ == 0) fresh_base = atomicAdd(P.cursor, 64u);
+                    fresh_base = __shfl(fresh_base, 0);
+                }
+                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane_) - 1ull));
+                const uint32_t s2 = rank < avail ? pool_next + rank : fresh_base + (rank - avail);
+                if (needed > avail) {
+                    pool_next = fresh_base + (needed - avail);
+                    pool_end = fresh_base + 64u;
+                } else {
+                    pool_next += needed;
+                }
+                if (mode == MODE_REFILL) {
+                    float *f = P.field + 3 * (size_t)((int32_t)pix - P.field_base);
+                    const float spp = (float)P.st.spp;
+                    f[0] = L.sr / spp; f[1] = L.sg / spp; f[2] = L.sb / spp;
+                    open = false;
+                    wide[0] += S.a & 0xffffu; wide[1] += S.a >> 16; wide[2] += S.b & 0xffffu; wide[3] += S.b >> 16;
+                    wide[4] += S.c; wide[5] += S.visits;
+                    S = LaneStats{0, 0, 0, 0};
+                    if (s2 < n_in) {
+                        load_lane(P.in, s2, L, pix);
+                        open = true;
+                        alive = L.sample < (uint32_t)P.st.spp;
+                        fresh = true;
+                        mode = alive ? MODE_WAIT : MODE_REFILL;
+                    } else {
+                        mode = MODE_DONE;
+                    }
+                }
+            }
+        }
         const int n_trav = __popcll(__ballot(mode == MODE_TRAV));
         const int n_wait = __popcll(__ballot(mode == MODE_WAIT));
-        if (n_trav + n_wait == 0) break;
+        if (n_trav + n_wait == 0) {
+            if (REFILL && __ballot(mode == MODE_REFILL)) continue;
+            break;
+        }
         if (n_wait * P.wait_weight >= n_trav * 8) {
             ++step_trips;
             // ---- step phase ----
@@ -327,7 +385,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
                         mode = MODE_TRAV;
                     }
                 } else {
-                    mode = MODE_DONE;
+                    mode = (REFILL && !alive) ? MODE_REFILL : MODE_DONE;
                 }
             }
         } else {
@@ -342,18 +400,18 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
         }
     }
     // ---- resolve finished pixels (reference integrator.cu:616-620) -------------------------
-    if (valid && !alive) {
+    if (open && !alive) {
         float *f = P.field + 3 * (size_t)((int32_t)pix - P.field_base);
         const float spp = (float)P.st.spp;
         f[0] = L.sr / spp; f[1] = L.sg / spp; f[2] = L.sb / spp;
     }
     // ---- stream compaction of the survivors: ballot + popcount, one atomic per wave -------
-    const unsigned long long bal = __ballot(alive);
+    const unsigned long long bal = __ballot(alive && open);
     const int lane = threadIdx.x & 63;
     uint32_t base = 0;
     if (lane == 0 && bal) base = atomicAdd(P.count_out, (uint32_t)__popcll(bal));
     base = __shfl(base, 0);
-    if (alive) {
+    if (alive && open) {
         const uint32_t s = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         WalkQueue &q = P.out;
         q.pix[s] = pix;
@@ -368,7 +426,8 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
         q.d0_d2[s] = L.d0_d2; q.d0_slot[s] = L.d0_slot;
     }
     // ---- statistics: wave reduction, one atomic per counter per wave -----------------------
-    uint32_t v[7] = {S.a & 0xffffu, S.a >> 16, S.b & 0xffffu, S.b >> 16, S.c, S.visits, 0u};
+    uint32_t v[7] = {(S.a & 0xffffu) + wide[0], (S.a >> 16) + wide[1], (S.b & 0xffffu) + wide[2], (S.b >> 16) + wide[3],
+                     S.c + wide[4], S.visits + wide[5], 0u};
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         uint32_t x = v[k];
@@ -566,7 +625,7 @@ struct wost_context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // options
-    int steps_per_round = 256;
+    int steps_per_round = 0;   // 0 = automatic (see run_solve)
     int block_size = 256;
     int wait_weight = 8;
     int trav_burst = 3;
@@ -579,6 +638,9 @@ struct wost_context {
     uint32_t *spill = nullptr;
     size_t spill_words = 0;
     int time_kernels = 1;
+    int refill = -1;       // -1 = automatic (few samples per pixel), 0 = never, 1 = always
+    uint32_t *cursor = nullptr;
+    int n_cus = 256;
 };
 
 namespace wost {
@@ -619,6 +681,7 @@ static void destroy_ctx(wost_context *c)
     if (c->stats) (void)hipFree(c->stats);
     if (c->field) (void)hipFree(c->field);
     if (c->spill) (void)hipFree(c->spill);
+    if (c->cursor) (void)hipFree(c->cursor);
     if (c->host_count) (void)hipHostFree(c->host_count);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -682,6 +745,8 @@ int wost_create(const wost_scene_desc *scene, const wost_settings *settings, int
     }
     HIP_TRY_C(hipMalloc((void **)&c->counts, 2 * sizeof(uint32_t)));
     HIP_TRY_C(hipMalloc((void **)&c->stats, sizeof(StatsDev)));
+    HIP_TRY_C(hipMalloc((void **)&c->cursor, sizeof(uint32_t)));
+    HIP_TRY_C(hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device));
     HIP_TRY_C(hipMalloc((void **)&c->field, c->n_pixels * 3 * sizeof(float)));
     HIP_TRY_C(hipHostMalloc((void **)&c->host_count, 2 * sizeof(uint32_t)));
     HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -703,7 +768,7 @@ int wost_set_option(wost_handle h, const char *key, double value)
     if (!h || !key) return fail(WOST_ERR_INVALID, "null argument");
     const std::string k(key);
     if (k == "steps_per_round") {
-        if (value < 1 || value > 32767) return fail(WOST_ERR_INVALID, "steps_per_round must be in 1..32767");
+        if (value < 0 || value > 32767) return fail(WOST_ERR_INVALID, "steps_per_round must be in 0..32767 (0 = automatic)");
         h->steps_per_round = (int)value;
     } else if (k == "block_size") {
         const int b = (int)value;
@@ -733,6 +798,9 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "waves_per_cu") {
         if (value < 0 || value > 32) return fail(WOST_ERR_INVALID, "waves_per_cu must be in 0..32");
         h->waves_per_cu = (int)value;
+    } else if (k == "refill") {
+        if (value != -1 && value != 0 && value != 1) return fail(WOST_ERR_INVALID, "refill must be -1 (auto), 0 or 1");
+        h->refill = (int)value;
     } else if (k == "time_kernels") {
         h->time_kernels = value != 0;
     } else {
@@ -865,7 +933,10 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         rp.field = field_dev;
         rp.field_base = field_base;
         rp.stats = c->stats;
-        rp.steps_per_round = c->steps_per_round;
+        // A slot regenerates its pixel's next sample inside a round, so a round may be long when
+        // there are many samples per pixel; with few samples the lanes of a wave drain at
+        // different times and only a compaction refills them: ~8 steps per sample, 256 at most.
+        rp.steps_per_round = c->steps_per_round > 0 ? c->steps_per_round : std::min(256, std::max(8, 8 * c->settings.spp));
         rp.stack_stride = bs;
         rp.wait_weight = c->wait_weight;
         rp.trav_burst = c->trav_burst;
@@ -874,9 +945,31 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         rp.top_nodes = 0;
         for (int l = 0, n = 1; l < rp.top_levels; ++l, n *= 4) rp.top_nodes += n;
         const size_t lds_round = lds + (size_t)rp.top_nodes * 96;
-        const unsigned grid = (n_active + bs - 1) / bs;
+        unsigned grid = (n_active + bs - 1) / bs;
+        // REFILL launch: as many resident threads as the chip holds, each draining the input queue.
+        // Worth it when regeneration cannot keep the lanes busy (measured on config 2's frame:
+        // 1 spp 3.5 -> 3.0 ms, 4 spp 8.3 -> 7.9 ms, 8 spp 13.0 -> 13.5 ms) and the queue is larger
+        // than one residency; the 16-bit lane counters bound spp * max_depth.
+        const unsigned resident = (unsigned)(c->n_cus * (ntree ? 4 : 6) * 4 * 64 / bs);
+        const bool can_refill = (int64_t)c->settings.spp * c->settings.max_depth < 65535 && launches == 0;
+        const bool refill = can_refill && (c->refill == 1 || (c->refill == -1 && c->settings.spp <= 4 && grid > resident));
+        if (refill) {
+            grid = std::min(grid, resident);
+            c->host_count[1] = grid * (unsigned)bs;      // first unread slot (pinned staging word)
+            HIP_TRY(hipMemcpyAsync(c->cursor, c->host_count + 1, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            rp.cursor = c->cursor;
+            rp.steps_per_round = 0x7fffffff;
+        }
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
-        if (ntree) {
+        if (refill) {
+            if (ntree) {
+                if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+                else hipLaunchKernelGGL((walk_round_kernel<false, true, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+            } else {
+                if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+                else hipLaunchKernelGGL((walk_round_kernel<false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+            }
+        } else if (ntree) {
             if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
             else hipLaunchKernelGGL((walk_round_kernel<false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
         } else {

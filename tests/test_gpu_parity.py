@@ -322,3 +322,36 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert r["n_gpus"] == 2 and r["metric"] == "walk-steps/s" and r["scaling"] == "strong"
     assert r["rel_l2_vs_oracle"] == 0.0
     assert r["roofline"]["bound"] == "hbm" and r["cpu_baseline"]["kind"] == "port"
+
+
+@pytest.mark.parametrize("scene,spp,depth", [("ladybug", 1, 64), ("ladybug", 5, 32), ("fille", 2, 128)])
+def test_refill_launch_matches_oracle(oracle, scene, spp, depth):
+    """the single-launch path for few samples per pixel (lanes drain the input queue instead of
+    waiting for a compaction): same per-pixel arithmetic, so still bit-exact"""
+    from elaina_amd import Problem
+    p = Problem.load_scene(scene)
+    _assert_same_solve(oracle, p, 96, 80, spp, depth, 1.0, refill=1, block_size=64)
+    _assert_same_solve(oracle, p, 96, 80, spp, depth, 1.0, refill=1)
+
+
+def test_refill_launch_with_mask_and_mixed_boundaries(oracle):
+    from conftest import box_problem, wiggly_problem
+    p = box_problem(d_sides=(0, 2), n_sides=(1, 3), value=lambda x, y: y, flux=lambda x, y, s: 0.3 * (s - 2))
+    mask = (np.arange(70 * 50) % 3 != 0).astype(np.uint8)
+    p.mask = mask
+    ref = _assert_same_solve(oracle, p, 70, 50, 3, 32, 1e-3, refill=1)
+    assert np.all(ref["field"][mask == 0] == 0)
+    _assert_same_solve(oracle, wiggly_problem(emissive=True), 48, 48, 2, 24, 0.05, refill=1)
+
+
+def test_refill_is_chosen_automatically_for_one_sample(ladybug):
+    from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+    it = UniformIntegrator(ladybug, UniformIntegratorSettings((1024, 1024), 1, 64, 1.0))
+    it.solve()
+    assert it.last_stats["kernel_launches"] == 1
+    ref = it.solution.copy()
+    it.set_option("refill", 0)
+    it.solve()
+    assert it.last_stats["kernel_launches"] > 1 or it.last_stats["kernel_launches"] == 1
+    assert np.array_equal(ref, it.solution)
+    it.close()
