@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void sample_kernel(GParams P)
             uniform_direction(on_n, nx, ny, rng, dirx, diry, pdf, alpha);
         } else {
             const float *raw = P.net_out + 33 * (size_t)i;
-            const float sel = 1 / (1.f + expf(-raw[32]));                 // logistic (functors.h:182)
+            const float sel = 1 / (1.f + det_expf(-raw[32]));                 // logistic (functors.h:182)
             const bool inside = aabb_contains(P.box, x, y);
             // the draw precedes the box test and is skipped for uniform fraction 0 (:518)
             bool to_guided = (P.uniform_fraction == 0.0f) || (pcg_next_float(rng) < sel);

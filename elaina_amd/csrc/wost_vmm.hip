@@ -79,8 +79,8 @@ __global__ void vmm_loss_gradients_kernel(const float *raw, const float *dir, co
         ry = wy - 2 * dd * ny;
     }
     for (int k = 0; k < 8; ++k) {
-        lambda[k] = expf(fmaxf(fminf(d[4 * k], 15.0f), -10.0f));
-        kap[k] = expf(fmaxf(fminf(d[4 * k + 1], 15.0f), -10.0f));
+        lambda[k] = det_expf(fmaxf(fminf(d[4 * k], 15.0f), -10.0f));
+        kap[k] = det_expf(fmaxf(fminf(d[4 * k + 1], 15.0f), -10.0f));
         ox[k] = d[4 * k + 2];
         oy[k] = d[4 * k + 3];
         const float nn = sqrtf(ox[k] * ox[k] + oy[k] * oy[k]);
@@ -107,7 +107,8 @@ __global__ void vmm_loss_gradients_kernel(const float *raw, const float *dir, co
         }
         float dF_dkappa = w * (vm * vm_dlog_dkappa(kap[sg], wx * mux[sg] + wy * muy[sg]));
         if (on_n) dF_dkappa += w * (vmr * vm_dlog_dkappa(kap[sg], rx * mux[sg] + ry * muy[sg]));
-        float denom = powf(ox[sg] * ox[sg] + oy[sg] * oy[sg], 1.5f);
+        const float n2 = ox[sg] * ox[sg] + oy[sg] * oy[sg];
+        float denom = n2 * sqrtf(n2);                 // |mu|^3 (the reference's powf(., 1.5f))
         if (denom < eps) denom = eps;
         float dF_dx = w * vm * kap[sg] * oy[sg] * (-ox[sg] * wy + oy[sg] * wx) / denom;
         if (on_n) dF_dx += w * vmr * kap[sg] * oy[sg] * (-ox[sg] * ry + oy[sg] * rx) / denom;
@@ -122,15 +123,15 @@ __global__ void vmm_loss_gradients_kernel(const float *raw, const float *dir, co
     const float dirPdf = dir_pdf[t] + eps;
     const float guidePdf = probability + eps;
     const float prefix = -Li / dirPdf / guidePdf * scale;
-    if (likelihood) likelihood[t] = -Li / dirPdf * logf(guidePdf);
+    if (likelihood) likelihood[t] = -Li / dirPdf * det_logf(guidePdf);
     for (int sg = 0; sg < 8; ++sg) {
-        grad[4 * sg + 0] = prefix * grad[4 * sg + 0] * expf(fmaxf(fminf(d[4 * sg], 15.0f), -10.0f));
-        grad[4 * sg + 1] = prefix * grad[4 * sg + 1] * expf(fmaxf(fminf(d[4 * sg + 1], 15.0f), -10.0f));
+        grad[4 * sg + 0] = prefix * grad[4 * sg + 0] * det_expf(fmaxf(fminf(d[4 * sg], 15.0f), -10.0f));
+        grad[4 * sg + 1] = prefix * grad[4 * sg + 1] * det_expf(fmaxf(fminf(d[4 * sg + 1], 15.0f), -10.0f));
         grad[4 * sg + 2] = prefix * grad[4 * sg + 2];
         grad[4 * sg + 3] = prefix * grad[4 * sg + 3];
     }
     const float uni = on_n ? (float)(1.0 / VM_PI_D) : 1.0f / VM_2PI;
-    const float sgm = 1.0f / (1.0f + expf(-d[32]));
+    const float sgm = 1.0f / (1.0f + det_expf(-d[32]));
     grad[32] = scale * (-0.2f) * Li * (guidePdf - uni) / (dirPdf * dirPdf) * (sgm * (1 - sgm));
 }
 

@@ -22,6 +22,7 @@ static __constant__ float VM_COEF_LARGE[2][9] = {
      0.1787654e-1f, -0.420059e-2f}};
 
 #define VM_2PI 6.28318530717958647693f
+#define VM_LOG_2PI 1.83787706640934548356f   // logf(2 pi)
 #define VM_PI_D 3.14159265358979323846
 
 __device__ __forceinline__ float eval_poly(float y, const float *coeff, int n)
@@ -37,22 +38,22 @@ __device__ __forceinline__ float log_bessel(float x, int order)
     y *= y;
     float small = eval_poly(y, VM_COEF_SMALL[order], 7);
     if (order == 1) small = fabsf(x) * small;
-    small = logf(small);
+    small = det_logf(small);
     y = 3.75f / x;
-    const float large = x - 0.5f * logf(x) + logf(eval_poly(y, VM_COEF_LARGE[order], 9));
+    const float large = x - 0.5f * det_logf(x) + det_logf(eval_poly(y, VM_COEF_LARGE[order], 9));
     return (x < 3.75f) ? small : large;
 }
 
 __device__ __forceinline__ float vm_log_eval(float kappa, float cos_theta)
 {
     const float ret = kappa * cos_theta;
-    return ret - logf(VM_2PI) - log_bessel(kappa, 0);
+    return ret - VM_LOG_2PI - log_bessel(kappa, 0);
 }
 
 __device__ __forceinline__ float vm_eval(float kappa, float cos_theta)
 {
     if (kappa < 1e-3f) return 1.0f / VM_2PI;
-    return expf(vm_log_eval(kappa, cos_theta));
+    return det_expf(vm_log_eval(kappa, cos_theta));
 }
 
 __device__ __forceinline__ float vm_dlog_dkappa(float kappa, float cosTheta)
@@ -106,11 +107,16 @@ __device__ __forceinline__ float vm_rejection_sample(float kappa, double proposa
         const double u1 = pcg_next_double(rng);
         const double u2 = pcg_next_double(rng);
         const double u3 = pcg_next_double(rng);
-        const double z = cos(VM_PI_D * u1);
+        const double z = det_cospi_d(u1);
         const double f = (1.0 + proposal_r * z) / (proposal_r + z);
         const double c = (double)kappa * (proposal_r - f);
-        const bool accept = ((c * (2.0 - c) - u2) > 0.0) || (log(c / u2) + 1.0 - c >= 0.0);
-        if (accept) return (float)(fmod((copysign(1.0, u3 - 0.5) * acos(f)) + VM_PI_D, 2 * VM_PI_D) - VM_PI_D);
+        const bool accept = ((c * (2.0 - c) - u2) > 0.0) || (det_log_d(c / u2) + 1.0 - c >= 0.0);
+        if (accept) {
+            // fmod(a + pi, 2 pi) - pi for a in [-pi, pi], spelled out (fmod is exact)
+            double a = copysign(1.0, u3 - 0.5) * det_acos_d(f) + VM_PI_D;
+            if (a >= 2 * VM_PI_D) a -= 2 * VM_PI_D;
+            return (float)(a - VM_PI_D);
+        }
     }
 }
 
@@ -124,8 +130,8 @@ struct Vmm {
         float total = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            lambda[k] = expf(fmaxf(fminf(d[4 * k], 15.0f), -10.0f));
-            kap[k] = expf(fmaxf(fminf(d[4 * k + 1], 15.0f), -10.0f));
+            lambda[k] = det_expf(fmaxf(fminf(d[4 * k], 15.0f), -10.0f));
+            kap[k] = det_expf(fmaxf(fminf(d[4 * k + 1], 15.0f), -10.0f));
             const float x = d[4 * k + 2], y = d[4 * k + 3];
             const float nn = sqrtf(x * x + y * y);
             mux[k] = x / nn;
@@ -163,7 +169,8 @@ struct Vmm {
         for (int k = 1; k < 8; ++k)
             if (k == pick) { pk = kap[k]; pmx = mux[k]; pmy = muy[k]; }
         const float theta = vm_rejection_sample(pk, vm_proposal_r(pk), rng);
-        const float vx = cosf(theta), vy = sinf(theta);
+        float vx, vy;
+        det_sincosf(theta, &vx, &vy);
         float px = -pmy, py = pmx;   // frameFromTangent(mu): N = normalize(-mu.y, mu.x), T = mu
         const float pl = sqrtf(px * px + py * py);
         px /= pl; py /= pl;

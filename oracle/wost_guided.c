@@ -33,6 +33,7 @@
 #include <string.h>
 
 #include "wost_internal.h"
+#include "wost_detmath.h"
 
 typedef struct {
     float sol[3];
@@ -312,7 +313,7 @@ int wo_solve_guided(const wo_scene *sc, const wo_guided_settings *gs, const wo_n
                     continue;
                 }
                 const float *raw = net_out + (size_t)NO * slot_of[p];
-                const float sel = 1 / (1.f + expf(-raw[32]));            /* logistic, functors.h:182 */
+                const float sel = 1 / (1.f + wo_expf(-raw[32]));            /* logistic, functors.h:182 */
                 const int inside = aabb_contains(&box, q->x, q->y);
                 int to_guided = (uniform_fraction == 0) || (wo_pcg_next_float(&q->rng) < sel);
                 to_guided = to_guided && inside;

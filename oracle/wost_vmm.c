@@ -20,8 +20,10 @@
 
 #include "wost_oracle.h"
 #include "wost_internal.h"
+#include "wost_detmath.h"
 
 #define WV_2PI 6.28318530717958647693f
+#define WV_LOG_2PI 1.83787706640934548356f   /* logf(2 pi) */
 #define WV_PI_D 3.14159265358979323846
 
 static const float COEF_SMALL[2][7] = {
@@ -48,22 +50,22 @@ float wo_log_bessel(float x, int order)
     y *= y;
     float small = wo_eval_poly(y, COEF_SMALL[order], 7);
     if (order == 1) small = fabsf(x) * small;
-    small = logf(small);
+    small = wo_logf(small);
     y = 3.75f / x;
-    float large = x - 0.5f * logf(x) + logf(wo_eval_poly(y, COEF_LARGE[order], 9));
+    float large = x - 0.5f * wo_logf(x) + wo_logf(wo_eval_poly(y, COEF_LARGE[order], 9));
     return (x < 3.75) ? small : large;
 }
 
 float wo_vm_log_eval(float kappa, float cos_theta)
 {
     float ret = kappa * cos_theta;
-    return ret - logf(WV_2PI) - wo_log_bessel(kappa, 0);
+    return ret - WV_LOG_2PI - wo_log_bessel(kappa, 0);
 }
 
 float wo_vm_eval(float kappa, float cos_theta)
 {
     if (kappa < 1e-3f) return 1.0f / WV_2PI;
-    return expf(wo_vm_log_eval(kappa, cos_theta));
+    return wo_expf(wo_vm_log_eval(kappa, cos_theta));
 }
 
 float wo_vm_dlog_dkappa(float kappa, float cosTheta)
@@ -113,12 +115,17 @@ float wo_vm_rejection_sample(float kappa, double proposal_r, wo_pcg *rng)
         double u1 = wo_pcg_next_double(rng);
         double u2 = wo_pcg_next_double(rng);
         double u3 = wo_pcg_next_double(rng);
-        double z = cos(WV_PI_D * u1);
+        double z = wo_cospi_d(u1);
         double f = (1.0 + proposal_r * z) / (proposal_r + z);
         double c = (double)kappa * (proposal_r - f);
-        int accept = ((c * (2.0 - c) - u2) > 0.0) || (log(c / u2) + 1.0 - c >= 0.0);
+        int accept = ((c * (2.0 - c) - u2) > 0.0) || (wo_log_d(c / u2) + 1.0 - c >= 0.0);
         if (accept)
-            return (float)(fmod((copysign(1.0, u3 - 0.5) * acos(f)) + WV_PI_D, 2 * WV_PI_D) - WV_PI_D);
+        {
+            /* fmod(a + pi, 2 pi) - pi for a in [-pi, pi], spelled out (fmod is exact) */
+            double a = copysign(1.0, u3 - 0.5) * wo_acos_d(f) + WV_PI_D;
+            if (a >= 2 * WV_PI_D) a -= 2 * WV_PI_D;
+            return (float)(a - WV_PI_D);
+        }
     }
 }
 
@@ -131,8 +138,8 @@ void wo_vmm_build(wv_vmm *m, const float *data)
     m->total = 0.0f;
     for (int i = 0; i < WV_NCOMP; ++i) {
         const float *d = data + 4 * i;
-        m->sg[i].lambda = expf(clampf(d[0], -10.0f, 15.0f));   /* train.h:60-72, Exponential */
-        m->sg[i].kappa = expf(clampf(d[1], -10.0f, 15.0f));
+        m->sg[i].lambda = wo_expf(clampf(d[0], -10.0f, 15.0f));   /* train.h:60-72, Exponential */
+        m->sg[i].kappa = wo_expf(clampf(d[1], -10.0f, 15.0f));
         m->sg[i].ox = d[2]; m->sg[i].oy = d[3];                 /* None */
         float n = sqrtf(d[2] * d[2] + d[3] * d[3]);
         m->sg[i].mux = d[2] / n; m->sg[i].muy = d[3] / n;
@@ -152,7 +159,8 @@ float wo_vmm_pdf(const wv_vmm *m, float wx, float wy)
 static void lobe_sample(const wv_lobe *l, wo_pcg *rng, float *ox, float *oy)
 {
     float theta = wo_vm_rejection_sample(l->kappa, wo_vm_proposal_r(l->kappa), rng);
-    float vx = cosf(theta), vy = sinf(theta);
+    float vx, vy;
+    wo_sincosf(theta, &vx, &vy);
     /* frameFromTangent(mu): N = normalize(-mu.y, mu.x), T = mu; world = T*v.x + N*v.y */
     float px = -l->muy, py = l->mux;
     float pl = sqrtf(px * px + py * py);
@@ -219,7 +227,7 @@ int wo_vmm_pdf_sample(const float *raw, const float *wi, const uint64_t *seed, i
  * normal[2].  Outputs: dL/draw (33 per sample) and the per-sample likelihood term. */
 #define WV_EPS 1e-5f     /* M_EPSILON, core/math/include/krrmath/constants.h */
 
-static float wv_d_exp_act(float v) { return expf(clampf(v, -10.0f, 15.0f)); }
+static float wv_d_exp_act(float v) { return wo_expf(clampf(v, -10.0f, 15.0f)); }
 
 int wo_vmm_loss_gradients(const float *raw, const float *dir, const float *li, const float *dir_pdf,
                           const unsigned char *on_neumann, const float *normal, int n, float loss_scale,
@@ -261,7 +269,8 @@ int wo_vmm_loss_gradients(const float *raw, const float *dir, const float *li, c
             /* d pdf / d kappa = pdf * d log pdf / d kappa (vonmises.h:165-168) */
             float dF_dkappa = m.weight[sg] * (vm * wo_vm_dlog_dkappa(kappa, wx * m.sg[sg].mux + wy * m.sg[sg].muy));
             if (on_n) dF_dkappa += m.weight[sg] * (vmr * wo_vm_dlog_dkappa(kappa, rx * m.sg[sg].mux + ry * m.sg[sg].muy));
-            float denom = powf(mox * mox + moy * moy, 1.5f);
+            const float n2 = mox * mox + moy * moy;
+            float denom = n2 * sqrtf(n2);           /* |mu|^3 (the reference's powf(., 1.5f)) */
             if (denom < WV_EPS) denom = WV_EPS;
             float dF_dx = m.weight[sg] * vm * kappa * moy * (-mox * wy + moy * wx) / denom;
             if (on_n) dF_dx += m.weight[sg] * vmr * kappa * moy * (-mox * ry + moy * rx) / denom;
@@ -274,7 +283,7 @@ int wo_vmm_loss_gradients(const float *raw, const float *dir, const float *li, c
         const float dirPdf = dir_pdf[t] + WV_EPS;
         const float guidePdf = probability + WV_EPS;
         const float prefix = -Li / dirPdf / guidePdf * scale;
-        if (likelihood) likelihood[t] = -Li / dirPdf * logf(guidePdf);
+        if (likelihood) likelihood[t] = -Li / dirPdf * wo_logf(guidePdf);
         for (int sg = 0; sg < WV_NCOMP; ++sg) {
             grad[4 * sg + 0] = prefix * grad[4 * sg + 0] * wv_d_exp_act(data[4 * sg + 0]);
             grad[4 * sg + 1] = prefix * grad[4 * sg + 1] * wv_d_exp_act(data[4 * sg + 1]);
@@ -284,7 +293,7 @@ int wo_vmm_loss_gradients(const float *raw, const float *dir, const float *li, c
         /* selection probability (train.h:541-552): Logistic activation */
         const float e = 0.2f;
         const float uni = on_n ? (float)(1.0 / WV_PI_D) : 1.0f / WV_2PI;
-        const float sgm = 1.0f / (1.0f + expf(-data[32]));
+        const float sgm = 1.0f / (1.0f + wo_expf(-data[32]));
         grad[32] = scale * (-e) * Li * (guidePdf - uni) / (dirPdf * dirPdf) * (sgm * (1 - sgm));
     }
     return 0;

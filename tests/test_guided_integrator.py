@@ -4,10 +4,12 @@ The reference's guided result is not bit-reproducible (atomic-ordered training s
 network, tiny-cuda-nn absent => PARITY UNPINNED).  What is checked here:
   CPU: the oracle (oracle/wost_guided.c) is deterministic, unbiased against an analytic Laplace
        solution with mixed boundaries, and its training records obey the reference's rules;
-  GPU: the HIP integrator (elaina_amd/csrc/wost_guided.hip) against the oracle --
-       bit-exact where no transcendental of the mixture is involved (unguided depths), and
-       within tolerance elsewhere: the device's expf/logf/cos/acos differ from glibc's in the
-       last ulp, which flips a rejection-sampling decision in a few per cent of the walks.
+  GPU: the HIP integrator (elaina_amd/csrc/wost_guided.hip) against the oracle -- bit-exact
+       whenever the network is not being trained (unguided depths, a frozen network, the records
+       of the first training pass): both sides use the same deterministic exp/log/sin/cos and
+       fp64 cos/acos/log kernels and the same k-ordered fmaf chains in the
+       network.  Training itself sums gradients with float atomics, so after the first Adam step
+       only statistics are compared.
 """
 import numpy as np
 import pytest
@@ -159,41 +161,57 @@ def test_gpu_unguided_depths_are_bit_exact(oracle):
 
 @pytest.mark.gpu
 def test_gpu_first_pass_records_match_oracle(oracle):
+    """one training pass without an optimizer step: routing, mixture sampling, MIS pdf, records and
+    the ordered training set, bit for bit"""
     prob = laplace_box()
     gi, ref = _gpu_and_oracle(oracle, prob, 48, 48, 1, 32, 1, min_batch=10 ** 9)
     ts, to = gi.train_set(), ref["train_set"]
     assert gi.last_stats["optimizer_steps"] == 0
-    assert abs(len(ts["xy"]) - len(to["xy"])) <= 0.005 * len(to["xy"])
-    assert gi.last_stats["train_samples"] == len(ts["xy"])
-    assert _close_fraction(gi.solution, ref["field"]) > 0.95
-    if len(ts["xy"]) == len(to["xy"]):
-        # same (pixel, record) order on both sides; a few walks diverge after an ulp-level flip
-        assert np.mean(ts["on_neumann"] == to["on_neumann"]) > 0.99
-        assert _close_fraction(ts["xy"], to["xy"]) > 0.99
-        assert _close_fraction(ts["dir"], to["dir"]) > 0.98
-        assert _close_fraction(ts["dir_pdf"], to["dir_pdf"]) > 0.98
-        assert _close_fraction(ts["solution"], to["solution"]) > 0.95
+    assert gi.last_stats["train_samples"] == len(ts["xy"]) == len(to["xy"]) == ref["train_samples"]
+    assert np.array_equal(gi.solution, ref["field"])
+    for k in ("xy", "dir", "solution", "dir_pdf", "normal", "on_neumann"):
+        assert np.array_equal(ts[k], to[k]), k
+    for k in ("walk_steps", "walks_absorbed", "walks_truncated", "neumann_hits", "guided_steps"):
+        assert gi.last_stats[k] == ref[k], k
     gi.close()
 
 
 @pytest.mark.gpu
-def test_gpu_frozen_network_matches_oracle(oracle):
+@pytest.mark.parametrize("spp,uf", [(8, (0.5, 0.5)), (3, (0.0, 0.0)), (3, (0.9, 0.25))])
+def test_gpu_frozen_network_matches_oracle(oracle, spp, uf):
     """training off, a random network with pronounced lobes: routing, mixture sampling (fp64
-    rejection), MIS pdf, reflection on the Neumann boundary, throughput"""
+    rejection), MIS pdf, reflection on the Neumann boundary, throughput -- bit-exact"""
     prob = laplace_box()
     cfg = default_net_config()
     rng = np.random.default_rng(3)
     n = oracle.net_n_params(cfg)
     p = rng.uniform(-0.3, 0.3, n).astype(np.float32)
     p[13312:] = rng.uniform(-1, 1, n - 13312).astype(np.float32)
-    gi, ref = _gpu_and_oracle(oracle, prob, 48, 48, 8, 32, 0, params=p)
-    f, fo = gi.solution, ref["field"]
-    assert _close_fraction(f, fo) > 0.85
-    assert abs(float(f.mean()) - float(fo.mean())) < 2e-3 * abs(float(fo.mean()))
-    for k in ("walk_steps", "neumann_hits", "guided_steps"):
-        assert abs(gi.last_stats[k] - ref[k]) < 0.01 * ref[k], k
-    assert gi.last_stats["walks_started"] == ref["walks_started"]
+    gi, ref = _gpu_and_oracle(oracle, prob, 48, 40, spp, 32, 0, params=p, uf=uf)
+    assert np.array_equal(gi.solution, ref["field"]), float(np.abs(gi.solution - ref["field"]).max())
+    for k in ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated", "neumann_hits", "guided_steps"):
+        assert gi.last_stats[k] == ref[k], k
+    assert ref["guided_steps"] > 0
     assert np.array_equal(gi.network.params(), p)            # no training happened
+    gi.close()
+
+
+@pytest.mark.gpu
+def test_gpu_frozen_network_on_ladybug_matches_oracle(oracle, ladybug):
+    """the shipped scene (61 476 Dirichlet segments, Neumann box), guided walks with the freshly
+    initialised network, no training: bit-exact against the oracle"""
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    w, h, spp, depth = 40, 32, 2, 48
+    aabb = ((-100.0, -100.0), (600.0, 600.0))
+    st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=0, maxWalkingDepth=depth,
+                                  epsilonShell=1.0)
+    gi = GuidedIntegrator(ladybug, st, aabb, seed=11)
+    p0 = gi.network.params()
+    gi.solve()
+    gs = guided_settings(w, h, spp, depth, 1.0, aabb[0], aabb[1], train_spp_count=0)
+    ref = oracle.solve_guided(ladybug.as_dict(), gs, default_net_config(), p0.copy(), threads=16)
+    assert np.array_equal(gi.solution, ref["field"])
+    assert gi.last_stats["walk_steps"] == ref["walk_steps"] and gi.last_stats["guided_steps"] == ref["guided_steps"] > 0
     gi.close()
 
 
@@ -201,14 +219,14 @@ def test_gpu_frozen_network_matches_oracle(oracle):
 def test_gpu_uniform_fraction_edge_cases(oracle):
     prob = laplace_box()
     gi, ref = _gpu_and_oracle(oracle, prob, 32, 32, 2, 32, 0, uf=(0.0, 0.0))
-    assert abs(gi.last_stats["guided_steps"] - ref["guided_steps"]) < 0.01 * ref["guided_steps"]
+    assert gi.last_stats["guided_steps"] == ref["guided_steps"] and np.array_equal(gi.solution, ref["field"])
     assert gi.last_stats["guided_steps"] > 0.5 * gi.last_stats["walk_steps"]
     gi.close()
     gi, ref = _gpu_and_oracle(oracle, prob, 32, 32, 2, 32, 0, uf=(1.0, 1.0))
     assert gi.last_stats["guided_steps"] == 0 == ref["guided_steps"]
     # walks routed to the never-launched guided kernel end there, on both sides alike
     assert gi.last_stats["walks_absorbed"] + gi.last_stats["walks_truncated"] < gi.last_stats["walks_started"]
-    assert abs(gi.last_stats["walk_steps"] - ref["walk_steps"]) < 0.02 * ref["walk_steps"]
+    assert gi.last_stats["walk_steps"] == ref["walk_steps"] and np.array_equal(gi.solution, ref["field"])
     gi.close()
 
 
@@ -237,7 +255,8 @@ def test_gpu_training_end_to_end_is_unbiased(oracle):
 def test_gpu_training_pixel_stride(oracle):
     prob = laplace_box()
     gi, ref = _gpu_and_oracle(oracle, prob, 32, 32, 1, 32, 1, min_batch=10 ** 9, stride=3, offset=2)
-    assert abs(gi.last_stats["train_samples"] - ref["train_samples"]) <= 0.01 * ref["train_samples"] + 2
+    assert gi.last_stats["train_samples"] == ref["train_samples"]
+    assert np.array_equal(gi.train_set()["xy"], ref["train_set"]["xy"])
     full, _ = _gpu_and_oracle(oracle, prob, 32, 32, 1, 32, 1, min_batch=10 ** 9)
     assert 0.25 * full.last_stats["train_samples"] < gi.last_stats["train_samples"] < 0.42 * full.last_stats["train_samples"]
     assert np.array_equal(full.solution, gi.solution)         # recording never changes a walk
