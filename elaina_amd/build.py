@@ -52,7 +52,8 @@ def build_library(force=False, verbose=False):
 HOST_DIR = os.path.join(_HERE, "host")
 HOST_SOURCES = ["main.cpp", "exec.cpp", os.path.join("core", "problem.cpp"),
                 os.path.join("integrator", "common.cpp"), os.path.join("integrator", "uniform", "integrator.cpp"),
-                os.path.join("integrator", "guided", "integrator.cpp"), os.path.join("util", "json.cpp")]
+                os.path.join("integrator", "guided", "integrator.cpp"), os.path.join("util", "json.cpp"),
+                os.path.join("util", "image_io.cpp")]
 
 
 def build_host(force=False, verbose=False):

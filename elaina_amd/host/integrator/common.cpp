@@ -24,35 +24,61 @@ void IntegratorOutputs::render_sdf(wost_handle scene, int which_mesh, ExportImag
     gray_to_rgb(d, channels[(size_t)c]);
 }
 
-void write_pfm(const fs::path &path, int width, int height, const std::vector<float> &rgb)
+// ---- colormaps of saveEnergy (reference util/film.h:107-145, util/tonemapping.cuh) ------------
+// MATLAB_JET is the reference's piecewise-linear formula.  The reference's MATLAB_PARULA and
+// IDL_RDBU are fitted polynomial tables (several hundred coefficients); here they are linear
+// interpolations through published anchor colours of the same maps (ColorBrewer RdBu-11; nine
+// samples of parula), within a few 1/255 of the originals -- previews, not parity data.
+static void lerp_anchors(const float (*a)[3], int n, float x, float rgb[3])
 {
-    std::ofstream f(path, std::ios::binary);
-    if (!f.is_open()) throw std::runtime_error("cannot write " + path.string());
-    f << "PF\n" << width << " " << height << "\n-1.0\n";  // little endian, rows top to bottom as stored
-    f.write(reinterpret_cast<const char *>(rgb.data()), (std::streamsize)(rgb.size() * sizeof(float)));
+    x = std::min(std::max(x, 0.0f), 1.0f) * (float)(n - 1);
+    const int i = std::min((int)x, n - 2);
+    const float t = x - (float)i;
+    for (int c = 0; c < 3; ++c) rgb[c] = a[i][c] * (1.0f - t) + a[i + 1][c] * t;
 }
 
-void write_ppm(const fs::path &path, int width, int height, const std::vector<float> &rgb)
+void tone_map(ToneMapping tone, float x, float rgb[3])
 {
-    std::ofstream f(path, std::ios::binary);
-    if (!f.is_open()) throw std::runtime_error("cannot write " + path.string());
-    f << "P6\n" << width << " " << height << "\n255\n";
-    std::vector<unsigned char> px(rgb.size());
-    for (size_t i = 0; i < rgb.size(); ++i) {
-        const float v = std::isfinite(rgb[i]) ? std::min(std::max(rgb[i], 0.0f), 1.0f) : 0.0f;
-        px[i] = (unsigned char)(v * 255.0f + 0.5f);
+    static const float rdbu[11][3] = {{103, 0, 31}, {178, 24, 43}, {214, 96, 77}, {244, 165, 130}, {253, 219, 199},
+                                      {247, 247, 247}, {209, 229, 240}, {146, 197, 222}, {67, 147, 195}, {33, 102, 172},
+                                      {5, 48, 97}};
+    static const float parula[9][3] = {{0.2422f, 0.1504f, 0.6603f}, {0.2810f, 0.3228f, 0.9579f}, {0.1786f, 0.5289f, 0.9682f},
+                                       {0.0689f, 0.6948f, 0.8394f}, {0.2161f, 0.7843f, 0.5923f}, {0.6720f, 0.7793f, 0.2227f},
+                                       {0.9970f, 0.7659f, 0.2199f}, {0.9632f, 0.9000f, 0.1300f}, {0.9769f, 0.9839f, 0.0805f}};
+    auto clamp01 = [](float v) { return std::min(std::max(v, 0.0f), 1.0f); };
+    switch (tone) {
+    case ToneMapping::MATLAB_JET:
+        rgb[0] = clamp01(x < 0.7f ? 4.0f * x - 1.5f : -4.0f * x + 4.5f);
+        rgb[1] = clamp01(x < 0.5f ? 4.0f * x - 0.5f : -4.0f * x + 3.5f);
+        rgb[2] = clamp01(x < 0.3f ? 4.0f * x + 0.5f : -4.0f * x + 2.5f);
+        break;
+    case ToneMapping::MATLAB_PARULA:
+        lerp_anchors(parula, 9, x, rgb);
+        break;
+    case ToneMapping::IDL_RDBU:
+        lerp_anchors(rdbu, 11, x, rgb);
+        for (int c = 0; c < 3; ++c) rgb[c] /= 255.0f;
+        break;
+    default:
+        rgb[0] = rgb[1] = rgb[2] = x;
+        break;
     }
-    f.write(reinterpret_cast<const char *>(px.data()), (std::streamsize)px.size());
+}
+
+static void save_all(const fs::path &base, const string &file_name, int w, int h, const std::vector<float> &rgb)
+{
+    // .exr and .png like the reference (integrator/common.h:197-201), .pfm = the raw fp32 field
+    ELAINA_LOG(Info, "Exporting image to %s.exr / .png / .pfm", (base / file_name).string().c_str());
+    write_exr(base / (file_name + ".exr"), w, h, rgb);
+    write_png(base / (file_name + ".png"), w, h, rgb);
+    write_pfm(base / (file_name + ".pfm"), w, h, rgb);
 }
 
 void IntegratorOutputs::exportImage(ExportImageChannel imageType, const string &file_name)
 {
     const std::vector<float> &c = channels[(size_t)imageType];
     if (c.empty()) throw std::runtime_error(string("channel ") + channel_name(imageType) + " has not been produced");
-    const int w = frameSize_.x, h = frameSize_.y;
-    ELAINA_LOG(Info, "Exporting image to %s.pfm / .ppm", (basePath / file_name).string().c_str());
-    write_pfm(basePath / (file_name + ".pfm"), w, h, c);
-    write_ppm(basePath / (file_name + ".ppm"), w, h, c);
+    save_all(basePath, file_name, frameSize_.x, frameSize_.y, c);
 }
 
 void IntegratorOutputs::exportEnergy(ExportImageChannel imageType, ToneMapping tone, const string &file_name)
@@ -71,14 +97,12 @@ void IntegratorOutputs::exportEnergy(ExportImageChannel imageType, ToneMapping t
     const float span = mx - mn;
     if (std::isnan(mn) || std::isnan(mx) || span == 0.0f)
         ELAINA_LOG(Warning, "Invalid min/max values for tone mapping: min = %f, max = %f", mn, mx);
-    if (tone != ToneMapping::NONE)
-        for (float &v : e) v = (v - mn) / span;
-    if (tone != ToneMapping::NONE && tone != ToneMapping::NONE_NORMALIZED)
-        ELAINA_LOG(Warning, "colormaps are not built (SURVEY.md 8f.1): writing the normalised energy as grey");
-    std::vector<float> rgb;
-    gray_to_rgb(e, rgb);
-    write_pfm(basePath / (file_name + ".pfm"), w, h, rgb);
-    write_ppm(basePath / (file_name + ".ppm"), w, h, rgb);
+    std::vector<float> rgb(e.size() * 3);
+    for (size_t i = 0; i < e.size(); ++i) {
+        if (tone == ToneMapping::NONE) rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = e[i];
+        else tone_map(tone, (e[i] - mn) / span, &rgb[3 * i]);
+    }
+    save_all(basePath, file_name, w, h, rgb);
 }
 
 }  // namespace elaina

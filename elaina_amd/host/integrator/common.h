@@ -6,6 +6,7 @@
 
 #include "../../../include/wost.h"
 #include "core/common.h"
+#include "util/image_io.h"
 
 namespace elaina {
 
@@ -29,9 +30,7 @@ protected:
 
 void check_wost(int rc, const char *what);
 
-// image writers for the raw field: binary PFM (fp32, what parity is measured on) and an
-// 8-bit PPM preview.  EXR/PNG and the colormaps are "next" rows.
-void write_pfm(const fs::path &path, int width, int height, const std::vector<float> &rgb);
-void write_ppm(const fs::path &path, int width, int height, const std::vector<float> &rgb);
+// normalised energy x in [0, 1] -> colour (reference util/tonemapping.cuh)
+void tone_map(ToneMapping tone, float x, float rgb[3]);
 
 }  // namespace elaina

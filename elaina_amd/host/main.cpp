@@ -76,6 +76,30 @@ static int selftest()
     return failures ? 1 : 0;
 }
 
+// writes a small known image in both export formats and every colormap at a few abscissae
+static int imagetest(const fs::path &dir)
+{
+    const int w = 5, h = 3;
+    std::vector<float> rgb((size_t)w * h * 3);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float *p = &rgb[3 * ((size_t)y * w + x)];
+            p[0] = (float)x / 4.0f;          // 0 .. 1
+            p[1] = (float)y - 0.5f;          // negative, in range, above 1
+            p[2] = 0.1f * (float)(x + y * w);
+        }
+    fs::create_directories(dir);
+    write_png(dir / "grad.png", w, h, rgb);
+    write_exr(dir / "grad.exr", w, h, rgb);
+    for (ToneMapping t : {ToneMapping::MATLAB_JET, ToneMapping::MATLAB_PARULA, ToneMapping::IDL_RDBU, ToneMapping::NONE_NORMALIZED})
+        for (float x : {0.0f, 0.25f, 0.5f, 0.75f, 1.0f}) {
+            float c[3];
+            tone_map(t, x, c);
+            std::cout << "tone " << (int)t << " " << x << " " << c[0] << " " << c[1] << " " << c[2] << std::endl;
+        }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) {
@@ -83,6 +107,7 @@ int main(int argc, char **argv)
         return 1;
     }
     if (std::strcmp(argv[1], "--selftest") == 0) return selftest();
+    if (std::strcmp(argv[1], "--imagetest") == 0 && argc > 2) return imagetest(argv[2]);
     try {
         run_expr(fs::path(argv[1]));
     } catch (const std::exception &e) {

@@ -54,7 +54,10 @@ def test_run_expr_end_to_end_matches_oracle(tmp_path, oracle, ladybug):
     assert np.array_equal(field, ref["field"])
     sdf = export_scene.read_pfm(exp / "dirichlet_sdf.pfm")[:, 0]
     assert np.array_equal(sdf, oracle.render_dirichlet_sdf(ladybug.as_dict(), 64, 64))
-    assert os.path.exists(exp / "solution.ppm") and os.path.exists(exp / "solution_energy.pfm")
+    for ext in (".exr", ".png", ".pfm"):
+        assert os.path.exists(exp / ("solution" + ext)) and os.path.exists(exp / ("solution_energy" + ext))
+    png = _read_png(exp / "solution.png")
+    assert np.array_equal(png[::-1, :, :3].reshape(-1, 3), np.clip((field * np.float32(255)).astype(np.int32), 0, 255))
 
 
 @pytest.mark.gpu
@@ -75,3 +78,81 @@ def test_run_expr_guided_configuration(tmp_path, ladybug):
     ui.solve()
     assert abs(float(field.mean()) - float(ui.solution.mean())) < 0.02 * abs(float(ui.solution.mean()))
     assert np.array_equal(export_scene.read_pfm(exp / "dirichlet_sdf.pfm")[:, 0], ui.renderDirichletSDF())
+
+
+def _read_png(path):
+    import struct
+    import zlib
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, size = 8, b"", None
+    while pos < len(b):
+        n, typ = struct.unpack(">I4s", b[pos:pos + 8])
+        data = b[pos + 8:pos + 8 + n]
+        crc = struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0]
+        assert zlib.crc32(typ + data) & 0xffffffff == crc
+        if typ == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", data[:10])
+            assert (depth, ctype) == (8, 6)
+            size = (w, h)
+        elif typ == b"IDAT":
+            idat += data
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(size[1], 1 + 4 * size[0])
+    assert np.all(raw[:, 0] == 0)
+    return raw[:, 1:].reshape(size[1], size[0], 4)
+
+
+def _read_exr_half_rgba(path):
+    import struct
+    b = open(path, "rb").read()
+    assert struct.unpack("<ii", b[:8]) == (20000630, 2)
+    pos, attrs = 8, {}
+    while b[pos] != 0:
+        e = b.index(b"\0", pos); name = b[pos:e].decode(); pos = e + 1
+        e = b.index(b"\0", pos); typ = b[pos:e].decode(); pos = e + 1
+        n = struct.unpack("<i", b[pos:pos + 4])[0]; pos += 4
+        attrs[name] = (typ, b[pos:pos + n]); pos += n
+    pos += 1
+    x0, y0, x1, y1 = struct.unpack("<iiii", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    assert attrs["compression"][1] == b"\0" and attrs["lineOrder"][1] == b"\0"
+    names = [c[:1].decode() for c in attrs["channels"][1][:-1].split(b"\0")[::1] if len(c) == 1 and c.isalpha()]
+    assert names[:4] == ["A", "B", "G", "R"]
+    offs = struct.unpack("<%dQ" % h, b[pos:pos + 8 * h])
+    img = np.zeros((h, w, 4), np.float32)
+    for y in range(h):
+        yy, nb = struct.unpack("<ii", b[offs[y]:offs[y] + 8])
+        line = np.frombuffer(b[offs[y] + 8:offs[y] + 8 + nb], dtype="<f2").reshape(4, w)
+        img[yy] = line[[3, 2, 1, 0]].T.astype(np.float32)          # -> R G B A
+    return img
+
+
+def test_png_and_exr_writers_and_colormaps(tmp_path):
+    """reference core/texture.cu:82-116: PNG = clamp((int)(v*255)), RGBA8, flipped vertically;
+    EXR = half RGBA, flipped; colormaps of util/tonemapping.cuh (JET exact, the others anchored)"""
+    out = subprocess.run([_exe(), "--imagetest", str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    w, h = 5, 3
+    ys, xs = np.mgrid[0:h, 0:w]
+    want = np.stack([xs / 4.0, ys - 0.5, 0.1 * (xs + ys * w)], -1).astype(np.float32)
+    png = _read_png(tmp_path / "grad.png")
+    q = np.clip((want[::-1] * np.float32(255)).astype(np.int32), 0, 255)
+    assert np.array_equal(png[..., :3], q) and np.all(png[..., 3] == 255)
+    exr = _read_exr_half_rgba(tmp_path / "grad.exr")
+    assert np.array_equal(exr[..., :3], want[::-1].astype(np.float16).astype(np.float32)) and np.all(exr[..., 3] == 1)
+    tones = {}
+    for line in out.stdout.splitlines():
+        f = line.split()
+        if f[0] == "tone":
+            tones[(int(f[1]), float(f[2]))] = np.array([float(v) for v in f[3:]])
+    # MATLAB_JET = 2: dark blue -> cyan/green -> yellow -> dark red
+    np.testing.assert_allclose(tones[(2, 0.0)], [0, 0, 0.5], atol=1e-6)
+    np.testing.assert_allclose(tones[(2, 0.5)], [0.5, 1.0, 0.5], atol=1e-6)
+    np.testing.assert_allclose(tones[(2, 1.0)], [0.5, 0, 0], atol=1e-6)
+    # IDL_RDBU = 4: red end at 0, white middle, blue end at 1
+    assert tones[(4, 0.0)][0] > 0.35 > tones[(4, 0.0)][2] and tones[(4, 1.0)][2] > 0.35 > tones[(4, 1.0)][0]
+    assert np.all(tones[(4, 0.5)] > 0.9)
+    # MATLAB_PARULA = 3: blue -> yellow, NONE_NORMALIZED = 1: grey ramp
+    assert tones[(3, 0.0)][2] > 0.6 and tones[(3, 1.0)][0] > 0.9 and tones[(3, 1.0)][2] < 0.2
+    np.testing.assert_allclose(tones[(1, 0.25)], [0.25] * 3)
