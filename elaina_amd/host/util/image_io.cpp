@@ -183,26 +183,13 @@ void write_exr(const fs::path &path, int width, int height, const std::vector<fl
     }
 }
 
-// ---- PFM / PPM ---------------------------------------------------------------------------------
+// ---- PFM ---------------------------------------------------------------------------------------
 void write_pfm(const fs::path &path, int width, int height, const std::vector<float> &rgb)
 {
     std::ofstream f(path, std::ios::binary);
     if (!f.is_open()) throw std::runtime_error("cannot write " + path.string());
     f << "PF\n" << width << " " << height << "\n-1.0\n";  // little endian, rows top to bottom as stored
     f.write(reinterpret_cast<const char *>(rgb.data()), (std::streamsize)(rgb.size() * sizeof(float)));
-}
-
-void write_ppm(const fs::path &path, int width, int height, const std::vector<float> &rgb)
-{
-    std::ofstream f(path, std::ios::binary);
-    if (!f.is_open()) throw std::runtime_error("cannot write " + path.string());
-    f << "P6\n" << width << " " << height << "\n255\n";
-    std::vector<unsigned char> px(rgb.size());
-    for (size_t i = 0; i < rgb.size(); ++i) {
-        const float v = std::isfinite(rgb[i]) ? std::min(std::max(rgb[i], 0.0f), 1.0f) : 0.0f;
-        px[i] = (unsigned char)(v * 255.0f + 0.5f);
-    }
-    f.write(reinterpret_cast<const char *>(px.data()), (std::streamsize)px.size());
 }
 
 }  // namespace elaina
