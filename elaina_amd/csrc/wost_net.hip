@@ -28,6 +28,19 @@ namespace wost {
 constexpr int kNetMaxLevels = 16;
 constexpr int kNetBlock = 64;
 
+// Gradients are SUMS over the training points, and float atomics would make them depend on the
+// order in which blocks and lanes arrive.  Every partial sum is therefore converted to 64-bit
+// fixed point (2^-36 resolution, +-1.3e8 range) and accumulated with integer atomics: integer
+// addition is associative, so the gradient -- and with it the whole training run -- is
+// reproducible bit for bit, on this device and against the CPU restatement.
+typedef long long fx_t;
+constexpr double kFxScale = 68719476736.0;   // 2^36
+__device__ __forceinline__ fx_t to_fx(float v) { return __double2ll_rn((double)v * kFxScale); }
+__device__ __forceinline__ void fx_add(fx_t *p, fx_t v)
+{
+    atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);
+}
+
 struct NetLayout {
     int32_t res[kNetMaxLevels];
     float scale[kNetMaxLevels];
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void net_backward_mfma_kernel(NetLayout L, 
 // one float atomic per (block, weight).
 template <int N_O, int N_I>
 __global__ __launch_bounds__(256) void weight_grad_mfma_kernel(const float *delta, int dstride, int doff, const float *input,
-                                                               int istride, int ioff, int n, int chunk, float *gW)
+                                                               int istride, int ioff, int n, int chunk, fx_t *gW)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(256) void weight_grad_mfma_kernel(const float *delt
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float v = acc[kt][c];
-                if (v != 0.0f) atomicAdd(gW + (size_t)(16 * rt + 4 * g + c) * N_I + 16 * kt + i, v);
+                if (v != 0.0f) fx_add(gW + (size_t)(16 * rt + 4 * g + c) * N_I + 16 * kt + i, to_fx(v));
             }
     }
 }
@@ -472,13 +485,14 @@ __global__ __launch_bounds__(kNetBlock) void net_backward_kernel(NetLayout L, co
 // level.  Training points arrive in pixel order, so neighbouring lanes hit the SAME entries:
 // direct global float atomics cost 39 ms per 524 288-sample batch.  Instead a launch takes a
 // group of consecutive levels [lv0, lv1) whose accumulators fit into LDS, a block accumulates its
-// chunk of points there (ds_add_f32) and flushes each touched entry with ONE global atomic.
+// chunk of points there (64-bit fixed point, ds_add_u64) and flushes each touched entry with ONE
+// global atomic; a level too large for LDS is split by feature range [q0, q1).
 // Work item = (point, level): neighbouring lanes read consecutive float4s of d_enc and hit
 // different levels.  use_lds = 0 (a level too large for LDS) scatters straight to global memory.
 __global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float *xy, const float *denc, int n, int chunk,
-                                                        int lv0, int lv1, int use_lds, float *grad)
+                                                        int lv0, int lv1, int q0, int q1, int use_lds, fx_t *grad)
 {
-    extern __shared__ float acc[];
+    extern __shared__ fx_t acc[];
     __shared__ float s_scale[kNetMaxLevels];
     __shared__ uint32_t s_res[kNetMaxLevels], s_off[kNetMaxLevels + 1];
     if (threadIdx.x <= (unsigned)L.n_levels) {
@@ -488,13 +502,13 @@ __global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float
             s_res[threadIdx.x] = (uint32_t)L.res[threadIdx.x];
         }
     }
-    const int nf = L.n_features;
-    const uint32_t base = L.level_off[lv0] * nf;                       // first float of the group
-    const int n_acc = use_lds ? (int)(L.level_off[lv1] * nf - base) : 0;
-    for (int e = threadIdx.x; e < n_acc; e += 256) acc[e] = 0.0f;
+    const int nf = L.n_features, nq = q1 - q0;                          // features [q0, q1) of every entry
+    const uint32_t base = L.level_off[lv0];                             // first entry of the group
+    const int n_acc = use_lds ? (int)(L.level_off[lv1] - base) * nq : 0;
+    for (int e = threadIdx.x; e < n_acc; e += 256) acc[e] = 0;
     __syncthreads();
     const int p0 = blockIdx.x * chunk, p1 = min(n, p0 + chunk);
-    float *gG = grad + L.n_mlp;
+    fx_t *gG = grad + L.n_mlp;
     const int n_lv = lv1 - lv0;
     const int n_items = (p1 - p0) * n_lv;
     for (int item = threadIdx.x; item < n_items; item += 256) {
@@ -510,18 +524,18 @@ __global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float
         for (int k = 0; k < 4; ++k) {
             const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
             const float w = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
-            const uint32_t e = (lo + (cx + cy * res) % n_level) * nf;
+            const uint32_t entry = lo + (cx + cy * res) % n_level;
             if (use_lds) {
-                for (int q = 0; q < nf; ++q) atomicAdd(&acc[e - base + q], w * d[q]);
+                for (int q = q0; q < q1; ++q) fx_add(&acc[(entry - base) * nq + (q - q0)], to_fx(w * d[q]));
             } else {
-                for (int q = 0; q < nf; ++q) atomicAdd(gG + e + q, w * d[q]);
+                for (int q = q0; q < q1; ++q) fx_add(gG + (size_t)entry * nf + q, to_fx(w * d[q]));
             }
         }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < n_acc; e += 256) {
-        const float v = acc[e];
-        if (v != 0.0f) atomicAdd(gG + base + e, v);
+        const fx_t v = acc[e];
+        if (v != 0) fx_add(gG + (size_t)(base + e / nq) * nf + q0 + e % nq, v);
     }
 }
 
@@ -529,7 +543,7 @@ __global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float
 // thread t owns the (r, k) pairs {t, t + 256, ...}; partial sums leave through float atomics.
 __global__ __launch_bounds__(256) void weight_grad_kernel(const float *delta, int dstride, int doff, const float *input,
                                                           int istride, int ioff, int n_o, int n_i, int n, int chunk,
-                                                          float *gW)
+                                                          fx_t *gW)
 {
     extern __shared__ float lds[];
     float *sd = lds;                 // [32][n_o]
@@ -566,7 +580,7 @@ __global__ __launch_bounds__(256) void weight_grad_kernel(const float *delta, in
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int pair = threadIdx.x + 256 * j;
-        if (pair < n_pairs && acc[j] != 0.0f) atomicAdd(gW + pair, acc[j]);
+        if (pair < n_pairs && acc[j] != 0.0f) fx_add(gW + pair, to_fx(acc[j]));
     }
 }
 
@@ -585,13 +599,13 @@ __global__ void transpose_mlp_kernel(NetLayout L, const float *src, float *dst)
 
 // tiny-cuda-nn adam.h adam_step nested in ema.h (debiased): step counts from 1
 __global__ void optimizer_kernel(uint32_t n, float *params, float *m1, float *m2, float *ema_raw, float *inference,
-                                 const float *grad, float lr_t, float beta1, float beta2, float eps, float l2, float decay,
+                                 const fx_t *grad, float lr_t, float beta1, float beta2, float eps, float l2, float decay,
                                  float debias, float loss_scale)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float w = params[i];
-    float g = grad[i] / loss_scale;
+    float g = (float)((double)grad[i] / kFxScale) / loss_scale;
     g += l2 * w;
     const float a = m1[i] = beta1 * m1[i] + (1.0f - beta1) * g;
     const float b = m2[i] = beta2 * m2[i] + (1.0f - beta2) * (g * g);
@@ -610,7 +624,8 @@ struct wost_net {
     wost_net_config cfg{};
     NetLayout L{};
     uint32_t n_params = 0;
-    float *params = nullptr, *inference = nullptr, *m1 = nullptr, *m2 = nullptr, *ema_raw = nullptr, *grad = nullptr;
+    float *params = nullptr, *inference = nullptr, *m1 = nullptr, *m2 = nullptr, *ema_raw = nullptr;
+    fx_t *grad = nullptr;   // fixed-point gradient sums of the last training step
     float *params_t = nullptr, *inference_t = nullptr;   // transposed MLP matrices (scalar forward pass)
     float *params_f = nullptr, *inference_f = nullptr;   // MFMA A-fragment order (MFMA forward pass)
     float *params_fb = nullptr;                          // MFMA fragments of the transposed matrices (backward pass)
@@ -691,8 +706,9 @@ static void net_free(wost_net *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    for (float *p : {h->params, h->inference, h->params_t, h->inference_t, h->params_f, h->inference_f, h->params_fb, h->m1, h->m2, h->ema_raw, h->grad, h->d_xy, h->d_out, h->d_dl, h->d_acts, h->d_deltas, h->d_denc})
+    for (float *p : {h->params, h->inference, h->params_t, h->inference_t, h->params_f, h->inference_f, h->params_fb, h->m1, h->m2, h->ema_raw, h->d_xy, h->d_out, h->d_dl, h->d_acts, h->d_deltas, h->d_denc})
         if (p) (void)hipFree(p);
+    if (h->grad) (void)hipFree(h->grad);
     delete h;
 }
 
@@ -721,7 +737,7 @@ int net_forward_train_dev(wost_net *h, const float *xy_dev, int n, hipStream_t s
 int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_scale, int apply_update, hipStream_t stream)
 {
     const NetLayout &L = h->L;
-    NET_TRY(hipMemsetAsync(h->grad, 0, (size_t)h->n_params * sizeof(float), stream));
+    NET_TRY(hipMemsetAsync(h->grad, 0, (size_t)h->n_params * sizeof(fx_t), stream));
     if (h->use_mfma) {
         const size_t lds = (size_t)L.n_mlp * sizeof(float);
         const int n_tiles = (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
@@ -735,32 +751,39 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
     }
     NET_TRY(hipGetLastError());
     {
-        // group consecutive levels so that each group's accumulators fit into LDS: up to 64 KB
-        // per group (two blocks per CU), a single larger level alone up to 150 KB (one block per CU)
+        // group consecutive levels so that each group's 8-byte accumulators fit into LDS: up to
+        // 64 KB per group (two blocks per CU), a single larger level alone up to 150 KB (one block
+        // per CU), and a level larger than that in feature slices
         const size_t small = 64 * 1024, big = 150 * 1024;
-        int lv = 0;
-        while (lv < L.n_levels) {
-            int end = lv;
-            size_t bytes = 0;
-            while (end < L.n_levels) {
-                const size_t add = (size_t)(L.level_off[end + 1] - L.level_off[end]) * L.n_features * sizeof(float);
-                if (bytes + add > small) break;
-                bytes += add;
-                ++end;
-            }
-            int use_lds = 1;
-            if (end == lv) {        // this level alone exceeds 64 KB
-                bytes = (size_t)(L.level_off[lv + 1] - L.level_off[lv]) * L.n_features * sizeof(float);
-                end = lv + 1;
-                if (bytes > big) { use_lds = 0; bytes = 0; }
-            }
+        auto level_bytes = [&](int l, int nq) { return (size_t)(L.level_off[l + 1] - L.level_off[l]) * nq * sizeof(fx_t); };
+        auto launch = [&](int lv0, int lv1, int q0, int q1, size_t bytes, int use_lds) {
             const int gchunk = bytes > small ? 4096 : 2048;
             if (bytes > small)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(grid_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)big);
             hipLaunchKernelGGL(grid_grad_kernel, dim3((unsigned)((n + gchunk - 1) / gchunk)), dim3(256), bytes, stream, L, xy_dev,
-                               h->d_denc, n, gchunk, lv, end, use_lds, h->grad);
-            lv = end;
+                               h->d_denc, n, gchunk, lv0, lv1, q0, q1, use_lds, h->grad);
+        };
+        int lv = 0;
+        while (lv < L.n_levels) {
+            int end = lv;
+            size_t bytes = 0;
+            while (end < L.n_levels && bytes + level_bytes(end, L.n_features) <= small) bytes += level_bytes(end++, L.n_features);
+            if (end > lv) {
+                launch(lv, end, 0, L.n_features, bytes, 1);
+                lv = end;
+                continue;
+            }
+            // this level alone exceeds 64 KB: whole if it fits one block per CU, else feature slices
+            int slices = 1;
+            while (slices < L.n_features && level_bytes(lv, (L.n_features + slices - 1) / slices) > big) ++slices;
+            const int per = (L.n_features + slices - 1) / slices;
+            for (int q0 = 0; q0 < L.n_features; q0 += per) {
+                const int q1 = std::min(L.n_features, q0 + per);
+                const size_t sb = level_bytes(lv, q1 - q0);
+                launch(lv, lv + 1, q0, q1, sb <= big ? sb : 0, sb <= big ? 1 : 0);
+            }
+            ++lv;
         }
         NET_TRY(hipGetLastError());
     }
@@ -772,7 +795,7 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
         const int n_i = layer == 0 ? L.enc : L.n_neurons, n_o = layer == L.n_hidden ? L.n_out_padded : L.n_neurons;
         const int doff = layer == L.n_hidden ? 0 : L.n_out_padded + layer * L.n_neurons;   // delta of this layer's output
         const int ioff = layer == 0 ? 0 : L.enc + (layer - 1) * L.n_neurons;               // this layer's input
-        float *gW = h->grad + L.w_off[layer];
+        fx_t *gW = h->grad + L.w_off[layer];
         if (h->use_mfma) {
 #define WG(NO, NI) hipLaunchKernelGGL((weight_grad_mfma_kernel<NO, NI>), dim3(gridc), dim3(256), 0, stream, h->d_deltas, dstride, \
                                       doff, h->d_acts, astride, ioff, n, chunk, gW)
@@ -856,12 +879,14 @@ int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_
     for (uint32_t e = 0; e < L.n_grid; ++e) init[L.n_mlp + e] = (uniform() * 2.0f - 1.0f) * 1e-4f;
     const size_t bytes = (size_t)h->n_params * sizeof(float);
     hipError_t e = hipSuccess;
-    for (float **p : {&h->params, &h->inference, &h->m1, &h->m2, &h->ema_raw, &h->grad, &h->params_t, &h->inference_t, &h->params_f, &h->inference_f, &h->params_fb})
+    for (float **p : {&h->params, &h->inference, &h->m1, &h->m2, &h->ema_raw, &h->params_t, &h->inference_t, &h->params_f, &h->inference_f, &h->params_fb})
         if (e == hipSuccess) e = hipMalloc((void **)p, bytes);
     if (e == hipSuccess) e = hipMemcpy(h->params, init.data(), bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->inference, init.data(), bytes, hipMemcpyHostToDevice);
-    for (float *p : {h->m1, h->m2, h->ema_raw, h->grad})
+    for (float *p : {h->m1, h->m2, h->ema_raw})
         if (e == hipSuccess) e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->grad, (size_t)h->n_params * sizeof(fx_t));
+    if (e == hipSuccess) e = hipMemset(h->grad, 0, (size_t)h->n_params * sizeof(fx_t));
     if (e != hipSuccess) {
         net_free(h);
         return set_error(WOST_ERR_DEVICE, std::string("network allocation: ") + hipGetErrorString(e));
@@ -892,7 +917,13 @@ int wost_net_get_params(wost_net_handle h, int which, float *host)
 {
     if (!h || !host || which < 0 || which > 2) return set_error(WOST_ERR_INVALID, "bad argument");
     NET_TRY(hipSetDevice(h->device));
-    const float *src = which == 0 ? h->params : which == 1 ? h->inference : h->grad;
+    if (which == 2) {
+        std::vector<fx_t> fx(h->n_params);
+        NET_TRY(hipMemcpy(fx.data(), h->grad, (size_t)h->n_params * sizeof(fx_t), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < h->n_params; ++i) host[i] = (float)((double)fx[i] / kFxScale);
+        return WOST_OK;
+    }
+    const float *src = which == 0 ? h->params : h->inference;
     NET_TRY(hipMemcpy(host, src, (size_t)h->n_params * sizeof(float), hipMemcpyDeviceToHost));
     return WOST_OK;
 }

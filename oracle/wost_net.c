@@ -122,83 +122,101 @@ int wo_net_forward(const wo_net_config *c, const float *params, const float *xy,
     return 0;
 }
 
-/* gradient of sum_p <dl_dout[p], out[p]> w.r.t. every parameter (grad must hold n_params floats) */
+/* Gradient of sum_p <dl_dout[p], out[p]> w.r.t. every parameter (grad must hold n_params floats).
+ * A gradient is a sum over the points; to make it independent of the order in which a parallel
+ * machine adds, every partial sum is converted to 64-bit fixed point (2^-36) and the integers are
+ * added: grid terms one by one, weight terms as fmaf chains over chunks of 1024
+ * consecutive points.  The HIP kernels do exactly the same, so both gradients are bit-identical. */
+#define WN_FX_SCALE 68719476736.0   /* 2^36 */
+#define WN_WGRAD_CHUNK 1024
+
 int wo_net_backward(const wo_net_config *c, const float *params, const float *xy, const float *dl_dout, int n,
                     float *grad)
 {
     wn_layout l;
     layout(c, &l);
     const int H = c->n_neurons, E = l.enc, NL = c->n_hidden_layers, NO = c->n_output_padded;
-    const int act_stride = E + NL * H;
-    memset(grad, 0, sizeof(float) * (l.n_mlp + l.n_grid));
-    float *a = malloc(sizeof(float) * (size_t)act_stride);
-    float *d = malloc(sizeof(float) * (size_t)(H > E ? H : E) * 2);
-    float *out = malloc(sizeof(float) * (size_t)NO);
+    const int act_stride = E + NL * H;        /* encoding + hidden activations of one point */
+    const int del_stride = NO + NL * H;       /* delta of the output layer, then of hidden layer 0.. */
+    const size_t n_params = l.n_mlp + l.n_grid;
+    long long *fx = calloc(n_params, sizeof(long long));
+    float *acts = malloc(sizeof(float) * (size_t)WN_WGRAD_CHUNK * act_stride);
+    float *dels = malloc(sizeof(float) * (size_t)WN_WGRAD_CHUNK * del_stride);
+    float *denc = malloc(sizeof(float) * (size_t)E);
     size_t *cidx = malloc(sizeof(size_t) * 4 * c->n_levels);
     float *cw = malloc(sizeof(float) * 4 * c->n_levels);
     const float *grid = params + l.n_mlp;
-    /* weight block offsets */
     size_t woff[WN_MAX_LEVELS];
     woff[0] = 0;
     woff[1] = (size_t)H * E;
     for (int i = 2; i <= NL; ++i) woff[i] = woff[i - 1] + (size_t)H * H;
-    for (int p = 0; p < n; ++p) {
-        encode(c, &l, grid, xy[2 * p], xy[2 * p + 1], a, cidx, cw);
-        /* forward, keeping activations */
-        const float *in = a;
-        int n_in = E;
-        for (int layer = 0; layer < NL; ++layer) {
-            const float *W = params + woff[layer];
-            float *o = a + E + layer * H;
-            for (int r = 0; r < H; ++r) {
-                float s = 0.0f;
-                for (int k = 0; k < n_in; ++k) s = fmaf(W[(size_t)r * n_in + k], in[k], s);
-                o[r] = s > 0.0f ? s : 0.0f;
+    for (int p0 = 0; p0 < n; p0 += WN_WGRAD_CHUNK) {
+        const int cnt = n - p0 < WN_WGRAD_CHUNK ? n - p0 : WN_WGRAD_CHUNK;
+        for (int q = 0; q < cnt; ++q) {
+            const int p = p0 + q;
+            float *a = acts + (size_t)q * act_stride;
+            float *d = dels + (size_t)q * del_stride;
+            encode(c, &l, grid, xy[2 * p], xy[2 * p + 1], a, cidx, cw);
+            /* forward, keeping activations */
+            const float *in = a;
+            int n_in = E;
+            for (int layer = 0; layer < NL; ++layer) {
+                const float *W = params + woff[layer];
+                float *o = a + E + layer * H;
+                for (int r = 0; r < H; ++r) {
+                    float s = 0.0f;
+                    for (int k = 0; k < n_in; ++k) s = fmaf(W[(size_t)r * n_in + k], in[k], s);
+                    o[r] = s > 0.0f ? s : 0.0f;
+                }
+                in = o; n_in = H;
             }
-            in = o; n_in = H;
-        }
-        /* output layer */
-        const float *dlo = dl_dout + (size_t)p * NO;
-        float *dcur = d, *dnext = d + (H > E ? H : E);
-        {
-            const float *W = params + woff[NL];
-            float *gW = grad + woff[NL];
-            const float *h = a + E + (NL - 1) * H;
-            for (int k = 0; k < H; ++k) dcur[k] = 0.0f;
-            for (int r = 0; r < NO; ++r) {
-                const float g = dlo[r];
-                if (g == 0.0f) continue;
+            /* deltas: output layer, then back through the hidden layers (sums over r ascending) */
+            for (int r = 0; r < NO; ++r) d[r] = dl_dout[(size_t)p * NO + r];
+            const float *dcur = d;
+            int n_o = NO;
+            for (int layer = NL; layer >= 1; --layer) {
+                const float *W = params + woff[layer];
+                const float *h = a + E + (layer - 1) * H;
+                float *dn = d + NO + (layer - 1) * H;
                 for (int k = 0; k < H; ++k) {
-                    gW[(size_t)r * H + k] += g * h[k];
-                    dcur[k] = fmaf(W[(size_t)r * H + k], g, dcur[k]);
+                    float s = 0.0f;
+                    for (int r = 0; r < n_o; ++r) s = fmaf(W[(size_t)r * H + k], dcur[r], s);
+                    dn[k] = h[k] > 0.0f ? s : 0.0f;                      /* ReLU' */
                 }
+                dcur = dn; n_o = H;
             }
+            for (int k = 0; k < E; ++k) {
+                float s = 0.0f;
+                const float *W = params + woff[0];
+                for (int r = 0; r < H; ++r) s = fmaf(W[(size_t)r * E + k], dcur[r], s);
+                denc[k] = s;
+            }
+            /* grid: every (corner, feature) term on its own */
+            long long *gG = fx + l.n_mlp;
+            for (int lv = 0; lv < c->n_levels; ++lv)
+                for (int k = 0; k < 4; ++k)
+                    for (int f = 0; f < c->n_features; ++f) {
+                        const float t = cw[4 * lv + k] * denc[lv * c->n_features + f];
+                        gG[cidx[4 * lv + k] * c->n_features + f] += llrint((double)t * WN_FX_SCALE);
+                    }
         }
-        for (int layer = NL - 1; layer >= 0; --layer) {
-            const int nin = layer == 0 ? E : H;
-            const float *W = params + woff[layer];
-            float *gW = grad + woff[layer];
-            const float *o = a + E + layer * H;
-            const float *inp = layer == 0 ? a : a + E + (layer - 1) * H;
-            for (int k = 0; k < nin; ++k) dnext[k] = 0.0f;
-            for (int r = 0; r < H; ++r) {
-                const float g = o[r] > 0.0f ? dcur[r] : 0.0f;   /* ReLU' */
-                if (g == 0.0f) continue;
-                for (int k = 0; k < nin; ++k) {
-                    gW[(size_t)r * nin + k] += g * inp[k];
-                    dnext[k] = fmaf(W[(size_t)r * nin + k], g, dnext[k]);
+        /* weights: one fmaf chain per (row, column) over the points of the chunk */
+        for (int layer = 0; layer <= NL; ++layer) {
+            const int n_i = layer == 0 ? E : H, n_o = layer == NL ? NO : H;
+            const int doff = layer == NL ? 0 : NO + layer * H;            /* delta of this layer's output */
+            const int ioff = layer == 0 ? 0 : E + (layer - 1) * H;         /* this layer's input */
+            long long *gW = fx + woff[layer];
+            for (int r = 0; r < n_o; ++r)
+                for (int k = 0; k < n_i; ++k) {
+                    float s = 0.0f;
+                    for (int q = 0; q < cnt; ++q)
+                        s = fmaf(dels[(size_t)q * del_stride + doff + r], acts[(size_t)q * act_stride + ioff + k], s);
+                    if (s != 0.0f) gW[(size_t)r * n_i + k] += llrint((double)s * WN_FX_SCALE);
                 }
-            }
-            float *t = dcur; dcur = dnext; dnext = t;
         }
-        /* dcur = dL/d(encoded input): scatter into the grid */
-        float *gG = grad + l.n_mlp;
-        for (int lv = 0; lv < c->n_levels; ++lv)
-            for (int k = 0; k < 4; ++k)
-                for (int q = 0; q < c->n_features; ++q)
-                    gG[cidx[4 * lv + k] * c->n_features + q] += cw[4 * lv + k] * dcur[lv * c->n_features + q];
     }
-    free(a); free(d); free(out); free(cidx); free(cw);
+    for (size_t i = 0; i < n_params; ++i) grad[i] = (float)((double)fx[i] / WN_FX_SCALE);
+    free(fx); free(acts); free(dels); free(denc); free(cidx); free(cw);
     return 0;
 }
 
