@@ -752,13 +752,13 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
     NET_TRY(hipGetLastError());
     {
         // group consecutive levels so that each group's 8-byte accumulators fit into LDS: up to
-        // 64 KB per group (two blocks per CU), a single larger level alone up to 150 KB (one block
+        // 72 KB per group (two blocks per CU), a single larger level alone up to 150 KB (one block
         // per CU), and a level larger than that in feature slices
-        const size_t small = 64 * 1024, big = 150 * 1024;
+        const size_t small = 72 * 1024, big = 150 * 1024;
         auto level_bytes = [&](int l, int nq) { return (size_t)(L.level_off[l + 1] - L.level_off[l]) * nq * sizeof(fx_t); };
         auto launch = [&](int lv0, int lv1, int q0, int q1, size_t bytes, int use_lds) {
             const int gchunk = bytes > small ? 4096 : 2048;
-            if (bytes > small)
+            if (bytes > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(grid_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)big);
             hipLaunchKernelGGL(grid_grad_kernel, dim3((unsigned)((n + gchunk - 1) / gchunk)), dim3(256), bytes, stream, L, xy_dev,
@@ -774,7 +774,7 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
                 lv = end;
                 continue;
             }
-            // this level alone exceeds 64 KB: whole if it fits one block per CU, else feature slices
+            // this level alone exceeds the group budget: whole if it fits one block per CU, else feature slices
             int slices = 1;
             while (slices < L.n_features && level_bytes(lv, (L.n_features + slices - 1) / slices) > big) ++slices;
             const int per = (L.n_features + slices - 1) / slices;
