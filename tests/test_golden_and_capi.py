@@ -84,3 +84,36 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"oracle[/.]|wost_oracle|from oracle|import oracle", text):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_guided_and_network_entry_points_reject_bad_arguments(ladybug):
+    """every new entry point of the boundary validates its arguments before touching a device,
+    and without a GPU the constructors fail loudly (no CPU path)"""
+    import torch
+    from elaina_amd import capi
+    from elaina_amd.guided import (GuidedIntegrator, GuidedIntegratorSettings, GuidingNetwork, default_net_config)
+    lib = capi.load()
+    assert lib.wost_net_create(0, None, 1, None) == -1
+    assert lib.wost_guided_create(None, None, None, 1, 0, None) == -1
+    assert lib.wost_net_inference(None, None, 0, None, 1) == -1
+    assert lib.wost_net_train_step(None, None, None, 0, 1.0, 1) == -1
+    assert lib.wost_guided_solve(None, None, None) == -1
+    assert lib.wost_guided_solve_sharded(None, 0, 1, None, None) == -1
+    assert lib.wost_guided_train_set(None, 0, None, None, None, None, None, None, None) == -1
+    assert lib.wost_guided_query_network(None, None, 0, None) == -1
+    # shape restrictions are reported before any device work
+    cfg = default_net_config()
+    cfg.n_neurons = 100
+    h = C.c_void_p()
+    assert lib.wost_net_create(0, C.byref(cfg), 1, C.byref(h)) == -3 and b"network shape" in lib.wost_last_error()
+    if not torch.cuda.is_available():
+        with pytest.raises(capi.WostError, match="no HIP device"):
+            GuidingNetwork()
+        with pytest.raises(capi.WostError, match="no HIP device"):
+            GuidedIntegrator(ladybug, GuidedIntegratorSettings(frameSize=(8, 8), samplesPerPixel=1), ((0, 0), (1, 1)))
+    # settings the device code does not cover are refused up front
+    bad = GuidedIntegratorSettings(frameSize=(8, 8), samplesPerPixel=1, maxTrainDepth=7)
+    with pytest.raises(capi.WostError, match="max_train_depth|no HIP device"):
+        GuidedIntegrator(ladybug, bad, ((0, 0), (1, 1)))
+    with pytest.raises(capi.WostError, match="bad guided settings|no HIP device"):
+        GuidedIntegrator(ladybug, GuidedIntegratorSettings(frameSize=(8, 8), samplesPerPixel=1), ((1, 1), (0, 0)))

@@ -1,15 +1,20 @@
-"""BASELINE config 4 (ladybug, guided integrator with online training, 1024^2, 256 spp) on one
-MI355X: wall time, walk-steps/s, share of the training passes.  Prints one JSON line.
-Usage: python tools/gpu_guided_bench.py [--frame 1024] [--spp 256] [--train-spp 256] [--depth 64]"""
+"""Guided integrator runner.  One GPU: BASELINE config 4 (ladybug, guided integrator with online
+training, 1024^2, 256 spp).  Several GPUs (config 5): launch with
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/gpu_guided_bench.py --frame 2048 --spp 1024 --train-spp 256
+every rank owns the 8x8 pixel tiles t % N == rank and trains its own network;
+the fields are summed with one RCCL all-reduce.  Prints one JSON line on rank 0.
+Usage: python tools/gpu_guided_bench.py [--scene ladybug] [--frame 1024] [--spp 256] [--train-spp 256] [--depth 64]"""
 import argparse
 import json
+import os
 import sys
 import time
 
-import numpy as np
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import torch  # noqa: E402
 
-sys.path.insert(0, ".")
 from elaina_amd import Problem  # noqa: E402
+from elaina_amd import distributed as D  # noqa: E402
 from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -19,22 +24,44 @@ ap.add_argument("--spp", type=int, default=256)
 ap.add_argument("--train-spp", type=int, default=256)
 ap.add_argument("--depth", type=int, default=64)
 ap.add_argument("--guided-depth", type=int, default=10)
+ap.add_argument("--backend", default=None)
 a = ap.parse_args()
 
+rank, world, local = D.init_process_group(a.backend)
+device = local % max(torch.cuda.device_count(), 1)
+torch.cuda.set_device(device)
 prob = Problem.load_scene(a.scene)
 st = GuidedIntegratorSettings(frameSize=(a.frame, a.frame), samplesPerPixel=a.spp, trainSppCount=a.train_spp,
                               maxWalkingDepth=a.depth, epsilonShell=1.0, maxGuidedDepthInTrainingPhase=a.guided_depth,
                               maxGuidedDepthInGuidingPhase=a.guided_depth)
 t0 = time.time()
-gi = GuidedIntegrator(prob, st, ((-100.0, -100.0), (600.0, 600.0)))
+gi = GuidedIntegrator(prob, st, ((-100.0, -100.0), (600.0, 600.0)), device=device)
 t_create = time.time() - t0
-gi.solve()
-s = gi.last_stats
-print(json.dumps({
-    "workload": "%s guided %dx%d %d spp (train %d) depth %d" % (a.scene, a.frame, a.frame, a.spp, a.train_spp, a.depth),
-    "solve_s": s["solve_ms"] / 1e3, "train_s": s["train_ms"] / 1e3, "create_s": t_create,
-    "walk_steps": s["walk_steps"], "walk_steps_per_s": s["walk_steps"] / (s["solve_ms"] / 1e3),
-    "guided_steps": s["guided_steps"], "train_samples": s["train_samples"], "optimizer_steps": s["optimizer_steps"],
-    "kernel_launches": s["kernel_launches"], "truncated": s["walks_truncated"], "started": s["walks_started"],
-    "mean": float(np.mean(gi.solution)),
-}))
+field = torch.zeros(a.frame * a.frame * 3, dtype=torch.float32, device="cuda")
+if world > 1:
+    import torch.distributed as dist
+    dist.barrier()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+s = gi.solve_sharded(rank, world, field.data_ptr())
+D.reduce_field(field, world)
+torch.cuda.synchronize()
+elapsed = time.perf_counter() - t0
+tot = torch.tensor([float(s["walk_steps"]), float(s["guided_steps"]), float(s["train_samples"]), float(s["optimizer_steps"])],
+                   dtype=torch.float64, device="cuda")
+mx = torch.tensor([elapsed, s["train_ms"] / 1e3], dtype=torch.float64, device="cuda")
+if world > 1:
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+if rank == 0:
+    print(json.dumps({
+        "workload": "%s guided %dx%d %d spp (train %d) depth %d" % (a.scene, a.frame, a.frame, a.spp, a.train_spp, a.depth),
+        "n_gpus": world, "solve_s": float(mx[0]), "train_s": float(mx[1]), "create_s": t_create,
+        "walk_steps": int(tot[0]), "walk_steps_per_s": float(tot[0]) / float(mx[0]), "guided_steps": int(tot[1]),
+        "train_samples": int(tot[2]), "optimizer_steps_all_ranks": int(tot[3]), "kernel_launches": s["kernel_launches"],
+        "mean": float(field.mean().item()),
+    }))
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+gi.close()
