@@ -26,6 +26,13 @@ class MeshDesc(C.Structure):
     ]
 
 
+class SourceDesc(C.Structure):
+    _fields_ = [
+        ("nx", C.c_int32), ("ny", C.c_int32), ("rgb", C.POINTER(C.c_float)),
+        ("index_scale", C.c_float * 2), ("index_offset", C.c_float * 2), ("intensity", C.c_float),
+    ]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [
         ("dirichlet", MeshDesc),
@@ -36,6 +43,7 @@ class SceneDesc(C.Structure):
         ("probe_pos", C.c_float * 2),
         ("probe_up", C.c_float * 2),
         ("mask", C.POINTER(C.c_uint8)),
+        ("source", SourceDesc),
     ]
 
 
@@ -108,7 +116,7 @@ class GuidedStats(C.Structure):
 
 
 EXPORTS = [
-    "wost_create", "wost_solve", "wost_solve_sharded", "wost_render_sdf", "wost_closest_point",
+    "wost_create", "wost_solve", "wost_solve_sharded", "wost_render_sdf", "wost_render_source", "wost_closest_point",
     "wost_closest_silhouette", "wost_ray_intersect", "wost_set_option", "wost_destroy",
     "wost_vonmises_eval", "wost_vonmises_sample", "wost_vmm_pdf_sample", "wost_vmm_loss_gradients",
     "wost_net_create", "wost_net_destroy", "wost_net_n_params", "wost_net_get_params",
@@ -147,6 +155,7 @@ def load():
     L.wost_solve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, fp, C.POINTER(Stats)]
     L.wost_solve_sharded.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     L.wost_render_sdf.argtypes = [C.c_void_p, C.c_int, fp]
+    L.wost_render_source.argtypes = [C.c_void_p, fp]
     L.wost_closest_point.argtypes = [C.c_void_p, C.c_int, fp, C.c_int32, ip, fp, fp, ip]
     L.wost_closest_silhouette.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_int32, fp]
     L.wost_ray_intersect.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, C.c_int32, ip, fp, ip]

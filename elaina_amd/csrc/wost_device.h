@@ -53,6 +53,14 @@ struct DevProbe {
     float scale, posx, posy, upx, upy;
 };
 
+// source term: dense RGB grid, index = world * scale + offset (see wost_source_desc)
+struct DevSource {
+    const float *rgb;   // nullptr = no source term
+    int32_t nx, ny;
+    float sx, sy, ox, oy;
+    float intensity;
+};
+
 struct DevSettings {
     int32_t width, height, spp, max_depth;
     float eps;

@@ -69,6 +69,7 @@ struct GParams {
     DevMesh dm, nm;
     DevSettings st;
     DevProbe probe;
+    DevSource src;
     GAabb box;
     const uint8_t *mask;
     GQueue in, out;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void begin_sample_kernel(GParams P)
 
 // ---- separateEvaluationPoint + handleBoundary + sampleNeumann + generate_inference_data -----
 // (reference guided/integrator.cu:153-249, 252-274, 367-494; train.h:474-486)
-template <bool EMISSIVE, bool TREE>
+template <bool EMISSIVE, bool TREE, bool SOURCE>
 __global__ __launch_bounds__(256) void separate_kernel(GParams P)
 {
     extern __shared__ uint32_t lds_stack[];
@@ -223,6 +224,17 @@ __global__ __launch_bounds__(256) void separate_kernel(GParams P)
             if (P.nm.n_segs > 0) R_N = closest_silhouette<TREE>(P.nm, x, y, R_D, stk);
             R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));     // no 0.99 in the guided integrator (:238-239)
             keep = !isinf(R_B);                              // no boundary at all: nothing to walk to
+            if (SOURCE && keep) {
+                // sampleSource (reference guided/integrator.cu:277-364) + recordSourceContribution
+                Pcg rng{P.rng[pid], 1};
+                float cr, cg, cb;
+                if (source_sample<TREE>(P.src, P.nm, eps, x, y, R_B, on_n, nx, ny, thp, rng, stk, cr, cg, cb)) {
+                    float *s = P.sol + 3 * (size_t)pid;
+                    s[0] = cr + s[0]; s[1] = cg + s[1]; s[2] = cb + s[2];
+                    if (train_px) record_solution(P, pid, cr, cg, cb);
+                }
+                P.rng[pid] = rng.state;
+            }
             if (keep && P.nm.n_segs > 0) {
                 Pcg rng{P.rng[pid], 1};
                 float cr, cg, cb;
@@ -661,7 +673,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
 
     G_TRY(hipMemsetAsync(g->stats, 0, sizeof(GStatsDev), stream));
     GParams P{};
-    P.dm = v.dm; P.nm = v.nm; P.st = v.st; P.probe = v.probe; P.box = g->box; P.mask = v.mask;
+    P.dm = v.dm; P.nm = v.nm; P.st = v.st; P.probe = v.probe; P.src = v.src; P.box = g->box; P.mask = v.mask;
     P.rng = g->rng; P.sol = g->sol; P.cur_depth = g->cur_depth; P.rec = g->rec; P.hint0 = g->hint0;
     P.net_in = g->net_in; P.net_out = g->net_out; P.stats = g->stats; P.n_pixels = N; P.stack_stride = 256;
     P.max_train_depth = s.max_train_depth;
@@ -697,7 +709,11 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
             P.out = g->q[nxt]; P.count_out = g->counts + nxt;
             G_TRY(hipMemsetAsync(g->counts + nxt, 0, sizeof(uint32_t), stream));
             const unsigned grid = (n_cur + 255) / 256;
-#define LAUNCH_SEP(E, T) hipLaunchKernelGGL((separate_kernel<E, T>), dim3(grid), dim3(256), lds, stream, P)
+#define LAUNCH_SEP(E, T)                                                                                             \
+    do {                                                                                                             \
+        if (v.src.rgb) hipLaunchKernelGGL((separate_kernel<E, T, true>), dim3(grid), dim3(256), lds, stream, P);       \
+        else hipLaunchKernelGGL((separate_kernel<E, T, false>), dim3(grid), dim3(256), lds, stream, P);                 \
+    } while (0)
             if (emissive) { if (tree) LAUNCH_SEP(true, true); else LAUNCH_SEP(true, false); }
             else          { if (tree) LAUNCH_SEP(false, true); else LAUNCH_SEP(false, false); }
 #undef LAUNCH_SEP

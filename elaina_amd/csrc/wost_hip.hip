@@ -60,6 +60,7 @@ struct RoundParams {
     DevMesh dm, nm;
     DevSettings st;
     DevProbe probe;
+    DevSource src;
     WalkQueue in, out;
     const uint32_t *count_in;
     uint32_t *count_out;
@@ -181,9 +182,9 @@ struct LaneStats {
 // status bits returned by step_finish
 enum : uint32_t { STEP_ENDED = 1u, STEP_ABSORBED = 2u, STEP_TRUNCATED = 4u, STEP_NEUMANN_HIT = 8u };
 
-template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, class STK>
+template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, bool SOURCE = false, class STK = LdsColumn>
 __device__ __forceinline__ uint32_t step_finish(const DevMesh &dm, const DevMesh &nm, const DevSettings &st, Lane &L,
-                                                const Closest cp, const STK &stk)
+                                                const Closest cp, const STK &stk, const DevSource &src = DevSource{})
 {
     const bool has_d = dm.n_segs > 0, has_n = nm.n_segs > 0;
     const float eps = st.eps;
@@ -216,6 +217,14 @@ __device__ __forceinline__ uint32_t step_finish(const DevMesh &dm, const DevMesh
     float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
     R_B *= WOST_R_B_SHRINK;
     if (isinf(R_B)) return STEP_ENDED;
+
+    // ---- sampleSource (problems with a source term only) ------------------------------------
+    if (SOURCE) {
+        float cr_, cg_, cb_;
+        if (source_sample<NEUMANN_TREE>(src, nm, eps, px, py, R_B, L.on_n, L.nx, L.ny, L.thp, L.rng, stk, cr_, cg_, cb_)) {
+            L.sr = cr_ + L.sr; L.sg = cg_ + L.sg; L.sb = cb_ + L.sb;
+        }
+    }
 
     // ---- sampleNeumann -------------------------------------------------------------------
     if (has_n) {
@@ -264,7 +273,7 @@ __device__ __forceinline__ void load_lane(const WalkQueue &q, uint32_t slot, Lan
 // is complete writes it out and takes the next unread slot of the input queue (one atomic per
 // wave), so the whole solve is ONE launch and no lane idles while work is left -- the
 // low-sample-count path (time-to-1spp), where regeneration cannot fill the lanes.
-template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, bool REFILL = false>
+template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, bool REFILL = false, bool SOURCE = false>
 __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(RoundParams P)
 {
     extern __shared__ uint32_t lds_stack[];
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
             // ---- step phase ----
             if (mode == MODE_WAIT) {
                 if (!fresh) {
-                    const uint32_t status = step_finish<NEUMANN_EMISSIVE, NEUMANN_TREE>(P.dm, P.nm, P.st, L, T.best, stk);
+                    const uint32_t status = step_finish<NEUMANN_EMISSIVE, NEUMANN_TREE, SOURCE>(P.dm, P.nm, P.st, L, T.best, stk, P.src);
                     const bool ended = (status & STEP_ENDED) != 0u;
                     S.b += ((status >> 1) & 1u) | (((status >> 2) & 1u) << 16);
                     S.c += (status >> 3) & 1u;
@@ -495,6 +504,16 @@ __global__ __launch_bounds__(256) void sdf_kernel(DevMesh m, DevProbe probe, int
     out[pid] = d;
 }
 
+__global__ __launch_bounds__(256) void source_kernel(DevSource src, DevProbe probe, int width, int height, float *out)
+{
+    const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= width * height) return;
+    float x, y, r = 0.0f, g = 0.0f, b = 0.0f;
+    eval_point(probe, pid % width, pid / width, width, height, x, y);
+    if (src.rgb) source_eval(src, x, y, r, g, b);
+    out[3 * (size_t)pid] = r; out[3 * (size_t)pid + 1] = g; out[3 * (size_t)pid + 2] = b;
+}
+
 __global__ __launch_bounds__(256) void silhouette_kernel(DevMesh m, const float *pts, const float *rmax, int n,
                                                          float *out)
 {
@@ -614,6 +633,7 @@ struct wost_context {
     DevProbe probe{};
     DeviceMeshStorage dm, nm;
     uint8_t *mask = nullptr;
+    DevSource src{};                // rgb == nullptr: no source term
     size_t n_pixels = 0;
     // queues
     void *queue_mem[2] = {nullptr, nullptr};
@@ -646,7 +666,7 @@ struct wost_context {
 namespace wost {
 SceneView scene_view(wost_handle h)
 {
-    return SceneView{h->device, h->dm.view, h->nm.view, h->dst, h->probe, h->mask, h->stream};
+    return SceneView{h->device, h->dm.view, h->nm.view, h->dst, h->probe, h->mask, h->stream, h->src};
 }
 }  // namespace wost
 
@@ -675,6 +695,7 @@ static void destroy_ctx(wost_context *c)
     for (void *p : c->dm.allocs) (void)hipFree(p);
     for (void *p : c->nm.allocs) (void)hipFree(p);
     if (c->mask) (void)hipFree(c->mask);
+    if (c->src.rgb) (void)hipFree(const_cast<float *>(c->src.rgb));
     for (int i = 0; i < 2; ++i)
         if (c->queue_mem[i]) (void)hipFree(c->queue_mem[i]);
     if (c->counts) (void)hipFree(c->counts);
@@ -737,6 +758,19 @@ int wost_create(const wost_scene_desc *scene, const wost_settings *settings, int
     if (scene->mask) {
         HIP_TRY_C(hipMalloc((void **)&c->mask, c->n_pixels));
         HIP_TRY_C(hipMemcpy(c->mask, scene->mask, c->n_pixels, hipMemcpyHostToDevice));
+    }
+    if (scene->source.nx > 0 && scene->source.ny > 0) {
+        const wost_source_desc &sd = scene->source;
+        if (!sd.rgb) {
+            fail(WOST_ERR_INVALID, "source grid without data");
+            return bail(WOST_ERR_INVALID);
+        }
+        const size_t bytes = (size_t)sd.nx * sd.ny * 3 * sizeof(float);
+        float *dev = nullptr;
+        HIP_TRY_C(hipMalloc((void **)&dev, bytes));
+        c->src = DevSource{dev, sd.nx, sd.ny, sd.index_scale[0], sd.index_scale[1], sd.index_offset[0], sd.index_offset[1],
+                           sd.intensity};
+        HIP_TRY_C(hipMemcpy(dev, sd.rgb, bytes, hipMemcpyHostToDevice));
     }
     const size_t qbytes = c->n_pixels * 4 * kQueueWords;
     for (int i = 0; i < 2; ++i) {
@@ -858,7 +892,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     int cur = 0;
     const bool emissive = c->nm.view.n_segs > 0 && c->nm.view.emissive;
     const bool ntree = c->nm.view.n_segs > WOST_FLAT_MAX;
-    if (c->kernel == 1 && n_active > 0) {
+    if (c->kernel == 1 && n_active > 0 && c->src.rgb == nullptr) {
         // ---- pool kernel: one launch walks every pixel of this call ----
         PoolParams pp{};
         pp.dm = c->dm.view;
@@ -926,6 +960,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         rp.nm = c->nm.view;
         rp.st = c->dst;
         rp.probe = c->probe;
+        rp.src = c->src;
         rp.in = c->queue[cur];
         rp.out = c->queue[nxt];
         rp.count_in = c->counts + cur;
@@ -951,7 +986,8 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         // 1 spp 3.5 -> 3.0 ms, 4 spp 8.3 -> 7.9 ms, 8 spp 13.0 -> 13.5 ms) and the queue is larger
         // than one residency; the 16-bit lane counters bound spp * max_depth.
         const unsigned resident = (unsigned)(c->n_cus * (ntree ? 4 : 6) * 4 * 64 / bs);
-        const bool can_refill = (int64_t)c->settings.spp * c->settings.max_depth < 65535 && launches == 0;
+        const bool has_src = c->src.rgb != nullptr;
+        const bool can_refill = (int64_t)c->settings.spp * c->settings.max_depth < 65535 && launches == 0 && !has_src;
         const bool refill = can_refill && (c->refill == 1 || (c->refill == -1 && c->settings.spp <= 4 && grid > resident));
         if (refill) {
             grid = std::min(grid, resident);
@@ -961,7 +997,16 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
             rp.steps_per_round = 0x7fffffff;
         }
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
-        if (refill) {
+        if (has_src) {
+            // problems with a source term: the SOURCE instantiations (one extra stage per step)
+            if (ntree) {
+                if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+                else hipLaunchKernelGGL((walk_round_kernel<false, true, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+            } else {
+                if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+                else hipLaunchKernelGGL((walk_round_kernel<false, false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+            }
+        } else if (refill) {
             if (ntree) {
                 if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
                 else hipLaunchKernelGGL((walk_round_kernel<false, true, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
@@ -1087,6 +1132,22 @@ int wost_render_sdf(wost_handle h, int which_mesh, float *out_dist)
                        h->settings.width, h->settings.height, which_mesh, d_out, bs);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_dist, d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return WOST_OK;
+}
+
+int wost_render_source(wost_handle h, float *out_rgb)
+{
+    if (!h || !out_rgb) return fail(WOST_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const int n = (int)h->n_pixels;
+    Scratch sc;
+    float *d = nullptr;
+    HIP_TRY(sc.alloc(&d, (size_t)n * 3));
+    hipLaunchKernelGGL(source_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->src, h->probe, h->settings.width,
+                       h->settings.height, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_rgb, d, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return WOST_OK;
 }

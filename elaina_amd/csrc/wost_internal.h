@@ -23,6 +23,7 @@ struct SceneView {
     DevProbe probe;
     const uint8_t *mask;   // device, width*height bytes or nullptr
     hipStream_t stream;
+    DevSource src;         // rgb == nullptr: no source term
 };
 SceneView scene_view(wost_handle h);
 

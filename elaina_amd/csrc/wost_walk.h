@@ -55,6 +55,76 @@ __device__ __forceinline__ bool neumann_sample(const DevMesh &nm, float neumann_
     return true;
 }
 
+// bilinear sample of the source grid at a world point, times the intensity
+__device__ __forceinline__ void source_eval(const DevSource &src, float x, float y, float &r, float &g, float &b)
+{
+    const float gx = __builtin_fmaf(x, src.sx, src.ox), gy = __builtin_fmaf(y, src.sy, src.oy);
+    const float fx = floorf(gx), fy = floorf(gy);
+    const float u = gx - fx, v = gy - fy;
+    const int i = (int)fmaxf(fminf(fx, 1e9f), -1e9f), j = (int)fmaxf(fminf(fy, 1e9f), -1e9f);
+    float t[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ii = i + (k & 1), jj = j + (k >> 1);
+        const bool in = ii >= 0 && jj >= 0 && ii < src.nx && jj < src.ny;
+        const float *p = src.rgb + 3 * ((size_t)(in ? jj : 0) * src.nx + (in ? ii : 0));
+        t[k][0] = in ? p[0] : 0.0f; t[k][1] = in ? p[1] : 0.0f; t[k][2] = in ? p[2] : 0.0f;
+    }
+    float out[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a = t[0][c] + (t[1][c] - t[0][c]) * u;
+        const float bb = t[2][c] + (t[3][c] - t[2][c]) * u;
+        out[c] = (a + (bb - a) * v) * src.intensity;
+    }
+    r = out[0]; g = out[1]; b = out[2];
+}
+
+__device__ __forceinline__ void uniform_direction(bool on_n, float nx, float ny, Pcg &rng, float &dirx, float &diry,
+                                                  float &pdf, float &alpha);
+template <bool TREE, class STK>
+__device__ __forceinline__ bool ray_closest(const DevMesh &m, float ox, float oy, float dx, float dy, float tmax, float &t_out,
+                                            int &idx_out, const STK &stk);
+
+// sampleSource (reference integrator/uniform/integrator.cu:255-314, guided/integrator.cu:297-363):
+// one direction draw, the straight line clipped by the Neumann boundary, a radius from the
+// rejection sampler of HarmonicGreenBall<2> (util/green.h:44-73: two draws per trial, at most
+// 1000 trials), the source value there.  Returns true and the term to ADD to the solution when
+// the sampled point lies inside the star-shaped region.
+template <bool TREE, class STK>
+__device__ __forceinline__ bool source_sample(const DevSource &src, const DevMesh &nm, float eps, float px, float py, float R_B,
+                                              bool on_n, float nx, float ny, float thp, Pcg &rng, const STK &stk, float &cr,
+                                              float &cg, float &cb)
+{
+    float dirx, diry, dir_pdf, alpha;
+    uniform_direction(on_n, nx, ny, rng, dirx, diry, dir_pdf, alpha);
+    float dist = R_B;
+    if (nm.n_segs > 0) {
+        float t;
+        int hi;
+        if (ray_closest<TREE>(nm, px + eps * dirx, py + eps * diry, dirx, diry, dist, t, hi, stk)) dist = fminf(t, dist);
+    }
+    const float norm = R_B * R_B / 4.0f, bound = 1.5f / R_B;
+    float r = 0.0f;
+    for (int iter = 0; iter < 1000; ++iter) {
+        const float u = pcg_next_float(rng);
+        r = pcg_next_float(rng) * R_B;
+        const float pdf = (det_logf(R_B / r) / WOST_2PI) / norm;        // r == 0 -> +inf: accepted
+        const float pdf_radius = pdf / (1.0f / WOST_2PI);
+        if (u < pdf_radius / bound) break;
+    }
+    r = fmaxf(1e-4f, r);                                                 // ELAINA_GREEN_FUNC_R_CLAMP
+    if (r > R_B) r = R_B / 2.0f;
+    if (!(r <= dist)) return false;
+    float fr, fg, fb;
+    source_eval(src, px + r * dirx, py + r * diry, fr, fg, fb);
+    const float c1 = (1.0f / WOST_2PI) / r, c2 = dir_pdf / r;            // conditionalSampleSpherePDF<2>
+    cr = thp * fr * norm * c1 / c2 / alpha;
+    cg = thp * fg * norm * c1 / c2 / alpha;
+    cb = thp * fb * norm * c1 / c2 / alpha;
+    return true;
+}
+
 // uniformSampleSphere<2> / uniformSampleHemisphere<2> in the frame of the Neumann normal
 // (util/sampling.h:29-33,80-85, util/transformation.h:30-55): one draw.
 __device__ __forceinline__ void uniform_direction(bool on_n, float nx, float ny, Pcg &rng, float &dirx, float &diry,

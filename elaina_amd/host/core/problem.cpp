@@ -161,8 +161,26 @@ void Problem<2>::loadConfig(const json &config, const fs::path &search_dir)
         if (vertex_color_neumann.size() != scene_stat.neumann_vertices_size * 6)
             throw std::runtime_error("Neumann colour file does not have one entry per vertex");
     }
+    // The reference reads a nanovdb Vec3f grid ("source_path", core/problem.cu:136-149); nanovdb is
+    // not available here, so the source term comes as a dense grid:
+    //   "source_grid": {"path": raw little-endian float32 [ny][nx][3], "nx", "ny",
+    //                   "index_scale": [sx, sy], "index_offset": [ox, oy]}   index = world * scale + offset
     if (json_get_optional<string>(config, "source_path"))
-        throw std::runtime_error("source_path: the source term is outside this build's scope (SURVEY.md 8f.2)");
+        throw std::runtime_error("source_path: nanovdb grids cannot be read by this build; export the grid as \"source_grid\" "
+                                 "(dense float32 RGB, see core/problem.cpp)");
+    if (const auto sg = json_get_optional<json>(config, "source_grid")) {
+        const int nx = json_get_or_throw<int>(*sg, "nx"), ny = json_get_or_throw<int>(*sg, "ny");
+        const auto sc = json_get_or_throw<std::vector<float>>(*sg, "index_scale");
+        const auto of = json_get_or_throw<std::vector<float>>(*sg, "index_offset");
+        if (nx <= 0 || ny <= 0 || sc.size() != 2 || of.size() != 2) throw std::runtime_error("source_grid: bad shape");
+        const string path = resolve(json_get_or_throw<string>(*sg, "path"), search_dir);
+        std::ifstream f(path, std::ios::binary);
+        if (!f.is_open()) throw std::runtime_error("cannot open source grid " + path);
+        std::vector<float> rgb((size_t)nx * ny * 3);
+        f.read(reinterpret_cast<char *>(rgb.data()), (std::streamsize)(rgb.size() * sizeof(float)));
+        if ((size_t)f.gcount() != rgb.size() * sizeof(float)) throw std::runtime_error("source grid file is too short: " + path);
+        set_source(nx, ny, std::move(rgb), {sc[0], sc[1]}, {of[0], of[1]});
+    }
     if (json_get_optional<string>(config, "mask_path"))
         throw std::runtime_error("mask_path: mask images are not loaded by this build (SURVEY.md 8f.4); use set_mask()");
     source_intensity = json_get_optional<float>(config, "source_intensity", 1.0f);
@@ -177,6 +195,16 @@ void Problem<2>::loadConfig(const json &config, const fs::path &search_dir)
             ELAINA_LOG(Info, "Neumann: %zu vertices, %zu primitives, intensity %f", scene_stat.neumann_vertices_size,
                        scene_stat.neumann_primitives_size, neumann_intensity);
     }
+}
+
+void Problem<2>::set_source(int nx, int ny, std::vector<float> rgb, Vector2f index_scale, Vector2f index_offset)
+{
+    if (nx <= 0 || ny <= 0 || rgb.size() != (size_t)nx * ny * 3) throw std::runtime_error("set_source: size mismatch");
+    source_nx = nx; source_ny = ny;
+    source_rgb = std::move(rgb);
+    source_index_scale = index_scale;
+    source_index_offset = index_offset;
+    enable_source = true;
 }
 
 wost_scene_desc Problem<2>::scene_desc(int width, int height) const
@@ -205,6 +233,13 @@ wost_scene_desc Problem<2>::scene_desc(int width, int height) const
     if (!mask.empty()) {
         if (mask.size() != (size_t)width * height) throw std::runtime_error("mask size does not match the frame");
         d.mask = mask.data();
+    }
+    if (enable_source) {
+        d.source.nx = source_nx; d.source.ny = source_ny;
+        d.source.rgb = source_rgb.data();
+        d.source.index_scale[0] = source_index_scale.x; d.source.index_scale[1] = source_index_scale.y;
+        d.source.index_offset[0] = source_index_offset.x; d.source.index_offset[1] = source_index_offset.y;
+        d.source.intensity = source_intensity;
     }
     return d;
 }

@@ -41,7 +41,7 @@ public:
     // reference core/problem.h:104-171
     bool isDirichletEnabled() const { return enable_dirichlet; }
     bool isNeumannEnabled() const { return enable_neumann; }
-    bool isSourceEnabled() const { return false; }
+    bool isSourceEnabled() const { return enable_source; }
     const SceneProbe &getProbe() const { return *mpProbe; }
     const AABB2f &getAABB() const { return mAABB; }
     const ProblemStatistics &get_problem_stat() const { return scene_stat; }
@@ -52,6 +52,9 @@ public:
     const std::vector<float> &get_vertex_color_neumann() const { return vertex_color_neumann; }
     const std::vector<uint8_t> &get_mask() const { return mask; }
     void set_mask(std::vector<uint8_t> m) { mask = std::move(m); }
+    // dense source grid (stands in for the reference's nanovdb grid, core/problem.cu:136-149):
+    // rgb = ny*nx*3 floats, index = world * scale + offset
+    void set_source(int nx, int ny, std::vector<float> rgb, Vector2f index_scale, Vector2f index_offset);
 
     // what crosses the C-ABI (valid while this Problem is alive and unchanged)
     wost_scene_desc scene_desc(int width, int height) const;
@@ -61,7 +64,10 @@ private:
     AABB2f mAABB;
     std::unique_ptr<SceneLoader2> scene_dirichlet_loader, scene_neumann_loader;
     std::vector<float> vertex_color_dirichlet, vertex_color_neumann;  // 6 floats per vertex
-    bool enable_dirichlet{false}, enable_neumann{false};
+    bool enable_dirichlet{false}, enable_neumann{false}, enable_source{false};
+    int source_nx{0}, source_ny{0};
+    std::vector<float> source_rgb;
+    Vector2f source_index_scale{1.0f, 1.0f}, source_index_offset{0.0f, 0.0f};
     bool verbose{false};
     ProblemStatistics scene_stat;
     float source_intensity{1.0f}, dirichlet_intensity{1.0f}, neumann_intensity{1.0f};

@@ -120,7 +120,9 @@ void GuidedIntegrator<2>::renderSilhouetteSDF() { render_sdf(scene_handle(), WOS
 
 void GuidedIntegrator<2>::renderSource()
 {
-    throw std::runtime_error("renderSource: the source term is outside this build's scope (SURVEY.md 8f.2)");
+    std::vector<float> &c = channels[(size_t)ExportImageChannel::SOURCE];
+    c.assign((size_t)frameSize_.x * frameSize_.y * 3, 0.0f);
+    check_wost(wost_render_source(scene_handle(), c.data()), "wost_render_source");
 }
 
 void GuidedIntegrator<2>::queryNetwork(const VectorType &p)

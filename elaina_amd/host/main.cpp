@@ -62,6 +62,18 @@ static int selftest()
     try { network_config_from_json(json::parse(R"({"encoding":{"otype":"HashGrid"},"network":{},"optimizer":{}})")); }
     catch (const std::runtime_error &) { threw = true; }
     expect(threw, "unsupported encoding throws");
+    // source grid binding: nanovdb paths are refused with a pointer to the dense format
+    {
+        Problem<2> pr(false);
+        threw = false;
+        try {
+            pr.loadConfig(json::parse(R"({"aabb":{"min":[0,0],"max":[1,1]},"evaluation_grid":{"mData":{"scale":1,"pos":[0,0],"up":[0,1]}},
+                "mesh":{},"source_path":"x.nvdb"})"));
+        } catch (const std::runtime_error &e) { threw = string(e.what()).find("source_grid") != string::npos; }
+        expect(threw, "source_path is refused with a hint");
+        pr.set_source(2, 1, {1, 2, 3, 4, 5, 6}, {2.0f, 2.0f}, {0.5f, 0.0f});
+        expect(pr.isSourceEnabled() && pr.scene_desc(4, 4).source.nx == 2 && pr.scene_desc(4, 4).source.rgb[5] == 6.0f, "set_source");
+    }
     // OBJ polylines
     const fs::path tmp = fs::temp_directory_path() / "elaina_selftest.obj";
     { std::ofstream f(tmp); f << "# c\no P\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nl 1 2 3\nl -1 1\n"; }

@@ -55,6 +55,14 @@ def scene_desc(keep, problem, w, h):
             raise ValueError("mask must have width*height entries")
         keep.append(problem.mask)
         sc.mask = problem.mask.ctypes.data_as(C.POINTER(C.c_uint8))
+    if problem.source is not None:
+        rgb = problem.source["rgb"]
+        keep.append(rgb)
+        sc.source.ny, sc.source.nx = rgb.shape[0], rgb.shape[1]
+        sc.source.rgb = _fp(rgb)
+        sc.source.index_scale[0], sc.source.index_scale[1] = problem.source["index_scale"]
+        sc.source.index_offset[0], sc.source.index_offset[1] = problem.source["index_offset"]
+        sc.source.intensity = problem.source["intensity"]
     return sc
 
 
@@ -106,7 +114,9 @@ class UniformIntegrator:
         return out
 
     def renderSource(self):
-        raise NotImplementedError("source term is outside the hot-path scope (SURVEY 8f.2)")
+        out = np.zeros((self.n_pixels, 3), dtype=np.float32)
+        _check(self.lib.wost_render_source(self._handle, _fp(out)), "wost_render_source")
+        return out
 
     def queryNetwork(self, p):
         raise NotImplementedError("uniform integrator has no network (reference integrator.cu:661-664)")

@@ -16,7 +16,7 @@ class Problem:
 
     def __init__(self, d_verts=None, d_segs=None, d_colors=None, n_verts=None, n_segs=None, n_colors=None,
                  probe=(1.0, 0.0, 0.0, 0.0, 1.0), dirichlet_intensity=1.0, neumann_intensity=1.0, mask=None,
-                 aabb=None):
+                 aabb=None, source=None):
         f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
         i32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
         self.d_verts, self.d_segs, self.d_colors = f32(d_verts), i32(d_segs), f32(d_colors)
@@ -26,6 +26,17 @@ class Problem:
         self.neumann_intensity = float(neumann_intensity)
         self.mask = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         self.aabb = aabb
+        # source term f of laplace(u) = -f: dict(rgb=[ny, nx, 3], index_scale=(sx, sy), index_offset=(ox, oy),
+        # intensity=1.0), index = world * scale + offset, bilinear, zero outside (stands in for the
+        # reference's nanovdb grid, core/problem.cu:136-149)
+        self.source = None
+        if source is not None:
+            self.source = {"rgb": np.ascontiguousarray(source["rgb"], dtype=np.float32),
+                           "index_scale": tuple(float(v) for v in source["index_scale"]),
+                           "index_offset": tuple(float(v) for v in source["index_offset"]),
+                           "intensity": float(source.get("intensity", 1.0))}
+            if self.source["rgb"].ndim != 3 or self.source["rgb"].shape[2] != 3:
+                raise ValueError("source rgb must be [ny, nx, 3]")
 
     # reference getters (core/problem.h:104-111)
     def isDirichletEnabled(self):
@@ -35,7 +46,7 @@ class Problem:
         return self.n_segs is not None and len(self.n_segs) > 0
 
     def isSourceEnabled(self):
-        return False
+        return self.source is not None
 
     def as_dict(self):
         """plain dict of arrays (the oracle binding in tests takes the same dict)"""
@@ -43,7 +54,7 @@ class Problem:
             "d_verts": self.d_verts, "d_segs": self.d_segs, "d_colors": self.d_colors,
             "n_verts": self.n_verts, "n_segs": self.n_segs, "n_colors": self.n_colors,
             "probe": self.probe, "dirichlet_intensity": self.dirichlet_intensity,
-            "neumann_intensity": self.neumann_intensity, "mask": self.mask,
+            "neumann_intensity": self.neumann_intensity, "mask": self.mask, "source": self.source,
         }
 
     @staticmethod

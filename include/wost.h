@@ -45,6 +45,18 @@ typedef struct wost_mesh_desc {
     const float *colors;   /* n_verts * 6: (left r,g,b, right r,g,b); NULL => all zero   */
 } wost_mesh_desc;
 
+/* Source term f of  laplace(u) = -f  (SURVEY 8f.2).  Replaces the nanovdb Vec3f grid of
+ * Problem<2>::loadSource (core/problem.cu:136-149) as the integrator reads it
+ * (worldToIndex + order-1 SampleFromVoxels at z = 0, integrator/uniform/integrator.cu:303-306): a
+ * dense 2-D grid of RGB samples at integer index coordinates, index = world * index_scale +
+ * index_offset, bilinear, zero outside.  nx == 0 disables the source term. */
+typedef struct wost_source_desc {
+    int32_t nx, ny;
+    const float *rgb;            /* ny * nx * 3, x fastest                                      */
+    float index_scale[2], index_offset[2];
+    float intensity;             /* source_intensity (core/problem.cu:179)                      */
+} wost_source_desc;
+
 /* Replaces Problem<2> as seen by the integrator (core/problem.h:104-171) and the
  * probe EvaluationGrid<2>::ProbeData (core/evaluation_grid.h:16-23). */
 typedef struct wost_scene_desc {
@@ -58,6 +70,7 @@ typedef struct wost_scene_desc {
     const uint8_t *mask;         /* width*height bytes, 0 = pixel masked out; NULL = all on
                                     (problem.h:163; the reference's fixed 1024^2 default mask,
                                     core/problem.cu:245-247, is sized to the frame here)     */
+    wost_source_desc source;     /* zero-initialised = no source term                          */
 } wost_scene_desc;
 
 /* Replaces UniformIntegratorSettings (integrator/uniform/integrator.h:27-48); the
@@ -114,6 +127,10 @@ int wost_solve_sharded(wost_handle h, int32_t shard_index, int32_t shard_count,
 /* renderDirichletSDF / renderSilhouetteSDF (integrator/common.h:52-123): one query per
  * pixel of the frame, out receives width*height distances. */
 int wost_render_sdf(wost_handle h, int which_mesh, float *out_dist);
+
+/* renderSource (integrator/common.h:126-163): intensity * f at every pixel of the frame, out
+ * receives width*height*3 floats (zeros without a source term). */
+int wost_render_source(wost_handle h, float *out_rgb);
 
 /* lbvh::query_device(bvh, lbvh::nearest(q), distance_calculator()) + checkPointSide +
  * computeProjectionRatio for a batch of host points (call sites

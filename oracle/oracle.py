@@ -35,6 +35,13 @@ class Mesh(C.Structure):
     ]
 
 
+class Source(C.Structure):
+    _fields_ = [
+        ("nx", C.c_int), ("ny", C.c_int), ("rgb", C.POINTER(C.c_float)),
+        ("index_scale", C.c_float * 2), ("index_offset", C.c_float * 2), ("intensity", C.c_float),
+    ]
+
+
 class Scene(C.Structure):
     _fields_ = [
         ("dirichlet", Mesh),
@@ -45,6 +52,7 @@ class Scene(C.Structure):
         ("probe_pos", C.c_float * 2),
         ("probe_up", C.c_float * 2),
         ("mask", C.POINTER(C.c_ubyte)),
+        ("source", Source),
     ]
 
 
@@ -193,6 +201,16 @@ class Oracle:
             mk = np.ascontiguousarray(mask, dtype=np.uint8)
             self._keep.append(mk)
             sc.mask = mk.ctypes.data_as(C.POINTER(C.c_ubyte))
+        src = sd.get("source")
+        if src is not None:
+            rgb = np.ascontiguousarray(src["rgb"], dtype=np.float32)
+            assert rgb.ndim == 3 and rgb.shape[2] == 3
+            self._keep.append(rgb)
+            sc.source.ny, sc.source.nx = rgb.shape[0], rgb.shape[1]
+            sc.source.rgb = _fp(rgb)
+            sc.source.index_scale[0], sc.source.index_scale[1] = [float(v) for v in src["index_scale"]]
+            sc.source.index_offset[0], sc.source.index_offset[1] = [float(v) for v in src["index_offset"]]
+            sc.source.intensity = float(src.get("intensity", 1.0))
         return sc
 
     # ---- solver ----------------------------------------------------------------
@@ -255,6 +273,15 @@ class Oracle:
         out.update({k: int(getattr(stats, k)) for k, _ in GuidedStats._fields_})
         if dump is not None:
             out["train_set"] = {k: v[:dump.n] for k, v in arrays.items()}
+        return out
+
+    def render_source(self, sd, width, height):
+        sc = self.make_scene(sd)
+        st = Settings(width, height, 1, 1, 1.0)
+        out = np.zeros((width * height, 3), dtype=np.float32)
+        rc = self.lib.wo_render_source(C.byref(sc), C.byref(st), _fp(out))
+        if rc != 0:
+            raise RuntimeError("wo_render_source failed: %d" % rc)
         return out
 
     def render_dirichlet_sdf(self, sd, width, height, threads=8):

@@ -239,6 +239,13 @@ int wo_solve_guided(const wo_scene *sc, const wo_guided_settings *gs, const wo_n
                 if (isinf(R_B)) { q->state = 0; continue; }            /* no boundary at all: nothing to walk to */
                 q->R_B = R_B;
                 q->state = 2;
+                if (sc->source.nx > 0) {          /* sampleSource (guided/integrator.cu:277-364) */
+                    float col[3];
+                    if (wo_sample_source(&sc->source, &nm, eps, q->x, q->y, R_B, q->on_n, q->nx, q->ny, q->thp, &q->rng, col)) {
+                        for (int c = 0; c < 3; ++c) q->sol[c] = col[c] + q->sol[c];
+                        if (train_px) record_solution(q, col, 1);
+                    }
+                }
                 if (has_n) {
                     float u0 = wo_pcg_next_float(&q->rng);
                     float u1 = wo_pcg_next_float(&q->rng);

@@ -84,6 +84,13 @@ static inline void surface_color(const float *colors, int i0, int i1, int side, 
     }
 }
 
+/* bilinear sample of the source grid at a world point, times the intensity */
+void wo_source_eval(const wo_source *src, float x, float y, float out[3]);
+/* sampleSource of one out-of-shell point (integrator/uniform/integrator.cu:255-314): returns 1 and
+ * the contribution to ADD when the sampled point lies inside the star-shaped region */
+int wo_sample_source(const wo_source *src, const pmesh *nm, float eps, float px, float py, float R_B, int on_n,
+                     float nx, float ny, float thp, wo_pcg *rng, float out[3]);
+
 void pmesh_free(pmesh *m);
 int pmesh_prepare(pmesh *m, const wo_mesh *in);
 cp_result closest_bvh(const pmesh *m, float qx, float qy);

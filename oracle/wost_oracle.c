@@ -492,6 +492,92 @@ int sample_in_sphere(const pmesh *m, float qx, float qy, float R, float u, float
 /* surface colour: integrator/common.h:242-260 + functors.h:60-64            */
 /* ------------------------------------------------------------------------ */
 /* ------------------------------------------------------------------------ */
+/* source term                                                               */
+/* ------------------------------------------------------------------------ */
+static void source_tap(const wo_source *src, int i, int j, float v[3])
+{
+    if (i < 0 || j < 0 || i >= src->nx || j >= src->ny) { v[0] = v[1] = v[2] = 0.0f; return; }
+    const float *p = src->rgb + 3 * ((size_t)j * src->nx + i);
+    v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+}
+
+void wo_source_eval(const wo_source *src, float x, float y, float out[3])
+{
+    const float gx = fmaf(x, src->index_scale[0], src->index_offset[0]);
+    const float gy = fmaf(y, src->index_scale[1], src->index_offset[1]);
+    const float fx = floorf(gx), fy = floorf(gy);
+    const float u = gx - fx, v = gy - fy;
+    /* keep the integer conversion in range for far-away points */
+    const int i = (int)fmaxf(fminf(fx, 1e9f), -1e9f), j = (int)fmaxf(fminf(fy, 1e9f), -1e9f);
+    float v00[3], v10[3], v01[3], v11[3];
+    source_tap(src, i, j, v00); source_tap(src, i + 1, j, v10);
+    source_tap(src, i, j + 1, v01); source_tap(src, i + 1, j + 1, v11);
+    for (int c = 0; c < 3; ++c) {
+        const float a = v00[c] + (v10[c] - v00[c]) * u;
+        const float b = v01[c] + (v11[c] - v01[c]) * u;
+        out[c] = (a + (b - a) * v) * src->intensity;
+    }
+}
+
+int wo_sample_source(const wo_source *src, const pmesh *nm, float eps, float px, float py, float R_B, int on_n,
+                     float nx, float ny, float thp, wo_pcg *rng, float out[3])
+{
+    /* direction: uniform on the circle, or on the half circle around the Neumann normal */
+    float dirx, diry, dir_pdf, alpha = 1.0f;
+    const float u0 = wo_pcg_next_float(rng);
+    if (on_n) {
+        float lc, ls;
+        wo_sincos_2pi(u0 * 0.5f, &lc, &ls);
+        float qx = -ny, qy = nx;
+        float ql = sqrtf(wo_dot2(qx, qy, qx, qy));
+        float tx = -(qx / ql), ty = -(qy / ql);
+        dirx = tx * lc + nx * ls;
+        diry = ty * lc + ny * ls;
+        dir_pdf = (float)(1.0 / WO_PI_D);
+        alpha = 0.5f;
+    } else {
+        wo_sincos_2pi(u0, &dirx, &diry);
+        dir_pdf = 1.0f / WO_2PI;
+    }
+    /* how far the straight line stays inside the star-shaped region (integrator.cu:279-292) */
+    float dist = R_B;
+    if (nm->n_segs > 0) {
+        float t; int hi;
+        if (ray_closest(nm, px + eps * dirx, py + eps * diry, dirx, diry, dist, &t, &hi)) dist = fminf(t, dist);
+    }
+    /* HarmonicGreenBall<2>::sample (util/green.h:44-73): rejection, at most 1000 trials */
+    const float norm = R_B * R_B / 4.0f, bound = 1.5f / R_B;
+    float r = 0.0f;
+    for (int iter = 0; iter < 1000; ++iter) {
+        const float u = wo_pcg_next_float(rng);
+        r = wo_pcg_next_float(rng) * R_B;
+        const float pdf = (wo_logf(R_B / r) / WO_2PI) / norm;          /* r == 0 -> +inf: accepted */
+        const float pdf_radius = pdf / (1.0f / WO_2PI);
+        if (u < pdf_radius / bound) break;
+    }
+    r = fmaxf(1e-4f, r);                                                /* ELAINA_GREEN_FUNC_R_CLAMP */
+    if (r > R_B) r = R_B / 2.0f;
+    if (!(r <= dist)) return 0;
+    float f[3];
+    wo_source_eval(src, px + r * dirx, py + r * diry, f);
+    const float c1 = (1.0f / WO_2PI) / r, c2 = dir_pdf / r;             /* conditionalSampleSpherePDF<2> */
+    for (int c = 0; c < 3; ++c) out[c] = thp * f[c] * norm * c1 / c2 / alpha;
+    return 1;
+}
+
+int wo_render_source(const wo_scene *sc, const wo_settings *st, float *out_rgb)
+{
+    if (!sc || !st || !out_rgb) return -1;
+    for (int p = 0; p < st->width * st->height; ++p) {
+        float x, y;
+        wo_eval_point(sc, p % st->width, p / st->width, st->width, st->height, &x, &y);
+        if (sc->source.nx > 0) wo_source_eval(&sc->source, x, y, out_rgb + 3 * (size_t)p);
+        else out_rgb[3 * (size_t)p] = out_rgb[3 * (size_t)p + 1] = out_rgb[3 * (size_t)p + 2] = 0.0f;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* one pixel: the whole spp x depth loop (integrator.cu:529-623 restated     */
 /* per pixel; legal because a pixel's walk only touches its own sampler and  */
 /* solution -- workqueue.h:25-29, integrator.cu:255,342,466)                 */
@@ -561,6 +647,13 @@ static void solve_pixel(const solve_ctx *cx, int pixel_id, float sol_out[3], uin
             float R_B = fmaxf(WO_R_B_FLOOR, fminf(R_D, R_N));
             R_B *= WO_R_B_SHRINK;
             if (isinf(R_B)) break;                      /* integrator.cu:197-200 */
+
+            /* ---- sampleSource (integrator.cu:235-316), only when the problem has a source ---- */
+            if (sc->source.nx > 0) {
+                float col[3];
+                if (wo_sample_source(&sc->source, cx->nm, eps, px, py, R_B, on_n, nnx, nny, thp[0], &rng, col))
+                    for (int c = 0; c < 3; ++c) sol[c] = col[c] + sol[c];
+            }
 
             /* ---- sampleNeumann (integrator.cu:336-444) ---- */
             if (has_n) {

@@ -50,6 +50,17 @@ typedef struct wo_mesh {
     const float *colors;  /* n_verts * 6 (left rgb, right rgb) or NULL = zeros  */
 } wo_mesh;
 
+/* Source term f of  laplace(u) = -f  as a dense 2-D grid of RGB samples at integer index
+ * coordinates, index = world * index_scale + index_offset, bilinear, zero outside: what the
+ * reference reads from a nanovdb Vec3f grid at z = 0 (worldToIndex + order-1 SampleFromVoxels,
+ * integrator/uniform/integrator.cu:303-306; nanovdb is absent => PARITY UNPINNED). */
+typedef struct wo_source {
+    int nx, ny;               /* nx == 0 -> no source term */
+    const float *rgb;         /* ny * nx * 3, x fastest */
+    float index_scale[2], index_offset[2];
+    float intensity;          /* source_intensity (core/problem.cu:179) */
+} wo_source;
+
 typedef struct wo_scene {
     wo_mesh dirichlet;    /* n_segs == 0  -> Dirichlet disabled */
     wo_mesh neumann;      /* n_segs == 0  -> Neumann disabled   */
@@ -59,6 +70,7 @@ typedef struct wo_scene {
     float probe_pos[2];
     float probe_up[2];
     const unsigned char *mask; /* width*height bytes (0 = masked out) or NULL   */
+    wo_source source;
 } wo_scene;
 
 typedef struct wo_settings {
@@ -119,6 +131,9 @@ int wo_ray_intersect_batch(const wo_mesh *mesh, const float *origins, const floa
 int wo_solve(const wo_scene *sc, const wo_settings *st, int pixel_begin, int pixel_end,
              int n_threads, float *field_rgb, uint32_t *steps_per_pixel,
              uint64_t *depth_hist, wo_stats *stats);
+
+/* SOURCE channel (renderSource, integrator/common.h:126-163): intensity * f at every pixel. */
+int wo_render_source(const wo_scene *sc, const wo_settings *st, float *out_rgb);
 
 /* Dirichlet SDF channel (integrator/common.h:52-85): distance per pixel. */
 int wo_render_dirichlet_sdf(const wo_scene *sc, const wo_settings *st, int n_threads,

@@ -355,3 +355,42 @@ def test_refill_is_chosen_automatically_for_one_sample(ladybug):
     assert it.last_stats["kernel_launches"] > 1 or it.last_stats["kernel_launches"] == 1
     assert np.array_equal(ref, it.solution)
     it.close()
+
+
+def _with_source(problem, lo, hi, cells=24, seed=9, intensity=0.7):
+    """attach a smooth random RGB source grid covering [lo, hi]^2 (and a margin of zero outside)"""
+    rng = np.random.default_rng(seed)
+    n = cells + 1
+    gx, gy = np.meshgrid(np.linspace(0, 1, n), np.linspace(0, 1, n))
+    rgb = np.stack([np.sin(3 * gx + 2 * gy) + 0.3 * rng.normal(size=gx.shape), gx * gy, 1.0 - gy], -1).astype(np.float32)
+    s = cells / (hi - lo)
+    problem.source = {"rgb": rgb, "index_scale": (s, s), "index_offset": (-lo * s, -lo * s), "intensity": intensity}
+    return problem
+
+
+def test_source_term_matches_oracle(oracle, ladybug):
+    """sampleSource in the walk step: variable draw count per step (rejection
+    sampler), Neumann clipping of the source ray, bilinear grid sampling -- bit-exact"""
+    import copy
+    from conftest import box_problem, wiggly_problem
+    from test_oracle_solver import _poisson_disc
+    _assert_same_solve(oracle, _poisson_disc(), 40, 36, 6, 48, 1e-3)
+    mixed = _with_source(box_problem(d_sides=(0, 2), n_sides=(1, 3), value=lambda x, y: y, flux=lambda x, y, s: 0.2), 0.0, 1.0)
+    _assert_same_solve(oracle, mixed, 48, 40, 5, 32, 1e-3)
+    _assert_same_solve(oracle, mixed, 48, 40, 5, 32, 1e-3, steps_per_round=3, block_size=64)
+    lb = _with_source(copy.copy(ladybug), -100.0, 600.0, cells=40, intensity=1e-3)
+    _assert_same_solve(oracle, lb, 64, 48, 3, 64, 1.0)
+    _assert_same_solve(oracle, _with_source(wiggly_problem(emissive=True), -130.0, 130.0, intensity=1e-3), 40, 40, 2, 24, 0.05)
+
+
+def test_render_source_matches_oracle(oracle):
+    from test_oracle_solver import _poisson_disc
+    p = _with_source(_poisson_disc(), -0.8, 0.9, cells=7)
+    p.probe = np.asarray((1.3, 0.1, -0.2, 0.6, 0.8), np.float32)
+    it = _integrator(p, 37, 21, 1, 4, 1e-3)
+    assert np.array_equal(it.renderSource(), oracle.render_source(p.as_dict(), 37, 21))
+    it.close()
+    p.source = None
+    it = _integrator(p, 8, 8, 1, 4, 1e-3)
+    assert np.all(it.renderSource() == 0)
+    it.close()

@@ -122,20 +122,21 @@ def test_oracle_guided_phase_switch_and_quirks(oracle):
 
 # ---- HIP integrator against the oracle ---------------------------------------------------------
 def _gpu_and_oracle(oracle, prob, w, h, spp, depth, train_spp, uf=(0.5, 0.5), mgd=(10, 10), batch=2048, min_batch=512,
-                    params=None, seed=7, dump=True, stride=1, offset=0):
+                    params=None, seed=7, dump=True, stride=1, offset=0, aabb=None):
     from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
     cfg = default_net_config()
+    aabb = aabb or AABB
     st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=train_spp, maxWalkingDepth=depth,
                                   epsilonShell=EPS, uniformFractionInTrainingPhase=uf[0],
                                   uniformFractionInGuidingPhase=uf[1], maxGuidedDepthInTrainingPhase=mgd[0],
                                   maxGuidedDepthInGuidingPhase=mgd[1], batchSize=batch, minBatchSize=min_batch,
                                   trainPixelStride=stride, trainPixelOffset=offset)
-    gi = GuidedIntegrator(prob, st, AABB, seed=seed)
+    gi = GuidedIntegrator(prob, st, aabb, seed=seed)
     if params is not None:
         gi.network.set_params(params)
     p0 = gi.network.params()
     gi.solve()
-    gs = guided_settings(w, h, spp, depth, EPS, AABB[0], AABB[1], train_spp_count=train_spp, uniform_fraction=uf,
+    gs = guided_settings(w, h, spp, depth, EPS, aabb[0], aabb[1], train_spp_count=train_spp, uniform_fraction=uf,
                          max_guided_depth=mgd, batch_size=batch, min_batch_size=min_batch, train_pixel_stride=stride,
                          train_pixel_offset=offset)
     dump_spp = min(train_spp, spp) - 1 if (dump and train_spp > 0) else -1
@@ -358,3 +359,21 @@ def test_gpu_sharded_guided_solve(oracle):
     ys = eval_ys(prob, w, h)
     f = total.cpu().numpy().reshape(-1, 3)[:, 0].reshape(h, w)
     assert abs(float(np.mean(f - ys))) < 0.03
+
+
+@pytest.mark.gpu
+def test_gpu_guided_with_source_term_matches_oracle(oracle):
+    """guided integrator on a Poisson problem (sampleSource + recordSourceContribution), frozen and
+    trained: bit-exact, and unbiased against u = (1 - r^2) / 4"""
+    from test_oracle_solver import _poisson_disc
+    prob = _poisson_disc()
+    gi, ref = _gpu_and_oracle(oracle, prob, 40, 40, 24, 48, 12, batch=2048, min_batch=512, dump=False,
+                              aabb=((-1.2, -1.2), (1.2, 1.2)))
+    assert gi.last_stats["optimizer_steps"] == ref["optimizer_steps"] > 0
+    assert np.array_equal(gi.solution, ref["field"])
+    ys, xs = np.mgrid[0:40, 0:40]
+    x, y = (xs * 2 / 40 - 1) * 0.7, (ys * 2 / 40 - 1) * 0.7
+    want = (1 - x ** 2 - y ** 2) / 4
+    f = gi.solution[:, 0].reshape(40, 40)
+    assert abs(float(np.mean(f - want))) < 5e-3
+    gi.close()

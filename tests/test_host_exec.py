@@ -156,3 +156,26 @@ def test_png_and_exr_writers_and_colormaps(tmp_path):
     # MATLAB_PARULA = 3: blue -> yellow, NONE_NORMALIZED = 1: grey ramp
     assert tones[(3, 0.0)][2] > 0.6 and tones[(3, 1.0)][0] > 0.9 and tones[(3, 1.0)][2] < 0.2
     np.testing.assert_allclose(tones[(1, 0.25)], [0.25] * 3)
+
+
+@pytest.mark.gpu
+def test_run_expr_with_a_source_grid(tmp_path, oracle, ladybug):
+    """scene.source_grid (dense stand-in for the nanovdb source_path) through the C++ host:
+    Poisson solve and the SOURCE channel, both equal to the oracle"""
+    import copy
+    import export_scene
+    n = 33
+    gx, gy = np.meshgrid(np.linspace(0, 1, n), np.linspace(0, 1, n))
+    src = {"rgb": np.stack([np.sin(4 * gx) * gy, gx, 1 - gy], -1).astype(np.float32), "index_scale": (32 / 700.0, 32 / 700.0),
+           "index_offset": (100 * 32 / 700.0, 100 * 32 / 700.0), "intensity": 2e-3}
+    conf = export_scene.export("ladybug", str(tmp_path), frame=48, spp=4, depth=32, source=src)
+    out = subprocess.run([_exe(), conf], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    exp = tmp_path / "exp" / "ladybug_u"
+    p = copy.copy(ladybug)
+    p.source = {"rgb": src["rgb"], "index_scale": src["index_scale"], "index_offset": src["index_offset"], "intensity": 2e-3}
+    ref = oracle.solve(p.as_dict(), 48, 48, 4, 32, 1.0, threads=os.cpu_count())
+    assert np.array_equal(export_scene.read_pfm(exp / "solution.pfm"), ref["field"])
+    assert np.array_equal(export_scene.read_pfm(exp / "source.pfm"), oracle.render_source(p.as_dict(), 48, 48))
+    plain = oracle.solve(ladybug.as_dict(), 48, 48, 4, 32, 1.0, threads=os.cpu_count())
+    assert not np.array_equal(plain["field"], ref["field"])

@@ -114,3 +114,51 @@ def test_libm_variant_agrees_statistically(oracle, oracle_libm, ladybug):
     rel = np.linalg.norm(a["field"] - b["field"]) / np.linalg.norm(a["field"])
     assert 0 < rel < 0.08, rel
     assert abs(a["walk_steps"] - b["walk_steps"]) / a["walk_steps"] < 0.03
+
+
+def _poisson_disc(n_seg=256, cells_per_unit=16, f=(1.0, 0.5, 0.0)):
+    """unit disc, u = 0 on the boundary, constant source f: u(r) = f (1 - r^2) / 4"""
+    from elaina_amd import Problem
+    t = np.linspace(0, 2 * np.pi, n_seg, endpoint=False)
+    dv = np.stack([np.cos(t), np.sin(t)], 1).astype(np.float32)
+    ds = np.stack([np.arange(n_seg), (np.arange(n_seg) + 1) % n_seg], 1).astype(np.int32)
+    g = cells_per_unit
+    n = 3 * g + 1
+    rgb = np.ones((n, n, 3), np.float32) * np.asarray(f, np.float32)
+    src = {"rgb": rgb, "index_scale": (g, g), "index_offset": (1.5 * g, 1.5 * g), "intensity": 1.0}
+    return Problem(d_verts=dv, d_segs=ds, d_colors=np.zeros((n_seg, 6), np.float32), probe=(0.7, 0, 0, 0, 1), source=src)
+
+
+def test_source_term_solves_the_poisson_equation(oracle):
+    """sampleSource (reference integrator/uniform/integrator.cu:235-316): laplace(u) = -f; with a
+    constant f on the unit disc and u = 0 on the rim, u = f (1 - r^2) / 4 -- fixes sign and scale"""
+    p = _poisson_disc()
+    w = h = 20
+    r = oracle.solve(p.as_dict(), w, h, 192, 64, 1e-3)
+    ys, xs = np.mgrid[0:h, 0:w]
+    x, y = (xs * 2 / w - 1) * 0.7, (ys * 2 / h - 1) * 0.7
+    want = (1 - x ** 2 - y ** 2) / 4
+    f = r["field"].reshape(h, w, 3)
+    assert abs(float(np.mean(f[..., 0] - want))) < 2e-3 and float(np.sqrt(np.mean((f[..., 0] - want) ** 2))) < 0.015
+    np.testing.assert_allclose(f[..., 1], 0.5 * f[..., 0], rtol=1e-5, atol=1e-7)
+    assert np.all(f[..., 2] == 0)
+    # the SOURCE channel is the grid itself, bilinear, zero outside
+    p2 = _poisson_disc()
+    p2.probe = np.asarray((2.0, 0, 0, 0, 1), np.float32)
+    img = oracle.render_source(p2.as_dict(), 16, 16).reshape(16, 16, 3)
+    assert np.allclose(img[8, 8], (1.0, 0.5, 0.0)) and np.all(img[0, 0] == 0)
+
+
+def test_source_term_bilinear_interpolation_and_intensity(oracle):
+    from elaina_amd import Problem
+    rgb = np.zeros((2, 3, 3), np.float32)
+    rgb[0, :, 0] = (0, 1, 2)
+    rgb[1, :, 0] = (10, 11, 12)
+    src = {"rgb": rgb, "index_scale": (1, 1), "index_offset": (0, 0), "intensity": 2.0}
+    p = Problem(d_verts=np.zeros((2, 2), np.float32), d_segs=np.zeros((0, 2), np.int32), probe=(1, 1, 0.5, 0, 1), source=src)
+    # pixel centres of a 2x1 frame with this probe: x = 0 and 1, y = -0.5 ... use render at known points
+    img = oracle.render_source(p.as_dict(), 4, 4).reshape(4, 4, 3)[..., 0]
+    # eval point of pixel (px, py): (1 + (2px/4 - 1), 0.5 + (2py/4 - 1)) -> x in {0, .5, 1, 1.5}, y in {-.5, 0, .5, 1}
+    assert img[1, 0] == 0.0 and img[1, 2] == 2.0 and img[1, 1] == 1.0          # y = 0 row, intensity 2
+    assert img[2, 1] == 2.0 * (0.5 * 0.5 + 0.5 * 10.5)                          # (0.5, 0.5): mean of the four
+    assert img[0, 1] == 2.0 * 0.5 * 0.5                                          # y = -0.5: half outside

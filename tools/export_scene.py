@@ -46,7 +46,7 @@ NETWORK_SECTION = {
 }
 
 
-def export(scene, out_dir, frame=128, spp=16, depth=32, exp_name=None, integrator="uniform", train_spp=None):
+def export(scene, out_dir, frame=128, spp=16, depth=32, exp_name=None, integrator="uniform", train_spp=None, source=None):
     p = Problem.load_scene(scene)
     os.makedirs(out_dir, exist_ok=True)
     write_obj(os.path.join(out_dir, "model.obj"), p.d_verts, p.d_segs)
@@ -69,6 +69,16 @@ def export(scene, out_dir, frame=128, spp=16, depth=32, exp_name=None, integrato
             "mesh": {"dirichlet_path": os.path.join(out_dir, "model.obj"),
                      "vertex_color_dirichlet_path": os.path.join(out_dir, "color.json"),
                      "neumann_path": os.path.join(out_dir, "boundary.obj")}}}
+    if source is not None:
+        # dense source grid (this build's stand-in for the reference's nanovdb "source_path")
+        rgb = np.ascontiguousarray(source["rgb"], dtype="<f4")
+        rgb.tofile(os.path.join(out_dir, "source.raw"))
+        conf["scene"]["source_grid"] = {"path": os.path.join(out_dir, "source.raw"), "nx": int(rgb.shape[1]), "ny": int(rgb.shape[0]),
+                                        "index_scale": [float(v) for v in source["index_scale"]],
+                                        "index_offset": [float(v) for v in source["index_offset"]]}
+        conf["scene"]["source_intensity"] = float(source.get("intensity", 1.0))
+        conf["integrator"]["channels"].append("SOURCE")
+        conf["export"].append({"type": "image", "channel": "SOURCE", "file_name": "source"})
     if integrator == "guided":
         conf["exp_name"] = exp_name or (scene + "_n")
         conf["integrator"]["type"] = "guided"
