@@ -12,6 +12,8 @@
 //     registers, then compacts the still-unfinished slots into the other queue with
 //     ballot/popcount + one atomic per wave, and resolves finished pixels into the field.
 //   * the per-lane LBVH traversal stack lives in LDS (one column per lane, bank = lane).
+//   * with few samples per pixel the REFILL instantiation drains the queue in ONE launch;
+//     problems with a source term use the SOURCE instantiations (wost_walk.h).
 //   * no managed memory, no CPU fallback.
 #include <hip/hip_runtime.h>
 

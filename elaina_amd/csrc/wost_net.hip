@@ -3,12 +3,16 @@
 // -> raw mixture parameters; backward pass; Adam nested in a debiased EMA.  gfx950 only.
 //
 // Replaces (does not port) tiny-cuda-nn as used through the reference adapter
-// util/network.h:21-196 with the configuration of data/ladybug/n.json:49-81.  This first version
-// computes in fp32 (the reference uses half precision on tensor cores): one thread per point,
-// activations in a per-lane LDS column (bank = lane), weights read with scalar loads because
-// they are wave-uniform.  Numerically it is the stronger sibling of the reference network and
-// matches the fp32 CPU oracle to ~1e-6; the f16-MFMA fused version is future work
-// (DESIGN.md section 8).
+// util/network.h:21-196 with the configuration of data/ladybug/n.json:49-81.  The reference runs
+// the MLP in half precision on tensor cores; here everything is fp32 with k-ordered fmaf chains,
+// so the result is reproducible and equal to the CPU restatement bit for bit:
+//   * the reference's network shape runs on the matrix cores (v_mfma_f32_16x16x4_f32, exact
+//     fp32): net_forward_mfma_kernel, net_backward_mfma_kernel, weight_grad_mfma_kernel;
+//   * other shapes (and WOST_NET_SCALAR=1) use the scalar kernels: one thread per point,
+//     activations in a per-lane LDS column, wave-uniform weights through scalar loads;
+//   * gradients are sums over the training points and are accumulated in 64-bit fixed point
+//     with integer atomics, hence independent of the order in which blocks arrive.
+// DESIGN.md section 4.7 has the numbers.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
