@@ -171,8 +171,81 @@ __global__ __launch_bounds__(256) void begin_sample_kernel(GParams P)
     }
 }
 
-// ---- separateEvaluationPoint + handleBoundary + sampleNeumann + generate_inference_data -----
-// (reference guided/integrator.cu:153-249, 252-274, 367-494; train.h:474-486)
+// ---- separateEvaluationPoint + handleBoundary + sampleSource + sampleNeumann ------------------
+// (reference guided/integrator.cu:153-249, 252-274, 277-364, 367-494) for ONE walker at the start
+// of a step.  Returns SEP_ABSORBED (colour added to the pixel and its records), SEP_DROPPED (no
+// boundary at all) or SEP_KEEP with R_B set and the Neumann / source terms added.
+enum { SEP_ABSORBED = 0, SEP_DROPPED = 1, SEP_KEEP = 2 };
+
+template <bool EMISSIVE, bool TREE, bool SOURCE>
+__device__ __forceinline__ int separate_step(const GParams &P, uint32_t pid, bool on_n, float x, float y, float thp, float nx,
+                                             float ny, int depth, int32_t &hint, float &R_B, Pcg &rng, uint32_t *stack,
+                                             const LdsColumn &stk)
+{
+    const bool train_px = is_training_pixel(P, pid);
+    const float eps = P.st.eps;
+    float R_D = WOST_INF;
+    if (P.dm.n_segs > 0) {
+        const Closest cp = closest_point(P.dm, x, y, slot_candidate(P.dm, hint, x, y), stack, P.stack_stride);
+        hint = cp.slot;
+        if (depth == 0) P.hint0[pid] = cp.slot;
+        const float4 a = P.dm.segA[cp.slot];
+        const float inv = P.dm.segInv[cp.slot];
+        const float wx = x - a.x, wy = y - a.y;
+        const float uv = dot2(wx, wy, a.z, a.w) * inv;
+        const float cr = cross2(a.z, a.w, wx, wy);
+        const int side = (0.0f < cr) - (cr < 0.0f);
+        R_D = sqrtf(cp.d2);
+        if ((R_D < eps) && (uv > 0.0f && uv < 1.0f)) {
+            float r, g, b;
+            surface_color(P.dm.segCol + 12 * (size_t)cp.slot, side, uv, r, g, b);
+            r *= P.st.dirichlet_intensity; g *= P.st.dirichlet_intensity; b *= P.st.dirichlet_intensity;
+            r *= thp; g *= thp; b *= thp;
+            float *s = P.sol + 3 * (size_t)pid;
+            s[0] = r + s[0]; s[1] = g + s[1]; s[2] = b + s[2];
+            if (train_px) record_solution(P, pid, r, g, b);
+            return SEP_ABSORBED;
+        }
+    }
+    float R_N = WOST_INF;
+    if (P.nm.n_segs > 0) R_N = closest_silhouette<TREE>(P.nm, x, y, R_D, stk);
+    R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));     // no 0.99 in the guided integrator (:238-239)
+    if (isinf(R_B)) return SEP_DROPPED;               // no boundary at all: nothing to walk to
+    if (SOURCE) {
+        float cr, cg, cb;
+        if (source_sample<TREE>(P.src, P.nm, eps, x, y, R_B, on_n, nx, ny, thp, rng, stk, cr, cg, cb)) {
+            float *s = P.sol + 3 * (size_t)pid;
+            s[0] = cr + s[0]; s[1] = cg + s[1]; s[2] = cb + s[2];
+            if (train_px) record_solution(P, pid, cr, cg, cb);
+        }
+    }
+    if (P.nm.n_segs > 0) {
+        float cr, cg, cb;
+        if (neumann_sample<EMISSIVE, TREE>(P.nm, P.st.neumann_intensity, eps, x, y, R_B, on_n, nx, ny, thp, rng, stk, cr, cg, cb)) {
+            float *s = P.sol + 3 * (size_t)pid;
+            s[0] = cr + s[0]; s[1] = cg + s[1]; s[2] = cb + s[2];
+            if (train_px) record_solution(P, pid, cr, cg, cb);
+        }
+    }
+    return SEP_KEEP;
+}
+
+// incrementDepth (reference guided.h:21-46): the vertex BEFORE the step becomes a training record
+__device__ __forceinline__ void record_vertex(const GParams &P, uint32_t pid, float x, float y, float dirx, float diry, float pdf,
+                                              float thp, bool on_n, float nx, float ny)
+{
+    const uint32_t d = P.cur_depth[pid];
+    if (d >= (uint32_t)kMaxTrainDepth) return;
+    rec_at(P, d, 0, pid) = 0.0f; rec_at(P, d, 1, pid) = 0.0f; rec_at(P, d, 2, pid) = 0.0f;
+    rec_at(P, d, 3, pid) = x; rec_at(P, d, 4, pid) = y;
+    rec_at(P, d, 5, pid) = dirx; rec_at(P, d, 6, pid) = diry;
+    rec_at(P, d, 7, pid) = pdf;
+    rec_at(P, d, 8, pid) = thp;
+    rec_at(P, d, 9, pid) = nx; rec_at(P, d, 10, pid) = ny;
+    rec_at(P, d, 11, pid) = on_n ? 1.0f : 0.0f;
+    P.cur_depth[pid] = d + 1;
+}
+
 template <bool EMISSIVE, bool TREE, bool SOURCE>
 __global__ __launch_bounds__(256) void separate_kernel(GParams P)
 {
@@ -185,8 +258,7 @@ __global__ __launch_bounds__(256) void separate_kernel(GParams P)
     if (i < n_in) pidf = P.in.pid[i];
     const bool live = pidf != kDead;
     wave_count(live, &P.stats->steps);
-    bool keep = false;
-    bool absorbed = false;
+    int status = SEP_DROPPED;
     float x = 0, y = 0, thp = 0, nx = 0, ny = 0, R_B = 0;
     int32_t hint = 0;
     const uint32_t pid = pidf & ~kOnNeumann;
@@ -194,61 +266,12 @@ __global__ __launch_bounds__(256) void separate_kernel(GParams P)
     if (live) {
         x = P.in.x[i]; y = P.in.y[i]; thp = P.in.thp[i]; nx = P.in.nx[i]; ny = P.in.ny[i];
         hint = P.in.hint[i];
-        const bool train_px = is_training_pixel(P, pid);
-        const float eps = P.st.eps;
-        float R_D = WOST_INF;
-        if (P.dm.n_segs > 0) {
-            const Closest cp = closest_point(P.dm, x, y, slot_candidate(P.dm, hint, x, y), stack, P.stack_stride);
-            hint = cp.slot;
-            if (P.depth == 0) P.hint0[pid] = cp.slot;
-            const float4 a = P.dm.segA[cp.slot];
-            const float inv = P.dm.segInv[cp.slot];
-            const float wx = x - a.x, wy = y - a.y;
-            const float uv = dot2(wx, wy, a.z, a.w) * inv;
-            const float cr = cross2(a.z, a.w, wx, wy);
-            const int side = (0.0f < cr) - (cr < 0.0f);
-            R_D = sqrtf(cp.d2);
-            if ((R_D < eps) && (uv > 0.0f && uv < 1.0f)) {
-                float r, g, b;
-                surface_color(P.dm.segCol + 12 * (size_t)cp.slot, side, uv, r, g, b);
-                r *= P.st.dirichlet_intensity; g *= P.st.dirichlet_intensity; b *= P.st.dirichlet_intensity;
-                r *= thp; g *= thp; b *= thp;
-                float *s = P.sol + 3 * (size_t)pid;
-                s[0] = r + s[0]; s[1] = g + s[1]; s[2] = b + s[2];
-                if (train_px) record_solution(P, pid, r, g, b);
-                absorbed = true;
-            }
-        }
-        if (!absorbed) {
-            float R_N = WOST_INF;
-            if (P.nm.n_segs > 0) R_N = closest_silhouette<TREE>(P.nm, x, y, R_D, stk);
-            R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));     // no 0.99 in the guided integrator (:238-239)
-            keep = !isinf(R_B);                              // no boundary at all: nothing to walk to
-            if (SOURCE && keep) {
-                // sampleSource (reference guided/integrator.cu:277-364) + recordSourceContribution
-                Pcg rng{P.rng[pid], 1};
-                float cr, cg, cb;
-                if (source_sample<TREE>(P.src, P.nm, eps, x, y, R_B, on_n, nx, ny, thp, rng, stk, cr, cg, cb)) {
-                    float *s = P.sol + 3 * (size_t)pid;
-                    s[0] = cr + s[0]; s[1] = cg + s[1]; s[2] = cb + s[2];
-                    if (train_px) record_solution(P, pid, cr, cg, cb);
-                }
-                P.rng[pid] = rng.state;
-            }
-            if (keep && P.nm.n_segs > 0) {
-                Pcg rng{P.rng[pid], 1};
-                float cr, cg, cb;
-                if (neumann_sample<EMISSIVE, TREE>(P.nm, P.st.neumann_intensity, eps, x, y, R_B, on_n, nx, ny, thp, rng, stk,
-                                                   cr, cg, cb)) {
-                    float *s = P.sol + 3 * (size_t)pid;
-                    s[0] = cr + s[0]; s[1] = cg + s[1]; s[2] = cb + s[2];
-                    if (train_px) record_solution(P, pid, cr, cg, cb);
-                }
-                P.rng[pid] = rng.state;
-            }
-        }
+        Pcg rng{P.rng[pid], 1};
+        status = separate_step<EMISSIVE, TREE, SOURCE>(P, pid, on_n, x, y, thp, nx, ny, P.depth, hint, R_B, rng, stack, stk);
+        P.rng[pid] = rng.state;
     }
-    wave_count(absorbed, &P.stats->absorbed);
+    const bool keep = live && status == SEP_KEEP;
+    wave_count(live && status == SEP_ABSORBED, &P.stats->absorbed);
     const uint32_t s = wave_push(keep, P.count_out);
     if (keep) {
         P.out.pid[s] = pidf;
@@ -260,6 +283,68 @@ __global__ __launch_bounds__(256) void separate_kernel(GParams P)
         normalize_coord(P.box, x, y, ix, iy);
         P.net_in[2 * (size_t)s] = ix;
         P.net_in[2 * (size_t)s + 1] = iy;
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+// ---- the unguided tail of a sample ------------------------------------------------------------
+// From depth >= maxGuidedDepth on, the reference keeps issuing separate / oneStepWalk launches
+// over a queue that shrinks to a few walkers (integrator.cu:1014,1027-1041): 40 % of the walk
+// phase of config 4 went into launches whose duration is one walker's latency.  Nothing there
+// needs the network, so every walker simply runs to its end in registers: one launch per sample
+// for all remaining depths, the same per-pixel arithmetic in the same order.
+template <bool EMISSIVE, bool TREE, bool SOURCE>
+__global__ __launch_bounds__(256) void tail_kernel(GParams P)
+{
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const LdsColumn stk{stack, (uint32_t)P.stack_stride};
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_in = *P.count_in;
+    uint32_t pidf = kDead;
+    if (i < n_in) pidf = P.in.pid[i];
+    bool live = pidf != kDead;
+    const uint32_t pid = pidf & ~kOnNeumann;
+    uint32_t steps = 0, absorbed = 0, truncated = 0, hits = 0;
+    if (live) {
+        bool on_n = (pidf & kOnNeumann) != 0u;
+        float x = P.in.x[i], y = P.in.y[i], thp = P.in.thp[i], nx = P.in.nx[i], ny = P.in.ny[i];
+        int32_t hint = P.in.hint[i];
+        Pcg rng{P.rng[pid], 1};
+        const bool train_px = is_training_pixel(P, pid);
+        for (int depth = P.depth; depth < P.st.max_depth; ++depth) {
+            ++steps;
+            float R_B = 0.0f;
+            const int status = separate_step<EMISSIVE, TREE, SOURCE>(P, pid, on_n, x, y, thp, nx, ny, depth, hint, R_B, rng, stack, stk);
+            if (status != SEP_KEEP) {
+                absorbed = status == SEP_ABSORBED ? 1u : 0u;
+                live = false;
+                break;
+            }
+            // oneStepWalk (reference guided/integrator.cu:883-965)
+            float dirx, diry, pdf, alpha, nxt_x, nxt_y, hnx, hny;
+            uniform_direction(on_n, nx, ny, rng, dirx, diry, pdf, alpha);
+            const bool hit = walk_advance<TREE>(P.nm, P.st.eps, x, y, R_B, on_n, nx, ny, dirx, diry, stk, nxt_x, nxt_y, hnx, hny);
+            if (train_px && depth < P.max_train_depth) record_vertex(P, pid, x, y, dirx, diry, pdf, thp, on_n, nx, ny);
+            thp = thp / pdf / alpha / WOST_2PI;
+            x = nxt_x; y = nxt_y; on_n = hit; nx = hnx; ny = hny;
+            hits += hit ? 1u : 0u;
+        }
+        if (live) truncated = 1u;       // still walking after the last depth
+        P.rng[pid] = rng.state;
+    }
+    const uint32_t s_steps = wave_sum(steps), s_abs = wave_sum(absorbed), s_tr = wave_sum(truncated), s_hit = wave_sum(hits);
+    if ((threadIdx.x & 63) == 0) {
+        if (s_steps) atomicAdd(&P.stats->steps, (unsigned long long)s_steps);
+        if (s_abs) atomicAdd(&P.stats->absorbed, (unsigned long long)s_abs);
+        if (s_tr) atomicAdd(&P.stats->truncated, (unsigned long long)s_tr);
+        if (s_hit) atomicAdd(&P.stats->nhits, (unsigned long long)s_hit);
     }
 }
 
@@ -333,20 +418,7 @@ __global__ __launch_bounds__(256) void sample_kernel(GParams P)
         } else {
             float nxt_x, nxt_y, hnx, hny;
             hit_n = walk_advance<TREE>(P.nm, P.st.eps, x, y, R_B, on_n, nx, ny, dirx, diry, stk, nxt_x, nxt_y, hnx, hny);
-            if (record) {
-                // incrementDepth (guided.h:21-46): the vertex BEFORE the step
-                const uint32_t d = P.cur_depth[pid];
-                if (d < (uint32_t)kMaxTrainDepth) {
-                    rec_at(P, d, 0, pid) = 0.0f; rec_at(P, d, 1, pid) = 0.0f; rec_at(P, d, 2, pid) = 0.0f;
-                    rec_at(P, d, 3, pid) = x; rec_at(P, d, 4, pid) = y;
-                    rec_at(P, d, 5, pid) = dirx; rec_at(P, d, 6, pid) = diry;
-                    rec_at(P, d, 7, pid) = pdf;
-                    rec_at(P, d, 8, pid) = thp;
-                    rec_at(P, d, 9, pid) = nx; rec_at(P, d, 10, pid) = ny;
-                    rec_at(P, d, 11, pid) = on_n ? 1.0f : 0.0f;
-                    P.cur_depth[pid] = d + 1;
-                }
-            }
+            if (record) record_vertex(P, pid, x, y, dirx, diry, pdf, thp, on_n, nx, ny);
             P.in.pid[i] = pid | (hit_n ? kOnNeumann : 0u);
             P.in.x[i] = nxt_x; P.in.y[i] = nxt_y;
             P.in.thp[i] = thp / pdf / alpha / WOST_2PI;
@@ -707,8 +779,22 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
             P.last_depth = depth == s.max_depth - 1;
             P.in = g->q[cur]; P.count_in = g->counts + cur;
             P.out = g->q[nxt]; P.count_out = g->counts + nxt;
-            G_TRY(hipMemsetAsync(g->counts + nxt, 0, sizeof(uint32_t), stream));
             const unsigned grid = (n_cur + 255) / 256;
+            if (!P.guiding) {
+                // no network from here on: every remaining walker runs to its end in one launch
+#define LAUNCH_TAIL(E, T)                                                                                            \
+    do {                                                                                                             \
+        if (v.src.rgb) hipLaunchKernelGGL((tail_kernel<E, T, true>), dim3(grid), dim3(256), lds, stream, P);           \
+        else hipLaunchKernelGGL((tail_kernel<E, T, false>), dim3(grid), dim3(256), lds, stream, P);                     \
+    } while (0)
+                if (emissive) { if (tree) LAUNCH_TAIL(true, true); else LAUNCH_TAIL(true, false); }
+                else          { if (tree) LAUNCH_TAIL(false, true); else LAUNCH_TAIL(false, false); }
+#undef LAUNCH_TAIL
+                ++launches;
+                G_TRY(hipGetLastError());
+                break;
+            }
+            G_TRY(hipMemsetAsync(g->counts + nxt, 0, sizeof(uint32_t), stream));
 #define LAUNCH_SEP(E, T)                                                                                             \
     do {                                                                                                             \
         if (v.src.rgb) hipLaunchKernelGGL((separate_kernel<E, T, true>), dim3(grid), dim3(256), lds, stream, P);       \
