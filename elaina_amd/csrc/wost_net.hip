@@ -389,38 +389,47 @@ __global__ __launch_bounds__(256, 2) void net_backward_mfma_kernel(NetLayout L, 
 }
 
 // dW[r][k] += sum_p delta[p][r] * input[p][k] as MFMA over the point index: A = delta^T tile
-// (16 rows r x 4 points), B = input tile (4 points x 16 columns k).  One block = a chunk of
-// points, wave w owns the row tiles w, w+4, .. and all column tiles; partial sums leave through
-// one float atomic per (block, weight).
+// (16 rows r x 4 points), B = input tile (4 points x 16 columns k).  One WAVE owns a chunk of
+// consecutive points and all (row tile, column tile) pairs: 4 + 4 operand loads feed 16 MFMAs
+// per 4 points, nothing is read twice, 16 independent accumulators hide the MFMA latency.  The
+// chunk's sums leave through one fixed-point atomic per weight.
 template <int N_O, int N_I>
 __global__ __launch_bounds__(256) void weight_grad_mfma_kernel(const float *delta, int dstride, int doff, const float *input,
                                                                int istride, int ioff, int n, int chunk, fx_t *gW)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int p0 = blockIdx.x * chunk, p1 = min(n, p0 + chunk);
-    constexpr int KT = N_I / 16;
-    for (int rt = wave; rt < N_O / 16; rt += 4) {
-        f32x4_t acc[KT];
+    const int p0 = (blockIdx.x * 4 + wave) * chunk, p1 = min(n, p0 + chunk);
+    if (p0 >= n) return;
+    constexpr int RT = N_O / 16, KT = N_I / 16;
+    f32x4_t acc[RT][KT];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) acc[kt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-        for (int p = p0; p < p1; p += 4) {
-            const bool ok = p + g < p1;
-            const float a = ok ? delta[(size_t)(p + g) * dstride + doff + 16 * rt + i] : 0.0f;
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                const float bb = ok ? input[(size_t)(p + g) * istride + ioff + 16 * kt + i] : 0.0f;
-                acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc[kt], 0, 0, 0);
-            }
-        }
+        for (int kt = 0; kt < KT; ++kt) acc[rt][kt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int p = p0; p < p1; p += 4) {
+        const bool ok = p + g < p1;
+        const float *dp = delta + (size_t)(p + g) * dstride + doff + i;
+        const float *ip = input + (size_t)(p + g) * istride + ioff + i;
+        float a[RT], b[KT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[rt] = ok ? dp[16 * rt] : 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) b[kt] = ok ? ip[16 * kt] : 0.0f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) acc[rt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], b[kt], acc[rt][kt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float v = acc[kt][c];
+                const float v = acc[rt][kt][c];
                 if (v != 0.0f) fx_add(gW + (size_t)(16 * rt + 4 * g + c) * N_I + 16 * kt + i, to_fx(v));
             }
-    }
 }
 
 // backward, one thread per point: propagates dL/dout to every layer input (kept per point in
@@ -801,8 +810,8 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
         const int ioff = layer == 0 ? 0 : L.enc + (layer - 1) * L.n_neurons;               // this layer's input
         fx_t *gW = h->grad + L.w_off[layer];
         if (h->use_mfma) {
-#define WG(NO, NI) hipLaunchKernelGGL((weight_grad_mfma_kernel<NO, NI>), dim3(gridc), dim3(256), 0, stream, h->d_deltas, dstride, \
-                                      doff, h->d_acts, astride, ioff, n, chunk, gW)
+#define WG(NO, NI) hipLaunchKernelGGL((weight_grad_mfma_kernel<NO, NI>), dim3((gridc + 3) / 4), dim3(256), 0, stream, h->d_deltas, \
+                                      dstride, doff, h->d_acts, astride, ioff, n, chunk, gW)
             if (layer == 0) WG(64, 32);
             else if (layer == L.n_hidden) WG(48, 64);
             else WG(64, 64);
