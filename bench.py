@@ -163,7 +163,7 @@ def main():
                          "avg_launch_ms": kernel_ms / max(launches, 1),
                          "algorithmic_bytes_per_walk_step": BYTES_PER_STEP},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the host baseline is reported at N = 1 only
             base, (b, e, ref_field) = cpu_baseline(problem, frame, args.spp, depth, eps)
             out["cpu_baseline"] = base
             import numpy as np
