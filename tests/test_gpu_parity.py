@@ -320,8 +320,8 @@ def test_bench_two_ranks_sharing_one_gpu():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
     assert r["n_gpus"] == 2 and r["metric"] == "walk-steps/s" and r["scaling"] == "strong"
-    assert r["rel_l2_vs_oracle"] == 0.0
-    assert r["roofline"]["bound"] == "hbm" and r["cpu_baseline"]["kind"] == "port"
+    assert r["rel_l2_vs_oracle"] == 0.0                       # the assembled field, checked against the oracle
+    assert r["roofline"]["bound"] == "hbm" and "cpu_baseline" not in r     # host baseline: N = 1 only
 
 
 @pytest.mark.parametrize("scene,spp,depth", [("ladybug", 1, 64), ("ladybug", 5, 32), ("fille", 2, 128)])
