@@ -377,3 +377,57 @@ def test_gpu_guided_with_source_term_matches_oracle(oracle):
     f = gi.solution[:, 0].reshape(40, 40)
     assert abs(float(np.mean(f - want))) < 5e-3
     gi.close()
+
+
+def _exact(gi, ref):
+    assert np.array_equal(gi.solution, ref["field"]), float(np.abs(gi.solution - ref["field"]).max())
+    for k in ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated", "neumann_hits", "guided_steps",
+              "train_samples", "optimizer_steps"):
+        assert gi.last_stats[k] == ref[k], k
+
+
+@pytest.mark.gpu
+def test_gpu_guided_edge_cases_match_oracle(oracle):
+    """the instantiations and corner cases the shipped scenes never reach: a 3000-segment emissive
+    Neumann boundary (tree queries, SNCH cones), Dirichlet only, a masked ragged frame, depth 1,
+    training longer than the solve, zero samples"""
+    from conftest import wiggly_problem
+    big = ((-140.0, -140.0), (140.0, 140.0))
+    gi, ref = _gpu_and_oracle(oracle, wiggly_problem(emissive=True), 36, 28, 6, 40, 3, batch=1024, min_batch=256,
+                              aabb=big, dump=False)
+    _exact(gi, ref)
+    assert ref["neumann_hits"] > 0 and ref["optimizer_steps"] > 0
+    gi.close()
+    # open Neumann polyline (silhouette vertices at the ends), frozen network
+    gi, ref = _gpu_and_oracle(oracle, wiggly_problem(open_gap=40), 30, 30, 3, 32, 0, aabb=big, dump=False)
+    _exact(gi, ref)
+    gi.close()
+    # Dirichlet only
+    prob = box_problem(value=lambda x, y: x * y)
+    gi, ref = _gpu_and_oracle(oracle, prob, 33, 21, 5, 32, 2, batch=1024, min_batch=256, dump=False)
+    _exact(gi, ref)
+    assert ref["neumann_hits"] == 0
+    gi.close()
+    # mask + ragged frame + training pixel stride
+    prob = laplace_box()
+    prob.mask = (np.arange(37 * 19) % 5 != 0).astype(np.uint8)
+    gi, ref = _gpu_and_oracle(oracle, prob, 37, 19, 6, 32, 4, batch=512, min_batch=128, stride=2, offset=1, dump=False)
+    _exact(gi, ref)
+    assert np.all(gi.solution[prob.mask == 0] == 0)
+    gi.close()
+    prob.mask = None
+    # one step per walk; training longer than the solve; guided depth beyond the walk depth
+    gi, ref = _gpu_and_oracle(oracle, prob, 24, 24, 3, 1, 10, batch=512, min_batch=128, dump=False)
+    _exact(gi, ref)
+    assert ref["walks_truncated"] > 0
+    gi.close()
+    gi, ref = _gpu_and_oracle(oracle, prob, 24, 24, 2, 6, 1, mgd=(50, 50), batch=512, min_batch=128, dump=False)
+    _exact(gi, ref)
+    gi.close()
+    # guiding only in the second phase, and no samples at all
+    gi, ref = _gpu_and_oracle(oracle, prob, 24, 24, 6, 24, 3, mgd=(0, 10), uf=(0.5, 0.0), batch=512, min_batch=128, dump=False)
+    _exact(gi, ref)
+    gi.close()
+    gi, ref = _gpu_and_oracle(oracle, prob, 16, 16, 0, 8, 0, dump=False)
+    assert gi.last_stats["walk_steps"] == 0 == ref["walk_steps"]
+    gi.close()
