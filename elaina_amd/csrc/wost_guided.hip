@@ -572,6 +572,8 @@ struct wost_guided {
     TrainSet ts{};
     uint32_t last_train_n = 0;
     GAabb box{};
+    wost_sync_fn sync = nullptr;       // shared-network mode: collective hooks of the caller
+    void *sync_user = nullptr;
 };
 
 #define G_TRY(expr)                                                                                      \
@@ -682,6 +684,14 @@ int wost_guided_network(wost_guided_handle h, wost_net_handle *net)
 {
     if (!h || !net) return set_error(WOST_ERR_INVALID, "null argument");
     *net = h->net;
+    return WOST_OK;
+}
+
+int wost_guided_set_sync(wost_guided_handle h, wost_sync_fn fn, void *user)
+{
+    if (!h) return set_error(WOST_ERR_INVALID, "null argument");
+    h->sync = fn;
+    h->sync_user = user;
     return WOST_OK;
 }
 
@@ -842,6 +852,21 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
             train_samples += n;
             const size_t bs = (size_t)s.batch_size;
             size_t n_batches = std::min<size_t>(n / bs + 1, (size_t)s.batches_per_spp);
+            if (g->sync) {
+                // shared network: every rank must take the same number of steps -- the smallest
+                // number of full batches any rank has
+                size_t usable = 0;
+                for (size_t it = 0; it < n_batches; ++it) {
+                    size_t local = std::min(n - it * bs, bs);
+                    local -= local % 128;
+                    if (local < (size_t)s.min_batch_size) break;
+                    ++usable;
+                }
+                int64_t v = (int64_t)usable;
+                if (g->sync(g->sync_user, WOST_SYNC_MIN_I64_HOST, &v, 1) != 0)
+                    return set_error(WOST_ERR_DEVICE, "sync callback failed (batch count)");
+                n_batches = (size_t)std::max<int64_t>(v, 0);
+            }
             for (size_t it = 0; it < n_batches; ++it) {
                 size_t local = std::min(n - it * bs, bs);
                 local -= local % 128;
@@ -852,8 +877,19 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
                 if (rc != WOST_OK) return rc;
                 launch_vmm_loss_gradients(stream, raw, g->ts.dir + 2 * o, g->ts.li + o, g->ts.pdf + o, g->ts.onn + o,
                                           g->ts.nrm + 2 * o, (int)local, s.loss_scale, dl, nullptr);
-                rc = net_backward_update_dev(g->net, g->ts.xy + 2 * o, (int)local, s.loss_scale, 1, stream);
+                rc = net_backward_update_dev(g->net, g->ts.xy + 2 * o, (int)local, s.loss_scale, g->sync ? 0 : 1, stream);
                 if (rc != WOST_OK) return rc;
+                if (g->sync) {
+                    // sum the fixed-point gradients of all ranks (integer sums: the same network
+                    // everywhere, bit for bit), then step
+                    G_TRY(hipStreamSynchronize(stream));
+                    uint64_t count = 0;
+                    void *gbuf = net_gradient_buffer(g->net, &count);
+                    if (g->sync(g->sync_user, WOST_SYNC_SUM_I64_DEVICE, gbuf, count) != 0)
+                        return set_error(WOST_ERR_DEVICE, "sync callback failed (gradient all-reduce)");
+                    rc = net_apply_update_dev(g->net, s.loss_scale, stream);
+                    if (rc != WOST_OK) return rc;
+                }
                 launches += 8;
             }
             G_TRY(hipStreamSynchronize(stream));

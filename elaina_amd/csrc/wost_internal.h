@@ -41,6 +41,8 @@ int net_forward_train_dev(wost_net_handle h, const float *xy_dev, int n, hipStre
                           float **dl_dev);
 int net_backward_update_dev(wost_net_handle h, const float *xy_dev, int n, float loss_scale, int apply_update,
                             hipStream_t stream);
+int net_apply_update_dev(wost_net_handle h, float loss_scale, hipStream_t stream);
+void *net_gradient_buffer(wost_net_handle h, uint64_t *count);   // int64 fixed point, device
 int net_optimizer_steps(const wost_net *h);
 int net_n_output(const wost_net *h);
 

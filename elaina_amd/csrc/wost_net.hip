@@ -639,6 +639,7 @@ struct wost_net {
     uint32_t n_params = 0;
     float *params = nullptr, *inference = nullptr, *m1 = nullptr, *m2 = nullptr, *ema_raw = nullptr;
     fx_t *grad = nullptr;   // fixed-point gradient sums of the last training step
+    bool grad_owned = true; // false: the caller's buffer (wost_net_set_gradient_buffer)
     float *params_t = nullptr, *inference_t = nullptr;   // transposed MLP matrices (scalar forward pass)
     float *params_f = nullptr, *inference_f = nullptr;   // MFMA A-fragment order (MFMA forward pass)
     float *params_fb = nullptr;                          // MFMA fragments of the transposed matrices (backward pass)
@@ -721,7 +722,7 @@ static void net_free(wost_net *h)
     (void)hipSetDevice(h->device);
     for (float *p : {h->params, h->inference, h->params_t, h->inference_t, h->params_f, h->inference_f, h->params_fb, h->m1, h->m2, h->ema_raw, h->d_xy, h->d_out, h->d_dl, h->d_acts, h->d_deltas, h->d_denc})
         if (p) (void)hipFree(p);
-    if (h->grad) (void)hipFree(h->grad);
+    if (h->grad && h->grad_owned) (void)hipFree(h->grad);
     delete h;
 }
 
@@ -746,6 +747,8 @@ int net_forward_train_dev(wost_net *h, const float *xy_dev, int n, hipStream_t s
     *dl_dev = h->d_dl;
     return WOST_OK;
 }
+
+int net_apply_update_dev(wost_net *h, float loss_scale, hipStream_t stream);
 
 int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_scale, int apply_update, hipStream_t stream)
 {
@@ -822,20 +825,30 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
         }
     }
     NET_TRY(hipGetLastError());
-    if (apply_update) {
-        h->step += 1;
-        const wost_net_config &c = h->cfg;
-        const float lr_t = c.learning_rate * std::sqrt(1.0f - std::pow(c.beta2, (float)h->step)) /
-                           (1.0f - std::pow(c.beta1, (float)h->step));
-        const float debias = 1.0f / (1.0f - std::pow(c.ema_decay, (float)h->step));
-        hipLaunchKernelGGL(optimizer_kernel, dim3((h->n_params + 255) / 256), dim3(256), 0, stream, h->n_params, h->params,
-                           h->m1, h->m2, h->ema_raw, h->inference, h->grad, lr_t, c.beta1, c.beta2, c.epsilon, c.l2_reg,
-                           c.ema_decay, debias, loss_scale);
-        NET_TRY(hipGetLastError());
-        int rc = refresh_transposed(h, stream);
-        if (rc != WOST_OK) return rc;
-    }
+    if (apply_update) return net_apply_update_dev(h, loss_scale, stream);
     return WOST_OK;
+}
+
+// one Adam + EMA step on the accumulated gradient (kept apart from the backward pass so that a
+// multi-GPU caller can sum the fixed-point gradients of all ranks in between)
+int net_apply_update_dev(wost_net *h, float loss_scale, hipStream_t stream)
+{
+    h->step += 1;
+    const wost_net_config &c = h->cfg;
+    const float lr_t = c.learning_rate * std::sqrt(1.0f - std::pow(c.beta2, (float)h->step)) /
+                       (1.0f - std::pow(c.beta1, (float)h->step));
+    const float debias = 1.0f / (1.0f - std::pow(c.ema_decay, (float)h->step));
+    hipLaunchKernelGGL(optimizer_kernel, dim3((h->n_params + 255) / 256), dim3(256), 0, stream, h->n_params, h->params, h->m1,
+                       h->m2, h->ema_raw, h->inference, h->grad, lr_t, c.beta1, c.beta2, c.epsilon, c.l2_reg, c.ema_decay,
+                       debias, loss_scale);
+    NET_TRY(hipGetLastError());
+    return refresh_transposed(h, stream);
+}
+
+void *net_gradient_buffer(wost_net *h, uint64_t *count)
+{
+    if (count) *count = h->n_params;
+    return h->grad;
 }
 
 int net_optimizer_steps(const wost_net *h) { return h->step; }
@@ -938,6 +951,24 @@ int wost_net_get_params(wost_net_handle h, int which, float *host)
     }
     const float *src = which == 0 ? h->params : h->inference;
     NET_TRY(hipMemcpy(host, src, (size_t)h->n_params * sizeof(float), hipMemcpyDeviceToHost));
+    return WOST_OK;
+}
+
+int wost_net_set_gradient_buffer(wost_net_handle h, void *dev_int64)
+{
+    if (!h) return set_error(WOST_ERR_INVALID, "null argument");
+    NET_TRY(hipSetDevice(h->device));
+    if (!dev_int64) {                     // back to an internal buffer
+        if (!h->grad_owned) {
+            h->grad = nullptr;
+            NET_TRY(hipMalloc((void **)&h->grad, (size_t)h->n_params * sizeof(fx_t)));
+            h->grad_owned = true;
+        }
+        return WOST_OK;
+    }
+    if (h->grad && h->grad_owned) (void)hipFree(h->grad);
+    h->grad = static_cast<fx_t *>(dev_int64);
+    h->grad_owned = false;
     return WOST_OK;
 }
 

@@ -228,6 +228,35 @@ class GuidedIntegrator:
         self.last_stats = st.as_dict()
         return self.last_stats
 
+    def share_network(self):
+        """Train ONE network across all ranks of the initialised torch.distributed group
+        (wost_guided_set_sync): the fixed-point gradient buffer lives in a torch tensor, which is
+        all-reduced (RCCL over xGMI with the nccl backend) before every Adam step; integer sums
+        keep the ranks' networks bit-identical.  Without this call every shard trains its own."""
+        import torch
+        import torch.distributed as dist
+        self._grad = torch.zeros(self.network.n_params, dtype=torch.int64, device="cuda")
+        _check(self.lib.wost_net_set_gradient_buffer(self.network._h, C.c_void_p(self._grad.data_ptr())),
+               "wost_net_set_gradient_buffer")
+
+        def sync(user, op, data, count):
+            try:
+                if op == capi.SYNC_SUM_I64_DEVICE:
+                    dist.all_reduce(self._grad, op=dist.ReduceOp.SUM)
+                    torch.cuda.synchronize()
+                else:
+                    v = C.cast(data, C.POINTER(C.c_int64))
+                    t = torch.tensor([v[0]], dtype=torch.int64, device="cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                    v[0] = int(t.item())
+                return 0
+            except Exception as e:     # never let an exception cross the C boundary
+                print("share_network sync failed: %r" % (e,))
+                return 1
+
+        self._sync = capi.SYNC_FN(sync)       # keep the trampoline alive
+        _check(self.lib.wost_guided_set_sync(self._handle, self._sync, None), "wost_guided_set_sync")
+
     def train_set(self):
         """training set of the most recent training pass, (pixel, record) order"""
         n = C.c_int32()

@@ -206,6 +206,11 @@ int wost_net_n_params(wost_net_handle h, uint64_t *n_total, uint64_t *n_mlp);
 /* which: 0 = training parameters, 1 = inference (EMA) parameters, 2 = gradients of the last
  * wost_net_train_step (scaled by loss_scale). */
 int wost_net_get_params(wost_net_handle h, int which, float *host);
+/* Gradients are accumulated as 64-bit fixed point (value * 2^36) with integer atomics, so they do
+ * not depend on the order of summation.  A multi-GPU caller may supply the accumulation buffer
+ * itself (device memory, n_total int64; NULL = internal again), e.g. memory it can hand to a
+ * collective. */
+int wost_net_set_gradient_buffer(wost_net_handle h, void *dev_int64);
 /* sets training and inference parameters, resets the optimizer state */
 int wost_net_set_params(wost_net_handle h, const float *host);
 /* network->inference (integrator/guided/integrator.cu:560,597; util/network.h:39-47): xy[n*2] in [0,1]^2 -> out[n*n_output];
@@ -277,6 +282,17 @@ int wost_guided_solve(wost_guided_handle h, float *field_rgb, wost_guided_stats 
  * after the work has completed. */
 int wost_guided_solve_sharded(wost_guided_handle h, int32_t shard_index, int32_t shard_count,
                               float *field_rgb_dev, wost_guided_stats *stats);
+/* Shared network across shards (optional).  By default every shard trains its own network; with
+ * a sync callback the shards train ONE network: before every Adam step the callback must sum the
+ * fixed-point gradient buffer over all ranks (WOST_SYNC_SUM_I64_DEVICE: data = device int64[count],
+ * e.g. ncclAllReduce(.., ncclInt64, ncclSum, ..) followed by a stream synchronisation), and once per
+ * training pass it must reduce the number of usable batches to the minimum over the ranks
+ * (WOST_SYNC_MIN_I64_HOST: data = host int64[1]).  Integer sums make the result independent of
+ * the reduction order: all ranks hold the same network bit for bit.  Return 0 on success. */
+#define WOST_SYNC_SUM_I64_DEVICE 0
+#define WOST_SYNC_MIN_I64_HOST 1
+typedef int (*wost_sync_fn)(void *user, int op, void *data, uint64_t count);
+int wost_guided_set_sync(wost_guided_handle h, wost_sync_fn fn, void *user);
 /* The training set built by the most recent training pass, in (pixel, record) order
  * (generate_training_data, train.h:423-471): xy[n*2] normalised positions, dir[n*2],
  * solution[n*3] = |record.solution / record.thp|, dir_pdf[n], normal[n*2], on_neumann[n].

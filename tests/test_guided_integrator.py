@@ -431,3 +431,30 @@ def test_gpu_guided_edge_cases_match_oracle(oracle):
     gi, ref = _gpu_and_oracle(oracle, prob, 16, 16, 0, 8, 0, dump=False)
     assert gi.last_stats["walk_steps"] == 0 == ref["walk_steps"]
     gi.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shared", [True, False])
+def test_gpu_two_ranks_guided_runner(shared):
+    """config 5 in miniature through tools/gpu_guided_bench.py with two processes on the one GPU of
+    the test box (gloo carries the collectives): per-shard networks by default, ONE network --
+    bit-identical on both ranks thanks to the integer gradient sums -- with --shared-network"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tools", "gpu_guided_bench.py"), "--backend", "gloo", "--frame", "192",
+           "--spp", "6", "--train-spp", "4", "--batch", "8192", "--min-batch", "2048"] + (["--shared-network"] if shared else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["optimizer_steps_all_ranks"] > 0 and r["shared_network"] == shared
+    assert r["networks_identical"] == shared
+    assert 0.4 < r["mean"] < 0.6

@@ -25,6 +25,9 @@ ap.add_argument("--train-spp", type=int, default=256)
 ap.add_argument("--depth", type=int, default=64)
 ap.add_argument("--guided-depth", type=int, default=10)
 ap.add_argument("--backend", default=None)
+ap.add_argument("--shared-network", action="store_true", help="one network for all ranks (gradient all-reduce)")
+ap.add_argument("--batch", type=int, default=65536 * 8)
+ap.add_argument("--min-batch", type=int, default=65536)
 a = ap.parse_args()
 
 rank, world, local = D.init_process_group(a.backend)
@@ -33,10 +36,12 @@ torch.cuda.set_device(device)
 prob = Problem.load_scene(a.scene)
 st = GuidedIntegratorSettings(frameSize=(a.frame, a.frame), samplesPerPixel=a.spp, trainSppCount=a.train_spp,
                               maxWalkingDepth=a.depth, epsilonShell=1.0, maxGuidedDepthInTrainingPhase=a.guided_depth,
-                              maxGuidedDepthInGuidingPhase=a.guided_depth)
+                              maxGuidedDepthInGuidingPhase=a.guided_depth, batchSize=a.batch, minBatchSize=a.min_batch)
 t0 = time.time()
 gi = GuidedIntegrator(prob, st, ((-100.0, -100.0), (600.0, 600.0)), device=device)
 t_create = time.time() - t0
+if a.shared_network and world > 1:
+    gi.share_network()
 field = torch.zeros(a.frame * a.frame * 3, dtype=torch.float32, device="cuda")
 if world > 1:
     import torch.distributed as dist
@@ -53,8 +58,15 @@ mx = torch.tensor([elapsed, s["train_ms"] / 1e3], dtype=torch.float64, device="c
 if world > 1:
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+# are the ranks' networks the same? (they are with --shared-network, they are not without)
+psum = torch.tensor([float(abs(gi.network.params()).sum()), float(gi.network.params()[::97].sum())], dtype=torch.float64, device="cuda")
+pmin, pmax = psum.clone(), psum.clone()
+if world > 1:
+    dist.all_reduce(pmin, op=dist.ReduceOp.MIN)
+    dist.all_reduce(pmax, op=dist.ReduceOp.MAX)
 if rank == 0:
     print(json.dumps({
+        "networks_identical": bool((pmin == pmax).all().item()), "shared_network": bool(a.shared_network and world > 1),
         "workload": "%s guided %dx%d %d spp (train %d) depth %d" % (a.scene, a.frame, a.frame, a.spp, a.train_spp, a.depth),
         "n_gpus": world, "solve_s": float(mx[0]), "train_s": float(mx[1]), "create_s": t_create,
         "walk_steps": int(tot[0]), "walk_steps_per_s": float(tot[0]) / float(mx[0]), "guided_steps": int(tot[1]),
