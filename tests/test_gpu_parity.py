@@ -394,3 +394,38 @@ def test_render_source_matches_oracle(oracle):
     it = _integrator(p, 8, 8, 1, 4, 1e-3)
     assert np.all(it.renderSource() == 0)
     it.close()
+
+
+def test_full_size_properties_config2(ladybug):
+    """BASELINE config 2 at its full size (1024^2, 256 spp): properties that need no oracle run --
+    reproducibility, exact linearity in a power-of-two intensity, shard union, counter identities"""
+    import copy
+    import torch
+    from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+    st = UniformIntegratorSettings((1024, 1024), 256, 64, 1.0)
+    it = UniformIntegrator(ladybug, st)
+    it.solve()
+    a, sa = it.solution.copy(), dict(it.last_stats)
+    it.solve()
+    assert np.array_equal(a, it.solution) and it.last_stats["walk_steps"] == sa["walk_steps"]
+    it.close()
+    assert sa["walks_started"] == 1024 * 1024 * 256 == sa["walks_absorbed"] + sa["walks_truncated"]
+    assert sa["walk_steps"] == 1949024384          # the count every run of this configuration must reproduce
+    assert np.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 1.0 + 1e-6      # convex combinations of colours in [0, 1]
+    # doubling the Dirichlet intensity doubles every fp32 contribution exactly
+    p2 = copy.copy(ladybug)
+    p2.dirichlet_intensity = 2.0
+    it = UniformIntegrator(p2, st)
+    it.solve()
+    assert np.array_equal(it.solution, 2.0 * a)
+    it.close()
+    # three shards written into device buffers sum to the same field
+    total = torch.zeros(1024 * 1024 * 3, device="cuda")
+    it = UniformIntegrator(ladybug, st)
+    for r in range(3):
+        buf = torch.zeros(1024 * 1024 * 3, device="cuda")
+        it.solve_sharded(r, 3, buf.data_ptr())
+        torch.cuda.synchronize()
+        total += buf
+    it.close()
+    assert np.array_equal(total.cpu().numpy().reshape(-1, 3), a)

@@ -458,3 +458,37 @@ def test_gpu_two_ranks_guided_runner(shared):
     assert r["n_gpus"] == 2 and r["optimizer_steps_all_ranks"] > 0 and r["shared_network"] == shared
     assert r["networks_identical"] == shared
     assert 0.4 < r["mean"] < 0.6
+
+
+@pytest.mark.gpu
+def test_gpu_full_frame_guided_properties(ladybug):
+    """BASELINE config 4's frame (1024^2, full batch sizes) at 12 samples: reproducible with training,
+    every walk accounted for, exact linearity in a power-of-two intensity while the network is
+    frozen, and agreement of the mean with the uniform integrator"""
+    import copy
+    from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    aabb = ((-100.0, -100.0), (600.0, 600.0))
+
+    def run(problem, train):
+        st = GuidedIntegratorSettings(frameSize=(1024, 1024), samplesPerPixel=12, trainSppCount=train, maxWalkingDepth=64,
+                                      epsilonShell=1.0)
+        gi = GuidedIntegrator(problem, st, aabb, seed=42)
+        gi.solve()
+        out = gi.solution.copy(), dict(gi.last_stats), gi.network.params()
+        gi.close()
+        return out
+
+    f1, s1, p1 = run(ladybug, 8)
+    f2, s2, p2 = run(ladybug, 8)
+    assert np.array_equal(f1, f2) and np.array_equal(p1, p2)
+    assert s1["optimizer_steps"] == 8 * 5 and s1["walks_absorbed"] + s1["walks_truncated"] == s1["walks_started"] == 12 * 1024 * 1024
+    frozen, _, _ = run(ladybug, 0)
+    dbl = copy.copy(ladybug)
+    dbl.dirichlet_intensity = 2.0
+    frozen2, _, _ = run(dbl, 0)
+    assert np.array_equal(frozen2, 2.0 * frozen)
+    ui = UniformIntegrator(ladybug, UniformIntegratorSettings((1024, 1024), 12, 64, 1.0))
+    ui.solve()
+    assert abs(float(f1.mean()) - float(ui.solution.mean())) < 2e-3 * float(ui.solution.mean())
+    ui.close()
