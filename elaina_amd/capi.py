@@ -118,6 +118,8 @@ class GuidedStats(C.Structure):
 # wost_sync_fn (include/wost.h): int (*)(void *user, int op, void *data, uint64_t count)
 SYNC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64)
 SYNC_SUM_I64_DEVICE, SYNC_MIN_I64_HOST = 0, 1
+# wost_frame_fn: int (*)(void *user, int reason, int32_t sample_id, double elapsed_ms, const float *field_rgb)
+FRAME_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_double, C.POINTER(C.c_float))
 
 EXPORTS = [
     "wost_create", "wost_solve", "wost_solve_sharded", "wost_render_sdf", "wost_render_source", "wost_closest_point",
@@ -125,7 +127,7 @@ EXPORTS = [
     "wost_vonmises_eval", "wost_vonmises_sample", "wost_vmm_pdf_sample", "wost_vmm_loss_gradients",
     "wost_net_create", "wost_net_destroy", "wost_net_n_params", "wost_net_get_params",
     "wost_net_set_params", "wost_net_set_gradient_buffer", "wost_net_inference", "wost_net_train_step",
-    "wost_guided_create", "wost_guided_set_sync", "wost_guided_network", "wost_guided_scene", "wost_guided_query_network", "wost_guided_solve", "wost_guided_solve_sharded", "wost_guided_train_set", "wost_guided_destroy",
+    "wost_guided_create", "wost_guided_set_sync", "wost_guided_set_frame_callback", "wost_guided_network", "wost_guided_scene", "wost_guided_query_network", "wost_guided_solve", "wost_guided_solve_sharded", "wost_guided_train_set", "wost_guided_destroy",
     "wost_last_error", "wost_version",
 ]
 
@@ -180,6 +182,7 @@ def load():
                                      C.c_int, C.POINTER(C.c_void_p)]
     L.wost_guided_network.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.wost_guided_set_sync.argtypes = [C.c_void_p, SYNC_FN, C.c_void_p]
+    L.wost_guided_set_frame_callback.argtypes = [C.c_void_p, FRAME_FN, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     L.wost_net_set_gradient_buffer.argtypes = [C.c_void_p, C.c_void_p]
     L.wost_guided_scene.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.wost_guided_query_network.argtypes = [C.c_void_p, fp, C.c_int32, fp]

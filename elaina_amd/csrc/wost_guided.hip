@@ -574,6 +574,9 @@ struct wost_guided {
     GAabb box{};
     wost_sync_fn sync = nullptr;       // shared-network mode: collective hooks of the caller
     void *sync_user = nullptr;
+    wost_frame_fn frame_fn = nullptr;  // intermediate frames (saveSppMetrics / saveTimeMetrics)
+    void *frame_user = nullptr;
+    int32_t frame_spp_every = 0, frame_spp_until = 0, frame_time_every = 0;
 };
 
 #define G_TRY(expr)                                                                                      \
@@ -684,6 +687,18 @@ int wost_guided_network(wost_guided_handle h, wost_net_handle *net)
 {
     if (!h || !net) return set_error(WOST_ERR_INVALID, "null argument");
     *net = h->net;
+    return WOST_OK;
+}
+
+int wost_guided_set_frame_callback(wost_guided_handle h, wost_frame_fn fn, void *user, int32_t spp_every, int32_t spp_until,
+                                   int32_t time_every)
+{
+    if (!h) return set_error(WOST_ERR_INVALID, "null argument");
+    h->frame_fn = fn;
+    h->frame_user = user;
+    h->frame_spp_every = spp_every;
+    h->frame_spp_until = spp_until;
+    h->frame_time_every = time_every;
     return WOST_OK;
 }
 
@@ -894,6 +909,24 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
             }
             G_TRY(hipStreamSynchronize(stream));
             train_ms += std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+        }
+        // intermediate frames (reference integrator.cu:1049-1081)
+        if (g->frame_fn) {
+            const bool by_spp = g->frame_spp_every > 0 && sample % g->frame_spp_every == 0 && sample < g->frame_spp_until;
+            const bool by_time = g->frame_time_every > 0 && sample % g->frame_time_every == 0;
+            if (by_spp || by_time) {
+                hipLaunchKernelGGL(resolve_kernel, dim3((3 * N + 255) / 256), dim3(256), 0, stream, g->sol, N, (float)(sample + 1),
+                                   g->field);
+                std::vector<float> frame((size_t)N * 3);
+                G_TRY(hipMemcpyAsync(frame.data(), g->field, frame.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+                G_TRY(hipStreamSynchronize(stream));
+                const double ms =
+                    std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_start).count();
+                if (by_spp && g->frame_fn(g->frame_user, 0, sample, ms, frame.data()) != 0)
+                    return set_error(WOST_ERR_INVALID, "frame callback asked to stop");
+                if (by_time && g->frame_fn(g->frame_user, 1, sample, ms, frame.data()) != 0)
+                    return set_error(WOST_ERR_INVALID, "frame callback asked to stop");
+            }
         }
     }
     hipLaunchKernelGGL(resolve_kernel, dim3((3 * N + 255) / 256), dim3(256), 0, stream, g->sol, N, (float)s.spp, g->field);

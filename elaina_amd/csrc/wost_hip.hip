@@ -834,6 +834,10 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "waves_per_cu") {
         if (value < 0 || value > 32) return fail(WOST_ERR_INVALID, "waves_per_cu must be in 0..32");
         h->waves_per_cu = (int)value;
+    } else if (k == "spp") {
+        if (value < 0 || value >= (1 << 20)) return fail(WOST_ERR_INVALID, "spp must be in 0..2^20-1");
+        h->settings.spp = (int32_t)value;
+        h->dst.spp = (int32_t)value;
     } else if (k == "refill") {
         if (value != -1 && value != 0 && value != 1) return fail(WOST_ERR_INVALID, "refill must be -1 (auto), 0 or 1");
         h->refill = (int)value;

@@ -61,8 +61,6 @@ GuidedIntegrator<2>::GuidedIntegrator(Problem<2> &problem_, const IntegratorSett
                                       int device_)
     : IntegratorOutputs(settings.frameSize, basePath_), problem(problem_), integratorSettings(settings), device(device_)
 {
-    if (settings.saveSppMetricsDuration > 0 || settings.saveTimeMetricsDuration > 0)
-        ELAINA_LOG(Warning, "periodic metric dumps are not built (SURVEY.md 8f.4); ignoring save*Metrics* settings");
 }
 
 GuidedIntegrator<2>::~GuidedIntegrator()
@@ -103,9 +101,32 @@ wost_handle GuidedIntegrator<2>::scene_handle()
     return scene;
 }
 
+// frames/<sampleId>.exr|png and frames_time/<ms>.exr|png (reference integrator.cu:1049-1081)
+static int save_frame(void *user, int reason, int32_t sample_id, double elapsed_ms, const float *field)
+{
+    const GuidedIntegrator<2> *self = static_cast<const GuidedIntegrator<2> *>(user);
+    const Vector2i fs_ = self->get_integratorSettings().frameSize;
+    const std::vector<float> rgb(field, field + (size_t)fs_.x * fs_.y * 3);
+    try {
+        const fs::path dir = self->get_basePath() / (reason == 0 ? "frames" : "frames_time");
+        fs::create_directories(dir);
+        const string name = reason == 0 ? std::to_string(sample_id) : std::to_string((long long)elapsed_ms);
+        write_exr(dir / (name + ".exr"), fs_.x, fs_.y, rgb);
+        write_png(dir / (name + ".png"), fs_.x, fs_.y, rgb);
+    } catch (const std::exception &e) {
+        ELAINA_LOG(Error, "saving an intermediate frame failed: %s", e.what());
+        return 1;
+    }
+    return 0;
+}
+
 uint64_t GuidedIntegrator<2>::solve()
 {
     if (!handle) throw std::runtime_error("GuidedIntegrator: resetNetwork() has not been called");
+    const IntegratorSettings &s = integratorSettings;
+    if (s.saveSppMetricsDuration > 0 || s.saveTimeMetricsDuration > 0)
+        check_wost(wost_guided_set_frame_callback(handle, save_frame, this, s.saveSppMetricsDuration, s.saveSppMetricsUntil,
+                                                  s.saveTimeMetricsDuration), "wost_guided_set_frame_callback");
     const auto start = std::chrono::high_resolution_clock::now();
     std::vector<float> &f = channels[(size_t)ExportImageChannel::SOLUTION];
     f.assign((size_t)frameSize_.x * frameSize_.y * 3, 0.0f);

@@ -120,6 +120,20 @@ int main(int argc, char **argv)
     }
     if (std::strcmp(argv[1], "--selftest") == 0) return selftest();
     if (std::strcmp(argv[1], "--imagetest") == 0 && argc > 2) return imagetest(argv[2]);
+    if (std::strcmp(argv[1], "--readpng") == 0 && argc > 3) {   // decode a PNG to raw RGBA8 (tests of the mask reader)
+        try {
+            int w = 0, h = 0;
+            std::vector<uint8_t> rgba;
+            read_png(argv[2], &w, &h, &rgba);
+            std::ofstream f(argv[3], std::ios::binary);
+            f.write(reinterpret_cast<const char *>(rgba.data()), (std::streamsize)rgba.size());
+            std::cout << w << " " << h << std::endl;
+            return 0;
+        } catch (const std::exception &e) {
+            std::cerr << e.what() << std::endl;
+            return 1;
+        }
+    }
     try {
         run_expr(fs::path(argv[1]));
     } catch (const std::exception &e) {

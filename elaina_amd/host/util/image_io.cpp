@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <stdexcept>
 #include <string>
 
@@ -96,6 +97,206 @@ void write_png(const fs::path &path, int width, int height, const std::vector<fl
     png_chunk(f, "IHDR", ihdr);
     png_chunk(f, "IDAT", z);
     png_chunk(f, "IEND", {});
+}
+
+// ---- PNG reader: zlib inflate (RFC 1950/1951) + unfiltering (PNG 1.2 section 6) ------------------
+namespace {
+struct BitReader {
+    const uint8_t *p;
+    size_t n, pos = 0;
+    uint32_t bitbuf = 0;
+    int bitcnt = 0;
+    uint32_t bits(int k)
+    {
+        while (bitcnt < k) {
+            if (pos >= n) throw std::runtime_error("png: truncated deflate stream");
+            bitbuf |= (uint32_t)p[pos++] << bitcnt;
+            bitcnt += 8;
+        }
+        const uint32_t v = bitbuf & ((k == 32) ? 0xffffffffu : ((1u << k) - 1u));
+        bitbuf >>= k;
+        bitcnt -= k;
+        return v;
+    }
+    void align() { bitbuf = 0; bitcnt = 0; }
+};
+
+struct Huffman {
+    uint16_t count[16] = {0}, symbol[288] = {0};
+    void build(const uint8_t *lengths, int n)
+    {
+        for (int i = 0; i < 16; ++i) count[i] = 0;
+        for (int i = 0; i < n; ++i) count[lengths[i]]++;
+        count[0] = 0;
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int i = 1; i < 15; ++i) offs[i + 1] = (uint16_t)(offs[i] + count[i]);
+        for (int i = 0; i < n; ++i)
+            if (lengths[i]) symbol[offs[lengths[i]]++] = (uint16_t)i;
+    }
+    int decode(BitReader &br) const
+    {
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len <= 15; ++len) {
+            code |= (int)br.bits(1);
+            const int c = count[len];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+        throw std::runtime_error("png: bad Huffman code");
+    }
+};
+
+std::vector<uint8_t> inflate_zlib(const std::vector<uint8_t> &z)
+{
+    if (z.size() < 6 || (z[0] & 0x0f) != 8) throw std::runtime_error("png: not a zlib stream");
+    BitReader br{z.data() + 2, z.size() - 2};
+    std::vector<uint8_t> out;
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131,
+                                       163, 195, 227, 258};
+    static const uint16_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537,
+                                       2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint16_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    for (;;) {
+        const uint32_t last = br.bits(1), type = br.bits(2);
+        if (type == 0) {
+            br.align();
+            if (br.pos + 4 > br.n) throw std::runtime_error("png: truncated stored block");
+            const uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8);
+            br.pos += 4;
+            if (br.pos + len > br.n) throw std::runtime_error("png: truncated stored block");
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+            br.pos += len;
+        } else if (type == 1 || type == 2) {
+            Huffman lit, dist;
+            uint8_t lengths[320];
+            if (type == 1) {
+                for (int i = 0; i < 144; ++i) lengths[i] = 8;
+                for (int i = 144; i < 256; ++i) lengths[i] = 9;
+                for (int i = 256; i < 280; ++i) lengths[i] = 7;
+                for (int i = 280; i < 288; ++i) lengths[i] = 8;
+                lit.build(lengths, 288);
+                for (int i = 0; i < 30; ++i) lengths[i] = 5;
+                dist.build(lengths, 30);
+            } else {
+                const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
+                static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                uint8_t cl[19] = {0};
+                for (int i = 0; i < ncode; ++i) cl[order[i]] = (uint8_t)br.bits(3);
+                Huffman code;
+                code.build(cl, 19);
+                int i = 0;
+                while (i < nlen + ndist) {
+                    const int sym = code.decode(br);
+                    if (sym < 16) lengths[i++] = (uint8_t)sym;
+                    else {
+                        int rep, val = 0;
+                        if (sym == 16) {
+                            if (i == 0) throw std::runtime_error("png: bad code lengths");
+                            val = lengths[i - 1];
+                            rep = 3 + (int)br.bits(2);
+                        } else if (sym == 17) rep = 3 + (int)br.bits(3);
+                        else rep = 11 + (int)br.bits(7);
+                        if (i + rep > nlen + ndist) throw std::runtime_error("png: bad code lengths");
+                        while (rep--) lengths[i++] = (uint8_t)val;
+                    }
+                }
+                lit.build(lengths, nlen);
+                dist.build(lengths + nlen, ndist);
+            }
+            for (;;) {
+                const int sym = lit.decode(br);
+                if (sym < 256) out.push_back((uint8_t)sym);
+                else if (sym == 256) break;
+                else {
+                    if (sym > 285) throw std::runtime_error("png: bad length symbol");
+                    const int len = lbase[sym - 257] + (int)br.bits(lext[sym - 257]);
+                    const int ds = dist.decode(br);
+                    if (ds > 29) throw std::runtime_error("png: bad distance symbol");
+                    const size_t d = dbase[ds] + br.bits(dext[ds]);
+                    if (d > out.size()) throw std::runtime_error("png: distance too far back");
+                    for (int k = 0; k < len; ++k) out.push_back(out[out.size() - d]);
+                }
+            }
+        } else {
+            throw std::runtime_error("png: bad block type");
+        }
+        if (last) break;
+    }
+    return out;
+}
+}  // namespace
+
+void read_png(const fs::path &path, int *width, int *height, std::vector<uint8_t> *rgba)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) throw std::runtime_error("cannot open " + path.string());
+    std::vector<uint8_t> b((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (b.size() < 8 || std::memcmp(b.data(), sig, 8) != 0) throw std::runtime_error("not a PNG file: " + path.string());
+    auto be32 = [&](size_t o) { return ((uint32_t)b[o] << 24) | ((uint32_t)b[o + 1] << 16) | ((uint32_t)b[o + 2] << 8) | b[o + 3]; };
+    size_t pos = 8;
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, plte, trns;
+    while (pos + 12 <= b.size()) {
+        const uint32_t n = be32(pos);
+        const std::string type(reinterpret_cast<const char *>(&b[pos + 4]), 4);
+        if (pos + 12 + n > b.size()) throw std::runtime_error("png: truncated chunk");
+        const uint8_t *d = &b[pos + 8];
+        if (type == "IHDR") {
+            w = be32(pos + 8); h = be32(pos + 12);
+            depth = d[8]; ctype = d[9]; interlace = d[12];
+        } else if (type == "PLTE") plte.assign(d, d + n);
+        else if (type == "tRNS") trns.assign(d, d + n);
+        else if (type == "IDAT") idat.insert(idat.end(), d, d + n);
+        else if (type == "IEND") break;
+        pos += 12 + n;
+    }
+    if (w == 0 || h == 0 || depth != 8 || interlace != 0) throw std::runtime_error("png: only 8-bit non-interlaced images are read");
+    const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!ch) throw std::runtime_error("png: unknown colour type");
+    std::vector<uint8_t> raw = inflate_zlib(idat);
+    const size_t stride = (size_t)w * ch;
+    if (raw.size() < (stride + 1) * h) throw std::runtime_error("png: image data too short");
+    std::vector<uint8_t> img(stride * h);
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t *src = &raw[(stride + 1) * y];
+        uint8_t *dst = &img[stride * y];
+        const uint8_t *up = y ? &img[stride * (y - 1)] : nullptr;
+        const int ft = src[0];
+        for (size_t x = 0; x < stride; ++x) {
+            const int a = x >= (size_t)ch ? dst[x - ch] : 0, bb = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = bb;
+            else if (ft == 3) pred = (a + bb) >> 1;
+            else if (ft == 4) {
+                const int p = a + bb - c, pa = std::abs(p - a), pb = std::abs(p - bb), pc = std::abs(p - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c);
+            } else if (ft != 0) throw std::runtime_error("png: bad filter type");
+            dst[x] = (uint8_t)(src[1 + x] + pred);
+        }
+    }
+    *width = (int)w;
+    *height = (int)h;
+    rgba->assign((size_t)w * h * 4, 255);
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        uint8_t *o = &(*rgba)[4 * i];
+        const uint8_t *s = &img[i * ch];
+        if (ctype == 0) { o[0] = o[1] = o[2] = s[0]; }
+        else if (ctype == 2) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; }
+        else if (ctype == 3) {
+            if ((size_t)s[0] * 3 + 2 >= plte.size()) throw std::runtime_error("png: palette index out of range");
+            o[0] = plte[3 * s[0]]; o[1] = plte[3 * s[0] + 1]; o[2] = plte[3 * s[0] + 2];
+            if (s[0] < trns.size()) o[3] = trns[s[0]];
+        } else if (ctype == 4) { o[0] = o[1] = o[2] = s[0]; o[3] = s[1]; }
+        else { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; }
+    }
 }
 
 // ---- OpenEXR, single part, scan lines, no compression, half RGBA -------------------------------

@@ -1,8 +1,8 @@
 // image_io.h -- the file formats of the reference's exports (reference core/texture.cu:82-116,
 // util/image.cpp:28-103): 8-bit RGBA PNG with value = clamp((int)(v * 255), 0, 255), and OpenEXR
 // RGBA in half precision; both flipped vertically on write like stbi_flip_vertically_on_write /
-// tinyexr::save_exr(.., flip = true).  Plus raw-float PFM (what parity is measured on).
-// Self-contained writers: no zlib / stb / tinyexr in this image.
+// tinyexr::save_exr(.., flip = true).  Plus raw-float PFM (what parity is measured on) and a PNG
+// reader for mask images.  Self-contained: no zlib / stb / tinyexr in this image.
 #pragma once
 #include <filesystem>
 #include <vector>
@@ -17,5 +17,10 @@ void write_exr(const fs::path &path, int width, int height, const std::vector<fl
 void write_pfm(const fs::path &path, int width, int height, const std::vector<float> &rgb);
 
 uint16_t float_to_half(float f);   // round to nearest even, IEEE binary16
+
+// 8-bit PNG reader (grey, grey+alpha, RGB, RGBA, palette; non-interlaced) for mask images
+// (reference core/problem.cu:216-242 loads them through stb_image).  rgba: height*width*4 bytes,
+// rows top to bottom as stored in the file.
+void read_png(const fs::path &path, int *width, int *height, std::vector<uint8_t> *rgba);
 
 }  // namespace elaina

@@ -293,6 +293,14 @@ int wost_guided_solve_sharded(wost_guided_handle h, int32_t shard_index, int32_t
 #define WOST_SYNC_MIN_I64_HOST 1
 typedef int (*wost_sync_fn)(void *user, int op, void *data, uint64_t count);
 int wost_guided_set_sync(wost_guided_handle h, wost_sync_fn fn, void *user);
+/* Intermediate frames (saveSppMetrics* / saveTimeMetrics* of GuidedIntegratorSettings, reference
+ * integrator/guided/integrator.cu:1049-1081): during wost_guided_solve the callback receives
+ * solution / (sample_id + 1) after sample sample_id when  spp_every > 0 && sample_id % spp_every
+ * == 0 && sample_id < spp_until  (reason 0), and when  time_every > 0 && sample_id % time_every
+ * == 0  (reason 1, with the milliseconds since the start of the solve).  Return 0 to continue. */
+typedef int (*wost_frame_fn)(void *user, int reason, int32_t sample_id, double elapsed_ms, const float *field_rgb);
+int wost_guided_set_frame_callback(wost_guided_handle h, wost_frame_fn fn, void *user, int32_t spp_every,
+                                   int32_t spp_until, int32_t time_every);
 /* The training set built by the most recent training pass, in (pixel, record) order
  * (generate_training_data, train.h:423-471): xy[n*2] normalised positions, dir[n*2],
  * solution[n*3] = |record.solution / record.thp|, dir_pdf[n], normal[n*2], on_neumann[n].
@@ -301,7 +309,10 @@ int wost_guided_train_set(wost_guided_handle h, int32_t capacity, int32_t *n, fl
                           float *solution, float *dir_pdf, float *normal, uint8_t *on_neumann);
 int wost_guided_destroy(wost_guided_handle h);
 
-/* Tuning knobs ("steps_per_round", "block_size", ...); unknown keys -> WOST_ERR_INVALID. */
+/* Tuning knobs ("steps_per_round", "block_size", ...); unknown keys -> WOST_ERR_INVALID.
+ * "spp" changes samplesPerPixel of an existing handle (a pixel's first k samples do not depend on
+ * the total, so solving with spp = k reproduces the state of a longer solve after k samples: the
+ * host mirror uses this for saveSppMetrics frames). */
 int wost_set_option(wost_handle h, const char *key, double value);
 
 int wost_destroy(wost_handle h);

@@ -179,3 +179,127 @@ def test_run_expr_with_a_source_grid(tmp_path, oracle, ladybug):
     assert np.array_equal(export_scene.read_pfm(exp / "source.pfm"), oracle.render_source(p.as_dict(), 48, 48))
     plain = oracle.solve(ladybug.as_dict(), 48, 48, 4, 32, 1.0, threads=os.cpu_count())
     assert not np.array_equal(plain["field"], ref["field"])
+
+
+def _write_png(path, img, ctype, level=9, strategy=0, palette=None, filters=None):
+    """minimal PNG writer for the reader's tests: img uint8 [h, w, channels]; per-row filter types"""
+    import struct
+    import zlib
+    h, w, ch = img.shape
+    rows = bytearray()
+    prev = np.zeros(w * ch, np.int32)
+    for y in range(h):
+        cur = img[y].reshape(-1).astype(np.int32)
+        ft = (filters[y % len(filters)] if filters else 0)
+        left = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+        ul = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+        if ft == 0:
+            pred = np.zeros_like(cur)
+        elif ft == 1:
+            pred = left
+        elif ft == 2:
+            pred = prev
+        elif ft == 3:
+            pred = (left + prev) >> 1
+        else:
+            p = left + prev - ul
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - ul)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+        rows.append(ft)
+        rows += bytes(((cur - pred) & 255).astype(np.uint8))
+        prev = cur
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 9, strategy)
+    z = co.compress(bytes(rows)) + co.flush()
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(palette.reshape(-1)))
+    # split IDAT into two chunks on purpose
+    out += chunk(b"IDAT", z[:len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b"")
+    open(path, "wb").write(out)
+
+
+def test_png_reader_and_mask_loading(tmp_path):
+    """read_png (mask images, reference core/problem.cu:216-242 via stb_image): stored / fixed /
+    dynamic deflate blocks, all five filters, grey / RGB / RGBA / grey+alpha / palette"""
+    import zlib
+    rng = np.random.default_rng(1)
+    exe = _exe()
+    cases = [("rgb", 2, 3, 9, 0), ("rgba", 6, 4, 6, 0), ("grey", 0, 1, 0, 0), ("ga", 4, 2, 9, zlib.Z_FIXED), ("pal", 3, 1, 9, 0)]
+    for name, ctype, ch, level, strategy in cases:
+        w, h = 37, 23
+        # smooth + noisy content so that every filter and long back-references occur
+        base = (np.add.outer(np.arange(h) * 3, np.arange(w) * 5)[..., None] + np.arange(ch) * 40) % 256
+        img = np.where(rng.uniform(size=(h, w, ch)) < 0.2, rng.integers(0, 256, (h, w, ch)), base).astype(np.uint8)
+        palette = rng.integers(0, 256, (256, 3)).astype(np.uint8) if ctype == 3 else None
+        _write_png(tmp_path / (name + ".png"), img, ctype, level, strategy, palette, filters=[0, 1, 2, 3, 4])
+        out = subprocess.run([exe, "--readpng", str(tmp_path / (name + ".png")), str(tmp_path / (name + ".raw"))],
+                             capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.split() == [str(w), str(h)], out.stderr
+        got = np.fromfile(tmp_path / (name + ".raw"), dtype=np.uint8).reshape(h, w, 4)
+        if ctype == 2:
+            want = np.concatenate([img, np.full((h, w, 1), 255, np.uint8)], -1)
+        elif ctype == 6:
+            want = img
+        elif ctype == 0:
+            want = np.concatenate([img.repeat(3, -1), np.full((h, w, 1), 255, np.uint8)], -1)
+        elif ctype == 4:
+            want = np.concatenate([img[..., :1].repeat(3, -1), img[..., 1:]], -1)
+        else:
+            want = np.concatenate([palette[img[..., 0]], np.full((h, w, 1), 255, np.uint8)], -1)
+        assert np.array_equal(got, want), name
+    bad = subprocess.run([exe, "--readpng", str(tmp_path / "missing.png"), str(tmp_path / "x.raw")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "cannot open" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_run_expr_with_a_mask_image(tmp_path, oracle, ladybug):
+    """scene.mask_path through the C++ host: flipped vertically, on = any non-zero RGB byte"""
+    import copy
+    import export_scene
+    conf = export_scene.export("ladybug", str(tmp_path), frame=40, spp=3, depth=24)
+    rng = np.random.default_rng(2)
+    img = (rng.uniform(size=(40, 40, 3)) < 0.25).astype(np.uint8) * rng.integers(1, 256, (40, 40, 3)).astype(np.uint8)
+    _write_png(tmp_path / "mask.png", img, 2, filters=[4, 1])
+    c = json.load(open(conf))
+    c["scene"]["mask_path"] = str(tmp_path / "mask.png")
+    json.dump(c, open(conf, "w"))
+    out = subprocess.run([_exe(), conf], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    p = copy.copy(ladybug)
+    p.mask = (img[::-1].max(-1) != 0).astype(np.uint8).reshape(-1)
+    ref = oracle.solve(p.as_dict(), 40, 40, 3, 24, 1.0)
+    field = export_scene.read_pfm(tmp_path / "exp" / "ladybug_u" / "solution.pfm")
+    assert np.array_equal(field, ref["field"]) and np.all(field[p.mask == 0] == 0) and 0 < p.mask.sum() < 1600
+
+
+@pytest.mark.gpu
+def test_run_expr_spp_metric_frames(tmp_path, oracle, ladybug):
+    """saveSppMetricsDuration / Until (reference integrator.cu:578-592, guided :1049-1063): frame k
+    holds the solution after k + 1 samples -- for the uniform integrator that is the oracle's solve
+    with spp = k + 1, bit for bit (8-bit PNG quantisation applied)"""
+    import export_scene
+    for integrator in ("uniform", "guided"):
+        d = tmp_path / integrator
+        conf = export_scene.export("ladybug", str(d), frame=32, spp=5, depth=24, integrator=integrator, train_spp=0)
+        c = json.load(open(conf))
+        c["integrator"]["setting"].update({"saveSppMetricsDuration": 2, "saveSppMetricsUntil": 4})
+        if integrator == "guided":
+            c["integrator"]["setting"]["saveTimeMetricsDuration"] = 4
+        json.dump(c, open(conf, "w"))
+        out = subprocess.run([_exe(), conf], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        exp = d / "exp" / ("ladybug_u" if integrator == "uniform" else "ladybug_n")
+        frames = sorted(os.listdir(exp / "frames"))
+        assert frames == ["0.exr", "0.png", "2.exr", "2.png"]          # sampleId 0 and 2 (< until 4), not 4
+        if integrator == "uniform":
+            for k in (0, 2):
+                ref = oracle.solve(ladybug.as_dict(), 32, 32, k + 1, 24, 1.0)["field"]
+                png = _read_png(exp / "frames" / ("%d.png" % k))
+                assert np.array_equal(png[::-1, :, :3].reshape(-1, 3), np.clip((ref * np.float32(255)).astype(np.int32), 0, 255))
+            final = oracle.solve(ladybug.as_dict(), 32, 32, 5, 24, 1.0)["field"]
+            assert np.array_equal(export_scene.read_pfm(exp / "solution.pfm"), final)      # spp restored afterwards
+        else:
+            assert len(os.listdir(exp / "frames_time")) in (2, 4)      # samples 0 and 4 (.exr + .png; names are elapsed ms)
