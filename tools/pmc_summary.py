@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Sum rocprofv3 --pmc counter_collection.csv per kernel and counter."""
+"""Sum rocprofv3 --pmc counter_collection.csv per kernel and counter.
+Usage: pmc_summary.py counter_collection.csv [kernel-name substrings; default: the walk kernels]"""
 import csv
 import sys
 from collections import defaultdict
 
+wanted = sys.argv[2:] or ["walk_round", "init_kernel"]
 tot = defaultdict(float)
 calls = defaultdict(int)
 with open(sys.argv[1]) as f:
@@ -12,5 +14,5 @@ with open(sys.argv[1]) as f:
         tot[k] += float(row["Counter_Value"])
         calls[k] += 1
 for (k, c), v in sorted(tot.items()):
-    if "walk_round" in k or "init_kernel" in k:
+    if any(w in k for w in wanted):
         print("%-62s %-32s calls=%-5d sum=%.6g avg=%.6g" % (k, c, calls[(k, c)], v, v / calls[(k, c)]))
