@@ -389,25 +389,27 @@ __global__ __launch_bounds__(256, 2) void net_backward_mfma_kernel(NetLayout L, 
 }
 
 // dW[r][k] += sum_p delta[p][r] * input[p][k] as MFMA over the point index: A = delta^T tile
-// (16 rows r x 4 points), B = input tile (4 points x 16 columns k).  One WAVE owns a chunk of
-// consecutive points and all (row tile, column tile) pairs: 4 + 4 operand loads feed 16 MFMAs
-// per 4 points, nothing is read twice, 16 independent accumulators hide the MFMA latency.  The
-// chunk's sums leave through one fixed-point atomic per weight.
+// (16 rows r x 4 points), B = input tile (4 points x 16 columns k).  One BLOCK owns a chunk of
+// 1024 consecutive points; its four waves take the 4-point groups round robin (wave w: groups
+// w, w+4, ..), each wave owns all (row tile, column tile) pairs: 4 + 4 operand loads feed 16 MFMAs
+// per group and 16 independent accumulators hide the MFMA latency.  The four partial sums are
+// added in the fixed order ((w0 + w1) + w2) + w3 through LDS and leave through one fixed-point
+// atomic per weight -- the summation order every implementation of this gradient follows.
 template <int N_O, int N_I>
 __global__ __launch_bounds__(256) void weight_grad_mfma_kernel(const float *delta, int dstride, int doff, const float *input,
                                                                int istride, int ioff, int n, int chunk, fx_t *gW)
 {
+    constexpr int RT = N_O / 16, KT = N_I / 16;
+    __shared__ float red[3][RT * KT * 4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int p0 = (blockIdx.x * 4 + wave) * chunk, p1 = min(n, p0 + chunk);
-    if (p0 >= n) return;
-    constexpr int RT = N_O / 16, KT = N_I / 16;
+    const int p0 = blockIdx.x * chunk, p1 = min(n, p0 + chunk);
     f32x4_t acc[RT][KT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) acc[rt][kt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int p = p0; p < p1; p += 4) {
+    for (int p = p0 + 4 * wave; p < p1; p += 16) {
         const bool ok = p + g < p1;
         const float *dp = delta + (size_t)(p + g) * dstride + doff + i;
         const float *ip = input + (size_t)(p + g) * istride + ioff + i;
@@ -421,13 +423,24 @@ __global__ __launch_bounds__(256) void weight_grad_mfma_kernel(const float *delt
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) acc[rt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], b[kt], acc[rt][kt], 0, 0, 0);
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) red[wave - 1][(rt * KT + kt) * 4 + c][lane] = acc[rt][kt][c];
+    }
+    __syncthreads();
+    if (wave != 0) return;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float v = acc[rt][kt][c];
+                const int e = (rt * KT + kt) * 4 + c;
+                const float v = ((acc[rt][kt][c] + red[0][e][lane]) + red[1][e][lane]) + red[2][e][lane];
                 if (v != 0.0f) fx_add(gW + (size_t)(16 * rt + 4 * g + c) * N_I + 16 * kt + i, to_fx(v));
             }
 }
@@ -553,7 +566,8 @@ __global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float
 }
 
 // dW[r][k] += sum_p delta[p][r] * input[p][k] for one layer: a block owns a chunk of points,
-// thread t owns the (r, k) pairs {t, t + 256, ...}; partial sums leave through float atomics.
+// thread t owns the (r, k) pairs {t, t + 256, ...}; per pair four fmaf chains over the 4-point
+// groups taken round robin, added as ((c0 + c1) + c2) + c3 -- the order of the MFMA kernel.
 __global__ __launch_bounds__(256) void weight_grad_kernel(const float *delta, int dstride, int doff, const float *input,
                                                           int istride, int ioff, int n_o, int n_i, int n, int chunk,
                                                           fx_t *gW)
@@ -564,9 +578,11 @@ __global__ __launch_bounds__(256) void weight_grad_kernel(const float *delta, in
     const int p0 = blockIdx.x * chunk;
     const int p1 = min(n, p0 + chunk);
     const int n_pairs = n_o * n_i;
-    float acc[16];
+    float acc[16][4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc[j][w] = 0.0f;
     for (int pb = p0; pb < p1; pb += 32) {
         const int cnt = min(32, p1 - pb);
         __syncthreads();
@@ -584,16 +600,16 @@ __global__ __launch_bounds__(256) void weight_grad_kernel(const float *delta, in
             const int pair = threadIdx.x + 256 * j;
             if (pair < n_pairs) {
                 const int r = pair / n_i, k = pair % n_i;
-                float a = acc[j];
-                for (int q = 0; q < 32; ++q) a = __builtin_fmaf(sd[q * 64 + r], si[q * 64 + k], a);
-                acc[j] = a;
+#pragma unroll
+                for (int q = 0; q < 32; ++q) acc[j][(q >> 2) & 3] = __builtin_fmaf(sd[q * 64 + r], si[q * 64 + k], acc[j][(q >> 2) & 3]);
             }
         }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int pair = threadIdx.x + 256 * j;
-        if (pair < n_pairs && acc[j] != 0.0f) fx_add(gW + pair, to_fx(acc[j]));
+        const float v = ((acc[j][0] + acc[j][1]) + acc[j][2]) + acc[j][3];
+        if (pair < n_pairs && v != 0.0f) fx_add(gW + pair, to_fx(v));
     }
 }
 
@@ -813,8 +829,8 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
         const int ioff = layer == 0 ? 0 : L.enc + (layer - 1) * L.n_neurons;               // this layer's input
         fx_t *gW = h->grad + L.w_off[layer];
         if (h->use_mfma) {
-#define WG(NO, NI) hipLaunchKernelGGL((weight_grad_mfma_kernel<NO, NI>), dim3((gridc + 3) / 4), dim3(256), 0, stream, h->d_deltas, \
-                                      dstride, doff, h->d_acts, astride, ioff, n, chunk, gW)
+#define WG(NO, NI) hipLaunchKernelGGL((weight_grad_mfma_kernel<NO, NI>), dim3(gridc), dim3(256), 0, stream, h->d_deltas, dstride, \
+                                      doff, h->d_acts, astride, ioff, n, chunk, gW)
             if (layer == 0) WG(64, 32);
             else if (layer == L.n_hidden) WG(48, 64);
             else WG(64, 64);

@@ -126,7 +126,7 @@ int wo_net_forward(const wo_net_config *c, const float *params, const float *xy,
  * A gradient is a sum over the points; to make it independent of the order in which a parallel
  * machine adds, every partial sum is converted to 64-bit fixed point (2^-36) and the integers are
  * added: grid terms one by one, weight terms as fmaf chains over chunks of 1024
- * consecutive points.  The HIP kernels do exactly the same, so both gradients are bit-identical. */
+ * consecutive points (four interleaved chains per chunk).  The HIP kernels do exactly the same, so both gradients are bit-identical. */
 #define WN_FX_SCALE 68719476736.0   /* 2^36 */
 #define WN_WGRAD_CHUNK 1024
 
@@ -200,7 +200,9 @@ int wo_net_backward(const wo_net_config *c, const float *params, const float *xy
                         gG[cidx[4 * lv + k] * c->n_features + f] += llrint((double)t * WN_FX_SCALE);
                     }
         }
-        /* weights: one fmaf chain per (row, column) over the points of the chunk */
+        /* weights: per (row, column) four fmaf chains over the 4-point groups of the chunk taken round
+         * robin (group j goes to chain j mod 4: what the four waves of a block do), added in the
+         * fixed order ((c0 + c1) + c2) + c3 */
         for (int layer = 0; layer <= NL; ++layer) {
             const int n_i = layer == 0 ? E : H, n_o = layer == NL ? NO : H;
             const int doff = layer == NL ? 0 : NO + layer * H;            /* delta of this layer's output */
@@ -208,9 +210,11 @@ int wo_net_backward(const wo_net_config *c, const float *params, const float *xy
             long long *gW = fx + woff[layer];
             for (int r = 0; r < n_o; ++r)
                 for (int k = 0; k < n_i; ++k) {
-                    float s = 0.0f;
+                    float c4[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
                     for (int q = 0; q < cnt; ++q)
-                        s = fmaf(dels[(size_t)q * del_stride + doff + r], acts[(size_t)q * act_stride + ioff + k], s);
+                        c4[(q >> 2) & 3] = fmaf(dels[(size_t)q * del_stride + doff + r], acts[(size_t)q * act_stride + ioff + k],
+                                                c4[(q >> 2) & 3]);
+                    const float s = ((c4[0] + c4[1]) + c4[2]) + c4[3];
                     if (s != 0.0f) gW[(size_t)r * n_i + k] += llrint((double)s * WN_FX_SCALE);
                 }
         }
