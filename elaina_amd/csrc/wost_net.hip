@@ -216,7 +216,7 @@ __device__ __forceinline__ void mfma_layer(const float *wf, int lane, const floa
 template <int ENC, int H, int NH, int NOP, bool SAVE>
 __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, const float *params, const float *frag,
                                                                   const float *xy, int n, const uint32_t *n_dev, float *out,
-                                                                  float *acts)
+                                                                  float *acts, unsigned long long *relu_mask)
 {
     static_assert(ENC % 4 == 0 && ENC <= 64 && H % 16 == 0 && H <= 64 && NOP % 16 == 0 && NOP <= 64, "shape");
     extern __shared__ float lds[];
@@ -280,6 +280,12 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
             for (int s = 0; s < ENC / 4; ++s) b[u][s] = stage[(u * 16 + i) * ENC + 4 * s + g];
         __threadfence_block();      // before the next iteration overwrites the staging area
         f32x4_t acc[kMfmaSub][4];
+        // which hidden activations are positive, bit (layer * 16 + 4 rt + c) of this lane's word: the
+        // backward kernel holds the same features in the same lanes and needs nothing else of them
+        static_assert(NH * (H / 16) * 4 <= 64, "ReLU mask word");
+        unsigned long long mask[kMfmaSub];
+#pragma unroll
+        for (int u = 0; u < kMfmaSub; ++u) mask[u] = 0ull;
         // ---- hidden layers: ReLU, the accumulators become the next B operands
 #pragma unroll
         for (int layer = 0; layer < NH; ++layer) {
@@ -293,8 +299,14 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
                     for (int c = 0; c < 4; ++c) {
                         const float v = fmaxf(acc[u][rt][c], 0.0f);
                         b[u][4 * rt + c] = v;
+                        if (SAVE) mask[u] |= (unsigned long long)(v > 0.0f) << (layer * 16 + 4 * rt + c);
                         if (SAVE && valid[u]) acts[(size_t)pt[u] * astride + ENC + layer * H + 16 * rt + 4 * c + g] = v;
                     }
+        }
+        if (SAVE) {
+#pragma unroll
+            for (int u = 0; u < kMfmaSub; ++u)
+                if (valid[u]) relu_mask[(size_t)pt[u] * 4 + g] = mask[u];
         }
         // ---- output layer
         mfma_layer<H / 4, NOP / 16>(wfrag + L.w_off[NH], lane, b, acc);
@@ -333,7 +345,8 @@ __global__ void fragment_mlp_t_kernel(NetLayout L, const float *src, float *dst)
 
 template <int ENC, int H, int NH, int NOP>
 __global__ __launch_bounds__(256, 2) void net_backward_mfma_kernel(NetLayout L, const float *fragb, const float *dl_dout,
-                                                                   const float *acts, int n, float *deltas, float *denc)
+                                                                   const unsigned long long *relu_mask, int n, float *deltas,
+                                                                   float *denc)
 {
     extern __shared__ float lds[];
     float *wfrag = lds;
@@ -342,15 +355,17 @@ __global__ __launch_bounds__(256, 2) void net_backward_mfma_kernel(NetLayout L, 
     __syncthreads();
     const int i = lane & 15, g = lane >> 4;
     const int n_tiles = (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
-    const int astride = ENC + NH * H, dstride = NOP + NH * H;
+    const int dstride = NOP + NH * H;
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         int pt[kMfmaSub];
         bool valid[kMfmaSub];
         float b[kMfmaSub][16];
+        unsigned long long mask[kMfmaSub];
 #pragma unroll
         for (int u = 0; u < kMfmaSub; ++u) {
             pt[u] = (tile * kMfmaSub + u) * 16 + i;
             valid[u] = pt[u] < n;
+            mask[u] = valid[u] ? relu_mask[(size_t)pt[u] * 4 + g] : 0ull;
 #pragma unroll
             for (int s = 0; s < NOP / 4; ++s) {
                 const int r = 4 * s + g;
@@ -371,8 +386,8 @@ __global__ __launch_bounds__(256, 2) void net_backward_mfma_kernel(NetLayout L, 
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int k = 16 * kt + 4 * c + g;
-                        const float h = valid[u] ? acts[(size_t)pt[u] * astride + ENC + (layer - 1) * H + k] : 0.0f;
-                        const float v = h > 0.0f ? acc[u][kt][c] : 0.0f;
+                        const bool on = (mask[u] >> ((layer - 1) * 16 + 4 * kt + c)) & 1ull;      // ReLU'
+                        const float v = on ? acc[u][kt][c] : 0.0f;
                         b[u][4 * kt + c] = v;
                         if (valid[u]) deltas[(size_t)pt[u] * dstride + NOP + (layer - 1) * H + k] = v;
                     }
@@ -663,6 +678,7 @@ struct wost_net {
     int step = 0;
     // scratch (grown on demand)
     float *d_xy = nullptr, *d_out = nullptr, *d_dl = nullptr, *d_acts = nullptr, *d_deltas = nullptr, *d_denc = nullptr;
+    unsigned long long *d_mask = nullptr;   // MFMA path: signs of the hidden activations, 4 words per point
     size_t cap_points = 0;
 };
 
@@ -701,10 +717,10 @@ static int launch_forward(wost_net *h, bool use_inference_params, const float *x
         const unsigned grid = (unsigned)std::min((n_tiles + 3) / 4, 512);
         if (acts_dev)
             hipLaunchKernelGGL((net_forward_mfma_kernel<32, 64, 3, 48, true>), dim3(grid), dim3(256), lds, stream, L, p, f, xy_dev,
-                               n, n_dev, out_dev, acts_dev);
+                               n, n_dev, out_dev, acts_dev, h->d_mask);
         else
             hipLaunchKernelGGL((net_forward_mfma_kernel<32, 64, 3, 48, false>), dim3(grid), dim3(256), lds, stream, L, p, f, xy_dev,
-                               n, n_dev, out_dev, acts_dev);
+                               n, n_dev, out_dev, acts_dev, (unsigned long long *)nullptr);
     } else {
         const float *t = use_inference_params ? h->inference_t : h->params_t;
         const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
@@ -728,6 +744,8 @@ static int ensure_points(wost_net *h, size_t n)
     NET_TRY(hipMalloc((void **)&h->d_acts, n * (size_t)(L.enc + L.n_hidden * L.n_neurons) * sizeof(float)));
     NET_TRY(hipMalloc((void **)&h->d_deltas, n * (size_t)(L.n_out_padded + L.n_hidden * L.n_neurons) * sizeof(float)));
     NET_TRY(hipMalloc((void **)&h->d_denc, n * (size_t)L.enc * sizeof(float)));
+    if (h->d_mask) { (void)hipFree(h->d_mask); h->d_mask = nullptr; }
+    NET_TRY(hipMalloc((void **)&h->d_mask, n * 4 * sizeof(unsigned long long)));
     h->cap_points = n;
     return WOST_OK;
 }
@@ -739,6 +757,7 @@ static void net_free(wost_net *h)
     for (float *p : {h->params, h->inference, h->params_t, h->inference_t, h->params_f, h->inference_f, h->params_fb, h->m1, h->m2, h->ema_raw, h->d_xy, h->d_out, h->d_dl, h->d_acts, h->d_deltas, h->d_denc})
         if (p) (void)hipFree(p);
     if (h->grad && h->grad_owned) (void)hipFree(h->grad);
+    if (h->d_mask) (void)hipFree(h->d_mask);
     delete h;
 }
 
@@ -774,7 +793,7 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
         const size_t lds = (size_t)L.n_mlp * sizeof(float);
         const int n_tiles = (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
         hipLaunchKernelGGL((net_backward_mfma_kernel<32, 64, 3, 48>), dim3((unsigned)std::min((n_tiles + 3) / 4, 512)), dim3(256), lds,
-                           stream, L, h->params_fb, h->d_dl, h->d_acts, n, h->d_deltas, h->d_denc);
+                           stream, L, h->params_fb, h->d_dl, h->d_mask, n, h->d_deltas, h->d_denc);
     } else {
         const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
         const unsigned gridp = (unsigned)((n + kNetBlock - 1) / kNetBlock);

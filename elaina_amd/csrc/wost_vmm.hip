@@ -78,6 +78,7 @@ __global__ void vmm_loss_gradients_kernel(const float *raw, const float *dir, co
         rx = wx - 2 * dd * nx;
         ry = wy - 2 * dd * ny;
     }
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
         lambda[k] = det_expf(fmaxf(fminf(d[4 * k], 15.0f), -10.0f));
         kap[k] = det_expf(fmaxf(fminf(d[4 * k + 1], 15.0f), -10.0f));
@@ -88,17 +89,22 @@ __global__ void vmm_loss_gradients_kernel(const float *raw, const float *dir, co
         muy[k] = oy[k] / nn;
         total += lambda[k];
     }
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
         pk[k] = vm_eval(kap[k], wx * mux[k] + wy * muy[k]);
         pkr[k] = on_n ? vm_eval(kap[k], rx * mux[k] + ry * muy[k]) : 0.0f;
     }
+    // the unscaled partial derivatives stay in registers; one pass over dL/draw at the end
+    float g_lambda[8], g_kappa[8], g_x[8], g_y[8];
     float probability = 0.0f;
+#pragma unroll
     for (int sg = 0; sg < 8; ++sg) {
         const float w = lambda[sg] / total;
         const float vm = pk[sg], vmr = pkr[sg];
         probability += w * vm;
         if (on_n) probability += w * vmr;
         float dF_dlambda = (vm + vmr) * (total - lambda[sg]) / (total * total);
+#pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (k == sg) continue;
             const float wk = lambda[k] / total;
@@ -114,21 +120,23 @@ __global__ void vmm_loss_gradients_kernel(const float *raw, const float *dir, co
         if (on_n) dF_dx += w * vmr * kap[sg] * oy[sg] * (-ox[sg] * ry + oy[sg] * rx) / denom;
         float dF_dy = w * vm * kap[sg] * ox[sg] * (ox[sg] * wy - oy[sg] * wx) / denom;
         if (on_n) dF_dy += w * vmr * kap[sg] * ox[sg] * (ox[sg] * ry - oy[sg] * rx) / denom;
-        grad[4 * sg + 0] = dF_dlambda;
-        grad[4 * sg + 1] = dF_dkappa;
-        grad[4 * sg + 2] = dF_dx;
-        grad[4 * sg + 3] = dF_dy;
+        g_lambda[sg] = dF_dlambda;
+        g_kappa[sg] = dF_dkappa;
+        g_x[sg] = dF_dx;
+        g_y[sg] = dF_dy;
     }
     const float Li = li[t];
     const float dirPdf = dir_pdf[t] + eps;
     const float guidePdf = probability + eps;
     const float prefix = -Li / dirPdf / guidePdf * scale;
     if (likelihood) likelihood[t] = -Li / dirPdf * det_logf(guidePdf);
+#pragma unroll
     for (int sg = 0; sg < 8; ++sg) {
-        grad[4 * sg + 0] = prefix * grad[4 * sg + 0] * det_expf(fmaxf(fminf(d[4 * sg], 15.0f), -10.0f));
-        grad[4 * sg + 1] = prefix * grad[4 * sg + 1] * det_expf(fmaxf(fminf(d[4 * sg + 1], 15.0f), -10.0f));
-        grad[4 * sg + 2] = prefix * grad[4 * sg + 2];
-        grad[4 * sg + 3] = prefix * grad[4 * sg + 3];
+        // d exp(clamp(x)) / dx as the reference takes it = exp(clamp(x)) = the lobe's own lambda / kappa
+        grad[4 * sg + 0] = prefix * g_lambda[sg] * lambda[sg];
+        grad[4 * sg + 1] = prefix * g_kappa[sg] * kap[sg];
+        grad[4 * sg + 2] = prefix * g_x[sg];
+        grad[4 * sg + 3] = prefix * g_y[sg];
     }
     const float uni = on_n ? (float)(1.0 / VM_PI_D) : 1.0f / VM_2PI;
     const float sgm = 1.0f / (1.0f + det_expf(-d[32]));
