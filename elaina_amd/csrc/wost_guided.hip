@@ -15,6 +15,9 @@
 //   sample_kernel    routing by the learned selection probability, mixture or uniform
 //                    direction with one-sample MIS, boundary intersection, throughput, training
 //                    record; in place -- the out-of-shell queue becomes the next depth's queue
+//   tail_kernel      from depth >= maxGuidedDepth on nothing needs the network: every remaining
+//                    walker runs to its end in registers, ONE launch per sample instead of two
+//                    per depth
 // Free choices of the reference that made it irreproducible are fixed: the training set is
 // ordered by (pixel, record) through a prefix sum instead of by atomics, so two runs -- and the
 // CPU restatement the tests compare against -- see the same batches.
