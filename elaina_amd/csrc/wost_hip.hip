@@ -983,8 +983,12 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         rp.trav_burst = c->trav_burst;
         rp.top_levels = std::min(c->top_levels, levels + 1);
         if (c->dm.view.n_segs == 0) rp.top_levels = 0;
-        rp.top_nodes = 0;
-        for (int l = 0, n = 1; l < rp.top_levels; ++l, n *= 4) rp.top_nodes += n;
+        // the LDS mirror of the tree top must not cost a resident block (160 KB of LDS per CU):
+        // on fille (one level deeper than ladybug) three mirrored levels dropped 6 blocks to 5
+        // and 5 % of the throughput, two do not
+        auto top_nodes_of = [](int tl) { int t = 0; for (int l = 0, n = 1; l < tl; ++l, n *= 4) t += n; return t; };
+        while (rp.top_levels > 0 && (160 * 1024) / (lds + (size_t)top_nodes_of(rp.top_levels) * 96) < (160 * 1024) / lds) --rp.top_levels;
+        rp.top_nodes = top_nodes_of(rp.top_levels);
         const size_t lds_round = lds + (size_t)rp.top_nodes * 96;
         unsigned grid = (n_active + bs - 1) / bs;
         // REFILL launch: as many resident threads as the chip holds, each draining the input queue.
