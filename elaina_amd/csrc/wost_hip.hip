@@ -1039,6 +1039,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
             float ms = 0.0f;
             HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
             kernel_ms += ms;
+            if (getenv("WOST_TRACE_LAUNCHES")) fprintf(stderr, "launch %d: walkers %d grid %u %.3f ms -> %u left\n", launches, n_active, grid, ms, c->host_count[0]);
         }
         ++launches;
         n_active = c->host_count[0];

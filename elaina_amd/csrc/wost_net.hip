@@ -176,6 +176,9 @@ __global__ __launch_bounds__(kNetBlock) void net_forward_kernel(NetLayout L, con
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kMfmaSub = 2;   // 16-point subtiles per wave iteration
+// staging rows of the encoded features are padded by two floats: the B-operand reads of a k-step
+// (16 points x 4 consecutive features) then fall into 32 different LDS banks per half wave
+constexpr int kStagePad = 2;
 
 // frag[w_off[layer] + (rt * S + s) * 64 + l] = W[16rt + 4((l&15)&3) + ((l&15)>>2)][4s + (l>>4)]
 __global__ void fragment_mlp_kernel(NetLayout L, const float *src, float *dst)
@@ -212,8 +215,9 @@ __device__ __forceinline__ void mfma_layer(const float *wf, int lane, const floa
     }
 }
 
-// ENC = encoded width, H = neurons, NH = hidden layers (the first takes ENC inputs), NOP = padded outputs
-template <int ENC, int H, int NH, int NOP, bool SAVE>
+// ENC = encoded width, H = neurons, NH = hidden layers (the first takes ENC inputs), NOP = padded outputs,
+// NF = features per grid level known at compile time (0: read from the layout)
+template <int ENC, int H, int NH, int NOP, bool SAVE, int NF>
 __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, const float *params, const float *frag,
                                                                   const float *xy, int n, const uint32_t *n_dev, float *out,
                                                                   float *acts, unsigned long long *relu_mask)
@@ -224,7 +228,8 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
     __shared__ uint32_t s_res[kNetMaxLevels], s_off[kNetMaxLevels + 1];
     float *wfrag = lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *stage = lds + L.n_mlp + wave * (kMfmaSub * 16 * ENC);
+    constexpr int SS = ENC + kStagePad;
+    float *stage = lds + L.n_mlp + wave * (kMfmaSub * 16 * SS);
     for (uint32_t e = threadIdx.x; e < L.n_mlp; e += 256) wfrag[e] = frag[e];
     if (threadIdx.x <= (unsigned)L.n_levels) {
         s_off[threadIdx.x] = L.level_off[threadIdx.x];
@@ -248,6 +253,46 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
             pt[u] = (tile * kMfmaSub + u) * 16 + i;
             valid[u] = pt[u] < n;
             const float x = valid[u] ? xy[2 * (size_t)pt[u]] : 0.5f, y = valid[u] ? xy[2 * (size_t)pt[u] + 1] : 0.5f;
+            if constexpr (NF == 4) {
+                // the reference's grid (4 features per level): one 16-byte gather per corner, all
+                // eight of a point's two levels in flight together; the wrap of the dense index
+                // is a compare-subtract except for points far outside the unit square
+                static_assert(ENC == 32, "8 levels x 4 features");
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int lv = g + 4 * h;
+                    const float sc = s_scale[lv];
+                    const uint32_t res = s_res[lv], lo = s_off[lv];
+                    const uint32_t n_level = s_off[lv + 1] - lo;
+                    float px = __builtin_fmaf(sc, x, 0.5f), py = __builtin_fmaf(sc, y, 0.5f);
+                    const float fx = floorf(px), fy = floorf(py);
+                    px -= fx;
+                    py -= fy;
+                    const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+                    float4 c[4];
+                    float w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
+                        w[k] = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
+                        uint32_t idx = cx + cy * res;
+                        if (idx >= n_level) {
+                            idx -= n_level;
+                            if (idx >= n_level) idx %= n_level;
+                        }
+                        c[k] = *reinterpret_cast<const float4 *>(grid + (size_t)(lo + idx) * 4);
+                    }
+                    float4 f = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        f.x += w[k] * c[k].x; f.y += w[k] * c[k].y; f.z += w[k] * c[k].z; f.w += w[k] * c[k].w;
+                    }
+                    float2 *st = reinterpret_cast<float2 *>(stage + (u * 16 + i) * SS + lv * 4);
+                    st[0] = float2{f.x, f.y};
+                    st[1] = float2{f.z, f.w};
+                    if (SAVE && valid[u]) *reinterpret_cast<float4 *>(acts + (size_t)pt[u] * astride + lv * 4) = f;
+                }
+            } else
             for (int lv = g; lv < L.n_levels; lv += 4) {
                 const float sc = s_scale[lv];
                 const uint32_t res = s_res[lv], lo = s_off[lv];
@@ -267,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
                     for (int q = 0; q < L.n_features; ++q) f[q] += w * gp[q];
                 }
                 for (int q = 0; q < L.n_features; ++q) {
-                    stage[(u * 16 + i) * ENC + lv * L.n_features + q] = f[q];
+                    stage[(u * 16 + i) * SS + lv * L.n_features + q] = f[q];
                     if (SAVE && valid[u]) acts[(size_t)pt[u] * astride + lv * L.n_features + q] = f[q];
                 }
             }
@@ -277,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
 #pragma unroll
         for (int u = 0; u < kMfmaSub; ++u)
 #pragma unroll
-            for (int s = 0; s < ENC / 4; ++s) b[u][s] = stage[(u * 16 + i) * ENC + 4 * s + g];
+            for (int s = 0; s < ENC / 4; ++s) b[u][s] = stage[(u * 16 + i) * SS + 4 * s + g];
         __threadfence_block();      // before the next iteration overwrites the staging area
         f32x4_t acc[kMfmaSub][4];
         // which hidden activations are positive, bit (layer * 16 + 4 rt + c) of this lane's word: the
@@ -530,8 +575,9 @@ __global__ __launch_bounds__(kNetBlock) void net_backward_kernel(NetLayout L, co
 // global atomic; a level too large for LDS is split by feature range [q0, q1).
 // Work item = (point, level): neighbouring lanes read consecutive float4s of d_enc and hit
 // different levels.  use_lds = 0 (a level too large for LDS) scatters straight to global memory.
-__global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float *xy, const float *denc, int n, int chunk,
-                                                        int lv0, int lv1, int q0, int q1, int use_lds, fx_t *grad)
+constexpr int kGridGradBlock = 1024;
+__global__ __launch_bounds__(kGridGradBlock) void grid_grad_kernel(NetLayout L, const float *xy, const float *denc, int n, int chunk,
+                                                                   int lv0, int lv1, int q0, int q1, int use_lds, fx_t *grad)
 {
     extern __shared__ fx_t acc[];
     __shared__ float s_scale[kNetMaxLevels];
@@ -546,14 +592,21 @@ __global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float
     const int nf = L.n_features, nq = q1 - q0;                          // features [q0, q1) of every entry
     const uint32_t base = L.level_off[lv0];                             // first entry of the group
     const int n_acc = use_lds ? (int)(L.level_off[lv1] - base) * nq : 0;
-    for (int e = threadIdx.x; e < n_acc; e += 256) acc[e] = 0;
+    for (int e = threadIdx.x; e < n_acc; e += kGridGradBlock) acc[e] = 0;
     __syncthreads();
     const int p0 = blockIdx.x * chunk, p1 = min(n, p0 + chunk);
     fx_t *gG = grad + L.n_mlp;
     const int n_lv = lv1 - lv0;
-    const int n_items = (p1 - p0) * n_lv;
-    for (int item = threadIdx.x; item < n_items; item += 256) {
-        const int p = p0 + item / n_lv, lv = lv0 + item % n_lv;
+    // The sums are integers, so the order of the additions is free: consecutive work items take
+    // points that lie chunk / 64 apart (chunk is a multiple of 64).  Neighbouring training points
+    // are neighbouring pixels and fall into the same grid cells; spread out, the lanes of a wave
+    // mostly hit different accumulators instead of queueing on one.
+    const int spread = chunk >> 6;
+    const int n_items = chunk * n_lv;
+    for (int item = threadIdx.x; item < n_items; item += kGridGradBlock) {
+        const int pi = item / n_lv, lv = lv0 + item % n_lv;
+        const int p = p0 + (pi & 63) * spread + (pi >> 6);
+        if (p >= p1) continue;
         const float s = s_scale[lv];
         const uint32_t res = s_res[lv], lo = s_off[lv], n_level = s_off[lv + 1] - lo;
         float px = __builtin_fmaf(s, xy[2 * p], 0.5f), py = __builtin_fmaf(s, xy[2 * p + 1], 0.5f);
@@ -565,7 +618,12 @@ __global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float
         for (int k = 0; k < 4; ++k) {
             const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
             const float w = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
-            const uint32_t entry = lo + (cx + cy * res) % n_level;
+            uint32_t idx = cx + cy * res;              // % n_level, a compare-subtract inside the unit square
+            if (idx >= n_level) {
+                idx -= n_level;
+                if (idx >= n_level) idx %= n_level;
+            }
+            const uint32_t entry = lo + idx;
             if (use_lds) {
                 for (int q = q0; q < q1; ++q) fx_add(&acc[(entry - base) * nq + (q - q0)], to_fx(w * d[q]));
             } else {
@@ -574,7 +632,7 @@ __global__ __launch_bounds__(256) void grid_grad_kernel(NetLayout L, const float
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < n_acc; e += 256) {
+    for (int e = threadIdx.x; e < n_acc; e += kGridGradBlock) {
         const fx_t v = acc[e];
         if (v != 0) fx_add(gG + (size_t)(base + e / nq) * nf + q0 + e % nq, v);
     }
@@ -712,15 +770,19 @@ static int launch_forward(wost_net *h, bool use_inference_params, const float *x
     const float *p = use_inference_params ? h->inference : h->params;
     if (h->use_mfma) {
         const float *f = use_inference_params ? h->inference_f : h->params_f;
-        const size_t lds = ((size_t)L.n_mlp + 4 * kMfmaSub * 16 * 32) * sizeof(float);
+        const size_t lds = ((size_t)L.n_mlp + 4 * kMfmaSub * 16 * (32 + kStagePad)) * sizeof(float);
         const int n_tiles = (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
         const unsigned grid = (unsigned)std::min((n_tiles + 3) / 4, 512);
-        if (acts_dev)
-            hipLaunchKernelGGL((net_forward_mfma_kernel<32, 64, 3, 48, true>), dim3(grid), dim3(256), lds, stream, L, p, f, xy_dev,
-                               n, n_dev, out_dev, acts_dev, h->d_mask);
-        else
-            hipLaunchKernelGGL((net_forward_mfma_kernel<32, 64, 3, 48, false>), dim3(grid), dim3(256), lds, stream, L, p, f, xy_dev,
-                               n, n_dev, out_dev, acts_dev, (unsigned long long *)nullptr);
+        unsigned long long *mask = acts_dev ? h->d_mask : nullptr;
+#define WOST_FWD(SAVE, NF)                                                                                              \
+    hipLaunchKernelGGL((net_forward_mfma_kernel<32, 64, 3, 48, SAVE, NF>), dim3(grid), dim3(256), lds, stream, L, p, f, xy_dev, n, \
+                       n_dev, out_dev, acts_dev, mask)
+        if (L.n_features == 4) {
+            if (acts_dev) WOST_FWD(true, 4); else WOST_FWD(false, 4);
+        } else {
+            if (acts_dev) WOST_FWD(true, 0); else WOST_FWD(false, 0);
+        }
+#undef WOST_FWD
     } else {
         const float *t = use_inference_params ? h->inference_t : h->params_t;
         const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
@@ -812,7 +874,7 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
             if (bytes > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(grid_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)big);
-            hipLaunchKernelGGL(grid_grad_kernel, dim3((unsigned)((n + gchunk - 1) / gchunk)), dim3(256), bytes, stream, L, xy_dev,
+            hipLaunchKernelGGL(grid_grad_kernel, dim3((unsigned)((n + gchunk - 1) / gchunk)), dim3(kGridGradBlock), bytes, stream, L, xy_dev,
                                h->d_denc, n, gchunk, lv0, lv1, q0, q1, use_lds, h->grad);
         };
         int lv = 0;

@@ -28,9 +28,12 @@ ap.add_argument("--backend", default=None)
 ap.add_argument("--shared-network", action="store_true", help="one network for all ranks (gradient all-reduce)")
 ap.add_argument("--batch", type=int, default=65536 * 8)
 ap.add_argument("--min-batch", type=int, default=65536)
+ap.add_argument("--one-shard-of", type=int, default=0,
+                help="single process: run only shard 0 of N (what ONE rank of an N-GPU job does, no reduce)")
 a = ap.parse_args()
 
 rank, world, local = D.init_process_group(a.backend)
+shard_world = a.one_shard_of if (a.one_shard_of > 1 and world == 1) else world
 device = local % max(torch.cuda.device_count(), 1)
 torch.cuda.set_device(device)
 prob = Problem.load_scene(a.scene)
@@ -48,7 +51,7 @@ if world > 1:
     dist.barrier()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-s = gi.solve_sharded(rank, world, field.data_ptr())
+s = gi.solve_sharded(rank, shard_world, field.data_ptr())
 D.reduce_field(field, world)
 torch.cuda.synchronize()
 elapsed = time.perf_counter() - t0
@@ -68,7 +71,7 @@ if rank == 0:
     print(json.dumps({
         "networks_identical": bool((pmin == pmax).all().item()), "shared_network": bool(a.shared_network and world > 1),
         "workload": "%s guided %dx%d %d spp (train %d) depth %d" % (a.scene, a.frame, a.frame, a.spp, a.train_spp, a.depth),
-        "n_gpus": world, "solve_s": float(mx[0]), "train_s": float(mx[1]), "create_s": t_create,
+        "n_gpus": world, "shard": "%d of %d" % (rank, shard_world), "solve_s": float(mx[0]), "train_s": float(mx[1]), "create_s": t_create,
         "walk_steps": int(tot[0]), "walk_steps_per_s": float(tot[0]) / float(mx[0]), "guided_steps": int(tot[1]),
         "train_samples": int(tot[2]), "optimizer_steps_all_ranks": int(tot[3]), "kernel_launches": s["kernel_launches"],
         "mean": float(field.mean().item()),
