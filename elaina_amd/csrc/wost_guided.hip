@@ -47,7 +47,11 @@ struct GQueue {
     int32_t *hint;     // slot of the closest Dirichlet segment of the previous step
 };
 
-struct GStatsDev {
+// Counters of a solve.  Atomics on ONE cache line are served one after the other by its L2 channel
+// (measured: about 120 M/s, 270 us for the 16 384 waves of one launch), so the counters exist in
+// kStatCopies copies 256 bytes apart, a wave adds to the copy of its block, and the host sums them.
+constexpr int kStatCopies = 64;
+struct alignas(256) GStatsDev {
     unsigned long long steps, started, absorbed, truncated, nhits, guided;
 };
 
@@ -84,7 +88,8 @@ struct GParams {
     float *rec;               // [slot][field][n_pixels]
     int32_t *hint0;           // per pixel: closest slot of the evaluation point
     float *net_in;            // [2 * slot]
-    const float *net_out;     // [33 * slot]
+    const float *net_out;     // [33][net_ld]: output o of queue slot s at net_out[o * net_ld + s]
+    size_t net_ld;
     GStatsDev *stats;
     int32_t n_pixels;
     int32_t depth;
@@ -140,6 +145,27 @@ __device__ __forceinline__ void wave_count(bool pred, unsigned long long *counte
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(counter, (unsigned long long)__popcll(bal));
 }
 
+// block-level compaction (256 threads, every thread of the block must call it): one atomic per
+// block on the queue counter instead of one per wave
+__device__ __forceinline__ uint32_t block_push(bool keep, uint32_t *counter)
+{
+    __shared__ uint32_t s_cnt[4], s_base;
+    const unsigned long long bal = __ballot(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_base;
+    for (int w = 0; w < wave; ++w) base += s_cnt[w];
+    return base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ GStatsDev *my_stats(GStatsDev *stats) { return stats + (blockIdx.x & (kStatCopies - 1)); }
+
 // ---- start of a sample: every unmasked pixel queues its evaluation point ---------------------
 // (reference prepareSolve :112-128 on the first sample, reset + generateEvaluationPoints
 // :131-150 on every sample)
@@ -163,8 +189,8 @@ __global__ __launch_bounds__(256) void begin_sample_kernel(GParams P)
         active = (tile % P.shard_count) == P.shard_index && (P.mask == nullptr || P.mask[p] != 0);
         if (active) eval_point(P.probe, p % P.st.width, p / P.st.width, P.st.width, P.st.height, x, y);
     }
-    const uint32_t s = wave_push(active, P.count_out);
-    wave_count(active, &P.stats->started);
+    const uint32_t s = block_push(active, P.count_out);
+    wave_count(active, &my_stats(P.stats)->started);
     if (active) {
         P.out.pid[s] = (uint32_t)p;
         P.out.x[s] = x; P.out.y[s] = y;
@@ -260,7 +286,7 @@ __global__ __launch_bounds__(256) void separate_kernel(GParams P)
     uint32_t pidf = kDead;
     if (i < n_in) pidf = P.in.pid[i];
     const bool live = pidf != kDead;
-    wave_count(live, &P.stats->steps);
+    wave_count(live, &my_stats(P.stats)->steps);
     int status = SEP_DROPPED;
     float x = 0, y = 0, thp = 0, nx = 0, ny = 0, R_B = 0;
     int32_t hint = 0;
@@ -274,8 +300,8 @@ __global__ __launch_bounds__(256) void separate_kernel(GParams P)
         P.rng[pid] = rng.state;
     }
     const bool keep = live && status == SEP_KEEP;
-    wave_count(live && status == SEP_ABSORBED, &P.stats->absorbed);
-    const uint32_t s = wave_push(keep, P.count_out);
+    wave_count(live && status == SEP_ABSORBED, &my_stats(P.stats)->absorbed);
+    const uint32_t s = block_push(keep, P.count_out);
     if (keep) {
         P.out.pid[s] = pidf;
         P.out.x[s] = x; P.out.y[s] = y; P.out.thp[s] = thp;
@@ -344,10 +370,11 @@ __global__ __launch_bounds__(256) void tail_kernel(GParams P)
     }
     const uint32_t s_steps = wave_sum(steps), s_abs = wave_sum(absorbed), s_tr = wave_sum(truncated), s_hit = wave_sum(hits);
     if ((threadIdx.x & 63) == 0) {
-        if (s_steps) atomicAdd(&P.stats->steps, (unsigned long long)s_steps);
-        if (s_abs) atomicAdd(&P.stats->absorbed, (unsigned long long)s_abs);
-        if (s_tr) atomicAdd(&P.stats->truncated, (unsigned long long)s_tr);
-        if (s_hit) atomicAdd(&P.stats->nhits, (unsigned long long)s_hit);
+        GStatsDev *st = my_stats(P.stats);
+        if (s_steps) atomicAdd(&st->steps, (unsigned long long)s_steps);
+        if (s_abs) atomicAdd(&st->absorbed, (unsigned long long)s_abs);
+        if (s_tr) atomicAdd(&st->truncated, (unsigned long long)s_tr);
+        if (s_hit) atomicAdd(&st->nhits, (unsigned long long)s_hit);
     }
 }
 
@@ -375,44 +402,54 @@ __global__ __launch_bounds__(256) void sample_kernel(GParams P)
         if (!P.guiding) {
             uniform_direction(on_n, nx, ny, rng, dirx, diry, pdf, alpha);
         } else {
-            const float *raw = P.net_out + 33 * (size_t)i;
-            const float sel = 1 / (1.f + det_expf(-raw[32]));                 // logistic (functors.h:182)
+            // raw output j of this walker (one array per output: neighbouring lanes, neighbouring words)
+            // all 33 loads are issued together, ahead of the branches of the arithmetic below
+            // (issued one by one between those branches they cost a memory round trip each:
+            // 74 % of the kernel's wave cycles were spent waiting)
+            const float *rp = P.net_out + i;
+            const size_t ld = P.net_ld;
+            Vmm::f32x8 r0, r1, r2, r3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                r0[j] = rp[j * ld]; r1[j] = rp[(8 + j) * ld]; r2[j] = rp[(16 + j) * ld]; r3[j] = rp[(24 + j) * ld];
+            }
+            const float raw32 = rp[32 * ld];
+            const auto raw = [&](int j) { return j < 8 ? r0[j & 7] : j < 16 ? r1[j & 7] : j < 24 ? r2[j & 7] : r3[j & 7]; };
+            const float sel = 1 / (1.f + det_expf(-raw32));                   // logistic (functors.h:182)
             const bool inside = aabb_contains(P.box, x, y);
             // the draw precedes the box test and is skipped for uniform fraction 0 (:518)
             bool to_guided = (P.uniform_fraction == 0.0f) || (pcg_next_float(rng) < sel);
             to_guided = to_guided && inside;
+            dropped = to_guided && !(P.uniform_fraction < 1.0f);              // kernel never launched (:1031)
+            // the mixture is needed by both branches inside the box: for the sample and its pdf,
+            // or for the MIS weight of a uniform sample
+            Vmm m;
+            const bool use_vmm = inside && !dropped;
+            if (use_vmm) m.build(raw);
+            float uniform_pdf = 0.0f;
             if (to_guided) {
-                if (!(P.uniform_fraction < 1.0f)) {
-                    dropped = true;                                       // kernel never launched (:1031)
-                } else {
-                    Vmm m;
-                    m.build(raw);
+                if (!dropped) {
                     m.sample(rng, dirx, diry);
-                    float guided_pdf = m.pdf(dirx, diry);
-                    float uniform_pdf = 1.0f / WOST_2PI;
-                    if (on_n) {
-                        uniform_pdf = (float)(1.0 / 3.14159265358979323846);
-                        alpha = 0.5f;
-                        const float dd = 2 * (dirx * nx + diry * ny);
-                        const float rx = dirx - dd * nx, ry = diry - dd * ny;
-                        if (nx * dirx + ny * diry <= 0) { dirx = rx; diry = ry; }
-                        guided_pdf += m.pdf(rx, ry);
-                    }
-                    pdf = sel * guided_pdf + (1.0f - sel) * uniform_pdf;
+                    uniform_pdf = on_n ? (float)(1.0 / 3.14159265358979323846) : 1.0f / WOST_2PI;
+                    alpha = on_n ? 0.5f : 1.0f;
                     guided_step = true;
                 }
             } else {
                 uniform_direction(on_n, nx, ny, rng, dirx, diry, pdf, alpha);
-                if (inside) {
-                    Vmm m;
-                    m.build(raw);
-                    float guided_pdf = m.pdf(dirx, diry);
-                    if (on_n) {
-                        const float dd = 2 * (dirx * nx + diry * ny);
-                        guided_pdf += m.pdf(dirx - dd * nx, diry - dd * ny);
-                    }
-                    pdf = sel * guided_pdf + (1.0f - sel) * pdf;
+                uniform_pdf = pdf;
+            }
+            if (use_vmm) {
+                // on a Neumann boundary the density of the mirrored direction is added; a guided
+                // sample pointing out of the domain is replaced by its mirror image afterwards
+                const float dd = 2 * (dirx * nx + diry * ny);
+                const float rx = dirx - dd * nx, ry = diry - dd * ny;
+                float guided_pdf, mirrored_pdf;
+                m.pdf_pair(dirx, diry, rx, ry, on_n, guided_pdf, mirrored_pdf);
+                if (on_n) {
+                    guided_pdf += mirrored_pdf;
+                    if (to_guided && nx * dirx + ny * diry <= 0) { dirx = rx; diry = ry; }
                 }
+                pdf = sel * guided_pdf + (1.0f - sel) * uniform_pdf;
             }
         }
         P.rng[pid] = rng.state;
@@ -429,9 +466,9 @@ __global__ __launch_bounds__(256) void sample_kernel(GParams P)
             alive_after = true;
         }
     }
-    wave_count(guided_step, &P.stats->guided);
-    wave_count(hit_n, &P.stats->nhits);
-    if (P.last_depth) wave_count(alive_after, &P.stats->truncated);
+    wave_count(guided_step, &my_stats(P.stats)->guided);
+    wave_count(hit_n, &my_stats(P.stats)->nhits);
+    if (P.last_depth) wave_count(alive_after, &my_stats(P.stats)->truncated);
 }
 
 // ---- training set: generate_training_data (reference train.h:423-471), ordered ----------------
@@ -663,7 +700,7 @@ int wost_guided_create(const wost_scene_desc *scene, const wost_guided_settings 
     }
     GA(g->counts, 2); GA(g->rng, N); GA(g->sol, 3 * N); GA(g->field, 3 * N);
     GA(g->rec, (size_t)kMaxTrainDepth * kRecFields * N);
-    GA(g->net_in, 2 * N); GA(g->net_out, 33 * N); GA(g->cur_depth, N); GA(g->hint0, N); GA(g->stats, 1);
+    GA(g->net_in, 2 * N); GA(g->net_out, 33 * N); GA(g->cur_depth, N); GA(g->hint0, N); GA(g->stats, kStatCopies);
     g->n_train_pixels = (int)((N - (size_t)s->train_pixel_offset + (size_t)s->train_pixel_stride - 1) / (size_t)s->train_pixel_stride);
     g->n_train_blocks = (g->n_train_pixels + 255) / 256;
     GA(g->block_sums, (size_t)g->n_train_blocks + 1);
@@ -771,11 +808,11 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     uint64_t train_samples = 0;
     const int opt_before = net_optimizer_steps(g->net);
 
-    G_TRY(hipMemsetAsync(g->stats, 0, sizeof(GStatsDev), stream));
+    G_TRY(hipMemsetAsync(g->stats, 0, kStatCopies * sizeof(GStatsDev), stream));
     GParams P{};
     P.dm = v.dm; P.nm = v.nm; P.st = v.st; P.probe = v.probe; P.src = v.src; P.box = g->box; P.mask = v.mask;
     P.rng = g->rng; P.sol = g->sol; P.cur_depth = g->cur_depth; P.rec = g->rec; P.hint0 = g->hint0;
-    P.net_in = g->net_in; P.net_out = g->net_out; P.stats = g->stats; P.n_pixels = N; P.stack_stride = 256;
+    P.net_in = g->net_in; P.net_out = g->net_out; P.net_ld = (size_t)N; P.stats = g->stats; P.n_pixels = N; P.stack_stride = 256;
     P.max_train_depth = s.max_train_depth;
     P.train_offset = (uint32_t)s.train_pixel_offset; P.train_stride = (uint32_t)s.train_pixel_stride;
     P.shard_index = shard_index; P.shard_count = shard_count;
@@ -838,7 +875,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
             const uint32_t n_out = g->host_counts[0];
             if (n_out == 0) break;
             if (P.guiding) {
-                int rc = net_inference_dev(g->net, g->net_in, nullptr, (int)n_out, g->net_out, true, stream);
+                int rc = net_inference_dev(g->net, g->net_in, nullptr, (int)n_out, g->net_out, true, stream, (size_t)N);
                 if (rc != WOST_OK) return rc;
                 ++launches;
             }
@@ -936,9 +973,14 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     G_TRY(hipGetLastError());
     if (field_host) G_TRY(hipMemcpyAsync(field_host, g->field, (size_t)N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
     if (field_dev) G_TRY(hipMemcpyAsync(field_dev, g->field, (size_t)N * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    GStatsDev hs{};
-    G_TRY(hipMemcpyAsync(&hs, g->stats, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    std::vector<GStatsDev> copies(kStatCopies);
+    G_TRY(hipMemcpyAsync(copies.data(), g->stats, kStatCopies * sizeof(GStatsDev), hipMemcpyDeviceToHost, stream));
     G_TRY(hipStreamSynchronize(stream));
+    GStatsDev hs{};
+    for (const GStatsDev &c : copies) {
+        hs.steps += c.steps; hs.started += c.started; hs.absorbed += c.absorbed;
+        hs.truncated += c.truncated; hs.nhits += c.nhits; hs.guided += c.guided;
+    }
     if (stats) {
         *stats = wost_guided_stats{};
         stats->walk_steps = hs.steps; stats->walks_started = hs.started; stats->walks_absorbed = hs.absorbed;

@@ -34,9 +34,10 @@ void launch_vmm_loss_gradients(hipStream_t stream, const float *raw, const float
                                float loss_scale, float *dl_draw, float *likelihood);
 
 // wost_net.hip: the network on device pointers.  count_dev (optional) overrides max_n with a
-// queue size that lives on the device; max_n only sizes the launch.
+// queue size that lives on the device; max_n only sizes the launch.  feature_stride = 0: outputs
+// as rows of n_output floats per point; > 0: output o of point p at out[o * feature_stride + p].
 int net_inference_dev(wost_net_handle h, const float *xy_dev, const uint32_t *count_dev, int max_n, float *out_dev,
-                      bool use_inference_params, hipStream_t stream);
+                      bool use_inference_params, hipStream_t stream, size_t feature_stride = 0);
 int net_forward_train_dev(wost_net_handle h, const float *xy_dev, int n, hipStream_t stream, float **out_dev,
                           float **dl_dev);
 int net_backward_update_dev(wost_net_handle h, const float *xy_dev, int n, float loss_scale, int apply_update,

@@ -132,7 +132,7 @@ __device__ __forceinline__ void dense_layer(const float *Wt, int n_out, int n_in
 // activations the backward pass needs.
 __global__ __launch_bounds__(kNetBlock) void net_forward_kernel(NetLayout L, const float *params, const float *wt,
                                                                 const float *xy, int n, const uint32_t *n_dev, float *out,
-                                                                float *acts)
+                                                                float *acts, size_t out_ldp, size_t out_ldf)
 {
     if (n_dev) n = (int)*n_dev;                              // queue size decided on the device
     if ((int)(blockIdx.x * kNetBlock) >= n) return;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kNetBlock) void net_forward_kernel(NetLayout L, con
     }
     dense_layer(wt + L.w_off[L.n_hidden], L.n_out_padded, n_in, in, o, false);
     if (valid)
-        for (int k = 0; k < L.n_out; ++k) out[(size_t)p * L.n_out + k] = act(o, k);
+        for (int k = 0; k < L.n_out; ++k) out[(size_t)p * out_ldp + k * out_ldf] = act(o, k);
 }
 
 // ---- MFMA forward -------------------------------------------------------------------------------
@@ -220,7 +220,8 @@ __device__ __forceinline__ void mfma_layer(const float *wf, int lane, const floa
 template <int ENC, int H, int NH, int NOP, bool SAVE, int NF>
 __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, const float *params, const float *frag,
                                                                   const float *xy, int n, const uint32_t *n_dev, float *out,
-                                                                  float *acts, unsigned long long *relu_mask)
+                                                                  float *acts, unsigned long long *relu_mask, size_t out_ldp,
+                                                                  size_t out_ldf)
 {
     static_assert(ENC % 4 == 0 && ENC <= 64 && H % 16 == 0 && H <= 64 && NOP % 16 == 0 && NOP <= 64, "shape");
     extern __shared__ float lds[];
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int o = 16 * rt + 4 * c + g;
-                    if (valid[u] && o < L.n_out) out[(size_t)pt[u] * L.n_out + o] = acc[u][rt][c];
+                    if (valid[u] && o < L.n_out) out[(size_t)pt[u] * out_ldp + o * out_ldf] = acc[u][rt][c];
                 }
     }
 }
@@ -763,10 +764,12 @@ static int refresh_transposed(wost_net *h, hipStream_t stream)
 // forward pass on device pointers: MFMA kernel for the reference's network shape, the scalar
 // kernel otherwise (or when WOST_NET_SCALAR=1 asks for the comparison path)
 static int launch_forward(wost_net *h, bool use_inference_params, const float *xy_dev, int n, const uint32_t *n_dev,
-                          float *out_dev, float *acts_dev, hipStream_t stream)
+                          float *out_dev, float *acts_dev, hipStream_t stream, size_t feature_stride = 0)
 {
     if (n <= 0) return WOST_OK;
     const NetLayout &L = h->L;
+    // outputs: point-major rows of n_out floats, or (feature_stride > 0) one array per output
+    const size_t ldp = feature_stride ? 1 : (size_t)L.n_out, ldf = feature_stride ? feature_stride : 1;
     const float *p = use_inference_params ? h->inference : h->params;
     if (h->use_mfma) {
         const float *f = use_inference_params ? h->inference_f : h->params_f;
@@ -776,7 +779,7 @@ static int launch_forward(wost_net *h, bool use_inference_params, const float *x
         unsigned long long *mask = acts_dev ? h->d_mask : nullptr;
 #define WOST_FWD(SAVE, NF)                                                                                              \
     hipLaunchKernelGGL((net_forward_mfma_kernel<32, 64, 3, 48, SAVE, NF>), dim3(grid), dim3(256), lds, stream, L, p, f, xy_dev, n, \
-                       n_dev, out_dev, acts_dev, mask)
+                       n_dev, out_dev, acts_dev, mask, ldp, ldf)
         if (L.n_features == 4) {
             if (acts_dev) WOST_FWD(true, 4); else WOST_FWD(false, 4);
         } else {
@@ -787,7 +790,7 @@ static int launch_forward(wost_net *h, bool use_inference_params, const float *x
         const float *t = use_inference_params ? h->inference_t : h->params_t;
         const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
         hipLaunchKernelGGL(net_forward_kernel, dim3((n + kNetBlock - 1) / kNetBlock), dim3(kNetBlock), lds, stream, L, p, t, xy_dev,
-                           n, n_dev, out_dev, acts_dev);
+                           n, n_dev, out_dev, acts_dev, ldp, ldf);
     }
     NET_TRY(hipGetLastError());
     return WOST_OK;
@@ -827,9 +830,9 @@ namespace wost {
 
 // ---- device-pointer entry points used by the guided integrator (wost_guided.hip) -----------
 int net_inference_dev(wost_net *h, const float *xy_dev, const uint32_t *count_dev, int max_n, float *out_dev,
-                      bool use_inference_params, hipStream_t stream)
+                      bool use_inference_params, hipStream_t stream, size_t feature_stride)
 {
-    return launch_forward(h, use_inference_params, xy_dev, max_n, count_dev, out_dev, nullptr, stream);
+    return launch_forward(h, use_inference_params, xy_dev, max_n, count_dev, out_dev, nullptr, stream, feature_stride);
 }
 
 // forward with the training parameters, keeping activations; *out_dev = raw outputs

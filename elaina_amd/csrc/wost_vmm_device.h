@@ -39,9 +39,9 @@ __device__ __forceinline__ float log_bessel(float x, int order)
     float small = eval_poly(y, VM_COEF_SMALL[order], 7);
     if (order == 1) small = fabsf(x) * small;
     small = det_logf(small);
+    if (x < 3.75f) return small;      // the asymptotic branch only where it is selected
     y = 3.75f / x;
-    const float large = x - 0.5f * det_logf(x) + det_logf(eval_poly(y, VM_COEF_LARGE[order], 9));
-    return (x < 3.75f) ? small : large;
+    return x - 0.5f * det_logf(x) + det_logf(eval_poly(y, VM_COEF_LARGE[order], 9));
 }
 
 __device__ __forceinline__ float vm_log_eval(float kappa, float cos_theta)
@@ -54,6 +54,14 @@ __device__ __forceinline__ float vm_eval(float kappa, float cos_theta)
 {
     if (kappa < 1e-3f) return 1.0f / VM_2PI;
     return det_expf(vm_log_eval(kappa, cos_theta));
+}
+
+// vm_eval with log I0(kappa) supplied by the caller (it depends on the lobe only)
+__device__ __forceinline__ float vm_eval_lb(float kappa, float lb, float cos_theta)
+{
+    if (kappa < 1e-3f) return 1.0f / VM_2PI;
+    const float ret = kappa * cos_theta;
+    return det_expf(ret - VM_LOG_2PI - lb);
 }
 
 __device__ __forceinline__ float vm_dlog_dkappa(float kappa, float cosTheta)
@@ -122,32 +130,55 @@ __device__ __forceinline__ float vm_rejection_sample(float kappa, double proposa
 
 // VMM<2,8>: lambda = exp(clamp(x,-10,15)), kappa likewise, mu = normalize(x,y), weights lambda/sum
 struct Vmm {
-    float weight[8], kap[8], mux[8], muy[8];
+    // register vectors (constant indices after unrolling), not arrays: the struct must not end up in scratch
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    f32x8 weight, kap, mux, muy;
+    f32x8 lb;       // log I0(kappa) of every lobe: pdf() is evaluated up to twice per build
 
-    __device__ __forceinline__ void build(const float *d)
+    // d(j) = raw network output j of this point
+    template <class F>
+    __device__ __forceinline__ void build(F d)
     {
-        float lambda[8];
+        f32x8 lambda;
         float total = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            lambda[k] = det_expf(fmaxf(fminf(d[4 * k], 15.0f), -10.0f));
-            kap[k] = det_expf(fmaxf(fminf(d[4 * k + 1], 15.0f), -10.0f));
-            const float x = d[4 * k + 2], y = d[4 * k + 3];
+            lambda[k] = det_expf(fmaxf(fminf(d(4 * k), 15.0f), -10.0f));
+            kap[k] = det_expf(fmaxf(fminf(d(4 * k + 1), 15.0f), -10.0f));
+            const float x = d(4 * k + 2), y = d(4 * k + 3);
             const float nn = sqrtf(x * x + y * y);
             mux[k] = x / nn;
             muy[k] = y / nn;
             total += lambda[k];
+            lb[k] = log_bessel(kap[k], 0);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) weight[k] = lambda[k] / total;
+    }
+
+    __device__ __forceinline__ void build(const float *d)
+    {
+        build([d](int j) { return d[j]; });
     }
 
     __device__ __forceinline__ float pdf(float wx, float wy) const
     {
         float val = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) val += weight[k] * vm_eval(kap[k], wx * mux[k] + wy * muy[k]);
+        for (int k = 0; k < 8; ++k) val += weight[k] * vm_eval_lb(kap[k], lb[k], wx * mux[k] + wy * muy[k]);
         return val;
+    }
+
+    // pdf(a) and, where `two` is set, pdf(b): one pass over the lobes
+    __device__ __forceinline__ void pdf_pair(float ax, float ay, float bx, float by, bool two, float &pa, float &pb) const
+    {
+        pa = 0.0f;
+        pb = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            pa += weight[k] * vm_eval_lb(kap[k], lb[k], ax * mux[k] + ay * muy[k]);
+            if (two) pb += weight[k] * vm_eval_lb(kap[k], lb[k], bx * mux[k] + by * muy[k]);
+        }
     }
 
     // VMM::sample (distribution.h:186-198): lobe picked by one float draw, then the lobe's
