@@ -25,6 +25,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <string>
 #include <vector>
@@ -206,16 +207,17 @@ __global__ __launch_bounds__(256) void begin_sample_kernel(GParams P)
 // boundary at all) or SEP_KEEP with R_B set and the Neumann / source terms added.
 enum { SEP_ABSORBED = 0, SEP_DROPPED = 1, SEP_KEEP = 2 };
 
+// everything of a step after the closest-point query on the Dirichlet boundary (`cp`, ignored when
+// that boundary is empty)
 template <bool EMISSIVE, bool TREE, bool SOURCE>
-__device__ __forceinline__ int separate_step(const GParams &P, uint32_t pid, bool on_n, float x, float y, float thp, float nx,
-                                             float ny, int depth, int32_t &hint, float &R_B, Pcg &rng, uint32_t *stack,
-                                             const LdsColumn &stk)
+__device__ __forceinline__ int separate_finish(const GParams &P, uint32_t pid, bool on_n, float x, float y, float thp, float nx,
+                                               float ny, int depth, Closest cp, int32_t &hint, float &R_B, Pcg &rng,
+                                               const LdsColumn &stk)
 {
     const bool train_px = is_training_pixel(P, pid);
     const float eps = P.st.eps;
     float R_D = WOST_INF;
     if (P.dm.n_segs > 0) {
-        const Closest cp = closest_point(P.dm, x, y, slot_candidate(P.dm, hint, x, y), stack, P.stack_stride);
         hint = cp.slot;
         if (depth == 0) P.hint0[pid] = cp.slot;
         const float4 a = P.dm.segA[cp.slot];
@@ -257,6 +259,16 @@ __device__ __forceinline__ int separate_step(const GParams &P, uint32_t pid, boo
         }
     }
     return SEP_KEEP;
+}
+
+template <bool EMISSIVE, bool TREE, bool SOURCE>
+__device__ __forceinline__ int separate_step(const GParams &P, uint32_t pid, bool on_n, float x, float y, float thp, float nx,
+                                             float ny, int depth, int32_t &hint, float &R_B, Pcg &rng, uint32_t *stack,
+                                             const LdsColumn &stk)
+{
+    Closest cp{WOST_INF, -1};
+    if (P.dm.n_segs > 0) cp = closest_point(P.dm, x, y, slot_candidate(P.dm, hint, x, y), stack, P.stack_stride);
+    return separate_finish<EMISSIVE, TREE, SOURCE>(P, pid, on_n, x, y, thp, nx, ny, depth, cp, hint, R_B, rng, stk);
 }
 
 // incrementDepth (reference guided.h:21-46): the vertex BEFORE the step becomes a training record

@@ -75,6 +75,7 @@ struct RoundParams {
     int32_t trav_burst;    // node visits per scheduling decision in the traversal phase
     int32_t top_levels;    // levels of the Dirichlet tree mirrored in LDS
     int32_t top_nodes;     // (4^top_levels - 1) / 3
+    int32_t lane_shift;    // one walker per 2^lane_shift lanes (0 = every lane)
     uint32_t *cursor;      // REFILL launches: next unread slot of the input queue
 };
 
@@ -287,9 +288,12 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
         __syncthreads();
     }
     uint32_t *stack = lds_stack + P.top_nodes * 24 + threadIdx.x;
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    // thin waves (lane_shift > 0, the last launches of a solve): only every 2^shift-th lane holds a
+    // walker, so a wave waits for the longest query of 64 >> shift walkers instead of 64
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = tid >> P.lane_shift;
     const uint32_t n_in = *P.count_in;
-    const bool valid = slot < n_in;
+    const bool valid = slot < n_in && (tid & ((1u << P.lane_shift) - 1u)) == 0u;
     Lane L;
     LaneStats S{0, 0, 0, 0};
     uint32_t pix = 0;
@@ -648,6 +652,7 @@ struct wost_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // options
     int steps_per_round = 0;   // 0 = automatic (see run_solve)
+    int thin_waves = 1;        // spread the walkers of an under-full launch over more waves
     int block_size = 256;
     int wait_weight = 8;
     int trav_burst = 3;
@@ -841,6 +846,8 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "refill") {
         if (value != -1 && value != 0 && value != 1) return fail(WOST_ERR_INVALID, "refill must be -1 (auto), 0 or 1");
         h->refill = (int)value;
+    } else if (k == "thin_waves") {
+        h->thin_waves = value != 0;
     } else if (k == "time_kernels") {
         h->time_kernels = value != 0;
     } else {
@@ -990,7 +997,17 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         while (rp.top_levels > 0 && (160 * 1024) / (lds + (size_t)top_nodes_of(rp.top_levels) * 96) < (160 * 1024) / lds) --rp.top_levels;
         rp.top_nodes = top_nodes_of(rp.top_levels);
         const size_t lds_round = lds + (size_t)rp.top_nodes * 96;
-        unsigned grid = (n_active + bs - 1) / bs;
+        // When the walkers left fill less than 1/16 of the resident threads, spread them out: the
+        // duration of such a launch is the latency of its slowest wave, and a wave is as slow as the
+        // longest query among its walkers (config 2's last three launches: 13.1 -> 8.9 ms; with 2 or
+        // 4 lanes per walker the extra waves cost more than they save: 9.2 -> 11.8 ms).
+        const unsigned resident_threads = (unsigned)(c->n_cus * (ntree ? 4 : 6) * 4 * 64);
+        rp.lane_shift = 0;
+        if (c->thin_waves) {
+            while (rp.lane_shift < 6 && ((uint64_t)n_active << (rp.lane_shift + 1)) <= resident_threads) ++rp.lane_shift;
+            if (rp.lane_shift < 4) rp.lane_shift = 0;
+        }
+        unsigned grid = (unsigned)((((uint64_t)n_active << rp.lane_shift) + bs - 1) / bs);
         // REFILL launch: as many resident threads as the chip holds, each draining the input queue.
         // Worth it when regeneration cannot keep the lanes busy (measured on config 2's frame:
         // 1 spp 3.5 -> 3.0 ms, 4 spp 8.3 -> 7.9 ms, 8 spp 13.0 -> 13.5 ms) and the queue is larger
@@ -1000,7 +1017,8 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         const bool can_refill = (int64_t)c->settings.spp * c->settings.max_depth < 65535 && launches == 0 && !has_src;
         const bool refill = can_refill && (c->refill == 1 || (c->refill == -1 && c->settings.spp <= 4 && grid > resident));
         if (refill) {
-            grid = std::min(grid, resident);
+            rp.lane_shift = 0;
+            grid = std::min((unsigned)((n_active + bs - 1) / bs), resident);
             c->host_count[1] = grid * (unsigned)bs;      // first unread slot (pinned staging word)
             HIP_TRY(hipMemcpyAsync(c->cursor, c->host_count + 1, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             rp.cursor = c->cursor;

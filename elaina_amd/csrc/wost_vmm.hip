@@ -68,6 +68,11 @@ __global__ void vmm_loss_gradients_kernel(const float *raw, const float *dir, co
     const float *d = raw + 33 * (size_t)t;
     float *grad = dl_draw + 33 * (size_t)t;
     float lambda[8], kap[8], mux[8], muy[8], ox[8], oy[8], pk[8], pkr[8];
+    // all raw outputs first: between the branches of the arithmetic below every load would cost
+    // its own memory round trip
+    float rawv[33];
+#pragma unroll
+    for (int j = 0; j < 33; ++j) rawv[j] = d[j];
     float total = 0.0f;
     const float wx = dir[2 * t], wy = dir[2 * t + 1];
     const bool on_n = on_neumann && on_neumann[t] != 0;
@@ -80,10 +85,10 @@ __global__ void vmm_loss_gradients_kernel(const float *raw, const float *dir, co
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        lambda[k] = det_expf(fmaxf(fminf(d[4 * k], 15.0f), -10.0f));
-        kap[k] = det_expf(fmaxf(fminf(d[4 * k + 1], 15.0f), -10.0f));
-        ox[k] = d[4 * k + 2];
-        oy[k] = d[4 * k + 3];
+        lambda[k] = det_expf(fmaxf(fminf(rawv[4 * k], 15.0f), -10.0f));
+        kap[k] = det_expf(fmaxf(fminf(rawv[4 * k + 1], 15.0f), -10.0f));
+        ox[k] = rawv[4 * k + 2];
+        oy[k] = rawv[4 * k + 3];
         const float nn = sqrtf(ox[k] * ox[k] + oy[k] * oy[k]);
         mux[k] = ox[k] / nn;
         muy[k] = oy[k] / nn;
@@ -91,8 +96,9 @@ __global__ void vmm_loss_gradients_kernel(const float *raw, const float *dir, co
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        pk[k] = vm_eval(kap[k], wx * mux[k] + wy * muy[k]);
-        pkr[k] = on_n ? vm_eval(kap[k], rx * mux[k] + ry * muy[k]) : 0.0f;
+        const float lb = log_bessel(kap[k], 0);       // shared by the direction and its mirror image
+        pk[k] = vm_eval_lb(kap[k], lb, wx * mux[k] + wy * muy[k]);
+        pkr[k] = on_n ? vm_eval_lb(kap[k], lb, rx * mux[k] + ry * muy[k]) : 0.0f;
     }
     // the unscaled partial derivatives stay in registers; one pass over dL/draw at the end
     float g_lambda[8], g_kappa[8], g_x[8], g_y[8];
@@ -139,7 +145,7 @@ __global__ void vmm_loss_gradients_kernel(const float *raw, const float *dir, co
         grad[4 * sg + 3] = prefix * g_y[sg];
     }
     const float uni = on_n ? (float)(1.0 / VM_PI_D) : 1.0f / VM_2PI;
-    const float sgm = 1.0f / (1.0f + det_expf(-d[32]));
+    const float sgm = 1.0f / (1.0f + det_expf(-rawv[32]));
     grad[32] = scale * (-0.2f) * Li * (guidePdf - uni) / (dirPdf * dirPdf) * (sgm * (1 - sgm));
 }
 
