@@ -180,6 +180,19 @@ constexpr int kMfmaSub = 2;   // 16-point subtiles per wave iteration
 // (16 points x 4 consecutive features) then fall into 32 different LDS banks per half wave
 constexpr int kStagePad = 2;
 
+// Training layout of the saved activations and deltas (MFMA path).  The weight-gradient kernel
+// contracts over points: chain w of a 1024-point chunk takes the 4-point groups w, w+4, w+8, ..
+// (net.c of the CPU restatement follows the same order).  A 16-column unit of the forward and
+// backward kernels therefore holds the four groups w, w+4, w+8, w+12 of one 64-point span, column
+// 4g+m being point 16m + 4w + g of the span, and the unit's values are stored feature-major,
+// [unit][feature][16 columns]: the forward / backward kernels write 256 contiguous bytes per
+// store, and lane (feature i, k-slot g) of the weight-gradient kernel reads its operands of four
+// consecutive MFMAs (columns 4g .. 4g+3 = slot g of the groups m = 0..3) as ONE 16-byte load.
+__device__ __forceinline__ int train_point(int unit, int column)
+{
+    return 64 * (unit >> 2) + 16 * (column & 3) + 4 * (unit & 3) + (column >> 2);
+}
+
 // frag[w_off[layer] + (rt * S + s) * 64 + l] = W[16rt + 4((l&15)&3) + ((l&15)>>2)][4s + (l>>4)]
 __global__ void fragment_mlp_kernel(NetLayout L, const float *src, float *dst)
 {
@@ -242,17 +255,21 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
     __syncthreads();
     if (n_dev) n = (int)*n_dev;
     const int i = lane & 15, g = lane >> 4;
-    const int n_tiles = (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
+    // 16-column units: consecutive points for inference, the training layout when activations are kept
+    const int n_tiles = SAVE ? (n + 63) / 64 * 4 / kMfmaSub : (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
     const float *grid = params + L.n_mlp;
     const int astride = ENC + NH * H;
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         int pt[kMfmaSub];
         bool valid[kMfmaSub];
+        float *arow[kMfmaSub];      // SAVE: this lane's column of the unit's activation block
         // ---- encoding: lane (i, g) interpolates the levels lv = g, g + 4, ... of its point
 #pragma unroll
         for (int u = 0; u < kMfmaSub; ++u) {
-            pt[u] = (tile * kMfmaSub + u) * 16 + i;
+            const int unit = tile * kMfmaSub + u;
+            pt[u] = SAVE ? train_point(unit, i) : unit * 16 + i;
             valid[u] = pt[u] < n;
+            arow[u] = SAVE ? acts + (size_t)unit * 16 * astride + i : nullptr;
             const float x = valid[u] ? xy[2 * (size_t)pt[u]] : 0.5f, y = valid[u] ? xy[2 * (size_t)pt[u] + 1] : 0.5f;
             if constexpr (NF == 4) {
                 // the reference's grid (4 features per level): one 16-byte gather per corner, all
@@ -291,7 +308,10 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
                     float2 *st = reinterpret_cast<float2 *>(stage + (u * 16 + i) * SS + lv * 4);
                     st[0] = float2{f.x, f.y};
                     st[1] = float2{f.z, f.w};
-                    if (SAVE && valid[u]) *reinterpret_cast<float4 *>(acts + (size_t)pt[u] * astride + lv * 4) = f;
+                    if (SAVE && valid[u]) {
+                        arow[u][(lv * 4 + 0) * 16] = f.x; arow[u][(lv * 4 + 1) * 16] = f.y;
+                        arow[u][(lv * 4 + 2) * 16] = f.z; arow[u][(lv * 4 + 3) * 16] = f.w;
+                    }
                 }
             } else
             for (int lv = g; lv < L.n_levels; lv += 4) {
@@ -314,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
                 }
                 for (int q = 0; q < L.n_features; ++q) {
                     stage[(u * 16 + i) * SS + lv * L.n_features + q] = f[q];
-                    if (SAVE && valid[u]) acts[(size_t)pt[u] * astride + lv * L.n_features + q] = f[q];
+                    if (SAVE && valid[u]) arow[u][(lv * L.n_features + q) * 16] = f[q];
                 }
             }
         }
@@ -346,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
                         const float v = fmaxf(acc[u][rt][c], 0.0f);
                         b[u][4 * rt + c] = v;
                         if (SAVE) mask[u] |= (unsigned long long)(v > 0.0f) << (layer * 16 + 4 * rt + c);
-                        if (SAVE && valid[u]) acts[(size_t)pt[u] * astride + ENC + layer * H + 16 * rt + 4 * c + g] = v;
+                        if (SAVE && valid[u]) arow[u][(ENC + layer * H + 16 * rt + 4 * c + g) * 16] = v;
                     }
         }
         if (SAVE) {
@@ -400,24 +420,27 @@ __global__ __launch_bounds__(256, 2) void net_backward_mfma_kernel(NetLayout L, 
     for (uint32_t e = threadIdx.x; e < L.n_mlp; e += 256) wfrag[e] = fragb[e];
     __syncthreads();
     const int i = lane & 15, g = lane >> 4;
-    const int n_tiles = (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
+    const int n_tiles = (n + 63) / 64 * 4 / kMfmaSub;      // 16-column units of the training layout
     const int dstride = NOP + NH * H;
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         int pt[kMfmaSub];
         bool valid[kMfmaSub];
         float b[kMfmaSub][16];
         unsigned long long mask[kMfmaSub];
+        float *drow[kMfmaSub];      // this lane's column of the unit's delta block
 #pragma unroll
         for (int u = 0; u < kMfmaSub; ++u) {
-            pt[u] = (tile * kMfmaSub + u) * 16 + i;
+            const int unit = tile * kMfmaSub + u;
+            pt[u] = train_point(unit, i);
             valid[u] = pt[u] < n;
+            drow[u] = deltas + (size_t)unit * 16 * dstride + i;
             mask[u] = valid[u] ? relu_mask[(size_t)pt[u] * 4 + g] : 0ull;
 #pragma unroll
             for (int s = 0; s < NOP / 4; ++s) {
                 const int r = 4 * s + g;
                 const float v = (valid[u] && r < L.n_out) ? dl_dout[(size_t)pt[u] * L.n_out + r] : 0.0f;
                 b[u][s] = v;
-                if (valid[u]) deltas[(size_t)pt[u] * dstride + r] = v;
+                if (valid[u]) drow[u][r * 16] = v;
             }
         }
         f32x4_t acc[kMfmaSub][4];
@@ -435,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void net_backward_mfma_kernel(NetLayout L, 
                         const bool on = (mask[u] >> ((layer - 1) * 16 + 4 * kt + c)) & 1ull;      // ReLU'
                         const float v = on ? acc[u][kt][c] : 0.0f;
                         b[u][4 * kt + c] = v;
-                        if (valid[u]) deltas[(size_t)pt[u] * dstride + NOP + (layer - 1) * H + k] = v;
+                        if (valid[u]) drow[u][(NOP + (layer - 1) * H + k) * 16] = v;
                     }
         }
         mfma_layer<H / 4, ENC / 16>(wfrag + L.w_off[0], lane, b, acc);
@@ -470,19 +493,41 @@ __global__ __launch_bounds__(256) void weight_grad_mfma_kernel(const float *delt
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) acc[rt][kt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int p = p0 + 4 * wave; p < p1; p += 16) {
-        const bool ok = p + g < p1;
-        const float *dp = delta + (size_t)(p + g) * dstride + doff + i;
-        const float *ip = input + (size_t)(p + g) * istride + ioff + i;
-        float a[RT], b[KT];
+    // wave w = chain w: per 64-point span one 16-column unit, i.e. the groups w, w+4, w+8, w+12
+    for (int span = p0 / 64; span * 64 < p1; ++span) {
+        const int unit = span * 4 + wave;
+        const float *dp = delta + (size_t)unit * 16 * dstride + (size_t)(doff + i) * 16 + 4 * g;
+        const float *ip = input + (size_t)unit * 16 * istride + (size_t)(ioff + i) * 16 + 4 * g;
+        float4 a[RT], b[KT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) a[rt] = ok ? dp[16 * rt] : 0.0f;
+        for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const float4 *>(dp + 16 * 16 * rt);
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) b[kt] = ok ? ip[16 * kt] : 0.0f;
+        for (int kt = 0; kt < KT; ++kt) b[kt] = *reinterpret_cast<const float4 *>(ip + 16 * 16 * kt);
+        // columns of points past the end were never written
+        const int pbase = 64 * span + 4 * wave + g;
+        const bool ok0 = pbase < p1, ok1 = pbase + 16 < p1, ok2 = pbase + 32 < p1, ok3 = pbase + 48 < p1;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT; ++rt) {
+            a[rt].x = ok0 ? a[rt].x : 0.0f; a[rt].y = ok1 ? a[rt].y : 0.0f;
+            a[rt].z = ok2 ? a[rt].z : 0.0f; a[rt].w = ok3 ? a[rt].w : 0.0f;
+        }
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) acc[rt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], b[kt], acc[rt][kt], 0, 0, 0);
+        for (int kt = 0; kt < KT; ++kt) {
+            b[kt].x = ok0 ? b[kt].x : 0.0f; b[kt].y = ok1 ? b[kt].y : 0.0f;
+            b[kt].z = ok2 ? b[kt].z : 0.0f; b[kt].w = ok3 ? b[kt].w : 0.0f;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (pbase - g + 16 * m >= p1) break;       // wave-uniform: no group left in this span
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const float av = m == 0 ? a[rt].x : m == 1 ? a[rt].y : m == 2 ? a[rt].z : a[rt].w;
+                    const float bv = m == 0 ? b[kt].x : m == 1 ? b[kt].y : m == 2 ? b[kt].z : b[kt].w;
+                    acc[rt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[rt][kt], 0, 0, 0);
+                }
+        }
     }
     if (wave > 0) {
 #pragma unroll
@@ -806,8 +851,9 @@ static int ensure_points(wost_net *h, size_t n)
     NET_TRY(hipMalloc((void **)&h->d_xy, n * 2 * sizeof(float)));
     NET_TRY(hipMalloc((void **)&h->d_out, n * L.n_out * sizeof(float)));
     NET_TRY(hipMalloc((void **)&h->d_dl, n * L.n_out * sizeof(float)));
-    NET_TRY(hipMalloc((void **)&h->d_acts, n * (size_t)(L.enc + L.n_hidden * L.n_neurons) * sizeof(float)));
-    NET_TRY(hipMalloc((void **)&h->d_deltas, n * (size_t)(L.n_out_padded + L.n_hidden * L.n_neurons) * sizeof(float)));
+    const size_t n64 = (n + 63) / 64 * 64;     // the MFMA training layout works in whole 64-point spans
+    NET_TRY(hipMalloc((void **)&h->d_acts, n64 * (size_t)(L.enc + L.n_hidden * L.n_neurons) * sizeof(float)));
+    NET_TRY(hipMalloc((void **)&h->d_deltas, n64 * (size_t)(L.n_out_padded + L.n_hidden * L.n_neurons) * sizeof(float)));
     NET_TRY(hipMalloc((void **)&h->d_denc, n * (size_t)L.enc * sizeof(float)));
     if (h->d_mask) { (void)hipFree(h->d_mask); h->d_mask = nullptr; }
     NET_TRY(hipMalloc((void **)&h->d_mask, n * 4 * sizeof(unsigned long long)));
