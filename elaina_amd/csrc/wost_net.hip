@@ -39,7 +39,15 @@ constexpr int kNetBlock = 64;
 // reproducible bit for bit, on this device and against the CPU restatement.
 typedef long long fx_t;
 constexpr double kFxScale = 68719476736.0;   // 2^36
-__device__ __forceinline__ fx_t to_fx(float v) { return __double2ll_rn((double)v * kFxScale); }
+// round-to-nearest-even of v * 2^36.  The product is exact in fp32 (a power of two), so below 2^31
+// the fp32 rounding instruction gives the same integer as the fp64 expression, which stays as
+// the path for larger values (and NaN / infinity).
+__device__ __forceinline__ fx_t to_fx(float v)
+{
+    const float f = v * 68719476736.0f;
+    if (fabsf(f) < 2147483648.0f) return (fx_t)(int)__builtin_rintf(f);
+    return __double2ll_rn((double)v * kFxScale);
+}
 __device__ __forceinline__ void fx_add(fx_t *p, fx_t v)
 {
     atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);
@@ -660,20 +668,39 @@ __global__ __launch_bounds__(kGridGradBlock) void grid_grad_kernel(NetLayout L, 
         px -= fx;
         py -= fy;
         const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+        // the point's gradient values first: loaded inside the corner loop, each load would wait
+        // for the atomics before it (they may alias) -- 16 dependent memory round trips per item
         const float *d = denc + (size_t)p * L.enc + lv * nf;
+        float dv[8];
+        if (nf == 4) {
+            const float4 d4 = *reinterpret_cast<const float4 *>(d);
+            dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
+            dv[4] = dv[5] = dv[6] = dv[7] = 0.0f;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dv[q] = q < nf ? d[q] : 0.0f;
+        }
+        uint32_t entry[4];
+        float w[4];
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
-            const float w = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
+            w[k] = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
             uint32_t idx = cx + cy * res;              // % n_level, a compare-subtract inside the unit square
             if (idx >= n_level) {
                 idx -= n_level;
                 if (idx >= n_level) idx %= n_level;
             }
-            const uint32_t entry = lo + idx;
-            if (use_lds) {
-                for (int q = q0; q < q1; ++q) fx_add(&acc[(entry - base) * nq + (q - q0)], to_fx(w * d[q]));
-            } else {
-                for (int q = q0; q < q1; ++q) fx_add(gG + (size_t)entry * nf + q, to_fx(w * d[q]));
+            entry[k] = lo + idx;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q < q0 || q >= q1) continue;
+                const fx_t v = to_fx(w[k] * dv[q]);
+                if (use_lds) fx_add(&acc[(entry[k] - base) * nq + (q - q0)], v);
+                else fx_add(gG + (size_t)entry[k] * nf + q, v);
             }
         }
     }
