@@ -187,6 +187,7 @@ constexpr int kMfmaSub = 2;   // 16-point subtiles per wave iteration
 // staging rows of the encoded features are padded by two floats: the B-operand reads of a k-step
 // (16 points x 4 consecutive features) then fall into 32 different LDS banks per half wave
 constexpr int kStagePad = 2;
+constexpr int kFwdThreads = 1024, kFwdTrainThreads = 256, kBwdThreads = 1024;   // block sizes of the MFMA kernels
 
 // Training layout of the saved activations and deltas (MFMA path).  The weight-gradient kernel
 // contracts over points: chain w of a 1024-point chunk takes the 4-point groups w, w+4, w+8, ..
@@ -238,8 +239,8 @@ __device__ __forceinline__ void mfma_layer(const float *wf, int lane, const floa
 
 // ENC = encoded width, H = neurons, NH = hidden layers (the first takes ENC inputs), NOP = padded outputs,
 // NF = features per grid level known at compile time (0: read from the layout)
-template <int ENC, int H, int NH, int NOP, bool SAVE, int NF>
-__global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, const float *params, const float *frag,
+template <int ENC, int H, int NH, int NOP, bool SAVE, int NF, int NT>
+__global__ __launch_bounds__(NT) void net_forward_mfma_kernel(NetLayout L, const float *params, const float *frag,
                                                                   const float *xy, int n, const uint32_t *n_dev, float *out,
                                                                   float *acts, unsigned long long *relu_mask, size_t out_ldp,
                                                                   size_t out_ldf)
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int SS = ENC + kStagePad;
     float *stage = lds + L.n_mlp + wave * (kMfmaSub * 16 * SS);
-    for (uint32_t e = threadIdx.x; e < L.n_mlp; e += 256) wfrag[e] = frag[e];
+    for (uint32_t e = threadIdx.x; e < L.n_mlp; e += NT) wfrag[e] = frag[e];
     if (threadIdx.x <= (unsigned)L.n_levels) {
         s_off[threadIdx.x] = L.level_off[threadIdx.x];
         if (threadIdx.x < (unsigned)L.n_levels) {
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void net_forward_mfma_kernel(NetLayout L, c
     const int n_tiles = SAVE ? (n + 63) / 64 * 4 / kMfmaSub : (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
     const float *grid = params + L.n_mlp;
     const int astride = ENC + NH * H;
-    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+    for (int tile = blockIdx.x * (NT / 64) + wave; tile < n_tiles; tile += gridDim.x * (NT / 64)) {
         int pt[kMfmaSub];
         bool valid[kMfmaSub];
         float *arow[kMfmaSub];      // SAVE: this lane's column of the unit's activation block
@@ -417,20 +418,20 @@ __global__ void fragment_mlp_t_kernel(NetLayout L, const float *src, float *dst)
     dst[e] = src[L.w_off[layer] + r * n_i + k];
 }
 
-template <int ENC, int H, int NH, int NOP>
-__global__ __launch_bounds__(256, 2) void net_backward_mfma_kernel(NetLayout L, const float *fragb, const float *dl_dout,
+template <int ENC, int H, int NH, int NOP, int NT>
+__global__ __launch_bounds__(NT) void net_backward_mfma_kernel(NetLayout L, const float *fragb, const float *dl_dout,
                                                                    const unsigned long long *relu_mask, int n, float *deltas,
                                                                    float *denc)
 {
     extern __shared__ float lds[];
     float *wfrag = lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t e = threadIdx.x; e < L.n_mlp; e += 256) wfrag[e] = fragb[e];
+    for (uint32_t e = threadIdx.x; e < L.n_mlp; e += NT) wfrag[e] = fragb[e];
     __syncthreads();
     const int i = lane & 15, g = lane >> 4;
     const int n_tiles = (n + 63) / 64 * 4 / kMfmaSub;      // 16-column units of the training layout
     const int dstride = NOP + NH * H;
-    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+    for (int tile = blockIdx.x * (NT / 64) + wave; tile < n_tiles; tile += gridDim.x * (NT / 64)) {
         int pt[kMfmaSub];
         bool valid[kMfmaSub];
         float b[kMfmaSub][16];
@@ -446,10 +447,16 @@ __global__ __launch_bounds__(256, 2) void net_backward_mfma_kernel(NetLayout L, 
 #pragma unroll
             for (int s = 0; s < NOP / 4; ++s) {
                 const int r = 4 * s + g;
-                const float v = (valid[u] && r < L.n_out) ? dl_dout[(size_t)pt[u] * L.n_out + r] : 0.0f;
-                b[u][s] = v;
-                if (valid[u]) drow[u][r * 16] = v;
+                b[u][s] = (valid[u] && r < L.n_out) ? dl_dout[(size_t)pt[u] * L.n_out + r] : 0.0f;
             }
+        }
+        // stores only after every load of the tile has been issued (a load cannot move above a
+        // store it might alias: interleaved, each of the 24 loads was its own memory round trip)
+#pragma unroll
+        for (int u = 0; u < kMfmaSub; ++u) {
+#pragma unroll
+            for (int s = 0; s < NOP / 4; ++s)
+                if (valid[u]) drow[u][(4 * s + g) * 16] = b[u][s];
         }
         f32x4_t acc[kMfmaSub][4];
 #pragma unroll
@@ -845,17 +852,23 @@ static int launch_forward(wost_net *h, bool use_inference_params, const float *x
     const float *p = use_inference_params ? h->inference : h->params;
     if (h->use_mfma) {
         const float *f = use_inference_params ? h->inference_f : h->params_f;
-        const size_t lds = ((size_t)L.n_mlp + 4 * kMfmaSub * 16 * (32 + kStagePad)) * sizeof(float);
+        // inference: one block of 16 waves per CU shares one copy of the weight fragments (53 KB,
+        // 120 registers); with the activations kept the kernel needs 168 registers: two blocks of 4 waves
+        const int nt = acts_dev ? kFwdTrainThreads : kFwdThreads;
+        const size_t lds = ((size_t)L.n_mlp + (nt / 64) * kMfmaSub * 16 * (32 + kStagePad)) * sizeof(float);
         const int n_tiles = (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
-        const unsigned grid = (unsigned)std::min((n_tiles + 3) / 4, 512);
+        const unsigned grid = (unsigned)std::min((n_tiles + nt / 64 - 1) / (nt / 64), nt >= 512 ? 256 : 512);
         unsigned long long *mask = acts_dev ? h->d_mask : nullptr;
-#define WOST_FWD(SAVE, NF)                                                                                              \
-    hipLaunchKernelGGL((net_forward_mfma_kernel<32, 64, 3, 48, SAVE, NF>), dim3(grid), dim3(256), lds, stream, L, p, f, xy_dev, n, \
-                       n_dev, out_dev, acts_dev, mask, ldp, ldf)
+#define WOST_FWD(SAVE, NF, NT)                                                                                          \
+    do {                                                                                                                \
+        auto kfn = net_forward_mfma_kernel<32, 64, 3, 48, SAVE, NF, NT>;                                                \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NT), lds, stream, L, p, f, xy_dev, n, n_dev, out_dev, acts_dev, mask, ldp, ldf); \
+    } while (0)
         if (L.n_features == 4) {
-            if (acts_dev) WOST_FWD(true, 4); else WOST_FWD(false, 4);
+            if (acts_dev) WOST_FWD(true, 4, kFwdTrainThreads); else WOST_FWD(false, 4, kFwdThreads);
         } else {
-            if (acts_dev) WOST_FWD(true, 0); else WOST_FWD(false, 0);
+            if (acts_dev) WOST_FWD(true, 0, kFwdTrainThreads); else WOST_FWD(false, 0, kFwdThreads);
         }
 #undef WOST_FWD
     } else {
@@ -929,9 +942,10 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
     NET_TRY(hipMemsetAsync(h->grad, 0, (size_t)h->n_params * sizeof(fx_t), stream));
     if (h->use_mfma) {
         const size_t lds = (size_t)L.n_mlp * sizeof(float);
-        const int n_tiles = (n + 16 * kMfmaSub - 1) / (16 * kMfmaSub);
-        hipLaunchKernelGGL((net_backward_mfma_kernel<32, 64, 3, 48>), dim3((unsigned)std::min((n_tiles + 3) / 4, 512)), dim3(256), lds,
-                           stream, L, h->params_fb, h->d_dl, h->d_mask, n, h->d_deltas, h->d_denc);
+        const int n_tiles = (n + 63) / 64 * 4 / kMfmaSub;
+        const unsigned gridb = (unsigned)std::min((n_tiles + kBwdThreads / 64 - 1) / (kBwdThreads / 64), 256);
+        hipLaunchKernelGGL((net_backward_mfma_kernel<32, 64, 3, 48, kBwdThreads>), dim3(gridb), dim3(kBwdThreads), lds, stream, L,
+                           h->params_fb, h->d_dl, h->d_mask, n, h->d_deltas, h->d_denc);
     } else {
         const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
         const unsigned gridp = (unsigned)((n + kNetBlock - 1) / kNetBlock);
