@@ -54,9 +54,35 @@ struct WalkQueue {
 
 static const int kQueueWords = 16 + 1;  // rng counts twice
 
-struct StatsDev {
+// Atomics on one cache line are served one by one by its L2 channel (about 10 ns each: the eight
+// counters of the 16 384 waves of a round cost over a millisecond), so the counters exist in
+// kStatCopies copies 256 bytes apart, a block adds to the copy blockIdx % kStatCopies and the host
+// sums the copies.
+constexpr int kStatCopies = 64;
+struct alignas(256) StatsDev {
     unsigned long long steps, started, absorbed, truncated, nhits, inner_visits, leaf_visits, trav_trips, step_trips, max_stack;
 };
+__device__ __forceinline__ StatsDev *my_stats(StatsDev *s) { return s + (blockIdx.x & (kStatCopies - 1)); }
+
+// block-level stream compaction (up to 1024 threads, every thread of the block must call it): one atomic
+// per block on the queue counter; returns the output slot of this lane (valid when `keep`)
+__device__ __forceinline__ uint32_t block_push(bool keep, uint32_t *counter)
+{
+    __shared__ uint32_t s_cnt[16], s_base;
+    const unsigned long long bal = __ballot(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63) >> 6;
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < n_waves; ++w) total += s_cnt[w];
+        s_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_base;
+    for (int w = 0; w < wave; ++w) base += s_cnt[w];
+    return base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+}
 
 struct RoundParams {
     DevMesh dm, nm;
@@ -128,14 +154,8 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams P)
         pcg_seed_pixel(rng, pid, P.st.width);
         if (P.dm.n_segs > 0) c0 = closest_point(P.dm, x0, y0, slot_candidate(P.dm, 0, x0, y0), stack, P.stack_stride);
     }
-    // wave-level compaction: one atomic per wave
-    const unsigned long long bal = __ballot(active);
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    if (lane == 0 && bal) base = atomicAdd(P.count_out, (uint32_t)__popcll(bal));
-    base = __shfl(base, 0);
+    const uint32_t s = block_push(active, P.count_out);
     if (active) {
-        const uint32_t s = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         WalkQueue &q = P.out;
         q.pix[s] = pid;
         q.x0[s] = x0; q.y0[s] = y0;
@@ -420,14 +440,10 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
         const float spp = (float)P.st.spp;
         f[0] = L.sr / spp; f[1] = L.sg / spp; f[2] = L.sb / spp;
     }
-    // ---- stream compaction of the survivors: ballot + popcount, one atomic per wave -------
-    const unsigned long long bal = __ballot(alive && open);
+    // ---- stream compaction of the survivors: ballot + popcount, one atomic per block ------
     const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    if (lane == 0 && bal) base = atomicAdd(P.count_out, (uint32_t)__popcll(bal));
-    base = __shfl(base, 0);
+    const uint32_t s = block_push(alive && open, P.count_out);
     if (alive && open) {
-        const uint32_t s = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         WalkQueue &q = P.out;
         q.pix[s] = pix;
         q.x0[s] = L.x0; q.y0[s] = L.y0;
@@ -451,14 +467,15 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
         v[k] = x;
     }
     if (lane == 0) {
-        if (v[0]) atomicAdd(&P.stats->steps, (unsigned long long)v[0]);
-        if (v[1]) atomicAdd(&P.stats->started, (unsigned long long)v[1]);
-        if (v[2]) atomicAdd(&P.stats->absorbed, (unsigned long long)v[2]);
-        if (v[3]) atomicAdd(&P.stats->truncated, (unsigned long long)v[3]);
-        if (v[4]) atomicAdd(&P.stats->nhits, (unsigned long long)v[4]);
-        if (v[5]) atomicAdd(&P.stats->inner_visits, (unsigned long long)v[5]);
-        atomicAdd(&P.stats->trav_trips, (unsigned long long)trav_trips);
-        atomicAdd(&P.stats->step_trips, (unsigned long long)step_trips);
+        StatsDev *st = my_stats(P.stats);
+        if (v[0]) atomicAdd(&st->steps, (unsigned long long)v[0]);
+        if (v[1]) atomicAdd(&st->started, (unsigned long long)v[1]);
+        if (v[2]) atomicAdd(&st->absorbed, (unsigned long long)v[2]);
+        if (v[3]) atomicAdd(&st->truncated, (unsigned long long)v[3]);
+        if (v[4]) atomicAdd(&st->nhits, (unsigned long long)v[4]);
+        if (v[5]) atomicAdd(&st->inner_visits, (unsigned long long)v[5]);
+        atomicAdd(&st->trav_trips, (unsigned long long)trav_trips);
+        atomicAdd(&st->step_trips, (unsigned long long)step_trips);
     }
 }
 
@@ -785,7 +802,7 @@ int wost_create(const wost_scene_desc *scene, const wost_settings *settings, int
         carve_queue(c->queue_mem[i], c->n_pixels, c->queue[i]);
     }
     HIP_TRY_C(hipMalloc((void **)&c->counts, 2 * sizeof(uint32_t)));
-    HIP_TRY_C(hipMalloc((void **)&c->stats, sizeof(StatsDev)));
+    HIP_TRY_C(hipMalloc((void **)&c->stats, kStatCopies * sizeof(StatsDev)));
     HIP_TRY_C(hipMalloc((void **)&c->cursor, sizeof(uint32_t)));
     HIP_TRY_C(hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device));
     HIP_TRY_C(hipMalloc((void **)&c->field, c->n_pixels * 3 * sizeof(float)));
@@ -873,7 +890,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     const int stack_depth = 3 * levels_any + 1;
     const size_t lds = (size_t)stack_depth * bs * sizeof(uint32_t);
     HIP_TRY(hipMemsetAsync(c->counts, 0, 2 * sizeof(uint32_t), stream));
-    HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(StatsDev), stream));
+    HIP_TRY(hipMemsetAsync(c->stats, 0, kStatCopies * sizeof(StatsDev), stream));
 
     const int tiles_x = (c->settings.width + 7) / 8, tiles_y = (c->settings.height + 7) / 8;
     InitParams ip{};
@@ -1063,9 +1080,16 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         n_active = c->host_count[0];
         cur = nxt;
     }
-    StatsDev sd{};
-    HIP_TRY(hipMemcpyAsync(&sd, c->stats, sizeof(sd), hipMemcpyDeviceToHost, stream));
+    std::vector<StatsDev> copies(kStatCopies);
+    HIP_TRY(hipMemcpyAsync(copies.data(), c->stats, kStatCopies * sizeof(StatsDev), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    StatsDev sd{};
+    for (const StatsDev &k : copies) {
+        sd.steps += k.steps; sd.started += k.started; sd.absorbed += k.absorbed; sd.truncated += k.truncated;
+        sd.nhits += k.nhits; sd.inner_visits += k.inner_visits; sd.leaf_visits += k.leaf_visits;
+        sd.trav_trips += k.trav_trips; sd.step_trips += k.step_trips;
+        sd.max_stack = std::max(sd.max_stack, k.max_stack);
+    }
     if (stats) {
         const auto t_end = std::chrono::high_resolution_clock::now();
         stats->walk_steps = sd.steps;

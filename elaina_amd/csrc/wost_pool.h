@@ -265,18 +265,18 @@ __global__ __launch_bounds__(64, 4) void walk_pool_kernel(PoolParams P)
         v[k] = x;
     }
     if (lane == 0) {
-        if (v[0]) atomicAdd(&P.stats->steps, (unsigned long long)v[0]);
-        if (v[1]) atomicAdd(&P.stats->started, (unsigned long long)v[1]);
-        if (v[2]) atomicAdd(&P.stats->absorbed, (unsigned long long)v[2]);
-        if (v[3]) atomicAdd(&P.stats->truncated, (unsigned long long)v[3]);
-        if (v[4]) atomicAdd(&P.stats->nhits, (unsigned long long)v[4]);
-        if (v[5]) atomicAdd(&P.stats->inner_visits, (unsigned long long)v[5]);
-        if (v[6]) atomicAdd(&P.stats->leaf_visits, (unsigned long long)v[6]);
-        atomicAdd(&P.stats->trav_trips, (unsigned long long)trav_trips);
-        atomicAdd(&P.stats->step_trips, (unsigned long long)step_trips);
+        if (v[0]) atomicAdd(&my_stats(P.stats)->steps, (unsigned long long)v[0]);
+        if (v[1]) atomicAdd(&my_stats(P.stats)->started, (unsigned long long)v[1]);
+        if (v[2]) atomicAdd(&my_stats(P.stats)->absorbed, (unsigned long long)v[2]);
+        if (v[3]) atomicAdd(&my_stats(P.stats)->truncated, (unsigned long long)v[3]);
+        if (v[4]) atomicAdd(&my_stats(P.stats)->nhits, (unsigned long long)v[4]);
+        if (v[5]) atomicAdd(&my_stats(P.stats)->inner_visits, (unsigned long long)v[5]);
+        if (v[6]) atomicAdd(&my_stats(P.stats)->leaf_visits, (unsigned long long)v[6]);
+        atomicAdd(&my_stats(P.stats)->trav_trips, (unsigned long long)trav_trips);
+        atomicAdd(&my_stats(P.stats)->step_trips, (unsigned long long)step_trips);
     }
     for (int off = 32; off > 0; off >>= 1) max_sp = max(max_sp, __shfl_down(max_sp, off));
-    if (lane == 0) atomicMax(&P.stats->max_stack, (unsigned long long)(max_sp));
+    if (lane == 0) atomicMax(&my_stats(P.stats)->max_stack, (unsigned long long)(max_sp));
 }
 
 }  // namespace wost
