@@ -172,7 +172,14 @@ __device__ __forceinline__ GStatsDev *my_stats(GStatsDev *stats) { return stats 
 // :131-150 on every sample)
 __global__ __launch_bounds__(256) void begin_sample_kernel(GParams P)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    // queue order = 8x8 pixel tiles (a wave starts with 64 walkers that are neighbours in BOTH
+    // directions and visit the same nodes of the tree), row-major when the frame is not made of
+    // whole tiles.  The order of the queue has no influence on any result.
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (((P.st.width | P.st.height) & 7) == 0 && p < P.n_pixels) {
+        const int tiles_x = P.st.width >> 3, tile = p >> 6, in_tile = p & 63;
+        p = ((tile / tiles_x) * 8 + (in_tile >> 3)) * P.st.width + (tile % tiles_x) * 8 + (in_tile & 7);
+    }
     const bool in_frame = p < P.n_pixels;
     bool active = false;
     float x = 0, y = 0;
