@@ -309,7 +309,8 @@ int wost_guided_train_set(wost_guided_handle h, int32_t capacity, int32_t *n, fl
                           float *solution, float *dir_pdf, float *normal, uint8_t *on_neumann);
 int wost_guided_destroy(wost_guided_handle h);
 
-/* Tuning knobs ("steps_per_round", "block_size", ...); unknown keys -> WOST_ERR_INVALID.
+/* Tuning knobs ("steps_per_round", "block_size", "refill", "thin_waves", ...; scheduling only,
+ * never the result); unknown keys -> WOST_ERR_INVALID.
  * "spp" changes samplesPerPixel of an existing handle (a pixel's first k samples do not depend on
  * the total, so solving with spp = k reproduces the state of a longer solve after k samples: the
  * host mirror uses this for saveSppMetrics frames). */

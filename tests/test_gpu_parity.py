@@ -153,6 +153,13 @@ def test_block_size_does_not_change_results(oracle, ladybug, block_size):
     _assert_same_solve(oracle, ladybug, 40, 48, 5, 24, 1.0, block_size=block_size)
 
 
+@pytest.mark.parametrize("thin", [0, 1])
+def test_thin_wave_launches_do_not_change_results(oracle, ladybug, thin):
+    # 96 x 96 walkers fill < 1/16 of the chip: with thin_waves every launch gives one walker to
+    # 2^k lanes; a pure scheduling choice
+    _assert_same_solve(oracle, ladybug, 96, 96, 3, 32, 1.0, thin_waves=thin)
+
+
 def test_ragged_frame_mask_and_ranges(oracle, ladybug):
     from elaina_amd import Problem
     w, h = 37, 29  # not a multiple of the 8x8 tile
