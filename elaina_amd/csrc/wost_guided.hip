@@ -621,6 +621,8 @@ struct wost_guided {
     GQueue q[2]{};
     uint32_t *counts = nullptr;        // [2]
     uint32_t *host_counts = nullptr;   // pinned [4]
+    uint32_t *depth_counts = nullptr;  // pinned [max_depth]: queue size after every depth, copied back without waiting
+    std::vector<hipEvent_t> depth_events;
     uint64_t *rng = nullptr;
     float *sol = nullptr, *field = nullptr, *rec = nullptr, *net_in = nullptr, *net_out = nullptr;
     uint32_t *cur_depth = nullptr;
@@ -662,6 +664,8 @@ static void guided_free(wost_guided *g)
     (void)hipSetDevice(g->device);
     for (void *p : g->allocs) (void)hipFree(p);
     if (g->host_counts) (void)hipHostFree(g->host_counts);
+    if (g->depth_counts) (void)hipHostFree(g->depth_counts);
+    for (hipEvent_t e : g->depth_events) (void)hipEventDestroy(e);
     if (g->net) wost_net_destroy(g->net);
     if (g->scene) wost_destroy(g->scene);
     delete g;
@@ -728,6 +732,12 @@ int wost_guided_create(const wost_scene_desc *scene, const wost_guided_settings 
     GA(g->ts.onn, M);
 #undef GA
     if (e == hipSuccess) e = hipHostMalloc((void **)&g->host_counts, 4 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&g->depth_counts, (size_t)std::max(1, s->max_depth) * sizeof(uint32_t));
+    for (int d = 0; e == hipSuccess && d < s->max_depth; ++d) {
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) g->depth_events.push_back(ev);
+    }
     if (e != hipSuccess) {
         set_error(WOST_ERR_DEVICE, std::string("guided allocation: ") + hipGetErrorString(e));
         return bail(WOST_ERR_DEVICE);
@@ -855,7 +865,11 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         P.out = g->q[cur]; P.count_out = g->counts + cur;
         hipLaunchKernelGGL(begin_sample_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, P);
         ++launches;
-        uint32_t n_cur = (uint32_t)N;    // upper bound of the queue size, refined by the read-backs below
+        // The queue only shrinks from depth to depth, so ANY earlier size bounds it.  The sizes come
+        // back through pinned memory without the host waiting for them (every kernel reads the exact
+        // size on the device); the launches of a sample are issued back to back.
+        uint32_t n_cur = (uint32_t)N;
+        int polled = -1;                 // last depth whose queue size has arrived
         for (int depth = 0; depth < s.max_depth; ++depth) {
             const int nxt = cur ^ 1;
             P.depth = depth;
@@ -889,12 +903,13 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
 #undef LAUNCH_SEP
             ++launches;
             // the out-of-shell queue is the input of the network and of the sampling kernel
-            G_TRY(hipMemcpyAsync(g->host_counts, g->counts + nxt, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            G_TRY(hipStreamSynchronize(stream));
-            const uint32_t n_out = g->host_counts[0];
-            if (n_out == 0) break;
+            G_TRY(hipMemcpyAsync(g->depth_counts + depth, g->counts + nxt, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            G_TRY(hipEventRecord(g->depth_events[depth], stream));
+            while (polled < depth && hipEventQuery(g->depth_events[polled + 1]) == hipSuccess) n_cur = g->depth_counts[++polled];
+            if (polled == depth && n_cur == 0) break;      // known to be empty
+            const uint32_t n_out = n_cur;                  // an upper bound
             if (P.guiding) {
-                int rc = net_inference_dev(g->net, g->net_in, nullptr, (int)n_out, g->net_out, true, stream, (size_t)N);
+                int rc = net_inference_dev(g->net, g->net_in, g->counts + nxt, (int)n_out, g->net_out, true, stream, (size_t)N);
                 if (rc != WOST_OK) return rc;
                 ++launches;
             }
@@ -909,6 +924,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         }
         // ---- trainStep (:618-668) ----
         if (training) {
+            G_TRY(hipStreamSynchronize(stream));     // the walk phase ends here; train_ms counts the training only
             const auto t0 = std::chrono::high_resolution_clock::now();
             TParams T{};
             T.box = g->box; T.cur_depth = g->cur_depth; T.rec = g->rec; T.n_pixels = N;
