@@ -255,6 +255,17 @@ def test_gpu_training_end_to_end_matches_oracle(oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_training_end_to_end_with_scalar_network_kernels(oracle, monkeypatch):
+    """the same solve through the one-thread-per-point network kernels (WOST_NET_SCALAR=1)"""
+    monkeypatch.setenv("WOST_NET_SCALAR", "1")
+    prob = laplace_box()
+    gi, ref = _gpu_and_oracle(oracle, prob, 32, 32, 6, 32, 4, dump=False)
+    assert gi.last_stats["optimizer_steps"] == ref["optimizer_steps"] > 0
+    assert np.array_equal(gi.solution, ref["field"])
+    gi.close()
+
+
+@pytest.mark.gpu
 def test_gpu_trained_solve_is_reproducible(oracle):
     """two runs of the same trained solve give the same field and the same network"""
     from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings

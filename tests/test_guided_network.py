@@ -186,6 +186,35 @@ def test_gpu_training_steps_match_oracle(net, orc):
 
 
 @pytest.mark.gpu
+def test_gpu_scalar_kernels_match_oracle(orc, monkeypatch):
+    """The one-thread-per-point kernels (other network shapes, WOST_NET_SCALAR=1) follow the same
+    operation order as the MFMA kernels: inference and a training step, bit for bit."""
+    from elaina_amd.guided import GuidingNetwork
+    monkeypatch.setenv("WOST_NET_SCALAR", "1")
+    net = GuidingNetwork(seed=7)
+    try:
+        cfg = default_net_config()
+        p = _rand_params(orc, cfg, seed=19, gscale=0.1)
+        net.set_params(p)
+        rng = np.random.default_rng(9)
+        n = 2048 + 77
+        xy = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+        assert np.array_equal(net.inference(xy), orc.net_forward(cfg, p, xy)[0][:, :33])
+        dl = (rng.normal(size=(n, 33)) * 128 / n).astype(np.float32)
+        net.train_step(xy, dl, loss_scale=128.0)
+        dl48 = np.zeros((n, 48), dtype=np.float32)
+        dl48[:, :33] = dl
+        g = orc.net_backward(cfg, p, xy, dl48)
+        assert np.array_equal(net.gradients(), g)
+        st = orc.net_optimizer_state(cfg)
+        po = p.copy()
+        inf = orc.net_optimizer_step(cfg, po, st, g, step=1, loss_scale=128.0)
+        assert np.array_equal(net.params(), po) and np.array_equal(net.inference_params(), inf)
+    finally:
+        net.close()
+
+
+@pytest.mark.gpu
 def test_gpu_network_learns_a_field(net):
     """End-to-end sanity: L2 regression of a smooth 33-channel field drives the loss down and the
     EMA weights follow (what the guided integrator relies on between training iterations)."""
