@@ -487,6 +487,241 @@ __global__ __launch_bounds__(NT) void net_backward_mfma_kernel(NetLayout L, cons
     }
 }
 
+// ---- backward pass and weight gradients in one kernel ------------------------------------------
+// The deltas of a layer are needed twice: as B operand of the next backward layer (held in lane
+// (column, g)) and as A operand of that layer's weight gradient (lane (feature, k-slot)).  Here
+// they never reach global memory: a block owns a 1024-point chunk, wave w is chain w and walks its
+// sixteen 16-column units in order; after every backward layer it turns the 16 x 64 delta block
+// around through a 5 KB LDS tile and feeds the weight-gradient MFMAs of that layer, whose other
+// operand (the layer's input activations) comes from the training layout in global memory with
+// one 16-byte load per four MFMAs.  The 13 312 weight-gradient sums of a chain live in registers
+// (208 per lane, accumulation registers: one wave per SIMD) for the whole chunk and are combined
+// as ((w0 + w1) + w2) + w3 at the end: the same sums in the same order as weight_grad_mfma_kernel.
+// The delta tile is written and read by the SAME wave, and a wave's LDS instructions execute in
+// order: the compiler only has to keep them in program order.  (A workgroup fence would also wait
+// for every global load in flight, i.e. for the prefetched operands of the next unit.)
+__device__ __forceinline__ void wave_lds_order() { asm volatile("" ::: "memory"); }
+
+// One wave per SIMD: nothing hides the LDS latency of a weight fragment unless it is requested well
+// ahead of its MFMA, so the fragments of four k-steps are read as a group, one group ahead.
+template <int S, int RT>
+__device__ __forceinline__ void mfma_layer1(const float *wf, int lane, const float (&b)[16], f32x4_t (&acc)[4])
+{
+    static_assert(S % 4 == 0, "groups of four k-steps");
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    float a[2][4 * RT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[0][q * RT + rt] = wf[(rt * S + q) * 64 + lane];
+#pragma unroll
+    for (int s0 = 0; s0 < S; s0 += 4) {
+        const int cur = (s0 >> 2) & 1;
+        if (s0 + 4 < S) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[cur ^ 1][q * RT + rt] = wf[(rt * S + s0 + 4 + q) * 64 + lane];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][q * RT + rt], b[s0 + q], acc[rt], 0, 0, 0);
+    }
+}
+
+constexpr int kTileStride = 20;   // floats per feature row of the delta tile (16 columns + padding, 16-byte aligned)
+
+// input activations of one layer for the four groups of a unit: lane (feature 16kt + i, k-slot g)
+// loads columns 4g .. 4g+3 in one piece.  Nothing touches the values here (that would wait for
+// them): columns of points past the end, which were never written, are zeroed where they are used.
+template <int KT>
+__device__ __forceinline__ void load_inputs(const float *in_unit, int i, int g, float4 (&b)[KT])
+{
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) b[kt] = *reinterpret_cast<const float4 *>(in_unit + (size_t)(16 * kt + i) * 16 + 4 * g);
+}
+
+// dW[16rt + ..][16kt + ..] += delta^T (from the LDS tile) x input (loaded by load_inputs) for one unit
+template <int RT, int KT>
+__device__ __forceinline__ void wgrad_unit(const float *tile, const float4 (&bin)[KT], bool ok0, bool ok1, bool ok2, bool ok3, int i,
+                                           int g, f32x4_t (&acc)[RT][KT])
+{
+    float4 a[RT], b[KT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const float4 *>(tile + (16 * rt + i) * kTileStride + 4 * g);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        b[kt].x = ok0 ? bin[kt].x : 0.0f; b[kt].y = ok1 ? bin[kt].y : 0.0f;
+        b[kt].z = ok2 ? bin[kt].z : 0.0f; b[kt].w = ok3 ? bin[kt].w : 0.0f;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const float av = m == 0 ? a[rt].x : m == 1 ? a[rt].y : m == 2 ? a[rt].z : a[rt].w;
+                const float bv = m == 0 ? b[kt].x : m == 1 ? b[kt].y : m == 2 ? b[kt].z : b[kt].w;
+                acc[rt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[rt][kt], 0, 0, 0);
+            }
+}
+
+// the four chains of a block -> ((w0 + w1) + w2) + w3 -> one fixed-point atomic per weight
+template <int RT, int KT>
+__device__ __forceinline__ void wgrad_reduce(float *red, int wave, int lane, int i, int g, int n_i, const f32x4_t (&acc)[RT][KT],
+                                             fx_t *gW)
+{
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) red[((wave - 1) * RT * KT * 4 + (rt * KT + kt) * 4 + c) * 64 + lane] = acc[rt][kt][c];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int e = (rt * KT + kt) * 4 + c;
+                    const float v = ((acc[rt][kt][c] + red[(0 * RT * KT * 4 + e) * 64 + lane]) + red[(1 * RT * KT * 4 + e) * 64 + lane]) +
+                                    red[(2 * RT * KT * 4 + e) * 64 + lane];
+                    if (v != 0.0f) fx_add(gW + (size_t)(16 * rt + 4 * g + c) * n_i + 16 * kt + i, to_fx(v));
+                }
+    }
+}
+
+template <int ENC, int H, int NH, int NOP>
+__global__ __launch_bounds__(256, 1) void net_backward_wgrad_kernel(NetLayout L, const float *fragb, const float *dl_dout,
+                                                                    const unsigned long long *relu_mask, int n, const float *acts,
+                                                                    float *denc, fx_t *grad)
+{
+    static_assert(NH == 3 && H == 64 && ENC == 32 && NOP == 48, "accumulator sets are spelled out for this shape");
+    extern __shared__ float lds[];
+    float *wfrag = lds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *tile = lds + L.n_mlp + wave * (64 * kTileStride);
+    float *red = lds + L.n_mlp + 4 * (64 * kTileStride);
+    for (uint32_t e = threadIdx.x; e < L.n_mlp; e += 256) wfrag[e] = fragb[e];
+    __syncthreads();
+    const int i = lane & 15, g = lane >> 4;
+    const int astride = ENC + NH * H;
+    const int p0 = blockIdx.x * 1024, p1 = min(n, p0 + 1024);
+    f32x4_t acc3[NOP / 16][H / 16], acc2[H / 16][H / 16], acc1[H / 16][H / 16], acc0[H / 16][ENC / 16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (a < NOP / 16) acc3[a][c] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            acc2[a][c] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            acc1[a][c] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            if (c < ENC / 16) acc0[a][c] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    // Software pipeline over the units of the chain: with one wave per SIMD nothing else hides a
+    // load, so every operand of unit u+1 is requested right after its counterpart of unit u has
+    // been consumed (the input activations reuse the same registers), a whole unit ahead of its use.
+    struct Unit {
+        int pt;
+        bool valid, ok0, ok1, ok2, ok3, any;
+        const float *aunit;
+    };
+    auto unit_of = [&](int span) {
+        Unit u;
+        const int pbase = 64 * span + 4 * wave;
+        u.any = span * 64 < p1 && pbase < p1;           // wave-uniform: a group of this chain is left
+        u.pt = train_point(span * 4 + wave, i);
+        u.valid = u.any && u.pt < p1;
+        u.ok0 = u.any && pbase + g < p1; u.ok1 = u.any && pbase + g + 16 < p1;
+        u.ok2 = u.any && pbase + g + 32 < p1; u.ok3 = u.any && pbase + g + 48 < p1;
+        u.aunit = acts + (size_t)(span * 4 + wave) * 16 * astride;
+        return u;
+    };
+    // requests only: a unit without points reads the chunk's first point, and nothing is selected
+    // or masked before the values are used one unit later
+    auto load_dl = [&](const Unit &u, float (&d)[NOP / 4], unsigned long long &m) {
+        const size_t q = (size_t)(u.valid ? u.pt : p0);
+        m = relu_mask[q * 4 + g];
+#pragma unroll
+        for (int s = 0; s < NOP / 4; ++s) d[s] = dl_dout[q * L.n_out + min(4 * s + g, L.n_out - 1)];
+    };
+    float4 in3[H / 16], in2[H / 16], in1[H / 16], in0[ENC / 16];
+    float ndl[NOP / 4];
+    unsigned long long nmask;
+    Unit cur = unit_of(p0 / 64);
+    load_dl(cur, ndl, nmask);
+    if (cur.any) {
+        load_inputs<H / 16>(cur.aunit + (size_t)(ENC + 2 * H) * 16, i, g, in3);
+        load_inputs<H / 16>(cur.aunit + (size_t)(ENC + H) * 16, i, g, in2);
+        load_inputs<H / 16>(cur.aunit + (size_t)ENC * 16, i, g, in1);
+        load_inputs<ENC / 16>(cur.aunit, i, g, in0);
+    }
+    for (int span = p0 / 64; cur.any; ++span) {
+        const Unit nxt = unit_of(span + 1);
+        const int pt = cur.pt;
+        const bool valid = cur.valid;
+        const unsigned long long mask = valid ? nmask : 0ull;
+        float b[16];
+#pragma unroll
+        for (int s = 0; s < NOP / 4; ++s) b[s] = (valid && 4 * s + g < L.n_out) ? ndl[s] : 0.0f;
+        load_dl(nxt, ndl, nmask);
+        // ---- output layer: dW3 += dl^T x h3
+#pragma unroll
+        for (int s = 0; s < NOP / 4; ++s) tile[(4 * s + g) * kTileStride + i] = b[s];
+        wave_lds_order();
+        wgrad_unit<NOP / 16, H / 16>(tile, in3, cur.ok0, cur.ok1, cur.ok2, cur.ok3, i, g, acc3);
+        wave_lds_order();
+        if (nxt.any) load_inputs<H / 16>(nxt.aunit + (size_t)(ENC + 2 * H) * 16, i, g, in3);
+        f32x4_t acc[4];
+        // ---- hidden layers, last to first: delta, then the weight gradient that consumes it
+#pragma unroll
+        for (int layer = NH; layer >= 1; --layer) {
+            if (layer == NH) mfma_layer1<NOP / 4, H / 16>(wfrag + L.w_off[layer], lane, b, acc);
+            else mfma_layer1<H / 4, H / 16>(wfrag + L.w_off[layer], lane, b, acc);
+#pragma unroll
+            for (int kt = 0; kt < H / 16; ++kt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool on = (mask >> ((layer - 1) * 16 + 4 * kt + c)) & 1ull;      // ReLU'
+                    const float v = on ? acc[kt][c] : 0.0f;
+                    b[4 * kt + c] = v;
+                    tile[(16 * kt + 4 * c + g) * kTileStride + i] = v;
+                }
+            wave_lds_order();
+            // delta of hidden layer (layer - 1) x its input: the encoding for the first, else the layer before
+            if (layer == 3) {
+                wgrad_unit<H / 16, H / 16>(tile, in2, cur.ok0, cur.ok1, cur.ok2, cur.ok3, i, g, acc2);
+                if (nxt.any) load_inputs<H / 16>(nxt.aunit + (size_t)(ENC + H) * 16, i, g, in2);
+            } else if (layer == 2) {
+                wgrad_unit<H / 16, H / 16>(tile, in1, cur.ok0, cur.ok1, cur.ok2, cur.ok3, i, g, acc1);
+                if (nxt.any) load_inputs<H / 16>(nxt.aunit + (size_t)ENC * 16, i, g, in1);
+            } else {
+                wgrad_unit<H / 16, ENC / 16>(tile, in0, cur.ok0, cur.ok1, cur.ok2, cur.ok3, i, g, acc0);
+                if (nxt.any) load_inputs<ENC / 16>(nxt.aunit, i, g, in0);
+            }
+            wave_lds_order();
+        }
+        // ---- gradient of the encoding, for grid_grad_kernel
+        mfma_layer1<H / 4, ENC / 16>(wfrag + L.w_off[0], lane, b, acc);
+#pragma unroll
+        for (int kt = 0; kt < ENC / 16; ++kt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (valid) denc[(size_t)pt * ENC + 16 * kt + 4 * c + g] = acc[kt][c];
+        cur = nxt;
+    }
+    wgrad_reduce<NOP / 16, H / 16>(red, wave, lane, i, g, H, acc3, grad + L.w_off[3]);
+    wgrad_reduce<H / 16, H / 16>(red, wave, lane, i, g, H, acc2, grad + L.w_off[2]);
+    wgrad_reduce<H / 16, H / 16>(red, wave, lane, i, g, H, acc1, grad + L.w_off[1]);
+    wgrad_reduce<H / 16, ENC / 16>(red, wave, lane, i, g, ENC, acc0, grad + L.w_off[0]);
+}
+
 // dW[r][k] += sum_p delta[p][r] * input[p][k] as MFMA over the point index: A = delta^T tile
 // (16 rows r x 4 points), B = input tile (4 points x 16 columns k).  One BLOCK owns a chunk of
 // 1024 consecutive points; its four waves take the 4-point groups round robin (wave w: groups
@@ -940,7 +1175,15 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
 {
     const NetLayout &L = h->L;
     NET_TRY(hipMemsetAsync(h->grad, 0, (size_t)h->n_params * sizeof(fx_t), stream));
-    if (h->use_mfma) {
+    static const bool fused = !(getenv("WOST_NET_FUSED") && atoi(getenv("WOST_NET_FUSED")) == 0);
+    if (h->use_mfma && fused) {
+        // backward pass and weight gradients of a 1024-point chunk in one block (deltas stay on chip)
+        const size_t lds = ((size_t)L.n_mlp + 4 * 64 * kTileStride + 3 * 64 * 64) * sizeof(float);
+        auto kfn = net_backward_wgrad_kernel<32, 64, 3, 48>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)((n + 1023) / 1024)), dim3(256), lds, stream, L, h->params_fb, h->d_dl, h->d_mask, n,
+                           h->d_acts, h->d_denc, h->grad);
+    } else if (h->use_mfma) {
         const size_t lds = (size_t)L.n_mlp * sizeof(float);
         const int n_tiles = (n + 63) / 64 * 4 / kMfmaSub;
         const unsigned gridb = (unsigned)std::min((n_tiles + kBwdThreads / 64 - 1) / (kBwdThreads / 64), 256);
@@ -994,7 +1237,7 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
     const int chunk = 1024;
     const unsigned gridc = (unsigned)((n + chunk - 1) / chunk);
     const size_t lds_w = 2 * 32 * 64 * sizeof(float);
-    for (int layer = 0; layer <= L.n_hidden; ++layer) {
+    for (int layer = 0; layer <= L.n_hidden && !(h->use_mfma && fused); ++layer) {
         const int n_i = layer == 0 ? L.enc : L.n_neurons, n_o = layer == L.n_hidden ? L.n_out_padded : L.n_neurons;
         const int doff = layer == L.n_hidden ? 0 : L.n_out_padded + layer * L.n_neurons;   // delta of this layer's output
         const int ioff = layer == 0 ? 0 : L.enc + (layer - 1) * L.n_neurons;               // this layer's input
