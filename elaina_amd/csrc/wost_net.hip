@@ -1048,6 +1048,7 @@ struct wost_net {
     float *params_f = nullptr, *inference_f = nullptr;   // MFMA A-fragment order (MFMA forward pass)
     float *params_fb = nullptr;                          // MFMA fragments of the transposed matrices (backward pass)
     bool use_mfma = false;
+    bool fused_backward = true;      // net_backward_wgrad_kernel (WOST_NET_FUSED=0: backward and weight gradients apart)
     int step = 0;
     // scratch (grown on demand)
     float *d_xy = nullptr, *d_out = nullptr, *d_dl = nullptr, *d_acts = nullptr, *d_deltas = nullptr, *d_denc = nullptr;
@@ -1175,7 +1176,7 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
 {
     const NetLayout &L = h->L;
     NET_TRY(hipMemsetAsync(h->grad, 0, (size_t)h->n_params * sizeof(fx_t), stream));
-    static const bool fused = !(getenv("WOST_NET_FUSED") && atoi(getenv("WOST_NET_FUSED")) == 0);
+    const bool fused = h->fused_backward;
     if (h->use_mfma && fused) {
         // backward pass and weight gradients of a 1024-point chunk in one block (deltas stay on chip)
         const size_t lds = ((size_t)L.n_mlp + 4 * 64 * kTileStride + 3 * 64 * 64) * sizeof(float);
@@ -1311,6 +1312,8 @@ int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_
     h->n_params = h->L.n_mlp + h->L.n_grid;
     {
         // the MFMA forward kernel is instantiated for the reference's network shape
+        const char *unfused = getenv("WOST_NET_FUSED");
+        h->fused_backward = !(unfused && atoi(unfused) == 0);
         const char *scalar = getenv("WOST_NET_SCALAR");
         h->use_mfma = h->L.enc == 32 && h->L.n_neurons == 64 && h->L.n_hidden == 3 && h->L.n_out_padded == 48 &&
                       h->L.n_features <= 8 && !(scalar && atoi(scalar) != 0);

@@ -186,6 +186,33 @@ def test_gpu_training_steps_match_oracle(net, orc):
 
 
 @pytest.mark.gpu
+def test_gpu_unfused_backward_kernels_give_the_same_gradient(net, orc, monkeypatch):
+    """WOST_NET_FUSED=0: backward pass and weight gradients as separate kernels (deltas through
+    global memory); the default is the fused kernel.  Same sums in the same order."""
+    from elaina_amd.guided import GuidingNetwork
+    cfg = default_net_config()
+    p = _rand_params(orc, cfg, seed=23, gscale=0.1)
+    rng = np.random.default_rng(12)
+    n = 5000 + 13
+    xy = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    dl = (rng.normal(size=(n, 33)) * 128 / n).astype(np.float32)
+    net.set_params(p)
+    net.train_step(xy, dl, apply_update=False)
+    fused = net.gradients().copy()
+    monkeypatch.setenv("WOST_NET_FUSED", "0")
+    other = GuidingNetwork(seed=7)
+    try:
+        other.set_params(p)
+        other.train_step(xy, dl, apply_update=False)
+        assert np.array_equal(other.gradients(), fused)
+    finally:
+        other.close()
+    dl48 = np.zeros((n, 48), dtype=np.float32)
+    dl48[:, :33] = dl
+    assert np.array_equal(fused, orc.net_backward(cfg, p, xy, dl48))
+
+
+@pytest.mark.gpu
 def test_gpu_scalar_kernels_match_oracle(orc, monkeypatch):
     """The one-thread-per-point kernels (other network shapes, WOST_NET_SCALAR=1) follow the same
     operation order as the MFMA kernels: inference and a training step, bit for bit."""
