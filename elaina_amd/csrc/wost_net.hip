@@ -662,6 +662,9 @@ __global__ __launch_bounds__(256, 1) void net_backward_wgrad_kernel(NetLayout L,
         load_inputs<H / 16>(cur.aunit + (size_t)ENC * 16, i, g, in1);
         load_inputs<ENC / 16>(cur.aunit, i, g, in0);
     }
+    f32x4_t st_acc[ENC / 16];          // encoding gradient of the previous unit, stored one unit late
+    int st_pt = 0;
+    bool st_valid = false;
     for (int span = p0 / 64; cur.any; ++span) {
         const Unit nxt = unit_of(span + 1);
         const int pt = cur.pt;
@@ -671,6 +674,18 @@ __global__ __launch_bounds__(256, 1) void net_backward_wgrad_kernel(NetLayout L,
 #pragma unroll
         for (int s = 0; s < NOP / 4; ++s) b[s] = (valid && 4 * s + g < L.n_out) ? ndl[s] : 0.0f;
         load_dl(nxt, ndl, nmask);
+        // The compiler drains every outstanding memory operation at the end of the loop body (it
+        // does not track them across the back edge), so nothing young may be in flight there: the
+        // encoding gradient of the PREVIOUS unit is stored now, and the encoding of the next unit
+        // (the last operand a unit consumes) is requested now, into a second set of registers.
+        if (st_valid) {
+#pragma unroll
+            for (int kt = 0; kt < ENC / 16; ++kt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) denc[(size_t)st_pt * ENC + 16 * kt + 4 * c + g] = st_acc[kt][c];
+        }
+        float4 in0n[ENC / 16];
+        if (nxt.any) load_inputs<ENC / 16>(nxt.aunit, i, g, in0n);
         // ---- output layer: dW3 += dl^T x h3
 #pragma unroll
         for (int s = 0; s < NOP / 4; ++s) tile[(4 * s + g) * kTileStride + i] = b[s];
@@ -703,18 +718,25 @@ __global__ __launch_bounds__(256, 1) void net_backward_wgrad_kernel(NetLayout L,
                 if (nxt.any) load_inputs<H / 16>(nxt.aunit + (size_t)ENC * 16, i, g, in1);
             } else {
                 wgrad_unit<H / 16, ENC / 16>(tile, in0, cur.ok0, cur.ok1, cur.ok2, cur.ok3, i, g, acc0);
-                if (nxt.any) load_inputs<ENC / 16>(nxt.aunit, i, g, in0);
             }
             wave_lds_order();
         }
         // ---- gradient of the encoding, for grid_grad_kernel
         mfma_layer1<H / 4, ENC / 16>(wfrag + L.w_off[0], lane, b, acc);
 #pragma unroll
+        for (int kt = 0; kt < ENC / 16; ++kt) {
+            st_acc[kt] = acc[kt];
+            in0[kt] = in0n[kt];
+        }
+        st_pt = pt;
+        st_valid = valid;
+        cur = nxt;
+    }
+    if (st_valid) {
+#pragma unroll
         for (int kt = 0; kt < ENC / 16; ++kt)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (valid) denc[(size_t)pt * ENC + 16 * kt + 4 * c + g] = acc[kt][c];
-        cur = nxt;
+            for (int c = 0; c < 4; ++c) denc[(size_t)st_pt * ENC + 16 * kt + 4 * c + g] = st_acc[kt][c];
     }
     wgrad_reduce<NOP / 16, H / 16>(red, wave, lane, i, g, H, acc3, grad + L.w_off[3]);
     wgrad_reduce<H / 16, H / 16>(red, wave, lane, i, g, H, acc2, grad + L.w_off[2]);
