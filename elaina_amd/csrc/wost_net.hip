@@ -7,7 +7,9 @@
 // the MLP in half precision on tensor cores; here everything is fp32 with k-ordered fmaf chains,
 // so the result is reproducible and equal to the CPU restatement bit for bit:
 //   * the reference's network shape runs on the matrix cores (v_mfma_f32_16x16x4_f32, exact
-//     fp32): net_forward_mfma_kernel, net_backward_mfma_kernel, weight_grad_mfma_kernel;
+//     fp32): net_forward_mfma_kernel, net_backward_wgrad_kernel (backward pass + weight gradients
+//     of a 1024-point chunk in one block; apart, for WOST_NET_FUSED=0: net_backward_mfma_kernel,
+//     weight_grad_mfma_kernel);
 //   * other shapes (and WOST_NET_SCALAR=1) use the scalar kernels: one thread per point,
 //     activations in a per-lane LDS column, wave-uniform weights through scalar loads;
 //   * gradients are sums over the training points and are accumulated in 64-bit fixed point
