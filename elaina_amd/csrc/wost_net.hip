@@ -1039,9 +1039,17 @@ __global__ void transpose_mlp_kernel(NetLayout L, const float *src, float *dst)
 }
 
 // tiny-cuda-nn adam.h adam_step nested in ema.h (debiased): step counts from 1
-__global__ void optimizer_kernel(uint32_t n, float *params, float *m1, float *m2, float *ema_raw, float *inference,
+// The copies of the MLP matrices in other orders (transposed for the scalar forward pass, MFMA
+// fragments for the forward and backward kernels) are written here too: the inverse of the index
+// maps of transpose_mlp_kernel / fragment_mlp_kernel / fragment_mlp_t_kernel, five launches less
+// per optimizer step.
+struct DerivedLayouts {
+    float *params_t, *inference_t, *params_f, *inference_f, *params_fb;   // any may be null
+};
+
+__global__ void optimizer_kernel(NetLayout L, uint32_t n, float *params, float *m1, float *m2, float *ema_raw, float *inference,
                                  const fx_t *grad, float lr_t, float beta1, float beta2, float eps, float l2, float decay,
-                                 float debias, float loss_scale)
+                                 float debias, float loss_scale, DerivedLayouts D)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1053,7 +1061,27 @@ __global__ void optimizer_kernel(uint32_t n, float *params, float *m1, float *m2
     const float nw = w - (lr_t / (sqrtf(b) + eps)) * a;
     params[i] = nw;
     const float e = ema_raw[i] = decay * ema_raw[i] + (1.0f - decay) * nw;
-    inference[i] = e * debias;
+    const float inf = e * debias;
+    inference[i] = inf;
+    if (i >= L.n_mlp) return;
+    int layer = 0;
+    while (layer < L.n_hidden && i >= L.w_off[layer + 1]) ++layer;
+    const uint32_t n_i = layer == 0 ? L.enc : L.n_neurons, n_o = layer == L.n_hidden ? L.n_out_padded : L.n_neurons;
+    const uint32_t off = L.w_off[layer], q = i - off, r = q / n_i, k = q % n_i;
+    if (D.params_t) {
+        D.params_t[off + k * n_o + r] = nw;
+        D.inference_t[off + k * n_o + r] = inf;
+    }
+    if (D.params_f) {
+        // forward fragments: row 16rt + 4(i&3) + (i>>2) of lane i, k = 4s + g
+        const uint32_t rem = r & 15u, ii = (rem & 3u) * 4u + (rem >> 2), S = n_i / 4;
+        const uint32_t f = off + ((r >> 4) * S + (k >> 2)) * 64u + (k & 3u) * 16u + ii;
+        D.params_f[f] = nw;
+        D.inference_f[f] = inf;
+        // backward fragments (transposed matrix): k = 16kt + 4(i&3) + (i>>2), r = 4s + g
+        const uint32_t remk = k & 15u, ik = (remk & 3u) * 4u + (remk >> 2), Sb = n_o / 4;
+        D.params_fb[off + ((k >> 4) * Sb + (r >> 2)) * 64u + (r & 3u) * 16u + ik] = nw;
+    }
 }
 
 }  // namespace wost
@@ -1293,11 +1321,13 @@ int net_apply_update_dev(wost_net *h, float loss_scale, hipStream_t stream)
     const float lr_t = c.learning_rate * std::sqrt(1.0f - std::pow(c.beta2, (float)h->step)) /
                        (1.0f - std::pow(c.beta1, (float)h->step));
     const float debias = 1.0f / (1.0f - std::pow(c.ema_decay, (float)h->step));
-    hipLaunchKernelGGL(optimizer_kernel, dim3((h->n_params + 255) / 256), dim3(256), 0, stream, h->n_params, h->params, h->m1,
+    DerivedLayouts D{h->params_t, h->inference_t, nullptr, nullptr, nullptr};
+    if (h->use_mfma) { D.params_f = h->params_f; D.inference_f = h->inference_f; D.params_fb = h->params_fb; }
+    hipLaunchKernelGGL(optimizer_kernel, dim3((h->n_params + 255) / 256), dim3(256), 0, stream, h->L, h->n_params, h->params, h->m1,
                        h->m2, h->ema_raw, h->inference, h->grad, lr_t, c.beta1, c.beta2, c.epsilon, c.l2_reg, c.ema_decay,
-                       debias, loss_scale);
+                       debias, loss_scale, D);
     NET_TRY(hipGetLastError());
-    return refresh_transposed(h, stream);
+    return WOST_OK;
 }
 
 void *net_gradient_buffer(wost_net *h, uint64_t *count)
