@@ -12,9 +12,9 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libwost_hip.so")
 HOST_EXE = os.path.join(LIB_DIR, "elaina-exec")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 
 SOURCES = ["wost_hip.hip", "wost_vmm.hip", "wost_net.hip", "wost_guided.hip", "lbvh_build.cpp"]
-HEADERS = ["lbvh.h", "wost_device.h", "wost_math.h", "wost_pool.h", os.path.join("..", "..", "include", "wost.h")]
 
 # -ffp-contract=off is part of the arithmetic contract (DESIGN.md "deterministic math")
 HIPCC_FLAGS = [
@@ -38,11 +38,27 @@ def _stale(target, deps):
 
 
 def build_library(force=False, verbose=False):
-    os.makedirs(LIB_DIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
-    if force or _stale(LIB_PATH, deps):
-        cmd = [_hipcc()] + HIPCC_FLAGS + srcs + ["-o", LIB_PATH]
+    """One object per translation unit (compiled in parallel, rebuilt when the unit or ANY header
+    of csrc/ or include/wost.h is newer), then one link."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    headers.append(os.path.join(_HERE, "..", "include", "wost.h"))
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs, objs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ_DIR, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    if force or jobs or _stale(LIB_PATH, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -67,6 +67,27 @@ struct DevSettings {
     float dirichlet_intensity, neumann_intensity;
 };
 
+// ---- block-level stream compaction (shared by the uniform and the guided kernels) --------------
+// Up to 1024 threads, every thread of the block must call it: ballot + popcount inside a wave, one
+// atomic per block on the queue counter; returns the output slot of this lane (valid when `keep`).
+__device__ __forceinline__ uint32_t block_push(bool keep, uint32_t *counter)
+{
+    __shared__ uint32_t s_cnt[16], s_base;
+    const unsigned long long bal = __ballot(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63) >> 6;
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < n_waves; ++w) total += s_cnt[w];
+        s_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_base;
+    for (int w = 0; w < wave; ++w) base += s_cnt[w];
+    return base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+}
+
 // ---- evaluation grid (reference core/evaluation_grid.h:27-33) --------------------------
 __device__ __forceinline__ void eval_point(const DevProbe &p, int px, int py, int width, int height,
                                            float &x, float &y)

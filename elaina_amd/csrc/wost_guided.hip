@@ -146,25 +146,6 @@ __device__ __forceinline__ void wave_count(bool pred, unsigned long long *counte
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(counter, (unsigned long long)__popcll(bal));
 }
 
-// block-level compaction (256 threads, every thread of the block must call it): one atomic per
-// block on the queue counter instead of one per wave
-__device__ __forceinline__ uint32_t block_push(bool keep, uint32_t *counter)
-{
-    __shared__ uint32_t s_cnt[4], s_base;
-    const unsigned long long bal = __ballot(keep);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(bal);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        s_base = total ? atomicAdd(counter, total) : 0u;
-    }
-    __syncthreads();
-    uint32_t base = s_base;
-    for (int w = 0; w < wave; ++w) base += s_cnt[w];
-    return base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-}
-
 __device__ __forceinline__ GStatsDev *my_stats(GStatsDev *stats) { return stats + (blockIdx.x & (kStatCopies - 1)); }
 
 // ---- start of a sample: every unmasked pixel queues its evaluation point ---------------------

@@ -64,26 +64,6 @@ struct alignas(256) StatsDev {
 };
 __device__ __forceinline__ StatsDev *my_stats(StatsDev *s) { return s + (blockIdx.x & (kStatCopies - 1)); }
 
-// block-level stream compaction (up to 1024 threads, every thread of the block must call it): one atomic
-// per block on the queue counter; returns the output slot of this lane (valid when `keep`)
-__device__ __forceinline__ uint32_t block_push(bool keep, uint32_t *counter)
-{
-    __shared__ uint32_t s_cnt[16], s_base;
-    const unsigned long long bal = __ballot(keep);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63) >> 6;
-    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(bal);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (int w = 0; w < n_waves; ++w) total += s_cnt[w];
-        s_base = total ? atomicAdd(counter, total) : 0u;
-    }
-    __syncthreads();
-    uint32_t base = s_base;
-    for (int w = 0; w < wave; ++w) base += s_cnt[w];
-    return base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-}
-
 struct RoundParams {
     DevMesh dm, nm;
     DevSettings st;
@@ -479,10 +459,6 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
     }
 }
 
-}  // namespace wost
-#include "wost_pool.h"
-namespace wost {
-
 // ------------------------------------------------------------------------------------------
 // batch query kernels (the lbvh::query_device call sites, exposed for tests and SDF renders)
 // ------------------------------------------------------------------------------------------
@@ -674,13 +650,6 @@ struct wost_context {
     int wait_weight = 8;
     int trav_burst = 3;
     int top_levels = 3;
-    int kernel = 0;        // 0 = round kernel (walker per lane), 1 = pool kernel (walkers in LDS)
-    int pool_k = 2;        // pool kernel: 64 * pool_k walkers per wave
-    int step_weight = 8;
-    int waves_per_cu = 0;  // pool kernel: 0 = as many as LDS admits
-    int pool_stack = 8;    // pool kernel: traversal stack entries kept in LDS per walker
-    uint32_t *spill = nullptr;
-    size_t spill_words = 0;
     int time_kernels = 1;
     int refill = -1;       // -1 = automatic (few samples per pixel), 0 = never, 1 = always
     uint32_t *cursor = nullptr;
@@ -725,7 +694,6 @@ static void destroy_ctx(wost_context *c)
     if (c->counts) (void)hipFree(c->counts);
     if (c->stats) (void)hipFree(c->stats);
     if (c->field) (void)hipFree(c->field);
-    if (c->spill) (void)hipFree(c->spill);
     if (c->cursor) (void)hipFree(c->cursor);
     if (c->host_count) (void)hipHostFree(c->host_count);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -841,21 +809,6 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "top_levels") {
         if (value < 0 || value > 6) return fail(WOST_ERR_INVALID, "top_levels must be in 0..6");
         h->top_levels = (int)value;
-    } else if (k == "kernel") {
-        if (value != 0 && value != 1) return fail(WOST_ERR_INVALID, "kernel must be 0 (round) or 1 (pool)");
-        h->kernel = (int)value;
-    } else if (k == "pool_k") {
-        if (value < 1 || value > 4) return fail(WOST_ERR_INVALID, "pool_k must be in 1..4");
-        h->pool_k = (int)value;
-    } else if (k == "step_weight") {
-        if (value < 1 || value > 512) return fail(WOST_ERR_INVALID, "step_weight must be in 1..512");
-        h->step_weight = (int)value;
-    } else if (k == "pool_stack") {
-        if (value < 3 || value > 64) return fail(WOST_ERR_INVALID, "pool_stack must be in 3..64");
-        h->pool_stack = (int)value;
-    } else if (k == "waves_per_cu") {
-        if (value < 0 || value > 32) return fail(WOST_ERR_INVALID, "waves_per_cu must be in 0..32");
-        h->waves_per_cu = (int)value;
     } else if (k == "spp") {
         if (value < 0 || value >= (1 << 20)) return fail(WOST_ERR_INVALID, "spp must be in 0..2^20-1");
         h->settings.spp = (int32_t)value;
@@ -922,66 +875,6 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     int cur = 0;
     const bool emissive = c->nm.view.n_segs > 0 && c->nm.view.emissive;
     const bool ntree = c->nm.view.n_segs > WOST_FLAT_MAX;
-    if (c->kernel == 1 && n_active > 0 && c->src.rgb == nullptr) {
-        // ---- pool kernel: one launch walks every pixel of this call ----
-        PoolParams pp{};
-        pp.dm = c->dm.view;
-        pp.nm = c->nm.view;
-        pp.st = c->dst;
-        pp.q = c->queue[0];
-        pp.n_walkers = n_active;
-        pp.next = c->counts + 1;
-        pp.field = field_dev;
-        pp.field_base = field_base;
-        pp.stats = c->stats;
-        const int full_stack = 3 * levels_any + 1;
-        pp.stack_words = std::min(full_stack, c->pool_stack);
-        pp.step_weight = c->step_weight;
-        const int K = c->pool_k;
-        const size_t pool_lds = ((size_t)(kPoolWordsPerWalker + pp.stack_words) * 64 * K + 64) * sizeof(uint32_t);
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-        int waves_per_cu = (int)((160 * 1024) / pool_lds);
-        if (waves_per_cu < 1) return fail(WOST_ERR_UNSUPPORTED, "tree too deep for the LDS walker pool");
-        if (c->waves_per_cu > 0) waves_per_cu = std::min(waves_per_cu, c->waves_per_cu);
-        const unsigned want = (n_active + 64 * K - 1) / (64 * K);
-        const unsigned grid = std::min<unsigned>(want, (unsigned)(prop.multiProcessorCount * waves_per_cu));
-        // overflow columns of the traversal stacks (entries beyond the LDS part)
-        const size_t spill_words = (size_t)std::max(1, full_stack - pp.stack_words) * grid * 64 * K;
-        if (c->spill_words < spill_words) {
-            if (c->spill) (void)hipFree(c->spill);
-            c->spill = nullptr;
-            c->spill_words = 0;
-            HIP_TRY(hipMalloc((void **)&c->spill, spill_words * sizeof(uint32_t)));
-            c->spill_words = spill_words;
-        }
-        pp.spill = c->spill;
-        HIP_TRY(hipMemsetAsync(c->counts + 1, 0, sizeof(uint32_t), stream));
-        if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
-#define WOST_LAUNCH_POOL(E, T, KK) hipLaunchKernelGGL((walk_pool_kernel<E, T, KK>), dim3(grid), dim3(64), pool_lds, stream, pp)
-#define WOST_LAUNCH_POOL_K(E, T)                                                                              \
-    do {                                                                                                      \
-        if (K == 1) WOST_LAUNCH_POOL(E, T, 1); else if (K == 2) WOST_LAUNCH_POOL(E, T, 2);                    \
-        else if (K == 3) WOST_LAUNCH_POOL(E, T, 3); else WOST_LAUNCH_POOL(E, T, 4);                           \
-    } while (0)
-        if (ntree) {
-            if (emissive) WOST_LAUNCH_POOL_K(true, true); else WOST_LAUNCH_POOL_K(false, true);
-        } else {
-            if (emissive) WOST_LAUNCH_POOL_K(true, false); else WOST_LAUNCH_POOL_K(false, false);
-        }
-#undef WOST_LAUNCH_POOL_K
-#undef WOST_LAUNCH_POOL
-        HIP_TRY(hipGetLastError());
-        if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev1, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (c->time_kernels) {
-            float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-            kernel_ms += ms;
-        }
-        launches = 1;
-        n_active = 0;
-    }
     while (n_active > 0) {
         const int nxt = cur ^ 1;
         HIP_TRY(hipMemsetAsync(c->counts + nxt, 0, sizeof(uint32_t), stream));

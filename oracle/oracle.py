@@ -14,14 +14,10 @@ _BUILD = os.path.join(_HERE, "_build")
 
 
 def build(force=False):
-    """Compile the oracle with gcc (plain C, seconds)."""
+    """Compile the oracle with gcc (plain C, seconds).  The Makefile lists every source and header
+    of both libraries, so `make` itself decides what is stale."""
     targets = [os.path.join(_BUILD, "libwost_oracle.so"), os.path.join(_BUILD, "libwost_oracle_libm.so")]
-    src = [os.path.join(_HERE, "wost_oracle.c"), os.path.join(_HERE, "wost_oracle.h"), os.path.join(_HERE, "wost_vmm.c"), os.path.join(_HERE, "wost_net.c")]
-    stale = force or any(
-        (not os.path.exists(t)) or os.path.getmtime(t) < max(os.path.getmtime(s) for s in src) for t in targets
-    )
-    if stale:
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return targets[0]
 
 

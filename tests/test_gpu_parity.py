@@ -131,21 +131,11 @@ def test_round_length_does_not_change_results(oracle, ladybug, steps_per_round):
 
 
 @pytest.mark.parametrize("opts", [
-    {"kernel": 1, "pool_k": 1}, {"kernel": 1, "pool_k": 2, "pool_stack": 3}, {"kernel": 1, "pool_k": 3, "pool_stack": 8},
-    {"kernel": 1, "pool_k": 4, "pool_stack": 64, "step_weight": 2}, {"kernel": 1, "pool_k": 2, "waves_per_cu": 1},
-    {"kernel": 0, "wait_weight": 1, "top_levels": 0}, {"kernel": 0, "wait_weight": 64, "top_levels": 6},
+    {"wait_weight": 1, "top_levels": 0}, {"wait_weight": 64, "top_levels": 6}, {"trav_burst": 1}, {"trav_burst": 7},
 ])
 def test_kernel_variants_do_not_change_results(oracle, ladybug, opts):
-    # the walker-pool kernel (walkers migrate between lanes through LDS, short LDS stack with
-    # global overflow) and the scheduler knobs of the round kernel: same bits, same counters
+    # the scheduler knobs of the round kernel: same bits, same counters
     _assert_same_solve(oracle, ladybug, 56, 48, 6, 32, 1.0, **opts)
-
-
-def test_pool_kernel_emissive_and_ragged(oracle):
-    flux = lambda x, y, side: -1.0 if side == 2 else 1.0
-    p = box_problem(0.0, 100.0, 25, d_sides=(1, 3), n_sides=(0, 2), value=lambda x, y: y, flux=flux,
-                    probe=(40.0, 50.0, 50.0, 0.0, 1.0))
-    _assert_same_solve(oracle, p, 19, 13, 32, 512, 0.25, kernel=1, pool_k=2, pool_stack=4)
 
 
 @pytest.mark.parametrize("block_size", [64, 128, 256])
@@ -293,7 +283,7 @@ def test_large_neumann_mesh_silhouette_and_ray_queries(oracle, open_gap):
     it.close()
 
 
-@pytest.mark.parametrize("opts", [{"kernel": 0}, {"kernel": 1, "pool_k": 2, "pool_stack": 5}])
+@pytest.mark.parametrize("opts", [{}, {"refill": 1}])
 def test_large_neumann_mesh_solve(oracle, opts):
     from conftest import wiggly_problem
     p = wiggly_problem(3000, 400)
