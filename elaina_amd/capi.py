@@ -109,6 +109,7 @@ class GuidedStats(C.Structure):
         ("walks_truncated", C.c_uint64), ("neumann_hits", C.c_uint64), ("guided_steps", C.c_uint64),
         ("train_samples", C.c_uint64), ("optimizer_steps", C.c_uint64),
         ("solve_ms", C.c_double), ("train_ms", C.c_double), ("kernel_launches", C.c_uint32), ("reserved", C.c_uint32),
+        ("net_points", C.c_uint64), ("net_infer_ms", C.c_double),
     ]
 
     def as_dict(self):
@@ -117,7 +118,7 @@ class GuidedStats(C.Structure):
 
 # wost_sync_fn (include/wost.h): int (*)(void *user, int op, void *data, uint64_t count)
 SYNC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64)
-SYNC_SUM_I64_DEVICE, SYNC_MIN_I64_HOST = 0, 1
+SYNC_SUM_I64_DEVICE, SYNC_MIN_I64_HOST, SYNC_RANKS_I64_HOST = 0, 1, 2
 # wost_frame_fn: int (*)(void *user, int reason, int32_t sample_id, double elapsed_ms, const float *field_rgb)
 FRAME_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_double, C.POINTER(C.c_float))
 

@@ -53,7 +53,60 @@ struct GQueue {
 // kStatCopies copies 256 bytes apart, a wave adds to the copy of its block, and the host sums them.
 constexpr int kStatCopies = 64;
 struct alignas(256) GStatsDev {
-    unsigned long long steps, started, absorbed, truncated, nhits, guided;
+    unsigned long long steps, started, absorbed, truncated, nhits, guided, net_points;
+};
+
+// HIP-event pairs around selected launches, read back lazily: a pair is only waited for when its
+// slot of the ring comes up again, so the host keeps running ahead of the GPU.
+struct EventRing {
+    std::vector<hipEvent_t> ev;     // 2 per slot
+    size_t next = 0, pending = 0;
+    double total_ms = 0.0;
+    hipError_t init(size_t slots)
+    {
+        ev.resize(2 * slots, nullptr);
+        for (hipEvent_t &e : ev) {
+            hipError_t rc = hipEventCreate(&e);
+            if (rc != hipSuccess) return rc;
+        }
+        return hipSuccess;
+    }
+    void destroy()
+    {
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+        ev.clear();
+    }
+    void collect_one()
+    {
+        const size_t slots = ev.size() / 2, oldest = (next + slots - pending) % slots;
+        float ms = 0.0f;
+        if (hipEventSynchronize(ev[2 * oldest + 1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, ev[2 * oldest], ev[2 * oldest + 1]) == hipSuccess)
+            total_ms += ms;
+        --pending;
+    }
+    size_t begin(hipStream_t s)
+    {
+        const size_t slots = ev.size() / 2;
+        if (pending == slots) collect_one();
+        const size_t slot = next;
+        (void)hipEventRecord(ev[2 * slot], s);
+        return slot;
+    }
+    void end(size_t slot, hipStream_t s)
+    {
+        (void)hipEventRecord(ev[2 * slot + 1], s);
+        next = (next + 1) % (ev.size() / 2);
+        ++pending;
+    }
+    double drain()
+    {
+        while (pending) collect_one();
+        const double t = total_ms;
+        total_ms = 0.0;
+        return t;
+    }
 };
 
 struct GAabb {
@@ -467,6 +520,7 @@ __global__ __launch_bounds__(256) void sample_kernel(GParams P)
         }
     }
     wave_count(guided_step, &my_stats(P.stats)->guided);
+    wave_count(live && P.guiding, &my_stats(P.stats)->net_points);
     wave_count(hit_n, &my_stats(P.stats)->nhits);
     if (P.last_depth) wave_count(alive_after, &my_stats(P.stats)->truncated);
 }
@@ -619,6 +673,7 @@ struct wost_guided {
     wost_frame_fn frame_fn = nullptr;  // intermediate frames (saveSppMetrics / saveTimeMetrics)
     void *frame_user = nullptr;
     int32_t frame_spp_every = 0, frame_spp_until = 0, frame_time_every = 0;
+    EventRing net_events;              // timing of the network-evaluating launches
 };
 
 #define G_TRY(expr)                                                                                      \
@@ -647,6 +702,7 @@ static void guided_free(wost_guided *g)
     if (g->host_counts) (void)hipHostFree(g->host_counts);
     if (g->depth_counts) (void)hipHostFree(g->depth_counts);
     for (hipEvent_t e : g->depth_events) (void)hipEventDestroy(e);
+    g->net_events.destroy();
     if (g->net) wost_net_destroy(g->net);
     if (g->scene) wost_destroy(g->scene);
     delete g;
@@ -719,6 +775,7 @@ int wost_guided_create(const wost_scene_desc *scene, const wost_guided_settings 
         e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (e == hipSuccess) g->depth_events.push_back(ev);
     }
+    if (e == hipSuccess) e = g->net_events.init(1024);
     if (e != hipSuccess) {
         set_error(WOST_ERR_DEVICE, std::string("guided allocation: ") + hipGetErrorString(e));
         return bail(WOST_ERR_DEVICE);
@@ -819,6 +876,15 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     const int opt_before = net_optimizer_steps(g->net);
 
     G_TRY(hipMemsetAsync(g->stats, 0, kStatCopies * sizeof(GStatsDev), stream));
+    if (g->sync) {
+        // shared network: the summed gradients are divided by the number of ranks (include/wost.h)
+        int64_t ranks = 1;
+        if (g->sync(g->sync_user, WOST_SYNC_RANKS_I64_HOST, &ranks, 1) != 0 || ranks < 1)
+            return set_error(WOST_ERR_DEVICE, "sync callback failed (rank count)");
+        net_set_gradient_divisor(g->net, (float)ranks);
+    } else {
+        net_set_gradient_divisor(g->net, 1.0f);
+    }
     GParams P{};
     P.dm = v.dm; P.nm = v.nm; P.st = v.st; P.probe = v.probe; P.src = v.src; P.box = g->box; P.mask = v.mask;
     P.rng = g->rng; P.sol = g->sol; P.cur_depth = g->cur_depth; P.rec = g->rec; P.hint0 = g->hint0;
@@ -890,7 +956,9 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
             if (polled == depth && n_cur == 0) break;      // known to be empty
             const uint32_t n_out = n_cur;                  // an upper bound
             if (P.guiding) {
+                const size_t ev = g->net_events.begin(stream);
                 int rc = net_inference_dev(g->net, g->net_in, g->counts + nxt, (int)n_out, g->net_out, true, stream, (size_t)N);
+                g->net_events.end(ev, stream);
                 if (rc != WOST_OK) return rc;
                 ++launches;
             }
@@ -995,8 +1063,9 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     GStatsDev hs{};
     for (const GStatsDev &c : copies) {
         hs.steps += c.steps; hs.started += c.started; hs.absorbed += c.absorbed;
-        hs.truncated += c.truncated; hs.nhits += c.nhits; hs.guided += c.guided;
+        hs.truncated += c.truncated; hs.nhits += c.nhits; hs.guided += c.guided; hs.net_points += c.net_points;
     }
+    const double net_infer_ms = g->net_events.drain();
     if (stats) {
         *stats = wost_guided_stats{};
         stats->walk_steps = hs.steps; stats->walks_started = hs.started; stats->walks_absorbed = hs.absorbed;
@@ -1005,6 +1074,8 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         stats->optimizer_steps = (uint64_t)(net_optimizer_steps(g->net) - opt_before);
         stats->train_ms = train_ms;
         stats->kernel_launches = launches;
+        stats->net_points = hs.net_points;
+        stats->net_infer_ms = net_infer_ms;
         stats->solve_ms =
             std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_start).count();
     }

@@ -1038,7 +1038,13 @@ __global__ void transpose_mlp_kernel(NetLayout L, const float *src, float *dst)
     dst[L.w_off[layer] + k * n_o + r] = src[i];
 }
 
-// tiny-cuda-nn adam.h adam_step nested in ema.h (debiased): step counts from 1
+// tiny-cuda-nn's adam_step (optimizers/adam.h) nested in its EMA optimizer (optimizers/ema.h), which is
+// what the reference trains with (data/ladybug/n.json:69-81), step counts from 1: L2 regularisation
+// only on the matrix weights; an encoding parameter whose gradient is exactly zero is not touched (no
+// moment decay, no step); every parameter debiases with ITS OWN step count (lr_table[s] =
+// lr sqrt(1 - b2^s) / (1 - b1^s), tabulated on the host so that the oracle's powf and this kernel agree
+// bit for bit); the EMA runs over all parameters.  grad_div: number of ranks whose gradients were
+// summed (shared-network mode).
 // The copies of the MLP matrices in other orders (transposed for the scalar forward pass, MFMA
 // fragments for the forward and backward kernels) are written here too: the inverse of the index
 // maps of transpose_mlp_kernel / fragment_mlp_kernel / fragment_mlp_t_kernel, five launches less
@@ -1048,18 +1054,24 @@ struct DerivedLayouts {
 };
 
 __global__ void optimizer_kernel(NetLayout L, uint32_t n, float *params, float *m1, float *m2, float *ema_raw, float *inference,
-                                 const fx_t *grad, float lr_t, float beta1, float beta2, float eps, float l2, float decay,
-                                 float debias, float loss_scale, DerivedLayouts D)
+                                 const fx_t *grad, const float *lr_table, uint32_t *param_steps, float beta1, float beta2,
+                                 float eps, float l2, float decay, float debias, float loss_scale, float grad_div,
+                                 DerivedLayouts D)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float w = params[i];
     float g = (float)((double)grad[i] / kFxScale) / loss_scale;
-    g += l2 * w;
-    const float a = m1[i] = beta1 * m1[i] + (1.0f - beta1) * g;
-    const float b = m2[i] = beta2 * m2[i] + (1.0f - beta2) * (g * g);
-    const float nw = w - (lr_t / (sqrtf(b) + eps)) * a;
-    params[i] = nw;
+    if (grad_div != 1.0f) g = g / grad_div;
+    float nw = w;
+    if (i < L.n_mlp || g != 0.0f) {
+        if (i < L.n_mlp) g += l2 * w;
+        const float a = m1[i] = beta1 * m1[i] + (1.0f - beta1) * g;
+        const float b = m2[i] = beta2 * m2[i] + (1.0f - beta2) * (g * g);
+        const uint32_t s = ++param_steps[i];
+        nw = w - (lr_table[s] / (sqrtf(b) + eps)) * a;
+        params[i] = nw;
+    }
     const float e = ema_raw[i] = decay * ema_raw[i] + (1.0f - decay) * nw;
     const float inf = e * debias;
     inference[i] = inf;
@@ -1102,6 +1114,10 @@ struct wost_net {
     bool use_mfma = false;
     bool fused_backward = true;      // net_backward_wgrad_kernel (WOST_NET_FUSED=0: backward and weight gradients apart)
     int step = 0;
+    uint32_t *param_steps = nullptr;   // Adam steps taken by each parameter (tiny-cuda-nn adam_step)
+    float *lr_table = nullptr;         // debiased learning rate of step s at [s], s = 1 .. lr_cap
+    int lr_cap = 0;
+    float grad_div = 1.0f;             // shared-network mode: ranks whose gradients are summed
     // scratch (grown on demand)
     float *d_xy = nullptr, *d_out = nullptr, *d_dl = nullptr, *d_acts = nullptr, *d_deltas = nullptr, *d_denc = nullptr;
     unsigned long long *d_mask = nullptr;   // MFMA path: signs of the hidden activations, 4 words per point
@@ -1197,6 +1213,8 @@ static void net_free(wost_net *h)
         if (p) (void)hipFree(p);
     if (h->grad && h->grad_owned) (void)hipFree(h->grad);
     if (h->d_mask) (void)hipFree(h->d_mask);
+    if (h->param_steps) (void)hipFree(h->param_steps);
+    if (h->lr_table) (void)hipFree(h->lr_table);
     delete h;
 }
 
@@ -1318,14 +1336,26 @@ int net_apply_update_dev(wost_net *h, float loss_scale, hipStream_t stream)
 {
     h->step += 1;
     const wost_net_config &c = h->cfg;
-    const float lr_t = c.learning_rate * std::sqrt(1.0f - std::pow(c.beta2, (float)h->step)) /
-                       (1.0f - std::pow(c.beta1, (float)h->step));
+    if (h->step > h->lr_cap) {
+        // grow the table of debiased learning rates (same expression as the oracle, evaluated by the
+        // host's libm on both sides)
+        const int cap = std::max(4096, 2 * h->step);
+        std::vector<float> tab((size_t)cap + 1, 0.0f);
+        for (int s_ = 1; s_ <= cap; ++s_)
+            tab[s_] = c.learning_rate * std::sqrt(1.0f - std::pow(c.beta2, (float)s_)) / (1.0f - std::pow(c.beta1, (float)s_));
+        NET_TRY(hipStreamSynchronize(stream));
+        if (h->lr_table) (void)hipFree(h->lr_table);
+        h->lr_table = nullptr;
+        NET_TRY(hipMalloc((void **)&h->lr_table, tab.size() * sizeof(float)));
+        NET_TRY(hipMemcpy(h->lr_table, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+        h->lr_cap = cap;
+    }
     const float debias = 1.0f / (1.0f - std::pow(c.ema_decay, (float)h->step));
     DerivedLayouts D{h->params_t, h->inference_t, nullptr, nullptr, nullptr};
     if (h->use_mfma) { D.params_f = h->params_f; D.inference_f = h->inference_f; D.params_fb = h->params_fb; }
     hipLaunchKernelGGL(optimizer_kernel, dim3((h->n_params + 255) / 256), dim3(256), 0, stream, h->L, h->n_params, h->params, h->m1,
-                       h->m2, h->ema_raw, h->inference, h->grad, lr_t, c.beta1, c.beta2, c.epsilon, c.l2_reg, c.ema_decay,
-                       debias, loss_scale, D);
+                       h->m2, h->ema_raw, h->inference, h->grad, h->lr_table, h->param_steps, c.beta1, c.beta2, c.epsilon,
+                       c.l2_reg, c.ema_decay, debias, loss_scale, h->grad_div, D);
     NET_TRY(hipGetLastError());
     return WOST_OK;
 }
@@ -1337,6 +1367,7 @@ void *net_gradient_buffer(wost_net *h, uint64_t *count)
 }
 
 int net_optimizer_steps(const wost_net *h) { return h->step; }
+void net_set_gradient_divisor(wost_net *h, float ranks) { h->grad_div = ranks > 0.0f ? ranks : 1.0f; }
 int net_n_output(const wost_net *h) { return h->L.n_out; }
 
 }  // namespace wost
@@ -1400,6 +1431,8 @@ int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_
         if (e == hipSuccess) e = hipMemset(p, 0, bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&h->grad, (size_t)h->n_params * sizeof(fx_t));
     if (e == hipSuccess) e = hipMemset(h->grad, 0, (size_t)h->n_params * sizeof(fx_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->param_steps, (size_t)h->n_params * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(h->param_steps, 0, (size_t)h->n_params * sizeof(uint32_t));
     if (e != hipSuccess) {
         net_free(h);
         return set_error(WOST_ERR_DEVICE, std::string("network allocation: ") + hipGetErrorString(e));
@@ -1467,6 +1500,7 @@ int wost_net_set_params(wost_net_handle h, const float *host)
     NET_TRY(hipMemcpy(h->params, host, bytes, hipMemcpyHostToDevice));
     NET_TRY(hipMemcpy(h->inference, host, bytes, hipMemcpyHostToDevice));
     for (float *p : {h->m1, h->m2, h->ema_raw}) NET_TRY(hipMemset(p, 0, bytes));
+    NET_TRY(hipMemset(h->param_steps, 0, (size_t)h->n_params * sizeof(uint32_t)));
     h->step = 0;
     int rc = refresh_transposed(h, nullptr);
     if (rc != WOST_OK) return rc;

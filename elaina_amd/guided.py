@@ -244,6 +244,8 @@ class GuidedIntegrator:
                 if op == capi.SYNC_SUM_I64_DEVICE:
                     dist.all_reduce(self._grad, op=dist.ReduceOp.SUM)
                     torch.cuda.synchronize()
+                elif op == capi.SYNC_RANKS_I64_HOST:
+                    C.cast(data, C.POINTER(C.c_int64))[0] = dist.get_world_size()
                 else:
                     v = C.cast(data, C.POINTER(C.c_int64))
                     t = torch.tensor([v[0]], dtype=torch.int64, device="cuda")

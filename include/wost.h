@@ -255,6 +255,8 @@ typedef struct wost_guided_stats {
     double train_ms;             /* part of it spent building training sets and training          */
     uint32_t kernel_launches;
     uint32_t reserved;
+    uint64_t net_points;         /* network evaluations made for walkers (out-of-shell entries of guided depths) */
+    double net_infer_ms;         /* GPU time of the launches that evaluate the network for walkers (HIP events)  */
 } wost_guided_stats;
 
 typedef struct wost_guided *wost_guided_handle;
@@ -288,9 +290,15 @@ int wost_guided_solve_sharded(wost_guided_handle h, int32_t shard_index, int32_t
  * e.g. ncclAllReduce(.., ncclInt64, ncclSum, ..) followed by a stream synchronisation), and once per
  * training pass it must reduce the number of usable batches to the minimum over the ranks
  * (WOST_SYNC_MIN_I64_HOST: data = host int64[1]).  Integer sums make the result independent of
- * the reduction order: all ranks hold the same network bit for bit.  Return 0 on success. */
+ * the reduction order: all ranks hold the same network bit for bit.  At the start of a solve the
+ * callback is asked once for the number of ranks (WOST_SYNC_RANKS_I64_HOST: it writes host
+ * int64[1]); the summed gradient is divided by it before the Adam step, so that a shared step is
+ * the step of ONE batch of ranks x batch_size samples (each rank normalises its loss gradient by
+ * its own batch) and the L2 term and epsilon keep their weight for any rank count.
+ * Return 0 on success. */
 #define WOST_SYNC_SUM_I64_DEVICE 0
 #define WOST_SYNC_MIN_I64_HOST 1
+#define WOST_SYNC_RANKS_I64_HOST 2
 typedef int (*wost_sync_fn)(void *user, int op, void *data, uint64_t count);
 int wost_guided_set_sync(wost_guided_handle h, wost_sync_fn fn, void *user);
 /* Intermediate frames (saveSppMetrics* / saveTimeMetrics* of GuidedIntegratorSettings, reference

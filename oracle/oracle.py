@@ -397,7 +397,9 @@ class Oracle:
 
     def net_optimizer_state(self, cfg):
         n = self.net_n_params(cfg)
-        return {k: np.zeros(n, dtype=np.float32) for k in ("m1", "m2", "ema_raw")}
+        st = {k: np.zeros(n, dtype=np.float32) for k in ("m1", "m2", "ema_raw")}
+        st["steps"] = np.zeros(n, dtype=np.uint32)      # per-parameter Adam step counters (tiny-cuda-nn adam_step)
+        return st
 
     def net_optimizer_step(self, cfg, params, state, grad, step, loss_scale):
         """updates params and state in place, returns the inference (EMA) parameters"""
@@ -405,7 +407,8 @@ class Oracle:
         g = np.ascontiguousarray(grad, dtype=np.float32)
         inf = np.zeros_like(params)
         self.lib.wo_net_optimizer_step(C.byref(cfg), _fp(params), _fp(state["m1"]), _fp(state["m2"]), _fp(state["ema_raw"]),
-                                       _fp(inf), _fp(g), step, C.c_float(loss_scale))
+                                       _fp(inf), _fp(g), step, C.c_float(loss_scale),
+                                       state["steps"].ctypes.data_as(C.POINTER(C.c_uint32)))
         return inf
 
     # ---- guided path: von Mises / mixture --------------------------------------------------

@@ -160,6 +160,7 @@ int wo_solve_guided(const wo_scene *sc, const wo_guided_settings *gs, const wo_n
     g_pixel *px = calloc((size_t)N, sizeof(g_pixel));
     float *inf_params = malloc(sizeof(float) * n_params);
     float *m1 = calloc(n_params, sizeof(float)), *m2 = calloc(n_params, sizeof(float)), *ema = calloc(n_params, sizeof(float));
+    uint32_t *param_steps = calloc(n_params, sizeof(uint32_t));
     float *grad = malloc(sizeof(float) * n_params);
     float *net_in = malloc(sizeof(float) * 2 * (size_t)N);
     float *net_out = malloc(sizeof(float) * (size_t)NO * N);
@@ -427,7 +428,7 @@ int wo_solve_guided(const wo_scene *sc, const wo_guided_settings *gs, const wo_n
                 free(raw33); free(dl33);
                 wo_net_backward(nc, params, t_xy + 2 * o, t_dl, (int)local, grad);
                 opt_step++;
-                wo_net_optimizer_step(nc, params, m1, m2, ema, inf_params, grad, opt_step, gs->loss_scale);
+                wo_net_optimizer_step(nc, params, m1, m2, ema, inf_params, grad, opt_step, gs->loss_scale, param_steps);
             }
         }
     }
@@ -438,7 +439,7 @@ int wo_solve_guided(const wo_scene *sc, const wo_guided_settings *gs, const wo_n
         stats->walks_truncated = truncated; stats->neumann_hits = nhits; stats->guided_steps = guided_steps;
         stats->train_samples = train_samples; stats->optimizer_steps = (uint64_t)opt_step;
     }
-    free(px); free(inf_params); free(m1); free(m2); free(ema); free(grad); free(net_in); free(net_out); free(slot_of);
+    free(px); free(inf_params); free(m1); free(m2); free(ema); free(param_steps); free(grad); free(net_in); free(net_out); free(slot_of);
     free(t_xy); free(t_dir); free(t_li); free(t_pdf); free(t_nrm); free(t_sol); free(t_onn); free(t_out); free(t_dl);
     pmesh_free(&dm); pmesh_free(&nm);
     return 0;

@@ -224,21 +224,37 @@ int wo_net_backward(const wo_net_config *c, const float *params, const float *xy
     return 0;
 }
 
-/* one optimizer step (tiny-cuda-nn adam.h adam_step nested in ema.h): step counts from 1 */
+/* one optimizer step: tiny-cuda-nn's adam_step (include/tiny-cuda-nn/optimizers/adam.h, v1.6/v1.7:
+ * pinned commit unknown) nested in its EMA optimizer (optimizers/ema.h), the pair the
+ * reference configures in data/ladybug/n.json:69-81.  Restated from the published kernel:
+ *   - gradient = grad / loss_scale;
+ *   - a NON-matrix parameter (the grid encoding, i >= n_matrix_weights) whose gradient is exactly 0
+ *     is left alone: no moment decay, no step, no step count;
+ *   - l2_reg * w is added for matrix weights only;
+ *   - every parameter debiases with its own step counter param_steps[i] (matrix weights move on
+ *     every step, so theirs equals `step`);
+ *   - the EMA (ema_step) runs over all parameters with the global step.
+ * `step` counts from 1; param_steps is n_params zero-initialised counters owned by the caller. */
 int wo_net_optimizer_step(const wo_net_config *c, float *params, float *m1, float *m2, float *ema_raw,
-                          float *inference_params, const float *grad, int step, float loss_scale)
+                          float *inference_params, const float *grad, int step, float loss_scale, uint32_t *param_steps)
 {
-    const uint64_t n = wo_net_n_params(c);
-    const float lr = c->learning_rate * sqrtf(1.0f - powf(c->beta2, (float)step)) / (1.0f - powf(c->beta1, (float)step));
+    wn_layout l;
+    layout(c, &l);
+    const uint64_t n = l.n_mlp + l.n_grid;
     const float debias = 1.0f / (1.0f - powf(c->ema_decay, (float)step));
     for (uint64_t i = 0; i < n; ++i) {
         const float w = params[i];
         float g = grad[i] / loss_scale;
-        g += c->l2_reg * w;
-        const float a = m1[i] = c->beta1 * m1[i] + (1.0f - c->beta1) * g;
-        const float b = m2[i] = c->beta2 * m2[i] + (1.0f - c->beta2) * (g * g);
-        const float nw = w - (lr / (sqrtf(b) + c->epsilon)) * a;
-        params[i] = nw;
+        float nw = w;
+        if (i < l.n_mlp || g != 0.0f) {
+            if (i < l.n_mlp) g += c->l2_reg * w;
+            const float a = m1[i] = c->beta1 * m1[i] + (1.0f - c->beta1) * g;
+            const float b = m2[i] = c->beta2 * m2[i] + (1.0f - c->beta2) * (g * g);
+            const uint32_t s = ++param_steps[i];
+            const float lr = c->learning_rate * sqrtf(1.0f - powf(c->beta2, (float)s)) / (1.0f - powf(c->beta1, (float)s));
+            nw = w - (lr / (sqrtf(b) + c->epsilon)) * a;
+            params[i] = nw;
+        }
         ema_raw[i] = c->ema_decay * ema_raw[i] + (1.0f - c->ema_decay) * nw;
         inference_params[i] = ema_raw[i] * debias;
     }

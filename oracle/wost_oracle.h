@@ -163,7 +163,7 @@ int wo_net_forward(const wo_net_config *c, const float *params, const float *xy,
 int wo_net_backward(const wo_net_config *c, const float *params, const float *xy, const float *dl_dout, int n,
                     float *grad);
 int wo_net_optimizer_step(const wo_net_config *c, float *params, float *m1, float *m2, float *ema_raw,
-                          float *inference_params, const float *grad, int step, float loss_scale);
+                          float *inference_params, const float *grad, int step, float loss_scale, uint32_t *param_steps);
 
 /* ---- guided integrator (oracle/wost_guided.c) ------------------------------------------ */
 typedef struct wo_guided_settings {

@@ -297,13 +297,20 @@ def test_large_emissive_neumann_mesh_solve(oracle):
     _assert_same_solve(oracle, p, 12, 10, 4, 64, 0.5)
 
 
+def _run_bench(cmd, timeout=900):
+    import json
+    import subprocess
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
 def test_bench_two_ranks_sharing_one_gpu():
     # the N > 1 path of bench.py end to end (tile sharding + reduce + JSON contract) with two
-    # processes on the one GPU of the test box; gloo carries the reduce because RCCL refuses
-    # two ranks on one device
-    import json
+    # processes on the one GPU of the test box under an EXTERNAL launcher (what the driver does);
+    # gloo carries the reduce because RCCL refuses two ranks on one device
     import socket
-    import subprocess
     import sys
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -312,13 +319,42 @@ def test_bench_two_ranks_sharing_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
            "--warmup", "0", "--frame", "128", "--spp", "8", "--backend", "gloo"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    r = json.loads(line)
-    assert r["n_gpus"] == 2 and r["metric"] == "walk-steps/s" and r["scaling"] == "strong"
+    r = _run_bench(cmd)
+    assert r["n_gpus"] == 2 and r["world_size"] == 2 and r["backend"] == "gloo"
+    assert r["metric"] == "walk-steps/s" and r["scaling"] == "strong"
     assert r["rel_l2_vs_oracle"] == 0.0                       # the assembled field, checked against the oracle
-    assert r["roofline"]["bound"] == "hbm" and "cpu_baseline" not in r     # host baseline: N = 1 only
+    assert r["roofline"]["kernel"] == "walk_round_kernel" and "cpu_baseline" not in r     # host baseline: N = 1 only
+
+
+def test_bench_starts_its_own_ranks():
+    # `python bench.py --gpus 2` WITHOUT a launcher: bench.py itself starts the two ranks (a child
+    # job spawned before the parent touches the GPU) and relays rank 0's line
+    import sys
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--frame", "128", "--spp", "8", "--backend", "gloo"], capture_output=True, text=True, timeout=900,
+                         cwd=ROOT, env=env_clean)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["world_size"] == 2 and r["rel_l2_vs_oracle"] == 0.0
+
+
+def test_bench_guided_config_two_ranks():
+    # --config 4 scaled down, two self-started ranks on one GPU: the guided integrator through the
+    # file the driver runs, shards + reduce, the MFMA fraction of the inference launches
+    import json
+    import subprocess
+    import sys
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--gpus", "2", "--steps", "1", "--warmup",
+                          "0", "--frame", "256", "--spp", "6", "--train-spp", "3", "--backend", "gloo"], capture_output=True,
+                         text=True, timeout=900, cwd=ROOT, env=env_clean)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["config"]["config"] == 4 and r["field_finite"]
+    assert r["guided"]["guided_steps_per_pass"] > 0 and r["roofline"]["bound"] == "mfma" and r["roofline"]["achieved"] > 0
 
 
 @pytest.mark.parametrize("scene,spp,depth", [("ladybug", 1, 64), ("ladybug", 5, 32), ("fille", 2, 128)])

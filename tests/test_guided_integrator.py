@@ -503,3 +503,93 @@ def test_gpu_full_frame_guided_properties(ladybug):
     ui.solve()
     assert abs(float(f1.mean()) - float(ui.solution.mean())) < 2e-3 * float(ui.solution.mean())
     ui.close()
+
+
+# ---- BASELINE config 5: the 2048 x 2048 frame, one shard of 8 ---------------------------------------
+def _band_of_shard_mask(w, h, rows, shard, shards):
+    """mask that keeps only the pixels of `rows` evaluation rows around the middle which shard
+    `shard` of `shards` owns (8x8 pixel tiles dealt round-robin)"""
+    from elaina_amd.distributed import owned_mask
+    m = np.zeros(w * h, np.uint8)
+    b = (h // 2 - rows // 2) * w
+    m[b:b + rows * w] = 1
+    m &= owned_mask(w, h, shard, shards).astype(np.uint8)
+    return m, b, b + rows * w
+
+
+@pytest.mark.gpu
+def test_gpu_config5_frame_shard_frozen_network_band_matches_oracle(oracle, ladybug):
+    """The frame of BASELINE config 5 (2048^2: four times the reference's fixed 1024^2 default mask,
+    core/problem.cu:245-247, and its MAX_RESOLUTION, guided/parameters.h:8) -- shard 0 of 8 of a
+    guided solve with the freshly initialised network and no training.  With a frozen network a
+    pixel does not depend on any other pixel, so the oracle walks only an 8-row band of the shard
+    (same frame, a mask selects the band) and the band must agree bit for bit; the default mask
+    (none) is sized to the frame: every owned pixel of the shard is walked."""
+    from elaina_amd.distributed import owned_mask
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    import torch
+    w = h = 2048
+    spp, depth = 8, 64
+    aabb = ((-100.0, -100.0), (600.0, 600.0))
+    st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=0, maxWalkingDepth=depth, epsilonShell=1.0)
+    gi = GuidedIntegrator(ladybug, st, aabb, seed=5)
+    p0 = gi.network.params()
+    field = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    stats = gi.solve_sharded(0, 8, field.data_ptr())
+    torch.cuda.synchronize()
+    got = field.cpu().numpy().reshape(-1, 3)
+    own = owned_mask(w, h, 0, 8)
+    assert stats["walks_started"] == int(own.sum()) * spp            # the whole shard, not a 1024^2 corner
+    assert not got[~own].any() and np.isfinite(got).all()
+    assert stats["guided_steps"] > 0 and stats["net_points"] > 0 and stats["optimizer_steps"] == 0
+    gi.close()
+    mask, b, e = _band_of_shard_mask(w, h, 8, 0, 8)
+    sd = ladybug.as_dict()
+    sd["mask"] = mask
+    gs = guided_settings(w, h, spp, depth, 1.0, aabb[0], aabb[1], train_spp_count=0)
+    ref = oracle.solve_guided(sd, gs, default_net_config(), p0.copy(), threads=16)
+    sel = mask.astype(bool)
+    assert ref["walks_started"] == int(sel.sum()) * spp
+    assert np.array_equal(got[sel], ref["field"][sel]), float(np.abs(got[sel] - ref["field"][sel]).max())
+
+
+@pytest.mark.gpu
+def test_gpu_config5_frame_shard_trained_solve(ladybug):
+    """shard 0 of 8 of the 2048^2 frame with 8 trained + 8 guided samples: counters, reproducibility
+    (same field and same network twice) and agreement with the uniform integrator on the same
+    pixels within Monte-Carlo noise (the guided estimator is unbiased for any network state)"""
+    from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+    from elaina_amd.distributed import owned_mask
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    import torch
+    w = h = 2048
+    aabb = ((-100.0, -100.0), (600.0, 600.0))
+    st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=16, trainSppCount=8, maxWalkingDepth=64, epsilonShell=1.0)
+    runs = []
+    for _ in range(2):
+        gi = GuidedIntegrator(ladybug, st, aabb, seed=9)
+        field = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+        s = gi.solve_sharded(0, 8, field.data_ptr())
+        torch.cuda.synchronize()
+        runs.append((field.cpu().numpy().reshape(-1, 3), gi.network.params(), s))
+        gi.close()
+    (f0, p0, s0), (f1, p1, s1) = runs
+    assert np.array_equal(f0, f1) and np.array_equal(p0, p1)
+    own = owned_mask(w, h, 0, 8)
+    n_own = int(own.sum())
+    assert n_own == w * h // 8 and s0["walks_started"] == n_own * 16
+    assert s0["optimizer_steps"] > 0 and s0["train_samples"] > n_own and s0["guided_steps"] > 0
+    assert s0["walks_absorbed"] + s0["walks_truncated"] == s0["walks_started"]
+    for k in ("walk_steps", "train_samples", "optimizer_steps", "guided_steps"):
+        assert s0[k] == s1[k], k
+    ui = UniformIntegrator(ladybug, UniformIntegratorSettings((w, h), 16, 64, 1.0))
+    uf = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    ui.solve_sharded(0, 8, uf.data_ptr())
+    torch.cuda.synchronize()
+    u = uf.cpu().numpy().reshape(-1, 3)
+    ui.close()
+    assert not f0[~own].any()
+    # two unbiased 16-spp estimates of the same field: their means agree far better than their pixels
+    assert abs(float(f0[own].mean()) - float(u[own].mean())) < 2e-3 * max(1.0, abs(float(u[own].mean())))
+    rel = np.linalg.norm(f0[own] - u[own]) / np.linalg.norm(u[own])
+    assert rel < 0.5, rel

@@ -89,14 +89,17 @@ def test_backward_matches_finite_differences(orc):
 def test_optimizer_first_step_closed_form(orc):
     cfg = default_net_config()
     n = orc.net_n_params(cfg)
+    n_mlp = 64 * 32 + 2 * 64 * 64 + 48 * 64
     rng = np.random.default_rng(3)
     p0 = rng.normal(size=n).astype(np.float32)
     g = rng.normal(size=n).astype(np.float32) * 128
     st = orc.net_optimizer_state(cfg)
     p = p0.copy()
     inf = orc.net_optimizer_step(cfg, p, st, g, step=1, loss_scale=128.0)
-    # step 1 of Adam with bias correction moves every weight by ~lr against the gradient sign ...
-    gg = g / 128.0 + cfg.l2_reg * p0
+    # step 1 of Adam with bias correction moves every weight by ~lr against the gradient sign;
+    # the L2 term belongs to the matrix weights only (tiny-cuda-nn adam_step) ...
+    gg = g / 128.0
+    gg[:n_mlp] += cfg.l2_reg * p0[:n_mlp]
     np.testing.assert_allclose(p - p0, -cfg.learning_rate * np.sign(gg), rtol=1e-3, atol=1e-7)
     # ... and the debiased EMA of one sample is that sample
     np.testing.assert_allclose(inf, p, rtol=1e-5, atol=1e-7)
@@ -104,6 +107,41 @@ def test_optimizer_first_step_closed_form(orc):
     inf2 = orc.net_optimizer_step(cfg, p2, st, g, step=2, loss_scale=128.0)
     d = cfg.ema_decay
     np.testing.assert_allclose(inf2, (d * (1 - d) * p + (1 - d) * p2) / (1 - d * d), rtol=1e-4, atol=1e-6)
+
+
+def test_optimizer_leaves_untouched_grid_entries_alone(orc):
+    """tiny-cuda-nn's adam_step returns early for an encoding parameter whose gradient is exactly
+    zero (no moment decay, no step, no L2 pull) and debiases every parameter with its own step
+    counter: a grid entry first touched at global step 3 takes a FIRST Adam step there."""
+    cfg = default_net_config()
+    n = orc.net_n_params(cfg)
+    n_mlp = 64 * 32 + 2 * 64 * 64 + 48 * 64
+    rng = np.random.default_rng(5)
+    p0 = rng.normal(size=n).astype(np.float32)
+    g = rng.normal(size=n).astype(np.float32) * 128
+    late = np.zeros(n, bool)
+    late[n_mlp + 5::7] = True                 # grid entries that see no gradient in steps 1 and 2
+    g_early = g.copy()
+    g_early[late] = 0.0
+    st = orc.net_optimizer_state(cfg)
+    p = p0.copy()
+    orc.net_optimizer_step(cfg, p, st, g_early, step=1, loss_scale=128.0)
+    orc.net_optimizer_step(cfg, p, st, g_early, step=2, loss_scale=128.0)
+    assert np.array_equal(p[late], p0[late])                      # not even the L2 term moved them
+    assert not st["m1"][late].any() and not st["m2"][late].any() and not st["steps"][late].any()
+    assert (st["steps"][~late] == 2).all()
+    before = p.copy()
+    inf = orc.net_optimizer_step(cfg, p, st, g, step=3, loss_scale=128.0)
+    # their own first step: |dw| = lr exactly as at global step 1, no L2 on the encoding
+    np.testing.assert_allclose((p - before)[late], -cfg.learning_rate * np.sign(g[late]), rtol=1e-3, atol=1e-7)
+    assert (st["steps"][late] == 1).all() and (st["steps"][~late] == 3).all()
+    # a matrix weight with zero gradient still decays its moments and feels the L2 term
+    g0 = g.copy()
+    g0[:n_mlp] = 0.0
+    m1_before = st["m1"][:n_mlp].copy()
+    orc.net_optimizer_step(cfg, p, st, g0, step=4, loss_scale=128.0)
+    assert (st["steps"][:n_mlp] == 4).all() and not np.array_equal(st["m1"][:n_mlp], m1_before)
+    assert np.isfinite(inf).all()
 
 
 # ---- HIP network against the oracle ----------------------------------------------------------

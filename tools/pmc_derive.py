@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Derive the per-launch HBM traffic and the VALU figures of walk_round_kernel from a PMC summary
+(tools/pmc_summary.py output) and the JSON line of the profiled bench run.
+Usage: pmc_derive.py pmc_summary.txt bench_trace.log out_dir "<bench args>"
+Writes out_dir/walk_round_traffic.json and out_dir/walk_round_valu.json (copied to profiles/ by hand)."""
+import json
+import re
+import sys
+
+summary, bench_log, out_dir, bargs = sys.argv[1:5]
+tot = {}
+for line in open(summary):
+    m = re.search(r"walk_round_kernel.*?(\w+)\s+calls=(\d+)\s+sum=([0-9.e+]+)", line)
+    if m:
+        tot[m.group(1)] = (int(m.group(2)), float(m.group(3)))
+steps = None
+try:
+    for line in open(bench_log):
+        if line.startswith("{"):
+            steps = json.loads(line)["config"]["walk_steps_per_pass"]
+except Exception:
+    pass
+if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+    calls = tot["FETCH_SIZE"][0]
+    # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+    # half of the bytes of 16-B-per-lane reads -> doubled; WRITE_SIZE is exact
+    per_launch = (2.0 * tot["FETCH_SIZE"][1] + tot["WRITE_SIZE"][1]) * 1024.0 / calls
+    json.dump({"kernel": "walk_round_kernel", "launches": calls, "fetch_kib_sum": tot["FETCH_SIZE"][1],
+               "write_kib_sum": tot["WRITE_SIZE"][1], "hbm_bytes_per_launch": per_launch,
+               "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 " + bargs,
+               "correction": "2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes"},
+              open(out_dir + "/walk_round_traffic.json", "w"), indent=1)
+need = ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE")
+if all(k in tot for k in need):
+    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs (MI355X_MICROARCH.md, cycle
+    # constants); GRBM_GUI_ACTIVE is the sum of the kernel's cycles over the 8 XCDs; 256 CUs x 4 SIMDs
+    kernel_cycles = tot["GRBM_GUI_ACTIVE"][1] / 8.0
+    pipe_busy = 4.0 * tot["SQ_ACTIVE_INST_VALU"][1] / (1024.0 * kernel_cycles)
+    lane_eff = tot["SQ_THREAD_CYCLES_VALU"][1] / (64.0 * tot["SQ_INSTS_VALU"][1])
+    out = {"kernel": "walk_round_kernel", "pipe_busy": pipe_busy, "lane_efficiency": lane_eff,
+           "valu_wave_instructions": tot["SQ_INSTS_VALU"][1], "salu_wave_instructions": tot.get("SQ_INSTS_SALU", (0, None))[1],
+           "walk_steps": steps,
+           "lane_instr_per_step": (tot["SQ_INSTS_VALU"][1] * 64.0 * lane_eff / steps) if steps else None,
+           "source": "rocprofv3 --pmc passes of `python3 %s` (tools/gpu_round.sh): pipe_busy = 4 SQ_ACTIVE_INST_VALU / "
+                     "(1024 SIMDs x GRBM_GUI_ACTIVE / 8), lane_efficiency = SQ_THREAD_CYCLES_VALU / (64 SQ_INSTS_VALU), "
+                     "lane_instr_per_step = active lane-instructions / walk steps" % bargs}
+    json.dump(out, open(out_dir + "/walk_round_valu.json", "w"), indent=1)
+    print(json.dumps(out))
