@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libwost_hip.so")
 HOST_EXE = os.path.join(LIB_DIR, "elaina-exec")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 
-SOURCES = ["wost_hip.hip", "wost_vmm.hip", "wost_net.hip", "wost_guided.hip", "lbvh_build.cpp"]
+SOURCES = ["wost_hip.hip", "wost_vmm.hip", "wost_net.hip", "wost_guided.hip", "lbvh_build.cpp", "cell_grid_build.cpp"]
 
 # -ffp-contract=off is part of the arithmetic contract (DESIGN.md "deterministic math")
 HIPCC_FLAGS = [
@@ -43,7 +43,8 @@ def build_library(force=False, verbose=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
     headers.append(os.path.join(_HERE, "..", "include", "wost.h"))
-    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    # developer knob: extra -D definitions for kernel-tuning experiments (WOST_HIPCC_DEFS="-DX=1 -DY=2")
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("WOST_HIPCC_DEFS", "").split()
     jobs, objs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -58,7 +59,7 @@ def build_library(force=False, verbose=False):
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
     if force or jobs or _stale(LIB_PATH, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", LIB_PATH]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

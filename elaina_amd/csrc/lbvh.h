@@ -21,6 +21,7 @@
 // minimum distance with ties broken by the lowest ORIGINAL segment index, and node
 // boxes are padded so that pruning can never cut a segment that ties or wins.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -53,6 +54,7 @@ struct HostTree {
     int32_t n_leaves_cap = 0;  // 4^levels
     int32_t n_leaves = 0;      // leaves holding at least one real segment
     float pad = 0.0f;
+    double obb_pad = 0.0;      // absolute padding of the oriented boxes
     std::vector<float> boxes;     // 4 floats per node g >= 1, stored at [g-1]: lox, loy, hix, hiy
     // 24 floats per node g in [0, first_leaf + n_leaves_cap): the four children as oriented
     // boxes, SoA: cx[4] cy[4] ux[4] uy[4] hl[4] hw[4].  Children of the nodes of the last
@@ -75,6 +77,9 @@ struct HostTree {
     std::vector<SilVertex> sil;   // one per mesh vertex (prev = next = -1: no incident segment)
     float aabb[4] = {0, 0, 0, 0}; // lox, loy, hix, hiy of the mesh
 };
+
+// Oriented box {cx cy ux uy hl hw} around n points (x y pairs), padded by obb_pad (lbvh_build.cpp).
+void fit_obb(const double *P, size_t n, double obb_pad, float out[6]);
 
 // Returns 0 on success, negative on invalid input (index out of range).
 // refine: true = perimeter-weighted (SAH) top-down assignment of the Morton-ordered segments

@@ -25,6 +25,49 @@ static inline uint32_t part1by1(uint32_t x)
 
 static inline float dot2(float ax, float ay, float bx, float by) { return std::fmaf(ax, bx, ay * by); }
 
+// Oriented box around n points (x0 y0 x1 y1 ...): the tightest (by half perimeter) of the PCA axis
+// and 16 fixed directions, measured in the frame of the fp32 axis it will be stored with, inflated by
+// a relative 1e-6 plus `pad`.  out = cx cy ux uy hl hw.
+void fit_obb(const double *P, size_t n, double obb_pad, float out[6])
+{
+    double mx = 0, my = 0;
+    for (size_t i = 0; i < n; ++i) { mx += P[2 * i]; my += P[2 * i + 1]; }
+    mx /= (double)n; my /= (double)n;
+    double sxx = 0, sxy = 0, syy = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const double x = P[2 * i] - mx, y = P[2 * i + 1] - my;
+        sxx += x * x; sxy += x * y; syy += y * y;
+    }
+    const double pca = 0.5 * std::atan2(2.0 * sxy, sxx - syy);
+    double best = std::numeric_limits<double>::infinity();
+    float b_cx = 0, b_cy = 0, b_ux = 1, b_uy = 0, b_hl = 0, b_hw = 0;
+    const int n_ang = 16;
+    for (int a = -1; a < n_ang; ++a) {
+        const double ang = (a < 0) ? pca : M_PI * (double)a / n_ang;
+        // the axis as it will be stored (fp32); extents are measured in THAT frame
+        const float uxf = (float)std::cos(ang), uyf = (float)std::sin(ang);
+        const double ux = uxf, uy = uyf, n2 = ux * ux + uy * uy;
+        double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+        for (size_t i = 0; i < n; ++i) {
+            const double u = P[2 * i] * ux + P[2 * i + 1] * uy;
+            const double v = -P[2 * i] * uy + P[2 * i + 1] * ux;
+            umin = std::min(umin, u); umax = std::max(umax, u);
+            vmin = std::min(vmin, v); vmax = std::max(vmax, v);
+        }
+        const double score = (umax - umin) + (vmax - vmin);
+        if (score < best) {
+            best = score;
+            const double uc = 0.5 * (umin + umax), vc = 0.5 * (vmin + vmax);
+            b_cx = (float)((uc * ux - vc * uy) / n2);
+            b_cy = (float)((uc * uy + vc * ux) / n2);
+            b_ux = uxf; b_uy = uyf;
+            b_hl = (float)(0.5 * (umax - umin) * (1.0 + 1e-6) + obb_pad);
+            b_hw = (float)(0.5 * (vmax - vmin) * (1.0 + 1e-6) + obb_pad);
+        }
+    }
+    out[0] = b_cx; out[1] = b_cy; out[2] = b_ux; out[3] = b_uy; out[4] = b_hl; out[5] = b_hw;
+}
+
 int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_t *segs,
                const float *colors, HostTree *t, bool refine, int extra_levels)
 {
@@ -304,6 +347,7 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
             }
         const char *e_pad = getenv("WOST_OBB_PAD_LOG2");   // developer knob: absolute pad = ext * 2^-k
         const double obb_pad = (double)ext * std::ldexp(1.0, -(e_pad ? atoi(e_pad) : 21)) + 1e-30;
+        t->obb_pad = obb_pad;
         auto set_child = [&](int parent, int j, float cx, float cy, float ux, float uy, float hl, float hw) {
             float *nd = &t->nodes[(size_t)parent * 24];
             nd[0 + j] = cx; nd[4 + j] = cy; nd[8 + j] = ux; nd[12 + j] = uy; nd[16 + j] = hl; nd[20 + j] = hw;
@@ -317,42 +361,9 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
                     set_child(g, j, kFarCoord, kFarCoord, 1.0f, 0.0f, 0.0f, 0.0f);
                     continue;
                 }
-                double mx = 0, my = 0;
-                for (size_t i = 0; i < n; ++i) { mx += P[2 * i]; my += P[2 * i + 1]; }
-                mx /= (double)n; my /= (double)n;
-                double sxx = 0, sxy = 0, syy = 0;
-                for (size_t i = 0; i < n; ++i) {
-                    const double x = P[2 * i] - mx, y = P[2 * i + 1] - my;
-                    sxx += x * x; sxy += x * y; syy += y * y;
-                }
-                const double pca = 0.5 * std::atan2(2.0 * sxy, sxx - syy);
-                double best = std::numeric_limits<double>::infinity();
-                float b_cx = 0, b_cy = 0, b_ux = 1, b_uy = 0, b_hl = 0, b_hw = 0;
-                const int n_ang = 16;
-                for (int a = -1; a < n_ang; ++a) {
-                    const double ang = (a < 0) ? pca : M_PI * (double)a / n_ang;
-                    // the axis as it will be stored (fp32); extents are measured in THAT frame
-                    const float uxf = (float)std::cos(ang), uyf = (float)std::sin(ang);
-                    const double ux = uxf, uy = uyf, n2 = ux * ux + uy * uy;
-                    double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
-                    for (size_t i = 0; i < n; ++i) {
-                        const double u = P[2 * i] * ux + P[2 * i + 1] * uy;
-                        const double v = -P[2 * i] * uy + P[2 * i + 1] * ux;
-                        umin = std::min(umin, u); umax = std::max(umax, u);
-                        vmin = std::min(vmin, v); vmax = std::max(vmax, v);
-                    }
-                    const double score = (umax - umin) + (vmax - vmin);
-                    if (score < best) {
-                        best = score;
-                        const double uc = 0.5 * (umin + umax), vc = 0.5 * (vmin + vmax);
-                        b_cx = (float)((uc * ux - vc * uy) / n2);
-                        b_cy = (float)((uc * uy + vc * ux) / n2);
-                        b_ux = uxf; b_uy = uyf;
-                        b_hl = (float)(0.5 * (umax - umin) * (1.0 + 1e-6) + obb_pad);
-                        b_hw = (float)(0.5 * (vmax - vmin) * (1.0 + 1e-6) + obb_pad);
-                    }
-                }
-                set_child(g, j, b_cx, b_cy, b_ux, b_uy, b_hl, b_hw);
+                float ob[6];
+                fit_obb(P.data(), n, obb_pad, ob);
+                set_child(g, j, ob[0], ob[1], ob[2], ob[3], ob[4], ob[5]);
             }
         }
         // last level: the children are the segments, exact records, no padding

@@ -31,6 +31,17 @@ struct DevSilVertex {
     int32_t prev, next;
 };
 
+// per-cell candidate lists of the closest-point query (cell_grid.h); nx == 0: not built
+struct DevCells {
+    const uint32_t *cell_off;  // [nx*ny + 2] first GROUP of each cell; cell nx*ny = all chunks
+    const uint2 *ids4;         // groups of four 16-bit chunk ids, padded with n_chunks (the sentinel)
+    const float4 *cbox;        // [2 * (n_chunks + 1)] cx cy ux uy | hl hw - -
+    const float4 *cseg;        // [20 * (n_chunks + 1)] cx[16] cy[16] ux[16] uy[16] hl[16]
+    const int32_t *cslot;      // [16 * (n_chunks + 1)] entry -> slot in the tree's leaf order, -1 unused
+    float ox, oy, inv_h;
+    int32_t nx, ny, n_chunks;
+};
+
 struct DevMesh {
     const float4 *nodes;     // [n_nodes * 6]: cx[4] cy[4] ux[4] uy[4] hl[4] hw[4] of the children
     const float4 *segA;      // [slots] ax, ay, ex, ey
@@ -47,6 +58,7 @@ struct DevMesh {
     int32_t levels;
     int32_t first_leaf;
     int32_t emissive;        // any non-zero colour
+    DevCells cells;          // candidate lists for closest_point_cells (Dirichlet mesh of enclosed scenes)
 };
 
 struct DevProbe {
