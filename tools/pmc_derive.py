@@ -10,7 +10,7 @@ import sys
 summary, bench_log, out_dir, bargs = sys.argv[1:5]
 tot = {}
 for line in open(summary):
-    m = re.search(r"walk_round_kernel.*?(\w+)\s+calls=(\d+)\s+sum=([0-9.e+]+)", line)
+    m = re.search(r"walk_(?:round|cells)_kernel.*?(\w+)\s+calls=(\d+)\s+sum=([0-9.e+]+)", line)
     if m:
         tot[m.group(1)] = (int(m.group(2)), float(m.group(3)))
 steps = None

@@ -5,7 +5,7 @@ import csv
 import sys
 from collections import defaultdict
 
-wanted = sys.argv[2:] or ["walk_round", "init_kernel"]
+wanted = sys.argv[2:] or ["walk_round", "walk_cells", "init_kernel"]
 tot = defaultdict(float)
 calls = defaultdict(int)
 with open(sys.argv[1]) as f:
