@@ -31,17 +31,6 @@ struct DevSilVertex {
     int32_t prev, next;
 };
 
-// per-cell candidate lists of the closest-point query (cell_grid.h); nx == 0: not built
-struct DevCells {
-    const uint32_t *cell_off;  // [nx*ny + 2] first GROUP of each cell; cell nx*ny = all chunks
-    const uint2 *ids4;         // groups of four 16-bit chunk ids, padded with n_chunks (the sentinel)
-    const float4 *cbox;        // [2 * (n_chunks + 1)] cx cy ux uy | hl hw - -
-    const float4 *cseg;        // [20 * (n_chunks + 1)] cx[16] cy[16] ux[16] uy[16] hl[16]
-    const int32_t *cslot;      // [16 * (n_chunks + 1)] entry -> slot in the tree's leaf order, -1 unused
-    float ox, oy, inv_h;
-    int32_t nx, ny, n_chunks;
-};
-
 struct DevMesh {
     const float4 *nodes;     // [n_nodes * 6]: cx[4] cy[4] ux[4] uy[4] hl[4] hw[4] of the children
     const float4 *segA;      // [slots] ax, ay, ex, ey
@@ -58,7 +47,6 @@ struct DevMesh {
     int32_t levels;
     int32_t first_leaf;
     int32_t emissive;        // any non-zero colour
-    DevCells cells;          // candidate lists for closest_point_cells (Dirichlet mesh of enclosed scenes)
 };
 
 struct DevProbe {
@@ -125,22 +113,6 @@ __device__ __forceinline__ float obb_d2(float cx, float cy, float ux, float uy, 
     return dot2(du, dv, du, dv);
 }
 
-// The same arithmetic for the four children of one node, two per instruction: gfx950 issues
-// v_pk_{add,mul,fma}_f32 at the rate of their scalar forms, and this kernel is bound by VALU
-// issue.  Component-wise IEEE operations, so the results equal four obb_d2() calls bit for bit.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f32x2 obb_d2_x2(f32x2 cx, f32x2 cy, f32x2 ux, f32x2 uy, f32x2 hl, f32x2 hw, f32x2 qx, f32x2 qy)
-{
-    const f32x2 wx = qx - cx, wy = qy - cy;
-    const f32x2 u = __builtin_elementwise_fma(wx, ux, wy * uy);
-    const f32x2 v = __builtin_elementwise_fma(ux, wy, -(uy * wx));
-    const f32x2 zero = {0.0f, 0.0f};
-    const f32x2 du = __builtin_elementwise_max(__builtin_elementwise_abs(u) - hl, zero);
-    const f32x2 dv = __builtin_elementwise_max(__builtin_elementwise_abs(v) - hw, zero);
-    return __builtin_elementwise_fma(du, du, dv * dv);
-}
-
 __device__ __forceinline__ float seg_d2(const DevFlatSeg &s, float qx, float qy)
 {
     return obb_d2(s.cx, s.cy, s.ux, s.uy, s.hl, 0.0f, qx, qy);
@@ -189,31 +161,15 @@ __device__ __forceinline__ uint32_t level_first(int level)
     return level == 0 ? 0u : (0x55555555u >> (32 - 2 * level));
 }
 
-// Where a traversal stack lives.  LdsColumn: entry i of this lane/walker at col[i * stride]
-// (one column per lane, bank = lane).  SplitColumn: the first `lds_entries` entries in an LDS
-// column, the rest in a global-memory column (rarely reached: deep stacks are the exception).
+// A lane's column of the LDS traversal stack: entry i at col[i * stride] (bank = lane).  Block sizes
+// are powers of two, so the entry address is ONE v_lshl_add_u32 (a 24-bit multiply plus a shift-add
+// cost two half-rate instructions per access: tools/micro/op_rate.hip).
 struct LdsColumn {
     uint32_t *col;
-    uint32_t stride;  // words between consecutive entries
-    __device__ __forceinline__ void put(int i, uint32_t key) const { col[__umul24((uint32_t)i, stride)] = key; }
-    __device__ __forceinline__ uint32_t get(int i) const { return col[__umul24((uint32_t)i, stride)]; }
-};
-
-struct SplitColumn {
-    uint32_t *col;
-    uint32_t stride;
-    int lds_entries;
-    uint32_t *gcol;    // global column of this walker
-    uint32_t gstride;  // words between consecutive global entries
-    __device__ __forceinline__ void put(int i, uint32_t key) const
-    {
-        if (i < lds_entries) col[__umul24((uint32_t)i, stride)] = key;
-        else gcol[(size_t)(i - lds_entries) * gstride] = key;
-    }
-    __device__ __forceinline__ uint32_t get(int i) const
-    {
-        return (i < lds_entries) ? col[__umul24((uint32_t)i, stride)] : gcol[(size_t)(i - lds_entries) * gstride];
-    }
+    uint32_t shift;   // log2 of the words between consecutive entries
+    __device__ __forceinline__ LdsColumn(uint32_t *c, uint32_t stride) : col(c), shift(31u - (uint32_t)__builtin_clz(stride)) {}
+    __device__ __forceinline__ void put(int i, uint32_t key) const { col[(uint32_t)i << shift] = key; }
+    __device__ __forceinline__ uint32_t get(int i) const { return col[(uint32_t)i << shift]; }
 };
 
 // Pop the next entry that can still tie or beat the current best.  Returns false when the
@@ -281,35 +237,27 @@ __device__ __forceinline__ void trav_leaf_ties(const DevMesh &m, Trav &T, int sl
 // push the children that can still tie or win in far-to-near order and step into the
 // nearest.  Returns false when the query is complete.  Ties between segments are broken by
 // the lowest ORIGINAL index, so the answer does not depend on the tree or the visiting order.
-// `top` (optional) is an LDS copy of the nodes of the levels < top_levels.
-// KIND: 0 = decide per lane from T.level, 1 = every active lane is at an inner node,
-// 2 = every active lane is at a node of the last level (children are segments); the pool
-// kernel batches lanes by kind so that only one tail is ever executed by a wave.
-template <bool USE_TOP = false, int KIND = 0, class STK = LdsColumn>
-__device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy, Trav &T, const STK &stk,
-                                           const float4 *top = nullptr, int top_levels = 0)
+// (An LDS mirror of the top levels of the tree was measured at +-0 % in round 1 and cost a flat
+// load path with its own branch per visit; the top of the tree is L1-resident anyway.)
+template <class STK = LdsColumn>
+__device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy, Trav &T, const STK &stk)
 {
     const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
-    float4 CX, CY, UX, UY, HL, HW;
-    if (USE_TOP && T.level < top_levels) {
-        const float4 *nd = top + 6 * g;
-        CX = nd[0]; CY = nd[1]; UX = nd[2]; UY = nd[3]; HL = nd[4]; HW = nd[5];
-    } else {
-        // 96-byte nodes; a 24-bit multiply is full rate and the byte offset stays below 4 GiB
-        const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
-        CX = nd[0]; CY = nd[1]; UX = nd[2]; UY = nd[3]; HL = nd[4]; HW = nd[5];
-    }
-    const f32x2 q2x = {qx, qx}, q2y = {qy, qy};
-    const f32x2 d01 = obb_d2_x2(f32x2{CX.x, CX.y}, f32x2{CY.x, CY.y}, f32x2{UX.x, UX.y}, f32x2{UY.x, UY.y},
-                                f32x2{HL.x, HL.y}, f32x2{HW.x, HW.y}, q2x, q2y);
-    const f32x2 d23 = obb_d2_x2(f32x2{CX.z, CX.w}, f32x2{CY.z, CY.w}, f32x2{UX.z, UX.w}, f32x2{UY.z, UY.w},
-                                f32x2{HL.z, HL.w}, f32x2{HW.z, HW.w}, q2x, q2y);
-    const float d0 = d01.x, d1 = d01.y, d2 = d23.x, d3 = d23.y;
+    // 96-byte nodes; the byte offset stays below 4 GiB
+    const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+    const float4 CX = nd[0], CY = nd[1], UX = nd[2], UY = nd[3], HL = nd[4], HW = nd[5];
+    // plain scalar fp32: on gfx950 a packed v_pk_fma_f32 costs two v_fma_f32 (tools/micro/op_rate.hip,
+    // profiles/r02_micro_*), has no |x| source modifier and needs hazard nops; the scalar form
+    // spends 12 instructions per child with the absolute values folded into the subtractions
+    const float d0 = obb_d2(CX.x, CY.x, UX.x, UY.x, HL.x, HW.x, qx, qy);
+    const float d1 = obb_d2(CX.y, CY.y, UX.y, UY.y, HL.y, HW.y, qx, qy);
+    const float d2 = obb_d2(CX.z, CY.z, UX.z, UY.z, HL.z, HW.z, qx, qy);
+    const float d3 = obb_d2(CX.w, CY.w, UX.w, UY.w, HL.w, HW.w, qx, qy);
     const float bd = T.best.d2;
-    const bool at_leaf = (KIND == 2) || (KIND == 0 && T.level == m.levels);
+    const bool at_leaf = T.level == m.levels;
     // ---- last level: the children are segments, the distances are exact.  Branch-free in
     // the common case (one strict winner); exact ties take the rare path.
-    if (KIND != 1) {
+    {
         const float mn = fminf(fminf(d0, d1), fminf(d2, d3));
         const int n_eq = (d0 == mn) + (d1 == mn) + (d2 == mn) + (d3 == mn);
         const int slot = 4 * T.pos + ((d0 == mn) ? 0 : (d1 == mn) ? 1 : (d2 == mn) ? 2 : 3);
@@ -325,7 +273,7 @@ __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy,
     // ---- inner level: near-first order.  The (non-negative) distance orders as an integer;
     // level and child index ride in the low mantissa bits, so five integer compare-exchanges
     // sort the candidates.  Lanes at the last level simply have no valid key.
-    if (KIND != 2) {
+    {
         const uint32_t tag = (uint32_t)(T.level + 1) << 2;
         const bool inner = !at_leaf;
         uint32_t k0 = (inner && d0 <= bd) ? ((__float_as_uint(d0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;

@@ -34,7 +34,6 @@
 #include "wost_internal.h"
 #include "wost_vmm_device.h"
 #include "wost_walk.h"
-#include "wost_cells.h"
 
 namespace wost {
 
@@ -309,10 +308,7 @@ __device__ __forceinline__ int separate_step(const GParams &P, uint32_t pid, boo
                                              const LdsColumn &stk)
 {
     Closest cp{WOST_INF, -1};
-    // per-cell candidate lists when the scene has them (enclosed scenes, cell_grid.h), else the tree
-    if (P.dm.n_segs > 0)
-        cp = P.dm.cells.nx > 0 ? closest_point_cells(P.dm, x, y)
-                               : closest_point(P.dm, x, y, slot_candidate(P.dm, hint, x, y), stack, P.stack_stride);
+    if (P.dm.n_segs > 0) cp = closest_point(P.dm, x, y, slot_candidate(P.dm, hint, x, y), stack, P.stack_stride);
     return separate_finish<EMISSIVE, TREE, SOURCE>(P, pid, on_n, x, y, thp, nx, ny, depth, cp, hint, R_B, rng, stk);
 }
 

@@ -32,8 +32,6 @@
 #include "wost_device.h"
 #include "wost_internal.h"
 #include "wost_walk.h"
-#include "wost_cells.h"
-#include "cell_grid.h"
 
 namespace wost {
 
@@ -81,8 +79,6 @@ struct RoundParams {
     int32_t stack_stride;  // = blockDim.x
     int32_t wait_weight;   // step phase runs when n_wait * wait_weight >= 8 * n_trav
     int32_t trav_burst;    // node visits per scheduling decision in the traversal phase
-    int32_t top_levels;    // levels of the Dirichlet tree mirrored in LDS
-    int32_t top_nodes;     // (4^top_levels - 1) / 3
     int32_t lane_shift;    // one walker per 2^lane_shift lanes (0 = every lane)
     uint32_t *cursor;      // REFILL launches: next unread slot of the input queue
 };
@@ -134,9 +130,7 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams P)
     if (active) {
         eval_point(P.probe, x, y, P.st.width, P.st.height, x0, y0);
         pcg_seed_pixel(rng, pid, P.st.width);
-        if (P.dm.n_segs > 0)
-            c0 = P.dm.cells.nx > 0 ? closest_point_cells(P.dm, x0, y0)
-                                   : closest_point(P.dm, x0, y0, slot_candidate(P.dm, 0, x0, y0), stack, P.stack_stride);
+        if (P.dm.n_segs > 0) c0 = closest_point(P.dm, x0, y0, slot_candidate(P.dm, 0, x0, y0), stack, P.stack_stride);
     }
     const uint32_t s = block_push(active, P.count_out);
     if (active) {
@@ -283,15 +277,8 @@ __device__ __forceinline__ void load_lane(const WalkQueue &q, uint32_t slot, Lan
 template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, bool REFILL = false, bool SOURCE = false>
 __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(RoundParams P)
 {
-    extern __shared__ uint32_t lds_stack[];
-    // LDS: [top of the tree: top_nodes * 6 float4][traversal stack columns]
-    const float4 *lds_top = reinterpret_cast<const float4 *>(lds_stack);
-    {
-        float4 *dst = reinterpret_cast<float4 *>(lds_stack);
-        for (int i = threadIdx.x; i < P.top_nodes * 6; i += blockDim.x) dst[i] = P.dm.nodes[i];
-        __syncthreads();
-    }
-    uint32_t *stack = lds_stack + P.top_nodes * 24 + threadIdx.x;
+    extern __shared__ uint32_t lds_stack[];       // the traversal stack columns, one per lane
+    uint32_t *stack = lds_stack + threadIdx.x;
     // thin waves (lane_shift > 0, the last launches of a solve): only every 2^shift-th lane holds a
     // walker, so a wave waits for the longest query of 64 >> shift walkers instead of 64
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -413,7 +400,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
             for (int b = 0; b < P.trav_burst; ++b) {
                 if (mode == MODE_TRAV) {
                     S.visits++;
-                    if (!trav_visit<true>(P.dm, L.px, L.py, T, stk, lds_top, P.top_levels)) mode = MODE_WAIT;
+                    if (!trav_visit(P.dm, L.px, L.py, T, stk)) mode = MODE_WAIT;
                 }
             }
         }
@@ -465,103 +452,6 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
 
 
 // ------------------------------------------------------------------------------------------
-// the walk round on per-cell candidate lists (wost_cells.h) -- the kernel of enclosed scenes
-// ------------------------------------------------------------------------------------------
-// Same walkers, same queue, same regeneration, compaction and statistics as walk_round_kernel; the
-// closest-point query is closest_point_cells() instead of a tree descent.  A query is a short
-// straight-line program of independent gathers (no traversal stack, no LDS, a fifth of the vector
-// instructions), so the lanes of a wave simply advance in lock step: every trip of the loop is one
-// walk step of every lane that still has one to make.
-template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, bool SOURCE = false>
-__global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_CELLS_WAVES) void walk_cells_kernel(RoundParams P)
-{
-    extern __shared__ uint32_t lds_stack[];          // Neumann-tree queries only
-    uint32_t *stack = lds_stack + threadIdx.x;
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t slot = tid >> P.lane_shift;
-    const uint32_t n_in = *P.count_in;
-    const bool valid = slot < n_in && (tid & ((1u << P.lane_shift) - 1u)) == 0u;
-    Lane L;
-    LaneStats S{0, 0, 0, 0};
-    uint32_t pix = 0;
-    bool alive = false;
-    if (valid) {
-        load_lane(P.in, slot, L, pix);
-        alive = L.sample < (uint32_t)P.st.spp;
-    }
-    const bool open = valid;
-    const bool has_d = P.dm.n_segs > 0;
-    const LdsColumn stk{stack, (uint32_t)P.stack_stride};
-    int budget = P.steps_per_round;
-    uint32_t step_trips = 0;
-    bool run = alive && budget > 0;
-    while (__ballot(run)) {
-        ++step_trips;
-        if (run) {
-            S.a += 1u + ((L.depth == 0) ? 0x10000u : 0u);
-            // depth 0 starts at the same point for every sample of the pixel: cached
-            Closest cp{L.d0_d2, L.d0_slot};
-            if (has_d && L.depth != 0) cp = closest_point_cells(P.dm, L.px, L.py);
-            const uint32_t status = step_finish<NEUMANN_EMISSIVE, NEUMANN_TREE, SOURCE>(P.dm, P.nm, P.st, L, cp, stk, P.src);
-            S.b += ((status >> 1) & 1u) | (((status >> 2) & 1u) << 16);
-            S.c += (status >> 3) & 1u;
-            if (status & STEP_ENDED) {
-                // next sample of this pixel starts right away (generateEvaluationPoints,
-                // reference integrator.cu:90-99 + workqueue.h:99-110)
-                L.sample++;
-                L.px = L.x0; L.py = L.y0;
-                L.depth = 0; L.on_n = false; L.nx = 0.0f; L.ny = 0.0f;
-                L.thp = 1.0f;
-                L.hint = L.d0_slot;
-                alive = L.sample < (uint32_t)P.st.spp;
-            }
-            --budget;
-            run = alive && budget > 0;
-        }
-    }
-    // ---- resolve finished pixels (reference integrator.cu:616-620) -------------------------
-    if (open && !alive) {
-        float *f = P.field + 3 * (size_t)((int32_t)pix - P.field_base);
-        const float spp = (float)P.st.spp;
-        f[0] = L.sr / spp; f[1] = L.sg / spp; f[2] = L.sb / spp;
-    }
-    // ---- stream compaction of the survivors: ballot + popcount, one atomic per block ------
-    const int lane = threadIdx.x & 63;
-    const uint32_t s = block_push(alive && open, P.count_out);
-    if (alive && open) {
-        WalkQueue &q = P.out;
-        q.pix[s] = pix;
-        q.x0[s] = L.x0; q.y0[s] = L.y0;
-        q.px[s] = L.px; q.py[s] = L.py;
-        q.rng[s] = L.rng.state;
-        q.meta[s] = META_PACK(L.sample, L.depth, L.on_n ? 1 : 0);
-        q.nx[s] = L.nx; q.ny[s] = L.ny;
-        q.hint[s] = L.hint;
-        q.thp[s] = L.thp;
-        q.sr[s] = L.sr; q.sg[s] = L.sg; q.sb[s] = L.sb;
-        q.d0_d2[s] = L.d0_d2; q.d0_slot[s] = L.d0_slot;
-    }
-    // ---- statistics: wave reduction, one atomic per counter per wave -----------------------
-    uint32_t v[5] = {S.a & 0xffffu, S.a >> 16, S.b & 0xffffu, S.b >> 16, S.c};
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        uint32_t x = v[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-        v[k] = x;
-    }
-    if (lane == 0) {
-        StatsDev *st = my_stats(P.stats);
-        if (v[0]) atomicAdd(&st->steps, (unsigned long long)v[0]);
-        if (v[1]) atomicAdd(&st->started, (unsigned long long)v[1]);
-        if (v[2]) atomicAdd(&st->absorbed, (unsigned long long)v[2]);
-        if (v[3]) atomicAdd(&st->truncated, (unsigned long long)v[3]);
-        if (v[4]) atomicAdd(&st->nhits, (unsigned long long)v[4]);
-        atomicAdd(&st->step_trips, (unsigned long long)step_trips);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // batch query kernels (the lbvh::query_device call sites, exposed for tests and SDF renders)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void closest_point_kernel(DevMesh m, const float *pts, int n, int32_t *out_idx,
@@ -573,8 +463,7 @@ __global__ __launch_bounds__(256) void closest_point_kernel(DevMesh m, const flo
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float qx = pts[2 * i], qy = pts[2 * i + 1];
-    const Closest c = m.cells.nx > 0 ? closest_point_cells(m, qx, qy)
-                                     : closest_point(m, qx, qy, slot_candidate(m, 0, qx, qy), stack, stack_stride);
+    const Closest c = closest_point(m, qx, qy, slot_candidate(m, 0, qx, qy), stack, stack_stride);
     const float4 a = m.segA[c.slot];
     const float inv = m.segInv[c.slot];
     const float wx = qx - a.x, wy = qy - a.y;
@@ -670,8 +559,6 @@ struct DeviceMeshStorage {
     DevMesh view{};
     std::vector<void *> allocs;
     HostTree host;
-    HostCellGrid cells;      // candidate lists of the closest-point query (valid = built and uploaded)
-    double cells_build_ms = 0.0;
 };
 
 
@@ -723,25 +610,6 @@ static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
     return WOST_OK;
 }
 
-// Build and upload the per-cell candidate lists of a mesh (cell_grid.h) over the world box [lo, hi].
-static int upload_cells(DeviceMeshStorage &s, const float lo[2], const float hi[2], int max_cells)
-{
-    const auto t0 = std::chrono::high_resolution_clock::now();
-    if (!build_cell_grid(s.host, lo, hi, max_cells, &s.cells)) return WOST_OK;      // not applicable: the tree serves
-    const HostCellGrid &g = s.cells;
-    DevCells &d = s.view.cells;
-    d = DevCells{};
-    HIP_TRY(upload(s.allocs, g.cell_off.data(), g.cell_off.size(), &d.cell_off));
-    HIP_TRY(upload(s.allocs, reinterpret_cast<const uint2 *>(g.ids.data()), g.ids.size() / 4, &d.ids4));
-    HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(g.chunk_box.data()), g.chunk_box.size() / 4, &d.cbox));
-    HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(g.chunk_seg.data()), g.chunk_seg.size() / 4, &d.cseg));
-    HIP_TRY(upload(s.allocs, g.chunk_slot.data(), g.chunk_slot.size(), &d.cslot));
-    d.ox = g.ox; d.oy = g.oy; d.inv_h = g.inv_h;
-    d.nx = g.nx; d.ny = g.ny; d.n_chunks = g.n_chunks;
-    s.cells_build_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
-    return WOST_OK;
-}
-
 static_assert(sizeof(FlatSeg) == sizeof(DevFlatSeg), "flat segment layout");
 static_assert(sizeof(SilVertex) == sizeof(DevSilVertex), "silhouette vertex layout");
 
@@ -773,10 +641,8 @@ struct wost_context {
     int block_size = 256;
     int wait_weight = 8;
     int trav_burst = 3;
-    int top_levels = 3;
     int time_kernels = 1;
     int refill = -1;       // -1 = automatic (few samples per pixel), 0 = never, 1 = always
-    int accel = -1;        // closest-point query: -1 = candidate lists when built, 0 = tree descent, 1 = lists
     uint32_t *cursor = nullptr;
     int n_cus = 256;
 };
@@ -864,31 +730,6 @@ int wost_create(const wost_scene_desc *scene, const wost_settings *settings, int
         return code;
     };
     if (rc != WOST_OK) return bail(rc);
-    {
-        // Candidate lists for the closest-point query on the Dirichlet boundary (cell_grid.h).  They
-        // cover the box of everything a walker can reach when the Neumann boundary encloses the
-        // scene; a walker outside that box falls back to a list of all chunks, so scenes that are
-        // not enclosed keep the tree (WOST_CELLS=1 / 0 forces the choice, WOST_CELLS_MAX the cell count).
-        const HostTree &td = c->dm.host, &tn = c->nm.host;
-        const char *e_cells = getenv("WOST_CELLS"), *e_max = getenv("WOST_CELLS_MAX");
-        const bool enclosed = tn.n_segs > 0 && tn.aabb[0] <= td.aabb[0] && tn.aabb[1] <= td.aabb[1] && tn.aabb[2] >= td.aabb[2] &&
-                              tn.aabb[3] >= td.aabb[3];
-        const bool want = e_cells ? atoi(e_cells) != 0 : (enclosed && td.n_segs >= 64);
-        if (want && td.n_segs > 0) {
-            const float ux = scene->probe_up[1], uy = -scene->probe_up[0], vx = scene->probe_up[0], vy = scene->probe_up[1];
-            const float rx = std::fabs(scene->probe_scale) * (std::fabs(ux) + std::fabs(vx));
-            const float ry = std::fabs(scene->probe_scale) * (std::fabs(uy) + std::fabs(vy));
-            float lo[2] = {std::min(td.aabb[0], scene->probe_pos[0] - rx), std::min(td.aabb[1], scene->probe_pos[1] - ry)};
-            float hi[2] = {std::max(td.aabb[2], scene->probe_pos[0] + rx), std::max(td.aabb[3], scene->probe_pos[1] + ry)};
-            if (tn.n_segs > 0) {
-                lo[0] = std::min(lo[0], tn.aabb[0]); lo[1] = std::min(lo[1], tn.aabb[1]);
-                hi[0] = std::max(hi[0], tn.aabb[2]); hi[1] = std::max(hi[1], tn.aabb[3]);
-            }
-            const int max_cells = e_max ? std::max(16, atoi(e_max)) : (int)std::min<int64_t>(1 << 20, std::max<int64_t>(4096, 64ll * td.n_segs));
-            rc = upload_cells(c->dm, lo, hi, max_cells);
-            if (rc != WOST_OK) return bail(rc);
-        }
-    }
 #define HIP_TRY_C(expr)                                                                                  \
     do {                                                                                                 \
         hipError_t e_ = (expr);                                                                          \
@@ -956,9 +797,6 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "trav_burst") {
         if (value < 1 || value > 16) return fail(WOST_ERR_INVALID, "trav_burst must be in 1..16");
         h->trav_burst = (int)value;
-    } else if (k == "top_levels") {
-        if (value < 0 || value > 6) return fail(WOST_ERR_INVALID, "top_levels must be in 0..6");
-        h->top_levels = (int)value;
     } else if (k == "spp") {
         if (value < 0 || value >= (1 << 20)) return fail(WOST_ERR_INVALID, "spp must be in 0..2^20-1");
         h->settings.spp = (int32_t)value;
@@ -966,10 +804,6 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "refill") {
         if (value != -1 && value != 0 && value != 1) return fail(WOST_ERR_INVALID, "refill must be -1 (auto), 0 or 1");
         h->refill = (int)value;
-    } else if (k == "accel") {
-        if (value != -1 && value != 0 && value != 1) return fail(WOST_ERR_INVALID, "accel must be -1 (auto), 0 (tree) or 1 (cell lists)");
-        if (value == 1 && h->dm.view.cells.nx == 0) return fail(WOST_ERR_UNSUPPORTED, "no cell lists were built for this scene");
-        h->accel = (int)value;
     } else if (k == "thin_waves") {
         h->thin_waves = value != 0;
     } else if (k == "time_kernels") {
@@ -1000,13 +834,8 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     HIP_TRY(hipMemsetAsync(c->stats, 0, kStatCopies * sizeof(StatsDev), stream));
 
     const int tiles_x = (c->settings.width + 7) / 8, tiles_y = (c->settings.height + 7) / 8;
-    // the closest-point query of this solve: candidate lists when they were built (and not switched
-    // off), else the tree descent; a view without lists selects the tree everywhere
-    const bool use_cells = c->dm.view.cells.nx > 0 && c->accel != 0;
-    DevMesh dmv = c->dm.view;
-    if (!use_cells) dmv.cells.nx = 0;
     InitParams ip{};
-    ip.dm = dmv;
+    ip.dm = c->dm.view;
     ip.st = c->dst;
     ip.probe = c->probe;
     ip.out = c->queue[0];
@@ -1038,7 +867,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         const int nxt = cur ^ 1;
         HIP_TRY(hipMemsetAsync(c->counts + nxt, 0, sizeof(uint32_t), stream));
         RoundParams rp{};
-        rp.dm = dmv;
+        rp.dm = c->dm.view;
         rp.nm = c->nm.view;
         rp.st = c->dst;
         rp.probe = c->probe;
@@ -1057,15 +886,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         rp.stack_stride = bs;
         rp.wait_weight = c->wait_weight;
         rp.trav_burst = c->trav_burst;
-        rp.top_levels = std::min(c->top_levels, levels + 1);
-        if (c->dm.view.n_segs == 0) rp.top_levels = 0;
-        // the LDS mirror of the tree top must not cost a resident block (160 KB of LDS per CU):
-        // on fille (one level deeper than ladybug) three mirrored levels dropped 6 blocks to 5
-        // and 5 % of the throughput, two do not
-        auto top_nodes_of = [](int tl) { int t = 0; for (int l = 0, n = 1; l < tl; ++l, n *= 4) t += n; return t; };
-        while (rp.top_levels > 0 && (160 * 1024) / (lds + (size_t)top_nodes_of(rp.top_levels) * 96) < (160 * 1024) / lds) --rp.top_levels;
-        rp.top_nodes = top_nodes_of(rp.top_levels);
-        const size_t lds_round = lds + (size_t)rp.top_nodes * 96;
+        const size_t lds_round = lds;
         // When the walkers left fill less than 1/16 of the resident threads, spread them out: the
         // duration of such a launch is the latency of its slowest wave, and a wave is as slow as the
         // longest query among its walkers (config 2's last three launches: 13.1 -> 8.9 ms; with 2 or
@@ -1094,18 +915,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
             rp.steps_per_round = 0x7fffffff;
         }
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
-        if (use_cells && !refill) {
-            // no traversal stack: LDS only for the queries on a large Neumann mesh
-            const size_t lds_cells = ntree ? lds : 0;
-#define WOST_LAUNCH_CELLS(E, T)                                                                                          \
-    do {                                                                                                                 \
-        if (has_src) hipLaunchKernelGGL((walk_cells_kernel<E, T, true>), dim3(grid), dim3(bs), lds_cells, stream, rp);    \
-        else hipLaunchKernelGGL((walk_cells_kernel<E, T, false>), dim3(grid), dim3(bs), lds_cells, stream, rp);           \
-    } while (0)
-            if (ntree) { if (emissive) WOST_LAUNCH_CELLS(true, true); else WOST_LAUNCH_CELLS(false, true); }
-            else       { if (emissive) WOST_LAUNCH_CELLS(true, false); else WOST_LAUNCH_CELLS(false, false); }
-#undef WOST_LAUNCH_CELLS
-        } else if (has_src) {
+        if (has_src) {
             // problems with a source term: the SOURCE instantiations (one extra stage per step)
             if (ntree) {
                 if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
@@ -1287,9 +1097,7 @@ int wost_closest_point(wost_handle h, int which_mesh, const float *pts, int32_t 
     HIP_TRY(hipMemcpyAsync(d_pts, pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
     const int bs = 256;
     const size_t lds = (size_t)(3 * m->view.levels + 1) * bs * sizeof(uint32_t);
-    DevMesh mv = m->view;
-    if (h->accel == 0) mv.cells.nx = 0;
-    hipLaunchKernelGGL(closest_point_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, mv, d_pts, n,
+    hipLaunchKernelGGL(closest_point_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, d_pts, n,
                        d_idx, d_dist, d_uv, d_side, bs);
     HIP_TRY(hipGetLastError());
     if (out_idx) HIP_TRY(hipMemcpyAsync(out_idx, d_idx, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));

@@ -34,16 +34,12 @@ def _assert_same_solve(oracle, problem, w, h, spp, depth, eps, **opts):
     return ref
 
 
-@pytest.mark.parametrize("accel", [0, 1])
 @pytest.mark.parametrize("scene", ["ladybug", "fille"])
-def test_closest_point_matches_golden_brute_force(scene, accel):
-    # accel 0 = descent of the LBVH, 1 = per-cell candidate lists (the shipped scenes are enclosed by
-    # their Neumann box, so the lists are built): the same answers, bit for bit
+def test_closest_point_matches_golden_brute_force(scene):
     from elaina_amd import Problem
     g = np.load(GOLD)
     p = Problem.load_scene(scene)
     it = _integrator(p, 16, 16, 1, 4, 1.0)
-    it.set_option("accel", accel)
     idx, dist, uv, side = it.closest_point(g[scene + "_cp_pts"])
     assert np.array_equal(idx, g[scene + "_cp_idx"])
     assert np.array_equal(dist, g[scene + "_cp_dist"])
@@ -52,12 +48,8 @@ def test_closest_point_matches_golden_brute_force(scene, accel):
     it.close()
 
 
-@pytest.mark.parametrize("cells", ["0", "1"])
-def test_closest_point_random_mesh_and_ties(oracle, monkeypatch, cells):
-    # cells = "1": the candidate lists forced onto a scene that is not enclosed (WOST_CELLS), with
-    # query points outside the grid (they take the list of all chunks) and exact ties across chunks
+def test_closest_point_random_mesh_and_ties(oracle):
     from elaina_amd import Problem
-    monkeypatch.setenv("WOST_CELLS", cells)
     rng = np.random.default_rng(2)
     n = 5000
     a = rng.uniform(0, 100, size=(n, 2))
@@ -76,13 +68,10 @@ def test_closest_point_random_mesh_and_ties(oracle, monkeypatch, cells):
     it.close()
 
 
-@pytest.mark.parametrize("cells", ["0", "1"])
 @pytest.mark.parametrize("n_segs", [1, 3, 4, 5, 16, 17, 64, 65, 257])
-def test_closest_point_tiny_meshes(oracle, n_segs, monkeypatch, cells):
-    # tree shapes around the leaf-size / arity boundaries, including padded (empty) leaves; with
-    # cells = "1" chunk counts around the group-of-four padding of the lists (1 .. 17 chunks)
+def test_closest_point_tiny_meshes(oracle, n_segs):
+    # tree shapes around the leaf-size / arity boundaries, including padded (empty) leaves
     from elaina_amd import Problem
-    monkeypatch.setenv("WOST_CELLS", cells)
     rng = np.random.default_rng(n_segs)
     verts = rng.uniform(0, 10, size=(n_segs + 1, 2)).astype(np.float32)
     segs = np.stack([np.arange(n_segs), np.arange(n_segs) + 1], 1).astype(np.int32)
@@ -122,11 +111,10 @@ def test_sdf_channels(oracle, ladybug):
     it.close()
 
 
-def test_cell_lists_on_parallel_segments_ties_across_chunks(oracle, monkeypatch):
-    # two stacks of 40 identical horizontal segments: a point midway is at EXACTLY the same distance
-    # from segments of different chunks, and duplicates tie inside a chunk; lowest original index wins
+def test_closest_point_exact_ties_between_parallel_segments(oracle):
+    # two rows of 40 collinear horizontal segments: a point midway is at EXACTLY the same distance
+    # from segments of different leaves, and duplicates tie inside a leaf; lowest original index wins
     from elaina_amd import Problem
-    monkeypatch.setenv("WOST_CELLS", "1")
     xs = np.arange(41, dtype=np.float32)
     verts = np.concatenate([np.stack([xs, np.zeros(41, np.float32)], 1), np.stack([xs, np.full(41, 2.0, np.float32)], 1)])
     segs = np.concatenate([np.stack([np.arange(40), np.arange(40) + 1], 1), np.stack([np.arange(40) + 41, np.arange(40) + 42], 1)])
@@ -143,15 +131,12 @@ def test_cell_lists_on_parallel_segments_ties_across_chunks(oracle, monkeypatch)
     it.close()
 
 
-@pytest.mark.parametrize("accel", [0, 1])
 @pytest.mark.parametrize("scene", ["ladybug", "fille"])
-def test_config1_field_is_bit_exact_vs_golden(scene, accel):
-    # BASELINE.json configs[0]: 128^2, 16 spp, max_depth 32, eps 1; accel 0 = the tree kernel,
-    # 1 = the cell-list kernel (the default for these enclosed scenes)
+def test_config1_field_is_bit_exact_vs_golden(scene):
+    # BASELINE.json configs[0]: 128^2, 16 spp, max_depth 32, eps 1
     from elaina_amd import Problem
     g = np.load(GOLD)
     it = _integrator(Problem.load_scene(scene), 128, 128, 16, 32, 1.0)
-    it.set_option("accel", accel)
     it.solve()
     counts = g[scene + "_cfg1_counts"]
     s = it.last_stats
@@ -167,11 +152,10 @@ def test_round_length_does_not_change_results(oracle, ladybug, steps_per_round):
 
 
 @pytest.mark.parametrize("opts", [
-    {"accel": 0, "wait_weight": 1, "top_levels": 0}, {"accel": 0, "wait_weight": 64, "top_levels": 6},
-    {"accel": 0, "trav_burst": 1}, {"accel": 0, "trav_burst": 7}, {"accel": 1}, {"accel": 1, "block_size": 64},
+    {"wait_weight": 1}, {"wait_weight": 64}, {"trav_burst": 1}, {"trav_burst": 7},
 ])
 def test_kernel_variants_do_not_change_results(oracle, ladybug, opts):
-    # the scheduler knobs of the tree kernel and the cell-list kernel: same bits, same counters
+    # the scheduler knobs of the round kernel: same bits, same counters
     _assert_same_solve(oracle, ladybug, 56, 48, 6, 32, 1.0, **opts)
 
 
