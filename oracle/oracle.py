@@ -73,6 +73,17 @@ class Stats(C.Structure):
     ]
 
 
+class Mesh3(C.Structure):
+    _fields_ = [("n_verts", C.c_int), ("n_tris", C.c_int), ("verts", C.POINTER(C.c_float)), ("tris", C.POINTER(C.c_int)),
+                ("colors", C.POINTER(C.c_float))]
+
+
+class Scene3(C.Structure):
+    _fields_ = [("dirichlet", Mesh3), ("neumann", Mesh3), ("dirichlet_intensity", C.c_float), ("neumann_intensity", C.c_float),
+                ("probe_scale", C.c_float), ("probe_pos", C.c_float * 3), ("probe_up", C.c_float * 3),
+                ("probe_right", C.c_float * 3), ("mask", C.POINTER(C.c_ubyte))]
+
+
 class GuidedSettings(C.Structure):
     """wo_guided_settings; defaults = the reference's constants (see wost_oracle.h)"""
     _fields_ = [
@@ -270,6 +281,98 @@ class Oracle:
         if dump is not None:
             out["train_set"] = {k: v[:dump.n] for k, v in arrays.items()}
         return out
+
+    # ---- 3-D uniform path (oracle/wost_oracle3d.c) -------------------------------------------
+    def _mesh3(self, verts, tris, colors):
+        m = Mesh3()
+        if verts is None or tris is None or len(tris) == 0:
+            return m
+        v = np.ascontiguousarray(verts, dtype=np.float32)
+        t = np.ascontiguousarray(tris, dtype=np.int32)
+        self._keep += [v, t]
+        m.n_verts, m.n_tris, m.verts, m.tris = len(v), len(t), _fp(v), _ip(t)
+        if colors is not None:
+            c = np.ascontiguousarray(colors, dtype=np.float32)
+            assert c.shape == (len(v), 6)
+            self._keep.append(c)
+            m.colors = _fp(c)
+        return m
+
+    def make_scene3(self, sd):
+        """sd: d_verts [n,3], d_tris [m,3], d_colors [n,6], n_verts, n_tris, n_colors, probe = (scale, pos[3],
+        up[3], right[3]), intensities, mask"""
+        self._keep = []
+        sc = Scene3()
+        sc.dirichlet = self._mesh3(sd.get("d_verts"), sd.get("d_tris"), sd.get("d_colors"))
+        sc.neumann = self._mesh3(sd.get("n_verts"), sd.get("n_tris"), sd.get("n_colors"))
+        sc.dirichlet_intensity = float(sd.get("dirichlet_intensity", 1.0))
+        sc.neumann_intensity = float(sd.get("neumann_intensity", 1.0))
+        scale, pos, up, right = sd["probe"]
+        sc.probe_scale = float(scale)
+        for k in range(3):
+            sc.probe_pos[k], sc.probe_up[k], sc.probe_right[k] = float(pos[k]), float(up[k]), float(right[k])
+        mask = sd.get("mask")
+        if mask is not None:
+            mk = np.ascontiguousarray(mask, dtype=np.uint8)
+            self._keep.append(mk)
+            sc.mask = mk.ctypes.data_as(C.POINTER(C.c_ubyte))
+        return sc
+
+    def solve3(self, sd, width, height, spp, max_depth, eps, pixel_begin=0, pixel_end=None, threads=8):
+        sc = self.make_scene3(sd)
+        st = Settings(width, height, spp, max_depth, eps)
+        if pixel_end is None:
+            pixel_end = width * height
+        field = np.zeros((pixel_end - pixel_begin, 3), dtype=np.float32)
+        stats = Stats()
+        rc = self.lib.wo3_solve(C.byref(sc), C.byref(st), pixel_begin, pixel_end, threads, _fp(field), C.byref(stats))
+        if rc != 0:
+            raise RuntimeError("wo3_solve failed: %d" % rc)
+        out = {"field": field}
+        out.update({k: int(getattr(stats, k)) for k in ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated",
+                                                         "neumann_hits")})
+        return out
+
+    def closest_point3(self, verts, tris, pts):
+        self._keep = []
+        m = self._mesh3(verts, tris, None)
+        p = np.ascontiguousarray(pts, dtype=np.float32)
+        n = len(p)
+        idx, dist, uv, side = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros((n, 2), np.float32), np.zeros(n, np.int32)
+        rc = self.lib.wo3_closest_point_batch(C.byref(m), _fp(p), n, _ip(idx), _fp(dist), _fp(uv), _ip(side))
+        if rc != 0:
+            raise RuntimeError("wo3_closest_point_batch failed")
+        return idx, dist, uv, side
+
+    def closest_silhouette3(self, verts, tris, pts, rmax=None):
+        self._keep = []
+        m = self._mesh3(verts, tris, None)
+        p = np.ascontiguousarray(pts, dtype=np.float32)
+        out = np.zeros(len(p), np.float32)
+        r = None if rmax is None else np.ascontiguousarray(rmax, dtype=np.float32)
+        rc = self.lib.wo3_closest_silhouette_batch(C.byref(m), _fp(p), _fp(r) if r is not None else None, len(p), _fp(out))
+        if rc != 0:
+            raise RuntimeError("wo3_closest_silhouette_batch failed")
+        return out
+
+    def ray_intersect3(self, verts, tris, origins, dirs, tmax):
+        self._keep = []
+        m = self._mesh3(verts, tris, None)
+        o = np.ascontiguousarray(origins, dtype=np.float32)
+        d = np.ascontiguousarray(dirs, dtype=np.float32)
+        t = np.ascontiguousarray(tmax, dtype=np.float32)
+        n = len(o)
+        hit, tt, idx = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+        rc = self.lib.wo3_ray_intersect_batch(C.byref(m), _fp(o), _fp(d), _fp(t), n, _ip(hit), _fp(tt), _ip(idx))
+        if rc != 0:
+            raise RuntimeError("wo3_ray_intersect_batch failed")
+        return hit, tt, idx
+
+    def green_ball3(self, R, r):
+        e, nrm, pdf = C.c_float(), C.c_float(), C.c_float()
+        self.lib.wo3_green_ball.restype = None
+        self.lib.wo3_green_ball(C.c_float(R), C.c_float(r), C.byref(e), C.byref(nrm), C.byref(pdf))
+        return e.value, nrm.value, pdf.value
 
     def render_source(self, sd, width, height):
         sc = self.make_scene(sd)

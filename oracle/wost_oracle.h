@@ -139,6 +139,31 @@ int wo_render_source(const wo_scene *sc, const wo_settings *st, float *out_rgb);
 int wo_render_dirichlet_sdf(const wo_scene *sc, const wo_settings *st, int n_threads,
                             float *out_dist);
 
+/* ---- 3-D uniform path (oracle/wost_oracle3d.c) --------------------------- */
+typedef struct wo3_mesh {
+    int n_verts;
+    int n_tris;
+    const float *verts;   /* n_verts * 3 */
+    const int *tris;      /* n_tris * 3, 0-based */
+    const float *colors;  /* n_verts * 6 (colour on the side the normal points to, colour on the other side) or NULL */
+} wo3_mesh;
+typedef struct wo3_scene {
+    wo3_mesh dirichlet, neumann;          /* n_tris == 0 -> disabled */
+    float dirichlet_intensity, neumann_intensity;
+    float probe_scale;                    /* EvaluationGrid<3>::ProbeData (core/evaluation_grid.h:48-55) */
+    float probe_pos[3], probe_up[3], probe_right[3];
+    const unsigned char *mask;
+} wo3_scene;
+int wo3_solve(const wo3_scene *sc, const wo_settings *st, int pixel_begin, int pixel_end, int n_threads, float *field_rgb,
+              wo_stats *stats);
+/* closest triangle (lowest index on ties), distance, barycentric (u, v) of the projection, side */
+int wo3_closest_point_batch(const wo3_mesh *mesh, const float *pts, int n, int *out_idx, float *out_dist, float *out_uv,
+                            int *out_side);
+int wo3_closest_silhouette_batch(const wo3_mesh *mesh, const float *pts, const float *rmax, int n, float *out_dist);
+int wo3_ray_intersect_batch(const wo3_mesh *mesh, const float *origins, const float *dirs, const float *tmax, int n,
+                            int *out_hit, float *out_t, int *out_idx);
+void wo3_green_ball(float R, float r, float *eval, float *norm, float *pdf_radius);
+
 /* ---- guided path, deterministic distribution layer (oracle/wost_vmm.c) ---- */
 float wo_eval_poly_large0(float y);
 float wo_log_bessel(float x, int order);

@@ -1,0 +1,550 @@
+/*
+ * wost_oracle3d.c -- CPU oracle of the 3-D uniform Walk-on-Stars path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see wost_oracle.h).  Restates, line by line, the DIM == 3 branches of
+ *   integrator/uniform/integrator.cu:128-211 (separateEvaluationPoint: triangle, barycentric uv, :150-168),
+ *   :224-231 (handleBoundary), :336-444 (sampleNeumann, u[3]), :465-525 (oneStepWalk),
+ *   integrator/common.h:242-260 + core/math/include/krrmath/functors.h:66-76 (barycentric_interpolate),
+ *   core/evaluation_grid.h:43-70 (EvaluationGrid<3>), util/sampling.h:20-27 (uniformSampleSphere<3>),
+ *   :57-66 (uniformSampleHemisphere<3>), :39-52,91-104,112-115 (pdfs, sphereMeasurement<3>),
+ *   util/transformation.h:11-22,62-67 (Frame<3>, frameFromNormal(Vector3f)),
+ *   util/math_utils.h:141-151 (getPerpendicular(Vector3f)), util/green.h:77-119 (HarmonicGreenBall<3>).
+ * The source term in 3-D (sampleSource with a nanovdb volume) is not restated.
+ *
+ * PARITY STATUS: unpinned.  Every geometric query of the path is snch-lbvh (absent); the reference
+ * ships no 3-D scene, test or golden vector.  As in 2-D the oracle implements the mathematical
+ * definition of each query (exact closest point on a triangle mesh, closest silhouette edge, first
+ * ray hit) by brute force and is checked against analytic harmonic solutions.
+ *
+ * Arithmetic contract, fp32, -ffp-contract=off, fmaf only where written:
+ *   dot3(a,b)  = fmaf(a.x, b.x, fmaf(a.y, b.y, a.z*b.z))
+ *   cross3(a,b) = ( fmaf(a.y,b.z,-(a.z*b.y)), fmaf(a.z,b.x,-(a.x*b.z)), fmaf(a.x,b.y,-(a.y*b.x)) )
+ *   closest point on a triangle: the region walk of Ericson, Real-Time Collision Detection 5.1.5,
+ *   written out below; ties between triangles go to the lowest index.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "wost_internal.h"
+#include "wost_oracle.h"
+
+#define WO_4PI 12.5663706143591729539f
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 v3_sub(v3 a, v3 b) { v3 r = { a.x - b.x, a.y - b.y, a.z - b.z }; return r; }
+static inline float dot3(v3 a, v3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+static inline v3 cross3(v3 a, v3 b)
+{
+    v3 r = { fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)) };
+    return r;
+}
+/* p + t * d, one fmaf per component */
+static inline v3 v3_madd(v3 p, float t, v3 d) { v3 r = { fmaf(t, d.x, p.x), fmaf(t, d.y, p.y), fmaf(t, d.z, p.z) }; return r; }
+static inline v3 v3_normalize(v3 a)
+{
+    const float l = sqrtf(dot3(a, a));
+    v3 r = { a.x / l, a.y / l, a.z / l };
+    return r;
+}
+
+/* ---- prepared triangle mesh ------------------------------------------------------------- */
+typedef struct {
+    v3 p0, e0, e1;       /* p0, p1 - p0, p2 - p0 */
+    v3 p1, p2;
+    v3 nraw, n;          /* cross3(e0, e1) and the unit normal (0 when degenerate) */
+    float area;
+    int i0, i1, i2;
+    v3 bc;               /* bounding sphere, pruning only */
+    float br;
+} ptri;
+
+typedef struct { int a, b, t0, t1; } pedge;   /* vertices in the winding order of t0; t1 = -1: boundary edge */
+
+typedef struct {
+    int n_tris, n_verts, n_edges;
+    ptri *tris;
+    pedge *edges;
+    const float *verts, *colors;
+} pmesh3;
+
+static v3 vert3(const float *v, int i) { v3 r = { v[3 * i], v[3 * i + 1], v[3 * i + 2] }; return r; }
+
+static void pmesh3_free(pmesh3 *m) { free(m->tris); free(m->edges); memset(m, 0, sizeof(*m)); }
+
+typedef struct { int a, b, t, k; } edge_key;
+static int edge_key_cmp(const void *x, const void *y)
+{
+    const edge_key *p = x, *q = y;
+    if (p->a != q->a) return p->a < q->a ? -1 : 1;
+    if (p->b != q->b) return p->b < q->b ? -1 : 1;
+    if (p->t != q->t) return p->t < q->t ? -1 : 1;
+    return 0;
+}
+
+static int pmesh3_prepare(pmesh3 *m, const wo3_mesh *in)
+{
+    memset(m, 0, sizeof(*m));
+    m->n_tris = in->n_tris; m->n_verts = in->n_verts; m->verts = in->verts; m->colors = in->colors;
+    if (in->n_tris <= 0) return 0;
+    m->tris = calloc((size_t)in->n_tris, sizeof(ptri));
+    for (int t = 0; t < in->n_tris; ++t) {
+        ptri *T = &m->tris[t];
+        T->i0 = in->tris[3 * t]; T->i1 = in->tris[3 * t + 1]; T->i2 = in->tris[3 * t + 2];
+        if (T->i0 < 0 || T->i1 < 0 || T->i2 < 0 || T->i0 >= in->n_verts || T->i1 >= in->n_verts || T->i2 >= in->n_verts) return -1;
+        T->p0 = vert3(in->verts, T->i0); T->p1 = vert3(in->verts, T->i1); T->p2 = vert3(in->verts, T->i2);
+        T->e0 = v3_sub(T->p1, T->p0); T->e1 = v3_sub(T->p2, T->p0);
+        T->nraw = cross3(T->e0, T->e1);
+        const float l = sqrtf(dot3(T->nraw, T->nraw));
+        T->area = 0.5f * l;
+        if (l > 0.0f) { T->n.x = T->nraw.x / l; T->n.y = T->nraw.y / l; T->n.z = T->nraw.z / l; }
+        /* bounding sphere around the centroid (double, padded): pruning only */
+        double cx = ((double)T->p0.x + T->p1.x + T->p2.x) / 3.0, cy = ((double)T->p0.y + T->p1.y + T->p2.y) / 3.0,
+               cz = ((double)T->p0.z + T->p1.z + T->p2.z) / 3.0, r = 0.0;
+        const v3 P[3] = { T->p0, T->p1, T->p2 };
+        for (int k = 0; k < 3; ++k) {
+            const double dx = P[k].x - cx, dy = P[k].y - cy, dz = P[k].z - cz, d = sqrt(dx * dx + dy * dy + dz * dz);
+            if (d > r) r = d;
+        }
+        T->bc.x = (float)cx; T->bc.y = (float)cy; T->bc.z = (float)cz;
+        T->br = (float)(r * 1.001 + 1e-6 * (fabs(cx) + fabs(cy) + fabs(cz) + 1.0));
+    }
+    /* edges: (min vertex, max vertex) -> the first two incident triangles in index order; the edge
+     * keeps the direction it has in its first triangle */
+    edge_key *keys = malloc(sizeof(edge_key) * 3 * (size_t)in->n_tris);
+    for (int t = 0; t < in->n_tris; ++t) {
+        const int v[3] = { m->tris[t].i0, m->tris[t].i1, m->tris[t].i2 };
+        for (int k = 0; k < 3; ++k) {
+            const int a = v[k], b = v[(k + 1) % 3];
+            edge_key e = { a < b ? a : b, a < b ? b : a, t, k };
+            keys[3 * t + k] = e;
+        }
+    }
+    qsort(keys, 3 * (size_t)in->n_tris, sizeof(edge_key), edge_key_cmp);
+    m->edges = malloc(sizeof(pedge) * 3 * (size_t)in->n_tris);
+    int ne = 0;
+    for (int i = 0; i < 3 * in->n_tris;) {
+        int j = i;
+        while (j < 3 * in->n_tris && keys[j].a == keys[i].a && keys[j].b == keys[i].b) ++j;
+        const int t0 = keys[i].t, k0 = keys[i].k;
+        const int v[3] = { m->tris[t0].i0, m->tris[t0].i1, m->tris[t0].i2 };
+        pedge e = { v[k0], v[(k0 + 1) % 3], t0, (j - i >= 2) ? keys[i + 1].t : -1 };
+        if (e.a != e.b) m->edges[ne++] = e;
+        i = j;
+    }
+    free(keys);
+    m->n_edges = ne;
+    return 0;
+}
+
+/* closest point of the triangle to q (Ericson 5.1.5), squared distance */
+static float tri_d2(const ptri *T, v3 q)
+{
+    const v3 ab = T->e0, ac = T->e1, ap = v3_sub(q, T->p0);
+    const float d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+    v3 c;
+    if (d1 <= 0.0f && d2 <= 0.0f) c = T->p0;
+    else {
+        const v3 bp = v3_sub(q, T->p1);
+        const float d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+        if (d3 >= 0.0f && d4 <= d3) c = T->p1;
+        else {
+            const float vc = fmaf(d1, d4, -(d3 * d2));
+            if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) c = v3_madd(T->p0, d1 / (d1 - d3), ab);
+            else {
+                const v3 cp = v3_sub(q, T->p2);
+                const float d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+                if (d6 >= 0.0f && d5 <= d6) c = T->p2;
+                else {
+                    const float vb = fmaf(d5, d2, -(d1 * d6));
+                    if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) c = v3_madd(T->p0, d2 / (d2 - d6), ac);
+                    else {
+                        const float va = fmaf(d3, d6, -(d5 * d4));
+                        if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f)
+                            c = v3_madd(T->p1, (d4 - d3) / ((d4 - d3) + (d5 - d6)), v3_sub(T->p2, T->p1));
+                        else {
+                            const float denom = 1.0f / (va + vb + vc);
+                            c = v3_madd(v3_madd(T->p0, vb * denom, ab), vc * denom, ac);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const v3 w = v3_sub(q, c);
+    return dot3(w, w);
+}
+
+typedef struct { int idx; float d2; } cp3;
+
+static cp3 closest_tri(const pmesh3 *m, v3 q)
+{
+    cp3 best = { -1, INFINITY };
+    for (int t = 0; t < m->n_tris; ++t) {
+        const ptri *T = &m->tris[t];
+        /* bounding-sphere rejection in double with slack: cannot drop a triangle that ties or wins */
+        if (best.idx >= 0) {
+            const double dx = (double)q.x - T->bc.x, dy = (double)q.y - T->bc.y, dz = (double)q.z - T->bc.z;
+            const double lb = sqrt(dx * dx + dy * dy + dz * dz) - T->br;
+            if (lb > 0.0 && lb * lb * (1.0 - 1e-5) > (double)best.d2) continue;
+        }
+        const float d = tri_d2(T, q);
+        if (d < best.d2) { best.d2 = d; best.idx = t; }     /* ascending t: lowest index wins ties */
+    }
+    return best;
+}
+
+/* lbvh::checkPointSide(p0, p1, p2, q): side of the plane the (unnormalised) normal points to */
+static int tri_side(const ptri *T, v3 q)
+{
+    const float s = dot3(T->nraw, v3_sub(q, T->p0));
+    return (0.0f < s) - (s < 0.0f);
+}
+/* lbvh::computeProjectionRatio(p0, p1, p2, q): barycentric (u, v) of the projection of q onto the
+ * plane, point = (1-u-v) p0 + u p1 + v p2 (functors.h:66-76), unclamped */
+static void tri_uv(const ptri *T, v3 q, float *u, float *v)
+{
+    const v3 ap = v3_sub(q, T->p0);
+    const float d00 = dot3(T->e0, T->e0), d01 = dot3(T->e0, T->e1), d11 = dot3(T->e1, T->e1);
+    const float d20 = dot3(ap, T->e0), d21 = dot3(ap, T->e1);
+    const float denom = fmaf(d00, d11, -(d01 * d01));
+    *u = fmaf(d11, d20, -(d01 * d21)) / denom;
+    *v = fmaf(d00, d21, -(d01 * d20)) / denom;
+}
+
+/* computeSurfaceColor<3> + barycentric_interpolate: (a w + b u) + c v, w = 1 - u - v */
+static void surface_color3(const float *colors, const ptri *T, int side, float u, float v, float out[3])
+{
+    const float w = 1 - u - v;
+    for (int c = 0; c < 3; ++c) {
+        float a = 0.0f, b = 0.0f, cc = 0.0f;
+        if (colors) {
+            const int off = (side >= 0) ? 0 : 3;
+            a = colors[6 * T->i0 + off + c]; b = colors[6 * T->i1 + off + c]; cc = colors[6 * T->i2 + off + c];
+        }
+        out[c] = (a * w + b * u) + cc * v;
+    }
+}
+
+/* closest silhouette EDGE (FCPW isSilhouetteEdge, flipNormalOrientation = false), within rmax */
+static float closest_silhouette3(const pmesh3 *m, v3 q, float rmax)
+{
+    float best2 = rmax * rmax;
+    int found = 0;
+    for (int i = 0; i < m->n_edges; ++i) {
+        const pedge *E = &m->edges[i];
+        const v3 pa = vert3(m->verts, E->a), pb = vert3(m->verts, E->b), e = v3_sub(pb, pa);
+        const float ee = dot3(e, e);
+        float t = ee > 0.0f ? dot3(v3_sub(q, pa), e) / ee : 0.0f;
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        const v3 pt = v3_madd(pa, t, e), view = v3_sub(q, pt);
+        const float d2 = dot3(view, view);
+        if (d2 > best2) continue;
+        int is_sil = E->t1 < 0;
+        if (!is_sil) {
+            const v3 n0 = m->tris[E->t0].n, n1 = m->tris[E->t1].n;
+            const float d = sqrtf(d2);
+            if (d <= WO_SIL_PRECISION) {
+                const v3 ed = v3_normalize(e);
+                const float det = dot3(ed, cross3(n0, n1));
+                is_sil = (-det > WO_SIL_PRECISION);
+            } else {
+                const v3 vd = { view.x / d, view.y / d, view.z / d };
+                const float dot0 = dot3(vd, n0), dot1 = dot3(vd, n1);
+                if (fabsf(dot0) <= WO_SIL_PRECISION || fabsf(dot1) <= WO_SIL_PRECISION) is_sil = 0;
+                else is_sil = (dot0 * dot1 < 0.0f);
+            }
+        }
+        if (is_sil && (d2 < best2 || !found)) { best2 = d2; found = 1; }
+    }
+    return found ? sqrtf(best2) : INFINITY;
+}
+
+/* ray / triangle (Moeller-Trumbore with the sign folded out, like the 2-D segment test) */
+static int tri_ray(const ptri *T, v3 o, v3 d, float tmax, float *t)
+{
+    const v3 pvec = cross3(d, T->e1);
+    const float det = dot3(T->e0, pvec);
+    if (det == 0.0f) return 0;
+    const v3 tvec = v3_sub(o, T->p0);
+    const float sgn = det < 0.0f ? -1.0f : 1.0f, adet = fabsf(det);
+    const float u = dot3(tvec, pvec) * sgn;
+    if (u < 0.0f || u > adet) return 0;
+    const v3 qvec = cross3(tvec, T->e0);
+    const float v = dot3(d, qvec) * sgn;
+    if (v < 0.0f || u + v > adet) return 0;
+    const float tt = dot3(T->e1, qvec);
+    const float ts = tt * sgn;
+    if (ts < 0.0f || ts > tmax * adet) return 0;
+    *t = tt / det;
+    return 1;
+}
+static int ray_closest3(const pmesh3 *m, v3 o, v3 d, float tmax, float *t_out, int *idx_out)
+{
+    int hit = 0, bi = -1;
+    float bt = INFINITY;
+    for (int i = 0; i < m->n_tris; ++i) {
+        float t;
+        if (tri_ray(&m->tris[i], o, d, tmax, &t) && (!hit || t < bt)) { bt = t; bi = i; hit = 1; }
+    }
+    *t_out = bt; *idx_out = bi;
+    return hit;
+}
+static int ray_any3(const pmesh3 *m, v3 o, v3 d, float tmax)
+{
+    for (int i = 0; i < m->n_tris; ++i) { float t; if (tri_ray(&m->tris[i], o, d, tmax, &t)) return 1; }
+    return 0;
+}
+
+/* sample_object_in_sphere for triangles: those touching the ball, probability ~ area, inverse CDF
+ * in index order, pdf = P(i) / area(i) (density with respect to area) */
+static int sample_in_sphere3(const pmesh3 *m, v3 q, float R, float u, float *pdf)
+{
+    const float R2 = R * R;
+    float total = 0.0f;
+    for (int i = 0; i < m->n_tris; ++i)
+        if (m->tris[i].area > 0.0f && tri_d2(&m->tris[i], q) <= R2) total += m->tris[i].area;
+    *pdf = 0.0f;
+    if (!(total > 0.0f)) return -1;
+    const float target = u * total;
+    float cum = 0.0f;
+    int last = -1;
+    for (int i = 0; i < m->n_tris; ++i)
+        if (m->tris[i].area > 0.0f && tri_d2(&m->tris[i], q) <= R2) {
+            cum += m->tris[i].area; last = i;
+            if (target < cum) break;
+        }
+    *pdf = (m->tris[last].area / total) / m->tris[last].area;
+    return last;
+}
+
+/* getPerpendicular(Vector3f) + frameFromNormal(Vector3f) + Frame<3>::toWorld */
+static v3 frame_to_world(v3 n, float lx, float ly, float lz)
+{
+    const float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
+    const unsigned uyx = (ax - ay) < 0 ? 1 : 0, uzx = (ax - az) < 0 ? 1 : 0, uzy = (ay - az) < 0 ? 1 : 0;
+    const unsigned xm = uyx & uzx, ym = (1 ^ xm) & uzy, zm = 1 ^ (xm | ym);
+    const v3 axis = { (float)xm, (float)ym, (float)zm };
+    const v3 t = v3_normalize(cross3(n, axis)), b = v3_normalize(cross3(n, t));
+    v3 r = { (t.x * lx + b.x * ly) + n.x * lz, (t.y * lx + b.y * ly) + n.y * lz, (t.z * lx + b.z * ly) + n.z * lz };
+    return r;
+}
+
+/* EvaluationGrid<3>::getEvaluationPoint (core/evaluation_grid.h:57-61) */
+static v3 eval_point3(const wo3_scene *sc, int px, int py, int width, int height)
+{
+    const float ndcx = 2.0f * (float)px / (float)width + -1.0f, ndcy = 2.0f * (float)py / (float)height + -1.0f;
+    v3 r;
+    r.x = sc->probe_scale * (ndcx * sc->probe_right[0] + ndcy * sc->probe_up[0]) + sc->probe_pos[0];
+    r.y = sc->probe_scale * (ndcx * sc->probe_right[1] + ndcy * sc->probe_up[1]) + sc->probe_pos[1];
+    r.z = sc->probe_scale * (ndcx * sc->probe_right[2] + ndcy * sc->probe_up[2]) + sc->probe_pos[2];
+    return r;
+}
+
+typedef struct { uint64_t steps, started, absorbed, truncated, nhits; } pix3_stats;
+
+static void solve_pixel3(const wo3_scene *sc, const wo_settings *st, const pmesh3 *dm, const pmesh3 *nm, int pixel_id,
+                         float sol_out[3], pix3_stats *ps)
+{
+    const int has_d = dm->n_tris > 0, has_n = nm->n_tris > 0;
+    const float eps = st->eps_shell;
+    wo_pcg rng;
+    wo_pcg_seed_pixel(&rng, pixel_id, st->width);
+    float sol[3] = { 0.0f, 0.0f, 0.0f };
+    const int masked = sc->mask && sc->mask[pixel_id] == 0;
+    for (int sample = 0; sample < st->spp && !masked; ++sample) {
+        v3 p = eval_point3(sc, pixel_id % st->width, pixel_id / st->width, st->width, st->height);
+        float thp = 1.0f;
+        int on_n = 0;
+        v3 nn = { 0.0f, 0.0f, 0.0f };
+        ps->started++;
+        int depth;
+        for (depth = 0; depth < st->max_depth; ++depth) {
+            ps->steps++;
+            /* ---- separateEvaluationPoint (integrator.cu:128-211, DIM == 3) ---- */
+            float R_D = INFINITY;
+            if (has_d) {
+                const cp3 cp = closest_tri(dm, p);
+                const ptri *T = &dm->tris[cp.idx];
+                const int side = tri_side(T, p);
+                float u, v;
+                tri_uv(T, p, &u, &v);
+                R_D = sqrtf(cp.d2);
+                if (R_D < eps && u > 0.0f && v > 0.0f && u + v < 1.0f) {
+                    float col[3];
+                    surface_color3(dm->colors, T, side, u, v, col);
+                    for (int c = 0; c < 3; ++c) {
+                        col[c] *= sc->dirichlet_intensity;
+                        col[c] *= thp;
+                        sol[c] = col[c] + sol[c];
+                    }
+                    ps->absorbed++;
+                    break;
+                }
+            }
+            float R_N = INFINITY;
+            if (has_n) R_N = closest_silhouette3(nm, p, R_D);
+            float R_B = fmaxf(WO_R_B_FLOOR, fminf(R_D, R_N));
+            R_B *= WO_R_B_SHRINK;
+            if (isinf(R_B)) break;
+            /* ---- sampleNeumann (integrator.cu:336-444): three draws in 3-D ---- */
+            if (has_n) {
+                const float u0 = wo_pcg_next_float(&rng), u1 = wo_pcg_next_float(&rng), u2 = wo_pcg_next_float(&rng);
+                float pdf;
+                const int oi = sample_in_sphere3(nm, p, R_B, u0, &pdf);
+                if (oi != -1 && pdf > 0) {
+                    const ptri *S = &nm->tris[oi];
+                    /* sample_on_object: uniform point of the triangle from (u1, u2) */
+                    const float su = sqrtf(u1), b1 = u2 * su, b0 = 1.0f - su;
+                    const float b2 = 1.0f - b0 - b1;
+                    v3 sp = { (S->p0.x * b0 + S->p1.x * b1) + S->p2.x * b2, (S->p0.y * b0 + S->p1.y * b1) + S->p2.y * b2,
+                              (S->p0.z * b0 + S->p1.z * b1) + S->p2.z * b2 };
+                    const v3 rv = v3_sub(sp, p);
+                    const float r = sqrtf(dot3(rv, rv));
+                    if (r < R_B && r > 0) {
+                        v3 o = p;
+                        if (on_n) o = (v3){ p.x + eps * nn.x, p.y + eps * nn.y, p.z + eps * nn.z };
+                        v3 rd = v3_sub(sp, o);
+                        const float cd = sqrtf(dot3(rd, rd));
+                        if (cd > 0) { rd.x /= cd; rd.y /= cd; rd.z /= cd; }
+                        if (!ray_any3(nm, o, rd, cd - eps)) {
+                            int side = tri_side(S, p);
+                            float uu, vv;
+                            tri_uv(S, sp, &uu, &vv);
+                            if (on_n) {
+                                const float dn = dot3(S->n, nn);
+                                side = (0.0f < dn) - (dn < 0.0f);
+                            }
+                            if (side != 0) {
+                                float col[3];
+                                surface_color3(nm->colors, S, side, uu, vv, col);
+                                const float alpha = on_n ? 0.5f : 1.0f;
+                                const float G = (1.0f / r - 1.0f / R_B) / WO_4PI;      /* HarmonicGreenBall<3>::eval */
+                                for (int c = 0; c < 3; ++c) {
+                                    col[c] *= sc->neumann_intensity;
+                                    col[c] *= thp * G / alpha / pdf;
+                                    sol[c] = -col[c] + sol[c];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            /* ---- oneStepWalk (integrator.cu:465-525) ---- */
+            v3 dir, cur = p;
+            float pdf, alpha = 1.0f;
+            {
+                const float u1 = wo_pcg_next_float(&rng), u2 = wo_pcg_next_float(&rng);
+                float c, s;
+                wo_sincos_2pi(u2, &c, &s);
+                if (on_n) {
+                    const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+                    dir = frame_to_world(nn, r * c, r * s, z);
+                    pdf = 1.0f / WO_2PI;
+                    alpha = 0.5f;
+                    cur = (v3){ p.x + eps * nn.x, p.y + eps * nn.y, p.z + eps * nn.z };
+                } else {
+                    const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
+                    dir = (v3){ r * c, r * s, z };
+                    pdf = 1.0f / WO_4PI;
+                }
+            }
+            v3 nxt = { p.x + R_B * dir.x, p.y + R_B * dir.y, p.z + R_B * dir.z };
+            int hit = 0;
+            v3 hn = { 0.0f, 0.0f, 0.0f };
+            if (has_n) {
+                float t; int hi;
+                hit = ray_closest3(nm, cur, dir, R_B, &t, &hi);
+                if (hit) {
+                    hn = nm->tris[hi].n;
+                    if (dot3(hn, dir) > 0) { hn.x = -hn.x; hn.y = -hn.y; hn.z = -hn.z; }
+                    nxt = (v3){ cur.x + t * dir.x, cur.y + t * dir.y, cur.z + t * dir.z };
+                    ps->nhits++;
+                }
+            }
+            thp = thp / pdf / alpha / WO_4PI;
+            p = nxt; on_n = hit; nn = hn;
+        }
+        if (depth == st->max_depth) ps->truncated++;
+    }
+    for (int c = 0; c < 3; ++c) sol_out[c] = sol[c] / (float)st->spp;
+}
+
+int wo3_solve(const wo3_scene *sc, const wo_settings *st, int pixel_begin, int pixel_end, int n_threads, float *field_rgb,
+              wo_stats *stats)
+{
+    if (!sc || !st || !field_rgb || pixel_begin < 0 || pixel_end > st->width * st->height || pixel_begin > pixel_end) return -1;
+    pmesh3 dm, nm;
+    if (pmesh3_prepare(&dm, &sc->dirichlet) != 0 || pmesh3_prepare(&nm, &sc->neumann) != 0) return -1;
+    uint64_t steps = 0, started = 0, absorbed = 0, truncated = 0, nhits = 0;
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads) reduction(+ : steps, started, absorbed, truncated, nhits)
+    for (int pid = pixel_begin; pid < pixel_end; ++pid) {
+        pix3_stats ps = { 0, 0, 0, 0, 0 };
+        solve_pixel3(sc, st, &dm, &nm, pid, field_rgb + 3 * (size_t)(pid - pixel_begin), &ps);
+        steps += ps.steps; started += ps.started; absorbed += ps.absorbed; truncated += ps.truncated; nhits += ps.nhits;
+    }
+    if (stats) {
+        stats->walk_steps = steps; stats->walks_started = started; stats->walks_absorbed = absorbed;
+        stats->walks_truncated = truncated; stats->neumann_hits = nhits; stats->seconds = 0.0;
+    }
+    pmesh3_free(&dm); pmesh3_free(&nm);
+    return 0;
+}
+
+int wo3_closest_point_batch(const wo3_mesh *mesh, const float *pts, int n, int *out_idx, float *out_dist, float *out_uv,
+                            int *out_side)
+{
+    pmesh3 m;
+    if (pmesh3_prepare(&m, mesh) != 0 || m.n_tris == 0) return -1;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        const v3 q = { pts[3 * i], pts[3 * i + 1], pts[3 * i + 2] };
+        const cp3 c = closest_tri(&m, q);
+        if (out_idx) out_idx[i] = c.idx;
+        if (out_dist) out_dist[i] = sqrtf(c.d2);
+        if (out_uv) tri_uv(&m.tris[c.idx], q, &out_uv[2 * i], &out_uv[2 * i + 1]);
+        if (out_side) out_side[i] = tri_side(&m.tris[c.idx], q);
+    }
+    pmesh3_free(&m);
+    return 0;
+}
+
+int wo3_closest_silhouette_batch(const wo3_mesh *mesh, const float *pts, const float *rmax, int n, float *out_dist)
+{
+    pmesh3 m;
+    if (pmesh3_prepare(&m, mesh) != 0) return -1;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        const v3 q = { pts[3 * i], pts[3 * i + 1], pts[3 * i + 2] };
+        out_dist[i] = m.n_tris ? closest_silhouette3(&m, q, rmax ? rmax[i] : INFINITY) : INFINITY;
+    }
+    pmesh3_free(&m);
+    return 0;
+}
+
+int wo3_ray_intersect_batch(const wo3_mesh *mesh, const float *origins, const float *dirs, const float *tmax, int n,
+                            int *out_hit, float *out_t, int *out_idx)
+{
+    pmesh3 m;
+    if (pmesh3_prepare(&m, mesh) != 0) return -1;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        const v3 o = { origins[3 * i], origins[3 * i + 1], origins[3 * i + 2] }, d = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
+        float t; int idx;
+        out_hit[i] = ray_closest3(&m, o, d, tmax[i], &t, &idx);
+        out_t[i] = t; out_idx[i] = idx;
+    }
+    pmesh3_free(&m);
+    return 0;
+}
+
+/* HarmonicGreenBall<3> (util/green.h:77-119): eval, norm, pdfRadius -- exposed for unit tests */
+void wo3_green_ball(float R, float r, float *eval, float *norm, float *pdf_radius)
+{
+    *eval = (1.0f / r - 1.0f / R) / WO_4PI;
+    *norm = R * R / 6.0f;
+    *pdf_radius = 6.0f * r * (R - r) / (R * R * R);
+}

@@ -113,3 +113,86 @@ def wiggly_problem(n_neumann=3000, n_dirichlet=400, emissive=False, open_gap=0):
         nc[:, 3:6] = nc[:, 0:3]
     return Problem(d_verts=dv, d_segs=ds, d_colors=dc, n_verts=nv, n_segs=ns, n_colors=nc,
                    probe=(110.0, 0.0, 0.0, 0.0, 1.0))
+
+
+def cube_scene3(n=4, d_faces=(0, 1, 2, 3, 4, 5), n_faces=(), value=None, flux=None, lo=0.0, hi=1.0, probe=None, weld=True):
+    """Axis-aligned cube [lo,hi]^3 as a 3-D scene dict for the oracle / Problem3: every face is an
+    n x n grid of quads cut into two triangles, outward normals.  Faces: 0 x=lo, 1 x=hi, 2 y=lo,
+    3 y=hi, 4 z=lo, 5 z=hi.  value(x,y,z) -> Dirichlet value, flux(x,y,z,face) -> Neumann colour
+    (derivative along the inward normal).  The probe is the slice z = mid.  weld: faces of one mesh share
+    the vertices on the cube's edges (watertight); per-face colours that jump across an edge need weld=False."""
+    def face_mesh(faces, fn):
+        verts, tris, cols = [], [], []
+        for f in faces:
+            axis, side = f // 2, f % 2
+            base = len(verts)
+            for j in range(n + 1):
+                for i in range(n + 1):
+                    a, b = lo + (hi - lo) * i / n, lo + (hi - lo) * j / n
+                    p = [0.0, 0.0, 0.0]
+                    p[axis] = hi if side else lo
+                    p[(axis + 1) % 3], p[(axis + 2) % 3] = a, b
+                    verts.append(p)
+                    v = 0.0 if fn is None else fn(p[0], p[1], p[2], f)
+                    cols.append([v] * 6)
+            for j in range(n):
+                for i in range(n):
+                    v00, v10 = base + j * (n + 1) + i, base + j * (n + 1) + i + 1
+                    v01, v11 = v00 + n + 1, v10 + n + 1
+                    # (axis+1, axis+2, axis) is right-handed: counter-clockwise in (a, b) faces +axis
+                    quad = [(v00, v10, v11), (v00, v11, v01)] if side else [(v00, v11, v10), (v00, v01, v11)]
+                    tris += quad
+        if not verts:
+            return None, None, None
+        # weld the vertices the faces share along the cube's edges (a closed, watertight surface)
+        index, wv, wc, remap = {}, [], [], []
+        for p, c in zip(verts, cols):
+            k = tuple(round(x, 9) for x in p) if weld else len(wv)
+            if k not in index:
+                index[k] = len(wv)
+                wv.append(p)
+                wc.append(c)
+            remap.append(index[k])
+        tris = [(remap[a], remap[b], remap[c]) for a, b, c in tris]
+        return np.asarray(wv, np.float32), np.asarray(tris, np.int32), np.asarray(wc, np.float32)
+
+    dv, dt, dc = face_mesh(d_faces, (lambda x, y, z, f: value(x, y, z)) if value else None)
+    nv, nt, nc = face_mesh(n_faces, flux)
+    mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    if probe is None:
+        probe = (0.9 * half, (mid, mid, mid), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0))
+    return {"d_verts": dv, "d_tris": dt, "d_colors": dc, "n_verts": nv, "n_tris": nt, "n_colors": nc, "probe": probe,
+            "dirichlet_intensity": 1.0, "neumann_intensity": 1.0}
+
+
+def sphere_scene3(subdiv=2, radius=1.0, value=None, probe=None):
+    """Icosphere (20 * 4^subdiv triangles, outward normals) with Dirichlet values value(x,y,z)."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1),
+         (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    verts = [np.asarray(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                m = verts[a] + verts[b]
+                verts.append(m / np.linalg.norm(m))
+                cache[k] = len(verts) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    V = (np.asarray(verts) * radius).astype(np.float32)
+    T = np.asarray(f, np.int32)
+    cols = np.zeros((len(V), 6), np.float32)
+    if value is not None:
+        cols[:] = np.asarray([value(*p) for p in V], np.float32)[:, None]
+    if probe is None:
+        probe = (0.8 * radius, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0))
+    return {"d_verts": V, "d_tris": T, "d_colors": cols, "n_verts": None, "n_tris": None, "n_colors": None, "probe": probe,
+            "dirichlet_intensity": 1.0, "neumann_intensity": 1.0}
