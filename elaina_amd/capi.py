@@ -78,6 +78,19 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class Mesh3Desc(C.Structure):
+    """wost3_mesh_desc (include/wost.h)"""
+    _fields_ = [("n_verts", C.c_int32), ("n_tris", C.c_int32), ("verts", C.POINTER(C.c_float)), ("tris", C.POINTER(C.c_int32)),
+                ("colors", C.POINTER(C.c_float))]
+
+
+class Scene3Desc(C.Structure):
+    """wost3_scene_desc (include/wost.h)"""
+    _fields_ = [("dirichlet", Mesh3Desc), ("neumann", Mesh3Desc), ("dirichlet_intensity", C.c_float),
+                ("neumann_intensity", C.c_float), ("probe_scale", C.c_float), ("probe_pos", C.c_float * 3),
+                ("probe_up", C.c_float * 3), ("probe_right", C.c_float * 3), ("mask", C.POINTER(C.c_uint8))]
+
+
 class NetConfig(C.Structure):
     """wost_net_config (include/wost.h); defaults = reference data/ladybug/n.json:49-81."""
     _fields_ = [
@@ -129,6 +142,8 @@ EXPORTS = [
     "wost_net_create", "wost_net_destroy", "wost_net_n_params", "wost_net_get_params",
     "wost_net_set_params", "wost_net_set_gradient_buffer", "wost_net_inference", "wost_net_train_step",
     "wost_guided_create", "wost_guided_set_sync", "wost_guided_set_frame_callback", "wost_guided_network", "wost_guided_scene", "wost_guided_query_network", "wost_guided_solve", "wost_guided_solve_sharded", "wost_guided_train_set", "wost_guided_destroy",
+    "wost3_create", "wost3_solve", "wost3_solve_sharded", "wost3_closest_point", "wost3_closest_silhouette", "wost3_ray_intersect",
+    "wost3_destroy",
     "wost_last_error", "wost_version",
 ]
 
@@ -192,6 +207,13 @@ def load():
     L.wost_guided_train_set.argtypes = [C.c_void_p, C.c_int32, ip, fp, fp, fp, fp, fp, C.POINTER(C.c_uint8)]
     L.wost_guided_destroy.argtypes = [C.c_void_p]
     L.wost_destroy.argtypes = [C.c_void_p]
+    L.wost3_create.argtypes = [C.POINTER(Scene3Desc), C.POINTER(Settings), C.c_int, C.POINTER(C.c_void_p)]
+    L.wost3_solve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, fp, C.POINTER(Stats)]
+    L.wost3_solve_sharded.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    L.wost3_closest_point.argtypes = [C.c_void_p, C.c_int, fp, C.c_int32, ip, fp, fp, ip]
+    L.wost3_closest_silhouette.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_int32, fp]
+    L.wost3_ray_intersect.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, C.c_int32, ip, fp, ip]
+    L.wost3_destroy.argtypes = [C.c_void_p]
     L.wost_last_error.restype = C.c_char_p
     L.wost_version.restype = C.c_char_p
     for name in EXPORTS:

@@ -1,0 +1,1015 @@
+// wost_hip3d.hip -- the 3-D uniform Walk-on-Stars path on MI355X, gfx950 only.
+//
+// UniformIntegrator<3> of the reference: the DIM == 3 branches of integrator/uniform/integrator.cu
+// (:128-211 separateEvaluationPoint with triangles and barycentric uv :150-168, :224-231
+// handleBoundary, :336-444 sampleNeumann with three draws, :465-525 oneStepWalk), EvaluationGrid<3>
+// (core/evaluation_grid.h:43-70), uniformSampleSphere<3> / Hemisphere<3> (util/sampling.h:20-27,57-66),
+// frameFromNormal(Vector3f) (util/transformation.h:62-67, util/math_utils.h:141-151) and
+// HarmonicGreenBall<3>::eval (util/green.h:82-90), behind wost3_* of include/wost.h.
+//
+// Design: the same regenerating walker as the 2-D round kernel -- one lane owns one PIXEL and walks
+// its samples one after the other on the pixel's PCG stream (the reference's per-pixel order) --
+// but a whole solve is ONE launch: a lane runs its pixel to the end.  Closest-point queries descend
+// an implicit 4-ary LBVH over the triangles (3-D Morton order, axis-aligned child boxes, 96-byte
+// nodes, near-first with the per-lane LDS stack and the key format of the 2-D tree, wost_device.h).
+// The Neumann mesh of this first 3-D slice is walked with wave-uniform flat loops (up to
+// WOST3_FLAT_MAX triangles: a box, a clipped plane); larger Neumann meshes and the source term are
+// not built.  Arithmetic contract: DESIGN.md 2.3 -- op for op what oracle/wost_oracle3d.c does.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/wost.h"
+#include "lbvh.h"
+#include "wost_device.h"
+#include "wost_internal.h"
+
+namespace wost {
+
+#define WOST_4PI 12.5663706143591729539f
+#define WOST3_FLAT_MAX 64
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b)
+{
+    return V3{__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x))};
+}
+__device__ __forceinline__ V3 madd3(V3 p, float t, V3 d) { return V3{__builtin_fmaf(t, d.x, p.x), __builtin_fmaf(t, d.y, p.y), __builtin_fmaf(t, d.z, p.z)}; }
+__device__ __forceinline__ V3 normalize3(V3 a)
+{
+    const float l = sqrtf(dot3(a, a));
+    return V3{a.x / l, a.y / l, a.z / l};
+}
+
+// one triangle as the flat loops read it (original order)
+struct DevTri {
+    float p0[3], p1[3], p2[3];
+    float nraw[3], n[3];
+    float area;
+};
+struct DevEdge3 {
+    float pa[3], pb[3];
+    int32_t t0, t1;
+};
+
+struct DevMesh3 {
+    const float4 *nodes;     // [n_nodes * 6] child boxes: lox[4] loy[4] loz[4] hix[4] hiy[4] hiz[4]
+    const float4 *tri;       // [slots * 3] p0, p1, p2 (w unused) in leaf order; empty slots far away
+    const int32_t *triOrig;  // [slots] original triangle index (WOST_FAR_INDEX = empty)
+    const int32_t *triVerts; // [slots * 3] vertex ids (colour lookup)
+    const float *colors;     // [n_verts * 6] or nullptr
+    const DevTri *flat;      // [n_tris] original order
+    const DevEdge3 *edges;   // [n_edges]
+    int32_t n_tris, n_edges, levels, first_leaf, emissive;
+};
+
+struct DevProbe3 {
+    float scale, pos[3], up[3], right[3];
+};
+
+// ---- closest point on one triangle (Ericson 5.1.5), squared distance ------------------------
+__device__ __forceinline__ float tri_d2(V3 p0, V3 p1, V3 p2, V3 q)
+{
+    const V3 ab = p1 - p0, ac = p2 - p0, ap = q - p0;
+    const float d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+    V3 c;
+    if (d1 <= 0.0f && d2 <= 0.0f) c = p0;
+    else {
+        const V3 bp = q - p1;
+        const float d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+        if (d3 >= 0.0f && d4 <= d3) c = p1;
+        else {
+            const float vc = __builtin_fmaf(d1, d4, -(d3 * d2));
+            if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) c = madd3(p0, d1 / (d1 - d3), ab);
+            else {
+                const V3 cp = q - p2;
+                const float d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+                if (d6 >= 0.0f && d5 <= d6) c = p2;
+                else {
+                    const float vb = __builtin_fmaf(d5, d2, -(d1 * d6));
+                    if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) c = madd3(p0, d2 / (d2 - d6), ac);
+                    else {
+                        const float va = __builtin_fmaf(d3, d6, -(d5 * d4));
+                        if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f)
+                            c = madd3(p1, (d4 - d3) / ((d4 - d3) + (d5 - d6)), p2 - p1);
+                        else {
+                            const float denom = 1.0f / (va + vb + vc);
+                            c = madd3(madd3(p0, vb * denom, ab), vc * denom, ac);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const V3 w = q - c;
+    return dot3(w, w);
+}
+
+__device__ __forceinline__ V3 ld3(const float *p) { return V3{p[0], p[1], p[2]}; }
+
+// ---- LBVH traversal: near-first, LDS stack, keys = box distance | level | child (wost_device.h) ----
+__device__ __forceinline__ float aabb_d2(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 q)
+{
+    const float dx = fmaxf(fmaxf(lox - q.x, q.x - hix), 0.0f), dy = fmaxf(fmaxf(loy - q.y, q.y - hiy), 0.0f),
+                dz = fmaxf(fmaxf(loz - q.z, q.z - hiz), 0.0f);
+    return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+}
+
+__device__ __forceinline__ bool trav_visit3(const DevMesh3 &m, V3 q, Trav &T, const LdsColumn &stk)
+{
+    const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
+    if (T.level == m.levels) {
+        // a leaf: its four triangles, exactly; ties go to the lowest ORIGINAL index
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int slot = 4 * T.pos + j;
+            const int o = m.triOrig[slot];
+            if (o == WOST_FAR_INDEX) continue;
+            const float4 a = m.tri[3 * (size_t)slot], b = m.tri[3 * (size_t)slot + 1], c = m.tri[3 * (size_t)slot + 2];
+            const float d = tri_d2(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), q);
+            if (d < T.best.d2) {
+                T.best.d2 = d; T.best.slot = slot; T.best_orig = o;
+            } else if (d == T.best.d2 && slot != T.best.slot) {
+                if (T.best_orig < 0) T.best_orig = (T.best.slot >= 0) ? m.triOrig[T.best.slot] : WOST_FAR_INDEX;
+                if (o < T.best_orig) { T.best.slot = slot; T.best_orig = o; }
+            }
+        }
+        return trav_pop(T, stk);
+    }
+    const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+    const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
+    const float d0 = aabb_d2(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, q), d1 = aabb_d2(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, q);
+    const float d2 = aabb_d2(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, q), d3 = aabb_d2(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, q);
+    const float bd = T.best.d2;
+    const uint32_t tag = (uint32_t)(T.level + 1) << 2;
+    uint32_t k0 = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;
+    uint32_t k1 = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3Fu) | tag | 1u) : 0xffffffffu;
+    uint32_t k2 = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3Fu) | tag | 2u) : 0xffffffffu;
+    uint32_t k3 = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3Fu) | tag | 3u) : 0xffffffffu;
+    cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
+    int sp = T.sp;
+    stk.put(sp, k3); sp += (k3 != 0xffffffffu) ? 1 : 0;
+    stk.put(sp, k2); sp += (k2 != 0xffffffffu) ? 1 : 0;
+    stk.put(sp, k1); sp += (k1 != 0xffffffffu) ? 1 : 0;
+    T.sp = sp;
+    if (k0 != 0xffffffffu) {
+        T.pos = 4 * T.pos + (int)(k0 & 3u);
+        T.level = T.level + 1;
+        return true;
+    }
+    return trav_pop(T, stk);
+}
+
+// seed of a query: the triangle in `slot` (temporal hint: the previous closest triangle)
+__device__ __forceinline__ Closest closest_triangle(const DevMesh3 &m, V3 q, int32_t hint, const LdsColumn &stk)
+{
+    Trav T = trav_begin(Closest{WOST_INF, -1});
+    if (hint >= 0 && m.triOrig[hint] != WOST_FAR_INDEX) {
+        const float4 a = m.tri[3 * (size_t)hint], b = m.tri[3 * (size_t)hint + 1], c = m.tri[3 * (size_t)hint + 2];
+        T.best = Closest{tri_d2(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), q), hint};
+        T.best_orig = m.triOrig[hint];
+    }
+    while (trav_visit3(m, q, T, stk)) {
+    }
+    return T.best;
+}
+
+// checkPointSide / computeProjectionRatio for triangles (oracle tri_side, tri_uv)
+__device__ __forceinline__ int tri_side(V3 p0, V3 nraw, V3 q)
+{
+    const float s = dot3(nraw, q - p0);
+    return (0.0f < s) - (s < 0.0f);
+}
+__device__ __forceinline__ void tri_uv(V3 p0, V3 e0, V3 e1, V3 q, float &u, float &v)
+{
+    const V3 ap = q - p0;
+    const float d00 = dot3(e0, e0), d01 = dot3(e0, e1), d11 = dot3(e1, e1), d20 = dot3(ap, e0), d21 = dot3(ap, e1);
+    const float denom = __builtin_fmaf(d00, d11, -(d01 * d01));
+    u = __builtin_fmaf(d11, d20, -(d01 * d21)) / denom;
+    v = __builtin_fmaf(d00, d21, -(d01 * d20)) / denom;
+}
+// computeSurfaceColor<3> + barycentric_interpolate: (a w + b u) + c v
+__device__ __forceinline__ void surface_color3(const float *colors, int i0, int i1, int i2, int side, float u, float v, float out[3])
+{
+    const float w = 1 - u - v;
+    const int off = (side >= 0) ? 0 : 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a = colors ? colors[6 * (size_t)i0 + off + c] : 0.0f, b = colors ? colors[6 * (size_t)i1 + off + c] : 0.0f,
+                    cc = colors ? colors[6 * (size_t)i2 + off + c] : 0.0f;
+        out[c] = (a * w + b * u) + cc * v;
+    }
+}
+
+// ---- Neumann mesh, flat wave-uniform loops -----------------------------------------------------
+__device__ __forceinline__ float closest_silhouette3_flat(const DevMesh3 &m, V3 q, float rmax)
+{
+    float best2 = rmax * rmax;
+    bool found = false;
+    for (int i = 0; i < m.n_edges; ++i) {
+        const DevEdge3 E = m.edges[i];
+        const V3 pa = ld3(E.pa), pb = ld3(E.pb), e = pb - pa;
+        const float ee = dot3(e, e);
+        float t = ee > 0.0f ? dot3(q - pa, e) / ee : 0.0f;
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        const V3 pt = madd3(pa, t, e), view = q - pt;
+        const float d2 = dot3(view, view);
+        if (d2 > best2) continue;
+        bool is_sil = E.t1 < 0;
+        if (!is_sil) {
+            const V3 n0 = ld3(m.flat[E.t0].n), n1 = ld3(m.flat[E.t1].n);
+            const float d = sqrtf(d2);
+            if (d <= WOST_SIL_PRECISION) {
+                const float det = dot3(normalize3(e), cross3(n0, n1));
+                is_sil = (-det > WOST_SIL_PRECISION);
+            } else {
+                const V3 vd = v3(view.x / d, view.y / d, view.z / d);
+                const float dot0 = dot3(vd, n0), dot1 = dot3(vd, n1);
+                is_sil = !(fabsf(dot0) <= WOST_SIL_PRECISION || fabsf(dot1) <= WOST_SIL_PRECISION) && (dot0 * dot1 < 0.0f);
+            }
+        }
+        if (is_sil && (d2 < best2 || !found)) {
+            best2 = d2;
+            found = true;
+        }
+    }
+    return found ? sqrtf(best2) : WOST_INF;
+}
+
+__device__ __forceinline__ bool tri_ray(const DevTri &T, V3 o, V3 d, float tmax, float &t)
+{
+    const V3 p0 = ld3(T.p0), e0 = ld3(T.p1) - p0, e1 = ld3(T.p2) - p0;
+    const V3 pvec = cross3(d, e1);
+    const float det = dot3(e0, pvec);
+    if (det == 0.0f) return false;
+    const V3 tvec = o - p0;
+    const float sgn = det < 0.0f ? -1.0f : 1.0f, adet = fabsf(det);
+    const float u = dot3(tvec, pvec) * sgn;
+    if (u < 0.0f || u > adet) return false;
+    const V3 qvec = cross3(tvec, e0);
+    const float v = dot3(d, qvec) * sgn;
+    if (v < 0.0f || u + v > adet) return false;
+    const float tt = dot3(e1, qvec), ts = tt * sgn;
+    if (ts < 0.0f || ts > tmax * adet) return false;
+    t = tt / det;
+    return true;
+}
+__device__ __forceinline__ bool ray_closest3_flat(const DevMesh3 &m, V3 o, V3 d, float tmax, float &t_out, int &idx_out)
+{
+    bool hit = false;
+    float bt = WOST_INF;
+    int bi = -1;
+    for (int i = 0; i < m.n_tris; ++i) {
+        float t;
+        if (tri_ray(m.flat[i], o, d, tmax, t) && (!hit || t < bt)) { bt = t; bi = i; hit = true; }
+    }
+    t_out = bt; idx_out = bi;
+    return hit;
+}
+__device__ __forceinline__ bool ray_any3_flat(const DevMesh3 &m, V3 o, V3 d, float tmax)
+{
+    bool hit = false;
+    for (int i = 0; i < m.n_tris; ++i) {
+        float t;
+        hit = hit || tri_ray(m.flat[i], o, d, tmax, t);
+    }
+    return hit;
+}
+__device__ __forceinline__ int sample_in_sphere3_flat(const DevMesh3 &m, V3 q, float R, float u, float &pdf)
+{
+    const float R2 = R * R;
+    float total = 0.0f;
+    for (int i = 0; i < m.n_tris; ++i) {
+        const DevTri T = m.flat[i];
+        if (T.area > 0.0f && tri_d2(ld3(T.p0), ld3(T.p1), ld3(T.p2), q) <= R2) total += T.area;
+    }
+    pdf = 0.0f;
+    if (!(total > 0.0f)) return -1;
+    const float target = u * total;
+    float cum = 0.0f;
+    int last = -1;
+    bool done = false;
+    for (int i = 0; i < m.n_tris; ++i) {
+        const DevTri T = m.flat[i];
+        if (!done && T.area > 0.0f && tri_d2(ld3(T.p0), ld3(T.p1), ld3(T.p2), q) <= R2) {
+            cum += T.area; last = i;
+            if (target < cum) done = true;
+        }
+    }
+    const float a = m.flat[last].area;
+    pdf = (a / total) / a;
+    return last;
+}
+
+// getPerpendicular(Vector3f) + frameFromNormal(Vector3f) + Frame<3>::toWorld
+__device__ __forceinline__ V3 frame_to_world(V3 n, float lx, float ly, float lz)
+{
+    const float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
+    const uint32_t uyx = (ax - ay) < 0 ? 1u : 0u, uzx = (ax - az) < 0 ? 1u : 0u, uzy = (ay - az) < 0 ? 1u : 0u;
+    const uint32_t xm = uyx & uzx, ym = (1u ^ xm) & uzy, zm = 1u ^ (xm | ym);
+    const V3 t = normalize3(cross3(n, v3((float)xm, (float)ym, (float)zm))), b = normalize3(cross3(n, t));
+    return V3{(t.x * lx + b.x * ly) + n.x * lz, (t.y * lx + b.y * ly) + n.y * lz, (t.z * lx + b.z * ly) + n.z * lz};
+}
+
+__device__ __forceinline__ V3 eval_point3(const DevProbe3 &p, int px, int py, int width, int height)
+{
+    const float ndcx = 2.0f * (float)px / (float)width + -1.0f, ndcy = 2.0f * (float)py / (float)height + -1.0f;
+    return V3{p.scale * (ndcx * p.right[0] + ndcy * p.up[0]) + p.pos[0], p.scale * (ndcx * p.right[1] + ndcy * p.up[1]) + p.pos[1],
+              p.scale * (ndcx * p.right[2] + ndcy * p.up[2]) + p.pos[2]};
+}
+
+constexpr int kStat3Copies = 64;
+struct alignas(256) Stats3Dev {
+    unsigned long long steps, started, absorbed, truncated, nhits;
+};
+
+struct Walk3Params {
+    DevMesh3 dm, nm;
+    DevSettings st;
+    DevProbe3 probe;
+    const uint8_t *mask;
+    float *field;              // solution / spp at field[(pix - field_base) * 3]
+    int32_t field_base, pixel_begin, pixel_end;
+    int32_t shard_index, shard_count;
+    Stats3Dev *stats;
+};
+
+// One lane = one pixel, all its samples one after the other on the pixel's PCG stream.
+template <bool EMISSIVE>
+__global__ __launch_bounds__(256) void walk3_kernel(Walk3Params P)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const LdsColumn stk(lds_stack + threadIdx.x, blockDim.x);
+    const int pid = P.pixel_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    bool owned = pid < P.pixel_end;
+    if (owned) {
+        const int px = pid % P.st.width, py = pid / P.st.width;
+        const int tile = (py >> 3) * ((P.st.width + 7) >> 3) + (px >> 3);
+        owned = (tile % P.shard_count) == P.shard_index;
+    }
+    uint32_t steps = 0, started = 0, absorbed = 0, truncated = 0, nhits = 0;
+    if (owned) {
+        const bool masked = P.mask != nullptr && P.mask[pid] == 0;
+        const bool has_d = P.dm.n_tris > 0, has_n = P.nm.n_tris > 0;
+        const float eps = P.st.eps;
+        Pcg rng{0, 1};
+        pcg_seed_pixel(rng, pid, P.st.width);
+        float sol[3] = {0.0f, 0.0f, 0.0f};
+        const V3 p_eval = eval_point3(P.probe, pid % P.st.width, pid / P.st.width, P.st.width, P.st.height);
+        int32_t hint = -1, hint0 = -1;
+        for (int sample = 0; sample < P.st.spp && !masked; ++sample) {
+            V3 p = p_eval;
+            float thp = 1.0f;
+            bool on_n = false;
+            V3 nn = v3(0.0f, 0.0f, 0.0f);
+            ++started;
+            hint = hint0;
+            int depth;
+            for (depth = 0; depth < P.st.max_depth; ++depth) {
+                ++steps;
+                // ---- separateEvaluationPoint ----
+                float R_D = WOST_INF;
+                if (has_d) {
+                    const Closest cp = closest_triangle(P.dm, p, hint, stk);
+                    hint = cp.slot;
+                    if (depth == 0) hint0 = cp.slot;
+                    const float4 a = P.dm.tri[3 * (size_t)cp.slot], b = P.dm.tri[3 * (size_t)cp.slot + 1], c = P.dm.tri[3 * (size_t)cp.slot + 2];
+                    const V3 p0 = v3(a.x, a.y, a.z), e0 = v3(b.x, b.y, b.z) - p0, e1 = v3(c.x, c.y, c.z) - p0;
+                    const int side = tri_side(p0, cross3(e0, e1), p);
+                    float u, v;
+                    tri_uv(p0, e0, e1, p, u, v);
+                    R_D = sqrtf(cp.d2);
+                    if (R_D < eps && u > 0.0f && v > 0.0f && u + v < 1.0f) {
+                        float col[3];
+                        const int32_t *tv = P.dm.triVerts + 3 * (size_t)cp.slot;
+                        surface_color3(P.dm.colors, tv[0], tv[1], tv[2], side, u, v, col);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            col[k] *= P.st.dirichlet_intensity;
+                            col[k] *= thp;
+                            sol[k] = col[k] + sol[k];
+                        }
+                        ++absorbed;
+                        break;
+                    }
+                }
+                float R_N = WOST_INF;
+                if (has_n) R_N = closest_silhouette3_flat(P.nm, p, R_D);
+                float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
+                R_B *= WOST_R_B_SHRINK;
+                if (isinf(R_B)) break;
+                // ---- sampleNeumann: three draws whether or not the boundary emits ----
+                if (has_n) {
+                    const float u0 = pcg_next_float(rng), u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
+                    if (EMISSIVE) {
+                        float pdf;
+                        const int oi = sample_in_sphere3_flat(P.nm, p, R_B, u0, pdf);
+                        if (oi != -1 && pdf > 0) {
+                            const DevTri S = P.nm.flat[oi];
+                            const V3 s0 = ld3(S.p0), s1 = ld3(S.p1), s2 = ld3(S.p2);
+                            const float su = sqrtf(u1), b1 = u2 * su, b0 = 1.0f - su, b2 = 1.0f - b0 - b1;
+                            const V3 sp = v3((s0.x * b0 + s1.x * b1) + s2.x * b2, (s0.y * b0 + s1.y * b1) + s2.y * b2,
+                                             (s0.z * b0 + s1.z * b1) + s2.z * b2);
+                            const V3 rv = sp - p;
+                            const float r = sqrtf(dot3(rv, rv));
+                            if (r < R_B && r > 0) {
+                                V3 o = p;
+                                if (on_n) o = v3(p.x + eps * nn.x, p.y + eps * nn.y, p.z + eps * nn.z);
+                                V3 rd = sp - o;
+                                const float cd = sqrtf(dot3(rd, rd));
+                                if (cd > 0) { rd.x /= cd; rd.y /= cd; rd.z /= cd; }
+                                if (!ray_any3_flat(P.nm, o, rd, cd - eps)) {
+                                    int side = tri_side(s0, ld3(S.nraw), p);
+                                    float uu, vv;
+                                    tri_uv(s0, s1 - s0, s2 - s0, sp, uu, vv);
+                                    if (on_n) {
+                                        const float dn = dot3(ld3(S.n), nn);
+                                        side = (0.0f < dn) - (dn < 0.0f);
+                                    }
+                                    if (side != 0) {
+                                        float col[3];
+                                        const int32_t *tv = P.nm.triVerts + 3 * (size_t)oi;     // flat order for the Neumann mesh
+                                        surface_color3(P.nm.colors, tv[0], tv[1], tv[2], side, uu, vv, col);
+                                        const float alpha = on_n ? 0.5f : 1.0f;
+                                        const float G = (1.0f / r - 1.0f / R_B) / WOST_4PI;
+#pragma unroll
+                                        for (int k = 0; k < 3; ++k) {
+                                            col[k] *= P.st.neumann_intensity;
+                                            col[k] *= thp * G / alpha / pdf;
+                                            sol[k] = -col[k] + sol[k];
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                // ---- oneStepWalk ----
+                V3 dir, cur = p;
+                float pdf, alpha = 1.0f;
+                {
+                    const float u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
+                    float c, s;
+                    sincos_2pi(u2, c, s);
+                    if (on_n) {
+                        const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+                        dir = frame_to_world(nn, r * c, r * s, z);
+                        pdf = 1.0f / WOST_2PI;
+                        alpha = 0.5f;
+                        cur = v3(p.x + eps * nn.x, p.y + eps * nn.y, p.z + eps * nn.z);
+                    } else {
+                        const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
+                        dir = v3(r * c, r * s, z);
+                        pdf = 1.0f / WOST_4PI;
+                    }
+                }
+                V3 nxt = v3(p.x + R_B * dir.x, p.y + R_B * dir.y, p.z + R_B * dir.z);
+                bool hit = false;
+                V3 hn = v3(0.0f, 0.0f, 0.0f);
+                if (has_n) {
+                    float t;
+                    int hi;
+                    hit = ray_closest3_flat(P.nm, cur, dir, R_B, t, hi);
+                    if (hit) {
+                        hn = ld3(P.nm.flat[hi].n);
+                        if (dot3(hn, dir) > 0) hn = v3(-hn.x, -hn.y, -hn.z);
+                        nxt = v3(cur.x + t * dir.x, cur.y + t * dir.y, cur.z + t * dir.z);
+                        ++nhits;
+                    }
+                }
+                thp = thp / pdf / alpha / WOST_4PI;
+                p = nxt; on_n = hit; nn = hn;
+            }
+            if (depth == P.st.max_depth) ++truncated;
+        }
+        float *f = P.field + 3 * (size_t)(pid - P.field_base);
+        const float spp = (float)P.st.spp;
+        f[0] = sol[0] / spp; f[1] = sol[1] / spp; f[2] = sol[2] / spp;
+    }
+    uint32_t v[5] = {steps, started, absorbed, truncated, nhits};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        uint32_t x = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        v[k] = x;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        Stats3Dev *st = P.stats + (blockIdx.x & (kStat3Copies - 1));
+        if (v[0]) atomicAdd(&st->steps, (unsigned long long)v[0]);
+        if (v[1]) atomicAdd(&st->started, (unsigned long long)v[1]);
+        if (v[2]) atomicAdd(&st->absorbed, (unsigned long long)v[2]);
+        if (v[3]) atomicAdd(&st->truncated, (unsigned long long)v[3]);
+        if (v[4]) atomicAdd(&st->nhits, (unsigned long long)v[4]);
+    }
+}
+
+// ---- batch queries (tests, SDF-style renders) ----------------------------------------------------
+__global__ __launch_bounds__(256) void closest_point3_kernel(DevMesh3 m, const float *pts, int n, int32_t *out_idx, float *out_dist,
+                                                             float *out_uv, int32_t *out_side)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const LdsColumn stk(lds_stack + threadIdx.x, blockDim.x);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 q = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    const Closest cp = closest_triangle(m, q, -1, stk);
+    const float4 a = m.tri[3 * (size_t)cp.slot], b = m.tri[3 * (size_t)cp.slot + 1], c = m.tri[3 * (size_t)cp.slot + 2];
+    const V3 p0 = v3(a.x, a.y, a.z), e0 = v3(b.x, b.y, b.z) - p0, e1 = v3(c.x, c.y, c.z) - p0;
+    if (out_idx) out_idx[i] = m.triOrig[cp.slot];
+    if (out_dist) out_dist[i] = sqrtf(cp.d2);
+    if (out_uv) tri_uv(p0, e0, e1, q, out_uv[2 * i], out_uv[2 * i + 1]);
+    if (out_side) out_side[i] = tri_side(p0, cross3(e0, e1), q);
+}
+
+__global__ __launch_bounds__(256) void silhouette3_kernel(DevMesh3 m, const float *pts, const float *rmax, int n, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = m.n_tris > 0 ? closest_silhouette3_flat(m, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), rmax ? rmax[i] : WOST_INF) : WOST_INF;
+}
+
+__global__ __launch_bounds__(256) void ray3_kernel(DevMesh3 m, const float *o, const float *d, const float *tmax, int n, int32_t *out_hit,
+                                                   float *out_t, int32_t *out_idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float t;
+    int idx;
+    const bool hit = ray_closest3_flat(m, v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i], t, idx);
+    out_hit[i] = hit ? 1 : 0;
+    out_t[i] = t;
+    out_idx[i] = idx;
+}
+
+// ---- host: LBVH over triangles ----------------------------------------------------------------------
+struct HostMesh3 {
+    int32_t n_tris = 0, n_edges = 0, levels = 1, first_leaf = 1;
+    bool emissive = false;
+    std::vector<float> nodes, tri, colors;
+    std::vector<int32_t> triOrig, triVerts;
+    std::vector<DevTri> flat;
+    std::vector<DevEdge3> edges;
+};
+
+static inline uint32_t part1by2(uint32_t x)
+{
+    x &= 0x3ff;
+    x = (x | (x << 16)) & 0x030000FF;
+    x = (x | (x << 8)) & 0x0300F00F;
+    x = (x | (x << 4)) & 0x030C30C3;
+    x = (x | (x << 2)) & 0x09249249;
+    return x;
+}
+static inline float hdot3(const float *a, const float *b) { return std::fmaf(a[0], b[0], std::fmaf(a[1], b[1], a[2] * b[2])); }
+
+// returns 0, or -1 on an index out of range
+static int build_mesh3(const wost3_mesh_desc &d, bool flat_order, HostMesh3 *out)
+{
+    HostMesh3 &h = *out;
+    h = HostMesh3();
+    h.n_tris = d.n_tris;
+    if (d.n_tris <= 0) return 0;
+    if (!d.verts || !d.tris || d.n_verts <= 0) return -1;
+    const int n = d.n_tris;
+    h.flat.resize(n);
+    std::vector<float> cen((size_t)n * 3);
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int t = 0; t < n; ++t) {
+        const int32_t *iv = d.tris + 3 * (size_t)t;
+        for (int k = 0; k < 3; ++k)
+            if (iv[k] < 0 || iv[k] >= d.n_verts) return -1;
+        DevTri &T = h.flat[t];
+        for (int c = 0; c < 3; ++c) {
+            T.p0[c] = d.verts[3 * (size_t)iv[0] + c]; T.p1[c] = d.verts[3 * (size_t)iv[1] + c]; T.p2[c] = d.verts[3 * (size_t)iv[2] + c];
+            lo[c] = std::min(lo[c], std::min(T.p0[c], std::min(T.p1[c], T.p2[c])));
+            hi[c] = std::max(hi[c], std::max(T.p0[c], std::max(T.p1[c], T.p2[c])));
+            cen[3 * (size_t)t + c] = (float)(((double)T.p0[c] + T.p1[c] + T.p2[c]) / 3.0);
+        }
+        // e0, e1, nraw = cross3(e0, e1), unit normal, area: the oracle's record
+        float e0[3], e1[3];
+        for (int c = 0; c < 3; ++c) { e0[c] = T.p1[c] - T.p0[c]; e1[c] = T.p2[c] - T.p0[c]; }
+        T.nraw[0] = std::fmaf(e0[1], e1[2], -(e0[2] * e1[1]));
+        T.nraw[1] = std::fmaf(e0[2], e1[0], -(e0[0] * e1[2]));
+        T.nraw[2] = std::fmaf(e0[0], e1[1], -(e0[1] * e1[0]));
+        const float l = std::sqrt(hdot3(T.nraw, T.nraw));
+        T.area = 0.5f * l;
+        for (int c = 0; c < 3; ++c) T.n[c] = l > 0.0f ? T.nraw[c] / l : 0.0f;
+    }
+    if (d.colors) {
+        h.colors.assign(d.colors, d.colors + (size_t)d.n_verts * 6);
+        for (float c : h.colors)
+            if (c != 0.0f) h.emissive = true;
+    }
+    // edges: as the oracle enumerates them (first two incident triangles in index order, direction of the first)
+    {
+        struct Key { int a, b, t, k; };
+        std::vector<Key> keys;
+        keys.reserve((size_t)n * 3);
+        for (int t = 0; t < n; ++t)
+            for (int k = 0; k < 3; ++k) {
+                const int a = d.tris[3 * (size_t)t + k], b = d.tris[3 * (size_t)t + (k + 1) % 3];
+                keys.push_back(Key{std::min(a, b), std::max(a, b), t, k});
+            }
+        std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) {
+            if (x.a != y.a) return x.a < y.a;
+            if (x.b != y.b) return x.b < y.b;
+            return x.t < y.t;
+        });
+        for (size_t i = 0; i < keys.size();) {
+            size_t j = i;
+            while (j < keys.size() && keys[j].a == keys[i].a && keys[j].b == keys[i].b) ++j;
+            const int t0 = keys[i].t, k0 = keys[i].k;
+            const int a = d.tris[3 * (size_t)t0 + k0], b = d.tris[3 * (size_t)t0 + (k0 + 1) % 3];
+            if (a != b) {
+                DevEdge3 E{};
+                for (int c = 0; c < 3; ++c) { E.pa[c] = d.verts[3 * (size_t)a + c]; E.pb[c] = d.verts[3 * (size_t)b + c]; }
+                E.t0 = t0;
+                E.t1 = (j - i >= 2) ? keys[i + 1].t : -1;
+                h.edges.push_back(E);
+            }
+            i = j;
+        }
+        h.n_edges = (int32_t)h.edges.size();
+    }
+    // Morton order of the centroids, leaves of 4, implicit complete 4-ary tree (lbvh.h in 3-D)
+    std::vector<int32_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    if (!flat_order) {
+        std::vector<uint32_t> code(n);
+        for (int t = 0; t < n; ++t) {
+            uint32_t q[3];
+            for (int c = 0; c < 3; ++c) {
+                const double s = hi[c] > lo[c] ? 1023.0 / ((double)hi[c] - lo[c]) : 0.0;
+                q[c] = (uint32_t)std::min(1023.0, std::max(0.0, ((double)cen[3 * (size_t)t + c] - lo[c]) * s));
+            }
+            code[t] = part1by2(q[0]) | (part1by2(q[1]) << 1) | (part1by2(q[2]) << 2);
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return code[a] < code[b]; });
+    }
+    const int n_leaves = (n + 3) / 4;
+    int levels = 1, cap = 4;
+    while (cap < n_leaves) { cap *= 4; ++levels; }
+    h.levels = levels;
+    h.first_leaf = (cap - 1) / 3;
+    const size_t n_slots = (size_t)cap * 4;
+    h.tri.assign(n_slots * 12, 1.0e18f);
+    h.triOrig.assign(n_slots, kFarIndex);
+    h.triVerts.assign(n_slots * 3, 0);
+    for (int k = 0; k < n; ++k) {
+        // flat_order (the Neumann mesh): slot == original index, so triVerts is indexed by triangle id
+        const int o = order[k];
+        const DevTri &T = h.flat[o];
+        float *r = &h.tri[(size_t)k * 12];
+        for (int c = 0; c < 3; ++c) { r[c] = T.p0[c]; r[4 + c] = T.p1[c]; r[8 + c] = T.p2[c]; }
+        r[3] = r[7] = r[11] = 0.0f;
+        h.triOrig[k] = o;
+        for (int c = 0; c < 3; ++c) h.triVerts[3 * (size_t)k + c] = d.tris[3 * (size_t)o + c];
+    }
+    // boxes bottom-up, padded (pruning slack)
+    float ext = 0.0f;
+    for (int c = 0; c < 3; ++c) ext = std::max(ext, std::max(std::fabs(lo[c]), std::fabs(hi[c])));
+    const float pad = ext * 0x1p-18f + 1e-30f;
+    const int n_nodes = h.first_leaf + cap;
+    std::vector<float> nb((size_t)n_nodes * 6);
+    std::vector<char> empty(n_nodes, 1);
+    for (int g = 0; g < n_nodes; ++g)
+        for (int c = 0; c < 3; ++c) { nb[6 * (size_t)g + c] = INFINITY; nb[6 * (size_t)g + 3 + c] = -INFINITY; }
+    for (int k = 0; k < n; ++k) {
+        const int g = h.first_leaf + k / 4;
+        const DevTri &T = h.flat[order[k]];
+        for (int c = 0; c < 3; ++c) {
+            nb[6 * (size_t)g + c] = std::min(nb[6 * (size_t)g + c], std::min(T.p0[c], std::min(T.p1[c], T.p2[c])));
+            nb[6 * (size_t)g + 3 + c] = std::max(nb[6 * (size_t)g + 3 + c], std::max(T.p0[c], std::max(T.p1[c], T.p2[c])));
+        }
+        empty[g] = 0;
+    }
+    for (int g = h.first_leaf - 1; g >= 0; --g)
+        for (int j = 1; j <= 4; ++j) {
+            const int c4 = 4 * g + j;
+            if (empty[c4]) continue;
+            for (int c = 0; c < 3; ++c) {
+                nb[6 * (size_t)g + c] = std::min(nb[6 * (size_t)g + c], nb[6 * (size_t)c4 + c]);
+                nb[6 * (size_t)g + 3 + c] = std::max(nb[6 * (size_t)g + 3 + c], nb[6 * (size_t)c4 + 3 + c]);
+            }
+            empty[g] = 0;
+        }
+    // inner nodes (levels 0 .. levels-1) store their four children; leaves (level == levels) store nothing
+    h.nodes.assign((size_t)h.first_leaf * 24, 0.0f);
+    for (int g = 0; g < h.first_leaf; ++g)
+        for (int j = 0; j < 4; ++j) {
+            const int c4 = 4 * g + 1 + j;
+            float *nd = &h.nodes[(size_t)g * 24];
+            for (int c = 0; c < 3; ++c) {
+                nd[4 * c + j] = empty[c4] ? 1.0e18f : nb[6 * (size_t)c4 + c] - pad;
+                nd[12 + 4 * c + j] = empty[c4] ? 1.0e18f : nb[6 * (size_t)c4 + 3 + c] + pad;
+            }
+        }
+    return 0;
+}
+
+struct DeviceMesh3 {
+    DevMesh3 view{};
+    HostMesh3 host;
+    std::vector<void *> allocs;
+};
+
+template <class T>
+static hipError_t upload3(std::vector<void *> &allocs, const T *src, size_t count, const T **dst)
+{
+    *dst = nullptr;
+    if (count == 0) return hipSuccess;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, count * sizeof(T));
+    if (e != hipSuccess) return e;
+    allocs.push_back(p);
+    *dst = reinterpret_cast<const T *>(p);
+    return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+}
+
+}  // namespace wost
+
+using namespace wost;
+
+struct wost3_context {
+    int device = 0;
+    wost_settings settings{};
+    DevSettings dst{};
+    DevProbe3 probe{};
+    DeviceMesh3 dm, nm;
+    uint8_t *mask = nullptr;
+    size_t n_pixels = 0;
+    float *field = nullptr;
+    Stats3Dev *stats = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+#define W3_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return set_error(WOST_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static int upload_mesh3(const wost3_mesh_desc &d, bool flat_order, DeviceMesh3 &s)
+{
+    if (d.n_tris < 0 || d.n_verts < 0) return set_error(WOST_ERR_INVALID, "negative mesh size");
+    if (build_mesh3(d, flat_order, &s.host) != 0) return set_error(WOST_ERR_INVALID, "mesh: triangle index out of range or null arrays");
+    const HostMesh3 &h = s.host;
+    DevMesh3 &v = s.view;
+    v = DevMesh3{};
+    v.n_tris = h.n_tris;
+    if (h.n_tris == 0) return WOST_OK;
+    v.n_edges = h.n_edges; v.levels = h.levels; v.first_leaf = h.first_leaf; v.emissive = h.emissive ? 1 : 0;
+    W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.nodes.data()), h.nodes.size() / 4, &v.nodes));
+    W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.tri.data()), h.tri.size() / 4, &v.tri));
+    W3_TRY(upload3(s.allocs, h.triOrig.data(), h.triOrig.size(), &v.triOrig));
+    W3_TRY(upload3(s.allocs, h.triVerts.data(), h.triVerts.size(), &v.triVerts));
+    W3_TRY(upload3(s.allocs, h.colors.data(), h.colors.size(), &v.colors));
+    W3_TRY(upload3(s.allocs, h.flat.data(), h.flat.size(), &v.flat));
+    W3_TRY(upload3(s.allocs, h.edges.data(), h.edges.size(), &v.edges));
+    return WOST_OK;
+}
+
+static void destroy3(wost3_context *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (void *p : c->dm.allocs) (void)hipFree(p);
+    for (void *p : c->nm.allocs) (void)hipFree(p);
+    if (c->mask) (void)hipFree(c->mask);
+    if (c->field) (void)hipFree(c->field);
+    if (c->stats) (void)hipFree(c->stats);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, int32_t shard_index, int32_t shard_count, float *field_dev,
+                      int32_t field_base, hipStream_t stream, wost_stats *stats)
+{
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    W3_TRY(hipSetDevice(c->device));
+    W3_TRY(hipMemsetAsync(c->stats, 0, kStat3Copies * sizeof(Stats3Dev), stream));
+    Walk3Params P{};
+    P.dm = c->dm.view; P.nm = c->nm.view; P.st = c->dst; P.probe = c->probe; P.mask = c->mask;
+    P.field = field_dev; P.field_base = field_base; P.pixel_begin = pixel_begin; P.pixel_end = pixel_end;
+    P.shard_index = shard_index; P.shard_count = shard_count; P.stats = c->stats;
+    const int bs = 256, n = pixel_end - pixel_begin;
+    const size_t lds = (size_t)(3 * (c->dm.view.n_tris > 0 ? c->dm.view.levels : 1) + 1) * bs * sizeof(uint32_t);
+    float ms = 0.0f;
+    if (n > 0) {
+        W3_TRY(hipEventRecord(c->ev0, stream));
+        if (c->nm.view.n_tris > 0 && c->nm.view.emissive)
+            hipLaunchKernelGGL((walk3_kernel<true>), dim3((n + bs - 1) / bs), dim3(bs), lds, stream, P);
+        else
+            hipLaunchKernelGGL((walk3_kernel<false>), dim3((n + bs - 1) / bs), dim3(bs), lds, stream, P);
+        W3_TRY(hipGetLastError());
+        W3_TRY(hipEventRecord(c->ev1, stream));
+    }
+    std::vector<Stats3Dev> copies(kStat3Copies);
+    W3_TRY(hipMemcpyAsync(copies.data(), c->stats, kStat3Copies * sizeof(Stats3Dev), hipMemcpyDeviceToHost, stream));
+    W3_TRY(hipStreamSynchronize(stream));
+    if (n > 0) W3_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        for (const Stats3Dev &k : copies) {
+            stats->walk_steps += k.steps; stats->walks_started += k.started; stats->walks_absorbed += k.absorbed;
+            stats->walks_truncated += k.truncated; stats->neumann_hits += k.nhits;
+        }
+        stats->kernel_ms = ms;
+        stats->kernel_launches = n > 0 ? 1 : 0;
+        stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    }
+    return WOST_OK;
+}
+
+static DeviceMesh3 *pick3(wost3_handle h, int which)
+{
+    return which == WOST_MESH_DIRICHLET ? &h->dm : which == WOST_MESH_NEUMANN ? &h->nm : nullptr;
+}
+
+struct Scratch3 {
+    std::vector<void *> ptrs;
+    ~Scratch3()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    hipError_t alloc(T **p, size_t count)
+    {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, count * sizeof(T) + 16);
+        if (e == hipSuccess) ptrs.push_back(q);
+        *p = reinterpret_cast<T *>(q);
+        return e;
+    }
+};
+
+extern "C" {
+
+int wost3_create(const wost3_scene_desc *scene, const wost_settings *settings, int device, wost3_handle *out)
+{
+    if (!scene || !settings || !out) return set_error(WOST_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (settings->width <= 0 || settings->height <= 0 || settings->spp < 0 || settings->max_depth <= 0)
+        return set_error(WOST_ERR_INVALID, "bad settings");
+    if ((int64_t)settings->width * settings->height > (1 << 28)) return set_error(WOST_ERR_UNSUPPORTED, "frame too large");
+    if (scene->neumann.n_tris > WOST3_FLAT_MAX)
+        return set_error(WOST_ERR_UNSUPPORTED, "3-D Neumann meshes are limited to 64 triangles in this build (flat queries)");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return set_error(WOST_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n_dev) return set_error(WOST_ERR_INVALID, "device index out of range");
+    W3_TRY(hipSetDevice(device));
+    wost3_context *c = new (std::nothrow) wost3_context();
+    if (!c) return set_error(WOST_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    c->settings = *settings;
+    c->dst = DevSettings{settings->width, settings->height, settings->spp, settings->max_depth, settings->eps_shell,
+                         scene->dirichlet_intensity, scene->neumann_intensity};
+    c->probe.scale = scene->probe_scale;
+    for (int k = 0; k < 3; ++k) { c->probe.pos[k] = scene->probe_pos[k]; c->probe.up[k] = scene->probe_up[k]; c->probe.right[k] = scene->probe_right[k]; }
+    c->n_pixels = (size_t)settings->width * settings->height;
+    int rc = upload_mesh3(scene->dirichlet, false, c->dm);
+    if (rc == WOST_OK) rc = upload_mesh3(scene->neumann, true, c->nm);
+    hipError_t e = hipSuccess;
+    if (rc == WOST_OK && scene->mask) {
+        e = hipMalloc((void **)&c->mask, c->n_pixels);
+        if (e == hipSuccess) e = hipMemcpy(c->mask, scene->mask, c->n_pixels, hipMemcpyHostToDevice);
+    }
+    if (rc == WOST_OK && e == hipSuccess) e = hipMalloc((void **)&c->field, c->n_pixels * 3 * sizeof(float));
+    if (rc == WOST_OK && e == hipSuccess) e = hipMalloc((void **)&c->stats, kStat3Copies * sizeof(Stats3Dev));
+    if (rc == WOST_OK && e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (rc == WOST_OK && e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (rc == WOST_OK && e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (rc == WOST_OK && e != hipSuccess) rc = set_error(WOST_ERR_DEVICE, std::string("wost3_create: ") + hipGetErrorString(e));
+    if (rc != WOST_OK) {
+        destroy3(c);
+        return rc;
+    }
+    *out = c;
+    return WOST_OK;
+}
+
+int wost3_destroy(wost3_handle h)
+{
+    destroy3(h);
+    return WOST_OK;
+}
+
+int wost3_solve(wost3_handle h, int32_t pixel_begin, int32_t pixel_end, float *field_rgb, wost_stats *stats)
+{
+    if (!h || !field_rgb) return set_error(WOST_ERR_INVALID, "null argument");
+    if (pixel_begin < 0 || pixel_end > (int64_t)h->n_pixels || pixel_begin > pixel_end)
+        return set_error(WOST_ERR_INVALID, "pixel range outside the frame");
+    const size_t n = (size_t)(pixel_end - pixel_begin);
+    if (n == 0) {
+        if (stats) std::memset(stats, 0, sizeof(*stats));
+        return WOST_OK;
+    }
+    W3_TRY(hipSetDevice(h->device));
+    W3_TRY(hipMemsetAsync(h->field, 0, n * 3 * sizeof(float), h->stream));
+    const int rc = run_solve3(h, pixel_begin, pixel_end, 0, 1, h->field, pixel_begin, h->stream, stats);
+    if (rc != WOST_OK) return rc;
+    W3_TRY(hipMemcpyAsync(field_rgb, h->field, n * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    W3_TRY(hipStreamSynchronize(h->stream));
+    return WOST_OK;
+}
+
+int wost3_solve_sharded(wost3_handle h, int32_t shard_index, int32_t shard_count, float *field_rgb_dev, void *stream, wost_stats *stats)
+{
+    if (!h || !field_rgb_dev) return set_error(WOST_ERR_INVALID, "null argument");
+    if (shard_count <= 0 || shard_index < 0 || shard_index >= shard_count) return set_error(WOST_ERR_INVALID, "bad shard");
+    return run_solve3(h, 0, (int32_t)h->n_pixels, shard_index, shard_count, field_rgb_dev, 0, reinterpret_cast<hipStream_t>(stream), stats);
+}
+
+int wost3_closest_point(wost3_handle h, int which_mesh, const float *pts, int32_t n, int32_t *out_idx, float *out_dist, float *out_uv,
+                        int32_t *out_side)
+{
+    if (!h || !pts || n < 0) return set_error(WOST_ERR_INVALID, "null argument");
+    DeviceMesh3 *m = pick3(h, which_mesh);
+    if (!m || m->view.n_tris == 0) return set_error(WOST_ERR_INVALID, "mesh is empty or unknown");
+    if (n == 0) return WOST_OK;
+    W3_TRY(hipSetDevice(h->device));
+    Scratch3 s;
+    float *d_pts, *d_dist, *d_uv;
+    int32_t *d_idx, *d_side;
+    W3_TRY(s.alloc(&d_pts, (size_t)n * 3)); W3_TRY(s.alloc(&d_dist, n)); W3_TRY(s.alloc(&d_uv, (size_t)n * 2));
+    W3_TRY(s.alloc(&d_idx, n)); W3_TRY(s.alloc(&d_side, n));
+    W3_TRY(hipMemcpyAsync(d_pts, pts, (size_t)n * 12, hipMemcpyHostToDevice, h->stream));
+    const int bs = 256;
+    const size_t lds = (size_t)(3 * m->view.levels + 1) * bs * sizeof(uint32_t);
+    hipLaunchKernelGGL(closest_point3_kernel, dim3((n + bs - 1) / bs), dim3(bs), lds, h->stream, m->view, d_pts, n, d_idx, d_dist, d_uv, d_side);
+    W3_TRY(hipGetLastError());
+    if (out_idx) W3_TRY(hipMemcpyAsync(out_idx, d_idx, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (out_dist) W3_TRY(hipMemcpyAsync(out_dist, d_dist, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (out_uv) W3_TRY(hipMemcpyAsync(out_uv, d_uv, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    if (out_side) W3_TRY(hipMemcpyAsync(out_side, d_side, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    W3_TRY(hipStreamSynchronize(h->stream));
+    return WOST_OK;
+}
+
+int wost3_closest_silhouette(wost3_handle h, int which_mesh, const float *pts, const float *rmax, int32_t n, float *out_dist)
+{
+    if (!h || !pts || !out_dist || n < 0) return set_error(WOST_ERR_INVALID, "null argument");
+    DeviceMesh3 *m = pick3(h, which_mesh);
+    if (!m) return set_error(WOST_ERR_INVALID, "unknown mesh selector");
+    if (m->view.n_tris > WOST3_FLAT_MAX) return set_error(WOST_ERR_UNSUPPORTED, "silhouette queries walk at most 64 triangles in this build");
+    if (n == 0) return WOST_OK;
+    W3_TRY(hipSetDevice(h->device));
+    Scratch3 s;
+    float *d_pts, *d_rmax = nullptr, *d_out;
+    W3_TRY(s.alloc(&d_pts, (size_t)n * 3)); W3_TRY(s.alloc(&d_out, n));
+    W3_TRY(hipMemcpyAsync(d_pts, pts, (size_t)n * 12, hipMemcpyHostToDevice, h->stream));
+    if (rmax) {
+        W3_TRY(s.alloc(&d_rmax, n));
+        W3_TRY(hipMemcpyAsync(d_rmax, rmax, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    hipLaunchKernelGGL(silhouette3_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, m->view, d_pts, d_rmax, n, d_out);
+    W3_TRY(hipGetLastError());
+    W3_TRY(hipMemcpyAsync(out_dist, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    W3_TRY(hipStreamSynchronize(h->stream));
+    return WOST_OK;
+}
+
+int wost3_ray_intersect(wost3_handle h, int which_mesh, const float *origins, const float *dirs, const float *tmax, int32_t n,
+                        int32_t *out_hit, float *out_t, int32_t *out_idx)
+{
+    if (!h || !origins || !dirs || !tmax || !out_hit || !out_t || !out_idx || n < 0) return set_error(WOST_ERR_INVALID, "null argument");
+    DeviceMesh3 *m = pick3(h, which_mesh);
+    if (!m) return set_error(WOST_ERR_INVALID, "unknown mesh selector");
+    if (m->view.n_tris > WOST3_FLAT_MAX) return set_error(WOST_ERR_UNSUPPORTED, "ray queries walk at most 64 triangles in this build");
+    if (n == 0) return WOST_OK;
+    W3_TRY(hipSetDevice(h->device));
+    Scratch3 s;
+    float *d_o, *d_d, *d_tm, *d_t;
+    int32_t *d_hit, *d_idx;
+    W3_TRY(s.alloc(&d_o, (size_t)n * 3)); W3_TRY(s.alloc(&d_d, (size_t)n * 3)); W3_TRY(s.alloc(&d_tm, n)); W3_TRY(s.alloc(&d_t, n));
+    W3_TRY(s.alloc(&d_hit, n)); W3_TRY(s.alloc(&d_idx, n));
+    W3_TRY(hipMemcpyAsync(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice, h->stream));
+    W3_TRY(hipMemcpyAsync(d_d, dirs, (size_t)n * 12, hipMemcpyHostToDevice, h->stream));
+    W3_TRY(hipMemcpyAsync(d_tm, tmax, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(ray3_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, m->view, d_o, d_d, d_tm, n, d_hit, d_t, d_idx);
+    W3_TRY(hipGetLastError());
+    W3_TRY(hipMemcpyAsync(out_hit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    W3_TRY(hipMemcpyAsync(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    W3_TRY(hipMemcpyAsync(out_idx, d_idx, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    W3_TRY(hipStreamSynchronize(h->stream));
+    return WOST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+"""Python mirror of Problem<3> / UniformIntegrator<3> (reference core/problem.h:197-260,
+integrator/uniform/integrator.h:55-131 with DIM = 3) on top of the wost3_* entry points of the C-ABI.
+Thin ctypes calls into libwost_hip.so -- no arithmetic happens here."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import Mesh3Desc, Scene3Desc, Settings, Stats, _check, _fp, _ip
+
+
+class Problem3:
+    """Triangle meshes + EvaluationGrid<3> probe.  probe = (scale, pos[3], up[3], right[3])
+    (core/evaluation_grid.h:48-55); colors [n_verts, 6] = rgb on the normal side, rgb on the other."""
+
+    def __init__(self, d_verts=None, d_tris=None, d_colors=None, n_verts=None, n_tris=None, n_colors=None,
+                 probe=(1.0, (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), (1.0, 0.0, 0.0)), dirichlet_intensity=1.0, neumann_intensity=1.0,
+                 mask=None):
+        def arr(a, dt, cols):
+            return None if a is None else np.ascontiguousarray(a, dtype=dt).reshape(-1, cols)
+        self.d_verts, self.d_tris, self.d_colors = arr(d_verts, np.float32, 3), arr(d_tris, np.int32, 3), arr(d_colors, np.float32, 6)
+        self.n_verts, self.n_tris, self.n_colors = arr(n_verts, np.float32, 3), arr(n_tris, np.int32, 3), arr(n_colors, np.float32, 6)
+        self.probe = probe
+        self.dirichlet_intensity, self.neumann_intensity = float(dirichlet_intensity), float(neumann_intensity)
+        self.mask = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(-1)
+
+    @classmethod
+    def from_dict(cls, sd):
+        return cls(**{k: sd.get(k) for k in ("d_verts", "d_tris", "d_colors", "n_verts", "n_tris", "n_colors", "mask")},
+                   probe=sd["probe"], dirichlet_intensity=sd.get("dirichlet_intensity", 1.0),
+                   neumann_intensity=sd.get("neumann_intensity", 1.0))
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k in ("d_verts", "d_tris", "d_colors", "n_verts", "n_tris", "n_colors", "probe",
+                                              "dirichlet_intensity", "neumann_intensity", "mask")}
+
+
+def _mesh3(keep, verts, tris, colors):
+    m = Mesh3Desc()
+    if verts is None or tris is None or len(tris) == 0:
+        return m
+    keep += [verts, tris]
+    m.n_verts, m.n_tris, m.verts, m.tris = len(verts), len(tris), _fp(verts), _ip(tris)
+    if colors is not None:
+        if colors.shape != (len(verts), 6):
+            raise ValueError("colors must be [n_verts, 6]")
+        keep.append(colors)
+        m.colors = _fp(colors)
+    return m
+
+
+class UniformIntegrator3:
+    VectorType = tuple
+
+    def __init__(self, problem, settings, device=0):
+        self.lib = capi.load()
+        self.problem, self.settings = problem, settings
+        keep = []
+        w, h = settings.frameSize
+        sc = Scene3Desc()
+        sc.dirichlet = _mesh3(keep, problem.d_verts, problem.d_tris, problem.d_colors)
+        sc.neumann = _mesh3(keep, problem.n_verts, problem.n_tris, problem.n_colors)
+        sc.dirichlet_intensity, sc.neumann_intensity = problem.dirichlet_intensity, problem.neumann_intensity
+        scale, pos, up, right = problem.probe
+        sc.probe_scale = float(scale)
+        for k in range(3):
+            sc.probe_pos[k], sc.probe_up[k], sc.probe_right[k] = float(pos[k]), float(up[k]), float(right[k])
+        if problem.mask is not None:
+            if problem.mask.size != w * h:
+                raise ValueError("mask must have width*height entries")
+            keep.append(problem.mask)
+            sc.mask = problem.mask.ctypes.data_as(C.POINTER(C.c_uint8))
+        st = Settings(w, h, settings.samplesPerPixel, settings.maxWalkingDepth, settings.epsilonShell)
+        self._handle = C.c_void_p()
+        _check(self.lib.wost3_create(C.byref(sc), C.byref(st), device, C.byref(self._handle)), "wost3_create")
+        self.n_pixels = w * h
+        self.solution, self.last_stats = None, None
+
+    def solve(self, pixel_begin=0, pixel_end=None):
+        """returns wall milliseconds like the reference; the field is in self.solution"""
+        if pixel_end is None:
+            pixel_end = self.n_pixels
+        field = np.zeros((pixel_end - pixel_begin, 3), dtype=np.float32)
+        st = Stats()
+        _check(self.lib.wost3_solve(self._handle, pixel_begin, pixel_end, _fp(field), C.byref(st)), "wost3_solve")
+        self.solution, self.last_stats = field, st.as_dict()
+        return int(st.solve_ms)
+
+    def solve_sharded(self, shard_index, shard_count, field_dev_ptr, stream_ptr=None):
+        st = Stats()
+        _check(self.lib.wost3_solve_sharded(self._handle, shard_index, shard_count, C.c_void_p(field_dev_ptr),
+                                            C.c_void_p(stream_ptr or 0), C.byref(st)), "wost3_solve_sharded")
+        self.last_stats = st.as_dict()
+        return self.last_stats
+
+    def closest_point(self, pts, which=capi.MESH_DIRICHLET):
+        p = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 3)
+        n = len(p)
+        idx, dist, uv, side = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros((n, 2), np.float32), np.zeros(n, np.int32)
+        _check(self.lib.wost3_closest_point(self._handle, which, _fp(p), n, _ip(idx), _fp(dist), _fp(uv), _ip(side)), "wost3_closest_point")
+        return idx, dist, uv, side
+
+    def closest_silhouette(self, pts, rmax=None, which=capi.MESH_NEUMANN):
+        p = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(len(p), np.float32)
+        r = None if rmax is None else np.ascontiguousarray(rmax, dtype=np.float32)
+        _check(self.lib.wost3_closest_silhouette(self._handle, which, _fp(p), _fp(r) if r is not None else None, len(p), _fp(out)),
+               "wost3_closest_silhouette")
+        return out
+
+    def ray_intersect(self, origins, dirs, tmax, which=capi.MESH_NEUMANN):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(tmax, dtype=np.float32)
+        n = len(o)
+        hit, tt, idx = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+        _check(self.lib.wost3_ray_intersect(self._handle, which, _fp(o), _fp(d), _fp(t), n, _ip(hit), _fp(tt), _ip(idx)),
+               "wost3_ray_intersect")
+        return hit, tt, idx
+
+    def queryNetwork(self, p):
+        raise NotImplementedError("uniform integrator has no network (reference integrator.cu:661-664)")
+
+    def close(self):
+        if self._handle:
+            self.lib.wost3_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

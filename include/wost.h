@@ -326,6 +326,47 @@ int wost_set_option(wost_handle h, const char *key, double value);
 
 int wost_destroy(wost_handle h);
 
+/* ---- 3-D: UniformIntegrator<3> on triangle meshes ---------------------------------
+ * Replaces Problem<3> geometry upload (core/problem.h:197-260, core/problem.cu:262-270) and
+ * UniformIntegrator<3>::solve() -- the DIM == 3 branches of integrator/uniform/integrator.cu
+ * (:150-168 triangle side / barycentric uv and the in-shell test, :343-365 three Neumann draws,
+ * :465-525 oneStepWalk), EvaluationGrid<3> (core/evaluation_grid.h:43-70), HarmonicGreenBall<3>
+ * (util/green.h:77-119), uniformSampleSphere<3> / Hemisphere<3> (util/sampling.h:20-27,57-66) and
+ * frameFromNormal(Vector3f) (util/transformation.h:62-67).  colors: per vertex 6 floats, rgb on the
+ * side the triangle normal (p1-p0) x (p2-p0) points to, then rgb on the other side
+ * (thrust::pair first / second, integrator/common.h:250-257).  This first slice walks the Neumann
+ * mesh with flat loops (at most 64 triangles) and has no source term: WOST_ERR_UNSUPPORTED otherwise. */
+typedef struct wost3_mesh_desc {
+    int32_t n_verts, n_tris;
+    const float *verts;       /* n_verts * 3 */
+    const int32_t *tris;      /* n_tris * 3, 0-based */
+    const float *colors;      /* n_verts * 6 or NULL = zeros */
+} wost3_mesh_desc;
+typedef struct wost3_scene_desc {
+    wost3_mesh_desc dirichlet, neumann;      /* n_tris == 0 -> disabled */
+    float dirichlet_intensity, neumann_intensity;
+    float probe_scale;                       /* EvaluationGrid<3>::ProbeData: point = scale (ndc.x right + ndc.y up) + pos */
+    float probe_pos[3], probe_up[3], probe_right[3];
+    const uint8_t *mask;                     /* width*height bytes (0 = masked out) or NULL */
+} wost3_scene_desc;
+typedef struct wost3_context *wost3_handle;
+int wost3_create(const wost3_scene_desc *scene, const wost_settings *settings, int device, wost3_handle *out);
+/* UniformIntegrator<3>::solve() for the pixels [pixel_begin, pixel_end): field_rgb = (n, 3) host floats */
+int wost3_solve(wost3_handle h, int32_t pixel_begin, int32_t pixel_end, float *field_rgb, wost_stats *stats);
+/* the 8x8 pixel tiles t % shard_count == shard_index into a zero-filled full-frame DEVICE buffer (as wost_solve_sharded) */
+int wost3_solve_sharded(wost3_handle h, int32_t shard_index, int32_t shard_count, float *field_rgb_dev, void *stream,
+                        wost_stats *stats);
+/* lbvh::nearest + checkPointSide + computeProjectionRatio for triangles (call sites integrator.cu:138,154-155):
+ * winning triangle (lowest index on ties), distance, barycentric (u, v) of the projection, side */
+int wost3_closest_point(wost3_handle h, int which_mesh, const float *pts, int32_t n, int32_t *out_idx, float *out_dist,
+                        float *out_uv, int32_t *out_side);
+/* lbvh::nearest_silhouette in 3-D: distance to the closest silhouette EDGE within rmax (NULL = unbounded) */
+int wost3_closest_silhouette(wost3_handle h, int which_mesh, const float *pts, const float *rmax, int32_t n, float *out_dist);
+/* lbvh::ray_intersect on triangles: closest hit (flag, t, triangle) */
+int wost3_ray_intersect(wost3_handle h, int which_mesh, const float *origins, const float *dirs, const float *tmax, int32_t n,
+                        int32_t *out_hit, float *out_t, int32_t *out_idx);
+int wost3_destroy(wost3_handle h);
+
 const char *wost_last_error(void);
 const char *wost_version(void);
 

@@ -55,7 +55,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     path = build.build_library()
     assert os.path.exists(path)
     header = open(os.path.join(ROOT, "include", "wost.h")).read()
-    declared = set(re.findall(r"\b(wost_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(wost3?_[a-z_]+)\s*\(", header))
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     lib = C.CDLL(path)
     for name in declared:

@@ -1,0 +1,115 @@
+"""3-D uniform path on the GPU (wost3_* of include/wost.h) against the CPU oracle
+(oracle/wost_oracle3d.c) on the same seeded inputs: bit-exact fields, counters and query results."""
+import numpy as np
+import pytest
+
+from conftest import cube_scene3, sphere_scene3
+
+pytestmark = pytest.mark.gpu
+
+
+def _it(sd, w, h, spp, depth, eps):
+    from elaina_amd import UniformIntegratorSettings
+    from elaina_amd.integrator3d import Problem3, UniformIntegrator3
+    return UniformIntegrator3(Problem3.from_dict(sd), UniformIntegratorSettings((w, h), spp, depth, eps))
+
+
+def _same_solve(oracle, sd, w, h, spp, depth, eps):
+    it = _it(sd, w, h, spp, depth, eps)
+    it.solve()
+    ref = oracle.solve3(sd, w, h, spp, depth, eps, threads=16)
+    for k in ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated", "neumann_hits"):
+        assert it.last_stats[k] == ref[k], k
+    assert np.array_equal(it.solution, ref["field"]), float(np.abs(it.solution - ref["field"]).max())
+    it.close()
+    return ref
+
+
+@pytest.mark.parametrize("subdiv", [0, 2, 3])
+def test_closest_point_on_triangles_matches_oracle(oracle, subdiv):
+    sd = sphere_scene3(subdiv=subdiv)
+    it = _it(sd, 8, 8, 1, 4, 1e-3)
+    rng = np.random.default_rng(subdiv)
+    pts = rng.uniform(-1.6, 1.6, size=(20000, 3)).astype(np.float32)
+    pts[:2000] = sd["d_verts"][rng.integers(0, len(sd["d_verts"]), 2000)]          # exactly on vertices: ties between triangles
+    got = it.closest_point(pts)
+    ref = oracle.closest_point3(sd["d_verts"], sd["d_tris"], pts)
+    for x, y in zip(got, ref):
+        assert np.array_equal(x, y)
+    it.close()
+
+
+def test_silhouette_and_ray_queries_match_oracle(oracle):
+    sd = cube_scene3(n=2, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x)
+    it = _it(sd, 8, 8, 1, 4, 1e-3)
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-0.5, 1.5, size=(20000, 3)).astype(np.float32)
+    V, T = sd["n_verts"], sd["n_tris"]
+    assert np.array_equal(it.closest_silhouette(pts), oracle.closest_silhouette3(V, T, pts))
+    rmax = rng.uniform(0.05, 1.0, 20000).astype(np.float32)
+    assert np.array_equal(it.closest_silhouette(pts, rmax), oracle.closest_silhouette3(V, T, pts, rmax))
+    o = rng.uniform(0.05, 0.95, size=(20000, 3)).astype(np.float32)
+    d = rng.normal(size=(20000, 3))
+    d = (d / np.linalg.norm(d, axis=1)[:, None]).astype(np.float32)
+    tmax = rng.uniform(0.1, 3.0, 20000).astype(np.float32)
+    got, ref = it.ray_intersect(o, d, tmax), oracle.ray_intersect3(V, T, o, d, tmax)
+    assert np.array_equal(got[0], ref[0]) and ref[0].mean() > 0.2
+    hit = ref[0] == 1
+    assert np.array_equal(got[1][hit], ref[1][hit]) and np.array_equal(got[2][hit], ref[2][hit])
+    it.close()
+
+
+def test_dirichlet_sphere_solve_matches_oracle_and_the_harmonic_solution(oracle):
+    sd = sphere_scene3(subdiv=3, value=lambda x, y, z: x * y + z)          # 1280 triangles, harmonic data
+    ref = _same_solve(oracle, sd, 24, 20, 24, 128, 2e-3)
+    assert ref["walks_absorbed"] > 0.99 * ref["walks_started"]
+    it = _it(sd, 32, 32, 512, 256, 2e-3)
+    it.solve()
+    scale, pos, up, right = sd["probe"]
+    ys, xs = np.divmod(np.arange(32 * 32), 32)
+    p = scale * ((2.0 * xs / 32 - 1.0)[:, None] * np.asarray(right)[None] + (2.0 * ys / 32 - 1.0)[:, None] * np.asarray(up)[None]) + np.asarray(pos)
+    exact = p[:, 0] * p[:, 1] + p[:, 2]
+    err = it.solution[:, 0] - exact
+    assert abs(float(err.mean())) < 5e-3 and float(np.sqrt((err ** 2).mean())) < 0.03
+    it.close()
+
+
+@pytest.mark.parametrize("case", ["zero_flux", "flux", "ragged_mask"])
+def test_mixed_boundary_cube_solves_match_oracle(oracle, case):
+    if case == "flux":
+        sd = cube_scene3(n=2, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: z,
+                         flux=lambda x, y, z, f: {4: 1.0, 5: -1.0}.get(f, 0.0), weld=False)
+        sd["probe"] = (0.35, (0.5, 0.5, 0.5), (0.0, 0.0, 1.0), (1.0, 0.0, 0.0))
+        ref = _same_solve(oracle, sd, 16, 12, 12, 96, 2e-3)
+    else:
+        sd = cube_scene3(n=3, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x, flux=lambda x, y, z, f: 0.0)
+        w, h = (16, 16) if case == "zero_flux" else (19, 13)
+        if case == "ragged_mask":
+            sd["mask"] = (np.arange(w * h) % 3 != 0).astype(np.uint8)
+        ref = _same_solve(oracle, sd, w, h, 10, 64, 2e-3)
+        if case == "ragged_mask":
+            assert ref["walks_started"] == int(sd["mask"].sum()) * 10
+    assert ref["neumann_hits"] > 0
+
+
+def test_3d_sharded_solve_sums_to_the_full_field(oracle):
+    import torch
+    sd = sphere_scene3(subdiv=2, value=lambda x, y, z: x)
+    it = _it(sd, 40, 24, 6, 64, 2e-3)
+    it.solve()
+    full = it.solution.copy()
+    acc = torch.zeros(40 * 24 * 3, dtype=torch.float32, device="cuda")
+    for r in range(3):
+        part = torch.zeros_like(acc)
+        it.solve_sharded(r, 3, part.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        acc += part
+    assert np.array_equal(acc.cpu().numpy().reshape(-1, 3), full)
+    it.close()
+
+
+def test_3d_limits_are_reported(oracle):
+    from elaina_amd.capi import WostError
+    sd = cube_scene3(n=4, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x)      # 128 Neumann triangles
+    with pytest.raises(WostError):
+        _it(sd, 8, 8, 1, 4, 1e-3)
