@@ -14,7 +14,8 @@
 // nodes, near-first with the per-lane LDS stack and the key format of the 2-D tree, wost_device.h).
 // The Neumann mesh of this first 3-D slice is walked with wave-uniform flat loops (up to
 // WOST3_FLAT_MAX triangles: a box, a clipped plane); larger Neumann meshes and the source term are
-// not built.  Arithmetic contract: DESIGN.md 2.3 -- op for op what oracle/wost_oracle3d.c does.
+// not built.  Arithmetic contract: DESIGN.md 2.3 (the CPU restatement the tests compare against
+// follows the same contract operation for operation).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -186,7 +187,7 @@ __device__ __forceinline__ Closest closest_triangle(const DevMesh3 &m, V3 q, int
     return T.best;
 }
 
-// checkPointSide / computeProjectionRatio for triangles (oracle tri_side, tri_uv)
+// checkPointSide / computeProjectionRatio for triangles
 __device__ __forceinline__ int tri_side(V3 p0, V3 nraw, V3 q)
 {
     const float s = dot3(nraw, q - p0);
@@ -598,7 +599,7 @@ static int build_mesh3(const wost3_mesh_desc &d, bool flat_order, HostMesh3 *out
             hi[c] = std::max(hi[c], std::max(T.p0[c], std::max(T.p1[c], T.p2[c])));
             cen[3 * (size_t)t + c] = (float)(((double)T.p0[c] + T.p1[c] + T.p2[c]) / 3.0);
         }
-        // e0, e1, nraw = cross3(e0, e1), unit normal, area: the oracle's record
+        // e0, e1, nraw = cross3(e0, e1), unit normal, area: the triangle record of DESIGN.md 2.3
         float e0[3], e1[3];
         for (int c = 0; c < 3; ++c) { e0[c] = T.p1[c] - T.p0[c]; e1[c] = T.p2[c] - T.p0[c]; }
         T.nraw[0] = std::fmaf(e0[1], e1[2], -(e0[2] * e1[1]));
@@ -613,7 +614,7 @@ static int build_mesh3(const wost3_mesh_desc &d, bool flat_order, HostMesh3 *out
         for (float c : h.colors)
             if (c != 0.0f) h.emissive = true;
     }
-    // edges: as the oracle enumerates them (first two incident triangles in index order, direction of the first)
+    // edges: the first two incident triangles in index order, direction of the first
     {
         struct Key { int a, b, t, k; };
         std::vector<Key> keys;

@@ -63,6 +63,7 @@ def test_dirichlet_sphere_solve_matches_oracle_and_the_harmonic_solution(oracle)
     sd = sphere_scene3(subdiv=3, value=lambda x, y, z: x * y + z)          # 1280 triangles, harmonic data
     ref = _same_solve(oracle, sd, 24, 20, 24, 128, 2e-3)
     assert ref["walks_absorbed"] > 0.99 * ref["walks_started"]
+    sd["probe"] = (0.55, (0.0, 0.0, 0.1), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0))       # the whole slice inside the ball
     it = _it(sd, 32, 32, 512, 256, 2e-3)
     it.solve()
     scale, pos, up, right = sd["probe"]
