@@ -83,7 +83,7 @@ def test_mixed_boundary_cube_solves_match_oracle(oracle, case):
         sd["probe"] = (0.35, (0.5, 0.5, 0.5), (0.0, 0.0, 1.0), (1.0, 0.0, 0.0))
         ref = _same_solve(oracle, sd, 16, 12, 12, 96, 2e-3)
     else:
-        sd = cube_scene3(n=3, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x, flux=lambda x, y, z, f: 0.0)
+        sd = cube_scene3(n=2, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x, flux=lambda x, y, z, f: 0.0)
         w, h = (16, 16) if case == "zero_flux" else (19, 13)
         if case == "ragged_mask":
             sd["mask"] = (np.arange(w * h) % 3 != 0).astype(np.uint8)
