@@ -16,6 +16,7 @@ using std::string;
 
 struct Vector2f { float x = 0, y = 0; };
 struct Vector2i { int x = 0, y = 0; };
+struct Vector3f { float x = 0, y = 0, z = 0; };
 struct AABB2f { Vector2f min, max; };
 
 // reference core/common.h:235-241

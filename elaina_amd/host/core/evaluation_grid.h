@@ -40,4 +40,39 @@ public:
     ProbeData mData;
 };
 
+// reference core/evaluation_grid.h:43-70
+template <> class EvaluationGrid<3> {
+public:
+    struct ProbeData {
+        float scale{1.0f};
+        Vector3f pos{0.0f, 0.0f, 0.0f};
+        Vector3f up{0.0f, 0.0f, 1.0f};     // +z as up vector
+        Vector3f right{1.0f, 0.0f, 0.0f};  // +x as right vector
+    };
+
+    EvaluationGrid() = default;
+    explicit EvaluationGrid(const json &config)
+    {
+        mData.scale = json_get_or_throw<float>(config, "mData/scale");
+        const auto pos = json_get_or_throw<std::vector<float>>(config, "mData/pos");
+        const auto up = json_get_or_throw<std::vector<float>>(config, "mData/up");
+        const auto right = json_get_or_throw<std::vector<float>>(config, "mData/right");
+        if (pos.size() != 3 || up.size() != 3 || right.size() != 3) throw std::runtime_error("evaluation_grid: pos/up/right must have 3 entries");
+        mData.pos = {pos[0], pos[1], pos[2]};
+        mData.up = {up[0], up[1], up[2]};
+        mData.right = {right[0], right[1], right[2]};
+    }
+
+    Vector3f getEvaluationPoint(Vector2i pixel, Vector2i frameSize) const
+    {
+        const float ndcx = 2.0f * (float)pixel.x / (float)frameSize.x + -1.0f;
+        const float ndcy = 2.0f * (float)pixel.y / (float)frameSize.y + -1.0f;
+        return {mData.scale * (ndcx * mData.right.x + ndcy * mData.up.x) + mData.pos.x,
+                mData.scale * (ndcx * mData.right.y + ndcy * mData.up.y) + mData.pos.y,
+                mData.scale * (ndcx * mData.right.z + ndcy * mData.up.z) + mData.pos.z};
+    }
+
+    ProbeData mData;
+};
+
 }  // namespace elaina

@@ -220,6 +220,118 @@ void Problem<2>::set_source(int nx, int ny, std::vector<float> rgb, Vector2f ind
     enable_source = true;
 }
 
+// ---- OBJ triangles + Problem<3> ------------------------------------------------------------------
+SceneLoader3::SceneLoader3(const string &path)
+{
+    std::ifstream f(path);
+    if (!f.is_open()) throw std::runtime_error("Failed to open model file: " + path);
+    string line;
+    while (std::getline(f, line)) {
+        const char *p = line.c_str();
+        while (*p == ' ' || *p == '\t') ++p;
+        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+            char *e = nullptr;
+            const double x = std::strtod(p + 1, &e), y = std::strtod(e, &e), z = std::strtod(e, &e);
+            vertices.push_back((float)x); vertices.push_back((float)y); vertices.push_back((float)z);
+        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+            std::vector<long> idx;
+            const char *q = p + 1;
+            while (true) {
+                char *e = nullptr;
+                const long v = std::strtol(q, &e, 10);
+                if (e == q) break;
+                idx.push_back(v);
+                q = e;
+                while (*q == '/' || (*q >= '0' && *q <= '9') || *q == '-') ++q;  // skip "/vt/vn" suffixes
+            }
+            const long nv = (long)(vertices.size() / 3);
+            auto fix = [nv](long i) { return (int32_t)(i > 0 ? i - 1 : nv + i); };
+            for (size_t i = 1; i + 1 < idx.size(); ++i) {
+                indices.push_back(fix(idx[0])); indices.push_back(fix(idx[i])); indices.push_back(fix(idx[i + 1]));
+            }
+        }
+    }
+    const long nv = (long)(vertices.size() / 3);
+    for (int32_t i : indices)
+        if (i < 0 || i >= nv) throw std::runtime_error("OBJ face references a missing vertex: " + path);
+}
+
+void Problem<3>::loadConfig(const json &config, const fs::path &search_dir)
+{
+    // reference core/problem.cu:152-181 with DIM == 3 (the aabb only serves the guided integrator)
+    mpProbe = std::make_shared<SceneProbe>(json_get_or_throw<json>(config, "evaluation_grid"));
+    const json meshConfig = json_get_or_throw<json>(config, "mesh");
+    if (const auto dp = json_get_optional<string>(meshConfig, "dirichlet_path")) {
+        scene_dirichlet_loader = std::make_unique<SceneLoader3>(resolve(*dp, search_dir));
+        enable_dirichlet = true;
+        scene_stat.dirichlet_vertices_size = scene_dirichlet_loader->vertices.size() / 3;
+        scene_stat.dirichlet_primitives_size = scene_dirichlet_loader->indices.size() / 3;
+    }
+    if (const auto np_ = json_get_optional<string>(meshConfig, "neumann_path")) {
+        scene_neumann_loader = std::make_unique<SceneLoader3>(resolve(*np_, search_dir));
+        enable_neumann = true;
+        scene_stat.neumann_vertices_size = scene_neumann_loader->vertices.size() / 3;
+        scene_stat.neumann_primitives_size = scene_neumann_loader->indices.size() / 3;
+    }
+    const auto cd = json_get_optional<string>(meshConfig, "vertex_color_dirichlet_path");
+    const auto cn = json_get_optional<string>(meshConfig, "vertex_color_neumann_path");
+    if (enable_dirichlet) {
+        if (cd) vertex_color_dirichlet = parseVertexColorFile(resolve(*cd, search_dir));
+        else vertex_color_dirichlet.assign(scene_stat.dirichlet_vertices_size * 6, 0.0f);
+        if (vertex_color_dirichlet.size() != scene_stat.dirichlet_vertices_size * 6)
+            throw std::runtime_error("Dirichlet colour file does not have one entry per vertex");
+    }
+    if (enable_neumann) {
+        if (cn) vertex_color_neumann = parseVertexColorFile(resolve(*cn, search_dir));
+        else vertex_color_neumann.assign(scene_stat.neumann_vertices_size * 6, 0.0f);
+        if (vertex_color_neumann.size() != scene_stat.neumann_vertices_size * 6)
+            throw std::runtime_error("Neumann colour file does not have one entry per vertex");
+    }
+    if (json_get_optional<string>(config, "source_path") || json_get_optional<json>(config, "source_grid"))
+        throw std::runtime_error("the source term is not built for 3-D scenes");
+    dirichlet_intensity = json_get_optional<float>(config, "dirichlet_intensity", 1.0f);
+    neumann_intensity = json_get_optional<float>(config, "neumann_intensity", 1.0f);
+    if (verbose) {
+        ELAINA_LOG(Success, "Problem<3>: loadConfig is completed.");
+        if (enable_dirichlet)
+            ELAINA_LOG(Info, "Dirichlet: %zu vertices, %zu triangles", scene_stat.dirichlet_vertices_size, scene_stat.dirichlet_primitives_size);
+        if (enable_neumann)
+            ELAINA_LOG(Info, "Neumann: %zu vertices, %zu triangles", scene_stat.neumann_vertices_size, scene_stat.neumann_primitives_size);
+    }
+}
+
+wost3_scene_desc Problem<3>::scene_desc(int width, int height) const
+{
+    wost3_scene_desc d;
+    std::memset(&d, 0, sizeof(d));
+    if (enable_dirichlet) {
+        d.dirichlet.n_verts = (int32_t)scene_stat.dirichlet_vertices_size;
+        d.dirichlet.n_tris = (int32_t)scene_stat.dirichlet_primitives_size;
+        d.dirichlet.verts = scene_dirichlet_loader->vertices.data();
+        d.dirichlet.tris = scene_dirichlet_loader->indices.data();
+        d.dirichlet.colors = vertex_color_dirichlet.data();
+    }
+    if (enable_neumann) {
+        d.neumann.n_verts = (int32_t)scene_stat.neumann_vertices_size;
+        d.neumann.n_tris = (int32_t)scene_stat.neumann_primitives_size;
+        d.neumann.verts = scene_neumann_loader->vertices.data();
+        d.neumann.tris = scene_neumann_loader->indices.data();
+        d.neumann.colors = vertex_color_neumann.data();
+    }
+    d.dirichlet_intensity = dirichlet_intensity;
+    d.neumann_intensity = neumann_intensity;
+    const SceneProbe::ProbeData &p = mpProbe->mData;
+    d.probe_scale = p.scale;
+    d.probe_pos[0] = p.pos.x; d.probe_pos[1] = p.pos.y; d.probe_pos[2] = p.pos.z;
+    d.probe_up[0] = p.up.x; d.probe_up[1] = p.up.y; d.probe_up[2] = p.up.z;
+    d.probe_right[0] = p.right.x; d.probe_right[1] = p.right.y; d.probe_right[2] = p.right.z;
+    if (!mask.empty()) {
+        if (mask.size() != (size_t)width * height) throw std::runtime_error("mask size does not match the frame");
+        d.mask = mask.data();
+    }
+    return d;
+}
+
 wost_scene_desc Problem<2>::scene_desc(int width, int height) const
 {
     wost_scene_desc d;

@@ -74,6 +74,44 @@ private:
     std::vector<uint8_t> mask;  // empty = all pixels on
 };
 
+// OBJ triangle loader: replaces lbvh::scene_loader<3> (reference core/problem.h:207).
+// Reads "v x y z" and "f i j k ..." (1-based, negative = relative, "i/vt/vn" accepted; polygons are fanned).
+struct SceneLoader3 {
+    explicit SceneLoader3(const string &path);
+    std::vector<float> vertices;   // x,y,z per vertex
+    std::vector<int32_t> indices;  // i0,i1,i2 per triangle, 0-based
+};
+
+// Problem<3> (reference core/problem.h:197-260): triangle meshes, EvaluationGrid<3>.  The source
+// term (a nanovdb volume in the reference) is not built for 3-D.
+template <> class Problem<3> {
+public:
+    explicit Problem(const bool verbose = true) : verbose(verbose) {}
+    using SceneProbe = EvaluationGrid<3>;
+
+    void loadConfig(const json &config, const fs::path &search_dir = {});
+    bool isDirichletEnabled() const { return enable_dirichlet; }
+    bool isNeumannEnabled() const { return enable_neumann; }
+    bool isSourceEnabled() const { return false; }
+    const SceneProbe &getProbe() const { return *mpProbe; }
+    const ProblemStatistics &get_problem_stat() const { return scene_stat; }
+    float get_dirichlet_intensity() const { return dirichlet_intensity; }
+    float get_neumann_intensity() const { return neumann_intensity; }
+    const std::vector<uint8_t> &get_mask() const { return mask; }
+    void set_mask(std::vector<uint8_t> m) { mask = std::move(m); }
+    wost3_scene_desc scene_desc(int width, int height) const;
+
+private:
+    std::shared_ptr<SceneProbe> mpProbe;
+    std::unique_ptr<SceneLoader3> scene_dirichlet_loader, scene_neumann_loader;
+    std::vector<float> vertex_color_dirichlet, vertex_color_neumann;
+    bool enable_dirichlet{false}, enable_neumann{false};
+    bool verbose{false};
+    ProblemStatistics scene_stat;
+    float dirichlet_intensity{1.0f}, neumann_intensity{1.0f};
+    std::vector<uint8_t> mask;
+};
+
 // reference core/problem.cu:63-96: {"ColorConfigurations":[{"vertexID":i+1,"leftColor":{R,G,B},"rightColor":{R,G,B}}]}
 std::vector<float> parseVertexColorFile(const string &path);
 

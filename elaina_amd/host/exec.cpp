@@ -2,8 +2,8 @@
 // requested channels, export, write result.json (reference exec.cu:39-221).  Differences,
 // on purpose: the output directory is created (the reference writes conf.json into a
 // directory it never makes, exec.cu:69); unknown channels / export entries are skipped
-// instead of dereferencing an empty optional (exec.cu:193-199); only 2-D is built -- 3-D
-// configurations exit(1) like an unsupported dimensionality does.
+// instead of dereferencing an empty optional (exec.cu:193-199); dimensionality 3 is built for the
+// uniform integrator only (exec.cu:102-122: the guided one exits like an unknown type).
 #include "exec.h"
 
 #include <chrono>
@@ -103,8 +103,28 @@ void run_expr(fs::path conf_path)
     const json integrator_section = json_get_or_throw<json>(conf_json, "integrator");
     const string integrator_type = json_get_or_throw<string>(integrator_section, "type");
     const json integrator_setting = json_get_or_throw<json>(integrator_section, "setting");
+    if (dimensionality == 3) {
+        if (integrator_type != "uniform") {
+            ELAINA_LOG(Error, "Unrecognized integrator type (3-D: uniform only in this build).");
+            exit(1);
+        }
+        Problem<3> scene3;
+        scene3.loadConfig(scene_section, conf_path.parent_path());
+        UniformIntegrator<3> obj(scene3, UniformIntegratorSettings::from_json(integrator_setting), outDir);
+        run_channels(obj, conf_json, integrator_section, result_json);
+        const wost_stats &s = obj.get_last_stats();
+        if (s.walk_steps) {
+            result_json["walk_steps"] = json((uint64_t)s.walk_steps);
+            result_json["walk_steps_per_second"] = json(s.solve_ms > 0 ? (double)s.walk_steps / (s.solve_ms * 1e-3) : 0.0);
+        }
+        result_json["timestamp"] = json(get_current_time());
+        std::ofstream resultFile(outDir / "result.json");
+        resultFile << result_json.dump(4) << std::endl;
+        ELAINA_LOG(Success, "Result file written to %s", (outDir / "result.json").c_str());
+        return;
+    }
     if (dimensionality != 2) {
-        ELAINA_LOG(Error, "Unsupported dimensionality (this build: 2).");
+        ELAINA_LOG(Error, "Unsupported dimensionality.");
         exit(1);
     }
     Problem<2> scene;

@@ -77,6 +77,35 @@ void UniformIntegrator<2>::renderSource()
     check_wost(wost_render_source(handle, c.data()), "wost_render_source");
 }
 
+UniformIntegrator<3>::UniformIntegrator(Problem<3> &problem_, const IntegratorSettings &settings, const fs::path &basePath_, int device)
+    : IntegratorOutputs(settings.frameSize, basePath_), problem(problem_), integratorSettings(settings)
+{
+    const wost3_scene_desc sd = problem.scene_desc(settings.frameSize.x, settings.frameSize.y);
+    wost_settings st{settings.frameSize.x, settings.frameSize.y, settings.samplesPerPixel, (int32_t)settings.maxWalkingDepth,
+                     settings.epsilonShell};
+    check_wost(wost3_create(&sd, &st, device, &handle), "wost3_create");
+}
+
+UniformIntegrator<3>::~UniformIntegrator()
+{
+    if (handle) wost3_destroy(handle);
+}
+
+uint64_t UniformIntegrator<3>::solve()
+{
+    const auto start = std::chrono::high_resolution_clock::now();
+    const int n = integratorSettings.frameSize.x * integratorSettings.frameSize.y;
+    std::vector<float> &f = channels[(size_t)ExportImageChannel::SOLUTION];
+    f.assign((size_t)n * 3, 0.0f);
+    check_wost(wost3_solve(handle, 0, n, f.data(), &last_stats), "wost3_solve");
+    return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - start).count();
+}
+
+void UniformIntegrator<3>::queryNetwork(const VectorType &)
+{
+    throw std::runtime_error("queryNetwork: not implemented for the uniform integrator (reference integrator.cu:661-664)");
+}
+
 void UniformIntegrator<2>::queryNetwork(const VectorType &)
 {
     throw std::runtime_error("queryNetwork: not implemented for the uniform integrator (reference integrator.cu:661-664)");

@@ -56,4 +56,31 @@ private:
     wost_stats last_stats{};
 };
 
+// UniformIntegrator<3> (reference integrator/uniform/integrator.h:55-131 with DIM = 3): SOLUTION only --
+// the SDF and source channels of the 3-D integrator are not built.
+template <> class UniformIntegrator<3> : public IntegratorOutputs {
+public:
+    using IntegratorSettings = UniformIntegratorSettings;
+    using VectorType = Vector3f;
+    using ProblemType = Problem<3>;
+
+    UniformIntegrator(Problem<3> &problem, const IntegratorSettings &settings, const fs::path &basePath_, int device = 0);
+    ~UniformIntegrator();
+    UniformIntegrator(const UniformIntegrator &) = delete;
+    UniformIntegrator &operator=(const UniformIntegrator &) = delete;
+
+    uint64_t solve();
+    void renderDirichletSDF() { throw std::runtime_error("renderDirichletSDF: not built for 3-D"); }
+    void renderSilhouetteSDF() { throw std::runtime_error("renderSilhouetteSDF: not built for 3-D"); }
+    void renderSource() { throw std::runtime_error("renderSource: not built for 3-D"); }
+    void queryNetwork(const VectorType &p);
+    const wost_stats &get_last_stats() const { return last_stats; }
+
+private:
+    Problem<3> &problem;
+    IntegratorSettings integratorSettings;
+    wost3_handle handle{nullptr};
+    wost_stats last_stats{};
+};
+
 }  // namespace elaina

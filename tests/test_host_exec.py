@@ -303,3 +303,26 @@ def test_run_expr_spp_metric_frames(tmp_path, oracle, ladybug):
             assert np.array_equal(export_scene.read_pfm(exp / "solution.pfm"), final)      # spp restored afterwards
         else:
             assert len(os.listdir(exp / "frames_time")) in (2, 4)      # samples 0 and 4 (.exr + .png; names are elapsed ms)
+
+
+@pytest.mark.gpu
+def test_run_expr_three_dimensional_configuration(tmp_path, oracle):
+    """"dimensionality": 3 through the C++ host (reference exec.cu:102-122): OBJ triangles + colour files ->
+    Problem<3> -> UniformIntegrator<3> -> raw field, against the oracle; the guided type is refused like an
+    unknown integrator"""
+    import export_scene
+    from conftest import cube_scene3
+    sd = cube_scene3(n=2, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x + z, flux=lambda x, y, z, f: 0.0)
+    conf = export_scene.export3(sd, str(tmp_path), frame=(24, 16), spp=6, depth=48, eps=2e-3)
+    out = subprocess.run([_exe(), conf], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    exp = tmp_path / "exp" / "scene3d"
+    res = json.load(open(exp / "result.json"))
+    ref = oracle.solve3(sd, 24, 16, 6, 48, 2e-3, threads=os.cpu_count())
+    assert res["walk_steps"] == ref["walk_steps"] and "duration" in res
+    assert np.array_equal(export_scene.read_pfm(exp / "solution.pfm"), ref["field"])
+    cj = json.load(open(conf))
+    cj["integrator"]["type"] = "guided"
+    json.dump(cj, open(conf, "w"))
+    out = subprocess.run([_exe(), conf], capture_output=True, text=True)
+    assert out.returncode == 1 and "integrator type" in out.stderr

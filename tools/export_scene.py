@@ -93,6 +93,43 @@ def export(scene, out_dir, frame=128, spp=16, depth=32, exp_name=None, integrato
     return path
 
 
+def export3(sd, out_dir, frame=(32, 32), spp=8, depth=64, eps=2e-3, exp_name="scene3d"):
+    """a 3-D scene dict (tests/conftest.py cube_scene3 / sphere_scene3) as model.obj (v / f records), boundary.obj,
+    colour files and a conf.json with "dimensionality": 3 (reference exec.cu:102-122, core/evaluation_grid.h:43-70)"""
+    os.makedirs(out_dir, exist_ok=True)
+
+    def write_obj3(path, verts, tris):
+        with open(path, "w") as f:
+            for x, y, z in verts:
+                f.write("v %.9g %.9g %.9g\n" % (x, y, z))
+            for a, b, c in tris:
+                f.write("f %d %d %d\n" % (a + 1, b + 1, c + 1))
+    mesh = {}
+    if sd.get("d_tris") is not None:
+        write_obj3(os.path.join(out_dir, "model.obj"), sd["d_verts"], sd["d_tris"])
+        write_colors(os.path.join(out_dir, "color.json"), sd["d_colors"])
+        mesh.update({"dirichlet_path": os.path.join(out_dir, "model.obj"), "vertex_color_dirichlet_path": os.path.join(out_dir, "color.json")})
+    if sd.get("n_tris") is not None:
+        write_obj3(os.path.join(out_dir, "boundary.obj"), sd["n_verts"], sd["n_tris"])
+        write_colors(os.path.join(out_dir, "color_n.json"), sd["n_colors"])
+        mesh.update({"neumann_path": os.path.join(out_dir, "boundary.obj"), "vertex_color_neumann_path": os.path.join(out_dir, "color_n.json")})
+    scale, pos, up, right = sd["probe"]
+    conf = {
+        "dimensionality": 3, "base_path": os.path.join(out_dir, "exp"), "exp_name": exp_name,
+        "integrator": {
+            "setting": {"debugPixel": 0, "frameSize": [int(frame[0]), int(frame[1])], "maxWalkingDepth": depth, "samplesPerPixel": spp,
+                        "saveSppMetricsDuration": -1, "saveSppMetricsUntil": -1, "saveTimeMetricsDuration": -1, "epsilonShell": float(eps)},
+            "type": "uniform", "channels": ["SOLUTION"]},
+        "export": [{"type": "image", "channel": "SOLUTION", "file_name": "solution"}],
+        "scene": {"evaluation_grid": {"mData": {"pos": [float(v) for v in pos], "scale": float(scale), "up": [float(v) for v in up],
+                                                "right": [float(v) for v in right]}},
+                  "mesh": mesh}}
+    path = os.path.join(out_dir, "conf.json")
+    with open(path, "w") as f:
+        json.dump(conf, f, indent=4)
+    return path
+
+
 def read_pfm(path):
     with open(path, "rb") as f:
         assert f.readline().strip() == b"PF"
