@@ -665,8 +665,10 @@ struct wost_guided {
     GStatsDev *stats = nullptr;
     uint32_t *block_sums = nullptr;
     int n_train_blocks = 0, n_train_pixels = 0;
+    uint64_t host_rng_state = 0, host_rng_inc = 3;   // mGuiding.sampler of the reference (trainPixelOffset draws)
     TrainSet ts{};
     uint32_t last_train_n = 0;
+    uint32_t last_train_offset = 0;    // trainPixelOffset of the most recent solve
     GAabb box{};
     wost_sync_fn sync = nullptr;       // shared-network mode: collective hooks of the caller
     void *sync_user = nullptr;
@@ -675,6 +677,14 @@ struct wost_guided {
     int32_t frame_spp_every = 0, frame_spp_until = 0, frame_time_every = 0;
     EventRing net_events;              // timing of the network-evaluating launches
 };
+
+static uint32_t host_pcg_next(wost_guided *g)
+{
+    const uint64_t old = g->host_rng_state;
+    g->host_rng_state = old * WOST_PCG32_MULT + g->host_rng_inc;
+    const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
 
 #define G_TRY(expr)                                                                                      \
     do {                                                                                                 \
@@ -717,7 +727,7 @@ int wost_guided_create(const wost_scene_desc *scene, const wost_guided_settings 
     *out = nullptr;
     if (s->width <= 0 || s->height <= 0 || s->spp < 0 || s->max_depth <= 0 || s->train_spp_count < 0 ||
         s->max_guided_depth_training < 0 || s->max_guided_depth_guiding < 0 || s->batch_size < 128 ||
-        s->min_batch_size < 1 || s->batches_per_spp < 0 || s->train_pixel_stride < 1 || s->train_pixel_offset < 0 ||
+        s->min_batch_size < 1 || s->batches_per_spp < 0 || s->train_pixel_stride < 1 || s->train_pixel_offset < -1 ||
         s->train_pixel_offset >= s->train_pixel_stride || !(s->loss_scale > 0.0f) ||
         !(s->aabb_min[0] < s->aabb_max[0]) || !(s->aabb_min[1] < s->aabb_max[1]))
         return set_error(WOST_ERR_INVALID, "bad guided settings");
@@ -761,8 +771,16 @@ int wost_guided_create(const wost_scene_desc *scene, const wost_guided_settings 
     GA(g->counts, 2); GA(g->rng, N); GA(g->sol, 3 * N); GA(g->field, 3 * N);
     GA(g->rec, (size_t)kMaxTrainDepth * kRecFields * N);
     GA(g->net_in, 2 * N); GA(g->net_out, 33 * N); GA(g->cur_depth, N); GA(g->hint0, N); GA(g->stats, kStatCopies);
-    g->n_train_pixels = (int)((N - (size_t)s->train_pixel_offset + (size_t)s->train_pixel_stride - 1) / (size_t)s->train_pixel_stride);
+    // sized for offset 0 (the largest set); the offset of a solve may be drawn per solve (run_guided)
+    g->n_train_pixels = (int)((N + (size_t)s->train_pixel_stride - 1) / (size_t)s->train_pixel_stride);
     g->n_train_blocks = (g->n_train_pixels + 255) / 256;
+    // the integrator's host sampler: setSeed(ELAINA_DEFAULT_RNG_SEED = 42) with the default sequence 1
+    // (reference integrator/guided/integrator.cu:1134, core/sampler.h:20-27, core/config.h:7)
+    g->host_rng_inc = (1ull << 1u) | 1ull;
+    g->host_rng_state = 0;
+    (void)host_pcg_next(g);
+    g->host_rng_state += 42ull;
+    (void)host_pcg_next(g);
     GA(g->block_sums, (size_t)g->n_train_blocks + 1);
     const size_t M = (size_t)g->n_train_pixels * kMaxTrainDepth;
     GA(g->ts.xy, 2 * M); GA(g->ts.dir, 2 * M); GA(g->ts.sol, 3 * M); GA(g->ts.li, M); GA(g->ts.pdf, M); GA(g->ts.nrm, 2 * M);
@@ -890,7 +908,21 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     P.rng = g->rng; P.sol = g->sol; P.cur_depth = g->cur_depth; P.rec = g->rec; P.hint0 = g->hint0;
     P.net_in = g->net_in; P.net_out = g->net_out; P.net_ld = (size_t)N; P.stats = g->stats; P.n_pixels = N; P.stack_stride = 256;
     P.max_train_depth = s.max_train_depth;
-    P.train_offset = (uint32_t)s.train_pixel_offset; P.train_stride = (uint32_t)s.train_pixel_stride;
+    // prepareSolve (integrator.cu:126): trainPixelOffset = stride <= 1 ? 0 : sampler.get1D() * stride, one draw per
+    // solve from the integrator's host sampler; a caller-fixed offset (>= 0) overrides the draw
+    uint32_t train_offset = 0;
+    if (s.train_pixel_stride > 1) {
+        if (s.train_pixel_offset >= 0) train_offset = (uint32_t)s.train_pixel_offset;
+        else {
+            union { uint32_t u; float f; } x;
+            x.u = (host_pcg_next(g) >> 9) | 0x3f800000u;
+            train_offset = (uint32_t)((x.f - 1.0f) * (float)s.train_pixel_stride);
+        }
+    }
+    g->last_train_offset = train_offset;
+    const int n_train_pixels = (int)(((size_t)N - train_offset + (size_t)s.train_pixel_stride - 1) / (size_t)s.train_pixel_stride);
+    const int n_train_blocks = (n_train_pixels + 255) / 256;
+    P.train_offset = train_offset; P.train_stride = (uint32_t)s.train_pixel_stride;
     P.shard_index = shard_index; P.shard_count = shard_count;
 
     // ctor state (integrator.cu:1158-1160), prepareSolve (:125-126)
@@ -977,13 +1009,13 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
             const auto t0 = std::chrono::high_resolution_clock::now();
             TParams T{};
             T.box = g->box; T.cur_depth = g->cur_depth; T.rec = g->rec; T.n_pixels = N;
-            T.train_offset = (uint32_t)s.train_pixel_offset; T.train_stride = (uint32_t)s.train_pixel_stride;
-            T.n_train_pixels = g->n_train_pixels; T.block_sums = g->block_sums; T.ts = g->ts;
-            hipLaunchKernelGGL((train_set_kernel<false>), dim3(g->n_train_blocks), dim3(256), 0, stream, T);
-            hipLaunchKernelGGL(train_scan_kernel, dim3(1), dim3(256), 0, stream, g->block_sums, g->n_train_blocks);
-            hipLaunchKernelGGL((train_set_kernel<true>), dim3(g->n_train_blocks), dim3(256), 0, stream, T);
+            T.train_offset = train_offset; T.train_stride = (uint32_t)s.train_pixel_stride;
+            T.n_train_pixels = n_train_pixels; T.block_sums = g->block_sums; T.ts = g->ts;
+            hipLaunchKernelGGL((train_set_kernel<false>), dim3(n_train_blocks), dim3(256), 0, stream, T);
+            hipLaunchKernelGGL(train_scan_kernel, dim3(1), dim3(256), 0, stream, g->block_sums, n_train_blocks);
+            hipLaunchKernelGGL((train_set_kernel<true>), dim3(n_train_blocks), dim3(256), 0, stream, T);
             launches += 3;
-            G_TRY(hipMemcpyAsync(g->host_counts + 1, g->block_sums + g->n_train_blocks, sizeof(uint32_t),
+            G_TRY(hipMemcpyAsync(g->host_counts + 1, g->block_sums + n_train_blocks, sizeof(uint32_t),
                                  hipMemcpyDeviceToHost, stream));
             G_TRY(hipStreamSynchronize(stream));
             const size_t n = g->host_counts[1];
@@ -1075,6 +1107,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         stats->train_ms = train_ms;
         stats->kernel_launches = launches;
         stats->net_points = hs.net_points;
+        stats->reserved = g->last_train_offset;
         stats->net_infer_ms = net_infer_ms;
         stats->solve_ms =
             std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_start).count();

@@ -136,7 +136,7 @@ class GuidedIntegratorSettings:
                  epsilonShell=1e-5, debugPixel=0, saveSppMetricsDuration=-1, saveSppMetricsUntil=1024,
                  saveTimeMetricsDuration=-1,
                  maxTrainDepth=3, batchSize=524288, minBatchSize=65536, batchPerFrame=5, trainPixelStride=1,
-                 trainPixelOffset=0, lossScale=128.0):
+                 trainPixelOffset=-1, lossScale=128.0):
         self.frameSize = (int(frameSize[0]), int(frameSize[1]))
         self.samplesPerPixel = int(samplesPerPixel)
         self.trainSppCount = int(trainSppCount)

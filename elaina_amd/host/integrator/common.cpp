@@ -1,5 +1,7 @@
 #include "common.h"
 
+#include "util/colormap_tables.h"
+
 #include <algorithm>
 #include <cmath>
 #include <fstream>
@@ -25,40 +27,46 @@ void IntegratorOutputs::render_sdf(wost_handle scene, int which_mesh, ExportImag
 }
 
 // ---- colormaps of saveEnergy (reference util/film.h:107-145, util/tonemapping.cuh) ------------
-// MATLAB_JET is the reference's piecewise-linear formula.  The reference's MATLAB_PARULA and
-// IDL_RDBU are fitted polynomial tables (several hundred coefficients); here they are linear
-// interpolations through published anchor colours of the same maps (ColorBrewer RdBu-11; nine
-// samples of parula), within a few 1/255 of the originals -- previews, not parity data.
-static void lerp_anchors(const float (*a)[3], int n, float x, float rgb[3])
+// MATLAB_JET is the reference's piecewise-linear formula; MATLAB_PARULA and IDL_RDBU evaluate the
+// reference's fitted tables (util/tonemapping.cuh:53-383, :385-480), restated as numbers in
+// util/colormap_tables.h, with the reference's arithmetic: parula in float Horner form on
+// dx = float(x - x0), RdBu in double Horner form, / 255, clamped.
+static double rdbu_channel(const RdBuPiece *rows, double x)
 {
-    x = std::min(std::max(x, 0.0f), 1.0f) * (float)(n - 1);
-    const int i = std::min((int)x, n - 2);
-    const float t = x - (float)i;
-    for (int c = 0; c < 3; ++c) rgb[c] = a[i][c] * (1.0f - t) + a[i + 1][c] * t;
+    const RdBuPiece *r = rows;
+    while (!(x < r->hi)) ++r;          // the last row has hi = 2
+    double v = r->c[0];
+    for (int k = 1; k < 6; ++k) v = v * x + r->c[k];
+    return v;
 }
 
 void tone_map(ToneMapping tone, float x, float rgb[3])
 {
-    static const float rdbu[11][3] = {{103, 0, 31}, {178, 24, 43}, {214, 96, 77}, {244, 165, 130}, {253, 219, 199},
-                                      {247, 247, 247}, {209, 229, 240}, {146, 197, 222}, {67, 147, 195}, {33, 102, 172},
-                                      {5, 48, 97}};
-    static const float parula[9][3] = {{0.2422f, 0.1504f, 0.6603f}, {0.2810f, 0.3228f, 0.9579f}, {0.1786f, 0.5289f, 0.9682f},
-                                       {0.0689f, 0.6948f, 0.8394f}, {0.2161f, 0.7843f, 0.5923f}, {0.6720f, 0.7793f, 0.2227f},
-                                       {0.9970f, 0.7659f, 0.2199f}, {0.9632f, 0.9000f, 0.1300f}, {0.9769f, 0.9839f, 0.0805f}};
     auto clamp01 = [](float v) { return std::min(std::max(v, 0.0f), 1.0f); };
     switch (tone) {
     case ToneMapping::MATLAB_JET:
-        rgb[0] = clamp01(x < 0.7f ? 4.0f * x - 1.5f : -4.0f * x + 4.5f);
-        rgb[1] = clamp01(x < 0.5f ? 4.0f * x - 0.5f : -4.0f * x + 3.5f);
-        rgb[2] = clamp01(x < 0.3f ? 4.0f * x + 0.5f : -4.0f * x + 2.5f);
+        rgb[0] = clamp01((float)(x < 0.7 ? 4.0 * x - 1.5 : -4.0 * x + 4.5));
+        rgb[1] = clamp01((float)(x < 0.5 ? 4.0 * x - 0.5 : -4.0 * x + 3.5));
+        rgb[2] = clamp01((float)(x < 0.3 ? 4.0 * x + 0.5 : -4.0 * x + 2.5));
         break;
-    case ToneMapping::MATLAB_PARULA:
-        lerp_anchors(parula, 9, x, rgb);
+    case ToneMapping::MATLAB_PARULA: {
+        if (x < 0.0 || 1.0 < x || std::isnan(x)) {
+            rgb[0] = rgb[1] = rgb[2] = 0.0f;
+            break;
+        }
+        const ParulaPiece *p = kParula;
+        while (!(x < p->hi)) ++p;      // the last piece has hi = 2
+        const float dx = (float)((double)x - p->x0);
+        for (int c = 0; c < 3; ++c) rgb[c] = ((p->c3[c] * dx + p->c2[c]) * dx + p->c1[c]) * dx + p->c0[c];
         break;
-    case ToneMapping::IDL_RDBU:
-        lerp_anchors(rdbu, 11, x, rgb);
-        for (int c = 0; c < 3; ++c) rgb[c] /= 255.0f;
+    }
+    case ToneMapping::IDL_RDBU: {
+        const double xd = std::isnan(x) ? 0.0 : (double)x;
+        rgb[0] = clamp01((float)(rdbu_channel(kRdBuRed, xd) / 255.0));
+        rgb[1] = clamp01((float)(rdbu_channel(kRdBuGreen, xd) / 255.0));
+        rgb[2] = clamp01((float)(rdbu_channel(kRdBuBlue, xd) / 255.0));
         break;
+    }
     default:
         rgb[0] = rgb[1] = rgb[2] = x;
         break;

@@ -89,7 +89,7 @@ void GuidedIntegrator<2>::resetNetwork(const json &config)
     gs.aabb_min[0] = b.min.x; gs.aabb_min[1] = b.min.y; gs.aabb_max[0] = b.max.x; gs.aabb_max[1] = b.max.y;
     // the reference's compile-time training constants (parameters.h:7-14, integrator.h:237-239)
     gs.max_train_depth = 3; gs.batch_size = 65536 * 8; gs.min_batch_size = 65536; gs.batches_per_spp = 5;
-    gs.train_pixel_stride = 1; gs.train_pixel_offset = 0; gs.loss_scale = 128.0f;
+    gs.train_pixel_stride = 1; gs.train_pixel_offset = -1; gs.loss_scale = 128.0f;   // offset drawn like the reference when the stride is > 1
     check_wost(wost_guided_create(&sd, &gs, &nc, /* ELAINA_DEFAULT_RNG_SEED */ 42, device, &handle), "wost_guided_create");
 }
 

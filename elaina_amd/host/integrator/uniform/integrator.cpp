@@ -27,9 +27,6 @@ UniformIntegrator<2>::UniformIntegrator(Problem<2> &problem_, const IntegratorSe
                                         int device)
     : IntegratorOutputs(settings.frameSize, basePath_), problem(problem_), integratorSettings(settings)
 {
-    if (settings.saveTimeMetricsDuration > 0)
-        ELAINA_LOG(Warning, "saveTimeMetricsDuration: pixels do not advance in lock step in this integrator, so there is no frame "
-                            "\"after t milliseconds\"; ignored (saveSppMetrics* is honoured)");
     const wost_scene_desc sd = problem.scene_desc(settings.frameSize.x, settings.frameSize.y);
     wost_settings st{settings.frameSize.x, settings.frameSize.y, settings.samplesPerPixel, (int32_t)settings.maxWalkingDepth,
                      settings.epsilonShell};
@@ -47,17 +44,30 @@ uint64_t UniformIntegrator<2>::solve()
     const int n = integratorSettings.frameSize.x * integratorSettings.frameSize.y;
     std::vector<float> &f = channels[(size_t)ExportImageChannel::SOLUTION];
     f.assign((size_t)n * 3, 0.0f);
-    // saveSppMetrics* (reference integrator.cu:578-592): frames/<sampleId>.exr|png = the solution after
-    // sampleId + 1 samples.  A pixel's first k samples do not depend on the total, so each frame is a
-    // solve with spp = k (extra work, debug feature).
+    // saveSppMetrics* / saveTimeMetrics* (reference integrator.cu:578-609): frames/<sampleId>.exr|png and
+    // frames_time/<elapsed ms>.exr|png = solution / (sampleId + 1) after sample sampleId.  The pixels of this
+    // integrator do not advance in lock step, but a pixel's first k samples do not depend on the total: each
+    // frame is a solve with spp = k (extra work, a debug feature); the time frames are keyed by the milliseconds
+    // since the start of solve(), as in the reference.
     const IntegratorSettings &s = integratorSettings;
-    if (s.saveSppMetricsDuration > 0) {
-        fs::create_directories(basePath / "frames");
-        for (int sampleId = 0; sampleId < s.samplesPerPixel && sampleId < s.saveSppMetricsUntil; sampleId += s.saveSppMetricsDuration) {
+    if (s.saveSppMetricsDuration > 0 || s.saveTimeMetricsDuration > 0) {
+        if (s.saveSppMetricsDuration > 0) fs::create_directories(basePath / "frames");
+        if (s.saveTimeMetricsDuration > 0) fs::create_directories(basePath / "frames_time");
+        for (int sampleId = 0; sampleId < s.samplesPerPixel; ++sampleId) {
+            const bool by_spp = s.saveSppMetricsDuration > 0 && sampleId % s.saveSppMetricsDuration == 0 && sampleId < s.saveSppMetricsUntil;
+            const bool by_time = s.saveTimeMetricsDuration > 0 && sampleId % s.saveTimeMetricsDuration == 0;
+            if (!by_spp && !by_time) continue;
             check_wost(wost_set_option(handle, "spp", sampleId + 1), "wost_set_option(spp)");
             check_wost(wost_solve(handle, 0, n, f.data(), &last_stats), "wost_solve");
-            write_exr(basePath / "frames" / (std::to_string(sampleId) + ".exr"), s.frameSize.x, s.frameSize.y, f);
-            write_png(basePath / "frames" / (std::to_string(sampleId) + ".png"), s.frameSize.x, s.frameSize.y, f);
+            if (by_spp) {
+                write_exr(basePath / "frames" / (std::to_string(sampleId) + ".exr"), s.frameSize.x, s.frameSize.y, f);
+                write_png(basePath / "frames" / (std::to_string(sampleId) + ".png"), s.frameSize.x, s.frameSize.y, f);
+            }
+            if (by_time) {
+                const auto elapsed = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - start).count();
+                write_exr(basePath / "frames_time" / (std::to_string(elapsed) + ".exr"), s.frameSize.x, s.frameSize.y, f);
+                write_png(basePath / "frames_time" / (std::to_string(elapsed) + ".png"), s.frameSize.x, s.frameSize.y, f);
+            }
         }
         check_wost(wost_set_option(handle, "spp", s.samplesPerPixel), "wost_set_option(spp)");
     }

@@ -242,7 +242,8 @@ typedef struct wost_guided_settings {
     int32_t min_batch_size;                     /* 65536   parameters.h:12                       */
     int32_t batches_per_spp;                    /* 5       integrator.h:238                      */
     int32_t train_pixel_stride;                 /* 1       guided.h:104-121                      */
-    int32_t train_pixel_offset;                 /* 0                                              */
+    int32_t train_pixel_offset;                 /* 0; -1 = drawn per solve from the integrator's host sampler when the
+                                                   stride is > 1, as the reference does (integrator.cu:126) */
     float loss_scale;                           /* 128     parameters.h:14                       */
 } wost_guided_settings;
 
@@ -254,7 +255,7 @@ typedef struct wost_guided_stats {
     double solve_ms;             /* host wall time of wost_guided_solve                           */
     double train_ms;             /* part of it spent building training sets and training          */
     uint32_t kernel_launches;
-    uint32_t reserved;
+    uint32_t reserved;           /* trainPixelOffset used by the solve                                */
     uint64_t net_points;         /* network evaluations made for walkers (out-of-shell entries of guided depths) */
     double net_infer_ms;         /* GPU time of the launches that evaluate the network for walkers (HIP events)  */
 } wost_guided_stats;

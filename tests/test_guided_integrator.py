@@ -593,3 +593,30 @@ def test_gpu_config5_frame_shard_trained_solve(ladybug):
     assert abs(float(f0[own].mean()) - float(u[own].mean())) < 2e-3 * max(1.0, abs(float(u[own].mean())))
     rel = np.linalg.norm(f0[own] - u[own]) / np.linalg.norm(u[own])
     assert rel < 0.5, rel
+
+
+@pytest.mark.gpu
+def test_gpu_train_pixel_offset_is_drawn_like_the_reference(oracle):
+    """trainPixelStride > 1: prepareSolve draws trainPixelOffset = get1D() * stride from the integrator's host
+    sampler, seeded setSeed(42) with sequence 1 in resetNetwork (reference integrator/guided/integrator.cu:126,
+    :1134, core/sampler.h:20-27); one draw per solve.  The solves equal the oracle's with those offsets."""
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    prob = laplace_box()
+    w, h, spp, depth, stride = 36, 28, 6, 32, 3
+    st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=3, maxWalkingDepth=depth, epsilonShell=EPS,
+                                  batchSize=1024, minBatchSize=128, trainPixelStride=stride)          # trainPixelOffset = -1: drawn
+    rng = oracle.pcg_seed(42, 1)
+    expect = [int(np.float32(oracle.pcg_float(rng)) * np.float32(stride)) for _ in range(2)]
+    assert all(0 <= e < stride for e in expect)
+    gi = GuidedIntegrator(prob, st, AABB, seed=7)
+    p0 = gi.network.params()
+    for k in range(2):
+        gi.network.set_params(p0)                    # same starting network, the next draw of the host sampler
+        gi.solve()
+        assert gi.last_stats["reserved"] == expect[k]
+        gs = guided_settings(w, h, spp, depth, EPS, AABB[0], AABB[1], train_spp_count=3, batch_size=1024, min_batch_size=128,
+                             train_pixel_stride=stride, train_pixel_offset=expect[k])
+        ref = oracle.solve_guided(prob.as_dict(), gs, default_net_config(), p0.copy(), threads=8)
+        assert gi.last_stats["train_samples"] == ref["train_samples"] and gi.last_stats["optimizer_steps"] == ref["optimizer_steps"] > 0
+        assert np.array_equal(gi.solution, ref["field"])
+    gi.close()

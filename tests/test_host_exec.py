@@ -130,7 +130,7 @@ def _read_exr_half_rgba(path):
 
 def test_png_and_exr_writers_and_colormaps(tmp_path):
     """reference core/texture.cu:82-116: PNG = clamp((int)(v*255)), RGBA8, flipped vertically;
-    EXR = half RGBA, flipped; colormaps of util/tonemapping.cuh (JET exact, the others anchored)"""
+    EXR = half RGBA, flipped; colormaps of util/tonemapping.cuh (JET formula, PARULA / RDBU fitted tables)"""
     out = subprocess.run([_exe(), "--imagetest", str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     w, h = 5, 3
@@ -150,11 +150,17 @@ def test_png_and_exr_writers_and_colormaps(tmp_path):
     np.testing.assert_allclose(tones[(2, 0.0)], [0, 0, 0.5], atol=1e-6)
     np.testing.assert_allclose(tones[(2, 0.5)], [0.5, 1.0, 0.5], atol=1e-6)
     np.testing.assert_allclose(tones[(2, 1.0)], [0.5, 0, 0], atol=1e-6)
-    # IDL_RDBU = 4: red end at 0, white middle, blue end at 1
-    assert tones[(4, 0.0)][0] > 0.35 > tones[(4, 0.0)][2] and tones[(4, 1.0)][2] > 0.35 > tones[(4, 1.0)][0]
-    assert np.all(tones[(4, 0.5)] > 0.9)
-    # MATLAB_PARULA = 3: blue -> yellow, NONE_NORMALIZED = 1: grey ramp
-    assert tones[(3, 0.0)][2] > 0.6 and tones[(3, 1.0)][0] > 0.9 and tones[(3, 1.0)][2] < 0.2
+    # IDL_RDBU = 4: the reference's fitted table (util/tonemapping.cuh:385-480) runs through the ColorBrewer
+    # RdBu-11 colours: #67001f at 0, #f7f7f7 in the middle, #053061 at 1
+    np.testing.assert_allclose(tones[(4, 0.0)], np.array([103, 0, 31]) / 255.0, atol=0.01)
+    np.testing.assert_allclose(tones[(4, 0.5)], np.array([247, 247, 247]) / 255.0, atol=0.01)
+    np.testing.assert_allclose(tones[(4, 1.0)], np.array([5, 48, 97]) / 255.0, atol=0.015)
+    # MATLAB_PARULA = 3 (util/tonemapping.cuh:53-383): cubic pieces through MATLAB's parula(64) table, whose first
+    # and last rows are (0.2081, 0.1663, 0.5292) and (0.9763, 0.9831, 0.0538)
+    # (the first knot sits at x = 1/64: x = 0 is the first cubic extrapolated half a step), the middle one (0.1801, 0.7177, 0.6424)
+    np.testing.assert_allclose(tones[(3, 0.0)], [0.2081, 0.1663, 0.5292], atol=0.06)
+    np.testing.assert_allclose(tones[(3, 0.5)], [0.1801, 0.7177, 0.6424], atol=2e-3)
+    np.testing.assert_allclose(tones[(3, 1.0)], [0.9763, 0.9831, 0.0538], atol=1e-5)
     np.testing.assert_allclose(tones[(1, 0.25)], [0.25] * 3)
 
 
@@ -286,8 +292,7 @@ def test_run_expr_spp_metric_frames(tmp_path, oracle, ladybug):
         conf = export_scene.export("ladybug", str(d), frame=32, spp=5, depth=24, integrator=integrator, train_spp=0)
         c = json.load(open(conf))
         c["integrator"]["setting"].update({"saveSppMetricsDuration": 2, "saveSppMetricsUntil": 4})
-        if integrator == "guided":
-            c["integrator"]["setting"]["saveTimeMetricsDuration"] = 4
+        c["integrator"]["setting"]["saveTimeMetricsDuration"] = 4      # both integrators (uniform: integrator.cu:594-609)
         json.dump(c, open(conf, "w"))
         out = subprocess.run([_exe(), conf], capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
@@ -301,6 +306,11 @@ def test_run_expr_spp_metric_frames(tmp_path, oracle, ladybug):
                 assert np.array_equal(png[::-1, :, :3].reshape(-1, 3), np.clip((ref * np.float32(255)).astype(np.int32), 0, 255))
             final = oracle.solve(ladybug.as_dict(), 32, 32, 5, 24, 1.0)["field"]
             assert np.array_equal(export_scene.read_pfm(exp / "solution.pfm"), final)      # spp restored afterwards
+            # frames_time/<elapsed ms>.png: samples 0 and 4; the later one is the solution after 5 samples
+            names = sorted(os.listdir(exp / "frames_time"), key=lambda n_: int(n_.split(".")[0]))
+            assert len(names) in (2, 4) and all(n_.split(".")[0].isdigit() for n_ in names)
+            last = _read_png(exp / "frames_time" / [n_ for n_ in names if n_.endswith(".png")][-1])
+            assert np.array_equal(last[::-1, :, :3].reshape(-1, 3), np.clip((final * np.float32(255)).astype(np.int32), 0, 255))
         else:
             assert len(os.listdir(exp / "frames_time")) in (2, 4)      # samples 0 and 4 (.exr + .png; names are elapsed ms)
 
