@@ -140,7 +140,7 @@ EXPORTS = [
     "wost_closest_silhouette", "wost_ray_intersect", "wost_set_option", "wost_destroy",
     "wost_vonmises_eval", "wost_vonmises_sample", "wost_vmm_pdf_sample", "wost_vmm_loss_gradients",
     "wost_net_create", "wost_net_destroy", "wost_net_n_params", "wost_net_get_params",
-    "wost_net_set_params", "wost_net_set_gradient_buffer", "wost_net_inference", "wost_net_train_step",
+    "wost_net_set_params", "wost_net_set_gradient_buffer", "wost_net_inference", "wost_net_train_step", "wost_net_set_option",
     "wost_guided_create", "wost_guided_set_sync", "wost_guided_set_frame_callback", "wost_guided_network", "wost_guided_scene", "wost_guided_query_network", "wost_guided_solve", "wost_guided_solve_sharded", "wost_guided_train_set", "wost_guided_destroy",
     "wost3_create", "wost3_solve", "wost3_solve_sharded", "wost3_closest_point", "wost3_closest_silhouette", "wost3_ray_intersect",
     "wost3_destroy",
@@ -193,6 +193,7 @@ def load():
     L.wost_net_get_params.argtypes = [C.c_void_p, C.c_int, fp]
     L.wost_net_set_params.argtypes = [C.c_void_p, fp]
     L.wost_net_inference.argtypes = [C.c_void_p, fp, C.c_int32, fp, C.c_int]
+    L.wost_net_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.wost_net_train_step.argtypes = [C.c_void_p, fp, fp, C.c_int32, C.c_float, C.c_int]
     L.wost_guided_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(GuidedSettings), C.POINTER(NetConfig), C.c_uint64,
                                      C.c_int, C.POINTER(C.c_void_p)]

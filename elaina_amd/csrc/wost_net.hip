@@ -399,6 +399,147 @@ __global__ __launch_bounds__(NT) void net_forward_mfma_kernel(NetLayout L, const
     }
 }
 
+// ---- half-precision inference (the reference's own arithmetic) ---------------------------------------
+// tiny-cuda-nn runs the guiding network in half precision (FullyFusedMLP on tensor cores, the grid
+// stored in half: util/network.h:21-196, data/ladybug/n.json:49-81).  This is that mode for the
+// inference launches of the guided walk: grid values rounded to f16, bilinear interpolation in
+// fp32, activations and weights in f16, v_mfma_f32_16x16x16_f16 with fp32 accumulation (16x the
+// matrix rate of the fp32 MFMA), ReLU, f16 again between layers, fp32 outputs.  NOT bit-comparable
+// with the fp32 path or the oracle -- gated by the tolerance tests of tests/test_guided_network.py;
+// fp32 stays the default.  Layout: lane (i, g) of a wave supplies B[k = 16 kt + 4g + c][point i]
+// and receives D[r = 16 rt + 4g + c][point i], so the accumulators of row tile rt ARE the B
+// operand of k-tile kt = rt of the next layer, and lane (i, g) encodes exactly the grid levels
+// g and g + 4 of its point: nothing is exchanged between lanes.
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+constexpr int kHalfSub = 4;       // 16-point groups per wave iteration
+constexpr int kHalfThreads = 256;
+
+// fragh[(w_off[layer] / 4) + (rt * KT + kt) * 64 + lane] = W[16 rt + i][16 kt + 4g .. 4g + 3], KT = n_i / 16
+__global__ void fragment_mlp_h_kernel(NetLayout L, const float *src, uint2 *dst)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L.n_mlp / 4) return;
+    int layer = 0;
+    while (layer < L.n_hidden && 4 * e >= L.w_off[layer + 1]) ++layer;
+    const int n_i = layer == 0 ? L.enc : L.n_neurons;
+    const int KT = n_i / 16;
+    const uint32_t f = e - L.w_off[layer] / 4, l = f & 63u, t = f >> 6;
+    const uint32_t rt = t / KT, kt = t % KT, i = l & 15u, g = l >> 4;
+    const float *w = src + L.w_off[layer] + (size_t)(16 * rt + i) * n_i + 16 * kt + 4 * g;
+    union { h4_t h; uint2 u; } v;
+    v.h = h4_t{(_Float16)w[0], (_Float16)w[1], (_Float16)w[2], (_Float16)w[3]};
+    dst[e] = v.u;
+}
+
+template <int KT, int RT>
+__device__ __forceinline__ void mfma_layer_h(const uint2 *wf, int lane, const h4_t (&b)[kHalfSub][4], f32x4_t (&acc)[kHalfSub][4])
+{
+#pragma unroll
+    for (int u = 0; u < kHalfSub; ++u)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[u][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            union { uint2 u; h4_t h; } a;
+            a.u = wf[(rt * KT + kt) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < kHalfSub; ++u) acc[u][rt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, b[u][kt], acc[u][rt], 0, 0, 0);
+        }
+}
+
+// the reference's network shape only: 8 levels x 4 features -> 64 -> 64 -> 64 -> 48 (33 used)
+__global__ __launch_bounds__(kHalfThreads) void net_forward_h_kernel(NetLayout L, const float *params, const uint2 *fragh, const float *xy, int n,
+                                                                       const uint32_t *n_dev, float *out, size_t out_ldp, size_t out_ldf)
+{
+    extern __shared__ uint2 lds_h[];
+    __shared__ float s_scale[kNetMaxLevels];
+    __shared__ uint32_t s_res[kNetMaxLevels], s_off[kNetMaxLevels + 1];
+    for (uint32_t e = threadIdx.x; e < L.n_mlp / 4; e += kHalfThreads) lds_h[e] = fragh[e];
+    if (threadIdx.x <= (unsigned)L.n_levels) {
+        s_off[threadIdx.x] = L.level_off[threadIdx.x];
+        if (threadIdx.x < (unsigned)L.n_levels) {
+            s_scale[threadIdx.x] = L.scale[threadIdx.x];
+            s_res[threadIdx.x] = (uint32_t)L.res[threadIdx.x];
+        }
+    }
+    __syncthreads();
+    if (n_dev) n = (int)*n_dev;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int n_tiles = (n + 16 * kHalfSub - 1) / (16 * kHalfSub);
+    const float *grid = params + L.n_mlp;
+    const uint2 *w0 = lds_h + L.w_off[0] / 4, *w1 = lds_h + L.w_off[1] / 4, *w2 = lds_h + L.w_off[2] / 4, *w3 = lds_h + L.w_off[3] / 4;
+    for (int tile = blockIdx.x * (kHalfThreads / 64) + wave; tile < n_tiles; tile += gridDim.x * (kHalfThreads / 64)) {
+        int pt[kHalfSub];
+        bool valid[kHalfSub];
+        h4_t b[kHalfSub][4];
+#pragma unroll
+        for (int u = 0; u < kHalfSub; ++u) {
+            pt[u] = (tile * kHalfSub + u) * 16 + i;
+            valid[u] = pt[u] < n;
+            const float x = valid[u] ? xy[2 * (size_t)pt[u]] : 0.5f, y = valid[u] ? xy[2 * (size_t)pt[u] + 1] : 0.5f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int lv = g + 4 * h;
+                const float sc = s_scale[lv];
+                const uint32_t res = s_res[lv], lo = s_off[lv];
+                const uint32_t n_level = s_off[lv + 1] - lo;
+                float px = __builtin_fmaf(sc, x, 0.5f), py = __builtin_fmaf(sc, y, 0.5f);
+                const float fx = floorf(px), fy = floorf(py);
+                px -= fx;
+                py -= fy;
+                const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+                float4 c[4];
+                float w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
+                    w[k] = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
+                    uint32_t idx = cx + cy * res;
+                    if (idx >= n_level) {
+                        idx -= n_level;
+                        if (idx >= n_level) idx %= n_level;
+                    }
+                    c[k] = *reinterpret_cast<const float4 *>(grid + (size_t)(lo + idx) * 4);
+                }
+                float4 f = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // the grid as the half-precision network holds it
+                    f.x += w[k] * (float)(_Float16)c[k].x; f.y += w[k] * (float)(_Float16)c[k].y;
+                    f.z += w[k] * (float)(_Float16)c[k].z; f.w += w[k] * (float)(_Float16)c[k].w;
+                }
+                b[u][h] = h4_t{(_Float16)f.x, (_Float16)f.y, (_Float16)f.z, (_Float16)f.w};
+            }
+        }
+        f32x4_t acc[kHalfSub][4];
+        // ---- hidden layers: ReLU, the accumulators of row tile rt become the B operand of k-tile rt
+#pragma unroll
+        for (int layer = 0; layer < 3; ++layer) {
+            if (layer == 0) mfma_layer_h<2, 4>(w0, lane, b, acc);
+            else mfma_layer_h<4, 4>(layer == 1 ? w1 : w2, lane, b, acc);
+#pragma unroll
+            for (int u = 0; u < kHalfSub; ++u)
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+                    b[u][rt] = h4_t{(_Float16)fmaxf(acc[u][rt][0], 0.0f), (_Float16)fmaxf(acc[u][rt][1], 0.0f),
+                                    (_Float16)fmaxf(acc[u][rt][2], 0.0f), (_Float16)fmaxf(acc[u][rt][3], 0.0f)};
+        }
+        mfma_layer_h<4, 3>(w3, lane, b, acc);
+#pragma unroll
+        for (int u = 0; u < kHalfSub; ++u)
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int o = 16 * rt + 4 * g + c;
+                    // the network's outputs are half-precision numbers in the reference
+                    if (valid[u] && o < L.n_out) out[(size_t)pt[u] * out_ldp + o * out_ldf] = (float)(_Float16)acc[u][rt][c];
+                }
+    }
+}
+
 // ---- MFMA backward ------------------------------------------------------------------------------
 // d_in[k][p] = relu'(h[k][p]) * sum_r W[r][k] d_out[r][p]: the same register-resident chain as the
 // forward pass, with A = tiles of W^T (rows = k, row-permuted like the forward fragments) and the
@@ -1112,6 +1253,8 @@ struct wost_net {
     float *params_f = nullptr, *inference_f = nullptr;   // MFMA A-fragment order (MFMA forward pass)
     float *params_fb = nullptr;                          // MFMA fragments of the transposed matrices (backward pass)
     bool use_mfma = false;
+    int precision = 32;              // 32 = fp32 everywhere (bit-exact mode, default), 16 = half-precision inference
+    uint2 *inference_h = nullptr;    // f16 MFMA fragments of the inference (EMA) weights, precision 16 only
     bool fused_backward = true;      // net_backward_wgrad_kernel (WOST_NET_FUSED=0: backward and weight gradients apart)
     int step = 0;
     uint32_t *param_steps = nullptr;   // Adam steps taken by each parameter (tiny-cuda-nn adam_step)
@@ -1140,6 +1283,8 @@ static int refresh_transposed(wost_net *h, hipStream_t stream)
         hipLaunchKernelGGL(fragment_mlp_kernel, dim3(g), dim3(256), 0, stream, h->L, h->inference, h->inference_f);
         hipLaunchKernelGGL(fragment_mlp_t_kernel, dim3(g), dim3(256), 0, stream, h->L, h->params, h->params_fb);
     }
+    if (h->precision == 16 && h->inference_h)
+        hipLaunchKernelGGL(fragment_mlp_h_kernel, dim3((h->L.n_mlp / 4 + 255) / 256), dim3(256), 0, stream, h->L, h->inference, h->inference_h);
     NET_TRY(hipGetLastError());
     return WOST_OK;
 }
@@ -1154,6 +1299,16 @@ static int launch_forward(wost_net *h, bool use_inference_params, const float *x
     // outputs: point-major rows of n_out floats, or (feature_stride > 0) one array per output
     const size_t ldp = feature_stride ? 1 : (size_t)L.n_out, ldf = feature_stride ? feature_stride : 1;
     const float *p = use_inference_params ? h->inference : h->params;
+    if (h->precision == 16 && use_inference_params && !acts_dev && h->inference_h) {
+        // half-precision inference (the reference's network precision); training stays fp32
+        const size_t lds = (size_t)L.n_mlp / 4 * sizeof(uint2);
+        const int n_tiles = (n + 16 * kHalfSub - 1) / (16 * kHalfSub);
+        const unsigned grid = (unsigned)std::min((n_tiles + kHalfThreads / 64 - 1) / (kHalfThreads / 64), 256 * 6);
+        hipLaunchKernelGGL(net_forward_h_kernel, dim3(grid), dim3(kHalfThreads), lds, stream, L, p, h->inference_h, xy_dev, n, n_dev, out_dev,
+                           ldp, ldf);
+        NET_TRY(hipGetLastError());
+        return WOST_OK;
+    }
     if (h->use_mfma) {
         const float *f = use_inference_params ? h->inference_f : h->params_f;
         // inference: one block of 16 waves per CU shares one copy of the weight fragments (53 KB,
@@ -1215,6 +1370,7 @@ static void net_free(wost_net *h)
     if (h->d_mask) (void)hipFree(h->d_mask);
     if (h->param_steps) (void)hipFree(h->param_steps);
     if (h->lr_table) (void)hipFree(h->lr_table);
+    if (h->inference_h) (void)hipFree(h->inference_h);
     delete h;
 }
 
@@ -1356,6 +1512,8 @@ int net_apply_update_dev(wost_net *h, float loss_scale, hipStream_t stream)
     hipLaunchKernelGGL(optimizer_kernel, dim3((h->n_params + 255) / 256), dim3(256), 0, stream, h->L, h->n_params, h->params, h->m1,
                        h->m2, h->ema_raw, h->inference, h->grad, h->lr_table, h->param_steps, c.beta1, c.beta2, c.epsilon,
                        c.l2_reg, c.ema_decay, debias, loss_scale, h->grad_div, D);
+    if (h->precision == 16 && h->inference_h)
+        hipLaunchKernelGGL(fragment_mlp_h_kernel, dim3((h->L.n_mlp / 4 + 255) / 256), dim3(256), 0, stream, h->L, h->inference, h->inference_h);
     NET_TRY(hipGetLastError());
     return WOST_OK;
 }
@@ -1506,6 +1664,30 @@ int wost_net_set_params(wost_net_handle h, const float *host)
     if (rc != WOST_OK) return rc;
     NET_TRY(hipDeviceSynchronize());
     return WOST_OK;
+}
+
+int wost_net_set_option(wost_net_handle h, const char *key, double value)
+{
+    if (!h || !key) return set_error(WOST_ERR_INVALID, "null argument");
+    const std::string k(key);
+    if (k == "precision") {
+        if (value != 16 && value != 32) return set_error(WOST_ERR_INVALID, "precision must be 32 (fp32, default) or 16 (half-precision inference)");
+        if (value == 16) {
+            const NetLayout &L = h->L;
+            if (!(L.enc == 32 && L.n_neurons == 64 && L.n_hidden == 3 && L.n_out_padded == 48 && L.n_features == 4 && L.n_levels == 8))
+                return set_error(WOST_ERR_UNSUPPORTED, "half-precision inference is built for the reference's network shape only");
+            NET_TRY(hipSetDevice(h->device));
+            if (!h->inference_h) NET_TRY(hipMalloc((void **)&h->inference_h, (size_t)L.n_mlp / 4 * sizeof(uint2)));
+            h->precision = 16;
+            hipLaunchKernelGGL(fragment_mlp_h_kernel, dim3((L.n_mlp / 4 + 255) / 256), dim3(256), 0, nullptr, L, h->inference, h->inference_h);
+            NET_TRY(hipGetLastError());
+            NET_TRY(hipDeviceSynchronize());
+        } else {
+            h->precision = 32;
+        }
+        return WOST_OK;
+    }
+    return set_error(WOST_ERR_INVALID, "unknown option: " + k);
 }
 
 int wost_net_inference(wost_net_handle h, const float *xy, int32_t n, float *out, int use_inference_params)

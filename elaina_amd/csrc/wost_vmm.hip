@@ -89,9 +89,9 @@ __global__ void vmm_loss_gradients_kernel(const float *raw, const float *dir, co
         kap[k] = det_expf(fmaxf(fminf(rawv[4 * k + 1], 15.0f), -10.0f));
         ox[k] = rawv[4 * k + 2];
         oy[k] = rawv[4 * k + 3];
-        const float nn = sqrtf(ox[k] * ox[k] + oy[k] * oy[k]);
-        mux[k] = ox[k] / nn;
-        muy[k] = oy[k] / nn;
+        const float z = ox[k] * ox[k] + oy[k] * oy[k], nn = sqrtf(z);
+        mux[k] = z > 0.0f ? ox[k] / nn : ox[k];      // Eigen normalized(): a zero vector stays zero
+        muy[k] = z > 0.0f ? oy[k] / nn : oy[k];
         total += lambda[k];
     }
 #pragma unroll

@@ -145,10 +145,13 @@ struct Vmm {
         for (int k = 0; k < 8; ++k) {
             lambda[k] = det_expf(fmaxf(fminf(d(4 * k), 15.0f), -10.0f));
             kap[k] = det_expf(fmaxf(fminf(d(4 * k + 1), 15.0f), -10.0f));
+            // Eigen's normalized() (Eigen/src/Core/Dot.h, the library behind mu_original.normalized(),
+            // distribution.h:160): v / sqrt(z) when z = |v|^2 > 0, else v unchanged -- a zero vector
+            // stays zero instead of becoming NaN (half-precision outputs do underflow to exact zeros)
             const float x = d(4 * k + 2), y = d(4 * k + 3);
-            const float nn = sqrtf(x * x + y * y);
-            mux[k] = x / nn;
-            muy[k] = y / nn;
+            const float z = x * x + y * y, nn = sqrtf(z);
+            mux[k] = z > 0.0f ? x / nn : x;
+            muy[k] = z > 0.0f ? y / nn : y;
             total += lambda[k];
             lb[k] = log_bessel(kap[k], 0);
         }
@@ -203,8 +206,8 @@ struct Vmm {
         float vx, vy;
         det_sincosf(theta, &vx, &vy);
         float px = -pmy, py = pmx;   // frameFromTangent(mu): N = normalize(-mu.y, mu.x), T = mu
-        const float pl = sqrtf(px * px + py * py);
-        px /= pl; py /= pl;
+        const float pz = px * px + py * py, pl = sqrtf(pz);
+        if (pz > 0.0f) { px /= pl; py /= pl; }      // Eigen normalized(): a zero vector stays zero
         ox = pmx * vx + px * vy;
         oy = pmy * vx + py * vy;
     }

@@ -112,6 +112,10 @@ class GuidingNetwork:
             raise ValueError("expected %d parameters" % self.n_params)
         _check(self._lib.wost_net_set_params(self._h, _fp(p)), "wost_net_set_params")
 
+    def set_option(self, key, value):
+        """"precision": 32 (fp32, bit-exact mode, default) or 16 (the reference's half-precision inference)"""
+        _check(self._lib.wost_net_set_option(self._h, key.encode(), float(value)), "wost_net_set_option")
+
     def inference(self, xy, use_inference_params=True):
         x = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
         out = np.zeros((len(x), self.config.n_output), dtype=np.float32)

@@ -216,6 +216,11 @@ int wost_net_set_params(wost_net_handle h, const float *host);
 /* network->inference (integrator/guided/integrator.cu:560,597; util/network.h:39-47): xy[n*2] in [0,1]^2 -> out[n*n_output];
  * use_inference_params = 1 evaluates the EMA weights (what rendering uses), 0 the training ones. */
 int wost_net_inference(wost_net_handle h, const float *xy, int32_t n, float *out, int use_inference_params);
+/* "precision": 32 (default) = fp32 everywhere, bit-exact against the CPU restatement; 16 = the reference's own
+ * network precision for inference (tiny-cuda-nn FullyFusedMLP + grid in half, util/network.h:21-196,
+ * data/ladybug/n.json:61-67): f16 weights / activations / grid values, fp32 accumulation on
+ * v_mfma_f32_16x16x16_f16.  Training keeps fp32 master weights and fp32 arithmetic in both modes. */
+int wost_net_set_option(wost_net_handle h, const char *key, double value);
 /* One training step (integrator/guided/integrator.cu:655-662: network->forward, ->backward,
  * trainer->optimizer_step(TRAIN_LOSS_SCALE)): forward with the training parameters, backward of
  * sum_p <dl_dout[p], out[p]>, then (apply_update != 0) one Adam+EMA step on gradient/loss_scale. */

@@ -141,8 +141,10 @@ void wo_vmm_build(wv_vmm *m, const float *data)
         m->sg[i].lambda = wo_expf(clampf(d[0], -10.0f, 15.0f));   /* train.h:60-72, Exponential */
         m->sg[i].kappa = wo_expf(clampf(d[1], -10.0f, 15.0f));
         m->sg[i].ox = d[2]; m->sg[i].oy = d[3];                 /* None */
-        float n = sqrtf(d[2] * d[2] + d[3] * d[3]);
-        m->sg[i].mux = d[2] / n; m->sg[i].muy = d[3] / n;
+        /* Eigen normalized() (Eigen/src/Core/Dot.h; ext/eigen is an empty submodule, .gitmodules): v / sqrt(z)
+         * when z = squaredNorm > 0, else v unchanged */
+        const float z = d[2] * d[2] + d[3] * d[3], n = sqrtf(z);
+        m->sg[i].mux = z > 0.0f ? d[2] / n : d[2]; m->sg[i].muy = z > 0.0f ? d[3] / n : d[3];
         m->total += m->sg[i].lambda;
     }
     for (int i = 0; i < WV_NCOMP; ++i) m->weight[i] = m->sg[i].lambda / m->total;
@@ -163,8 +165,8 @@ static void lobe_sample(const wv_lobe *l, wo_pcg *rng, float *ox, float *oy)
     wo_sincosf(theta, &vx, &vy);
     /* frameFromTangent(mu): N = normalize(-mu.y, mu.x), T = mu; world = T*v.x + N*v.y */
     float px = -l->muy, py = l->mux;
-    float pl = sqrtf(px * px + py * py);
-    px /= pl; py /= pl;
+    const float pz = px * px + py * py, pl = sqrtf(pz);
+    if (pz > 0.0f) { px /= pl; py /= pl; }             /* Eigen normalized(): a zero vector stays zero */
     *ox = l->mux * vx + px * vy;
     *oy = l->muy * vx + py * vy;
 }

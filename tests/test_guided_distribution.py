@@ -67,6 +67,18 @@ def test_vmm_pdf_integrates_to_one(oracle):
         assert pdf.sum() * (2 * np.pi / 4096) == pytest.approx(1.0, abs=2e-3)
 
 
+def test_vmm_with_a_zero_mean_vector_stays_finite(oracle):
+    """mu_original.normalized() is Eigen's normalized(): a zero vector is returned unchanged, not divided by its
+    zero norm (distribution.h:160).  Half-precision network outputs do underflow to exact zeros."""
+    rng = np.random.default_rng(1)
+    raw, wi = _random_vmm(rng, 64)
+    raw[:, 2:32:4] = 0.0          # mu.x of every lobe
+    raw[:, 3:32:4] = 0.0          # mu.y
+    pdf, d = oracle.vmm_pdf_sample(raw, wi, np.arange(64, dtype=np.uint64))
+    assert np.isfinite(pdf).all() and np.isfinite(d).all() and (pdf > 0).all()
+    assert not d.any()            # a lobe without a direction samples the zero vector, as the reference's frame does
+
+
 def test_vmm_samples_follow_the_pdf(oracle):
     rng = np.random.default_rng(1)
     raw, _ = _random_vmm(rng, 1)
@@ -124,6 +136,11 @@ def test_hip_vmm_pdf_and_sample_match_oracle(oracle):
     assert np.allclose(gp, rp, rtol=1e-4, atol=1e-7)     # 1e-4 agreement of the VMM sub-kernels
     close = np.isclose(gd, rd, rtol=0, atol=1e-5).all(1)
     assert close.mean() > 0.999, close.mean()
+    raw[:100, 2:32:4] = 0.0       # zero mean vectors (Eigen normalized(): left as they are): finite on both sides
+    raw[:100, 3:32:4] = 0.0
+    gp, gd = guided.vmm_pdf_sample(raw[:100], wi[:100], seed[:100])
+    rp, rd = oracle.vmm_pdf_sample(raw[:100], wi[:100], seed[:100])
+    assert np.isfinite(gp).all() and np.allclose(gp, rp, rtol=1e-4, atol=1e-7) and np.array_equal(gd, rd) and not gd.any()
 
 
 def _random_training_batch(rng, n):

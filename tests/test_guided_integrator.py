@@ -620,3 +620,36 @@ def test_gpu_train_pixel_offset_is_drawn_like_the_reference(oracle):
         assert gi.last_stats["train_samples"] == ref["train_samples"] and gi.last_stats["optimizer_steps"] == ref["optimizer_steps"] > 0
         assert np.array_equal(gi.solution, ref["field"])
     gi.close()
+
+
+@pytest.mark.gpu
+def test_gpu_half_precision_network_mode_is_unbiased_and_no_noisier(oracle):
+    """The reference evaluates its guiding network in half precision.  With precision 16 the guided walk
+    samples from a slightly different (but valid, normalised) mixture: the estimator stays unbiased -- its
+    field agrees with the analytic solution as well as the fp32-mode field does -- the variance is not
+    worse, and the solve is reproducible bit for bit.  fp32 remains the default, bit-exact mode."""
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    prob = laplace_box()
+    w = h = 64
+    spp = 48
+    exact = eval_ys(prob, w, h).reshape(-1)
+    fields = {}
+    for prec in (32, 16, 16):
+        st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=24, maxWalkingDepth=48, epsilonShell=EPS,
+                                      batchSize=4096, minBatchSize=1024)
+        gi = GuidedIntegrator(prob, st, AABB, seed=3)
+        if prec == 16:
+            gi.network.set_option("precision", 16)
+        gi.solve()
+        assert gi.last_stats["optimizer_steps"] > 0 and gi.last_stats["guided_steps"] > 0
+        fields.setdefault(prec, []).append((gi.solution[:, 0].copy(), gi.network.params()))
+        gi.close()
+    f32 = fields[32][0][0]
+    (h1, p1), (h2, p2) = fields[16]
+    assert np.isfinite(h1).all() and np.isfinite(f32).all()
+    assert np.array_equal(h1, h2) and np.array_equal(p1, p2)                 # reproducible
+    assert not np.array_equal(h1, f32)                                         # a different (half-precision) sampler
+    e32, e16 = f32 - exact, h1 - exact
+    assert abs(float(e16.mean())) < 4e-3 and abs(float(e32.mean())) < 4e-3     # both unbiased
+    r32, r16 = float(np.sqrt((e32 ** 2).mean())), float(np.sqrt((e16 ** 2).mean()))
+    assert r16 < 1.15 * r32, (r16, r32)                                        # variance not worse (same spp)

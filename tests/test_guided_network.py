@@ -300,3 +300,78 @@ def test_gpu_network_learns_a_field(net):
     last = float(np.mean((n.inference(test_xy) - target(test_xy)) ** 2))
     n.close()
     assert first > 0.3 and last < 0.1 * first, (first, last)
+
+
+# ---- half-precision inference (the reference's network precision) -----------------------------
+def _half_network_numpy(orc, cfg, p, xy):
+    """The half-precision network written out in numpy: grid values rounded to f16, the oracle's fp32
+    bilinear interpolation, then per layer f16 inputs and weights, fp32 accumulation, ReLU, f16."""
+    n_mlp = 64 * 32 + 2 * 64 * 64 + 48 * 64
+    ph = p.copy()
+    ph[n_mlp:] = p[n_mlp:].astype(np.float16).astype(np.float32)
+    enc = orc.net_forward(cfg, ph, xy, want_acts=True)[1][:, :32]
+    a = enc.astype(np.float16).astype(np.float32)
+    off = 0
+    for no, ni, relu in [(64, 32, True), (64, 64, True), (64, 64, True), (48, 64, False)]:
+        w = p[off:off + no * ni].reshape(no, ni).astype(np.float16).astype(np.float32)
+        off += no * ni
+        z = (a.astype(np.float64) @ w.T.astype(np.float64)).astype(np.float32)       # products of f16 numbers are exact in fp32
+        a = (np.maximum(z, 0.0) if relu else z).astype(np.float16).astype(np.float32)
+    return a[:, :33]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [7, 64, 8192 + 5])
+def test_gpu_half_precision_inference(orc, n):
+    """precision 16 = the arithmetic the reference's tiny-cuda-nn network runs in (half weights, activations
+    and grid, fp32 accumulation).  Gate 1: it IS that network -- equal to the numpy emulation up to the
+    summation order inside the matrix instruction (a few f16 ulps).  Gate 2: it stays close to the fp32
+    network (relative error of the raw outputs around 1e-3, the half-precision mantissa)."""
+    from elaina_amd.guided import GuidingNetwork
+    cfg = default_net_config()
+    net = GuidingNetwork(seed=7)
+    try:
+        p = _rand_params(orc, cfg, seed=31, wscale=0.2, gscale=0.4)
+        net.set_params(p)
+        rng = np.random.default_rng(n)
+        xy = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+        fp32 = net.inference(xy)
+        assert np.array_equal(fp32, orc.net_forward(cfg, p, xy)[0][:, :33])
+        net.set_option("precision", 16)
+        half = net.inference(xy)
+        emu = _half_network_numpy(orc, cfg, p, xy)
+        scale = float(np.sqrt(np.mean(fp32 ** 2)))
+        assert np.abs(half - emu).max() <= 4e-3 * scale, (float(np.abs(half - emu).max()), scale)
+        assert np.mean(half == emu) > 0.9                                  # most outputs agree to the last f16 bit
+        rel = float(np.sqrt(np.mean((half - fp32) ** 2))) / scale
+        assert rel < 5e-3, rel
+        assert np.array_equal(half, half.astype(np.float16).astype(np.float32))     # outputs are half-precision numbers
+        # training parameters are never evaluated in half precision; fp32 mode comes back bit for bit
+        assert np.array_equal(net.inference(xy, use_inference_params=False), fp32)
+        net.set_option("precision", 32)
+        assert np.array_equal(net.inference(xy), fp32)
+    finally:
+        net.close()
+
+
+@pytest.mark.gpu
+def test_gpu_half_precision_follows_the_optimizer(orc):
+    """the f16 fragments are refreshed after every Adam / EMA step: inference in half precision tracks the
+    fp32 inference weights through training"""
+    from elaina_amd.guided import GuidingNetwork
+    cfg = default_net_config()
+    net = GuidingNetwork(seed=5)
+    try:
+        net.set_option("precision", 16)
+        rng = np.random.default_rng(2)
+        xy = rng.uniform(0, 1, (4096, 2)).astype(np.float32)
+        test = rng.uniform(0, 1, (512, 2)).astype(np.float32)
+        for _ in range(20):
+            pred = net.inference(xy, use_inference_params=False)
+            net.train_step(xy, (2.0 * (pred - 0.5) / pred.size * 128.0).astype(np.float32), loss_scale=128.0)
+        half = net.inference(test)
+        emu = _half_network_numpy(orc, cfg, net.inference_params(), test)
+        scale = float(np.sqrt(np.mean(emu ** 2))) + 1e-6
+        assert np.abs(half - emu).max() <= 4e-3 * scale
+    finally:
+        net.close()
