@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 BYTES_PER_STEP = 98.0      # 37 B item read + 37 B successor + 16 B PCG read + 8 B PCG write
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+MFMA_F16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 matrix peak (~2.5 PF)
 FLOP_PER_POINT = 26624.0   # 2 * (32*64 + 64*64 + 64*64 + 64*48) per network evaluation
 GUIDED_AABB = ((-100.0, -100.0), (600.0, 600.0))   # scene.aabb of data/*/n.json
 
@@ -57,6 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--train-spp", type=int, default=-1)
     ap.add_argument("--depth", type=int, default=0, help="0 = the scene's maxWalkingDepth")
     ap.add_argument("--shared-network", action="store_true", help="guided, N > 1: one network for all ranks")
+    ap.add_argument("--net-precision", type=int, default=32, choices=[32, 16],
+                    help="guided: 32 = fp32 network (bit-exact mode, default), 16 = the reference's half-precision inference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the selected config (no \"configs\" object)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
@@ -196,11 +199,13 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
     env.barrier()
     t0 = time.perf_counter()
     steps_local, kernel_ms, launches = 0, 0.0, 0
+    sched = {"visits": 0, "trav_trips": 0, "step_trips": 0}
     for _ in range(steps):
         st = one_pass(it)
         steps_local += st["walk_steps"]
         kernel_ms += st["kernel_ms"]
         launches += st["kernel_launches"]
+        sched["visits"] += st["inner_visits"]; sched["trav_trips"] += st["trav_trips"]; sched["step_trips"] += st["step_trips"]
     torch.cuda.synchronize()
     env.barrier()
     elapsed = time.perf_counter() - t0
@@ -222,11 +227,19 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
     }
     if t1:
         out["time_to_1spp_ms"] = {"cold": t1[0], "steady": sorted(t1[1:])[len(t1[1:]) // 2]}
+    if sched["trav_trips"] and steps_local:
+        # wave-level scheduler of walk_round_kernel on this rank: node visits per walk step, and how full the
+        # two bodies run (a traversal trip is up to trav_burst = 3 visits of every traversing lane)
+        out["scheduler"] = {"visits_per_step": sched["visits"] / steps_local,
+                            "trav_lane_fill": sched["visits"] / (sched["trav_trips"] * 3.0 * 64.0),
+                            "step_lane_fill": steps_local / (sched["step_trips"] * 64.0),
+                            "trav_trips_per_wave_step": sched["trav_trips"] * 64.0 / steps_local,
+                            "step_trips_per_wave_step": sched["step_trips"] * 64.0 / steps_local}
     res = {"out": out, "field": field, "problem": problem, "depth": depth, "eps": eps, "it": it}
     return res
 
 
-def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args):
+def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, precision=None):
     """timed solves of the guided integrator (training included: it is part of the path)"""
     torch = env.torch
     from elaina_amd import Problem
@@ -243,6 +256,8 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args):
         gi = GuidedIntegrator(problem, st, GUIDED_AABB, device=env.local)
         if args.shared_network and env.world > 1:
             gi.share_network()
+        if (precision or args.net_precision) == 16:
+            gi.network.set_option("precision", 16)
         field.zero_()
         env.barrier()
         t0 = time.perf_counter()
@@ -267,6 +282,8 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args):
     train_s, infer_s, solve_s = float(mx[1]) / 1e3, float(mx[2]) / 1e3, float(mx[3]) / 1e3
     walk_s = max(elapsed - train_s, 1e-9)
     infer_tf = (net_points / max(env.world, 1)) * FLOP_PER_POINT / max(infer_s, 1e-9) / 1e12 if infer_s > 0 else None
+    half = (precision or args.net_precision) == 16
+    peak_tf = MFMA_F16_PEAK_TF if half else MFMA_F32_PEAK_TF
     out = {
         "workload": "%s guided %dx%d grid %d spp (train %d) depth %d eps %g" % (scene, frame, frame, spp, min(train_spp, spp), depth, eps),
         "value": walk_steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "walk_steps_per_pass": walk_steps / steps,
@@ -274,9 +291,10 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args):
         "guided_steps_per_pass": guided_steps / steps, "optimizer_steps_per_pass": opt_steps / steps,
         "train_samples_per_pass": train_samples / steps, "kernel_launches_per_pass": launches / steps / max(env.world, 1),
         "shared_network": bool(args.shared_network and env.world > 1),
-        "roofline_mfma": {"bound": "mfma", "kernel": "net_forward_mfma_kernel (inference launches, HIP events)",
-                          "achieved": infer_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                          "frac": (infer_tf / MFMA_F32_PEAK_TF) if infer_tf else None,
+        "network_precision": "f16 inference (v_mfma_f32_16x16x16_f16), fp32 training" if half else "fp32 (v_mfma_f32_16x16x4_f32)",
+        "roofline_mfma": {"bound": "mfma", "kernel": ("net_forward_h_kernel" if half else "net_forward_mfma_kernel") + " (inference launches, HIP events)",
+                          "achieved": infer_tf, "peak": peak_tf, "unit": "TFLOP/s",
+                          "frac": (infer_tf / peak_tf) if infer_tf else None,
                           "flop_per_point": FLOP_PER_POINT, "points_per_pass": net_points / steps,
                           "kernel_s_per_pass": infer_s / steps},
     }
@@ -315,6 +333,8 @@ def main():
                                 "walk_steps_per_pass": o["walk_steps_per_pass"], "config": args.config}})
         if "time_to_1spp_ms" in o:
             line["time_to_1spp_ms"] = o["time_to_1spp_ms"]
+        if "scheduler" in o:
+            line["scheduler"] = o["scheduler"]
         roof = o["roofline"]
         if env.rank == 0:
             traffic = None
@@ -375,6 +395,12 @@ def main():
                 # (bit-exact against the oracle above) up to the Monte-Carlo noise of 256 spp
                 e4["rel_l2_vs_uniform_field"] = rel_l2(r4["field"].cpu().numpy(), uniform_field.cpu().numpy())
             extras["cfg4"] = e4
+            # the same configuration with the reference's half-precision inference (tolerance-gated mode)
+            r4h = run_guided(env, "ladybug", 1024, 256, 256, 0, 1, 0, args, precision=16)
+            e4h = r4h["out"]
+            if uniform_field is not None:
+                e4h["rel_l2_vs_uniform_field"] = rel_l2(r4h["field"].cpu().numpy(), uniform_field.cpu().numpy())
+            extras["cfg4_f16_inference"] = e4h
         else:
             r5 = run_guided(env, "ladybug", 2048, 1024, 256, 0, 1, 0, args)
             extras["cfg5"] = r5["out"]
