@@ -249,8 +249,14 @@ void read_png(const fs::path &path, int *width, int *height, std::vector<uint8_t
         if (pos + 12 + n > b.size()) throw std::runtime_error("png: truncated chunk");
         const uint8_t *d = &b[pos + 8];
         if (type == "IHDR") {
+            // the header must be the first chunk, exactly 13 bytes long, and describe a sane image
+            // before any size is computed from it (mask images are user input)
+            if (pos != 8 || n != 13) throw std::runtime_error("png: malformed IHDR chunk");
             w = be32(pos + 8); h = be32(pos + 12);
+            if (w == 0 || h == 0 || w > (1u << 16) || h > (1u << 16)) throw std::runtime_error("png: image dimensions out of range");
             depth = d[8]; ctype = d[9]; interlace = d[12];
+        } else if (pos == 8) {
+            throw std::runtime_error("png: the first chunk is not IHDR");
         } else if (type == "PLTE") plte.assign(d, d + n);
         else if (type == "tRNS") trns.assign(d, d + n);
         else if (type == "IDAT") idat.insert(idat.end(), d, d + n);

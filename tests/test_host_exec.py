@@ -258,6 +258,24 @@ def test_png_reader_and_mask_loading(tmp_path):
         assert np.array_equal(got, want), name
     bad = subprocess.run([exe, "--readpng", str(tmp_path / "missing.png"), str(tmp_path / "x.raw")], capture_output=True, text=True)
     assert bad.returncode == 1 and "cannot open" in bad.stderr
+    # malformed headers are refused before any size is computed from them: a short IHDR, an IHDR that
+    # is not the first chunk, absurd dimensions, a file cut inside a chunk
+    import struct
+    good = open(tmp_path / "rgb.png", "rb").read()
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    ihdr = good[16:29]
+    rest = good[33:]
+    for name, blob, msg in [
+        ("short_ihdr", good[:8] + chunk(b"IHDR", ihdr[:9]) + rest, "IHDR"),
+        ("late_ihdr", good[:8] + chunk(b"tEXt", b"a\0b") + chunk(b"IHDR", ihdr) + rest, "IHDR"),
+        ("huge", good[:8] + chunk(b"IHDR", struct.pack(">II", 1 << 30, 1 << 30) + ihdr[8:]) + rest, "dimensions"),
+        ("cut", good[:40], "png:"),
+    ]:
+        open(tmp_path / (name + ".png"), "wb").write(blob)
+        out = subprocess.run([exe, "--readpng", str(tmp_path / (name + ".png")), str(tmp_path / "x.raw")], capture_output=True, text=True)
+        assert out.returncode == 1 and msg in out.stderr, (name, out.stderr)
 
 
 @pytest.mark.gpu
