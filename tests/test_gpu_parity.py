@@ -483,3 +483,21 @@ def test_full_size_properties_config2(ladybug):
         total += buf
     it.close()
     assert np.array_equal(total.cpu().numpy().reshape(-1, 3), a)
+
+
+def test_full_size_config3_fille_band_and_properties(oracle, fille):
+    """BASELINE config 3 at its full size (fille, 1024^2, 256 spp, depth 128: mixed boundary, one LBVH level
+    deeper than ladybug) through the default round kernel: an 8-row band bit-exact against the oracle,
+    reproducibility, counter identities and the walk-step count every run must reproduce"""
+    from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+    it = UniformIntegrator(fille, UniformIntegratorSettings((1024, 1024), 256, 128, 1.0))
+    it.solve()
+    a, sa = it.solution.copy(), dict(it.last_stats)
+    it.solve()
+    assert np.array_equal(a, it.solution) and it.last_stats["walk_steps"] == sa["walk_steps"] == 2467318167
+    it.close()
+    assert sa["walks_started"] == 1024 * 1024 * 256 == sa["walks_absorbed"] + sa["walks_truncated"]
+    assert np.isfinite(a).all()
+    b, e = 508 * 1024, 516 * 1024
+    ref = oracle.solve(fille.as_dict(), 1024, 1024, 256, 128, 1.0, pixel_begin=b, pixel_end=e, threads=THREADS)
+    assert np.array_equal(a[b:e], ref["field"])
