@@ -59,7 +59,10 @@ def parse_args(argv=None):
     ap.add_argument("--depth", type=int, default=0, help="0 = the scene's maxWalkingDepth")
     ap.add_argument("--shared-network", action="store_true", help="guided, N > 1: one network for all ranks")
     ap.add_argument("--net-precision", type=int, default=32, choices=[32, 16],
-                    help="guided: 32 = fp32 network (bit-exact mode, default), 16 = the reference's half-precision inference")
+                    help="guided: 32 = fp32 network (bit-exact mode, default), 16 = the reference's half-precision network "
+                         "(inference and the training passes on f16 MFMAs; fp32 master weights)")
+    ap.add_argument("--net-train-precision", type=int, default=0, choices=[0, 32, 16],
+                    help="guided: precision of the training passes alone (0 = follow --net-precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the selected config (no \"configs\" object)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
@@ -258,6 +261,8 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
             gi.share_network()
         if (precision or args.net_precision) == 16:
             gi.network.set_option("precision", 16)
+        if (args.net_train_precision or precision or args.net_precision) == 16:
+            gi.network.set_option("train_precision", 16)
         field.zero_()
         env.barrier()
         t0 = time.perf_counter()
@@ -283,6 +288,7 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
     walk_s = max(elapsed - train_s, 1e-9)
     infer_tf = (net_points / max(env.world, 1)) * FLOP_PER_POINT / max(infer_s, 1e-9) / 1e12 if infer_s > 0 else None
     half = (precision or args.net_precision) == 16
+    half_train = (args.net_train_precision or precision or args.net_precision) == 16
     peak_tf = MFMA_F16_PEAK_TF if half else MFMA_F32_PEAK_TF
     out = {
         "workload": "%s guided %dx%d grid %d spp (train %d) depth %d eps %g" % (scene, frame, frame, spp, min(train_spp, spp), depth, eps),
@@ -291,7 +297,8 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
         "guided_steps_per_pass": guided_steps / steps, "optimizer_steps_per_pass": opt_steps / steps,
         "train_samples_per_pass": train_samples / steps, "kernel_launches_per_pass": launches / steps / max(env.world, 1),
         "shared_network": bool(args.shared_network and env.world > 1),
-        "network_precision": "f16 inference (v_mfma_f32_16x16x16_f16), fp32 training" if half else "fp32 (v_mfma_f32_16x16x4_f32)",
+        "network_precision": ("f16 inference (v_mfma_f32_16x16x16_f16), " if half else "fp32 inference (v_mfma_f32_16x16x4_f32), ") +
+                             ("f16 training passes, fp32 master weights" if half_train else "fp32 training"),
         "roofline_mfma": {"bound": "mfma", "kernel": ("net_forward_h_kernel" if half else "net_forward_mfma_kernel") + " (inference launches, HIP events)",
                           "achieved": infer_tf, "peak": peak_tf, "unit": "TFLOP/s",
                           "frac": (infer_tf / peak_tf) if infer_tf else None,
@@ -395,12 +402,12 @@ def main():
                 # (bit-exact against the oracle above) up to the Monte-Carlo noise of 256 spp
                 e4["rel_l2_vs_uniform_field"] = rel_l2(r4["field"].cpu().numpy(), uniform_field.cpu().numpy())
             extras["cfg4"] = e4
-            # the same configuration with the reference's half-precision inference (tolerance-gated mode)
+            # the same configuration with the reference's half-precision network (tolerance-gated mode)
             r4h = run_guided(env, "ladybug", 1024, 256, 256, 0, 1, 0, args, precision=16)
             e4h = r4h["out"]
             if uniform_field is not None:
                 e4h["rel_l2_vs_uniform_field"] = rel_l2(r4h["field"].cpu().numpy(), uniform_field.cpu().numpy())
-            extras["cfg4_f16_inference"] = e4h
+            extras["cfg4_f16"] = e4h
         else:
             r5 = run_guided(env, "ladybug", 2048, 1024, 256, 0, 1, 0, args)
             extras["cfg5"] = r5["out"]

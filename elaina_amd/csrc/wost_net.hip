@@ -411,14 +411,24 @@ __global__ __launch_bounds__(NT) void net_forward_mfma_kernel(NetLayout L, const
 // operand of k-tile kt = rt of the next layer, and lane (i, g) encodes exactly the grid levels
 // g and g + 4 of its point: nothing is exchanged between lanes.
 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-constexpr int kHalfSub = 4;       // 16-point groups per wave iteration
-constexpr int kHalfThreads = 256;
+constexpr int kHalfSub = 2;       // 16-point groups per wave iteration
+constexpr int kHalfThreads = 256;      // training kernel (wost_net_half.h): one wave per SIMD, the accumulators take the registers
+constexpr int kHalfFwdThreads = 1024;  // forward kernel: sixteen waves share the LDS image, four per SIMD hide each other's latencies
 
 // fragh[(w_off[layer] / 4) + (rt * KT + kt) * 64 + lane] = W[16 rt + i][16 kt + 4g .. 4g + 3], KT = n_i / 16
+// followed by the grid, entry by entry (4 features, 8 bytes): the image net_forward_h_kernel keeps in LDS
 __global__ void fragment_mlp_h_kernel(NetLayout L, const float *src, uint2 *dst)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= L.n_mlp / 4) return;
+    if (e >= L.n_mlp / 4) {
+        const uint32_t entry = e - L.n_mlp / 4;
+        if (entry >= L.level_off[L.n_levels]) return;
+        const float4 c = *reinterpret_cast<const float4 *>(src + L.n_mlp + (size_t)entry * 4);
+        union { h4_t h; uint2 u; } v;
+        v.h = h4_t{(_Float16)c.x, (_Float16)c.y, (_Float16)c.z, (_Float16)c.w};
+        dst[e] = v.u;
+        return;
+    }
     int layer = 0;
     while (layer < L.n_hidden && 4 * e >= L.w_off[layer + 1]) ++layer;
     const int n_i = layer == 0 ? L.enc : L.n_neurons;
@@ -450,13 +460,16 @@ __device__ __forceinline__ void mfma_layer_h(const uint2 *wf, int lane, const h4
 }
 
 // the reference's network shape only: 8 levels x 4 features -> 64 -> 64 -> 64 -> 48 (33 used)
-__global__ __launch_bounds__(kHalfThreads) void net_forward_h_kernel(NetLayout L, const float *params, const uint2 *fragh, const float *xy, int n,
-                                                                       const uint32_t *n_dev, float *out, size_t out_ldp, size_t out_ldf)
+__global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayout L, const float *params, const uint2 *fragh, const float *xy, int n,
+                                                                       const uint32_t *n_dev, float *out, size_t out_ldp, size_t out_ldf, uint2 *enc_out)
 {
     extern __shared__ uint2 lds_h[];
     __shared__ float s_scale[kNetMaxLevels];
     __shared__ uint32_t s_res[kNetMaxLevels], s_off[kNetMaxLevels + 1];
-    for (uint32_t e = threadIdx.x; e < L.n_mlp / 4; e += kHalfThreads) lds_h[e] = fragh[e];
+    // weights and the whole grid (15 384 entries x 8 bytes in half precision): 150 KB of the CU's 160 KB, one block per CU;
+    // every gather of the encoding is an LDS read
+    const uint32_t n_image = L.n_mlp / 4 + L.level_off[L.n_levels];
+    for (uint32_t e = threadIdx.x; e < n_image; e += kHalfFwdThreads) lds_h[e] = fragh[e];
     if (threadIdx.x <= (unsigned)L.n_levels) {
         s_off[threadIdx.x] = L.level_off[threadIdx.x];
         if (threadIdx.x < (unsigned)L.n_levels) {
@@ -468,9 +481,10 @@ __global__ __launch_bounds__(kHalfThreads) void net_forward_h_kernel(NetLayout L
     if (n_dev) n = (int)*n_dev;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int n_tiles = (n + 16 * kHalfSub - 1) / (16 * kHalfSub);
-    const float *grid = params + L.n_mlp;
+    const uint2 *grid = lds_h + L.n_mlp / 4;
     const uint2 *w0 = lds_h + L.w_off[0] / 4, *w1 = lds_h + L.w_off[1] / 4, *w2 = lds_h + L.w_off[2] / 4, *w3 = lds_h + L.w_off[3] / 4;
-    for (int tile = blockIdx.x * (kHalfThreads / 64) + wave; tile < n_tiles; tile += gridDim.x * (kHalfThreads / 64)) {
+    for (int tile = blockIdx.x * (kHalfFwdThreads / 64) + wave; tile < n_tiles; tile += gridDim.x * (kHalfFwdThreads / 64)) {
+        asm volatile("" ::: "memory");      // the weight fragments are re-read from LDS per tile, not parked in registers
         int pt[kHalfSub];
         bool valid[kHalfSub];
         h4_t b[kHalfSub][4];
@@ -490,7 +504,7 @@ __global__ __launch_bounds__(kHalfThreads) void net_forward_h_kernel(NetLayout L
                 px -= fx;
                 py -= fy;
                 const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
-                float4 c[4];
+                union { uint2 u; h4_t h; } c[4];
                 float w[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -501,16 +515,21 @@ __global__ __launch_bounds__(kHalfThreads) void net_forward_h_kernel(NetLayout L
                         idx -= n_level;
                         if (idx >= n_level) idx %= n_level;
                     }
-                    c[k] = *reinterpret_cast<const float4 *>(grid + (size_t)(lo + idx) * 4);
+                    c[k].u = grid[lo + idx];      // the grid as the half-precision network holds it
                 }
                 float4 f = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    // the grid as the half-precision network holds it
-                    f.x += w[k] * (float)(_Float16)c[k].x; f.y += w[k] * (float)(_Float16)c[k].y;
-                    f.z += w[k] * (float)(_Float16)c[k].z; f.w += w[k] * (float)(_Float16)c[k].w;
+                    f.x += w[k] * (float)c[k].h[0]; f.y += w[k] * (float)c[k].h[1];
+                    f.z += w[k] * (float)c[k].h[2]; f.w += w[k] * (float)c[k].h[3];
                 }
                 b[u][h] = h4_t{(_Float16)f.x, (_Float16)f.y, (_Float16)f.z, (_Float16)f.w};
+                if (enc_out) {
+                    // training: the encoding goes to the fused backward kernel as it stands (wost_net_half.h)
+                    union { h4_t h; uint2 u; } e;
+                    e.h = b[u][h];
+                    enc_out[((size_t)(tile * kHalfSub + u) * 2 + h) * 64 + lane] = e.u;
+                }
             }
         }
         f32x4_t acc[kHalfSub][4];
@@ -523,8 +542,8 @@ __global__ __launch_bounds__(kHalfThreads) void net_forward_h_kernel(NetLayout L
             for (int u = 0; u < kHalfSub; ++u)
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt)
-                    b[u][rt] = h4_t{(_Float16)fmaxf(acc[u][rt][0], 0.0f), (_Float16)fmaxf(acc[u][rt][1], 0.0f),
-                                    (_Float16)fmaxf(acc[u][rt][2], 0.0f), (_Float16)fmaxf(acc[u][rt][3], 0.0f)};
+                    b[u][rt] = __builtin_elementwise_max(__builtin_convertvector(acc[u][rt], h4_t),
+                                                         h4_t{(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f});
         }
         mfma_layer_h<4, 3>(w3, lane, b, acc);
 #pragma unroll
@@ -1239,6 +1258,8 @@ __global__ void optimizer_kernel(NetLayout L, uint32_t n, float *params, float *
 
 }  // namespace wost
 
+#include "wost_net_half.h"
+
 using namespace wost;
 
 struct wost_net {
@@ -1255,6 +1276,9 @@ struct wost_net {
     bool use_mfma = false;
     int precision = 32;              // 32 = fp32 everywhere (bit-exact mode, default), 16 = half-precision inference
     uint2 *inference_h = nullptr;    // f16 MFMA fragments of the inference (EMA) weights, precision 16 only
+    int train_precision = 32;        // 16 = forward / backward / weight gradients of a training step on f16 MFMAs (wost_net_half.h)
+    uint2 *params_h = nullptr, *params_hb = nullptr;   // f16 fragments of the training weights and of their transposes
+    float *train_partial = nullptr;                    // per-block sums of the matrix gradients (net_train_h_kernel), 256 rows
     bool fused_backward = true;      // net_backward_wgrad_kernel (WOST_NET_FUSED=0: backward and weight gradients apart)
     int step = 0;
     uint32_t *param_steps = nullptr;   // Adam steps taken by each parameter (tiny-cuda-nn adam_step)
@@ -1273,6 +1297,33 @@ struct wost_net {
         if (e_ != hipSuccess) return set_error(WOST_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// entries of the half-precision image of one parameter set: MFMA fragments of the matrices, then the grid
+static size_t half_image_entries(const NetLayout &L) { return (size_t)L.n_mlp / 4 + L.level_off[L.n_levels]; }
+
+static int launch_forward_h(wost_net *h, const float *p, const uint2 *image, const float *xy_dev, int n, const uint32_t *n_dev, float *out_dev,
+                            size_t ldp, size_t ldf, uint2 *enc_out, hipStream_t stream)
+{
+    const NetLayout &L = h->L;
+    const size_t lds = half_image_entries(L) * sizeof(uint2);
+    const int n_tiles = (n + 16 * kHalfSub - 1) / (16 * kHalfSub);
+    // one block per CU (the image takes 150 KB of LDS), walking over the tiles
+    const unsigned grid = (unsigned)std::max(1, std::min((n_tiles + kHalfFwdThreads / 64 - 1) / (kHalfFwdThreads / 64), 256));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(net_forward_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(net_forward_h_kernel, dim3(grid), dim3(kHalfFwdThreads), lds, stream, L, p, image, xy_dev, n, n_dev, out_dev, ldp, ldf, enc_out);
+    NET_TRY(hipGetLastError());
+    return WOST_OK;
+}
+
+static void refresh_half(wost_net *h, hipStream_t stream)
+{
+    const unsigned gh = (unsigned)((half_image_entries(h->L) + 255) / 256);
+    if (h->precision == 16 && h->inference_h) hipLaunchKernelGGL(fragment_mlp_h_kernel, dim3(gh), dim3(256), 0, stream, h->L, h->inference, h->inference_h);
+    if (h->train_precision == 16 && h->params_h) {
+        hipLaunchKernelGGL(fragment_mlp_h_kernel, dim3(gh), dim3(256), 0, stream, h->L, h->params, h->params_h);
+        hipLaunchKernelGGL(fragment_mlp_hb_kernel, dim3(gh), dim3(256), 0, stream, h->L, h->params, h->params_hb);
+    }
+}
+
 static int refresh_transposed(wost_net *h, hipStream_t stream)
 {
     const unsigned g = (h->L.n_mlp + 255) / 256;
@@ -1283,8 +1334,7 @@ static int refresh_transposed(wost_net *h, hipStream_t stream)
         hipLaunchKernelGGL(fragment_mlp_kernel, dim3(g), dim3(256), 0, stream, h->L, h->inference, h->inference_f);
         hipLaunchKernelGGL(fragment_mlp_t_kernel, dim3(g), dim3(256), 0, stream, h->L, h->params, h->params_fb);
     }
-    if (h->precision == 16 && h->inference_h)
-        hipLaunchKernelGGL(fragment_mlp_h_kernel, dim3((h->L.n_mlp / 4 + 255) / 256), dim3(256), 0, stream, h->L, h->inference, h->inference_h);
+    refresh_half(h, stream);
     NET_TRY(hipGetLastError());
     return WOST_OK;
 }
@@ -1300,14 +1350,8 @@ static int launch_forward(wost_net *h, bool use_inference_params, const float *x
     const size_t ldp = feature_stride ? 1 : (size_t)L.n_out, ldf = feature_stride ? feature_stride : 1;
     const float *p = use_inference_params ? h->inference : h->params;
     if (h->precision == 16 && use_inference_params && !acts_dev && h->inference_h) {
-        // half-precision inference (the reference's network precision); training stays fp32
-        const size_t lds = (size_t)L.n_mlp / 4 * sizeof(uint2);
-        const int n_tiles = (n + 16 * kHalfSub - 1) / (16 * kHalfSub);
-        const unsigned grid = (unsigned)std::min((n_tiles + kHalfThreads / 64 - 1) / (kHalfThreads / 64), 256 * 6);
-        hipLaunchKernelGGL(net_forward_h_kernel, dim3(grid), dim3(kHalfThreads), lds, stream, L, p, h->inference_h, xy_dev, n, n_dev, out_dev,
-                           ldp, ldf);
-        NET_TRY(hipGetLastError());
-        return WOST_OK;
+        // half-precision inference (the reference's network precision)
+        return launch_forward_h(h, p, h->inference_h, xy_dev, n, n_dev, out_dev, ldp, ldf, nullptr, stream);
     }
     if (h->use_mfma) {
         const float *f = use_inference_params ? h->inference_f : h->params_f;
@@ -1371,6 +1415,9 @@ static void net_free(wost_net *h)
     if (h->param_steps) (void)hipFree(h->param_steps);
     if (h->lr_table) (void)hipFree(h->lr_table);
     if (h->inference_h) (void)hipFree(h->inference_h);
+    if (h->params_h) (void)hipFree(h->params_h);
+    if (h->params_hb) (void)hipFree(h->params_hb);
+    if (h->train_partial) (void)hipFree(h->train_partial);
     delete h;
 }
 
@@ -1389,8 +1436,14 @@ int net_forward_train_dev(wost_net *h, const float *xy_dev, int n, hipStream_t s
 {
     int rc = ensure_points(h, (size_t)n);
     if (rc != WOST_OK) return rc;
-    rc = launch_forward(h, false, xy_dev, n, nullptr, h->d_out, h->d_acts, stream);
-    if (rc != WOST_OK) return rc;
+    if (h->train_precision == 16) {
+        // the inference kernel on the training weights; the f16 encoding of every point (64 bytes) is kept
+        rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, h->d_out, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream);
+        if (rc != WOST_OK) return rc;
+    } else {
+        rc = launch_forward(h, false, xy_dev, n, nullptr, h->d_out, h->d_acts, stream);
+        if (rc != WOST_OK) return rc;
+    }
     *out_dev = h->d_out;
     *dl_dev = h->d_dl;
     return WOST_OK;
@@ -1402,8 +1455,20 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
 {
     const NetLayout &L = h->L;
     NET_TRY(hipMemsetAsync(h->grad, 0, (size_t)h->n_params * sizeof(fx_t), stream));
-    const bool fused = h->fused_backward;
-    if (h->use_mfma && fused) {
+    const bool half = h->train_precision == 16;
+    const bool fused = h->fused_backward || half;
+    if (half) {
+        // recompute the hidden layers from the stored encoding, backward pass, all weight gradients in registers
+        const size_t lds = (size_t)L.n_mlp / 4 * sizeof(uint2) * 2;
+        const int n_units = (n + 15) / 16;
+        const unsigned gridb = (unsigned)std::min((n_units + kHalfThreads / 64 - 1) / (kHalfThreads / 64), 256);
+        int k = 0;
+        while (k < 10 && (n >> (k + 10)) > 0) ++k;          // 2^k ~ n / 512, between 1 and 1024
+        hipLaunchKernelGGL(net_train_h_kernel, dim3(gridb), dim3(kHalfThreads), lds, stream, L, h->params_h, h->params_hb,
+                           reinterpret_cast<const uint2 *>(h->d_acts), h->d_dl, n, (float)(1 << k), h->d_denc, h->train_partial);
+        hipLaunchKernelGGL(net_train_h_reduce_kernel, dim3((L.n_mlp + 255) / 256, (gridb + 15) / 16), dim3(256), 0, stream, L, h->train_partial, (int)gridb,
+                           h->grad);
+    } else if (h->use_mfma && fused) {
         // backward pass and weight gradients of a 1024-point chunk in one block (deltas stay on chip)
         const size_t lds = ((size_t)L.n_mlp + 4 * 64 * kTileStride + 3 * 64 * 64) * sizeof(float);
         auto kfn = net_backward_wgrad_kernel<32, 64, 3, 48>;
@@ -1464,7 +1529,7 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
     const int chunk = 1024;
     const unsigned gridc = (unsigned)((n + chunk - 1) / chunk);
     const size_t lds_w = 2 * 32 * 64 * sizeof(float);
-    for (int layer = 0; layer <= L.n_hidden && !(h->use_mfma && fused); ++layer) {
+    for (int layer = 0; layer <= L.n_hidden && !(h->use_mfma && fused) && !half; ++layer) {
         const int n_i = layer == 0 ? L.enc : L.n_neurons, n_o = layer == L.n_hidden ? L.n_out_padded : L.n_neurons;
         const int doff = layer == L.n_hidden ? 0 : L.n_out_padded + layer * L.n_neurons;   // delta of this layer's output
         const int ioff = layer == 0 ? 0 : L.enc + (layer - 1) * L.n_neurons;               // this layer's input
@@ -1512,8 +1577,7 @@ int net_apply_update_dev(wost_net *h, float loss_scale, hipStream_t stream)
     hipLaunchKernelGGL(optimizer_kernel, dim3((h->n_params + 255) / 256), dim3(256), 0, stream, h->L, h->n_params, h->params, h->m1,
                        h->m2, h->ema_raw, h->inference, h->grad, h->lr_table, h->param_steps, c.beta1, c.beta2, c.epsilon,
                        c.l2_reg, c.ema_decay, debias, loss_scale, h->grad_div, D);
-    if (h->precision == 16 && h->inference_h)
-        hipLaunchKernelGGL(fragment_mlp_h_kernel, dim3((h->L.n_mlp / 4 + 255) / 256), dim3(256), 0, stream, h->L, h->inference, h->inference_h);
+    refresh_half(h, stream);
     NET_TRY(hipGetLastError());
     return WOST_OK;
 }
@@ -1677,13 +1741,36 @@ int wost_net_set_option(wost_net_handle h, const char *key, double value)
             if (!(L.enc == 32 && L.n_neurons == 64 && L.n_hidden == 3 && L.n_out_padded == 48 && L.n_features == 4 && L.n_levels == 8))
                 return set_error(WOST_ERR_UNSUPPORTED, "half-precision inference is built for the reference's network shape only");
             NET_TRY(hipSetDevice(h->device));
-            if (!h->inference_h) NET_TRY(hipMalloc((void **)&h->inference_h, (size_t)L.n_mlp / 4 * sizeof(uint2)));
+            if (half_image_entries(L) * sizeof(uint2) > 158 * 1024)
+                return set_error(WOST_ERR_UNSUPPORTED, "half-precision network: weights and grid must fit into 158 KB of LDS");
+            if (!h->inference_h) NET_TRY(hipMalloc((void **)&h->inference_h, half_image_entries(L) * sizeof(uint2)));
             h->precision = 16;
-            hipLaunchKernelGGL(fragment_mlp_h_kernel, dim3((L.n_mlp / 4 + 255) / 256), dim3(256), 0, nullptr, L, h->inference, h->inference_h);
+            refresh_half(h, nullptr);
             NET_TRY(hipGetLastError());
             NET_TRY(hipDeviceSynchronize());
         } else {
             h->precision = 32;
+        }
+        return WOST_OK;
+    }
+    if (k == "train_precision") {
+        if (value != 16 && value != 32) return set_error(WOST_ERR_INVALID, "train_precision must be 32 (fp32, default) or 16 (half-precision training passes)");
+        if (value == 16) {
+            const NetLayout &L = h->L;
+            if (!(L.enc == 32 && L.n_neurons == 64 && L.n_hidden == 3 && L.n_out_padded == 48 && L.n_features == 4 && L.n_levels == 8))
+                return set_error(WOST_ERR_UNSUPPORTED, "half-precision training is built for the reference's network shape only");
+            NET_TRY(hipSetDevice(h->device));
+            if (half_image_entries(L) * sizeof(uint2) > 158 * 1024)
+                return set_error(WOST_ERR_UNSUPPORTED, "half-precision network: weights and grid must fit into 158 KB of LDS");
+            if (!h->params_h) NET_TRY(hipMalloc((void **)&h->params_h, half_image_entries(L) * sizeof(uint2)));
+            if (!h->params_hb) NET_TRY(hipMalloc((void **)&h->params_hb, (size_t)L.n_mlp / 4 * sizeof(uint2)));
+            if (!h->train_partial) NET_TRY(hipMalloc((void **)&h->train_partial, (size_t)256 * L.n_mlp * sizeof(float)));
+            h->train_precision = 16;
+            refresh_half(h, nullptr);
+            NET_TRY(hipGetLastError());
+            NET_TRY(hipDeviceSynchronize());
+        } else {
+            h->train_precision = 32;
         }
         return WOST_OK;
     }
@@ -1698,7 +1785,13 @@ int wost_net_inference(wost_net_handle h, const float *xy, int32_t n, float *out
     int rc = ensure_points(h, (size_t)n);
     if (rc != WOST_OK) return rc;
     NET_TRY(hipMemcpy(h->d_xy, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice));
-    rc = launch_forward(h, use_inference_params != 0, h->d_xy, n, nullptr, h->d_out, nullptr, nullptr);
+    if (!use_inference_params && h->train_precision == 16) {
+        // the training weights as a half-precision training step evaluates them
+        float *o = nullptr, *dl = nullptr;
+        rc = wost::net_forward_train_dev(h, h->d_xy, n, nullptr, &o, &dl);
+    } else {
+        rc = launch_forward(h, use_inference_params != 0, h->d_xy, n, nullptr, h->d_out, nullptr, nullptr);
+    }
     if (rc != WOST_OK) return rc;
     NET_TRY(hipMemcpy(out, h->d_out, (size_t)n * h->L.n_out * sizeof(float), hipMemcpyDeviceToHost));
     return WOST_OK;

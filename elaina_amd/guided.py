@@ -113,7 +113,9 @@ class GuidingNetwork:
         _check(self._lib.wost_net_set_params(self._h, _fp(p)), "wost_net_set_params")
 
     def set_option(self, key, value):
-        """"precision": 32 (fp32, bit-exact mode, default) or 16 (the reference's half-precision inference)"""
+        """"precision": 32 (fp32, bit-exact mode, default) or 16 (the reference's half-precision inference);
+        "train_precision": 32 (default) or 16 (forward / backward / weight gradients of the training steps on
+        f16 matrix instructions, fp32 master weights)"""
         _check(self._lib.wost_net_set_option(self._h, key.encode(), float(value)), "wost_net_set_option")
 
     def inference(self, xy, use_inference_params=True):

@@ -320,6 +320,40 @@ def _half_network_numpy(orc, cfg, p, xy):
     return a[:, :33]
 
 
+def _half_training_numpy(orc, cfg, p, xy, dl):
+    """Forward and backward pass of one half-precision training step in numpy (float64 sums of f16
+    numbers): -> (raw outputs [n, 33], gradient of the MLP matrices, dL/d(encoding) [n, 32]).  The deltas
+    carry the kernel's extra power-of-two scale (~ n / 512, at most 1024) while they are f16."""
+    k = 0
+    while k < 10 and (len(xy) >> (k + 10)) > 0:
+        k += 1
+    dscale = float(1 << k)
+    n_mlp = 64 * 32 + 2 * 64 * 64 + 48 * 64
+    f16 = lambda v: np.asarray(v).astype(np.float16).astype(np.float64)
+    ph = p.copy()
+    ph[n_mlp:] = p[n_mlp:].astype(np.float16).astype(np.float32)
+    acts = [f16(orc.net_forward(cfg, ph, xy, want_acts=True)[1][:, :32])]
+    shapes = [(64, 32), (64, 64), (64, 64), (48, 64)]
+    ws, off = [], 0
+    for no, ni in shapes:
+        ws.append(f16(p[off:off + no * ni].reshape(no, ni)))
+        off += no * ni
+    for l in range(3):
+        acts.append(f16(np.maximum((acts[l] @ ws[l].T).astype(np.float32), 0.0)))
+    out = f16((acts[3] @ ws[3].T).astype(np.float32))[:, :33]
+    d = np.zeros((len(xy), 48))
+    d[:, :33] = f16(dl * np.float32(dscale))
+    grads = [None] * 4
+    for l in (3, 2, 1, 0):
+        grads[l] = (d.T @ acts[l]) / dscale
+        back = (d @ ws[l]).astype(np.float32)
+        if l == 0:
+            denc = back / np.float32(dscale)
+        else:
+            d = f16(np.where(acts[l] > 0, back, 0.0))
+    return out.astype(np.float32), np.concatenate([g.ravel() for g in grads]), denc
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [7, 64, 8192 + 5])
 def test_gpu_half_precision_inference(orc, n):
@@ -375,3 +409,84 @@ def test_gpu_half_precision_follows_the_optimizer(orc):
         assert np.abs(half - emu).max() <= 4e-3 * scale
     finally:
         net.close()
+
+
+# ---- half-precision training passes ("train_precision" 16) ---------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [5, 64, 4096 + 3, 70000])
+def test_gpu_half_precision_training_passes(orc, n):
+    """train_precision 16: forward, backward and weight gradients on f16 matrix instructions with fp32
+    accumulation.  Gate 1: equal to the numpy restatement of exactly that arithmetic up to summation
+    order.  Gate 2: close to the fp32 gradient (the bit-exact mode).  Gate 3: reproducible bit for bit."""
+    from elaina_amd.guided import GuidingNetwork
+    cfg = default_net_config()
+    n_mlp = 64 * 32 + 2 * 64 * 64 + 48 * 64
+    net = GuidingNetwork(seed=7)
+    try:
+        p = _rand_params(orc, cfg, seed=41, wscale=0.2, gscale=0.4)
+        net.set_params(p)
+        rng = np.random.default_rng(500 + n)
+        xy = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+        dl = (rng.normal(size=(n, 33)) * 128 / n).astype(np.float32)
+        net.train_step(xy, dl, apply_update=False)
+        g32 = net.gradients()
+        net.set_option("train_precision", 16)
+        emu_out, emu_g, _ = _half_training_numpy(orc, cfg, p, xy, dl)
+        out = net.inference(xy, use_inference_params=False)
+        scale = float(np.sqrt(np.mean(emu_out ** 2)))
+        assert np.abs(out - emu_out).max() <= 4e-3 * scale
+        assert np.mean(out == emu_out) > 0.9
+        net.train_step(xy, dl, apply_update=False)
+        g16 = net.gradients()
+        np.testing.assert_array_equal(net.params(), p)
+        # matrices: against the restatement (f16 rounding of a delta can flip with the summation order -> a few 1e-3)
+        gs = float(np.sqrt(np.mean(emu_g ** 2)))
+        assert np.sqrt(np.mean((g16[:n_mlp] - emu_g) ** 2)) < 3e-3 * gs, (float(np.sqrt(np.mean((g16[:n_mlp] - emu_g) ** 2))), gs)
+        # everything: against the fp32 gradient.  dL/dout is noise here, so the gradient is a random-walk sum and
+        # the ~1e-3 of the hidden units whose ReLU flips between the two precisions show up as sqrt(1e-3) ~ 3 %
+        # (the restatement above differs from fp32 by the same amount); a structured loss is far closer (the
+        # learning test below)
+        for sl in (slice(0, n_mlp), slice(n_mlp, None)):
+            ref = float(np.sqrt(np.mean(g32[sl] ** 2)))
+            err = float(np.sqrt(np.mean((g16[sl] - g32[sl]) ** 2)))
+            assert err < 6e-2 * ref, (sl, err, ref)
+        # grid entries no training point touched keep a zero gradient (the optimizer skips them)
+        assert np.array_equal(g16[n_mlp:] == 0, g32[n_mlp:] == 0) or n < 100
+        net.train_step(xy, dl, apply_update=False)
+        assert np.array_equal(net.gradients(), g16)
+        net.set_option("train_precision", 32)
+        net.train_step(xy, dl, apply_update=False)
+        assert np.array_equal(net.gradients(), g32)
+    finally:
+        net.close()
+
+
+@pytest.mark.gpu
+def test_gpu_half_precision_training_learns_a_field():
+    """the regression of test_gpu_network_learns_a_field with both passes in half precision: the loss
+    falls the same way (fp32 master weights, Adam and EMA as before)"""
+    from elaina_amd.guided import GuidingNetwork
+    rng0 = np.random.default_rng(8)
+    freq = rng0.uniform(1, 3, (33, 2))
+
+    def target(xy):
+        return np.sin(xy @ freq.T * 2 * np.pi).astype(np.float32)
+
+    test_xy = rng0.uniform(0, 1, (2048, 2)).astype(np.float32)
+    last = {}
+    for prec in (32, 16):
+        n = GuidingNetwork(seed=3)
+        try:
+            n.set_option("train_precision", prec)
+            n.set_option("precision", prec)
+            rng = np.random.default_rng(9)
+            first = float(np.mean((n.inference(test_xy) - target(test_xy)) ** 2))
+            for _ in range(300):
+                xy = rng.uniform(0, 1, (4096, 2)).astype(np.float32)
+                pred = n.inference(xy, use_inference_params=False)
+                n.train_step(xy, 2.0 * (pred - target(xy)) / pred.size * 128.0, loss_scale=128.0)
+            last[prec] = float(np.mean((n.inference(test_xy) - target(test_xy)) ** 2))
+            assert first > 0.3 and last[prec] < 0.1 * first, (prec, first, last[prec])
+        finally:
+            n.close()
+    assert abs(last[16] - last[32]) < 0.25 * last[32], last

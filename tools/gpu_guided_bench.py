@@ -30,6 +30,8 @@ ap.add_argument("--batch", type=int, default=65536 * 8)
 ap.add_argument("--min-batch", type=int, default=65536)
 ap.add_argument("--one-shard-of", type=int, default=0,
                 help="single process: run only shard 0 of N (what ONE rank of an N-GPU job does, no reduce)")
+ap.add_argument("--net-precision", type=int, default=32, choices=[32, 16])
+ap.add_argument("--net-train-precision", type=int, default=0, choices=[0, 32, 16])
 a = ap.parse_args()
 
 rank, world, local = D.init_process_group(a.backend)
@@ -45,6 +47,10 @@ gi = GuidedIntegrator(prob, st, ((-100.0, -100.0), (600.0, 600.0)), device=devic
 t_create = time.time() - t0
 if a.shared_network and world > 1:
     gi.share_network()
+if a.net_precision == 16:
+    gi.network.set_option("precision", 16)
+if (a.net_train_precision or a.net_precision) == 16:
+    gi.network.set_option("train_precision", 16)
 field = torch.zeros(a.frame * a.frame * 3, dtype=torch.float32, device="cuda")
 if world > 1:
     import torch.distributed as dist

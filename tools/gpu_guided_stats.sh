@@ -4,7 +4,7 @@
 TAG=${1:-dev}
 export TMPDIR=/tmp
 rm -rf gpurun_out/gs_$TAG
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/gs_$TAG -- python3 tools/gpu_guided_bench.py --spp 32 --train-spp 32 > gpurun_out/${TAG}_guided_stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/gs_$TAG -- python3 tools/gpu_guided_bench.py --spp 32 --train-spp 32 $GARGS > gpurun_out/${TAG}_guided_stats.log 2>&1
 f=$(find gpurun_out/gs_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/${TAG}_guided_kernel_stats.csv
 rm -rf gpurun_out/gs_$TAG
