@@ -32,6 +32,7 @@
 
 #include "../../include/wost.h"
 #include "wost_internal.h"
+#include "wost_net_device.h"
 #include "wost_vmm_device.h"
 #include "wost_walk.h"
 
@@ -157,6 +158,21 @@ struct GParams {
     int32_t first_sample;
     int32_t last_depth;
     int32_t shard_index, shard_count;   // this solve owns the 8x8 pixel tiles t with t % count == index
+    // fused sample kernel only
+    float *d0_d2;             // per pixel: squared distance of the evaluation point to the Dirichlet boundary (with hint0)
+    uint32_t *cursor;         // next unread pixel slot of this launch
+    int32_t max_guided_depth;
+    int32_t stack_words;      // LDS words of a lane's traversal stack
+    int32_t wait_weight, trav_burst;
+};
+
+// the half-precision network as the fused kernel needs it
+struct FusedNet {
+    const uint2 *image;       // MFMA fragments (n_frag entries), then the grid entries
+    uint32_t n_frag;
+    uint32_t w_off4[4];
+    float scale[8];
+    uint32_t res[8], off[9];
 };
 
 __device__ __forceinline__ bool is_training_pixel(const GParams &P, uint32_t pid)
@@ -432,7 +448,72 @@ __global__ __launch_bounds__(256) void tail_kernel(GParams P)
 }
 
 // ---- handleOutShellPoint + handleGuidedSampling + handleUniformSampling / oneStepWalk --------
-// (reference guided/integrator.cu:497-526, 782-880, 671-779, 883-965), in place on the queue
+// (reference guided/integrator.cu:497-526, 782-880, 671-779, 883-965) for ONE walker whose R_B is known.
+// raw(j) = output j of the network for this walker (only called when `guiding`).
+struct SampleOut {
+    bool dropped, guided_step, hit_n;
+    float x, y, thp, nx, ny;
+};
+
+template <bool TREE, class RAW>
+__device__ __forceinline__ SampleOut sample_step(const GParams &P, uint32_t pid, bool on_n, float x, float y, float thp, float nx, float ny,
+                                                 float R_B, int depth, bool guiding, Pcg &rng, const RAW &raw, const LdsColumn &stk)
+{
+    SampleOut o{false, false, false, x, y, thp, nx, ny};
+    const bool record = is_training_pixel(P, pid) && depth < P.max_train_depth;
+    float dirx = 0, diry = 0, pdf = 1, alpha = 1;
+    if (!guiding) {
+        uniform_direction(on_n, nx, ny, rng, dirx, diry, pdf, alpha);
+    } else {
+        const float sel = 1 / (1.f + det_expf(-raw(32)));                 // logistic (functors.h:182)
+        const bool inside = aabb_contains(P.box, x, y);
+        // the draw precedes the box test and is skipped for uniform fraction 0 (:518)
+        bool to_guided = (P.uniform_fraction == 0.0f) || (pcg_next_float(rng) < sel);
+        to_guided = to_guided && inside;
+        o.dropped = to_guided && !(P.uniform_fraction < 1.0f);            // kernel never launched (:1031)
+        // the mixture is needed by both branches inside the box: for the sample and its pdf,
+        // or for the MIS weight of a uniform sample
+        Vmm m;
+        const bool use_vmm = inside && !o.dropped;
+        if (use_vmm) m.build(raw);
+        float uniform_pdf = 0.0f;
+        if (to_guided) {
+            if (!o.dropped) {
+                m.sample(rng, dirx, diry);
+                uniform_pdf = on_n ? (float)(1.0 / 3.14159265358979323846) : 1.0f / WOST_2PI;
+                alpha = on_n ? 0.5f : 1.0f;
+                o.guided_step = true;
+            }
+        } else {
+            uniform_direction(on_n, nx, ny, rng, dirx, diry, pdf, alpha);
+            uniform_pdf = pdf;
+        }
+        if (use_vmm) {
+            // on a Neumann boundary the density of the mirrored direction is added; a guided
+            // sample pointing out of the domain is replaced by its mirror image afterwards
+            const float dd = 2 * (dirx * nx + diry * ny);
+            const float rx = dirx - dd * nx, ry = diry - dd * ny;
+            float guided_pdf, mirrored_pdf;
+            m.pdf_pair(dirx, diry, rx, ry, on_n, guided_pdf, mirrored_pdf);
+            if (on_n) {
+                guided_pdf += mirrored_pdf;
+                if (to_guided && nx * dirx + ny * diry <= 0) { dirx = rx; diry = ry; }
+            }
+            pdf = sel * guided_pdf + (1.0f - sel) * uniform_pdf;
+        }
+    }
+    if (!o.dropped) {
+        float nxt_x, nxt_y, hnx, hny;
+        o.hit_n = walk_advance<TREE>(P.nm, P.st.eps, x, y, R_B, on_n, nx, ny, dirx, diry, stk, nxt_x, nxt_y, hnx, hny);
+        if (record) record_vertex(P, pid, x, y, dirx, diry, pdf, thp, on_n, nx, ny);
+        o.x = nxt_x; o.y = nxt_y;
+        o.thp = thp / pdf / alpha / WOST_2PI;
+        o.nx = hnx; o.ny = hny;
+    }
+    return o;
+}
+
+// one launch per depth, in place on the queue
 template <bool TREE>
 __global__ __launch_bounds__(256) void sample_kernel(GParams P)
 {
@@ -449,73 +530,33 @@ __global__ __launch_bounds__(256) void sample_kernel(GParams P)
         const float x = P.in.x[i], y = P.in.y[i], thp = P.in.thp[i], nx = P.in.nx[i], ny = P.in.ny[i];
         const float R_B = P.in.rb[i];
         Pcg rng{P.rng[pid], 1};
-        const bool record = is_training_pixel(P, pid) && P.depth < P.max_train_depth;
-        float dirx = 0, diry = 0, pdf = 1, alpha = 1;
-        bool dropped = false;
-        if (!P.guiding) {
-            uniform_direction(on_n, nx, ny, rng, dirx, diry, pdf, alpha);
-        } else {
-            // raw output j of this walker (one array per output: neighbouring lanes, neighbouring words)
-            // all 33 loads are issued together, ahead of the branches of the arithmetic below
-            // (issued one by one between those branches they cost a memory round trip each:
-            // 74 % of the kernel's wave cycles were spent waiting)
+        // raw output j of this walker (one array per output: neighbouring lanes, neighbouring words)
+        // all 33 loads are issued together, ahead of the branches of the arithmetic below
+        // (issued one by one between those branches they cost a memory round trip each:
+        // 74 % of the kernel's wave cycles were spent waiting)
+        Vmm::f32x8 r0, r1, r2, r3;
+        float raw32 = 0.0f;
+        if (P.guiding) {
             const float *rp = P.net_out + i;
             const size_t ld = P.net_ld;
-            Vmm::f32x8 r0, r1, r2, r3;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 r0[j] = rp[j * ld]; r1[j] = rp[(8 + j) * ld]; r2[j] = rp[(16 + j) * ld]; r3[j] = rp[(24 + j) * ld];
             }
-            const float raw32 = rp[32 * ld];
-            const auto raw = [&](int j) { return j < 8 ? r0[j & 7] : j < 16 ? r1[j & 7] : j < 24 ? r2[j & 7] : r3[j & 7]; };
-            const float sel = 1 / (1.f + det_expf(-raw32));                   // logistic (functors.h:182)
-            const bool inside = aabb_contains(P.box, x, y);
-            // the draw precedes the box test and is skipped for uniform fraction 0 (:518)
-            bool to_guided = (P.uniform_fraction == 0.0f) || (pcg_next_float(rng) < sel);
-            to_guided = to_guided && inside;
-            dropped = to_guided && !(P.uniform_fraction < 1.0f);              // kernel never launched (:1031)
-            // the mixture is needed by both branches inside the box: for the sample and its pdf,
-            // or for the MIS weight of a uniform sample
-            Vmm m;
-            const bool use_vmm = inside && !dropped;
-            if (use_vmm) m.build(raw);
-            float uniform_pdf = 0.0f;
-            if (to_guided) {
-                if (!dropped) {
-                    m.sample(rng, dirx, diry);
-                    uniform_pdf = on_n ? (float)(1.0 / 3.14159265358979323846) : 1.0f / WOST_2PI;
-                    alpha = on_n ? 0.5f : 1.0f;
-                    guided_step = true;
-                }
-            } else {
-                uniform_direction(on_n, nx, ny, rng, dirx, diry, pdf, alpha);
-                uniform_pdf = pdf;
-            }
-            if (use_vmm) {
-                // on a Neumann boundary the density of the mirrored direction is added; a guided
-                // sample pointing out of the domain is replaced by its mirror image afterwards
-                const float dd = 2 * (dirx * nx + diry * ny);
-                const float rx = dirx - dd * nx, ry = diry - dd * ny;
-                float guided_pdf, mirrored_pdf;
-                m.pdf_pair(dirx, diry, rx, ry, on_n, guided_pdf, mirrored_pdf);
-                if (on_n) {
-                    guided_pdf += mirrored_pdf;
-                    if (to_guided && nx * dirx + ny * diry <= 0) { dirx = rx; diry = ry; }
-                }
-                pdf = sel * guided_pdf + (1.0f - sel) * uniform_pdf;
-            }
+            raw32 = rp[32 * ld];
         }
+        const auto raw = [&](int j) { return j < 8 ? r0[j & 7] : j < 16 ? r1[j & 7] : j < 24 ? r2[j & 7] : j < 32 ? r3[j & 7] : raw32; };
+        const SampleOut o = sample_step<TREE>(P, pid, on_n, x, y, thp, nx, ny, R_B, P.depth, P.guiding != 0, rng, raw, stk);
         P.rng[pid] = rng.state;
-        if (dropped) {
+        guided_step = o.guided_step;
+        if (o.dropped) {
             P.in.pid[i] = kDead;
         } else {
-            float nxt_x, nxt_y, hnx, hny;
-            hit_n = walk_advance<TREE>(P.nm, P.st.eps, x, y, R_B, on_n, nx, ny, dirx, diry, stk, nxt_x, nxt_y, hnx, hny);
-            if (record) record_vertex(P, pid, x, y, dirx, diry, pdf, thp, on_n, nx, ny);
+            hit_n = o.hit_n;
             P.in.pid[i] = pid | (hit_n ? kOnNeumann : 0u);
-            P.in.x[i] = nxt_x; P.in.y[i] = nxt_y;
-            P.in.thp[i] = thp / pdf / alpha / WOST_2PI;
-            P.in.nx[i] = hnx; P.in.ny[i] = hny;
+            P.in.x[i] = o.x; P.in.y[i] = o.y;
+            P.in.thp[i] = o.thp;
+            P.in.nx[i] = o.nx; P.in.ny[i] = o.ny;
             alive_after = true;
         }
     }
@@ -523,6 +564,235 @@ __global__ __launch_bounds__(256) void sample_kernel(GParams P)
     wave_count(live && P.guiding, &my_stats(P.stats)->net_points);
     wave_count(hit_n, &my_stats(P.stats)->nhits);
     if (P.last_depth) wave_count(alive_after, &my_stats(P.stats)->truncated);
+}
+
+// ---- a whole sample in one launch (half-precision network only) -----------------------------------
+// The guiding network is small: its f16 weight fragments take 26 KB of LDS and its grid 123 KB of L2, and one
+// evaluation is 52 matrix instructions per 16 walkers.  So a wave can evaluate the network for its OWN walkers,
+// and nothing forces the walk through a global queue and a launch boundary at every depth.  This kernel is the
+// uniform integrator's persistent round kernel (wost_hip.hip) with the guided step in its step phase:
+//   lanes hold walkers; a lane is traversing the Dirichlet tree (TRAV), waits with a finished query (WAIT),
+//   or wants the next pixel of the launch (REFILL).  Each trip of the loop runs the body more lanes are ready
+//   for.  The step body = separate_finish, then -- wave-uniform, on the matrix cores -- the network for the
+//   lanes that need it (compacted through LDS into 16-point units), then sample_step and the next query.
+// Per pixel the arithmetic and the order of the random draws are those of separate_kernel / sample_kernel /
+// tail_kernel, and the network arithmetic is that of net_forward_h_kernel (same device functions): the field,
+// the training records and hence the trained weights are bit-identical to the one-launch-per-depth path.
+constexpr int kFusedThreads = 768;       // twelve waves per CU share one copy of the weight fragments
+constexpr int kXchWords = 128 + 16 * 48 / 2;   // per wave: 64 network inputs (x, y), 16 x 48 f16 outputs
+
+template <bool EMISSIVE, bool TREE, bool SOURCE>
+__global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P, FusedNet F)
+{
+    extern __shared__ uint32_t lds_all[];
+    __shared__ float s_scale[8];
+    __shared__ uint32_t s_res[8], s_off[9];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // traversal stacks wave by wave (entry i of a lane at [i * 64 + lane]: the column stride must be a power of two)
+    const LdsColumn stk{lds_all + (size_t)wave * P.stack_words * 64 + lane, 64u};
+    uint2 *wf = reinterpret_cast<uint2 *>(lds_all + (size_t)P.stack_words * kFusedThreads);
+    float *xch_xy = reinterpret_cast<float *>(wf + F.n_frag) + (size_t)wave * kXchWords;
+    _Float16 *xch_out = reinterpret_cast<_Float16 *>(xch_xy + 128);
+    for (uint32_t e = threadIdx.x; e < F.n_frag; e += kFusedThreads) wf[e] = F.image[e];
+    if (threadIdx.x < 9) {
+        s_off[threadIdx.x] = F.off[threadIdx.x];
+        if (threadIdx.x < 8) {
+            s_scale[threadIdx.x] = F.scale[threadIdx.x];
+            s_res[threadIdx.x] = F.res[threadIdx.x];
+        }
+    }
+    __syncthreads();
+    const uint2 *grid = F.image + F.n_frag;
+    const int li = lane & 15, lg = lane >> 4;
+
+    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5 };
+    int mode = MODE_REFILL;
+    uint32_t pid = 0;
+    bool on_n = false;
+    float x = 0, y = 0, thp = 0, nx = 0, ny = 0;
+    int32_t hint = 0;
+    int depth = 0;
+    Pcg rng{0, 1};
+    Trav T = trav_begin(Closest{WOST_INF, -1});
+    uint32_t pool_next = 0, pool_end = 0;
+    uint32_t c_steps = 0, c_started = 0, c_abs = 0, c_trunc = 0, c_hits = 0, c_guided = 0, c_net = 0;
+    const bool has_d = P.dm.n_segs > 0;
+    const uint32_t n_slots = (uint32_t)P.n_pixels;
+    const bool tiled = ((P.st.width | P.st.height) & 7) == 0;
+
+    for (;;) {
+        // ---- lanes without a walker take the next pixel of the launch (begin_sample_kernel) ----
+        const unsigned long long need = __ballot(mode == MODE_REFILL);
+        if (need) {
+            const uint32_t needed = (uint32_t)__popcll(need), avail = pool_end - pool_next;
+            uint32_t fresh_base = 0;
+            if (needed > avail) {
+                if (lane == 0) fresh_base = atomicAdd(P.cursor, 64u);
+                fresh_base = __shfl(fresh_base, 0);
+            }
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            const uint32_t s2 = rank < avail ? pool_next + rank : fresh_base + (rank - avail);
+            if (needed > avail) {
+                pool_next = fresh_base + (needed - avail);
+                pool_end = fresh_base + 64u;
+            } else {
+                pool_next += needed;
+            }
+            if (mode == MODE_REFILL) {
+                if (s2 >= n_slots) {
+                    mode = MODE_DONE;
+                } else {
+                    int p = (int)s2;
+                    if (tiled) {
+                        const int tiles_x = P.st.width >> 3, tile = p >> 6, in_tile = p & 63;
+                        p = ((tile / tiles_x) * 8 + (in_tile >> 3)) * P.st.width + (tile % tiles_x) * 8 + (in_tile & 7);
+                    }
+                    if (P.first_sample) {
+                        Pcg r0;
+                        pcg_seed_pixel(r0, p, P.st.width);
+                        P.rng[p] = r0.state;
+                        P.sol[3 * (size_t)p] = 0.0f; P.sol[3 * (size_t)p + 1] = 0.0f; P.sol[3 * (size_t)p + 2] = 0.0f;
+                        P.hint0[p] = 0;
+                    }
+                    P.cur_depth[p] = 0;
+                    const int px = p % P.st.width, py = p / P.st.width;
+                    const int tile = (py >> 3) * ((P.st.width + 7) >> 3) + (px >> 3);
+                    const bool active = (tile % P.shard_count) == P.shard_index && (P.mask == nullptr || P.mask[p] != 0);
+                    if (active) {
+                        eval_point(P.probe, px, py, P.st.width, P.st.height, x, y);
+                        pid = (uint32_t)p;
+                        on_n = false; thp = 1.0f; nx = 0.0f; ny = 0.0f; depth = 0;
+                        hint = P.hint0[p];
+                        rng.state = P.rng[p];
+                        ++c_started;
+                        if (!has_d) {
+                            T.best = Closest{WOST_INF, -1};
+                            mode = MODE_WAIT;
+                        } else if (!P.first_sample) {
+                            // the evaluation point of a pixel is the same for every sample: its query is cached
+                            T.best = Closest{P.d0_d2[p], hint};
+                            mode = MODE_WAIT;
+                        } else {
+                            T = trav_begin(slot_candidate(P.dm, hint, x, y));
+                            mode = MODE_TRAV;
+                        }
+                    }
+                    // inactive pixel (mask, other shard): the lane asks again on the next trip
+                }
+            }
+        }
+        const int n_trav = __popcll(__ballot(mode == MODE_TRAV));
+        const int n_wait = __popcll(__ballot(mode == MODE_WAIT));
+        if (n_trav + n_wait == 0) {
+            if (__ballot(mode == MODE_REFILL)) continue;
+            break;
+        }
+        if (n_wait * P.wait_weight >= n_trav * 8) {
+            // ---- step phase -------------------------------------------------------------------
+            const bool act = mode == MODE_WAIT;
+            int status = SEP_DROPPED;
+            float R_B = 0.0f;
+            if (act) {
+                ++c_steps;
+                if (has_d && depth == 0 && P.first_sample) P.d0_d2[pid] = T.best.d2;
+                status = separate_finish<EMISSIVE, TREE, SOURCE>(P, pid, on_n, x, y, thp, nx, ny, depth, T.best, hint, R_B, rng, stk);
+                if (status == SEP_ABSORBED) ++c_abs;
+            }
+            const bool keep = act && status == SEP_KEEP;
+            const bool guiding = keep && depth < P.max_guided_depth;
+            // ---- the network for the lanes that need it: all 64 lanes take part (matrix instructions) ----
+            _Float16 rawh[33];
+#pragma unroll
+            for (int j = 0; j < 33; ++j) rawh[j] = (_Float16)0.0f;
+            const unsigned long long bal = __ballot(guiding);
+            if (bal) {
+                const int n_need = __popcll(bal);
+                const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+                if (guiding) {
+                    float ix, iy;
+                    normalize_coord(P.box, x, y, ix, iy);
+                    xch_xy[2 * rank] = ix;
+                    xch_xy[2 * rank + 1] = iy;
+                    ++c_net;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int u = 0; 16 * u < n_need; ++u) {
+                    const int q = 16 * u + li;
+                    const float qx = q < n_need ? xch_xy[2 * q] : 0.5f, qy = q < n_need ? xch_xy[2 * q + 1] : 0.5f;
+                    h4_t enc[2], out[3];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int lv = lg + 4 * h;
+                        enc[h] = half_encode_level(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], qx, qy);
+                    }
+                    half_mlp_unit(wf, F.w_off4, lane, enc, out);
+#pragma unroll
+                    for (int rt = 0; rt < 3; ++rt) {
+                        union { h4_t h; uint2 u; } o;
+                        o.h = out[rt];
+                        *reinterpret_cast<uint2 *>(xch_out + li * 48 + 16 * rt + 4 * lg) = o.u;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (guiding && (rank >> 4) == u) {
+#pragma unroll
+                        for (int j = 0; j < 33; ++j) rawh[j] = xch_out[(rank & 15) * 48 + j];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (act) {
+                bool ended = !keep;
+                if (keep) {
+                    const auto raw = [&](int j) { return (float)rawh[j]; };
+                    const SampleOut o = sample_step<TREE>(P, pid, on_n, x, y, thp, nx, ny, R_B, depth, guiding, rng, raw, stk);
+                    if (o.guided_step) ++c_guided;
+                    if (o.dropped) {
+                        ended = true;
+                    } else {
+                        if (o.hit_n) ++c_hits;
+                        x = o.x; y = o.y; thp = o.thp; nx = o.nx; ny = o.ny; on_n = o.hit_n;
+                        ++depth;
+                        if (depth >= P.st.max_depth) {
+                            ++c_trunc;
+                            ended = true;
+                        }
+                    }
+                }
+                if (ended) {
+                    P.rng[pid] = rng.state;
+                    mode = MODE_REFILL;
+                } else if (has_d) {
+                    T = trav_begin(slot_candidate(P.dm, hint, x, y));
+                    mode = MODE_TRAV;
+                } else {
+                    T.best = Closest{WOST_INF, -1};
+                    mode = MODE_WAIT;
+                }
+            }
+        } else {
+            // ---- traversal phase: every traversing lane visits nodes ----
+            for (int b = 0; b < P.trav_burst; ++b) {
+                if (mode == MODE_TRAV) {
+                    if (!trav_visit(P.dm, x, y, T, stk)) mode = MODE_WAIT;
+                }
+            }
+        }
+    }
+    const uint32_t s_steps = wave_sum(c_steps), s_st = wave_sum(c_started), s_abs = wave_sum(c_abs), s_tr = wave_sum(c_trunc),
+                   s_hit = wave_sum(c_hits), s_g = wave_sum(c_guided), s_net = wave_sum(c_net);
+    if (lane == 0) {
+        GStatsDev *st = my_stats(P.stats);
+        if (s_steps) atomicAdd(&st->steps, (unsigned long long)s_steps);
+        if (s_st) atomicAdd(&st->started, (unsigned long long)s_st);
+        if (s_abs) atomicAdd(&st->absorbed, (unsigned long long)s_abs);
+        if (s_tr) atomicAdd(&st->truncated, (unsigned long long)s_tr);
+        if (s_hit) atomicAdd(&st->nhits, (unsigned long long)s_hit);
+        if (s_g) atomicAdd(&st->guided, (unsigned long long)s_g);
+        if (s_net) atomicAdd(&st->net_points, (unsigned long long)s_net);
+    }
 }
 
 // ---- training set: generate_training_data (reference train.h:423-471), ordered ----------------
@@ -662,6 +932,8 @@ struct wost_guided {
     float *sol = nullptr, *field = nullptr, *rec = nullptr, *net_in = nullptr, *net_out = nullptr;
     uint32_t *cur_depth = nullptr;
     int32_t *hint0 = nullptr;
+    float *d0_d2 = nullptr;            // fused sample kernel: cached query of every evaluation point
+    uint32_t *cursor = nullptr;        // fused sample kernel: next pixel slot of the launch
     GStatsDev *stats = nullptr;
     uint32_t *block_sums = nullptr;
     int n_train_blocks = 0, n_train_pixels = 0;
@@ -771,6 +1043,7 @@ int wost_guided_create(const wost_scene_desc *scene, const wost_guided_settings 
     GA(g->counts, 2); GA(g->rng, N); GA(g->sol, 3 * N); GA(g->field, 3 * N);
     GA(g->rec, (size_t)kMaxTrainDepth * kRecFields * N);
     GA(g->net_in, 2 * N); GA(g->net_out, 33 * N); GA(g->cur_depth, N); GA(g->hint0, N); GA(g->stats, kStatCopies);
+    GA(g->d0_d2, N); GA(g->cursor, 1);
     // sized for offset 0 (the largest set); the offset of a solve may be drawn per solve (run_guided)
     g->n_train_pixels = (int)((N + (size_t)s->train_pixel_stride - 1) / (size_t)s->train_pixel_stride);
     g->n_train_blocks = (g->n_train_pixels + 255) / 256;
@@ -925,6 +1198,31 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     P.train_offset = train_offset; P.train_stride = (uint32_t)s.train_pixel_stride;
     P.shard_index = shard_index; P.shard_count = shard_count;
 
+    // half-precision network: a whole sample is one launch (guided_sample_kernel); WOST_GUIDED_FUSED=0 keeps the
+    // one-launch-per-depth path for comparison (same field, same records)
+    bool fused = false;
+    FusedNet F{};
+    {
+        HalfNetView hv{};
+        const char *env = std::getenv("WOST_GUIDED_FUSED");
+        const NetLayout &L = hv.L;
+        if (!(env && env[0] == '0') && net_half_view(g->net, &hv) == WOST_OK && L.n_levels == 8 && L.enc == 32 && L.n_neurons == 64 &&
+            L.n_hidden == 3 && L.n_out_padded == 48 && L.n_out == 33) {
+            fused = true;
+            F.image = hv.image;
+            F.n_frag = L.n_mlp / 4;
+            for (int l = 0; l < 4; ++l) F.w_off4[l] = L.w_off[l] / 4;
+            for (int l = 0; l < 8; ++l) { F.scale[l] = L.scale[l]; F.res[l] = (uint32_t)L.res[l]; }
+            for (int l = 0; l <= 8; ++l) F.off[l] = L.level_off[l];
+        }
+    }
+    P.d0_d2 = g->d0_d2; P.cursor = g->cursor; P.stack_words = stack_words;
+    P.wait_weight = 8; P.trav_burst = 3;
+    if (const char *w = std::getenv("WOST_GUIDED_WAIT_WEIGHT")) P.wait_weight = std::max(1, std::atoi(w));
+    if (const char *w = std::getenv("WOST_GUIDED_TRAV_BURST")) P.trav_burst = std::max(1, std::atoi(w));
+    const size_t lds_fused = ((size_t)stack_words * kFusedThreads + (size_t)(kFusedThreads / 64) * kXchWords) * sizeof(uint32_t) +
+                             (size_t)F.n_frag * sizeof(uint2);
+
     // ctor state (integrator.cu:1158-1160), prepareSolve (:125-126)
     bool training = true;
     float uniform_fraction = s.uniform_fraction_training;
@@ -939,17 +1237,35 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         P.training = training ? 1 : 0;
         P.uniform_fraction = uniform_fraction;
         P.first_sample = sample == 0;
+        if (fused) {
+            P.max_guided_depth = max_guided_depth;
+            G_TRY(hipMemsetAsync(g->cursor, 0, sizeof(uint32_t), stream));
+            const unsigned gridf = (unsigned)std::min<size_t>(256, ((size_t)N + kFusedThreads - 1) / kFusedThreads);
+#define LAUNCH_FUSED(E, T)                                                                                                      \
+    do {                                                                                                                        \
+        auto kfn = v.src.rgb ? guided_sample_kernel<E, T, true> : guided_sample_kernel<E, T, false>;                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused); \
+        hipLaunchKernelGGL(kfn, dim3(gridf), dim3(kFusedThreads), lds_fused, stream, P, F);                                       \
+    } while (0)
+            if (emissive) { if (tree) LAUNCH_FUSED(true, true); else LAUNCH_FUSED(true, false); }
+            else          { if (tree) LAUNCH_FUSED(false, true); else LAUNCH_FUSED(false, false); }
+#undef LAUNCH_FUSED
+            ++launches;
+            G_TRY(hipGetLastError());
+        }
         int cur = 0;     // queue holding the evaluation points of this depth
+        if (!fused) {
         G_TRY(hipMemsetAsync(g->counts + cur, 0, sizeof(uint32_t), stream));
         P.out = g->q[cur]; P.count_out = g->counts + cur;
         hipLaunchKernelGGL(begin_sample_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, P);
         ++launches;
+        }
         // The queue only shrinks from depth to depth, so ANY earlier size bounds it.  The sizes come
         // back through pinned memory without the host waiting for them (every kernel reads the exact
         // size on the device); the launches of a sample are issued back to back.
         uint32_t n_cur = (uint32_t)N;
         int polled = -1;                 // last depth whose queue size has arrived
-        for (int depth = 0; depth < s.max_depth; ++depth) {
+        for (int depth = 0; depth < s.max_depth && !fused; ++depth) {
             const int nxt = cur ^ 1;
             P.depth = depth;
             P.guiding = depth < max_guided_depth ? 1 : 0;

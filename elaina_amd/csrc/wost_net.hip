@@ -28,10 +28,10 @@
 #include "../../include/wost.h"
 #include "wost_internal.h"
 #include "wost_math.h"
+#include "wost_net_device.h"
 
 namespace wost {
 
-constexpr int kNetMaxLevels = 16;
 constexpr int kNetBlock = 64;
 
 // Gradients are SUMS over the training points, and float atomics would make them depend on the
@@ -54,15 +54,6 @@ __device__ __forceinline__ void fx_add(fx_t *p, fx_t v)
 {
     atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);
 }
-
-struct NetLayout {
-    int32_t res[kNetMaxLevels];
-    float scale[kNetMaxLevels];
-    uint32_t level_off[kNetMaxLevels + 1];  // entries (x n_features floats)
-    int32_t n_levels, n_features, enc, n_neurons, n_hidden, n_out, n_out_padded;
-    uint32_t n_mlp, n_grid;
-    uint32_t w_off[kNetMaxLevels];  // offset of every weight matrix in the parameter vector
-};
 
 static NetLayout make_layout(const wost_net_config &c)
 {
@@ -183,7 +174,6 @@ __global__ __launch_bounds__(kNetBlock) void net_forward_kernel(NetLayout L, con
 // s = 4rt + c of the next layer.  Layer outputs never leave the registers and the k order stays
 // ascending.  Weight fragments (13 312 floats) sit in LDS in lane order: one conflict-free
 // ds_read_b32 per MFMA pair.
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kMfmaSub = 2;   // 16-point subtiles per wave iteration
 // staging rows of the encoded features are padded by two floats: the B-operand reads of a k-step
@@ -410,7 +400,6 @@ __global__ __launch_bounds__(NT) void net_forward_mfma_kernel(NetLayout L, const
 // and receives D[r = 16 rt + 4g + c][point i], so the accumulators of row tile rt ARE the B
 // operand of k-tile kt = rt of the next layer, and lane (i, g) encodes exactly the grid levels
 // g and g + 4 of its point: nothing is exchanged between lanes.
-typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 constexpr int kHalfSub = 2;       // 16-point groups per wave iteration
 constexpr int kHalfThreads = 256;      // training kernel (wost_net_half.h): one wave per SIMD, the accumulators take the registers
 constexpr int kHalfFwdThreads = 1024;  // forward kernel: sixteen waves share the LDS image, four per SIMD hide each other's latencies
@@ -496,34 +485,7 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int lv = g + 4 * h;
-                const float sc = s_scale[lv];
-                const uint32_t res = s_res[lv], lo = s_off[lv];
-                const uint32_t n_level = s_off[lv + 1] - lo;
-                float px = __builtin_fmaf(sc, x, 0.5f), py = __builtin_fmaf(sc, y, 0.5f);
-                const float fx = floorf(px), fy = floorf(py);
-                px -= fx;
-                py -= fy;
-                const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
-                union { uint2 u; h4_t h; } c[4];
-                float w[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
-                    w[k] = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
-                    uint32_t idx = cx + cy * res;
-                    if (idx >= n_level) {
-                        idx -= n_level;
-                        if (idx >= n_level) idx %= n_level;
-                    }
-                    c[k].u = grid[lo + idx];      // the grid as the half-precision network holds it
-                }
-                float4 f = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    f.x += w[k] * (float)c[k].h[0]; f.y += w[k] * (float)c[k].h[1];
-                    f.z += w[k] * (float)c[k].h[2]; f.w += w[k] * (float)c[k].h[3];
-                }
-                b[u][h] = h4_t{(_Float16)f.x, (_Float16)f.y, (_Float16)f.z, (_Float16)f.w};
+                b[u][h] = half_encode_level(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], x, y);
                 if (enc_out) {
                     // training: the encoding goes to the fused backward kernel as it stands (wost_net_half.h)
                     union { h4_t h; uint2 u; } e;
@@ -1586,6 +1548,15 @@ void *net_gradient_buffer(wost_net *h, uint64_t *count)
 {
     if (count) *count = h->n_params;
     return h->grad;
+}
+
+int net_half_view(wost_net *h, HalfNetView *out)
+{
+    if (!h || !out) return set_error(WOST_ERR_INVALID, "null argument");
+    if (h->precision != 16 || !h->inference_h) return set_error(WOST_ERR_UNSUPPORTED, "the network does not run its inference in half precision");
+    out->L = h->L;
+    out->image = h->inference_h;
+    return WOST_OK;
 }
 
 int net_optimizer_steps(const wost_net *h) { return h->step; }

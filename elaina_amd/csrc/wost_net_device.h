@@ -1,0 +1,113 @@
+// wost_net_device.h -- what other kernels of the library need from the guiding network (wost_net.hip):
+// its layout, and the half-precision forward pass of ONE 16-point unit as a device function, so that a walk
+// kernel can evaluate the network for the walkers of its own wave (wost_guided.hip, the fused sample kernel)
+// with exactly the arithmetic of net_forward_h_kernel.  Not part of the C-ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/wost.h"
+
+namespace wost {
+
+constexpr int kNetMaxLevels = 16;
+
+struct NetLayout {
+    int32_t res[kNetMaxLevels];
+    float scale[kNetMaxLevels];
+    uint32_t level_off[kNetMaxLevels + 1];  // entries (x n_features floats)
+    int32_t n_levels, n_features, enc, n_neurons, n_hidden, n_out, n_out_padded;
+    uint32_t n_mlp, n_grid;
+    uint32_t w_off[kNetMaxLevels];  // offset of every weight matrix in the parameter vector
+};
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+
+// The half-precision image of the inference weights ("precision" 16): MFMA fragments of the four matrices
+// (n_mlp / 4 entries of 8 bytes, layout of fragment_mlp_h_kernel), then the grid entry by entry (4 features in f16).
+// Refreshed by the network after every optimizer step.
+struct HalfNetView {
+    NetLayout L;
+    const uint2 *image;
+};
+// WOST_ERR_UNSUPPORTED unless the network runs its inference in half precision
+int net_half_view(wost_net_handle h, HalfNetView *out);
+
+// one level of the DenseGrid encoding of (x, y) in the half-precision network: grid values as stored (f16),
+// bilinear interpolation in fp32, result rounded to f16.  `grid` = the entries of the image (LDS or global).
+__device__ __forceinline__ h4_t half_encode_level(const uint2 *grid, float sc, uint32_t res, uint32_t lo, uint32_t n_level, float x, float y)
+{
+    float px = __builtin_fmaf(sc, x, 0.5f), py = __builtin_fmaf(sc, y, 0.5f);
+    const float fx = floorf(px), fy = floorf(py);
+    px -= fx;
+    py -= fy;
+    const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+    union { uint2 u; h4_t h; } c[4];
+    float w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
+        w[k] = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
+        uint32_t idx = cx + cy * res;
+        if (idx >= n_level) {
+            idx -= n_level;
+            if (idx >= n_level) idx %= n_level;
+        }
+        c[k].u = grid[lo + idx];      // the grid as the half-precision network holds it
+    }
+    float4 f = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f.x += w[k] * (float)c[k].h[0]; f.y += w[k] * (float)c[k].h[1];
+        f.z += w[k] * (float)c[k].h[2]; f.w += w[k] * (float)c[k].h[3];
+    }
+    return h4_t{(_Float16)f.x, (_Float16)f.y, (_Float16)f.z, (_Float16)f.w};
+}
+
+// The four matrices on one 16-point unit, reference network shape (32 -> 64 -> 64 -> 64 -> 48).  Lane l = (i = l & 15,
+// g = l >> 4) supplies in[h] = the encoding of levels g + 4h of point i and receives out[rt][c] = output
+// 16 rt + 4 g + c of point i, rounded to f16 like the network's outputs.  `wf` = the fragment part of the image
+// (LDS), w_off4[l] = w_off[l] / 4.  Must be called by all 64 lanes together.
+__device__ __forceinline__ void half_mlp_unit(const uint2 *wf, const uint32_t (&w_off4)[4], int lane, const h4_t (&in)[2], h4_t (&out)[3])
+{
+    const h4_t zero = h4_t{(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+    h4_t b[4] = {in[0], in[1], zero, zero};
+    f32x4_t acc[4];
+#pragma unroll
+    for (int layer = 0; layer < 3; ++layer) {
+        const int KT = layer == 0 ? 2 : 4;
+        const uint2 *w = wf + w_off4[layer];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+            if (kt < KT) {
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    union { uint2 u; h4_t h; } a;
+                    a.u = w[(rt * KT + kt) * 64 + lane];
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, b[kt], acc[rt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) b[rt] = __builtin_elementwise_max(__builtin_convertvector(acc[rt], h4_t), zero);
+    }
+    const uint2 *w3 = wf + w_off4[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) acc[rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) {
+            union { uint2 u; h4_t h; } a;
+            a.u = w3[(rt * 4 + kt) * 64 + lane];
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, b[kt], acc[rt], 0, 0, 0);
+        }
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) out[rt] = __builtin_convertvector(acc[rt], h4_t);
+}
+
+}  // namespace wost

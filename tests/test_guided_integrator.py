@@ -653,3 +653,47 @@ def test_gpu_half_precision_network_mode_is_unbiased_and_no_noisier(oracle):
     assert abs(float(e16.mean())) < 4e-3 and abs(float(e32.mean())) < 4e-3     # both unbiased
     r32, r16 = float(np.sqrt((e32 ** 2).mean())), float(np.sqrt((e16 ** 2).mean()))
     assert r16 < 1.15 * r32, (r16, r32)                                        # variance not worse (same spp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["box", "ladybug", "wiggly", "source"])
+def test_gpu_fused_sample_kernel_equals_the_per_depth_launches(scene, oracle, monkeypatch):
+    """With the half-precision network a whole sample runs in ONE launch: walkers stay in their lanes from
+    depth to depth and every wave evaluates the network for its own walkers (guided_sample_kernel).  Per pixel
+    nothing changes -- same draws, same network arithmetic, same records -- so the field, the statistics and
+    the trained weights equal those of the one-launch-per-depth path (WOST_GUIDED_FUSED=0) bit for bit."""
+    from elaina_amd import Problem
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    if scene == "box":
+        prob, aabb, w, h, eps, depth = laplace_box(), AABB, 64, 48, EPS, 40
+    elif scene == "ladybug":
+        prob, aabb, w, h, eps, depth = Problem.load_scene("ladybug"), ((-100.0, -100.0), (600.0, 600.0)), 96, 96, 1.0, 64
+    elif scene == "wiggly":
+        # 3000-segment emissive Neumann boundary: tree queries and Neumann sampling inside the step
+        from conftest import wiggly_problem
+        prob, aabb, w, h, eps, depth = wiggly_problem(emissive=True), ((-140.0, -140.0), (140.0, 140.0)), 36, 28, EPS, 40
+    else:
+        from test_oracle_solver import _poisson_disc
+        prob, aabb, w, h, eps, depth = _poisson_disc(), ((-1.2, -1.2), (1.2, 1.2)), 40, 40, EPS, 48
+    out = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("WOST_GUIDED_FUSED", fused)
+        st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=10, trainSppCount=6, maxWalkingDepth=depth, epsilonShell=eps,
+                                      maxGuidedDepthInTrainingPhase=5, maxGuidedDepthInGuidingPhase=7, batchSize=4096, minBatchSize=512,
+                                      trainPixelStride=2)
+        gi = GuidedIntegrator(prob, st, aabb, seed=11)
+        gi.network.set_option("precision", 16)
+        gi.network.set_option("train_precision", 16)
+        gi.solve()
+        stats = dict(gi.last_stats)
+        out[fused] = (gi.solution.copy(), gi.network.params(), gi.network.inference_params(), stats)
+        gi.close()
+    (f0, p0, i0, s0), (f1, p1, i1, s1) = out["0"], out["1"]
+    assert s1["kernel_launches"] < s0["kernel_launches"]
+    for k in ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated", "neumann_hits", "guided_steps", "net_points",
+              "train_samples", "optimizer_steps"):
+        assert s0[k] == s1[k], (k, s0[k], s1[k])
+    assert s1["optimizer_steps"] > 0 and s1["guided_steps"] > 0
+    assert np.isfinite(f1).all()
+    assert np.array_equal(p0, p1) and np.array_equal(i0, i1)
+    assert np.array_equal(f0, f1), float(np.abs(f0 - f1).max())
