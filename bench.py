@@ -299,7 +299,8 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
         "shared_network": bool(args.shared_network and env.world > 1),
         "network_precision": ("f16 inference (v_mfma_f32_16x16x16_f16), " if half else "fp32 inference (v_mfma_f32_16x16x4_f32), ") +
                              ("f16 training passes, fp32 master weights" if half_train else "fp32 training"),
-        "roofline_mfma": {"bound": "mfma", "kernel": ("net_forward_h_kernel" if half else "net_forward_mfma_kernel") + " (inference launches, HIP events)",
+        "roofline_mfma": {"bound": "mfma", "kernel": ("guided_sample_kernel (f16 network evaluated inside the walk kernel: not timed apart)" if half and not infer_s
+                                                      else ("net_forward_h_kernel" if half else "net_forward_mfma_kernel") + " (inference launches, HIP events)"),
                           "achieved": infer_tf, "peak": peak_tf, "unit": "TFLOP/s",
                           "frac": (infer_tf / peak_tf) if infer_tf else None,
                           "flop_per_point": FLOP_PER_POINT, "points_per_pass": net_points / steps,
@@ -411,6 +412,8 @@ def main():
         else:
             r5 = run_guided(env, "ladybug", 2048, 1024, 256, 0, 1, 0, args)
             extras["cfg5"] = r5["out"]
+            r5h = run_guided(env, "ladybug", 2048, 1024, 256, 0, 1, 0, args, precision=16)
+            extras["cfg5_f16"] = r5h["out"]
     if env.rank == 0:
         if extras:
             line["configs"] = extras

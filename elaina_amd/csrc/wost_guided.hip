@@ -25,6 +25,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <new>
 #include <string>
@@ -164,6 +165,10 @@ struct GParams {
     int32_t max_guided_depth;
     int32_t stack_words;      // LDS words of a lane's traversal stack
     int32_t wait_weight, trav_burst;
+    int32_t n_samples;        // samples of every pixel in this launch (> 1 only when nothing is trained in between)
+    unsigned long long *dbg;  // WOST_GUIDED_DEBUG: [0] first start, [1] first wave out of pixels, [2] last wave out of pixels, [3] end (100 MHz ticks)
+    float *walk_len;          // per pixel: running mean of the walk length (steps), written at every walk end
+    const uint32_t *order;    // slot -> pixel of this launch (long walks first), nullptr: tile order
 };
 
 // the half-precision network as the fused kernel needs it
@@ -566,6 +571,55 @@ __global__ __launch_bounds__(256) void sample_kernel(GParams P)
     if (P.last_depth) wave_count(alive_after, &my_stats(P.stats)->truncated);
 }
 
+// ---- launch order of the fused sample kernel: pixels whose walks tend to be long go first ----------
+// A sample ends when its longest walk ends, and a 64-step walk takes over a millisecond of pure latency: started
+// last it idles the whole chip.  The pixels are bucketed by the running mean of their walk length (the order
+// has no influence on any result) and the buckets are laid out longest first.
+constexpr int kOrderBuckets = 8;
+__device__ __forceinline__ int order_bucket(float len)
+{
+    return len >= 24.0f ? 0 : len >= 16.0f ? 1 : len >= 12.0f ? 2 : len >= 9.0f ? 3 : len >= 7.0f ? 4 : len >= 5.0f ? 5 : len >= 3.0f ? 6 : 7;
+}
+
+// pass 0: bucket sizes; pass 1: scatter (cnt[8..15] = running offsets, initialised by order_offsets_kernel)
+template <int PASS>
+__global__ __launch_bounds__(256) void order_kernel(GParams P, uint32_t *cnt, uint32_t *order)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    int p = s;
+    const bool in = s < P.n_pixels;
+    if (in && ((P.st.width | P.st.height) & 7) == 0) {
+        const int tiles_x = P.st.width >> 3, tile = p >> 6, in_tile = p & 63;
+        p = ((tile / tiles_x) * 8 + (in_tile >> 3)) * P.st.width + (tile % tiles_x) * 8 + (in_tile & 7);
+    }
+    const int b = in ? order_bucket(P.walk_len[p]) : -1;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < kOrderBuckets; ++k) {
+        const unsigned long long bal = __ballot(b == k);
+        if (!bal) continue;
+        if (PASS == 0) {
+            if (lane == 0) atomicAdd(cnt + k, (uint32_t)__popcll(bal));
+        } else {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(cnt + kOrderBuckets + k, (uint32_t)__popcll(bal));
+            base = __shfl(base, 0);
+            if (b == k) order[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)p;
+        }
+    }
+}
+
+__global__ void order_offsets_kernel(uint32_t *cnt)
+{
+    if (threadIdx.x == 0) {
+        uint32_t off = 0;
+        for (int k = 0; k < kOrderBuckets; ++k) {
+            cnt[kOrderBuckets + k] = off;
+            off += cnt[k];
+        }
+    }
+}
+
 // ---- a whole sample in one launch (half-precision network only) -----------------------------------
 // The guiding network is small: its f16 weight fragments take 26 KB of LDS and its grid 123 KB of L2, and one
 // evaluation is 52 matrix instructions per 16 walkers.  So a wave can evaluate the network for its OWN walkers,
@@ -578,10 +632,10 @@ __global__ __launch_bounds__(256) void sample_kernel(GParams P)
 // Per pixel the arithmetic and the order of the random draws are those of separate_kernel / sample_kernel /
 // tail_kernel, and the network arithmetic is that of net_forward_h_kernel (same device functions): the field,
 // the training records and hence the trained weights are bit-identical to the one-launch-per-depth path.
-constexpr int kFusedThreads = 768;       // twelve waves per CU share one copy of the weight fragments
+constexpr int kFusedThreadsMax = 768;    // up to twelve waves per CU share one copy of the weight fragments
 constexpr int kXchWords = 128 + 16 * 48 / 2;   // per wave: 64 network inputs (x, y), 16 x 48 f16 outputs
 
-template <bool EMISSIVE, bool TREE, bool SOURCE>
+template <bool EMISSIVE, bool TREE, bool SOURCE, int kFusedThreads>
 __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P, FusedNet F)
 {
     extern __shared__ uint32_t lds_all[];
@@ -614,11 +668,14 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
     int depth = 0;
     Pcg rng{0, 1};
     Trav T = trav_begin(Closest{WOST_INF, -1});
+    int left = 0;                          // samples this lane still owes its pixel
     uint32_t pool_next = 0, pool_end = 0;
     uint32_t c_steps = 0, c_started = 0, c_abs = 0, c_trunc = 0, c_hits = 0, c_guided = 0, c_net = 0;
     const bool has_d = P.dm.n_segs > 0;
     const uint32_t n_slots = (uint32_t)P.n_pixels;
     const bool tiled = ((P.st.width | P.st.height) & 7) == 0;
+    bool dbg_out = false;
+    if (P.dbg && lane == 0) atomicMin(P.dbg + 0, wall_clock64());
 
     for (;;) {
         // ---- lanes without a walker take the next pixel of the launch (begin_sample_kernel) ----
@@ -641,9 +698,17 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
             if (mode == MODE_REFILL) {
                 if (s2 >= n_slots) {
                     mode = MODE_DONE;
+                    if (P.dbg && !dbg_out) {
+                        dbg_out = true;
+                        const unsigned long long t = wall_clock64();
+                        atomicMin(P.dbg + 1, t);
+                        atomicMax(P.dbg + 2, t);
+                    }
                 } else {
                     int p = (int)s2;
-                    if (tiled) {
+                    if (P.order) {
+                        p = (int)P.order[s2];
+                    } else if (tiled) {
                         const int tiles_x = P.st.width >> 3, tile = p >> 6, in_tile = p & 63;
                         p = ((tile / tiles_x) * 8 + (in_tile >> 3)) * P.st.width + (tile % tiles_x) * 8 + (in_tile & 7);
                     }
@@ -653,6 +718,7 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
                         P.rng[p] = r0.state;
                         P.sol[3 * (size_t)p] = 0.0f; P.sol[3 * (size_t)p + 1] = 0.0f; P.sol[3 * (size_t)p + 2] = 0.0f;
                         P.hint0[p] = 0;
+                        P.walk_len[p] = 0.0f;
                     }
                     P.cur_depth[p] = 0;
                     const int px = p % P.st.width, py = p / P.st.width;
@@ -664,11 +730,12 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
                         on_n = false; thp = 1.0f; nx = 0.0f; ny = 0.0f; depth = 0;
                         hint = P.hint0[p];
                         rng.state = P.rng[p];
+                        left = P.n_samples;
                         ++c_started;
                         if (!has_d) {
                             T.best = Closest{WOST_INF, -1};
                             mode = MODE_WAIT;
-                        } else if (!P.first_sample) {
+                        } else if (!P.first_sample) {   // (a first-sample launch traverses once, its later samples use the cache too)
                             // the evaluation point of a pixel is the same for every sample: its query is cached
                             T.best = Closest{P.d0_d2[p], hint};
                             mode = MODE_WAIT;
@@ -687,14 +754,15 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
             if (__ballot(mode == MODE_REFILL)) continue;
             break;
         }
-        if (n_wait * P.wait_weight >= n_trav * 8) {
+        const bool step_phase = n_wait * P.wait_weight >= n_trav * 8;
+        if (step_phase) {
             // ---- step phase -------------------------------------------------------------------
             const bool act = mode == MODE_WAIT;
             int status = SEP_DROPPED;
             float R_B = 0.0f;
             if (act) {
                 ++c_steps;
-                if (has_d && depth == 0 && P.first_sample) P.d0_d2[pid] = T.best.d2;
+                if (has_d && depth == 0 && P.first_sample && left == P.n_samples) P.d0_d2[pid] = T.best.d2;
                 status = separate_finish<EMISSIVE, TREE, SOURCE>(P, pid, on_n, x, y, thp, nx, ny, depth, T.best, hint, R_B, rng, stk);
                 if (status == SEP_ABSORBED) ++c_abs;
             }
@@ -763,7 +831,23 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
                 }
                 if (ended) {
                     P.rng[pid] = rng.state;
-                    mode = MODE_REFILL;
+                    // scheduling hint only (order_kernel): how long the walks of this pixel tend to be
+                    const float len = (float)(depth + (keep ? 0 : 1));
+                    P.walk_len[pid] = P.first_sample ? len : 0.75f * P.walk_len[pid] + 0.25f * len;
+                    if (--left > 0) {
+                        // the next sample of the same pixel starts right away (guiding phase: nothing is trained in
+                        // between, and the pixel's random stream simply continues)
+                        const int px = (int)pid % P.st.width, py = (int)pid / P.st.width;
+                        eval_point(P.probe, px, py, P.st.width, P.st.height, x, y);
+                        on_n = false; thp = 1.0f; nx = 0.0f; ny = 0.0f; depth = 0;
+                        P.cur_depth[pid] = 0;
+                        hint = P.hint0[pid];
+                        T.best = has_d ? Closest{P.d0_d2[pid], hint} : Closest{WOST_INF, -1};
+                        ++c_started;
+                        mode = MODE_WAIT;
+                    } else {
+                        mode = MODE_REFILL;
+                    }
                 } else if (has_d) {
                     T = trav_begin(slot_candidate(P.dm, hint, x, y));
                     mode = MODE_TRAV;
@@ -781,6 +865,7 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
             }
         }
     }
+    if (P.dbg && lane == 0) atomicMax(P.dbg + 3, wall_clock64());
     const uint32_t s_steps = wave_sum(c_steps), s_st = wave_sum(c_started), s_abs = wave_sum(c_abs), s_tr = wave_sum(c_trunc),
                    s_hit = wave_sum(c_hits), s_g = wave_sum(c_guided), s_net = wave_sum(c_net);
     if (lane == 0) {
@@ -934,6 +1019,9 @@ struct wost_guided {
     int32_t *hint0 = nullptr;
     float *d0_d2 = nullptr;            // fused sample kernel: cached query of every evaluation point
     uint32_t *cursor = nullptr;        // fused sample kernel: next pixel slot of the launch
+    unsigned long long *dbg = nullptr; // fused sample kernel: WOST_GUIDED_DEBUG timeline
+    float *walk_len = nullptr;         // fused sample kernel: running mean of every pixel's walk length
+    uint32_t *order = nullptr, *order_cnt = nullptr;   // launch order (long walks first) and its bucket counters
     GStatsDev *stats = nullptr;
     uint32_t *block_sums = nullptr;
     int n_train_blocks = 0, n_train_pixels = 0;
@@ -1043,7 +1131,7 @@ int wost_guided_create(const wost_scene_desc *scene, const wost_guided_settings 
     GA(g->counts, 2); GA(g->rng, N); GA(g->sol, 3 * N); GA(g->field, 3 * N);
     GA(g->rec, (size_t)kMaxTrainDepth * kRecFields * N);
     GA(g->net_in, 2 * N); GA(g->net_out, 33 * N); GA(g->cur_depth, N); GA(g->hint0, N); GA(g->stats, kStatCopies);
-    GA(g->d0_d2, N); GA(g->cursor, 1);
+    GA(g->dbg, 4); GA(g->d0_d2, N); GA(g->cursor, 1); GA(g->walk_len, N); GA(g->order, N); GA(g->order_cnt, 2 * kOrderBuckets);
     // sized for offset 0 (the largest set); the offset of a solve may be drawn per solve (run_guided)
     g->n_train_pixels = (int)((N + (size_t)s->train_pixel_stride - 1) / (size_t)s->train_pixel_stride);
     g->n_train_blocks = (g->n_train_pixels + 255) / 256;
@@ -1217,10 +1305,15 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         }
     }
     P.d0_d2 = g->d0_d2; P.cursor = g->cursor; P.stack_words = stack_words;
-    P.wait_weight = 8; P.trav_burst = 3;
+    P.wait_weight = 4; P.trav_burst = 10;     // measured on config 4 (tools/scratch/fused_sweep.sh)
+    P.walk_len = g->walk_len; P.order = nullptr;
+    const char *order_env = std::getenv("WOST_GUIDED_ORDER");
+    const int order_every = order_env ? std::atoi(order_env) : 0;      // re-bucket every so many samples (0: never)
     if (const char *w = std::getenv("WOST_GUIDED_WAIT_WEIGHT")) P.wait_weight = std::max(1, std::atoi(w));
     if (const char *w = std::getenv("WOST_GUIDED_TRAV_BURST")) P.trav_burst = std::max(1, std::atoi(w));
-    const size_t lds_fused = ((size_t)stack_words * kFusedThreads + (size_t)(kFusedThreads / 64) * kXchWords) * sizeof(uint32_t) +
+    int fused_threads = kFusedThreadsMax;
+    if (const char *w = std::getenv("WOST_GUIDED_FUSED_THREADS")) fused_threads = std::atoi(w) == 512 ? 512 : kFusedThreadsMax;
+    const size_t lds_fused = ((size_t)stack_words * fused_threads + (size_t)(fused_threads / 64) * kXchWords) * sizeof(uint32_t) +
                              (size_t)F.n_frag * sizeof(uint2);
 
     // ctor state (integrator.cu:1158-1160), prepareSolve (:125-126)
@@ -1237,21 +1330,64 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         P.training = training ? 1 : 0;
         P.uniform_fraction = uniform_fraction;
         P.first_sample = sample == 0;
+        int n_run = 1;      // samples this iteration covers
         if (fused) {
+            if (!training) {
+                // nothing is trained between the remaining samples: one launch runs them all, up to the next
+                // intermediate frame the caller asked for
+                int last = s.spp - 1;
+                if (g->frame_fn) {
+                    for (int j = sample; j < s.spp; ++j) {
+                        const bool by_spp = g->frame_spp_every > 0 && j % g->frame_spp_every == 0 && j < g->frame_spp_until;
+                        const bool by_time = g->frame_time_every > 0 && j % g->frame_time_every == 0;
+                        if (by_spp || by_time) { last = j; break; }
+                    }
+                }
+                n_run = last - sample + 1;
+                // a pixel's samples run one after the other in one lane, so the last pixels taken keep a few lanes busy for
+                // n_run walks while the chip idles: bounded launches keep that tail short against the launch itself
+                int cap = 64;
+                if (const char *w = std::getenv("WOST_GUIDED_SAMPLES_PER_LAUNCH")) cap = std::max(1, std::atoi(w));
+                n_run = std::min(n_run, cap);
+            }
+            P.n_samples = n_run;
             P.max_guided_depth = max_guided_depth;
             G_TRY(hipMemsetAsync(g->cursor, 0, sizeof(uint32_t), stream));
-            const unsigned gridf = (unsigned)std::min<size_t>(256, ((size_t)N + kFusedThreads - 1) / kFusedThreads);
+            const bool dbg = std::getenv("WOST_GUIDED_DEBUG") != nullptr;
+            P.dbg = dbg ? g->dbg : nullptr;
+            if (dbg) {
+                const unsigned long long init[4] = {~0ull, ~0ull, 0ull, 0ull};
+                G_TRY(hipMemcpyAsync(g->dbg, init, sizeof(init), hipMemcpyHostToDevice, stream));
+                G_TRY(hipStreamSynchronize(stream));
+            }
+            if (order_every > 0 && sample > 0 && (sample == 1 || sample % order_every == 0)) {
+                G_TRY(hipMemsetAsync(g->order_cnt, 0, 2 * kOrderBuckets * sizeof(uint32_t), stream));
+                hipLaunchKernelGGL((order_kernel<0>), dim3((N + 255) / 256), dim3(256), 0, stream, P, g->order_cnt, g->order);
+                hipLaunchKernelGGL(order_offsets_kernel, dim3(1), dim3(64), 0, stream, g->order_cnt);
+                hipLaunchKernelGGL((order_kernel<1>), dim3((N + 255) / 256), dim3(256), 0, stream, P, g->order_cnt, g->order);
+                launches += 3;
+                P.order = g->order;
+            }
+            const unsigned gridf = (unsigned)std::min<size_t>(256, ((size_t)N + fused_threads - 1) / fused_threads);
 #define LAUNCH_FUSED(E, T)                                                                                                      \
     do {                                                                                                                        \
-        auto kfn = v.src.rgb ? guided_sample_kernel<E, T, true> : guided_sample_kernel<E, T, false>;                             \
+        auto kfn = v.src.rgb ? (fused_threads == 512 ? guided_sample_kernel<E, T, true, 512> : guided_sample_kernel<E, T, true, 768>)    \
+                             : (fused_threads == 512 ? guided_sample_kernel<E, T, false, 512> : guided_sample_kernel<E, T, false, 768>); \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused); \
-        hipLaunchKernelGGL(kfn, dim3(gridf), dim3(kFusedThreads), lds_fused, stream, P, F);                                       \
+        hipLaunchKernelGGL(kfn, dim3(gridf), dim3(fused_threads), lds_fused, stream, P, F);                                       \
     } while (0)
             if (emissive) { if (tree) LAUNCH_FUSED(true, true); else LAUNCH_FUSED(true, false); }
             else          { if (tree) LAUNCH_FUSED(false, true); else LAUNCH_FUSED(false, false); }
 #undef LAUNCH_FUSED
             ++launches;
             G_TRY(hipGetLastError());
+            if (dbg) {
+                unsigned long long t[4];
+                G_TRY(hipMemcpy(t, g->dbg, sizeof(t), hipMemcpyDeviceToHost));
+                std::fprintf(stderr, "[fused sample %d x%d] first wave out of pixels at %.1f us, last at %.1f us, end %.1f us\n", sample, n_run,
+                             (double)(t[1] - t[0]) / 100.0, (double)(t[2] - t[0]) / 100.0, (double)(t[3] - t[0]) / 100.0);
+            }
+            sample += n_run - 1;     // the index of the last sample this launch has run
         }
         int cur = 0;     // queue holding the evaluation points of this depth
         if (!fused) {
