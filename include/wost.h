@@ -219,7 +219,12 @@ int wost_net_inference(wost_net_handle h, const float *xy, int32_t n, float *out
 /* "precision": 32 (default) = fp32 everywhere, bit-exact against the CPU restatement; 16 = the reference's own
  * network precision for inference (tiny-cuda-nn FullyFusedMLP + grid in half, util/network.h:21-196,
  * data/ladybug/n.json:61-67): f16 weights / activations / grid values, fp32 accumulation on
- * v_mfma_f32_16x16x16_f16.  Training keeps fp32 master weights and fp32 arithmetic in both modes. */
+ * v_mfma_f32_16x16x16_f16; the guided solve then runs a whole sample per launch with the network evaluated inside
+ * the walk kernel (same field and records as the per-depth launches).
+ * "train_precision": 32 (default) or 16 = forward / backward / weight-gradient passes of a training step in that
+ * half-precision arithmetic (tiny-cuda-nn trains in half with loss scale 128, guided/parameters.h:13); with 16,
+ * wost_net_inference(use_inference_params = 0) evaluates the training weights the way a training step does.
+ * Master weights, Adam and the EMA are fp32 in every mode; gradient sums are 64-bit fixed point (reproducible). */
 int wost_net_set_option(wost_net_handle h, const char *key, double value);
 /* One training step (integrator/guided/integrator.cu:655-662: network->forward, ->backward,
  * trainer->optimizer_step(TRAIN_LOSS_SCALE)): forward with the training parameters, backward of
