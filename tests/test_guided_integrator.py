@@ -697,3 +697,93 @@ def test_gpu_fused_sample_kernel_equals_the_per_depth_launches(scene, oracle, mo
     assert np.isfinite(f1).all()
     assert np.array_equal(p0, p1) and np.array_equal(i0, i1)
     assert np.array_equal(f0, f1), float(np.abs(f0 - f1).max())
+
+
+@pytest.mark.gpu
+def test_gpu_fused_sample_kernel_edge_cases(monkeypatch):
+    """the fused path against the per-depth path where the launch logic differs: a masked ragged frame (row-major
+    pixel order), pixel shards, one step per walk, guiding only after the training phase, guided depth beyond
+    the walk depth, no training at all (all samples in one launch), and a solve repeated on the same handle"""
+    import torch
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    prob = laplace_box()
+
+    def run(fused, w, h, spp, train, depth, mgd=(5, 7), uf=(0.5, 0.5), shard=None, stride=1, twice=False):
+        monkeypatch.setenv("WOST_GUIDED_FUSED", fused)
+        st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=train, maxWalkingDepth=depth, epsilonShell=EPS,
+                                      uniformFractionInTrainingPhase=uf[0], uniformFractionInGuidingPhase=uf[1],
+                                      maxGuidedDepthInTrainingPhase=mgd[0], maxGuidedDepthInGuidingPhase=mgd[1], batchSize=1024,
+                                      minBatchSize=256, trainPixelStride=stride)
+        gi = GuidedIntegrator(prob, st, AABB, seed=5)
+        gi.network.set_option("precision", 16)
+        gi.network.set_option("train_precision", 16)
+        outs = []
+        for _ in range(2 if twice else 1):
+            if shard is None:
+                gi.solve()
+                f = gi.solution.copy()
+            else:
+                buf = torch.full((w * h * 3,), 7.0, device="cuda")
+                gi.solve_sharded(shard[0], shard[1], buf.data_ptr())
+                torch.cuda.synchronize()
+                f = buf.cpu().numpy().reshape(-1, 3)
+            st_ = {k: v for k, v in gi.last_stats.items() if k in ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated",
+                                                                    "neumann_hits", "guided_steps", "net_points", "train_samples")}
+            outs.append((f, gi.network.params(), st_))
+        gi.close()
+        return outs
+
+    cases = {
+        "masked ragged frame, training pixel stride": dict(w=37, h=19, spp=6, train=4, depth=32, stride=2),
+        "shard 1 of 3": dict(w=40, h=24, spp=6, train=3, depth=32, shard=(1, 3)),
+        "one step per walk": dict(w=24, h=24, spp=3, train=10, depth=1),
+        "guided depth beyond the walk depth": dict(w=24, h=24, spp=3, train=1, depth=6, mgd=(50, 50)),
+        "guiding only in the second phase": dict(w=24, h=24, spp=6, train=3, depth=24, mgd=(0, 10), uf=(0.5, 0.0)),
+        "no training: every sample in one launch": dict(w=32, h=32, spp=9, train=0, depth=40),
+        "two solves on one handle": dict(w=24, h=16, spp=4, train=2, depth=24, twice=True),
+    }
+    for name, kw in cases.items():
+        if name.startswith("masked"):
+            prob.mask = (np.arange(37 * 19) % 5 != 0).astype(np.uint8)
+        a, b = run("0", **kw), run("1", **kw)
+        prob.mask = None
+        for (f0, p0, s0), (f1, p1, s1) in zip(a, b):
+            assert s0 == s1, (name, s0, s1)
+            assert np.array_equal(p0, p1), name
+            assert np.array_equal(f0, f1), (name, float(np.abs(f0 - f1).max()))
+        if name.startswith("masked"):
+            assert np.all(b[0][0][(np.arange(37 * 19) % 5) == 0] == 0)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_sample_kernel_intermediate_frames(monkeypatch):
+    """intermediate frames cut the multi-sample launches of the guiding phase at the samples the caller asked for:
+    the frames (and the samples they arrive after) are those of the per-depth path"""
+    import ctypes as C
+    from elaina_amd import capi
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    prob = laplace_box()
+    w, h = 24, 16
+    got = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("WOST_GUIDED_FUSED", fused)
+        st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=14, trainSppCount=3, maxWalkingDepth=24, epsilonShell=EPS,
+                                      batchSize=1024, minBatchSize=256)
+        gi = GuidedIntegrator(prob, st, AABB, seed=5)
+        gi.network.set_option("precision", 16)
+        frames = []
+
+        def cb(user, reason, sample, ms, field):
+            frames.append((reason, sample, np.ctypeslib.as_array(field, shape=(w * h * 3,)).copy()))
+            return 0
+
+        fn = capi.FRAME_FN(cb)
+        assert gi.lib.wost_guided_set_frame_callback(gi._handle, fn, None, 4, 10, 5) == 0      # spp frames at 0, 4, 8; time frames at 0, 5, 10
+        gi.solve()
+        got[fused] = (frames, gi.solution.copy())
+        gi.close()
+    (fa, sa), (fb, sb) = got["0"], got["1"]
+    assert [(r, k) for r, k, _ in fa] == [(r, k) for r, k, _ in fb] == [(0, 0), (1, 0), (0, 4), (1, 5), (0, 8), (1, 10)]
+    for (_, _, x), (_, _, y) in zip(fa, fb):
+        assert np.array_equal(x, y)
+    assert np.array_equal(sa, sb)
