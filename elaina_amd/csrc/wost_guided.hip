@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/wost.h"
@@ -166,16 +167,18 @@ struct GParams {
     int32_t stack_words;      // LDS words of a lane's traversal stack
     int32_t wait_weight, trav_burst;
     int32_t n_samples;        // samples of every pixel in this launch (> 1 only when nothing is trained in between)
+    int32_t d0_valid;         // d0_d2 holds the query of every evaluation point (after the first fused launch of a solve)
     unsigned long long *dbg;  // WOST_GUIDED_DEBUG: [0] first start, [1] first wave out of pixels, [2] last wave out of pixels, [3] end (100 MHz ticks)
-    float *walk_len;          // per pixel: running mean of the walk length (steps), written at every walk end
-    const uint32_t *order;    // slot -> pixel of this launch (long walks first), nullptr: tile order
 };
 
-// the half-precision network as the fused kernel needs it
+// the network as the fused kernel needs it: half precision (image) or fp32 (frag32 / grid32)
 struct FusedNet {
-    const uint2 *image;       // MFMA fragments (n_frag entries), then the grid entries
+    const uint2 *image;       // half: MFMA fragments (n_frag entries of 8 bytes), then the grid entries
     uint32_t n_frag;
     uint32_t w_off4[4];
+    const float *frag32, *grid32;   // fp32: MFMA fragments (n_mlp floats) and the grid of the inference weights
+    uint32_t n_mlp;
+    uint32_t w_off[4];
     float scale[8];
     uint32_t res[8], off[9];
 };
@@ -571,55 +574,6 @@ __global__ __launch_bounds__(256) void sample_kernel(GParams P)
     if (P.last_depth) wave_count(alive_after, &my_stats(P.stats)->truncated);
 }
 
-// ---- launch order of the fused sample kernel: pixels whose walks tend to be long go first ----------
-// A sample ends when its longest walk ends, and a 64-step walk takes over a millisecond of pure latency: started
-// last it idles the whole chip.  The pixels are bucketed by the running mean of their walk length (the order
-// has no influence on any result) and the buckets are laid out longest first.
-constexpr int kOrderBuckets = 8;
-__device__ __forceinline__ int order_bucket(float len)
-{
-    return len >= 24.0f ? 0 : len >= 16.0f ? 1 : len >= 12.0f ? 2 : len >= 9.0f ? 3 : len >= 7.0f ? 4 : len >= 5.0f ? 5 : len >= 3.0f ? 6 : 7;
-}
-
-// pass 0: bucket sizes; pass 1: scatter (cnt[8..15] = running offsets, initialised by order_offsets_kernel)
-template <int PASS>
-__global__ __launch_bounds__(256) void order_kernel(GParams P, uint32_t *cnt, uint32_t *order)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    int p = s;
-    const bool in = s < P.n_pixels;
-    if (in && ((P.st.width | P.st.height) & 7) == 0) {
-        const int tiles_x = P.st.width >> 3, tile = p >> 6, in_tile = p & 63;
-        p = ((tile / tiles_x) * 8 + (in_tile >> 3)) * P.st.width + (tile % tiles_x) * 8 + (in_tile & 7);
-    }
-    const int b = in ? order_bucket(P.walk_len[p]) : -1;
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 0; k < kOrderBuckets; ++k) {
-        const unsigned long long bal = __ballot(b == k);
-        if (!bal) continue;
-        if (PASS == 0) {
-            if (lane == 0) atomicAdd(cnt + k, (uint32_t)__popcll(bal));
-        } else {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(cnt + kOrderBuckets + k, (uint32_t)__popcll(bal));
-            base = __shfl(base, 0);
-            if (b == k) order[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)p;
-        }
-    }
-}
-
-__global__ void order_offsets_kernel(uint32_t *cnt)
-{
-    if (threadIdx.x == 0) {
-        uint32_t off = 0;
-        for (int k = 0; k < kOrderBuckets; ++k) {
-            cnt[kOrderBuckets + k] = off;
-            off += cnt[k];
-        }
-    }
-}
-
 // ---- a whole sample in one launch (half-precision network only) -----------------------------------
 // The guiding network is small: its f16 weight fragments take 26 KB of LDS and its grid 123 KB of L2, and one
 // evaluation is 52 matrix instructions per 16 walkers.  So a wave can evaluate the network for its OWN walkers,
@@ -632,22 +586,34 @@ __global__ void order_offsets_kernel(uint32_t *cnt)
 // Per pixel the arithmetic and the order of the random draws are those of separate_kernel / sample_kernel /
 // tail_kernel, and the network arithmetic is that of net_forward_h_kernel (same device functions): the field,
 // the training records and hence the trained weights are bit-identical to the one-launch-per-depth path.
-constexpr int kFusedThreadsMax = 768;    // up to twelve waves per CU share one copy of the weight fragments
-constexpr int kXchWords = 128 + 16 * 48 / 2;   // per wave: 64 network inputs (x, y), 16 x 48 f16 outputs
+// waves per CU sharing one copy of the weight fragments: 12 with the f16 fragments (26 KB), 10 with the fp32 ones (53 KB)
+constexpr int fused_threads(bool half) { return half ? 768 : 640; }
+// per wave: 64 network inputs (x, y), then 16 x 48 outputs (f16 / fp32; the fp32 unit stages its encoding in the same words)
+constexpr int fused_xch_words(bool half) { return half ? 128 + 16 * 48 / 2 : 128 + 16 * 48; }
+constexpr int kStageStride = 32 + 2;     // fp32 unit: staged encoding rows, padded like net_forward_mfma_kernel's
 
-template <bool EMISSIVE, bool TREE, bool SOURCE, int kFusedThreads>
-__global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P, FusedNet F)
+template <bool EMISSIVE, bool TREE, bool SOURCE, bool HALF>
+__global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GParams P, FusedNet F)
 {
+    constexpr int kFusedThreads = fused_threads(HALF), kXchWords = fused_xch_words(HALF);
     extern __shared__ uint32_t lds_all[];
     __shared__ float s_scale[8];
     __shared__ uint32_t s_res[8], s_off[9];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // traversal stacks wave by wave (entry i of a lane at [i * 64 + lane]: the column stride must be a power of two)
     const LdsColumn stk{lds_all + (size_t)wave * P.stack_words * 64 + lane, 64u};
-    uint2 *wf = reinterpret_cast<uint2 *>(lds_all + (size_t)P.stack_words * kFusedThreads);
-    float *xch_xy = reinterpret_cast<float *>(wf + F.n_frag) + (size_t)wave * kXchWords;
+    uint32_t *wbase = lds_all + (size_t)P.stack_words * kFusedThreads;
+    uint2 *wf = reinterpret_cast<uint2 *>(wbase);               // HALF
+    float *wf32 = reinterpret_cast<float *>(wbase);             // fp32
+    const uint32_t w_words = HALF ? 2u * F.n_frag : F.n_mlp;
+    float *xch_xy = reinterpret_cast<float *>(wbase + w_words) + (size_t)wave * kXchWords;
     _Float16 *xch_out = reinterpret_cast<_Float16 *>(xch_xy + 128);
-    for (uint32_t e = threadIdx.x; e < F.n_frag; e += kFusedThreads) wf[e] = F.image[e];
+    float *xch_out32 = xch_xy + 128;
+    if (HALF) {
+        for (uint32_t e = threadIdx.x; e < F.n_frag; e += kFusedThreads) wf[e] = F.image[e];
+    } else {
+        for (uint32_t e = threadIdx.x; e < F.n_mlp; e += kFusedThreads) wf32[e] = F.frag32[e];
+    }
     if (threadIdx.x < 9) {
         s_off[threadIdx.x] = F.off[threadIdx.x];
         if (threadIdx.x < 8) {
@@ -656,7 +622,7 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
         }
     }
     __syncthreads();
-    const uint2 *grid = F.image + F.n_frag;
+    const uint2 *grid = HALF ? F.image + F.n_frag : nullptr;
     const int li = lane & 15, lg = lane >> 4;
 
     enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5 };
@@ -706,9 +672,7 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
                     }
                 } else {
                     int p = (int)s2;
-                    if (P.order) {
-                        p = (int)P.order[s2];
-                    } else if (tiled) {
+                    if (tiled) {
                         const int tiles_x = P.st.width >> 3, tile = p >> 6, in_tile = p & 63;
                         p = ((tile / tiles_x) * 8 + (in_tile >> 3)) * P.st.width + (tile % tiles_x) * 8 + (in_tile & 7);
                     }
@@ -718,7 +682,6 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
                         P.rng[p] = r0.state;
                         P.sol[3 * (size_t)p] = 0.0f; P.sol[3 * (size_t)p + 1] = 0.0f; P.sol[3 * (size_t)p + 2] = 0.0f;
                         P.hint0[p] = 0;
-                        P.walk_len[p] = 0.0f;
                     }
                     P.cur_depth[p] = 0;
                     const int px = p % P.st.width, py = p / P.st.width;
@@ -735,7 +698,7 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
                         if (!has_d) {
                             T.best = Closest{WOST_INF, -1};
                             mode = MODE_WAIT;
-                        } else if (!P.first_sample) {   // (a first-sample launch traverses once, its later samples use the cache too)
+                        } else if (P.d0_valid) {
                             // the evaluation point of a pixel is the same for every sample: its query is cached
                             T.best = Closest{P.d0_d2[p], hint};
                             mode = MODE_WAIT;
@@ -762,16 +725,17 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
             float R_B = 0.0f;
             if (act) {
                 ++c_steps;
-                if (has_d && depth == 0 && P.first_sample && left == P.n_samples) P.d0_d2[pid] = T.best.d2;
+                if (has_d && depth == 0 && !P.d0_valid && left == P.n_samples) P.d0_d2[pid] = T.best.d2;   // the pixel's first walk of the launch
                 status = separate_finish<EMISSIVE, TREE, SOURCE>(P, pid, on_n, x, y, thp, nx, ny, depth, T.best, hint, R_B, rng, stk);
                 if (status == SEP_ABSORBED) ++c_abs;
             }
             const bool keep = act && status == SEP_KEEP;
             const bool guiding = keep && depth < P.max_guided_depth;
             // ---- the network for the lanes that need it: all 64 lanes take part (matrix instructions) ----
-            _Float16 rawh[33];
+            typedef typename std::conditional<HALF, _Float16, float>::type raw_t;
+            raw_t rawv[33];
 #pragma unroll
-            for (int j = 0; j < 33; ++j) rawh[j] = (_Float16)0.0f;
+            for (int j = 0; j < 33; ++j) rawv[j] = (raw_t)0.0f;
             const unsigned long long bal = __ballot(guiding);
             if (bal) {
                 const int n_need = __popcll(bal);
@@ -788,24 +752,49 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
                 for (int u = 0; 16 * u < n_need; ++u) {
                     const int q = 16 * u + li;
                     const float qx = q < n_need ? xch_xy[2 * q] : 0.5f, qy = q < n_need ? xch_xy[2 * q + 1] : 0.5f;
-                    h4_t enc[2], out[3];
+                    if (HALF) {
+                        h4_t enc[2], out[3];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int lv = lg + 4 * h;
-                        enc[h] = half_encode_level(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], qx, qy);
-                    }
-                    half_mlp_unit(wf, F.w_off4, lane, enc, out);
+                        for (int h = 0; h < 2; ++h) {
+                            const int lv = lg + 4 * h;
+                            enc[h] = half_encode_level(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], qx, qy);
+                        }
+                        half_mlp_unit(wf, F.w_off4, lane, enc, out);
 #pragma unroll
-                    for (int rt = 0; rt < 3; ++rt) {
-                        union { h4_t h; uint2 u; } o;
-                        o.h = out[rt];
-                        *reinterpret_cast<uint2 *>(xch_out + li * 48 + 16 * rt + 4 * lg) = o.u;
+                        for (int rt = 0; rt < 3; ++rt) {
+                            union { h4_t h; uint2 u; } o;
+                            o.h = out[rt];
+                            *reinterpret_cast<uint2 *>(xch_out + li * 48 + 16 * rt + 4 * lg) = o.u;
+                        }
+                    } else {
+                        // the encoding goes through LDS once (point-major rows), as in net_forward_mfma_kernel: the
+                        // matrix instruction wants feature 4 s + g of point i in lane (i, g)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int lv = lg + 4 * h;
+                            const float4 f = f32_encode_level(F.grid32, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], qx, qy);
+                            float2 *st = reinterpret_cast<float2 *>(xch_out32 + li * kStageStride + lv * 4);
+                            st[0] = float2{f.x, f.y};
+                            st[1] = float2{f.z, f.w};
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        float b0[8], out[12];
+#pragma unroll
+                        for (int s_ = 0; s_ < 8; ++s_) b0[s_] = xch_out32[li * kStageStride + 4 * s_ + lg];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        f32_mlp_unit(wf32, F.w_off, lane, b0, out);
+#pragma unroll
+                        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) xch_out32[li * 48 + 16 * rt + 4 * c + lg] = out[4 * rt + c];
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     if (guiding && (rank >> 4) == u) {
 #pragma unroll
-                        for (int j = 0; j < 33; ++j) rawh[j] = xch_out[(rank & 15) * 48 + j];
+                        for (int j = 0; j < 33; ++j) rawv[j] = HALF ? (raw_t)xch_out[(rank & 15) * 48 + j] : (raw_t)xch_out32[(rank & 15) * 48 + j];
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -814,7 +803,7 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
             if (act) {
                 bool ended = !keep;
                 if (keep) {
-                    const auto raw = [&](int j) { return (float)rawh[j]; };
+                    const auto raw = [&](int j) { return (float)rawv[j]; };
                     const SampleOut o = sample_step<TREE>(P, pid, on_n, x, y, thp, nx, ny, R_B, depth, guiding, rng, raw, stk);
                     if (o.guided_step) ++c_guided;
                     if (o.dropped) {
@@ -831,9 +820,6 @@ __global__ __launch_bounds__(kFusedThreads) void guided_sample_kernel(GParams P,
                 }
                 if (ended) {
                     P.rng[pid] = rng.state;
-                    // scheduling hint only (order_kernel): how long the walks of this pixel tend to be
-                    const float len = (float)(depth + (keep ? 0 : 1));
-                    P.walk_len[pid] = P.first_sample ? len : 0.75f * P.walk_len[pid] + 0.25f * len;
                     if (--left > 0) {
                         // the next sample of the same pixel starts right away (guiding phase: nothing is trained in
                         // between, and the pixel's random stream simply continues)
@@ -1020,8 +1006,6 @@ struct wost_guided {
     float *d0_d2 = nullptr;            // fused sample kernel: cached query of every evaluation point
     uint32_t *cursor = nullptr;        // fused sample kernel: next pixel slot of the launch
     unsigned long long *dbg = nullptr; // fused sample kernel: WOST_GUIDED_DEBUG timeline
-    float *walk_len = nullptr;         // fused sample kernel: running mean of every pixel's walk length
-    uint32_t *order = nullptr, *order_cnt = nullptr;   // launch order (long walks first) and its bucket counters
     GStatsDev *stats = nullptr;
     uint32_t *block_sums = nullptr;
     int n_train_blocks = 0, n_train_pixels = 0;
@@ -1131,7 +1115,7 @@ int wost_guided_create(const wost_scene_desc *scene, const wost_guided_settings 
     GA(g->counts, 2); GA(g->rng, N); GA(g->sol, 3 * N); GA(g->field, 3 * N);
     GA(g->rec, (size_t)kMaxTrainDepth * kRecFields * N);
     GA(g->net_in, 2 * N); GA(g->net_out, 33 * N); GA(g->cur_depth, N); GA(g->hint0, N); GA(g->stats, kStatCopies);
-    GA(g->dbg, 4); GA(g->d0_d2, N); GA(g->cursor, 1); GA(g->walk_len, N); GA(g->order, N); GA(g->order_cnt, 2 * kOrderBuckets);
+    GA(g->dbg, 4); GA(g->d0_d2, N); GA(g->cursor, 1);
     // sized for offset 0 (the largest set); the offset of a solve may be drawn per solve (run_guided)
     g->n_train_pixels = (int)((N + (size_t)s->train_pixel_stride - 1) / (size_t)s->train_pixel_stride);
     g->n_train_blocks = (g->n_train_pixels + 255) / 256;
@@ -1286,36 +1270,45 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     P.train_offset = train_offset; P.train_stride = (uint32_t)s.train_pixel_stride;
     P.shard_index = shard_index; P.shard_count = shard_count;
 
-    // half-precision network: a whole sample is one launch (guided_sample_kernel); WOST_GUIDED_FUSED=0 keeps the
-    // one-launch-per-depth path for comparison (same field, same records)
-    bool fused = false;
+    // A whole sample is one launch (guided_sample_kernel, the network evaluated inside the wave) whenever the network has
+    // the reference's shape: with the half-precision image when "precision" is 16, with the fp32 fragments otherwise.
+    // WOST_GUIDED_FUSED=0 keeps the one-launch-per-depth path for comparison (same field, same records).
+    bool fused = false, fused_half = false;
     FusedNet F{};
     {
-        HalfNetView hv{};
         const char *env = std::getenv("WOST_GUIDED_FUSED");
-        const NetLayout &L = hv.L;
-        if (!(env && env[0] == '0') && net_half_view(g->net, &hv) == WOST_OK && L.n_levels == 8 && L.enc == 32 && L.n_neurons == 64 &&
-            L.n_hidden == 3 && L.n_out_padded == 48 && L.n_out == 33) {
-            fused = true;
+        HalfNetView hv{};
+        F32NetView fv{};
+        const NetLayout *L = nullptr;
+        if (env && env[0] == '0') {
+        } else if (net_half_view(g->net, &hv) == WOST_OK) {
+            L = &hv.L;
+            fused_half = true;
             F.image = hv.image;
-            F.n_frag = L.n_mlp / 4;
-            for (int l = 0; l < 4; ++l) F.w_off4[l] = L.w_off[l] / 4;
-            for (int l = 0; l < 8; ++l) { F.scale[l] = L.scale[l]; F.res[l] = (uint32_t)L.res[l]; }
-            for (int l = 0; l <= 8; ++l) F.off[l] = L.level_off[l];
+        } else if (net_f32_view(g->net, &fv) == WOST_OK) {
+            L = &fv.L;
+            F.frag32 = fv.frag;
+            F.grid32 = fv.grid;
+        }
+        if (L && L->n_levels == 8 && L->n_features == 4 && L->enc == 32 && L->n_neurons == 64 && L->n_hidden == 3 && L->n_out_padded == 48 &&
+            L->n_out == 33) {
+            fused = true;
+            F.n_frag = L->n_mlp / 4;
+            F.n_mlp = L->n_mlp;
+            for (int l = 0; l < 4; ++l) { F.w_off[l] = L->w_off[l]; F.w_off4[l] = L->w_off[l] / 4; }
+            for (int l = 0; l < 8; ++l) { F.scale[l] = L->scale[l]; F.res[l] = (uint32_t)L->res[l]; }
+            for (int l = 0; l <= 8; ++l) F.off[l] = L->level_off[l];
         }
     }
     P.d0_d2 = g->d0_d2; P.cursor = g->cursor; P.stack_words = stack_words;
     P.wait_weight = 4; P.trav_burst = 10;     // measured on config 4 (tools/scratch/fused_sweep.sh)
-    P.walk_len = g->walk_len; P.order = nullptr;
-    const char *order_env = std::getenv("WOST_GUIDED_ORDER");
-    const int order_every = order_env ? std::atoi(order_env) : 0;      // re-bucket every so many samples (0: never)
     if (const char *w = std::getenv("WOST_GUIDED_WAIT_WEIGHT")) P.wait_weight = std::max(1, std::atoi(w));
     if (const char *w = std::getenv("WOST_GUIDED_TRAV_BURST")) P.trav_burst = std::max(1, std::atoi(w));
-    int fused_threads = kFusedThreadsMax;
-    if (const char *w = std::getenv("WOST_GUIDED_FUSED_THREADS")) fused_threads = std::atoi(w) == 512 ? 512 : kFusedThreadsMax;
-    const size_t lds_fused = ((size_t)stack_words * fused_threads + (size_t)(fused_threads / 64) * kXchWords) * sizeof(uint32_t) +
-                             (size_t)F.n_frag * sizeof(uint2);
+    const int n_fused_threads = fused_threads(fused_half);
+    const size_t lds_fused = ((size_t)stack_words * n_fused_threads + (size_t)(n_fused_threads / 64) * fused_xch_words(fused_half) +
+                              (fused_half ? (size_t)2 * F.n_frag : (size_t)F.n_mlp)) * sizeof(uint32_t);
 
+    bool d0_valid = false;
     // ctor state (integrator.cu:1158-1160), prepareSolve (:125-126)
     bool training = true;
     float uniform_fraction = s.uniform_fraction_training;
@@ -1331,7 +1324,10 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         P.uniform_fraction = uniform_fraction;
         P.first_sample = sample == 0;
         int n_run = 1;      // samples this iteration covers
-        if (fused) {
+        // the fp32 network costs four times the matrix passes inside the wave, and a trained sample is bound by its longest
+        // walk either way: while training, the fp32 mode keeps the per-depth launches (both paths give the same results)
+        const bool fused_now = fused && (fused_half || !training);
+        if (fused_now) {
             if (!training) {
                 // nothing is trained between the remaining samples: one launch runs them all, up to the next
                 // intermediate frame the caller asked for
@@ -1351,6 +1347,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
                 n_run = std::min(n_run, cap);
             }
             P.n_samples = n_run;
+            P.d0_valid = d0_valid ? 1 : 0;
             P.max_guided_depth = max_guided_depth;
             G_TRY(hipMemsetAsync(g->cursor, 0, sizeof(uint32_t), stream));
             const bool dbg = std::getenv("WOST_GUIDED_DEBUG") != nullptr;
@@ -1360,21 +1357,13 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
                 G_TRY(hipMemcpyAsync(g->dbg, init, sizeof(init), hipMemcpyHostToDevice, stream));
                 G_TRY(hipStreamSynchronize(stream));
             }
-            if (order_every > 0 && sample > 0 && (sample == 1 || sample % order_every == 0)) {
-                G_TRY(hipMemsetAsync(g->order_cnt, 0, 2 * kOrderBuckets * sizeof(uint32_t), stream));
-                hipLaunchKernelGGL((order_kernel<0>), dim3((N + 255) / 256), dim3(256), 0, stream, P, g->order_cnt, g->order);
-                hipLaunchKernelGGL(order_offsets_kernel, dim3(1), dim3(64), 0, stream, g->order_cnt);
-                hipLaunchKernelGGL((order_kernel<1>), dim3((N + 255) / 256), dim3(256), 0, stream, P, g->order_cnt, g->order);
-                launches += 3;
-                P.order = g->order;
-            }
-            const unsigned gridf = (unsigned)std::min<size_t>(256, ((size_t)N + fused_threads - 1) / fused_threads);
+            const unsigned gridf = (unsigned)std::min<size_t>(256, ((size_t)N + n_fused_threads - 1) / n_fused_threads);
 #define LAUNCH_FUSED(E, T)                                                                                                      \
     do {                                                                                                                        \
-        auto kfn = v.src.rgb ? (fused_threads == 512 ? guided_sample_kernel<E, T, true, 512> : guided_sample_kernel<E, T, true, 768>)    \
-                             : (fused_threads == 512 ? guided_sample_kernel<E, T, false, 512> : guided_sample_kernel<E, T, false, 768>); \
+        auto kfn = v.src.rgb ? (fused_half ? guided_sample_kernel<E, T, true, true> : guided_sample_kernel<E, T, true, false>)    \
+                             : (fused_half ? guided_sample_kernel<E, T, false, true> : guided_sample_kernel<E, T, false, false>); \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused); \
-        hipLaunchKernelGGL(kfn, dim3(gridf), dim3(fused_threads), lds_fused, stream, P, F);                                       \
+        hipLaunchKernelGGL(kfn, dim3(gridf), dim3(n_fused_threads), lds_fused, stream, P, F);                                    \
     } while (0)
             if (emissive) { if (tree) LAUNCH_FUSED(true, true); else LAUNCH_FUSED(true, false); }
             else          { if (tree) LAUNCH_FUSED(false, true); else LAUNCH_FUSED(false, false); }
@@ -1388,9 +1377,10 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
                              (double)(t[1] - t[0]) / 100.0, (double)(t[2] - t[0]) / 100.0, (double)(t[3] - t[0]) / 100.0);
             }
             sample += n_run - 1;     // the index of the last sample this launch has run
+            d0_valid = true;
         }
         int cur = 0;     // queue holding the evaluation points of this depth
-        if (!fused) {
+        if (!fused_now) {
         G_TRY(hipMemsetAsync(g->counts + cur, 0, sizeof(uint32_t), stream));
         P.out = g->q[cur]; P.count_out = g->counts + cur;
         hipLaunchKernelGGL(begin_sample_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, P);
@@ -1401,7 +1391,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         // size on the device); the launches of a sample are issued back to back.
         uint32_t n_cur = (uint32_t)N;
         int polled = -1;                 // last depth whose queue size has arrived
-        for (int depth = 0; depth < s.max_depth && !fused; ++depth) {
+        for (int depth = 0; depth < s.max_depth && !fused_now; ++depth) {
             const int nxt = cur ^ 1;
             P.depth = depth;
             P.guiding = depth < max_guided_depth ? 1 : 0;

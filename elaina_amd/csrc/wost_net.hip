@@ -280,32 +280,7 @@ __global__ __launch_bounds__(NT) void net_forward_mfma_kernel(NetLayout L, const
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int lv = g + 4 * h;
-                    const float sc = s_scale[lv];
-                    const uint32_t res = s_res[lv], lo = s_off[lv];
-                    const uint32_t n_level = s_off[lv + 1] - lo;
-                    float px = __builtin_fmaf(sc, x, 0.5f), py = __builtin_fmaf(sc, y, 0.5f);
-                    const float fx = floorf(px), fy = floorf(py);
-                    px -= fx;
-                    py -= fy;
-                    const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
-                    float4 c[4];
-                    float w[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
-                        w[k] = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
-                        uint32_t idx = cx + cy * res;
-                        if (idx >= n_level) {
-                            idx -= n_level;
-                            if (idx >= n_level) idx %= n_level;
-                        }
-                        c[k] = *reinterpret_cast<const float4 *>(grid + (size_t)(lo + idx) * 4);
-                    }
-                    float4 f = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        f.x += w[k] * c[k].x; f.y += w[k] * c[k].y; f.z += w[k] * c[k].z; f.w += w[k] * c[k].w;
-                    }
+                    const float4 f = f32_encode_level(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], x, y);
                     float2 *st = reinterpret_cast<float2 *>(stage + (u * 16 + i) * SS + lv * 4);
                     st[0] = float2{f.x, f.y};
                     st[1] = float2{f.z, f.w};
@@ -1548,6 +1523,16 @@ void *net_gradient_buffer(wost_net *h, uint64_t *count)
 {
     if (count) *count = h->n_params;
     return h->grad;
+}
+
+int net_f32_view(wost_net *h, F32NetView *out)
+{
+    if (!h || !out) return set_error(WOST_ERR_INVALID, "null argument");
+    if (!h->use_mfma || !h->inference_f) return set_error(WOST_ERR_UNSUPPORTED, "the network does not run on the fp32 matrix kernels");
+    out->L = h->L;
+    out->frag = h->inference_f;
+    out->grid = h->inference + h->L.n_mlp;
+    return WOST_OK;
 }
 
 int net_half_view(wost_net *h, HalfNetView *out)

@@ -36,6 +36,84 @@ struct HalfNetView {
 // WOST_ERR_UNSUPPORTED unless the network runs its inference in half precision
 int net_half_view(wost_net_handle h, HalfNetView *out);
 
+// The fp32 network (the bit-exact mode) for kernels that evaluate it themselves: `frag` = the MFMA fragments of the
+// inference matrices (n_mlp floats, layout of fragment_mlp_kernel), `grid` = the fp32 grid of the inference weights.
+struct F32NetView {
+    NetLayout L;
+    const float *frag, *grid;
+};
+// WOST_ERR_UNSUPPORTED unless the network has the reference's shape (the MFMA kernels)
+int net_f32_view(wost_net_handle h, F32NetView *out);
+
+// one level of the DenseGrid encoding of (x, y), fp32 (tiny-cuda-nn grid.h semantics as restated by the oracle): the
+// arithmetic of net_forward_mfma_kernel, which calls this function
+__device__ __forceinline__ float4 f32_encode_level(const float *grid, float sc, uint32_t res, uint32_t lo, uint32_t n_level, float x, float y)
+{
+    float px = __builtin_fmaf(sc, x, 0.5f), py = __builtin_fmaf(sc, y, 0.5f);
+    const float fx = floorf(px), fy = floorf(py);
+    px -= fx;
+    py -= fy;
+    const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+    float4 c[4];
+    float w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
+        w[k] = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
+        uint32_t idx = cx + cy * res;
+        if (idx >= n_level) {
+            idx -= n_level;
+            if (idx >= n_level) idx %= n_level;
+        }
+        c[k] = *reinterpret_cast<const float4 *>(grid + (size_t)(lo + idx) * 4);
+    }
+    float4 f = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f.x += w[k] * c[k].x; f.y += w[k] * c[k].y; f.z += w[k] * c[k].z; f.w += w[k] * c[k].w;
+    }
+    return f;
+}
+
+// The four matrices on one 16-point unit in fp32 (v_mfma_f32_16x16x4_f32, k ascending: bit-identical to the scalar
+// fmaf chains of the oracle), reference network shape.  Lane (i, g) supplies in[s] = encoded feature 4 s + g of point i
+// (s = 0 .. 7) and receives out[4 rt + c] = output 16 rt + 4 c + g of point i.  `wf` = the fragments in LDS.
+__device__ __forceinline__ void f32_mlp_unit(const float *wf, const uint32_t (&w_off)[4], int lane, const float (&in)[8], float (&out)[12])
+{
+    float b[16];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) b[s] = in[s];
+    f32x4_t acc[4];
+#pragma unroll
+    for (int layer = 0; layer < 3; ++layer) {
+        const int S = layer == 0 ? 8 : 16;
+        const float *w = wf + w_off[layer];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if (s < S) {
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[(rt * S + s) * 64 + lane], b[s], acc[rt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[4 * rt + c] = fmaxf(acc[rt][c], 0.0f);
+    }
+    const float *w3 = wf + w_off[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) acc[rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[(rt * 16 + s) * 64 + lane], b[s], acc[rt], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[4 * rt + c] = acc[rt][c];
+}
+
 // one level of the DenseGrid encoding of (x, y) in the half-precision network: grid values as stored (f16),
 // bilinear interpolation in fp32, result rounded to f16.  `grid` = the entries of the image (LDS or global).
 __device__ __forceinline__ h4_t half_encode_level(const uint2 *grid, float sc, uint32_t res, uint32_t lo, uint32_t n_level, float x, float y)

@@ -656,12 +656,15 @@ def test_gpu_half_precision_network_mode_is_unbiased_and_no_noisier(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", [32, 16])
 @pytest.mark.parametrize("scene", ["box", "ladybug", "wiggly", "source"])
-def test_gpu_fused_sample_kernel_equals_the_per_depth_launches(scene, oracle, monkeypatch):
-    """With the half-precision network a whole sample runs in ONE launch: walkers stay in their lanes from
-    depth to depth and every wave evaluates the network for its own walkers (guided_sample_kernel).  Per pixel
-    nothing changes -- same draws, same network arithmetic, same records -- so the field, the statistics and
-    the trained weights equal those of the one-launch-per-depth path (WOST_GUIDED_FUSED=0) bit for bit."""
+def test_gpu_fused_sample_kernel_equals_the_per_depth_launches(scene, precision, oracle, monkeypatch):
+    """A whole sample runs in ONE launch: walkers stay in their lanes from depth to depth and every wave
+    evaluates the network for its own walkers (guided_sample_kernel; fp32 fragments in the default mode, the
+    f16 image in the half-precision mode).  Per pixel nothing changes -- same draws, same network arithmetic,
+    same records -- so the field, the statistics and the trained weights equal those of the
+    one-launch-per-depth path (WOST_GUIDED_FUSED=0) bit for bit.  (In the fp32 mode every other test of this
+    file compares the fused path with the oracle.)"""
     from elaina_amd import Problem
     from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
     if scene == "box":
@@ -682,8 +685,9 @@ def test_gpu_fused_sample_kernel_equals_the_per_depth_launches(scene, oracle, mo
                                       maxGuidedDepthInTrainingPhase=5, maxGuidedDepthInGuidingPhase=7, batchSize=4096, minBatchSize=512,
                                       trainPixelStride=2)
         gi = GuidedIntegrator(prob, st, aabb, seed=11)
-        gi.network.set_option("precision", 16)
-        gi.network.set_option("train_precision", 16)
+        if precision == 16:
+            gi.network.set_option("precision", 16)
+            gi.network.set_option("train_precision", 16)
         gi.solve()
         stats = dict(gi.last_stats)
         out[fused] = (gi.solution.copy(), gi.network.params(), gi.network.inference_params(), stats)
