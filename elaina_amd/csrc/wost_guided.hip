@@ -166,6 +166,7 @@ struct GParams {
     int32_t max_guided_depth;
     int32_t stack_words;      // LDS words of a lane's traversal stack
     int32_t wait_weight, trav_burst;
+    int32_t tail_chunk, tail_margin_pct;   // reservation size near the end of the launch; how near, in % of the launch's lanes
     int32_t n_samples;        // samples of every pixel in this launch (> 1 only when nothing is trained in between)
     int32_t d0_valid;         // d0_d2 holds the query of every evaluation point (after the first fused launch of a solve)
     unsigned long long *dbg;  // WOST_GUIDED_DEBUG: [0] first start, [1] first wave out of pixels, [2] last wave out of pixels, [3] end (100 MHz ticks)
@@ -635,7 +636,8 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
     Pcg rng{0, 1};
     Trav T = trav_begin(Closest{WOST_INF, -1});
     int left = 0;                          // samples this lane still owes its pixel
-    uint32_t pool_next = 0, pool_end = 0;
+    uint32_t pool_next = 0, pool_end = 0, last_base = 0;
+    const uint32_t tail_margin = (uint32_t)P.tail_margin_pct * (gridDim.x * blockDim.x / 100u);
     uint32_t c_steps = 0, c_started = 0, c_abs = 0, c_trunc = 0, c_hits = 0, c_guided = 0, c_net = 0;
     const bool has_d = P.dm.n_segs > 0;
     const uint32_t n_slots = (uint32_t)P.n_pixels;
@@ -648,16 +650,22 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
         const unsigned long long need = __ballot(mode == MODE_REFILL);
         if (need) {
             const uint32_t needed = (uint32_t)__popcll(need), avail = pool_end - pool_next;
-            uint32_t fresh_base = 0;
+            // Pixels are reserved 64 at a time (one atomic on the shared cursor per 64 pixels: same-address atomics
+            // serialise in L2).  A reservation is private to its wave, so near the end of the launch the pixels a wave
+            // holds back would start only when ITS lanes come free while other waves idle: within `tail_margin` pixels
+            // of the end a wave reserves in small chunks.
+            uint32_t fresh_base = 0, chunk = 64u;
             if (needed > avail) {
-                if (lane == 0) fresh_base = atomicAdd(P.cursor, 64u);
+                if (P.tail_chunk > 0 && last_base + tail_margin >= n_slots) chunk = (needed - avail + (uint32_t)P.tail_chunk - 1u) / (uint32_t)P.tail_chunk * (uint32_t)P.tail_chunk;
+                if (lane == 0) fresh_base = atomicAdd(P.cursor, chunk);
                 fresh_base = __shfl(fresh_base, 0);
+                last_base = fresh_base;
             }
             const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
             const uint32_t s2 = rank < avail ? pool_next + rank : fresh_base + (rank - avail);
             if (needed > avail) {
                 pool_next = fresh_base + (needed - avail);
-                pool_end = fresh_base + 64u;
+                pool_end = fresh_base + chunk;
             } else {
                 pool_next += needed;
             }
@@ -1304,6 +1312,9 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     P.wait_weight = 4; P.trav_burst = 10;     // measured on config 4 (tools/scratch/fused_sweep.sh)
     if (const char *w = std::getenv("WOST_GUIDED_WAIT_WEIGHT")) P.wait_weight = std::max(1, std::atoi(w));
     if (const char *w = std::getenv("WOST_GUIDED_TRAV_BURST")) P.trav_burst = std::max(1, std::atoi(w));
+    P.tail_chunk = 4; P.tail_margin_pct = 300;      // tools/scratch/fused_sweep.sh: 3.52 -> 3.37 ms per trained sample of config 4
+    if (const char *w = std::getenv("WOST_GUIDED_TAIL_CHUNK")) P.tail_chunk = std::max(0, std::atoi(w));
+    if (const char *w = std::getenv("WOST_GUIDED_TAIL_MARGIN")) P.tail_margin_pct = std::max(0, std::atoi(w));
     const int n_fused_threads = fused_threads(fused_half);
     const size_t lds_fused = ((size_t)stack_words * n_fused_threads + (size_t)(n_fused_threads / 64) * fused_xch_words(fused_half) +
                               (fused_half ? (size_t)2 * F.n_frag : (size_t)F.n_mlp)) * sizeof(uint32_t);

@@ -9,10 +9,4 @@ run() {
   echo "$tag: $(python3 tools/print_kernel_stats.py $f | grep guided_sample | cut -c60-110)"
   rm -rf gpurun_out/fs_$tag
 }
-WOST_GUIDED_DEEP=1000 run nodeep
-WOST_GUIDED_DEEP=32 run deep32
-WOST_GUIDED_DEEP=24 run deep24
-WOST_GUIDED_DEEP=16 run deep16
-WOST_GUIDED_DEEP=12 run deep12
-WOST_GUIDED_DEEP=8 run deep8
-WOST_GUIDED_DEEP=16 WOST_GUIDED_ORDER=4 run deep16order4
+for c in 1 4; do for m in 300 400 600; do WOST_GUIDED_TAIL_CHUNK=$c WOST_GUIDED_TAIL_MARGIN=$m run chunk${c}_margin$m; done; done
