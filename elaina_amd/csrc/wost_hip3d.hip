@@ -12,9 +12,9 @@
 // but a whole solve is ONE launch: a lane runs its pixel to the end.  Closest-point queries descend
 // an implicit 4-ary LBVH over the triangles (3-D Morton order, axis-aligned child boxes, 96-byte
 // nodes, near-first with the per-lane LDS stack and the key format of the 2-D tree, wost_device.h).
-// The Neumann mesh of this first 3-D slice is walked with wave-uniform flat loops (up to
-// WOST3_FLAT_MAX triangles: a box, a clipped plane); larger Neumann meshes and the source term are
-// not built.  Arithmetic contract: DESIGN.md 2.3 (the CPU restatement the tests compare against
+// The Neumann mesh of this first 3-D slice is walked with wave-uniform flat loops (a box, a clipped plane:
+// every Neumann-side query is O(triangles), so meshes of hundreds of triangles work but are slow, and
+// WOST3_FLAT_MAX = 4096 is refused); a Neumann-side tree and the source term are not built.  Arithmetic contract: DESIGN.md 2.3 (the CPU restatement the tests compare against
 // follows the same contract operation for operation).
 #include <hip/hip_runtime.h>
 
@@ -35,7 +35,7 @@
 namespace wost {
 
 #define WOST_4PI 12.5663706143591729539f
-#define WOST3_FLAT_MAX 64
+#define WOST3_FLAT_MAX 4096
 
 struct V3 {
     float x, y, z;
@@ -870,7 +870,7 @@ int wost3_create(const wost3_scene_desc *scene, const wost_settings *settings, i
         return set_error(WOST_ERR_INVALID, "bad settings");
     if ((int64_t)settings->width * settings->height > (1 << 28)) return set_error(WOST_ERR_UNSUPPORTED, "frame too large");
     if (scene->neumann.n_tris > WOST3_FLAT_MAX)
-        return set_error(WOST_ERR_UNSUPPORTED, "3-D Neumann meshes are limited to 64 triangles in this build (flat queries)");
+        return set_error(WOST_ERR_UNSUPPORTED, "3-D Neumann meshes are limited to 4096 triangles in this build (flat queries, O(triangles) per step)");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
         return set_error(WOST_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
@@ -969,7 +969,7 @@ int wost3_closest_silhouette(wost3_handle h, int which_mesh, const float *pts, c
     if (!h || !pts || !out_dist || n < 0) return set_error(WOST_ERR_INVALID, "null argument");
     DeviceMesh3 *m = pick3(h, which_mesh);
     if (!m) return set_error(WOST_ERR_INVALID, "unknown mesh selector");
-    if (m->view.n_tris > WOST3_FLAT_MAX) return set_error(WOST_ERR_UNSUPPORTED, "silhouette queries walk at most 64 triangles in this build");
+    if (m->view.n_tris > WOST3_FLAT_MAX) return set_error(WOST_ERR_UNSUPPORTED, "silhouette queries walk at most 4096 triangles in this build");
     if (n == 0) return WOST_OK;
     W3_TRY(hipSetDevice(h->device));
     Scratch3 s;
@@ -993,7 +993,7 @@ int wost3_ray_intersect(wost3_handle h, int which_mesh, const float *origins, co
     if (!h || !origins || !dirs || !tmax || !out_hit || !out_t || !out_idx || n < 0) return set_error(WOST_ERR_INVALID, "null argument");
     DeviceMesh3 *m = pick3(h, which_mesh);
     if (!m) return set_error(WOST_ERR_INVALID, "unknown mesh selector");
-    if (m->view.n_tris > WOST3_FLAT_MAX) return set_error(WOST_ERR_UNSUPPORTED, "ray queries walk at most 64 triangles in this build");
+    if (m->view.n_tris > WOST3_FLAT_MAX) return set_error(WOST_ERR_UNSUPPORTED, "ray queries walk at most 4096 triangles in this build");
     if (n == 0) return WOST_OK;
     W3_TRY(hipSetDevice(h->device));
     Scratch3 s;

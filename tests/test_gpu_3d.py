@@ -109,8 +109,14 @@ def test_3d_sharded_solve_sums_to_the_full_field(oracle):
     it.close()
 
 
-def test_3d_limits_are_reported(oracle):
+def test_3d_neumann_mesh_of_hundreds_of_triangles(oracle):
+    """Neumann-side queries are flat loops over the mesh (no tree yet): 288 triangles work -- bit-exact against
+    the oracle, u = x reproduced under zero flux -- and 6 x 48 x 48 x 2 = 27 648 are refused with a message"""
     from elaina_amd.capi import WostError
-    sd = cube_scene3(n=4, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x)      # 128 Neumann triangles
+    sd = cube_scene3(n=6, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x, flux=lambda x, y, z, f: 0.0)
+    assert len(sd["n_tris"]) == 288
+    ref = _same_solve(oracle, sd, 12, 12, 8, 48, 2e-3)
+    assert ref["neumann_hits"] > 0
+    big = cube_scene3(n=48, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x)
     with pytest.raises(WostError):
-        _it(sd, 8, 8, 1, 4, 1e-3)
+        _it(big, 8, 8, 1, 4, 1e-3)
