@@ -125,6 +125,11 @@ def valu_block():
     return {k: v.get(k) for k in ("pipe_busy", "lane_efficiency", "lane_instr_per_step", "source")}
 
 
+def torch_zeros_like(t):
+    import torch
+    return torch.zeros_like(t)
+
+
 def rel_l2(a, b):
     import numpy as np
     den = float(np.linalg.norm(b)) or 1.0
@@ -409,6 +414,21 @@ def main():
             if uniform_field is not None:
                 e4h["rel_l2_vs_uniform_field"] = rel_l2(r4h["field"].cpu().numpy(), uniform_field.cpu().numpy())
             extras["cfg4_f16"] = e4h
+            if uniform_field is not None:
+                # SURVEY 8c, guided gate: against a 4096-spp field of the uniform integrator (bit-exact against the
+                # oracle at any spp) the guided estimator must not be noisier than the uniform one at equal spp
+                from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+                itr = UniformIntegrator(r["problem"], UniformIntegratorSettings((1024, 1024), 4096, r["depth"], r["eps"]), device=env.local)
+                ref = torch_zeros_like(uniform_field)
+                itr.solve_sharded(0, 1, ref.data_ptr(), env.torch.cuda.current_stream().cuda_stream)
+                env.torch.cuda.synchronize()
+                itr.close()
+                refn = ref.cpu().numpy()
+                extras["variance_check"] = {
+                    "reference": "ladybug 1024x1024, uniform integrator, 4096 spp",
+                    "rel_l2_uniform_256spp": rel_l2(uniform_field.cpu().numpy(), refn),
+                    "rel_l2_guided_256spp": rel_l2(r4["field"].cpu().numpy(), refn),
+                    "rel_l2_guided_f16_256spp": rel_l2(r4h["field"].cpu().numpy(), refn)}
         else:
             r5 = run_guided(env, "ladybug", 2048, 1024, 256, 0, 1, 0, args)
             extras["cfg5"] = r5["out"]
