@@ -84,11 +84,18 @@ class Mesh3Desc(C.Structure):
                 ("colors", C.POINTER(C.c_float))]
 
 
+class Source3Desc(C.Structure):
+    """wost3_source_desc (include/wost.h)"""
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("rgb", C.POINTER(C.c_float)),
+                ("index_scale", C.c_float * 3), ("index_offset", C.c_float * 3), ("intensity", C.c_float)]
+
+
 class Scene3Desc(C.Structure):
     """wost3_scene_desc (include/wost.h)"""
     _fields_ = [("dirichlet", Mesh3Desc), ("neumann", Mesh3Desc), ("dirichlet_intensity", C.c_float),
                 ("neumann_intensity", C.c_float), ("probe_scale", C.c_float), ("probe_pos", C.c_float * 3),
-                ("probe_up", C.c_float * 3), ("probe_right", C.c_float * 3), ("mask", C.POINTER(C.c_uint8))]
+                ("probe_up", C.c_float * 3), ("probe_right", C.c_float * 3), ("mask", C.POINTER(C.c_uint8)),
+                ("source", Source3Desc)]
 
 
 class NetConfig(C.Structure):

@@ -14,7 +14,7 @@
 // nodes, near-first with the per-lane LDS stack and the key format of the 2-D tree, wost_device.h).
 // The Neumann mesh of this first 3-D slice is walked with wave-uniform flat loops (a box, a clipped plane:
 // every Neumann-side query is O(triangles), so meshes of hundreds of triangles work but are slow, and
-// WOST3_FLAT_MAX = 4096 is refused); a Neumann-side tree and the source term are not built.  Arithmetic contract: DESIGN.md 2.3 (the CPU restatement the tests compare against
+// WOST3_FLAT_MAX = 4096 is refused); a Neumann-side tree is not built.  Source term: a dense grid, trilinear.  Arithmetic contract: DESIGN.md 2.3 (the CPU restatement the tests compare against
 // follows the same contract operation for operation).
 #include <hip/hip_runtime.h>
 
@@ -336,10 +336,53 @@ struct alignas(256) Stats3Dev {
     unsigned long long steps, started, absorbed, truncated, nhits;
 };
 
+// source term: dense grid, trilinear (wost3_source_desc)
+struct DevSource3 {
+    const float *rgb;          // nullptr: no source term
+    int32_t nx, ny, nz;
+    float sx, sy, sz, ox, oy, oz;
+    float intensity;
+};
+
+__device__ __forceinline__ void source3_tap(const DevSource3 &s, int i, int j, int k, float (&v)[3])
+{
+    if (i < 0 || j < 0 || k < 0 || i >= s.nx || j >= s.ny || k >= s.nz) {
+        v[0] = v[1] = v[2] = 0.0f;
+        return;
+    }
+    const float *p = s.rgb + 3 * (((size_t)k * s.ny + j) * s.nx + i);
+    v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+}
+
+__device__ __forceinline__ void source3_eval(const DevSource3 &s, V3 q, float (&out)[3])
+{
+    const float gx = __builtin_fmaf(q.x, s.sx, s.ox), gy = __builtin_fmaf(q.y, s.sy, s.oy), gz = __builtin_fmaf(q.z, s.sz, s.oz);
+    const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+    const float u = gx - fx, v = gy - fy, w = gz - fz;
+    const int i = (int)fmaxf(fminf(fx, 1e9f), -1e9f), j = (int)fmaxf(fminf(fy, 1e9f), -1e9f), k = (int)fmaxf(fminf(fz, 1e9f), -1e9f);
+    float c000[3], c001[3], c010[3], c011[3], c100[3], c101[3], c110[3], c111[3];     // [dk][dj][di]
+    source3_tap(s, i, j, k, c000); source3_tap(s, i + 1, j, k, c001);
+    source3_tap(s, i, j + 1, k, c010); source3_tap(s, i + 1, j + 1, k, c011);
+    source3_tap(s, i, j, k + 1, c100); source3_tap(s, i + 1, j, k + 1, c101);
+    source3_tap(s, i, j + 1, k + 1, c110); source3_tap(s, i + 1, j + 1, k + 1, c111);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        // x, then y, then z
+        const float a00 = c000[ch] + (c001[ch] - c000[ch]) * u, a01 = c010[ch] + (c011[ch] - c010[ch]) * u;
+        const float a10 = c100[ch] + (c101[ch] - c100[ch]) * u, a11 = c110[ch] + (c111[ch] - c110[ch]) * u;
+        const float b0 = a00 + (a01 - a00) * v, b1 = a10 + (a11 - a10) * v;
+        out[ch] = (b0 + (b1 - b0) * w) * s.intensity;
+    }
+}
+
+// cube root of x in [0, 1] through the deterministic log / exp (the arithmetic contract's std::cbrt)
+__device__ __forceinline__ float cbrt01(float x) { return x > 0.0f ? det_expf(det_logf(x) * (1.0f / 3.0f)) : 0.0f; }
+
 struct Walk3Params {
     DevMesh3 dm, nm;
     DevSettings st;
     DevProbe3 probe;
+    DevSource3 src;
     const uint8_t *mask;
     float *field;              // solution / spp at field[(pix - field_base) * 3]
     int32_t field_base, pixel_begin, pixel_end;
@@ -348,7 +391,7 @@ struct Walk3Params {
 };
 
 // One lane = one pixel, all its samples one after the other on the pixel's PCG stream.
-template <bool EMISSIVE>
+template <bool EMISSIVE, bool SOURCE>
 __global__ __launch_bounds__(256) void walk3_kernel(Walk3Params P)
 {
     extern __shared__ uint32_t lds_stack[];
@@ -411,6 +454,51 @@ __global__ __launch_bounds__(256) void walk3_kernel(Walk3Params P)
                 float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
                 R_B *= WOST_R_B_SHRINK;
                 if (isinf(R_B)) break;
+                // ---- sampleSource (reference integrator/uniform/integrator.cu:235-316, DIM == 3) ----
+                if (SOURCE) {
+                    V3 sdir;
+                    float dir_pdf, salpha = 1.0f;
+                    {
+                        const float u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
+                        float c, s;
+                        sincos_2pi(u2, c, s);
+                        if (on_n) {
+                            const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+                            sdir = frame_to_world(nn, r * c, r * s, z);
+                            dir_pdf = 1.0f / WOST_2PI;
+                            salpha = 0.5f;
+                        } else {
+                            const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
+                            sdir = v3(r * c, r * s, z);
+                            dir_pdf = 1.0f / WOST_4PI;
+                        }
+                    }
+                    // how far the straight line stays inside the star-shaped region (:279-292)
+                    float dist = R_B;
+                    if (has_n) {
+                        float t;
+                        int hi;
+                        if (ray_closest3_flat(P.nm, v3(p.x + eps * sdir.x, p.y + eps * sdir.y, p.z + eps * sdir.z), sdir, dist, t, hi)) dist = fminf(t, dist);
+                    }
+                    // HarmonicGreenBall<3>::sample (util/green.h:101-116): closed form, two draws
+                    const float g1 = pcg_next_float(rng), g2 = pcg_next_float(rng);
+                    float gc, gs;
+                    sincos_2pi(g2, gc, gs);
+                    float r = (1.0f + sqrtf(1.0f - cbrt01(g1 * g1)) * gc) * R_B / 2.0f;
+                    r = fmaxf(1e-4f, r);                                            // ELAINA_GREEN_FUNC_R_CLAMP
+                    if (r > R_B) r = R_B / 2.0f;
+                    if (r <= dist) {
+                        float f[3];
+                        source3_eval(P.src, v3(p.x + r * sdir.x, p.y + r * sdir.y, p.z + r * sdir.z), f);
+                        const float norm = R_B * R_B / 6.0f;
+                        const float c1 = (1.0f / WOST_4PI) / (r * r), c2 = dir_pdf / (r * r);     // conditionalSampleSpherePDF<3>
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const float col = thp * f[k] * norm * c1 / c2 / salpha;
+                            sol[k] = col + sol[k];
+                        }
+                    }
+                }
                 // ---- sampleNeumann: three draws whether or not the boundary emits ----
                 if (has_n) {
                     const float u0 = pcg_next_float(rng), u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
@@ -751,6 +839,7 @@ struct wost3_context {
     DevProbe3 probe{};
     DeviceMesh3 dm, nm;
     uint8_t *mask = nullptr;
+    DevSource3 src{};          // rgb owned by the context
     size_t n_pixels = 0;
     float *field = nullptr;
     Stats3Dev *stats = nullptr;
@@ -791,6 +880,7 @@ static void destroy3(wost3_context *c)
     for (void *p : c->dm.allocs) (void)hipFree(p);
     for (void *p : c->nm.allocs) (void)hipFree(p);
     if (c->mask) (void)hipFree(c->mask);
+    if (c->src.rgb) (void)hipFree(const_cast<float *>(c->src.rgb));
     if (c->field) (void)hipFree(c->field);
     if (c->stats) (void)hipFree(c->stats);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -806,7 +896,7 @@ static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, 
     W3_TRY(hipSetDevice(c->device));
     W3_TRY(hipMemsetAsync(c->stats, 0, kStat3Copies * sizeof(Stats3Dev), stream));
     Walk3Params P{};
-    P.dm = c->dm.view; P.nm = c->nm.view; P.st = c->dst; P.probe = c->probe; P.mask = c->mask;
+    P.dm = c->dm.view; P.nm = c->nm.view; P.st = c->dst; P.probe = c->probe; P.mask = c->mask; P.src = c->src;
     P.field = field_dev; P.field_base = field_base; P.pixel_begin = pixel_begin; P.pixel_end = pixel_end;
     P.shard_index = shard_index; P.shard_count = shard_count; P.stats = c->stats;
     const int bs = 256, n = pixel_end - pixel_begin;
@@ -814,10 +904,10 @@ static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, 
     float ms = 0.0f;
     if (n > 0) {
         W3_TRY(hipEventRecord(c->ev0, stream));
-        if (c->nm.view.n_tris > 0 && c->nm.view.emissive)
-            hipLaunchKernelGGL((walk3_kernel<true>), dim3((n + bs - 1) / bs), dim3(bs), lds, stream, P);
-        else
-            hipLaunchKernelGGL((walk3_kernel<false>), dim3((n + bs - 1) / bs), dim3(bs), lds, stream, P);
+        const bool emissive = c->nm.view.n_tris > 0 && c->nm.view.emissive;
+        auto kfn = c->src.rgb ? (emissive ? walk3_kernel<true, true> : walk3_kernel<false, true>)
+                              : (emissive ? walk3_kernel<true, false> : walk3_kernel<false, false>);
+        hipLaunchKernelGGL(kfn, dim3((n + bs - 1) / bs), dim3(bs), lds, stream, P);
         W3_TRY(hipGetLastError());
         W3_TRY(hipEventRecord(c->ev1, stream));
     }
@@ -891,6 +981,18 @@ int wost3_create(const wost3_scene_desc *scene, const wost_settings *settings, i
     if (rc == WOST_OK && scene->mask) {
         e = hipMalloc((void **)&c->mask, c->n_pixels);
         if (e == hipSuccess) e = hipMemcpy(c->mask, scene->mask, c->n_pixels, hipMemcpyHostToDevice);
+    }
+    if (rc == WOST_OK && e == hipSuccess && scene->source.nx > 0) {
+        const wost3_source_desc &sd = scene->source;
+        if (sd.ny <= 0 || sd.nz <= 0 || !sd.rgb) rc = set_error(WOST_ERR_INVALID, "source grid: bad size or null samples");
+        else {
+            const size_t bytes = (size_t)sd.nx * sd.ny * sd.nz * 3 * sizeof(float);
+            float *d = nullptr;
+            e = hipMalloc((void **)&d, bytes);
+            if (e == hipSuccess) e = hipMemcpy(d, sd.rgb, bytes, hipMemcpyHostToDevice);
+            c->src = DevSource3{d, sd.nx, sd.ny, sd.nz, sd.index_scale[0], sd.index_scale[1], sd.index_scale[2], sd.index_offset[0],
+                                sd.index_offset[1], sd.index_offset[2], sd.intensity};
+        }
     }
     if (rc == WOST_OK && e == hipSuccess) e = hipMalloc((void **)&c->field, c->n_pixels * 3 * sizeof(float));
     if (rc == WOST_OK && e == hipSuccess) e = hipMalloc((void **)&c->stats, kStat3Copies * sizeof(Stats3Dev));

@@ -287,8 +287,25 @@ void Problem<3>::loadConfig(const json &config, const fs::path &search_dir)
         if (vertex_color_neumann.size() != scene_stat.neumann_vertices_size * 6)
             throw std::runtime_error("Neumann colour file does not have one entry per vertex");
     }
-    if (json_get_optional<string>(config, "source_path") || json_get_optional<json>(config, "source_grid"))
-        throw std::runtime_error("the source term is not built for 3-D scenes");
+    // as in 2-D: "source_grid": {"path": raw little-endian float32 [nz][ny][nx][3], "nx", "ny", "nz",
+    //                            "index_scale": [sx, sy, sz], "index_offset": [ox, oy, oz]}
+    if (json_get_optional<string>(config, "source_path"))
+        throw std::runtime_error("source_path: nanovdb grids cannot be read by this build; export the grid as \"source_grid\" "
+                                 "(dense float32 RGB, see core/problem.cpp)");
+    if (const auto sg = json_get_optional<json>(config, "source_grid")) {
+        const int nx = json_get_or_throw<int>(*sg, "nx"), ny = json_get_or_throw<int>(*sg, "ny"), nz = json_get_or_throw<int>(*sg, "nz");
+        const auto sc = json_get_or_throw<std::vector<float>>(*sg, "index_scale");
+        const auto of = json_get_or_throw<std::vector<float>>(*sg, "index_offset");
+        if (nx <= 0 || ny <= 0 || nz <= 0 || sc.size() != 3 || of.size() != 3) throw std::runtime_error("source_grid: bad shape");
+        const string path = resolve(json_get_or_throw<string>(*sg, "path"), search_dir);
+        std::ifstream f(path, std::ios::binary);
+        if (!f.is_open()) throw std::runtime_error("cannot open source grid " + path);
+        std::vector<float> rgb((size_t)nx * ny * nz * 3);
+        f.read(reinterpret_cast<char *>(rgb.data()), (std::streamsize)(rgb.size() * sizeof(float)));
+        if ((size_t)f.gcount() != rgb.size() * sizeof(float)) throw std::runtime_error("source grid file is too short: " + path);
+        set_source(nx, ny, nz, std::move(rgb), {sc[0], sc[1], sc[2]}, {of[0], of[1], of[2]});
+    }
+    source_intensity = json_get_optional<float>(config, "source_intensity", 1.0f);
     dirichlet_intensity = json_get_optional<float>(config, "dirichlet_intensity", 1.0f);
     neumann_intensity = json_get_optional<float>(config, "neumann_intensity", 1.0f);
     if (verbose) {
@@ -298,6 +315,16 @@ void Problem<3>::loadConfig(const json &config, const fs::path &search_dir)
         if (enable_neumann)
             ELAINA_LOG(Info, "Neumann: %zu vertices, %zu triangles", scene_stat.neumann_vertices_size, scene_stat.neumann_primitives_size);
     }
+}
+
+void Problem<3>::set_source(int nx, int ny, int nz, std::vector<float> rgb, Vector3f index_scale, Vector3f index_offset)
+{
+    if (nx <= 0 || ny <= 0 || nz <= 0 || rgb.size() != (size_t)nx * ny * nz * 3) throw std::runtime_error("set_source: size mismatch");
+    source_nx = nx; source_ny = ny; source_nz = nz;
+    source_rgb = std::move(rgb);
+    source_index_scale = index_scale;
+    source_index_offset = index_offset;
+    enable_source = true;
 }
 
 wost3_scene_desc Problem<3>::scene_desc(int width, int height) const
@@ -328,6 +355,13 @@ wost3_scene_desc Problem<3>::scene_desc(int width, int height) const
     if (!mask.empty()) {
         if (mask.size() != (size_t)width * height) throw std::runtime_error("mask size does not match the frame");
         d.mask = mask.data();
+    }
+    if (enable_source) {
+        d.source.nx = source_nx; d.source.ny = source_ny; d.source.nz = source_nz;
+        d.source.rgb = source_rgb.data();
+        d.source.index_scale[0] = source_index_scale.x; d.source.index_scale[1] = source_index_scale.y; d.source.index_scale[2] = source_index_scale.z;
+        d.source.index_offset[0] = source_index_offset.x; d.source.index_offset[1] = source_index_offset.y; d.source.index_offset[2] = source_index_offset.z;
+        d.source.intensity = source_intensity;
     }
     return d;
 }

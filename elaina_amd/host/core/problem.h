@@ -82,8 +82,8 @@ struct SceneLoader3 {
     std::vector<int32_t> indices;  // i0,i1,i2 per triangle, 0-based
 };
 
-// Problem<3> (reference core/problem.h:197-260): triangle meshes, EvaluationGrid<3>.  The source
-// term (a nanovdb volume in the reference) is not built for 3-D.
+// Problem<3> (reference core/problem.h:197-260): triangle meshes, EvaluationGrid<3>.  The source term (a nanovdb
+// volume in the reference) comes as a dense grid: "source_grid" with "nz" and three-component scale / offset.
 template <> class Problem<3> {
 public:
     explicit Problem(const bool verbose = true) : verbose(verbose) {}
@@ -92,9 +92,13 @@ public:
     void loadConfig(const json &config, const fs::path &search_dir = {});
     bool isDirichletEnabled() const { return enable_dirichlet; }
     bool isNeumannEnabled() const { return enable_neumann; }
-    bool isSourceEnabled() const { return false; }
+    bool isSourceEnabled() const { return enable_source; }
     const SceneProbe &getProbe() const { return *mpProbe; }
     const ProblemStatistics &get_problem_stat() const { return scene_stat; }
+    float get_source_intensity() const { return source_intensity; }
+    // dense source grid [nz][ny][nx][3] (stands in for the reference's nanovdb grid, core/problem.cu:136-149):
+    // index = world * index_scale + index_offset per axis, trilinear
+    void set_source(int nx, int ny, int nz, std::vector<float> rgb, Vector3f index_scale, Vector3f index_offset);
     float get_dirichlet_intensity() const { return dirichlet_intensity; }
     float get_neumann_intensity() const { return neumann_intensity; }
     const std::vector<uint8_t> &get_mask() const { return mask; }
@@ -105,10 +109,13 @@ private:
     std::shared_ptr<SceneProbe> mpProbe;
     std::unique_ptr<SceneLoader3> scene_dirichlet_loader, scene_neumann_loader;
     std::vector<float> vertex_color_dirichlet, vertex_color_neumann;
-    bool enable_dirichlet{false}, enable_neumann{false};
+    bool enable_dirichlet{false}, enable_neumann{false}, enable_source{false};
+    int source_nx{0}, source_ny{0}, source_nz{0};
+    std::vector<float> source_rgb;
+    Vector3f source_index_scale{1.0f, 1.0f, 1.0f}, source_index_offset{0.0f, 0.0f, 0.0f};
     bool verbose{false};
     ProblemStatistics scene_stat;
-    float dirichlet_intensity{1.0f}, neumann_intensity{1.0f};
+    float source_intensity{1.0f}, dirichlet_intensity{1.0f}, neumann_intensity{1.0f};
     std::vector<uint8_t> mask;
 };
 

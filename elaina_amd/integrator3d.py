@@ -15,7 +15,7 @@ class Problem3:
 
     def __init__(self, d_verts=None, d_tris=None, d_colors=None, n_verts=None, n_tris=None, n_colors=None,
                  probe=(1.0, (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), (1.0, 0.0, 0.0)), dirichlet_intensity=1.0, neumann_intensity=1.0,
-                 mask=None):
+                 mask=None, source=None):
         def arr(a, dt, cols):
             return None if a is None else np.ascontiguousarray(a, dtype=dt).reshape(-1, cols)
         self.d_verts, self.d_tris, self.d_colors = arr(d_verts, np.float32, 3), arr(d_tris, np.int32, 3), arr(d_colors, np.float32, 6)
@@ -23,16 +23,18 @@ class Problem3:
         self.probe = probe
         self.dirichlet_intensity, self.neumann_intensity = float(dirichlet_intensity), float(neumann_intensity)
         self.mask = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(-1)
+        # source term: {"rgb": [nz, ny, nx, 3], "index_scale": (3,), "index_offset": (3,), "intensity": f} or None
+        self.source = None if source is None else dict(source, rgb=np.ascontiguousarray(source["rgb"], dtype=np.float32))
 
     @classmethod
     def from_dict(cls, sd):
-        return cls(**{k: sd.get(k) for k in ("d_verts", "d_tris", "d_colors", "n_verts", "n_tris", "n_colors", "mask")},
+        return cls(**{k: sd.get(k) for k in ("d_verts", "d_tris", "d_colors", "n_verts", "n_tris", "n_colors", "mask", "source")},
                    probe=sd["probe"], dirichlet_intensity=sd.get("dirichlet_intensity", 1.0),
                    neumann_intensity=sd.get("neumann_intensity", 1.0))
 
     def as_dict(self):
         return {k: getattr(self, k) for k in ("d_verts", "d_tris", "d_colors", "n_verts", "n_tris", "n_colors", "probe",
-                                              "dirichlet_intensity", "neumann_intensity", "mask")}
+                                              "dirichlet_intensity", "neumann_intensity", "mask", "source")}
 
 
 def _mesh3(keep, verts, tris, colors):
@@ -70,6 +72,17 @@ class UniformIntegrator3:
                 raise ValueError("mask must have width*height entries")
             keep.append(problem.mask)
             sc.mask = problem.mask.ctypes.data_as(C.POINTER(C.c_uint8))
+        if problem.source is not None:
+            rgb = problem.source["rgb"]
+            if rgb.ndim != 4 or rgb.shape[3] != 3:
+                raise ValueError("source rgb must be [nz, ny, nx, 3]")
+            keep.append(rgb)
+            sc.source.nz, sc.source.ny, sc.source.nx = rgb.shape[:3]
+            sc.source.rgb = _fp(rgb)
+            for k in range(3):
+                sc.source.index_scale[k] = float(problem.source["index_scale"][k])
+                sc.source.index_offset[k] = float(problem.source["index_offset"][k])
+            sc.source.intensity = float(problem.source.get("intensity", 1.0))
         st = Settings(w, h, settings.samplesPerPixel, settings.maxWalkingDepth, settings.epsilonShell)
         self._handle = C.c_void_p()
         _check(self.lib.wost3_create(C.byref(sc), C.byref(st), device, C.byref(self._handle)), "wost3_create")

@@ -353,12 +353,22 @@ typedef struct wost3_mesh_desc {
     const int32_t *tris;      /* n_tris * 3, 0-based */
     const float *colors;      /* n_verts * 6 or NULL = zeros */
 } wost3_mesh_desc;
+/* Source term f of laplace(u) = -f in 3-D (Problem<3>::source_vdb_ptr, core/problem.cu:136-149; sampled at
+ * integrator/uniform/integrator.cu:296-304): dense grid of RGB samples at integer index coordinates,
+ * index = world * index_scale + index_offset per axis, trilinear, zero outside.  nx == 0 disables the source term. */
+typedef struct wost3_source_desc {
+    int32_t nx, ny, nz;
+    const float *rgb;                        /* nz * ny * nx * 3, x fastest */
+    float index_scale[3], index_offset[3];
+    float intensity;                         /* source_intensity (core/problem.cu:179) */
+} wost3_source_desc;
 typedef struct wost3_scene_desc {
     wost3_mesh_desc dirichlet, neumann;      /* n_tris == 0 -> disabled */
     float dirichlet_intensity, neumann_intensity;
     float probe_scale;                       /* EvaluationGrid<3>::ProbeData: point = scale (ndc.x right + ndc.y up) + pos */
     float probe_pos[3], probe_up[3], probe_right[3];
     const uint8_t *mask;                     /* width*height bytes (0 = masked out) or NULL */
+    wost3_source_desc source;                /* zero-initialised = no source term */
 } wost3_scene_desc;
 typedef struct wost3_context *wost3_handle;
 int wost3_create(const wost3_scene_desc *scene, const wost_settings *settings, int device, wost3_handle *out);

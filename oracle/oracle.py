@@ -78,10 +78,15 @@ class Mesh3(C.Structure):
                 ("colors", C.POINTER(C.c_float))]
 
 
+class Source3(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("rgb", C.POINTER(C.c_float)), ("index_scale", C.c_float * 3),
+                ("index_offset", C.c_float * 3), ("intensity", C.c_float)]
+
+
 class Scene3(C.Structure):
     _fields_ = [("dirichlet", Mesh3), ("neumann", Mesh3), ("dirichlet_intensity", C.c_float), ("neumann_intensity", C.c_float),
                 ("probe_scale", C.c_float), ("probe_pos", C.c_float * 3), ("probe_up", C.c_float * 3),
-                ("probe_right", C.c_float * 3), ("mask", C.POINTER(C.c_ubyte))]
+                ("probe_right", C.c_float * 3), ("mask", C.POINTER(C.c_ubyte)), ("source", Source3)]
 
 
 class GuidedSettings(C.Structure):
@@ -316,7 +321,28 @@ class Oracle:
             mk = np.ascontiguousarray(mask, dtype=np.uint8)
             self._keep.append(mk)
             sc.mask = mk.ctypes.data_as(C.POINTER(C.c_ubyte))
+        src = sd.get("source")
+        if src is not None:
+            # {"rgb": [nz, ny, nx, 3], "index_scale": (sx, sy, sz), "index_offset": (ox, oy, oz), "intensity": f}
+            rgb = np.ascontiguousarray(src["rgb"], dtype=np.float32)
+            self._keep.append(rgb)
+            sc.source.nz, sc.source.ny, sc.source.nx = rgb.shape[:3]
+            sc.source.rgb = _fp(rgb)
+            for k in range(3):
+                sc.source.index_scale[k] = float(src["index_scale"][k])
+                sc.source.index_offset[k] = float(src["index_offset"][k])
+            sc.source.intensity = float(src.get("intensity", 1.0))
         return sc
+
+    def source_eval3(self, sd, pts):
+        sc = self.make_scene3(sd)
+        p = np.ascontiguousarray(pts, dtype=np.float32)
+        out = np.zeros((len(p), 3), np.float32)
+        tmp = (C.c_float * 3)()
+        for i in range(len(p)):
+            self.lib.wo3_source_eval(C.byref(sc.source), C.c_float(p[i, 0]), C.c_float(p[i, 1]), C.c_float(p[i, 2]), tmp)
+            out[i] = tmp[:]
+        return out
 
     def solve3(self, sd, width, height, spp, max_depth, eps, pixel_begin=0, pixel_end=None, threads=8):
         sc = self.make_scene3(sd)

@@ -147,13 +147,25 @@ typedef struct wo3_mesh {
     const int *tris;      /* n_tris * 3, 0-based */
     const float *colors;  /* n_verts * 6 (colour on the side the normal points to, colour on the other side) or NULL */
 } wo3_mesh;
+/* Source term f of  laplace(u) = -f  in 3-D: a dense grid of RGB samples at integer index coordinates,
+ * index = world * index_scale + index_offset per axis, trilinear (order-1) interpolation, zero outside -- what
+ * nanovdb's worldToIndex + SampleFromVoxels<.., 1> compute on the reference's Vec3fGrid (core/problem.cu:136-149,
+ * integrator/uniform/integrator.cu:296-304); the nanovdb file format itself cannot be read here. */
+typedef struct wo3_source {
+    int nx, ny, nz;                       /* nx == 0 -> no source term */
+    const float *rgb;                     /* [nz][ny][nx][3] */
+    float index_scale[3], index_offset[3];
+    float intensity;
+} wo3_source;
 typedef struct wo3_scene {
     wo3_mesh dirichlet, neumann;          /* n_tris == 0 -> disabled */
     float dirichlet_intensity, neumann_intensity;
     float probe_scale;                    /* EvaluationGrid<3>::ProbeData (core/evaluation_grid.h:48-55) */
     float probe_pos[3], probe_up[3], probe_right[3];
     const unsigned char *mask;
+    wo3_source source;
 } wo3_scene;
+void wo3_source_eval(const wo3_source *src, float x, float y, float z, float out[3]);
 int wo3_solve(const wo3_scene *sc, const wo_settings *st, int pixel_begin, int pixel_end, int n_threads, float *field_rgb,
               wo_stats *stats);
 /* closest triangle (lowest index on ties), distance, barycentric (u, v) of the projection, side */

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "wost_detmath.h"
 #include "wost_internal.h"
 #include "wost_oracle.h"
 
@@ -343,6 +344,38 @@ static v3 eval_point3(const wo3_scene *sc, int px, int py, int width, int height
     return r;
 }
 
+/* ---- source term (integrator/uniform/integrator.cu:235-316, DIM == 3) ---- */
+static void source3_tap(const wo3_source *src, int i, int j, int k, float v[3])
+{
+    if (i < 0 || j < 0 || k < 0 || i >= src->nx || j >= src->ny || k >= src->nz) { v[0] = v[1] = v[2] = 0.0f; return; }
+    const float *p = src->rgb + 3 * (((size_t)k * src->ny + j) * src->nx + i);
+    v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+}
+
+void wo3_source_eval(const wo3_source *src, float x, float y, float z, float out[3])
+{
+    const float gx = fmaf(x, src->index_scale[0], src->index_offset[0]);
+    const float gy = fmaf(y, src->index_scale[1], src->index_offset[1]);
+    const float gz = fmaf(z, src->index_scale[2], src->index_offset[2]);
+    const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+    const float u = gx - fx, v = gy - fy, w = gz - fz;
+    const int i = (int)fmaxf(fminf(fx, 1e9f), -1e9f), j = (int)fmaxf(fminf(fy, 1e9f), -1e9f), k = (int)fmaxf(fminf(fz, 1e9f), -1e9f);
+    float c[2][2][2][3];
+    for (int dk = 0; dk < 2; ++dk)
+        for (int dj = 0; dj < 2; ++dj)
+            for (int di = 0; di < 2; ++di) source3_tap(src, i + di, j + dj, k + dk, c[dk][dj][di]);
+    for (int ch = 0; ch < 3; ++ch) {
+        /* x, then y, then z */
+        const float a00 = c[0][0][0][ch] + (c[0][0][1][ch] - c[0][0][0][ch]) * u, a01 = c[0][1][0][ch] + (c[0][1][1][ch] - c[0][1][0][ch]) * u;
+        const float a10 = c[1][0][0][ch] + (c[1][0][1][ch] - c[1][0][0][ch]) * u, a11 = c[1][1][0][ch] + (c[1][1][1][ch] - c[1][1][0][ch]) * u;
+        const float b0 = a00 + (a01 - a00) * v, b1 = a10 + (a11 - a10) * v;
+        out[ch] = (b0 + (b1 - b0) * w) * src->intensity;
+    }
+}
+
+/* cube root of x in [0, 1] through the deterministic log / exp (the arithmetic contract's std::cbrt) */
+static float cbrt01(float x) { return x > 0.0f ? wo_expf(wo_logf(x) * (1.0f / 3.0f)) : 0.0f; }
+
 typedef struct { uint64_t steps, started, absorbed, truncated, nhits; } pix3_stats;
 
 static void solve_pixel3(const wo3_scene *sc, const wo_settings *st, const pmesh3 *dm, const pmesh3 *nm, int pixel_id,
@@ -389,6 +422,51 @@ static void solve_pixel3(const wo3_scene *sc, const wo_settings *st, const pmesh
             float R_B = fmaxf(WO_R_B_FLOOR, fminf(R_D, R_N));
             R_B *= WO_R_B_SHRINK;
             if (isinf(R_B)) break;
+            /* ---- sampleSource (integrator.cu:235-316), only when the problem has a source ---- */
+            if (sc->source.nx > 0) {
+                /* direction: uniform on the sphere, or on the hemisphere around the Neumann normal (the draws of oneStepWalk) */
+                v3 sdir;
+                float dir_pdf, salpha = 1.0f;
+                {
+                    const float u1 = wo_pcg_next_float(&rng), u2 = wo_pcg_next_float(&rng);
+                    float c, s;
+                    wo_sincos_2pi(u2, &c, &s);
+                    if (on_n) {
+                        const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+                        sdir = frame_to_world(nn, r * c, r * s, z);
+                        dir_pdf = 1.0f / WO_2PI;
+                        salpha = 0.5f;
+                    } else {
+                        const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
+                        sdir = (v3){ r * c, r * s, z };
+                        dir_pdf = 1.0f / WO_4PI;
+                    }
+                }
+                /* how far the straight line stays inside the star-shaped region (:279-292) */
+                float dist = R_B;
+                if (has_n) {
+                    float t; int hi;
+                    const v3 o = { p.x + eps * sdir.x, p.y + eps * sdir.y, p.z + eps * sdir.z };
+                    if (ray_closest3(nm, o, sdir, dist, &t, &hi)) dist = fminf(t, dist);
+                }
+                /* HarmonicGreenBall<3>::sample (util/green.h:101-116): closed form, two draws */
+                const float g1 = wo_pcg_next_float(&rng), g2 = wo_pcg_next_float(&rng);
+                float gc, gs;
+                wo_sincos_2pi(g2, &gc, &gs);
+                float r = (1.0f + sqrtf(1.0f - cbrt01(g1 * g1)) * gc) * R_B / 2.0f;
+                r = fmaxf(1e-4f, r);                                            /* ELAINA_GREEN_FUNC_R_CLAMP */
+                if (r > R_B) r = R_B / 2.0f;
+                if (r <= dist) {
+                    float f[3];
+                    wo3_source_eval(&sc->source, p.x + r * sdir.x, p.y + r * sdir.y, p.z + r * sdir.z, f);
+                    const float norm = R_B * R_B / 6.0f;
+                    const float c1 = (1.0f / WO_4PI) / (r * r), c2 = dir_pdf / (r * r);     /* conditionalSampleSpherePDF<3> */
+                    for (int c = 0; c < 3; ++c) {
+                        const float col = thp * f[c] * norm * c1 / c2 / salpha;
+                        sol[c] = col + sol[c];
+                    }
+                }
+            }
             /* ---- sampleNeumann (integrator.cu:336-444): three draws in 3-D ---- */
             if (has_n) {
                 const float u0 = wo_pcg_next_float(&rng), u1 = wo_pcg_next_float(&rng), u2 = wo_pcg_next_float(&rng);

@@ -120,3 +120,29 @@ def test_3d_neumann_mesh_of_hundreds_of_triangles(oracle):
     big = cube_scene3(n=48, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x)
     with pytest.raises(WostError):
         _it(big, 8, 8, 1, 4, 1e-3)
+
+
+@pytest.mark.parametrize("case", ["ball", "cube_with_reflecting_walls", "emissive_walls_and_mask"])
+def test_3d_source_term_matches_oracle(oracle, case):
+    """sampleSource in 3-D (dense grid, trilinear; HarmonicGreenBall<3>::sample): bit-exact against the oracle, whose
+    Poisson solutions are checked analytically in tests/test_oracle_3d.py"""
+    from test_oracle_3d import _unit_source
+    if case == "ball":
+        sd = sphere_scene3(subdiv=2, value=lambda x, y, z: 0.25 * x)
+        sd["probe"] = (0.5, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0))
+        sd["source"] = _unit_source()
+        w, h = 16, 16
+    else:
+        flux = (lambda x, y, z, f: 0.0) if case.startswith("cube") else (lambda x, y, z, f: {4: 0.5, 5: -0.5}.get(f, 0.0))
+        sd = cube_scene3(n=2, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x, flux=flux, weld=case.startswith("cube"))
+        rng = np.random.default_rng(4)
+        sd["source"] = {"rgb": rng.uniform(0, 2, (3, 4, 5, 3)).astype(np.float32), "index_scale": (4.0, 3.0, 2.0),
+                        "index_offset": (0.0, 0.0, 0.0), "intensity": 1.5}
+        w, h = (16, 12) if case.startswith("cube") else (19, 13)
+        if not case.startswith("cube"):
+            sd["mask"] = (np.arange(w * h) % 4 != 1).astype(np.uint8)
+    ref = _same_solve(oracle, sd, w, h, 12, 64, 2e-3)
+    assert np.any(ref["field"] != 0)
+    if case != "ball":
+        assert ref["neumann_hits"] > 0
+        assert not np.array_equal(ref["field"][:, 0], ref["field"][:, 1])      # the random source grid differs per channel

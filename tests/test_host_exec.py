@@ -354,3 +354,14 @@ def test_run_expr_three_dimensional_configuration(tmp_path, oracle):
     json.dump(cj, open(conf, "w"))
     out = subprocess.run([_exe(), conf], capture_output=True, text=True)
     assert out.returncode == 1 and "integrator type" in out.stderr
+    # a Poisson problem: the source term as a dense 3-D grid ("source_grid" with nz)
+    from test_oracle_3d import _unit_source
+    sd["source"] = dict(_unit_source(), intensity=0.75)
+    conf = export_scene.export3(sd, str(tmp_path / "poisson"), frame=(16, 16), spp=5, depth=48, eps=2e-3)
+    out = subprocess.run([_exe(), conf], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    ref = oracle.solve3(sd, 16, 16, 5, 48, 2e-3, threads=os.cpu_count())
+    got = export_scene.read_pfm(tmp_path / "poisson" / "exp" / "scene3d" / "solution.pfm")
+    assert np.array_equal(got, ref["field"])
+    plain = oracle.solve3({k: v for k, v in sd.items() if k != "source"}, 16, 16, 5, 48, 2e-3, threads=4)["field"]
+    assert np.mean(got[:, 0] - plain[:, 0]) > 0.01          # f > 0 raises the solution

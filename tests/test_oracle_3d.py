@@ -135,3 +135,57 @@ def test_oracle_solves_harmonic_problems_in_3d(oracle, case):
     r2 = oracle.solve3(sd, w, h, 8, 64, eps, threads=3)
     r3 = oracle.solve3(sd, w, h, 8, 64, eps, threads=8)
     assert np.array_equal(r2["field"], r3["field"]) and r2["walk_steps"] == r3["walk_steps"]
+
+
+def _unit_source(value=1.0, n=5, lo=-1.3, hi=1.3):
+    """a constant source f = value on a dense grid over [lo, hi]^3 (index = (x - lo) * (n - 1) / (hi - lo))"""
+    sc = (n - 1) / (hi - lo)
+    return {"rgb": np.full((n, n, n, 3), value, np.float32), "index_scale": (sc, sc, sc), "index_offset": (-lo * sc,) * 3, "intensity": 1.0}
+
+
+def test_source_grid_is_trilinear_and_zero_outside(oracle):
+    rng = np.random.default_rng(3)
+    g = rng.uniform(0, 1, (4, 5, 6, 3)).astype(np.float32)          # [nz, ny, nx, 3]
+    sd = sphere_scene3(subdiv=0)
+    sd["source"] = {"rgb": g, "index_scale": (2.0, 1.0, 0.5), "index_offset": (1.0, 2.0, 1.5), "intensity": 3.0}
+    pts = rng.uniform(-1.5, 4.0, (400, 3)).astype(np.float32)
+    got = oracle.source_eval3(sd, pts)
+    gi = pts.astype(np.float64) * np.array([2.0, 1.0, 0.5]) + np.array([1.0, 2.0, 1.5])
+    f = np.floor(gi)
+    t = gi - f
+    want = np.zeros((len(pts), 3))
+    for dk in (0, 1):
+        for dj in (0, 1):
+            for di in (0, 1):
+                i, j, k = (f[:, 0] + di).astype(int), (f[:, 1] + dj).astype(int), (f[:, 2] + dk).astype(int)
+                ok = (i >= 0) & (i < 6) & (j >= 0) & (j < 5) & (k >= 0) & (k < 4)
+                wgt = np.where(di, t[:, 0], 1 - t[:, 0]) * np.where(dj, t[:, 1], 1 - t[:, 1]) * np.where(dk, t[:, 2], 1 - t[:, 2])
+                v = np.zeros((len(pts), 3))
+                v[ok] = g[k[ok], j[ok], i[ok]]
+                want += wgt[:, None] * v
+    np.testing.assert_allclose(got, 3.0 * want, rtol=2e-5, atol=2e-6)
+    assert np.all(got[(gi < -1).any(axis=1)] == 0)
+
+
+@pytest.mark.parametrize("case", ["ball", "cube_with_reflecting_walls"])
+def test_oracle_solves_poisson_problems_in_3d(oracle, case):
+    """laplace(u) = -f with f = 1: u = (1 - r^2) / 6 in the unit ball with u = 0 on the sphere (sampleSource with
+    HarmonicGreenBall<3>::sample); u = x (1 - x) / 2 between two Dirichlet planes with reflecting (zero-flux) side walls"""
+    w = h = 10
+    if case == "ball":
+        sd = sphere_scene3(subdiv=3, value=lambda x, y, z: 0.0)
+        sd["probe"] = (0.5, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0))
+        exact = lambda p: (1.0 - (p ** 2).sum(axis=1)) / 6.0
+    else:
+        sd = cube_scene3(n=2, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: 0.0, flux=lambda x, y, z, f: 0.0)
+        exact = lambda p: p[:, 0] * (1.0 - p[:, 0]) / 2.0
+    sd["source"] = _unit_source()
+    r = oracle.solve3(sd, w, h, 512, 256, 2e-3, threads=8)
+    got, ref = r["field"][:, 0], exact(eval_points(sd, w, h))
+    assert abs(float(np.mean(got - ref))) < 3e-3, float(np.mean(got - ref))
+    assert float(np.sqrt(np.mean((got - ref) ** 2))) < 0.02
+    if case != "ball":
+        assert r["neumann_hits"] > 0
+    # no source -> the homogeneous problem: exactly zero
+    del sd["source"]
+    assert np.all(oracle.solve3(sd, w, h, 4, 64, 2e-3, threads=4)["field"] == 0)

@@ -124,6 +124,15 @@ def export3(sd, out_dir, frame=(32, 32), spp=8, depth=64, eps=2e-3, exp_name="sc
         "scene": {"evaluation_grid": {"mData": {"pos": [float(v) for v in pos], "scale": float(scale), "up": [float(v) for v in up],
                                                 "right": [float(v) for v in right]}},
                   "mesh": mesh}}
+    src = sd.get("source")
+    if src is not None:
+        import numpy as np
+        rgb = np.ascontiguousarray(src["rgb"], dtype="<f4")
+        rgb.tofile(os.path.join(out_dir, "source.f32"))
+        conf["scene"]["source_grid"] = {"path": os.path.join(out_dir, "source.f32"), "nx": int(rgb.shape[2]), "ny": int(rgb.shape[1]),
+                                        "nz": int(rgb.shape[0]), "index_scale": [float(v) for v in src["index_scale"]],
+                                        "index_offset": [float(v) for v in src["index_offset"]]}
+        conf["scene"]["source_intensity"] = float(src.get("intensity", 1.0))
     path = os.path.join(out_dir, "conf.json")
     with open(path, "w") as f:
         json.dump(conf, f, indent=4)
