@@ -623,6 +623,28 @@ __global__ __launch_bounds__(256) void closest_point3_kernel(DevMesh3 m, const f
     if (out_side) out_side[i] = tri_side(p0, cross3(e0, e1), q);
 }
 
+// debug channels at the evaluation points of the frame
+__global__ __launch_bounds__(256) void render3_sdf_kernel(DevMesh3 m, DevProbe3 probe, int width, int height, int silhouette, float *out)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const LdsColumn stk(lds_stack + threadIdx.x, blockDim.x);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * height) return;
+    const V3 q = eval_point3(probe, i % width, i / width, width, height);
+    float d = WOST_INF;
+    if (m.n_tris > 0) d = silhouette ? closest_silhouette3_flat(m, q, WOST_INF) : sqrtf(closest_triangle(m, q, -1, stk).d2);
+    out[i] = d;
+}
+
+__global__ __launch_bounds__(256) void render3_source_kernel(DevSource3 src, DevProbe3 probe, int width, int height, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * height) return;
+    float f[3] = {0.0f, 0.0f, 0.0f};
+    if (src.rgb) source3_eval(src, eval_point3(probe, i % width, i / width, width, height), f);
+    out[3 * (size_t)i] = f[0]; out[3 * (size_t)i + 1] = f[1]; out[3 * (size_t)i + 2] = f[2];
+}
+
 __global__ __launch_bounds__(256) void silhouette3_kernel(DevMesh3 m, const float *pts, const float *rmax, int n, float *out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1085,6 +1107,40 @@ int wost3_closest_silhouette(wost3_handle h, int which_mesh, const float *pts, c
     hipLaunchKernelGGL(silhouette3_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, m->view, d_pts, d_rmax, n, d_out);
     W3_TRY(hipGetLastError());
     W3_TRY(hipMemcpyAsync(out_dist, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    W3_TRY(hipStreamSynchronize(h->stream));
+    return WOST_OK;
+}
+
+int wost3_render_sdf(wost3_handle h, int which_mesh, float *out_dist)
+{
+    if (!h || !out_dist) return set_error(WOST_ERR_INVALID, "null argument");
+    DeviceMesh3 *m = pick3(h, which_mesh);
+    if (!m) return set_error(WOST_ERR_INVALID, "unknown mesh selector");
+    W3_TRY(hipSetDevice(h->device));
+    const int n = (int)h->n_pixels;
+    Scratch3 s;
+    float *d_out;
+    W3_TRY(s.alloc(&d_out, n));
+    const size_t lds = (size_t)(3 * (m->view.n_tris > 0 ? m->view.levels : 1) + 1) * 256 * sizeof(uint32_t);
+    hipLaunchKernelGGL(render3_sdf_kernel, dim3((n + 255) / 256), dim3(256), lds, h->stream, m->view, h->probe, h->settings.width, h->settings.height,
+                       which_mesh == WOST_MESH_NEUMANN ? 1 : 0, d_out);
+    W3_TRY(hipGetLastError());
+    W3_TRY(hipMemcpyAsync(out_dist, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    W3_TRY(hipStreamSynchronize(h->stream));
+    return WOST_OK;
+}
+
+int wost3_render_source(wost3_handle h, float *out_rgb)
+{
+    if (!h || !out_rgb) return set_error(WOST_ERR_INVALID, "null argument");
+    W3_TRY(hipSetDevice(h->device));
+    const int n = (int)h->n_pixels;
+    Scratch3 s;
+    float *d_out;
+    W3_TRY(s.alloc(&d_out, (size_t)n * 3));
+    hipLaunchKernelGGL(render3_source_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->src, h->probe, h->settings.width, h->settings.height, d_out);
+    W3_TRY(hipGetLastError());
+    W3_TRY(hipMemcpyAsync(out_rgb, d_out, (size_t)n * 12, hipMemcpyDeviceToHost, h->stream));
     W3_TRY(hipStreamSynchronize(h->stream));
     return WOST_OK;
 }

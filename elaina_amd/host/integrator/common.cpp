@@ -19,6 +19,8 @@ static void gray_to_rgb(const std::vector<float> &g, std::vector<float> &rgb)
     for (size_t i = 0; i < g.size(); ++i) rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = g[i];
 }
 
+void IntegratorOutputs::set_gray_channel(ExportImageChannel c, const std::vector<float> &gray) { gray_to_rgb(gray, channels[(size_t)c]); }
+
 void IntegratorOutputs::render_sdf(wost_handle scene, int which_mesh, ExportImageChannel c)
 {
     std::vector<float> d((size_t)frameSize_.x * frameSize_.y);

@@ -22,6 +22,7 @@ public:
 
 protected:
     void render_sdf(wost_handle scene, int which_mesh, ExportImageChannel c);
+    void set_gray_channel(ExportImageChannel c, const std::vector<float> &gray);   // a distance per pixel as an RGB channel
 
     Vector2i frameSize_;
     fs::path basePath;

@@ -96,6 +96,27 @@ UniformIntegrator<3>::UniformIntegrator(Problem<3> &problem_, const IntegratorSe
     check_wost(wost3_create(&sd, &st, device, &handle), "wost3_create");
 }
 
+void UniformIntegrator<3>::renderDirichletSDF()
+{
+    std::vector<float> d((size_t)frameSize_.x * frameSize_.y);
+    check_wost(wost3_render_sdf(handle, WOST_MESH_DIRICHLET, d.data()), "wost3_render_sdf");
+    set_gray_channel(ExportImageChannel::DIRICHLET_SDF, d);
+}
+
+void UniformIntegrator<3>::renderSilhouetteSDF()
+{
+    std::vector<float> d((size_t)frameSize_.x * frameSize_.y);
+    check_wost(wost3_render_sdf(handle, WOST_MESH_NEUMANN, d.data()), "wost3_render_sdf");
+    set_gray_channel(ExportImageChannel::NEUMANN_SDF, d);
+}
+
+void UniformIntegrator<3>::renderSource()
+{
+    std::vector<float> &c = channels[(size_t)ExportImageChannel::SOURCE];
+    c.assign((size_t)frameSize_.x * frameSize_.y * 3, 0.0f);
+    check_wost(wost3_render_source(handle, c.data()), "wost3_render_source");
+}
+
 UniformIntegrator<3>::~UniformIntegrator()
 {
     if (handle) wost3_destroy(handle);

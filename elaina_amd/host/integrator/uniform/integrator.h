@@ -56,8 +56,7 @@ private:
     wost_stats last_stats{};
 };
 
-// UniformIntegrator<3> (reference integrator/uniform/integrator.h:55-131 with DIM = 3): SOLUTION only --
-// the SDF and source channels of the 3-D integrator are not built.
+// UniformIntegrator<3> (reference integrator/uniform/integrator.h:55-131 with DIM = 3)
 template <> class UniformIntegrator<3> : public IntegratorOutputs {
 public:
     using IntegratorSettings = UniformIntegratorSettings;
@@ -70,9 +69,9 @@ public:
     UniformIntegrator &operator=(const UniformIntegrator &) = delete;
 
     uint64_t solve();
-    void renderDirichletSDF() { throw std::runtime_error("renderDirichletSDF: not built for 3-D"); }
-    void renderSilhouetteSDF() { throw std::runtime_error("renderSilhouetteSDF: not built for 3-D"); }
-    void renderSource() { throw std::runtime_error("renderSource: not built for 3-D"); }
+    void renderDirichletSDF();
+    void renderSilhouetteSDF();
+    void renderSource();
     void queryNetwork(const VectorType &p);
     const wost_stats &get_last_stats() const { return last_stats; }
 

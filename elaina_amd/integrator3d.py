@@ -99,6 +99,18 @@ class UniformIntegrator3:
         self.solution, self.last_stats = field, st.as_dict()
         return int(st.solve_ms)
 
+    def render_sdf(self, which=0):
+        """renderDirichletSDF (which = 0) / renderSilhouetteSDF (which = 1): one distance per pixel of the frame"""
+        out = np.zeros(self.n_pixels, dtype=np.float32)
+        _check(self.lib.wost3_render_sdf(self._handle, int(which), _fp(out)), "wost3_render_sdf")
+        return out
+
+    def render_source(self):
+        """renderSource: intensity * f at every pixel's evaluation point"""
+        out = np.zeros((self.n_pixels, 3), dtype=np.float32)
+        _check(self.lib.wost3_render_source(self._handle, _fp(out)), "wost3_render_source")
+        return out
+
     def solve_sharded(self, shard_index, shard_count, field_dev_ptr, stream_ptr=None):
         st = Stats()
         _check(self.lib.wost3_solve_sharded(self._handle, shard_index, shard_count, C.c_void_p(field_dev_ptr),

@@ -386,6 +386,11 @@ int wost3_closest_silhouette(wost3_handle h, int which_mesh, const float *pts, c
 /* lbvh::ray_intersect on triangles: closest hit (flag, t, triangle) */
 int wost3_ray_intersect(wost3_handle h, int which_mesh, const float *origins, const float *dirs, const float *tmax, int32_t n,
                         int32_t *out_hit, float *out_t, int32_t *out_idx);
+/* renderDirichletSDF / renderSilhouetteSDF / renderSource with DIM = 3 (integrator/common.h:52-163): one query per pixel
+ * of the frame at its evaluation point; which_mesh as above; out_dist width*height floats (+inf without that mesh),
+ * out_rgb width*height*3 floats (zeros without a source term) */
+int wost3_render_sdf(wost3_handle h, int which_mesh, float *out_dist);
+int wost3_render_source(wost3_handle h, float *out_rgb);
 int wost3_destroy(wost3_handle h);
 
 const char *wost_last_error(void);

@@ -359,6 +359,22 @@ class Oracle:
                                                          "neumann_hits")})
         return out
 
+    def render_sdf3(self, sd, width, height, which):
+        sc = self.make_scene3(sd)
+        st = Settings(width, height, 1, 1, 1e-3)
+        out = np.zeros(width * height, np.float32)
+        if self.lib.wo3_render_sdf(C.byref(sc), C.byref(st), int(which), _fp(out)) != 0:
+            raise RuntimeError("wo3_render_sdf failed")
+        return out
+
+    def render_source3(self, sd, width, height):
+        sc = self.make_scene3(sd)
+        st = Settings(width, height, 1, 1, 1e-3)
+        out = np.zeros((width * height, 3), np.float32)
+        if self.lib.wo3_render_source(C.byref(sc), C.byref(st), _fp(out)) != 0:
+            raise RuntimeError("wo3_render_source failed")
+        return out
+
     def closest_point3(self, verts, tris, pts):
         self._keep = []
         m = self._mesh3(verts, tris, None)

@@ -175,6 +175,11 @@ int wo3_closest_silhouette_batch(const wo3_mesh *mesh, const float *pts, const f
 int wo3_ray_intersect_batch(const wo3_mesh *mesh, const float *origins, const float *dirs, const float *tmax, int n,
                             int *out_hit, float *out_t, int *out_idx);
 void wo3_green_ball(float R, float r, float *eval, float *norm, float *pdf_radius);
+/* debug channels of the 3-D integrator at the evaluation points of the frame (integrator/common.h:52-163 with DIM = 3):
+ * which = 0 distance to the Dirichlet mesh, 1 distance to the closest silhouette edge of the Neumann mesh
+ * (+inf without that mesh); the source channel = intensity * f (zeros without a source term) */
+int wo3_render_sdf(const wo3_scene *sc, const wo_settings *st, int which, float *out_dist);
+int wo3_render_source(const wo3_scene *sc, const wo_settings *st, float *out_rgb);
 
 /* ---- guided path, deterministic distribution layer (oracle/wost_vmm.c) ---- */
 float wo_eval_poly_large0(float y);

@@ -590,6 +590,34 @@ int wo3_closest_point_batch(const wo3_mesh *mesh, const float *pts, int n, int *
     return 0;
 }
 
+int wo3_render_sdf(const wo3_scene *sc, const wo_settings *st, int which, float *out_dist)
+{
+    pmesh3 m;
+    if (!sc || !st || !out_dist || (which != 0 && which != 1)) return -1;
+    if (pmesh3_prepare(&m, which == 0 ? &sc->dirichlet : &sc->neumann) != 0) return -1;
+    const int n = st->width * st->height;
+    for (int i = 0; i < n; ++i) {
+        const v3 q = eval_point3(sc, i % st->width, i / st->width, st->width, st->height);
+        float d = INFINITY;
+        if (m.n_tris > 0) d = which == 0 ? sqrtf(closest_tri(&m, q).d2) : closest_silhouette3(&m, q, INFINITY);
+        out_dist[i] = d;
+    }
+    pmesh3_free(&m);
+    return 0;
+}
+
+int wo3_render_source(const wo3_scene *sc, const wo_settings *st, float *out_rgb)
+{
+    if (!sc || !st || !out_rgb) return -1;
+    const int n = st->width * st->height;
+    for (int i = 0; i < n; ++i) {
+        const v3 q = eval_point3(sc, i % st->width, i / st->width, st->width, st->height);
+        if (sc->source.nx > 0) wo3_source_eval(&sc->source, q.x, q.y, q.z, out_rgb + 3 * (size_t)i);
+        else out_rgb[3 * (size_t)i] = out_rgb[3 * (size_t)i + 1] = out_rgb[3 * (size_t)i + 2] = 0.0f;
+    }
+    return 0;
+}
+
 int wo3_closest_silhouette_batch(const wo3_mesh *mesh, const float *pts, const float *rmax, int n, float *out_dist)
 {
     pmesh3 m;

@@ -146,3 +146,23 @@ def test_3d_source_term_matches_oracle(oracle, case):
     if case != "ball":
         assert ref["neumann_hits"] > 0
         assert not np.array_equal(ref["field"][:, 0], ref["field"][:, 1])      # the random source grid differs per channel
+
+
+def test_3d_debug_channels_match_oracle(oracle):
+    """renderDirichletSDF / renderSilhouetteSDF / renderSource of the 3-D integrator: one query per pixel at its evaluation point"""
+    from test_oracle_3d import _unit_source
+    sd = cube_scene3(n=3, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x, flux=lambda x, y, z, f: 0.0)
+    sd["probe"] = (0.8, (0.5, 0.5, 0.4), (0.0, 0.6, 0.8), (1.0, 0.0, 0.0))      # a tilted slice that leaves the cube
+    sd["source"] = dict(_unit_source(n=4, lo=-0.2, hi=1.2), intensity=2.0)
+    sd["source"]["rgb"] = np.random.default_rng(1).uniform(0, 1, (4, 4, 4, 3)).astype(np.float32)
+    it = _it(sd, 21, 17, 1, 4, 1e-3)
+    for which in (0, 1):
+        got, want = it.render_sdf(which), oracle.render_sdf3(sd, 21, 17, which)
+        assert np.array_equal(got, want) and np.isfinite(got).all() and got.max() > 0.1
+    assert np.array_equal(it.render_source(), oracle.render_source3(sd, 21, 17))
+    it.close()
+    # without the meshes / the source: +inf and zeros
+    only_d = sphere_scene3(subdiv=1, value=lambda x, y, z: 1.0)
+    it = _it(only_d, 8, 8, 1, 4, 1e-3)
+    assert np.all(np.isinf(it.render_sdf(1))) and np.all(it.render_source() == 0)
+    it.close()

@@ -349,6 +349,9 @@ def test_run_expr_three_dimensional_configuration(tmp_path, oracle):
     ref = oracle.solve3(sd, 24, 16, 6, 48, 2e-3, threads=os.cpu_count())
     assert res["walk_steps"] == ref["walk_steps"] and "duration" in res
     assert np.array_equal(export_scene.read_pfm(exp / "solution.pfm"), ref["field"])
+    # the SDF channels of the 3-D integrator (renderDirichletSDF / renderSilhouetteSDF, integrator/common.h:52-123)
+    assert np.array_equal(export_scene.read_pfm(exp / "dirichlet_sdf.pfm")[:, 0], oracle.render_sdf3(sd, 24, 16, 0))
+    assert np.array_equal(export_scene.read_pfm(exp / "neumann_sdf.pfm")[:, 0], oracle.render_sdf3(sd, 24, 16, 1))
     cj = json.load(open(conf))
     cj["integrator"]["type"] = "guided"
     json.dump(cj, open(conf, "w"))
@@ -365,3 +368,4 @@ def test_run_expr_three_dimensional_configuration(tmp_path, oracle):
     assert np.array_equal(got, ref["field"])
     plain = oracle.solve3({k: v for k, v in sd.items() if k != "source"}, 16, 16, 5, 48, 2e-3, threads=4)["field"]
     assert np.mean(got[:, 0] - plain[:, 0]) > 0.01          # f > 0 raises the solution
+    assert np.array_equal(export_scene.read_pfm(tmp_path / "poisson" / "exp" / "scene3d" / "source.pfm"), oracle.render_source3(sd, 16, 16))

@@ -119,8 +119,10 @@ def export3(sd, out_dir, frame=(32, 32), spp=8, depth=64, eps=2e-3, exp_name="sc
         "integrator": {
             "setting": {"debugPixel": 0, "frameSize": [int(frame[0]), int(frame[1])], "maxWalkingDepth": depth, "samplesPerPixel": spp,
                         "saveSppMetricsDuration": -1, "saveSppMetricsUntil": -1, "saveTimeMetricsDuration": -1, "epsilonShell": float(eps)},
-            "type": "uniform", "channels": ["SOLUTION"]},
-        "export": [{"type": "image", "channel": "SOLUTION", "file_name": "solution"}],
+            "type": "uniform", "channels": ["SOLUTION", "DIRICHLET_SDF", "NEUMANN_SDF"]},
+        "export": [{"type": "image", "channel": "SOLUTION", "file_name": "solution"},
+                   {"type": "image", "channel": "DIRICHLET_SDF", "file_name": "dirichlet_sdf"},
+                   {"type": "image", "channel": "NEUMANN_SDF", "file_name": "neumann_sdf"}],
         "scene": {"evaluation_grid": {"mData": {"pos": [float(v) for v in pos], "scale": float(scale), "up": [float(v) for v in up],
                                                 "right": [float(v) for v in right]}},
                   "mesh": mesh}}
@@ -133,6 +135,8 @@ def export3(sd, out_dir, frame=(32, 32), spp=8, depth=64, eps=2e-3, exp_name="sc
                                         "nz": int(rgb.shape[0]), "index_scale": [float(v) for v in src["index_scale"]],
                                         "index_offset": [float(v) for v in src["index_offset"]]}
         conf["scene"]["source_intensity"] = float(src.get("intensity", 1.0))
+        conf["integrator"]["channels"].append("SOURCE")
+        conf["export"].append({"type": "image", "channel": "SOURCE", "file_name": "source"})
     path = os.path.join(out_dir, "conf.json")
     with open(path, "w") as f:
         json.dump(conf, f, indent=4)
