@@ -12,9 +12,9 @@
 // but a whole solve is ONE launch: a lane runs its pixel to the end.  Closest-point queries descend
 // an implicit 4-ary LBVH over the triangles (3-D Morton order, axis-aligned child boxes, 96-byte
 // nodes, near-first with the per-lane LDS stack and the key format of the 2-D tree, wost_device.h).
-// The Neumann mesh of this first 3-D slice is walked with wave-uniform flat loops (a box, a clipped plane:
-// every Neumann-side query is O(triangles), so meshes of hundreds of triangles work but are slow, and
-// WOST3_FLAT_MAX = 4096 is refused); a Neumann-side tree is not built.  Source term: a dense grid, trilinear.  Arithmetic contract: DESIGN.md 2.3 (the CPU restatement the tests compare against
+// Neumann meshes of up to WOST3_FLAT_MAX triangles (a box, a clipped plane) are walked with wave-uniform flat
+// loops; larger ones descend the same kind of tree for the silhouette and ray queries (the triangle sampling of an
+// EMISSIVE Neumann mesh stays a flat loop, as in 2-D).  Source term: a dense grid, trilinear.  Arithmetic contract: DESIGN.md 2.3 (the CPU restatement the tests compare against
 // follows the same contract operation for operation).
 #include <hip/hip_runtime.h>
 
@@ -35,7 +35,7 @@
 namespace wost {
 
 #define WOST_4PI 12.5663706143591729539f
-#define WOST3_FLAT_MAX 4096
+#define WOST3_FLAT_MAX 64        // Neumann meshes up to this size are walked with flat loops, larger ones through their tree
 
 struct V3 {
     float x, y, z;
@@ -72,7 +72,9 @@ struct DevMesh3 {
     const int32_t *triVerts; // [slots * 3] vertex ids (colour lookup)
     const float *colors;     // [n_verts * 6] or nullptr
     const DevTri *flat;      // [n_tris] original order
+    const int32_t *flatVerts;// [n_tris * 3] vertex ids, original order
     const DevEdge3 *edges;   // [n_edges]
+    const int32_t *triEdges; // [slots * 3] the edge records of a triangle's three sides (-1: degenerate side)
     int32_t n_tris, n_edges, levels, first_leaf, emissive;
 };
 
@@ -314,6 +316,205 @@ __device__ __forceinline__ int sample_in_sphere3_flat(const DevMesh3 &m, V3 q, f
     return last;
 }
 
+// ---- the same queries on the tree, for Neumann meshes too large for flat loops -------------------------
+// silhouette: an edge lies inside its triangle, a triangle inside its (padded) box, so boxes farther than the best
+// silhouette edge so far cannot improve it; a leaf tests the three sides of its four triangles with the body of the
+// flat loop (an edge shared by two triangles is simply tested twice).  The result is a minimum: order-free.
+__device__ __forceinline__ void silhouette_edge_test(const DevMesh3 &m, int e, V3 q, float &best2, bool &found)
+{
+    const DevEdge3 E = m.edges[e];
+    const V3 pa = ld3(E.pa), pb = ld3(E.pb), ev = pb - pa;
+    const float ee = dot3(ev, ev);
+    float t = ee > 0.0f ? dot3(q - pa, ev) / ee : 0.0f;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const V3 pt = madd3(pa, t, ev), view = q - pt;
+    const float d2 = dot3(view, view);
+    if (d2 > best2) return;
+    bool is_sil = E.t1 < 0;
+    if (!is_sil) {
+        const V3 n0 = ld3(m.flat[E.t0].n), n1 = ld3(m.flat[E.t1].n);
+        const float d = sqrtf(d2);
+        if (d <= WOST_SIL_PRECISION) {
+            const float det = dot3(normalize3(ev), cross3(n0, n1));
+            is_sil = (-det > WOST_SIL_PRECISION);
+        } else {
+            const V3 vd = v3(view.x / d, view.y / d, view.z / d);
+            const float dot0 = dot3(vd, n0), dot1 = dot3(vd, n1);
+            is_sil = !(fabsf(dot0) <= WOST_SIL_PRECISION || fabsf(dot1) <= WOST_SIL_PRECISION) && (dot0 * dot1 < 0.0f);
+        }
+    }
+    if (is_sil && (d2 < best2 || !found)) {
+        best2 = d2;
+        found = true;
+    }
+}
+
+__device__ __forceinline__ float closest_silhouette3_tree(const DevMesh3 &m, V3 q, float rmax, const LdsColumn &stk)
+{
+    Trav T = trav_begin(Closest{rmax * rmax, -1});
+    bool found = false;
+    for (;;) {
+        bool more;
+        if (T.level == m.levels) {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const int slot = 4 * T.pos + j;
+                if (m.triOrig[slot] == WOST_FAR_INDEX) continue;
+#pragma unroll 1
+                for (int k = 0; k < 3; ++k) {
+                    const int e = m.triEdges[3 * (size_t)slot + k];
+                    if (e >= 0) silhouette_edge_test(m, e, q, T.best.d2, found);
+                }
+            }
+            more = trav_pop(T, stk);
+        } else {
+            const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
+            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+            const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
+            const float d0 = aabb_d2(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, q), d1 = aabb_d2(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, q);
+            const float d2 = aabb_d2(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, q), d3 = aabb_d2(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, q);
+            const float bd = T.best.d2;
+            const uint32_t tag = (uint32_t)(T.level + 1) << 2;
+            uint32_t k0 = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;
+            uint32_t k1 = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3Fu) | tag | 1u) : 0xffffffffu;
+            uint32_t k2 = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3Fu) | tag | 2u) : 0xffffffffu;
+            uint32_t k3 = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3Fu) | tag | 3u) : 0xffffffffu;
+            cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
+            int sp = T.sp;
+            stk.put(sp, k3); sp += (k3 != 0xffffffffu) ? 1 : 0;
+            stk.put(sp, k2); sp += (k2 != 0xffffffffu) ? 1 : 0;
+            stk.put(sp, k1); sp += (k1 != 0xffffffffu) ? 1 : 0;
+            T.sp = sp;
+            if (k0 != 0xffffffffu) {
+                T.pos = 4 * T.pos + (int)(k0 & 3u);
+                T.level = T.level + 1;
+                more = true;
+            } else {
+                more = trav_pop(T, stk);
+            }
+        }
+        if (!more) break;
+    }
+    return found ? sqrtf(T.best.d2) : WOST_INF;
+}
+
+// rays: where the ray enters a child box (slabs; the boxes are padded and the comparison is slack, so a box that
+// holds a hit of tri_ray is never skipped), +inf if it misses it or enters beyond `limit`
+__device__ __forceinline__ float ray_aabb_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 o, V3 d, V3 inv, float limit)
+{
+    float tmin = 0.0f, tmax = limit;
+    // an axis the ray does not move along only asks whether the origin lies in the slab
+    {
+        const float t1 = (lox - o.x) * inv.x, t2 = (hix - o.x) * inv.x;
+        const bool par = d.x == 0.0f;
+        const bool out = par && (o.x < lox || o.x > hix);
+        tmin = out ? WOST_INF : fmaxf(tmin, par ? tmin : fminf(t1, t2));
+        tmax = par ? tmax : fminf(tmax, fmaxf(t1, t2));
+    }
+    {
+        const float t1 = (loy - o.y) * inv.y, t2 = (hiy - o.y) * inv.y;
+        const bool par = d.y == 0.0f;
+        const bool out = par && (o.y < loy || o.y > hiy);
+        tmin = out ? WOST_INF : fmaxf(tmin, par ? tmin : fminf(t1, t2));
+        tmax = par ? tmax : fminf(tmax, fmaxf(t1, t2));
+    }
+    {
+        const float t1 = (loz - o.z) * inv.z, t2 = (hiz - o.z) * inv.z;
+        const bool par = d.z == 0.0f;
+        const bool out = par && (o.z < loz || o.z > hiz);
+        tmin = out ? WOST_INF : fmaxf(tmin, par ? tmin : fminf(t1, t2));
+        tmax = par ? tmax : fminf(tmax, fmaxf(t1, t2));
+    }
+    // slack of a few ulps on the comparison: the parameter of a hit and the slab parameters are rounded independently
+    return (tmin <= tmax * 1.00001f + 1e-30f) ? fminf(tmin, tmax) : WOST_INF;
+}
+
+// closest hit (smallest t, lowest original index on ties: the flat loop's answer) or any hit
+template <bool ANY_HIT>
+__device__ __forceinline__ bool ray3_tree(const DevMesh3 &m, V3 o, V3 d, float tmax, float &t_out, int &idx_out, const LdsColumn &stk)
+{
+    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // Trav.best.d2 carries the pruning bound: boxes entered beyond it cannot hold a better hit
+    Trav T = trav_begin(Closest{tmax * 1.00001f + 1e-30f, -1});
+    bool hit = false;
+    float bt = WOST_INF;
+    int bi = -1;
+    for (;;) {
+        bool more;
+        if (T.level == m.levels) {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const int slot = 4 * T.pos + j;
+                const int oi = m.triOrig[slot];
+                if (oi == WOST_FAR_INDEX) continue;
+                float t;
+                if (tri_ray(m.flat[oi], o, d, tmax, t)) {
+                    if (ANY_HIT) {
+                        t_out = t; idx_out = oi;
+                        return true;
+                    }
+                    if (!hit || t < bt || (t == bt && oi < bi)) {
+                        bt = t; bi = oi; hit = true;
+                        T.best.d2 = fminf(T.best.d2, bt * 1.00001f + 1e-30f);
+                    }
+                }
+            }
+            more = trav_pop(T, stk);
+        } else {
+            const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
+            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+            const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
+            const float bd = T.best.d2;
+            const float d0 = ray_aabb_entry(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, o, d, inv, bd), d1 = ray_aabb_entry(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, o, d, inv, bd);
+            const float d2 = ray_aabb_entry(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, o, d, inv, bd), d3 = ray_aabb_entry(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, o, d, inv, bd);
+            const uint32_t tag = (uint32_t)(T.level + 1) << 2;
+            uint32_t k0 = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;
+            uint32_t k1 = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3Fu) | tag | 1u) : 0xffffffffu;
+            uint32_t k2 = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3Fu) | tag | 2u) : 0xffffffffu;
+            uint32_t k3 = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3Fu) | tag | 3u) : 0xffffffffu;
+            cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
+            int sp = T.sp;
+            stk.put(sp, k3); sp += (k3 != 0xffffffffu) ? 1 : 0;
+            stk.put(sp, k2); sp += (k2 != 0xffffffffu) ? 1 : 0;
+            stk.put(sp, k1); sp += (k1 != 0xffffffffu) ? 1 : 0;
+            T.sp = sp;
+            if (k0 != 0xffffffffu) {
+                T.pos = 4 * T.pos + (int)(k0 & 3u);
+                T.level = T.level + 1;
+                more = true;
+            } else {
+                more = trav_pop(T, stk);
+            }
+        }
+        if (!more) break;
+    }
+    t_out = bt; idx_out = bi;
+    return hit;
+}
+
+template <bool NTREE>
+__device__ __forceinline__ float closest_silhouette3(const DevMesh3 &m, V3 q, float rmax, const LdsColumn &stk)
+{
+    if (NTREE) return closest_silhouette3_tree(m, q, rmax, stk);
+    return closest_silhouette3_flat(m, q, rmax);
+}
+template <bool NTREE>
+__device__ __forceinline__ bool ray_closest3(const DevMesh3 &m, V3 o, V3 d, float tmax, float &t_out, int &idx_out, const LdsColumn &stk)
+{
+    if (NTREE) return ray3_tree<false>(m, o, d, tmax, t_out, idx_out, stk);
+    return ray_closest3_flat(m, o, d, tmax, t_out, idx_out);
+}
+template <bool NTREE>
+__device__ __forceinline__ bool ray_any3(const DevMesh3 &m, V3 o, V3 d, float tmax, const LdsColumn &stk)
+{
+    if (NTREE) {
+        float t;
+        int i;
+        return ray3_tree<true>(m, o, d, tmax, t, i, stk);
+    }
+    return ray_any3_flat(m, o, d, tmax);
+}
+
 // getPerpendicular(Vector3f) + frameFromNormal(Vector3f) + Frame<3>::toWorld
 __device__ __forceinline__ V3 frame_to_world(V3 n, float lx, float ly, float lz)
 {
@@ -391,7 +592,7 @@ struct Walk3Params {
 };
 
 // One lane = one pixel, all its samples one after the other on the pixel's PCG stream.
-template <bool EMISSIVE, bool SOURCE>
+template <bool EMISSIVE, bool SOURCE, bool NTREE>
 __global__ __launch_bounds__(256) void walk3_kernel(Walk3Params P)
 {
     extern __shared__ uint32_t lds_stack[];
@@ -450,7 +651,7 @@ __global__ __launch_bounds__(256) void walk3_kernel(Walk3Params P)
                     }
                 }
                 float R_N = WOST_INF;
-                if (has_n) R_N = closest_silhouette3_flat(P.nm, p, R_D);
+                if (has_n) R_N = closest_silhouette3<NTREE>(P.nm, p, R_D, stk);
                 float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
                 R_B *= WOST_R_B_SHRINK;
                 if (isinf(R_B)) break;
@@ -478,7 +679,7 @@ __global__ __launch_bounds__(256) void walk3_kernel(Walk3Params P)
                     if (has_n) {
                         float t;
                         int hi;
-                        if (ray_closest3_flat(P.nm, v3(p.x + eps * sdir.x, p.y + eps * sdir.y, p.z + eps * sdir.z), sdir, dist, t, hi)) dist = fminf(t, dist);
+                        if (ray_closest3<NTREE>(P.nm, v3(p.x + eps * sdir.x, p.y + eps * sdir.y, p.z + eps * sdir.z), sdir, dist, t, hi, stk)) dist = fminf(t, dist);
                     }
                     // HarmonicGreenBall<3>::sample (util/green.h:101-116): closed form, two draws
                     const float g1 = pcg_next_float(rng), g2 = pcg_next_float(rng);
@@ -519,7 +720,7 @@ __global__ __launch_bounds__(256) void walk3_kernel(Walk3Params P)
                                 V3 rd = sp - o;
                                 const float cd = sqrtf(dot3(rd, rd));
                                 if (cd > 0) { rd.x /= cd; rd.y /= cd; rd.z /= cd; }
-                                if (!ray_any3_flat(P.nm, o, rd, cd - eps)) {
+                                if (!ray_any3<NTREE>(P.nm, o, rd, cd - eps, stk)) {
                                     int side = tri_side(s0, ld3(S.nraw), p);
                                     float uu, vv;
                                     tri_uv(s0, s1 - s0, s2 - s0, sp, uu, vv);
@@ -529,7 +730,7 @@ __global__ __launch_bounds__(256) void walk3_kernel(Walk3Params P)
                                     }
                                     if (side != 0) {
                                         float col[3];
-                                        const int32_t *tv = P.nm.triVerts + 3 * (size_t)oi;     // flat order for the Neumann mesh
+                                        const int32_t *tv = P.nm.flatVerts + 3 * (size_t)oi;
                                         surface_color3(P.nm.colors, tv[0], tv[1], tv[2], side, uu, vv, col);
                                         const float alpha = on_n ? 0.5f : 1.0f;
                                         const float G = (1.0f / r - 1.0f / R_B) / WOST_4PI;
@@ -570,7 +771,7 @@ __global__ __launch_bounds__(256) void walk3_kernel(Walk3Params P)
                 if (has_n) {
                     float t;
                     int hi;
-                    hit = ray_closest3_flat(P.nm, cur, dir, R_B, t, hi);
+                    hit = ray_closest3<NTREE>(P.nm, cur, dir, R_B, t, hi, stk);
                     if (hit) {
                         hn = ld3(P.nm.flat[hi].n);
                         if (dot3(hn, dir) > 0) hn = v3(-hn.x, -hn.y, -hn.z);
@@ -632,7 +833,10 @@ __global__ __launch_bounds__(256) void render3_sdf_kernel(DevMesh3 m, DevProbe3 
     if (i >= width * height) return;
     const V3 q = eval_point3(probe, i % width, i / width, width, height);
     float d = WOST_INF;
-    if (m.n_tris > 0) d = silhouette ? closest_silhouette3_flat(m, q, WOST_INF) : sqrtf(closest_triangle(m, q, -1, stk).d2);
+    if (m.n_tris > 0) {
+        if (!silhouette) d = sqrtf(closest_triangle(m, q, -1, stk).d2);
+        else d = m.n_tris > WOST3_FLAT_MAX ? closest_silhouette3_tree(m, q, WOST_INF, stk) : closest_silhouette3_flat(m, q, WOST_INF);
+    }
     out[i] = d;
 }
 
@@ -645,21 +849,27 @@ __global__ __launch_bounds__(256) void render3_source_kernel(DevSource3 src, Dev
     out[3 * (size_t)i] = f[0]; out[3 * (size_t)i + 1] = f[1]; out[3 * (size_t)i + 2] = f[2];
 }
 
+template <bool NTREE>
 __global__ __launch_bounds__(256) void silhouette3_kernel(DevMesh3 m, const float *pts, const float *rmax, int n, float *out)
 {
+    extern __shared__ uint32_t lds_stack[];
+    const LdsColumn stk(lds_stack + threadIdx.x, blockDim.x);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = m.n_tris > 0 ? closest_silhouette3_flat(m, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), rmax ? rmax[i] : WOST_INF) : WOST_INF;
+    out[i] = m.n_tris > 0 ? closest_silhouette3<NTREE>(m, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), rmax ? rmax[i] : WOST_INF, stk) : WOST_INF;
 }
 
+template <bool NTREE>
 __global__ __launch_bounds__(256) void ray3_kernel(DevMesh3 m, const float *o, const float *d, const float *tmax, int n, int32_t *out_hit,
                                                    float *out_t, int32_t *out_idx)
 {
+    extern __shared__ uint32_t lds_stack[];
+    const LdsColumn stk(lds_stack + threadIdx.x, blockDim.x);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float t;
     int idx;
-    const bool hit = ray_closest3_flat(m, v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i], t, idx);
+    const bool hit = ray_closest3<NTREE>(m, v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i], t, idx, stk);
     out_hit[i] = hit ? 1 : 0;
     out_t[i] = t;
     out_idx[i] = idx;
@@ -670,7 +880,7 @@ struct HostMesh3 {
     int32_t n_tris = 0, n_edges = 0, levels = 1, first_leaf = 1;
     bool emissive = false;
     std::vector<float> nodes, tri, colors;
-    std::vector<int32_t> triOrig, triVerts;
+    std::vector<int32_t> triOrig, triVerts, flatVerts, triEdges;
     std::vector<DevTri> flat;
     std::vector<DevEdge3> edges;
 };
@@ -687,7 +897,7 @@ static inline uint32_t part1by2(uint32_t x)
 static inline float hdot3(const float *a, const float *b) { return std::fmaf(a[0], b[0], std::fmaf(a[1], b[1], a[2] * b[2])); }
 
 // returns 0, or -1 on an index out of range
-static int build_mesh3(const wost3_mesh_desc &d, bool flat_order, HostMesh3 *out)
+static int build_mesh3(const wost3_mesh_desc &d, HostMesh3 *out)
 {
     HostMesh3 &h = *out;
     h = HostMesh3();
@@ -725,6 +935,7 @@ static int build_mesh3(const wost3_mesh_desc &d, bool flat_order, HostMesh3 *out
             if (c != 0.0f) h.emissive = true;
     }
     // edges: the first two incident triangles in index order, direction of the first
+    std::vector<int32_t> edge_of;
     {
         struct Key { int a, b, t, k; };
         std::vector<Key> keys;
@@ -739,6 +950,7 @@ static int build_mesh3(const wost3_mesh_desc &d, bool flat_order, HostMesh3 *out
             if (x.b != y.b) return x.b < y.b;
             return x.t < y.t;
         });
+        edge_of.assign((size_t)n * 3, -1);        // the edge record of side k of triangle t
         for (size_t i = 0; i < keys.size();) {
             size_t j = i;
             while (j < keys.size() && keys[j].a == keys[i].a && keys[j].b == keys[i].b) ++j;
@@ -749,16 +961,18 @@ static int build_mesh3(const wost3_mesh_desc &d, bool flat_order, HostMesh3 *out
                 for (int c = 0; c < 3; ++c) { E.pa[c] = d.verts[3 * (size_t)a + c]; E.pb[c] = d.verts[3 * (size_t)b + c]; }
                 E.t0 = t0;
                 E.t1 = (j - i >= 2) ? keys[i + 1].t : -1;
+                for (size_t q = i; q < j; ++q) edge_of[3 * (size_t)keys[q].t + keys[q].k] = (int32_t)h.edges.size();
                 h.edges.push_back(E);
             }
             i = j;
         }
         h.n_edges = (int32_t)h.edges.size();
     }
+    h.flatVerts.assign(d.tris, d.tris + (size_t)n * 3);
     // Morton order of the centroids, leaves of 4, implicit complete 4-ary tree (lbvh.h in 3-D)
     std::vector<int32_t> order(n);
     std::iota(order.begin(), order.end(), 0);
-    if (!flat_order) {
+    {
         std::vector<uint32_t> code(n);
         for (int t = 0; t < n; ++t) {
             uint32_t q[3];
@@ -779,9 +993,10 @@ static int build_mesh3(const wost3_mesh_desc &d, bool flat_order, HostMesh3 *out
     h.tri.assign(n_slots * 12, 1.0e18f);
     h.triOrig.assign(n_slots, kFarIndex);
     h.triVerts.assign(n_slots * 3, 0);
+    h.triEdges.assign(n_slots * 3, -1);
     for (int k = 0; k < n; ++k) {
-        // flat_order (the Neumann mesh): slot == original index, so triVerts is indexed by triangle id
         const int o = order[k];
+        for (int c = 0; c < 3; ++c) h.triEdges[3 * (size_t)k + c] = edge_of[3 * (size_t)o + c];
         const DevTri &T = h.flat[o];
         float *r = &h.tri[(size_t)k * 12];
         for (int c = 0; c < 3; ++c) { r[c] = T.p0[c]; r[4 + c] = T.p1[c]; r[8 + c] = T.p2[c]; }
@@ -875,10 +1090,10 @@ struct wost3_context {
         if (e_ != hipSuccess) return set_error(WOST_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-static int upload_mesh3(const wost3_mesh_desc &d, bool flat_order, DeviceMesh3 &s)
+static int upload_mesh3(const wost3_mesh_desc &d, DeviceMesh3 &s)
 {
     if (d.n_tris < 0 || d.n_verts < 0) return set_error(WOST_ERR_INVALID, "negative mesh size");
-    if (build_mesh3(d, flat_order, &s.host) != 0) return set_error(WOST_ERR_INVALID, "mesh: triangle index out of range or null arrays");
+    if (build_mesh3(d, &s.host) != 0) return set_error(WOST_ERR_INVALID, "mesh: triangle index out of range or null arrays");
     const HostMesh3 &h = s.host;
     DevMesh3 &v = s.view;
     v = DevMesh3{};
@@ -892,6 +1107,8 @@ static int upload_mesh3(const wost3_mesh_desc &d, bool flat_order, DeviceMesh3 &
     W3_TRY(upload3(s.allocs, h.colors.data(), h.colors.size(), &v.colors));
     W3_TRY(upload3(s.allocs, h.flat.data(), h.flat.size(), &v.flat));
     W3_TRY(upload3(s.allocs, h.edges.data(), h.edges.size(), &v.edges));
+    W3_TRY(upload3(s.allocs, h.flatVerts.data(), h.flatVerts.size(), &v.flatVerts));
+    W3_TRY(upload3(s.allocs, h.triEdges.data(), h.triEdges.size(), &v.triEdges));
     return WOST_OK;
 }
 
@@ -922,13 +1139,17 @@ static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, 
     P.field = field_dev; P.field_base = field_base; P.pixel_begin = pixel_begin; P.pixel_end = pixel_end;
     P.shard_index = shard_index; P.shard_count = shard_count; P.stats = c->stats;
     const int bs = 256, n = pixel_end - pixel_begin;
-    const size_t lds = (size_t)(3 * (c->dm.view.n_tris > 0 ? c->dm.view.levels : 1) + 1) * bs * sizeof(uint32_t);
+    const int lv = std::max(c->dm.view.n_tris > 0 ? c->dm.view.levels : 1, c->nm.view.n_tris > 0 ? c->nm.view.levels : 1);
+    const size_t lds = (size_t)(3 * lv + 1) * bs * sizeof(uint32_t);
     float ms = 0.0f;
     if (n > 0) {
         W3_TRY(hipEventRecord(c->ev0, stream));
         const bool emissive = c->nm.view.n_tris > 0 && c->nm.view.emissive;
-        auto kfn = c->src.rgb ? (emissive ? walk3_kernel<true, true> : walk3_kernel<false, true>)
-                              : (emissive ? walk3_kernel<true, false> : walk3_kernel<false, false>);
+        const bool ntree = c->nm.view.n_tris > WOST3_FLAT_MAX;
+        auto kfn = ntree ? (c->src.rgb ? (emissive ? walk3_kernel<true, true, true> : walk3_kernel<false, true, true>)
+                                       : (emissive ? walk3_kernel<true, false, true> : walk3_kernel<false, false, true>))
+                         : (c->src.rgb ? (emissive ? walk3_kernel<true, true, false> : walk3_kernel<false, true, false>)
+                                       : (emissive ? walk3_kernel<true, false, false> : walk3_kernel<false, false, false>));
         hipLaunchKernelGGL(kfn, dim3((n + bs - 1) / bs), dim3(bs), lds, stream, P);
         W3_TRY(hipGetLastError());
         W3_TRY(hipEventRecord(c->ev1, stream));
@@ -981,8 +1202,6 @@ int wost3_create(const wost3_scene_desc *scene, const wost_settings *settings, i
     if (settings->width <= 0 || settings->height <= 0 || settings->spp < 0 || settings->max_depth <= 0)
         return set_error(WOST_ERR_INVALID, "bad settings");
     if ((int64_t)settings->width * settings->height > (1 << 28)) return set_error(WOST_ERR_UNSUPPORTED, "frame too large");
-    if (scene->neumann.n_tris > WOST3_FLAT_MAX)
-        return set_error(WOST_ERR_UNSUPPORTED, "3-D Neumann meshes are limited to 4096 triangles in this build (flat queries, O(triangles) per step)");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
         return set_error(WOST_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
@@ -997,8 +1216,8 @@ int wost3_create(const wost3_scene_desc *scene, const wost_settings *settings, i
     c->probe.scale = scene->probe_scale;
     for (int k = 0; k < 3; ++k) { c->probe.pos[k] = scene->probe_pos[k]; c->probe.up[k] = scene->probe_up[k]; c->probe.right[k] = scene->probe_right[k]; }
     c->n_pixels = (size_t)settings->width * settings->height;
-    int rc = upload_mesh3(scene->dirichlet, false, c->dm);
-    if (rc == WOST_OK) rc = upload_mesh3(scene->neumann, true, c->nm);
+    int rc = upload_mesh3(scene->dirichlet, c->dm);
+    if (rc == WOST_OK) rc = upload_mesh3(scene->neumann, c->nm);
     hipError_t e = hipSuccess;
     if (rc == WOST_OK && scene->mask) {
         e = hipMalloc((void **)&c->mask, c->n_pixels);
@@ -1093,7 +1312,6 @@ int wost3_closest_silhouette(wost3_handle h, int which_mesh, const float *pts, c
     if (!h || !pts || !out_dist || n < 0) return set_error(WOST_ERR_INVALID, "null argument");
     DeviceMesh3 *m = pick3(h, which_mesh);
     if (!m) return set_error(WOST_ERR_INVALID, "unknown mesh selector");
-    if (m->view.n_tris > WOST3_FLAT_MAX) return set_error(WOST_ERR_UNSUPPORTED, "silhouette queries walk at most 4096 triangles in this build");
     if (n == 0) return WOST_OK;
     W3_TRY(hipSetDevice(h->device));
     Scratch3 s;
@@ -1104,7 +1322,11 @@ int wost3_closest_silhouette(wost3_handle h, int which_mesh, const float *pts, c
         W3_TRY(s.alloc(&d_rmax, n));
         W3_TRY(hipMemcpyAsync(d_rmax, rmax, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     }
-    hipLaunchKernelGGL(silhouette3_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, m->view, d_pts, d_rmax, n, d_out);
+    {
+        const size_t lds = (size_t)(3 * (m->view.n_tris > 0 ? m->view.levels : 1) + 1) * 256 * sizeof(uint32_t);
+        if (m->view.n_tris > WOST3_FLAT_MAX) hipLaunchKernelGGL((silhouette3_kernel<true>), dim3((n + 255) / 256), dim3(256), lds, h->stream, m->view, d_pts, d_rmax, n, d_out);
+        else hipLaunchKernelGGL((silhouette3_kernel<false>), dim3((n + 255) / 256), dim3(256), lds, h->stream, m->view, d_pts, d_rmax, n, d_out);
+    }
     W3_TRY(hipGetLastError());
     W3_TRY(hipMemcpyAsync(out_dist, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     W3_TRY(hipStreamSynchronize(h->stream));
@@ -1151,7 +1373,6 @@ int wost3_ray_intersect(wost3_handle h, int which_mesh, const float *origins, co
     if (!h || !origins || !dirs || !tmax || !out_hit || !out_t || !out_idx || n < 0) return set_error(WOST_ERR_INVALID, "null argument");
     DeviceMesh3 *m = pick3(h, which_mesh);
     if (!m) return set_error(WOST_ERR_INVALID, "unknown mesh selector");
-    if (m->view.n_tris > WOST3_FLAT_MAX) return set_error(WOST_ERR_UNSUPPORTED, "ray queries walk at most 4096 triangles in this build");
     if (n == 0) return WOST_OK;
     W3_TRY(hipSetDevice(h->device));
     Scratch3 s;
@@ -1162,7 +1383,11 @@ int wost3_ray_intersect(wost3_handle h, int which_mesh, const float *origins, co
     W3_TRY(hipMemcpyAsync(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice, h->stream));
     W3_TRY(hipMemcpyAsync(d_d, dirs, (size_t)n * 12, hipMemcpyHostToDevice, h->stream));
     W3_TRY(hipMemcpyAsync(d_tm, tmax, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(ray3_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, m->view, d_o, d_d, d_tm, n, d_hit, d_t, d_idx);
+    {
+        const size_t lds = (size_t)(3 * (m->view.n_tris > 0 ? m->view.levels : 1) + 1) * 256 * sizeof(uint32_t);
+        if (m->view.n_tris > WOST3_FLAT_MAX) hipLaunchKernelGGL((ray3_kernel<true>), dim3((n + 255) / 256), dim3(256), lds, h->stream, m->view, d_o, d_d, d_tm, n, d_hit, d_t, d_idx);
+        else hipLaunchKernelGGL((ray3_kernel<false>), dim3((n + 255) / 256), dim3(256), lds, h->stream, m->view, d_o, d_d, d_tm, n, d_hit, d_t, d_idx);
+    }
     W3_TRY(hipGetLastError());
     W3_TRY(hipMemcpyAsync(out_hit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     W3_TRY(hipMemcpyAsync(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
