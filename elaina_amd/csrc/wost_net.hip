@@ -1148,6 +1148,9 @@ __global__ void transpose_mlp_kernel(NetLayout L, const float *src, float *dst)
 // per optimizer step.
 struct DerivedLayouts {
     float *params_t, *inference_t, *params_f, *inference_f, *params_fb;   // any may be null
+    // half-precision images (wost_net_half.h), as arrays of halves: fragments of the matrices then the grid (inference
+    // and training weights), fragments of the transposed training matrices
+    _Float16 *inference_h, *params_h, *params_hb;
 };
 
 __global__ void optimizer_kernel(NetLayout L, uint32_t n, float *params, float *m1, float *m2, float *ema_raw, float *inference,
@@ -1172,7 +1175,12 @@ __global__ void optimizer_kernel(NetLayout L, uint32_t n, float *params, float *
     const float e = ema_raw[i] = decay * ema_raw[i] + (1.0f - decay) * nw;
     const float inf = e * debias;
     inference[i] = inf;
-    if (i >= L.n_mlp) return;
+    if (i >= L.n_mlp) {
+        // grid entry (i - n_mlp) / 4, feature (i - n_mlp) % 4 of the images: the same index as the parameter
+        if (D.inference_h) D.inference_h[i] = (_Float16)inf;
+        if (D.params_h) D.params_h[i] = (_Float16)nw;
+        return;
+    }
     int layer = 0;
     while (layer < L.n_hidden && i >= L.w_off[layer + 1]) ++layer;
     const uint32_t n_i = layer == 0 ? L.enc : L.n_neurons, n_o = layer == L.n_hidden ? L.n_out_padded : L.n_neurons;
@@ -1190,6 +1198,17 @@ __global__ void optimizer_kernel(NetLayout L, uint32_t n, float *params, float *
         // backward fragments (transposed matrix): k = 16kt + 4(i&3) + (i>>2), r = 4s + g
         const uint32_t remk = k & 15u, ik = (remk & 3u) * 4u + (remk >> 2), Sb = n_o / 4;
         D.params_fb[off + ((k >> 4) * Sb + (r >> 2)) * 64u + (r & 3u) * 16u + ik] = nw;
+    }
+    if (D.inference_h || D.params_h) {
+        // fragment_mlp_h_kernel: entry w_off / 4 + (rt KT + kt) 64 + lane holds W[16 rt + i][16 kt + 4 g .. + 3], lane = (i, g)
+        const uint32_t KT = n_i / 16, e4 = off / 4 + ((r >> 4) * KT + (k >> 4)) * 64u + ((k & 15u) >> 2) * 16u + (r & 15u);
+        if (D.inference_h) D.inference_h[4u * e4 + (k & 3u)] = (_Float16)inf;
+        if (D.params_h) D.params_h[4u * e4 + (k & 3u)] = (_Float16)nw;
+        // fragment_mlp_hb_kernel: entry w_off / 4 + (kt RT + rt) 64 + lane holds W[16 rt + 4 g .. + 3][16 kt + i]
+        if (D.params_hb) {
+            const uint32_t RT = n_o / 16, b4 = off / 4 + ((k >> 4) * RT + (r >> 4)) * 64u + ((r & 15u) >> 2) * 16u + (k & 15u);
+            D.params_hb[4u * b4 + (r & 3u)] = (_Float16)nw;
+        }
     }
 }
 
@@ -1509,12 +1528,17 @@ int net_apply_update_dev(wost_net *h, float loss_scale, hipStream_t stream)
         h->lr_cap = cap;
     }
     const float debias = 1.0f / (1.0f - std::pow(c.ema_decay, (float)h->step));
-    DerivedLayouts D{h->params_t, h->inference_t, nullptr, nullptr, nullptr};
+    DerivedLayouts D{h->params_t, h->inference_t, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (h->use_mfma) { D.params_f = h->params_f; D.inference_f = h->inference_f; D.params_fb = h->params_fb; }
+    // the half-precision images are kept up to date by the same kernel (three launches less per step)
+    if (h->precision == 16 && h->inference_h) D.inference_h = reinterpret_cast<_Float16 *>(h->inference_h);
+    if (h->train_precision == 16 && h->params_h) {
+        D.params_h = reinterpret_cast<_Float16 *>(h->params_h);
+        D.params_hb = reinterpret_cast<_Float16 *>(h->params_hb);
+    }
     hipLaunchKernelGGL(optimizer_kernel, dim3((h->n_params + 255) / 256), dim3(256), 0, stream, h->L, h->n_params, h->params, h->m1,
                        h->m2, h->ema_raw, h->inference, h->grad, h->lr_table, h->param_steps, c.beta1, c.beta2, c.epsilon,
                        c.l2_reg, c.ema_decay, debias, loss_scale, h->grad_div, D);
-    refresh_half(h, stream);
     NET_TRY(hipGetLastError());
     return WOST_OK;
 }
