@@ -993,8 +993,10 @@ __global__ __launch_bounds__(kNetBlock) void net_backward_kernel(NetLayout L, co
 // Work item = (point, level): neighbouring lanes read consecutive float4s of d_enc and hit
 // different levels.  use_lds = 0 (a level too large for LDS) scatters straight to global memory.
 constexpr int kGridGradBlock = 1024;
-__global__ __launch_bounds__(kGridGradBlock) void grid_grad_kernel(NetLayout L, const float *xy, const float *denc, int n, int chunk,
-                                                                   int lv0, int lv1, int q0, int q1, int use_lds, fx_t *grad)
+// denc: dL/d(encoding) of point p, level lv at denc + p * ld_point + lv * ld_level (rows of the encoding per point in the
+// fp32 path; level-major in the half-precision path, where every launch then reads only the levels it works on)
+__global__ __launch_bounds__(kGridGradBlock) void grid_grad_kernel(NetLayout L, const float *xy, const float *denc, size_t ld_point, size_t ld_level,
+                                                                   int n, int chunk, int lv0, int lv1, int q0, int q1, int use_lds, fx_t *grad)
 {
     extern __shared__ fx_t acc[];
     __shared__ float s_scale[kNetMaxLevels];
@@ -1033,7 +1035,7 @@ __global__ __launch_bounds__(kGridGradBlock) void grid_grad_kernel(NetLayout L, 
         const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
         // the point's gradient values first: loaded inside the corner loop, each load would wait
         // for the atomics before it (they may alias) -- 16 dependent memory round trips per item
-        const float *d = denc + (size_t)p * L.enc + lv * nf;
+        const float *d = denc + (size_t)p * ld_point + (size_t)lv * ld_level;
         float dv[8];
         if (nf == 4) {
             const float4 d4 = *reinterpret_cast<const float4 *>(d);
@@ -1455,8 +1457,9 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
             if (bytes > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(grid_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)big);
+            const size_t ld_point = half ? (size_t)L.n_features : (size_t)L.enc, ld_level = half ? (size_t)n * L.n_features : (size_t)L.n_features;
             hipLaunchKernelGGL(grid_grad_kernel, dim3((unsigned)((n + gchunk - 1) / gchunk)), dim3(kGridGradBlock), bytes, stream, L, xy_dev,
-                               h->d_denc, n, gchunk, lv0, lv1, q0, q1, use_lds, h->grad);
+                               h->d_denc, ld_point, ld_level, n, gchunk, lv0, lv1, q0, q1, use_lds, h->grad);
         };
         int lv = 0;
         while (lv < L.n_levels) {

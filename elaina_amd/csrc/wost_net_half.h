@@ -157,7 +157,7 @@ __device__ __forceinline__ void flush_h(const f32x4_t (&gacc)[RT][KT], int lane,
 // dl: rows of n_out floats (dL/dout times the loss scale); dscale: extra power-of-two scale of the
 // deltas while they are f16 (loss scale 128 / batch 524 288 ~ 2e-4 sits at the f16 subnormal edge;
 // chosen by the host from the batch size, divided out before anything leaves the kernel);
-// denc: rows of 32 floats; partial: one row of n_mlp block sums per block
+// denc: level-major, [8 levels][n points][4 features]; partial: one row of n_mlp block sums per block
 __global__ __launch_bounds__(kHalfThreads, 1) void net_train_h_kernel(NetLayout L, const uint2 *fragh, const uint2 *fragb, const uint2 *enc, const float *dl,
                                                                         int n, float dscale, float *denc, float *partial)
 {
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(kHalfThreads, 1) void net_train_h_kernel(NetLayout 
         back_h<4, 2>(wb0, lane, d, e2);
         if (valid) {
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-                *reinterpret_cast<float4 *>(denc + (size_t)pt * 32 + 16 * kt + 4 * g) =
+            for (int kt = 0; kt < 2; ++kt)      // level 4 kt + g of point pt, level-major
+                *reinterpret_cast<float4 *>(denc + ((size_t)(4 * kt + g) * n + pt) * 4) =
                     float4{e2[kt][0] * inv_scale, e2[kt][1] * inv_scale, e2[kt][2] * inv_scale, e2[kt][3] * inv_scale};
         }
     }
