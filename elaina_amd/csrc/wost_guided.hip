@@ -1242,6 +1242,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     const int stack_words = 3 * std::max(d_levels, n_levels) + 1;
     const size_t lds = (size_t)stack_words * 256 * sizeof(uint32_t);
     uint32_t launches = 0;
+    const uint64_t net_launches_before = net_launch_count(g->net);
     double train_ms = 0.0;
     uint64_t train_samples = 0;
     const int opt_before = net_optimizer_steps(g->net);
@@ -1444,8 +1445,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
                 const size_t ev = g->net_events.begin(stream);
                 int rc = net_inference_dev(g->net, g->net_in, g->counts + nxt, (int)n_out, g->net_out, true, stream, (size_t)N);
                 g->net_events.end(ev, stream);
-                if (rc != WOST_OK) return rc;
-                ++launches;
+                if (rc != WOST_OK) return rc;      // (counted by the network)
             }
             P.in = g->q[nxt]; P.count_in = g->counts + nxt;
             const unsigned grid2 = (n_out + 255) / 256;
@@ -1514,7 +1514,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
                     rc = net_apply_update_dev(g->net, s.loss_scale, stream);
                     if (rc != WOST_OK) return rc;
                 }
-                launches += 8;
+                ++launches;      // the loss-gradient kernel; the network's own launches are counted by the network
             }
             G_TRY(hipStreamSynchronize(stream));
             train_ms += std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
@@ -1558,7 +1558,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         stats->train_samples = train_samples;
         stats->optimizer_steps = (uint64_t)(net_optimizer_steps(g->net) - opt_before);
         stats->train_ms = train_ms;
-        stats->kernel_launches = launches;
+        stats->kernel_launches = launches + (uint32_t)(net_launch_count(g->net) - net_launches_before);
         stats->net_points = hs.net_points;
         stats->reserved = g->last_train_offset;
         stats->net_infer_ms = net_infer_ms;

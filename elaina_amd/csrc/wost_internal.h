@@ -45,6 +45,8 @@ int net_backward_update_dev(wost_net_handle h, const float *xy_dev, int n, float
 int net_apply_update_dev(wost_net_handle h, float loss_scale, hipStream_t stream);
 void *net_gradient_buffer(wost_net_handle h, uint64_t *count);   // int64 fixed point, device
 int net_optimizer_steps(const wost_net *h);
+// kernels and fills the *_dev entry points above have issued on this network so far
+uint64_t net_launch_count(const wost_net *h);
 // shared-network mode: the summed gradient of `ranks` ranks is divided by their number before the step
 void net_set_gradient_divisor(wost_net_handle h, float ranks);
 int net_n_output(const wost_net *h);

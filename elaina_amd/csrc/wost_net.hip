@@ -1239,6 +1239,7 @@ struct wost_net {
     float *train_partial = nullptr;                    // per-block sums of the matrix gradients (net_train_h_kernel), 256 rows
     bool fused_backward = true;      // net_backward_wgrad_kernel (WOST_NET_FUSED=0: backward and weight gradients apart)
     int step = 0;
+    uint64_t n_launches = 0;           // kernels and fills issued by the *_dev entry points (wost_guided_stats.kernel_launches)
     uint32_t *param_steps = nullptr;   // Adam steps taken by each parameter (tiny-cuda-nn adam_step)
     float *lr_table = nullptr;         // debiased learning rate of step s at [s], s = 1 .. lr_cap
     int lr_cap = 0;
@@ -1268,6 +1269,7 @@ static int launch_forward_h(wost_net *h, const float *p, const uint2 *image, con
     const unsigned grid = (unsigned)std::max(1, std::min((n_tiles + kHalfFwdThreads / 64 - 1) / (kHalfFwdThreads / 64), 256));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(net_forward_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(net_forward_h_kernel, dim3(grid), dim3(kHalfFwdThreads), lds, stream, L, p, image, xy_dev, n, n_dev, out_dev, ldp, ldf, enc_out);
+    ++h->n_launches;
     NET_TRY(hipGetLastError());
     return WOST_OK;
 }
@@ -1338,6 +1340,7 @@ static int launch_forward(wost_net *h, bool use_inference_params, const float *x
         hipLaunchKernelGGL(net_forward_kernel, dim3((n + kNetBlock - 1) / kNetBlock), dim3(kNetBlock), lds, stream, L, p, t, xy_dev,
                            n, n_dev, out_dev, acts_dev, ldp, ldf);
     }
+    ++h->n_launches;
     NET_TRY(hipGetLastError());
     return WOST_OK;
 }
@@ -1413,6 +1416,7 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
 {
     const NetLayout &L = h->L;
     NET_TRY(hipMemsetAsync(h->grad, 0, (size_t)h->n_params * sizeof(fx_t), stream));
+    ++h->n_launches;
     const bool half = h->train_precision == 16;
     const bool fused = h->fused_backward || half;
     if (half) {
@@ -1426,6 +1430,7 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
                            reinterpret_cast<const uint2 *>(h->d_acts), h->d_dl, n, (float)(1 << k), h->d_denc, h->train_partial);
         hipLaunchKernelGGL(net_train_h_reduce_kernel, dim3((L.n_mlp + 255) / 256, (gridb + 15) / 16), dim3(256), 0, stream, L, h->train_partial, (int)gridb,
                            h->grad);
+        h->n_launches += 2;
     } else if (h->use_mfma && fused) {
         // backward pass and weight gradients of a 1024-point chunk in one block (deltas stay on chip)
         const size_t lds = ((size_t)L.n_mlp + 4 * 64 * kTileStride + 3 * 64 * 64) * sizeof(float);
@@ -1433,17 +1438,20 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kfn, dim3((unsigned)((n + 1023) / 1024)), dim3(256), lds, stream, L, h->params_fb, h->d_dl, h->d_mask, n,
                            h->d_acts, h->d_denc, h->grad);
+        ++h->n_launches;
     } else if (h->use_mfma) {
         const size_t lds = (size_t)L.n_mlp * sizeof(float);
         const int n_tiles = (n + 63) / 64 * 4 / kMfmaSub;
         const unsigned gridb = (unsigned)std::min((n_tiles + kBwdThreads / 64 - 1) / (kBwdThreads / 64), 256);
         hipLaunchKernelGGL((net_backward_mfma_kernel<32, 64, 3, 48, kBwdThreads>), dim3(gridb), dim3(kBwdThreads), lds, stream, L,
                            h->params_fb, h->d_dl, h->d_mask, n, h->d_deltas, h->d_denc);
+        ++h->n_launches;
     } else {
         const size_t lds = 2 * 64 * kNetBlock * sizeof(float);
         const unsigned gridp = (unsigned)((n + kNetBlock - 1) / kNetBlock);
         hipLaunchKernelGGL(net_backward_kernel, dim3(gridp), dim3(kNetBlock), lds, stream, L, h->params, xy_dev, h->d_dl, h->d_acts,
                            n, h->d_deltas, h->d_denc);
+        ++h->n_launches;
     }
     NET_TRY(hipGetLastError());
     {
@@ -1460,6 +1468,7 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
             const size_t ld_point = half ? (size_t)L.n_features : (size_t)L.enc, ld_level = half ? (size_t)n * L.n_features : (size_t)L.n_features;
             hipLaunchKernelGGL(grid_grad_kernel, dim3((unsigned)((n + gchunk - 1) / gchunk)), dim3(kGridGradBlock), bytes, stream, L, xy_dev,
                                h->d_denc, ld_point, ld_level, n, gchunk, lv0, lv1, q0, q1, use_lds, h->grad);
+            ++h->n_launches;
         };
         int lv = 0;
         while (lv < L.n_levels) {
@@ -1493,6 +1502,7 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
         const int doff = layer == L.n_hidden ? 0 : L.n_out_padded + layer * L.n_neurons;   // delta of this layer's output
         const int ioff = layer == 0 ? 0 : L.enc + (layer - 1) * L.n_neurons;               // this layer's input
         fx_t *gW = h->grad + L.w_off[layer];
+        ++h->n_launches;
         if (h->use_mfma) {
 #define WG(NO, NI) hipLaunchKernelGGL((weight_grad_mfma_kernel<NO, NI>), dim3(gridc), dim3(256), 0, stream, h->d_deltas, dstride, \
                                       doff, h->d_acts, astride, ioff, n, chunk, gW)
@@ -1542,6 +1552,7 @@ int net_apply_update_dev(wost_net *h, float loss_scale, hipStream_t stream)
     hipLaunchKernelGGL(optimizer_kernel, dim3((h->n_params + 255) / 256), dim3(256), 0, stream, h->L, h->n_params, h->params, h->m1,
                        h->m2, h->ema_raw, h->inference, h->grad, h->lr_table, h->param_steps, c.beta1, c.beta2, c.epsilon,
                        c.l2_reg, c.ema_decay, debias, loss_scale, h->grad_div, D);
+    ++h->n_launches;
     NET_TRY(hipGetLastError());
     return WOST_OK;
 }
@@ -1572,6 +1583,7 @@ int net_half_view(wost_net *h, HalfNetView *out)
 }
 
 int net_optimizer_steps(const wost_net *h) { return h->step; }
+uint64_t net_launch_count(const wost_net *h) { return h->n_launches; }
 void net_set_gradient_divisor(wost_net *h, float ranks) { h->grad_div = ranks > 0.0f ? ranks : 1.0f; }
 int net_n_output(const wost_net *h) { return h->L.n_out; }
 
