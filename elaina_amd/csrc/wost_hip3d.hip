@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -589,206 +590,343 @@ struct Walk3Params {
     int32_t field_base, pixel_begin, pixel_end;
     int32_t shard_index, shard_count;
     Stats3Dev *stats;
+    uint32_t *cursor;          // next unread pixel slot of the launch
+    int32_t tiled;             // the range is a whole frame made of 8x8 tiles: slots follow the tiles
+    int32_t wait_weight, trav_burst;
 };
 
-// One lane = one pixel, all its samples one after the other on the pixel's PCG stream.
+// One lane = one pixel, all its samples one after the other on the pixel's PCG stream (the reference's per-pixel
+// order) -- scheduled like the 2-D round kernel: a lane is descending the Dirichlet tree (TRAV), waits with a finished
+// query for the rest of its step (WAIT), or wants the next pixel of the solve (REFILL); every trip of the loop runs
+// the body more lanes are ready for, persistent blocks drain one pixel cursor.  (The first version ran every lane's
+// query to completion in lock step, one launch of pixel-many lanes: 4.7e8 walk-steps/s on a 1280-triangle sphere.)
+struct Lane3 {
+    int pid, sample, depth;
+    V3 p, p_eval, nn;
+    float thp;
+    bool on_n;
+    int32_t hint, hint0;
+    Pcg rng;
+    float sol[3];
+    Closest d0;          // the query of the evaluation point, the same for every sample of the pixel
+    bool d0_valid;
+    uint32_t c_steps, c_started, c_absorbed, c_truncated, c_nhits;
+};
+
+// the rest of a step once the closest Dirichlet triangle is known (`cp`, ignored without that mesh); true = the walk
+// has ended (absorbed, no boundary at all), false = L.p is the next point
 template <bool EMISSIVE, bool SOURCE, bool NTREE>
-__global__ __launch_bounds__(256) void walk3_kernel(Walk3Params P)
+__device__ __forceinline__ bool step3(const Walk3Params &P, Lane3 &L, Closest cp, const LdsColumn &stk)
 {
-    extern __shared__ uint32_t lds_stack[];
-    const LdsColumn stk(lds_stack + threadIdx.x, blockDim.x);
-    const int pid = P.pixel_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    bool owned = pid < P.pixel_end;
-    if (owned) {
-        const int px = pid % P.st.width, py = pid / P.st.width;
-        const int tile = (py >> 3) * ((P.st.width + 7) >> 3) + (px >> 3);
-        owned = (tile % P.shard_count) == P.shard_index;
-    }
-    uint32_t steps = 0, started = 0, absorbed = 0, truncated = 0, nhits = 0;
-    if (owned) {
-        const bool masked = P.mask != nullptr && P.mask[pid] == 0;
-        const bool has_d = P.dm.n_tris > 0, has_n = P.nm.n_tris > 0;
-        const float eps = P.st.eps;
-        Pcg rng{0, 1};
-        pcg_seed_pixel(rng, pid, P.st.width);
-        float sol[3] = {0.0f, 0.0f, 0.0f};
-        const V3 p_eval = eval_point3(P.probe, pid % P.st.width, pid / P.st.width, P.st.width, P.st.height);
-        int32_t hint = -1, hint0 = -1;
-        for (int sample = 0; sample < P.st.spp && !masked; ++sample) {
-            V3 p = p_eval;
-            float thp = 1.0f;
-            bool on_n = false;
-            V3 nn = v3(0.0f, 0.0f, 0.0f);
-            ++started;
-            hint = hint0;
-            int depth;
-            for (depth = 0; depth < P.st.max_depth; ++depth) {
-                ++steps;
-                // ---- separateEvaluationPoint ----
-                float R_D = WOST_INF;
-                if (has_d) {
-                    const Closest cp = closest_triangle(P.dm, p, hint, stk);
-                    hint = cp.slot;
-                    if (depth == 0) hint0 = cp.slot;
-                    const float4 a = P.dm.tri[3 * (size_t)cp.slot], b = P.dm.tri[3 * (size_t)cp.slot + 1], c = P.dm.tri[3 * (size_t)cp.slot + 2];
-                    const V3 p0 = v3(a.x, a.y, a.z), e0 = v3(b.x, b.y, b.z) - p0, e1 = v3(c.x, c.y, c.z) - p0;
-                    const int side = tri_side(p0, cross3(e0, e1), p);
-                    float u, v;
-                    tri_uv(p0, e0, e1, p, u, v);
-                    R_D = sqrtf(cp.d2);
-                    if (R_D < eps && u > 0.0f && v > 0.0f && u + v < 1.0f) {
-                        float col[3];
-                        const int32_t *tv = P.dm.triVerts + 3 * (size_t)cp.slot;
-                        surface_color3(P.dm.colors, tv[0], tv[1], tv[2], side, u, v, col);
+    const bool has_d = P.dm.n_tris > 0, has_n = P.nm.n_tris > 0;
+    const float eps = P.st.eps;
+    V3 &p = L.p;
+    float &thp = L.thp;
+    bool &on_n = L.on_n;
+    V3 &nn = L.nn;
+    float (&sol)[3] = L.sol;
+    Pcg &rng = L.rng;
+    int32_t &hint = L.hint;
+    uint32_t &nhits = L.c_nhits;
+    float R_D = WOST_INF;
+    if (has_d) {
+            hint = cp.slot;
+            if (L.depth == 0) L.hint0 = cp.slot;
+            const float4 a = P.dm.tri[3 * (size_t)cp.slot], b = P.dm.tri[3 * (size_t)cp.slot + 1], c = P.dm.tri[3 * (size_t)cp.slot + 2];
+            const V3 p0 = v3(a.x, a.y, a.z), e0 = v3(b.x, b.y, b.z) - p0, e1 = v3(c.x, c.y, c.z) - p0;
+            const int side = tri_side(p0, cross3(e0, e1), p);
+            float u, v;
+            tri_uv(p0, e0, e1, p, u, v);
+            R_D = sqrtf(cp.d2);
+            if (R_D < eps && u > 0.0f && v > 0.0f && u + v < 1.0f) {
+                float col[3];
+                const int32_t *tv = P.dm.triVerts + 3 * (size_t)cp.slot;
+                surface_color3(P.dm.colors, tv[0], tv[1], tv[2], side, u, v, col);
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            col[k] *= P.st.dirichlet_intensity;
-                            col[k] *= thp;
-                            sol[k] = col[k] + sol[k];
-                        }
-                        ++absorbed;
-                        break;
-                    }
+                for (int k = 0; k < 3; ++k) {
+                    col[k] *= P.st.dirichlet_intensity;
+                    col[k] *= thp;
+                    sol[k] = col[k] + sol[k];
                 }
-                float R_N = WOST_INF;
-                if (has_n) R_N = closest_silhouette3<NTREE>(P.nm, p, R_D, stk);
-                float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
-                R_B *= WOST_R_B_SHRINK;
-                if (isinf(R_B)) break;
-                // ---- sampleSource (reference integrator/uniform/integrator.cu:235-316, DIM == 3) ----
-                if (SOURCE) {
-                    V3 sdir;
-                    float dir_pdf, salpha = 1.0f;
-                    {
-                        const float u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
-                        float c, s;
-                        sincos_2pi(u2, c, s);
-                        if (on_n) {
-                            const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
-                            sdir = frame_to_world(nn, r * c, r * s, z);
-                            dir_pdf = 1.0f / WOST_2PI;
-                            salpha = 0.5f;
-                        } else {
-                            const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
-                            sdir = v3(r * c, r * s, z);
-                            dir_pdf = 1.0f / WOST_4PI;
-                        }
-                    }
-                    // how far the straight line stays inside the star-shaped region (:279-292)
-                    float dist = R_B;
-                    if (has_n) {
-                        float t;
-                        int hi;
-                        if (ray_closest3<NTREE>(P.nm, v3(p.x + eps * sdir.x, p.y + eps * sdir.y, p.z + eps * sdir.z), sdir, dist, t, hi, stk)) dist = fminf(t, dist);
-                    }
-                    // HarmonicGreenBall<3>::sample (util/green.h:101-116): closed form, two draws
-                    const float g1 = pcg_next_float(rng), g2 = pcg_next_float(rng);
-                    float gc, gs;
-                    sincos_2pi(g2, gc, gs);
-                    float r = (1.0f + sqrtf(1.0f - cbrt01(g1 * g1)) * gc) * R_B / 2.0f;
-                    r = fmaxf(1e-4f, r);                                            // ELAINA_GREEN_FUNC_R_CLAMP
-                    if (r > R_B) r = R_B / 2.0f;
-                    if (r <= dist) {
-                        float f[3];
-                        source3_eval(P.src, v3(p.x + r * sdir.x, p.y + r * sdir.y, p.z + r * sdir.z), f);
-                        const float norm = R_B * R_B / 6.0f;
-                        const float c1 = (1.0f / WOST_4PI) / (r * r), c2 = dir_pdf / (r * r);     // conditionalSampleSpherePDF<3>
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const float col = thp * f[k] * norm * c1 / c2 / salpha;
-                            sol[k] = col + sol[k];
-                        }
-                    }
-                }
-                // ---- sampleNeumann: three draws whether or not the boundary emits ----
-                if (has_n) {
-                    const float u0 = pcg_next_float(rng), u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
-                    if (EMISSIVE) {
-                        float pdf;
-                        const int oi = sample_in_sphere3_flat(P.nm, p, R_B, u0, pdf);
-                        if (oi != -1 && pdf > 0) {
-                            const DevTri S = P.nm.flat[oi];
-                            const V3 s0 = ld3(S.p0), s1 = ld3(S.p1), s2 = ld3(S.p2);
-                            const float su = sqrtf(u1), b1 = u2 * su, b0 = 1.0f - su, b2 = 1.0f - b0 - b1;
-                            const V3 sp = v3((s0.x * b0 + s1.x * b1) + s2.x * b2, (s0.y * b0 + s1.y * b1) + s2.y * b2,
-                                             (s0.z * b0 + s1.z * b1) + s2.z * b2);
-                            const V3 rv = sp - p;
-                            const float r = sqrtf(dot3(rv, rv));
-                            if (r < R_B && r > 0) {
-                                V3 o = p;
-                                if (on_n) o = v3(p.x + eps * nn.x, p.y + eps * nn.y, p.z + eps * nn.z);
-                                V3 rd = sp - o;
-                                const float cd = sqrtf(dot3(rd, rd));
-                                if (cd > 0) { rd.x /= cd; rd.y /= cd; rd.z /= cd; }
-                                if (!ray_any3<NTREE>(P.nm, o, rd, cd - eps, stk)) {
-                                    int side = tri_side(s0, ld3(S.nraw), p);
-                                    float uu, vv;
-                                    tri_uv(s0, s1 - s0, s2 - s0, sp, uu, vv);
-                                    if (on_n) {
-                                        const float dn = dot3(ld3(S.n), nn);
-                                        side = (0.0f < dn) - (dn < 0.0f);
-                                    }
-                                    if (side != 0) {
-                                        float col[3];
-                                        const int32_t *tv = P.nm.flatVerts + 3 * (size_t)oi;
-                                        surface_color3(P.nm.colors, tv[0], tv[1], tv[2], side, uu, vv, col);
-                                        const float alpha = on_n ? 0.5f : 1.0f;
-                                        const float G = (1.0f / r - 1.0f / R_B) / WOST_4PI;
-#pragma unroll
-                                        for (int k = 0; k < 3; ++k) {
-                                            col[k] *= P.st.neumann_intensity;
-                                            col[k] *= thp * G / alpha / pdf;
-                                            sol[k] = -col[k] + sol[k];
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-                // ---- oneStepWalk ----
-                V3 dir, cur = p;
-                float pdf, alpha = 1.0f;
+                ++L.c_absorbed;
+                return true;
+            }
+        }
+            float R_N = WOST_INF;
+            if (has_n) R_N = closest_silhouette3<NTREE>(P.nm, p, R_D, stk);
+            float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
+            R_B *= WOST_R_B_SHRINK;
+            if (isinf(R_B)) return true;
+            // ---- sampleSource (reference integrator/uniform/integrator.cu:235-316, DIM == 3) ----
+            if (SOURCE) {
+                V3 sdir;
+                float dir_pdf, salpha = 1.0f;
                 {
                     const float u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
                     float c, s;
                     sincos_2pi(u2, c, s);
                     if (on_n) {
                         const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
-                        dir = frame_to_world(nn, r * c, r * s, z);
-                        pdf = 1.0f / WOST_2PI;
-                        alpha = 0.5f;
-                        cur = v3(p.x + eps * nn.x, p.y + eps * nn.y, p.z + eps * nn.z);
+                        sdir = frame_to_world(nn, r * c, r * s, z);
+                        dir_pdf = 1.0f / WOST_2PI;
+                        salpha = 0.5f;
                     } else {
                         const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
-                        dir = v3(r * c, r * s, z);
-                        pdf = 1.0f / WOST_4PI;
+                        sdir = v3(r * c, r * s, z);
+                        dir_pdf = 1.0f / WOST_4PI;
                     }
                 }
-                V3 nxt = v3(p.x + R_B * dir.x, p.y + R_B * dir.y, p.z + R_B * dir.z);
-                bool hit = false;
-                V3 hn = v3(0.0f, 0.0f, 0.0f);
+                // how far the straight line stays inside the star-shaped region (:279-292)
+                float dist = R_B;
                 if (has_n) {
                     float t;
                     int hi;
-                    hit = ray_closest3<NTREE>(P.nm, cur, dir, R_B, t, hi, stk);
-                    if (hit) {
-                        hn = ld3(P.nm.flat[hi].n);
-                        if (dot3(hn, dir) > 0) hn = v3(-hn.x, -hn.y, -hn.z);
-                        nxt = v3(cur.x + t * dir.x, cur.y + t * dir.y, cur.z + t * dir.z);
-                        ++nhits;
+                    if (ray_closest3<NTREE>(P.nm, v3(p.x + eps * sdir.x, p.y + eps * sdir.y, p.z + eps * sdir.z), sdir, dist, t, hi, stk)) dist = fminf(t, dist);
+                }
+                // HarmonicGreenBall<3>::sample (util/green.h:101-116): closed form, two draws
+                const float g1 = pcg_next_float(rng), g2 = pcg_next_float(rng);
+                float gc, gs;
+                sincos_2pi(g2, gc, gs);
+                float r = (1.0f + sqrtf(1.0f - cbrt01(g1 * g1)) * gc) * R_B / 2.0f;
+                r = fmaxf(1e-4f, r);                                            // ELAINA_GREEN_FUNC_R_CLAMP
+                if (r > R_B) r = R_B / 2.0f;
+                if (r <= dist) {
+                    float f[3];
+                    source3_eval(P.src, v3(p.x + r * sdir.x, p.y + r * sdir.y, p.z + r * sdir.z), f);
+                    const float norm = R_B * R_B / 6.0f;
+                    const float c1 = (1.0f / WOST_4PI) / (r * r), c2 = dir_pdf / (r * r);     // conditionalSampleSpherePDF<3>
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float col = thp * f[k] * norm * c1 / c2 / salpha;
+                        sol[k] = col + sol[k];
                     }
                 }
-                thp = thp / pdf / alpha / WOST_4PI;
-                p = nxt; on_n = hit; nn = hn;
             }
-            if (depth == P.st.max_depth) ++truncated;
+            // ---- sampleNeumann: three draws whether or not the boundary emits ----
+            if (has_n) {
+                const float u0 = pcg_next_float(rng), u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
+                if (EMISSIVE) {
+                    float pdf;
+                    const int oi = sample_in_sphere3_flat(P.nm, p, R_B, u0, pdf);
+                    if (oi != -1 && pdf > 0) {
+                        const DevTri S = P.nm.flat[oi];
+                        const V3 s0 = ld3(S.p0), s1 = ld3(S.p1), s2 = ld3(S.p2);
+                        const float su = sqrtf(u1), b1 = u2 * su, b0 = 1.0f - su, b2 = 1.0f - b0 - b1;
+                        const V3 sp = v3((s0.x * b0 + s1.x * b1) + s2.x * b2, (s0.y * b0 + s1.y * b1) + s2.y * b2,
+                                         (s0.z * b0 + s1.z * b1) + s2.z * b2);
+                        const V3 rv = sp - p;
+                        const float r = sqrtf(dot3(rv, rv));
+                        if (r < R_B && r > 0) {
+                            V3 o = p;
+                            if (on_n) o = v3(p.x + eps * nn.x, p.y + eps * nn.y, p.z + eps * nn.z);
+                            V3 rd = sp - o;
+                            const float cd = sqrtf(dot3(rd, rd));
+                            if (cd > 0) { rd.x /= cd; rd.y /= cd; rd.z /= cd; }
+                            if (!ray_any3<NTREE>(P.nm, o, rd, cd - eps, stk)) {
+                                int side = tri_side(s0, ld3(S.nraw), p);
+                                float uu, vv;
+                                tri_uv(s0, s1 - s0, s2 - s0, sp, uu, vv);
+                                if (on_n) {
+                                    const float dn = dot3(ld3(S.n), nn);
+                                    side = (0.0f < dn) - (dn < 0.0f);
+                                }
+                                if (side != 0) {
+                                    float col[3];
+                                    const int32_t *tv = P.nm.flatVerts + 3 * (size_t)oi;
+                                    surface_color3(P.nm.colors, tv[0], tv[1], tv[2], side, uu, vv, col);
+                                    const float alpha = on_n ? 0.5f : 1.0f;
+                                    const float G = (1.0f / r - 1.0f / R_B) / WOST_4PI;
+#pragma unroll
+                                    for (int k = 0; k < 3; ++k) {
+                                        col[k] *= P.st.neumann_intensity;
+                                        col[k] *= thp * G / alpha / pdf;
+                                        sol[k] = -col[k] + sol[k];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- oneStepWalk ----
+            V3 dir, cur = p;
+            float pdf, alpha = 1.0f;
+            {
+                const float u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
+                float c, s;
+                sincos_2pi(u2, c, s);
+                if (on_n) {
+                    const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+                    dir = frame_to_world(nn, r * c, r * s, z);
+                    pdf = 1.0f / WOST_2PI;
+                    alpha = 0.5f;
+                    cur = v3(p.x + eps * nn.x, p.y + eps * nn.y, p.z + eps * nn.z);
+                } else {
+                    const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
+                    dir = v3(r * c, r * s, z);
+                    pdf = 1.0f / WOST_4PI;
+                }
+            }
+            V3 nxt = v3(p.x + R_B * dir.x, p.y + R_B * dir.y, p.z + R_B * dir.z);
+            bool hit = false;
+            V3 hn = v3(0.0f, 0.0f, 0.0f);
+            if (has_n) {
+                float t;
+                int hi;
+                hit = ray_closest3<NTREE>(P.nm, cur, dir, R_B, t, hi, stk);
+                if (hit) {
+                    hn = ld3(P.nm.flat[hi].n);
+                    if (dot3(hn, dir) > 0) hn = v3(-hn.x, -hn.y, -hn.z);
+                    nxt = v3(cur.x + t * dir.x, cur.y + t * dir.y, cur.z + t * dir.z);
+                    ++nhits;
+                }
+            }
+    thp = thp / pdf / alpha / WOST_4PI;
+    p = nxt; on_n = hit; nn = hn;
+    return false;
+}
+
+constexpr int kWalk3Threads = 256;
+
+template <bool EMISSIVE, bool SOURCE, bool NTREE>
+__global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const LdsColumn stk(lds_stack + threadIdx.x, blockDim.x);
+    const int lane = threadIdx.x & 63;
+    const bool has_d = P.dm.n_tris > 0;
+    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5 };
+    int mode = MODE_REFILL;
+    Lane3 L{};
+    L.rng = Pcg{0, 1};
+    Trav T = trav_begin(Closest{WOST_INF, -1});
+    uint32_t pool_next = 0, pool_end = 0;
+    uint32_t t_steps = 0, t_started = 0, t_absorbed = 0, t_truncated = 0, t_nhits = 0;
+    const uint32_t n_slots = (uint32_t)(P.pixel_end - P.pixel_begin);
+
+    // start the query of a step (or serve it from the cache of the evaluation point)
+    auto begin_step = [&]() {
+        ++L.c_steps;
+        if (!has_d) {
+            T.best = Closest{WOST_INF, -1};
+            mode = MODE_WAIT;
+        } else if (L.depth == 0 && L.d0_valid) {
+            T.best = L.d0;
+            mode = MODE_WAIT;
+        } else {
+            T = trav_begin(Closest{WOST_INF, -1});
+            if (L.hint >= 0 && P.dm.triOrig[L.hint] != WOST_FAR_INDEX) {
+                const float4 a = P.dm.tri[3 * (size_t)L.hint], b = P.dm.tri[3 * (size_t)L.hint + 1], c = P.dm.tri[3 * (size_t)L.hint + 2];
+                T.best = Closest{tri_d2(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), L.p), L.hint};
+                T.best_orig = P.dm.triOrig[L.hint];
+            }
+            mode = MODE_TRAV;
         }
-        float *f = P.field + 3 * (size_t)(pid - P.field_base);
-        const float spp = (float)P.st.spp;
-        f[0] = sol[0] / spp; f[1] = sol[1] / spp; f[2] = sol[2] / spp;
+    };
+    auto begin_sample = [&]() {
+        L.p = L.p_eval;
+        L.thp = 1.0f;
+        L.on_n = false;
+        L.nn = v3(0.0f, 0.0f, 0.0f);
+        ++L.c_started;
+        L.hint = L.hint0;
+        L.depth = 0;
+        begin_step();
+    };
+
+    for (;;) {
+        const unsigned long long need = __ballot(mode == MODE_REFILL);
+        if (need) {
+            const uint32_t needed = (uint32_t)__popcll(need), avail = pool_end - pool_next;
+            uint32_t fresh_base = 0;
+            if (needed > avail) {
+                if (lane == 0) fresh_base = atomicAdd(P.cursor, 64u);
+                fresh_base = __shfl(fresh_base, 0);
+            }
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            const uint32_t s2 = rank < avail ? pool_next + rank : fresh_base + (rank - avail);
+            if (needed > avail) {
+                pool_next = fresh_base + (needed - avail);
+                pool_end = fresh_base + 64u;
+            } else {
+                pool_next += needed;
+            }
+            if (mode == MODE_REFILL) {
+                if (s2 >= n_slots) {
+                    mode = MODE_DONE;
+                } else {
+                    // slots walk the frame in 8x8 tiles when the range is the whole tiled frame (neighbouring walkers in a wave)
+                    int pid = P.pixel_begin + (int)s2;
+                    if (P.tiled) {
+                        const int tiles_x = P.st.width >> 3, tile = pid >> 6, in_tile = pid & 63;
+                        pid = ((tile / tiles_x) * 8 + (in_tile >> 3)) * P.st.width + (tile % tiles_x) * 8 + (in_tile & 7);
+                    }
+                    const int px = pid % P.st.width, py = pid / P.st.width;
+                    const int tile = (py >> 3) * ((P.st.width + 7) >> 3) + (px >> 3);
+                    if ((tile % P.shard_count) == P.shard_index) {
+                        const bool masked = P.mask != nullptr && P.mask[pid] == 0;
+                        if (masked || P.st.spp <= 0) {
+                            float *f = P.field + 3 * (size_t)(pid - P.field_base);
+                            const float spp = (float)P.st.spp;
+                            f[0] = 0.0f / spp; f[1] = 0.0f / spp; f[2] = 0.0f / spp;
+                        } else {
+                            // fold the counters of the previous pixel into the lane totals (16-bit-safe: per pixel)
+                            t_steps += L.c_steps; t_started += L.c_started; t_absorbed += L.c_absorbed; t_truncated += L.c_truncated; t_nhits += L.c_nhits;
+                            L = Lane3{};
+                            L.pid = pid;
+                            L.rng = Pcg{0, 1};
+                            pcg_seed_pixel(L.rng, pid, P.st.width);
+                            L.p_eval = eval_point3(P.probe, px, py, P.st.width, P.st.height);
+                            L.hint = L.hint0 = -1;
+                            L.sample = 0;
+                            begin_sample();
+                        }
+                    }
+                    // a pixel of another shard or a masked one: the lane asks again on the next trip
+                }
+            }
+        }
+        const int n_trav = __popcll(__ballot(mode == MODE_TRAV));
+        const int n_wait = __popcll(__ballot(mode == MODE_WAIT));
+        if (n_trav + n_wait == 0) {
+            if (__ballot(mode == MODE_REFILL)) continue;
+            break;
+        }
+        if (n_wait * P.wait_weight >= n_trav * 8) {
+            if (mode == MODE_WAIT) {
+                if (has_d && L.depth == 0 && !L.d0_valid) {
+                    L.d0 = T.best;
+                    L.d0_valid = true;
+                }
+                bool ended = step3<EMISSIVE, SOURCE, NTREE>(P, L, T.best, stk);
+                if (!ended) {
+                    ++L.depth;
+                    if (L.depth == P.st.max_depth) {
+                        ++L.c_truncated;
+                        ended = true;
+                    }
+                }
+                if (!ended) {
+                    begin_step();
+                } else if (++L.sample < P.st.spp) {
+                    begin_sample();
+                } else {
+                    float *f = P.field + 3 * (size_t)(L.pid - P.field_base);
+                    const float spp = (float)P.st.spp;
+                    f[0] = L.sol[0] / spp; f[1] = L.sol[1] / spp; f[2] = L.sol[2] / spp;
+                    mode = MODE_REFILL;
+                }
+            }
+        } else {
+            for (int b = 0; b < P.trav_burst; ++b) {
+                if (mode == MODE_TRAV) {
+                    if (!trav_visit3(P.dm, L.p, T, stk)) mode = MODE_WAIT;
+                }
+            }
+        }
     }
-    uint32_t v[5] = {steps, started, absorbed, truncated, nhits};
+    t_steps += L.c_steps; t_started += L.c_started; t_absorbed += L.c_absorbed; t_truncated += L.c_truncated; t_nhits += L.c_nhits;
+    uint32_t v[5] = {t_steps, t_started, t_absorbed, t_truncated, t_nhits};
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         uint32_t x = v[k];
@@ -796,7 +934,7 @@ __global__ __launch_bounds__(256) void walk3_kernel(Walk3Params P)
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
         v[k] = x;
     }
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
         Stats3Dev *st = P.stats + (blockIdx.x & (kStat3Copies - 1));
         if (v[0]) atomicAdd(&st->steps, (unsigned long long)v[0]);
         if (v[1]) atomicAdd(&st->started, (unsigned long long)v[1]);
@@ -1080,6 +1218,8 @@ struct wost3_context {
     size_t n_pixels = 0;
     float *field = nullptr;
     Stats3Dev *stats = nullptr;
+    uint32_t *cursor = nullptr;
+    int wait_weight = 32, trav_burst = 3;   // tools/scratch/sweep3d.sh: a leaf visit (four exact triangle distances) is dear, steps are served early
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -1122,6 +1262,7 @@ static void destroy3(wost3_context *c)
     if (c->src.rgb) (void)hipFree(const_cast<float *>(c->src.rgb));
     if (c->field) (void)hipFree(c->field);
     if (c->stats) (void)hipFree(c->stats);
+    if (c->cursor) (void)hipFree(c->cursor);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1138,7 +1279,13 @@ static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, 
     P.dm = c->dm.view; P.nm = c->nm.view; P.st = c->dst; P.probe = c->probe; P.mask = c->mask; P.src = c->src;
     P.field = field_dev; P.field_base = field_base; P.pixel_begin = pixel_begin; P.pixel_end = pixel_end;
     P.shard_index = shard_index; P.shard_count = shard_count; P.stats = c->stats;
-    const int bs = 256, n = pixel_end - pixel_begin;
+    P.cursor = c->cursor;
+    P.tiled = (pixel_begin == 0 && pixel_end == (int32_t)c->n_pixels && ((c->settings.width | c->settings.height) & 7) == 0) ? 1 : 0;
+    P.wait_weight = c->wait_weight; P.trav_burst = c->trav_burst;
+    if (const char *w = std::getenv("WOST3_WAIT_WEIGHT")) P.wait_weight = std::max(1, std::atoi(w));
+    if (const char *w = std::getenv("WOST3_TRAV_BURST")) P.trav_burst = std::max(1, std::atoi(w));
+    W3_TRY(hipMemsetAsync(c->cursor, 0, sizeof(uint32_t), stream));
+    const int bs = kWalk3Threads, n = pixel_end - pixel_begin;
     const int lv = std::max(c->dm.view.n_tris > 0 ? c->dm.view.levels : 1, c->nm.view.n_tris > 0 ? c->nm.view.levels : 1);
     const size_t lds = (size_t)(3 * lv + 1) * bs * sizeof(uint32_t);
     float ms = 0.0f;
@@ -1150,7 +1297,13 @@ static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, 
                                        : (emissive ? walk3_kernel<true, false, true> : walk3_kernel<false, false, true>))
                          : (c->src.rgb ? (emissive ? walk3_kernel<true, true, false> : walk3_kernel<false, true, false>)
                                        : (emissive ? walk3_kernel<true, false, false> : walk3_kernel<false, false, false>));
-        hipLaunchKernelGGL(kfn, dim3((n + bs - 1) / bs), dim3(bs), lds, stream, P);
+        // persistent blocks: as many as the chip holds (LDS stacks and registers allow about four per CU), or fewer for small frames
+        int n_cus = 256;
+        (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+        int per_cu = 4;
+        if (const char *w = std::getenv("WOST3_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(w));
+        const unsigned grid = (unsigned)std::min((n + bs - 1) / bs, n_cus * per_cu);
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(bs), lds, stream, P);
         W3_TRY(hipGetLastError());
         W3_TRY(hipEventRecord(c->ev1, stream));
     }
@@ -1237,6 +1390,7 @@ int wost3_create(const wost3_scene_desc *scene, const wost_settings *settings, i
     }
     if (rc == WOST_OK && e == hipSuccess) e = hipMalloc((void **)&c->field, c->n_pixels * 3 * sizeof(float));
     if (rc == WOST_OK && e == hipSuccess) e = hipMalloc((void **)&c->stats, kStat3Copies * sizeof(Stats3Dev));
+    if (rc == WOST_OK && e == hipSuccess) e = hipMalloc((void **)&c->cursor, sizeof(uint32_t));
     if (rc == WOST_OK && e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (rc == WOST_OK && e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (rc == WOST_OK && e == hipSuccess) e = hipEventCreate(&c->ev1);
