@@ -291,8 +291,34 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
     walk_steps, guided_steps, train_samples, opt_steps, net_points, launches = [float(x) for x in tot.tolist()]
     train_s, infer_s, solve_s = float(mx[1]) / 1e3, float(mx[2]) / 1e3, float(mx[3]) / 1e3
     walk_s = max(elapsed - train_s, 1e-9)
-    infer_tf = (net_points / max(env.world, 1)) * FLOP_PER_POINT / max(infer_s, 1e-9) / 1e12 if infer_s > 0 else None
     half = (precision or args.net_precision) == 16
+    probe = None
+    if infer_s <= 0 and net_points > 0:
+        # the solve evaluates the network inside its walk kernel (one launch per sample): the matrix fraction of the
+        # network kernel is measured on a short pass of the per-depth path (same network arithmetic, launches timed apart)
+        prev = os.environ.get("WOST_GUIDED_FUSED")
+        os.environ["WOST_GUIDED_FUSED"] = "0"
+        try:
+            pst = GuidedIntegratorSettings(frameSize=(frame, frame), samplesPerPixel=min(spp, 6), trainSppCount=min(train_spp, spp, 6),
+                                           maxWalkingDepth=depth, epsilonShell=eps)
+            gi = GuidedIntegrator(problem, pst, GUIDED_AABB, device=env.local)
+            if half:
+                gi.network.set_option("precision", 16)
+            scratch = torch.zeros_like(field)
+            ps = gi.solve_sharded(env.rank, env.world, scratch.data_ptr())
+            torch.cuda.synchronize()
+            gi.close()
+        finally:
+            if prev is None:
+                os.environ.pop("WOST_GUIDED_FUSED", None)
+            else:
+                os.environ["WOST_GUIDED_FUSED"] = prev
+        pv = torch.tensor([float(ps.get("net_points", 0)), ps.get("net_infer_ms", 0.0)], dtype=torch.float64, device=env.dev)
+        env.reduce(pv, env.dist.ReduceOp.SUM)
+        if float(pv[1]) > 0:
+            probe = float(pv[0]) * FLOP_PER_POINT / (float(pv[1]) * 1e-3) / 1e12       # per GPU: all points over all kernel time
+            probe_points, probe_s = float(pv[0]) / max(env.world, 1), float(pv[1]) / max(env.world, 1) * 1e-3
+    infer_tf = (net_points / max(env.world, 1)) * FLOP_PER_POINT / max(infer_s, 1e-9) / 1e12 if infer_s > 0 else probe
     half_train = (args.net_train_precision or precision or args.net_precision) == 16
     peak_tf = MFMA_F16_PEAK_TF if half else MFMA_F32_PEAK_TF
     out = {
@@ -304,12 +330,14 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
         "shared_network": bool(args.shared_network and env.world > 1),
         "network_precision": ("f16 inference (v_mfma_f32_16x16x16_f16), " if half else "fp32 inference (v_mfma_f32_16x16x4_f32), ") +
                              ("f16 training passes, fp32 master weights" if half_train else "fp32 training"),
-        "roofline_mfma": {"bound": "mfma", "kernel": ("guided_sample_kernel (f16 network evaluated inside the walk kernel: not timed apart)" if half and not infer_s
-                                                      else ("net_forward_h_kernel" if half else "net_forward_mfma_kernel") + " (inference launches, HIP events)"),
+        "roofline_mfma": {"bound": "mfma", "kernel": ("net_forward_h_kernel" if half else "net_forward_mfma_kernel") +
+                          (" (inference launches, HIP events)" if infer_s > 0 else
+                           " (inference launches of a 6-spp pass of the per-depth path, HIP events; the solve itself evaluates the network inside guided_sample_kernel)"),
                           "achieved": infer_tf, "peak": peak_tf, "unit": "TFLOP/s",
                           "frac": (infer_tf / peak_tf) if infer_tf else None,
                           "flop_per_point": FLOP_PER_POINT, "points_per_pass": net_points / steps,
-                          "kernel_s_per_pass": infer_s / steps},
+                          "kernel_s_per_pass": infer_s / steps if infer_s > 0 else None,
+                          "probe": None if (infer_s > 0 or probe is None) else {"points": probe_points, "kernel_s": probe_s}},
     }
     return {"out": out, "field": field, "problem": problem, "depth": depth, "eps": eps}
 

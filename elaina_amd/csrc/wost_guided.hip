@@ -1336,9 +1336,8 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         P.uniform_fraction = uniform_fraction;
         P.first_sample = sample == 0;
         int n_run = 1;      // samples this iteration covers
-        // the fp32 network costs four times the matrix passes inside the wave, and a trained sample is bound by its longest
-        // walk either way: while training, the fp32 mode keeps the per-depth launches (both paths give the same results)
-        const bool fused_now = fused && (fused_half || !training);
+        // both paths give the same results and could alternate within a solve; the fused one is used whenever it exists
+        const bool fused_now = fused;
         if (fused_now) {
             if (!training) {
                 // nothing is trained between the remaining samples: one launch runs them all, up to the next
