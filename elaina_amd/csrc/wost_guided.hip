@@ -1,12 +1,13 @@
 // wost_guided.hip -- the GUIDED Walk-on-Stars integrator on MI355X (SURVEY.md 8a rows a21, a22,
 // a25, a26, a27) behind the C-ABI (include/wost.h, wost_guided_*).  gfx950 only.
 //
-// Unlike the uniform integrator (wost_hip.hip), whose walkers are independent and live in
-// registers for hundreds of steps, the guided walk is synchronous per sample and per depth:
-// every pixel consults ONE guiding network that is retrained between samples (reference
-// integrator/guided/integrator.cu:968-1094).  The reference issues ~10 kernels and 2 stream
-// syncs per depth over 45-byte AoS-like work items; here one depth is three launches over a
-// compact SoA queue:
+// Every pixel consults ONE guiding network that is retrained between samples (reference
+// integrator/guided/integrator.cu:968-1094), and the reference issues ~10 kernels and 2 stream syncs
+// per depth over 45-byte AoS-like work items.  Here a whole sample is ONE launch when the network has
+// the reference's shape (guided_sample_kernel below: the uniform integrator's persistent scheduler with
+// the network evaluated inside the wave, up to 64 samples per launch once training has ended).  For
+// other networks, and as the comparison path (WOST_GUIDED_FUSED=0), one depth is three launches over
+// a compact SoA queue:
 //   separate_kernel  closest point on the Dirichlet LBVH (LDS stack, temporal hint), epsilon
 //                    shell -> boundary colour into the pixel; else closest silhouette, R_B,
 //                    Neumann sampling, normalised network input; ballot/popcount compaction
