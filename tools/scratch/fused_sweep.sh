@@ -9,4 +9,4 @@ run() {
   echo "$tag: $(python3 tools/print_kernel_stats.py $f | grep guided_sample | cut -c60-110)"
   rm -rf gpurun_out/fs_$tag
 }
-for c in 1 4; do for m in 300 400 600; do WOST_GUIDED_TAIL_CHUNK=$c WOST_GUIDED_TAIL_MARGIN=$m run chunk${c}_margin$m; done; done
+for i in 1 2; do WOST_GUIDED_TAIL_CHUNK=0 run chunk0_$i; WOST_GUIDED_TAIL_CHUNK=4 run chunk4_$i; done
