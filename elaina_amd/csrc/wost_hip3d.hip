@@ -135,10 +135,18 @@ __device__ __forceinline__ bool trav_visit3(const DevMesh3 &m, V3 q, Trav &T, co
 {
     const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
     if (T.level == m.levels) {
-        // a leaf: its four triangles, exactly; ties go to the lowest ORIGINAL index
+        // a leaf: its four triangles, exactly; ties go to the lowest ORIGINAL index.  The leaf's record holds the
+        // (padded) box of every triangle: a triangle whose box is farther than the best so far cannot win or tie,
+        // and the box test costs a sixth of the exact distance.
+        const float4 *ld = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+        const float4 BLX = ld[0], BLY = ld[1], BLZ = ld[2], BHX = ld[3], BHY = ld[4], BHZ = ld[5];
+        const float bd0 = aabb_d2(BLX.x, BLY.x, BLZ.x, BHX.x, BHY.x, BHZ.x, q), bd1 = aabb_d2(BLX.y, BLY.y, BLZ.y, BHX.y, BHY.y, BHZ.y, q);
+        const float bd2 = aabb_d2(BLX.z, BLY.z, BLZ.z, BHX.z, BHY.z, BHZ.z, q), bd3 = aabb_d2(BLX.w, BLY.w, BLZ.w, BHX.w, BHY.w, BHZ.w, q);
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
             const int slot = 4 * T.pos + j;
+            const float bdj = j == 0 ? bd0 : j == 1 ? bd1 : j == 2 ? bd2 : bd3;
+            if (bdj > T.best.d2) continue;
             const int o = m.triOrig[slot];
             if (o == WOST_FAR_INDEX) continue;
             const float4 a = m.tri[3 * (size_t)slot], b = m.tri[3 * (size_t)slot + 1], c = m.tri[3 * (size_t)slot + 2];
@@ -1170,8 +1178,24 @@ static int build_mesh3(const wost3_mesh_desc &d, HostMesh3 *out)
             }
             empty[g] = 0;
         }
-    // inner nodes (levels 0 .. levels-1) store their four children; leaves (level == levels) store nothing
-    h.nodes.assign((size_t)h.first_leaf * 24, 0.0f);
+    // inner nodes (levels 0 .. levels-1) store the boxes of their four children; a leaf (level == levels) stores the
+    // boxes of its four triangles
+    h.nodes.assign((size_t)n_nodes * 24, 0.0f);
+    for (int g = h.first_leaf; g < n_nodes; ++g) {
+        float *nd = &h.nodes[(size_t)g * 24];
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * (g - h.first_leaf) + j;
+            for (int c = 0; c < 3; ++c) {
+                if (k < n) {
+                    const DevTri &T = h.flat[order[k]];
+                    nd[4 * c + j] = std::min(T.p0[c], std::min(T.p1[c], T.p2[c])) - pad;
+                    nd[12 + 4 * c + j] = std::max(T.p0[c], std::max(T.p1[c], T.p2[c])) + pad;
+                } else {
+                    nd[4 * c + j] = nd[12 + 4 * c + j] = 1.0e18f;
+                }
+            }
+        }
+    }
     for (int g = 0; g < h.first_leaf; ++g)
         for (int j = 0; j < 4; ++j) {
             const int c4 = 4 * g + 1 + j;
