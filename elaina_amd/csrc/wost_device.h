@@ -47,6 +47,11 @@ struct DevMesh {
     int32_t levels;
     int32_t first_leaf;
     int32_t emissive;        // any non-zero colour
+    // boxes over runs of consecutive ORIGINAL indices (sample_in_sphere_tree): level l holds one box (lo.x, lo.y,
+    // hi.x, hi.y) per run of 4^(l+1) segments, obox + obox_off[l]; obox_levels = 0: not built
+    const float4 *obox;
+    int32_t obox_off[12];
+    int32_t obox_levels;
 };
 
 struct DevProbe {
@@ -174,8 +179,10 @@ struct LdsColumn {
 
 // Pop the next entry that can still tie or beat the current best.  Returns false when the
 // stack is exhausted (query complete).
+// `bound` = what an entry's (truncated) box distance may not exceed: the best distance so far, or a slightly larger
+// number where box and primitive distances come from different formulas (3-D)
 template <class STK>
-__device__ __forceinline__ bool trav_pop(Trav &T, const STK &stk)
+__device__ __forceinline__ bool trav_pop(Trav &T, const STK &stk, float bound)
 {
     // Divergent branches are what this kernel pays most for (scalar exec-mask traffic), so the
     // common case -- the first or second entry is live -- runs as straight-line predicated
@@ -187,7 +194,7 @@ __device__ __forceinline__ bool trav_pop(Trav &T, const STK &stk)
         const uint32_t key = stk.get(idx);
         const bool can = need && T.sp > 0;
         const float dlb = __uint_as_float(key & ~0x3Fu);
-        const bool take = can && dlb <= T.best.d2;
+        const bool take = can && dlb <= bound;
         const int el = (int)((key >> 2) & 15u);
         const int parent = T.pos >> (2 * (T.level - el + 1));
         T.pos = take ? 4 * parent + (int)(key & 3u) : T.pos;
@@ -199,7 +206,7 @@ __device__ __forceinline__ bool trav_pop(Trav &T, const STK &stk)
         --T.sp;
         const uint32_t key = stk.get(T.sp);
         const float dlb = __uint_as_float(key & ~0x3Fu);
-        if (dlb <= T.best.d2) {
+        if (dlb <= bound) {
             const int el = (int)((key >> 2) & 15u);
             const int parent = T.pos >> (2 * (T.level - el + 1));
             T.pos = 4 * parent + (int)(key & 3u);
@@ -208,6 +215,12 @@ __device__ __forceinline__ bool trav_pop(Trav &T, const STK &stk)
         }
     }
     return !need;
+}
+
+template <class STK>
+__device__ __forceinline__ bool trav_pop(Trav &T, const STK &stk)
+{
+    return trav_pop(T, stk, T.best.d2);
 }
 
 // rare path of a leaf visit: an exact tie between candidates; lowest ORIGINAL index wins
@@ -451,6 +464,72 @@ __device__ __forceinline__ int sample_in_sphere_flat(const DevMesh &m, float qx,
         }
     }
     float len = m.flat[last].len;
+    pdf = (len / total) / len;
+    return last;
+}
+
+// The same selection for boundary meshes too large to walk twice per step.  The probabilities are defined over
+// the segments in ORIGINAL index order (inverse CDF), so the LBVH's Morton order is of no use; instead runs of
+// consecutive indices carry boxes (level l: runs of 4^(l+1)), and an index-ordered sweep skips every aligned run
+// whose box lies beyond the ball -- coarsest first.  The segments that are tested, their order and the float sums
+// are those of the flat loop: identical result.
+__device__ __forceinline__ float obox_d2(float4 b, float qx, float qy)
+{
+    const float dx = fmaxf(fmaxf(b.x - qx, qx - b.z), 0.0f), dy = fmaxf(fmaxf(b.y - qy, qy - b.w), 0.0f);
+    return __builtin_fmaf(dx, dx, dy * dy);
+}
+
+// calls f(i) for every segment i whose run boxes all touch the ball, in ascending order; f returns false to stop
+template <class F>
+__device__ __forceinline__ void sweep_in_sphere(const DevMesh &m, float qx, float qy, float R2, F f)
+{
+    // the boxes are padded by a fraction of the mesh extent, but a walker can be far outside the mesh (open boundaries:
+    // |q| and R of 10^7 mesh units occur), where the rounding of both distances grows with |q|: the skip test is slack
+    // by a relative 10^-4 on top (a run that is tested needlessly costs four exact tests; one that is skipped wrongly
+    // changes the result)
+    const float R2s = R2 * 1.0001f;
+    int i = 0;
+    while (i < m.n_segs) {
+        // the longest aligned runs starting at i, coarsest first
+        int skip = 0;
+        for (int l = m.obox_levels - 1; l >= 0 && skip == 0; --l) {
+            const int run = 4 << (2 * l);
+            if ((i & (run - 1)) == 0 && obox_d2(m.obox[m.obox_off[l] + i / run], qx, qy) > R2s) skip = run;
+        }
+        if (skip) {
+            i += skip;
+            continue;
+        }
+        const int end = min(i + 4, m.n_segs);
+        for (; i < end; ++i)
+            if (!f(i)) return;
+    }
+}
+
+__device__ __forceinline__ int sample_in_sphere_tree(const DevMesh &m, float qx, float qy, float R, float u, float &pdf)
+{
+    const float R2 = R * R;
+    float total = 0.0f;
+    sweep_in_sphere(m, qx, qy, R2, [&](int i) {
+        const DevFlatSeg s = m.flat[i];
+        if (seg_d2(s, qx, qy) <= R2 && s.len > 0.0f) total += s.len;
+        return true;
+    });
+    pdf = 0.0f;
+    if (!(total > 0.0f)) return -1;
+    const float target = u * total;
+    float cum = 0.0f;
+    int last = -1;
+    sweep_in_sphere(m, qx, qy, R2, [&](int i) {
+        const DevFlatSeg s = m.flat[i];
+        if (seg_d2(s, qx, qy) <= R2 && s.len > 0.0f) {
+            cum += s.len;
+            last = i;
+            if (target < cum) return false;
+        }
+        return true;
+    });
+    const float len = m.flat[last].len;
     pdf = (len / total) / len;
     return last;
 }

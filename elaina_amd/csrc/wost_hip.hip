@@ -607,6 +607,43 @@ static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
     HIP_TRY(upload(s.allocs, reinterpret_cast<const DevSilVertex *>(t.sil.data()), t.sil.size(), &v.sil));
     HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(t.cones.data()), t.cones.size() / 4, &v.cones));
     HIP_TRY(upload(s.allocs, reinterpret_cast<const int2 *>(t.segVerts.data()), t.segVerts.size() / 2, &v.segVerts));
+    // boxes over runs of consecutive original indices, for the index-ordered sampling of emissive Neumann meshes
+    // (sample_in_sphere_tree); padded like the tree's boxes, so that rounding never hides a segment the flat loop takes
+    if (v.emissive && t.n_segs > WOST_FLAT_MAX) {
+        float ext = 0.0f;
+        for (const FlatSeg &f : t.flat) ext = std::max(ext, std::max(std::max(std::fabs(f.ax), std::fabs(f.ay)), std::max(std::fabs(f.ax + f.ex), std::fabs(f.ay + f.ey))));
+        const float pad = ext * 0x1p-18f + 1e-30f;
+        std::vector<float> ob;
+        int levels = 0;
+        size_t prev_off = 0, prev_n = 0;
+        for (int l = 0; l < 12; ++l) {
+            const size_t run = (size_t)4 << (2 * l), n_runs = ((size_t)t.n_segs + run - 1) / run;
+            v.obox_off[l] = (int32_t)(ob.size() / 4);
+            for (size_t r = 0; r < n_runs; ++r) {
+                float lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
+                if (l == 0) {
+                    for (size_t i = r * 4; i < std::min<size_t>(r * 4 + 4, (size_t)t.n_segs); ++i) {
+                        const FlatSeg &f = t.flat[i];
+                        lo[0] = std::min(lo[0], std::min(f.ax, f.ax + f.ex)); hi[0] = std::max(hi[0], std::max(f.ax, f.ax + f.ex));
+                        lo[1] = std::min(lo[1], std::min(f.ay, f.ay + f.ey)); hi[1] = std::max(hi[1], std::max(f.ay, f.ay + f.ey));
+                    }
+                    lo[0] -= pad; lo[1] -= pad; hi[0] += pad; hi[1] += pad;
+                } else {
+                    for (size_t c = r * 4; c < std::min(r * 4 + 4, prev_n); ++c) {
+                        const float *b = &ob[(prev_off + c) * 4];
+                        lo[0] = std::min(lo[0], b[0]); lo[1] = std::min(lo[1], b[1]); hi[0] = std::max(hi[0], b[2]); hi[1] = std::max(hi[1], b[3]);
+                    }
+                }
+                ob.insert(ob.end(), {lo[0], lo[1], hi[0], hi[1]});
+            }
+            prev_off = (size_t)v.obox_off[l];
+            prev_n = n_runs;
+            levels = l + 1;
+            if (n_runs <= 1) break;
+        }
+        v.obox_levels = levels;
+        HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(ob.data()), ob.size() / 4, &v.obox));
+    }
     return WOST_OK;
 }
 

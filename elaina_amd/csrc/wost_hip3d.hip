@@ -77,6 +77,11 @@ struct DevMesh3 {
     const DevEdge3 *edges;   // [n_edges]
     const int32_t *triEdges; // [slots * 3] the edge records of a triangle's three sides (-1: degenerate side)
     int32_t n_tris, n_edges, levels, first_leaf, emissive;
+    // boxes over runs of consecutive ORIGINAL triangle indices (sample_in_sphere3_tree): level l holds, per run of
+    // 4^(l+1) triangles, two float4 (lo.xyz, hi.xyz) at obox + 2 * (obox_off[l] + run); obox_levels = 0: not built
+    const float4 *obox;
+    int32_t obox_off[12];
+    int32_t obox_levels;
 };
 
 struct DevProbe3 {
@@ -131,6 +136,8 @@ __device__ __forceinline__ float aabb_d2(float lox, float loy, float loz, float 
     return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
 }
 
+constexpr float kSlack3 = 1.0001f;     // relative slack of every box-against-best comparison of the 3-D trees
+
 __device__ __forceinline__ bool trav_visit3(const DevMesh3 &m, V3 q, Trav &T, const LdsColumn &stk)
 {
     const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
@@ -138,6 +145,8 @@ __device__ __forceinline__ bool trav_visit3(const DevMesh3 &m, V3 q, Trav &T, co
         // a leaf: its four triangles, exactly; ties go to the lowest ORIGINAL index.  The leaf's record holds the
         // (padded) box of every triangle: a triangle whose box is farther than the best so far cannot win or tie,
         // and the box test costs a sixth of the exact distance.
+        // (the slack of kSlack3: box and triangle distances come from different formulas, and far outside the mesh --
+        // open boundaries let walkers escape -- their rounding grows with |q|, beyond the padding of the boxes)
         const float4 *ld = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
         const float4 BLX = ld[0], BLY = ld[1], BLZ = ld[2], BHX = ld[3], BHY = ld[4], BHZ = ld[5];
         const float bd0 = aabb_d2(BLX.x, BLY.x, BLZ.x, BHX.x, BHY.x, BHZ.x, q), bd1 = aabb_d2(BLX.y, BLY.y, BLZ.y, BHX.y, BHY.y, BHZ.y, q);
@@ -146,7 +155,7 @@ __device__ __forceinline__ bool trav_visit3(const DevMesh3 &m, V3 q, Trav &T, co
         for (int j = 0; j < 4; ++j) {
             const int slot = 4 * T.pos + j;
             const float bdj = j == 0 ? bd0 : j == 1 ? bd1 : j == 2 ? bd2 : bd3;
-            if (bdj > T.best.d2) continue;
+            if (bdj > T.best.d2 * kSlack3) continue;
             const int o = m.triOrig[slot];
             if (o == WOST_FAR_INDEX) continue;
             const float4 a = m.tri[3 * (size_t)slot], b = m.tri[3 * (size_t)slot + 1], c = m.tri[3 * (size_t)slot + 2];
@@ -158,13 +167,13 @@ __device__ __forceinline__ bool trav_visit3(const DevMesh3 &m, V3 q, Trav &T, co
                 if (o < T.best_orig) { T.best.slot = slot; T.best_orig = o; }
             }
         }
-        return trav_pop(T, stk);
+        return trav_pop(T, stk, T.best.d2 * kSlack3);
     }
     const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
     const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
     const float d0 = aabb_d2(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, q), d1 = aabb_d2(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, q);
     const float d2 = aabb_d2(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, q), d3 = aabb_d2(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, q);
-    const float bd = T.best.d2;
+    const float bd = T.best.d2 * kSlack3;
     const uint32_t tag = (uint32_t)(T.level + 1) << 2;
     uint32_t k0 = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;
     uint32_t k1 = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3Fu) | tag | 1u) : 0xffffffffu;
@@ -181,7 +190,7 @@ __device__ __forceinline__ bool trav_visit3(const DevMesh3 &m, V3 q, Trav &T, co
         T.level = T.level + 1;
         return true;
     }
-    return trav_pop(T, stk);
+    return trav_pop(T, stk, bd);
 }
 
 // seed of a query: the triangle in `slot` (temporal hint: the previous closest triangle)
@@ -360,7 +369,9 @@ __device__ __forceinline__ void silhouette_edge_test(const DevMesh3 &m, int e, V
 
 __device__ __forceinline__ float closest_silhouette3_tree(const DevMesh3 &m, V3 q, float rmax, const LdsColumn &stk)
 {
-    Trav T = trav_begin(Closest{rmax * rmax, -1});
+    // best2 is the exact minimum (the flat loop's variable); T.best.d2 carries the slack pruning bound
+    float best2 = rmax * rmax;
+    Trav T = trav_begin(Closest{best2 * kSlack3, -1});
     bool found = false;
     for (;;) {
         bool more;
@@ -372,9 +383,10 @@ __device__ __forceinline__ float closest_silhouette3_tree(const DevMesh3 &m, V3 
 #pragma unroll 1
                 for (int k = 0; k < 3; ++k) {
                     const int e = m.triEdges[3 * (size_t)slot + k];
-                    if (e >= 0) silhouette_edge_test(m, e, q, T.best.d2, found);
+                    if (e >= 0) silhouette_edge_test(m, e, q, best2, found);
                 }
             }
+            T.best.d2 = best2 * kSlack3;
             more = trav_pop(T, stk);
         } else {
             const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
@@ -404,7 +416,7 @@ __device__ __forceinline__ float closest_silhouette3_tree(const DevMesh3 &m, V3 
         }
         if (!more) break;
     }
-    return found ? sqrtf(T.best.d2) : WOST_INF;
+    return found ? sqrtf(best2) : WOST_INF;
 }
 
 // rays: where the ray enters a child box (slabs; the boxes are padded and the comparison is slack, so a box that
@@ -522,6 +534,62 @@ __device__ __forceinline__ bool ray_any3(const DevMesh3 &m, V3 o, V3 d, float tm
         return ray3_tree<true>(m, o, d, tmax, t, i, stk);
     }
     return ray_any3_flat(m, o, d, tmax);
+}
+
+// The selection of sample_in_sphere3_flat for meshes too large to walk twice per step: the probabilities are defined
+// over the triangles in ORIGINAL index order, so runs of consecutive indices carry boxes and an index-ordered sweep
+// skips every aligned run whose box lies beyond the ball, coarsest first (wost_device.h has the 2-D twin).  The
+// triangles that are tested, their order and the float sums are those of the flat loop.
+template <class F>
+__device__ __forceinline__ void sweep_in_sphere3(const DevMesh3 &m, V3 q, float R2, F f)
+{
+    const float R2s = R2 * kSlack3;
+    int i = 0;
+    while (i < m.n_tris) {
+        int skip = 0;
+        for (int l = m.obox_levels - 1; l >= 0 && skip == 0; --l) {
+            const int run = 4 << (2 * l);
+            if ((i & (run - 1)) == 0) {
+                const float4 lo = m.obox[2 * (m.obox_off[l] + i / run)], hi = m.obox[2 * (m.obox_off[l] + i / run) + 1];
+                if (aabb_d2(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, q) > R2s) skip = run;
+            }
+        }
+        if (skip) {
+            i += skip;
+            continue;
+        }
+        const int end = min(i + 4, m.n_tris);
+        for (; i < end; ++i)
+            if (!f(i)) return;
+    }
+}
+
+__device__ __forceinline__ int sample_in_sphere3_tree(const DevMesh3 &m, V3 q, float R, float u, float &pdf)
+{
+    const float R2 = R * R;
+    float total = 0.0f;
+    sweep_in_sphere3(m, q, R2, [&](int i) {
+        const DevTri T = m.flat[i];
+        if (T.area > 0.0f && tri_d2(ld3(T.p0), ld3(T.p1), ld3(T.p2), q) <= R2) total += T.area;
+        return true;
+    });
+    pdf = 0.0f;
+    if (!(total > 0.0f)) return -1;
+    const float target = u * total;
+    float cum = 0.0f;
+    int last = -1;
+    sweep_in_sphere3(m, q, R2, [&](int i) {
+        const DevTri T = m.flat[i];
+        if (T.area > 0.0f && tri_d2(ld3(T.p0), ld3(T.p1), ld3(T.p2), q) <= R2) {
+            cum += T.area;
+            last = i;
+            if (target < cum) return false;
+        }
+        return true;
+    });
+    const float a = m.flat[last].area;
+    pdf = (a / total) / a;
+    return last;
 }
 
 // getPerpendicular(Vector3f) + frameFromNormal(Vector3f) + Frame<3>::toWorld
@@ -715,7 +783,7 @@ __device__ __forceinline__ bool step3(const Walk3Params &P, Lane3 &L, Closest cp
                 const float u0 = pcg_next_float(rng), u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
                 if (EMISSIVE) {
                     float pdf;
-                    const int oi = sample_in_sphere3_flat(P.nm, p, R_B, u0, pdf);
+                    const int oi = (NTREE && P.nm.obox_levels > 0) ? sample_in_sphere3_tree(P.nm, p, R_B, u0, pdf) : sample_in_sphere3_flat(P.nm, p, R_B, u0, pdf);
                     if (oi != -1 && pdf > 0) {
                         const DevTri S = P.nm.flat[oi];
                         const V3 s0 = ld3(S.p0), s1 = ld3(S.p1), s2 = ld3(S.p2);
@@ -1027,6 +1095,8 @@ struct HostMesh3 {
     bool emissive = false;
     std::vector<float> nodes, tri, colors;
     std::vector<int32_t> triOrig, triVerts, flatVerts, triEdges;
+    std::vector<float> obox;          // index-ordered run boxes (emissive meshes above the flat limit)
+    int32_t obox_off[12] = {0}, obox_levels = 0;
     std::vector<DevTri> flat;
     std::vector<DevEdge3> edges;
 };
@@ -1178,6 +1248,36 @@ static int build_mesh3(const wost3_mesh_desc &d, HostMesh3 *out)
             }
             empty[g] = 0;
         }
+    if (h.emissive && n > WOST3_FLAT_MAX) {
+        size_t prev_off = 0, prev_n = 0;
+        for (int l = 0; l < 12; ++l) {
+            const size_t run = (size_t)4 << (2 * l), n_runs = ((size_t)n + run - 1) / run;
+            h.obox_off[l] = (int32_t)(h.obox.size() / 8);
+            for (size_t r = 0; r < n_runs; ++r) {
+                float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                if (l == 0) {
+                    for (size_t i = r * 4; i < std::min<size_t>(r * 4 + 4, (size_t)n); ++i)
+                        for (int c = 0; c < 3; ++c) {
+                            const DevTri &T = h.flat[i];
+                            blo[c] = std::min(blo[c], std::min(T.p0[c], std::min(T.p1[c], T.p2[c])));
+                            bhi[c] = std::max(bhi[c], std::max(T.p0[c], std::max(T.p1[c], T.p2[c])));
+                        }
+                    for (int c = 0; c < 3; ++c) { blo[c] -= pad; bhi[c] += pad; }
+                } else {
+                    for (size_t c4 = r * 4; c4 < std::min(r * 4 + 4, prev_n); ++c4)
+                        for (int c = 0; c < 3; ++c) {
+                            blo[c] = std::min(blo[c], h.obox[(prev_off + c4) * 8 + c]);
+                            bhi[c] = std::max(bhi[c], h.obox[(prev_off + c4) * 8 + 4 + c]);
+                        }
+                }
+                h.obox.insert(h.obox.end(), {blo[0], blo[1], blo[2], 0.0f, bhi[0], bhi[1], bhi[2], 0.0f});
+            }
+            prev_off = (size_t)h.obox_off[l];
+            prev_n = n_runs;
+            h.obox_levels = l + 1;
+            if (n_runs <= 1) break;
+        }
+    }
     // inner nodes (levels 0 .. levels-1) store the boxes of their four children; a leaf (level == levels) stores the
     // boxes of its four triangles
     h.nodes.assign((size_t)n_nodes * 24, 0.0f);
@@ -1273,6 +1373,9 @@ static int upload_mesh3(const wost3_mesh_desc &d, DeviceMesh3 &s)
     W3_TRY(upload3(s.allocs, h.edges.data(), h.edges.size(), &v.edges));
     W3_TRY(upload3(s.allocs, h.flatVerts.data(), h.flatVerts.size(), &v.flatVerts));
     W3_TRY(upload3(s.allocs, h.triEdges.data(), h.triEdges.size(), &v.triEdges));
+    W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.obox.data()), h.obox.size() / 4, &v.obox));
+    for (int l = 0; l < 12; ++l) v.obox_off[l] = h.obox_off[l];
+    v.obox_levels = h.obox_levels;
     return WOST_OK;
 }
 

@@ -24,7 +24,7 @@ __device__ __forceinline__ bool neumann_sample(const DevMesh &nm, float neumann_
     const float u0 = pcg_next_float(rng);
     const float u1 = pcg_next_float(rng);
     float pdf;
-    const int oi = sample_in_sphere_flat(nm, px, py, R_B, u0, pdf);
+    const int oi = (TREE && nm.obox_levels > 0) ? sample_in_sphere_tree(nm, px, py, R_B, u0, pdf) : sample_in_sphere_flat(nm, px, py, R_B, u0, pdf);
     if (!(oi != -1 && pdf > 0)) return false;
     const DevFlatSeg so = nm.flat[oi];
     const float spx = __builtin_fmaf(u1, so.ex, so.ax), spy = __builtin_fmaf(u1, so.ey, so.ay);

@@ -207,3 +207,31 @@ def test_3d_debug_channels_match_oracle(oracle):
     it = _it(only_d, 8, 8, 1, 4, 1e-3)
     assert np.all(np.isinf(it.render_sdf(1))) and np.all(it.render_source() == 0)
     it.close()
+
+
+def test_3d_queries_and_walks_far_outside_the_meshes(oracle):
+    """an OPEN Neumann shell lets walkers escape: positions and radii of 10^3 .. 10^7 mesh units occur, where the
+    rounding of box and primitive distances grows with |q| -- the tree queries must still give the flat answers"""
+    sd = _shell_scene(2, 3)
+    keep = np.ones(len(sd["n_tris"]), bool)
+    keep[::7] = False                                   # holes all over the shell
+    sd["n_tris"] = sd["n_tris"][keep]
+    assert len(sd["n_tris"]) > 1000
+    it = _it(sd, 8, 8, 1, 4, 1e-3)
+    rng = np.random.default_rng(11)
+    d = rng.normal(size=(4000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts = (d * 10.0 ** rng.uniform(0.5, 7.0, (4000, 1))).astype(np.float32)
+    for x, y in zip(it.closest_point(pts), oracle.closest_point3(sd["d_verts"], sd["d_tris"], pts)):
+        assert np.array_equal(x, y)
+    V, T = sd["n_verts"], sd["n_tris"]
+    assert np.array_equal(it.closest_silhouette(pts), oracle.closest_silhouette3(V, T, pts))
+    aim = (-pts / np.linalg.norm(pts, axis=1, keepdims=True) + rng.normal(scale=1e-7, size=pts.shape)).astype(np.float32)
+    tmax = (np.linalg.norm(pts, axis=1) * 2.0).astype(np.float32)
+    got, ref = it.ray_intersect(pts, aim, tmax), oracle.ray_intersect3(V, T, pts, aim, tmax)
+    assert np.array_equal(got[0], ref[0])
+    hit = ref[0] != 0
+    assert np.array_equal(got[1][hit], ref[1][hit]) and np.array_equal(got[2][hit], ref[2][hit])
+    it.close()
+    ref = _same_solve(oracle, sd, 14, 12, 8, 96, 2e-3)
+    assert ref["walks_truncated"] > 0 and ref["neumann_hits"] > 0

@@ -15,3 +15,14 @@ for subdiv, frame, spp in ((3, 512, 64), (5, 512, 64), (5, 1024, 64)):
     st = it.last_stats
     print("icosphere %d triangles, %dx%d, %d spp: %.3g walk steps in %.1f ms (kernel %.1f ms) -> %.3g steps/s" % (len(sd["d_tris"]), frame, frame, spp, st["walk_steps"], dt * 1e3, st["kernel_ms"], st["walk_steps"] / (st["kernel_ms"] * 1e-3)), flush=True)
     it.close()
+
+# emissive Neumann shell around a Dirichlet ball: the Neumann sampling sweeps runs of consecutive triangle indices
+from test_gpu_3d import _shell_scene
+for subdiv in (3, 4):
+    sd = _shell_scene(2, subdiv, flux=lambda x, y, z: 0.3 * y)
+    it = UniformIntegrator3(Problem3.from_dict(sd), UniformIntegratorSettings((256, 256), 16, 64, 2e-3))
+    it.solve()
+    it.solve()
+    st = it.last_stats
+    print("emissive shell %d triangles, 256x256, 16 spp: %.3g walk steps, kernel %.1f ms -> %.3g steps/s" % (len(sd["n_tris"]), st["walk_steps"], st["kernel_ms"], st["walk_steps"] / (st["kernel_ms"] * 1e-3)), flush=True)
+    it.close()
