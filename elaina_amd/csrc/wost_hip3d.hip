@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -75,7 +76,11 @@ struct DevMesh3 {
     const DevTri *flat;      // [n_tris] original order
     const int32_t *flatVerts;// [n_tris * 3] vertex ids, original order
     const DevEdge3 *edges;   // [n_edges]
-    const int32_t *triEdges; // [slots * 3] the edge records of a triangle's three sides (-1: degenerate side)
+    const int32_t *triEdges; // [slots * 3] the edge records of a triangle's three sides (-1: degenerate side, or an edge
+                             // that an earlier slot already lists: every edge is tested from one triangle only)
+    const float4 *slotEdges; // [slots * 3 * 4] the silhouette test's operands of side k of the triangle in a slot, one record:
+                             // (pa, kind) (pb, -) (n0, -) (n1, -); kind 0 = not listed here, 1 = two triangles, 2 = boundary
+    const float4 *cones;     // [n_nodes * 6] normal cones of the four children: ax[4] ay[4] az[4] cos[4] sin[4] rad[4]
     int32_t n_tris, n_edges, levels, first_leaf, emissive;
     // boxes over runs of consecutive ORIGINAL triangle indices (sample_in_sphere3_tree): level l holds, per run of
     // 4^(l+1) triangles, two float4 (lo.xyz, hi.xyz) at obox + 2 * (obox_off[l] + run); obox_levels = 0: not built
@@ -269,9 +274,9 @@ __device__ __forceinline__ float closest_silhouette3_flat(const DevMesh3 &m, V3 
     return found ? sqrtf(best2) : WOST_INF;
 }
 
-__device__ __forceinline__ bool tri_ray(const DevTri &T, V3 o, V3 d, float tmax, float &t)
+__device__ __forceinline__ bool tri_ray3(V3 p0, V3 p1, V3 p2, V3 o, V3 d, float tmax, float &t)
 {
-    const V3 p0 = ld3(T.p0), e0 = ld3(T.p1) - p0, e1 = ld3(T.p2) - p0;
+    const V3 e0 = p1 - p0, e1 = p2 - p0;
     const V3 pvec = cross3(d, e1);
     const float det = dot3(e0, pvec);
     if (det == 0.0f) return false;
@@ -286,6 +291,10 @@ __device__ __forceinline__ bool tri_ray(const DevTri &T, V3 o, V3 d, float tmax,
     if (ts < 0.0f || ts > tmax * adet) return false;
     t = tt / det;
     return true;
+}
+__device__ __forceinline__ bool tri_ray(const DevTri &T, V3 o, V3 d, float tmax, float &t)
+{
+    return tri_ray3(ld3(T.p0), ld3(T.p1), ld3(T.p2), o, d, tmax, t);
 }
 __device__ __forceinline__ bool ray_closest3_flat(const DevMesh3 &m, V3 o, V3 d, float tmax, float &t_out, int &idx_out)
 {
@@ -334,6 +343,10 @@ __device__ __forceinline__ int sample_in_sphere3_flat(const DevMesh3 &m, V3 q, f
     return last;
 }
 
+#ifdef WOST3_PROFILE
+// developer build: wave-clock time spent in the sections of a step, summed over waves; visit counts of the queries
+__device__ unsigned long long g_prof3[16];
+#endif
 // ---- the same queries on the tree, for Neumann meshes too large for flat loops -------------------------
 // silhouette: an edge lies inside its triangle, a triangle inside its (padded) box, so boxes farther than the best
 // silhouette edge so far cannot improve it; a leaf tests the three sides of its four triangles with the body of the
@@ -367,39 +380,105 @@ __device__ __forceinline__ void silhouette_edge_test(const DevMesh3 &m, int e, V
     }
 }
 
+// Normal cone of a subtree (Sawhney et al. 2023, spatialized normal cone hierarchy; the 2-D twin is
+// cone_may_hold_silhouette in wost_device.h): every normal of a triangle next to an edge of the subtree lies within
+// `half` of the axis, every point of those edges within `rad` of c.  A silhouette edge needs view . n0 and view . n1 of
+// opposite signs, i.e. a normal of the cone perpendicular to a direction of the view cone: impossible while
+// |cos(angle(axis, q - c))| > sin(half + view half angle).  Conservative (slack 1e-3 on both comparisons, rad padded
+// by more than WOST_SIL_PRECISION so that a query standing on an edge is inside the ball): it only ever removes
+// edges the exact test would reject, so the minimum is that of the flat loop.
+__device__ __forceinline__ bool cone3_may_hold_silhouette(float ax, float ay, float az, float ch, float sh, float rad, V3 c, V3 q)
+{
+    if (ch <= 0.0f) return true;                       // marked "cannot prune"
+    const V3 w = c - q;
+    const float l2 = dot3(w, w);
+    if (l2 <= rad * rad * 1.0001f) return true;        // q inside the ball: no view cone
+    const float inv_l = 1.0f / sqrtf(l2);
+    const float sv = fminf(rad * inv_l, 1.0f);
+    const float cv = sqrtf(fmaxf(1.0f - sv * sv, 0.0f));
+    const float cos_sum = ch * cv - sh * sv;
+    if (cos_sum <= 1e-3f) return true;
+    const float sin_sum = sh * cv + ch * sv;
+    const float cs = (ax * w.x + ay * w.y + az * w.z) * inv_l;
+    return fabsf(cs) <= sin_sum + 1e-3f;
+}
+
+// silhouette_edge_test on the packed record of a leaf slot (the same operands, one load instead of three dependent ones)
+__device__ __forceinline__ void silhouette_record_test(float4 r0, float4 r1, float4 r2, float4 r3, V3 q, float &best2, bool &found)
+{
+    if (r0.w == 0.0f) return;
+    const V3 pa = v3(r0.x, r0.y, r0.z), pb = v3(r1.x, r1.y, r1.z), ev = pb - pa;
+    const float ee = dot3(ev, ev);
+    float t = ee > 0.0f ? dot3(q - pa, ev) / ee : 0.0f;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const V3 pt = madd3(pa, t, ev), view = q - pt;
+    const float d2 = dot3(view, view);
+    if (d2 > best2) return;
+    bool is_sil = r0.w == 2.0f;
+    if (!is_sil) {
+        const V3 n0 = v3(r2.x, r2.y, r2.z), n1 = v3(r3.x, r3.y, r3.z);
+        const float d = sqrtf(d2);
+        if (d <= WOST_SIL_PRECISION) {
+            const float det = dot3(normalize3(ev), cross3(n0, n1));
+            is_sil = (-det > WOST_SIL_PRECISION);
+        } else {
+            const V3 vd = v3(view.x / d, view.y / d, view.z / d);
+            const float dot0 = dot3(vd, n0), dot1 = dot3(vd, n1);
+            is_sil = !(fabsf(dot0) <= WOST_SIL_PRECISION || fabsf(dot1) <= WOST_SIL_PRECISION) && (dot0 * dot1 < 0.0f);
+        }
+    }
+    if (is_sil && (d2 < best2 || !found)) {
+        best2 = d2;
+        found = true;
+    }
+}
+
 __device__ __forceinline__ float closest_silhouette3_tree(const DevMesh3 &m, V3 q, float rmax, const LdsColumn &stk)
 {
     // best2 is the exact minimum (the flat loop's variable); T.best.d2 carries the slack pruning bound
     float best2 = rmax * rmax;
     Trav T = trav_begin(Closest{best2 * kSlack3, -1});
     bool found = false;
+#ifdef WOST3_PROFILE
+    unsigned prof_inner = 0, prof_leaf = 0;
+#endif
     for (;;) {
         bool more;
+#ifdef WOST3_PROFILE
+        if (T.level == m.levels) ++prof_leaf; else ++prof_inner;
+#endif
+        const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
+        const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+        const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
+        const float d0 = aabb_d2(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, q), d1 = aabb_d2(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, q);
+        const float d2 = aabb_d2(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, q), d3 = aabb_d2(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, q);
         if (T.level == m.levels) {
+            // the record of a leaf holds the boxes of its four triangles: an edge is tested from the triangle that
+            // lists it, and only while that triangle's box is not beyond the best edge
 #pragma unroll 1
             for (int j = 0; j < 4; ++j) {
                 const int slot = 4 * T.pos + j;
-                if (m.triOrig[slot] == WOST_FAR_INDEX) continue;
+                const float bdj = j == 0 ? d0 : j == 1 ? d1 : j == 2 ? d2 : d3;
+                if (bdj > best2 * kSlack3) continue;
+                const float4 *rec = m.slotEdges + 12 * (size_t)slot;
 #pragma unroll 1
-                for (int k = 0; k < 3; ++k) {
-                    const int e = m.triEdges[3 * (size_t)slot + k];
-                    if (e >= 0) silhouette_edge_test(m, e, q, best2, found);
-                }
+                for (int k = 0; k < 3; ++k) silhouette_record_test(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3], q, best2, found);
             }
             T.best.d2 = best2 * kSlack3;
             more = trav_pop(T, stk);
         } else {
-            const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
-            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
-            const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
-            const float d0 = aabb_d2(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, q), d1 = aabb_d2(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, q);
-            const float d2 = aabb_d2(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, q), d3 = aabb_d2(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, q);
             const float bd = T.best.d2;
             const uint32_t tag = (uint32_t)(T.level + 1) << 2;
-            uint32_t k0 = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;
-            uint32_t k1 = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3Fu) | tag | 1u) : 0xffffffffu;
-            uint32_t k2 = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3Fu) | tag | 2u) : 0xffffffffu;
-            uint32_t k3 = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3Fu) | tag | 3u) : 0xffffffffu;
+            const float4 *cn = m.cones + 6 * (size_t)g;
+            const float4 AX = cn[0], AY = cn[1], AZ = cn[2], CH = cn[3], SH = cn[4], RD = cn[5];
+            const bool c0 = d0 <= bd && cone3_may_hold_silhouette(AX.x, AY.x, AZ.x, CH.x, SH.x, RD.x, v3(0.5f * (LX.x + HX.x), 0.5f * (LY.x + HY.x), 0.5f * (LZ.x + HZ.x)), q);
+            const bool c1 = d1 <= bd && cone3_may_hold_silhouette(AX.y, AY.y, AZ.y, CH.y, SH.y, RD.y, v3(0.5f * (LX.y + HX.y), 0.5f * (LY.y + HY.y), 0.5f * (LZ.y + HZ.y)), q);
+            const bool c2 = d2 <= bd && cone3_may_hold_silhouette(AX.z, AY.z, AZ.z, CH.z, SH.z, RD.z, v3(0.5f * (LX.z + HX.z), 0.5f * (LY.z + HY.z), 0.5f * (LZ.z + HZ.z)), q);
+            const bool c3 = d3 <= bd && cone3_may_hold_silhouette(AX.w, AY.w, AZ.w, CH.w, SH.w, RD.w, v3(0.5f * (LX.w + HX.w), 0.5f * (LY.w + HY.w), 0.5f * (LZ.w + HZ.w)), q);
+            uint32_t k0 = c0 ? ((__float_as_uint(d0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;
+            uint32_t k1 = c1 ? ((__float_as_uint(d1) & ~0x3Fu) | tag | 1u) : 0xffffffffu;
+            uint32_t k2 = c2 ? ((__float_as_uint(d2) & ~0x3Fu) | tag | 2u) : 0xffffffffu;
+            uint32_t k3 = c3 ? ((__float_as_uint(d3) & ~0x3Fu) | tag | 3u) : 0xffffffffu;
             cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
             int sp = T.sp;
             stk.put(sp, k3); sp += (k3 != 0xffffffffu) ? 1 : 0;
@@ -416,6 +495,11 @@ __device__ __forceinline__ float closest_silhouette3_tree(const DevMesh3 &m, V3 
         }
         if (!more) break;
     }
+#ifdef WOST3_PROFILE
+    atomicAdd(&g_prof3[12], (unsigned long long)prof_inner);
+    atomicAdd(&g_prof3[13], (unsigned long long)prof_leaf);
+    atomicAdd(&g_prof3[14], 1ull);
+#endif
     return found ? sqrtf(best2) : WOST_INF;
 }
 
@@ -463,13 +547,22 @@ __device__ __forceinline__ bool ray3_tree(const DevMesh3 &m, V3 o, V3 d, float t
     for (;;) {
         bool more;
         if (T.level == m.levels) {
+            // the record of a leaf: the boxes of its four triangles; the triangles themselves in leaf order
+            const uint32_t gl = level_first(T.level) + (uint32_t)T.pos;
+            const float4 *ld = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(gl, 96u));
+            const float4 LX = ld[0], LY = ld[1], LZ = ld[2], HX = ld[3], HY = ld[4], HZ = ld[5];
+            const float bd = T.best.d2;
+            const float e0 = ray_aabb_entry(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, o, d, inv, bd), e1 = ray_aabb_entry(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, o, d, inv, bd);
+            const float e2 = ray_aabb_entry(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, o, d, inv, bd), e3 = ray_aabb_entry(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, o, d, inv, bd);
 #pragma unroll 1
             for (int j = 0; j < 4; ++j) {
                 const int slot = 4 * T.pos + j;
-                const int oi = m.triOrig[slot];
-                if (oi == WOST_FAR_INDEX) continue;
+                const float ej = j == 0 ? e0 : j == 1 ? e1 : j == 2 ? e2 : e3;
+                if (!(ej <= T.best.d2)) continue;                 // empty slots lie far away
+                const float4 a = m.tri[3 * (size_t)slot], b = m.tri[3 * (size_t)slot + 1], c = m.tri[3 * (size_t)slot + 2];
                 float t;
-                if (tri_ray(m.flat[oi], o, d, tmax, t)) {
+                if (tri_ray3(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), o, d, tmax, t)) {
+                    const int oi = m.triOrig[slot];
                     if (ANY_HIT) {
                         t_out = t; idx_out = oi;
                         return true;
@@ -691,6 +784,14 @@ struct Lane3 {
 
 // the rest of a step once the closest Dirichlet triangle is known (`cp`, ignored without that mesh); true = the walk
 // has ended (absorbed, no boundary at all), false = L.p is the next point
+#ifdef WOST3_PROFILE
+#define PROF3_T0() unsigned long long prof_t = __builtin_readcyclecounter()
+#define PROF3(k) do { const unsigned long long prof_n = __builtin_readcyclecounter(); if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&g_prof3[k], prof_n - prof_t); prof_t = prof_n; } while (0)
+#else
+#define PROF3_T0() do {} while (0)
+#define PROF3(k) do {} while (0)
+#endif
+
 template <bool EMISSIVE, bool SOURCE, bool NTREE>
 __device__ __forceinline__ bool step3(const Walk3Params &P, Lane3 &L, Closest cp, const LdsColumn &stk)
 {
@@ -729,7 +830,9 @@ __device__ __forceinline__ bool step3(const Walk3Params &P, Lane3 &L, Closest cp
             }
         }
             float R_N = WOST_INF;
+            PROF3_T0();
             if (has_n) R_N = closest_silhouette3<NTREE>(P.nm, p, R_D, stk);
+            PROF3(0);
             float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
             R_B *= WOST_R_B_SHRINK;
             if (isinf(R_B)) return true;
@@ -778,6 +881,7 @@ __device__ __forceinline__ bool step3(const Walk3Params &P, Lane3 &L, Closest cp
                     }
                 }
             }
+            PROF3(1);
             // ---- sampleNeumann: three draws whether or not the boundary emits ----
             if (has_n) {
                 const float u0 = pcg_next_float(rng), u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
@@ -824,6 +928,7 @@ __device__ __forceinline__ bool step3(const Walk3Params &P, Lane3 &L, Closest cp
                     }
                 }
             }
+            PROF3(2);
             // ---- oneStepWalk ----
             V3 dir, cur = p;
             float pdf, alpha = 1.0f;
@@ -857,6 +962,7 @@ __device__ __forceinline__ bool step3(const Walk3Params &P, Lane3 &L, Closest cp
                     ++nhits;
                 }
             }
+    PROF3(3);
     thp = thp / pdf / alpha / WOST_4PI;
     p = nxt; on_n = hit; nn = hn;
     return false;
@@ -869,6 +975,9 @@ __global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
 {
     extern __shared__ uint32_t lds_stack[];
     const LdsColumn stk(lds_stack + threadIdx.x, blockDim.x);
+#ifdef WOST3_PROFILE
+    const unsigned long long prof_begin = __builtin_readcyclecounter();
+#endif
     const int lane = threadIdx.x & 63;
     const bool has_d = P.dm.n_tris > 0;
     enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5 };
@@ -968,7 +1077,11 @@ __global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
             if (__ballot(mode == MODE_REFILL)) continue;
             break;
         }
+        PROF3_T0();
         if (n_wait * P.wait_weight >= n_trav * 8) {
+#ifdef WOST3_PROFILE
+            if (lane == 0) { atomicAdd(&g_prof3[8], 1ull); atomicAdd(&g_prof3[9], (unsigned long long)n_wait); }
+#endif
             if (mode == MODE_WAIT) {
                 if (has_d && L.depth == 0 && !L.d0_valid) {
                     L.d0 = T.best;
@@ -993,14 +1106,22 @@ __global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
                     mode = MODE_REFILL;
                 }
             }
+            PROF3(4);
         } else {
             for (int b = 0; b < P.trav_burst; ++b) {
                 if (mode == MODE_TRAV) {
                     if (!trav_visit3(P.dm, L.p, T, stk)) mode = MODE_WAIT;
                 }
             }
+            PROF3(5);
+#ifdef WOST3_PROFILE
+            if (lane == 0) { atomicAdd(&g_prof3[10], 1ull); atomicAdd(&g_prof3[11], (unsigned long long)n_trav); }
+#endif
         }
     }
+#ifdef WOST3_PROFILE
+    if (lane == 0) atomicAdd(&g_prof3[6], __builtin_readcyclecounter() - prof_begin);
+#endif
     t_steps += L.c_steps; t_started += L.c_started; t_absorbed += L.c_absorbed; t_truncated += L.c_truncated; t_nhits += L.c_nhits;
     uint32_t v[5] = {t_steps, t_started, t_absorbed, t_truncated, t_nhits};
 #pragma unroll
@@ -1093,7 +1214,7 @@ __global__ __launch_bounds__(256) void ray3_kernel(DevMesh3 m, const float *o, c
 struct HostMesh3 {
     int32_t n_tris = 0, n_edges = 0, levels = 1, first_leaf = 1;
     bool emissive = false;
-    std::vector<float> nodes, tri, colors;
+    std::vector<float> nodes, tri, colors, cones, slotEdges;
     std::vector<int32_t> triOrig, triVerts, flatVerts, triEdges;
     std::vector<float> obox;          // index-ordered run boxes (emissive meshes above the flat limit)
     int32_t obox_off[12] = {0}, obox_levels = 0;
@@ -1210,9 +1331,25 @@ static int build_mesh3(const wost3_mesh_desc &d, HostMesh3 *out)
     h.triOrig.assign(n_slots, kFarIndex);
     h.triVerts.assign(n_slots * 3, 0);
     h.triEdges.assign(n_slots * 3, -1);
+    std::vector<char> edge_listed(h.edges.size(), 0);
+    h.slotEdges.assign(n_slots * 3 * 16, 0.0f);
     for (int k = 0; k < n; ++k) {
         const int o = order[k];
-        for (int c = 0; c < 3; ++c) h.triEdges[3 * (size_t)k + c] = edge_of[3 * (size_t)o + c];
+        for (int c = 0; c < 3; ++c) {
+            const int32_t e = edge_of[3 * (size_t)o + c];
+            if (e >= 0 && !edge_listed[e]) {
+                edge_listed[e] = 1;
+                h.triEdges[3 * (size_t)k + c] = e;
+                const DevEdge3 &E = h.edges[e];
+                float *r = &h.slotEdges[(3 * (size_t)k + c) * 16];
+                for (int x = 0; x < 3; ++x) {
+                    r[x] = E.pa[x]; r[4 + x] = E.pb[x];
+                    r[8 + x] = h.flat[E.t0].n[x];
+                    r[12 + x] = E.t1 >= 0 ? h.flat[E.t1].n[x] : 0.0f;
+                }
+                r[3] = E.t1 >= 0 ? 1.0f : 2.0f;
+            }
+        }
         const DevTri &T = h.flat[o];
         float *r = &h.tri[(size_t)k * 12];
         for (int c = 0; c < 3; ++c) { r[c] = T.p0[c]; r[4 + c] = T.p1[c]; r[8 + c] = T.p2[c]; }
@@ -1305,6 +1442,68 @@ static int build_mesh3(const wost3_mesh_desc &d, HostMesh3 *out)
                 nd[12 + 4 * c + j] = empty[c4] ? 1.0e18f : nb[6 * (size_t)c4 + 3 + c] + pad;
             }
         }
+    // normal cones of the children of every inner node (cone3_may_hold_silhouette): the normals of both triangles of
+    // every edge of the subtree's triangles, the end points of those edges; a boundary edge is always a silhouette
+    {
+        struct Acc { std::vector<double> nrm, pts; bool open = false; };
+        std::vector<Acc> acc(n_nodes);
+        for (int k = 0; k < n; ++k) {
+            Acc &a = acc[h.first_leaf + k / 4];
+            const int o = order[k];
+            for (int c = 0; c < 3; ++c) {
+                const int32_t e = edge_of[3 * (size_t)o + c];
+                if (e < 0) continue;
+                const DevEdge3 &E = h.edges[e];
+                if (E.t1 < 0) a.open = true;
+                for (int t : {E.t0, E.t1}) {
+                    if (t < 0) continue;
+                    const DevTri &T = h.flat[t];
+                    if (hdot3(T.n, T.n) > 0.0f) a.nrm.insert(a.nrm.end(), {T.n[0], T.n[1], T.n[2]});
+                }
+                a.pts.insert(a.pts.end(), {E.pa[0], E.pa[1], E.pa[2], E.pb[0], E.pb[1], E.pb[2]});
+            }
+        }
+        for (int g = h.first_leaf - 1; g >= 1; --g)
+            for (int j = 1; j <= 4; ++j) {
+                const Acc &c = acc[4 * g + j];
+                acc[g].nrm.insert(acc[g].nrm.end(), c.nrm.begin(), c.nrm.end());
+                acc[g].pts.insert(acc[g].pts.end(), c.pts.begin(), c.pts.end());
+                acc[g].open = acc[g].open || c.open;
+            }
+        h.cones.assign((size_t)n_nodes * 24, 0.0f);
+        for (int g = 0; g < h.first_leaf; ++g)
+            for (int j = 0; j < 4; ++j) {
+                const Acc &a = acc[4 * g + 1 + j];
+                const float *nd = &h.nodes[(size_t)g * 24];
+                float *cn = &h.cones[(size_t)g * 24];
+                cn[12 + j] = -1.0f;                                             // cannot prune
+                cn[0 + j] = 1.0f;
+                if (a.open || a.nrm.empty()) continue;
+                double ax[3] = {0.0, 0.0, 0.0};
+                for (size_t i = 0; i < a.nrm.size(); i += 3)
+                    for (int c = 0; c < 3; ++c) ax[c] += a.nrm[i + c];
+                const double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+                if (!(al > 1e-9 * (double)(a.nrm.size() / 3))) continue;
+                for (int c = 0; c < 3; ++c) ax[c] /= al;
+                double cmin = 1.0;
+                for (size_t i = 0; i < a.nrm.size(); i += 3) {
+                    const double l = std::sqrt(a.nrm[i] * a.nrm[i] + a.nrm[i + 1] * a.nrm[i + 1] + a.nrm[i + 2] * a.nrm[i + 2]);
+                    cmin = std::min(cmin, (ax[0] * a.nrm[i] + ax[1] * a.nrm[i + 1] + ax[2] * a.nrm[i + 2]) / l);
+                }
+                const double half = std::acos(std::max(-1.0, std::min(1.0, cmin))) + 1e-4;
+                if (half >= 0.5 * M_PI - 1e-3) continue;
+                // the centre the kernel uses: the middle of the child's box, in the kernel's float arithmetic
+                float cf[3];
+                for (int c = 0; c < 3; ++c) cf[c] = 0.5f * (nd[4 * c + j] + nd[12 + 4 * c + j]);
+                double rad = 0.0;
+                for (size_t i = 0; i < a.pts.size(); i += 3)
+                    rad = std::max(rad, std::sqrt((a.pts[i] - cf[0]) * (a.pts[i] - cf[0]) + (a.pts[i + 1] - cf[1]) * (a.pts[i + 1] - cf[1]) +
+                                                  (a.pts[i + 2] - cf[2]) * (a.pts[i + 2] - cf[2])));
+                cn[0 + j] = (float)ax[0]; cn[4 + j] = (float)ax[1]; cn[8 + j] = (float)ax[2];
+                cn[12 + j] = (float)std::cos(half); cn[16 + j] = (float)std::sin(half);
+                cn[20 + j] = (float)(rad * (1.0 + 1e-6) + (double)pad + 2.0 * (double)WOST_SIL_PRECISION);
+            }
+    }
     return 0;
 }
 
@@ -1373,6 +1572,8 @@ static int upload_mesh3(const wost3_mesh_desc &d, DeviceMesh3 &s)
     W3_TRY(upload3(s.allocs, h.edges.data(), h.edges.size(), &v.edges));
     W3_TRY(upload3(s.allocs, h.flatVerts.data(), h.flatVerts.size(), &v.flatVerts));
     W3_TRY(upload3(s.allocs, h.triEdges.data(), h.triEdges.size(), &v.triEdges));
+    W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.cones.data()), h.cones.size() / 4, &v.cones));
+    W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.slotEdges.data()), h.slotEdges.size() / 4, &v.slotEdges));
     W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.obox.data()), h.obox.size() / 4, &v.obox));
     for (int l = 0; l < 12; ++l) v.obox_off[l] = h.obox_off[l];
     v.obox_levels = h.obox_levels;
@@ -1409,6 +1610,9 @@ static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, 
     P.cursor = c->cursor;
     P.tiled = (pixel_begin == 0 && pixel_end == (int32_t)c->n_pixels && ((c->settings.width | c->settings.height) & 7) == 0) ? 1 : 0;
     P.wait_weight = c->wait_weight; P.trav_burst = c->trav_burst;
+    // a step that answers its Neumann queries on the tree is long and divergent: it waits until four fifths of the
+    // wave's walkers stand at it (tools/scratch/bench3d_shell.py: 1.8x over the Dirichlet-only setting on a 1280-triangle shell)
+    if (c->nm.view.n_tris > WOST3_FLAT_MAX) P.wait_weight = 2;
     if (const char *w = std::getenv("WOST3_WAIT_WEIGHT")) P.wait_weight = std::max(1, std::atoi(w));
     if (const char *w = std::getenv("WOST3_TRAV_BURST")) P.trav_burst = std::max(1, std::atoi(w));
     W3_TRY(hipMemsetAsync(c->cursor, 0, sizeof(uint32_t), stream));
@@ -1438,6 +1642,16 @@ static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, 
     W3_TRY(hipMemcpyAsync(copies.data(), c->stats, kStat3Copies * sizeof(Stats3Dev), hipMemcpyDeviceToHost, stream));
     W3_TRY(hipStreamSynchronize(stream));
     if (n > 0) W3_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+#ifdef WOST3_PROFILE
+    {
+        unsigned long long prof[16], zero[16] = {0};
+        W3_TRY(hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_prof3), sizeof(prof)));
+        W3_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prof3), zero, sizeof(zero)));
+        std::fprintf(stderr, "[wost3 profile] wave cycles: silhouette %llu source %llu neumann-sample %llu walk-ray %llu | step trips %llu (cycles %llu, lanes %llu) trav trips %llu (cycles %llu, lanes %llu) | kernel total %llu, %.1f ms\n",
+                     prof[0], prof[1], prof[2], prof[3], prof[8], prof[4], prof[9], prof[10], prof[5], prof[11], prof[6], ms);
+        std::fprintf(stderr, "[wost3 profile] silhouette queries %llu: inner visits %llu, leaf visits %llu\n", prof[14], prof[12], prof[13]);
+    }
+#endif
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         for (const Stats3Dev &k : copies) {

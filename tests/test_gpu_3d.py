@@ -149,6 +149,42 @@ def test_3d_neumann_tree_queries_match_oracle(oracle, subdiv):
     it.close()
 
 
+@pytest.mark.parametrize("case", ["bumpy", "bumpy_with_holes", "flat_patches"])
+def test_3d_silhouette_tree_prunes_by_normal_cones_exactly(oracle, case):
+    """the tree skips subtrees whose normal cone proves that no edge below can be a silhouette from the query point;
+    reflex and convex folds seen from inside and outside, boundary edges (always silhouettes), coplanar neighbours,
+    query points on the surface and on edges: the distances of the oracle's loop over all edges, bit for bit"""
+    if case == "flat_patches":
+        sd = cube_scene3(n=8, d_faces=(0,), n_faces=(1, 2, 3, 4, 5), value=lambda x, y, z: x, flux=lambda x, y, z, f: 0.0)
+        V, T = sd["n_verts"], sd["n_tris"]
+    else:
+        sd = _shell_scene(1, 3)
+        V = sd["n_verts"].astype(np.float64)
+        V *= (1.0 + 0.22 * np.sin(5.0 * V[:, :1]) * np.sin(4.0 * V[:, 1:2] + 0.3) * np.cos(3.0 * V[:, 2:3]))
+        V = V.astype(np.float32)
+        T = sd["n_tris"]
+        if case == "bumpy_with_holes":
+            keep = np.ones(len(T), bool)
+            keep[np.random.default_rng(5).choice(len(T), 40, replace=False)] = False
+            T = np.ascontiguousarray(T[keep])
+        sd["n_verts"], sd["n_tris"] = V, T
+    it = _it(sd, 8, 8, 1, 4, 1e-3)
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-1.5, 1.5, size=(8000, 3)).astype(np.float32)
+    pts[:1000] = V[rng.integers(0, len(V), 1000)] * rng.uniform(0.97, 1.03, (1000, 1)).astype(np.float32)
+    pts[1000:1300] = V[rng.integers(0, len(V), 300)]                                                     # on vertices
+    tri = T[rng.integers(0, len(T), 300)]
+    pts[1300:1600] = (0.5 * (V[tri[:, 0]].astype(np.float64) + V[tri[:, 1]])).astype(np.float32)       # on edges
+    pts[1600:1900] = (V[tri].astype(np.float64).mean(axis=1)).astype(np.float32)                         # on faces
+    pts[1900:2200] *= np.float32(40.0)                                                                   # far away
+    got, ref = it.closest_silhouette(pts), oracle.closest_silhouette3(V, T, pts)
+    assert np.array_equal(got, ref) and np.isfinite(ref).any()
+    rmax = rng.uniform(0.02, 0.8, len(pts)).astype(np.float32)
+    got, ref = it.closest_silhouette(pts, rmax), oracle.closest_silhouette3(V, T, pts, rmax)
+    assert np.array_equal(got, ref) and np.isinf(ref).any() and np.isfinite(ref).any()
+    it.close()
+
+
 @pytest.mark.parametrize("case", ["zero_flux_shell", "emissive_shell", "cube_walls"])
 def test_3d_neumann_mesh_of_hundreds_of_triangles(oracle, case):
     """whole solves with the Neumann side on the tree: bit-exact against the oracle"""
