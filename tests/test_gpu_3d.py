@@ -149,7 +149,7 @@ def test_3d_neumann_tree_queries_match_oracle(oracle, subdiv):
     it.close()
 
 
-@pytest.mark.parametrize("case", ["bumpy", "bumpy_with_holes", "flat_patches"])
+@pytest.mark.parametrize("case", ["bumpy", "bumpy_with_holes", "flat_patches", "tiny", "huge", "degenerate_and_doubled"])
 def test_3d_silhouette_tree_prunes_by_normal_cones_exactly(oracle, case):
     """the tree skips subtrees whose normal cone proves that no edge below can be a silhouette from the query point;
     reflex and convex folds seen from inside and outside, boundary edges (always silhouettes), coplanar neighbours,
@@ -167,10 +167,19 @@ def test_3d_silhouette_tree_prunes_by_normal_cones_exactly(oracle, case):
             keep = np.ones(len(T), bool)
             keep[np.random.default_rng(5).choice(len(T), 40, replace=False)] = False
             T = np.ascontiguousarray(T[keep])
+        if case == "degenerate_and_doubled":
+            # zero-area triangles (no normal), triangles listed twice (edges with four incident triangles: the first two count)
+            T = np.concatenate([T, T[:60], np.stack([T[100:160, 0], T[100:160, 0], T[100:160, 1]], axis=1)]).astype(T.dtype)
         sd["n_verts"], sd["n_tris"] = V, T
+    # the silhouette test carries ABSOLUTE thresholds (1e-3): a scene of that size is all "near" cases, a huge one none
+    scale = np.float32({"tiny": 2e-3, "huge": 3e3}.get(case, 1.0))
+    if scale != 1.0:
+        V = (V * scale).astype(np.float32)
+        sd["n_verts"] = V
+        sd["d_verts"] = (sd["d_verts"] * scale).astype(np.float32)
     it = _it(sd, 8, 8, 1, 4, 1e-3)
     rng = np.random.default_rng(11)
-    pts = rng.uniform(-1.5, 1.5, size=(8000, 3)).astype(np.float32)
+    pts = (rng.uniform(-1.5, 1.5, size=(8000, 3)) * scale).astype(np.float32)
     pts[:1000] = V[rng.integers(0, len(V), 1000)] * rng.uniform(0.97, 1.03, (1000, 1)).astype(np.float32)
     pts[1000:1300] = V[rng.integers(0, len(V), 300)]                                                     # on vertices
     tri = T[rng.integers(0, len(T), 300)]
@@ -179,7 +188,7 @@ def test_3d_silhouette_tree_prunes_by_normal_cones_exactly(oracle, case):
     pts[1900:2200] *= np.float32(40.0)                                                                   # far away
     got, ref = it.closest_silhouette(pts), oracle.closest_silhouette3(V, T, pts)
     assert np.array_equal(got, ref) and np.isfinite(ref).any()
-    rmax = rng.uniform(0.02, 0.8, len(pts)).astype(np.float32)
+    rmax = (rng.uniform(0.02, 0.8, len(pts)) * scale).astype(np.float32)
     got, ref = it.closest_silhouette(pts, rmax), oracle.closest_silhouette3(V, T, pts, rmax)
     assert np.array_equal(got, ref) and np.isinf(ref).any() and np.isfinite(ref).any()
     it.close()
