@@ -677,6 +677,7 @@ struct wost_context {
     int thin_waves = 1;        // spread the walkers of an under-full launch over more waves
     int block_size = 256;
     int wait_weight = 8;
+    bool wait_weight_set = false;   // by wost_set_option: otherwise steps with tree queries on the Neumann side use weight 1
     int trav_burst = 3;
     int time_kernels = 1;
     int refill = -1;       // -1 = automatic (few samples per pixel), 0 = never, 1 = always
@@ -831,6 +832,7 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "wait_weight") {
         if (value < 1 || value > 512) return fail(WOST_ERR_INVALID, "wait_weight must be in 1..512");
         h->wait_weight = (int)value;
+        h->wait_weight_set = true;
     } else if (k == "trav_burst") {
         if (value < 1 || value > 16) return fail(WOST_ERR_INVALID, "trav_burst must be in 1..16");
         h->trav_burst = (int)value;
@@ -921,7 +923,9 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         // 0.95 -> 1.39 ms with 8-step rounds)
         rp.steps_per_round = c->steps_per_round > 0 ? c->steps_per_round : 256;
         rp.stack_stride = bs;
-        rp.wait_weight = c->wait_weight;
+        // a step that answers its Neumann queries on the tree is long and divergent: served when eight ninths of the
+        // busy lanes wait (tools/scratch/bench2d_wiggly.py: 3.87 -> 4.40 x 10^8 walk-steps/s on 3000 segments)
+        rp.wait_weight = (ntree && !c->wait_weight_set) ? 1 : c->wait_weight;
         rp.trav_burst = c->trav_burst;
         const size_t lds_round = lds;
         // When the walkers left fill less than 1/16 of the resident threads, spread them out: the
