@@ -52,6 +52,11 @@ struct DevMesh {
     const float4 *obox;
     int32_t obox_off[12];
     int32_t obox_levels;
+    // compact copies for those sweeps, original order, padded to a multiple of four segments (length 0): a run of four is
+    // fetched with six loads issued together instead of four dependent 64-byte records
+    const float *lens;       // lengths
+    const float4 *sampBox;   // cx cy ux uy of seg_d2
+    const float *sampHl;     // hl of seg_d2
 };
 
 struct DevProbe {
@@ -479,57 +484,98 @@ __device__ __forceinline__ float obox_d2(float4 b, float qx, float qy)
     return __builtin_fmaf(dx, dx, dy * dy);
 }
 
-// calls f(i) for every segment i whose run boxes all touch the ball, in ascending order; f returns false to stop
-template <class F>
-__device__ __forceinline__ void sweep_in_sphere(const DevMesh &m, float qx, float qy, float R2, F f)
+// largest squared distance from q to a point of the box
+__device__ __forceinline__ float obox_far_d2(float4 b, float qx, float qy)
+{
+    const float dx = fmaxf(fabsf(qx - b.x), fabsf(qx - b.z)), dy = fmaxf(fabsf(qy - b.y), fabsf(qy - b.w));
+    return __builtin_fmaf(dx, dx, dy * dy);
+}
+
+// Calls, in ascending order of i (a multiple of four), f(i) for every group of four segments whose run boxes all touch
+// the ball and g(i) for the groups of runs that lie INSIDE it (every point of the padded box closer than R by a
+// relative margin, so the flat loop's test d2 <= R2 holds for each of them without being evaluated); both return
+// false to stop.
+template <class F, class G>
+__device__ __forceinline__ void sweep_in_sphere(const DevMesh &m, float qx, float qy, float R2, F f, G g)
 {
     // the boxes are padded by a fraction of the mesh extent, but a walker can be far outside the mesh (open boundaries:
     // |q| and R of 10^7 mesh units occur), where the rounding of both distances grows with |q|: the skip test is slack
     // by a relative 10^-4 on top (a run that is tested needlessly costs four exact tests; one that is skipped wrongly
     // changes the result)
-    const float R2s = R2 * 1.0001f;
+    const float R2s = R2 * 1.0001f, R2i = R2 * 0.9999f;
     int i = 0;
     while (i < m.n_segs) {
-        // the longest aligned runs starting at i, coarsest first
-        int skip = 0;
-        for (int l = m.obox_levels - 1; l >= 0 && skip == 0; --l) {
+        // the longest aligned run starting at i that is decided as a whole, coarsest first
+        int skip = 0, inside = 0;
+        for (int l = m.obox_levels - 1; l >= 0 && (skip | inside) == 0; --l) {
             const int run = 4 << (2 * l);
-            if ((i & (run - 1)) == 0 && obox_d2(m.obox[m.obox_off[l] + i / run], qx, qy) > R2s) skip = run;
+            if ((i & (run - 1)) == 0) {
+                const float4 b = m.obox[m.obox_off[l] + i / run];
+                if (obox_d2(b, qx, qy) > R2s) skip = run;
+                else if (obox_far_d2(b, qx, qy) <= R2i) inside = run;
+            }
         }
         if (skip) {
             i += skip;
             continue;
         }
-        const int end = min(i + 4, m.n_segs);
-        for (; i < end; ++i)
-            if (!f(i)) return;
+        if (inside) {
+            const int end = min(i + inside, m.n_segs);
+            for (; i < end; i += 4)
+                if (!g(i)) return;
+            continue;
+        }
+        if (!f(i)) return;
+        i += 4;
     }
+}
+
+// the four segments from i on, in order: take(index, length) for those the flat loop accepts (padding has length 0)
+template <bool TEST, class T>
+__device__ __forceinline__ bool sample_group(const DevMesh &m, int i, float qx, float qy, float R2, T take)
+{
+    const float4 l = *reinterpret_cast<const float4 *>(m.lens + i);
+    if (TEST) {
+        const float4 b0 = m.sampBox[i], b1 = m.sampBox[i + 1], b2 = m.sampBox[i + 2], b3 = m.sampBox[i + 3];
+        const float4 h = *reinterpret_cast<const float4 *>(m.sampHl + i);
+        if (obb_d2(b0.x, b0.y, b0.z, b0.w, h.x, 0.0f, qx, qy) <= R2 && l.x > 0.0f && !take(i, l.x)) return false;
+        if (obb_d2(b1.x, b1.y, b1.z, b1.w, h.y, 0.0f, qx, qy) <= R2 && l.y > 0.0f && !take(i + 1, l.y)) return false;
+        if (obb_d2(b2.x, b2.y, b2.z, b2.w, h.z, 0.0f, qx, qy) <= R2 && l.z > 0.0f && !take(i + 2, l.z)) return false;
+        if (obb_d2(b3.x, b3.y, b3.z, b3.w, h.w, 0.0f, qx, qy) <= R2 && l.w > 0.0f && !take(i + 3, l.w)) return false;
+    } else {
+        if (l.x > 0.0f && !take(i, l.x)) return false;
+        if (l.y > 0.0f && !take(i + 1, l.y)) return false;
+        if (l.z > 0.0f && !take(i + 2, l.z)) return false;
+        if (l.w > 0.0f && !take(i + 3, l.w)) return false;
+    }
+    return true;
 }
 
 __device__ __forceinline__ int sample_in_sphere_tree(const DevMesh &m, float qx, float qy, float R, float u, float &pdf)
 {
     const float R2 = R * R;
     float total = 0.0f;
-    sweep_in_sphere(m, qx, qy, R2, [&](int i) {
-        const DevFlatSeg s = m.flat[i];
-        if (seg_d2(s, qx, qy) <= R2 && s.len > 0.0f) total += s.len;
+    auto add = [&](int, float len) {
+        total += len;
         return true;
-    });
+    };
+    sweep_in_sphere(
+        m, qx, qy, R2, [&](int i) { return sample_group<true>(m, i, qx, qy, R2, add); },
+        [&](int i) { return sample_group<false>(m, i, qx, qy, R2, add); });
     pdf = 0.0f;
     if (!(total > 0.0f)) return -1;
     const float target = u * total;
     float cum = 0.0f;
     int last = -1;
-    sweep_in_sphere(m, qx, qy, R2, [&](int i) {
-        const DevFlatSeg s = m.flat[i];
-        if (seg_d2(s, qx, qy) <= R2 && s.len > 0.0f) {
-            cum += s.len;
-            last = i;
-            if (target < cum) return false;
-        }
-        return true;
-    });
-    const float len = m.flat[last].len;
+    auto pick = [&](int i, float len) {
+        cum += len;
+        last = i;
+        return !(target < cum);
+    };
+    sweep_in_sphere(
+        m, qx, qy, R2, [&](int i) { return sample_group<true>(m, i, qx, qy, R2, pick); },
+        [&](int i) { return sample_group<false>(m, i, qx, qy, R2, pick); });
+    const float len = m.lens[last];
     pdf = (len / total) / len;
     return last;
 }
@@ -577,19 +623,24 @@ __device__ __forceinline__ bool cone_may_hold_silhouette(float ax, float ay, flo
     return fabsf(c) <= sin_sum + 1e-3f;
 }
 
+// Near-first like the closest-point descent (Trav, trav_pop: the keys carry the box distance, so entries that a
+// silhouette found meanwhile has overtaken are culled at the pop without a visit).  T.best.d2 is the pruning bound --
+// the best squared distance with a relative slack, because box and vertex distances come from different formulas
+// and a walker may stand far outside the scene -- the exact minimum is kept apart: the flat loop's answer.
 template <class STK>
 __device__ __forceinline__ float closest_silhouette_tree(const DevMesh &m, float qx, float qy, float rmax, const STK &stk)
 {
+    constexpr float kSlack = 1.0001f;
     float best2 = rmax * rmax;
     bool found = false;
-    int sp = 0;
-    uint32_t g = 0;      // heap index of the node whose children are examined
+    Trav T = trav_begin(Closest{best2 * kSlack, -1});
     for (;;) {
+        const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
         const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
         const float4 CX = nd[0], CY = nd[1], UX = nd[2], UY = nd[3], HL = nd[4], HW = nd[5];
-        const bool leaf_level = g >= (uint32_t)m.first_leaf;
-        if (leaf_level) {
-            const int slot0 = 4 * (int)(g - (uint32_t)m.first_leaf);
+        bool more;
+        if (T.level == m.levels) {
+            const int slot0 = 4 * T.pos;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int2 vv = m.segVerts[slot0 + j];
@@ -606,32 +657,38 @@ __device__ __forceinline__ float closest_silhouette_tree(const DevMesh &m, float
                     }
                 }
             }
+            T.best.d2 = best2 * kSlack;
+            more = trav_pop(T, stk);
         } else {
             const float4 *cn = m.cones + 5 * (size_t)g;
             const float4 AX = cn[0], AY = cn[1], CH = cn[2], SH = cn[3], RD = cn[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float cx = j == 0 ? CX.x : j == 1 ? CX.y : j == 2 ? CX.z : CX.w;
-                const float cy = j == 0 ? CY.x : j == 1 ? CY.y : j == 2 ? CY.z : CY.w;
-                const float ux = j == 0 ? UX.x : j == 1 ? UX.y : j == 2 ? UX.z : UX.w;
-                const float uy = j == 0 ? UY.x : j == 1 ? UY.y : j == 2 ? UY.z : UY.w;
-                const float hl = j == 0 ? HL.x : j == 1 ? HL.y : j == 2 ? HL.z : HL.w;
-                const float hw = j == 0 ? HW.x : j == 1 ? HW.y : j == 2 ? HW.z : HW.w;
-                const float d = obb_d2(cx, cy, ux, uy, hl, hw, qx, qy);
-                if (!(d <= best2)) continue;
-                const float ax = j == 0 ? AX.x : j == 1 ? AX.y : j == 2 ? AX.z : AX.w;
-                const float ay = j == 0 ? AY.x : j == 1 ? AY.y : j == 2 ? AY.z : AY.w;
-                const float ch = j == 0 ? CH.x : j == 1 ? CH.y : j == 2 ? CH.z : CH.w;
-                const float sh = j == 0 ? SH.x : j == 1 ? SH.y : j == 2 ? SH.z : SH.w;
-                const float rd = j == 0 ? RD.x : j == 1 ? RD.y : j == 2 ? RD.z : RD.w;
-                if (!cone_may_hold_silhouette(ax, ay, ch, sh, rd, cx, cy, qx, qy)) continue;
-                stk.put(sp, 4u * g + 1u + (uint32_t)j);
-                ++sp;
+            const float bd = T.best.d2;
+            const float d0 = obb_d2(CX.x, CY.x, UX.x, UY.x, HL.x, HW.x, qx, qy), d1 = obb_d2(CX.y, CY.y, UX.y, UY.y, HL.y, HW.y, qx, qy);
+            const float d2 = obb_d2(CX.z, CY.z, UX.z, UY.z, HL.z, HW.z, qx, qy), d3 = obb_d2(CX.w, CY.w, UX.w, UY.w, HL.w, HW.w, qx, qy);
+            const bool c0 = d0 <= bd && cone_may_hold_silhouette(AX.x, AY.x, CH.x, SH.x, RD.x, CX.x, CY.x, qx, qy);
+            const bool c1 = d1 <= bd && cone_may_hold_silhouette(AX.y, AY.y, CH.y, SH.y, RD.y, CX.y, CY.y, qx, qy);
+            const bool c2 = d2 <= bd && cone_may_hold_silhouette(AX.z, AY.z, CH.z, SH.z, RD.z, CX.z, CY.z, qx, qy);
+            const bool c3 = d3 <= bd && cone_may_hold_silhouette(AX.w, AY.w, CH.w, SH.w, RD.w, CX.w, CY.w, qx, qy);
+            const uint32_t tag = (uint32_t)(T.level + 1) << 2;
+            uint32_t k0 = c0 ? ((__float_as_uint(d0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;
+            uint32_t k1 = c1 ? ((__float_as_uint(d1) & ~0x3Fu) | tag | 1u) : 0xffffffffu;
+            uint32_t k2 = c2 ? ((__float_as_uint(d2) & ~0x3Fu) | tag | 2u) : 0xffffffffu;
+            uint32_t k3 = c3 ? ((__float_as_uint(d3) & ~0x3Fu) | tag | 3u) : 0xffffffffu;
+            cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
+            int sp = T.sp;
+            stk.put(sp, k3); sp += (k3 != 0xffffffffu) ? 1 : 0;
+            stk.put(sp, k2); sp += (k2 != 0xffffffffu) ? 1 : 0;
+            stk.put(sp, k1); sp += (k1 != 0xffffffffu) ? 1 : 0;
+            T.sp = sp;
+            if (k0 != 0xffffffffu) {
+                T.pos = 4 * T.pos + (int)(k0 & 3u);
+                T.level = T.level + 1;
+                more = true;
+            } else {
+                more = trav_pop(T, stk);
             }
         }
-        if (sp == 0) break;
-        --sp;
-        g = stk.get(sp);
+        if (!more) break;
     }
     return found ? sqrtf(best2) : WOST_INF;
 }
@@ -662,7 +719,11 @@ __device__ __forceinline__ float ray_obb_entry(float cx, float cy, float ux, flo
     return (t0 <= t1 + tol) ? fmaxf(t0 - tol, 0.0f) : WOST_INF;
 }
 
-// closest hit (ANY_HIT = false) or any hit (true); ties in t go to the lowest ORIGINAL index
+// closest hit (ANY_HIT = false) or any hit (true); ties in t go to the lowest ORIGINAL index.
+// Near-first like the closest-point descent: the key of a child is where the ray enters its box (a lower bound, see
+// ray_obb_entry), T.best.d2 carries the limit -- tmax, then the best hit -- so entries beyond a hit found meanwhile
+// are culled at the pop.  A leaf measures its four segments as boxes of no width first and runs the exact test
+// (the flat loop's seg_ray on the flat record) only for those the ray can reach within the limit.
 template <bool ANY_HIT, class STK>
 __device__ __forceinline__ bool ray_tree(const DevMesh &m, float ox, float oy, float dx, float dy, float tmax, float &t_out,
                                          int &idx_out, const STK &stk)
@@ -670,13 +731,23 @@ __device__ __forceinline__ bool ray_tree(const DevMesh &m, float ox, float oy, f
     bool hit = false;
     float bt = WOST_INF;
     int bi = -1;
-    int sp = 0;
-    uint32_t g = 0;
+    Trav T = trav_begin(Closest{tmax, -1});
     for (;;) {
-        if (g >= (uint32_t)m.first_leaf) {
-            const int slot0 = 4 * (int)(g - (uint32_t)m.first_leaf);
-#pragma unroll
+        const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
+        const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+        const float4 CX = nd[0], CY = nd[1], UX = nd[2], UY = nd[3], HL = nd[4], HW = nd[5];
+        const float lim = T.best.d2;
+        const float e0 = CX.x >= 1.0e17f ? WOST_INF : ray_obb_entry(CX.x, CY.x, UX.x, UY.x, HL.x, HW.x, ox, oy, dx, dy, lim);
+        const float e1 = CX.y >= 1.0e17f ? WOST_INF : ray_obb_entry(CX.y, CY.y, UX.y, UY.y, HL.y, HW.y, ox, oy, dx, dy, lim);
+        const float e2 = CX.z >= 1.0e17f ? WOST_INF : ray_obb_entry(CX.z, CY.z, UX.z, UY.z, HL.z, HW.z, ox, oy, dx, dy, lim);
+        const float e3 = CX.w >= 1.0e17f ? WOST_INF : ray_obb_entry(CX.w, CY.w, UX.w, UY.w, HL.w, HW.w, ox, oy, dx, dy, lim);
+        bool more;
+        if (T.level == m.levels) {
+            const int slot0 = 4 * T.pos;
+#pragma unroll 1
             for (int j = 0; j < 4; ++j) {
+                const float ej = j == 0 ? e0 : j == 1 ? e1 : j == 2 ? e2 : e3;
+                if (!(ej <= T.best.d2)) continue;
                 const int o = m.segOrig[slot0 + j];
                 if (o == WOST_FAR_INDEX) continue;
                 const DevFlatSeg s = m.flat[o];
@@ -686,32 +757,33 @@ __device__ __forceinline__ bool ray_tree(const DevMesh &m, float ox, float oy, f
                         bt = t;
                         bi = o;
                         hit = true;
+                        T.best.d2 = fminf(bt, tmax);
                     }
                 }
             }
             if (ANY_HIT && hit) break;
+            more = trav_pop(T, stk);
         } else {
-            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
-            const float4 CX = nd[0], CY = nd[1], UX = nd[2], UY = nd[3], HL = nd[4], HW = nd[5];
-            const float lim = hit ? fminf(bt, tmax) : tmax;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float cx = j == 0 ? CX.x : j == 1 ? CX.y : j == 2 ? CX.z : CX.w;
-                const float cy = j == 0 ? CY.x : j == 1 ? CY.y : j == 2 ? CY.z : CY.w;
-                const float ux = j == 0 ? UX.x : j == 1 ? UX.y : j == 2 ? UX.z : UX.w;
-                const float uy = j == 0 ? UY.x : j == 1 ? UY.y : j == 2 ? UY.z : UY.w;
-                const float hl = j == 0 ? HL.x : j == 1 ? HL.y : j == 2 ? HL.z : HL.w;
-                const float hw = j == 0 ? HW.x : j == 1 ? HW.y : j == 2 ? HW.z : HW.w;
-                if (cx >= 1.0e17f) continue;  // empty child
-                const float te = ray_obb_entry(cx, cy, ux, uy, hl, hw, ox, oy, dx, dy, lim);
-                if (!(te <= lim)) continue;
-                stk.put(sp, 4u * g + 1u + (uint32_t)j);
-                ++sp;
+            const uint32_t tag = (uint32_t)(T.level + 1) << 2;
+            uint32_t k0 = (e0 <= lim) ? ((__float_as_uint(e0) & ~0x3Fu) | tag | 0u) : 0xffffffffu;
+            uint32_t k1 = (e1 <= lim) ? ((__float_as_uint(e1) & ~0x3Fu) | tag | 1u) : 0xffffffffu;
+            uint32_t k2 = (e2 <= lim) ? ((__float_as_uint(e2) & ~0x3Fu) | tag | 2u) : 0xffffffffu;
+            uint32_t k3 = (e3 <= lim) ? ((__float_as_uint(e3) & ~0x3Fu) | tag | 3u) : 0xffffffffu;
+            cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
+            int sp = T.sp;
+            stk.put(sp, k3); sp += (k3 != 0xffffffffu) ? 1 : 0;
+            stk.put(sp, k2); sp += (k2 != 0xffffffffu) ? 1 : 0;
+            stk.put(sp, k1); sp += (k1 != 0xffffffffu) ? 1 : 0;
+            T.sp = sp;
+            if (k0 != 0xffffffffu) {
+                T.pos = 4 * T.pos + (int)(k0 & 3u);
+                T.level = T.level + 1;
+                more = true;
+            } else {
+                more = trav_pop(T, stk);
             }
         }
-        if (sp == 0) break;
-        --sp;
-        g = stk.get(sp);
+        if (!more) break;
     }
     t_out = bt;
     idx_out = bi;

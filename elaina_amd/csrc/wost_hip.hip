@@ -643,6 +643,16 @@ static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
         }
         v.obox_levels = levels;
         HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(ob.data()), ob.size() / 4, &v.obox));
+        const size_t n4 = (t.flat.size() + 3) / 4 * 4;
+        std::vector<float> lens(n4, 0.0f), hl(n4, 0.0f), box(n4 * 4, 1.0e18f);
+        for (size_t i = 0; i < t.flat.size(); ++i) {
+            const FlatSeg &f = t.flat[i];
+            lens[i] = f.len; hl[i] = f.hl;
+            box[4 * i] = f.cx; box[4 * i + 1] = f.cy; box[4 * i + 2] = f.ux; box[4 * i + 3] = f.uy;
+        }
+        HIP_TRY(upload(s.allocs, lens.data(), lens.size(), &v.lens));
+        HIP_TRY(upload(s.allocs, hl.data(), hl.size(), &v.sampHl));
+        HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(box.data()), n4, &v.sampBox));
     }
     return WOST_OK;
 }

@@ -87,6 +87,9 @@ struct DevMesh3 {
     const float4 *obox;
     int32_t obox_off[12];
     int32_t obox_levels;
+    // compact copies for those sweeps, original order, padded to a multiple of four triangles (area 0)
+    const float *areas;      // the areas alone: the sums over runs that lie inside the ball
+    const float4 *sampTri;   // [n * 3] p0 p1 p2 (w unused): a run of four is fetched with loads issued together
 };
 
 struct DevProbe3 {
@@ -633,54 +636,91 @@ __device__ __forceinline__ bool ray_any3(const DevMesh3 &m, V3 o, V3 d, float tm
 // over the triangles in ORIGINAL index order, so runs of consecutive indices carry boxes and an index-ordered sweep
 // skips every aligned run whose box lies beyond the ball, coarsest first (wost_device.h has the 2-D twin).  The
 // triangles that are tested, their order and the float sums are those of the flat loop.
-template <class F>
-__device__ __forceinline__ void sweep_in_sphere3(const DevMesh3 &m, V3 q, float R2, F f)
+// f(i): the group of four triangles from i on, of a run that touches the ball; g(i): of a run inside it (wost_device.h)
+template <class F, class G>
+__device__ __forceinline__ void sweep_in_sphere3(const DevMesh3 &m, V3 q, float R2, F f, G g)
 {
-    const float R2s = R2 * kSlack3;
+    const float R2s = R2 * kSlack3, R2i = R2 * 0.9999f;
     int i = 0;
     while (i < m.n_tris) {
-        int skip = 0;
-        for (int l = m.obox_levels - 1; l >= 0 && skip == 0; --l) {
+        int skip = 0, inside = 0;
+        for (int l = m.obox_levels - 1; l >= 0 && (skip | inside) == 0; --l) {
             const int run = 4 << (2 * l);
             if ((i & (run - 1)) == 0) {
                 const float4 lo = m.obox[2 * (m.obox_off[l] + i / run)], hi = m.obox[2 * (m.obox_off[l] + i / run) + 1];
-                if (aabb_d2(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, q) > R2s) skip = run;
+                if (aabb_d2(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, q) > R2s) {
+                    skip = run;
+                } else {
+                    const float fx = fmaxf(fabsf(q.x - lo.x), fabsf(q.x - hi.x)), fy = fmaxf(fabsf(q.y - lo.y), fabsf(q.y - hi.y));
+                    const float fz = fmaxf(fabsf(q.z - lo.z), fabsf(q.z - hi.z));
+                    if (__builtin_fmaf(fx, fx, __builtin_fmaf(fy, fy, fz * fz)) <= R2i) inside = run;
+                }
             }
         }
         if (skip) {
             i += skip;
             continue;
         }
-        const int end = min(i + 4, m.n_tris);
-        for (; i < end; ++i)
-            if (!f(i)) return;
+        if (inside) {
+            const int end = min(i + inside, m.n_tris);
+            for (; i < end; i += 4)
+                if (!g(i)) return;
+            continue;
+        }
+        if (!f(i)) return;
+        i += 4;
     }
+}
+
+// the four triangles from i on, in order: take(index, area) for those the flat loop accepts (padding has area 0)
+template <bool TEST, class T>
+__device__ __forceinline__ bool sample_group3(const DevMesh3 &m, int i, V3 q, float R2, T take)
+{
+    const float4 a = *reinterpret_cast<const float4 *>(m.areas + i);
+    if (TEST) {
+        float4 t[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) t[k] = m.sampTri[3 * (size_t)i + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float ak = k == 0 ? a.x : k == 1 ? a.y : k == 2 ? a.z : a.w;
+            if (ak > 0.0f && tri_d2(v3(t[3 * k].x, t[3 * k].y, t[3 * k].z), v3(t[3 * k + 1].x, t[3 * k + 1].y, t[3 * k + 1].z),
+                                    v3(t[3 * k + 2].x, t[3 * k + 2].y, t[3 * k + 2].z), q) <= R2 &&
+                !take(i + k, ak))
+                return false;
+        }
+    } else {
+        if (a.x > 0.0f && !take(i, a.x)) return false;
+        if (a.y > 0.0f && !take(i + 1, a.y)) return false;
+        if (a.z > 0.0f && !take(i + 2, a.z)) return false;
+        if (a.w > 0.0f && !take(i + 3, a.w)) return false;
+    }
+    return true;
 }
 
 __device__ __forceinline__ int sample_in_sphere3_tree(const DevMesh3 &m, V3 q, float R, float u, float &pdf)
 {
     const float R2 = R * R;
     float total = 0.0f;
-    sweep_in_sphere3(m, q, R2, [&](int i) {
-        const DevTri T = m.flat[i];
-        if (T.area > 0.0f && tri_d2(ld3(T.p0), ld3(T.p1), ld3(T.p2), q) <= R2) total += T.area;
+    auto add = [&](int, float area) {
+        total += area;
         return true;
-    });
+    };
+    sweep_in_sphere3(
+        m, q, R2, [&](int i) { return sample_group3<true>(m, i, q, R2, add); }, [&](int i) { return sample_group3<false>(m, i, q, R2, add); });
     pdf = 0.0f;
     if (!(total > 0.0f)) return -1;
     const float target = u * total;
     float cum = 0.0f;
     int last = -1;
-    sweep_in_sphere3(m, q, R2, [&](int i) {
-        const DevTri T = m.flat[i];
-        if (T.area > 0.0f && tri_d2(ld3(T.p0), ld3(T.p1), ld3(T.p2), q) <= R2) {
-            cum += T.area;
-            last = i;
-            if (target < cum) return false;
-        }
-        return true;
-    });
-    const float a = m.flat[last].area;
+    auto pick = [&](int i, float area) {
+        cum += area;
+        last = i;
+        return !(target < cum);
+    };
+    sweep_in_sphere3(
+        m, q, R2, [&](int i) { return sample_group3<true>(m, i, q, R2, pick); }, [&](int i) { return sample_group3<false>(m, i, q, R2, pick); });
+    const float a = m.areas[last];
     pdf = (a / total) / a;
     return last;
 }
@@ -1575,6 +1615,17 @@ static int upload_mesh3(const wost3_mesh_desc &d, DeviceMesh3 &s)
     W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.cones.data()), h.cones.size() / 4, &v.cones));
     W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.slotEdges.data()), h.slotEdges.size() / 4, &v.slotEdges));
     W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.obox.data()), h.obox.size() / 4, &v.obox));
+    if (!h.obox.empty()) {
+        const size_t n4 = (h.flat.size() + 3) / 4 * 4;
+        std::vector<float> areas(n4, 0.0f), tri(n4 * 12, 1.0e18f);
+        for (size_t i = 0; i < h.flat.size(); ++i) {
+            const DevTri &T = h.flat[i];
+            areas[i] = T.area;
+            for (int c = 0; c < 3; ++c) { tri[12 * i + c] = T.p0[c]; tri[12 * i + 4 + c] = T.p1[c]; tri[12 * i + 8 + c] = T.p2[c]; }
+        }
+        W3_TRY(upload3(s.allocs, areas.data(), areas.size(), &v.areas));
+        W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(tri.data()), n4 * 3, &v.sampTri));
+    }
     for (int l = 0; l < 12; ++l) v.obox_off[l] = h.obox_off[l];
     v.obox_levels = h.obox_levels;
     return WOST_OK;
