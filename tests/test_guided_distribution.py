@@ -35,6 +35,81 @@ def test_von_mises_dlog_dkappa_kat(oracle):
     assert r["dlog_dkappa"][1] == pytest.approx(-0.08729398250579834, rel=REL)
 
 
+def test_von_mises_kernel_kats_of_the_distribution_test(oracle):
+    """test/distribution_test.cu:49-56,112-128 (commented out there, written for an older kernel class, but the numbers
+    do not depend on its parametrisation): the von Mises density with kappa 1.45 and mean pi/4 at angle 0 -- also with
+    the mean given as pi/4 + 2 pi -- and its derivatives by kappa and by the mean, within that file's 1e-5"""
+    for mean in (math.pi / 4, math.pi / 4 + 2 * math.pi):
+        r = oracle.vonmises_eval([1.45], [math.cos(0.0 - mean)])
+        pdf = math.exp(r["log_pdf"][0])
+        assert pdf == pytest.approx(0.27751895785331726, abs=1e-5)
+        assert pdf * r["dlog_dkappa"][0] == pytest.approx(0.034295544028282166, abs=1e-5)
+        # d/d(mean) exp(kappa cos(theta - mean)) = kappa sin(theta - mean) pdf
+        assert pdf * 1.45 * math.sin(0.0 - mean) == pytest.approx(-0.284541517496109, abs=1e-5)
+
+
+def _mixture_kat_raw():
+    """the three-component mixture of test/distribution_test.cu:178-185 in today's parametrisation.  That (older) class
+    read (lambda, kappa, mean) per component as exp(x), exp(x), 2 pi sigmoid(x) -- the only reading of its nine numbers
+    that reproduces its own expected density, to 4e-9 -- and today's takes exp(x), exp(x) and a mean VECTOR; the
+    weights lambda / sum(lambda) do not change when all lambdas are scaled, so the three are raised by 13 and the five
+    components the old class did not have sit at the lower clamp: 1e-10 of the weight"""
+    d = np.array([-0.3391095697879791, 1.3653955459594727, -0.11165934801101685, 0.7329881191253662, 1.1205719709396362,
+                  -1.145609736442566, 1.5198860168457031, -0.962236225605011, 1.4103161096572876]).reshape(3, 3)
+    raw = np.zeros((1, 33), np.float32)
+    raw[0, 0:32:4] = -10.0
+    for i in range(3):
+        mean = 2.0 * math.pi / (1.0 + math.exp(-d[i, 2]))
+        raw[0, 4 * i:4 * i + 4] = [d[i, 0] + 13.0, d[i, 1], math.cos(mean), math.sin(mean)]
+    return raw
+
+
+def test_mixture_density_kat_of_the_distribution_test(oracle):
+    # test/distribution_test.cu:186-188: density of the mixture at angle 0 (the value gradients_probability returns)
+    pdf, _ = oracle.vmm_pdf_sample(_mixture_kat_raw(), np.array([[1.0, 0.0]], np.float32), np.array([1], np.uint64))
+    assert pdf[0] == pytest.approx(0.11850630, abs=1e-5)
+
+
+_MIXTURE_KAT_GRADIENTS = [-0.016046222299337387, -5.7009561714949086e-05, -2.110011519107502e-05,
+                          -0.011129779741168022, -0.007846416905522346, -0.031608663499355316,
+                          0.00756735447794199, 0.015586040914058685, 0.0389787033200264]
+
+
+def _mixture_kat_gradients(loss_gradients):
+    """d(density) / d(lambda, kappa, mean angle) of the three components at angle 0, recovered from the gradient of the
+    training loss: with one sample, Li = 1, dirPdf + eps = 1 and loss scale 1 the loss gradient of a raw output is
+    -1 / (density + eps) times the parameter gradient times the derivative of the activation
+    (integrator/guided/train.h:81-105,492-553); the mean angle moves the unit mean vector along its tangent"""
+    raw = _mixture_kat_raw()
+    g, _ = loss_gradients(raw, np.array([[1.0, 0.0]], np.float32), np.array([1.0], np.float32), np.array([1.0 - 1e-5], np.float32),
+                          np.array([0], np.uint8), np.zeros((1, 2), np.float32), loss_scale=1.0)
+    prefix = -1.0 / (0.11850630 + 1e-5)
+    out = []
+    for i in range(3):
+        lam, kap = math.exp(float(raw[0, 4 * i]) - 13.0), math.exp(float(raw[0, 4 * i + 1]))
+        mx, my = float(raw[0, 4 * i + 2]), float(raw[0, 4 * i + 3])
+        out += [g[0, 4 * i] / (prefix * lam), g[0, 4 * i + 1] / (prefix * kap), (g[0, 4 * i + 2] * -my + g[0, 4 * i + 3] * mx) / prefix]
+    return out
+
+
+def test_mixture_gradient_kat_of_the_distribution_test(oracle):
+    # test/distribution_test.cu:186-196: the nine expected gradients of the density, within that file's 1e-5
+    assert np.allclose(_mixture_kat_gradients(oracle.vmm_loss_gradients), _MIXTURE_KAT_GRADIENTS, rtol=0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_mixture_gradient_kat_of_the_distribution_test():
+    from elaina_amd import guided
+    assert np.allclose(_mixture_kat_gradients(guided.vmm_loss_gradients), _MIXTURE_KAT_GRADIENTS, rtol=0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_mixture_density_kat_of_the_distribution_test():
+    from elaina_amd import guided
+    pdf, _ = guided.vmm_pdf_sample(_mixture_kat_raw(), np.array([[1.0, 0.0]], np.float32), np.array([1], np.uint64))
+    assert pdf[0] == pytest.approx(0.11850630, abs=1e-5)
+
+
 @pytest.mark.parametrize("kappa,n,eps", [(1.45, 200000, 0.02), (145.0, 20000, 0.05), (1e-4, 50000, None)])
 def test_von_mises_sampling_moments(oracle, kappa, n, eps):
     # test/vonmises_test.cu:72-122: circular mean ~ 0 and circular variance 1 - I1/I0, seed 42
