@@ -832,10 +832,51 @@ struct Lane3 {
 #define PROF3(k) do {} while (0)
 #endif
 
-template <bool EMISSIVE, bool SOURCE, bool NTREE>
-__device__ __forceinline__ bool step3(const Walk3Params &P, Lane3 &L, Closest cp, const LdsColumn &stk)
+// One walk step in three parts, so that the kernel can answer the two tree queries between them -- the closest
+// silhouette edge after part A, the walker's ray after part B -- either inline (small Neumann meshes: flat loops) or as
+// states of the lane machine, one node visit per trip like the closest-point descent (walk3_kernel).
+// A: the Dirichlet side.  true = absorbed.
+__device__ __forceinline__ bool step3_a(const Walk3Params &P, Lane3 &L, Closest cp, float &R_D)
 {
-    const bool has_d = P.dm.n_tris > 0, has_n = P.nm.n_tris > 0;
+    const bool has_d = P.dm.n_tris > 0;
+    const float eps = P.st.eps;
+    V3 &p = L.p;
+    float &thp = L.thp;
+    float (&sol)[3] = L.sol;
+    int32_t &hint = L.hint;
+    R_D = WOST_INF;
+    if (has_d) {
+        hint = cp.slot;
+        if (L.depth == 0) L.hint0 = cp.slot;
+        const float4 a = P.dm.tri[3 * (size_t)cp.slot], b = P.dm.tri[3 * (size_t)cp.slot + 1], c = P.dm.tri[3 * (size_t)cp.slot + 2];
+        const V3 p0 = v3(a.x, a.y, a.z), e0 = v3(b.x, b.y, b.z) - p0, e1 = v3(c.x, c.y, c.z) - p0;
+        const int side = tri_side(p0, cross3(e0, e1), p);
+        float u, v;
+        tri_uv(p0, e0, e1, p, u, v);
+        R_D = sqrtf(cp.d2);
+        if (R_D < eps && u > 0.0f && v > 0.0f && u + v < 1.0f) {
+            float col[3];
+            const int32_t *tv = P.dm.triVerts + 3 * (size_t)cp.slot;
+            surface_color3(P.dm.colors, tv[0], tv[1], tv[2], side, u, v, col);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                col[k] *= P.st.dirichlet_intensity;
+                col[k] *= thp;
+                sol[k] = col[k] + sol[k];
+            }
+            ++L.c_absorbed;
+            return true;
+        }
+    }
+    return false;
+}
+
+// B: the star radius, the source and Neumann samples (their rays inline), the direction of the step.  true = no boundary
+// at all (the walk ends); else the walker's ray starts at `cur` along `dir` and is at most R_B long.
+template <bool EMISSIVE, bool SOURCE, bool NTREE>
+__device__ __forceinline__ bool step3_b(const Walk3Params &P, Lane3 &L, float R_D, float R_N, const LdsColumn &stk, float &R_B_out, V3 &dir_out, V3 &cur_out)
+{
+    const bool has_n = P.nm.n_tris > 0;
     const float eps = P.st.eps;
     V3 &p = L.p;
     float &thp = L.thp;
@@ -843,36 +884,7 @@ __device__ __forceinline__ bool step3(const Walk3Params &P, Lane3 &L, Closest cp
     V3 &nn = L.nn;
     float (&sol)[3] = L.sol;
     Pcg &rng = L.rng;
-    int32_t &hint = L.hint;
-    uint32_t &nhits = L.c_nhits;
-    float R_D = WOST_INF;
-    if (has_d) {
-            hint = cp.slot;
-            if (L.depth == 0) L.hint0 = cp.slot;
-            const float4 a = P.dm.tri[3 * (size_t)cp.slot], b = P.dm.tri[3 * (size_t)cp.slot + 1], c = P.dm.tri[3 * (size_t)cp.slot + 2];
-            const V3 p0 = v3(a.x, a.y, a.z), e0 = v3(b.x, b.y, b.z) - p0, e1 = v3(c.x, c.y, c.z) - p0;
-            const int side = tri_side(p0, cross3(e0, e1), p);
-            float u, v;
-            tri_uv(p0, e0, e1, p, u, v);
-            R_D = sqrtf(cp.d2);
-            if (R_D < eps && u > 0.0f && v > 0.0f && u + v < 1.0f) {
-                float col[3];
-                const int32_t *tv = P.dm.triVerts + 3 * (size_t)cp.slot;
-                surface_color3(P.dm.colors, tv[0], tv[1], tv[2], side, u, v, col);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    col[k] *= P.st.dirichlet_intensity;
-                    col[k] *= thp;
-                    sol[k] = col[k] + sol[k];
-                }
-                ++L.c_absorbed;
-                return true;
-            }
-        }
-            float R_N = WOST_INF;
-            PROF3_T0();
-            if (has_n) R_N = closest_silhouette3<NTREE>(P.nm, p, R_D, stk);
-            PROF3(0);
+    PROF3_T0();
             float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
             R_B *= WOST_R_B_SHRINK;
             if (isinf(R_B)) return true;
@@ -988,23 +1000,43 @@ __device__ __forceinline__ bool step3(const Walk3Params &P, Lane3 &L, Closest cp
                     pdf = 1.0f / WOST_4PI;
                 }
             }
-            V3 nxt = v3(p.x + R_B * dir.x, p.y + R_B * dir.y, p.z + R_B * dir.z);
-            bool hit = false;
-            V3 hn = v3(0.0f, 0.0f, 0.0f);
-            if (has_n) {
-                float t;
-                int hi;
-                hit = ray_closest3<NTREE>(P.nm, cur, dir, R_B, t, hi, stk);
-                if (hit) {
-                    hn = ld3(P.nm.flat[hi].n);
-                    if (dot3(hn, dir) > 0) hn = v3(-hn.x, -hn.y, -hn.z);
-                    nxt = v3(cur.x + t * dir.x, cur.y + t * dir.y, cur.z + t * dir.z);
-                    ++nhits;
-                }
-            }
-    PROF3(3);
-    thp = thp / pdf / alpha / WOST_4PI;
-    p = nxt; on_n = hit; nn = hn;
+    (void)pdf; (void)alpha;
+    R_B_out = R_B; dir_out = dir; cur_out = cur;
+    return false;
+}
+
+// C: where the ray ended.
+__device__ __forceinline__ void step3_c(const Walk3Params &P, Lane3 &L, float R_B, V3 dir, V3 cur, bool hit, float t, int hi)
+{
+    V3 nxt = v3(L.p.x + R_B * dir.x, L.p.y + R_B * dir.y, L.p.z + R_B * dir.z);
+    V3 hn = v3(0.0f, 0.0f, 0.0f);
+    if (hit) {
+        hn = ld3(P.nm.flat[hi].n);
+        if (dot3(hn, dir) > 0) hn = v3(-hn.x, -hn.y, -hn.z);
+        nxt = v3(cur.x + t * dir.x, cur.y + t * dir.y, cur.z + t * dir.z);
+        ++L.c_nhits;
+    }
+    // uniformSampleSphere / Hemisphere pdf and the boundary factor of the step that was taken from L.on_n
+    const float pdf = L.on_n ? 1.0f / WOST_2PI : 1.0f / WOST_4PI, alpha = L.on_n ? 0.5f : 1.0f;
+    L.thp = L.thp / pdf / alpha / WOST_4PI;
+    L.p = nxt; L.on_n = hit; L.nn = hn;
+}
+
+// the whole step with both queries answered on the spot; true = the walk has ended
+template <bool EMISSIVE, bool SOURCE, bool NTREE>
+__device__ __forceinline__ bool step3(const Walk3Params &P, Lane3 &L, Closest cp, const LdsColumn &stk)
+{
+    float R_D, R_B;
+    if (step3_a(P, L, cp, R_D)) return true;
+    float R_N = WOST_INF;
+    if (P.nm.n_tris > 0) R_N = closest_silhouette3<NTREE>(P.nm, L.p, R_D, stk);
+    V3 dir, cur;
+    if (step3_b<EMISSIVE, SOURCE, NTREE>(P, L, R_D, R_N, stk, R_B, dir, cur)) return true;
+    bool hit = false;
+    float t = 0.0f;
+    int hi = -1;
+    if (P.nm.n_tris > 0) hit = ray_closest3<NTREE>(P.nm, cur, dir, R_B, t, hi, stk);
+    step3_c(P, L, R_B, dir, cur, hit, t, hi);
     return false;
 }
 
