@@ -436,20 +436,27 @@ __device__ __forceinline__ void silhouette_record_test(float4 r0, float4 r1, flo
     }
 }
 
-__device__ __forceinline__ float closest_silhouette3_tree(const DevMesh3 &m, V3 q, float rmax, const LdsColumn &stk)
+// state of a silhouette query between node visits: the traversal (T.best.d2 = the slack pruning bound), the exact
+// minimum so far (the flat loop's variable) and whether any silhouette edge was met
+struct SilQuery3 {
+    Trav T;
+    float best2;
+    bool found;
+};
+__device__ __forceinline__ SilQuery3 sil3_begin(float rmax)
 {
-    // best2 is the exact minimum (the flat loop's variable); T.best.d2 carries the slack pruning bound
-    float best2 = rmax * rmax;
-    Trav T = trav_begin(Closest{best2 * kSlack3, -1});
-    bool found = false;
-#ifdef WOST3_PROFILE
-    unsigned prof_inner = 0, prof_leaf = 0;
-#endif
-    for (;;) {
-        bool more;
-#ifdef WOST3_PROFILE
-        if (T.level == m.levels) ++prof_leaf; else ++prof_inner;
-#endif
+    const float best2 = rmax * rmax;
+    return SilQuery3{trav_begin(Closest{best2 * kSlack3, -1}), best2, false};
+}
+__device__ __forceinline__ float sil3_result(const SilQuery3 &Q) { return Q.found ? sqrtf(Q.best2) : WOST_INF; }
+
+// visit ONE node; false = the query is complete
+__device__ __forceinline__ bool sil3_visit(const DevMesh3 &m, V3 q, SilQuery3 &Q, const LdsColumn &stk)
+{
+    Trav &T = Q.T;
+    float &best2 = Q.best2;
+    bool &found = Q.found;
+    bool more;
         const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
         const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
         const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
@@ -496,14 +503,27 @@ __device__ __forceinline__ float closest_silhouette3_tree(const DevMesh3 &m, V3 
                 more = trav_pop(T, stk);
             }
         }
-        if (!more) break;
+    return more;
+}
+
+__device__ __forceinline__ float closest_silhouette3_tree(const DevMesh3 &m, V3 q, float rmax, const LdsColumn &stk)
+{
+    SilQuery3 Q = sil3_begin(rmax);
+#ifdef WOST3_PROFILE
+    unsigned prof_inner = 0, prof_leaf = 0;
+#endif
+    for (;;) {
+#ifdef WOST3_PROFILE
+        if (Q.T.level == m.levels) ++prof_leaf; else ++prof_inner;
+#endif
+        if (!sil3_visit(m, q, Q, stk)) break;
     }
 #ifdef WOST3_PROFILE
     atomicAdd(&g_prof3[12], (unsigned long long)prof_inner);
     atomicAdd(&g_prof3[13], (unsigned long long)prof_leaf);
     atomicAdd(&g_prof3[14], 1ull);
 #endif
-    return found ? sqrtf(best2) : WOST_INF;
+    return sil3_result(Q);
 }
 
 // rays: where the ray enters a child box (slabs; the boxes are padded and the comparison is slack, so a box that
@@ -537,18 +557,31 @@ __device__ __forceinline__ float ray_aabb_entry(float lox, float loy, float loz,
     return (tmin <= tmax * 1.00001f + 1e-30f) ? fminf(tmin, tmax) : WOST_INF;
 }
 
-// closest hit (smallest t, lowest original index on ties: the flat loop's answer) or any hit
-template <bool ANY_HIT>
-__device__ __forceinline__ bool ray3_tree(const DevMesh3 &m, V3 o, V3 d, float tmax, float &t_out, int &idx_out, const LdsColumn &stk)
+// state of a ray query between node visits: T.best.d2 = the pruning bound (boxes entered beyond it cannot hold a better
+// hit), the best hit so far
+struct RayQuery3 {
+    Trav T;
+    V3 inv;
+    float bt;
+    int bi;
+    bool hit;
+};
+__device__ __forceinline__ RayQuery3 ray3_begin(V3 d, float tmax)
 {
-    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    // Trav.best.d2 carries the pruning bound: boxes entered beyond it cannot hold a better hit
-    Trav T = trav_begin(Closest{tmax * 1.00001f + 1e-30f, -1});
-    bool hit = false;
-    float bt = WOST_INF;
-    int bi = -1;
-    for (;;) {
-        bool more;
+    return RayQuery3{trav_begin(Closest{tmax * 1.00001f + 1e-30f, -1}), v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), WOST_INF, -1, false};
+}
+
+// closest hit (smallest t, lowest original index on ties: the flat loop's answer) or any hit: visit ONE node;
+// false = the query is complete
+template <bool ANY_HIT>
+__device__ __forceinline__ bool ray3_visit(const DevMesh3 &m, V3 o, V3 d, float tmax, RayQuery3 &Q, const LdsColumn &stk)
+{
+    Trav &T = Q.T;
+    const V3 inv = Q.inv;
+    float &bt = Q.bt;
+    int &bi = Q.bi;
+    bool &hit = Q.hit;
+    bool more;
         if (T.level == m.levels) {
             // the record of a leaf: the boxes of its four triangles; the triangles themselves in leaf order
             const uint32_t gl = level_first(T.level) + (uint32_t)T.pos;
@@ -567,8 +600,8 @@ __device__ __forceinline__ bool ray3_tree(const DevMesh3 &m, V3 o, V3 d, float t
                 if (tri_ray3(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), o, d, tmax, t)) {
                     const int oi = m.triOrig[slot];
                     if (ANY_HIT) {
-                        t_out = t; idx_out = oi;
-                        return true;
+                        bt = t; bi = oi; hit = true;
+                        return false;
                     }
                     if (!hit || t < bt || (t == bt && oi < bi)) {
                         bt = t; bi = oi; hit = true;
@@ -603,10 +636,17 @@ __device__ __forceinline__ bool ray3_tree(const DevMesh3 &m, V3 o, V3 d, float t
                 more = trav_pop(T, stk);
             }
         }
-        if (!more) break;
+    return more;
+}
+
+template <bool ANY_HIT>
+__device__ __forceinline__ bool ray3_tree(const DevMesh3 &m, V3 o, V3 d, float tmax, float &t_out, int &idx_out, const LdsColumn &stk)
+{
+    RayQuery3 Q = ray3_begin(d, tmax);
+    while (ray3_visit<ANY_HIT>(m, o, d, tmax, Q, stk)) {
     }
-    t_out = bt; idx_out = bi;
-    return hit;
+    t_out = Q.bt; idx_out = Q.bi;
+    return Q.hit;
 }
 
 template <bool NTREE>
@@ -832,9 +872,12 @@ struct Lane3 {
 #define PROF3(k) do {} while (0)
 #endif
 
-// One walk step in three parts, so that the kernel can answer the two tree queries between them -- the closest
-// silhouette edge after part A, the walker's ray after part B -- either inline (small Neumann meshes: flat loops) or as
-// states of the lane machine, one node visit per trip like the closest-point descent (walk3_kernel).
+// One walk step in three parts around its two tree queries -- the closest silhouette edge after part A, the walker's
+// ray after part B.  The kernel answers them on the spot (step3).  Making them states of the lane machine like the
+// closest-point descent (one node visit per trip: sil3_visit / ray3_visit, a trip running the body most lanes are
+// ready for) was built on these parts and measured: bit-exact, but SLOWER on a 1280-triangle shell (zero flux 660 ->
+// 770 ms, emissive 1570 -> 1950 ms at the best scheduler constants of each): four kinds of lanes per wave fill a body
+// worse than the longest-lane wait inside the step costs, and the kernel holds both query states (165 VGPRs).
 // A: the Dirichlet side.  true = absorbed.
 __device__ __forceinline__ bool step3_a(const Walk3Params &P, Lane3 &L, Closest cp, float &R_D)
 {
@@ -1693,9 +1736,9 @@ static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, 
     P.cursor = c->cursor;
     P.tiled = (pixel_begin == 0 && pixel_end == (int32_t)c->n_pixels && ((c->settings.width | c->settings.height) & 7) == 0) ? 1 : 0;
     P.wait_weight = c->wait_weight; P.trav_burst = c->trav_burst;
-    // a step that answers its Neumann queries on the tree is long and divergent: it waits until four fifths of the
-    // wave's walkers stand at it (tools/scratch/bench3d_shell.py: 1.8x over the Dirichlet-only setting on a 1280-triangle shell)
-    if (c->nm.view.n_tris > WOST3_FLAT_MAX) P.wait_weight = 2;
+    // a step that answers its Neumann queries on the tree is long and divergent: it waits until eight ninths of the
+    // busy walkers of the wave stand at it (tools/scratch/bench3d_shell.py: 1.8x over the Dirichlet-only setting on a 1280-triangle shell)
+    if (c->nm.view.n_tris > WOST3_FLAT_MAX) P.wait_weight = 1;
     if (const char *w = std::getenv("WOST3_WAIT_WEIGHT")) P.wait_weight = std::max(1, std::atoi(w));
     if (const char *w = std::getenv("WOST3_TRAV_BURST")) P.trav_burst = std::max(1, std::atoi(w));
     W3_TRY(hipMemsetAsync(c->cursor, 0, sizeof(uint32_t), stream));
