@@ -1641,6 +1641,55 @@ static hipError_t upload3(std::vector<void *> &allocs, const T *src, size_t coun
     return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
 }
 
+// ---- von Mises-Fisher lobe on the sphere (reference util/vmf.h:21-70, the Jakob [2012] form; the lobes of
+// GuidedIntegrator<3>'s mixture -- that integrator is not built, the distribution is its first piece) ----------------
+constexpr float kVmfEpsilon = 1e-5f;   // M_EPSILON, core/math/include/krrmath/constants.h
+
+// VMF::eval(cosTheta)
+__device__ __forceinline__ float vmf_eval(float kappa, float cos_theta)
+{
+    if (kappa < kVmfEpsilon) return 1.0f / WOST_4PI;
+    return det_expf(kappa * fminf(0.0f, cos_theta - 1.0f)) * kappa / (WOST_2PI * (1.0f - det_expf(-2.0f * kappa)));
+}
+
+// VMF::sample(sampler, mu): two draws, the lobe about +z turned into the frame of mu
+__device__ __forceinline__ V3 vmf_sample(float kappa, V3 mu, Pcg &rng)
+{
+    const float u0 = pcg_next_float(rng), u1 = pcg_next_float(rng);
+    float c, s;
+    sincos_2pi(u1, c, s);
+    V3 local;
+    if (kappa < kVmfEpsilon) {
+        const float z = 1 - 2 * u0, r = sqrtf(1 - z * z);               // uniformSampleSphere<3>
+        local = v3(r * c, r * s, z);
+    } else {
+        const float cos_theta = 1.0f + det_logf(1.0f + (-u0 + det_expf(-2.0f * kappa) * u0)) / kappa;
+        const float sin_theta = sqrtf(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
+        local = v3(c * sin_theta, s * sin_theta, cos_theta);
+    }
+    return frame_to_world(mu, local.x, local.y, local.z);
+}
+
+__global__ __launch_bounds__(256) void vmf_eval_kernel(const float *kappa, const float *cos_theta, int n, float *pdf)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pdf[i] = vmf_eval(kappa[i], cos_theta[i]);
+}
+
+__global__ __launch_bounds__(256) void vmf_sample_kernel(const float *kappa, const float *mu, const uint64_t *seed, int n, int per_point, float *dirs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Pcg rng{0, 1};
+    pcg_set_seed(rng, seed[i], 1);
+    const V3 m = v3(mu[3 * i], mu[3 * i + 1], mu[3 * i + 2]);
+    for (int k = 0; k < per_point; ++k) {
+        const V3 w = vmf_sample(kappa[i], m, rng);
+        float *o = dirs + 3 * ((size_t)i * per_point + k);
+        o[0] = w.x; o[1] = w.y; o[2] = w.z;
+    }
+}
+
 }  // namespace wost
 
 using namespace wost;
@@ -2014,6 +2063,40 @@ int wost3_ray_intersect(wost3_handle h, int which_mesh, const float *origins, co
     W3_TRY(hipMemcpyAsync(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     W3_TRY(hipMemcpyAsync(out_idx, d_idx, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     W3_TRY(hipStreamSynchronize(h->stream));
+    return WOST_OK;
+}
+
+int wost3_vmf_eval(int device, const float *kappa, const float *cos_theta, int32_t n, float *pdf)
+{
+    if (!kappa || !cos_theta || !pdf || n < 0) return set_error(WOST_ERR_INVALID, "null argument");
+    if (n == 0) return WOST_OK;
+    W3_TRY(hipSetDevice(device));
+    Scratch3 s;
+    float *d_k, *d_c, *d_p;
+    W3_TRY(s.alloc(&d_k, n)); W3_TRY(s.alloc(&d_c, n)); W3_TRY(s.alloc(&d_p, n));
+    W3_TRY(hipMemcpy(d_k, kappa, (size_t)n * 4, hipMemcpyHostToDevice));
+    W3_TRY(hipMemcpy(d_c, cos_theta, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(vmf_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d_k, d_c, n, d_p);
+    W3_TRY(hipGetLastError());
+    W3_TRY(hipMemcpy(pdf, d_p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return WOST_OK;
+}
+
+int wost3_vmf_sample(int device, const float *kappa, const float *mu, const uint64_t *seed, int32_t n, int32_t per_point, float *dirs)
+{
+    if (!kappa || !mu || !seed || !dirs || n < 0 || per_point < 1) return set_error(WOST_ERR_INVALID, "null argument");
+    if (n == 0) return WOST_OK;
+    W3_TRY(hipSetDevice(device));
+    Scratch3 s;
+    float *d_k, *d_m, *d_o;
+    uint64_t *d_s;
+    W3_TRY(s.alloc(&d_k, n)); W3_TRY(s.alloc(&d_m, (size_t)n * 3)); W3_TRY(s.alloc(&d_s, n)); W3_TRY(s.alloc(&d_o, (size_t)n * per_point * 3));
+    W3_TRY(hipMemcpy(d_k, kappa, (size_t)n * 4, hipMemcpyHostToDevice));
+    W3_TRY(hipMemcpy(d_m, mu, (size_t)n * 12, hipMemcpyHostToDevice));
+    W3_TRY(hipMemcpy(d_s, seed, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(vmf_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d_k, d_m, d_s, n, per_point, d_o);
+    W3_TRY(hipGetLastError());
+    W3_TRY(hipMemcpy(dirs, d_o, (size_t)n * per_point * 12, hipMemcpyDeviceToHost));
     return WOST_OK;
 }
 

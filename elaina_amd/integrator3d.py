@@ -156,3 +156,25 @@ class UniformIntegrator3:
             self.close()
         except Exception:
             pass
+
+
+def vmf_eval(kappa, cos_theta, device=0):
+    """VMF::eval(cosTheta) (reference util/vmf.h:27-32) for pairs (kappa, cos_theta)"""
+    lib = capi.load()
+    k = np.ascontiguousarray(kappa, dtype=np.float32)
+    c = np.ascontiguousarray(cos_theta, dtype=np.float32)
+    out = np.zeros(len(k), np.float32)
+    _check(lib.wost3_vmf_eval(device, _fp(k), _fp(c), len(k), _fp(out)), "wost3_vmf_eval")
+    return out
+
+
+def vmf_sample(kappa, mu, seed, per_point=1, device=0):
+    """VMF::sample(sampler, mu) (reference util/vmf.h:45-70): per point a PCG32 stream setSeed(seed, 1) and per_point
+    consecutive directions about mu"""
+    lib = capi.load()
+    k = np.ascontiguousarray(kappa, dtype=np.float32)
+    m = np.ascontiguousarray(mu, dtype=np.float32).reshape(-1, 3)
+    s = np.ascontiguousarray(seed, dtype=np.uint64)
+    out = np.zeros((len(k), per_point, 3), np.float32)
+    _check(lib.wost3_vmf_sample(device, _fp(k), _fp(m), s.ctypes.data_as(C.POINTER(C.c_uint64)), len(k), per_point, _fp(out)), "wost3_vmf_sample")
+    return out

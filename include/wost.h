@@ -386,6 +386,13 @@ int wost3_closest_silhouette(wost3_handle h, int which_mesh, const float *pts, c
 /* lbvh::ray_intersect on triangles: closest hit (flag, t, triangle) */
 int wost3_ray_intersect(wost3_handle h, int which_mesh, const float *origins, const float *dirs, const float *tmax, int32_t n,
                         int32_t *out_hit, float *out_t, int32_t *out_idx);
+/* VMF (reference util/vmf.h:21-70), the lobe of the 3-D guided integrator's mixture (that integrator is not built; this is
+ * its distribution layer, batch entry points over HOST arrays like wost_vonmises_*): eval(cosTheta) for n (kappa,
+ * cos_theta) pairs; sample(sampler, mu): per point a PCG32 stream setSeed(seed[i], 1) and per_point consecutive unit
+ * directions about mu[n*3] in dirs[n*per_point*3]. */
+int wost3_vmf_eval(int device, const float *kappa, const float *cos_theta, int32_t n, float *pdf);
+int wost3_vmf_sample(int device, const float *kappa, const float *mu, const uint64_t *seed, int32_t n, int32_t per_point,
+                     float *dirs);
 /* renderDirichletSDF / renderSilhouetteSDF / renderSource with DIM = 3 (integrator/common.h:52-163): one query per pixel
  * of the frame at its evaluation point; which_mesh as above; out_dist width*height floats (+inf without that mesh),
  * out_rgb width*height*3 floats (zeros without a source term) */

@@ -410,6 +410,21 @@ class Oracle:
             raise RuntimeError("wo3_ray_intersect_batch failed")
         return hit, tt, idx
 
+    def vmf_eval(self, kappa, cos_theta):
+        k = np.ascontiguousarray(kappa, dtype=np.float32)
+        c = np.ascontiguousarray(cos_theta, dtype=np.float32)
+        out = np.zeros(len(k), dtype=np.float32)
+        self.lib.wo3_vmf_eval_batch(_fp(k), _fp(c), len(k), _fp(out))
+        return out
+
+    def vmf_sample(self, kappa, mu, seed, per_point=1):
+        k = np.ascontiguousarray(kappa, dtype=np.float32)
+        m = np.ascontiguousarray(mu, dtype=np.float32)
+        s = np.ascontiguousarray(seed, dtype=np.uint64)
+        out = np.zeros((len(k), per_point, 3), dtype=np.float32)
+        self.lib.wo3_vmf_sample_batch(_fp(k), _fp(m), s.ctypes.data_as(C.POINTER(C.c_uint64)), len(k), per_point, _fp(out))
+        return out
+
     def green_ball3(self, R, r):
         e, nrm, pdf = C.c_float(), C.c_float(), C.c_float()
         self.lib.wo3_green_ball.restype = None

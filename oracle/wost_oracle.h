@@ -178,6 +178,11 @@ void wo3_green_ball(float R, float r, float *eval, float *norm, float *pdf_radiu
 /* debug channels of the 3-D integrator at the evaluation points of the frame (integrator/common.h:52-163 with DIM = 3):
  * which = 0 distance to the Dirichlet mesh, 1 distance to the closest silhouette edge of the Neumann mesh
  * (+inf without that mesh); the source channel = intensity * f (zeros without a source term) */
+/* von Mises-Fisher lobe (util/vmf.h): density by cos(theta); directions about mu[n*3] from PCG32 streams setSeed(seed[i], 1) */
+float wo3_vmf_eval(float kappa, float cos_theta);
+void wo3_vmf_sample(float kappa, const float mu[3], wo_pcg *rng, float out[3]);
+int wo3_vmf_eval_batch(const float *kappa, const float *cos_theta, int n, float *pdf);
+int wo3_vmf_sample_batch(const float *kappa, const float *mu, const uint64_t *seed, int n, int per_point, float *dirs);
 int wo3_render_sdf(const wo3_scene *sc, const wo_settings *st, int which, float *out_dist);
 int wo3_render_source(const wo3_scene *sc, const wo_settings *st, float *out_rgb);
 

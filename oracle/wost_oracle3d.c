@@ -654,3 +654,52 @@ void wo3_green_ball(float R, float r, float *eval, float *norm, float *pdf_radiu
     *norm = R * R / 6.0f;
     *pdf_radius = 6.0f * r * (R - r) / (R * R * R);
 }
+
+/* ---- von Mises-Fisher distribution on the sphere (util/vmf.h:21-67, the Jakob [2012] form the reference uses; the lobes
+ * of GuidedIntegrator<3>'s mixture).  Deterministic math like the rest of the oracle; log1p(x) is log(1 + x). -------- */
+#define WO3_M_EPSILON 1e-5f   /* M_EPSILON, core/math/include/krrmath/constants.h */
+
+/* VMF::eval(cosTheta) (vmf.h:27-32) */
+float wo3_vmf_eval(float kappa, float cos_theta)
+{
+    if (kappa < WO3_M_EPSILON) return 1.0f / WO_4PI;
+    return wo_expf(kappa * fminf(0.0f, cos_theta - 1.0f)) * kappa / (WO_2PI * (1.0f - wo_expf(-2.0f * kappa)));
+}
+
+/* VMF::sample(sampler, mu) (vmf.h:45-70): two draws; the lobe about +z turned into the frame of mu */
+void wo3_vmf_sample(float kappa, const float mu[3], wo_pcg *rng, float out[3])
+{
+    const float u0 = wo_pcg_next_float(rng), u1 = wo_pcg_next_float(rng);
+    float c, s;
+    wo_sincos_2pi(u1, &c, &s);
+    v3 local;
+    if (kappa < WO3_M_EPSILON) {
+        /* uniformSampleSphere<3> (util/sampling.h), as in the walk */
+        const float z = 1 - 2 * u0, r = sqrtf(1 - z * z);
+        local.x = r * c; local.y = r * s; local.z = z;
+    } else {
+        const float cos_theta = 1.0f + wo_logf(1.0f + (-u0 + wo_expf(-2.0f * kappa) * u0)) / kappa;
+        const float sin_theta = sqrtf(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));      /* safe_sqrt */
+        local.x = c * sin_theta; local.y = s * sin_theta; local.z = cos_theta;
+    }
+    const v3 m = { mu[0], mu[1], mu[2] };
+    const v3 w = frame_to_world(m, local.x, local.y, local.z);
+    out[0] = w.x; out[1] = w.y; out[2] = w.z;
+}
+
+int wo3_vmf_eval_batch(const float *kappa, const float *cos_theta, int n, float *pdf)
+{
+    for (int i = 0; i < n; ++i) pdf[i] = wo3_vmf_eval(kappa[i], cos_theta[i]);
+    return 0;
+}
+
+/* per point a PCG32 stream setSeed(seed[i], 1) and per_point consecutive directions */
+int wo3_vmf_sample_batch(const float *kappa, const float *mu, const uint64_t *seed, int n, int per_point, float *dirs)
+{
+    for (int i = 0; i < n; ++i) {
+        wo_pcg rng;
+        wo_pcg_set_seed(&rng, seed[i], 1);
+        for (int k = 0; k < per_point; ++k) wo3_vmf_sample(kappa[i], mu + 3 * (size_t)i, &rng, dirs + 3 * ((size_t)i * per_point + k));
+    }
+    return 0;
+}
