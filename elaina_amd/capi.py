@@ -150,7 +150,7 @@ EXPORTS = [
     "wost_net_set_params", "wost_net_set_gradient_buffer", "wost_net_inference", "wost_net_train_step", "wost_net_set_option",
     "wost_guided_create", "wost_guided_set_sync", "wost_guided_set_frame_callback", "wost_guided_network", "wost_guided_scene", "wost_guided_query_network", "wost_guided_solve", "wost_guided_solve_sharded", "wost_guided_train_set", "wost_guided_destroy",
     "wost3_create", "wost3_solve", "wost3_solve_sharded", "wost3_closest_point", "wost3_closest_silhouette", "wost3_ray_intersect",
-    "wost3_render_sdf", "wost3_render_source", "wost3_destroy", "wost3_vmf_eval", "wost3_vmf_sample",
+    "wost3_render_sdf", "wost3_render_source", "wost3_destroy", "wost3_vmf_eval", "wost3_vmf_sample", "wost3_vmm_pdf_sample", "wost3_vmm_loss_gradients",
     "wost_last_error", "wost_version",
 ]
 
@@ -226,6 +226,8 @@ def load():
     L.wost3_destroy.argtypes = [C.c_void_p]
     L.wost3_vmf_eval.argtypes = [C.c_int, fp, fp, C.c_int32, fp]
     L.wost3_vmf_sample.argtypes = [C.c_int, fp, fp, u64p, C.c_int32, C.c_int32, fp]
+    L.wost3_vmm_pdf_sample.argtypes = [C.c_int, fp, fp, u64p, C.c_int32, fp, fp]
+    L.wost3_vmm_loss_gradients.argtypes = [C.c_int, fp, fp, fp, fp, C.POINTER(C.c_ubyte), fp, C.c_int32, C.c_float, fp, fp]
     L.wost_last_error.restype = C.c_char_p
     L.wost_version.restype = C.c_char_p
     for name in EXPORTS:

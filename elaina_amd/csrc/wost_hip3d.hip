@@ -1690,6 +1690,162 @@ __global__ __launch_bounds__(256) void vmf_sample_kernel(const float *kappa, con
     }
 }
 
+// ---- VMM<3,8>: the mixture of eight vMF lobes (reference integrator/guided/distribution.h:279-436, train.h:60-105 and
+// 492-553 with common3d: 5 numbers per lobe -- lambda, kappa, mean vector -- and the selection logit = 41 outputs) ------
+constexpr int kVmm3Lobes = 8;
+struct Vmm3 {
+    float lambda[kVmm3Lobes], kappa[kVmm3Lobes], weight[kVmm3Lobes], total;
+    V3 mu[kVmm3Lobes], mo[kVmm3Lobes];
+};
+
+__device__ __forceinline__ float clamp_act(float v) { return fmaxf(fminf(v, 15.0f), -10.0f); }
+
+__device__ __forceinline__ void vmm3_build(Vmm3 &m, const float *data)
+{
+    m.total = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kVmm3Lobes; ++i) {
+        const float *d = data + 5 * i;
+        m.lambda[i] = det_expf(clamp_act(d[0]));
+        m.kappa[i] = det_expf(clamp_act(d[1]));
+        // Eigen normalized(): v / sqrt(z) when z = squaredNorm > 0, else v unchanged
+        const float z = (d[2] * d[2] + d[3] * d[3]) + d[4] * d[4], n = sqrtf(z);
+        m.mo[i] = v3(d[2], d[3], d[4]);
+        m.mu[i] = z > 0.0f ? v3(d[2] / n, d[3] / n, d[4] / n) : m.mo[i];
+        m.total += m.lambda[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kVmm3Lobes; ++i) m.weight[i] = m.lambda[i] / m.total;
+}
+
+__device__ __forceinline__ float vmm3_lobe_pdf(const Vmm3 &m, int i, V3 w)
+{
+    return vmf_eval(m.kappa[i], (w.x * m.mu[i].x + w.y * m.mu[i].y) + w.z * m.mu[i].z);
+}
+
+__device__ __forceinline__ float vmm3_pdf(const Vmm3 &m, V3 w)
+{
+    float val = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kVmm3Lobes; ++i) val += m.weight[i] * vmm3_lobe_pdf(m, i, w);
+    return val;
+}
+
+// one draw picks the lobe, two more the direction
+__device__ __forceinline__ V3 vmm3_sample(const Vmm3 &m, Pcg &rng)
+{
+    float u = pcg_next_float(rng);
+    int pick = 0;
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < kVmm3Lobes; ++i) {
+        if (!done && u < m.weight[i]) { pick = i; done = true; }
+        if (!done) u -= m.weight[i];
+    }
+    float kap = m.kappa[0];
+    V3 mu = m.mu[0];
+#pragma unroll
+    for (int i = 1; i < kVmm3Lobes; ++i)
+        if (pick == i) { kap = m.kappa[i]; mu = m.mu[i]; }
+    return vmf_sample(kap, mu, rng);
+}
+
+__global__ __launch_bounds__(256) void vmm3_pdf_sample_kernel(const float *raw, const float *wi, const uint64_t *seed, int n, float *pdf, float *dir)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Vmm3 m;
+    vmm3_build(m, raw + 40 * (size_t)i);
+    if (pdf) pdf[i] = vmm3_pdf(m, v3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]));
+    if (dir) {
+        Pcg rng{0, 1};
+        pcg_set_seed(rng, seed[i], 1);
+        const V3 w = vmm3_sample(m, rng);
+        dir[3 * i] = w.x; dir[3 * i + 1] = w.y; dir[3 * i + 2] = w.z;
+    }
+}
+
+// compute_dL_doutput_divergence with GuidedOutput = common3d around VMM<3,N>::gradients_probability
+__global__ __launch_bounds__(256) void vmm3_loss_gradients_kernel(const float *raw, const float *dir, const float *li, const float *dir_pdf,
+                                                                  const unsigned char *on_neumann, const float *normal, int n, float loss_scale,
+                                                                  float *dl_draw, float *likelihood)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const float eps = 1e-5f;
+    const float scale = loss_scale / (float)n;
+    const float *data = raw + 41 * (size_t)t;
+    float *grad = dl_draw + 41 * (size_t)t;
+    Vmm3 m;
+    vmm3_build(m, data);
+    const V3 w = v3(dir[3 * t], dir[3 * t + 1], dir[3 * t + 2]);
+    const bool on_n = on_neumann ? on_neumann[t] != 0 : false;
+    V3 r = v3(0.0f, 0.0f, 0.0f);
+    if (on_n) {
+        const V3 nn = v3(normal[3 * t], normal[3 * t + 1], normal[3 * t + 2]);
+        const float d = (w.x * nn.x + w.y * nn.y) + w.z * nn.z;
+        r = v3(w.x - 2 * d * nn.x, w.y - 2 * d * nn.y, w.z - 2 * d * nn.z);
+    }
+    float pk[kVmm3Lobes], pkr[kVmm3Lobes];
+#pragma unroll
+    for (int k = 0; k < kVmm3Lobes; ++k) {
+        pk[k] = vmm3_lobe_pdf(m, k, w);
+        pkr[k] = on_n ? vmm3_lobe_pdf(m, k, r) : 0.0f;
+    }
+    float probability = 0.0f;
+    float g5[kVmm3Lobes][5];
+#pragma unroll
+    for (int sg = 0; sg < kVmm3Lobes; ++sg) {
+        const float lambda = m.lambda[sg], kappa = m.kappa[sg];
+        const float ox = m.mo[sg].x, oy = m.mo[sg].y, oz = m.mo[sg].z;
+        const V3 mu = m.mu[sg];
+        const float vmf = pk[sg];
+        probability += m.weight[sg] * vmf;
+        float vmfr = 0.0f;
+        if (on_n) { vmfr = pkr[sg]; probability += m.weight[sg] * vmfr; }
+        float dF_dlambda = (vmf + vmfr) * (m.total - lambda) / (m.total * m.total);
+#pragma unroll
+        for (int k = 0; k < kVmm3Lobes; ++k) {
+            if (k == sg) continue;
+            dF_dlambda -= m.weight[k] / m.total * pk[k];
+            if (on_n) dF_dlambda -= m.weight[k] / m.total * pkr[k];
+        }
+        float ik;
+        if (kappa < 1) ik = 0.000962f + -0.344883f * kappa + 0.030147f * (kappa * kappa);
+        else ik = 1 / kappa - (1 + det_expf(-2 * kappa)) / (1 - det_expf(-2 * kappa));
+        float dF_dkappa = m.weight[sg] * vmf * ((w.x * mu.x + w.y * mu.y + w.z * mu.z) + ik);
+        if (on_n) dF_dkappa += m.weight[sg] * vmfr * ((r.x * mu.x + r.y * mu.y + r.z * mu.z) + ik);
+        const float n2 = (ox * ox + oy * oy) + oz * oz;
+        float denom = n2 * sqrtf(n2);
+        if (denom < eps) denom = eps;
+        const float x = w.x, y = w.y, z = w.z, xr = r.x, yr = r.y, zr = r.z;
+        float dF_dx = m.weight[sg] * vmf * kappa * (-ox * oy * y - ox * oz * z + (oy * oy) * x + (oz * oz) * x) / denom;
+        if (on_n) dF_dx += m.weight[sg] * vmfr * kappa * (-ox * oy * yr - ox * oz * zr + (oy * oy) * xr + (oz * oz) * xr) / denom;
+        float dF_dy = m.weight[sg] * vmf * kappa * (-ox * oy * x - oy * oz * z + (ox * ox) * y + (oz * oz) * y) / denom;
+        if (on_n) dF_dy += m.weight[sg] * vmfr * kappa * (-ox * oy * xr - oy * oz * zr + (ox * ox) * yr + (oz * oz) * yr) / denom;
+        float dF_dz = m.weight[sg] * vmf * kappa * (-ox * oz * x - oy * oz * y + (ox * ox) * z + (oy * oy) * z) / denom;
+        if (on_n) dF_dz += m.weight[sg] * vmfr * kappa * (-ox * oz * xr - oy * oz * yr + (ox * ox) * zr + (oy * oy) * zr) / denom;
+        g5[sg][0] = dF_dlambda; g5[sg][1] = dF_dkappa; g5[sg][2] = dF_dx; g5[sg][3] = dF_dy; g5[sg][4] = dF_dz;
+    }
+    const float Li = li[t];
+    const float dirPdf = dir_pdf[t] + eps;
+    const float guidePdf = probability + eps;
+    const float prefix = -Li / dirPdf / guidePdf * scale;
+    if (likelihood) likelihood[t] = -Li / dirPdf * det_logf(guidePdf);
+#pragma unroll
+    for (int sg = 0; sg < kVmm3Lobes; ++sg) {
+        grad[5 * sg + 0] = prefix * g5[sg][0] * det_expf(clamp_act(data[5 * sg + 0]));
+        grad[5 * sg + 1] = prefix * g5[sg][1] * det_expf(clamp_act(data[5 * sg + 1]));
+        grad[5 * sg + 2] = prefix * g5[sg][2];
+        grad[5 * sg + 3] = prefix * g5[sg][3];
+        grad[5 * sg + 4] = prefix * g5[sg][4];
+    }
+    const float e = 0.2f;
+    const float uni = on_n ? 1.0f / WOST_2PI : 1.0f / WOST_4PI;
+    const float sgm = 1.0f / (1.0f + det_expf(-data[40]));
+    grad[40] = scale * (-e) * Li * (guidePdf - uni) / (dirPdf * dirPdf) * (sgm * (1 - sgm));
+}
+
 }  // namespace wost
 
 using namespace wost;
@@ -2097,6 +2253,57 @@ int wost3_vmf_sample(int device, const float *kappa, const float *mu, const uint
     hipLaunchKernelGGL(vmf_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d_k, d_m, d_s, n, per_point, d_o);
     W3_TRY(hipGetLastError());
     W3_TRY(hipMemcpy(dirs, d_o, (size_t)n * per_point * 12, hipMemcpyDeviceToHost));
+    return WOST_OK;
+}
+
+int wost3_vmm_pdf_sample(int device, const float *raw, const float *wi, const uint64_t *seed, int32_t n, float *pdf, float *sample_dir)
+{
+    if (!raw || !wi || (sample_dir && !seed) || n < 0) return set_error(WOST_ERR_INVALID, "null argument");
+    if (n == 0) return WOST_OK;
+    W3_TRY(hipSetDevice(device));
+    Scratch3 s;
+    float *d_r, *d_w, *d_p = nullptr, *d_d = nullptr;
+    uint64_t *d_s = nullptr;
+    W3_TRY(s.alloc(&d_r, (size_t)n * 40)); W3_TRY(s.alloc(&d_w, (size_t)n * 3));
+    W3_TRY(hipMemcpy(d_r, raw, (size_t)n * 160, hipMemcpyHostToDevice));
+    W3_TRY(hipMemcpy(d_w, wi, (size_t)n * 12, hipMemcpyHostToDevice));
+    if (pdf) W3_TRY(s.alloc(&d_p, n));
+    if (sample_dir) {
+        W3_TRY(s.alloc(&d_d, (size_t)n * 3)); W3_TRY(s.alloc(&d_s, n));
+        W3_TRY(hipMemcpy(d_s, seed, (size_t)n * 8, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(vmm3_pdf_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d_r, d_w, d_s, n, d_p, d_d);
+    W3_TRY(hipGetLastError());
+    if (pdf) W3_TRY(hipMemcpy(pdf, d_p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (sample_dir) W3_TRY(hipMemcpy(sample_dir, d_d, (size_t)n * 12, hipMemcpyDeviceToHost));
+    return WOST_OK;
+}
+
+int wost3_vmm_loss_gradients(int device, const float *raw, const float *dir, const float *li, const float *dir_pdf, const uint8_t *on_neumann,
+                             const float *normal, int32_t n, float loss_scale, float *dl_draw, float *likelihood)
+{
+    if (!raw || !dir || !li || !dir_pdf || !dl_draw || (on_neumann && !normal) || n < 0) return set_error(WOST_ERR_INVALID, "null argument");
+    if (n == 0) return WOST_OK;
+    W3_TRY(hipSetDevice(device));
+    Scratch3 s;
+    float *d_r, *d_d, *d_l, *d_p, *d_n = nullptr, *d_g, *d_k = nullptr;
+    unsigned char *d_o = nullptr;
+    W3_TRY(s.alloc(&d_r, (size_t)n * 41)); W3_TRY(s.alloc(&d_d, (size_t)n * 3)); W3_TRY(s.alloc(&d_l, n)); W3_TRY(s.alloc(&d_p, n));
+    W3_TRY(s.alloc(&d_g, (size_t)n * 41));
+    W3_TRY(hipMemcpy(d_r, raw, (size_t)n * 164, hipMemcpyHostToDevice));
+    W3_TRY(hipMemcpy(d_d, dir, (size_t)n * 12, hipMemcpyHostToDevice));
+    W3_TRY(hipMemcpy(d_l, li, (size_t)n * 4, hipMemcpyHostToDevice));
+    W3_TRY(hipMemcpy(d_p, dir_pdf, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (on_neumann) {
+        W3_TRY(s.alloc(&d_o, n)); W3_TRY(s.alloc(&d_n, (size_t)n * 3));
+        W3_TRY(hipMemcpy(d_o, on_neumann, (size_t)n, hipMemcpyHostToDevice));
+        W3_TRY(hipMemcpy(d_n, normal, (size_t)n * 12, hipMemcpyHostToDevice));
+    }
+    if (likelihood) W3_TRY(s.alloc(&d_k, n));
+    hipLaunchKernelGGL(vmm3_loss_gradients_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d_r, d_d, d_l, d_p, d_o, d_n, n, loss_scale, d_g, d_k);
+    W3_TRY(hipGetLastError());
+    W3_TRY(hipMemcpy(dl_draw, d_g, (size_t)n * 164, hipMemcpyDeviceToHost));
+    if (likelihood) W3_TRY(hipMemcpy(likelihood, d_k, (size_t)n * 4, hipMemcpyDeviceToHost));
     return WOST_OK;
 }
 

@@ -178,3 +178,31 @@ def vmf_sample(kappa, mu, seed, per_point=1, device=0):
     out = np.zeros((len(k), per_point, 3), np.float32)
     _check(lib.wost3_vmf_sample(device, _fp(k), _fp(m), s.ctypes.data_as(C.POINTER(C.c_uint64)), len(k), per_point, _fp(out)), "wost3_vmf_sample")
     return out
+
+
+def vmm3_pdf_sample(raw, wi, seed, device=0):
+    """VMM<3,8>::pdf(wi) and ::sample (reference distribution.h:279-345) from 40 raw outputs per point"""
+    lib = capi.load()
+    r = np.ascontiguousarray(raw, dtype=np.float32)
+    w = np.ascontiguousarray(wi, dtype=np.float32).reshape(-1, 3)
+    s = np.ascontiguousarray(seed, dtype=np.uint64)
+    n = len(w)
+    pdf, d = np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
+    _check(lib.wost3_vmm_pdf_sample(device, _fp(r), _fp(w), s.ctypes.data_as(C.POINTER(C.c_uint64)), n, _fp(pdf), _fp(d)), "wost3_vmm_pdf_sample")
+    return pdf, d
+
+
+def vmm3_loss_gradients(raw41, dirs, li, dir_pdf, on_neumann, normal, loss_scale=128.0, device=0):
+    """the loss gradient of the 3-D mixture by its 41 raw outputs (reference train.h:492-553) and the likelihood term"""
+    lib = capi.load()
+    r = np.ascontiguousarray(raw41, dtype=np.float32)
+    d = np.ascontiguousarray(dirs, dtype=np.float32)
+    l = np.ascontiguousarray(li, dtype=np.float32)
+    p = np.ascontiguousarray(dir_pdf, dtype=np.float32)
+    o = np.ascontiguousarray(on_neumann, dtype=np.uint8)
+    nn = np.ascontiguousarray(normal, dtype=np.float32)
+    n = len(l)
+    g, lk = np.zeros((n, 41), np.float32), np.zeros(n, np.float32)
+    _check(lib.wost3_vmm_loss_gradients(device, _fp(r), _fp(d), _fp(l), _fp(p), o.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(nn), n,
+                                        C.c_float(loss_scale), _fp(g), _fp(lk)), "wost3_vmm_loss_gradients")
+    return g, lk

@@ -393,6 +393,17 @@ int wost3_ray_intersect(wost3_handle h, int which_mesh, const float *origins, co
 int wost3_vmf_eval(int device, const float *kappa, const float *cos_theta, int32_t n, float *pdf);
 int wost3_vmf_sample(int device, const float *kappa, const float *mu, const uint64_t *seed, int32_t n, int32_t per_point,
                      float *dirs);
+/* VMM<3,8> built from 40 raw network outputs per point (integrator/guided/distribution.h:279-345, train.h:50-79 with
+ * common3d: 8 x (lambda, kappa, mean vector)): mixture pdf at direction wi[n*3] (pdf may be NULL) and one sampled
+ * direction per point with the stream setSeed(seed[i], 1) (sample_dir may be NULL). */
+int wost3_vmm_pdf_sample(int device, const float *raw, const float *wi, const uint64_t *seed, int32_t n, float *pdf,
+                         float *sample_dir);
+/* compute_dL_doutput_divergence with common3d::GuidedOutput (train.h:492-553) around VMM<3,N>::gradients_probability
+ * (distribution.h:348-421): raw and dl_draw 41 floats per sample (the selection logit last); record dir[n*3], li, dir_pdf,
+ * on_neumann (may be NULL), normal[n*3]; likelihood may be NULL. */
+int wost3_vmm_loss_gradients(int device, const float *raw, const float *dir, const float *li, const float *dir_pdf,
+                             const uint8_t *on_neumann, const float *normal, int32_t n, float loss_scale, float *dl_draw,
+                             float *likelihood);
 /* renderDirichletSDF / renderSilhouetteSDF / renderSource with DIM = 3 (integrator/common.h:52-163): one query per pixel
  * of the frame at its evaluation point; which_mesh as above; out_dist width*height floats (+inf without that mesh),
  * out_rgb width*height*3 floats (zeros without a source term) */

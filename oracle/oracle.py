@@ -425,6 +425,30 @@ class Oracle:
         self.lib.wo3_vmf_sample_batch(_fp(k), _fp(m), s.ctypes.data_as(C.POINTER(C.c_uint64)), len(k), per_point, _fp(out))
         return out
 
+    def vmm3_pdf_sample(self, raw, wi, seed):
+        r = np.ascontiguousarray(raw, dtype=np.float32)
+        w = np.ascontiguousarray(wi, dtype=np.float32)
+        s = np.ascontiguousarray(seed, dtype=np.uint64)
+        n = len(w)
+        pdf = np.zeros(n, dtype=np.float32)
+        d = np.zeros((n, 3), dtype=np.float32)
+        self.lib.wo3_vmm_pdf_sample(_fp(r), _fp(w), s.ctypes.data_as(C.POINTER(C.c_uint64)), n, _fp(pdf), _fp(d))
+        return pdf, d
+
+    def vmm3_loss_gradients(self, raw41, dirs, li, dir_pdf, on_neumann, normal, loss_scale=128.0):
+        r = np.ascontiguousarray(raw41, dtype=np.float32)
+        d = np.ascontiguousarray(dirs, dtype=np.float32)
+        l = np.ascontiguousarray(li, dtype=np.float32)
+        p = np.ascontiguousarray(dir_pdf, dtype=np.float32)
+        o = np.ascontiguousarray(on_neumann, dtype=np.uint8)
+        nn = np.ascontiguousarray(normal, dtype=np.float32)
+        n = len(l)
+        g = np.zeros((n, 41), dtype=np.float32)
+        lk = np.zeros(n, dtype=np.float32)
+        self.lib.wo3_vmm_loss_gradients(_fp(r), _fp(d), _fp(l), _fp(p), o.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(nn), n,
+                                        C.c_float(loss_scale), _fp(g), _fp(lk))
+        return g, lk
+
     def green_ball3(self, R, r):
         e, nrm, pdf = C.c_float(), C.c_float(), C.c_float()
         self.lib.wo3_green_ball.restype = None

@@ -183,6 +183,12 @@ float wo3_vmf_eval(float kappa, float cos_theta);
 void wo3_vmf_sample(float kappa, const float mu[3], wo_pcg *rng, float out[3]);
 int wo3_vmf_eval_batch(const float *kappa, const float *cos_theta, int n, float *pdf);
 int wo3_vmf_sample_batch(const float *kappa, const float *mu, const uint64_t *seed, int n, int per_point, float *dirs);
+/* VMM<3,8> (distribution.h:279-436): raw = 40 floats per point (8 x (lambda, kappa, mean vector)); loss gradients over 41
+ * (with the selection logit), reference record dir[3], Li, dirPdf, onNeumann, normal[3] */
+int wo3_vmm_pdf_sample(const float *raw, const float *wi, const uint64_t *seed, int n, float *pdf, float *dir);
+int wo3_vmm_loss_gradients(const float *raw, const float *dir, const float *li, const float *dir_pdf,
+                           const unsigned char *on_neumann, const float *normal, int n, float loss_scale,
+                           float *dl_draw, float *likelihood);
 int wo3_render_sdf(const wo3_scene *sc, const wo_settings *st, int which, float *out_dist);
 int wo3_render_source(const wo3_scene *sc, const wo_settings *st, float *out_rgb);
 

@@ -703,3 +703,145 @@ int wo3_vmf_sample_batch(const float *kappa, const float *mu, const uint64_t *se
     }
     return 0;
 }
+
+/* ---- VMM<3,8>: the mixture of eight vMF lobes the 3-D guided integrator samples from (integrator/guided/distribution.h:
+ * 279-436, train.h:60-105,492-553 with common3d: 5 numbers per lobe -- lambda, kappa, mean vector -- and the selection
+ * logit: 41 network outputs).  Same conventions as the 2-D mixture (oracle/wost_vmm.c). ----------------------------- */
+#define WV3_NCOMP 8
+typedef struct { float lambda, kappa, mu[3], mo[3]; } wv3_lobe;
+typedef struct { wv3_lobe sg[WV3_NCOMP]; float weight[WV3_NCOMP], total; } wv3_vmm;
+
+static float wv3_clampf(float v, float lo, float hi) { return fmaxf(fminf(v, hi), lo); }
+
+static void wv3_build(wv3_vmm *m, const float *data)
+{
+    m->total = 0.0f;
+    for (int i = 0; i < WV3_NCOMP; ++i) {
+        const float *d = data + 5 * i;
+        wv3_lobe *g = &m->sg[i];
+        g->lambda = wo_expf(wv3_clampf(d[0], -10.0f, 15.0f));      /* train.h:60-72, Exponential */
+        g->kappa = wo_expf(wv3_clampf(d[1], -10.0f, 15.0f));
+        /* Eigen normalized(): v / sqrt(z) when z = squaredNorm > 0, else v unchanged (see wost_vmm.c) */
+        const float z = (d[2] * d[2] + d[3] * d[3]) + d[4] * d[4], n = sqrtf(z);
+        for (int c = 0; c < 3; ++c) { g->mo[c] = d[2 + c]; g->mu[c] = z > 0.0f ? d[2 + c] / n : d[2 + c]; }
+        m->total += g->lambda;
+    }
+    for (int i = 0; i < WV3_NCOMP; ++i) m->weight[i] = m->sg[i].lambda / m->total;
+}
+
+static float wv3_lobe_pdf(const wv3_lobe *g, const float w[3])
+{
+    return wo3_vmf_eval(g->kappa, (w[0] * g->mu[0] + w[1] * g->mu[1]) + w[2] * g->mu[2]);
+}
+
+static float wv3_pdf(const wv3_vmm *m, const float w[3])
+{
+    float val = 0.0f;
+    for (int i = 0; i < WV3_NCOMP; ++i) val += m->weight[i] * wv3_lobe_pdf(&m->sg[i], w);
+    return val;
+}
+
+/* VMM<3,N>::sample (:333-345): one draw picks the lobe, two more the direction */
+static void wv3_sample(const wv3_vmm *m, wo_pcg *rng, float out[3])
+{
+    float u = wo_pcg_next_float(rng);
+    for (int i = 0; i < WV3_NCOMP; ++i) {
+        if (u < m->weight[i]) { wo3_vmf_sample(m->sg[i].kappa, m->sg[i].mu, rng, out); return; }
+        u -= m->weight[i];
+    }
+    wo3_vmf_sample(m->sg[0].kappa, m->sg[0].mu, rng, out);
+}
+
+int wo3_vmm_pdf_sample(const float *raw, const float *wi, const uint64_t *seed, int n, float *pdf, float *dir)
+{
+    for (int i = 0; i < n; ++i) {
+        wv3_vmm m;
+        wv3_build(&m, raw + 40 * (size_t)i);
+        if (pdf) pdf[i] = wv3_pdf(&m, wi + 3 * (size_t)i);
+        if (dir) {
+            wo_pcg rng;
+            wo_pcg_set_seed(&rng, seed[i], 1);
+            wv3_sample(&m, &rng, dir + 3 * (size_t)i);
+        }
+    }
+    return 0;
+}
+
+/* compute_dL_doutput_divergence with GuidedOutput = common3d (train.h:492-553) around
+ * VMM<3,N>::gradients_probability (distribution.h:348-421).  raw / dl_draw: 41 floats per sample. */
+int wo3_vmm_loss_gradients(const float *raw, const float *dir, const float *li, const float *dir_pdf,
+                           const unsigned char *on_neumann, const float *normal, int n, float loss_scale,
+                           float *dl_draw, float *likelihood)
+{
+    const float eps = 1e-5f;                                    /* M_EPSILON */
+    const float scale = loss_scale / (float)n;
+    for (int t = 0; t < n; ++t) {
+        const float *data = raw + 41 * (size_t)t;
+        float *grad = dl_draw + 41 * (size_t)t;
+        wv3_vmm m;
+        wv3_build(&m, data);
+        const float w[3] = { dir[3 * t], dir[3 * t + 1], dir[3 * t + 2] };
+        const int on_n = on_neumann ? on_neumann[t] : 0;
+        float r[3] = { 0.0f, 0.0f, 0.0f };
+        if (on_n) {   /* reflect(wi, n) = wi - 2 (wi . n) n */
+            const float *nn = normal + 3 * (size_t)t;
+            const float d = (w[0] * nn[0] + w[1] * nn[1]) + w[2] * nn[2];
+            for (int c = 0; c < 3; ++c) r[c] = w[c] - 2 * d * nn[c];
+        }
+        float pk[WV3_NCOMP], pkr[WV3_NCOMP];
+        for (int k = 0; k < WV3_NCOMP; ++k) {
+            pk[k] = wv3_lobe_pdf(&m.sg[k], w);
+            pkr[k] = on_n ? wv3_lobe_pdf(&m.sg[k], r) : 0.0f;
+        }
+        float probability = 0.0f;
+        for (int sg = 0; sg < WV3_NCOMP; ++sg) {
+            const wv3_lobe *g = &m.sg[sg];
+            const float lambda = g->lambda, kappa = g->kappa;
+            const float ox = g->mo[0], oy = g->mo[1], oz = g->mo[2];
+            const float vmf = pk[sg];
+            probability += m.weight[sg] * vmf;
+            float vmfr = 0.0f;
+            if (on_n) { vmfr = pkr[sg]; probability += m.weight[sg] * vmfr; }
+            float dF_dlambda = (vmf + vmfr) * (m.total - lambda) / (m.total * m.total);
+            for (int k = 0; k < WV3_NCOMP; ++k) {
+                if (k == sg) continue;
+                dF_dlambda -= m.weight[k] / m.total * pk[k];
+                if (on_n) dF_dlambda -= m.weight[k] / m.total * pkr[k];
+            }
+            /* 1/kappa - coth(kappa), below 1 by the reference's fitted parabola (:389-397) */
+            float ik;
+            if (kappa < 1) ik = 0.000962f + -0.344883f * kappa + 0.030147f * (kappa * kappa);
+            else ik = 1 / kappa - (1 + wo_expf(-2 * kappa)) / (1 - wo_expf(-2 * kappa));
+            float dF_dkappa = m.weight[sg] * vmf * ((w[0] * g->mu[0] + w[1] * g->mu[1] + w[2] * g->mu[2]) + ik);
+            if (on_n) dF_dkappa += m.weight[sg] * vmfr * ((r[0] * g->mu[0] + r[1] * g->mu[1] + r[2] * g->mu[2]) + ik);
+            const float n2 = (ox * ox + oy * oy) + oz * oz;
+            float denom = n2 * sqrtf(n2);                       /* pow(., 1.5f) */
+            if (denom < eps) denom = eps;
+            const float x = w[0], y = w[1], z = w[2], xr = r[0], yr = r[1], zr = r[2];
+            float dF_dx = m.weight[sg] * vmf * kappa * (-ox * oy * y - ox * oz * z + (oy * oy) * x + (oz * oz) * x) / denom;
+            if (on_n) dF_dx += m.weight[sg] * vmfr * kappa * (-ox * oy * yr - ox * oz * zr + (oy * oy) * xr + (oz * oz) * xr) / denom;
+            float dF_dy = m.weight[sg] * vmf * kappa * (-ox * oy * x - oy * oz * z + (ox * ox) * y + (oz * oz) * y) / denom;
+            if (on_n) dF_dy += m.weight[sg] * vmfr * kappa * (-ox * oy * xr - oy * oz * zr + (ox * ox) * yr + (oz * oz) * yr) / denom;
+            float dF_dz = m.weight[sg] * vmf * kappa * (-ox * oz * x - oy * oz * y + (ox * ox) * z + (oy * oy) * z) / denom;
+            if (on_n) dF_dz += m.weight[sg] * vmfr * kappa * (-ox * oz * xr - oy * oz * yr + (ox * ox) * zr + (oy * oy) * zr) / denom;
+            grad[5 * sg + 0] = dF_dlambda; grad[5 * sg + 1] = dF_dkappa;
+            grad[5 * sg + 2] = dF_dx; grad[5 * sg + 3] = dF_dy; grad[5 * sg + 4] = dF_dz;
+        }
+        const float Li = li[t];
+        const float dirPdf = dir_pdf[t] + eps;
+        const float guidePdf = probability + eps;
+        const float prefix = -Li / dirPdf / guidePdf * scale;
+        if (likelihood) likelihood[t] = -Li / dirPdf * wo_logf(guidePdf);
+        for (int sg = 0; sg < WV3_NCOMP; ++sg) {
+            grad[5 * sg + 0] = prefix * grad[5 * sg + 0] * wo_expf(wv3_clampf(data[5 * sg + 0], -10.0f, 15.0f));
+            grad[5 * sg + 1] = prefix * grad[5 * sg + 1] * wo_expf(wv3_clampf(data[5 * sg + 1], -10.0f, 15.0f));
+            for (int c = 2; c < 5; ++c) grad[5 * sg + c] = prefix * grad[5 * sg + c];
+        }
+        /* selection probability (:541-552): uniformSampleSpherePDF<3> = 1/4pi, hemisphere 1/2pi; Logistic activation */
+        const float e = 0.2f;
+        const float uni = on_n ? 1.0f / WO_2PI : 1.0f / WO_4PI;
+        const float sgm = 1.0f / (1.0f + wo_expf(-data[40]));
+        grad[40] = scale * (-e) * Li * (guidePdf - uni) / (dirPdf * dirPdf) * (sgm * (1 - sgm));
+    }
+    return 0;
+}
