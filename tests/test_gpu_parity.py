@@ -159,6 +159,13 @@ def test_kernel_variants_do_not_change_results(oracle, ladybug, opts):
     _assert_same_solve(oracle, ladybug, 56, 48, 6, 32, 1.0, **opts)
 
 
+def test_ground_truth_sample_count(oracle, ladybug):
+    """the reference's ground-truth configuration runs 65 536 samples per pixel (data/ladybug/gt.json): a pixel's sample
+    counter, the per-launch 16-bit statistics and hundreds of rounds, on a frame the oracle finishes in seconds"""
+    ref = _assert_same_solve(oracle, ladybug, 8, 8, 65536, 64, 1.0)
+    assert ref["walks_started"] == 64 * 65536
+
+
 @pytest.mark.parametrize("block_size", [64, 128, 256])
 def test_block_size_does_not_change_results(oracle, ladybug, block_size):
     _assert_same_solve(oracle, ladybug, 40, 48, 5, 24, 1.0, block_size=block_size)
