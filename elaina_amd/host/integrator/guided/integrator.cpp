@@ -40,6 +40,9 @@ wost_net_config network_config_from_json(const json &n)
         throw std::runtime_error("network.optimizer: this build implements Ema{Adam}");
     const json adam = json_get_or_throw<json>(opt, "nested");
     if (json_get_or_throw<string>(adam, "otype") != "Adam") throw std::runtime_error("network.optimizer.nested: Adam expected");
+    // tiny-cuda-nn's Adam has an AdaBound variant behind this switch; the shipped configurations turn it off
+    if (json_get_optional<bool>(adam, "adabound", false))
+        throw std::runtime_error("network.optimizer.nested.adabound: the AdaBound variant is not implemented");
     wost_net_config c{};
     c.n_levels = json_get_or_throw<int>(enc, "n_levels");
     c.n_features_per_level = json_get_or_throw<int>(enc, "n_features_per_level");
