@@ -76,10 +76,9 @@ struct DevMesh3 {
     const DevTri *flat;      // [n_tris] original order
     const int32_t *flatVerts;// [n_tris * 3] vertex ids, original order
     const DevEdge3 *edges;   // [n_edges]
-    const int32_t *triEdges; // [slots * 3] the edge records of a triangle's three sides (-1: degenerate side, or an edge
-                             // that an earlier slot already lists: every edge is tested from one triangle only)
     const float4 *slotEdges; // [slots * 3 * 4] the silhouette test's operands of side k of the triangle in a slot, one record:
-                             // (pa, kind) (pb, -) (n0, -) (n1, -); kind 0 = not listed here, 1 = two triangles, 2 = boundary
+                             // (pa, kind) (pb, -) (n0, -) (n1, -); kind 0 = degenerate side or an edge that an earlier slot
+                             // already lists (every edge is tested from one triangle only), 1 = two triangles, 2 = boundary
     const float4 *cones;     // [n_nodes * 6] normal cones of the four children: ax[4] ay[4] az[4] cos[4] sin[4] rad[4]
     int32_t n_tris, n_edges, levels, first_leaf, emissive;
     // boxes over runs of consecutive ORIGINAL triangle indices (sample_in_sphere3_tree): level l holds, per run of
@@ -354,35 +353,6 @@ __device__ unsigned long long g_prof3[16];
 // silhouette: an edge lies inside its triangle, a triangle inside its (padded) box, so boxes farther than the best
 // silhouette edge so far cannot improve it; a leaf tests the three sides of its four triangles with the body of the
 // flat loop (an edge shared by two triangles is simply tested twice).  The result is a minimum: order-free.
-__device__ __forceinline__ void silhouette_edge_test(const DevMesh3 &m, int e, V3 q, float &best2, bool &found)
-{
-    const DevEdge3 E = m.edges[e];
-    const V3 pa = ld3(E.pa), pb = ld3(E.pb), ev = pb - pa;
-    const float ee = dot3(ev, ev);
-    float t = ee > 0.0f ? dot3(q - pa, ev) / ee : 0.0f;
-    t = fminf(fmaxf(t, 0.0f), 1.0f);
-    const V3 pt = madd3(pa, t, ev), view = q - pt;
-    const float d2 = dot3(view, view);
-    if (d2 > best2) return;
-    bool is_sil = E.t1 < 0;
-    if (!is_sil) {
-        const V3 n0 = ld3(m.flat[E.t0].n), n1 = ld3(m.flat[E.t1].n);
-        const float d = sqrtf(d2);
-        if (d <= WOST_SIL_PRECISION) {
-            const float det = dot3(normalize3(ev), cross3(n0, n1));
-            is_sil = (-det > WOST_SIL_PRECISION);
-        } else {
-            const V3 vd = v3(view.x / d, view.y / d, view.z / d);
-            const float dot0 = dot3(vd, n0), dot1 = dot3(vd, n1);
-            is_sil = !(fabsf(dot0) <= WOST_SIL_PRECISION || fabsf(dot1) <= WOST_SIL_PRECISION) && (dot0 * dot1 < 0.0f);
-        }
-    }
-    if (is_sil && (d2 < best2 || !found)) {
-        best2 = d2;
-        found = true;
-    }
-}
-
 // Normal cone of a subtree (Sawhney et al. 2023, spatialized normal cone hierarchy; the 2-D twin is
 // cone_may_hold_silhouette in wost_device.h): every normal of a triangle next to an edge of the subtree lies within
 // `half` of the axis, every point of those edges within `rad` of c.  A silhouette edge needs view . n0 and view . n1 of
@@ -406,7 +376,7 @@ __device__ __forceinline__ bool cone3_may_hold_silhouette(float ax, float ay, fl
     return fabsf(cs) <= sin_sum + 1e-3f;
 }
 
-// silhouette_edge_test on the packed record of a leaf slot (the same operands, one load instead of three dependent ones)
+// the flat loop's edge test on the packed record of a leaf slot (its operands in one load instead of three dependent ones)
 __device__ __forceinline__ void silhouette_record_test(float4 r0, float4 r1, float4 r2, float4 r3, V3 q, float &best2, bool &found)
 {
     if (r0.w == 0.0f) return;
@@ -1330,7 +1300,7 @@ struct HostMesh3 {
     int32_t n_tris = 0, n_edges = 0, levels = 1, first_leaf = 1;
     bool emissive = false;
     std::vector<float> nodes, tri, colors, cones, slotEdges;
-    std::vector<int32_t> triOrig, triVerts, flatVerts, triEdges;
+    std::vector<int32_t> triOrig, triVerts, flatVerts;
     std::vector<float> obox;          // index-ordered run boxes (emissive meshes above the flat limit)
     int32_t obox_off[12] = {0}, obox_levels = 0;
     std::vector<DevTri> flat;
@@ -1445,7 +1415,6 @@ static int build_mesh3(const wost3_mesh_desc &d, HostMesh3 *out)
     h.tri.assign(n_slots * 12, 1.0e18f);
     h.triOrig.assign(n_slots, kFarIndex);
     h.triVerts.assign(n_slots * 3, 0);
-    h.triEdges.assign(n_slots * 3, -1);
     std::vector<char> edge_listed(h.edges.size(), 0);
     h.slotEdges.assign(n_slots * 3 * 16, 0.0f);
     for (int k = 0; k < n; ++k) {
@@ -1454,7 +1423,6 @@ static int build_mesh3(const wost3_mesh_desc &d, HostMesh3 *out)
             const int32_t e = edge_of[3 * (size_t)o + c];
             if (e >= 0 && !edge_listed[e]) {
                 edge_listed[e] = 1;
-                h.triEdges[3 * (size_t)k + c] = e;
                 const DevEdge3 &E = h.edges[e];
                 float *r = &h.slotEdges[(3 * (size_t)k + c) * 16];
                 for (int x = 0; x < 3; ++x) {
@@ -1891,7 +1859,6 @@ static int upload_mesh3(const wost3_mesh_desc &d, DeviceMesh3 &s)
     W3_TRY(upload3(s.allocs, h.flat.data(), h.flat.size(), &v.flat));
     W3_TRY(upload3(s.allocs, h.edges.data(), h.edges.size(), &v.edges));
     W3_TRY(upload3(s.allocs, h.flatVerts.data(), h.flatVerts.size(), &v.flatVerts));
-    W3_TRY(upload3(s.allocs, h.triEdges.data(), h.triEdges.size(), &v.triEdges));
     W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.cones.data()), h.cones.size() / 4, &v.cones));
     W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.slotEdges.data()), h.slotEdges.size() / 4, &v.slotEdges));
     W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.obox.data()), h.obox.size() / 4, &v.obox));
