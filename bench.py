@@ -342,6 +342,66 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
     return {"out": out, "field": field, "problem": problem, "depth": depth, "eps": eps}
 
 
+def icosphere(subdiv, radius):
+    """unit icosphere subdivided `subdiv` times (20 * 4^subdiv triangles, outward normals), scaled"""
+    import numpy as np
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1),
+         (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    verts = [np.asarray(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+        for a, b, c in f:
+            m = []
+            for x, y in ((a, b), (b, c), (c, a)):
+                k = (min(x, y), max(x, y))
+                if k not in cache:
+                    w = verts[x] + verts[y]
+                    verts.append(w / np.linalg.norm(w))
+                    cache[k] = len(verts) - 1
+                m.append(cache[k])
+            nf += [(a, m[0], m[2]), (b, m[1], m[0]), (c, m[2], m[1]), (m[0], m[1], m[2])]
+        f = nf
+    return (np.asarray(verts) * radius).astype(np.float32), np.asarray(f, np.int32)
+
+
+def run_uniform3d(env, args):
+    """SURVEY 8 f.3, the 3-D uniform integrator, synthetic scenes (the reference ships no 3-D data): (a) a Dirichlet
+    icosphere of 1280 triangles with the harmonic boundary values x y + z, the slice z = 0.1 (tools/scratch/bench3d.py's scene); (b) a Dirichlet ball
+    inside a zero-flux Neumann shell of 1280 triangles (silhouette and ray queries on the tree).  One timed solve each
+    after a warm-up solve; a band of (a) against the oracle."""
+    import numpy as np
+    from elaina_amd import UniformIntegratorSettings
+    from elaina_amd.integrator3d import Problem3, UniformIntegrator3
+    out = {}
+    V, T = icosphere(3, 1.0)
+    col = np.repeat((V[:, 0] * V[:, 1] + V[:, 2]).astype(np.float32)[:, None], 6, axis=1)
+    ball = {"d_verts": V, "d_tris": T, "d_colors": col, "n_verts": None, "n_tris": None, "n_colors": None,
+            "probe": (0.6, (0.0, 0.0, 0.1), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0)), "dirichlet_intensity": 1.0, "neumann_intensity": 1.0}
+    Vi, Ti = icosphere(2, 0.45)
+    shell = {"d_verts": Vi, "d_tris": Ti, "d_colors": np.repeat(Vi[:, :1], 6, axis=1).astype(np.float32), "n_verts": V, "n_tris": T,
+             "n_colors": np.zeros((len(V), 6), np.float32), "probe": (0.7, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0)),
+             "dirichlet_intensity": 1.0, "neumann_intensity": 1.0}
+    for name, sd, frame, spp in (("dirichlet_icosphere_1280", ball, 512, 64), ("neumann_shell_1280", shell, 512, 16)):
+        it = UniformIntegrator3(Problem3.from_dict(sd), UniformIntegratorSettings((frame, frame), spp, 64, 2e-3), device=env.local)
+        it.solve()
+        it.solve()
+        st = it.last_stats
+        e = {"workload": "%s %dx%d %d spp depth 64 eps 2e-3" % (name, frame, frame, spp), "walk_steps": float(st["walk_steps"]),
+             "kernel_ms": float(st["kernel_ms"]), "value": st["walk_steps"] / (st["kernel_ms"] * 1e-3), "unit": "walk-steps/s"}
+        if name.startswith("dirichlet") and not args.no_cpu_baseline:
+            from oracle.oracle import Oracle
+            b, e_ = band_of(frame, 4)
+            ref = Oracle().solve3(sd, frame, frame, spp, 64, 2e-3, pixel_begin=b, pixel_end=e_, threads=os.cpu_count() or 1)
+            e["rel_l2_vs_oracle"] = rel_l2(it.solution.reshape(-1, 3)[b:e_], ref["field"])
+            e["rel_l2_band"] = "rows %d..%d" % (b // frame, e_ // frame)
+        it.close()
+        out[name] = e
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -442,6 +502,7 @@ def main():
             if uniform_field is not None:
                 e4h["rel_l2_vs_uniform_field"] = rel_l2(r4h["field"].cpu().numpy(), uniform_field.cpu().numpy())
             extras["cfg4_f16"] = e4h
+            extras["uniform3d"] = run_uniform3d(env, args)
             if uniform_field is not None:
                 # SURVEY 8c, guided gate: against a 4096-spp field of the uniform integrator (bit-exact against the
                 # oracle at any spp) the guided estimator must not be noisier than the uniform one at equal spp

@@ -1,0 +1,8 @@
+"""the 3-D entries of bench.py alone (developer scratch)"""
+import os, sys, json
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
+import bench
+class Env: local = 0
+class Args: no_cpu_baseline = True
+for k in range(3):
+    print(json.dumps({n: (round(e["kernel_ms"], 1), "%.3g" % e["value"]) for n, e in bench.run_uniform3d(Env, Args).items()}), flush=True)
