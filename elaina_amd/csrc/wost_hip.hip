@@ -397,10 +397,21 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
         } else {
             // ---- traversal phase: every traversing lane visits one node ----
             ++trav_trips;
-            for (int b = 0; b < P.trav_burst; ++b) {
-                if (mode == MODE_TRAV) {
-                    S.visits++;
-                    if (!trav_visit(P.dm, L.px, L.py, T, stk)) mode = MODE_WAIT;
+            if (P.trav_burst == 3) {
+                // the default burst, unrolled: no loop counter, and the compiler may start a visit's node load early
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    if (mode == MODE_TRAV) {
+                        S.visits++;
+                        if (!trav_visit(P.dm, L.px, L.py, T, stk)) mode = MODE_WAIT;
+                    }
+                }
+            } else {
+                for (int b = 0; b < P.trav_burst; ++b) {
+                    if (mode == MODE_TRAV) {
+                        S.visits++;
+                        if (!trav_visit(P.dm, L.px, L.py, T, stk)) mode = MODE_WAIT;
+                    }
                 }
             }
         }
