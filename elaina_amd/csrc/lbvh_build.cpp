@@ -427,7 +427,9 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
             double rad = 0.0;
             for (size_t i = 0; i + 1 < a.pts.size(); i += 2)
                 rad = std::max(rad, std::hypot(a.pts[i] - (double)cx, a.pts[i + 1] - (double)cy));
-            const float radf = (float)(rad * (1.0 + 1e-6) + (double)ext * 0x1p-18);
+            // padded by more than the silhouette test's absolute precision (10^-3): a query within that distance of a
+            // vertex takes the test's near branch, which the cone argument does not cover -- it must count as inside
+            const float radf = (float)(rad * (1.0 + 1e-6) + (double)ext * 0x1p-18 + 2.0e-3);
             if (a.open || a.ang.empty()) { set_cone(parent, j, 1.0f, 0.0f, -1.0f, 0.0f, radf); return; }
             std::sort(a.ang.begin(), a.ang.end());
             double gap = a.ang.front() + two_pi - a.ang.back(), gap_end = a.ang.front() + two_pi;

@@ -47,6 +47,7 @@ struct DevMesh {
     int32_t levels;
     int32_t first_leaf;
     int32_t emissive;        // any non-zero colour
+    float far2;              // squared distance from the mesh beyond which box pruning needs the relative slack (trav_visit<true>)
     // boxes over runs of consecutive ORIGINAL indices (sample_in_sphere_tree): level l holds one box (lo.x, lo.y,
     // hi.x, hi.y) per run of 4^(l+1) segments, obox + obox_off[l]; obox_levels = 0: not built
     const float4 *obox;
@@ -153,6 +154,11 @@ __device__ __forceinline__ void cswap(uint32_t &a, uint32_t &b)
 // the node position is recovered from the position of the last visited node (which always
 // lies below the entry's parent in a depth-first traversal):
 // parent pos = pos >> 2*(level - entry_level + 1).
+// relative slack of the box-against-best comparisons of trav_visit<true>: 1 - 2^-17.  The box distance and the exact segment
+// distance each carry a few 10^-7 of relative rounding; a looser slack (10^-4 was tried) is as exact but opens every box of
+// the mesh for a query thousands of scene sizes away -- 73 ms for the 64 steps of ONE leaked walker on ladybug
+constexpr float kBoxShrink = 0.99999237060546875f;
+
 struct Trav {
     int32_t level;      // level of the node to visit next
     int32_t pos;        // position of that node inside its level
@@ -257,7 +263,13 @@ __device__ __forceinline__ void trav_leaf_ties(const DevMesh &m, Trav &T, int sl
 // the lowest ORIGINAL index, so the answer does not depend on the tree or the visiting order.
 // (An LDS mirror of the top levels of the tree was measured at +-0 % in round 1 and cost a flat
 // load path with its own branch per visit; the top of the tree is L1-resident anyway.)
-template <class STK = LdsColumn>
+// SLACK = true prunes boxes with a relative slack as well (their distance shrunk by 10^-4): box and segment distances come
+// from different formulas, and for a query far outside the mesh one ulp of the squared distance exceeds the absolute
+// padding of the boxes -- a closer or tying segment would be skipped (found by tools/scratch/fuzz_parity.py: probes and
+// escaped walkers 50 scene sizes away).  Within DevMesh::far2 of the mesh the padding covers the rounding and the plain
+// form is exact; it is the one the walk kernels run in their lane machines, where a single extra live register costs a
+// quarter of the throughput; a query that starts beyond far2 is answered by closest_point_far instead.
+template <bool SLACK = false, class STK = LdsColumn>
 __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy, Trav &T, const STK &stk)
 {
     const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
@@ -267,12 +279,13 @@ __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy,
     // plain scalar fp32: on gfx950 a packed v_pk_fma_f32 costs two v_fma_f32 (tools/micro/op_rate.hip,
     // profiles/r02_micro_*), has no |x| source modifier and needs hazard nops; the scalar form
     // spends 12 instructions per child with the absolute values folded into the subtractions
-    const float d0 = obb_d2(CX.x, CY.x, UX.x, UY.x, HL.x, HW.x, qx, qy);
-    const float d1 = obb_d2(CX.y, CY.y, UX.y, UY.y, HL.y, HW.y, qx, qy);
-    const float d2 = obb_d2(CX.z, CY.z, UX.z, UY.z, HL.z, HW.z, qx, qy);
-    const float d3 = obb_d2(CX.w, CY.w, UX.w, UY.w, HL.w, HW.w, qx, qy);
     const float bd = T.best.d2;
     const bool at_leaf = T.level == m.levels;
+    const float shrink = (SLACK && !at_leaf) ? kBoxShrink : 1.0f;
+    const float d0 = SLACK ? obb_d2(CX.x, CY.x, UX.x, UY.x, HL.x, HW.x, qx, qy) * shrink : obb_d2(CX.x, CY.x, UX.x, UY.x, HL.x, HW.x, qx, qy);
+    const float d1 = SLACK ? obb_d2(CX.y, CY.y, UX.y, UY.y, HL.y, HW.y, qx, qy) * shrink : obb_d2(CX.y, CY.y, UX.y, UY.y, HL.y, HW.y, qx, qy);
+    const float d2 = SLACK ? obb_d2(CX.z, CY.z, UX.z, UY.z, HL.z, HW.z, qx, qy) * shrink : obb_d2(CX.z, CY.z, UX.z, UY.z, HL.z, HW.z, qx, qy);
+    const float d3 = SLACK ? obb_d2(CX.w, CY.w, UX.w, UY.w, HL.w, HW.w, qx, qy) * shrink : obb_d2(CX.w, CY.w, UX.w, UY.w, HL.w, HW.w, qx, qy);
     // ---- last level: the children are segments, the distances are exact.  Branch-free in
     // the common case (one strict winner); exact ties take the rare path.
     {
@@ -327,7 +340,7 @@ __device__ __forceinline__ Closest closest_point(const DevMesh &m, float qx, flo
 {
     Trav T = trav_begin(seed);
     const LdsColumn stk{stack, (uint32_t)stride};
-    while (trav_visit(m, qx, qy, T, stk)) {
+    while (trav_visit<true>(m, qx, qy, T, stk)) {
     }
     return T.best;
 }

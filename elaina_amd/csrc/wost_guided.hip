@@ -855,7 +855,7 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
             // ---- traversal phase: every traversing lane visits nodes ----
             for (int b = 0; b < P.trav_burst; ++b) {
                 if (mode == MODE_TRAV) {
-                    if (!trav_visit(P.dm, x, y, T, stk)) mode = MODE_WAIT;
+                    if (!trav_visit<true>(P.dm, x, y, T, stk)) mode = MODE_WAIT;     // the form that is exact at any distance from the mesh (wost_device.h)
                 }
             }
         }

@@ -81,6 +81,10 @@ struct RoundParams {
     int32_t trav_burst;    // node visits per scheduling decision in the traversal phase
     int32_t lane_shift;    // one walker per 2^lane_shift lanes (0 = every lane)
     uint32_t *cursor;      // REFILL launches: next unread slot of the input queue
+    // walkers that the plain kernel cannot serve exactly (a closest-point query that starts beyond dm.far2) leave the launch
+    // at that point and are queued from the TOP of the output queue downwards: slot out_capacity - 1 - k, k from *count_far
+    uint32_t *count_far;
+    uint32_t out_capacity;
 };
 
 struct InitParams {
@@ -274,7 +278,12 @@ __device__ __forceinline__ void load_lane(const WalkQueue &q, uint32_t slot, Lan
 // is complete writes it out and takes the next unread slot of the input queue (one atomic per
 // wave), so the whole solve is ONE launch and no lane idles while work is left -- the
 // low-sample-count path (time-to-1spp), where regeneration cannot fill the lanes.
-template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, bool REFILL = false, bool SOURCE = false>
+// SLACK = false, the kernel of every ordinary launch: node visits in the plain form, exact within dm.far2 of the Dirichlet mesh.
+// A walker whose query starts beyond that (it leaked through a corner of the boundary or escaped through an open one, or the
+// probe looks at the scene from afar) stops there, untouched, and goes to the far end of the output queue; the host runs those
+// few walkers through the SLACK = true instantiation -- node visits exact at any distance (trav_visit<true>), which costs this
+// kernel a quarter of its throughput: more visits and, above all, registers -- for the length of a walk and returns them.
+template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, bool REFILL = false, bool SOURCE = false, bool SLACK = false>
 __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(RoundParams P)
 {
     extern __shared__ uint32_t lds_stack[];       // the traversal stack columns, one per lane
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
     // lane's query to completion in lock step, each trip of the loop runs ONE of two bodies
     // -- "visit one node" or "finish a step and start the next query" -- whichever more lanes
     // of the wave are ready for (weighted), while the lanes of the other kind accumulate.
-    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5 };
+    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5, MODE_FAR = 6 };
     const bool has_d = P.dm.n_segs > 0;
     int mode = alive ? MODE_WAIT : MODE_DONE;
     bool fresh = true;   // first trip: no finished step yet, only start the query
@@ -381,14 +390,19 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
                 }
                 fresh = false;
                 if (alive && budget > 0) {
-                    S.a += 1u + ((L.depth == 0) ? 0x10000u : 0u);
                     if (!has_d || L.depth == 0) {
                         // depth 0 starts at the same point for every sample of the pixel: cached
+                        S.a += 1u + ((L.depth == 0) ? 0x10000u : 0u);
                         T.best = Closest{L.d0_d2, L.d0_slot};
                         mode = MODE_WAIT;
                     } else {
                         T = trav_begin(slot_candidate(P.dm, L.hint, L.px, L.py));
-                        mode = MODE_TRAV;
+                        if (!SLACK && T.best.d2 > P.dm.far2) {
+                            mode = MODE_FAR;      // not started, not counted: the SLACK launch takes the step from here
+                        } else {
+                            S.a += 1u;
+                            mode = MODE_TRAV;
+                        }
                     }
                 } else {
                     mode = (REFILL && !alive) ? MODE_REFILL : MODE_DONE;
@@ -403,14 +417,14 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
                 for (int b = 0; b < 3; ++b) {
                     if (mode == MODE_TRAV) {
                         S.visits++;
-                        if (!trav_visit(P.dm, L.px, L.py, T, stk)) mode = MODE_WAIT;
+                        if (!trav_visit<SLACK>(P.dm, L.px, L.py, T, stk)) mode = MODE_WAIT;
                     }
                 }
             } else {
                 for (int b = 0; b < P.trav_burst; ++b) {
                     if (mode == MODE_TRAV) {
                         S.visits++;
-                        if (!trav_visit(P.dm, L.px, L.py, T, stk)) mode = MODE_WAIT;
+                        if (!trav_visit<SLACK>(P.dm, L.px, L.py, T, stk)) mode = MODE_WAIT;
                     }
                 }
             }
@@ -424,7 +438,13 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
     }
     // ---- stream compaction of the survivors: ballot + popcount, one atomic per block ------
     const int lane = threadIdx.x & 63;
-    const uint32_t s = block_push(alive && open, P.count_out);
+    const bool far = !SLACK && mode == MODE_FAR;
+    uint32_t s = block_push(alive && open && !far, P.count_out);
+    if (!SLACK) {
+        __syncthreads();      // block_push reuses its shared words
+        const uint32_t k = block_push(alive && open && far, P.count_far);
+        if (far) s = P.out_capacity - 1u - k;
+    }
     if (alive && open) {
         WalkQueue &q = P.out;
         q.pix[s] = pix;
@@ -604,6 +624,17 @@ static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
     if (t.n_segs == 0) return WOST_OK;
     v.n_sil = (int32_t)t.sil.size();
     v.levels = t.levels;
+    {
+        // the boxes are padded by 2^-21 of the largest coordinate; the rounding of a box distance grows with the distance
+        // to the box (about 10^-7 of it): up to one and a half extents from the closest segment the padding covers it
+        float ext = 0.0f;
+        for (int i = 0; i < d.n_segs; ++i)
+            for (int e = 0; e < 2; ++e) {
+                const int32_t vi = d.segs[2 * i + e];
+                ext = std::max(ext, std::max(std::fabs(d.verts[2 * vi]), std::fabs(d.verts[2 * vi + 1])));
+            }
+        v.far2 = 2.25f * ext * ext;
+    }
     v.first_leaf = t.first_leaf;
     v.emissive = 0;
     for (float c : t.flatCol)
@@ -703,6 +734,8 @@ struct wost_context {
     int time_kernels = 1;
     int refill = -1;       // -1 = automatic (few samples per pixel), 0 = never, 1 = always
     uint32_t *cursor = nullptr;
+    hipStream_t far_stream = nullptr;          // the launches that take strayed walkers through the SLACK kernel (run_solve)
+    hipEvent_t far_ev0 = nullptr, far_ev1 = nullptr;
     int n_cus = 256;
 };
 
@@ -745,6 +778,9 @@ static void destroy_ctx(wost_context *c)
     if (c->stats) (void)hipFree(c->stats);
     if (c->field) (void)hipFree(c->field);
     if (c->cursor) (void)hipFree(c->cursor);
+    if (c->far_stream) (void)hipStreamDestroy(c->far_stream);
+    if (c->far_ev0) (void)hipEventDestroy(c->far_ev0);
+    if (c->far_ev1) (void)hipEventDestroy(c->far_ev1);
     if (c->host_count) (void)hipHostFree(c->host_count);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -819,13 +855,16 @@ int wost_create(const wost_scene_desc *scene, const wost_settings *settings, int
         HIP_TRY_C(hipMalloc(&c->queue_mem[i], qbytes));
         carve_queue(c->queue_mem[i], c->n_pixels, c->queue[i]);
     }
-    HIP_TRY_C(hipMalloc((void **)&c->counts, 2 * sizeof(uint32_t)));
+    HIP_TRY_C(hipMalloc((void **)&c->counts, 4 * sizeof(uint32_t)));   // two queue counts, the far count
     HIP_TRY_C(hipMalloc((void **)&c->stats, kStatCopies * sizeof(StatsDev)));
     HIP_TRY_C(hipMalloc((void **)&c->cursor, sizeof(uint32_t)));
     HIP_TRY_C(hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device));
     HIP_TRY_C(hipMalloc((void **)&c->field, c->n_pixels * 3 * sizeof(float)));
-    HIP_TRY_C(hipHostMalloc((void **)&c->host_count, 2 * sizeof(uint32_t)));
+    HIP_TRY_C(hipHostMalloc((void **)&c->host_count, 4 * sizeof(uint32_t)));
     HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY_C(hipStreamCreateWithFlags(&c->far_stream, hipStreamNonBlocking));
+    HIP_TRY_C(hipEventCreateWithFlags(&c->far_ev0, hipEventDisableTiming));
+    HIP_TRY_C(hipEventCreateWithFlags(&c->far_ev1, hipEventDisableTiming));
     HIP_TRY_C(hipEventCreate(&c->ev0));
     HIP_TRY_C(hipEventCreate(&c->ev1));
 #undef HIP_TRY_C
@@ -876,6 +915,45 @@ int wost_set_option(wost_handle h, const char *key, double value)
 
 }  // extern "C"
 
+// the instantiation of the round kernel for a launch
+template <bool SLACK>
+static void launch_round(bool has_src, bool refill, bool ntree, bool emissive, unsigned grid, int bs, size_t lds_round, hipStream_t stream,
+                         const RoundParams &rp)
+{
+    if (has_src) {
+        // problems with a source term: the SOURCE instantiations (one extra stage per step)
+        if (ntree) {
+            if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true, false, true, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
+            else hipLaunchKernelGGL((walk_round_kernel<false, true, false, true, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
+        } else {
+            if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, false, false, true, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
+            else hipLaunchKernelGGL((walk_round_kernel<false, false, false, true, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
+        }
+    } else if (refill) {
+        if (ntree) {
+            if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true, true, false, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
+            else hipLaunchKernelGGL((walk_round_kernel<false, true, true, false, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
+        } else {
+            if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, false, true, false, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
+            else hipLaunchKernelGGL((walk_round_kernel<false, false, true, false, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
+        }
+    } else if (ntree) {
+        if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true, false, false, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
+        else hipLaunchKernelGGL((walk_round_kernel<false, true, false, false, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
+    } else {
+        if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, false, false, false, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
+        else hipLaunchKernelGGL((walk_round_kernel<false, false, false, false, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
+    }
+}
+
+static WalkQueue queue_from(const WalkQueue &q, size_t k)
+{
+    WalkQueue r = q;
+    r.pix += k; r.x0 += k; r.y0 += k; r.px += k; r.py += k; r.rng += k; r.meta += k; r.nx += k; r.ny += k; r.hint += k; r.thp += k;
+    r.sr += k; r.sg += k; r.sb += k; r.d0_d2 += k; r.d0_slot += k;
+    return r;
+}
+
 // the shared solve driver: field_dev indexed by (pix - field_base)
 static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, int32_t shard_index, int32_t shard_count,
                      float *field_dev, int32_t field_base, hipStream_t stream, wost_stats *stats)
@@ -890,7 +968,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     // and pop 1 per inner level: 3L+1 entries
     const int stack_depth = 3 * levels_any + 1;
     const size_t lds = (size_t)stack_depth * bs * sizeof(uint32_t);
-    HIP_TRY(hipMemsetAsync(c->counts, 0, 2 * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(c->counts, 0, 4 * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(c->stats, 0, kStatCopies * sizeof(StatsDev), stream));
 
     const int tiles_x = (c->settings.width + 7) / 8, tiles_y = (c->settings.height + 7) / 8;
@@ -923,9 +1001,11 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     int cur = 0;
     const bool emissive = c->nm.view.n_segs > 0 && c->nm.view.emissive;
     const bool ntree = c->nm.view.n_segs > WOST_FLAT_MAX;
-    while (n_active > 0) {
+    uint32_t pending_far = 0;     // walkers at the far end of queue[cur] that the previous launch could not serve (see below)
+    while (n_active > 0 || pending_far > 0) {
         const int nxt = cur ^ 1;
         HIP_TRY(hipMemsetAsync(c->counts + nxt, 0, sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(c->counts + 2, 0, sizeof(uint32_t), stream));
         RoundParams rp{};
         rp.dm = c->dm.view;
         rp.nm = c->nm.view;
@@ -939,6 +1019,8 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         rp.field = field_dev;
         rp.field_base = field_base;
         rp.stats = c->stats;
+        rp.count_far = c->counts + 2;
+        rp.out_capacity = (uint32_t)c->n_pixels;
         // a slot regenerates its pixel's next sample inside a round, so rounds are long: 256 steps
         // unless the caller chose otherwise (shorter rounds only added launches: 128^2 at 1 spp
         // 0.95 -> 1.39 ms with 8-step rounds)
@@ -949,6 +1031,25 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         rp.wait_weight = (ntree && !c->wait_weight_set) ? 1 : c->wait_weight;
         rp.trav_burst = c->trav_burst;
         const size_t lds_round = lds;
+        // Walkers that left the previous launch at a query beyond the plain kernel's range wait at the far end of its output queue,
+        // which is this launch's input queue.  The SLACK instantiation takes them through max_depth steps -- the walk that strayed
+        // ends within that many -- on a stream of its own, next to this launch, and appends them to the same output queue (both
+        // kernels only read the input queue and claim output slots from one counter).
+        if (pending_far > 0) {
+            c->host_count[3] = pending_far;
+            HIP_TRY(hipMemcpyAsync(c->counts + 3, c->host_count + 3, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipEventRecord(c->far_ev0, stream));                      // the counters are ready
+            HIP_TRY(hipStreamWaitEvent(c->far_stream, c->far_ev0, 0));
+            RoundParams fp = rp;
+            fp.in = queue_from(c->queue[cur], c->n_pixels - pending_far);
+            fp.count_in = c->counts + 3;
+            fp.steps_per_round = std::max(1, c->settings.max_depth);
+            fp.lane_shift = 0;
+            launch_round<true>(c->src.rgb != nullptr, false, ntree, emissive, (unsigned)((pending_far + bs - 1) / bs), bs, lds_round, c->far_stream, fp);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->far_ev1, c->far_stream));
+            ++launches;
+        }
         // When the walkers left fill less than 1/16 of the resident threads, spread them out: the
         // duration of such a launch is the latency of its slowest wave, and a wave is as slow as the
         // longest query among its walkers (config 2's last three launches: 13.1 -> 8.9 ms; with 2 or
@@ -976,42 +1077,25 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
             rp.cursor = c->cursor;
             rp.steps_per_round = 0x7fffffff;
         }
+        // (the last strayed walkers can outlive the ordinary queue: then only their launch runs)
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
-        if (has_src) {
-            // problems with a source term: the SOURCE instantiations (one extra stage per step)
-            if (ntree) {
-                if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-                else hipLaunchKernelGGL((walk_round_kernel<false, true, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-            } else {
-                if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-                else hipLaunchKernelGGL((walk_round_kernel<false, false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-            }
-        } else if (refill) {
-            if (ntree) {
-                if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-                else hipLaunchKernelGGL((walk_round_kernel<false, true, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-            } else {
-                if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-                else hipLaunchKernelGGL((walk_round_kernel<false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-            }
-        } else if (ntree) {
-            if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-            else hipLaunchKernelGGL((walk_round_kernel<false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-        } else {
-            if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, false>), dim3(grid), dim3(bs), lds_round, stream, rp);
-            else hipLaunchKernelGGL((walk_round_kernel<false, false>), dim3(grid), dim3(bs), lds_round, stream, rp);
+        if (n_active > 0) {
+            launch_round<false>(has_src, refill, ntree, emissive, grid, bs, lds_round, stream, rp);
+            HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipGetLastError());
+        if (pending_far > 0) HIP_TRY(hipStreamWaitEvent(stream, c->far_ev1, 0));
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev1, stream));
         HIP_TRY(hipMemcpyAsync(c->host_count, c->counts + nxt, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(c->host_count + 2, c->counts + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (c->time_kernels) {
             float ms = 0.0f;
             HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
             kernel_ms += ms;
-            if (getenv("WOST_TRACE_LAUNCHES")) fprintf(stderr, "launch %d: walkers %d grid %u %.3f ms -> %u left\n", launches, n_active, grid, ms, c->host_count[0]);
+            if (getenv("WOST_TRACE_LAUNCHES")) fprintf(stderr, "launch %d: walkers %d (+ %u strayed) grid %u %.3f ms -> %u left, %u strayed\n", launches, n_active, pending_far, grid, ms, c->host_count[0], c->host_count[2]);
         }
-        ++launches;
+        if (n_active > 0) ++launches;
+        pending_far = c->host_count[2];
         n_active = c->host_count[0];
         cur = nxt;
     }

@@ -1,0 +1,82 @@
+"""random 2-D scenes, HIP against the oracle bit for bit (developer scratch; the seeds that matter become tests):
+closed and open polylines of 3 .. 2000 segments on either boundary kind, emissive or not, degenerate and doubled
+segments, scales from 1e-3 to 1e4, probes that look at the scene from far away, source terms"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
+from elaina_amd import Problem, UniformIntegrator, UniformIntegratorSettings
+from oracle.oracle import Oracle
+
+
+def polyline(rng, n, radius, centre, wobble, closed, jitter):
+    t = np.sort(rng.uniform(0, 2 * np.pi, n)) if jitter else np.linspace(0, 2 * np.pi, n, endpoint=False)
+    r = radius * (1.0 + wobble * np.sin(rng.integers(2, 9) * t + rng.uniform(0, 6)) + 0.3 * wobble * np.sin(rng.integers(9, 40) * t))
+    v = np.stack([centre[0] + r * np.cos(t), centre[1] + r * np.sin(t)], 1)
+    s = np.stack([np.arange(n), (np.arange(n) + 1) % n], 1)
+    if not closed:
+        k = rng.integers(1, max(2, n // 4))
+        s = np.roll(s, -rng.integers(0, n), axis=0)[:-k]
+    return v, s
+
+
+def random_problem(rng):
+    feat = []
+    scale = 10.0 ** rng.uniform(-3, 4)
+    nd = int(rng.choice([3, 5, 40, 64, 65, 300, 2000]))
+    nn = int(rng.choice([0, 4, 30, 64, 65, 200, 1500]))
+    dv, ds = polyline(rng, nd, 0.3 * scale, (0.1 * scale, -0.05 * scale), rng.uniform(0, 0.3), rng.uniform() < 0.8, rng.uniform() < 0.5)
+    dc = rng.uniform(0, 1, (len(dv), 6)).astype(np.float32)
+    kw = dict(d_verts=dv, d_segs=ds, d_colors=dc)
+    if rng.uniform() < 0.3:                       # degenerate and doubled segments
+        feat.append('degenerate')
+        ds2 = np.concatenate([ds, ds[:3], np.stack([ds[:2, 0], ds[:2, 0]], 1)])
+        kw.update(d_segs=ds2)
+    if nn:
+        nv, ns = polyline(rng, nn, scale, (0.0, 0.0), rng.uniform(0, 0.25), rng.uniform() < 0.6, rng.uniform() < 0.5)
+        nc = None
+        if rng.uniform() < 0.5:
+            feat.append('emissive')
+            nc = (0.05 * rng.normal(size=(len(nv), 6))).astype(np.float32)
+        kw.update(n_verts=nv, n_segs=ns, n_colors=nc)
+    ang = rng.uniform(0, 2 * np.pi)
+    view = scale * rng.choice([0.5, 1.1, 3.0, 50.0])
+    kw["probe"] = (view, rng.uniform(-0.2, 0.2) * scale, rng.uniform(-0.2, 0.2) * scale, np.cos(ang), np.sin(ang))
+    if rng.uniform() < 0.25:
+        feat.append('source')
+        g = rng.uniform(-1, 1, (9, 7, 3)).astype(np.float32)
+        kw["source"] = {"rgb": g, "index_scale": (3.0 / scale, 4.0 / scale), "index_offset": (3.0, 4.0), "intensity": 0.1 * scale ** -2}
+    feat.append('view %.3g' % (view / scale))
+    return Problem(**kw), scale, feat
+
+
+def main():
+    first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    oracle = Oracle()
+    bad = 0
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(seed)
+        p, scale, feat = random_problem(rng)
+        w, h, spp, depth = int(rng.choice([8, 24, 40])), int(rng.choice([8, 16, 24])), int(rng.choice([1, 3, 6])), int(rng.choice([4, 24, 64]))
+        eps = scale * 10.0 ** rng.uniform(-4, -1.5)
+        it = UniformIntegrator(p, UniformIntegratorSettings((w, h), spp, depth, eps))
+        if rng.uniform() < 0.3:
+            feat.append('refill')
+            it.set_option("refill", 1 if p.source is None else 0)
+        it.solve()
+        ref = oracle.solve(p.as_dict(), w, h, spp, depth, eps, threads=os.cpu_count() or 8)
+        s = it.last_stats
+        ok = all(s[k] == ref[k] for k in ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated", "neumann_hits")) and \
+            np.array_equal(it.solution, ref["field"], equal_nan=True)
+        if not ok:
+            bad += 1
+            d = np.abs(it.solution - ref["field"])
+            print("seed %d MISMATCH: scale %.3g D %d N %s frame %dx%d spp %d depth %d eps %.3g steps %d/%d maxdiff %s" % (
+                seed, scale, len(p.d_segs), 0 if p.n_segs is None else len(p.n_segs), w, h, spp, depth, eps, s["walk_steps"], ref["walk_steps"],
+                np.nanmax(d)), feat, {k: (s[k], ref[k]) for k in ("walks_absorbed", "walks_truncated", "neumann_hits") if s[k] != ref[k]},
+                "pixels differing: %d of %d" % (int((d.max(axis=1) > 0).sum()), len(d)), flush=True)
+        it.close()
+    print("fuzz %d..%d: %d mismatches" % (first, first + count - 1, bad), flush=True)
+
+
+if __name__ == "__main__":
+    main()
