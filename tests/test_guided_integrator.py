@@ -11,6 +11,8 @@ network, tiny-cuda-nn absent => PARITY UNPINNED).  What is checked here:
        network; gradients are summed in 64-bit fixed point with integer atomics, so training is
        order-independent as well and a whole trained solve equals the oracle's bit for bit.
 """
+import os
+
 import numpy as np
 import pytest
 
