@@ -143,7 +143,10 @@ __device__ __forceinline__ float aabb_d2(float lox, float loy, float loz, float 
     return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
 }
 
-constexpr float kSlack3 = 1.0001f;     // relative slack of every box-against-best comparison of the 3-D trees
+// relative slack of every box-against-best comparison of the 3-D trees: 1 + 2^-15.  Box, triangle and edge distances each carry a
+// few 10^-7 of relative rounding; a looser slack (10^-4 at first) is as exact but opens every box of the mesh for a walker
+// thousands of scene sizes away
+constexpr float kSlack3 = 1.000030517578125f;
 
 __device__ __forceinline__ bool trav_visit3(const DevMesh3 &m, V3 q, Trav &T, const LdsColumn &stk)
 {
