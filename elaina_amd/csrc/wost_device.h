@@ -48,6 +48,13 @@ struct DevMesh {
     int32_t first_leaf;
     int32_t emissive;        // any non-zero colour
     float far2;              // squared distance from the mesh beyond which box pruning needs the relative slack (trav_visit<true>)
+    float huge2;             // squared distance beyond which a closest-point query is answered by a scan of the whole wave (closest_point_wave)
+    // the segments once more, compact and in slot order, for that scan: (cx, cy, ux, uy) + half length = the operands of a leaf
+    // visit's distance, the slot and the original index; padded to a multiple of 256 with records that cannot win
+    const float4 *scanBox;
+    const float *scanHl;
+    const int2 *scanId;      // (slot, original index)
+    int32_t n_scan;
     // boxes over runs of consecutive ORIGINAL indices (sample_in_sphere_tree): level l holds one box (lo.x, lo.y,
     // hi.x, hi.y) per run of 4^(l+1) segments, obox + obox_off[l]; obox_levels = 0: not built
     const float4 *obox;
@@ -350,6 +357,46 @@ __device__ __forceinline__ Closest slot_candidate(const DevMesh &m, int32_t slot
 {
     const float *nd = reinterpret_cast<const float *>(m.nodes + 6 * (size_t)(m.first_leaf + (slot >> 2))) + (slot & 3);
     return Closest{obb_d2(nd[0], nd[4], nd[8], nd[12], nd[16], 0.0f, qx, qy), slot};
+}
+
+// The closest segment to (qx, qy) -- the same point in all 64 lanes -- by a scan of every segment, the lanes sharing the leaf
+// level of the tree: the same distances as a leaf visit, the lowest ORIGINAL index among equal ones.  For the walkers that
+// strayed so far from the mesh (DevMesh::huge2) that all its segments lie within the rounding of one another: the descent with
+// its relative slack would open every box for them, one lane and one node at a time (two seconds for the 128 steps of one
+// leaked walker on the 61 000 segments of fille).  Returns the same answer in every lane.
+__device__ __forceinline__ Closest closest_point_wave(const DevMesh &m, float qx, float qy)
+{
+    const int lane = threadIdx.x & 63;
+    float bd = WOST_INF;
+    int32_t bs = -1, bo = WOST_FAR_INDEX;
+    for (int i = lane; i < m.n_scan; i += 256) {
+        // four records per lane and trip, their loads in flight together
+        float4 b[4];
+        float h[4];
+        int2 id[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b[j] = m.scanBox[i + 64 * j];
+            h[j] = m.scanHl[i + 64 * j];
+            id[j] = m.scanId[i + 64 * j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = obb_d2(b[j].x, b[j].y, b[j].z, b[j].w, h[j], 0.0f, qx, qy);
+            if (id[j].y != WOST_FAR_INDEX && (d < bd || (d == bd && id[j].y < bo))) {       // (padding records never win)
+                bd = d; bs = id[j].x; bo = id[j].y;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(bd, off);
+        const int32_t os = __shfl_xor(bs, off), oo = __shfl_xor(bo, off);
+        if (od < bd || (od == bd && oo < bo)) {
+            bd = od; bs = os; bo = oo;
+        }
+    }
+    return Closest{bd, bs};
 }
 
 // Brute-force variant for tiny meshes (wave-uniform loop over the flat records, which the

@@ -627,7 +627,7 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
     const uint2 *grid = HALF ? F.image + F.n_frag : nullptr;
     const int li = lane & 15, lg = lane >> 4;
 
-    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5 };
+    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5, MODE_HUGE = 7 };
     int mode = MODE_REFILL;
     uint32_t pid = 0;
     bool on_n = false;
@@ -845,10 +845,23 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
                     }
                 } else if (has_d) {
                     T = trav_begin(slot_candidate(P.dm, hint, x, y));
-                    mode = MODE_TRAV;
+                    // a walker that strayed so far that the whole mesh ties within rounding: answered by the wave below
+                    mode = T.best.d2 > P.dm.huge2 ? MODE_HUGE : MODE_TRAV;
                 } else {
                     T.best = Closest{WOST_INF, -1};
                     mode = MODE_WAIT;
+                }
+            }
+            {
+                unsigned long long hb = __ballot(mode == MODE_HUGE);
+                while (hb) {
+                    const int src = __builtin_ctzll(hb);
+                    const Closest r = closest_point_wave(P.dm, __shfl(x, src), __shfl(y, src));
+                    if (lane == src) {
+                        T.best = r;
+                        mode = MODE_WAIT;
+                    }
+                    hb &= hb - 1;
                 }
             }
         } else {

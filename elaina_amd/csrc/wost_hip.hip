@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
     // lane's query to completion in lock step, each trip of the loop runs ONE of two bodies
     // -- "visit one node" or "finish a step and start the next query" -- whichever more lanes
     // of the wave are ready for (weighted), while the lanes of the other kind accumulate.
-    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5, MODE_FAR = 6 };
+    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5, MODE_FAR = 6, MODE_HUGE = 7 };
     const bool has_d = P.dm.n_segs > 0;
     int mode = alive ? MODE_WAIT : MODE_DONE;
     bool fresh = true;   // first trip: no finished step yet, only start the query
@@ -401,11 +401,25 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
                             mode = MODE_FAR;      // not started, not counted: the SLACK launch takes the step from here
                         } else {
                             S.a += 1u;
-                            mode = MODE_TRAV;
+                            // SLACK: a query from so far away that every segment of the mesh ties within rounding is answered
+                            // by the whole wave at the end of this trip
+                            mode = (SLACK && T.best.d2 > P.dm.huge2) ? MODE_HUGE : MODE_TRAV;
                         }
                     }
                 } else {
                     mode = (REFILL && !alive) ? MODE_REFILL : MODE_DONE;
+                }
+            }
+            if (SLACK) {
+                unsigned long long hb = __ballot(mode == MODE_HUGE);
+                while (hb) {
+                    const int src = __builtin_ctzll(hb);
+                    const Closest r = closest_point_wave(P.dm, __shfl(L.px, src), __shfl(L.py, src));
+                    if ((int)(threadIdx.x & 63) == src) {
+                        T.best = r;
+                        mode = MODE_WAIT;
+                    }
+                    hb &= hb - 1;
                 }
             }
         } else {
@@ -634,6 +648,7 @@ static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
                 ext = std::max(ext, std::max(std::fabs(d.verts[2 * vi]), std::fabs(d.verts[2 * vi + 1])));
             }
         v.far2 = 2.25f * ext * ext;
+        v.huge2 = 4096.0f * ext * ext;       // 64 extents
     }
     v.first_leaf = t.first_leaf;
     v.emissive = 0;
@@ -648,6 +663,29 @@ static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
     HIP_TRY(upload(s.allocs, t.flatCol.data(), t.flatCol.size(), &v.flatCol));
     HIP_TRY(upload(s.allocs, reinterpret_cast<const DevSilVertex *>(t.sil.data()), t.sil.size(), &v.sil));
     HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(t.cones.data()), t.cones.size() / 4, &v.cones));
+    {
+        // closest_point_wave: the occupied slots, compact; the operands are those of the leaf-level node records
+        std::vector<float> box, hl;
+        std::vector<int32_t> id;
+        for (size_t k = 0; k < t.segOrig.size(); ++k) {
+            if (t.segOrig[k] == kFarIndex) continue;
+            const float *nd = &t.nodes[((size_t)t.first_leaf + k / 4) * 24] + (k & 3);
+            box.insert(box.end(), {nd[0], nd[4], nd[8], nd[12]});
+            hl.push_back(nd[16]);
+            id.push_back((int32_t)k);
+            id.push_back(t.segOrig[k]);
+        }
+        while (hl.size() % 256) {
+            box.insert(box.end(), {1.0e18f, 1.0e18f, 1.0f, 0.0f});
+            hl.push_back(0.0f);
+            id.push_back(-1);
+            id.push_back(kFarIndex);
+        }
+        v.n_scan = (int32_t)hl.size();
+        HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(box.data()), hl.size(), &v.scanBox));
+        HIP_TRY(upload(s.allocs, hl.data(), hl.size(), &v.scanHl));
+        HIP_TRY(upload(s.allocs, reinterpret_cast<const int2 *>(id.data()), hl.size(), &v.scanId));
+    }
     HIP_TRY(upload(s.allocs, reinterpret_cast<const int2 *>(t.segVerts.data()), t.segVerts.size() / 2, &v.segVerts));
     // boxes over runs of consecutive original indices, for the index-ordered sampling of emissive Neumann meshes
     // (sample_in_sphere_tree); padded like the tree's boxes, so that rounding never hides a segment the flat loop takes
@@ -1044,8 +1082,9 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
             fp.in = queue_from(c->queue[cur], c->n_pixels - pending_far);
             fp.count_in = c->counts + 3;
             fp.steps_per_round = std::max(1, c->settings.max_depth);
-            fp.lane_shift = 0;
-            launch_round<true>(c->src.rgb != nullptr, false, ntree, emissive, (unsigned)((pending_far + bs - 1) / bs), bs, lds_round, c->far_stream, fp);
+            // one walker per wave: a query from very far away is a scan of the whole mesh by the 64 lanes (closest_point_wave)
+            fp.lane_shift = 6;
+            launch_round<true>(c->src.rgb != nullptr, false, ntree, emissive, (unsigned)((((uint64_t)pending_far << 6) + bs - 1) / bs), bs, lds_round, c->far_stream, fp);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->far_ev1, c->far_stream));
             ++launches;
