@@ -1087,7 +1087,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
             launch_round<true>(c->src.rgb != nullptr, false, ntree, emissive, (unsigned)((((uint64_t)pending_far << 6) + bs - 1) / bs), bs, lds_round, c->far_stream, fp);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->far_ev1, c->far_stream));
-            ++launches;
+            // (not counted in `launches`: kernel_ms / kernel_launches stays the average duration of the ordinary launches)
         }
         // When the walkers left fill less than 1/16 of the resident threads, spread them out: the
         // duration of such a launch is the latency of its slowest wave, and a wave is as slow as the

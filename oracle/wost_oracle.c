@@ -362,8 +362,9 @@ cp_result closest_bvh(const pmesh *m, float qx, float qy)
         const bnode *n = &m->nodes[stack[--sp]];
         /* relative slack: the box distance and the exact segment distance are rounded independently, and far outside the
          * scene one ulp of either exceeds the padding of the boxes (a fuzz test met closest points that differed from
-         * closest_brute at 50 scene sizes); a box skipped wrongly changes the answer, one opened needlessly does not */
-        if (box_d2(n, qx, qy) > r.d2 * 1.0001f) continue;
+         * closest_brute at 50 scene sizes); a box skipped wrongly changes the answer, one opened needlessly does not -- but a
+         * slack of 10^-4 opens every box for a walker thousands of scene sizes away */
+        if (box_d2(n, qx, qy) > r.d2 * 1.0000153f) continue;       /* 1 + 2^-16: the rounding is a few 10^-7 */
         if (n->left < 0) {
             for (int k = n->first; k < n->first + n->count; ++k) {
                 int i = m->order[k];
