@@ -562,7 +562,7 @@ __device__ __forceinline__ void sweep_in_sphere(const DevMesh &m, float qx, floa
     // |q| and R of 10^7 mesh units occur), where the rounding of both distances grows with |q|: the skip test is slack
     // by a relative 10^-4 on top (a run that is tested needlessly costs four exact tests; one that is skipped wrongly
     // changes the result)
-    const float R2s = R2 * 1.0001f, R2i = R2 * 0.9999f;
+    const float R2s = R2 * 1.000030517578125f, R2i = R2 * 0.9999f;     // skip: 1 + 2^-15 (a loose slack tests whole far meshes)
     int i = 0;
     while (i < m.n_segs) {
         // the longest aligned run starting at i that is decided as a whole, coarsest first
@@ -690,7 +690,7 @@ __device__ __forceinline__ bool cone_may_hold_silhouette(float ax, float ay, flo
 template <class STK>
 __device__ __forceinline__ float closest_silhouette_tree(const DevMesh &m, float qx, float qy, float rmax, const STK &stk)
 {
-    constexpr float kSlack = 1.0001f;
+    constexpr float kSlack = 1.000030517578125f;   // 1 + 2^-15: the rounding is a few 10^-7; 10^-4 opens every box for a far walker
     float best2 = rmax * rmax;
     bool found = false;
     Trav T = trav_begin(Closest{best2 * kSlack, -1});
