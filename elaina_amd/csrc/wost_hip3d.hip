@@ -81,6 +81,7 @@ struct DevMesh3 {
                              // already lists (every edge is tested from one triangle only), 1 = two triangles, 2 = boundary
     const float4 *cones;     // [n_nodes * 6] normal cones of the four children: ax[4] ay[4] az[4] cos[4] sin[4] rad[4]
     int32_t n_tris, n_edges, levels, first_leaf, emissive;
+    float huge2;             // squared distance beyond which a closest-point query is a scan by the whole wave (closest_triangle_wave)
     // boxes over runs of consecutive ORIGINAL triangle indices (sample_in_sphere3_tree): level l holds, per run of
     // 4^(l+1) triangles, two float4 (lo.xyz, hi.xyz) at obox + 2 * (obox_off[l] + run); obox_levels = 0: not built
     const float4 *obox;
@@ -1058,6 +1059,36 @@ __device__ __forceinline__ bool step3(const Walk3Params &P, Lane3 &L, Closest cp
 
 constexpr int kWalk3Threads = 256;
 
+// The closest triangle to q -- the same point in all 64 lanes -- by a scan of every slot of the leaf level, the lanes sharing
+// them: the exact distances of a leaf visit, the lowest ORIGINAL index among equal ones.  For a walker that strayed so far
+// (DevMesh3::huge2) that all triangles lie within the rounding of one another, where the descent -- its boxes pruned with a
+// relative slack -- opens every box, one lane and one node at a time.  Returns the same answer in every lane.
+__device__ __forceinline__ Closest closest_triangle_wave(const DevMesh3 &m, V3 q)
+{
+    const int lane = threadIdx.x & 63;
+    const int n_slots = 4 << (2 * m.levels);
+    float bd = WOST_INF;
+    int32_t bs = -1, bo = WOST_FAR_INDEX;
+    for (int k = lane; k < n_slots; k += 64) {
+        const int32_t o = m.triOrig[k];
+        if (o == WOST_FAR_INDEX) continue;
+        const float4 a = m.tri[3 * (size_t)k], b = m.tri[3 * (size_t)k + 1], c = m.tri[3 * (size_t)k + 2];
+        const float d = tri_d2(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), q);
+        if (d < bd || (d == bd && o < bo)) {
+            bd = d; bs = k; bo = o;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(bd, off);
+        const int32_t os = __shfl_xor(bs, off), oo = __shfl_xor(bo, off);
+        if (od < bd || (od == bd && oo < bo)) {
+            bd = od; bs = os; bo = oo;
+        }
+    }
+    return Closest{bd, bs};
+}
+
 template <bool EMISSIVE, bool SOURCE, bool NTREE>
 __global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
 {
@@ -1068,7 +1099,7 @@ __global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
 #endif
     const int lane = threadIdx.x & 63;
     const bool has_d = P.dm.n_tris > 0;
-    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5 };
+    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5, MODE_HUGE = 7 };
     int mode = MODE_REFILL;
     Lane3 L{};
     L.rng = Pcg{0, 1};
@@ -1093,7 +1124,8 @@ __global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
                 T.best = Closest{tri_d2(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), L.p), L.hint};
                 T.best_orig = P.dm.triOrig[L.hint];
             }
-            mode = MODE_TRAV;
+            // a walker that strayed so far that the whole mesh ties within rounding: answered by the wave (main loop)
+            mode = T.best.d2 > P.dm.huge2 ? MODE_HUGE : MODE_TRAV;
         }
     };
     auto begin_sample = [&]() {
@@ -1157,6 +1189,18 @@ __global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
                     }
                     // a pixel of another shard or a masked one: the lane asks again on the next trip
                 }
+            }
+        }
+        {
+            unsigned long long hb = __ballot(mode == MODE_HUGE);
+            while (hb) {
+                const int src = __builtin_ctzll(hb);
+                const Closest r = closest_triangle_wave(P.dm, v3(__shfl(L.p.x, src), __shfl(L.p.y, src), __shfl(L.p.z, src)));
+                if (lane == src) {
+                    T.best = r;
+                    mode = MODE_WAIT;
+                }
+                hb &= hb - 1;
             }
         }
         const int n_trav = __popcll(__ballot(mode == MODE_TRAV));
@@ -1303,6 +1347,7 @@ struct HostMesh3 {
     int32_t n_tris = 0, n_edges = 0, levels = 1, first_leaf = 1;
     bool emissive = false;
     std::vector<float> nodes, tri, colors, cones, slotEdges;
+    float ext = 0.0f;                 // largest coordinate
     std::vector<int32_t> triOrig, triVerts, flatVerts;
     std::vector<float> obox;          // index-ordered run boxes (emissive meshes above the flat limit)
     int32_t obox_off[12] = {0}, obox_levels = 0;
@@ -1447,6 +1492,7 @@ static int build_mesh3(const wost3_mesh_desc &d, HostMesh3 *out)
     float ext = 0.0f;
     for (int c = 0; c < 3; ++c) ext = std::max(ext, std::max(std::fabs(lo[c]), std::fabs(hi[c])));
     const float pad = ext * 0x1p-18f + 1e-30f;
+    h.ext = ext;
     const int n_nodes = h.first_leaf + cap;
     std::vector<float> nb((size_t)n_nodes * 6);
     std::vector<char> empty(n_nodes, 1);
@@ -1854,6 +1900,7 @@ static int upload_mesh3(const wost3_mesh_desc &d, DeviceMesh3 &s)
     v.n_tris = h.n_tris;
     if (h.n_tris == 0) return WOST_OK;
     v.n_edges = h.n_edges; v.levels = h.levels; v.first_leaf = h.first_leaf; v.emissive = h.emissive ? 1 : 0;
+    v.huge2 = 4096.0f * h.ext * h.ext;        // 64 extents
     W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.nodes.data()), h.nodes.size() / 4, &v.nodes));
     W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.tri.data()), h.tri.size() / 4, &v.tri));
     W3_TRY(upload3(s.allocs, h.triOrig.data(), h.triOrig.size(), &v.triOrig));
