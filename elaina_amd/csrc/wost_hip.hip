@@ -1082,9 +1082,11 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
             fp.in = queue_from(c->queue[cur], c->n_pixels - pending_far);
             fp.count_in = c->counts + 3;
             fp.steps_per_round = std::max(1, c->settings.max_depth);
-            // one walker per wave: a query from very far away is a scan of the whole mesh by the 64 lanes (closest_point_wave)
-            fp.lane_shift = 6;
-            launch_round<true>(c->src.rgb != nullptr, false, ntree, emissive, (unsigned)((((uint64_t)pending_far << 6) + bs - 1) / bs), bs, lds_round, c->far_stream, fp);
+            // a few strayed walkers (leaks of a closed scene): one per wave -- a query from very far away is a scan of the whole
+            // mesh by the 64 lanes (closest_point_wave), and the launch lasts as long as its slowest wave; many (an open scene:
+            // every walk that misses the boundary strays): every lane loaded
+            fp.lane_shift = pending_far <= 4096u ? 6 : 0;
+            launch_round<true>(c->src.rgb != nullptr, false, ntree, emissive, (unsigned)((((uint64_t)pending_far << fp.lane_shift) + bs - 1) / bs), bs, lds_round, c->far_stream, fp);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->far_ev1, c->far_stream));
             // (not counted in `launches`: kernel_ms / kernel_launches stays the average duration of the ordinary launches)
