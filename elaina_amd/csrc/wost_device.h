@@ -272,7 +272,7 @@ __device__ __forceinline__ void trav_leaf_ties(const DevMesh &m, Trav &T, int sl
 // load path with its own branch per visit; the top of the tree is L1-resident anyway.)
 // SLACK = true prunes boxes with a relative slack as well (their distance shrunk by 10^-4): box and segment distances come
 // from different formulas, and for a query far outside the mesh one ulp of the squared distance exceeds the absolute
-// padding of the boxes -- a closer or tying segment would be skipped (found by tools/scratch/fuzz_parity.py: probes and
+// padding of the boxes -- a closer or tying segment would be skipped (found by tools/fuzz/fuzz_parity.py: probes and
 // escaped walkers 50 scene sizes away).  Within DevMesh::far2 of the mesh the padding covers the rounding and the plain
 // form is exact; it is the one the walk kernels run in their lane machines, where a single extra live register costs a
 // quarter of the throughput; a query that starts beyond far2 is answered by closest_point_far instead.

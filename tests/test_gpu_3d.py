@@ -283,13 +283,13 @@ def test_3d_queries_and_walks_far_outside_the_meshes(oracle):
 
 
 def test_3d_random_scenes_match_the_oracle():
-    """tools/scratch/fuzz_parity3d.py: random bumpy icospheres of 20 .. 1280 triangles on either boundary kind, holes, emissive or
+    """tools/fuzz/fuzz_parity3d.py: random bumpy icospheres of 20 .. 1280 triangles on either boundary kind, holes, emissive or
     not, doubled and zero-area triangles, scales 1e-3 .. 1e3, probes that look at the scene from 40 scene sizes away"""
     import os
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "scratch", "fuzz_parity3d.py"), "0", "40"], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz", "fuzz_parity3d.py"), "0", "40"], capture_output=True, text=True,
                          timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "fuzz3d 0..39: 0 mismatches" in out.stdout, out.stdout[-3000:]

@@ -512,7 +512,7 @@ def test_full_size_config3_fille_band_and_properties(oracle, fille):
 
 @pytest.mark.parametrize("first", [0, 40, 80])
 def test_random_scenes_match_the_oracle(first):
-    """tools/scratch/fuzz_parity.py: random closed and open polylines of 3 .. 2000 segments on either boundary kind, emissive
+    """tools/fuzz/fuzz_parity.py: random closed and open polylines of 3 .. 2000 segments on either boundary kind, emissive
     or not, degenerate and doubled segments, scales from 1e-3 to 1e4, probes that look at the scene from 50 scene sizes away,
     source terms, the REFILL launch.  Found: closest points that differed from brute force far outside the mesh (HIP tree and
     the oracle's BVH alike -- walkers that stray that far leave the ordinary launch now and finish their walk in the kernel whose
@@ -520,7 +520,7 @@ def test_random_scenes_match_the_oracle(first):
     vertex in scenes of that size."""
     import subprocess
     import sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scratch", "fuzz_parity.py"), str(first), "40"], capture_output=True,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz", "fuzz_parity.py"), str(first), "40"], capture_output=True,
                          text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "fuzz %d..%d: 0 mismatches" % (first, first + 39) in out.stdout, out.stdout[-3000:]

@@ -797,13 +797,13 @@ def test_gpu_fused_sample_kernel_intermediate_frames(monkeypatch):
 
 @pytest.mark.gpu
 def test_gpu_random_scenes_match_the_oracle():
-    """tools/scratch/fuzz_guided.py: random closed and open boundaries of 4 .. 400 segments on either kind, emissive or not, probes
+    """tools/fuzz/fuzz_guided.py: random closed and open boundaries of 4 .. 400 segments on either kind, emissive or not, probes
     from half to three scene sizes, trained and guiding samples, three uniform fractions -- fields and counters bit for bit
     (40 seeds were run when the test was written; two stay here: the oracle trains the network on the CPU)"""
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "scratch", "fuzz_guided.py"), "3", "2"], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz", "fuzz_guided.py"), "3", "2"], capture_output=True, text=True,
                          timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "fuzz guided 3..4: 0 mismatches" in out.stdout, out.stdout[-3000:]

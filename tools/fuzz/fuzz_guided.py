@@ -1,5 +1,5 @@
 """random 2-D scenes through the guided integrator (fp32 network, online training), HIP against the oracle bit for bit
-(developer scratch): the scenes of fuzz_parity.py without sources at moderate scales, a few trained and a few guiding samples"""
+: the scenes of fuzz_parity.py without sources at moderate scales, a few trained and a few guiding samples"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))

@@ -1,4 +1,4 @@
-"""random 2-D scenes, HIP against the oracle bit for bit (developer scratch; the seeds that matter become tests):
+"""random 2-D scenes, HIP against the oracle bit for bit (some seeds run as tests):
 closed and open polylines of 3 .. 2000 segments on either boundary kind, emissive or not, degenerate and doubled
 segments, scales from 1e-3 to 1e4, probes that look at the scene from far away, source terms"""
 import os, sys

@@ -1,4 +1,4 @@
-"""random 3-D scenes, HIP against the oracle bit for bit (developer scratch): bumpy icospheres of 20 .. 1280 triangles on
+"""random 3-D scenes, HIP against the oracle bit for bit : bumpy icospheres of 20 .. 1280 triangles on
 either boundary kind, holes (boundary edges), emissive or not, scales 1e-3 .. 1e3, probes from afar, doubled and zero-area
 triangles"""
 import os, sys

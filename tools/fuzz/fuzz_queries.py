@@ -1,5 +1,5 @@
 """closest-point / silhouette / ray queries of a fuzz scene: HIP against the oracle's brute-force loops and its BVH
-(developer scratch; which side is wrong when a fuzz solve differs)"""
+(which side is wrong when a fuzz solve differs)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
