@@ -58,10 +58,19 @@ def main():
         p, scale, feat = random_problem(rng)
         w, h, spp, depth = int(rng.choice([8, 24, 40])), int(rng.choice([8, 16, 24])), int(rng.choice([1, 3, 6])), int(rng.choice([4, 24, 64]))
         eps = scale * 10.0 ** rng.uniform(-4, -1.5)
+        if rng.uniform() < 0.2:
+            feat.append('mask')
+            p.mask = (rng.uniform(size=w * h) < 0.7).astype(np.uint8)
         it = UniformIntegrator(p, UniformIntegratorSettings((w, h), spp, depth, eps))
         if rng.uniform() < 0.3:
             feat.append('refill')
             it.set_option("refill", 1 if p.source is None else 0)
+        if rng.uniform() < 0.4:            # launch shapes and scheduler constants: none of them may change a bit
+            opts = {"steps_per_round": int(rng.choice([1, 3, 17, 256])), "block_size": int(rng.choice([64, 128, 256])),
+                    "wait_weight": int(rng.choice([1, 8, 64])), "trav_burst": int(rng.choice([1, 3, 5])), "thin_waves": int(rng.choice([0, 1]))}
+            feat.append(str(opts))
+            for k, v in opts.items():
+                it.set_option(k, v)
         it.solve()
         ref = oracle.solve(p.as_dict(), w, h, spp, depth, eps, threads=os.cpu_count() or 8)
         s = it.last_stats
