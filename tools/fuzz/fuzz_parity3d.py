@@ -56,6 +56,13 @@ def main():
         sd, scale, feat = random_scene(rng)
         w, h, spp, depth = int(rng.choice([8, 16, 24])), int(rng.choice([8, 16])), int(rng.choice([1, 3])), int(rng.choice([4, 24, 64]))
         eps = scale * 10.0 ** rng.uniform(-3.5, -1.5)
+        if rng.uniform() < 0.25:
+            feat.append("source")
+            sd["source"] = {"rgb": rng.uniform(-1, 1, (4, 5, 6, 3)).astype(np.float32), "index_scale": (2.5 / scale, 2.0 / scale, 1.5 / scale),
+                            "index_offset": (3.0, 2.5, 2.0), "intensity": 0.1 * scale ** -2}
+        if rng.uniform() < 0.2:
+            feat.append("mask")
+            sd["mask"] = (rng.uniform(size=w * h) < 0.7).astype(np.uint8)
         it = UniformIntegrator3(Problem3.from_dict(sd), UniformIntegratorSettings((w, h), spp, depth, eps))
         it.solve()
         ref = oracle.solve3(sd, w, h, spp, depth, eps, threads=os.cpu_count() or 8)
