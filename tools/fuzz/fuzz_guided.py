@@ -36,15 +36,22 @@ def main():
         eps = scale * 10.0 ** rng.uniform(-3.5, -2)
         aabb = ((-1.3 * scale, -1.3 * scale), (1.3 * scale, 1.3 * scale))
         uf = (float(rng.choice([0.0, 0.5, 1.0])), float(rng.choice([0.0, 0.5])))
+        mgd = (int(rng.choice([10, 2])), int(rng.choice([10, 3, 0])))
+        stride = int(rng.choice([1, 1, 2]))
+        offset = int(rng.integers(0, stride))
+        if rng.uniform() < 0.25:
+            feat.append("mask")
+            p.mask = (rng.uniform(size=w * h) < 0.75).astype(np.uint8)
+        feat.append("mgd %s stride %d+%d" % (mgd, stride, offset))
         st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=train, maxWalkingDepth=depth, epsilonShell=eps,
                                       uniformFractionInTrainingPhase=uf[0], uniformFractionInGuidingPhase=uf[1],
-                                      maxGuidedDepthInTrainingPhase=10, maxGuidedDepthInGuidingPhase=10, batchSize=1024, minBatchSize=256,
-                                      trainPixelStride=1, trainPixelOffset=0)
+                                      maxGuidedDepthInTrainingPhase=mgd[0], maxGuidedDepthInGuidingPhase=mgd[1], batchSize=1024, minBatchSize=256,
+                                      trainPixelStride=stride, trainPixelOffset=offset)
         gi = GuidedIntegrator(p, st, aabb, seed=7)
         p0 = gi.network.params()
         gi.solve()
-        gs = guided_settings(w, h, spp, depth, eps, aabb[0], aabb[1], train_spp_count=train, uniform_fraction=uf, max_guided_depth=(10, 10),
-                             batch_size=1024, min_batch_size=256, train_pixel_stride=1, train_pixel_offset=0)
+        gs = guided_settings(w, h, spp, depth, eps, aabb[0], aabb[1], train_spp_count=train, uniform_fraction=uf, max_guided_depth=mgd,
+                             batch_size=1024, min_batch_size=256, train_pixel_stride=stride, train_pixel_offset=offset)
         ref = oracle.solve_guided(p.as_dict(), gs, default_net_config(), p0.copy(), threads=os.cpu_count() or 8, dump_spp=-1)
         s = gi.last_stats
         keys = ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated", "neumann_hits", "guided_steps")
