@@ -12,7 +12,10 @@ from oracle.oracle import Oracle, default_net_config, guided_settings
 
 def main():
     first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 20
-    oracle = Oracle()
+    # "half": the half-precision network mode has no bit-exact oracle; its fused launch (the network inside the walk kernel)
+    # must equal its own one-launch-per-depth path bit for bit instead
+    half = len(sys.argv) > 3 and sys.argv[3] == "half"
+    oracle = None if half else Oracle()
     bad = 0
     for seed in range(first, first + count):
         rng = np.random.default_rng(10_000 + seed)
@@ -47,6 +50,25 @@ def main():
                                       uniformFractionInTrainingPhase=uf[0], uniformFractionInGuidingPhase=uf[1],
                                       maxGuidedDepthInTrainingPhase=mgd[0], maxGuidedDepthInGuidingPhase=mgd[1], batchSize=1024, minBatchSize=256,
                                       trainPixelStride=stride, trainPixelOffset=offset)
+        if half:
+            out = []
+            for fused in ("1", "0"):
+                os.environ["WOST_GUIDED_FUSED"] = fused
+                gi = GuidedIntegrator(p, st, aabb, seed=7)
+                gi.network.set_option("precision", 16)
+                gi.network.set_option("train_precision", 16)
+                gi.solve()
+                out.append((gi.solution.copy(), dict(gi.last_stats), gi.network.params().copy()))
+                gi.close()
+            os.environ.pop("WOST_GUIDED_FUSED", None)
+            keys = ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated", "neumann_hits", "guided_steps")
+            ok = all(out[0][1][k] == out[1][1][k] for k in keys) and np.array_equal(out[0][0], out[1][0], equal_nan=True) and \
+                np.array_equal(out[0][2], out[1][2])
+            if not ok:
+                bad += 1
+                print("seed %d MISMATCH (half precision, fused against per-depth): scale %.3g frame %dx%d spp %d train %d depth %d" % (
+                    seed, scale, w, h, spp, train, depth), feat, flush=True)
+            continue
         gi = GuidedIntegrator(p, st, aabb, seed=7)
         p0 = gi.network.params()
         gi.solve()
