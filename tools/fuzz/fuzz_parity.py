@@ -76,6 +76,18 @@ def main():
         s = it.last_stats
         ok = all(s[k] == ref[k] for k in ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated", "neumann_hits")) and \
             np.array_equal(it.solution, ref["field"], equal_nan=True)
+        if ok and rng.uniform() < 0.15 and (w % 8 == 0 and h % 8 == 0):
+            # the tile-sharded solve of the multi-GPU path: the shards' fields add up to the field, bit for bit
+            import torch
+            n_sh = int(rng.choice([2, 3, 5]))
+            acc = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+            for r in range(n_sh):
+                part = torch.zeros_like(acc)
+                it.solve_sharded(r, n_sh, part.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                acc += part
+            feat.append("sharded x%d" % n_sh)
+            ok = np.array_equal(acc.cpu().numpy().reshape(-1, 3), ref["field"], equal_nan=True)
         if not ok:
             bad += 1
             d = np.abs(it.solution - ref["field"])
