@@ -3,6 +3,7 @@
 hipcc cross-compiles without a GPU, so this runs in the build container as the
 "does it build" check and the resulting .so travels to the GPU box with the tree.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -39,12 +40,23 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=False):
     """One object per translation unit (compiled in parallel, rebuilt when the unit or ANY header
-    of csrc/ or include/wost.h is newer), then one link."""
+    of csrc/ or include/wost.h is newer, or when the compiler flags differ from those the objects
+    were built with), then one link."""
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
     headers.append(os.path.join(_HERE, "..", "include", "wost.h"))
     # developer knob: extra -D definitions for kernel-tuning experiments (WOST_HIPCC_DEFS="-DX=1 -DY=2")
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("WOST_HIPCC_DEFS", "").split()
+    # objects are only reused under the flags they were compiled with: a library carrying experimental -D variants must
+    # never be mistaken for the default build by the next plain build (and the other way round)
+    stamp = os.path.join(OBJ_DIR, "flags.stamp")
+    flag_id = hashlib.sha256(" ".join(flags).encode()).hexdigest()
+    try:
+        same_flags = open(stamp).read().strip() == flag_id
+    except OSError:
+        same_flags = False
+    if not same_flags:
+        force = True
     jobs, objs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -55,9 +67,12 @@ def build_library(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             jobs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in jobs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
+    # wait for every compiler before reporting a failure: none is left running behind an exception
+    failed = [(cmd, p.returncode) for cmd, p in jobs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(failed[0][1], failed[0][0])
+    with open(stamp, "w") as f:
+        f.write(flag_id + "\n")
     if force or jobs or _stale(LIB_PATH, objs):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", LIB_PATH]
         if verbose:

@@ -293,6 +293,24 @@ __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy,
     const float d1 = SLACK ? obb_d2(CX.y, CY.y, UX.y, UY.y, HL.y, HW.y, qx, qy) * shrink : obb_d2(CX.y, CY.y, UX.y, UY.y, HL.y, HW.y, qx, qy);
     const float d2 = SLACK ? obb_d2(CX.z, CY.z, UX.z, UY.z, HL.z, HW.z, qx, qy) * shrink : obb_d2(CX.z, CY.z, UX.z, UY.z, HL.z, HW.z, qx, qy);
     const float d3 = SLACK ? obb_d2(CX.w, CY.w, UX.w, UY.w, HL.w, HW.w, qx, qy) * shrink : obb_d2(CX.w, CY.w, UX.w, UY.w, HL.w, HW.w, qx, qy);
+#ifdef WOST_EXP_VALU
+    {   // sensitivity experiment (developer builds only): extra dependent vector instructions per visit
+        float acc = qx;
+#pragma unroll
+        for (int k = 0; k < WOST_EXP_VALU; ++k) acc = __builtin_fmaf(acc, 1.0000001f, d0);
+        if (acc == 12345.678f) T.best_orig = 0;
+    }
+#endif
+#ifdef WOST_EXP_LOADS
+    {   // sensitivity experiment (developer builds only): a second, unrelated node fetched per visit
+        const uint32_t nn = level_first(m.levels + 1);
+        uint32_t g2 = g + (nn >> 1);
+        g2 = g2 >= nn ? g2 - nn : g2;
+        const float4 *n2 = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g2, 96u));
+        const float acc = n2[0].x + n2[1].x + n2[2].x + n2[3].x + n2[4].x + n2[5].x;
+        if (acc == 12345.678f) T.best_orig = 0;
+    }
+#endif
     // ---- last level: the children are segments, the distances are exact.  Branch-free in
     // the common case (one strict winner); exact ties take the rare path.
     {

@@ -32,6 +32,7 @@
 #include "wost_device.h"
 #include "wost_internal.h"
 #include "wost_walk.h"
+#include "wost_quad.h"
 
 namespace wost {
 
@@ -61,6 +62,7 @@ static const int kQueueWords = 16 + 1;  // rng counts twice
 constexpr int kStatCopies = 64;
 struct alignas(256) StatsDev {
     unsigned long long steps, started, absorbed, truncated, nhits, inner_visits, leaf_visits, trav_trips, step_trips, max_stack;
+    unsigned long long sp_ge6, sp_ge10, sp_ge14;     // WOST_TRACK developer builds: visits that left at least that many stack entries
 };
 __device__ __forceinline__ StatsDev *my_stats(StatsDev *s) { return s + (blockIdx.x & (kStatCopies - 1)); }
 
@@ -272,6 +274,20 @@ __device__ __forceinline__ void load_lane(const WalkQueue &q, uint32_t slot, Lan
     L.d0_d2 = q.d0_d2[slot]; L.d0_slot = q.d0_slot[slot];
 }
 
+__device__ __forceinline__ void store_lane(const WalkQueue &q, uint32_t s, const Lane &L, uint32_t pix)
+{
+    q.pix[s] = pix;
+    q.x0[s] = L.x0; q.y0[s] = L.y0;
+    q.px[s] = L.px; q.py[s] = L.py;
+    q.rng[s] = L.rng.state;
+    q.meta[s] = META_PACK(L.sample, L.depth, L.on_n ? 1 : 0);
+    q.nx[s] = L.nx; q.ny[s] = L.ny;
+    q.hint[s] = L.hint;
+    q.thp[s] = L.thp;
+    q.sr[s] = L.sr; q.sg[s] = L.sg; q.sb[s] = L.sb;
+    q.d0_d2[s] = L.d0_d2; q.d0_slot[s] = L.d0_slot;
+}
+
 // REFILL = false: one thread per queue slot, the round ends after steps_per_round steps and the
 // survivors are compacted (the throughput path: with many samples per pixel a slot keeps itself
 // busy by regenerating).  REFILL = true: a fixed number of resident threads; a lane whose pixel
@@ -318,6 +334,15 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
     int budget = P.steps_per_round;
     Trav T = trav_begin(Closest{WOST_INF, -1});
     uint32_t trav_trips = 0, step_trips = 0;   // wave-uniform: scheduler diagnostics
+#ifdef WOST_TRACK
+    uint32_t trk_leaf = 0, trk_ge6 = 0, trk_ge10 = 0, trk_ge14 = 0;
+    int trk_sp = 0;
+#define WOST_TRACK_VISIT_PRE() do { trk_leaf += (T.level == P.dm.levels) ? 1u : 0u; } while (0)
+#define WOST_TRACK_VISIT_POST() do { trk_sp = max(trk_sp, T.sp); trk_ge6 += T.sp >= 6; trk_ge10 += T.sp >= 10; trk_ge14 += T.sp >= 14; } while (0)
+#else
+#define WOST_TRACK_VISIT_PRE() do {} while (0)
+#define WOST_TRACK_VISIT_POST() do {} while (0)
+#endif
     const LdsColumn stk{stack, (uint32_t)P.stack_stride};
     for (;;) {
         if (REFILL) {
@@ -342,9 +367,11 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
                     pool_next += needed;
                 }
                 if (mode == MODE_REFILL) {
-                    float *f = P.field + 3 * (size_t)((int32_t)pix - P.field_base);
-                    const float spp = (float)P.st.spp;
-                    f[0] = L.sr / spp; f[1] = L.sg / spp; f[2] = L.sb / spp;
+                    if (open) {       // (a walker that left for the slack launch is not resolved here: `open` is false)
+                        float *f = P.field + 3 * (size_t)((int32_t)pix - P.field_base);
+                        const float spp = (float)P.st.spp;
+                        f[0] = L.sr / spp; f[1] = L.sg / spp; f[2] = L.sb / spp;
+                    }
                     open = false;
                     wide[0] += S.a & 0xffffu; wide[1] += S.a >> 16; wide[2] += S.b & 0xffffu; wide[3] += S.b >> 16;
                     wide[4] += S.c; wide[5] += S.visits;
@@ -399,6 +426,16 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
                         T = trav_begin(slot_candidate(P.dm, L.hint, L.px, L.py));
                         if (!SLACK && T.best.d2 > P.dm.far2) {
                             mode = MODE_FAR;      // not started, not counted: the SLACK launch takes the step from here
+                            if (REFILL) {
+                                // a resident lane must go on draining the input queue (parked, it would strand the unread slots
+                                // of its wave's reservation, and a launch whose lanes all strayed would drop the rest of the
+                                // frame): the walker goes to the far end of the output queue right away -- strayed walkers are
+                                // few, so one atomic each -- and the lane takes the next pixel
+                                const uint32_t k = atomicAdd(P.count_far, 1u);
+                                store_lane(P.out, P.out_capacity - 1u - k, L, pix);
+                                open = false;
+                                mode = MODE_REFILL;
+                            }
                         } else {
                             S.a += 1u;
                             // SLACK: a query from so far away that every segment of the mesh ties within rounding is answered
@@ -431,14 +468,18 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
                 for (int b = 0; b < 3; ++b) {
                     if (mode == MODE_TRAV) {
                         S.visits++;
+                        WOST_TRACK_VISIT_PRE();
                         if (!trav_visit<SLACK>(P.dm, L.px, L.py, T, stk)) mode = MODE_WAIT;
+                        WOST_TRACK_VISIT_POST();
                     }
                 }
             } else {
                 for (int b = 0; b < P.trav_burst; ++b) {
                     if (mode == MODE_TRAV) {
                         S.visits++;
+                        WOST_TRACK_VISIT_PRE();
                         if (!trav_visit<SLACK>(P.dm, L.px, L.py, T, stk)) mode = MODE_WAIT;
+                        WOST_TRACK_VISIT_POST();
                     }
                 }
             }
@@ -459,19 +500,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
         const uint32_t k = block_push(alive && open && far, P.count_far);
         if (far) s = P.out_capacity - 1u - k;
     }
-    if (alive && open) {
-        WalkQueue &q = P.out;
-        q.pix[s] = pix;
-        q.x0[s] = L.x0; q.y0[s] = L.y0;
-        q.px[s] = L.px; q.py[s] = L.py;
-        q.rng[s] = L.rng.state;
-        q.meta[s] = META_PACK(L.sample, L.depth, L.on_n ? 1 : 0);
-        q.nx[s] = L.nx; q.ny[s] = L.ny;
-        q.hint[s] = L.hint;
-        q.thp[s] = L.thp;
-        q.sr[s] = L.sr; q.sg[s] = L.sg; q.sb[s] = L.sb;
-        q.d0_d2[s] = L.d0_d2; q.d0_slot[s] = L.d0_slot;
-    }
+    if (alive && open) store_lane(P.out, s, L, pix);
     // ---- statistics: wave reduction, one atomic per counter per wave -----------------------
     uint32_t v[7] = {(S.a & 0xffffu) + wide[0], (S.a >> 16) + wide[1], (S.b & 0xffffu) + wide[2], (S.b >> 16) + wide[3],
                      S.c + wide[4], S.visits + wide[5], 0u};
@@ -493,8 +522,160 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(R
         atomicAdd(&st->trav_trips, (unsigned long long)trav_trips);
         atomicAdd(&st->step_trips, (unsigned long long)step_trips);
     }
+#ifdef WOST_TRACK
+    {
+        uint32_t w[4] = {trk_leaf, trk_ge6, trk_ge10, trk_ge14};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            for (int off = 32; off > 0; off >>= 1) w[k] += __shfl_down(w[k], off);
+        for (int off = 32; off > 0; off >>= 1) trk_sp = max(trk_sp, __shfl_down(trk_sp, off));
+        if (lane == 0) {
+            StatsDev *st = my_stats(P.stats);
+            atomicAdd(&st->leaf_visits, (unsigned long long)w[0]);
+            atomicAdd(&st->sp_ge6, (unsigned long long)w[1]);
+            atomicAdd(&st->sp_ge10, (unsigned long long)w[2]);
+            atomicAdd(&st->sp_ge14, (unsigned long long)w[3]);
+            atomicMax(&st->max_stack, (unsigned long long)trk_sp);
+        }
+    }
+#endif
 }
 
+
+// ------------------------------------------------------------------------------------------
+// the walk round of an under-filled launch: four lanes per walker (wost_quad.h)
+// ------------------------------------------------------------------------------------------
+// Same rounds, same queue records, same per-walker arithmetic as walk_round_kernel -- and so the same field, counters
+// and visiting order -- but a quad of lanes holds ONE walker: the closest-point descent is shared between the four
+// lanes (one child box each), everything else runs replicated.  The host launches it when the walkers left would fill
+// less than a quarter of the resident lanes, where a launch lasts as long as its longest chain of dependent visits.
+template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, bool SOURCE, bool SLACK>
+__global__ __launch_bounds__(256, 4) void walk_quad_kernel(RoundParams P)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const int j = threadIdx.x & 3;
+    const QuadColumn stk{lds_stack + (threadIdx.x >> 2) * P.stack_stride};     // stack_stride = entries per column here
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    // lane_shift > 0 (the very last rounds): only every 2^shift-th quad holds a walker, down to one walker per wave -- such a
+    // wave never waits for another walker's query
+    const uint32_t quad_id = tid >> 2;
+    const uint32_t slot = quad_id >> P.lane_shift;
+    const uint32_t n_in = *P.count_in;
+    const bool valid = slot < n_in && (quad_id & ((1u << P.lane_shift) - 1u)) == 0u;
+    Lane L;
+    LaneStats S{0, 0, 0, 0};
+    uint32_t pix = 0;
+    bool alive = false;
+    if (valid) {
+        load_lane(P.in, slot, L, pix);
+        alive = L.sample < (uint32_t)P.st.spp;
+    }
+    const bool open = valid;
+    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_FAR = 6, MODE_HUGE = 7 };
+    const bool has_d = P.dm.n_segs > 0;
+    int mode = alive ? MODE_WAIT : MODE_DONE;       // quad-uniform throughout
+    bool fresh = true;
+    int budget = P.steps_per_round;
+    Trav T = trav_begin(Closest{WOST_INF, -1});
+    uint32_t trav_trips = 0, step_trips = 0;
+    for (;;) {
+        const int n_trav = __popcll(__ballot(mode == MODE_TRAV));
+        const int n_wait = __popcll(__ballot(mode == MODE_WAIT));
+        if (n_trav + n_wait == 0) break;
+        if (n_wait * P.wait_weight >= n_trav * 8) {
+            ++step_trips;
+            if (mode == MODE_WAIT) {
+                if (!fresh) {
+                    const uint32_t status = step_finish<NEUMANN_EMISSIVE, NEUMANN_TREE, SOURCE>(P.dm, P.nm, P.st, L, T.best, stk, P.src);
+                    const bool ended = (status & STEP_ENDED) != 0u;
+                    S.b += ((status >> 1) & 1u) | (((status >> 2) & 1u) << 16);
+                    S.c += (status >> 3) & 1u;
+                    if (ended) {
+                        L.sample++;
+                        L.px = L.x0; L.py = L.y0;
+                        L.depth = 0; L.on_n = false; L.nx = 0.0f; L.ny = 0.0f;
+                        L.thp = 1.0f;
+                        L.hint = L.d0_slot;
+                        alive = L.sample < (uint32_t)P.st.spp;
+                    }
+                    --budget;
+                }
+                fresh = false;
+                if (alive && budget > 0) {
+                    if (!has_d || L.depth == 0) {
+                        S.a += 1u + ((L.depth == 0) ? 0x10000u : 0u);
+                        T.best = Closest{L.d0_d2, L.d0_slot};
+                        mode = MODE_WAIT;
+                    } else {
+                        T = trav_begin(slot_candidate(P.dm, L.hint, L.px, L.py));
+                        if (!SLACK && T.best.d2 > P.dm.far2) {
+                            mode = MODE_FAR;
+                        } else {
+                            S.a += 1u;
+                            mode = (SLACK && T.best.d2 > P.dm.huge2) ? MODE_HUGE : MODE_TRAV;
+                        }
+                    }
+                } else {
+                    mode = MODE_DONE;
+                }
+            }
+            if (SLACK) {
+                unsigned long long hb = __ballot(mode == MODE_HUGE);
+                while (hb) {
+                    const int src = __builtin_ctzll(hb);
+                    const Closest r = closest_point_wave(P.dm, __shfl(L.px, src), __shfl(L.py, src));
+                    if (((int)(threadIdx.x & 63) >> 2) == (src >> 2)) {
+                        T.best = r;
+                        mode = MODE_WAIT;
+                    }
+                    hb &= ~(0xfull << (src & ~3));
+                }
+            }
+        } else {
+            ++trav_trips;
+            for (int b = 0; b < P.trav_burst; ++b) {
+                if (mode == MODE_TRAV) {
+                    S.visits++;
+                    if (!quad_visit<SLACK>(P.dm, L.px, L.py, T, stk, j)) mode = MODE_WAIT;
+                }
+            }
+        }
+    }
+    const bool lead = j == 0;       // one lane of the quad speaks for the walker
+    if (open && !alive && lead) {
+        float *f = P.field + 3 * (size_t)((int32_t)pix - P.field_base);
+        const float spp = (float)P.st.spp;
+        f[0] = L.sr / spp; f[1] = L.sg / spp; f[2] = L.sb / spp;
+    }
+    const int lane = threadIdx.x & 63;
+    const bool far = !SLACK && mode == MODE_FAR;
+    uint32_t s = block_push(alive && open && !far && lead, P.count_out);
+    if (!SLACK) {
+        __syncthreads();
+        const uint32_t k = block_push(alive && open && far && lead, P.count_far);
+        if (far) s = P.out_capacity - 1u - k;
+    }
+    if (alive && open && lead) store_lane(P.out, s, L, pix);
+    uint32_t v[7] = {(S.a & 0xffffu), (S.a >> 16), (S.b & 0xffffu), (S.b >> 16), S.c, S.visits, 0u};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        uint32_t x = lead ? v[k] : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        v[k] = x;
+    }
+    if (lane == 0) {
+        StatsDev *st = my_stats(P.stats);
+        if (v[0]) atomicAdd(&st->steps, (unsigned long long)v[0]);
+        if (v[1]) atomicAdd(&st->started, (unsigned long long)v[1]);
+        if (v[2]) atomicAdd(&st->absorbed, (unsigned long long)v[2]);
+        if (v[3]) atomicAdd(&st->truncated, (unsigned long long)v[3]);
+        if (v[4]) atomicAdd(&st->nhits, (unsigned long long)v[4]);
+        if (v[5]) atomicAdd(&st->inner_visits, (unsigned long long)v[5]);
+        atomicAdd(&st->trav_trips, (unsigned long long)trav_trips);
+        atomicAdd(&st->step_trips, (unsigned long long)step_trips);
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // batch query kernels (the lbvh::query_device call sites, exposed for tests and SDF renders)
@@ -771,6 +952,8 @@ struct wost_context {
     int trav_burst = 3;
     int time_kernels = 1;
     int refill = -1;       // -1 = automatic (few samples per pixel), 0 = never, 1 = always
+    int quad = -1;         // four lanes per walker in under-filled launches: -1 = automatic, 0 = never, 1 = every ordinary round
+    double quad_fill = 1.0;   // automatic: when 4 x walkers <= quad_fill x resident lanes
     uint32_t *cursor = nullptr;
     hipStream_t far_stream = nullptr;          // the launches that take strayed walkers through the SLACK kernel (run_solve)
     hipEvent_t far_ev0 = nullptr, far_ev1 = nullptr;
@@ -941,6 +1124,12 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "refill") {
         if (value != -1 && value != 0 && value != 1) return fail(WOST_ERR_INVALID, "refill must be -1 (auto), 0 or 1");
         h->refill = (int)value;
+    } else if (k == "quad") {
+        if (value != -1 && value != 0 && value != 1) return fail(WOST_ERR_INVALID, "quad must be -1 (auto), 0 or 1");
+        h->quad = (int)value;
+    } else if (k == "quad_fill") {
+        if (!(value > 0) || value > 64) return fail(WOST_ERR_INVALID, "quad_fill must be in (0, 64]");
+        h->quad_fill = value;
     } else if (k == "thin_waves") {
         h->thin_waves = value != 0;
     } else if (k == "time_kernels") {
@@ -982,6 +1171,19 @@ static void launch_round(bool has_src, bool refill, bool ntree, bool emissive, u
         if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, false, false, false, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
         else hipLaunchKernelGGL((walk_round_kernel<false, false, false, false, SLACK>), dim3(grid), dim3(bs), lds_round, stream, rp);
     }
+}
+
+// the quad instantiation (four lanes per walker) for an ordinary launch
+static void launch_quad(bool has_src, bool ntree, bool emissive, unsigned grid, int bs, size_t lds, hipStream_t stream, const RoundParams &rp)
+{
+#define WOST_QUAD_CASE(E, T, S)                                                                                                  \
+    if (emissive == E && ntree == T && has_src == S) {                                                                           \
+        hipLaunchKernelGGL((walk_quad_kernel<E, T, S, false>), dim3(grid), dim3(bs), lds, stream, rp);                          \
+        return;                                                                                                                  \
+    }
+    WOST_QUAD_CASE(false, false, false) WOST_QUAD_CASE(true, false, false) WOST_QUAD_CASE(false, true, false) WOST_QUAD_CASE(true, true, false)
+    WOST_QUAD_CASE(false, false, true) WOST_QUAD_CASE(true, false, true) WOST_QUAD_CASE(false, true, true) WOST_QUAD_CASE(true, true, true)
+#undef WOST_QUAD_CASE
 }
 
 static WalkQueue queue_from(const WalkQueue &q, size_t k)
@@ -1068,7 +1270,8 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         // busy lanes wait (tools/scratch/bench2d_wiggly.py: 3.87 -> 4.40 x 10^8 walk-steps/s on 3000 segments)
         rp.wait_weight = (ntree && !c->wait_weight_set) ? 1 : c->wait_weight;
         rp.trav_burst = c->trav_burst;
-        const size_t lds_round = lds;
+        // developer experiment: extra LDS per block lowers the number of resident blocks (occupancy sensitivity)
+        const size_t lds_round = lds + (getenv("WOST_EXP_LDS_PAD") ? (size_t)atoi(getenv("WOST_EXP_LDS_PAD")) : 0);
         // Walkers that left the previous launch at a query beyond the plain kernel's range wait at the far end of its output queue,
         // which is this launch's input queue.  The SLACK instantiation takes them through max_depth steps -- the walk that strayed
         // ends within that many -- on a stream of its own, next to this launch, and appends them to the same output queue (both
@@ -1118,9 +1321,21 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
             rp.cursor = c->cursor;
             rp.steps_per_round = 0x7fffffff;
         }
+        // Under-filled launch: four lanes per walker (walk_quad_kernel).  Such a launch lasts as long as its longest chain of
+        // dependent node visits; sharing a descent between the lanes of a quad halves that chain.
+        const bool quad = !refill && n_active > 0 &&
+                          (c->quad == 1 || (c->quad == -1 && 4.0 * (double)n_active <= c->quad_fill * (double)resident_threads));
         // (the last strayed walkers can outlive the ordinary queue: then only their launch runs)
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
-        if (n_active > 0) {
+        if (quad) {
+            // few walkers: fewer quads per wave (16 -> 4 -> 1), as long as the waves still fit the chip
+            rp.lane_shift = 0;
+            while (rp.lane_shift < 4 && ((uint64_t)n_active << (2 + rp.lane_shift + 2)) <= resident_threads) rp.lane_shift += 2;
+            rp.stack_stride = stack_depth;      // entries per (contiguous) quad column
+            grid = (unsigned)((((uint64_t)n_active << (2 + rp.lane_shift)) + bs - 1) / bs);
+            launch_quad(has_src, ntree, emissive, grid, bs, (size_t)stack_depth * (bs / 4) * sizeof(uint32_t), stream, rp);
+            HIP_TRY(hipGetLastError());
+        } else if (n_active > 0) {
             launch_round<false>(has_src, refill, ntree, emissive, grid, bs, lds_round, stream, rp);
             HIP_TRY(hipGetLastError());
         }
@@ -1149,7 +1364,12 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         sd.nhits += k.nhits; sd.inner_visits += k.inner_visits; sd.leaf_visits += k.leaf_visits;
         sd.trav_trips += k.trav_trips; sd.step_trips += k.step_trips;
         sd.max_stack = std::max(sd.max_stack, k.max_stack);
+        sd.sp_ge6 += k.sp_ge6; sd.sp_ge10 += k.sp_ge10; sd.sp_ge14 += k.sp_ge14;
     }
+#ifdef WOST_TRACK
+    fprintf(stderr, "WOST_TRACK: visits %llu leaf %llu max_stack %llu visits leaving >=6 / >=10 / >=14 entries: %llu / %llu / %llu\n", sd.inner_visits,
+            sd.leaf_visits, sd.max_stack, sd.sp_ge6, sd.sp_ge10, sd.sp_ge14);
+#endif
     if (stats) {
         const auto t_end = std::chrono::high_resolution_clock::now();
         stats->walk_steps = sd.steps;

@@ -188,7 +188,8 @@ int wost_vmm_loss_gradients(int device, const float *raw, const float *dir, cons
  * interpolation) -> bias-free ReLU MLP -> n_output raw values per point; Adam nested in a
  * debiased EMA.  Parameter vector order as in util/network.h:99-117 (network first, encoding
  * second): [W1 n_neurons x enc][W2..][Wout pad16(n_output) x n_neurons][grid levels].
- * fp32 arithmetic in this version (the reference computes in half precision). */
+ * fp32 arithmetic by default (the bit-exact mode); wost_net_set_option("precision" / "train_precision", 16) selects the
+ * reference's half precision for the inference and for the training passes (f16 MFMAs, fp32 master weights). */
 typedef struct wost_net_config {
     int32_t n_levels, n_features_per_level, base_resolution;
     float per_level_scale;
@@ -345,8 +346,8 @@ int wost_destroy(wost_handle h);
  * (util/green.h:77-119), uniformSampleSphere<3> / Hemisphere<3> (util/sampling.h:20-27,57-66) and
  * frameFromNormal(Vector3f) (util/transformation.h:62-67).  colors: per vertex 6 floats, rgb on the
  * side the triangle normal (p1-p0) x (p2-p0) points to, then rgb on the other side
- * (thrust::pair first / second, integrator/common.h:250-257).  This first slice walks the Neumann
- * mesh with flat loops (at most 64 triangles) and has no source term: WOST_ERR_UNSUPPORTED otherwise. */
+ * (thrust::pair first / second, integrator/common.h:250-257).  Neumann meshes of any size (flat loops up to 64
+ * triangles, the LBVH with normal cones beyond), optional source term (wost3_source_desc). */
 typedef struct wost3_mesh_desc {
     int32_t n_verts, n_tris;
     const float *verts;       /* n_verts * 3 */

@@ -418,6 +418,81 @@ def test_refill_is_chosen_automatically_for_one_sample(ladybug):
     it.close()
 
 
+def test_quad_rounds_match_oracle(oracle, ladybug, fille):
+    """walk_quad_kernel -- four lanes per walker, the descent shared between the lanes of a quad (wost_quad.h): the launch
+    of an under-filled round.  Forced for every round here; same arithmetic per child, same keys and visiting order, so
+    field and counters stay bit-exact: shipped scenes, exact ties, mixed boundaries with a mask, a 3000-segment emissive
+    Neumann boundary on the tree, a source term, strayed walkers (open boundary seen from afar), short rounds."""
+    from conftest import box_problem, wiggly_problem
+    from elaina_amd import Problem
+    _assert_same_solve(oracle, ladybug, 96, 80, 5, 64, 1.0, quad=1)
+    _assert_same_solve(oracle, fille, 64, 48, 3, 128, 1.0, quad=1, steps_per_round=7, block_size=64)
+    p = box_problem(d_sides=(0, 2), n_sides=(1, 3), value=lambda x, y: y, flux=lambda x, y, s: 0.3 * (s - 2))
+    p.mask = (np.arange(70 * 50) % 3 != 0).astype(np.uint8)
+    _assert_same_solve(oracle, p, 70, 50, 3, 32, 1e-3, quad=1, wait_weight=1, trav_burst=1)
+    _assert_same_solve(oracle, wiggly_problem(emissive=True), 48, 48, 2, 24, 0.05, quad=1)
+    _assert_same_solve(oracle, _with_source(wiggly_problem(emissive=False), -130.0, 130.0, intensity=1e-3), 40, 40, 2, 24, 0.05, quad=1)
+    # two rows of collinear segments: exact ties between leaves and inside a leaf
+    xs = np.arange(41, dtype=np.float32)
+    verts = np.concatenate([np.stack([xs, np.zeros(41, np.float32)], 1), np.stack([xs, np.full(41, 2.0, np.float32)], 1)])
+    segs = np.concatenate([np.stack([np.arange(40), np.arange(40) + 1], 1), np.stack([np.arange(40) + 41, np.arange(40) + 42], 1)])
+    segs = np.concatenate([segs, segs[5:25]]).astype(np.int32)
+    cols = np.random.default_rng(3).uniform(0, 1, (82, 6)).astype(np.float32)
+    tie = Problem(d_verts=verts, d_segs=segs, d_colors=cols, probe=(30.0, 20.0, 1.0, 0.0, 1.0))
+    _assert_same_solve(oracle, tie, 64, 64, 4, 16, 0.05, quad=1)
+    # an open polyline seen from three scene sizes away: most walks stray and finish in the slack launch
+    t = np.linspace(0.0, 1.0, 301)
+    ov = np.stack([100.0 * t, 20.0 * np.sin(9.0 * t)], 1).astype(np.float32)
+    os_ = np.stack([np.arange(300), np.arange(300) + 1], 1).astype(np.int32)
+    far = Problem(d_verts=ov, d_segs=os_, d_colors=cols[:1].repeat(301, 0), probe=(300.0, 50.0, 0.0, 0.0, 1.0))
+    _assert_same_solve(oracle, far, 64, 64, 3, 12, 0.5, quad=1)
+
+
+def test_quad_rounds_are_chosen_for_under_filled_launches(ladybug):
+    """automatic choice: the last rounds of a solve and a small shard run four lanes per walker; the field does not change"""
+    from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+    it = UniformIntegrator(ladybug, UniformIntegratorSettings((512, 512), 32, 64, 1.0))
+    it.set_option("quad", 0)
+    it.solve()
+    a, sa = it.solution.copy(), dict(it.last_stats)
+    it.set_option("quad", -1)
+    it.solve()
+    assert np.array_equal(a, it.solution) and it.last_stats["walk_steps"] == sa["walk_steps"]
+    it.set_option("quad", 1)
+    it.solve()
+    assert np.array_equal(a, it.solution) and it.last_stats["walk_steps"] == sa["walk_steps"]
+    it.close()
+
+
+def test_refill_launch_open_scene_every_walk_strays(oracle):
+    """An open Dirichlet polyline seen from three scene sizes away, 1024^2 at 1 spp (the automatic REFILL launch with a
+    queue of 2.7 residencies): almost every walk strays beyond the plain visits' range at depth 1.  A resident lane whose
+    walker strays hands it to the slack launch at once and goes on draining the queue; parked, the lanes stranded the
+    unread pixels of the frame (round-2 advisor finding).  Every pixel must be solved: counters, then a band against the
+    oracle bit for bit."""
+    from elaina_amd import Problem, UniformIntegrator, UniformIntegratorSettings
+    t = np.linspace(0.0, 1.0, 301)
+    verts = np.stack([100.0 * t, 20.0 * np.sin(9.0 * t) + 5.0 * np.cos(31.0 * t)], 1).astype(np.float32)
+    segs = np.stack([np.arange(300), np.arange(300) + 1], 1).astype(np.int32)
+    rng = np.random.default_rng(5)
+    cols = rng.uniform(0.0, 1.0, size=(301, 6)).astype(np.float32)
+    p = Problem(d_verts=verts, d_segs=segs, d_colors=cols, probe=(300.0, 50.0, 0.0, 0.0, 1.0))
+    W = 1024
+    it = UniformIntegrator(p, UniformIntegratorSettings((W, W), 1, 12, 0.5))
+    it.solve()
+    s, a = dict(it.last_stats), it.solution.copy()
+    assert s["walks_started"] == W * W == s["walks_absorbed"] + s["walks_truncated"]
+    it.set_option("refill", 0)
+    it.solve()
+    assert it.last_stats["walks_started"] == W * W and it.last_stats["walk_steps"] == s["walk_steps"]
+    assert np.array_equal(a, it.solution)
+    it.close()
+    b, e = 500 * W, 524 * W
+    ref = oracle.solve(p.as_dict(), W, W, 1, 12, 0.5, pixel_begin=b, pixel_end=e, threads=THREADS)
+    assert np.array_equal(a[b:e], ref["field"])
+    assert np.isfinite(a).all()
+
+
 def _with_source(problem, lo, hi, cells=24, seed=9, intensity=0.7):
     """attach a smooth random RGB source grid covering [lo, hi]^2 (and a margin of zero outside)"""
     rng = np.random.default_rng(seed)

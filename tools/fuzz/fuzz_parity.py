@@ -67,7 +67,8 @@ def main():
             it.set_option("refill", 1 if p.source is None else 0)
         if rng.uniform() < 0.4:            # launch shapes and scheduler constants: none of them may change a bit
             opts = {"steps_per_round": int(rng.choice([1, 3, 17, 256])), "block_size": int(rng.choice([64, 128, 256])),
-                    "wait_weight": int(rng.choice([1, 8, 64])), "trav_burst": int(rng.choice([1, 3, 5])), "thin_waves": int(rng.choice([0, 1]))}
+                    "wait_weight": int(rng.choice([1, 8, 64])), "trav_burst": int(rng.choice([1, 3, 5])), "thin_waves": int(rng.choice([0, 1])),
+                    "quad": int(rng.choice([0, 1]))}       # (quad: four lanes per walker in every ordinary round)
             feat.append(str(opts))
             for k, v in opts.items():
                 it.set_option(k, v)

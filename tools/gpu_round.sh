@@ -2,11 +2,15 @@
 # one GPU-box trip: gpu tests, smoke, bench, rocprof kernel trace + PMC passes of the bench command.
 # TAG names the output directory under gpurun_out/; STAGES selects what runs (default: all).
 export TMPDIR=/tmp
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 STAGES=${STAGES:-"tests smoke micro bench trace pmc"}
 mkdir -p gpurun_out/$TAG
 has() { [[ " $STAGES " == *" $1 "* ]]; }
-if has tests; then python -m pytest tests -x -q -m gpu 2>&1 | tail -15 | tee gpurun_out/$TAG/pytest_gpu.log; fi
+if has tests; then
+  python -m pytest tests -x -q -m gpu -rs 2>&1 | tail -25 | tee gpurun_out/$TAG/pytest_gpu.log
+  # a green run with skipped GPU tests is a broken environment, not a pass
+  if grep -qE '[0-9]+ skipped' gpurun_out/$TAG/pytest_gpu.log; then echo "GPU TESTS WERE SKIPPED" | tee -a gpurun_out/$TAG/pytest_gpu.log; fi
+fi
 if has smoke; then python __graft_entry__.py smoke 2>&1 | tail -3 | tee gpurun_out/$TAG/smoke.log; fi
 if has micro; then ./tools/micro/valu_rate 2>&1 | tee gpurun_out/$TAG/valu_rate.txt; fi
 if has bench; then python bench.py 2>gpurun_out/$TAG/bench.err | grep -v amdgpu.ids | tee gpurun_out/$TAG/bench.json; tail -5 gpurun_out/$TAG/bench.err; fi
