@@ -115,14 +115,24 @@ def cpu_baseline(problem, frame, spp, depth, eps, target_s=15.0):
     }, (b, e, r["field"])
 
 
-def valu_block():
-    """VALU figures of walk_round_kernel from the committed PMC summary (rocprofv3 --pmc passes of this
-    same command cannot run inside this process): tools/gpu_round.sh writes profiles/walk_round_valu.json."""
-    path = os.path.join(ROOT, "profiles", "walk_round_valu.json")
+def committed_counters(name, keys):
+    """Figures derived from rocprofv3 --pmc passes (they cannot run inside this process): tools/gpu_round.sh writes
+    profiles/<name>.json together with the identity of the kernel sources it measured (elaina_amd.build.source_id);
+    "stale" says whether the running tree still has those sources."""
+    path = os.path.join(ROOT, "profiles", name + ".json")
     if not os.path.exists(path):
         return None
+    from elaina_amd.build import source_id
     v = json.load(open(path))
-    return {k: v.get(k) for k in ("pipe_busy", "lane_efficiency", "lane_instr_per_step", "source")}
+    out = {k: v.get(k) for k in keys}
+    out["measured_on_sources"] = v.get("source_id")
+    out["stale"] = v.get("source_id") != source_id()
+    return out
+
+
+def valu_block():
+    """VALU figures of walk_round_kernel (profiles/walk_round_valu.json)"""
+    return committed_counters("walk_round_valu", ("pipe_busy", "lane_efficiency", "lane_instr_per_step", "source"))
 
 
 def torch_zeros_like(t):
@@ -183,10 +193,18 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
     field = torch.zeros(frame * frame * 3, dtype=torch.float32, device=env.dev)
     stream = torch.cuda.current_stream(env.dev)
 
+    exchange_ms = [0.0]
+
     def one_pass(integ):
         field.zero_()
         st = integ.solve_sharded(env.rank, env.world, field.data_ptr(), stream.cuda_stream)
-        env.D.reduce_field(field, env.world)
+        if env.world > 1:
+            # the one exchange of the solve, timed on its own (it waits for the slowest rank's shard: rank imbalance shows here)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            env.D.assemble_field(field, env.world, env.rank, frame, frame)
+            torch.cuda.synchronize()
+            exchange_ms[0] += (time.perf_counter() - t) * 1e3
         return st
 
     # time-to-1spp (cold first pass of a fresh handle, then steady state), outside the timed region
@@ -233,6 +251,19 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
                      "kernel": "walk_round_kernel", "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
                      "algorithmic_bytes_per_walk_step": BYTES_PER_STEP},
     }
+    if env.world > 1:
+        # per-rank figures of the timed passes, so that an N-GPU record shows imbalance at a glance
+        mine = torch.tensor([kernel_ms / steps, float(steps_local) / steps, exchange_ms[0] / (steps + warmup + (4 if one_spp else 0))],
+                            dtype=torch.float64, device=env.dev)
+        allr = [torch.zeros_like(mine) for _ in range(env.world)]
+        env.dist.all_gather(allr, mine)
+        a = torch.stack(allr).cpu().numpy()
+        out["ranks"] = {"kernel_ms_per_pass": {"min": float(a[:, 0].min()), "max": float(a[:, 0].max()), "mean": float(a[:, 0].mean())},
+                        "walk_steps_per_pass": {"min": float(a[:, 1].min()), "max": float(a[:, 1].max())},
+                        "exchange_ms_per_pass": {"max": float(a[:, 2].max()), "mean": float(a[:, 2].mean()),
+                                                 "what": "one %s of the %d-byte field (waits for the slowest rank)" % (
+                                                     "all-gather of disjoint shards" if field.numel() * 4 >= env.D.GATHER_THRESHOLD_BYTES
+                                                     else "all-reduce of zero-padded frames", field.numel() * 4)}}
     if t1:
         out["time_to_1spp_ms"] = {"cold": t1[0], "steady": sorted(t1[1:])[len(t1[1:]) // 2]}
     if sched["trav_trips"] and steps_local:
@@ -272,7 +303,7 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
         env.barrier()
         t0 = time.perf_counter()
         s = gi.solve_sharded(env.rank, env.world, field.data_ptr())
-        env.D.reduce_field(field, env.world)
+        env.D.assemble_field(field, env.world, env.rank, frame, frame)
         torch.cuda.synchronize()
         env.barrier()
         dt = time.perf_counter() - t0
@@ -321,6 +352,13 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
     infer_tf = (net_points / max(env.world, 1)) * FLOP_PER_POINT / max(infer_s, 1e-9) / 1e12 if infer_s > 0 else probe
     half_train = (args.net_train_precision or precision or args.net_precision) == 16
     peak_tf = MFMA_F16_PEAK_TF if half else MFMA_F32_PEAK_TF
+    # the training step: forward + backward + weight gradients = 3 x FLOP_PER_POINT per training sample
+    train_tf = 3.0 * FLOP_PER_POINT * (train_samples / max(env.world, 1)) / max(train_s, 1e-9) / 1e12 if train_samples > 0 else None
+    train_peak = MFMA_F16_PEAK_TF if half_train else MFMA_F32_PEAK_TF
+    # the kernel the solve spends most of its time in: VALU / matrix-pipe / LDS figures from the committed PMC pass
+    sample_kernel = committed_counters("guided_sample_f16" if half else "guided_sample_f32",
+                                       ("kernel", "share_of_gpu_time", "pipe_busy", "lane_efficiency", "mfma_busy", "lds_conflict_ratio",
+                                        "lane_instr_per_step", "source"))
     out = {
         "workload": "%s guided %dx%d grid %d spp (train %d) depth %d eps %g" % (scene, frame, frame, spp, min(train_spp, spp), depth, eps),
         "value": walk_steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "walk_steps_per_pass": walk_steps / steps,
@@ -330,6 +368,12 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
         "shared_network": bool(args.shared_network and env.world > 1),
         "network_precision": ("f16 inference (v_mfma_f32_16x16x16_f16), " if half else "fp32 inference (v_mfma_f32_16x16x4_f32), ") +
                              ("f16 training passes, fp32 master weights" if half_train else "fp32 training"),
+        "roofline": {"bound": "valu", "kernel": "guided_sample_kernel", "counters": sample_kernel,
+                     "what": "the dominant kernel of this configuration (one launch per sample: walk, network inference on the matrix "
+                             "cores and mixture sampling in one wave); the network-only probe is roofline_mfma"},
+        "training_step": {"ms": (train_s / max(opt_steps / max(env.world, 1), 1.0)) * 1e3 if opt_steps else None,
+                          "achieved": train_tf, "peak": train_peak, "unit": "TFLOP/s", "frac": (train_tf / train_peak) if train_tf else None,
+                          "flop_per_sample": 3.0 * FLOP_PER_POINT, "samples_per_step": train_samples / max(opt_steps, 1.0)},
         "roofline_mfma": {"bound": "mfma", "kernel": ("net_forward_h_kernel" if half else "net_forward_mfma_kernel") +
                           (" (inference launches, HIP events)" if infer_s > 0 else
                            " (inference launches of a 6-spp pass of the per-depth path, HIP events; the solve itself evaluates the network inside guided_sample_kernel)"),
@@ -340,6 +384,43 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
                           "probe": None if (infer_s > 0 or probe is None) else {"points": probe_points, "kernel_s": probe_s}},
     }
     return {"out": out, "field": field, "problem": problem, "depth": depth, "eps": eps}
+
+
+def run_guiding_gain(env):
+    """Does the guiding guide?  A small bright Dirichlet disc and a large dark one in a reflecting box
+    (elaina_amd/scenes.py): RMSE of 64 trained + 64 guided samples against 128 uniform ones, both measured on a
+    8192-sample field of the uniform integrator (tests/test_guided_integrator.py::test_gpu_guiding_reduces_the_variance
+    gates the same numbers)."""
+    import numpy as np
+    from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    from elaina_amd.scenes import BRIGHT_DISC_AABB, bright_disc_scene
+    p = bright_disc_scene()
+    w, depth, eps = 128, 128, 0.05
+
+    def uniform(spp):
+        it = UniformIntegrator(p, UniformIntegratorSettings((w, w), spp, depth, eps), device=env.local)
+        it.solve()
+        f = it.solution.copy()
+        it.close()
+        return f
+
+    ref, u = uniform(8192), uniform(128)
+    out = {"scene": "bright disc (r 3) + dark disc (r 14) in a reflecting box, 128x128, depth 128, eps 0.05",
+           "reference": "uniform integrator, 8192 spp", "rmse_uniform_128spp": float(np.sqrt(np.mean((u - ref) ** 2)))}
+    for prec in (32, 16):
+        st = GuidedIntegratorSettings(frameSize=(w, w), samplesPerPixel=128, trainSppCount=64, maxWalkingDepth=depth, epsilonShell=eps,
+                                      batchSize=65536, minBatchSize=8192)
+        g = GuidedIntegrator(p, st, BRIGHT_DISC_AABB, device=env.local)
+        if prec == 16:
+            g.network.set_option("precision", 16)
+            g.network.set_option("train_precision", 16)
+        g.solve()
+        r = float(np.sqrt(np.mean((g.solution - ref) ** 2)))
+        out["rmse_guided_f%d_64+64spp" % prec] = r
+        out["ratio_f%d" % prec] = r / out["rmse_uniform_128spp"]
+        g.close()
+    return out
 
 
 def icosphere(subdiv, radius):
@@ -369,7 +450,7 @@ def icosphere(subdiv, radius):
 
 def run_uniform3d(env, args):
     """SURVEY 8 f.3, the 3-D uniform integrator, synthetic scenes (the reference ships no 3-D data): (a) a Dirichlet
-    icosphere of 1280 triangles with the harmonic boundary values x y + z, the slice z = 0.1 (tools/scratch/bench3d.py's scene); (b) a Dirichlet ball
+    icosphere of 1280 triangles with the harmonic boundary values x y + z, the slice z = 0.1 (tools/probes/bench3d.py's scene); (b) a Dirichlet ball
     inside a zero-flux Neumann shell of 1280 triangles (silhouette and ray queries on the tree).  One timed solve each
     after a warm-up solve; a band of (a) against the oracle."""
     import numpy as np
@@ -436,16 +517,16 @@ def main():
             line["time_to_1spp_ms"] = o["time_to_1spp_ms"]
         if "scheduler" in o:
             line["scheduler"] = o["scheduler"]
+        if "ranks" in o:
+            line["ranks"] = o["ranks"]
         roof = o["roofline"]
         if env.rank == 0:
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "walk_round_traffic.json")
-            if os.path.exists(tpath) and args.config == 2:
-                # PMC passes cannot run inside this process: the figure comes from the committed
-                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command (tools/gpu_round.sh)
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            roof["traffic"] = traffic
+            # PMC passes cannot run inside this process: the figure comes from the committed
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command (tools/gpu_round.sh)
+            tr = committed_counters("walk_round_traffic", ("hbm_bytes_per_launch",)) if args.config == 2 else None
+            roof["traffic"] = tr["hbm_bytes_per_launch"] if tr else None
             roof["traffic_unit"] = "HBM bytes per launch (profiles/walk_round_traffic.json)"
+            roof["traffic_stale"] = tr["stale"] if tr else None
             roof["valu"] = valu_block() if args.config == 2 else None
             # "bound" is what the counters say binds the kernel (VALU issue); achieved/peak/frac stay the
             # SURVEY 8(d) HBM formula so that rounds remain comparable
@@ -467,8 +548,8 @@ def main():
         line.update({"value": o["value"], "ms_per_step": o["ms_per_step"],
                      "config": {"workload": o["workload"], "parallelism": "pixel-tiles x%d" % env.world,
                                 "walk_steps_per_pass": o["walk_steps_per_pass"], "config": args.config},
-                     "guided": {k: o[k] for k in o if k not in ("workload", "value", "ms_per_step", "walk_steps_per_pass", "roofline_mfma")},
-                     "roofline": o["roofline_mfma"]})
+                     "guided": {k: o[k] for k in o if k not in ("workload", "value", "ms_per_step", "walk_steps_per_pass", "roofline_mfma", "roofline")},
+                     "roofline": o["roofline"], "roofline_mfma": o["roofline_mfma"]})
         if env.rank == 0:
             f = r["field"].cpu().numpy()
             line["field_mean"] = float(f.mean())
@@ -503,6 +584,7 @@ def main():
                 e4h["rel_l2_vs_uniform_field"] = rel_l2(r4h["field"].cpu().numpy(), uniform_field.cpu().numpy())
             extras["cfg4_f16"] = e4h
             extras["uniform3d"] = run_uniform3d(env, args)
+            extras["guiding_gain"] = run_guiding_gain(env)
             if uniform_field is not None:
                 # SURVEY 8c, guided gate: against a 4096-spp field of the uniform integrator (bit-exact against the
                 # oracle at any spp) the guided estimator must not be noisier than the uniform one at equal spp

@@ -81,6 +81,17 @@ def build_library(force=False, verbose=False):
     return LIB_PATH
 
 
+def source_id():
+    """identity of the kernel sources (csrc/*.h, *.hip, *.cpp and include/wost.h): committed counter files carry the id of
+    the tree they were measured on, and bench.py marks them stale when the running tree differs"""
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp")))
+    for f in files + [os.path.join(_HERE, "..", "include", "wost.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 HOST_DIR = os.path.join(_HERE, "host")
 HOST_SOURCES = ["main.cpp", "exec.cpp", os.path.join("core", "problem.cpp"),
                 os.path.join("integrator", "common.cpp"), os.path.join("integrator", "uniform", "integrator.cpp"),

@@ -1264,9 +1264,13 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     G_TRY(hipMemsetAsync(g->stats, 0, kStatCopies * sizeof(GStatsDev), stream));
     if (g->sync) {
         // shared network: the summed gradients are divided by the number of ranks (include/wost.h)
+        // (WOST_SYNC_RANKS_I64_HOST was added to the callback's ops in library version 0.2: a callback written against 0.1 that
+        // refuses it keeps the old behaviour -- the summed gradient is used undivided -- instead of failing the solve)
         int64_t ranks = 1;
-        if (g->sync(g->sync_user, WOST_SYNC_RANKS_I64_HOST, &ranks, 1) != 0 || ranks < 1)
-            return set_error(WOST_ERR_DEVICE, "sync callback failed (rank count)");
+        if (g->sync(g->sync_user, WOST_SYNC_RANKS_I64_HOST, &ranks, 1) != 0 || ranks < 1) {
+            fprintf(stderr, "wost: the sync callback does not answer WOST_SYNC_RANKS_I64_HOST; shared gradients stay undivided\n");
+            ranks = 1;
+        }
         net_set_gradient_divisor(g->net, (float)ranks);
     } else {
         net_set_gradient_divisor(g->net, 1.0f);
@@ -1324,15 +1328,24 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         }
     }
     P.d0_d2 = g->d0_d2; P.cursor = g->cursor; P.stack_words = stack_words;
-    P.wait_weight = 4; P.trav_burst = 10;     // measured on config 4 (tools/scratch/fused_sweep.sh)
+    P.wait_weight = 4; P.trav_burst = 10;     // measured on config 4 (a sweep over both constants)
     if (const char *w = std::getenv("WOST_GUIDED_WAIT_WEIGHT")) P.wait_weight = std::max(1, std::atoi(w));
     if (const char *w = std::getenv("WOST_GUIDED_TRAV_BURST")) P.trav_burst = std::max(1, std::atoi(w));
-    P.tail_chunk = 4; P.tail_margin_pct = 300;      // tools/scratch/fused_sweep.sh: 3.52 -> 3.37 ms per trained sample of config 4
+    P.tail_chunk = 4; P.tail_margin_pct = 300;      // a sweep over both, DESIGN.md 4.9: 3.52 -> 3.37 ms per trained sample of config 4
     if (const char *w = std::getenv("WOST_GUIDED_TAIL_CHUNK")) P.tail_chunk = std::max(0, std::atoi(w));
     if (const char *w = std::getenv("WOST_GUIDED_TAIL_MARGIN")) P.tail_margin_pct = std::max(0, std::atoi(w));
     const int n_fused_threads = fused_threads(fused_half);
     const size_t lds_fused = ((size_t)stack_words * n_fused_threads + (size_t)(n_fused_threads / 64) * fused_xch_words(fused_half) +
                               (fused_half ? (size_t)2 * F.n_frag : (size_t)F.n_mlp)) * sizeof(uint32_t);
+    if (fused) {
+        // the stack columns grow with the depth of the trees: when the fused kernel's LDS no longer fits a block (the fp32
+        // fragments with a 10-level tree), the solve takes the one-launch-per-depth path instead of failing at the launch
+        int max_lds = 0;
+        if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, g->device) != hipSuccess || max_lds <= 0) max_lds = 64 * 1024;
+        int dev_optin = 0;
+        if (hipDeviceGetAttribute(&dev_optin, hipDeviceAttributeSharedMemPerBlockOptin, g->device) == hipSuccess && dev_optin > max_lds) max_lds = dev_optin;
+        if (lds_fused > (size_t)max_lds) fused = false;
+    }
 
     bool d0_valid = false;
     // ctor state (integrator.cu:1158-1160), prepareSolve (:125-126)
@@ -1564,6 +1577,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         hs.truncated += c.truncated; hs.nhits += c.nhits; hs.guided += c.guided; hs.net_points += c.net_points;
     }
     const double net_infer_ms = g->net_events.drain();
+    net_set_gradient_divisor(g->net, 1.0f);      // the rank count belongs to this solve: a later wost_net_train_step on the handle is a plain step
     if (stats) {
         *stats = wost_guided_stats{};
         stats->walk_steps = hs.steps; stats->walks_started = hs.started; stats->walks_absorbed = hs.absorbed;

@@ -300,7 +300,10 @@ __device__ __forceinline__ void store_lane(const WalkQueue &q, uint32_t s, const
 // few walkers through the SLACK = true instantiation -- node visits exact at any distance (trav_visit<true>), which costs this
 // kernel a quarter of its throughput: more visits and, above all, registers -- for the length of a walk and returns them.
 template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, bool REFILL = false, bool SOURCE = false, bool SLACK = false>
-__global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : 6) void walk_round_kernel(RoundParams P)
+#ifndef WOST_ROUND_WAVES
+#define WOST_ROUND_WAVES 6      // waves per SIMD the round kernel is compiled for (tuning builds override it)
+#endif
+__global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk_round_kernel(RoundParams P)
 {
     extern __shared__ uint32_t lds_stack[];       // the traversal stack columns, one per lane
     uint32_t *stack = lds_stack + threadIdx.x;
@@ -1011,7 +1014,8 @@ static void destroy_ctx(wost_context *c)
 
 extern "C" {
 
-const char *wost_version(void) { return "wost-hip 0.1 (gfx950)"; }
+// 0.2: the sync callback of a shared guiding network is also asked for the number of ranks (WOST_SYNC_RANKS_I64_HOST)
+const char *wost_version(void) { return "wost-hip 0.2 (gfx950)"; }
 
 const char *wost_last_error(void) { return g_last_error.c_str(); }
 
@@ -1267,7 +1271,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         rp.steps_per_round = c->steps_per_round > 0 ? c->steps_per_round : 256;
         rp.stack_stride = bs;
         // a step that answers its Neumann queries on the tree is long and divergent: served when eight ninths of the
-        // busy lanes wait (tools/scratch/bench2d_wiggly.py: 3.87 -> 4.40 x 10^8 walk-steps/s on 3000 segments)
+        // busy lanes wait (tools/probes/bench2d_wiggly.py: 3.87 -> 4.40 x 10^8 walk-steps/s on 3000 segments)
         rp.wait_weight = (ntree && !c->wait_weight_set) ? 1 : c->wait_weight;
         rp.trav_burst = c->trav_burst;
         // developer experiment: extra LDS per block lowers the number of resident blocks (occupancy sensitivity)

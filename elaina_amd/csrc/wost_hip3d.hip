@@ -1879,7 +1879,7 @@ struct wost3_context {
     float *field = nullptr;
     Stats3Dev *stats = nullptr;
     uint32_t *cursor = nullptr;
-    int wait_weight = 32, trav_burst = 3;   // tools/scratch/sweep3d.sh: a leaf visit (four exact triangle distances) is dear, steps are served early
+    int wait_weight = 32, trav_burst = 3;   // a sweep over both constants: a leaf visit (four exact triangle distances) is dear, steps are served early
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -1959,7 +1959,7 @@ static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, 
     P.tiled = (pixel_begin == 0 && pixel_end == (int32_t)c->n_pixels && ((c->settings.width | c->settings.height) & 7) == 0) ? 1 : 0;
     P.wait_weight = c->wait_weight; P.trav_burst = c->trav_burst;
     // a step that answers its Neumann queries on the tree is long and divergent: it waits until eight ninths of the
-    // busy walkers of the wave stand at it (tools/scratch/bench3d_shell.py: 1.8x over the Dirichlet-only setting on a 1280-triangle shell)
+    // busy walkers of the wave stand at it (tools/probes/bench3d_shell.py: 1.8x over the Dirichlet-only setting on a 1280-triangle shell)
     if (c->nm.view.n_tris > WOST3_FLAT_MAX) P.wait_weight = 1;
     if (const char *w = std::getenv("WOST3_WAIT_WEIGHT")) P.wait_weight = std::max(1, std::atoi(w));
     if (const char *w = std::getenv("WOST3_TRAV_BURST")) P.trav_burst = std::max(1, std::atoi(w));

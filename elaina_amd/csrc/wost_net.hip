@@ -1566,7 +1566,7 @@ void *net_gradient_buffer(wost_net *h, uint64_t *count)
 int net_f32_view(wost_net *h, F32NetView *out)
 {
     if (!h || !out) return set_error(WOST_ERR_INVALID, "null argument");
-    if (!h->use_mfma || !h->inference_f) return set_error(WOST_ERR_UNSUPPORTED, "the network does not run on the fp32 matrix kernels");
+    if (!h->use_mfma || !h->inference_f) return WOST_ERR_UNSUPPORTED;      // a probe: the caller falls back, no error is recorded
     out->L = h->L;
     out->frag = h->inference_f;
     out->grid = h->inference + h->L.n_mlp;
@@ -1576,7 +1576,7 @@ int net_f32_view(wost_net *h, F32NetView *out)
 int net_half_view(wost_net *h, HalfNetView *out)
 {
     if (!h || !out) return set_error(WOST_ERR_INVALID, "null argument");
-    if (h->precision != 16 || !h->inference_h) return set_error(WOST_ERR_UNSUPPORTED, "the network does not run its inference in half precision");
+    if (h->precision != 16 || !h->inference_h) return WOST_ERR_UNSUPPORTED;      // a probe, as above
     out->L = h->L;
     out->image = h->inference_h;
     return WOST_OK;

@@ -245,22 +245,11 @@ class GuidedIntegrator:
         _check(self.lib.wost_net_set_gradient_buffer(self.network._h, C.c_void_p(self._grad.data_ptr())),
                "wost_net_set_gradient_buffer")
 
+        from . import distributed as D
+        body = D.make_network_sync(self._grad, torch.cuda.synchronize)
+
         def sync(user, op, data, count):
-            try:
-                if op == capi.SYNC_SUM_I64_DEVICE:
-                    dist.all_reduce(self._grad, op=dist.ReduceOp.SUM)
-                    torch.cuda.synchronize()
-                elif op == capi.SYNC_RANKS_I64_HOST:
-                    C.cast(data, C.POINTER(C.c_int64))[0] = dist.get_world_size()
-                else:
-                    v = C.cast(data, C.POINTER(C.c_int64))
-                    t = torch.tensor([v[0]], dtype=torch.int64, device="cuda")
-                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                    v[0] = int(t.item())
-                return 0
-            except Exception as e:     # never let an exception cross the C boundary
-                print("share_network sync failed: %r" % (e,))
-                return 1
+            return body(op, data, count)
 
         self._sync = capi.SYNC_FN(sync)       # keep the trampoline alive
         _check(self.lib.wost_guided_set_sync(self._handle, self._sync, None), "wost_guided_set_sync")

@@ -183,18 +183,11 @@ void Problem<2>::loadConfig(const json &config, const fs::path &search_dir)
         if ((size_t)f.gcount() != rgb.size() * sizeof(float)) throw std::runtime_error("source grid file is too short: " + path);
         set_source(nx, ny, std::move(rgb), {sc[0], sc[1]}, {of[0], of[1]});
     }
-    // reference core/problem.cu:216-242: the image is loaded flipped vertically; a pixel is on when
-    // any of its R, G, B bytes is non-zero.  PNG only here (the reference goes through stb_image).
+    // reference core/problem.cu:216-242: the image is loaded flipped vertically; a pixel is on when any of its R, G, B
+    // values is non-zero.  PNG, OpenEXR and PFM are read (util/image_io.cpp); the reference goes through stb_image / tinyexr.
     if (const auto mp = json_get_optional<string>(config, "mask_path")) {
         int w = 0, h = 0;
-        std::vector<uint8_t> rgba;
-        read_png(resolve(*mp, search_dir), &w, &h, &rgba);
-        mask.assign((size_t)w * h, 0);
-        for (int y = 0; y < h; ++y)
-            for (int x = 0; x < w; ++x) {
-                const uint8_t *px = &rgba[4 * ((size_t)(h - 1 - y) * w + x)];
-                mask[(size_t)y * w + x] = (px[0] | px[1] | px[2]) ? 1 : 0;
-            }
+        read_mask_image(resolve(*mp, search_dir), &w, &h, &mask);
     }
     source_intensity = json_get_optional<float>(config, "source_intensity", 1.0f);
     dirichlet_intensity = json_get_optional<float>(config, "dirichlet_intensity", 1.0f);

@@ -134,6 +134,20 @@ int main(int argc, char **argv)
             return 1;
         }
     }
+    if (std::strcmp(argv[1], "--readmask") == 0 && argc > 3) {   // a mask image of any readable format to raw bytes (tests)
+        try {
+            int w = 0, h = 0;
+            std::vector<uint8_t> mask;
+            read_mask_image(argv[2], &w, &h, &mask);
+            std::ofstream f(argv[3], std::ios::binary);
+            f.write(reinterpret_cast<const char *>(mask.data()), (std::streamsize)mask.size());
+            std::cout << w << " " << h << std::endl;
+            return 0;
+        } catch (const std::exception &e) {
+            std::cerr << e.what() << std::endl;
+            return 1;
+        }
+    }
     try {
         run_expr(fs::path(argv[1]));
     } catch (const std::exception &e) {

@@ -399,4 +399,183 @@ void write_pfm(const fs::path &path, int width, int height, const std::vector<fl
     f.write(reinterpret_cast<const char *>(rgb.data()), (std::streamsize)(rgb.size() * sizeof(float)));
 }
 
+
+// ---- readers of the float formats (mask images, reference Image::loadImage core/texture.cu:26-80) ----------------------
+float half_to_float(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u;
+    uint32_t bits;
+    if (e == 0) {
+        if (m == 0) bits = sign;
+        else {      // subnormal: renormalise
+            int k = 0;
+            uint32_t mm = m;
+            while (!(mm & 1024u)) { mm <<= 1; ++k; }
+            bits = sign | ((uint32_t)(113 - k) << 23) | ((mm & 1023u) << 13);
+        }
+    } else if (e == 31) bits = sign | 0x7f800000u | (m << 13);
+    else bits = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+// PFM ("PF" colour, "Pf" grey; scale < 0 = little endian).  Rows are returned in file order.
+void read_pfm(const fs::path &path, int *width, int *height, std::vector<float> *rgb)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) throw std::runtime_error("cannot open " + path.string());
+    std::string magic;
+    int w = 0, h = 0;
+    double scale = 0;
+    f >> magic >> w >> h >> scale;
+    if ((magic != "PF" && magic != "Pf") || w <= 0 || h <= 0 || w > (1 << 16) || h > (1 << 16) || scale == 0 || !f)
+        throw std::runtime_error("not a PFM file: " + path.string());
+    f.get();        // the single whitespace byte after the scale
+    const int ch = magic == "PF" ? 3 : 1;
+    std::vector<uint8_t> raw((size_t)w * h * ch * 4);
+    f.read(reinterpret_cast<char *>(raw.data()), (std::streamsize)raw.size());
+    if ((size_t)f.gcount() != raw.size()) throw std::runtime_error("pfm: file too short: " + path.string());
+    rgb->assign((size_t)w * h * 3, 0.0f);
+    for (size_t i = 0; i < (size_t)w * h; ++i)
+        for (int c = 0; c < 3; ++c) {
+            const uint8_t *b = &raw[(i * ch + (ch == 3 ? c : 0)) * 4];
+            const uint32_t u = scale < 0 ? ((uint32_t)b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24))
+                                         : ((uint32_t)b[3] | (b[2] << 8) | (b[1] << 16) | ((uint32_t)b[0] << 24));
+            std::memcpy(&(*rgb)[3 * i + c], &u, 4);
+        }
+    *width = w;
+    *height = h;
+}
+
+// OpenEXR: single part, scan lines, compression NONE / ZIPS / ZIP, HALF or FLOAT channels; R, G, B (or Y) are
+// returned as floats, rows top to bottom (increasing y), missing channels 0.
+void read_exr(const fs::path &path, int *width, int *height, std::vector<float> *rgb)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) throw std::runtime_error("cannot open " + path.string());
+    std::vector<uint8_t> b((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    size_t pos = 0;
+    auto need = [&](size_t n) { if (pos + n > b.size()) throw std::runtime_error("exr: truncated file: " + path.string()); };
+    auto i32 = [&]() { need(4); int32_t v; std::memcpy(&v, &b[pos], 4); pos += 4; return v; };
+    auto str = [&]() { std::string s; for (;;) { need(1); const char c = (char)b[pos++]; if (!c) break; s.push_back(c); if (s.size() > 255) throw std::runtime_error("exr: bad string"); } return s; };
+    if (i32() != 20000630) throw std::runtime_error("not an OpenEXR file: " + path.string());
+    const int32_t version = i32();
+    if ((version & 0xff) != 2 || (version & 0x1a00)) throw std::runtime_error("exr: only single-part scan-line files are read");
+    struct Chan { std::string name; int type; };
+    std::vector<Chan> chans;
+    int compression = -1, x0 = 0, y0 = 0, x1 = -1, y1 = -1, line_order = 0;
+    for (;;) {
+        const std::string name = str();
+        if (name.empty()) break;
+        const std::string type = str();
+        const int32_t size = i32();
+        if (size < 0) throw std::runtime_error("exr: bad attribute size");
+        need((size_t)size);
+        const size_t end = pos + (size_t)size;
+        if (name == "channels") {
+            while (pos < end) {
+                const std::string cn = str();
+                if (cn.empty()) break;
+                const int t = i32();
+                pos += 4;                                   // pLinear + reserved
+                const int xs = i32(), ys = i32();
+                if (xs != 1 || ys != 1) throw std::runtime_error("exr: subsampled channels are not read");
+                chans.push_back({cn, t});
+            }
+        } else if (name == "compression") compression = b[pos];
+        else if (name == "dataWindow") { x0 = i32(); y0 = i32(); x1 = i32(); y1 = i32(); }
+        else if (name == "lineOrder") line_order = b[pos];
+        pos = end;
+    }
+    const int64_t w = (int64_t)x1 - x0 + 1, h = (int64_t)y1 - y0 + 1;
+    if (w <= 0 || h <= 0 || w > (1 << 16) || h > (1 << 16) || chans.empty()) throw std::runtime_error("exr: bad header: " + path.string());
+    if (compression != 0 && compression != 2 && compression != 3) throw std::runtime_error("exr: only NONE / ZIPS / ZIP compression is read");
+    (void)line_order;       // the offset table is indexed by y either way
+    const int lines_per_block = compression == 3 ? 16 : 1;
+    const int64_t n_blocks = (h + lines_per_block - 1) / lines_per_block;
+    size_t line_bytes = 0;
+    for (const Chan &c : chans) {
+        if (c.type != 1 && c.type != 2) throw std::runtime_error("exr: only HALF and FLOAT channels are read");
+        line_bytes += (size_t)w * (c.type == 1 ? 2 : 4);
+    }
+    need((size_t)n_blocks * 8);
+    std::vector<uint64_t> offs((size_t)n_blocks);
+    std::memcpy(offs.data(), &b[pos], (size_t)n_blocks * 8);
+    rgb->assign((size_t)w * h * 3, 0.0f);
+    for (int64_t k = 0; k < n_blocks; ++k) {
+        pos = (size_t)offs[(size_t)k];
+        const int32_t y = i32(), nbytes = i32();
+        if (nbytes < 0 || y < y0 || y > y1) throw std::runtime_error("exr: bad block");
+        need((size_t)nbytes);
+        const int rows = (int)std::min<int64_t>(lines_per_block, (int64_t)y1 - y + 1);
+        const size_t want = line_bytes * (size_t)rows;
+        std::vector<uint8_t> px;
+        if (compression == 0 || (size_t)nbytes == want) px.assign(&b[pos], &b[pos] + nbytes);
+        else {
+            std::vector<uint8_t> z(&b[pos], &b[pos] + nbytes), t = inflate_zlib(z);
+            if (t.size() != want) throw std::runtime_error("exr: block inflates to the wrong size");
+            for (size_t i = 1; i < t.size(); ++i) t[i] = (uint8_t)(t[i - 1] + t[i] - 128);      // the predictor
+            px.resize(want);                                                                      // then de-interleave the halves
+            const size_t half = (want + 1) / 2;
+            for (size_t i = 0; i < want; ++i) px[i] = (i & 1) ? t[half + i / 2] : t[i / 2];
+        }
+        if (px.size() < want) throw std::runtime_error("exr: block too short");
+        for (int r = 0; r < rows; ++r) {
+            const uint8_t *lp = &px[line_bytes * (size_t)r];
+            float *dst = &(*rgb)[(size_t)(y - y0 + r) * (size_t)w * 3];
+            for (const Chan &c : chans) {            // channels are stored one after the other within a line, alphabetically
+                const int slot = (c.name == "R") ? 0 : (c.name == "G") ? 1 : (c.name == "B") ? 2 : (c.name == "Y") ? 3 : -1;
+                for (int64_t x = 0; x < w; ++x) {
+                    float v;
+                    if (c.type == 1) { uint16_t hv; std::memcpy(&hv, lp + 2 * x, 2); v = half_to_float(hv); }
+                    else std::memcpy(&v, lp + 4 * x, 4);
+                    if (slot >= 0 && slot < 3) dst[3 * x + slot] = v;
+                    else if (slot == 3) dst[3 * x] = dst[3 * x + 1] = dst[3 * x + 2] = v;
+                }
+                lp += (size_t)w * (c.type == 1 ? 2 : 4);
+            }
+        }
+    }
+    *width = (int)w;
+    *height = (int)h;
+}
+
+// A mask image of any format the build can read: a pixel is on when any of R, G, B is non-zero; rows bottom to top
+// (the reference loads it flipped vertically, core/problem.cu:216-242).
+void read_mask_image(const fs::path &path, int *width, int *height, std::vector<uint8_t> *mask)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) throw std::runtime_error("cannot open " + path.string());
+    uint8_t head[8] = {0};
+    f.read(reinterpret_cast<char *>(head), 8);
+    f.close();
+    int w = 0, h = 0;
+    if (head[0] == 0x89 && head[1] == 'P' && head[2] == 'N' && head[3] == 'G') {
+        std::vector<uint8_t> rgba;
+        read_png(path, &w, &h, &rgba);
+        mask->assign((size_t)w * h, 0);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const uint8_t *px = &rgba[4 * ((size_t)(h - 1 - y) * w + x)];
+                (*mask)[(size_t)y * w + x] = (px[0] | px[1] | px[2]) ? 1 : 0;
+            }
+    } else {
+        std::vector<float> rgb;
+        bool file_is_bottom_up = false;
+        if (head[0] == 0x76 && head[1] == 0x2f && head[2] == 0x31 && head[3] == 0x01) read_exr(path, &w, &h, &rgb);
+        else if (head[0] == 'P' && (head[1] == 'F' || head[1] == 'f')) { read_pfm(path, &w, &h, &rgb); file_is_bottom_up = true; }
+        else throw std::runtime_error("mask image: only PNG, OpenEXR and PFM files are read here (no JPEG / Radiance decoder in this build): " + path.string());
+        mask->assign((size_t)w * h, 0);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                // PFM stores its rows bottom to top already; the others are flipped like the PNG
+                const float *px = &rgb[3 * ((size_t)(file_is_bottom_up ? y : h - 1 - y) * w + x)];
+                (*mask)[(size_t)y * w + x] = (px[0] != 0.0f || px[1] != 0.0f || px[2] != 0.0f) ? 1 : 0;
+            }
+    }
+    *width = w;
+    *height = h;
+}
+
 }  // namespace elaina

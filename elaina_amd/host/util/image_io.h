@@ -23,4 +23,15 @@ uint16_t float_to_half(float f);   // round to nearest even, IEEE binary16
 // rows top to bottom as stored in the file.
 void read_png(const fs::path &path, int *width, int *height, std::vector<uint8_t> *rgba);
 
+// The float formats of Image::loadImage (reference core/texture.cu:26-80).  rgb: height*width*3 floats, rows in file order
+// (PFM: bottom to top by the format's convention; EXR: top to bottom).  EXR: single part, scan lines, compression NONE / ZIPS /
+// ZIP, HALF or FLOAT channels R G B (or Y).  JPEG and Radiance .hdr have no decoder in this build.
+void read_pfm(const fs::path &path, int *width, int *height, std::vector<float> *rgb);
+void read_exr(const fs::path &path, int *width, int *height, std::vector<float> *rgb);
+float half_to_float(uint16_t h);
+
+// mask_path of the scene configuration (reference core/problem.cu:216-242): any format above, by content; a pixel is on when
+// any of R, G, B is non-zero; mask: height*width bytes, rows flipped vertically like the reference's load.
+void read_mask_image(const fs::path &path, int *width, int *height, std::vector<uint8_t> *mask);
+
 }  // namespace elaina

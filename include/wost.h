@@ -306,7 +306,9 @@ int wost_guided_solve_sharded(wost_guided_handle h, int32_t shard_index, int32_t
  * callback is asked once for the number of ranks (WOST_SYNC_RANKS_I64_HOST: it writes host
  * int64[1]); the summed gradient is divided by it before the Adam step, so that a shared step is
  * the step of ONE batch of ranks x batch_size samples (each rank normalises its loss gradient by
- * its own batch) and the L2 term and epsilon keep their weight for any rank count.
+ * its own batch) and the L2 term and epsilon keep their weight for any rank count.  (The op exists since library
+ * version 0.2, wost_version(); a callback that refuses it gets the summed gradient undivided, with a warning on stderr.)
+ * The divisor belongs to the solve: afterwards wost_net_train_step on the same network is a plain single-rank step.
  * Return 0 on success. */
 #define WOST_SYNC_SUM_I64_DEVICE 0
 #define WOST_SYNC_MIN_I64_HOST 1

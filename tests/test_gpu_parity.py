@@ -382,7 +382,8 @@ def test_bench_guided_config_two_ranks():
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["n_gpus"] == 2 and r["config"]["config"] == 4 and r["field_finite"]
-    assert r["guided"]["guided_steps_per_pass"] > 0 and r["roofline"]["bound"] == "mfma" and r["roofline"]["achieved"] > 0
+    assert r["guided"]["guided_steps_per_pass"] > 0 and r["roofline_mfma"]["bound"] == "mfma" and r["roofline_mfma"]["achieved"] > 0
+    assert r["roofline"]["kernel"] == "guided_sample_kernel" and r["guided"]["training_step"]["achieved"] > 0
 
 
 @pytest.mark.parametrize("scene,spp,depth", [("ladybug", 1, 64), ("ladybug", 5, 32), ("fille", 2, 128)])

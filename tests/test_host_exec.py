@@ -278,6 +278,91 @@ def test_png_reader_and_mask_loading(tmp_path):
         assert out.returncode == 1 and msg in out.stderr, (name, out.stderr)
 
 
+def _write_exr(path, img, compression, half):
+    """single-part scan-line OpenEXR with channels B G R (alphabetical), compression 0 NONE / 2 ZIPS / 3 ZIP"""
+    import struct, zlib
+    h, w, _ = img.shape
+    hdr = struct.pack("<ii", 20000630, 2)
+
+    def attr(name, typ, data):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(data)) + data
+    chl = b"".join(c + b"\0" + struct.pack("<iBBBBii", 1 if half else 2, 0, 0, 0, 0, 1, 1) for c in (b"B", b"G", b"R")) + b"\0"
+    hdr += attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression]))
+    hdr += attr("dataWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1)) + attr("displayWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1))
+    hdr += attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    hdr += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    per = 16 if compression == 3 else 1
+    blocks = []
+    for y0 in range(0, h, per):
+        raw = b""
+        for y in range(y0, min(y0 + per, h)):
+            for c in (2, 1, 0):            # B, G, R
+                raw += img[y, :, c].astype(np.float16 if half else np.float32).tobytes()
+        if compression:
+            t = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([t[0::2], t[1::2]]).astype(np.int32)
+            d = t.copy()
+            d[1:] = (t[1:] - t[:-1] + 128 + 256) & 255
+            z = zlib.compress(bytes(d.astype(np.uint8)))
+            raw = z if len(z) < len(raw) else raw
+        blocks.append((y0, raw))
+    table_at = len(hdr)
+    pos = table_at + 8 * len(blocks)
+    offs, body = b"", b""
+    for y0, raw in blocks:
+        offs += struct.pack("<Q", pos)
+        body += struct.pack("<ii", y0, len(raw)) + raw
+        pos += 8 + len(raw)
+    open(path, "wb").write(hdr + offs + body)
+
+
+def test_mask_images_of_every_readable_format(tmp_path):
+    """mask_path goes through Image::loadImage in the reference (core/problem.cu:216-242, core/texture.cu:26-80): PNG, OpenEXR
+    (uncompressed, ZIPS, ZIP; half and float) and PFM (colour and grey, both byte orders) give the same mask here; JPEG and
+    Radiance files are refused with a message"""
+    rng = np.random.default_rng(3)
+    exe = _exe()
+    w, h = 41, 35
+    img = np.zeros((h, w, 3), np.float32)
+    on = rng.uniform(size=(h, w)) < 0.6
+    img[on] = rng.uniform(0.01, 2.0, size=(int(on.sum()), 3)).astype(np.float32)
+    img[3, 5] = (0.0, 0.0, 0.25)          # a single non-zero channel is enough
+    on[3, 5] = True
+    want = on[::-1].astype(np.uint8)      # loaded flipped vertically
+
+    def mask_of(name):
+        out = subprocess.run([exe, "--readmask", str(tmp_path / name), str(tmp_path / "m.raw")], capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.split() == [str(w), str(h)], (name, out.stderr)
+        return np.fromfile(tmp_path / "m.raw", dtype=np.uint8).reshape(h, w)
+
+    _write_png(tmp_path / "m.png", np.ceil(np.clip(img, 0, 1) * 255).astype(np.uint8), 2, filters=[1, 4])
+    assert np.array_equal(mask_of("m.png"), want)
+    for comp in (0, 2, 3):
+        for half in (True, False):
+            name = "m_%d_%d.exr" % (comp, half)
+            _write_exr(tmp_path / name, img, comp, half)
+            assert np.array_equal(mask_of(name), want), name
+    for big_endian in (False, True):
+        # PFM rows run bottom to top: the file holds the image flipped, the load flips it back
+        data = img[::-1].astype(">f4" if big_endian else "<f4").tobytes()
+        open(tmp_path / "m.pfm", "wb").write(b"PF\n%d %d\n%s\n" % (w, h, b"1.0" if big_endian else b"-1.0") + data)
+        assert np.array_equal(mask_of("m.pfm"), want)
+    grey = img[::-1].max(-1).astype("<f4").tobytes()
+    open(tmp_path / "g.pfm", "wb").write(b"Pf\n%d %d\n-1.0\n" % (w, h) + grey)
+    assert np.array_equal(mask_of("g.pfm"), want)
+    # the exporter's own EXR files read back (half RGBA, uncompressed): grad.exr of --imagetest has a zero at (0, 0) only where all channels vanish
+    out = subprocess.run([exe, "--imagetest", str(tmp_path / "img")], capture_output=True, text=True)
+    assert out.returncode == 0
+    got = subprocess.run([exe, "--readmask", str(tmp_path / "img" / "grad.exr"), str(tmp_path / "m.raw")], capture_output=True, text=True)
+    assert got.returncode == 0 and got.stdout.split() == ["5", "3"], got.stderr
+    open(tmp_path / "x.jpg", "wb").write(b"\xff\xd8\xff\xe0" + b"\0" * 64)
+    bad = subprocess.run([exe, "--readmask", str(tmp_path / "x.jpg"), str(tmp_path / "m.raw")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "only PNG, OpenEXR and PFM" in bad.stderr
+    open(tmp_path / "cut.exr", "wb").write(open(tmp_path / "m_3_1.exr", "rb").read()[:300])
+    bad = subprocess.run([exe, "--readmask", str(tmp_path / "cut.exr"), str(tmp_path / "m.raw")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "exr" in bad.stderr
+
+
 @pytest.mark.gpu
 def test_run_expr_with_a_mask_image(tmp_path, oracle, ladybug):
     """scene.mask_path through the C++ host: flipped vertically, on = any non-zero RGB byte"""

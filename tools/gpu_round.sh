@@ -3,7 +3,7 @@
 # TAG names the output directory under gpurun_out/; STAGES selects what runs (default: all).
 export TMPDIR=/tmp
 TAG=${TAG:-r03}
-STAGES=${STAGES:-"tests smoke micro bench trace pmc"}
+STAGES=${STAGES:-"tests smoke micro bench trace pmc pmc_guided"}
 mkdir -p gpurun_out/$TAG
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 if has tests; then
@@ -32,5 +32,26 @@ if has pmc; then
     [ -n "$f" ] && python3 tools/pmc_summary.py "$f" | tee -a gpurun_out/$TAG/pmc_summary.txt
   done
   python3 tools/pmc_derive.py gpurun_out/$TAG/pmc_summary.txt gpurun_out/$TAG/bench_trace.log gpurun_out/$TAG "$BARGS"
+fi
+# the guided configuration's dominant kernel (config 4 at 32 spp, 16 of them trained): kernel trace + PMC passes per precision
+if has pmc_guided; then
+  for prec in 16 32; do
+    GARGS="bench.py --config 4 --spp 32 --train-spp 16 --steps 1 --warmup 0 --net-precision $prec"
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/gtrace$prec -- python3 $GARGS > gpurun_out/$TAG/guided_trace_f$prec.log 2>&1
+    f=$(find gpurun_out/$TAG/gtrace$prec -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/$TAG/guided_kernel_stats_f$prec.csv
+    rm -f gpurun_out/$TAG/guided_pmc_f$prec.txt
+    i=0
+    for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+               "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
+               "GRBM_GUI_ACTIVE"; do
+      i=$((i+1))
+      timeout 300 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/$TAG/gpmc$i -- python3 $GARGS > gpurun_out/$TAG/gpmc$i.log 2>&1
+      f=$(find gpurun_out/$TAG/gpmc$i -name '*counter_collection.csv' | head -1)
+      [ -n "$f" ] && python3 tools/pmc_summary.py "$f" guided_sample grid_grad net_train net_forward optimizer | tee -a gpurun_out/$TAG/guided_pmc_f$prec.txt
+      rm -rf gpurun_out/$TAG/gpmc$i
+    done
+    python3 tools/pmc_derive_guided.py gpurun_out/$TAG/guided_pmc_f$prec.txt gpurun_out/$TAG/guided_kernel_stats_f$prec.csv gpurun_out/$TAG/guided_trace_f$prec.log gpurun_out/$TAG/guided_sample_f$prec.json "$GARGS"
+    rm -rf gpurun_out/$TAG/gtrace$prec
+  done
 fi
 rm -rf gpurun_out/$TAG/pmc[0-9] gpurun_out/$TAG/trace

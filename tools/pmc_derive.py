@@ -4,8 +4,12 @@
 Usage: pmc_derive.py pmc_summary.txt bench_trace.log out_dir "<bench args>"
 Writes out_dir/walk_round_traffic.json and out_dir/walk_round_valu.json (copied to profiles/ by hand)."""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from elaina_amd.build import source_id  # noqa: E402
 
 summary, bench_log, out_dir, bargs = sys.argv[1:5]
 tot = {}
@@ -27,7 +31,7 @@ if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
     # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
     # half of the bytes of 16-B-per-lane reads -> doubled; WRITE_SIZE is exact
     per_launch = (2.0 * tot["FETCH_SIZE"][1] + tot["WRITE_SIZE"][1]) * 1024.0 / calls
-    json.dump({"kernel": "walk_round_kernel", "launches": calls, "fetch_kib_sum": tot["FETCH_SIZE"][1],
+    json.dump({"kernel": "walk_round_kernel", "source_id": source_id(), "launches": calls, "fetch_kib_sum": tot["FETCH_SIZE"][1],
                "write_kib_sum": tot["WRITE_SIZE"][1], "hbm_bytes_per_launch": per_launch,
                "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 " + bargs,
                "correction": "2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes"},
@@ -39,7 +43,7 @@ if all(k in tot for k in need):
     kernel_cycles = tot["GRBM_GUI_ACTIVE"][1] / 8.0
     pipe_busy = 4.0 * tot["SQ_ACTIVE_INST_VALU"][1] / (1024.0 * kernel_cycles)
     lane_eff = tot["SQ_THREAD_CYCLES_VALU"][1] / (64.0 * tot["SQ_INSTS_VALU"][1])
-    out = {"kernel": "walk_round_kernel", "pipe_busy": pipe_busy, "lane_efficiency": lane_eff,
+    out = {"kernel": "walk_round_kernel", "source_id": source_id(), "pipe_busy": pipe_busy, "lane_efficiency": lane_eff,
            "valu_wave_instructions": tot["SQ_INSTS_VALU"][1], "salu_wave_instructions": tot.get("SQ_INSTS_SALU", (0, None))[1],
            "walk_steps": steps,
            "lane_instr_per_step": (tot["SQ_INSTS_VALU"][1] * 64.0 * lane_eff / steps) if steps else None,
