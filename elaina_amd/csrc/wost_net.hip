@@ -55,15 +55,17 @@ __device__ __forceinline__ void fx_add(fx_t *p, fx_t v)
     atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);
 }
 
-static NetLayout make_layout(const wost_net_config &c)
+static NetLayout make_layout(const wost_net_config &c, int dims)
 {
     NetLayout l{};
+    l.dims = dims;
     const float log2s = std::log2(c.per_level_scale);
     uint32_t off = 0;
     for (int i = 0; i < c.n_levels; ++i) {
         l.scale[i] = std::exp2((float)i * log2s) * (float)c.base_resolution - 1.0f;
         l.res[i] = (int)std::ceil(l.scale[i]) + 1;
         uint32_t n = (uint32_t)l.res[i] * (uint32_t)l.res[i];
+        if (dims == 3) n *= (uint32_t)l.res[i];
         n = (n + 7u) / 8u * 8u;
         l.level_off[i] = off;
         off += n;
@@ -90,22 +92,30 @@ __device__ __forceinline__ float &act(float *col, int k) { return col[k * kNetBl
 
 // DenseGrid encoding of one point into col[0..enc) (tiny-cuda-nn grid.h: grid_scale,
 // grid_resolution, dense grid_index with wrap, linear interpolation)
-__device__ __forceinline__ void encode_point(const NetLayout &L, const float *grid, float x, float y, float *col)
+__device__ __forceinline__ void encode_point(const NetLayout &L, const float *grid, float x, float y, float z, float *col)
 {
+    const int n_corners = 1 << L.dims;
     for (int lv = 0; lv < L.n_levels; ++lv) {
         const float s = L.scale[lv];
         const uint32_t res = (uint32_t)L.res[lv];
         const uint32_t n_level = L.level_off[lv + 1] - L.level_off[lv];
-        float px = __builtin_fmaf(s, x, 0.5f), py = __builtin_fmaf(s, y, 0.5f);
-        const float fx = floorf(px), fy = floorf(py);
+        float px = __builtin_fmaf(s, x, 0.5f), py = __builtin_fmaf(s, y, 0.5f), pz = __builtin_fmaf(s, z, 0.5f);
+        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
         px -= fx;
         py -= fy;
-        const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+        pz -= fz;
+        const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy, iz = (uint32_t)(int)fz;
         for (int q = 0; q < L.n_features; ++q) act(col, lv * L.n_features + q) = 0.0f;
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
-            const float w = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
-            const uint32_t idx = (cx + cy * res) % n_level;
+        for (int k = 0; k < n_corners; ++k) {
+            // corner k: bit 0 = +x, bit 1 = +y, bit 2 = +z (three inputs only); weight = product of the axis weights in that order
+            const uint32_t cx = ix + (k & 1), cy = iy + ((k >> 1) & 1);
+            float w = ((k & 1) ? px : 1.0f - px) * ((k & 2) ? py : 1.0f - py);
+            uint32_t lin = cx + cy * res;
+            if (L.dims == 3) {
+                w = w * ((k & 4) ? pz : 1.0f - pz);
+                lin += (iz + ((k >> 2) & 1)) * res * res;
+            }
+            const uint32_t idx = lin % n_level;
             const float *g = grid + (size_t)(L.level_off[lv] + idx) * L.n_features;
             for (int q = 0; q < L.n_features; ++q) act(col, lv * L.n_features + q) += w * g[q];
         }
@@ -142,8 +152,9 @@ __global__ __launch_bounds__(kNetBlock) void net_forward_kernel(NetLayout L, con
     float *col_b = lds + 64 * kNetBlock + threadIdx.x;      // pong (widths <= 64)
     const int p = blockIdx.x * kNetBlock + threadIdx.x;
     const bool valid = p < n;
-    const float x = valid ? xy[2 * p] : 0.5f, y = valid ? xy[2 * p + 1] : 0.5f;
-    encode_point(L, params + L.n_mlp, x, y, col_a);
+    const size_t xo = (size_t)L.dims * p;        // inputs: dims floats per point
+    const float x = valid ? xy[xo] : 0.5f, y = valid ? xy[xo + 1] : 0.5f, z = (valid && L.dims == 3) ? xy[xo + 2] : 0.5f;
+    encode_point(L, params + L.n_mlp, x, y, z, col_a);
     const int stride = L.enc + L.n_hidden * L.n_neurons;
     if (acts && valid)
         for (int k = 0; k < L.enc; ++k) acts[(size_t)p * stride + k] = act(col_a, k);
@@ -1028,6 +1039,36 @@ __global__ __launch_bounds__(kGridGradBlock) void grid_grad_kernel(NetLayout L, 
         if (p >= p1) continue;
         const float s = s_scale[lv];
         const uint32_t res = s_res[lv], lo = s_off[lv], n_level = s_off[lv + 1] - lo;
+        if (L.dims == 3) {
+            // three inputs: the eight corners of the cell, weights as in encode_point; these levels are far larger than LDS
+            // (res^3 entries), so use_lds is 0 for all but the coarsest and the sums go straight to global memory
+            const float *q3 = xy + 3 * (size_t)p;
+            float pf[3];
+            uint32_t pi[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float v = __builtin_fmaf(s, q3[a], 0.5f), fl = floorf(v);
+                pf[a] = v - fl;
+                pi[a] = (uint32_t)(int)fl;
+            }
+            const float *d = denc + (size_t)p * ld_point + (size_t)lv * ld_level;
+            float dv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dv[q] = q < nf ? d[q] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float w = (((k & 1) ? pf[0] : 1.0f - pf[0]) * ((k & 2) ? pf[1] : 1.0f - pf[1])) * ((k & 4) ? pf[2] : 1.0f - pf[2]);
+                const uint32_t idx = ((pi[0] + (k & 1)) + (pi[1] + ((k >> 1) & 1)) * res + (pi[2] + ((k >> 2) & 1)) * res * res) % n_level;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (q < q0 || q >= q1) continue;
+                    const fx_t v = to_fx(w * dv[q]);
+                    if (use_lds) fx_add(&acc[(lo + idx - base) * nq + (q - q0)], v);
+                    else fx_add(gG + (size_t)(lo + idx) * nf + q, v);
+                }
+            }
+            continue;
+        }
         float px = __builtin_fmaf(s, xy[2 * p], 0.5f), py = __builtin_fmaf(s, xy[2 * p + 1], 0.5f);
         const float fx = floorf(px), fy = floorf(py);
         px -= fx;
@@ -1352,7 +1393,7 @@ static int ensure_points(wost_net *h, size_t n)
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     h->cap_points = 0;
     const NetLayout &L = h->L;
-    NET_TRY(hipMalloc((void **)&h->d_xy, n * 2 * sizeof(float)));
+    NET_TRY(hipMalloc((void **)&h->d_xy, n * 3 * sizeof(float)));
     NET_TRY(hipMalloc((void **)&h->d_out, n * L.n_out * sizeof(float)));
     NET_TRY(hipMalloc((void **)&h->d_dl, n * L.n_out * sizeof(float)));
     const size_t n64 = (n + 63) / 64 * 64;     // the MFMA training layout works in whole 64-point spans
@@ -1566,7 +1607,7 @@ void *net_gradient_buffer(wost_net *h, uint64_t *count)
 int net_f32_view(wost_net *h, F32NetView *out)
 {
     if (!h || !out) return set_error(WOST_ERR_INVALID, "null argument");
-    if (!h->use_mfma || !h->inference_f) return WOST_ERR_UNSUPPORTED;      // a probe: the caller falls back, no error is recorded
+    if (!h->use_mfma || !h->inference_f || h->L.dims != 2) return WOST_ERR_UNSUPPORTED;      // a probe: the caller falls back, no error is recorded
     out->L = h->L;
     out->frag = h->inference_f;
     out->grid = h->inference + h->L.n_mlp;
@@ -1591,7 +1632,7 @@ int net_n_output(const wost_net *h) { return h->L.n_out; }
 
 extern "C" {
 
-int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_net_handle *out)
+static int net_create_dims(int device, const wost_net_config *cfg, uint64_t seed, int dims, wost_net_handle *out)
 {
     if (!cfg || !out) return set_error(WOST_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -1610,14 +1651,27 @@ int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_
     if (!h) return set_error(WOST_ERR_NOMEM, "out of host memory");
     h->device = device;
     h->cfg = *cfg;
-    h->L = make_layout(*cfg);
+    {
+        // (offsets are 32-bit: a grid of three inputs has res^3 entries per level)
+        double entries = 0.0;
+        for (int i = 0; i < cfg->n_levels; ++i) {
+            const double r = std::ceil(std::exp2((double)i * std::log2((double)cfg->per_level_scale)) * cfg->base_resolution - 1.0) + 1.0;
+            entries += dims == 3 ? r * r * r : r * r;
+        }
+        if (entries * cfg->n_features_per_level > 1.0e9) {
+            delete h;
+            return set_error(WOST_ERR_UNSUPPORTED, "grid encoding too large");
+        }
+    }
+    h->L = make_layout(*cfg, dims);
     h->n_params = h->L.n_mlp + h->L.n_grid;
     {
         // the MFMA forward kernel is instantiated for the reference's network shape
         const char *unfused = getenv("WOST_NET_FUSED");
         h->fused_backward = !(unfused && atoi(unfused) == 0);
         const char *scalar = getenv("WOST_NET_SCALAR");
-        h->use_mfma = h->L.enc == 32 && h->L.n_neurons == 64 && h->L.n_hidden == 3 && h->L.n_out_padded == 48 &&
+        // (the matrix-core kernels encode two inputs; the three-input network of GuidedIntegrator<3> runs on the scalar kernels)
+        h->use_mfma = dims == 2 && h->L.enc == 32 && h->L.n_neurons == 64 && h->L.n_hidden == 3 && h->L.n_out_padded == 48 &&
                       h->L.n_features <= 8 && !(scalar && atoi(scalar) != 0);
     }
     // initialisation (tiny-cuda-nn defaults): MLP xavier uniform, grid uniform(-1e-4, 1e-4)
@@ -1660,6 +1714,16 @@ int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_
     }
     *out = h;
     return WOST_OK;
+}
+
+int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_net_handle *out)
+{
+    return net_create_dims(device, cfg, seed, 2, out);
+}
+
+int wost_net_create3(int device, const wost_net_config *cfg, uint64_t seed, wost_net_handle *out)
+{
+    return net_create_dims(device, cfg, seed, 3, out);
 }
 
 int wost_net_destroy(wost_net_handle h)
@@ -1733,8 +1797,8 @@ int wost_net_set_option(wost_net_handle h, const char *key, double value)
         if (value != 16 && value != 32) return set_error(WOST_ERR_INVALID, "precision must be 32 (fp32, default) or 16 (half-precision inference)");
         if (value == 16) {
             const NetLayout &L = h->L;
-            if (!(L.enc == 32 && L.n_neurons == 64 && L.n_hidden == 3 && L.n_out_padded == 48 && L.n_features == 4 && L.n_levels == 8))
-                return set_error(WOST_ERR_UNSUPPORTED, "half-precision inference is built for the reference's network shape only");
+            if (!(L.dims == 2 && L.enc == 32 && L.n_neurons == 64 && L.n_hidden == 3 && L.n_out_padded == 48 && L.n_features == 4 && L.n_levels == 8))
+                return set_error(WOST_ERR_UNSUPPORTED, "half-precision inference is built for the reference's 2-D network shape only");
             NET_TRY(hipSetDevice(h->device));
             if (half_image_entries(L) * sizeof(uint2) > 158 * 1024)
                 return set_error(WOST_ERR_UNSUPPORTED, "half-precision network: weights and grid must fit into 158 KB of LDS");
@@ -1752,8 +1816,8 @@ int wost_net_set_option(wost_net_handle h, const char *key, double value)
         if (value != 16 && value != 32) return set_error(WOST_ERR_INVALID, "train_precision must be 32 (fp32, default) or 16 (half-precision training passes)");
         if (value == 16) {
             const NetLayout &L = h->L;
-            if (!(L.enc == 32 && L.n_neurons == 64 && L.n_hidden == 3 && L.n_out_padded == 48 && L.n_features == 4 && L.n_levels == 8))
-                return set_error(WOST_ERR_UNSUPPORTED, "half-precision training is built for the reference's network shape only");
+            if (!(L.dims == 2 && L.enc == 32 && L.n_neurons == 64 && L.n_hidden == 3 && L.n_out_padded == 48 && L.n_features == 4 && L.n_levels == 8))
+                return set_error(WOST_ERR_UNSUPPORTED, "half-precision training is built for the reference's 2-D network shape only");
             NET_TRY(hipSetDevice(h->device));
             if (half_image_entries(L) * sizeof(uint2) > 158 * 1024)
                 return set_error(WOST_ERR_UNSUPPORTED, "half-precision network: weights and grid must fit into 158 KB of LDS");
@@ -1779,7 +1843,7 @@ int wost_net_inference(wost_net_handle h, const float *xy, int32_t n, float *out
     NET_TRY(hipSetDevice(h->device));
     int rc = ensure_points(h, (size_t)n);
     if (rc != WOST_OK) return rc;
-    NET_TRY(hipMemcpy(h->d_xy, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice));
+    NET_TRY(hipMemcpy(h->d_xy, xy, (size_t)n * h->L.dims * sizeof(float), hipMemcpyHostToDevice));
     if (!use_inference_params && h->train_precision == 16) {
         // the training weights as a half-precision training step evaluates them
         float *o = nullptr, *dl = nullptr;
@@ -1799,7 +1863,7 @@ int wost_net_train_step(wost_net_handle h, const float *xy, const float *dl_dout
     NET_TRY(hipSetDevice(h->device));
     int rc = ensure_points(h, (size_t)n);
     if (rc != WOST_OK) return rc;
-    NET_TRY(hipMemcpy(h->d_xy, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice));
+    NET_TRY(hipMemcpy(h->d_xy, xy, (size_t)n * h->L.dims * sizeof(float), hipMemcpyHostToDevice));
     float *out = nullptr, *dl = nullptr;
     rc = wost::net_forward_train_dev(h, h->d_xy, n, nullptr, &out, &dl);
     if (rc != WOST_OK) return rc;

@@ -21,6 +21,7 @@ struct NetLayout {
     int32_t n_levels, n_features, enc, n_neurons, n_hidden, n_out, n_out_padded;
     uint32_t n_mlp, n_grid;
     uint32_t w_off[kNetMaxLevels];  // offset of every weight matrix in the parameter vector
+    int32_t dims;                   // input dimensions: 2 (GuidedIntegrator<2>) or 3 (GuidedIntegrator<3>: trilinear grid, res^3 entries per level)
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));

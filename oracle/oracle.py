@@ -115,6 +115,31 @@ def guided_settings(width, height, spp, max_depth, eps, aabb_min, aabb_max, trai
     return g
 
 
+class GuidedSettings3(C.Structure):
+    """wo3_guided_settings: the same with a 3-D box"""
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int), ("spp", C.c_int), ("max_depth", C.c_int), ("eps_shell", C.c_float),
+        ("train_spp_count", C.c_int),
+        ("uniform_fraction_training", C.c_float), ("uniform_fraction_guiding", C.c_float),
+        ("max_guided_depth_training", C.c_int), ("max_guided_depth_guiding", C.c_int),
+        ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3),
+        ("max_train_depth", C.c_int), ("batch_size", C.c_int), ("min_batch_size", C.c_int), ("batches_per_spp", C.c_int),
+        ("train_pixel_stride", C.c_int), ("train_pixel_offset", C.c_int), ("loss_scale", C.c_float),
+    ]
+
+
+def guided_settings3(width, height, spp, max_depth, eps, aabb_min, aabb_max, train_spp_count=150,
+                     uniform_fraction=(0.5, 0.5), max_guided_depth=(10, 10), max_train_depth=3, batch_size=524288,
+                     min_batch_size=65536, batches_per_spp=5, train_pixel_stride=1, train_pixel_offset=0, loss_scale=128.0):
+    g = GuidedSettings3(width, height, spp, max_depth, eps, train_spp_count, uniform_fraction[0], uniform_fraction[1],
+                        max_guided_depth[0], max_guided_depth[1])
+    for k in range(3):
+        g.aabb_min[k], g.aabb_max[k] = float(aabb_min[k]), float(aabb_max[k])
+    g.max_train_depth, g.batch_size, g.min_batch_size, g.batches_per_spp = max_train_depth, batch_size, min_batch_size, batches_per_spp
+    g.train_pixel_stride, g.train_pixel_offset, g.loss_scale = train_pixel_stride, train_pixel_offset, loss_scale
+    return g
+
+
 class GuidedStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated",
                                           "neumann_hits", "guided_steps", "train_samples", "optimizer_steps")]
@@ -138,6 +163,13 @@ class NetConfig(C.Structure):
 def default_net_config():
     """data/ladybug/n.json:49-81 of the reference + guided/parameters.h:16-24"""
     return NetConfig(8, 4, 8, 1.4049999713897705, 64, 3, 33, 48, 0.00800000037997961, 0.8999999761581421,
+                     0.9900000095367432, 1.0000000036274937e-15, 9.999999974752427e-07, 0.949999988079071)
+
+
+def default_net_config3(n_levels=8, base_resolution=8, per_level_scale=1.4049999713897705):
+    """the same network with the 41 outputs of GuidedIntegrator<3> (guided/parameters.h:26-33: 8 lobes x (lambda, kappa, mean
+    vector) + the selection logit); its input has three components (wo_net3_*)"""
+    return NetConfig(n_levels, 4, base_resolution, per_level_scale, 64, 3, 41, 48, 0.00800000037997961, 0.8999999761581421,
                      0.9900000095367432, 1.0000000036274937e-15, 9.999999974752427e-07, 0.949999988079071)
 
 
@@ -281,6 +313,32 @@ class Oracle:
                                       C.byref(stats), dump_spp, C.byref(dump) if dump is not None else None)
         if rc != 0:
             raise RuntimeError("wo_solve_guided failed: %d" % rc)
+        out = {"field": field}
+        out.update({k: int(getattr(stats, k)) for k, _ in GuidedStats._fields_})
+        if dump is not None:
+            out["train_set"] = {k: v[:dump.n] for k, v in arrays.items()}
+        return out
+
+    def solve_guided3(self, sd, gs, net_cfg, params, threads=8, dump_spp=-1):
+        """GuidedIntegrator<3> (wo3_solve_guided); params (float32, net3_n_params) are trained IN PLACE"""
+        sc = self.make_scene3(sd)
+        n = gs.width * gs.height
+        field = np.zeros((n, 3), dtype=np.float32)
+        stats = GuidedStats()
+        assert params.dtype == np.float32 and params.flags.c_contiguous and params.size == self.net3_n_params(net_cfg)
+        dump = None
+        arrays = {}
+        if dump_spp >= 0:
+            cap = n * 4
+            arrays = {"xyz": np.zeros((cap, 3), np.float32), "dir": np.zeros((cap, 3), np.float32),
+                      "solution": np.zeros((cap, 3), np.float32), "dir_pdf": np.zeros(cap, np.float32),
+                      "normal": np.zeros((cap, 3), np.float32), "on_neumann": np.zeros(cap, np.uint8)}
+            dump = TrainDump(cap, 0, _fp(arrays["xyz"]), _fp(arrays["dir"]), _fp(arrays["solution"]), _fp(arrays["dir_pdf"]),
+                             _fp(arrays["normal"]), arrays["on_neumann"].ctypes.data_as(C.POINTER(C.c_ubyte)))
+        rc = self.lib.wo3_solve_guided(C.byref(sc), C.byref(gs), C.byref(net_cfg), _fp(params), threads, _fp(field),
+                                       C.byref(stats), dump_spp, C.byref(dump) if dump is not None else None)
+        if rc != 0:
+            raise RuntimeError("wo3_solve_guided failed: %d" % rc)
         out = {"field": field}
         out.update({k: int(getattr(stats, k)) for k, _ in GuidedStats._fields_})
         if dump is not None:
@@ -552,6 +610,35 @@ class Oracle:
     def net_n_params(self, cfg):
         self.lib.wo_net_n_params.restype = C.c_uint64
         return int(self.lib.wo_net_n_params(C.byref(cfg)))
+
+    def net3_n_params(self, cfg):
+        self.lib.wo_net3_n_params.restype = C.c_uint64
+        return int(self.lib.wo_net3_n_params(C.byref(cfg)))
+
+    def net3_forward(self, cfg, params, xyz):
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        x = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((len(x), cfg.n_output_padded), dtype=np.float32)
+        self.lib.wo_net3_forward(C.byref(cfg), _fp(p), _fp(x), len(x), _fp(out), None)
+        return out
+
+    def net3_backward(self, cfg, params, xyz, dl_dout):
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        x = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dl_dout, dtype=np.float32)
+        assert d.shape == (len(x), cfg.n_output_padded)
+        g = np.zeros(len(p), dtype=np.float32)
+        self.lib.wo_net3_backward(C.byref(cfg), _fp(p), _fp(x), _fp(d), len(x), _fp(g))
+        return g
+
+    def net3_optimizer_step(self, cfg, params, state, grad, step, loss_scale):
+        assert params.dtype == np.float32 and params.flags.c_contiguous
+        g = np.ascontiguousarray(grad, dtype=np.float32)
+        inf = np.zeros_like(params)
+        self.lib.wo_net3_optimizer_step(C.byref(cfg), _fp(params), _fp(state["m1"]), _fp(state["m2"]), _fp(state["ema_raw"]),
+                                        _fp(inf), _fp(g), step, C.c_float(loss_scale),
+                                        state["steps"].ctypes.data_as(C.POINTER(C.c_uint32)))
+        return inf
 
     def net_levels(self, cfg):
         res = np.zeros(cfg.n_levels, dtype=np.int32)

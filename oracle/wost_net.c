@@ -15,7 +15,12 @@
  *
  * Parameter vector order (util/network.h:99-117: network first, then encoding):
  *   [W1: n_neurons x enc] [W(hidden-1) x: n_neurons x n_neurons] [Wout: n_out_padded x n_neurons]
- *   [grid level 0 .. L-1: res^2 (rounded up to 8) x n_features]
+ *   [grid level 0 .. L-1: res^D (rounded up to 8) x n_features]
+ *
+ * D = 2 is the network of GuidedIntegrator<2> (guided/parameters.h:16-24: 2 inputs, 8 x 4 + 1 = 33 outputs); D = 3 the one of
+ * GuidedIntegrator<3> (:26-33: 3 inputs, 8 x 5 + 1 = 41 outputs): trilinear interpolation over the 8 corners of a cell, dense index
+ * x + y res + z res^2 (grid.h grid_index, stride *= resolution per dimension).  The wo_net_* entry points are the 2-D network, the
+ * wo_net3_* ones the 3-D network; both run the same code below.
  */
 #include <math.h>
 #include <stddef.h>
@@ -35,7 +40,7 @@ typedef struct {
     size_t n_mlp, n_grid;
 } wn_layout;
 
-static void layout(const wo_net_config *c, wn_layout *l)
+static void layout_d(const wo_net_config *c, int dims, wn_layout *l)
 {
     const float log2s = log2f(c->per_level_scale);
     size_t off = 0;
@@ -43,6 +48,7 @@ static void layout(const wo_net_config *c, wn_layout *l)
         l->scale[i] = exp2f((float)i * log2s) * (float)c->base_resolution - 1.0f;   /* grid.h grid_scale */
         l->res[i] = (int)ceilf(l->scale[i]) + 1;                                     /* grid.h grid_resolution */
         size_t n = (size_t)l->res[i] * l->res[i];
+        if (dims == 3) n *= (size_t)l->res[i];
         n = (n + 7) / 8 * 8;
         l->level_off[i] = off;
         off += n;
@@ -54,50 +60,62 @@ static void layout(const wo_net_config *c, wn_layout *l)
                (size_t)c->n_output_padded * c->n_neurons;
 }
 
-uint64_t wo_net_n_params(const wo_net_config *c)
+static uint64_t n_params_d(const wo_net_config *c, int dims)
 {
     wn_layout l;
-    layout(c, &l);
+    layout_d(c, dims, &l);
     return l.n_mlp + l.n_grid;
 }
+uint64_t wo_net_n_params(const wo_net_config *c) { return n_params_d(c, 2); }
+uint64_t wo_net3_n_params(const wo_net_config *c) { return n_params_d(c, 3); }
 
-/* encode one point; optionally return the 4 corner indices/weights per level for backward */
-static void encode(const wo_net_config *c, const wn_layout *l, const float *grid, float x, float y, float *enc,
+/* encode one point (x[dims]); optionally return the 2^dims corner indices/weights per level for backward.
+ * Corner k of a cell: bit 0 = +x, bit 1 = +y, bit 2 = +z; weight = product of the per-axis weights in the order x, y(, z). */
+static void encode(const wo_net_config *c, int dims, const wn_layout *l, const float *grid, const float *x, float *enc,
                    size_t *cidx, float *cw)
 {
+    const int nc = 1 << dims;
     for (int lv = 0; lv < c->n_levels; ++lv) {
         const float s = l->scale[lv];
         const int res = l->res[lv];
         const size_t n_level = l->level_off[lv + 1] - l->level_off[lv];
-        float px = fmaf(s, x, 0.5f), py = fmaf(s, y, 0.5f);
-        const float fx = floorf(px), fy = floorf(py);
-        px -= fx; py -= fy;
-        const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+        float pf[3] = { 0.0f, 0.0f, 0.0f };
+        uint32_t pi[3] = { 0, 0, 0 };
+        for (int d = 0; d < dims; ++d) {
+            const float p = fmaf(s, x[d], 0.5f), fl = floorf(p);
+            pf[d] = p - fl;
+            pi[d] = (uint32_t)(int)fl;
+        }
         float f[8] = {0};
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t cx = ix + (k & 1), cy = iy + (k >> 1);
-            const float w = ((k & 1) ? px : 1.0f - px) * ((k >> 1) ? py : 1.0f - py);
-            const size_t idx = ((size_t)cx + (size_t)cy * (size_t)res) % n_level;   /* dense grid_index */
+        for (int k = 0; k < nc; ++k) {
+            const uint32_t cx = pi[0] + (k & 1), cy = pi[1] + ((k >> 1) & 1), cz = pi[2] + ((k >> 2) & 1);
+            float w = ((k & 1) ? pf[0] : 1.0f - pf[0]) * ((k & 2) ? pf[1] : 1.0f - pf[1]);
+            size_t lin = (size_t)cx + (size_t)cy * (size_t)res;
+            if (dims == 3) {
+                w = w * ((k & 4) ? pf[2] : 1.0f - pf[2]);
+                lin += (size_t)cz * (size_t)res * (size_t)res;
+            }
+            const size_t idx = lin % n_level;                                       /* dense grid_index */
             const float *g = grid + (l->level_off[lv] + idx) * c->n_features;
             for (int q = 0; q < c->n_features; ++q) f[q] += w * g[q];
-            if (cidx) { cidx[4 * lv + k] = l->level_off[lv] + idx; cw[4 * lv + k] = w; }
+            if (cidx) { cidx[nc * lv + k] = l->level_off[lv] + idx; cw[nc * lv + k] = w; }
         }
         for (int q = 0; q < c->n_features; ++q) enc[lv * c->n_features + q] = f[q];
     }
 }
 
 /* forward for n points; out: n x n_output_padded.  acts (optional): per point enc + hidden*n_neurons */
-int wo_net_forward(const wo_net_config *c, const float *params, const float *xy, int n, float *out, float *acts)
+static int forward_d(const wo_net_config *c, int dims, const float *params, const float *xy, int n, float *out, float *acts)
 {
     wn_layout l;
-    layout(c, &l);
+    layout_d(c, dims, &l);
     const float *grid = params + l.n_mlp;
     const int H = c->n_neurons, E = l.enc, NL = c->n_hidden_layers;
     const int act_stride = E + NL * H;
     float *buf = malloc(sizeof(float) * (size_t)act_stride);
     for (int p = 0; p < n; ++p) {
         float *a = acts ? acts + (size_t)p * act_stride : buf;
-        encode(c, &l, grid, xy[2 * p], xy[2 * p + 1], a, NULL, NULL);
+        encode(c, dims, &l, grid, xy + (size_t)dims * p, a, NULL, NULL);
         const float *W = params;
         const float *in = a;
         int n_in = E;
@@ -121,6 +139,14 @@ int wo_net_forward(const wo_net_config *c, const float *params, const float *xy,
     free(buf);
     return 0;
 }
+int wo_net_forward(const wo_net_config *c, const float *params, const float *xy, int n, float *out, float *acts)
+{
+    return forward_d(c, 2, params, xy, n, out, acts);
+}
+int wo_net3_forward(const wo_net_config *c, const float *params, const float *xyz, int n, float *out, float *acts)
+{
+    return forward_d(c, 3, params, xyz, n, out, acts);
+}
 
 /* Gradient of sum_p <dl_dout[p], out[p]> w.r.t. every parameter (grad must hold n_params floats).
  * A gradient is a sum over the points; to make it independent of the order in which a parallel
@@ -130,11 +156,12 @@ int wo_net_forward(const wo_net_config *c, const float *params, const float *xy,
 #define WN_FX_SCALE 68719476736.0   /* 2^36 */
 #define WN_WGRAD_CHUNK 1024
 
-int wo_net_backward(const wo_net_config *c, const float *params, const float *xy, const float *dl_dout, int n,
-                    float *grad)
+static int backward_d(const wo_net_config *c, int dims, const float *params, const float *xy, const float *dl_dout, int n,
+                      float *grad)
 {
     wn_layout l;
-    layout(c, &l);
+    layout_d(c, dims, &l);
+    const int ncorner = 1 << dims;
     const int H = c->n_neurons, E = l.enc, NL = c->n_hidden_layers, NO = c->n_output_padded;
     const int act_stride = E + NL * H;        /* encoding + hidden activations of one point */
     const int del_stride = NO + NL * H;       /* delta of the output layer, then of hidden layer 0.. */
@@ -143,8 +170,8 @@ int wo_net_backward(const wo_net_config *c, const float *params, const float *xy
     float *acts = malloc(sizeof(float) * (size_t)WN_WGRAD_CHUNK * act_stride);
     float *dels = malloc(sizeof(float) * (size_t)WN_WGRAD_CHUNK * del_stride);
     float *denc = malloc(sizeof(float) * (size_t)E);
-    size_t *cidx = malloc(sizeof(size_t) * 4 * c->n_levels);
-    float *cw = malloc(sizeof(float) * 4 * c->n_levels);
+    size_t *cidx = malloc(sizeof(size_t) * 8 * c->n_levels);
+    float *cw = malloc(sizeof(float) * 8 * c->n_levels);
     const float *grid = params + l.n_mlp;
     size_t woff[WN_MAX_LEVELS];
     woff[0] = 0;
@@ -156,7 +183,7 @@ int wo_net_backward(const wo_net_config *c, const float *params, const float *xy
             const int p = p0 + q;
             float *a = acts + (size_t)q * act_stride;
             float *d = dels + (size_t)q * del_stride;
-            encode(c, &l, grid, xy[2 * p], xy[2 * p + 1], a, cidx, cw);
+            encode(c, dims, &l, grid, xy + (size_t)dims * p, a, cidx, cw);
             /* forward, keeping activations */
             const float *in = a;
             int n_in = E;
@@ -194,10 +221,10 @@ int wo_net_backward(const wo_net_config *c, const float *params, const float *xy
             /* grid: every (corner, feature) term on its own */
             long long *gG = fx + l.n_mlp;
             for (int lv = 0; lv < c->n_levels; ++lv)
-                for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < ncorner; ++k)
                     for (int f = 0; f < c->n_features; ++f) {
-                        const float t = cw[4 * lv + k] * denc[lv * c->n_features + f];
-                        gG[cidx[4 * lv + k] * c->n_features + f] += llrint((double)t * WN_FX_SCALE);
+                        const float t = cw[ncorner * lv + k] * denc[lv * c->n_features + f];
+                        gG[cidx[ncorner * lv + k] * c->n_features + f] += llrint((double)t * WN_FX_SCALE);
                     }
         }
         /* weights: per (row, column) four fmaf chains over the 4-point groups of the chunk taken round
@@ -223,6 +250,14 @@ int wo_net_backward(const wo_net_config *c, const float *params, const float *xy
     free(fx); free(acts); free(dels); free(denc); free(cidx); free(cw);
     return 0;
 }
+int wo_net_backward(const wo_net_config *c, const float *params, const float *xy, const float *dl_dout, int n, float *grad)
+{
+    return backward_d(c, 2, params, xy, dl_dout, n, grad);
+}
+int wo_net3_backward(const wo_net_config *c, const float *params, const float *xyz, const float *dl_dout, int n, float *grad)
+{
+    return backward_d(c, 3, params, xyz, dl_dout, n, grad);
+}
 
 /* one optimizer step: tiny-cuda-nn's adam_step (include/tiny-cuda-nn/optimizers/adam.h, v1.6/v1.7:
  * pinned commit unknown) nested in its EMA optimizer (optimizers/ema.h), the pair the
@@ -235,11 +270,11 @@ int wo_net_backward(const wo_net_config *c, const float *params, const float *xy
  *     every step, so theirs equals `step`);
  *   - the EMA (ema_step) runs over all parameters with the global step.
  * `step` counts from 1; param_steps is n_params zero-initialised counters owned by the caller. */
-int wo_net_optimizer_step(const wo_net_config *c, float *params, float *m1, float *m2, float *ema_raw,
-                          float *inference_params, const float *grad, int step, float loss_scale, uint32_t *param_steps)
+static int optimizer_step_d(const wo_net_config *c, int dims, float *params, float *m1, float *m2, float *ema_raw,
+                            float *inference_params, const float *grad, int step, float loss_scale, uint32_t *param_steps)
 {
     wn_layout l;
-    layout(c, &l);
+    layout_d(c, dims, &l);
     const uint64_t n = l.n_mlp + l.n_grid;
     const float debias = 1.0f / (1.0f - powf(c->ema_decay, (float)step));
     for (uint64_t i = 0; i < n; ++i) {
@@ -260,11 +295,21 @@ int wo_net_optimizer_step(const wo_net_config *c, float *params, float *m1, floa
     }
     return 0;
 }
+int wo_net_optimizer_step(const wo_net_config *c, float *params, float *m1, float *m2, float *ema_raw,
+                          float *inference_params, const float *grad, int step, float loss_scale, uint32_t *param_steps)
+{
+    return optimizer_step_d(c, 2, params, m1, m2, ema_raw, inference_params, grad, step, loss_scale, param_steps);
+}
+int wo_net3_optimizer_step(const wo_net_config *c, float *params, float *m1, float *m2, float *ema_raw,
+                           float *inference_params, const float *grad, int step, float loss_scale, uint32_t *param_steps)
+{
+    return optimizer_step_d(c, 3, params, m1, m2, ema_raw, inference_params, grad, step, loss_scale, param_steps);
+}
 
 int wo_net_levels(const wo_net_config *c, int *res, float *scale)
 {
     wn_layout l;
-    layout(c, &l);
+    layout_d(c, 2, &l);
     for (int i = 0; i < c->n_levels; ++i) { res[i] = l.res[i]; scale[i] = l.scale[i]; }
     return l.enc;
 }

@@ -217,6 +217,12 @@ int wo_net_backward(const wo_net_config *c, const float *params, const float *xy
                     float *grad);
 int wo_net_optimizer_step(const wo_net_config *c, float *params, float *m1, float *m2, float *ema_raw,
                           float *inference_params, const float *grad, int step, float loss_scale, uint32_t *param_steps);
+/* the same network with THREE inputs (GuidedIntegrator<3>, guided/parameters.h:26-33): trilinear DenseGrid, res^3 entries per level */
+uint64_t wo_net3_n_params(const wo_net_config *c);
+int wo_net3_forward(const wo_net_config *c, const float *params, const float *xyz, int n, float *out, float *acts);
+int wo_net3_backward(const wo_net_config *c, const float *params, const float *xyz, const float *dl_dout, int n, float *grad);
+int wo_net3_optimizer_step(const wo_net_config *c, float *params, float *m1, float *m2, float *ema_raw,
+                           float *inference_params, const float *grad, int step, float loss_scale, uint32_t *param_steps);
 
 /* ---- guided integrator (oracle/wost_guided.c) ------------------------------------------ */
 typedef struct wo_guided_settings {
@@ -250,6 +256,27 @@ typedef struct wo_train_dump {
 /* params: n_params floats, initial weights in, trained weights out. */
 int wo_solve_guided(const wo_scene *sc, const wo_guided_settings *gs, const wo_net_config *nc, float *params,
                     int n_threads, float *field_rgb, wo_guided_stats *stats, int dump_spp, wo_train_dump *dump);
+
+/* ---- GuidedIntegrator<3> (oracle/wost_oracle3d.c) ---------------------------------------------- */
+typedef struct wo3_guided_settings {
+    int width, height, spp, max_depth;
+    float eps_shell;
+    int train_spp_count;
+    float uniform_fraction_training, uniform_fraction_guiding;
+    int max_guided_depth_training, max_guided_depth_guiding;
+    float aabb_min[3], aabb_max[3];
+    int max_train_depth, batch_size, min_batch_size, batches_per_spp, train_pixel_stride, train_pixel_offset;
+    float loss_scale;
+} wo3_guided_settings;
+typedef struct wo3_train_dump {
+    int capacity, n;
+    float *xyz, *dir, *solution, *dir_pdf, *normal;      /* xyz: normalised network inputs; dir / normal: 3 floats per sample */
+    unsigned char *on_neumann;
+} wo3_train_dump;
+/* nc: n_output 41 (guided/parameters.h:26-33), params: wo_net3_n_params floats (in: initial, out: trained).  Returns -3 for a
+ * scene with a source term (not restated for the 3-D guided solve). */
+int wo3_solve_guided(const wo3_scene *sc, const wo3_guided_settings *gs, const wo_net_config *nc, float *params, int n_threads,
+                     float *field_rgb, wo_guided_stats *stats, int dump_spp, wo3_train_dump *dump);
 
 const char *wo_version(void);
 

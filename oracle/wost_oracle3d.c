@@ -845,3 +845,408 @@ int wo3_vmm_loss_gradients(const float *raw, const float *dir, const float *li, 
     }
     return 0;
 }
+
+
+/* ==== GuidedIntegrator<3> (SURVEY 8a rows a21-a27 with DIM == 3) ==========================================================
+ * The guided solve of oracle/wost_guided.c on triangle meshes: integrator/guided/integrator.cu with DIM == 3 (:153-249 separate,
+ * :252-274 handleBoundary + records, :367-494 sampleNeumann with three draws, :497-526 routing, :529-563 inference, :618-668
+ * training, :671-779 / :782-880 uniform / guided sampling with VMM<3,8> and the reflection about the Neumann normal, :883-965
+ * oneStepWalk, :968-1094 the sample loop), guided/parameters.h:26-33 (3 inputs, 8 x 5 + 1 = 41 outputs padded to 48), train.h:149-155
+ * (normalizeSpatialCoord with the diagonal of the 3-D box), :423-471 (training data), :492-553 (loss gradients, wo3_vmm_loss_gradients
+ * above).  The same free choices as in 2-D make it deterministic: training set in (pixel, record) order, the fp32 network of
+ * wost_net.c with three inputs.  The source term is not restated here (a scene with one is refused). */
+typedef struct {
+    float sol[3];
+    v3 p, d, n;
+    float pdf, thp;
+    int on_n;
+} g3_record;
+
+#define G3_MAX_TRAIN_DEPTH 4
+
+typedef struct {
+    wo_pcg rng;
+    float sol[3];
+    int state;            /* 0 = none, 1 = evaluation point queued, 2 = out of shell (has R_B) */
+    v3 x, nn;
+    float thp, R_B;
+    int on_n;
+    g3_record rec[G3_MAX_TRAIN_DEPTH + 1];
+    unsigned cur_depth;
+} g3_pixel;
+
+typedef struct { float min[3], max[3]; } g3_aabb;
+
+static int aabb3_contains(const g3_aabb *b, v3 q)
+{
+    return b->min[0] <= q.x && q.x <= b->max[0] && b->min[1] <= q.y && q.y <= b->max[1] && b->min[2] <= q.z && q.z <= b->max[2];
+}
+
+/* train.h:149-155: inflate by 0.5 % of the diagonal length, then 0.5 + (p - centre) / extent */
+static void normalize_coord3(const g3_aabb *b, v3 q, float out[3])
+{
+    const float e[3] = { b->max[0] - b->min[0], b->max[1] - b->min[1], b->max[2] - b->min[2] };
+    const float infl = sqrtf((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) * 0.005f;      /* Eigen norm(): squared terms added in order */
+    const float c[3] = { q.x, q.y, q.z };
+    for (int a = 0; a < 3; ++a) {
+        const float lo = b->min[a] - infl, hi = b->max[a] + infl;
+        out[a] = 0.5f + (c[a] - (lo + hi) / 2.0f) / (hi - lo);
+    }
+}
+
+static void record_solution3(g3_pixel *p, const float c[3], int inclusive)
+{
+    unsigned depth = p->cur_depth < G3_MAX_TRAIN_DEPTH ? p->cur_depth : G3_MAX_TRAIN_DEPTH;
+    unsigned end = inclusive ? depth + 1 : depth;      /* guided.h:48-57 against :59-68 */
+    for (unsigned i = 0; i < end; ++i)
+        for (int ch = 0; ch < 3; ++ch) p->rec[i].sol[ch] = p->rec[i].sol[ch] + c[ch];
+}
+
+static void increment_depth3(g3_pixel *p, v3 dir, float pdf)
+{
+    unsigned d = p->cur_depth;
+    if (d >= G3_MAX_TRAIN_DEPTH) return;
+    g3_record *r = &p->rec[d];
+    r->sol[0] = r->sol[1] = r->sol[2] = 0.0f;
+    r->p = p->x; r->d = dir; r->pdf = pdf; r->thp = p->thp; r->on_n = p->on_n; r->n = p->nn;
+    p->cur_depth = d + 1;
+}
+
+/* the shared tail of the three sampling kernels: intersect, advance, record */
+static void advance_walker3(const pmesh3 *nm, g3_pixel *p, float eps, v3 dir, float pdf, float alpha, int record, uint64_t *nhits)
+{
+    v3 cur = p->x;
+    if (p->on_n) cur = (v3){ p->x.x + eps * p->nn.x, p->x.y + eps * p->nn.y, p->x.z + eps * p->nn.z };
+    v3 nxt = { p->x.x + p->R_B * dir.x, p->x.y + p->R_B * dir.y, p->x.z + p->R_B * dir.z };
+    int hit = 0;
+    v3 hn = { 0.0f, 0.0f, 0.0f };
+    if (nm->n_tris > 0) {
+        float t; int hi;
+        hit = ray_closest3(nm, cur, dir, p->R_B, &t, &hi);
+        if (hit) {
+            hn = nm->tris[hi].n;
+            if (dot3(hn, dir) > 0) { hn.x = -hn.x; hn.y = -hn.y; hn.z = -hn.z; }
+            nxt = (v3){ cur.x + t * dir.x, cur.y + t * dir.y, cur.z + t * dir.z };
+            if (nhits) __atomic_fetch_add(nhits, 1, __ATOMIC_RELAXED);
+        }
+    }
+    if (record) increment_depth3(p, dir, pdf);      /* records the state BEFORE the step */
+    p->thp = p->thp / pdf / alpha / WO_4PI;
+    p->x = nxt; p->on_n = hit; p->nn = hn;
+    p->state = 1;
+}
+
+/* uniformSampleSphere<3> / uniformSampleHemisphere<3> in the frame of the Neumann normal: the two draws of oneStepWalk */
+static void uniform_direction3(g3_pixel *p, v3 *dir, float *pdf, float *alpha)
+{
+    const float u1 = wo_pcg_next_float(&p->rng), u2 = wo_pcg_next_float(&p->rng);
+    float c, s;
+    wo_sincos_2pi(u2, &c, &s);
+    if (p->on_n) {
+        const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+        *dir = frame_to_world(p->nn, r * c, r * s, z);
+        *pdf = 1.0f / WO_2PI;
+        *alpha = 0.5f;
+    } else {
+        const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
+        *dir = (v3){ r * c, r * s, z };
+        *pdf = 1.0f / WO_4PI;
+        *alpha = 1.0f;
+    }
+}
+
+int wo3_solve_guided(const wo3_scene *sc, const wo3_guided_settings *gs, const wo_net_config *nc, float *params, int n_threads,
+                     float *field_rgb, wo_guided_stats *stats, int dump_spp, wo3_train_dump *dump)
+{
+    if (!sc || !gs || !nc || !params || !field_rgb) return -1;
+    if (sc->source.nx > 0) return -3;      /* the 3-D guided solve has no source term here */
+    if (nc->n_output != 41 || nc->n_output_padded < 41) return -1;
+    const int W = gs->width, H = gs->height, N = W * H;
+    pmesh3 dm, nm;
+    if (pmesh3_prepare(&dm, &sc->dirichlet) != 0) return -2;
+    if (pmesh3_prepare(&nm, &sc->neumann) != 0) { pmesh3_free(&dm); return -2; }
+    const int has_d = dm.n_tris > 0, has_n = nm.n_tris > 0;
+    const float eps = gs->eps_shell;
+    g3_aabb box;
+    for (int a = 0; a < 3; ++a) { box.min[a] = gs->aabb_min[a]; box.max[a] = gs->aabb_max[a]; }
+    const uint64_t n_params = wo_net3_n_params(nc);
+    const int NO = nc->n_output_padded;
+    g3_pixel *px = calloc((size_t)N, sizeof(g3_pixel));
+    float *inf_params = malloc(sizeof(float) * n_params);
+    float *m1 = calloc(n_params, sizeof(float)), *m2 = calloc(n_params, sizeof(float)), *ema = calloc(n_params, sizeof(float));
+    uint32_t *param_steps = calloc(n_params, sizeof(uint32_t));
+    float *grad = malloc(sizeof(float) * n_params);
+    float *net_in = malloc(sizeof(float) * 3 * (size_t)N);
+    float *net_out = malloc(sizeof(float) * (size_t)NO * N);
+    int *slot_of = malloc(sizeof(int) * (size_t)N);
+    const size_t max_samples = (size_t)N * G3_MAX_TRAIN_DEPTH;
+    float *t_x = malloc(sizeof(float) * 3 * max_samples), *t_dir = malloc(sizeof(float) * 3 * max_samples);
+    float *t_li = malloc(sizeof(float) * max_samples), *t_pdf = malloc(sizeof(float) * max_samples);
+    float *t_nrm = malloc(sizeof(float) * 3 * max_samples), *t_sol = malloc(sizeof(float) * 3 * max_samples);
+    unsigned char *t_onn = malloc(max_samples);
+    float *t_out = NULL, *t_dl = NULL;
+    memcpy(inf_params, params, sizeof(float) * n_params);
+    int opt_step = 0;
+    uint64_t steps = 0, nhits = 0, guided_steps = 0, train_samples = 0, absorbed = 0, truncated = 0, started = 0;
+    if (n_threads < 1) n_threads = 1;
+    for (int p = 0; p < N; ++p) wo_pcg_seed_pixel(&px[p].rng, p, W);
+    int training = 1;
+    float uniform_fraction = gs->uniform_fraction_training;
+    int max_guided_depth = gs->max_guided_depth_training;
+
+    for (int sample = 0; sample < gs->spp; ++sample) {
+        if (sample == gs->train_spp_count) {            /* integrator.cu:991-996 */
+            training = 0;
+            uniform_fraction = gs->uniform_fraction_guiding;
+            max_guided_depth = gs->max_guided_depth_guiding;
+        }
+        for (int p = 0; p < N; ++p) {
+            g3_pixel *q = &px[p];
+            q->cur_depth = 0;
+            q->state = 0;
+            if (sc->mask && sc->mask[p] == 0) continue;
+            q->x = eval_point3(sc, p % W, p / W, W, H);
+            q->thp = 1.0f; q->on_n = 0; q->nn = (v3){ 0.0f, 0.0f, 0.0f };
+            q->state = 1;
+            started++;
+        }
+        for (int depth = 0; depth < gs->max_depth; ++depth) {
+            const int guiding = depth < max_guided_depth;
+            /* ---- separate + handleBoundary + sampleNeumann ---- */
+#pragma omp parallel for schedule(dynamic, 64) num_threads(n_threads) reduction(+ : steps, absorbed)
+            for (int p = 0; p < N; ++p) {
+                g3_pixel *q = &px[p];
+                if (q->state != 1) continue;
+                steps++;
+                const int train_px = training && ((unsigned)(p - gs->train_pixel_offset) % (unsigned)gs->train_pixel_stride == 0);
+                float R_D = INFINITY;
+                if (has_d) {
+                    const cp3 cp = closest_tri(&dm, q->x);
+                    const ptri *T = &dm.tris[cp.idx];
+                    const int side = tri_side(T, q->x);
+                    float u, v;
+                    tri_uv(T, q->x, &u, &v);
+                    R_D = sqrtf(cp.d2);
+                    if (R_D < eps && u > 0.0f && v > 0.0f && u + v < 1.0f) {
+                        float col[3];
+                        surface_color3(dm.colors, T, side, u, v, col);
+                        for (int c = 0; c < 3; ++c) {
+                            col[c] *= sc->dirichlet_intensity;
+                            col[c] *= q->thp;
+                            q->sol[c] = col[c] + q->sol[c];
+                        }
+                        if (train_px) record_solution3(q, col, 0);
+                        q->state = 0;
+                        absorbed++;
+                        continue;
+                    }
+                }
+                float R_N = INFINITY;
+                if (has_n) R_N = closest_silhouette3(&nm, q->x, R_D);
+                const float R_B = fmaxf(WO_R_B_FLOOR, fminf(R_D, R_N));      /* no 0.99 in the guided integrator (:238-239) */
+                if (isinf(R_B)) { q->state = 0; continue; }
+                q->R_B = R_B;
+                q->state = 2;
+                if (has_n) {                                    /* sampleNeumann: three draws in 3-D */
+                    const float u0 = wo_pcg_next_float(&q->rng), u1 = wo_pcg_next_float(&q->rng), u2 = wo_pcg_next_float(&q->rng);
+                    float pdf;
+                    const int oi = sample_in_sphere3(&nm, q->x, R_B, u0, &pdf);
+                    if (oi != -1 && pdf > 0) {
+                        const ptri *S = &nm.tris[oi];
+                        const float su = sqrtf(u1), b1 = u2 * su, b0 = 1.0f - su;
+                        const float b2 = 1.0f - b0 - b1;
+                        const v3 sp = { (S->p0.x * b0 + S->p1.x * b1) + S->p2.x * b2, (S->p0.y * b0 + S->p1.y * b1) + S->p2.y * b2,
+                                        (S->p0.z * b0 + S->p1.z * b1) + S->p2.z * b2 };
+                        const v3 rv = v3_sub(sp, q->x);
+                        const float r = sqrtf(dot3(rv, rv));
+                        if (r < R_B && r > 0) {
+                            v3 o = q->x;
+                            if (q->on_n) o = (v3){ q->x.x + eps * q->nn.x, q->x.y + eps * q->nn.y, q->x.z + eps * q->nn.z };
+                            v3 rd = v3_sub(sp, o);
+                            const float cd = sqrtf(dot3(rd, rd));
+                            if (cd > 0) { rd.x /= cd; rd.y /= cd; rd.z /= cd; }
+                            if (!ray_any3(&nm, o, rd, cd - eps)) {
+                                int side = tri_side(S, q->x);
+                                float uu, vv;
+                                tri_uv(S, sp, &uu, &vv);
+                                if (q->on_n) {
+                                    const float dn = dot3(S->n, q->nn);
+                                    side = (0.0f < dn) - (dn < 0.0f);
+                                }
+                                if (side != 0) {
+                                    float col[3];
+                                    surface_color3(nm.colors, S, side, uu, vv, col);
+                                    const float alpha = q->on_n ? 0.5f : 1.0f;
+                                    const float G = (1.0f / r - 1.0f / R_B) / WO_4PI;
+                                    for (int c = 0; c < 3; ++c) {
+                                        col[c] *= sc->neumann_intensity;
+                                        col[c] *= q->thp * G / alpha / pdf;
+                                        col[c] = -col[c];
+                                        q->sol[c] = col[c] + q->sol[c];
+                                    }
+                                    if (train_px) record_solution3(q, col, 1);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            /* ---- inferenceStep ---- */
+            int n_out = 0;
+            for (int p = 0; p < N; ++p) {
+                slot_of[p] = -1;
+                if (px[p].state == 2) {
+                    slot_of[p] = n_out;
+                    normalize_coord3(&box, px[p].x, &net_in[3 * (size_t)n_out]);
+                    n_out++;
+                }
+            }
+            if (n_out == 0) break;
+            if (guiding) {
+                const int chunk = 256;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads)
+                for (int b = 0; b < n_out; b += chunk) {
+                    const int cnt = n_out - b < chunk ? n_out - b : chunk;
+                    wo_net3_forward(nc, inf_params, net_in + 3 * (size_t)b, cnt, net_out + (size_t)NO * b, NULL);
+                }
+            }
+            /* ---- handleOutShellPoint + guided / uniform sampling, or oneStepWalk ---- */
+#pragma omp parallel for schedule(dynamic, 64) num_threads(n_threads) reduction(+ : guided_steps)
+            for (int p = 0; p < N; ++p) {
+                g3_pixel *q = &px[p];
+                if (q->state != 2) continue;
+                const int train_px = training && ((unsigned)(p - gs->train_pixel_offset) % (unsigned)gs->train_pixel_stride == 0);
+                const int record = train_px && depth < gs->max_train_depth;
+                v3 dir;
+                float pdf, alpha;
+                if (!guiding) {
+                    uniform_direction3(q, &dir, &pdf, &alpha);
+                    advance_walker3(&nm, q, eps, dir, pdf, alpha, record, &nhits);
+                    continue;
+                }
+                const float *raw = net_out + (size_t)NO * slot_of[p];
+                const float sel = 1 / (1.f + wo_expf(-raw[40]));
+                const int inside = aabb3_contains(&box, q->x);
+                int to_guided = (uniform_fraction == 0) || (wo_pcg_next_float(&q->rng) < sel);
+                to_guided = to_guided && inside;
+                if (to_guided) {
+                    if (!(uniform_fraction < 1.0f)) { q->state = 0; continue; }
+                    wv3_vmm m;
+                    wv3_build(&m, raw);
+                    float w[3];
+                    wv3_sample(&m, &q->rng, w);
+                    float guided_pdf = wv3_pdf(&m, w);
+                    float uniform_pdf = 1.0f / WO_4PI;
+                    alpha = 1.0f;
+                    if (q->on_n) {
+                        uniform_pdf = 1.0f / WO_2PI;
+                        alpha = 0.5f;
+                        /* reflect(v, n) = v - 2 (v . n) n; Eigen dot(): products added in order */
+                        const float dn = (w[0] * q->nn.x + w[1] * q->nn.y) + w[2] * q->nn.z;
+                        const float r[3] = { w[0] - 2 * dn * q->nn.x, w[1] - 2 * dn * q->nn.y, w[2] - 2 * dn * q->nn.z };
+                        if ((q->nn.x * w[0] + q->nn.y * w[1]) + q->nn.z * w[2] <= 0) { w[0] = r[0]; w[1] = r[1]; w[2] = r[2]; }
+                        guided_pdf += wv3_pdf(&m, r);
+                    }
+                    dir = (v3){ w[0], w[1], w[2] };
+                    pdf = sel * guided_pdf + (1.0f - sel) * uniform_pdf;
+                    guided_steps++;
+                } else {
+                    uniform_direction3(q, &dir, &pdf, &alpha);
+                    if (inside) {
+                        wv3_vmm m;
+                        wv3_build(&m, raw);
+                        const float w[3] = { dir.x, dir.y, dir.z };
+                        float guided_pdf = wv3_pdf(&m, w);
+                        if (q->on_n) {
+                            const float dn = (w[0] * q->nn.x + w[1] * q->nn.y) + w[2] * q->nn.z;
+                            const float r[3] = { w[0] - 2 * dn * q->nn.x, w[1] - 2 * dn * q->nn.y, w[2] - 2 * dn * q->nn.z };
+                            guided_pdf += wv3_pdf(&m, r);
+                        }
+                        pdf = sel * guided_pdf + (1.0f - sel) * pdf;
+                    }
+                }
+                advance_walker3(&nm, q, eps, dir, pdf, alpha, record, &nhits);
+            }
+            if (depth == gs->max_depth - 1)
+                for (int p = 0; p < N; ++p) truncated += px[p].state == 1;
+        }
+        /* ---- trainStep ---- */
+        if (training) {
+            size_t n = 0;
+            for (unsigned p = (unsigned)gs->train_pixel_offset; p < (unsigned)N; p += (unsigned)gs->train_pixel_stride) {
+                const g3_pixel *q = &px[p];
+                for (unsigned k = 0; k < q->cur_depth; ++k) {
+                    const g3_record *r = &q->rec[k];
+                    if (!aabb3_contains(&box, r->p)) continue;
+                    float s3[3];
+                    for (int ch = 0; ch < 3; ++ch) {
+                        float v = 0.0f;
+                        if (fabsf(r->thp) > 1e-5f) v = r->sol[ch] / r->thp;
+                        s3[ch] = fabsf(v);
+                    }
+                    float in3[3];
+                    normalize_coord3(&box, r->p, in3);
+                    if (isnan(in3[0]) || isnan(in3[1]) || isnan(in3[2]) || isnan(r->d.x) || isnan(r->d.y) || isnan(r->d.z) || isnan(r->pdf) ||
+                        r->pdf == 0 || isnan(s3[0]) || isnan(s3[1]) || isnan(s3[2]))
+                        continue;
+                    memcpy(t_x + 3 * n, in3, sizeof(in3));
+                    t_dir[3 * n] = r->d.x; t_dir[3 * n + 1] = r->d.y; t_dir[3 * n + 2] = r->d.z;
+                    t_sol[3 * n] = s3[0]; t_sol[3 * n + 1] = s3[1]; t_sol[3 * n + 2] = s3[2];
+                    t_li[n] = (s3[0] + s3[1] + s3[2]) / 3.0f;
+                    t_pdf[n] = r->pdf;
+                    t_onn[n] = (unsigned char)r->on_n;
+                    t_nrm[3 * n] = r->n.x; t_nrm[3 * n + 1] = r->n.y; t_nrm[3 * n + 2] = r->n.z;
+                    n++;
+                }
+            }
+            train_samples += n;
+            if (dump && sample == dump_spp) {
+                dump->n = (int)n;
+                const size_t m = n < (size_t)dump->capacity ? n : (size_t)dump->capacity;
+                if (dump->xyz) memcpy(dump->xyz, t_x, sizeof(float) * 3 * m);
+                if (dump->dir) memcpy(dump->dir, t_dir, sizeof(float) * 3 * m);
+                if (dump->solution) memcpy(dump->solution, t_sol, sizeof(float) * 3 * m);
+                if (dump->dir_pdf) memcpy(dump->dir_pdf, t_pdf, sizeof(float) * m);
+                if (dump->on_neumann) memcpy(dump->on_neumann, t_onn, m);
+                if (dump->normal) memcpy(dump->normal, t_nrm, sizeof(float) * 3 * m);
+            }
+            const size_t bs = (size_t)gs->batch_size;
+            size_t n_batches = n / bs + 1;
+            if (n_batches > (size_t)gs->batches_per_spp) n_batches = (size_t)gs->batches_per_spp;
+            for (size_t it = 0; it < n_batches; ++it) {
+                size_t local = n - it * bs < bs ? n - it * bs : bs;
+                local -= local % 128;
+                if (local < (size_t)gs->min_batch_size) break;
+                const size_t o = it * bs;
+                t_out = realloc(t_out, sizeof(float) * (size_t)NO * local);
+                t_dl = realloc(t_dl, sizeof(float) * (size_t)NO * local);
+                const int chunk = 256;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads)
+                for (size_t b = 0; b < local; b += chunk) {
+                    const int cnt = local - b < (size_t)chunk ? (int)(local - b) : chunk;
+                    wo_net3_forward(nc, params, t_x + 3 * (o + b), cnt, t_out + (size_t)NO * b, NULL);
+                }
+                float *raw41 = malloc(sizeof(float) * 41 * local), *dl41 = malloc(sizeof(float) * 41 * local);
+                for (size_t i = 0; i < local; ++i) memcpy(raw41 + 41 * i, t_out + (size_t)NO * i, sizeof(float) * 41);
+                wo3_vmm_loss_gradients(raw41, t_dir + 3 * o, t_li + o, t_pdf + o, t_onn + o, t_nrm + 3 * o, (int)local, gs->loss_scale, dl41, NULL);
+                memset(t_dl, 0, sizeof(float) * (size_t)NO * local);
+                for (size_t i = 0; i < local; ++i) memcpy(t_dl + (size_t)NO * i, dl41 + 41 * i, sizeof(float) * 41);
+                free(raw41); free(dl41);
+                wo_net3_backward(nc, params, t_x + 3 * o, t_dl, (int)local, grad);
+                opt_step++;
+                wo_net3_optimizer_step(nc, params, m1, m2, ema, inf_params, grad, opt_step, gs->loss_scale, param_steps);
+            }
+        }
+    }
+    for (int p = 0; p < N; ++p)
+        for (int c = 0; c < 3; ++c) field_rgb[3 * (size_t)p + c] = px[p].sol[c] / (float)gs->spp;
+    if (stats) {
+        stats->walk_steps = steps; stats->walks_started = started; stats->walks_absorbed = absorbed;
+        stats->walks_truncated = truncated; stats->neumann_hits = nhits; stats->guided_steps = guided_steps;
+        stats->train_samples = train_samples; stats->optimizer_steps = (uint64_t)opt_step;
+    }
+    free(px); free(inf_params); free(m1); free(m2); free(ema); free(param_steps); free(grad); free(net_in); free(net_out); free(slot_of);
+    free(t_x); free(t_dir); free(t_li); free(t_pdf); free(t_nrm); free(t_sol); free(t_onn); free(t_out); free(t_dl);
+    pmesh3_free(&dm); pmesh3_free(&nm);
+    return 0;
+}

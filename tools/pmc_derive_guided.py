@@ -41,11 +41,11 @@ out = {"kernel": "guided_sample_kernel", "source_id": source_id(), "share_of_gpu
        "mfma_busy": tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc) if cyc and "SQ_VALU_MFMA_BUSY_CYCLES" in tot else None,
        "lds_conflict_ratio": tot["SQ_LDS_BANK_CONFLICT"] / tot["SQ_ACTIVE_INST_LDS"] if tot.get("SQ_ACTIVE_INST_LDS") else None,
        "walk_steps": steps,
-       "lane_instr_per_step": (tot["SQ_THREAD_CYCLES_VALU"] / 4.0 / steps) if steps and "SQ_THREAD_CYCLES_VALU" in tot else None,
+       "lane_instr_per_step": (tot["SQ_THREAD_CYCLES_VALU"] / steps) if steps and "SQ_THREAD_CYCLES_VALU" in tot else None,
        "top_kernels_by_gpu_time": top,
        "source": "rocprofv3 --pmc passes of `%s` (tools/gpu_round.sh, stage pmc_guided): pipe_busy = 4 SQ_ACTIVE_INST_VALU / (1024 SIMDs x "
                  "GRBM_GUI_ACTIVE / 8), lane_efficiency = SQ_THREAD_CYCLES_VALU / (64 SQ_INSTS_VALU), mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
                  "(1024 x kernel cycles), lds_conflict_ratio = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS, lane_instr_per_step = active "
-                 "lane-instructions / walk steps (SQ_THREAD_CYCLES_VALU counts 4 per active lane-instruction)" % cmd}
+                 "lane-instructions / walk steps" % cmd}
 json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps(out))
