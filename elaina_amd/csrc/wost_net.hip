@@ -110,12 +110,15 @@ __device__ __forceinline__ void encode_point(const NetLayout &L, const float *gr
             // corner k: bit 0 = +x, bit 1 = +y, bit 2 = +z (three inputs only); weight = product of the axis weights in that order
             const uint32_t cx = ix + (k & 1), cy = iy + ((k >> 1) & 1);
             float w = ((k & 1) ? px : 1.0f - px) * ((k & 2) ? py : 1.0f - py);
-            uint32_t lin = cx + cy * res;
+            uint32_t idx;
             if (L.dims == 3) {
+                // (64-bit like the CPU restatement, so that inputs outside the unit cube -- walkers outside the scene box -- wrap alike)
                 w = w * ((k & 4) ? pz : 1.0f - pz);
-                lin += (iz + ((k >> 2) & 1)) * res * res;
+                const uint32_t cz = iz + ((k >> 2) & 1);
+                idx = (uint32_t)(((unsigned long long)cx + (unsigned long long)cy * res + (unsigned long long)cz * res * res) % n_level);
+            } else {
+                idx = (cx + cy * res) % n_level;
             }
-            const uint32_t idx = lin % n_level;
             const float *g = grid + (size_t)(L.level_off[lv] + idx) * L.n_features;
             for (int q = 0; q < L.n_features; ++q) act(col, lv * L.n_features + q) += w * g[q];
         }
@@ -1058,7 +1061,8 @@ __global__ __launch_bounds__(kGridGradBlock) void grid_grad_kernel(NetLayout L, 
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float w = (((k & 1) ? pf[0] : 1.0f - pf[0]) * ((k & 2) ? pf[1] : 1.0f - pf[1])) * ((k & 4) ? pf[2] : 1.0f - pf[2]);
-                const uint32_t idx = ((pi[0] + (k & 1)) + (pi[1] + ((k >> 1) & 1)) * res + (pi[2] + ((k >> 2) & 1)) * res * res) % n_level;
+                const uint32_t idx = (uint32_t)(((unsigned long long)(pi[0] + (k & 1)) + (unsigned long long)(pi[1] + ((k >> 1) & 1)) * res +
+                                                 (unsigned long long)(pi[2] + ((k >> 2) & 1)) * res * res) % n_level);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if (q < q0 || q >= q1) continue;

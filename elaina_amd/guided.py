@@ -72,11 +72,14 @@ class GuidingNetwork:
     ReLU MLP, Adam nested in EMA.  Mirrors how integrator/guided/integrator.cu drives
     tiny-cuda-nn: inference() (:560,:597) and one training step (:655-662)."""
 
-    def __init__(self, config=None, seed=1337, device=0):
+    def __init__(self, config=None, seed=1337, device=0, dims=2):
+        """dims = 3: the three-input network of GuidedIntegrator<3> (wost_net_create3)"""
         self._lib = capi.load()
         self.config = config or default_net_config()
+        self.dims = dims
         self._h = C.c_void_p()
-        _check(self._lib.wost_net_create(device, C.byref(self.config), seed, C.byref(self._h)), "wost_net_create")
+        create = self._lib.wost_net_create3 if dims == 3 else self._lib.wost_net_create
+        _check(create(device, C.byref(self.config), seed, C.byref(self._h)), "wost_net_create")
         total, mlp = C.c_uint64(), C.c_uint64()
         _check(self._lib.wost_net_n_params(self._h, C.byref(total), C.byref(mlp)), "wost_net_n_params")
         self.n_params, self.n_mlp_params = total.value, mlp.value
@@ -119,14 +122,14 @@ class GuidingNetwork:
         _check(self._lib.wost_net_set_option(self._h, key.encode(), float(value)), "wost_net_set_option")
 
     def inference(self, xy, use_inference_params=True):
-        x = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        x = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, getattr(self, "dims", 2))
         out = np.zeros((len(x), self.config.n_output), dtype=np.float32)
         _check(self._lib.wost_net_inference(self._h, _fp(x), len(x), _fp(out), int(use_inference_params)),
                "wost_net_inference")
         return out
 
     def train_step(self, xy, dl_dout, loss_scale=128.0, apply_update=True):
-        x = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        x = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, getattr(self, "dims", 2))
         g = np.ascontiguousarray(dl_dout, dtype=np.float32).reshape(len(x), self.config.n_output)
         _check(self._lib.wost_net_train_step(self._h, _fp(x), _fp(g), len(x), loss_scale, int(apply_update)),
                "wost_net_train_step")
@@ -164,8 +167,8 @@ class GuidedIntegratorSettings:
 class _BorrowedNetwork(GuidingNetwork):
     """the integrator's own network: same methods, lifetime owned by the integrator"""
 
-    def __init__(self, lib, handle, config):
-        self._lib, self._h, self.config = lib, handle, config
+    def __init__(self, lib, handle, config, dims=2):
+        self._lib, self._h, self.config, self.dims = lib, handle, config, dims
         total, mlp = C.c_uint64(), C.c_uint64()
         _check(lib.wost_net_n_params(handle, C.byref(total), C.byref(mlp)), "wost_net_n_params")
         self.n_params, self.n_mlp_params = total.value, mlp.value

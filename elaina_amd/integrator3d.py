@@ -51,6 +51,35 @@ def _mesh3(keep, verts, tris, colors):
     return m
 
 
+def scene3_desc(keep, problem, w, h):
+    """wost3_scene_desc of a Problem3 (arrays referenced from `keep`)"""
+    sc = Scene3Desc()
+    sc.dirichlet = _mesh3(keep, problem.d_verts, problem.d_tris, problem.d_colors)
+    sc.neumann = _mesh3(keep, problem.n_verts, problem.n_tris, problem.n_colors)
+    sc.dirichlet_intensity, sc.neumann_intensity = problem.dirichlet_intensity, problem.neumann_intensity
+    scale, pos, up, right = problem.probe
+    sc.probe_scale = float(scale)
+    for k in range(3):
+        sc.probe_pos[k], sc.probe_up[k], sc.probe_right[k] = float(pos[k]), float(up[k]), float(right[k])
+    if problem.mask is not None:
+        if problem.mask.size != w * h:
+            raise ValueError("mask must have width*height entries")
+        keep.append(problem.mask)
+        sc.mask = problem.mask.ctypes.data_as(C.POINTER(C.c_uint8))
+    if problem.source is not None:
+        rgb = problem.source["rgb"]
+        if rgb.ndim != 4 or rgb.shape[3] != 3:
+            raise ValueError("source rgb must be [nz, ny, nx, 3]")
+        keep.append(rgb)
+        sc.source.nz, sc.source.ny, sc.source.nx = rgb.shape[:3]
+        sc.source.rgb = _fp(rgb)
+        for k in range(3):
+            sc.source.index_scale[k] = float(problem.source["index_scale"][k])
+            sc.source.index_offset[k] = float(problem.source["index_offset"][k])
+        sc.source.intensity = float(problem.source.get("intensity", 1.0))
+    return sc
+
+
 class UniformIntegrator3:
     VectorType = tuple
 
@@ -59,30 +88,7 @@ class UniformIntegrator3:
         self.problem, self.settings = problem, settings
         keep = []
         w, h = settings.frameSize
-        sc = Scene3Desc()
-        sc.dirichlet = _mesh3(keep, problem.d_verts, problem.d_tris, problem.d_colors)
-        sc.neumann = _mesh3(keep, problem.n_verts, problem.n_tris, problem.n_colors)
-        sc.dirichlet_intensity, sc.neumann_intensity = problem.dirichlet_intensity, problem.neumann_intensity
-        scale, pos, up, right = problem.probe
-        sc.probe_scale = float(scale)
-        for k in range(3):
-            sc.probe_pos[k], sc.probe_up[k], sc.probe_right[k] = float(pos[k]), float(up[k]), float(right[k])
-        if problem.mask is not None:
-            if problem.mask.size != w * h:
-                raise ValueError("mask must have width*height entries")
-            keep.append(problem.mask)
-            sc.mask = problem.mask.ctypes.data_as(C.POINTER(C.c_uint8))
-        if problem.source is not None:
-            rgb = problem.source["rgb"]
-            if rgb.ndim != 4 or rgb.shape[3] != 3:
-                raise ValueError("source rgb must be [nz, ny, nx, 3]")
-            keep.append(rgb)
-            sc.source.nz, sc.source.ny, sc.source.nx = rgb.shape[:3]
-            sc.source.rgb = _fp(rgb)
-            for k in range(3):
-                sc.source.index_scale[k] = float(problem.source["index_scale"][k])
-                sc.source.index_offset[k] = float(problem.source["index_offset"][k])
-            sc.source.intensity = float(problem.source.get("intensity", 1.0))
+        sc = scene3_desc(keep, problem, w, h)
         st = Settings(w, h, settings.samplesPerPixel, settings.maxWalkingDepth, settings.epsilonShell)
         self._handle = C.c_void_p()
         _check(self.lib.wost3_create(C.byref(sc), C.byref(st), device, C.byref(self._handle)), "wost3_create")
@@ -206,3 +212,83 @@ def vmm3_loss_gradients(raw41, dirs, li, dir_pdf, on_neumann, normal, loss_scale
     _check(lib.wost3_vmm_loss_gradients(device, _fp(r), _fp(d), _fp(l), _fp(p), o.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(nn), n,
                                         C.c_float(loss_scale), _fp(g), _fp(lk)), "wost3_vmm_loss_gradients")
     return g, lk
+
+
+def default_net_config3(n_levels=8, base_resolution=8, per_level_scale=1.4049999713897705):
+    """the network of GuidedIntegrator<3>: data/ladybug/n.json:49-81 with the 41 outputs of guided/parameters.h:26-33"""
+    return capi.NetConfig(n_levels, 4, base_resolution, per_level_scale, 64, 3, 41, 0.00800000037997961, 0.8999999761581421,
+                          0.9900000095367432, 1.0000000036274937e-15, 9.999999974752427e-07, 0.949999988079071)
+
+
+class GuidedIntegrator3:
+    """Mirror of GuidedIntegrator<3> (reference integrator/guided/integrator.h:77-256 with DIM = 3; exec.cu:102-122): ctor +
+    resetNetwork, solve(), queryNetwork(); `aabb` = scene.aabb ((min xyz), (max xyz)); settings: GuidedIntegratorSettings"""
+
+    def __init__(self, problem, settings, aabb, network_config=None, seed=42, device=0):
+        from .guided import _BorrowedNetwork
+        self.lib = capi.load()
+        self.problem, self.settings = problem, settings
+        keep = []
+        w, h = settings.frameSize
+        sc = scene3_desc(keep, problem, w, h)
+        gs = capi.Guided3Settings(w, h, settings.samplesPerPixel, settings.maxWalkingDepth, settings.epsilonShell, settings.trainSppCount,
+                                  settings.uniformFractionInTrainingPhase, settings.uniformFractionInGuidingPhase,
+                                  settings.maxGuidedDepthInTrainingPhase, settings.maxGuidedDepthInGuidingPhase)
+        for k in range(3):
+            gs.aabb_min[k], gs.aabb_max[k] = float(aabb[0][k]), float(aabb[1][k])
+        gs.max_train_depth, gs.batch_size, gs.min_batch_size = settings.maxTrainDepth, settings.batchSize, settings.minBatchSize
+        gs.batches_per_spp, gs.train_pixel_stride = settings.batchPerFrame, settings.trainPixelStride
+        gs.train_pixel_offset, gs.loss_scale = settings.trainPixelOffset, settings.lossScale
+        self.network_config = network_config or default_net_config3()
+        self._handle = C.c_void_p()
+        _check(self.lib.wost3_guided_create(C.byref(sc), C.byref(gs), C.byref(self.network_config), seed, device, C.byref(self._handle)),
+               "wost3_guided_create")
+        nh = C.c_void_p()
+        _check(self.lib.wost3_guided_network(self._handle, C.byref(nh)), "wost3_guided_network")
+        self.network = _BorrowedNetwork(self.lib, nh, self.network_config, dims=3)
+        self.n_pixels = w * h
+        self.solution, self.last_stats = None, None
+
+    def close(self):
+        if self._handle:
+            self.network.close()
+            self.lib.wost3_guided_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self):
+        field = np.zeros((self.n_pixels, 3), dtype=np.float32)
+        st = capi.GuidedStats()
+        _check(self.lib.wost3_guided_solve(self._handle, _fp(field), C.byref(st)), "wost3_guided_solve")
+        self.solution, self.last_stats = field, st.as_dict()
+        return int(st.solve_ms)
+
+    def solve_sharded(self, shard_index, shard_count, field_dev_ptr):
+        st = capi.GuidedStats()
+        _check(self.lib.wost3_guided_solve_sharded(self._handle, shard_index, shard_count, C.c_void_p(field_dev_ptr), C.byref(st)),
+               "wost3_guided_solve_sharded")
+        self.last_stats = st.as_dict()
+        return self.last_stats
+
+    def queryNetwork(self, p):
+        pts = np.ascontiguousarray(p, dtype=np.float32).reshape(-1, 3)
+        raw = np.zeros((len(pts), 41), dtype=np.float32)
+        _check(self.lib.wost3_guided_query_network(self._handle, _fp(pts), len(pts), _fp(raw)), "wost3_guided_query_network")
+        return raw if np.ndim(p) > 1 else raw[0]
+
+    def train_set(self):
+        n = C.c_int32()
+        _check(self.lib.wost3_guided_train_set(self._handle, 0, C.byref(n), None, None, None, None, None, None), "wost3_guided_train_set")
+        m = n.value
+        out = {"xyz": np.zeros((m, 3), np.float32), "dir": np.zeros((m, 3), np.float32), "solution": np.zeros((m, 3), np.float32),
+               "dir_pdf": np.zeros(m, np.float32), "normal": np.zeros((m, 3), np.float32), "on_neumann": np.zeros(m, np.uint8)}
+        if m:
+            _check(self.lib.wost3_guided_train_set(self._handle, m, C.byref(n), _fp(out["xyz"]), _fp(out["dir"]), _fp(out["solution"]),
+                                                   _fp(out["dir_pdf"]), _fp(out["normal"]),
+                                                   out["on_neumann"].ctypes.data_as(C.POINTER(C.c_uint8))), "wost3_guided_train_set")
+        return out

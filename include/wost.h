@@ -414,6 +414,42 @@ int wost3_render_sdf(wost3_handle h, int which_mesh, float *out_dist);
 int wost3_render_source(wost3_handle h, float *out_rgb);
 int wost3_destroy(wost3_handle h);
 
+/* ---- 3-D: GuidedIntegrator<3> (SURVEY.md 8a rows a21-a27 with DIM == 3) -----------------------------------------------
+ * Replaces the GuidedIntegrator<3> alternative of run_expr's variant (exec.cu:102-122) and its solve() -- the DIM == 3
+ * branches of integrator/guided/integrator.cu (:181-215 triangle side / barycentric uv, :347 three Neumann draws, :508-511,
+ * :690-693, :800-803 VMM<3,8> and the reflection about the Neumann normal), guided/parameters.h:26-33 (3 network inputs,
+ * 8 x (lambda, kappa, mean vector) + selection logit = 41 outputs padded to 48), train.h:289-353 (3-D records) -- on the
+ * scene types of the 3-D uniform integrator above.  The network is the one of wost_net_create3: the DenseGrid encoding
+ * with three inputs (trilinear, res^3 entries per level), otherwise the configuration of data/ladybug/n.json:49-81; fp32.
+ * Scenes with a source term are refused (WOST_ERR_UNSUPPORTED). */
+int wost_net_create3(int device, const wost_net_config *cfg, uint64_t seed, wost_net_handle *out);   /* inputs: 3 floats per point */
+typedef struct wost3_guided_settings {
+    int32_t width, height, spp, max_depth;
+    float eps_shell;
+    int32_t train_spp_count;
+    float uniform_fraction_training, uniform_fraction_guiding;
+    int32_t max_guided_depth_training, max_guided_depth_guiding;
+    float aabb_min[3], aabb_max[3];             /* scene.aabb */
+    int32_t max_train_depth, batch_size, min_batch_size, batches_per_spp, train_pixel_stride, train_pixel_offset;
+    float loss_scale;                           /* meanings and reference defaults as in wost_guided_settings */
+} wost3_guided_settings;
+typedef struct wost3_guided *wost3_guided_handle;
+/* integrator/guided/integrator.h:127,175 (ctor + resetNetwork) with DIM == 3; net->n_output must be 41 */
+int wost3_guided_create(const wost3_scene_desc *scene, const wost3_guided_settings *settings, const wost_net_config *net,
+                        uint64_t net_seed, int device, wost3_guided_handle *out);
+int wost3_guided_destroy(wost3_guided_handle h);
+int wost3_guided_network(wost3_guided_handle h, wost_net_handle *net);            /* borrowed: owned by the integrator */
+/* solve() (integrator.cu:1189-1195): field_rgb = width*height*3 floats on the host / in device memory (tile shard as in
+ * wost3_solve_sharded, every shard its own network) */
+int wost3_guided_solve(wost3_guided_handle h, float *field_rgb, wost_guided_stats *stats);
+int wost3_guided_solve_sharded(wost3_guided_handle h, int32_t shard_index, int32_t shard_count, float *field_rgb_dev,
+                               wost_guided_stats *stats);
+/* queryNetwork(Vector3f) (exec.cu:175-186): raw = n * 41 mixture parameters of the inference weights at pts (n * 3, world) */
+int wost3_guided_query_network(wost3_guided_handle h, const float *pts, int32_t n, float *raw);
+/* the ordered training set of the last training pass (tests): xyz = normalised inputs, dir / normal 3 floats per sample */
+int wost3_guided_train_set(wost3_guided_handle h, int32_t capacity, int32_t *n, float *xyz, float *dir, float *solution,
+                           float *dir_pdf, float *normal, uint8_t *on_neumann);
+
 const char *wost_last_error(void);
 const char *wost_version(void);
 

@@ -1,0 +1,262 @@
+"""GuidedIntegrator<3> (SURVEY.md 8a rows a21-a27 with DIM == 3; reference exec.cu:102-122, guided/parameters.h:26-33).
+
+CPU part: the three-input network of the oracle (oracle/wost_net.c wo_net3_*) against finite differences and a numpy
+restatement of the trilinear encoding; the guided 3-D solve of the oracle (wost_oracle3d.c wo3_solve_guided) -- deterministic,
+unbiased against an analytic harmonic solution.  GPU part: the HIP integrator (wost3_guided_*, wost_net_create3) through the
+C-ABI against the oracle, bit for bit: network, frozen-network walks, first-pass records, a whole trained solve.
+PARITY UNPINNED w.r.t. tiny-cuda-nn and snch-lbvh (submodules absent), like the 2-D path."""
+import numpy as np
+import pytest
+
+from conftest import cube_scene3
+from oracle.oracle import Oracle, default_net_config3, guided_settings3
+
+AABB3 = ((-0.1, -0.1, -0.1), (1.1, 1.1, 1.1))
+EPS = 1e-3
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+def _cfg():
+    # four levels keep the dense 3-D grid small (8^3 + 12^3 + 16^3 + 23^3 entries); the code path is the same for eight
+    return default_net_config3(n_levels=4)
+
+
+def _rand_params3(orc, cfg, seed=5, wscale=0.25, gscale=0.5):
+    n = orc.net3_n_params(cfg)
+    rng = np.random.default_rng(seed)
+    p = rng.uniform(-wscale, wscale, n).astype(np.float32)
+    n_mlp = 64 * 16 + 2 * 64 * 64 + 48 * 64
+    p[n_mlp:] = rng.uniform(-gscale, gscale, n - n_mlp).astype(np.float32)
+    return p
+
+
+def mixed_cube():
+    """Dirichlet u = z on the faces z = 0 and z = 1, zero flux on the four others: u = z inside"""
+    return cube_scene3(n=3, d_faces=(4, 5), n_faces=(0, 1, 2, 3), value=lambda x, y, z: z, flux=lambda x, y, z, f: 0.0)
+
+
+# ---- CPU: the three-input network ------------------------------------------------------------------------------------
+def test_net3_layout_and_trilinear_encoding(orc):
+    cfg = default_net_config3()
+    # 8 levels: res = ceil(8 * 1.405^l - 1) + 1, res^3 entries rounded up to 8, 4 features each
+    res = [8, 12, 16, 23, 32, 44, 62, 87]
+    n_grid = sum((r ** 3 + 7) // 8 * 8 for r in res) * 4
+    n_mlp = 64 * 32 + 2 * 64 * 64 + 48 * 64
+    assert orc.net3_n_params(cfg) == n_mlp + n_grid
+    cfg = _cfg()
+    p = _rand_params3(orc, cfg)
+    n_mlp = 64 * 16 + 2 * 64 * 64 + 48 * 64
+    # level 0 of the encoding against a numpy restatement: scale 7, res 8, index x + 8 y + 64 z
+    rng = np.random.default_rng(2)
+    x = rng.uniform(0.02, 0.98, (32, 3)).astype(np.float32)
+    W1 = p[:64 * 16].reshape(64, 16).astype(np.float64)
+    grid0 = p[n_mlp:n_mlp + 512 * 4].reshape(512, 4).astype(np.float64)
+    pos = x.astype(np.float64) * 7.0 + 0.5
+    i0 = np.floor(pos).astype(int)
+    f = pos - i0
+    enc0 = np.zeros((32, 4))
+    for k in range(8):
+        c = i0 + np.array([k & 1, (k >> 1) & 1, (k >> 2) & 1])
+        w = np.prod(np.where(np.array([k & 1, (k >> 1) & 1, (k >> 2) & 1]) == 1, f, 1 - f), axis=1)
+        enc0 += w[:, None] * grid0[(c[:, 0] + 8 * c[:, 1] + 64 * c[:, 2]) % 512]
+    # isolate level 0: zero the other levels' grids, compare the first hidden pre-activation's contribution through W1[:, :4]
+    q = p.copy()
+    q[n_mlp + 512 * 4:] = 0.0
+    out = orc.net3_forward(cfg, q, x)
+    h = np.maximum(enc0 @ W1[:, :4].T, 0)
+    W2 = p[1024:1024 + 4096].reshape(64, 64).astype(np.float64)
+    W3 = p[1024 + 4096:1024 + 8192].reshape(64, 64).astype(np.float64)
+    Wo = p[1024 + 8192:n_mlp].reshape(48, 64).astype(np.float64)
+    h = np.maximum(np.maximum(h @ W2.T, 0) @ W3.T, 0) @ Wo.T
+    np.testing.assert_allclose(out, h, rtol=3e-4, atol=3e-5)
+
+
+def test_net3_backward_matches_finite_differences(orc):
+    cfg = _cfg()
+    p = _rand_params3(orc, cfg, seed=7)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0.05, 0.95, (24, 3)).astype(np.float32)
+    dl = np.zeros((24, 48), np.float32)
+    dl[:, :41] = rng.normal(size=(24, 41)).astype(np.float32)
+    g = orc.net3_backward(cfg, p, x, dl)
+
+    def loss(pp):
+        return float((orc.net3_forward(cfg, pp, x).astype(np.float64) * dl).sum())
+    n_mlp = 64 * 16 + 2 * 64 * 64 + 48 * 64
+    idx = list(rng.integers(0, n_mlp, 6)) + [int(i) for i in np.flatnonzero(g[n_mlp:])[:6] + n_mlp]
+    for i in idx:
+        h = 2e-3
+        a, b = p.copy(), p.copy()
+        a[i] += h
+        b[i] -= h
+        fd = (loss(a) - loss(b)) / (float(a[i]) - float(b[i]))
+        assert abs(fd - g[i]) <= 2e-2 * max(1.0, abs(fd)), (i, fd, g[i])
+
+
+def test_oracle_guided3_is_deterministic_and_unbiased(orc):
+    sd = mixed_cube()
+    cfg = _cfg()
+    p1 = _rand_params3(orc, cfg, seed=1, wscale=0.3, gscale=0.3)
+    p2 = p1.copy()
+    gs = guided_settings3(24, 16, 24, 64, EPS, AABB3[0], AABB3[1], train_spp_count=12, batch_size=1024, min_batch_size=256)
+    r1 = orc.solve_guided3(sd, gs, cfg, p1, threads=8)
+    r2 = orc.solve_guided3(sd, gs, cfg, p2, threads=3)
+    assert np.array_equal(r1["field"], r2["field"]) and np.array_equal(p1, p2)
+    assert r1["optimizer_steps"] > 0 and r1["guided_steps"] > 0 and r1["neumann_hits"] > 0
+    assert r1["walks_started"] == 24 * 16 * 24 == r1["walks_absorbed"] + r1["walks_truncated"]
+    # the slice z = 1/2 of u = z, up to the few walks cut at depth 64
+    trunc = r1["walks_truncated"] / r1["walks_started"]
+    assert abs(float(r1["field"][:, 0].mean()) - 0.5) < 0.02 + 0.5 * trunc
+    # phases: no guided depth at all = plain uniform steps; uniform fraction 1 = walks routed to the mixture end
+    g0 = guided_settings3(16, 12, 3, 32, EPS, AABB3[0], AABB3[1], train_spp_count=0, max_guided_depth=(0, 0))
+    assert orc.solve_guided3(sd, g0, cfg, p1.copy(), threads=4)["guided_steps"] == 0
+    g1 = guided_settings3(16, 12, 3, 32, EPS, AABB3[0], AABB3[1], train_spp_count=0, uniform_fraction=(1.0, 1.0))
+    assert orc.solve_guided3(sd, g1, cfg, p1.copy(), threads=4)["guided_steps"] == 0
+
+
+# ---- GPU -------------------------------------------------------------------------------------------------------------
+def _hip_cfg(cfg):
+    from elaina_amd import capi
+    return capi.NetConfig(cfg.n_levels, cfg.n_features, cfg.base_resolution, cfg.per_level_scale, cfg.n_neurons, cfg.n_hidden_layers,
+                          cfg.n_output, cfg.learning_rate, cfg.beta1, cfg.beta2, cfg.epsilon, cfg.l2_reg, cfg.ema_decay)
+
+
+@pytest.mark.gpu
+def test_gpu_net3_inference_and_training_match_oracle(orc):
+    from elaina_amd.guided import GuidingNetwork
+    cfg = _cfg()
+    net = GuidingNetwork(_hip_cfg(cfg), seed=3, dims=3)
+    assert net.n_params == orc.net3_n_params(cfg)
+    p = _rand_params3(orc, cfg, seed=11)
+    net.set_params(p)
+    rng = np.random.default_rng(4)
+    x = rng.uniform(-0.05, 1.05, (3000, 3)).astype(np.float32)        # a little outside the unit cube too: the index wraps
+    assert np.array_equal(net.inference(x), orc.net3_forward(cfg, p, x)[:, :41])
+    # two Adam steps on random loss gradients: gradients, weights and EMA weights bit for bit
+    state = orc.net_optimizer_state(cfg)
+    for k in state:
+        state[k] = np.zeros(len(p), state[k].dtype)
+    po = p.copy()
+    for step in (1, 2):
+        dl = rng.normal(size=(len(x), 41)).astype(np.float32)
+        dl48 = np.zeros((len(x), 48), np.float32)
+        dl48[:, :41] = dl
+        g = orc.net3_backward(cfg, po, x, dl48)
+        net.train_step(x, dl, 128.0, apply_update=True)
+        assert np.array_equal(net.gradients(), g)
+        inf = orc.net3_optimizer_step(cfg, po, state, g, step, 128.0)
+        assert np.array_equal(net.params(), po) and np.array_equal(net.inference_params(), inf)
+    net.close()
+
+
+def _gpu_and_oracle3(orc, sd, w, h, spp, depth, train_spp, uf=(0.5, 0.5), mgd=(10, 10), batch=1024, min_batch=256, params=None,
+                     stride=1, offset=0, dump=True):
+    from elaina_amd.guided import GuidedIntegratorSettings
+    from elaina_amd.integrator3d import GuidedIntegrator3, Problem3
+    cfg = _cfg()
+    st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=train_spp, maxWalkingDepth=depth, epsilonShell=EPS,
+                                  uniformFractionInTrainingPhase=uf[0], uniformFractionInGuidingPhase=uf[1],
+                                  maxGuidedDepthInTrainingPhase=mgd[0], maxGuidedDepthInGuidingPhase=mgd[1], batchSize=batch,
+                                  minBatchSize=min_batch, trainPixelStride=stride, trainPixelOffset=offset)
+    gi = GuidedIntegrator3(Problem3.from_dict(sd), st, AABB3, network_config=_hip_cfg(cfg), seed=7)
+    if params is not None:
+        gi.network.set_params(params)
+    p0 = gi.network.params()
+    gi.solve()
+    gs = guided_settings3(w, h, spp, depth, EPS, AABB3[0], AABB3[1], train_spp_count=train_spp, uniform_fraction=uf, max_guided_depth=mgd,
+                          batch_size=batch, min_batch_size=min_batch, train_pixel_stride=stride, train_pixel_offset=offset)
+    dump_spp = min(train_spp, spp) - 1 if (dump and train_spp > 0) else -1
+    trained = p0.copy()
+    ref = orc.solve_guided3(sd, gs, cfg, trained, threads=16, dump_spp=dump_spp)
+    ref["params"] = trained
+    return gi, ref
+
+
+COUNTERS = ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated", "neumann_hits", "guided_steps")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spp,uf,mgd", [(4, (0.5, 0.5), (10, 10)), (2, (0.0, 0.0), (10, 10)), (2, (0.9, 0.25), (3, 3)), (3, (0.5, 0.5), (0, 0)),
+                                        (2, (1.0, 1.0), (10, 10))])
+def test_gpu_frozen_network_walks_match_oracle(orc, spp, uf, mgd):
+    """training off, a random network with pronounced lobes: routing, vMF mixture sampling, MIS pdf, reflection about the
+    Neumann normals of the cube's side faces, throughput -- bit-exact; also with no guided depth (plain steps, R_B without
+    the 0.99 factor) and with uniform fraction 1 (walks routed to the mixture end, :1031)"""
+    sd = mixed_cube()
+    p = _rand_params3(orc, _cfg(), seed=3, wscale=0.3, gscale=1.0)
+    gi, ref = _gpu_and_oracle3(orc, sd, 40, 32, spp, 48, 0, uf=uf, mgd=mgd, params=p)
+    assert np.array_equal(gi.solution, ref["field"]), float(np.abs(gi.solution - ref["field"]).max())
+    for k in COUNTERS:
+        assert gi.last_stats[k] == ref[k], k
+    assert np.array_equal(gi.network.params(), p)
+    gi.close()
+
+
+@pytest.mark.gpu
+def test_gpu_first_pass_records_match_oracle_3d(orc):
+    """one training pass without an optimizer step: the 3-D records and the ordered training set, bit for bit; an emissive
+    Neumann face adds contributions to the records (recordSourceContribution)"""
+    sd = cube_scene3(n=3, d_faces=(4, 5), n_faces=(0, 1, 2, 3), value=lambda x, y, z: z, flux=lambda x, y, z, f: 0.3 * (f - 1.5))
+    gi, ref = _gpu_and_oracle3(orc, sd, 40, 40, 1, 48, 1, min_batch=10 ** 9)
+    ts, to = gi.train_set(), ref["train_set"]
+    assert gi.last_stats["optimizer_steps"] == 0
+    assert gi.last_stats["train_samples"] == len(ts["xyz"]) == len(to["xyz"]) == ref["train_samples"] > 1000
+    assert np.array_equal(gi.solution, ref["field"])
+    for k in ("xyz", "dir", "solution", "dir_pdf", "normal", "on_neumann"):
+        assert np.array_equal(ts[k], to[k]), k
+    for k in COUNTERS:
+        assert gi.last_stats[k] == ref[k], k
+    gi.close()
+
+
+@pytest.mark.gpu
+def test_gpu_trained_solve_matches_oracle_3d(orc):
+    """8 trained + 8 guided samples: every walk, record, batch, gradient and Adam step equal; training pixels every third
+    pixel from offset 1; and the harmonic check on the GPU field"""
+    sd = mixed_cube()
+    gi, ref = _gpu_and_oracle3(orc, sd, 36, 30, 16, 64, 8, stride=3, offset=1, batch=512, min_batch=128)
+    for k in COUNTERS + ("train_samples", "optimizer_steps"):
+        assert gi.last_stats[k] == ref[k], k
+    assert ref["optimizer_steps"] >= 8
+    assert np.array_equal(gi.solution, ref["field"]), float(np.abs(gi.solution - ref["field"]).max())
+    assert np.array_equal(gi.network.params(), ref["params"])
+    trunc = ref["walks_truncated"] / ref["walks_started"]
+    assert abs(float(gi.solution[:, 0].mean()) - 0.5) < 0.02 + 0.5 * trunc
+    # queryNetwork(Vector3f) = the inference weights at a world point (exec.cu:175-186 asks for (0, -0.21, 0))
+    raw = gi.queryNetwork((0.5, 0.29, 0.5))
+    assert raw.shape == (41,) and np.isfinite(raw).all()
+    gi.close()
+
+
+@pytest.mark.gpu
+def test_gpu_guided3_shards_and_refusals(orc):
+    """wost3_guided_solve_sharded: with a frozen network the shards' fields add up to the full frame; a source term and a
+    2-D shaped network are refused"""
+    import torch
+    from elaina_amd import capi
+    from elaina_amd.guided import GuidedIntegratorSettings
+    from elaina_amd.integrator3d import GuidedIntegrator3, Problem3
+    sd = mixed_cube()
+    p = _rand_params3(orc, _cfg(), seed=9, wscale=0.3, gscale=1.0)
+    st = GuidedIntegratorSettings(frameSize=(32, 24), samplesPerPixel=3, trainSppCount=0, maxWalkingDepth=32, epsilonShell=EPS)
+    gi = GuidedIntegrator3(Problem3.from_dict(sd), st, AABB3, network_config=_hip_cfg(_cfg()))
+    gi.network.set_params(p)
+    gi.solve()
+    full = gi.solution.copy()
+    total = torch.zeros(32 * 24 * 3, device="cuda")
+    for r in range(3):
+        buf = torch.zeros(32 * 24 * 3, device="cuda")
+        gi.solve_sharded(r, 3, buf.data_ptr())
+        torch.cuda.synchronize()
+        total += buf
+    assert np.array_equal(total.cpu().numpy().reshape(-1, 3), full)
+    gi.close()
+    with pytest.raises(capi.WostError):
+        GuidedIntegrator3(Problem3.from_dict(sd), st, AABB3, network_config=capi.NetConfig(4, 4, 8, 1.405, 64, 3, 33, 8e-3, 0.9, 0.99, 1e-15, 1e-6, 0.95))
+    src = dict(sd, source={"rgb": np.ones((3, 3, 3, 3), np.float32), "index_scale": (2.0, 2.0, 2.0), "index_offset": (0.0, 0.0, 0.0)})
+    with pytest.raises(capi.WostError):
+        GuidedIntegrator3(Problem3.from_dict(src), st, AABB3, network_config=_hip_cfg(_cfg()))
