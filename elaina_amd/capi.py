@@ -165,8 +165,8 @@ EXPORTS = [
     "wost_guided_create", "wost_guided_set_sync", "wost_guided_set_frame_callback", "wost_guided_network", "wost_guided_scene", "wost_guided_query_network", "wost_guided_solve", "wost_guided_solve_sharded", "wost_guided_train_set", "wost_guided_destroy",
     "wost3_create", "wost3_solve", "wost3_solve_sharded", "wost3_closest_point", "wost3_closest_silhouette", "wost3_ray_intersect",
     "wost3_render_sdf", "wost3_render_source", "wost3_destroy", "wost3_vmf_eval", "wost3_vmf_sample", "wost3_vmm_pdf_sample", "wost3_vmm_loss_gradients",
-    "wost_net_create3", "wost3_guided_create", "wost3_guided_destroy", "wost3_guided_network", "wost3_guided_solve", "wost3_guided_solve_sharded",
-    "wost3_guided_query_network", "wost3_guided_train_set",
+    "wost3_net_create", "wost3_guided_create", "wost3_guided_destroy", "wost3_guided_network", "wost3_guided_solve", "wost3_guided_solve_sharded",
+    "wost3_guided_query_network", "wost3_guided_train_set", "wost3_guided_scene",
     "wost_last_error", "wost_version",
 ]
 
@@ -244,11 +244,12 @@ def load():
     L.wost3_vmf_sample.argtypes = [C.c_int, fp, fp, u64p, C.c_int32, C.c_int32, fp]
     L.wost3_vmm_pdf_sample.argtypes = [C.c_int, fp, fp, u64p, C.c_int32, fp, fp]
     L.wost3_vmm_loss_gradients.argtypes = [C.c_int, fp, fp, fp, fp, C.POINTER(C.c_ubyte), fp, C.c_int32, C.c_float, fp, fp]
-    L.wost_net_create3.argtypes = [C.c_int, C.POINTER(NetConfig), C.c_uint64, C.POINTER(C.c_void_p)]
+    L.wost3_net_create.argtypes = [C.c_int, C.POINTER(NetConfig), C.c_uint64, C.POINTER(C.c_void_p)]
     L.wost3_guided_create.argtypes = [C.POINTER(Scene3Desc), C.POINTER(Guided3Settings), C.POINTER(NetConfig), C.c_uint64, C.c_int,
                                       C.POINTER(C.c_void_p)]
     L.wost3_guided_destroy.argtypes = [C.c_void_p]
     L.wost3_guided_network.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.wost3_guided_scene.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.wost3_guided_solve.argtypes = [C.c_void_p, fp, C.POINTER(GuidedStats)]
     L.wost3_guided_solve_sharded.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(GuidedStats)]
     L.wost3_guided_query_network.argtypes = [C.c_void_p, fp, C.c_int32, fp]

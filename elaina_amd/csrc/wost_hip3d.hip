@@ -2335,7 +2335,7 @@ int wost3_vmm_loss_gradients(int device, const float *raw, const float *dir, con
 //   g3_separate_kernel  closest triangle, epsilon-shell -> colour into the pixel and its training records; else closest
 //                       silhouette edge, star radius (no 0.99 here, :238-239), Neumann sample; the out-of-shell walkers are
 //                       compacted into a queue together with their normalised network inputs
-//   network inference   on the queue (the three-input network, wost_net_create3; scalar kernels)
+//   network inference   on the queue (the three-input network, wost3_net_create; scalar kernels)
 //   g3_sample_kernel    routing by the selection probability, direction from the vMF mixture or uniform with one-sample
 //                       MIS (reflection about the Neumann normal), the walker's ray, throughput, training record
 // and after every trained sample the ordered training set, the loss gradients (vmm3_loss_gradients_kernel) and the Adam
@@ -3004,7 +3004,7 @@ int wost3_guided_create(const wost3_scene_desc *scene, const wost3_guided_settin
     if (!g) { (void)wost3_destroy(sc); return set_error(WOST_ERR_NOMEM, "out of host memory"); }
     g->device = device; g->scene = sc; g->s = *s;
     g->host_rng = 0x853c49e6748fea9bULL ^ net_seed;
-    rc = wost_net_create3(device, net, net_seed, &g->net);
+    rc = wost3_net_create(device, net, net_seed, &g->net);
     if (rc != WOST_OK) { g3_free(g); return rc; }
     {
         // normalizeSpatialCoord (train.h:149-155): the box inflated by 0.5 % of its diagonal; Eigen norm() adds the squares in order
@@ -3044,6 +3044,13 @@ int wost3_guided_network(wost3_guided_handle h, wost_net_handle *net)
 {
     if (!h || !net) return set_error(WOST_ERR_INVALID, "null argument");
     *net = h->net;
+    return WOST_OK;
+}
+
+int wost3_guided_scene(wost3_guided_handle h, wost3_handle *scene)
+{
+    if (!h || !scene) return set_error(WOST_ERR_INVALID, "null argument");
+    *scene = h->scene;
     return WOST_OK;
 }
 

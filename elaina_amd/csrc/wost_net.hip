@@ -1725,7 +1725,7 @@ int wost_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_
     return net_create_dims(device, cfg, seed, 2, out);
 }
 
-int wost_net_create3(int device, const wost_net_config *cfg, uint64_t seed, wost_net_handle *out)
+int wost3_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_net_handle *out)
 {
     return net_create_dims(device, cfg, seed, 3, out);
 }

@@ -73,12 +73,12 @@ class GuidingNetwork:
     tiny-cuda-nn: inference() (:560,:597) and one training step (:655-662)."""
 
     def __init__(self, config=None, seed=1337, device=0, dims=2):
-        """dims = 3: the three-input network of GuidedIntegrator<3> (wost_net_create3)"""
+        """dims = 3: the three-input network of GuidedIntegrator<3> (wost3_net_create)"""
         self._lib = capi.load()
         self.config = config or default_net_config()
         self.dims = dims
         self._h = C.c_void_p()
-        create = self._lib.wost_net_create3 if dims == 3 else self._lib.wost_net_create
+        create = self._lib.wost3_net_create if dims == 3 else self._lib.wost_net_create
         _check(create(device, C.byref(self.config), seed, C.byref(self._h)), "wost_net_create")
         total, mlp = C.c_uint64(), C.c_uint64()
         _check(self._lib.wost_net_n_params(self._h, C.byref(total), C.byref(mlp)), "wost_net_n_params")

@@ -18,6 +18,7 @@ struct Vector2f { float x = 0, y = 0; };
 struct Vector2i { int x = 0, y = 0; };
 struct Vector3f { float x = 0, y = 0, z = 0; };
 struct AABB2f { Vector2f min, max; };
+struct AABB3f { Vector3f min, max; };
 
 // reference core/common.h:235-241
 enum class ExportImageChannel { DIRICHLET_SDF, NEUMANN_SDF, SOURCE, SOLUTION, CHANNEL_COUNT };

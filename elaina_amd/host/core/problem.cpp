@@ -251,8 +251,16 @@ SceneLoader3::SceneLoader3(const string &path)
 
 void Problem<3>::loadConfig(const json &config, const fs::path &search_dir)
 {
-    // reference core/problem.cu:152-181 with DIM == 3 (the aabb only serves the guided integrator)
+    // reference core/problem.cu:152-181 with DIM == 3 (the aabb only serves the guided integrator: optional here, required there)
     mpProbe = std::make_shared<SceneProbe>(json_get_or_throw<json>(config, "evaluation_grid"));
+    {
+        const auto amin = json_get_optional<std::vector<float>>(config, "aabb/min"), amax = json_get_optional<std::vector<float>>(config, "aabb/max");
+        if (amin && amax) {
+            if (amin->size() != 3 || amax->size() != 3) throw std::runtime_error("aabb/min and aabb/max must have 3 entries");
+            mAABB = AABB3f{{(*amin)[0], (*amin)[1], (*amin)[2]}, {(*amax)[0], (*amax)[1], (*amax)[2]}};
+            has_aabb = true;
+        }
+    }
     const json meshConfig = json_get_or_throw<json>(config, "mesh");
     if (const auto dp = json_get_optional<string>(meshConfig, "dirichlet_path")) {
         scene_dirichlet_loader = std::make_unique<SceneLoader3>(resolve(*dp, search_dir));

@@ -94,6 +94,8 @@ public:
     bool isNeumannEnabled() const { return enable_neumann; }
     bool isSourceEnabled() const { return enable_source; }
     const SceneProbe &getProbe() const { return *mpProbe; }
+    const AABB3f &getAABB() const { return mAABB; }      // scene.aabb, three components (the guided integrator's box)
+    bool hasAABB() const { return has_aabb; }
     const ProblemStatistics &get_problem_stat() const { return scene_stat; }
     float get_source_intensity() const { return source_intensity; }
     // dense source grid [nz][ny][nx][3] (stands in for the reference's nanovdb grid, core/problem.cu:136-149):
@@ -107,6 +109,8 @@ public:
 
 private:
     std::shared_ptr<SceneProbe> mpProbe;
+    AABB3f mAABB;
+    bool has_aabb{false};
     std::unique_ptr<SceneLoader3> scene_dirichlet_loader, scene_neumann_loader;
     std::vector<float> vertex_color_dirichlet, vertex_color_neumann;
     bool enable_dirichlet{false}, enable_neumann{false}, enable_source{false};

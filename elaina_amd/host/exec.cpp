@@ -10,6 +10,7 @@
 #include <ctime>
 #include <fstream>
 #include <set>
+#include <type_traits>
 
 #include "core/problem.h"
 #include "integrator/guided/integrator.h"
@@ -51,7 +52,9 @@ static void run_channels(Integrator &obj, const json &conf_json, const json &int
     }
     if (json_get_optional<bool>(conf_json, "print_network", false)) {
         try {
-            obj.queryNetwork(typename Integrator::VectorType{});
+            // exec.cu:175-186: the 3-D run asks for the mixture at (0, -0.21, 0), the 2-D run at the origin
+            if constexpr (std::is_same_v<typename Integrator::VectorType, Vector3f>) obj.queryNetwork(Vector3f{0.0f, -0.21f, 0.0f});
+            else obj.queryNetwork(typename Integrator::VectorType{});
         } catch (const std::exception &e) {
             ELAINA_LOG(Warning, "print_network: %s", e.what());
         }
@@ -104,18 +107,32 @@ void run_expr(fs::path conf_path)
     const string integrator_type = json_get_or_throw<string>(integrator_section, "type");
     const json integrator_setting = json_get_or_throw<json>(integrator_section, "setting");
     if (dimensionality == 3) {
-        if (integrator_type != "uniform") {
-            ELAINA_LOG(Error, "Unrecognized integrator type (3-D: uniform only in this build).");
-            exit(1);
-        }
+        // exec.cu:102-122: the same two integrator types on Problem<3>
         Problem<3> scene3;
         scene3.loadConfig(scene_section, conf_path.parent_path());
-        UniformIntegrator<3> obj(scene3, UniformIntegratorSettings::from_json(integrator_setting), outDir);
-        run_channels(obj, conf_json, integrator_section, result_json);
-        const wost_stats &s = obj.get_last_stats();
-        if (s.walk_steps) {
-            result_json["walk_steps"] = json((uint64_t)s.walk_steps);
-            result_json["walk_steps_per_second"] = json(s.solve_ms > 0 ? (double)s.walk_steps / (s.solve_ms * 1e-3) : 0.0);
+        if (integrator_type == "uniform") {
+            UniformIntegrator<3> obj(scene3, UniformIntegratorSettings::from_json(integrator_setting), outDir);
+            run_channels(obj, conf_json, integrator_section, result_json);
+            const wost_stats &s = obj.get_last_stats();
+            if (s.walk_steps) {
+                result_json["walk_steps"] = json((uint64_t)s.walk_steps);
+                result_json["walk_steps_per_second"] = json(s.solve_ms > 0 ? (double)s.walk_steps / (s.solve_ms * 1e-3) : 0.0);
+            }
+        } else if (integrator_type == "guided") {
+            const json network_section = json_get_or_throw<json>(conf_json, "network");
+            GuidedIntegrator<3> obj(scene3, GuidedIntegratorSettings::from_json(integrator_setting), outDir);
+            obj.resetNetwork(network_section);
+            run_channels(obj, conf_json, integrator_section, result_json);
+            const wost_guided_stats &s = obj.get_last_stats();
+            if (s.walk_steps) {
+                result_json["walk_steps"] = json((uint64_t)s.walk_steps);
+                result_json["guided_steps"] = json((uint64_t)s.guided_steps);
+                result_json["optimizer_steps"] = json((uint64_t)s.optimizer_steps);
+                result_json["walk_steps_per_second"] = json(s.solve_ms > 0 ? (double)s.walk_steps / (s.solve_ms * 1e-3) : 0.0);
+            }
+        } else {
+            ELAINA_LOG(Error, "Unrecognized integrator type.");
+            exit(1);
         }
         result_json["timestamp"] = json(get_current_time());
         std::ofstream resultFile(outDir / "result.json");

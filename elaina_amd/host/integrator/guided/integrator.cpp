@@ -167,4 +167,99 @@ void GuidedIntegrator<2>::queryNetwork(const VectorType &p)
     ELAINA_LOG(Info, "  selection probability %.4f", 1.0f / (1.0f + std::exp(-raw[32])));
 }
 
+// ---- GuidedIntegrator<3> ---------------------------------------------------------------------------------------------
+GuidedIntegrator<3>::GuidedIntegrator(Problem<3> &problem_, const IntegratorSettings &settings, const fs::path &basePath_, int device_)
+    : IntegratorOutputs(settings.frameSize, basePath_), problem(problem_), integratorSettings(settings), device(device_)
+{
+}
+
+GuidedIntegrator<3>::~GuidedIntegrator()
+{
+    if (handle) wost3_guided_destroy(handle);
+}
+
+void GuidedIntegrator<3>::resetNetwork(const json &config)
+{
+    if (handle) {
+        wost3_guided_destroy(handle);
+        handle = nullptr;
+    }
+    if (!problem.hasAABB()) throw std::runtime_error("scene.aabb (min / max with three entries) is required by the guided integrator");
+    const IntegratorSettings &s = integratorSettings;
+    wost_net_config nc = network_config_from_json(config);
+    nc.n_output = 41;       // 8 lobes x (lambda, kappa, mean vector) + selection logit (guided/parameters.h:26-33)
+    const wost3_scene_desc sd = problem.scene_desc(s.frameSize.x, s.frameSize.y);
+    wost3_guided_settings gs{};
+    gs.width = s.frameSize.x; gs.height = s.frameSize.y; gs.spp = s.samplesPerPixel; gs.max_depth = (int32_t)s.maxWalkingDepth;
+    gs.eps_shell = s.epsilonShell;
+    gs.train_spp_count = (int32_t)s.trainSppCount;
+    gs.uniform_fraction_training = s.uniformFractionInTrainingPhase;
+    gs.uniform_fraction_guiding = s.uniformFractionInGuidingPhase;
+    gs.max_guided_depth_training = (int32_t)s.maxGuidedDepthInTrainingPhase;
+    gs.max_guided_depth_guiding = (int32_t)s.maxGuidedDepthInGuidingPhase;
+    const AABB3f &b = problem.getAABB();
+    gs.aabb_min[0] = b.min.x; gs.aabb_min[1] = b.min.y; gs.aabb_min[2] = b.min.z;
+    gs.aabb_max[0] = b.max.x; gs.aabb_max[1] = b.max.y; gs.aabb_max[2] = b.max.z;
+    gs.max_train_depth = 3; gs.batch_size = 65536 * 8; gs.min_batch_size = 65536; gs.batches_per_spp = 5;
+    gs.train_pixel_stride = 1; gs.train_pixel_offset = -1; gs.loss_scale = 128.0f;
+    check_wost(wost3_guided_create(&sd, &gs, &nc, /* ELAINA_DEFAULT_RNG_SEED */ 42, device, &handle), "wost3_guided_create");
+}
+
+wost3_handle GuidedIntegrator<3>::scene_handle()
+{
+    if (!handle) throw std::runtime_error("GuidedIntegrator: resetNetwork() has not been called");
+    wost3_handle scene = nullptr;
+    check_wost(wost3_guided_scene(handle, &scene), "wost3_guided_scene");
+    return scene;
+}
+
+uint64_t GuidedIntegrator<3>::solve()
+{
+    if (!handle) throw std::runtime_error("GuidedIntegrator: resetNetwork() has not been called");
+    const auto start = std::chrono::high_resolution_clock::now();
+    std::vector<float> &f = channels[(size_t)ExportImageChannel::SOLUTION];
+    f.assign((size_t)frameSize_.x * frameSize_.y * 3, 0.0f);
+    check_wost(wost3_guided_solve(handle, f.data(), &last_stats), "wost3_guided_solve");
+    return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - start).count();
+}
+
+void GuidedIntegrator<3>::renderDirichletSDF()
+{
+    std::vector<float> d((size_t)frameSize_.x * frameSize_.y);
+    check_wost(wost3_render_sdf(scene_handle(), WOST_MESH_DIRICHLET, d.data()), "wost3_render_sdf");
+    set_gray_channel(ExportImageChannel::DIRICHLET_SDF, d);
+}
+
+void GuidedIntegrator<3>::renderSilhouetteSDF()
+{
+    std::vector<float> d((size_t)frameSize_.x * frameSize_.y);
+    check_wost(wost3_render_sdf(scene_handle(), WOST_MESH_NEUMANN, d.data()), "wost3_render_sdf");
+    set_gray_channel(ExportImageChannel::NEUMANN_SDF, d);
+}
+
+void GuidedIntegrator<3>::renderSource()
+{
+    std::vector<float> &c = channels[(size_t)ExportImageChannel::SOURCE];
+    c.assign((size_t)frameSize_.x * frameSize_.y * 3, 0.0f);
+    check_wost(wost3_render_source(scene_handle(), c.data()), "wost3_render_source");
+}
+
+void GuidedIntegrator<3>::queryNetwork(const VectorType &p)
+{
+    if (!handle) throw std::runtime_error("GuidedIntegrator: resetNetwork() has not been called");
+    float raw[41];
+    const float xyz[3] = {p.x, p.y, p.z};
+    check_wost(wost3_guided_query_network(handle, xyz, 1, raw), "wost3_guided_query_network");
+    ELAINA_LOG(Info, "VMM @ (%f, %f, %f): ", p.x, p.y, p.z);
+    float total = 0.0f;
+    float lambda[8];
+    for (int k = 0; k < 8; ++k) total += lambda[k] = std::exp(std::fmin(std::fmax(raw[5 * k], -10.0f), 15.0f));
+    for (int k = 0; k < 8; ++k) {
+        const float nn = std::sqrt(raw[5 * k + 2] * raw[5 * k + 2] + raw[5 * k + 3] * raw[5 * k + 3] + raw[5 * k + 4] * raw[5 * k + 4]);
+        ELAINA_LOG(Info, "  lobe %d: weight %.4f kappa %.4f mu (%.4f, %.4f, %.4f)", k, lambda[k] / total,
+                   std::exp(std::fmin(std::fmax(raw[5 * k + 1], -10.0f), 15.0f)), raw[5 * k + 2] / nn, raw[5 * k + 3] / nn, raw[5 * k + 4] / nn);
+    }
+    ELAINA_LOG(Info, "  selection probability %.4f", 1.0f / (1.0f + std::exp(-raw[40])));
+}
+
 }  // namespace elaina

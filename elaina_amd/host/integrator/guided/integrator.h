@@ -67,4 +67,34 @@ private:
     wost_guided_stats last_stats{};
 };
 
+// GuidedIntegrator<3> (reference integrator/guided/integrator.h:77-256 with DIM = 3, dispatched by exec.cu:102-122): the same
+// surface on Problem<3>; 41 network outputs (guided/parameters.h:26-33), queryNetwork(Vector3f) (exec.cu:175-186).
+template <> class GuidedIntegrator<3> : public IntegratorOutputs {
+public:
+    using IntegratorSettings = GuidedIntegratorSettings;
+    using VectorType = Vector3f;
+    using ProblemType = Problem<3>;
+
+    GuidedIntegrator(Problem<3> &problem, const IntegratorSettings &settings, const fs::path &basePath_, int device = 0);
+    ~GuidedIntegrator();
+    GuidedIntegrator(const GuidedIntegrator &) = delete;
+    GuidedIntegrator &operator=(const GuidedIntegrator &) = delete;
+
+    void resetNetwork(const json &config);
+    uint64_t solve();
+    void renderDirichletSDF();
+    void renderSilhouetteSDF();
+    void renderSource();
+    void queryNetwork(const VectorType &p);
+    const wost_guided_stats &get_last_stats() const { return last_stats; }
+
+private:
+    wost3_handle scene_handle();
+    Problem<3> &problem;
+    IntegratorSettings integratorSettings;
+    int device;
+    wost3_guided_handle handle{nullptr};
+    wost_guided_stats last_stats{};
+};
+
 }  // namespace elaina

@@ -419,10 +419,10 @@ int wost3_destroy(wost3_handle h);
  * branches of integrator/guided/integrator.cu (:181-215 triangle side / barycentric uv, :347 three Neumann draws, :508-511,
  * :690-693, :800-803 VMM<3,8> and the reflection about the Neumann normal), guided/parameters.h:26-33 (3 network inputs,
  * 8 x (lambda, kappa, mean vector) + selection logit = 41 outputs padded to 48), train.h:289-353 (3-D records) -- on the
- * scene types of the 3-D uniform integrator above.  The network is the one of wost_net_create3: the DenseGrid encoding
+ * scene types of the 3-D uniform integrator above.  The network is the one of wost3_net_create: the DenseGrid encoding
  * with three inputs (trilinear, res^3 entries per level), otherwise the configuration of data/ladybug/n.json:49-81; fp32.
  * Scenes with a source term are refused (WOST_ERR_UNSUPPORTED). */
-int wost_net_create3(int device, const wost_net_config *cfg, uint64_t seed, wost_net_handle *out);   /* inputs: 3 floats per point */
+int wost3_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_net_handle *out);   /* inputs: 3 floats per point */
 typedef struct wost3_guided_settings {
     int32_t width, height, spp, max_depth;
     float eps_shell;
@@ -439,6 +439,7 @@ int wost3_guided_create(const wost3_scene_desc *scene, const wost3_guided_settin
                         uint64_t net_seed, int device, wost3_guided_handle *out);
 int wost3_guided_destroy(wost3_guided_handle h);
 int wost3_guided_network(wost3_guided_handle h, wost_net_handle *net);            /* borrowed: owned by the integrator */
+int wost3_guided_scene(wost3_guided_handle h, wost3_handle *scene);               /* borrowed: for the SDF / source channels */
 /* solve() (integrator.cu:1189-1195): field_rgb = width*height*3 floats on the host / in device memory (tile shard as in
  * wost3_solve_sharded, every shard its own network) */
 int wost3_guided_solve(wost3_guided_handle h, float *field_rgb, wost_guided_stats *stats);

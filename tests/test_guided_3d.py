@@ -2,7 +2,7 @@
 
 CPU part: the three-input network of the oracle (oracle/wost_net.c wo_net3_*) against finite differences and a numpy
 restatement of the trilinear encoding; the guided 3-D solve of the oracle (wost_oracle3d.c wo3_solve_guided) -- deterministic,
-unbiased against an analytic harmonic solution.  GPU part: the HIP integrator (wost3_guided_*, wost_net_create3) through the
+unbiased against an analytic harmonic solution.  GPU part: the HIP integrator (wost3_guided_*, wost3_net_create) through the
 C-ABI against the oracle, bit for bit: network, frozen-network walks, first-pass records, a whole trained solve.
 PARITY UNPINNED w.r.t. tiny-cuda-nn and snch-lbvh (submodules absent), like the 2-D path."""
 import numpy as np

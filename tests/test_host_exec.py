@@ -421,8 +421,7 @@ def test_run_expr_spp_metric_frames(tmp_path, oracle, ladybug):
 @pytest.mark.gpu
 def test_run_expr_three_dimensional_configuration(tmp_path, oracle):
     """"dimensionality": 3 through the C++ host (reference exec.cu:102-122): OBJ triangles + colour files ->
-    Problem<3> -> UniformIntegrator<3> -> raw field, against the oracle; the guided type is refused like an
-    unknown integrator"""
+    Problem<3> -> UniformIntegrator<3> -> raw field, against the oracle; an unknown integrator type is refused"""
     import export_scene
     from conftest import cube_scene3
     sd = cube_scene3(n=2, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x + z, flux=lambda x, y, z, f: 0.0)
@@ -438,7 +437,7 @@ def test_run_expr_three_dimensional_configuration(tmp_path, oracle):
     assert np.array_equal(export_scene.read_pfm(exp / "dirichlet_sdf.pfm")[:, 0], oracle.render_sdf3(sd, 24, 16, 0))
     assert np.array_equal(export_scene.read_pfm(exp / "neumann_sdf.pfm")[:, 0], oracle.render_sdf3(sd, 24, 16, 1))
     cj = json.load(open(conf))
-    cj["integrator"]["type"] = "guided"
+    cj["integrator"]["type"] = "nonesuch"
     json.dump(cj, open(conf, "w"))
     out = subprocess.run([_exe(), conf], capture_output=True, text=True)
     assert out.returncode == 1 and "integrator type" in out.stderr
@@ -454,3 +453,48 @@ def test_run_expr_three_dimensional_configuration(tmp_path, oracle):
     plain = oracle.solve3({k: v for k, v in sd.items() if k != "source"}, 16, 16, 5, 48, 2e-3, threads=4)["field"]
     assert np.mean(got[:, 0] - plain[:, 0]) > 0.01          # f > 0 raises the solution
     assert np.array_equal(export_scene.read_pfm(tmp_path / "poisson" / "exp" / "scene3d" / "source.pfm"), oracle.render_source3(sd, 16, 16))
+
+
+@pytest.mark.gpu
+def test_run_expr_three_dimensional_guided_configuration(tmp_path, oracle):
+    """"dimensionality": 3 with "type": "guided" through the C++ host (reference exec.cu:102-122 dispatches GuidedIntegrator<3>;
+    :175-186 print_network asks for the mixture at (0, -0.21, 0)): the network section, scene.aabb with three entries, the
+    reference's training constants (one Adam step needs 65 536 records) -- field, counters and optimizer steps against the oracle"""
+    import export_scene
+    from conftest import cube_scene3
+    from oracle.oracle import default_net_config3, guided_settings3
+    sd = cube_scene3(n=2, d_faces=(4, 5), n_faces=(0, 1, 2, 3), value=lambda x, y, z: z, flux=lambda x, y, z, f: 0.0)
+    w, h, spp, train, depth, eps = 176, 160, 3, 2, 32, 2e-3
+    conf = export_scene.export3(sd, str(tmp_path), frame=(w, h), spp=spp, depth=depth, eps=eps)
+    cj = json.load(open(conf))
+    cj["integrator"]["type"] = "guided"
+    cj["integrator"]["setting"].update({"trainSppCount": train, "uniformFractionInTrainingPhase": 0.5, "uniformFractionInGuidingPhase": 0.5,
+                                        "maxGuidedDepthInTrainingPhase": 10, "maxGuidedDepthInGuidingPhase": 10})
+    cj["scene"]["aabb"] = {"min": [-0.1, -0.1, -0.1], "max": [1.1, 1.1, 1.1]}
+    net = dict(export_scene.NETWORK_SECTION)
+    net["encoding"] = dict(net["encoding"], n_levels=4)          # a small dense grid (four levels), the same code path
+    cj["network"] = net
+    cj["print_network"] = True
+    json.dump(cj, open(conf, "w"))
+    out = subprocess.run([_exe(), conf], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "VMM @ (0.000000, -0.210000, 0.000000)" in out.stdout + out.stderr
+    exp = tmp_path / "exp" / "scene3d"
+    res = json.load(open(exp / "result.json"))
+    # the oracle from the network the library initialises (seed 42): read it through the Python mirror
+    from elaina_amd.guided import GuidedIntegratorSettings
+    from elaina_amd.integrator3d import GuidedIntegrator3, Problem3, default_net_config3 as hip_cfg3
+    st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=train, maxWalkingDepth=depth, epsilonShell=eps)
+    gi = GuidedIntegrator3(Problem3.from_dict(sd), st, ((-0.1, -0.1, -0.1), (1.1, 1.1, 1.1)), network_config=hip_cfg3(n_levels=4), seed=42)
+    p0 = gi.network.params()
+    gi.close()
+    gs = guided_settings3(w, h, spp, depth, eps, (-0.1, -0.1, -0.1), (1.1, 1.1, 1.1), train_spp_count=train)
+    ref = oracle.solve_guided3(sd, gs, default_net_config3(n_levels=4), p0.copy(), threads=os.cpu_count())
+    assert res["walk_steps"] == ref["walk_steps"] and res["guided_steps"] == ref["guided_steps"] > 0
+    assert res["optimizer_steps"] == ref["optimizer_steps"] >= 1
+    assert np.array_equal(export_scene.read_pfm(exp / "solution.pfm"), ref["field"])
+    # without scene.aabb the guided integrator cannot be built
+    del cj["scene"]["aabb"]
+    json.dump(cj, open(conf, "w"))
+    out = subprocess.run([_exe(), conf], capture_output=True, text=True)
+    assert out.returncode == 1 and "aabb" in out.stderr
