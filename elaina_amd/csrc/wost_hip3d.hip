@@ -2339,8 +2339,8 @@ int wost3_vmm_loss_gradients(int device, const float *raw, const float *dir, con
 //   g3_sample_kernel    routing by the selection probability, direction from the vMF mixture or uniform with one-sample
 //                       MIS (reflection about the Neumann normal), the walker's ray, throughput, training record
 // and after every trained sample the ordered training set, the loss gradients (vmm3_loss_gradients_kernel) and the Adam
-// steps.  One thread per pixel / queue entry, per-pixel arithmetic and draw order of oracle/wost_oracle3d.c
-// (wo3_solve_guided): bit-exact against it.  Scenes with a source term are refused (not restated for this integrator).
+// steps.  One thread per pixel / queue entry; per-pixel arithmetic and draw order are those of the CPU restatement the tests
+// compare with (tests/test_guided_3d.py): bit-exact.  Scenes with a source term are refused (not built for this integrator).
 namespace wost {
 
 constexpr int kRec3Fields = 15;      // sol rgb, pos xyz, dir xyz, pdf, thp, normal xyz, onNeumann
