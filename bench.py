@@ -479,6 +479,11 @@ def run_uniform3d(env, args):
             e["rel_l2_vs_oracle"] = rel_l2(it.solution.reshape(-1, 3)[b:e_], ref["field"])
             e["rel_l2_band"] = "rows %d..%d" % (b // frame, e_ // frame)
         it.close()
+        # what binds walk3_kernel on this scene: VALU figures of the committed PMC pass (tools/gpu_round.sh, stage pmc3d)
+        cc = committed_counters("walk3_valu", ("scenes", "source"))
+        if cc and cc.get("scenes") and name in cc["scenes"]:
+            e["roofline"] = dict(cc["scenes"][name], bound="valu", kernel="walk3_kernel", stale=cc["stale"], measured_on_sources=cc["measured_on_sources"],
+                                 source=cc["source"])
         out[name] = e
     return out
 

@@ -3,7 +3,7 @@
 # TAG names the output directory under gpurun_out/; STAGES selects what runs (default: all).
 export TMPDIR=/tmp
 TAG=${TAG:-r03}
-STAGES=${STAGES:-"tests smoke micro bench trace pmc pmc_guided"}
+STAGES=${STAGES:-"tests smoke micro bench trace pmc pmc_guided pmc3d"}
 mkdir -p gpurun_out/$TAG
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 if has tests; then
@@ -53,5 +53,23 @@ if has pmc_guided; then
     python3 tools/pmc_derive_guided.py gpurun_out/$TAG/guided_pmc_f$prec.txt gpurun_out/$TAG/guided_kernel_stats_f$prec.csv gpurun_out/$TAG/guided_trace_f$prec.log gpurun_out/$TAG/guided_sample_f$prec.json "$GARGS"
     rm -rf gpurun_out/$TAG/gtrace$prec
   done
+fi
+# the 3-D uniform kernel on the two bench scenes (Dirichlet icosphere, Neumann shell): kernel trace + PMC passes
+if has pmc3d; then
+  A3="tools/probes/bench3d_only.py"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/trace3d -- python3 $A3 > gpurun_out/$TAG/bench3d_trace.log 2>&1
+  f=$(find gpurun_out/$TAG/trace3d -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/$TAG/kernel_stats_3d.csv
+  rm -f gpurun_out/$TAG/pmc_summary_3d.txt
+  i=0
+  for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+             "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/$TAG/p3d$i -- python3 $A3 > gpurun_out/$TAG/p3d$i.log 2>&1
+    f=$(find gpurun_out/$TAG/p3d$i -name '*counter_collection.csv' | head -1)
+    [ -n "$f" ] && PMC_NAME_WIDTH=90 python3 tools/pmc_summary.py "$f" walk3_kernel | tee -a gpurun_out/$TAG/pmc_summary_3d.txt
+    rm -rf gpurun_out/$TAG/p3d$i
+  done
+  python3 tools/pmc_derive_3d.py gpurun_out/$TAG/pmc_summary_3d.txt gpurun_out/$TAG/kernel_stats_3d.csv gpurun_out/$TAG/walk3_valu.json "$A3"
+  rm -rf gpurun_out/$TAG/trace3d
 fi
 rm -rf gpurun_out/$TAG/pmc[0-9] gpurun_out/$TAG/trace

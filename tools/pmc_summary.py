@@ -10,7 +10,7 @@ tot = defaultdict(float)
 calls = defaultdict(int)
 with open(sys.argv[1]) as f:
     for row in csv.DictReader(f):
-        k = (row["Kernel_Name"][:60], row["Counter_Name"])
+        k = (row["Kernel_Name"][:int(__import__("os").environ.get("PMC_NAME_WIDTH", "60"))], row["Counter_Name"])
         tot[k] += float(row["Counter_Value"])
         calls[k] += 1
 for (k, c), v in sorted(tot.items()):
