@@ -623,6 +623,254 @@ __device__ __forceinline__ bool ray3_tree(const DevMesh3 &m, V3 o, V3 d, float t
     return Q.hit;
 }
 
+// ---- the same two queries answered by a whole WAVE for all its walkers together ------------------------------------------
+// Inside a step every lane used to run its own query to completion (closest_silhouette3_tree, ray3_tree): a wave lasts as long
+// as its longest query, and a leaf visit -- twelve edge records, or four triangles, behind per-lane skips -- is executed for
+// the whole wave whenever one lane needs it: 9 % of the vector lanes did work on a 1280-triangle shell (profiles/walk3_valu.json),
+// and a frame of 512^2 walkers cannot be cut into stage queues across the chip either (it has fewer walkers than the chip has
+// lanes: every query would still sit alone in its lane).  Here the work of all walkers of the wave goes through two pools of
+// tasks in LDS -- (owner lane, tree node) and (owner lane, leaf slot) -- and every trip runs ONE body on up to 64 tasks, whoever
+// owns them: a node task measures the four children (and their normal cones) against its owner's bound and pushes those that
+// survive, farthest first, so that the next trip takes every task's nearest child off the top (a 64-wide depth-first descent);
+// a slot task tests the three edge records (or the triangle) of one leaf slot and folds the result into its owner's words
+// with LDS atomics.  Both queries are minima -- over silhouette edges within rmax, over (t, original index) of the hits -- so
+// the order in which candidates are met does not matter and the answer is that of the flat loop, bit for bit; a bound that is
+// tightened later than the serial descent would have (tasks carry no distance and are not re-checked when popped) only costs
+// visits.  The pools are bounded: a trip takes only as many node tasks as leave room for all their children, and a wave that
+// cannot take any (pool full of inner nodes: never seen) answers its queries the old way.
+struct WavePool3 {
+    uint32_t *node, *slot;      // [cap] owner lane << 26 | node index / leaf slot
+    uint32_t *own;              // [10][64] per-owner operands and results
+    int cap;
+};
+constexpr uint32_t kPool3Index = (1u << 26) - 1u;
+constexpr int kPool3OwnerWords = 10 * 64;
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // LDS instructions of one wave execute in order: only the compiler has to keep the order
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void pool3_push(uint32_t *pool, int &n, bool valid, uint32_t value, int lane)
+{
+    const unsigned long long mask = __ballot(valid);
+    if (valid) pool[n + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+    n += __popcll(mask);
+}
+
+__device__ __forceinline__ void node3_level_pos(uint32_t g, int &level, int &pos)
+{
+    level = (31 - __clz((int)(3u * g + 1u))) >> 1;
+    pos = (int)(g - level_first(level));
+}
+
+// closest silhouette edge within rmax of q, for every lane with `active` (all 64 lanes must call)
+__device__ __forceinline__ float closest_silhouette3_wave(const DevMesh3 &m, V3 q, float rmax, bool active, const WavePool3 &W, const LdsColumn &stk)
+{
+    const int lane = threadIdx.x & 63;
+    float *oq = reinterpret_cast<float *>(W.own);                 // x [0, 64), y [64, 128), z [128, 192)
+    uint32_t *obest = W.own + 192, *ofound = W.own + 256;         // the flat loop's best2 (bits) and `found`
+    if (active) {
+        oq[lane] = q.x; oq[64 + lane] = q.y; oq[128 + lane] = q.z;
+        obest[lane] = __float_as_uint(rmax * rmax);
+        ofound[lane] = 0u;
+    }
+    int n_node = 0, n_slot = 0;
+    pool3_push(W.node, n_node, active, (uint32_t)lane << 26, lane);        // the roots
+    bool overflow = false;
+    wave_lds_fence();
+    while (n_node > 0 || n_slot > 0) {
+        if (n_slot >= 64 || n_node == 0) {
+            const int k = min(64, n_slot);
+            n_slot -= k;
+            if (lane < k) {
+                const uint32_t e = W.slot[n_slot + lane];
+                const int owner = (int)(e >> 26);
+                const V3 oqv = v3(oq[owner], oq[64 + owner], oq[128 + owner]);
+                const float b0 = __uint_as_float(obest[owner]);
+                const bool f0 = ofound[owner] != 0u;
+                float b = b0;
+                bool f = f0;
+                const float4 *rec = m.slotEdges + 12 * (size_t)(e & kPool3Index);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) silhouette_record_test(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3], oqv, b, f);
+                if (f && (b < b0 || !f0)) {
+                    atomicMin(&obest[owner], __float_as_uint(b));
+                    ofound[owner] = 1u;
+                }
+            }
+        } else {
+            const int k = min(min(64, n_node), (W.cap - n_node) / 3);
+            if (k <= 0 || n_slot + 4 * k > W.cap) {
+                overflow = true;
+                break;
+            }
+            n_node -= k;
+            const bool t = lane < k;
+            const uint32_t e = t ? W.node[n_node + lane] : 0u;
+            wave_lds_fence();        // the tasks are read before the pushes below overwrite them
+            const uint32_t own_bits = e & ~kPool3Index;
+            bool leaf = false, v0 = false, v1 = false, v2 = false, v3_ = false;
+            uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
+            uint32_t child0 = 0;     // the first child: node index (inner) or leaf slot
+            if (t) {
+                const uint32_t g = e & kPool3Index;
+                const int owner = (int)(e >> 26);
+                int level, pos;
+                node3_level_pos(g, level, pos);
+                const V3 oqv = v3(oq[owner], oq[64 + owner], oq[128 + owner]);
+                const float bd = __uint_as_float(obest[owner]) * kSlack3;
+                const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+                const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
+                const float d0 = aabb_d2(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, oqv), d1 = aabb_d2(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, oqv);
+                const float d2 = aabb_d2(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, oqv), d3 = aabb_d2(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, oqv);
+                leaf = level == m.levels;
+                if (leaf) {
+                    child0 = 4u * (uint32_t)pos;
+                    v0 = !(d0 > bd); v1 = !(d1 > bd); v2 = !(d2 > bd); v3_ = !(d3 > bd);
+                } else {
+                    child0 = level_first(level + 1) + 4u * (uint32_t)pos;
+                    const float4 *cn = m.cones + 6 * (size_t)g;
+                    const float4 AX = cn[0], AY = cn[1], AZ = cn[2], CH = cn[3], SH = cn[4], RD = cn[5];
+                    const bool c0 = d0 <= bd && cone3_may_hold_silhouette(AX.x, AY.x, AZ.x, CH.x, SH.x, RD.x, v3(0.5f * (LX.x + HX.x), 0.5f * (LY.x + HY.x), 0.5f * (LZ.x + HZ.x)), oqv);
+                    const bool c1 = d1 <= bd && cone3_may_hold_silhouette(AX.y, AY.y, AZ.y, CH.y, SH.y, RD.y, v3(0.5f * (LX.y + HX.y), 0.5f * (LY.y + HY.y), 0.5f * (LZ.y + HZ.y)), oqv);
+                    const bool c2 = d2 <= bd && cone3_may_hold_silhouette(AX.z, AY.z, AZ.z, CH.z, SH.z, RD.z, v3(0.5f * (LX.z + HX.z), 0.5f * (LY.z + HY.z), 0.5f * (LZ.z + HZ.z)), oqv);
+                    const bool c3 = d3 <= bd && cone3_may_hold_silhouette(AX.w, AY.w, AZ.w, CH.w, SH.w, RD.w, v3(0.5f * (LX.w + HX.w), 0.5f * (LY.w + HY.w), 0.5f * (LZ.w + HZ.w)), oqv);
+                    k0 = c0 ? ((__float_as_uint(d0) & ~0x3u) | 0u) : 0xffffffffu;
+                    k1 = c1 ? ((__float_as_uint(d1) & ~0x3u) | 1u) : 0xffffffffu;
+                    k2 = c2 ? ((__float_as_uint(d2) & ~0x3u) | 2u) : 0xffffffffu;
+                    k3 = c3 ? ((__float_as_uint(d3) & ~0x3u) | 3u) : 0xffffffffu;
+                    cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
+                }
+            }
+            // a leaf's triangles whose box is within the bound become slot tasks ...
+            pool3_push(W.slot, n_slot, leaf && v0, own_bits | (child0 + 0u), lane);
+            pool3_push(W.slot, n_slot, leaf && v1, own_bits | (child0 + 1u), lane);
+            pool3_push(W.slot, n_slot, leaf && v2, own_bits | (child0 + 2u), lane);
+            pool3_push(W.slot, n_slot, leaf && v3_, own_bits | (child0 + 3u), lane);
+            // ... an inner node's children node tasks, the farthest first: every task's nearest child ends up in the top 64
+            pool3_push(W.node, n_node, k3 != 0xffffffffu, own_bits | (child0 + (k3 & 3u)), lane);
+            pool3_push(W.node, n_node, k2 != 0xffffffffu, own_bits | (child0 + (k2 & 3u)), lane);
+            pool3_push(W.node, n_node, k1 != 0xffffffffu, own_bits | (child0 + (k1 & 3u)), lane);
+            pool3_push(W.node, n_node, k0 != 0xffffffffu, own_bits | (child0 + (k0 & 3u)), lane);
+        }
+        wave_lds_fence();
+    }
+    float r = WOST_INF;
+    if (overflow) {
+        if (active) r = closest_silhouette3_tree(m, q, rmax, stk);
+    } else if (active && ofound[lane] != 0u) {
+        r = sqrtf(__uint_as_float(obest[lane]));
+    }
+    wave_lds_fence();
+    return r;
+}
+
+// the walker's ray: closest hit (smallest t, lowest original index among equal ones) for every lane with `active`
+__device__ __forceinline__ bool ray_closest3_wave(const DevMesh3 &m, V3 o, V3 d, float tmax, bool active, float &t_out, int &idx_out, const WavePool3 &W,
+                                                  const LdsColumn &stk, int slot_trigger)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long *okey = reinterpret_cast<unsigned long long *>(W.own);     // [64]: bits(|t|) << 32 | original index
+    float *of = reinterpret_cast<float *>(W.own) + 128;                            // o.xyz, d.xyz, tmax: 7 x [64]
+    uint32_t *obound = W.own + 128 + 7 * 64;                                       // the pruning bound (bits)
+    if (active) {
+        okey[lane] = ~0ull;
+        of[lane] = o.x; of[64 + lane] = o.y; of[128 + lane] = o.z;
+        of[192 + lane] = d.x; of[256 + lane] = d.y; of[320 + lane] = d.z;
+        of[384 + lane] = tmax;
+        obound[lane] = __float_as_uint(tmax * 1.00001f + 1e-30f);
+    }
+    int n_node = 0, n_slot = 0;
+    pool3_push(W.node, n_node, active, (uint32_t)lane << 26, lane);
+    bool overflow = false;
+    wave_lds_fence();
+    while (n_node > 0 || n_slot > 0) {
+        if (n_slot >= slot_trigger || n_node == 0) {
+            const int k = min(64, n_slot);
+            n_slot -= k;
+            if (lane < k) {
+                const uint32_t e = W.slot[n_slot + lane];
+                const int owner = (int)(e >> 26);
+                const uint32_t s = e & kPool3Index;
+                const V3 ro = v3(of[owner], of[64 + owner], of[128 + owner]), rd = v3(of[192 + owner], of[256 + owner], of[320 + owner]);
+                const float4 a = m.tri[3 * (size_t)s], b = m.tri[3 * (size_t)s + 1], c = m.tri[3 * (size_t)s + 2];
+                float t;
+                if (tri_ray3(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), ro, rd, of[384 + owner], t)) {
+                    const float at = fabsf(t);       // (t may be -0)
+                    atomicMin(&okey[owner], ((unsigned long long)__float_as_uint(at) << 32) | (unsigned long long)(uint32_t)m.triOrig[s]);
+                    atomicMin(&obound[owner], __float_as_uint(at * 1.00001f + 1e-30f));
+                }
+            }
+        } else {
+            const int k = min(min(64, n_node), (W.cap - n_node) / 3);
+            if (k <= 0 || n_slot + 4 * k > W.cap) {
+                overflow = true;
+                break;
+            }
+            n_node -= k;
+            const bool t = lane < k;
+            const uint32_t e = t ? W.node[n_node + lane] : 0u;
+            wave_lds_fence();
+            const uint32_t own_bits = e & ~kPool3Index;
+            bool leaf = false, v0 = false, v1 = false, v2 = false, v3_ = false;
+            uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
+            uint32_t child0 = 0;
+            if (t) {
+                const uint32_t g = e & kPool3Index;
+                const int owner = (int)(e >> 26);
+                int level, pos;
+                node3_level_pos(g, level, pos);
+                const V3 ro = v3(of[owner], of[64 + owner], of[128 + owner]), rd = v3(of[192 + owner], of[256 + owner], of[320 + owner]);
+                const V3 inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                const float bd = __uint_as_float(obound[owner]);
+                const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+                const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
+                const float d0 = ray_aabb_entry(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, ro, rd, inv, bd), d1 = ray_aabb_entry(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, ro, rd, inv, bd);
+                const float d2 = ray_aabb_entry(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, ro, rd, inv, bd), d3 = ray_aabb_entry(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, ro, rd, inv, bd);
+                leaf = level == m.levels;
+                if (leaf) {
+                    child0 = 4u * (uint32_t)pos;
+                    v0 = d0 <= bd; v1 = d1 <= bd; v2 = d2 <= bd; v3_ = d3 <= bd;
+                } else {
+                    child0 = level_first(level + 1) + 4u * (uint32_t)pos;
+                    k0 = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3u) | 0u) : 0xffffffffu;
+                    k1 = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3u) | 1u) : 0xffffffffu;
+                    k2 = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3u) | 2u) : 0xffffffffu;
+                    k3 = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3u) | 3u) : 0xffffffffu;
+                    cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
+                }
+            }
+            pool3_push(W.slot, n_slot, leaf && v0, own_bits | (child0 + 0u), lane);
+            pool3_push(W.slot, n_slot, leaf && v1, own_bits | (child0 + 1u), lane);
+            pool3_push(W.slot, n_slot, leaf && v2, own_bits | (child0 + 2u), lane);
+            pool3_push(W.slot, n_slot, leaf && v3_, own_bits | (child0 + 3u), lane);
+            pool3_push(W.node, n_node, k3 != 0xffffffffu, own_bits | (child0 + (k3 & 3u)), lane);
+            pool3_push(W.node, n_node, k2 != 0xffffffffu, own_bits | (child0 + (k2 & 3u)), lane);
+            pool3_push(W.node, n_node, k1 != 0xffffffffu, own_bits | (child0 + (k1 & 3u)), lane);
+            pool3_push(W.node, n_node, k0 != 0xffffffffu, own_bits | (child0 + (k0 & 3u)), lane);
+        }
+        wave_lds_fence();
+    }
+    bool hit = false;
+    t_out = WOST_INF;
+    idx_out = -1;
+    if (overflow) {
+        if (active) hit = ray3_tree<false>(m, o, d, tmax, t_out, idx_out, stk);
+    } else if (active) {
+        const unsigned long long key = okey[lane];
+        if (key != ~0ull) {
+            // the winner's parameter from its own test (the key holds |t|; the operands are the leaf-ordered copy's)
+            idx_out = (int)(uint32_t)key;
+            hit = tri_ray(m.flat[idx_out], o, d, tmax, t_out);
+        }
+    }
+    wave_lds_fence();
+    return hit;
+}
+
 template <bool NTREE>
 __device__ __forceinline__ float closest_silhouette3(const DevMesh3 &m, V3 q, float rmax, const LdsColumn &stk)
 {
@@ -816,6 +1064,9 @@ struct Walk3Params {
     uint32_t *cursor;          // next unread pixel slot of the launch
     int32_t tiled;             // the range is a whole frame made of 8x8 tiles: slots follow the tiles
     int32_t wait_weight, trav_burst;
+    // NTREE kernels: the Neumann-side tree queries of a step answered by the wave as a whole (closest_silhouette3_wave,
+    // ray_closest3_wave); pool_cap tasks per pool and wave, behind the stack columns of the block in LDS
+    int32_t coop, pool_cap, stack_words, ray_slot_trigger;
 };
 
 // One lane = one pixel, all its samples one after the other on the pixel's PCG stream (the reference's per-pixel
@@ -1214,12 +1465,37 @@ __global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
 #ifdef WOST3_PROFILE
             if (lane == 0) { atomicAdd(&g_prof3[8], 1ull); atomicAdd(&g_prof3[9], (unsigned long long)n_wait); }
 #endif
-            if (mode == MODE_WAIT) {
-                if (has_d && L.depth == 0 && !L.d0_valid) {
-                    L.d0 = T.best;
-                    L.d0_valid = true;
+            const bool stepping = mode == MODE_WAIT;
+            bool ended = false;
+            if (stepping && has_d && L.depth == 0 && !L.d0_valid) {
+                L.d0 = T.best;
+                L.d0_valid = true;
+            }
+            if (NTREE && P.coop) {
+                // the step in its three parts (step3), the two tree queries between them answered by all 64 lanes together
+                const int pool_words = 2 * P.pool_cap + kPool3OwnerWords;
+                uint32_t *pw = lds_stack + P.stack_words + (threadIdx.x >> 6) * pool_words;
+                const WavePool3 W{pw + kPool3OwnerWords, pw + kPool3OwnerWords + P.pool_cap, pw, P.pool_cap};
+                float R_D = WOST_INF, R_B = 0.0f;
+                V3 dir = v3(0.0f, 0.0f, 0.0f), cur = dir;
+                bool mid = false, go = false;
+                if (stepping) {
+                    ended = step3_a(P, L, T.best, R_D);
+                    mid = !ended;
                 }
-                bool ended = step3<EMISSIVE, SOURCE, NTREE>(P, L, T.best, stk);
+                const float R_N = closest_silhouette3_wave(P.nm, L.p, R_D, mid, W, stk);
+                if (mid) {
+                    ended = step3_b<EMISSIVE, SOURCE, NTREE>(P, L, R_D, R_N, stk, R_B, dir, cur);
+                    go = !ended;
+                }
+                float t = 0.0f;
+                int hi = -1;
+                const bool hit = ray_closest3_wave(P.nm, cur, dir, R_B, go, t, hi, W, stk, P.ray_slot_trigger);
+                if (go) step3_c(P, L, R_B, dir, cur, hit, t, hi);
+            } else if (stepping) {
+                ended = step3<EMISSIVE, SOURCE, NTREE>(P, L, T.best, stk);
+            }
+            if (stepping) {
                 if (!ended) {
                     ++L.depth;
                     if (L.depth == P.st.max_depth) {
@@ -1966,12 +2242,23 @@ static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, 
     W3_TRY(hipMemsetAsync(c->cursor, 0, sizeof(uint32_t), stream));
     const int bs = kWalk3Threads, n = pixel_end - pixel_begin;
     const int lv = std::max(c->dm.view.n_tris > 0 ? c->dm.view.levels : 1, c->nm.view.n_tris > 0 ? c->nm.view.levels : 1);
-    const size_t lds = (size_t)(3 * lv + 1) * bs * sizeof(uint32_t);
+    size_t lds = (size_t)(3 * lv + 1) * bs * sizeof(uint32_t);
     float ms = 0.0f;
     if (n > 0) {
         W3_TRY(hipEventRecord(c->ev0, stream));
         const bool emissive = c->nm.view.n_tris > 0 && c->nm.view.emissive;
         const bool ntree = c->nm.view.n_tris > WOST3_FLAT_MAX;
+        // Neumann mesh on the tree: its silhouette and ray queries are answered by the wave as a whole, through task pools in LDS
+        // behind the stack columns (developer knobs: WOST3_COOP=0 for the per-lane queries, WOST3_POOL_CAP, WOST3_RAY_TRIGGER)
+        P.coop = ntree ? 1 : 0;
+        P.pool_cap = 384;
+        P.ray_slot_trigger = 32;
+        if (const char *w = std::getenv("WOST3_COOP")) P.coop = (ntree && std::atoi(w) != 0) ? 1 : 0;
+        if (const char *w = std::getenv("WOST3_POOL_CAP")) P.pool_cap = std::min(4096, std::max(8, std::atoi(w)));
+        if (const char *w = std::getenv("WOST3_RAY_TRIGGER")) P.ray_slot_trigger = std::min(64, std::max(1, std::atoi(w)));
+        if (c->nm.view.levels > 11) P.coop = 0;      // (node and slot indices of a task: 26 bits, 4^(levels + 1) slots)
+        P.stack_words = (3 * lv + 1) * bs;
+        if (P.coop) lds += (size_t)(bs / 64) * (2 * (size_t)P.pool_cap + kPool3OwnerWords) * sizeof(uint32_t);
         auto kfn = ntree ? (c->src.rgb ? (emissive ? walk3_kernel<true, true, true> : walk3_kernel<false, true, true>)
                                        : (emissive ? walk3_kernel<true, false, true> : walk3_kernel<false, false, true>))
                          : (c->src.rgb ? (emissive ? walk3_kernel<true, true, false> : walk3_kernel<false, true, false>)
