@@ -71,6 +71,7 @@ struct DevMesh3 {
     const float4 *nodes;     // [n_nodes * 6] child boxes: lox[4] loy[4] loz[4] hix[4] hiy[4] hiz[4]
     const float4 *tri;       // [slots * 3] p0, p1, p2 (w unused) in leaf order; empty slots far away
     const int32_t *triOrig;  // [slots] original triangle index (WOST_FAR_INDEX = empty)
+    const int32_t *slotOfOrig; // [n_tris] the slot of an original triangle (closest_triangle_pool: its minimum is taken over original indices)
     const int32_t *triVerts; // [slots * 3] vertex ids (colour lookup)
     const float *colors;     // [n_verts * 6] or nullptr
     const DevTri *flat;      // [n_tris] original order
@@ -871,6 +872,98 @@ __device__ __forceinline__ bool ray_closest3_wave(const DevMesh3 &m, V3 o, V3 d,
     return hit;
 }
 
+// the closest triangle (closest_triangle: smallest distance, lowest original index among equal ones) for every lane with
+// `active`, seeded with `seed` = (squared distance, slot) of the temporal hint or (inf, -1)
+__device__ __forceinline__ Closest closest_triangle_pool(const DevMesh3 &m, V3 q, Closest seed, bool active, const WavePool3 &W, const LdsColumn &stk, int slot_trigger)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long *okey = reinterpret_cast<unsigned long long *>(W.own);     // [64]: bits(d2) << 32 | original index
+    float *oq = reinterpret_cast<float *>(W.own) + 128;                            // q.xyz: 3 x [64]
+    if (active) {
+        const uint32_t so = seed.slot >= 0 ? (uint32_t)m.triOrig[seed.slot] : 0xffffffffu;
+        okey[lane] = ((unsigned long long)__float_as_uint(seed.d2) << 32) | so;
+        oq[lane] = q.x; oq[64 + lane] = q.y; oq[128 + lane] = q.z;
+    }
+    int n_node = 0, n_slot = 0;
+    pool3_push(W.node, n_node, active, (uint32_t)lane << 26, lane);
+    bool overflow = false;
+    wave_lds_fence();
+    while (n_node > 0 || n_slot > 0) {
+        if (n_slot >= slot_trigger || n_node == 0) {
+            const int k = min(64, n_slot);
+            n_slot -= k;
+            if (lane < k) {
+                const uint32_t e = W.slot[n_slot + lane];
+                const int owner = (int)(e >> 26);
+                const uint32_t sl = e & kPool3Index;
+                const int32_t o = m.triOrig[sl];
+                if (o != WOST_FAR_INDEX) {
+                    const float4 a = m.tri[3 * (size_t)sl], b = m.tri[3 * (size_t)sl + 1], c = m.tri[3 * (size_t)sl + 2];
+                    const float d = tri_d2(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), v3(oq[owner], oq[64 + owner], oq[128 + owner]));
+                    atomicMin(&okey[owner], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)o);
+                }
+            }
+        } else {
+            const int k = min(min(64, n_node), (W.cap - n_node) / 3);
+            if (k <= 0 || n_slot + 4 * k > W.cap) {
+                overflow = true;
+                break;
+            }
+            n_node -= k;
+            const bool t = lane < k;
+            const uint32_t e = t ? W.node[n_node + lane] : 0u;
+            wave_lds_fence();
+            const uint32_t own_bits = e & ~kPool3Index;
+            bool leaf = false, v0 = false, v1 = false, v2 = false, v3_ = false;
+            uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
+            uint32_t child0 = 0;
+            if (t) {
+                const uint32_t g = e & kPool3Index;
+                const int owner = (int)(e >> 26);
+                int level, pos;
+                node3_level_pos(g, level, pos);
+                const V3 oqv = v3(oq[owner], oq[64 + owner], oq[128 + owner]);
+                const float bd = __uint_as_float((uint32_t)(okey[owner] >> 32)) * kSlack3;
+                const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+                const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
+                const float d0 = aabb_d2(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, oqv), d1 = aabb_d2(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, oqv);
+                const float d2 = aabb_d2(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, oqv), d3 = aabb_d2(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, oqv);
+                leaf = level == m.levels;
+                if (leaf) {
+                    child0 = 4u * (uint32_t)pos;
+                    v0 = !(d0 > bd); v1 = !(d1 > bd); v2 = !(d2 > bd); v3_ = !(d3 > bd);
+                } else {
+                    child0 = level_first(level + 1) + 4u * (uint32_t)pos;
+                    k0 = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3u) | 0u) : 0xffffffffu;
+                    k1 = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3u) | 1u) : 0xffffffffu;
+                    k2 = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3u) | 2u) : 0xffffffffu;
+                    k3 = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3u) | 3u) : 0xffffffffu;
+                    cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
+                }
+            }
+            pool3_push(W.slot, n_slot, leaf && v0, own_bits | (child0 + 0u), lane);
+            pool3_push(W.slot, n_slot, leaf && v1, own_bits | (child0 + 1u), lane);
+            pool3_push(W.slot, n_slot, leaf && v2, own_bits | (child0 + 2u), lane);
+            pool3_push(W.slot, n_slot, leaf && v3_, own_bits | (child0 + 3u), lane);
+            pool3_push(W.node, n_node, k3 != 0xffffffffu, own_bits | (child0 + (k3 & 3u)), lane);
+            pool3_push(W.node, n_node, k2 != 0xffffffffu, own_bits | (child0 + (k2 & 3u)), lane);
+            pool3_push(W.node, n_node, k1 != 0xffffffffu, own_bits | (child0 + (k1 & 3u)), lane);
+            pool3_push(W.node, n_node, k0 != 0xffffffffu, own_bits | (child0 + (k0 & 3u)), lane);
+        }
+        wave_lds_fence();
+    }
+    Closest r = seed;
+    if (overflow) {
+        if (active) r = closest_triangle(m, q, seed.slot, stk);
+    } else if (active) {
+        const unsigned long long key = okey[lane];
+        const uint32_t o = (uint32_t)key;
+        r = Closest{__uint_as_float((uint32_t)(key >> 32)), o == 0xffffffffu ? -1 : m.slotOfOrig[o]};
+    }
+    wave_lds_fence();
+    return r;
+}
+
 template <bool NTREE>
 __device__ __forceinline__ float closest_silhouette3(const DevMesh3 &m, V3 q, float rmax, const LdsColumn &stk)
 {
@@ -1066,7 +1159,7 @@ struct Walk3Params {
     int32_t wait_weight, trav_burst;
     // NTREE kernels: the Neumann-side tree queries of a step answered by the wave as a whole (closest_silhouette3_wave,
     // ray_closest3_wave); pool_cap tasks per pool and wave, behind the stack columns of the block in LDS
-    int32_t coop, pool_cap, stack_words, ray_slot_trigger;
+    int32_t coop, pool_cap, stack_words, ray_slot_trigger, cp_slot_trigger;
 };
 
 // One lane = one pixel, all its samples one after the other on the pixel's PCG stream (the reference's per-pixel
@@ -1340,17 +1433,22 @@ __device__ __forceinline__ Closest closest_triangle_wave(const DevMesh3 &m, V3 q
     return Closest{bd, bs};
 }
 
-template <bool EMISSIVE, bool SOURCE, bool NTREE>
+// WAVE = true: the closest-point queries are answered by the wave as a whole as well (closest_triangle_pool) -- every trip of
+// the loop is then "all queries of the wave, then one step for every walker": no lane waits for another's descent.
+template <bool EMISSIVE, bool SOURCE, bool NTREE, bool WAVE = false>
 __global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
 {
     extern __shared__ uint32_t lds_stack[];
     const LdsColumn stk(lds_stack + threadIdx.x, blockDim.x);
+    // the task pools of this wave (closest_silhouette3_wave & co.), behind the stack columns
+    uint32_t *const pool_mem = lds_stack + P.stack_words + (threadIdx.x >> 6) * (2 * P.pool_cap + kPool3OwnerWords);
+    const WavePool3 W{pool_mem + kPool3OwnerWords, pool_mem + kPool3OwnerWords + P.pool_cap, pool_mem, P.pool_cap};
 #ifdef WOST3_PROFILE
     const unsigned long long prof_begin = __builtin_readcyclecounter();
 #endif
     const int lane = threadIdx.x & 63;
     const bool has_d = P.dm.n_tris > 0;
-    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5, MODE_HUGE = 7 };
+    enum { MODE_TRAV = 1, MODE_QUERY = 2, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5, MODE_HUGE = 7 };
     int mode = MODE_REFILL;
     Lane3 L{};
     L.rng = Pcg{0, 1};
@@ -1376,7 +1474,7 @@ __global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
                 T.best_orig = P.dm.triOrig[L.hint];
             }
             // a walker that strayed so far that the whole mesh ties within rounding: answered by the wave (main loop)
-            mode = T.best.d2 > P.dm.huge2 ? MODE_HUGE : MODE_TRAV;
+            mode = T.best.d2 > P.dm.huge2 ? MODE_HUGE : (WAVE ? MODE_QUERY : MODE_TRAV);
         }
     };
     auto begin_sample = [&]() {
@@ -1454,6 +1552,16 @@ __global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
                 hb &= hb - 1;
             }
         }
+        if (WAVE) {
+            const bool asks = mode == MODE_QUERY;
+            if (__ballot(asks)) {
+                const Closest r = closest_triangle_pool(P.dm, L.p, T.best, asks, W, stk, P.cp_slot_trigger);
+                if (asks) {
+                    T.best = r;
+                    mode = MODE_WAIT;
+                }
+            }
+        }
         const int n_trav = __popcll(__ballot(mode == MODE_TRAV));
         const int n_wait = __popcll(__ballot(mode == MODE_WAIT));
         if (n_trav + n_wait == 0) {
@@ -1473,9 +1581,6 @@ __global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
             }
             if (NTREE && P.coop) {
                 // the step in its three parts (step3), the two tree queries between them answered by all 64 lanes together
-                const int pool_words = 2 * P.pool_cap + kPool3OwnerWords;
-                uint32_t *pw = lds_stack + P.stack_words + (threadIdx.x >> 6) * pool_words;
-                const WavePool3 W{pw + kPool3OwnerWords, pw + kPool3OwnerWords + P.pool_cap, pw, P.pool_cap};
                 float R_D = WOST_INF, R_B = 0.0f;
                 V3 dir = v3(0.0f, 0.0f, 0.0f), cur = dir;
                 bool mid = false, go = false;
@@ -2180,6 +2285,12 @@ static int upload_mesh3(const wost3_mesh_desc &d, DeviceMesh3 &s)
     W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.nodes.data()), h.nodes.size() / 4, &v.nodes));
     W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.tri.data()), h.tri.size() / 4, &v.tri));
     W3_TRY(upload3(s.allocs, h.triOrig.data(), h.triOrig.size(), &v.triOrig));
+    {
+        std::vector<int32_t> inv((size_t)std::max(h.n_tris, 1), 0);
+        for (size_t k = 0; k < h.triOrig.size(); ++k)
+            if (h.triOrig[k] != kFarIndex) inv[(size_t)h.triOrig[k]] = (int32_t)k;
+        W3_TRY(upload3(s.allocs, inv.data(), inv.size(), &v.slotOfOrig));
+    }
     W3_TRY(upload3(s.allocs, h.triVerts.data(), h.triVerts.size(), &v.triVerts));
     W3_TRY(upload3(s.allocs, h.colors.data(), h.colors.size(), &v.colors));
     W3_TRY(upload3(s.allocs, h.flat.data(), h.flat.size(), &v.flat));
@@ -2251,18 +2362,28 @@ static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, 
         // Neumann mesh on the tree: its silhouette and ray queries are answered by the wave as a whole, through task pools in LDS
         // behind the stack columns (developer knobs: WOST3_COOP=0 for the per-lane queries, WOST3_POOL_CAP, WOST3_RAY_TRIGGER)
         P.coop = ntree ? 1 : 0;
-        P.pool_cap = 384;
+        P.pool_cap = 512;
         P.ray_slot_trigger = 32;
+        P.cp_slot_trigger = 64;
+        if (const char *w = std::getenv("WOST3_CP_TRIGGER")) P.cp_slot_trigger = std::min(64, std::max(1, std::atoi(w)));
         if (const char *w = std::getenv("WOST3_COOP")) P.coop = (ntree && std::atoi(w) != 0) ? 1 : 0;
-        if (const char *w = std::getenv("WOST3_POOL_CAP")) P.pool_cap = std::min(4096, std::max(8, std::atoi(w)));
+        if (const char *w = std::getenv("WOST3_POOL_CAP")) P.pool_cap = std::min(4096, std::max(96, std::atoi(w)));     // (64 roots must fit)
         if (const char *w = std::getenv("WOST3_RAY_TRIGGER")) P.ray_slot_trigger = std::min(64, std::max(1, std::atoi(w)));
         if (c->nm.view.levels > 11) P.coop = 0;      // (node and slot indices of a task: 26 bits, 4^(levels + 1) slots)
         P.stack_words = (3 * lv + 1) * bs;
-        if (P.coop) lds += (size_t)(bs / 64) * (2 * (size_t)P.pool_cap + kPool3OwnerWords) * sizeof(uint32_t);
+        // the closest-point queries by the wave as well (WOST3_WAVE=0: the lane machine)
+        bool wave = c->dm.view.n_tris > 0 && c->dm.view.levels <= 11;
+        if (const char *w = std::getenv("WOST3_WAVE")) wave = wave && std::atoi(w) != 0;
+        if (wave || P.coop) lds += (size_t)(bs / 64) * (2 * (size_t)P.pool_cap + kPool3OwnerWords) * sizeof(uint32_t);
         auto kfn = ntree ? (c->src.rgb ? (emissive ? walk3_kernel<true, true, true> : walk3_kernel<false, true, true>)
                                        : (emissive ? walk3_kernel<true, false, true> : walk3_kernel<false, false, true>))
                          : (c->src.rgb ? (emissive ? walk3_kernel<true, true, false> : walk3_kernel<false, true, false>)
                                        : (emissive ? walk3_kernel<true, false, false> : walk3_kernel<false, false, false>));
+        if (wave)
+            kfn = ntree ? (c->src.rgb ? (emissive ? walk3_kernel<true, true, true, true> : walk3_kernel<false, true, true, true>)
+                                      : (emissive ? walk3_kernel<true, false, true, true> : walk3_kernel<false, false, true, true>))
+                        : (c->src.rgb ? (emissive ? walk3_kernel<true, true, false, true> : walk3_kernel<false, true, false, true>)
+                                      : (emissive ? walk3_kernel<true, false, false, true> : walk3_kernel<false, false, false, true>));
         // persistent blocks: as many as the chip holds (LDS stacks and registers allow about four per CU), or fewer for small frames
         int n_cus = 256;
         (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, c->device);

@@ -254,6 +254,22 @@ def test_3d_debug_channels_match_oracle(oracle):
     it.close()
 
 
+@pytest.mark.parametrize("knobs", [{"WOST3_WAVE": "0", "WOST3_COOP": "0"}, {"WOST3_WAVE": "0", "WOST3_COOP": "1"}, {"WOST3_WAVE": "1", "WOST3_COOP": "0"},
+                                   {"WOST3_POOL_CAP": "96"}, {"WOST3_POOL_CAP": "200", "WOST3_RAY_TRIGGER": "1", "WOST3_CP_TRIGGER": "1"}])
+def test_3d_wave_cooperative_queries_and_their_fallbacks_match_oracle(oracle, monkeypatch, knobs):
+    """the tree queries of a walk answered by the wave through its LDS task pools (closest_triangle_pool, closest_silhouette3_wave,
+    ray_closest3_wave: the default) against the per-lane descents they replace, each side alone and both; pools so small that
+    the waves cannot take a batch and answer the old way (96 tasks: the 64 roots leave room for ten node tasks); slot tasks
+    served as soon as one exists.  Every variant: the oracle's field and counters."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    _same_solve(oracle, _shell_scene(2, 3), 14, 12, 6, 64, 2e-3)
+    _same_solve(oracle, _shell_scene(2, 3, flux=lambda x, y, z: 0.3 * y), 12, 10, 4, 48, 2e-3)
+    _same_solve(oracle, sphere_scene3(subdiv=3, radius=1.0, value=lambda x, y, z: x * y), 24, 20, 6, 32, 2e-3)
+    sd = cube_scene3(n=6, d_faces=(0, 1), n_faces=(2, 3, 4, 5), value=lambda x, y, z: x, flux=lambda x, y, z, f: 0.1 * f)
+    _same_solve(oracle, sd, 12, 12, 8, 48, 2e-3)
+
+
 def test_3d_queries_and_walks_far_outside_the_meshes(oracle):
     """an OPEN Neumann shell lets walkers escape: positions and radii of 10^3 .. 10^7 mesh units occur, where the
     rounding of box and primitive distances grows with |q| -- the tree queries must still give the flat answers"""
