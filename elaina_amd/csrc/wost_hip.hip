@@ -33,6 +33,7 @@
 #include "wost_internal.h"
 #include "wost_walk.h"
 #include "wost_quad.h"
+#include "wost_coop.h"
 
 namespace wost {
 
@@ -87,6 +88,9 @@ struct RoundParams {
     // at that point and are queued from the TOP of the output queue downwards: slot out_capacity - 1 - k, k from *count_far
     uint32_t *count_far;
     uint32_t out_capacity;
+    // NEUMANN_TREE launches of walk_round_kernel: the Neumann-side tree queries of a step by the wave as a whole (wost_coop.h):
+    // pool_cap tasks per pool and wave, pool_offset words into the block's LDS (behind the stack columns); 0 = per lane
+    int32_t coop, pool_cap, pool_offset, ray_slot_trigger;
 };
 
 struct InitParams {
@@ -259,6 +263,92 @@ __device__ __forceinline__ uint32_t step_finish(const DevMesh &dm, const DevMesh
     return (truncated ? (STEP_ENDED | STEP_TRUNCATED) : 0u) | (hit_count ? STEP_NEUMANN_HIT : 0u);
 }
 
+// step_finish for ALL lanes of a wave at once, `stepping` marking those that take the step: the same statements in the same
+// order per walker, but the two tree queries on the Neumann side -- the closest silhouette vertex after the Dirichlet part, the
+// walker's ray at the end -- are answered by the wave as a whole between the parts (wost_coop.h).  Neumann meshes on the tree only.
+template <bool NEUMANN_EMISSIVE, bool SOURCE, class STK>
+__device__ __forceinline__ uint32_t step_finish_wave(const DevMesh &dm, const DevMesh &nm, const DevSettings &st, Lane &L, const Closest cp,
+                                                     bool stepping, const WavePool &W, const STK &stk, int ray_slot_trigger, const DevSource &src)
+{
+    const bool has_d = dm.n_segs > 0;
+    const float eps = st.eps;
+    const float px = L.px, py = L.py;
+    uint32_t status = 0u;
+    bool mid = stepping;
+    // ---- separateEvaluationPoint / handleBoundary ----
+    float R_D = WOST_INF;
+    if (stepping && has_d) {
+        L.hint = cp.slot;
+        const float4 a = dm.segA[cp.slot];
+        const float inv = dm.segInv[cp.slot];
+        const float wx = px - a.x, wy = py - a.y;
+        const float uv = dot2(wx, wy, a.z, a.w) * inv;
+        const float cr = cross2(a.z, a.w, wx, wy);
+        const int side = (0.0f < cr) - (cr < 0.0f);
+        R_D = sqrtf(cp.d2);
+        if ((R_D < eps) && (uv > 0.0f && uv < 1.0f)) {
+            float r, g, b;
+            surface_color(dm.segCol + 12 * (size_t)cp.slot, side, uv, r, g, b);
+            r *= st.dirichlet_intensity; g *= st.dirichlet_intensity; b *= st.dirichlet_intensity;
+            r *= L.thp; g *= L.thp; b *= L.thp;
+            L.sr = r + L.sr; L.sg = g + L.sg; L.sb = b + L.sb;
+            status = STEP_ENDED | STEP_ABSORBED;
+            mid = false;
+        }
+    }
+    const float R_N = closest_silhouette_wave(nm, px, py, R_D, mid, W, stk);
+    float R_B = 0.0f, dirx = 0.0f, diry = 0.0f, pdf = 1.0f, alpha = 1.0f;
+    bool go = false;
+    if (mid) {
+        R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
+        R_B *= WOST_R_B_SHRINK;
+        if (isinf(R_B)) {
+            status = STEP_ENDED;
+        } else {
+            if (SOURCE) {
+                float cr_, cg_, cb_;
+                if (source_sample<true>(src, nm, eps, px, py, R_B, L.on_n, L.nx, L.ny, L.thp, L.rng, stk, cr_, cg_, cb_)) {
+                    L.sr = cr_ + L.sr; L.sg = cg_ + L.sg; L.sb = cb_ + L.sb;
+                }
+            }
+            {
+                float cr_, cg_, cb_;
+                if (neumann_sample<NEUMANN_EMISSIVE, true>(nm, st.neumann_intensity, eps, px, py, R_B, L.on_n, L.nx, L.ny, L.thp, L.rng, stk, cr_, cg_, cb_)) {
+                    L.sr = cr_ + L.sr; L.sg = cg_ + L.sg; L.sb = cb_ + L.sb;
+                }
+            }
+            uniform_direction(L.on_n, L.nx, L.ny, L.rng, dirx, diry, pdf, alpha);
+            go = true;
+        }
+    }
+    // ---- oneStepWalk: walk_advance with the ray answered by the wave ----
+    float cxp = px, cyp = py;
+    if (go && L.on_n) {
+        cxp += eps * L.nx;
+        cyp += eps * L.ny;
+    }
+    float t = 0.0f;
+    int hi = -1;
+    const bool hit = ray_closest_wave(nm, cxp, cyp, dirx, diry, R_B, go, t, hi, W, stk, ray_slot_trigger);
+    if (go) {
+        float nxt_x = px + R_B * dirx, nxt_y = py + R_B * diry, hnx = 0.0f, hny = 0.0f;
+        if (hit) {
+            hnx = nm.flat[hi].nx;
+            hny = nm.flat[hi].ny;
+            if (dot2(hnx, hny, dirx, diry) > 0) { hnx = -hnx; hny = -hny; }
+            nxt_x = cxp + t * dirx;
+            nxt_y = cyp + t * diry;
+        }
+        if (L.thp != 1.0f) L.thp = L.thp / pdf / alpha / WOST_2PI;
+        L.px = nxt_x; L.py = nxt_y;
+        L.on_n = hit; L.nx = hnx; L.ny = hny;
+        L.depth++;
+        const bool truncated = L.depth == (uint32_t)st.max_depth;
+        status = (truncated ? (STEP_ENDED | STEP_TRUNCATED) : 0u) | (hit ? STEP_NEUMANN_HIT : 0u);
+    }
+    return status;
+}
+
 __device__ __forceinline__ void load_lane(const WalkQueue &q, uint32_t slot, Lane &L, uint32_t &pix)
 {
     pix = q.pix[slot];
@@ -400,9 +490,18 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
         if (n_wait * P.wait_weight >= n_trav * 8) {
             ++step_trips;
             // ---- step phase ----
+            uint32_t wave_status = 0u;
+            if (NEUMANN_TREE && P.coop) {
+                // (8-byte LDS atomics: the pools start at an 8-byte boundary whatever lies before the dynamic segment)
+                uint32_t *pw = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(lds_stack + P.pool_offset) + 7u) & ~(uintptr_t)7u) +
+                               (threadIdx.x >> 6) * (2 * P.pool_cap + kPoolOwnerWords);
+                const WavePool W{pw + kPoolOwnerWords, pw + kPoolOwnerWords + P.pool_cap, pw, P.pool_cap};
+                wave_status = step_finish_wave<NEUMANN_EMISSIVE, SOURCE>(P.dm, P.nm, P.st, L, T.best, mode == MODE_WAIT && !fresh, W, stk, P.ray_slot_trigger, P.src);
+            }
             if (mode == MODE_WAIT) {
                 if (!fresh) {
-                    const uint32_t status = step_finish<NEUMANN_EMISSIVE, NEUMANN_TREE, SOURCE>(P.dm, P.nm, P.st, L, T.best, stk, P.src);
+                    const uint32_t status = (NEUMANN_TREE && P.coop) ? wave_status
+                                                                     : step_finish<NEUMANN_EMISSIVE, NEUMANN_TREE, SOURCE>(P.dm, P.nm, P.st, L, T.best, stk, P.src);
                     const bool ended = (status & STEP_ENDED) != 0u;
                     S.b += ((status >> 1) & 1u) | (((status >> 2) & 1u) << 16);
                     S.c += (status >> 3) & 1u;
@@ -957,6 +1056,9 @@ struct wost_context {
     int refill = -1;       // -1 = automatic (few samples per pixel), 0 = never, 1 = always
     int quad = -1;         // four lanes per walker in under-filled launches: -1 = automatic, 0 = never, 1 = every ordinary round
     double quad_fill = 1.0;   // automatic: when 4 x walkers <= quad_fill x resident lanes
+    int coop = 1;             // a Neumann mesh on the tree: its silhouette and ray queries by the wave as a whole (wost_coop.h); 0 = per lane
+    int pool_cap = 384;       // ... tasks per pool and wave
+    int ray_slot_trigger = 32;
     uint32_t *cursor = nullptr;
     hipStream_t far_stream = nullptr;          // the launches that take strayed walkers through the SLACK kernel (run_solve)
     hipEvent_t far_ev0 = nullptr, far_ev1 = nullptr;
@@ -1134,6 +1236,14 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "quad_fill") {
         if (!(value > 0) || value > 64) return fail(WOST_ERR_INVALID, "quad_fill must be in (0, 64]");
         h->quad_fill = value;
+    } else if (k == "coop") {
+        h->coop = value != 0;
+    } else if (k == "pool_cap") {
+        if (value < 96 || value > 4096) return fail(WOST_ERR_INVALID, "pool_cap must be in 96..4096");
+        h->pool_cap = (int)value;
+    } else if (k == "ray_slot_trigger") {
+        if (value < 1 || value > 64) return fail(WOST_ERR_INVALID, "ray_slot_trigger must be in 1..64");
+        h->ray_slot_trigger = (int)value;
     } else if (k == "thin_waves") {
         h->thin_waves = value != 0;
     } else if (k == "time_kernels") {
@@ -1274,8 +1384,14 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         // busy lanes wait (tools/probes/bench2d_wiggly.py: 3.87 -> 4.40 x 10^8 walk-steps/s on 3000 segments)
         rp.wait_weight = (ntree && !c->wait_weight_set) ? 1 : c->wait_weight;
         rp.trav_burst = c->trav_burst;
+        // a Neumann mesh on the tree: the task pools of every wave behind the stack columns (wost_coop.h)
+        rp.coop = (ntree && c->coop && c->nm.view.levels <= 11) ? 1 : 0;
+        rp.pool_cap = c->pool_cap;
+        rp.pool_offset = (int32_t)(lds / sizeof(uint32_t));
+        rp.ray_slot_trigger = c->ray_slot_trigger;
+        const size_t lds_pools = rp.coop ? (size_t)(bs / 64) * (2 * (size_t)rp.pool_cap + kPoolOwnerWords) * sizeof(uint32_t) + 8 : 0;
         // developer experiment: extra LDS per block lowers the number of resident blocks (occupancy sensitivity)
-        const size_t lds_round = lds + (getenv("WOST_EXP_LDS_PAD") ? (size_t)atoi(getenv("WOST_EXP_LDS_PAD")) : 0);
+        const size_t lds_round = lds + lds_pools + (getenv("WOST_EXP_LDS_PAD") ? (size_t)atoi(getenv("WOST_EXP_LDS_PAD")) : 0);
         // Walkers that left the previous launch at a query beyond the plain kernel's range wait at the far end of its output queue,
         // which is this launch's input queue.  The SLACK instantiation takes them through max_depth steps -- the walk that strayed
         // ends within that many -- on a stream of its own, next to this launch, and appends them to the same output queue (both

@@ -419,6 +419,21 @@ def test_refill_is_chosen_automatically_for_one_sample(ladybug):
     it.close()
 
 
+@pytest.mark.parametrize("opts", [{"coop": 0}, {"coop": 1}, {"coop": 1, "pool_cap": 96}, {"coop": 1, "pool_cap": 200, "ray_slot_trigger": 1},
+                                  {"coop": 1, "refill": 1}, {"coop": 1, "wait_weight": 8, "trav_burst": 1, "steps_per_round": 5}])
+def test_neumann_tree_queries_by_the_wave_match_oracle(oracle, opts):
+    """a Neumann mesh on the tree: the silhouette and ray queries of a step answered by the wave through its LDS task pools
+    (wost_coop.h: closest_silhouette_wave, ray_closest_wave, step_finish_wave -- the default) against the per-lane descents;
+    pools so small that the waves answer the old way (96 tasks: the 64 roots leave room for ten node tasks), slot tasks served
+    one by one, the REFILL launch, short rounds.  Closed and open boundaries (open ends are silhouettes), emissive or not, with a
+    source term: the oracle's field and counters."""
+    from conftest import wiggly_problem
+    _assert_same_solve(oracle, wiggly_problem(3000, 64, open_gap=0), 40, 40, 2, 24, 0.05, **opts)
+    _assert_same_solve(oracle, wiggly_problem(3000, 64, open_gap=37), 40, 40, 2, 24, 0.05, **opts)
+    _assert_same_solve(oracle, wiggly_problem(600, 200, emissive=True, open_gap=3), 32, 32, 3, 16, 0.05, **opts)
+    _assert_same_solve(oracle, _with_source(wiggly_problem(emissive=True), -130.0, 130.0, intensity=1e-3), 32, 32, 2, 16, 0.05, **opts)
+
+
 def test_quad_rounds_match_oracle(oracle, ladybug, fille):
     """walk_quad_kernel -- four lanes per walker, the descent shared between the lanes of a quad (wost_quad.h): the launch
     of an under-filled round.  Forced for every round here; same arithmetic per child, same keys and visiting order, so
