@@ -68,7 +68,9 @@ def main():
         if rng.uniform() < 0.4:            # launch shapes and scheduler constants: none of them may change a bit
             opts = {"steps_per_round": int(rng.choice([1, 3, 17, 256])), "block_size": int(rng.choice([64, 128, 256])),
                     "wait_weight": int(rng.choice([1, 8, 64])), "trav_burst": int(rng.choice([1, 3, 5])), "thin_waves": int(rng.choice([0, 1])),
-                    "quad": int(rng.choice([0, 1]))}       # (quad: four lanes per walker in every ordinary round)
+                    "quad": int(rng.choice([0, 1])),       # (quad: four lanes per walker in every ordinary round)
+                    # a Neumann mesh on the tree: its step queries per lane, by the wave, or by a wave whose pools are too small for a trip
+                    "coop": int(rng.choice([0, 1, 1])), "pool_cap": int(rng.choice([96, 200, 384])), "ray_slot_trigger": int(rng.choice([1, 32, 64]))}
             feat.append(str(opts))
             for k, v in opts.items():
                 it.set_option(k, v)

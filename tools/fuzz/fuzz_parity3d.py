@@ -63,6 +63,16 @@ def main():
         if rng.uniform() < 0.2:
             feat.append("mask")
             sd["mask"] = (rng.uniform(size=w * h) < 0.7).astype(np.uint8)
+        # how the tree queries are answered -- by the wave through its task pools (default), per lane, pools too small for a trip
+        # (the waves then answer the old way), slot tasks served eagerly -- must not change a bit
+        for k in ("WOST3_WAVE", "WOST3_COOP", "WOST3_POOL_CAP", "WOST3_RAY_TRIGGER", "WOST3_CP_TRIGGER"):
+            os.environ.pop(k, None)
+        if rng.uniform() < 0.5:
+            knobs = {"WOST3_WAVE": str(int(rng.choice([0, 1, 1]))), "WOST3_COOP": str(int(rng.choice([0, 1, 1]))),
+                     "WOST3_POOL_CAP": str(int(rng.choice([96, 200, 512]))), "WOST3_RAY_TRIGGER": str(int(rng.choice([1, 32]))),
+                     "WOST3_CP_TRIGGER": str(int(rng.choice([1, 64])))}
+            feat.append(str(knobs))
+            os.environ.update(knobs)
         it = UniformIntegrator3(Problem3.from_dict(sd), UniformIntegratorSettings((w, h), spp, depth, eps))
         it.solve()
         ref = oracle.solve3(sd, w, h, spp, depth, eps, threads=os.cpu_count() or 8)
