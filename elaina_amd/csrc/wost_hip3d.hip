@@ -2787,7 +2787,18 @@ struct G3Params {
     int32_t training, train_offset, train_stride, max_train_depth;
     int32_t depth, guiding, first_sample, stack_stride;
     float uniform_fraction;
+    // the tree queries of a wave's walkers through its task pools (closest_triangle_pool & co.): pool_cap tasks per pool and wave,
+    // pool_offset words into the block's LDS (behind the stack columns); pool_cap = 0: one descent per thread
+    int32_t pool_cap, pool_offset;
 };
+
+// the task pools of this wave (8-byte LDS atomics: from an 8-byte boundary, whatever static words precede the dynamic segment)
+__device__ __forceinline__ WavePool3 g3_pools(const G3Params &P, uint32_t *lds)
+{
+    uint32_t *pw = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(lds + P.pool_offset) + 7u) & ~(uintptr_t)7u) +
+                   (threadIdx.x >> 6) * (2 * P.pool_cap + kPool3OwnerWords);
+    return WavePool3{pw + kPool3OwnerWords, pw + kPool3OwnerWords + P.pool_cap, pw, P.pool_cap};
+}
 
 __device__ __forceinline__ GStats3Dev *g3_stats(GStats3Dev *s) { return s + (blockIdx.x & (kStat3Copies - 1)); }
 
@@ -2863,23 +2874,43 @@ __global__ __launch_bounds__(256) void g3_separate_kernel(G3Params P)
 {
     extern __shared__ uint32_t lds_stack[];
     const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
+    const bool pooled = P.pool_cap > 0;
+    const WavePool3 W = g3_pools(P, lds_stack);
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = p < P.n_pixels && P.state[p] == 1;
     g3_count(live, &g3_stats(P.stats)->steps);
     bool keep = false, absorbed = false;
     V3 x = v3(0.0f, 0.0f, 0.0f);
+    // ---- the closest Dirichlet triangle: by the wave for all its walkers (closest_triangle_pool), or one descent per thread ----
+    Closest cp{WOST_INF, -1};
+    const bool has_d = P.dm.n_tris > 0;
     if (live) {
-        const uint32_t pid = (uint32_t)p;
         x = v3(P.wx[3 * (size_t)p], P.wx[3 * (size_t)p + 1], P.wx[3 * (size_t)p + 2]);
-        const V3 nn = v3(P.wn[3 * (size_t)p], P.wn[3 * (size_t)p + 1], P.wn[3 * (size_t)p + 2]);
-        const float thp = P.wthp[p];
-        const bool on_n = P.won[p] != 0;
-        const bool train_px = g3_training_pixel(P, pid);
-        const float eps = P.st.eps;
-        Pcg rng{P.rng[p], 1};
-        float R_D = WOST_INF;
-        if (P.dm.n_tris > 0) {
-            const Closest cp = closest_triangle(P.dm, x, P.whint[p], stk);
+        if (has_d && pooled) {
+            const int32_t hint = P.whint[p];      // closest_triangle's seed
+            if (hint >= 0 && P.dm.triOrig[hint] != WOST_FAR_INDEX) {
+                const float4 a = P.dm.tri[3 * (size_t)hint], b = P.dm.tri[3 * (size_t)hint + 1], c = P.dm.tri[3 * (size_t)hint + 2];
+                cp = Closest{tri_d2(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), x), hint};
+            }
+        }
+    }
+    if (has_d) {
+        if (pooled) cp = closest_triangle_pool(P.dm, x, cp, live, W, stk, 64);
+        else if (live) cp = closest_triangle(P.dm, x, P.whint[p], stk);
+    }
+    V3 nn = v3(0.0f, 0.0f, 0.0f);
+    float thp = 0.0f, R_D = WOST_INF;
+    bool on_n = false, train_px = false;
+    Pcg rng{0, 1};
+    const float eps = P.st.eps;
+    const uint32_t pid = (uint32_t)p;
+    if (live) {
+        nn = v3(P.wn[3 * (size_t)p], P.wn[3 * (size_t)p + 1], P.wn[3 * (size_t)p + 2]);
+        thp = P.wthp[p];
+        on_n = P.won[p] != 0;
+        train_px = g3_training_pixel(P, pid);
+        rng = Pcg{P.rng[p], 1};
+        if (has_d) {
             P.whint[p] = cp.slot;
             if (P.depth == 0) P.hint0[p] = cp.slot;
             const float4 a = P.dm.tri[3 * (size_t)cp.slot], b = P.dm.tri[3 * (size_t)cp.slot + 1], c = P.dm.tri[3 * (size_t)cp.slot + 2];
@@ -2902,9 +2933,17 @@ __global__ __launch_bounds__(256) void g3_separate_kernel(G3Params P)
                 absorbed = true;
             }
         }
+    }
+    // ---- the closest silhouette edge: the same choice ----
+    const bool mid = live && !absorbed;
+    float R_N = WOST_INF;
+    if (P.nm.n_tris > 0) {
+        if (NTREE && pooled) R_N = closest_silhouette3_wave(P.nm, x, R_D, mid, W, stk);
+        else if (mid) R_N = closest_silhouette3<NTREE>(P.nm, x, R_D, stk);
+    }
+    if (live) {
         if (!absorbed) {
-            float R_N = WOST_INF;
-            if (P.nm.n_tris > 0) R_N = closest_silhouette3<NTREE>(P.nm, x, R_D, stk);
+
             const float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));     // no 0.99 in the guided integrator (:238-239)
             if (!isinf(R_B)) {
                 keep = true;
@@ -2977,23 +3016,29 @@ __global__ __launch_bounds__(256) void g3_sample_kernel(G3Params P)
 {
     extern __shared__ uint32_t lds_stack[];
     const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
+    const bool pooled = NTREE && P.pool_cap > 0;
+    const WavePool3 W = g3_pools(P, lds_stack);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_in = *P.q_count;
     const bool live = i < n_in;
     bool guided = false, hit = false, moved = false;
+    // (the walker's ray is answered by the wave for all its walkers, ray_closest3_wave: the step is cut in two around it)
+    uint32_t pid = 0;
+    size_t p = 0;
+    V3 x = v3(0.0f, 0.0f, 0.0f), nn = x, dir = x, cur = x;
+    float thp = 0.0f, R_B = 0.0f, pdf = 0.0f, alpha = 1.0f;
+    bool on_n = false, record = false, dropped = false;
+    const float eps = P.st.eps;
+    Pcg rng{0, 1};
     if (live) {
-        const uint32_t pid = P.q_pid[i];
-        const size_t p = pid;
-        const V3 x = v3(P.wx[3 * p], P.wx[3 * p + 1], P.wx[3 * p + 2]);
-        const V3 nn = v3(P.wn[3 * p], P.wn[3 * p + 1], P.wn[3 * p + 2]);
-        const float thp = P.wthp[p], R_B = P.wrb[p];
-        const bool on_n = P.won[p] != 0;
-        const bool record = g3_training_pixel(P, pid) && P.depth < P.max_train_depth;
-        const float eps = P.st.eps;
-        Pcg rng{P.rng[p], 1};
-        V3 dir = v3(0.0f, 0.0f, 0.0f);
-        float pdf = 0.0f, alpha = 1.0f;
-        bool dropped = false;
+        pid = P.q_pid[i];
+        p = pid;
+        x = v3(P.wx[3 * p], P.wx[3 * p + 1], P.wx[3 * p + 2]);
+        nn = v3(P.wn[3 * p], P.wn[3 * p + 1], P.wn[3 * p + 2]);
+        thp = P.wthp[p]; R_B = P.wrb[p];
+        on_n = P.won[p] != 0;
+        record = g3_training_pixel(P, pid) && P.depth < P.max_train_depth;
+        rng = Pcg{P.rng[p], 1};
         auto uniform_dir = [&]() {
             const float u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
             float c, s;
@@ -3054,17 +3099,23 @@ __global__ __launch_bounds__(256) void g3_sample_kernel(G3Params P)
                 }
             }
         }
+        cur = x;
+        if (on_n) cur = v3(x.x + eps * nn.x, x.y + eps * nn.y, x.z + eps * nn.z);
+    }
+    const bool go = live && !dropped;
+    float t = 0.0f;
+    int hi = -1;
+    if (P.nm.n_tris > 0) {
+        if (pooled) hit = ray_closest3_wave(P.nm, cur, dir, R_B, go, t, hi, W, stk, 32);
+        else if (go) hit = ray_closest3<NTREE>(P.nm, cur, dir, R_B, t, hi, stk);
+    }
+    if (live) {
         if (dropped) {
             P.state[p] = 0;
         } else {
-            V3 cur = x;
-            if (on_n) cur = v3(x.x + eps * nn.x, x.y + eps * nn.y, x.z + eps * nn.z);
             V3 nxt = v3(x.x + R_B * dir.x, x.y + R_B * dir.y, x.z + R_B * dir.z);
             V3 hn = v3(0.0f, 0.0f, 0.0f);
             if (P.nm.n_tris > 0) {
-                float t;
-                int hi;
-                hit = ray_closest3<NTREE>(P.nm, cur, dir, R_B, t, hi, stk);
                 if (hit) {
                     hn = ld3(P.nm.flat[hi].n);
                     if (dot3(hn, dir) > 0) hn = v3(-hn.x, -hn.y, -hn.z);
@@ -3264,9 +3315,15 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
     hipStream_t stream = c->stream;
     const int d_levels = c->dm.view.n_tris > 0 ? c->dm.view.levels : 1, n_levels = c->nm.view.n_tris > 0 ? c->nm.view.levels : 1;
     const int stack_words = 3 * std::max(d_levels, n_levels) + 4;
-    const size_t lds = (size_t)stack_words * 256 * sizeof(uint32_t);
+    size_t lds = (size_t)stack_words * 256 * sizeof(uint32_t);
     const bool ntree = c->nm.view.n_tris > WOST_FLAT_MAX, emissive = c->nm.view.n_tris > 0 && c->nm.view.emissive;
     G3Params P{};
+    // the tree queries of a wave's walkers through its task pools, as in walk3_kernel (WOST3_WAVE=0: one descent per thread)
+    P.pool_cap = (d_levels <= 11 && n_levels <= 11) ? 512 : 0;
+    if (const char *w = std::getenv("WOST3_WAVE")) P.pool_cap = std::atoi(w) != 0 ? P.pool_cap : 0;
+    if (const char *w = std::getenv("WOST3_POOL_CAP")) P.pool_cap = P.pool_cap ? std::min(4096, std::max(96, std::atoi(w))) : 0;
+    P.pool_offset = stack_words * 256;
+    if (P.pool_cap) lds += (size_t)4 * (2 * (size_t)P.pool_cap + kPool3OwnerWords) * sizeof(uint32_t) + 8;
     P.dm = c->dm.view; P.nm = c->nm.view; P.st = c->dst; P.probe = c->probe; P.mask = c->mask; P.box = g->box;
     P.n_pixels = N; P.shard_index = shard_index; P.shard_count = shard_count;
     P.rng = g->rng; P.sol = g->sol; P.cur_depth = g->cur_depth; P.rec = g->rec; P.state = g->state; P.wx = g->wx; P.wn = g->wn;
