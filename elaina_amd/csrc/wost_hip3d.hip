@@ -1436,7 +1436,10 @@ __device__ __forceinline__ Closest closest_triangle_wave(const DevMesh3 &m, V3 q
 // WAVE = true: the closest-point queries are answered by the wave as a whole as well (closest_triangle_pool) -- every trip of
 // the loop is then "all queries of the wave, then one step for every walker": no lane waits for another's descent.
 template <bool EMISSIVE, bool SOURCE, bool NTREE, bool WAVE = false>
-__global__ __launch_bounds__(kWalk3Threads) void walk3_kernel(Walk3Params P)
+#ifndef WOST3_WAVES
+#define WOST3_WAVES 1       // waves per SIMD walk3_kernel is compiled for (tuning builds override it)
+#endif
+__global__ __launch_bounds__(kWalk3Threads, WOST3_WAVES) void walk3_kernel(Walk3Params P)
 {
     extern __shared__ uint32_t lds_stack[];
     const LdsColumn stk(lds_stack + threadIdx.x, blockDim.x);
