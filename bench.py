@@ -15,8 +15,9 @@ inside the timed region.  Scene upload and acceleration-structure build happen b
 `python bench.py --gpus N` without a launcher starts the N ranks itself (a torch.distributed.run child,
 spawned before this process touches the GPU) and relays rank 0's JSON line; under an external launcher
 (RANK / WORLD_SIZE in the environment) it is one of the ranks.  With the default --config 2 on one GPU
-the line also carries "configs": one pass each of config 3 and config 4 (--no-extras skips them); at
-N > 1 it carries one pass of config 5.
+the line also carries "configs": one pass each of config 3 and config 4 (both network precisions), the 3-D scenes
+(uniform3d, guided3d), a 2-D scene with a Neumann boundary on the tree (neumann2d), the guiding gain and the variance check
+(--no-extras skips them); at N > 1 it carries one pass of config 5.
 
 Prints ONE JSON line on rank 0.
 """
@@ -488,6 +489,77 @@ def run_uniform3d(env, args):
     return out
 
 
+def run_neumann2d(env, args):
+    """A Neumann boundary too large for the flat loops (its silhouette and ray queries on the tree, answered by the wave:
+    wost_coop.h): the non-convex closed curve r(t) = 100 (1 + .2 sin 7t + .05 sin 31t) in 3000 segments, zero flux, around a
+    Dirichlet circle of 400 segments; 512^2, 64 spp, depth 64 (tools/probes/bench2d_coop.py's scene).  One timed solve after a
+    warm-up solve; a band against the oracle."""
+    import numpy as np
+    from elaina_amd import Problem, UniformIntegrator, UniformIntegratorSettings
+    nn, nd = 3000, 400
+    t = np.linspace(0.0, 2.0 * np.pi, nn, endpoint=False)
+    r = 100.0 * (1.0 + 0.2 * np.sin(7 * t) + 0.05 * np.sin(31 * t))
+    nv = np.stack([r * np.cos(t), r * np.sin(t)], 1).astype(np.float32)
+    ns = np.stack([np.arange(nn), (np.arange(nn) + 1) % nn], 1).astype(np.int32)
+    td = np.linspace(0.0, 2.0 * np.pi, nd, endpoint=False)
+    dv = np.stack([15.0 * np.cos(td) + 5.0, 15.0 * np.sin(td) - 3.0], 1).astype(np.float32)
+    ds = np.stack([np.arange(nd), (np.arange(nd) + 1) % nd], 1).astype(np.int32)
+    dc = np.zeros((nd, 6), np.float32)
+    dc[:, 0:3] = (0.5 + 0.5 * np.cos(td))[:, None] * np.array([1.0, 0.5, 0.25])
+    dc[:, 3:6] = 0.3
+    p = Problem(d_verts=dv, d_segs=ds, d_colors=dc, n_verts=nv, n_segs=ns, n_colors=None, probe=(110.0, 0.0, 0.0, 0.0, 1.0))
+    frame, spp, depth, eps = 512, 64, 64, 0.05
+    it = UniformIntegrator(p, UniformIntegratorSettings((frame, frame), spp, depth, eps), device=env.local)
+    it.solve()
+    it.solve()
+    st = it.last_stats
+    e = {"workload": "3000-segment zero-flux Neumann curve around a Dirichlet circle, %dx%d %d spp depth %d eps %g" % (frame, frame, spp, depth, eps),
+         "walk_steps": float(st["walk_steps"]), "kernel_ms": float(st["kernel_ms"]), "value": st["walk_steps"] / (st["kernel_ms"] * 1e-3),
+         "unit": "walk-steps/s"}
+    if not args.no_cpu_baseline:
+        from oracle.oracle import Oracle
+        b, e_ = band_of(frame, 4)
+        ref = Oracle().solve(p.as_dict(), frame, frame, spp, depth, eps, pixel_begin=b, pixel_end=e_, threads=os.cpu_count() or 1)
+        e["rel_l2_vs_oracle"] = rel_l2(it.solution.reshape(-1, 3)[b:e_], ref["field"])
+        e["rel_l2_band"] = "rows %d..%d" % (b // frame, e_ // frame)
+    it.close()
+    return e
+
+
+def run_guided3d(env, args):
+    """GuidedIntegrator<3> on the two 3-D bench scenes at 256^2, 16 spp (8 of them trained), depth 64: the whole solve (walks,
+    network inference per depth, training), as walk-steps per second of wall time."""
+    import numpy as np
+    from elaina_amd.guided import GuidedIntegratorSettings
+    from elaina_amd.integrator3d import GuidedIntegrator3, Problem3, default_net_config3
+    out = {}
+    V, T = icosphere(3, 1.0)
+    col = np.repeat((V[:, 0] * V[:, 1] + V[:, 2]).astype(np.float32)[:, None], 6, axis=1)
+    ball = {"d_verts": V, "d_tris": T, "d_colors": col, "n_verts": None, "n_tris": None, "n_colors": None,
+            "probe": (0.6, (0.0, 0.0, 0.1), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0)), "dirichlet_intensity": 1.0, "neumann_intensity": 1.0}
+    Vi, Ti = icosphere(2, 0.45)
+    shell = {"d_verts": Vi, "d_tris": Ti, "d_colors": np.repeat(Vi[:, :1], 6, axis=1).astype(np.float32), "n_verts": V, "n_tris": T,
+             "n_colors": np.zeros((len(V), 6), np.float32), "probe": (0.7, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0)),
+             "dirichlet_intensity": 1.0, "neumann_intensity": 1.0}
+    frame, spp = 256, 16
+    for name, sd in (("dirichlet_icosphere_1280", ball), ("neumann_shell_1280", shell)):
+        st = GuidedIntegratorSettings(frameSize=(frame, frame), samplesPerPixel=spp, trainSppCount=spp // 2, maxWalkingDepth=64, epsilonShell=2e-3)
+        gi = GuidedIntegrator3(Problem3.from_dict(sd), st, ((-1.1, -1.1, -1.1), (1.1, 1.1, 1.1)), network_config=default_net_config3(), seed=7,
+                               device=env.local)
+        dt = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            gi.solve()
+            dt = time.perf_counter() - t0
+        g = gi.last_stats
+        out[name] = {"workload": "%s guided %dx%d %d spp (train %d) depth 64 eps 2e-3" % (name, frame, frame, spp, spp // 2),
+                     "walk_steps": float(g["walk_steps"]), "guided_steps": float(g["guided_steps"]), "optimizer_steps": float(g["optimizer_steps"]),
+                     "ms_per_step": dt * 1e3, "value": g["walk_steps"] / dt, "unit": "walk-steps/s",
+                     "field_finite": bool(np.isfinite(gi.solution).all())}
+        gi.close()
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -589,6 +661,8 @@ def main():
                 e4h["rel_l2_vs_uniform_field"] = rel_l2(r4h["field"].cpu().numpy(), uniform_field.cpu().numpy())
             extras["cfg4_f16"] = e4h
             extras["uniform3d"] = run_uniform3d(env, args)
+            extras["guided3d"] = run_guided3d(env, args)
+            extras["neumann2d"] = run_neumann2d(env, args)
             extras["guiding_gain"] = run_guiding_gain(env)
             if uniform_field is not None:
                 # SURVEY 8c, guided gate: against a 4096-spp field of the uniform integrator (bit-exact against the
