@@ -33,6 +33,7 @@
 #include "lbvh.h"
 #include "wost_device.h"
 #include "wost_internal.h"
+#include "wost_pool.h"
 
 namespace wost {
 
@@ -624,48 +625,19 @@ __device__ __forceinline__ bool ray3_tree(const DevMesh3 &m, V3 o, V3 d, float t
     return Q.hit;
 }
 
-// ---- the same two queries answered by a whole WAVE for all its walkers together ------------------------------------------
-// Inside a step every lane used to run its own query to completion (closest_silhouette3_tree, ray3_tree): a wave lasts as long
-// as its longest query, and a leaf visit -- twelve edge records, or four triangles, behind per-lane skips -- is executed for
-// the whole wave whenever one lane needs it: 9 % of the vector lanes did work on a 1280-triangle shell (profiles/walk3_valu.json),
-// and a frame of 512^2 walkers cannot be cut into stage queues across the chip either (it has fewer walkers than the chip has
-// lanes: every query would still sit alone in its lane).  Here the work of all walkers of the wave goes through two pools of
-// tasks in LDS -- (owner lane, tree node) and (owner lane, leaf slot) -- and every trip runs ONE body on up to 64 tasks, whoever
-// owns them: a node task measures the four children (and their normal cones) against its owner's bound and pushes those that
-// survive, farthest first, so that the next trip takes every task's nearest child off the top (a 64-wide depth-first descent);
-// a slot task tests the three edge records (or the triangle) of one leaf slot and folds the result into its owner's words
-// with LDS atomics.  Both queries are minima -- over silhouette edges within rmax, over (t, original index) of the hits -- so
-// the order in which candidates are met does not matter and the answer is that of the flat loop, bit for bit; a bound that is
-// tightened later than the serial descent would have (tasks carry no distance and are not re-checked when popped) only costs
-// visits.  The pools are bounded: a trip takes only as many node tasks as leave room for all their children, and a wave that
-// cannot take any (pool full of inner nodes: never seen) answers its queries the old way.
-struct WavePool3 {
-    uint32_t *node, *slot;      // [cap] owner lane << 26 | node index / leaf slot
-    uint32_t *own;              // [10][64] per-owner operands and results
-    int cap;
-};
-constexpr uint32_t kPool3Index = (1u << 26) - 1u;
-constexpr int kPool3OwnerWords = 10 * 64;
-
-__device__ __forceinline__ void wave_lds_fence()
-{
-    // LDS instructions of one wave execute in order: only the compiler has to keep the order
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ void pool3_push(uint32_t *pool, int &n, bool valid, uint32_t value, int lane)
-{
-    const unsigned long long mask = __ballot(valid);
-    if (valid) pool[n + __popcll(mask & ((1ull << lane) - 1ull))] = value;
-    n += __popcll(mask);
-}
-
-__device__ __forceinline__ void node3_level_pos(uint32_t g, int &level, int &pos)
-{
-    level = (31 - __clz((int)(3u * g + 1u))) >> 1;
-    pos = (int)(g - level_first(level));
-}
+// ---- the same queries answered by a whole WAVE for all its walkers together (the loop of wost_pool.h) -----------------------
+// Inside a step every lane used to run its own query to completion (closest_silhouette3_tree, ray3_tree), and its closest
+// triangle in the lane machine of walk3_kernel: a wave lasts as long as its longest query, and a leaf visit -- twelve edge
+// records, or four exact triangle distances, behind per-lane skips -- is executed for the whole wave whenever one lane needs
+// it: 9 % (Neumann shell) and 20 % (Dirichlet icosphere) of the vector lanes did work (profiles/r03_b_*).  A frame of 512^2
+// walkers cannot be cut into stage queues across the chip either: it has fewer walkers than the chip has lanes, every query
+// would still sit alone in its lane.  So the work of the 64 walkers of ONE wave goes through task pools in LDS (wost_pool.h):
+// node tasks measure the four children (boxes, normal cones, slabs) against their owner's bound, slot tasks evaluate one
+// triangle (or its three edge records) and fold the result into the owner's words with LDS atomics.  All three queries are
+// minima -- over bits(d^2) << 32 | original index, over silhouette edges within rmax, over bits(|t|) << 32 | original index --
+// so the answers are the flat loops', bit for bit.
+using WavePool3 = WavePool;
+constexpr int kPool3OwnerWords = 10 * 64;      // per-owner words of the largest of the three queries (the ray)
 
 // closest silhouette edge within rmax of q, for every lane with `active` (all 64 lanes must call)
 __device__ __forceinline__ float closest_silhouette3_wave(const DevMesh3 &m, V3 q, float rmax, bool active, const WavePool3 &W, const LdsColumn &stk)
@@ -678,89 +650,47 @@ __device__ __forceinline__ float closest_silhouette3_wave(const DevMesh3 &m, V3 
         obest[lane] = __float_as_uint(rmax * rmax);
         ofound[lane] = 0u;
     }
-    int n_node = 0, n_slot = 0;
-    pool3_push(W.node, n_node, active, (uint32_t)lane << 26, lane);        // the roots
-    bool overflow = false;
-    wave_lds_fence();
-    while (n_node > 0 || n_slot > 0) {
-        if (n_slot >= 64 || n_node == 0) {
-            const int k = min(64, n_slot);
-            n_slot -= k;
-            if (lane < k) {
-                const uint32_t e = W.slot[n_slot + lane];
-                const int owner = (int)(e >> 26);
-                const V3 oqv = v3(oq[owner], oq[64 + owner], oq[128 + owner]);
-                const float b0 = __uint_as_float(obest[owner]);
-                const bool f0 = ofound[owner] != 0u;
-                float b = b0;
-                bool f = f0;
-                const float4 *rec = m.slotEdges + 12 * (size_t)(e & kPool3Index);
+    const bool done = pool_run(
+        W, m.levels, active, 64,
+        [&](uint32_t g, int owner, bool leaf, bool (&v)[4], uint32_t (&key)[4]) {
+            const V3 oqv = v3(oq[owner], oq[64 + owner], oq[128 + owner]);
+            const float bd = __uint_as_float(obest[owner]) * kSlack3;
+            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+            const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
+            const float d0 = aabb_d2(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, oqv), d1 = aabb_d2(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, oqv);
+            const float d2 = aabb_d2(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, oqv), d3 = aabb_d2(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, oqv);
+            if (leaf) {
+                // the record of a leaf holds the boxes of its four triangles: an edge is tested from the triangle that lists it
+                v[0] = !(d0 > bd); v[1] = !(d1 > bd); v[2] = !(d2 > bd); v[3] = !(d3 > bd);
+            } else {
+                const float4 *cn = m.cones + 6 * (size_t)g;
+                const float4 AX = cn[0], AY = cn[1], AZ = cn[2], CH = cn[3], SH = cn[4], RD = cn[5];
+                const bool c0 = d0 <= bd && cone3_may_hold_silhouette(AX.x, AY.x, AZ.x, CH.x, SH.x, RD.x, v3(0.5f * (LX.x + HX.x), 0.5f * (LY.x + HY.x), 0.5f * (LZ.x + HZ.x)), oqv);
+                const bool c1 = d1 <= bd && cone3_may_hold_silhouette(AX.y, AY.y, AZ.y, CH.y, SH.y, RD.y, v3(0.5f * (LX.y + HX.y), 0.5f * (LY.y + HY.y), 0.5f * (LZ.y + HZ.y)), oqv);
+                const bool c2 = d2 <= bd && cone3_may_hold_silhouette(AX.z, AY.z, AZ.z, CH.z, SH.z, RD.z, v3(0.5f * (LX.z + HX.z), 0.5f * (LY.z + HY.z), 0.5f * (LZ.z + HZ.z)), oqv);
+                const bool c3 = d3 <= bd && cone3_may_hold_silhouette(AX.w, AY.w, AZ.w, CH.w, SH.w, RD.w, v3(0.5f * (LX.w + HX.w), 0.5f * (LY.w + HY.w), 0.5f * (LZ.w + HZ.w)), oqv);
+                key[0] = c0 ? ((__float_as_uint(d0) & ~0x3u) | 0u) : 0xffffffffu;
+                key[1] = c1 ? ((__float_as_uint(d1) & ~0x3u) | 1u) : 0xffffffffu;
+                key[2] = c2 ? ((__float_as_uint(d2) & ~0x3u) | 2u) : 0xffffffffu;
+                key[3] = c3 ? ((__float_as_uint(d3) & ~0x3u) | 3u) : 0xffffffffu;
+            }
+        },
+        [&](uint32_t slot, int owner) {
+            const V3 oqv = v3(oq[owner], oq[64 + owner], oq[128 + owner]);
+            const float b0 = __uint_as_float(obest[owner]);
+            const bool f0 = ofound[owner] != 0u;
+            float b = b0;
+            bool f = f0;
+            const float4 *rec = m.slotEdges + 12 * (size_t)slot;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) silhouette_record_test(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3], oqv, b, f);
-                if (f && (b < b0 || !f0)) {
-                    atomicMin(&obest[owner], __float_as_uint(b));
-                    ofound[owner] = 1u;
-                }
+            for (int c = 0; c < 3; ++c) silhouette_record_test(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3], oqv, b, f);
+            if (f && (b < b0 || !f0)) {
+                atomicMin(&obest[owner], __float_as_uint(b));
+                ofound[owner] = 1u;
             }
-        } else {
-            const int k = min(min(64, n_node), (W.cap - n_node) / 3);
-            if (k <= 0 || n_slot + 4 * k > W.cap) {
-                overflow = true;
-                break;
-            }
-            n_node -= k;
-            const bool t = lane < k;
-            const uint32_t e = t ? W.node[n_node + lane] : 0u;
-            wave_lds_fence();        // the tasks are read before the pushes below overwrite them
-            const uint32_t own_bits = e & ~kPool3Index;
-            bool leaf = false, v0 = false, v1 = false, v2 = false, v3_ = false;
-            uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
-            uint32_t child0 = 0;     // the first child: node index (inner) or leaf slot
-            if (t) {
-                const uint32_t g = e & kPool3Index;
-                const int owner = (int)(e >> 26);
-                int level, pos;
-                node3_level_pos(g, level, pos);
-                const V3 oqv = v3(oq[owner], oq[64 + owner], oq[128 + owner]);
-                const float bd = __uint_as_float(obest[owner]) * kSlack3;
-                const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
-                const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
-                const float d0 = aabb_d2(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, oqv), d1 = aabb_d2(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, oqv);
-                const float d2 = aabb_d2(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, oqv), d3 = aabb_d2(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, oqv);
-                leaf = level == m.levels;
-                if (leaf) {
-                    child0 = 4u * (uint32_t)pos;
-                    v0 = !(d0 > bd); v1 = !(d1 > bd); v2 = !(d2 > bd); v3_ = !(d3 > bd);
-                } else {
-                    child0 = level_first(level + 1) + 4u * (uint32_t)pos;
-                    const float4 *cn = m.cones + 6 * (size_t)g;
-                    const float4 AX = cn[0], AY = cn[1], AZ = cn[2], CH = cn[3], SH = cn[4], RD = cn[5];
-                    const bool c0 = d0 <= bd && cone3_may_hold_silhouette(AX.x, AY.x, AZ.x, CH.x, SH.x, RD.x, v3(0.5f * (LX.x + HX.x), 0.5f * (LY.x + HY.x), 0.5f * (LZ.x + HZ.x)), oqv);
-                    const bool c1 = d1 <= bd && cone3_may_hold_silhouette(AX.y, AY.y, AZ.y, CH.y, SH.y, RD.y, v3(0.5f * (LX.y + HX.y), 0.5f * (LY.y + HY.y), 0.5f * (LZ.y + HZ.y)), oqv);
-                    const bool c2 = d2 <= bd && cone3_may_hold_silhouette(AX.z, AY.z, AZ.z, CH.z, SH.z, RD.z, v3(0.5f * (LX.z + HX.z), 0.5f * (LY.z + HY.z), 0.5f * (LZ.z + HZ.z)), oqv);
-                    const bool c3 = d3 <= bd && cone3_may_hold_silhouette(AX.w, AY.w, AZ.w, CH.w, SH.w, RD.w, v3(0.5f * (LX.w + HX.w), 0.5f * (LY.w + HY.w), 0.5f * (LZ.w + HZ.w)), oqv);
-                    k0 = c0 ? ((__float_as_uint(d0) & ~0x3u) | 0u) : 0xffffffffu;
-                    k1 = c1 ? ((__float_as_uint(d1) & ~0x3u) | 1u) : 0xffffffffu;
-                    k2 = c2 ? ((__float_as_uint(d2) & ~0x3u) | 2u) : 0xffffffffu;
-                    k3 = c3 ? ((__float_as_uint(d3) & ~0x3u) | 3u) : 0xffffffffu;
-                    cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
-                }
-            }
-            // a leaf's triangles whose box is within the bound become slot tasks ...
-            pool3_push(W.slot, n_slot, leaf && v0, own_bits | (child0 + 0u), lane);
-            pool3_push(W.slot, n_slot, leaf && v1, own_bits | (child0 + 1u), lane);
-            pool3_push(W.slot, n_slot, leaf && v2, own_bits | (child0 + 2u), lane);
-            pool3_push(W.slot, n_slot, leaf && v3_, own_bits | (child0 + 3u), lane);
-            // ... an inner node's children node tasks, the farthest first: every task's nearest child ends up in the top 64
-            pool3_push(W.node, n_node, k3 != 0xffffffffu, own_bits | (child0 + (k3 & 3u)), lane);
-            pool3_push(W.node, n_node, k2 != 0xffffffffu, own_bits | (child0 + (k2 & 3u)), lane);
-            pool3_push(W.node, n_node, k1 != 0xffffffffu, own_bits | (child0 + (k1 & 3u)), lane);
-            pool3_push(W.node, n_node, k0 != 0xffffffffu, own_bits | (child0 + (k0 & 3u)), lane);
-        }
-        wave_lds_fence();
-    }
+        });
     float r = WOST_INF;
-    if (overflow) {
+    if (!done) {
         if (active) r = closest_silhouette3_tree(m, q, rmax, stk);
     } else if (active && ofound[lane] != 0u) {
         r = sqrtf(__uint_as_float(obest[lane]));
@@ -784,81 +714,39 @@ __device__ __forceinline__ bool ray_closest3_wave(const DevMesh3 &m, V3 o, V3 d,
         of[384 + lane] = tmax;
         obound[lane] = __float_as_uint(tmax * 1.00001f + 1e-30f);
     }
-    int n_node = 0, n_slot = 0;
-    pool3_push(W.node, n_node, active, (uint32_t)lane << 26, lane);
-    bool overflow = false;
-    wave_lds_fence();
-    while (n_node > 0 || n_slot > 0) {
-        if (n_slot >= slot_trigger || n_node == 0) {
-            const int k = min(64, n_slot);
-            n_slot -= k;
-            if (lane < k) {
-                const uint32_t e = W.slot[n_slot + lane];
-                const int owner = (int)(e >> 26);
-                const uint32_t s = e & kPool3Index;
-                const V3 ro = v3(of[owner], of[64 + owner], of[128 + owner]), rd = v3(of[192 + owner], of[256 + owner], of[320 + owner]);
-                const float4 a = m.tri[3 * (size_t)s], b = m.tri[3 * (size_t)s + 1], c = m.tri[3 * (size_t)s + 2];
-                float t;
-                if (tri_ray3(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), ro, rd, of[384 + owner], t)) {
-                    const float at = fabsf(t);       // (t may be -0)
-                    atomicMin(&okey[owner], ((unsigned long long)__float_as_uint(at) << 32) | (unsigned long long)(uint32_t)m.triOrig[s]);
-                    atomicMin(&obound[owner], __float_as_uint(at * 1.00001f + 1e-30f));
-                }
+    const bool done = pool_run(
+        W, m.levels, active, slot_trigger,
+        [&](uint32_t g, int owner, bool leaf, bool (&v)[4], uint32_t (&key)[4]) {
+            const V3 ro = v3(of[owner], of[64 + owner], of[128 + owner]), rd = v3(of[192 + owner], of[256 + owner], of[320 + owner]);
+            const V3 inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+            const float bd = __uint_as_float(obound[owner]);
+            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+            const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
+            const float d0 = ray_aabb_entry(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, ro, rd, inv, bd), d1 = ray_aabb_entry(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, ro, rd, inv, bd);
+            const float d2 = ray_aabb_entry(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, ro, rd, inv, bd), d3 = ray_aabb_entry(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, ro, rd, inv, bd);
+            if (leaf) {
+                v[0] = d0 <= bd; v[1] = d1 <= bd; v[2] = d2 <= bd; v[3] = d3 <= bd;
+            } else {
+                key[0] = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3u) | 0u) : 0xffffffffu;
+                key[1] = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3u) | 1u) : 0xffffffffu;
+                key[2] = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3u) | 2u) : 0xffffffffu;
+                key[3] = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3u) | 3u) : 0xffffffffu;
             }
-        } else {
-            const int k = min(min(64, n_node), (W.cap - n_node) / 3);
-            if (k <= 0 || n_slot + 4 * k > W.cap) {
-                overflow = true;
-                break;
+        },
+        [&](uint32_t slot, int owner) {
+            const V3 ro = v3(of[owner], of[64 + owner], of[128 + owner]), rd = v3(of[192 + owner], of[256 + owner], of[320 + owner]);
+            const float4 a = m.tri[3 * (size_t)slot], b = m.tri[3 * (size_t)slot + 1], c = m.tri[3 * (size_t)slot + 2];
+            float t;
+            if (tri_ray3(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), ro, rd, of[384 + owner], t)) {
+                const float at = fabsf(t);       // (t may be -0)
+                atomicMin(&okey[owner], ((unsigned long long)__float_as_uint(at) << 32) | (unsigned long long)(uint32_t)m.triOrig[slot]);
+                atomicMin(&obound[owner], __float_as_uint(at * 1.00001f + 1e-30f));
             }
-            n_node -= k;
-            const bool t = lane < k;
-            const uint32_t e = t ? W.node[n_node + lane] : 0u;
-            wave_lds_fence();
-            const uint32_t own_bits = e & ~kPool3Index;
-            bool leaf = false, v0 = false, v1 = false, v2 = false, v3_ = false;
-            uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
-            uint32_t child0 = 0;
-            if (t) {
-                const uint32_t g = e & kPool3Index;
-                const int owner = (int)(e >> 26);
-                int level, pos;
-                node3_level_pos(g, level, pos);
-                const V3 ro = v3(of[owner], of[64 + owner], of[128 + owner]), rd = v3(of[192 + owner], of[256 + owner], of[320 + owner]);
-                const V3 inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                const float bd = __uint_as_float(obound[owner]);
-                const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
-                const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
-                const float d0 = ray_aabb_entry(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, ro, rd, inv, bd), d1 = ray_aabb_entry(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, ro, rd, inv, bd);
-                const float d2 = ray_aabb_entry(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, ro, rd, inv, bd), d3 = ray_aabb_entry(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, ro, rd, inv, bd);
-                leaf = level == m.levels;
-                if (leaf) {
-                    child0 = 4u * (uint32_t)pos;
-                    v0 = d0 <= bd; v1 = d1 <= bd; v2 = d2 <= bd; v3_ = d3 <= bd;
-                } else {
-                    child0 = level_first(level + 1) + 4u * (uint32_t)pos;
-                    k0 = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3u) | 0u) : 0xffffffffu;
-                    k1 = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3u) | 1u) : 0xffffffffu;
-                    k2 = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3u) | 2u) : 0xffffffffu;
-                    k3 = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3u) | 3u) : 0xffffffffu;
-                    cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
-                }
-            }
-            pool3_push(W.slot, n_slot, leaf && v0, own_bits | (child0 + 0u), lane);
-            pool3_push(W.slot, n_slot, leaf && v1, own_bits | (child0 + 1u), lane);
-            pool3_push(W.slot, n_slot, leaf && v2, own_bits | (child0 + 2u), lane);
-            pool3_push(W.slot, n_slot, leaf && v3_, own_bits | (child0 + 3u), lane);
-            pool3_push(W.node, n_node, k3 != 0xffffffffu, own_bits | (child0 + (k3 & 3u)), lane);
-            pool3_push(W.node, n_node, k2 != 0xffffffffu, own_bits | (child0 + (k2 & 3u)), lane);
-            pool3_push(W.node, n_node, k1 != 0xffffffffu, own_bits | (child0 + (k1 & 3u)), lane);
-            pool3_push(W.node, n_node, k0 != 0xffffffffu, own_bits | (child0 + (k0 & 3u)), lane);
-        }
-        wave_lds_fence();
-    }
+        });
     bool hit = false;
     t_out = WOST_INF;
     idx_out = -1;
-    if (overflow) {
+    if (!done) {
         if (active) hit = ray3_tree<false>(m, o, d, tmax, t_out, idx_out, stk);
     } else if (active) {
         const unsigned long long key = okey[lane];
@@ -884,76 +772,33 @@ __device__ __forceinline__ Closest closest_triangle_pool(const DevMesh3 &m, V3 q
         okey[lane] = ((unsigned long long)__float_as_uint(seed.d2) << 32) | so;
         oq[lane] = q.x; oq[64 + lane] = q.y; oq[128 + lane] = q.z;
     }
-    int n_node = 0, n_slot = 0;
-    pool3_push(W.node, n_node, active, (uint32_t)lane << 26, lane);
-    bool overflow = false;
-    wave_lds_fence();
-    while (n_node > 0 || n_slot > 0) {
-        if (n_slot >= slot_trigger || n_node == 0) {
-            const int k = min(64, n_slot);
-            n_slot -= k;
-            if (lane < k) {
-                const uint32_t e = W.slot[n_slot + lane];
-                const int owner = (int)(e >> 26);
-                const uint32_t sl = e & kPool3Index;
-                const int32_t o = m.triOrig[sl];
-                if (o != WOST_FAR_INDEX) {
-                    const float4 a = m.tri[3 * (size_t)sl], b = m.tri[3 * (size_t)sl + 1], c = m.tri[3 * (size_t)sl + 2];
-                    const float d = tri_d2(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), v3(oq[owner], oq[64 + owner], oq[128 + owner]));
-                    atomicMin(&okey[owner], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)o);
-                }
+    const bool done = pool_run(
+        W, m.levels, active, slot_trigger,
+        [&](uint32_t g, int owner, bool leaf, bool (&v)[4], uint32_t (&key)[4]) {
+            const V3 oqv = v3(oq[owner], oq[64 + owner], oq[128 + owner]);
+            const float bd = __uint_as_float((uint32_t)(okey[owner] >> 32)) * kSlack3;
+            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+            const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
+            const float d0 = aabb_d2(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, oqv), d1 = aabb_d2(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, oqv);
+            const float d2 = aabb_d2(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, oqv), d3 = aabb_d2(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, oqv);
+            if (leaf) {
+                v[0] = !(d0 > bd); v[1] = !(d1 > bd); v[2] = !(d2 > bd); v[3] = !(d3 > bd);
+            } else {
+                key[0] = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3u) | 0u) : 0xffffffffu;
+                key[1] = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3u) | 1u) : 0xffffffffu;
+                key[2] = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3u) | 2u) : 0xffffffffu;
+                key[3] = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3u) | 3u) : 0xffffffffu;
             }
-        } else {
-            const int k = min(min(64, n_node), (W.cap - n_node) / 3);
-            if (k <= 0 || n_slot + 4 * k > W.cap) {
-                overflow = true;
-                break;
-            }
-            n_node -= k;
-            const bool t = lane < k;
-            const uint32_t e = t ? W.node[n_node + lane] : 0u;
-            wave_lds_fence();
-            const uint32_t own_bits = e & ~kPool3Index;
-            bool leaf = false, v0 = false, v1 = false, v2 = false, v3_ = false;
-            uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
-            uint32_t child0 = 0;
-            if (t) {
-                const uint32_t g = e & kPool3Index;
-                const int owner = (int)(e >> 26);
-                int level, pos;
-                node3_level_pos(g, level, pos);
-                const V3 oqv = v3(oq[owner], oq[64 + owner], oq[128 + owner]);
-                const float bd = __uint_as_float((uint32_t)(okey[owner] >> 32)) * kSlack3;
-                const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
-                const float4 LX = nd[0], LY = nd[1], LZ = nd[2], HX = nd[3], HY = nd[4], HZ = nd[5];
-                const float d0 = aabb_d2(LX.x, LY.x, LZ.x, HX.x, HY.x, HZ.x, oqv), d1 = aabb_d2(LX.y, LY.y, LZ.y, HX.y, HY.y, HZ.y, oqv);
-                const float d2 = aabb_d2(LX.z, LY.z, LZ.z, HX.z, HY.z, HZ.z, oqv), d3 = aabb_d2(LX.w, LY.w, LZ.w, HX.w, HY.w, HZ.w, oqv);
-                leaf = level == m.levels;
-                if (leaf) {
-                    child0 = 4u * (uint32_t)pos;
-                    v0 = !(d0 > bd); v1 = !(d1 > bd); v2 = !(d2 > bd); v3_ = !(d3 > bd);
-                } else {
-                    child0 = level_first(level + 1) + 4u * (uint32_t)pos;
-                    k0 = (d0 <= bd) ? ((__float_as_uint(d0) & ~0x3u) | 0u) : 0xffffffffu;
-                    k1 = (d1 <= bd) ? ((__float_as_uint(d1) & ~0x3u) | 1u) : 0xffffffffu;
-                    k2 = (d2 <= bd) ? ((__float_as_uint(d2) & ~0x3u) | 2u) : 0xffffffffu;
-                    k3 = (d3 <= bd) ? ((__float_as_uint(d3) & ~0x3u) | 3u) : 0xffffffffu;
-                    cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
-                }
-            }
-            pool3_push(W.slot, n_slot, leaf && v0, own_bits | (child0 + 0u), lane);
-            pool3_push(W.slot, n_slot, leaf && v1, own_bits | (child0 + 1u), lane);
-            pool3_push(W.slot, n_slot, leaf && v2, own_bits | (child0 + 2u), lane);
-            pool3_push(W.slot, n_slot, leaf && v3_, own_bits | (child0 + 3u), lane);
-            pool3_push(W.node, n_node, k3 != 0xffffffffu, own_bits | (child0 + (k3 & 3u)), lane);
-            pool3_push(W.node, n_node, k2 != 0xffffffffu, own_bits | (child0 + (k2 & 3u)), lane);
-            pool3_push(W.node, n_node, k1 != 0xffffffffu, own_bits | (child0 + (k1 & 3u)), lane);
-            pool3_push(W.node, n_node, k0 != 0xffffffffu, own_bits | (child0 + (k0 & 3u)), lane);
-        }
-        wave_lds_fence();
-    }
+        },
+        [&](uint32_t slot, int owner) {
+            const int32_t o = m.triOrig[slot];
+            if (o == WOST_FAR_INDEX) return;
+            const float4 a = m.tri[3 * (size_t)slot], b = m.tri[3 * (size_t)slot + 1], c = m.tri[3 * (size_t)slot + 2];
+            const float d = tri_d2(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), v3(oq[owner], oq[64 + owner], oq[128 + owner]));
+            atomicMin(&okey[owner], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)o);
+        });
     Closest r = seed;
-    if (overflow) {
+    if (!done) {
         if (active) r = closest_triangle(m, q, seed.slot, stk);
     } else if (active) {
         const unsigned long long key = okey[lane];
