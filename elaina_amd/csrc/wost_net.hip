@@ -1009,10 +1009,10 @@ __global__ __launch_bounds__(kNetBlock) void net_backward_kernel(NetLayout L, co
 constexpr int kGridGradBlock = 1024;
 // denc: dL/d(encoding) of point p, level lv at denc + p * ld_point + lv * ld_level (rows of the encoding per point in the
 // fp32 path; level-major in the half-precision path, where every launch then reads only the levels it works on)
-__global__ __launch_bounds__(kGridGradBlock) void grid_grad_kernel(NetLayout L, const float *xy, const float *denc, size_t ld_point, size_t ld_level,
-                                                                   int n, int chunk, int lv0, int lv1, int q0, int q1, int use_lds, fx_t *grad)
+// the work of one block: the points [p0, p0 + chunk) against the levels [lv0, lv1), features [q0, q1)
+__device__ __forceinline__ void grid_grad_block(const NetLayout &L, const float *xy, const float *denc, size_t ld_point, size_t ld_level, int n, int p0,
+                                                int chunk, int lv0, int lv1, int q0, int q1, int use_lds, fx_t *grad, fx_t *acc)
 {
-    extern __shared__ fx_t acc[];
     __shared__ float s_scale[kNetMaxLevels];
     __shared__ uint32_t s_res[kNetMaxLevels], s_off[kNetMaxLevels + 1];
     if (threadIdx.x <= (unsigned)L.n_levels) {
@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(kGridGradBlock) void grid_grad_kernel(NetLayout L, 
     const int n_acc = use_lds ? (int)(L.level_off[lv1] - base) * nq : 0;
     for (int e = threadIdx.x; e < n_acc; e += kGridGradBlock) acc[e] = 0;
     __syncthreads();
-    const int p0 = blockIdx.x * chunk, p1 = min(n, p0 + chunk);
+    const int p1 = min(n, p0 + chunk);
     fx_t *gG = grad + L.n_mlp;
     const int n_lv = lv1 - lv0;
     // The sums are integers, so the order of the additions is free: consecutive work items take
@@ -1119,6 +1119,33 @@ __global__ __launch_bounds__(kGridGradBlock) void grid_grad_kernel(NetLayout L, 
         const fx_t v = acc[e];
         if (v != 0) fx_add(gG + (size_t)(base + e / nq) * nf + q0 + e % nq, v);
     }
+}
+
+__global__ __launch_bounds__(kGridGradBlock) void grid_grad_kernel(NetLayout L, const float *xy, const float *denc, size_t ld_point, size_t ld_level,
+                                                                   int n, int chunk, int lv0, int lv1, int q0, int q1, int use_lds, fx_t *grad)
+{
+    extern __shared__ fx_t acc[];
+    grid_grad_block(L, xy, denc, ld_point, ld_level, n, (int)blockIdx.x * chunk, chunk, lv0, lv1, q0, q1, use_lds, grad, acc);
+}
+
+// ALL level groups of a training step in ONE launch.  The five launches above ran one after the other, each a single wave of
+// blocks (one per CU, its accumulators up to 150 KB of LDS) that spent as long flushing its accumulators as filling them:
+// 137 us of a 400-us step.  Here every group's accumulators fit 72 KB (a larger level is cut into feature slices), so two
+// blocks share a CU, and a block of group g takes chunk[g] points with chunk[g] x (atomics per point of g) about equal for
+// all groups: the whole grid is resident at once, every block flushes once.  The sums are integers: any split is bit-exact.
+struct GridGradPlan {
+    int32_t n_groups;
+    int32_t lv0[16], lv1[16], q0[16], q1[16], chunk[16], first_block[17];
+};
+__global__ __launch_bounds__(kGridGradBlock, 2) void grid_grad_plan_kernel(NetLayout L, const float *xy, const float *denc, size_t ld_point, size_t ld_level,
+                                                                           int n, GridGradPlan plan, fx_t *grad)
+{
+    extern __shared__ fx_t acc[];
+    int g = 0;
+    while (g + 1 < plan.n_groups && (int)blockIdx.x >= plan.first_block[g + 1]) ++g;
+    const int chunk = plan.chunk[g];
+    grid_grad_block(L, xy, denc, ld_point, ld_level, n, ((int)blockIdx.x - plan.first_block[g]) * chunk, chunk, plan.lv0[g], plan.lv1[g], plan.q0[g],
+                    plan.q1[g], 1, grad, acc);
 }
 
 // dW[r][k] += sum_p delta[p][r] * input[p][k] for one layer: a block owns a chunk of points,
@@ -1515,7 +1542,58 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
                                h->d_denc, ld_point, ld_level, n, gchunk, lv0, lv1, q0, q1, use_lds, h->grad);
             ++h->n_launches;
         };
-        int lv = 0;
+        // one launch for all groups when every group fits the budget of two blocks per CU (two-input networks: the three-input
+        // grids are far larger than LDS); WOST_GRID_GRAD_PLAN=0: the launches per group below
+        GridGradPlan plan{};
+        size_t plan_bytes = 0;
+        bool planned = L.dims == 2 && !(std::getenv("WOST_GRID_GRAD_PLAN") && std::atoi(std::getenv("WOST_GRID_GRAD_PLAN")) == 0);
+        for (int lv = 0; planned && lv < L.n_levels;) {
+            int end = lv;
+            size_t bytes = 0;
+            while (end < L.n_levels && bytes + level_bytes(end, L.n_features) <= small) bytes += level_bytes(end++, L.n_features);
+            if (end > lv) {
+                if (plan.n_groups >= 16) { planned = false; break; }
+                const int g = plan.n_groups++;
+                plan.lv0[g] = lv; plan.lv1[g] = end; plan.q0[g] = 0; plan.q1[g] = L.n_features;
+                plan_bytes = std::max(plan_bytes, bytes);
+                lv = end;
+                continue;
+            }
+            int slices = 1;
+            while (slices < L.n_features && level_bytes(lv, (L.n_features + slices - 1) / slices) > small) ++slices;
+            const int per = (L.n_features + slices - 1) / slices;
+            if (level_bytes(lv, per) > small) { planned = false; break; }
+            for (int q0 = 0; q0 < L.n_features; q0 += per) {
+                if (plan.n_groups >= 16) { planned = false; break; }
+                const int g = plan.n_groups++;
+                plan.lv0[g] = lv; plan.lv1[g] = lv + 1; plan.q0[g] = q0; plan.q1[g] = std::min(L.n_features, q0 + per);
+                plan_bytes = std::max(plan_bytes, level_bytes(lv, plan.q1[g] - plan.q0[g]));
+            }
+            ++lv;
+        }
+        if (planned && plan.n_groups > 0) {
+            // equal work per block: chunk[g] x (levels x features of g) about the same for every group, ~ 448 blocks in all (two per CU)
+            double total = 0.0;
+            for (int g = 0; g < plan.n_groups; ++g) total += (double)(plan.lv1[g] - plan.lv0[g]) * (plan.q1[g] - plan.q0[g]);
+            const double per_block = total * (double)n / 448.0;
+            int blocks = 0;
+            for (int g = 0; g < plan.n_groups; ++g) {
+                const double w = (double)(plan.lv1[g] - plan.lv0[g]) * (plan.q1[g] - plan.q0[g]);
+                long long chunk_g = (long long)(per_block / w);
+                chunk_g = std::max<long long>(1024, (chunk_g + 63) / 64 * 64);
+                chunk_g = std::min<long long>(chunk_g, ((long long)n + 63) / 64 * 64);
+                plan.chunk[g] = (int32_t)chunk_g;
+                plan.first_block[g] = blocks;
+                blocks += (int)(((long long)n + chunk_g - 1) / chunk_g);
+            }
+            plan.first_block[plan.n_groups] = blocks;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(grid_grad_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small);
+            const size_t ld_point = half ? (size_t)L.n_features : (size_t)L.enc, ld_level = half ? (size_t)n * L.n_features : (size_t)L.n_features;
+            hipLaunchKernelGGL(grid_grad_plan_kernel, dim3((unsigned)blocks), dim3(kGridGradBlock), plan_bytes, stream, L, xy_dev, h->d_denc, ld_point, ld_level, n,
+                               plan, h->grad);
+            ++h->n_launches;
+        }
+        int lv = planned && plan.n_groups > 0 ? L.n_levels : 0;
         while (lv < L.n_levels) {
             int end = lv;
             size_t bytes = 0;
