@@ -1010,8 +1010,10 @@ constexpr int kGridGradBlock = 1024;
 // denc: dL/d(encoding) of point p, level lv at denc + p * ld_point + lv * ld_level (rows of the encoding per point in the
 // fp32 path; level-major in the half-precision path, where every launch then reads only the levels it works on)
 // the work of one block: the points [p0, p0 + chunk) against the levels [lv0, lv1), features [q0, q1)
+// `replicas` (a power of two, LDS accumulators only): that many copies of the accumulators, a lane adds to copy lane % replicas --
+// on the coarse levels the 64 lanes of a wave fall into a few dozen cells, and LDS atomics on one address are served one by one
 __device__ __forceinline__ void grid_grad_block(const NetLayout &L, const float *xy, const float *denc, size_t ld_point, size_t ld_level, int n, int p0,
-                                                int chunk, int lv0, int lv1, int q0, int q1, int use_lds, fx_t *grad, fx_t *acc)
+                                                int chunk, int lv0, int lv1, int q0, int q1, int use_lds, fx_t *grad, fx_t *acc, int replicas = 1)
 {
     __shared__ float s_scale[kNetMaxLevels];
     __shared__ uint32_t s_res[kNetMaxLevels], s_off[kNetMaxLevels + 1];
@@ -1024,8 +1026,12 @@ __device__ __forceinline__ void grid_grad_block(const NetLayout &L, const float 
     }
     const int nf = L.n_features, nq = q1 - q0;                          // features [q0, q1) of every entry
     const uint32_t base = L.level_off[lv0];                             // first entry of the group
-    const int n_acc = use_lds ? (int)(L.level_off[lv1] - base) * nq : 0;
-    for (int e = threadIdx.x; e < n_acc; e += kGridGradBlock) acc[e] = 0;
+    // accumulators feature-major: [feature][entry] -- entry-major (four 8-byte words per entry) put the lanes of every
+    // atomic instruction 32 bytes apart, on four of the LDS banks
+    const int n_ent = (int)(L.level_off[lv1] - base);
+    const int n_acc = use_lds ? n_ent * nq : 0;
+    for (int e = threadIdx.x; e < n_acc * replicas; e += kGridGradBlock) acc[e] = 0;
+    acc += (size_t)(threadIdx.x & (unsigned)(replicas - 1)) * n_acc;      // this lane's copy
     __syncthreads();
     const int p1 = min(n, p0 + chunk);
     fx_t *gG = grad + L.n_mlp;
@@ -1067,7 +1073,7 @@ __device__ __forceinline__ void grid_grad_block(const NetLayout &L, const float 
                 for (int q = 0; q < 8; ++q) {
                     if (q < q0 || q >= q1) continue;
                     const fx_t v = to_fx(w * dv[q]);
-                    if (use_lds) fx_add(&acc[(lo + idx - base) * nq + (q - q0)], v);
+                    if (use_lds) fx_add(&acc[(q - q0) * n_ent + (int)(lo + idx - base)], v);
                     else fx_add(gG + (size_t)(lo + idx) * nf + q, v);
                 }
             }
@@ -1109,15 +1115,17 @@ __device__ __forceinline__ void grid_grad_block(const NetLayout &L, const float 
             for (int q = 0; q < 8; ++q) {
                 if (q < q0 || q >= q1) continue;
                 const fx_t v = to_fx(w[k] * dv[q]);
-                if (use_lds) fx_add(&acc[(entry[k] - base) * nq + (q - q0)], v);
+                if (use_lds) fx_add(&acc[(q - q0) * n_ent + (int)(entry[k] - base)], v);
                 else fx_add(gG + (size_t)entry[k] * nf + q, v);
             }
         }
     }
     __syncthreads();
+    acc -= (size_t)(threadIdx.x & (unsigned)(replicas - 1)) * n_acc;
     for (int e = threadIdx.x; e < n_acc; e += kGridGradBlock) {
-        const fx_t v = acc[e];
-        if (v != 0) fx_add(gG + (size_t)(base + e / nq) * nf + q0 + e % nq, v);
+        fx_t v = acc[e];
+        for (int r = 1; r < replicas; ++r) v += acc[e + (size_t)r * n_acc];
+        if (v != 0) fx_add(gG + (size_t)(base + e % n_ent) * nf + q0 + e / n_ent, v);
     }
 }
 
@@ -1135,7 +1143,7 @@ __global__ __launch_bounds__(kGridGradBlock) void grid_grad_kernel(NetLayout L, 
 // all groups: the whole grid is resident at once, every block flushes once.  The sums are integers: any split is bit-exact.
 struct GridGradPlan {
     int32_t n_groups;
-    int32_t lv0[16], lv1[16], q0[16], q1[16], chunk[16], first_block[17];
+    int32_t lv0[16], lv1[16], q0[16], q1[16], chunk[16], replicas[16], first_block[17];
 };
 __global__ __launch_bounds__(kGridGradBlock, 2) void grid_grad_plan_kernel(NetLayout L, const float *xy, const float *denc, size_t ld_point, size_t ld_level,
                                                                            int n, GridGradPlan plan, fx_t *grad)
@@ -1145,7 +1153,7 @@ __global__ __launch_bounds__(kGridGradBlock, 2) void grid_grad_plan_kernel(NetLa
     while (g + 1 < plan.n_groups && (int)blockIdx.x >= plan.first_block[g + 1]) ++g;
     const int chunk = plan.chunk[g];
     grid_grad_block(L, xy, denc, ld_point, ld_level, n, ((int)blockIdx.x - plan.first_block[g]) * chunk, chunk, plan.lv0[g], plan.lv1[g], plan.q0[g],
-                    plan.q1[g], 1, grad, acc);
+                    plan.q1[g], 1, grad, acc, plan.replicas[g]);
 }
 
 // dW[r][k] += sum_p delta[p][r] * input[p][k] for one layer: a block owns a chunk of points,
@@ -1547,15 +1555,25 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
         GridGradPlan plan{};
         size_t plan_bytes = 0;
         bool planned = L.dims == 2 && !(std::getenv("WOST_GRID_GRAD_PLAN") && std::atoi(std::getenv("WOST_GRID_GRAD_PLAN")) == 0);
+        int coarse_copies = 4;       // copies of the accumulators of levels below 1024 cells (WOST_GRID_GRAD_COPIES)
+        if (const char *w = std::getenv("WOST_GRID_GRAD_COPIES")) coarse_copies = std::max(1, std::min(8, std::atoi(w)));
+        while (coarse_copies & (coarse_copies - 1)) --coarse_copies;
         for (int lv = 0; planned && lv < L.n_levels;) {
             int end = lv;
             size_t bytes = 0;
-            while (end < L.n_levels && bytes + level_bytes(end, L.n_features) <= small) bytes += level_bytes(end++, L.n_features);
+            const bool coarse = L.level_off[lv + 1] - L.level_off[lv] < 1024u;
+            const size_t budget = coarse ? small / (size_t)coarse_copies : small;
+            while (end < L.n_levels && (L.level_off[end + 1] - L.level_off[end] < 1024u) == coarse && bytes + level_bytes(end, L.n_features) <= budget)
+                bytes += level_bytes(end++, L.n_features);
+            if (end == lv && coarse && level_bytes(lv, L.n_features) <= small) bytes = level_bytes(end++, L.n_features);      // alone, fewer copies
             if (end > lv) {
                 if (plan.n_groups >= 16) { planned = false; break; }
                 const int g = plan.n_groups++;
                 plan.lv0[g] = lv; plan.lv1[g] = end; plan.q0[g] = 0; plan.q1[g] = L.n_features;
-                plan_bytes = std::max(plan_bytes, bytes);
+                int copies = 1;
+                while (copies < 8 && (size_t)(2 * copies) * bytes <= small) copies *= 2;
+                plan.replicas[g] = copies;
+                plan_bytes = std::max(plan_bytes, bytes * (size_t)copies);
                 lv = end;
                 continue;
             }
@@ -1567,6 +1585,7 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
                 if (plan.n_groups >= 16) { planned = false; break; }
                 const int g = plan.n_groups++;
                 plan.lv0[g] = lv; plan.lv1[g] = lv + 1; plan.q0[g] = q0; plan.q1[g] = std::min(L.n_features, q0 + per);
+                plan.replicas[g] = 1;
                 plan_bytes = std::max(plan_bytes, level_bytes(lv, plan.q1[g] - plan.q0[g]));
             }
             ++lv;
