@@ -285,7 +285,9 @@ __global__ __launch_bounds__(NT) void net_forward_mfma_kernel(NetLayout L, const
             pt[u] = SAVE ? train_point(unit, i) : unit * 16 + i;
             valid[u] = pt[u] < n;
             arow[u] = SAVE ? acts + (size_t)unit * 16 * astride + i : nullptr;
-            const float x = valid[u] ? xy[2 * (size_t)pt[u]] : 0.5f, y = valid[u] ? xy[2 * (size_t)pt[u] + 1] : 0.5f;
+            const size_t dims = (size_t)L.dims;      // two inputs, or three (GuidedIntegrator<3>: the NF == 4 branch only)
+            const float x = valid[u] ? xy[dims * (size_t)pt[u]] : 0.5f, y = valid[u] ? xy[dims * (size_t)pt[u] + 1] : 0.5f;
+            const float z = (valid[u] && dims == 3) ? xy[3 * (size_t)pt[u] + 2] : 0.5f;
             if constexpr (NF == 4) {
                 // the reference's grid (4 features per level): one 16-byte gather per corner, all
                 // eight of a point's two levels in flight together; the wrap of the dense index
@@ -294,7 +296,8 @@ __global__ __launch_bounds__(NT) void net_forward_mfma_kernel(NetLayout L, const
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int lv = g + 4 * h;
-                    const float4 f = f32_encode_level(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], x, y);
+                    const float4 f = dims == 3 ? f32_encode_level3(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], x, y, z)
+                                               : f32_encode_level(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], x, y);
                     float2 *st = reinterpret_cast<float2 *>(stage + (u * 16 + i) * SS + lv * 4);
                     st[0] = float2{f.x, f.y};
                     st[1] = float2{f.z, f.w};
@@ -1771,9 +1774,9 @@ static int net_create_dims(int device, const wost_net_config *cfg, uint64_t seed
         const char *unfused = getenv("WOST_NET_FUSED");
         h->fused_backward = !(unfused && atoi(unfused) == 0);
         const char *scalar = getenv("WOST_NET_SCALAR");
-        // (the matrix-core kernels encode two inputs; the three-input network of GuidedIntegrator<3> runs on the scalar kernels)
-        h->use_mfma = dims == 2 && h->L.enc == 32 && h->L.n_neurons == 64 && h->L.n_hidden == 3 && h->L.n_out_padded == 48 &&
-                      h->L.n_features <= 8 && !(scalar && atoi(scalar) != 0);
+        // (three inputs -- GuidedIntegrator<3> -- only with the reference's four features per level: f32_encode_level3)
+        h->use_mfma = (dims == 2 || (dims == 3 && h->L.n_features == 4)) && h->L.enc == 32 && h->L.n_neurons == 64 && h->L.n_hidden == 3 &&
+                      h->L.n_out_padded == 48 && h->L.n_features <= 8 && !(scalar && atoi(scalar) != 0);
     }
     // initialisation (tiny-cuda-nn defaults): MLP xavier uniform, grid uniform(-1e-4, 1e-4)
     std::vector<float> init(h->n_params);

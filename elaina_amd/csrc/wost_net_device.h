@@ -76,6 +76,33 @@ __device__ __forceinline__ float4 f32_encode_level(const float *grid, float sc, 
     return f;
 }
 
+// the same for three inputs (GuidedIntegrator<3>): the eight corners of the cell, the weight of corner k = (wx wy) wz with bit 0 = +x,
+// bit 1 = +y, bit 2 = +z, the dense index in 64 bits -- the arithmetic of encode_point (wost_net.hip)
+__device__ __forceinline__ float4 f32_encode_level3(const float *grid, float sc, uint32_t res, uint32_t lo, uint32_t n_level, float x, float y, float z)
+{
+    float px = __builtin_fmaf(sc, x, 0.5f), py = __builtin_fmaf(sc, y, 0.5f), pz = __builtin_fmaf(sc, z, 0.5f);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    px -= fx;
+    py -= fy;
+    pz -= fz;
+    const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy, iz = (uint32_t)(int)fz;
+    float4 c[8];
+    float w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t cx = ix + (k & 1), cy = iy + ((k >> 1) & 1), cz = iz + ((k >> 2) & 1);
+        w[k] = (((k & 1) ? px : 1.0f - px) * ((k & 2) ? py : 1.0f - py)) * ((k & 4) ? pz : 1.0f - pz);
+        const uint32_t idx = (uint32_t)(((unsigned long long)cx + (unsigned long long)cy * res + (unsigned long long)cz * res * res) % n_level);
+        c[k] = *reinterpret_cast<const float4 *>(grid + (size_t)(lo + idx) * 4);
+    }
+    float4 f = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        f.x += w[k] * c[k].x; f.y += w[k] * c[k].y; f.z += w[k] * c[k].z; f.w += w[k] * c[k].w;
+    }
+    return f;
+}
+
 // The four matrices on one 16-point unit in fp32 (v_mfma_f32_16x16x4_f32, k ascending: bit-identical to the scalar
 // fmaf chains of the oracle), reference network shape.  Lane (i, g) supplies in[s] = encoded feature 4 s + g of point i
 // (s = 0 .. 7) and receives out[4 rt + c] = output 16 rt + 4 c + g of point i.  `wf` = the fragments in LDS.

@@ -29,7 +29,7 @@ def _rand_params3(orc, cfg, seed=5, wscale=0.25, gscale=0.5):
     n = orc.net3_n_params(cfg)
     rng = np.random.default_rng(seed)
     p = rng.uniform(-wscale, wscale, n).astype(np.float32)
-    n_mlp = 64 * 16 + 2 * 64 * 64 + 48 * 64
+    n_mlp = 64 * (4 * cfg.n_levels) + 2 * 64 * 64 + 48 * 64
     p[n_mlp:] = rng.uniform(-gscale, gscale, n - n_mlp).astype(np.float32)
     return p
 
@@ -49,7 +49,7 @@ def test_net3_layout_and_trilinear_encoding(orc):
     assert orc.net3_n_params(cfg) == n_mlp + n_grid
     cfg = _cfg()
     p = _rand_params3(orc, cfg)
-    n_mlp = 64 * 16 + 2 * 64 * 64 + 48 * 64
+    n_mlp = 64 * (4 * cfg.n_levels) + 2 * 64 * 64 + 48 * 64
     # level 0 of the encoding against a numpy restatement: scale 7, res 8, index x + 8 y + 64 z
     rng = np.random.default_rng(2)
     x = rng.uniform(0.02, 0.98, (32, 3)).astype(np.float32)
@@ -86,7 +86,7 @@ def test_net3_backward_matches_finite_differences(orc):
 
     def loss(pp):
         return float((orc.net3_forward(cfg, pp, x).astype(np.float64) * dl).sum())
-    n_mlp = 64 * 16 + 2 * 64 * 64 + 48 * 64
+    n_mlp = 64 * (4 * cfg.n_levels) + 2 * 64 * 64 + 48 * 64
     idx = list(rng.integers(0, n_mlp, 6)) + [int(i) for i in np.flatnonzero(g[n_mlp:])[:6] + n_mlp]
     for i in idx:
         h = 2e-3
@@ -126,9 +126,12 @@ def _hip_cfg(cfg):
 
 
 @pytest.mark.gpu
-def test_gpu_net3_inference_and_training_match_oracle(orc):
+@pytest.mark.parametrize("n_levels", [4, 8])
+def test_gpu_net3_inference_and_training_match_oracle(orc, n_levels):
+    """four levels: the scalar kernels; eight (the reference's network shape): the matrix-core kernels with the trilinear encoding
+    (f32_encode_level3) -- both the oracle's numbers bit for bit"""
     from elaina_amd.guided import GuidingNetwork
-    cfg = _cfg()
+    cfg = default_net_config3(n_levels=n_levels)
     net = GuidingNetwork(_hip_cfg(cfg), seed=3, dims=3)
     assert net.n_params == orc.net3_n_params(cfg)
     p = _rand_params3(orc, cfg, seed=11)
