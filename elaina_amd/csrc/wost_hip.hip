@@ -1239,7 +1239,7 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "coop") {
         h->coop = value != 0;
     } else if (k == "pool_cap") {
-        if (value < 96 || value > 4096) return fail(WOST_ERR_INVALID, "pool_cap must be in 96..4096");
+        if (value < 96 || value > 2048) return fail(WOST_ERR_INVALID, "pool_cap must be in 96..2048");
         h->pool_cap = (int)value;
     } else if (k == "ray_slot_trigger") {
         if (value < 1 || value > 64) return fail(WOST_ERR_INVALID, "ray_slot_trigger must be in 1..64");
@@ -1389,7 +1389,11 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         rp.pool_cap = c->pool_cap;
         rp.pool_offset = (int32_t)(lds / sizeof(uint32_t));
         rp.ray_slot_trigger = c->ray_slot_trigger;
-        const size_t lds_pools = rp.coop ? (size_t)(bs / 64) * (2 * (size_t)rp.pool_cap + kPoolOwnerWords) * sizeof(uint32_t) + 8 : 0;
+        size_t lds_pools = rp.coop ? (size_t)(bs / 64) * (2 * (size_t)rp.pool_cap + kPoolOwnerWords) * sizeof(uint32_t) + 8 : 0;
+        if (lds + lds_pools > 64 * 1024) {      // (the stack columns of a very deep tree leave no room: one descent per lane)
+            rp.coop = 0;
+            lds_pools = 0;
+        }
         // developer experiment: extra LDS per block lowers the number of resident blocks (occupancy sensitivity)
         const size_t lds_round = lds + lds_pools + (getenv("WOST_EXP_LDS_PAD") ? (size_t)atoi(getenv("WOST_EXP_LDS_PAD")) : 0);
         // Walkers that left the previous launch at a query beyond the plain kernel's range wait at the far end of its output queue,

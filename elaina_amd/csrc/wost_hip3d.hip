@@ -2222,7 +2222,12 @@ static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, 
         // the closest-point queries by the wave as well (WOST3_WAVE=0: the lane machine)
         bool wave = c->dm.view.n_tris > 0 && c->dm.view.levels <= 11;
         if (const char *w = std::getenv("WOST3_WAVE")) wave = wave && std::atoi(w) != 0;
-        if (wave || P.coop) lds += (size_t)(bs / 64) * (2 * (size_t)P.pool_cap + kPool3OwnerWords) * sizeof(uint32_t);
+        const size_t lds_pools = (size_t)(bs / 64) * (2 * (size_t)P.pool_cap + kPool3OwnerWords) * sizeof(uint32_t);
+        if (lds + lds_pools > 64 * 1024) {      // (trees of millions of triangles: the stack columns alone fill the block's LDS)
+            wave = false;
+            P.coop = 0;
+        }
+        if (wave || P.coop) lds += lds_pools;
         auto kfn = ntree ? (c->src.rgb ? (emissive ? walk3_kernel<true, true, true> : walk3_kernel<false, true, true>)
                                        : (emissive ? walk3_kernel<true, false, true> : walk3_kernel<false, false, true>))
                          : (c->src.rgb ? (emissive ? walk3_kernel<true, true, false> : walk3_kernel<false, true, false>)
@@ -3171,6 +3176,7 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
     if (const char *w = std::getenv("WOST3_WAVE")) P.pool_cap = std::atoi(w) != 0 ? P.pool_cap : 0;
     if (const char *w = std::getenv("WOST3_POOL_CAP")) P.pool_cap = P.pool_cap ? std::min(4096, std::max(96, std::atoi(w))) : 0;
     P.pool_offset = stack_words * 256;
+    if (P.pool_cap && lds + (size_t)4 * (2 * (size_t)P.pool_cap + kPool3OwnerWords) * sizeof(uint32_t) + 8 > 64 * 1024) P.pool_cap = 0;
     if (P.pool_cap) lds += (size_t)4 * (2 * (size_t)P.pool_cap + kPool3OwnerWords) * sizeof(uint32_t) + 8;
     P.dm = c->dm.view; P.nm = c->nm.view; P.st = c->dst; P.probe = c->probe; P.mask = c->mask; P.box = g->box;
     P.n_pixels = N; P.shard_index = shard_index; P.shard_count = shard_count;
