@@ -3219,6 +3219,10 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
         P.training = training ? 1 : 0; P.uniform_fraction = uniform_fraction; P.first_sample = sample == 0 ? 1 : 0;
         hipLaunchKernelGGL(g3_begin_kernel, dim3(grid_px), dim3(256), 0, stream, P);
         ++launches;
+        // The host looks at the length of a depth's queue only every fourth depth: walkers only ever leave within a sample, so the
+        // last length it has seen bounds the grids of the depths in between (their kernels read the true length on the device),
+        // and a round trip per depth was a fifth of the solve's wall time.
+        uint32_t n_upper = (uint32_t)N;
         for (int depth = 0; depth < s.max_depth; ++depth) {
             P.depth = depth; P.guiding = depth < max_guided_depth ? 1 : 0;
             W3_TRY(hipMemsetAsync(g->q_count, 0, sizeof(uint32_t), stream));
@@ -3229,16 +3233,18 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
                 if (emissive) hipLaunchKernelGGL((g3_separate_kernel<true, false>), dim3(grid_px), dim3(256), lds, stream, P);
                 else hipLaunchKernelGGL((g3_separate_kernel<false, false>), dim3(grid_px), dim3(256), lds, stream, P);
             }
-            W3_TRY(hipMemcpyAsync(g->host_word, g->q_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            W3_TRY(hipStreamSynchronize(stream));
             ++launches;
-            const uint32_t n_out = g->host_word[0];
-            if (n_out == 0) break;
+            if ((depth & 3) == 0) {
+                W3_TRY(hipMemcpyAsync(g->host_word, g->q_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                W3_TRY(hipStreamSynchronize(stream));
+                n_upper = g->host_word[0];
+                if (n_upper == 0) break;
+            }
             if (P.guiding) {
-                const int rc = net_inference_dev(g->net, g->net_in, nullptr, (int)n_out, g->net_out, true, stream, 0);
+                const int rc = net_inference_dev(g->net, g->net_in, g->q_count, (int)n_upper, g->net_out, true, stream, 0);
                 if (rc != WOST_OK) return rc;
             }
-            const unsigned grid_q = (n_out + 255u) / 256u;
+            const unsigned grid_q = (n_upper + 255u) / 256u;
             if (ntree) hipLaunchKernelGGL((g3_sample_kernel<true>), dim3(grid_q), dim3(256), lds, stream, P);
             else hipLaunchKernelGGL((g3_sample_kernel<false>), dim3(grid_q), dim3(256), lds, stream, P);
             ++launches;
