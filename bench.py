@@ -367,7 +367,7 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
         "guided_steps_per_pass": guided_steps / steps, "optimizer_steps_per_pass": opt_steps / steps,
         "train_samples_per_pass": train_samples / steps, "kernel_launches_per_pass": launches / steps / max(env.world, 1),
         "shared_network": bool(args.shared_network and env.world > 1),
-        "network_precision": ("f16 inference (v_mfma_f32_16x16x16_f16), " if half else "fp32 inference (v_mfma_f32_16x16x4_f32), ") +
+        "network_precision": ("f16 inference (v_mfma_f32_16x16x32_f16), " if half else "fp32 inference (v_mfma_f32_16x16x4_f32), ") +
                              ("f16 training passes, fp32 master weights" if half_train else "fp32 training"),
         "roofline": {"bound": "valu", "kernel": "guided_sample_kernel", "counters": sample_kernel,
                      "what": "the dominant kernel of this configuration (one launch per sample: walk, network inference on the matrix "

@@ -429,14 +429,16 @@ __device__ __forceinline__ void mfma_layer_h(const uint2 *wf, int lane, const h4
     for (int u = 0; u < kHalfSub; ++u)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[u][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    static_assert(KT % 2 == 0, "pairs of 16-deep operands (mfma_k32)");
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int kt = 0; kt < KT; kt += 2)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            union { uint2 u; h4_t h; } a;
-            a.u = wf[(rt * KT + kt) * 64 + lane];
+            union { uint2 u; h4_t h; } a0, a1;
+            a0.u = wf[(rt * KT + kt) * 64 + lane];
+            a1.u = wf[(rt * KT + kt + 1) * 64 + lane];
 #pragma unroll
-            for (int u = 0; u < kHalfSub; ++u) acc[u][rt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, b[u][kt], acc[u][rt], 0, 0, 0);
+            for (int u = 0; u < kHalfSub; ++u) acc[u][rt] = mfma_k32(a0.h, a1.h, b[u][kt], b[u][kt + 1], acc[u][rt]);
         }
 }
 

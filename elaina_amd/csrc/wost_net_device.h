@@ -26,6 +26,17 @@ struct NetLayout {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+
+// gfx950's v_mfma_f32_16x16x32_f16 on TWO of the 16-deep operand pairs this library keeps (fragments of four halves per lane, the
+// "chain" layout of the activations): lane (i, g) owns k-slots 8g .. 8g + 7 of the 32-deep product; filling slots 0..3 with the
+// features 16 t0 + 4g + c and slots 4..7 with 16 t1 + 4g + c on BOTH operands is a permutation of the summation index, so
+// acc += A[.][t0] B[t0][.] + A[.][t1] B[t1][.] in one issue -- no relayout of weights or activations, twice the K per instruction.
+__device__ __forceinline__ f32x4_t mfma_k32(h4_t a0, h4_t a1, h4_t b0, h4_t b1, f32x4_t acc)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7),
+                                                  acc, 0, 0, 0);
+}
 
 // The half-precision image of the inference weights ("precision" 16): MFMA fragments of the four matrices
 // (n_mlp / 4 entries of 8 bytes, layout of fragment_mlp_h_kernel), then the grid entry by entry (4 features in f16).
@@ -189,13 +200,14 @@ __device__ __forceinline__ void half_mlp_unit(const uint2 *wf, const uint32_t (&
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; kt += 2)
             if (kt < KT) {
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
-                    union { uint2 u; h4_t h; } a;
-                    a.u = w[(rt * KT + kt) * 64 + lane];
-                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, b[kt], acc[rt], 0, 0, 0);
+                    union { uint2 u; h4_t h; } a0, a1;
+                    a0.u = w[(rt * KT + kt) * 64 + lane];
+                    a1.u = w[(rt * KT + kt + 1) * 64 + lane];
+                    acc[rt] = mfma_k32(a0.h, a1.h, b[kt], b[kt + 1], acc[rt]);
                 }
             }
 #pragma unroll
@@ -205,12 +217,13 @@ __device__ __forceinline__ void half_mlp_unit(const uint2 *wf, const uint32_t (&
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt) acc[rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < 4; kt += 2)
 #pragma unroll
         for (int rt = 0; rt < 3; ++rt) {
-            union { uint2 u; h4_t h; } a;
-            a.u = w3[(rt * 4 + kt) * 64 + lane];
-            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, b[kt], acc[rt], 0, 0, 0);
+            union { uint2 u; h4_t h; } a0, a1;
+            a0.u = w3[(rt * 4 + kt) * 64 + lane];
+            a1.u = w3[(rt * 4 + kt + 1) * 64 + lane];
+            acc[rt] = mfma_k32(a0.h, a1.h, b[kt], b[kt + 1], acc[rt]);
         }
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt) out[rt] = __builtin_convertvector(acc[rt], h4_t);

@@ -2,7 +2,8 @@
 // after its layout / fixed-point definitions and the half-precision inference kernel).
 //
 // "train_precision" 16 of wost_net_set_option: the forward pass, the backward pass and the weight
-// gradients of a training step run on v_mfma_f32_16x16x16_f16 with f16 operands and fp32
+// gradients of a training step run on v_mfma_f32_16x16x32_f16 (layers, backward products: mfma_k32) and v_mfma_f32_16x16x16_f16
+// (weight gradients: K = the 16 points of a unit) with f16 operands and fp32
 // accumulation -- the arithmetic the reference's tiny-cuda-nn network trains in (util/network.h:21-196,
 // half precision with loss scale 128, guided/parameters.h:13).  Master weights, Adam and the EMA stay
 // fp32; the gradient sums stay 64-bit fixed point, so a step is still reproducible bit for bit (the
@@ -85,13 +86,15 @@ __device__ __forceinline__ void hidden_h(const uint2 *wf, int lane, const h4_t (
     f32x4_t acc[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    static_assert(KT % 2 == 0, "pairs of 16-deep operands (mfma_k32)");
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int kt = 0; kt < KT; kt += 2)
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            HalfFrag a;
-            a.u = wf[(rt * KT + kt) * 64 + lane];
-            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, in[kt], acc[rt], 0, 0, 0);
+            HalfFrag a0, a1;
+            a0.u = wf[(rt * KT + kt) * 64 + lane];
+            a1.u = wf[(rt * KT + kt + 1) * 64 + lane];
+            acc[rt] = mfma_k32(a0.h, a1.h, in[kt], in[kt + 1], acc[rt]);
         }
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) out[rt] = relu_pack(acc[rt]);
@@ -118,14 +121,24 @@ __device__ __forceinline__ void back_h(const uint2 *wb, int lane, const h4_t (&d
 {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) acc[kt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    // pairs of output tiles in one 32-deep instruction (mfma_k32); the 48-row output layer leaves one tile over
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt + 1 < RT; rt += 2)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            HalfFrag a0, a1;
+            a0.u = wb[(kt * RT + rt) * 64 + lane];
+            a1.u = wb[(kt * RT + rt + 1) * 64 + lane];
+            acc[kt] = mfma_k32(a0.h, a1.h, d[rt], d[rt + 1], acc[kt]);
+        }
+    if (RT % 2) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             HalfFrag a;
-            a.u = wb[(kt * RT + rt) * 64 + lane];
-            acc[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, d[rt], acc[kt], 0, 0, 0);
+            a.u = wb[(kt * RT + RT - 1) * 64 + lane];
+            acc[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, d[RT - 1], acc[kt], 0, 0, 0);
         }
+    }
 }
 
 // delta of the hidden layer whose activations are a: relu'(a) * acc, saturated, f16
