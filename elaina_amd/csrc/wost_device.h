@@ -779,7 +779,10 @@ __device__ __forceinline__ float ray_obb_entry(float cx, float cy, float ux, flo
     const float wx = ox - cx, wy = oy - cy;
     const float ou = wx * ux + wy * uy, ov = wy * ux - wx * uy;
     const float du = dx * ux + dy * uy, dv = dy * ux - dx * uy;
-    const float slack = 1e-4f * (fabsf(ou) + fabsf(ov) + hl + hw) + 1e-30f;
+    // (the second term: the record's centre and axis are the ROUNDED image of a segment whose exact test runs on its end points;
+    // on a fine mesh far from the origin -- segments of 0.02 at |x| = 100 -- that image lies several 10^-6 off the segment, more
+    // than the relative widening: a ray that starts on the boundary was missed by the box and hit by the flat loop)
+    const float slack = 1e-4f * (fabsf(ou) + fabsf(ov) + hl + hw) + 2.4e-7f * (fabsf(cx) + fabsf(cy)) + 1e-30f;
     const float hlp = hl + slack, hwp = hw + slack;
     float t0 = 0.0f, t1 = tmax;
     // slab along u

@@ -311,6 +311,39 @@ def test_large_neumann_mesh_silhouette_and_ray_queries(oracle, open_gap):
     it.close()
 
 
+def test_fine_neumann_mesh_rays_that_start_on_the_boundary(oracle):
+    """30 000 segments of length 0.02 at |x| ~ 100: the node records are rounded images of the segments, several 10^-6 off the
+    end points the exact test runs on -- more than the relative widening of the ray / box test allowed before round 3: rays that
+    start on the boundary (a walker that has just hit it) were missed by the box of the very segment they stand on (630 of
+    200 000 such rays; found by tools/probes/bench2d_coop.py with N_NEUMANN=30000).  Queries and a whole solve against the
+    flat loops of the oracle."""
+    from conftest import wiggly_problem
+    p = wiggly_problem(30000, 64)
+    it = _integrator(p, 16, 16, 1, 4, 1.0)
+    rng = np.random.default_rng(9)
+    n = 60000
+    V, S = p.n_verts, p.n_segs
+    si = rng.integers(0, len(S), n)
+    a, b = V[S[si, 0]], V[S[si, 1]]
+    on = (a + (b - a) * rng.uniform(0, 1, (n, 1)).astype(np.float32)).astype(np.float32)
+    e = b - a
+    nrm = np.stack([e[:, 1], -e[:, 0]], 1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    pts = (on + rng.choice([0.0, 0.0, 0.05, -0.05, 1e-3, -1e-3], n)[:, None].astype(np.float32) * nrm).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, size=n)
+    d = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+    tmax = (rng.uniform(0.5, 1.0, n) * rng.choice([0.03, 0.5, 10.0], n)).astype(np.float32)
+    gh, gt, gi = it.ray_intersect(pts, d, tmax)
+    rh, rt, ri = oracle.ray_intersect(V, S, pts, d, tmax)
+    assert np.array_equal(gh, rh) and 0.1 < rh.mean() < 0.95
+    hit = rh == 1
+    assert np.array_equal(gt[hit], rt[hit]) and np.array_equal(gi[hit], ri[hit])
+    assert np.array_equal(it.closest_silhouette(pts, np.full(n, 0.5, np.float32)), oracle.closest_silhouette(V, S, pts, np.full(n, 0.5, np.float32)))
+    it.close()
+    _assert_same_solve(oracle, wiggly_problem(30000, 400), 48, 48, 4, 64, 0.05)
+    _assert_same_solve(oracle, wiggly_problem(30000, 400), 48, 48, 4, 64, 0.05, coop=0)
+
+
 @pytest.mark.parametrize("opts", [{}, {"refill": 1}])
 def test_large_neumann_mesh_solve(oracle, opts):
     from conftest import wiggly_problem
