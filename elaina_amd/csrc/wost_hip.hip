@@ -1057,7 +1057,7 @@ struct wost_context {
     int quad = -1;         // four lanes per walker in under-filled launches: -1 = automatic, 0 = never, 1 = every ordinary round
     double quad_fill = 1.0;   // automatic: when 4 x walkers <= quad_fill x resident lanes
     int coop = 1;             // a Neumann mesh on the tree: its silhouette and ray queries by the wave as a whole (wost_coop.h); 0 = per lane
-    int pool_cap = 384;       // ... tasks per pool and wave
+    int pool_cap = 0;         // ... tasks per pool and wave; 0 = automatic: 128 per level of the Neumann tree (a deeper tree keeps more tasks in flight)
     int ray_slot_trigger = 32;
     uint32_t *cursor = nullptr;
     hipStream_t far_stream = nullptr;          // the launches that take strayed walkers through the SLACK kernel (run_solve)
@@ -1239,7 +1239,7 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "coop") {
         h->coop = value != 0;
     } else if (k == "pool_cap") {
-        if (value < 96 || value > 2048) return fail(WOST_ERR_INVALID, "pool_cap must be in 96..2048");
+        if (value != 0 && (value < 96 || value > 2048)) return fail(WOST_ERR_INVALID, "pool_cap must be 0 (automatic) or in 96..2048");
         h->pool_cap = (int)value;
     } else if (k == "ray_slot_trigger") {
         if (value < 1 || value > 64) return fail(WOST_ERR_INVALID, "ray_slot_trigger must be in 1..64");
@@ -1386,11 +1386,14 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         rp.trav_burst = c->trav_burst;
         // a Neumann mesh on the tree: the task pools of every wave behind the stack columns (wost_coop.h)
         rp.coop = (ntree && c->coop && c->nm.view.levels <= 11) ? 1 : 0;
-        rp.pool_cap = c->pool_cap;
+        rp.pool_cap = c->pool_cap > 0 ? c->pool_cap : std::min(1024, std::max(384, 128 * c->nm.view.levels));
         rp.pool_offset = (int32_t)(lds / sizeof(uint32_t));
         rp.ray_slot_trigger = c->ray_slot_trigger;
-        size_t lds_pools = rp.coop ? (size_t)(bs / 64) * (2 * (size_t)rp.pool_cap + kPoolOwnerWords) * sizeof(uint32_t) + 8 : 0;
-        if (lds + lds_pools > 64 * 1024) {      // (the stack columns of a very deep tree leave no room: one descent per lane)
+        auto pools_bytes = [&](int cap) { return (size_t)(bs / 64) * (2 * (size_t)cap + kPoolOwnerWords) * sizeof(uint32_t) + 8; };
+        // (the automatic size gives way to the stack columns of a deep Dirichlet tree; with no room at all: one descent per lane)
+        while (c->pool_cap <= 0 && rp.pool_cap > 256 && lds + pools_bytes(rp.pool_cap) > 64 * 1024) rp.pool_cap -= 64;
+        size_t lds_pools = rp.coop ? pools_bytes(rp.pool_cap) : 0;
+        if (lds + lds_pools > 64 * 1024) {
             rp.coop = 0;
             lds_pools = 0;
         }
