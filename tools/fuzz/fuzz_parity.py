@@ -46,6 +46,19 @@ def random_problem(rng):
         g = rng.uniform(-1, 1, (9, 7, 3)).astype(np.float32)
         kw["source"] = {"rgb": g, "index_scale": (3.0 / scale, 4.0 / scale), "index_offset": (3.0, 4.0), "intensity": 0.1 * scale ** -2}
     feat.append('view %.3g' % (view / scale))
+    if rng.uniform() < 0.3:
+        # the whole scene far from the origin: coordinates 10 .. 300 scene sizes large, so the rounding of the coordinates themselves
+        # (node records, probe, walk positions) is no longer small against the segments (found a ray / box miss in round 3)
+        off = (scale * rng.choice([10.0, 100.0, 300.0]) * rng.uniform(0.5, 1.0, 2) * rng.choice([-1.0, 1.0], 2)).astype(np.float32)
+        feat.append('offset %.3g %.3g' % (off[0] / scale, off[1] / scale))
+        kw["d_verts"] = (kw["d_verts"] + off).astype(np.float32)
+        if kw.get("n_verts") is not None:
+            kw["n_verts"] = (kw["n_verts"] + off).astype(np.float32)
+        pr = kw["probe"]
+        kw["probe"] = (pr[0], pr[1] + float(off[0]), pr[2] + float(off[1]), pr[3], pr[4])
+        if "source" in kw:
+            so = kw["source"]
+            so["index_offset"] = (so["index_offset"][0] - float(off[0]) * so["index_scale"][0], so["index_offset"][1] - float(off[1]) * so["index_scale"][1])
     return Problem(**kw), scale, feat
 
 

@@ -43,7 +43,18 @@ def random_scene(rng):
     feat.append("view %g" % view)
     up = rng.normal(size=3); up /= np.linalg.norm(up)
     right = np.cross(up, rng.normal(size=3)); right /= np.linalg.norm(right)
-    sd["probe"] = (view * scale, tuple(rng.uniform(-0.1, 0.1, 3) * scale), tuple(up), tuple(right))
+    pos = rng.uniform(-0.1, 0.1, 3) * scale
+    sd["offset"] = np.zeros(3, np.float32)
+    if rng.uniform() < 0.3:
+        # the whole scene far from the origin: the rounding of the coordinates is no longer small against the triangles
+        off = (scale * rng.choice([10.0, 100.0, 300.0]) * rng.uniform(0.5, 1.0, 3) * rng.choice([-1.0, 1.0], 3)).astype(np.float32)
+        feat.append("offset %.3g %.3g %.3g" % tuple(off / scale))
+        sd["d_verts"] = (sd["d_verts"] + off).astype(np.float32)
+        if sd["n_verts"] is not None:
+            sd["n_verts"] = (sd["n_verts"] + off).astype(np.float32)
+        pos = pos + off
+        sd["offset"] = off
+    sd["probe"] = (view * scale, tuple(float(x) for x in pos), tuple(up), tuple(right))
     return sd, scale, feat
 
 
@@ -58,8 +69,9 @@ def main():
         eps = scale * 10.0 ** rng.uniform(-3.5, -1.5)
         if rng.uniform() < 0.25:
             feat.append("source")
-            sd["source"] = {"rgb": rng.uniform(-1, 1, (4, 5, 6, 3)).astype(np.float32), "index_scale": (2.5 / scale, 2.0 / scale, 1.5 / scale),
-                            "index_offset": (3.0, 2.5, 2.0), "intensity": 0.1 * scale ** -2}
+            isc = (2.5 / scale, 2.0 / scale, 1.5 / scale)
+            sd["source"] = {"rgb": rng.uniform(-1, 1, (4, 5, 6, 3)).astype(np.float32), "index_scale": isc,
+                            "index_offset": tuple(float(o - f * k) for o, f, k in zip((3.0, 2.5, 2.0), sd["offset"], isc)), "intensity": 0.1 * scale ** -2}
         if rng.uniform() < 0.2:
             feat.append("mask")
             sd["mask"] = (rng.uniform(size=w * h) < 0.7).astype(np.uint8)
