@@ -153,6 +153,7 @@ class GuidedStats(C.Structure):
 # wost_sync_fn (include/wost.h): int (*)(void *user, int op, void *data, uint64_t count)
 SYNC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64)
 SYNC_SUM_I64_DEVICE, SYNC_MIN_I64_HOST, SYNC_RANKS_I64_HOST = 0, 1, 2
+SYNC_UNSUPPORTED = 2       # callback return value for an unknown op
 # wost_frame_fn: int (*)(void *user, int reason, int32_t sample_id, double elapsed_ms, const float *field_rgb)
 FRAME_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_double, C.POINTER(C.c_float))
 
@@ -162,7 +163,7 @@ EXPORTS = [
     "wost_vonmises_eval", "wost_vonmises_sample", "wost_vmm_pdf_sample", "wost_vmm_loss_gradients",
     "wost_net_create", "wost_net_destroy", "wost_net_n_params", "wost_net_get_params",
     "wost_net_set_params", "wost_net_set_gradient_buffer", "wost_net_inference", "wost_net_train_step", "wost_net_set_option",
-    "wost_guided_create", "wost_guided_set_sync", "wost_guided_set_frame_callback", "wost_guided_network", "wost_guided_scene", "wost_guided_query_network", "wost_guided_solve", "wost_guided_solve_sharded", "wost_guided_train_set", "wost_guided_destroy",
+    "wost_guided_create", "wost_guided_set_sync", "wost_guided_set_frame_callback", "wost_guided_network", "wost_guided_scene", "wost_guided_query_network", "wost_guided_solve", "wost_guided_solve_sharded", "wost_guided_train_set", "wost_guided_set_option", "wost_guided_destroy",
     "wost3_create", "wost3_solve", "wost3_solve_sharded", "wost3_closest_point", "wost3_closest_silhouette", "wost3_ray_intersect",
     "wost3_render_sdf", "wost3_render_source", "wost3_destroy", "wost3_vmf_eval", "wost3_vmf_sample", "wost3_vmm_pdf_sample", "wost3_vmm_loss_gradients",
     "wost3_net_create", "wost3_guided_create", "wost3_guided_destroy", "wost3_guided_network", "wost3_guided_solve", "wost3_guided_solve_sharded",
@@ -229,6 +230,7 @@ def load():
     L.wost_guided_solve.argtypes = [C.c_void_p, fp, C.POINTER(GuidedStats)]
     L.wost_guided_solve_sharded.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(GuidedStats)]
     L.wost_guided_train_set.argtypes = [C.c_void_p, C.c_int32, ip, fp, fp, fp, fp, fp, C.POINTER(C.c_uint8)]
+    L.wost_guided_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.wost_guided_destroy.argtypes = [C.c_void_p]
     L.wost_destroy.argtypes = [C.c_void_p]
     L.wost3_create.argtypes = [C.POINTER(Scene3Desc), C.POINTER(Settings), C.c_int, C.POINTER(C.c_void_p)]

@@ -143,7 +143,8 @@ struct GParams {
     uint64_t *rng;            // per pixel (inc == 1)
     float *sol;               // per pixel rgb
     uint32_t *cur_depth;      // per pixel: training records of the current sample
-    float *rec;               // [slot][field][n_pixels]
+    float *rec;               // [slot][field][rec_ld]: record set j of pixel p at column j * n_pixels + p (one set unless a launch
+    size_t rec_ld;            //   trains on several samples of a pixel: "train_group"); cur_depth is indexed by the same column
     int32_t *hint0;           // per pixel: closest slot of the evaluation point
     float *net_in;            // [2 * slot]
     const float *net_out;     // [33][net_ld]: output o of queue slot s at net_out[o * net_ld + s]
@@ -168,7 +169,8 @@ struct GParams {
     int32_t stack_words;      // LDS words of a lane's traversal stack
     int32_t wait_weight, trav_burst;
     int32_t tail_chunk, tail_margin_pct;   // reservation size near the end of the launch; how near, in % of the launch's lanes
-    int32_t n_samples;        // samples of every pixel in this launch (> 1 only when nothing is trained in between)
+    int32_t n_samples;        // samples of every pixel in this launch (> 1: nothing is trained between them)
+    uint32_t *pstate;         // n_samples > 1: per pixel, samples of this launch that have arrived << 16 | that are complete (zero at the start)
     int32_t d0_valid;         // d0_d2 holds the query of every evaluation point (after the first fused launch of a solve)
     unsigned long long *dbg;  // WOST_GUIDED_DEBUG: [0] first start, [1] first wave out of pixels, [2] last wave out of pixels, [3] end (100 MHz ticks)
 };
@@ -185,26 +187,48 @@ struct FusedNet {
     uint32_t res[8], off[9];
 };
 
+// Per-pixel state that one lane leaves and ANOTHER lane -- another CU, another XCD -- may pick up inside the same launch (the
+// samples of a pixel are handed from lane to lane, guided_sample_kernel): its loads and stores bypass the CU's vector L1, which
+// no other CU's store ever refreshes (agent-scope relaxed = `sc1`), and the hand-over itself is an agent-scope atomic on the
+// pixel's state word after the storing wave has drained its stores.
+template <class T>
+__device__ __forceinline__ T ld_px(const T *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ __forceinline__ void st_px(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void add_px(float *s, float r, float g, float b)
+{
+    st_px(s, r + ld_px(s));
+    st_px(s + 1, g + ld_px(s + 1));
+    st_px(s + 2, b + ld_px(s + 2));
+}
+
 __device__ __forceinline__ bool is_training_pixel(const GParams &P, uint32_t pid)
 {
     return P.training && ((pid - P.train_offset) % P.train_stride == 0u);
 }
 
-__device__ __forceinline__ float &rec_at(const GParams &P, int slot, int field, uint32_t pid)
+// `rp` = record column of the pixel: pid + (record set of the sample) * n_pixels
+__device__ __forceinline__ float &rec_at(const GParams &P, int slot, int field, uint32_t rp)
 {
-    return P.rec[((size_t)slot * kRecFields + field) * (size_t)P.n_pixels + pid];
+    return P.rec[((size_t)slot * kRecFields + field) * P.rec_ld + rp];
 }
 
 // recordSolution / recordSourceContribution (reference guided.h:48-68): add to every record
 // this walk has already created.  (The reference's inclusive variant also touches the slot of
 // the record not yet created, which incrementDepth then wipes: no observable effect.)
-__device__ __forceinline__ void record_solution(const GParams &P, uint32_t pid, float r, float g, float b)
+__device__ __forceinline__ void record_solution(const GParams &P, uint32_t rp, float r, float g, float b)
 {
-    const uint32_t n = min(P.cur_depth[pid], (uint32_t)kMaxTrainDepth);
+    const uint32_t n = min(P.cur_depth[rp], (uint32_t)kMaxTrainDepth);
     for (uint32_t i = 0; i < n; ++i) {
-        rec_at(P, i, 0, pid) = rec_at(P, i, 0, pid) + r;
-        rec_at(P, i, 1, pid) = rec_at(P, i, 1, pid) + g;
-        rec_at(P, i, 2, pid) = rec_at(P, i, 2, pid) + b;
+        rec_at(P, i, 0, rp) = rec_at(P, i, 0, rp) + r;
+        rec_at(P, i, 1, rp) = rec_at(P, i, 1, rp) + g;
+        rec_at(P, i, 2, rp) = rec_at(P, i, 2, rp) + b;
     }
 }
 
@@ -279,14 +303,14 @@ enum { SEP_ABSORBED = 0, SEP_DROPPED = 1, SEP_KEEP = 2 };
 template <bool EMISSIVE, bool TREE, bool SOURCE>
 __device__ __forceinline__ int separate_finish(const GParams &P, uint32_t pid, bool on_n, float x, float y, float thp, float nx,
                                                float ny, int depth, Closest cp, int32_t &hint, float &R_B, Pcg &rng,
-                                               const LdsColumn &stk)
+                                               const LdsColumn &stk, uint32_t rofs = 0u)
 {
     const bool train_px = is_training_pixel(P, pid);
     const float eps = P.st.eps;
     float R_D = WOST_INF;
     if (P.dm.n_segs > 0) {
         hint = cp.slot;
-        if (depth == 0) P.hint0[pid] = cp.slot;
+        if (depth == 0) st_px(P.hint0 + pid, (int32_t)cp.slot);
         const float4 a = P.dm.segA[cp.slot];
         const float inv = P.dm.segInv[cp.slot];
         const float wx = x - a.x, wy = y - a.y;
@@ -299,9 +323,8 @@ __device__ __forceinline__ int separate_finish(const GParams &P, uint32_t pid, b
             surface_color(P.dm.segCol + 12 * (size_t)cp.slot, side, uv, r, g, b);
             r *= P.st.dirichlet_intensity; g *= P.st.dirichlet_intensity; b *= P.st.dirichlet_intensity;
             r *= thp; g *= thp; b *= thp;
-            float *s = P.sol + 3 * (size_t)pid;
-            s[0] = r + s[0]; s[1] = g + s[1]; s[2] = b + s[2];
-            if (train_px) record_solution(P, pid, r, g, b);
+            add_px(P.sol + 3 * (size_t)pid, r, g, b);
+            if (train_px) record_solution(P, pid + rofs, r, g, b);
             return SEP_ABSORBED;
         }
     }
@@ -312,17 +335,15 @@ __device__ __forceinline__ int separate_finish(const GParams &P, uint32_t pid, b
     if (SOURCE) {
         float cr, cg, cb;
         if (source_sample<TREE>(P.src, P.nm, eps, x, y, R_B, on_n, nx, ny, thp, rng, stk, cr, cg, cb)) {
-            float *s = P.sol + 3 * (size_t)pid;
-            s[0] = cr + s[0]; s[1] = cg + s[1]; s[2] = cb + s[2];
-            if (train_px) record_solution(P, pid, cr, cg, cb);
+            add_px(P.sol + 3 * (size_t)pid, cr, cg, cb);
+            if (train_px) record_solution(P, pid + rofs, cr, cg, cb);
         }
     }
     if (P.nm.n_segs > 0) {
         float cr, cg, cb;
         if (neumann_sample<EMISSIVE, TREE>(P.nm, P.st.neumann_intensity, eps, x, y, R_B, on_n, nx, ny, thp, rng, stk, cr, cg, cb)) {
-            float *s = P.sol + 3 * (size_t)pid;
-            s[0] = cr + s[0]; s[1] = cg + s[1]; s[2] = cb + s[2];
-            if (train_px) record_solution(P, pid, cr, cg, cb);
+            add_px(P.sol + 3 * (size_t)pid, cr, cg, cb);
+            if (train_px) record_solution(P, pid + rofs, cr, cg, cb);
         }
     }
     return SEP_KEEP;
@@ -339,19 +360,19 @@ __device__ __forceinline__ int separate_step(const GParams &P, uint32_t pid, boo
 }
 
 // incrementDepth (reference guided.h:21-46): the vertex BEFORE the step becomes a training record
-__device__ __forceinline__ void record_vertex(const GParams &P, uint32_t pid, float x, float y, float dirx, float diry, float pdf,
+__device__ __forceinline__ void record_vertex(const GParams &P, uint32_t rp, float x, float y, float dirx, float diry, float pdf,
                                               float thp, bool on_n, float nx, float ny)
 {
-    const uint32_t d = P.cur_depth[pid];
+    const uint32_t d = P.cur_depth[rp];
     if (d >= (uint32_t)kMaxTrainDepth) return;
-    rec_at(P, d, 0, pid) = 0.0f; rec_at(P, d, 1, pid) = 0.0f; rec_at(P, d, 2, pid) = 0.0f;
-    rec_at(P, d, 3, pid) = x; rec_at(P, d, 4, pid) = y;
-    rec_at(P, d, 5, pid) = dirx; rec_at(P, d, 6, pid) = diry;
-    rec_at(P, d, 7, pid) = pdf;
-    rec_at(P, d, 8, pid) = thp;
-    rec_at(P, d, 9, pid) = nx; rec_at(P, d, 10, pid) = ny;
-    rec_at(P, d, 11, pid) = on_n ? 1.0f : 0.0f;
-    P.cur_depth[pid] = d + 1;
+    rec_at(P, d, 0, rp) = 0.0f; rec_at(P, d, 1, rp) = 0.0f; rec_at(P, d, 2, rp) = 0.0f;
+    rec_at(P, d, 3, rp) = x; rec_at(P, d, 4, rp) = y;
+    rec_at(P, d, 5, rp) = dirx; rec_at(P, d, 6, rp) = diry;
+    rec_at(P, d, 7, rp) = pdf;
+    rec_at(P, d, 8, rp) = thp;
+    rec_at(P, d, 9, rp) = nx; rec_at(P, d, 10, rp) = ny;
+    rec_at(P, d, 11, rp) = on_n ? 1.0f : 0.0f;
+    P.cur_depth[rp] = d + 1;
 }
 
 template <bool EMISSIVE, bool TREE, bool SOURCE>
@@ -467,7 +488,7 @@ struct SampleOut {
 
 template <bool TREE, class RAW>
 __device__ __forceinline__ SampleOut sample_step(const GParams &P, uint32_t pid, bool on_n, float x, float y, float thp, float nx, float ny,
-                                                 float R_B, int depth, bool guiding, Pcg &rng, const RAW &raw, const LdsColumn &stk)
+                                                 float R_B, int depth, bool guiding, Pcg &rng, const RAW &raw, const LdsColumn &stk, uint32_t rofs = 0u)
 {
     SampleOut o{false, false, false, x, y, thp, nx, ny};
     const bool record = is_training_pixel(P, pid) && depth < P.max_train_depth;
@@ -515,7 +536,7 @@ __device__ __forceinline__ SampleOut sample_step(const GParams &P, uint32_t pid,
     if (!o.dropped) {
         float nxt_x, nxt_y, hnx, hny;
         o.hit_n = walk_advance<TREE>(P.nm, P.st.eps, x, y, R_B, on_n, nx, ny, dirx, diry, stk, nxt_x, nxt_y, hnx, hny);
-        if (record) record_vertex(P, pid, x, y, dirx, diry, pdf, thp, on_n, nx, ny);
+        if (record) record_vertex(P, pid + rofs, x, y, dirx, diry, pdf, thp, on_n, nx, ny);
         o.x = nxt_x; o.y = nxt_y;
         o.thp = thp / pdf / alpha / WOST_2PI;
         o.nx = hnx; o.ny = hny;
@@ -574,6 +595,19 @@ __global__ __launch_bounds__(256) void sample_kernel(GParams P)
     wave_count(live && P.guiding, &my_stats(P.stats)->net_points);
     wave_count(hit_n, &my_stats(P.stats)->nhits);
     if (P.last_depth) wave_count(alive_after, &my_stats(P.stats)->truncated);
+}
+
+// the per-pixel state of a solve before its first sample (prepareSolve, reference :112-128), for the launches that cannot set
+// it on the fly (several samples per pixel: the items of a pixel arrive in any order)
+__global__ __launch_bounds__(256) void guided_init_kernel(GParams P)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P.n_pixels) return;
+    Pcg r0;
+    pcg_seed_pixel(r0, p, P.st.width);
+    P.rng[p] = r0.state;
+    P.sol[3 * (size_t)p] = 0.0f; P.sol[3 * (size_t)p + 1] = 0.0f; P.sol[3 * (size_t)p + 2] = 0.0f;
+    P.hint0[p] = 0;
 }
 
 // ---- a whole sample in one launch (half-precision network only) -----------------------------------
@@ -636,28 +670,61 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
     int depth = 0;
     Pcg rng{0, 1};
     Trav T = trav_begin(Closest{WOST_INF, -1});
-    int left = 0;                          // samples this lane still owes its pixel
+    uint32_t sidx = 0;                     // which sample of its pixel in this launch the lane is walking
+    uint32_t rofs = 0;                     // record column offset of that sample (training launches of several samples: one set each)
     uint32_t pool_next = 0, pool_end = 0, last_base = 0;
     const uint32_t tail_margin = (uint32_t)P.tail_margin_pct * (gridDim.x * blockDim.x / 100u);
     uint32_t c_steps = 0, c_started = 0, c_abs = 0, c_trunc = 0, c_hits = 0, c_guided = 0, c_net = 0;
     const bool has_d = P.dm.n_segs > 0;
     const uint32_t n_slots = (uint32_t)P.n_pixels;
+    // A launch of several samples per pixel hands out (pixel, one more sample) items: item i belongs to pixel slot i % n_slots.
+    // The samples of a pixel are sequential (one random stream, reference integrator.cu:71-77) but need not stay in one lane:
+    // the pixel's state word counts the items that ARRIVED and the samples that are COMPLETE.  A lane that arrives at an idle
+    // pixel (arrived == complete) walks its next sample; one that arrives while another lane is walking the pixel leaves its
+    // item there as a credit and takes the next item; a lane that completes a sample and finds credits walks the next sample
+    // itself.  Every transition is ONE atomic on that word, so no credit is lost, a pixel gets exactly n_samples samples, in
+    // order, and no lane waits -- where a lane that kept its pixel for all the samples held the last pixels taken for n_samples
+    // walks while the chip ran empty.  Which lane walks a sample has no influence on any result.
+    const bool handed = P.n_samples > 1;
+    const uint32_t n_items = n_slots * (uint32_t)P.n_samples;
     const bool tiled = ((P.st.width | P.st.height) & 7) == 0;
     bool dbg_out = false;
     if (P.dbg && lane == 0) atomicMin(P.dbg + 0, wall_clock64());
 
+    // start sample `sidx` of pixel `pid` in this lane (begin_sample_kernel for one pixel)
+    auto begin_walk = [&]() {
+        const int px = (int)pid % P.st.width, py = (int)pid / P.st.width;
+        eval_point(P.probe, px, py, P.st.width, P.st.height, x, y);
+        on_n = false; thp = 1.0f; nx = 0.0f; ny = 0.0f; depth = 0;
+        hint = ld_px(P.hint0 + pid);
+        rng.state = ld_px(P.rng + pid);
+        rofs = P.training ? sidx * n_slots : 0u;
+        ++c_started;
+        if (!has_d) {
+            T.best = Closest{WOST_INF, -1};
+            mode = MODE_WAIT;
+        } else if (P.d0_valid || sidx > 0) {
+            // the evaluation point of a pixel is the same for every sample: its query is cached
+            T.best = Closest{ld_px(P.d0_d2 + pid), hint};
+            mode = MODE_WAIT;
+        } else {
+            T = trav_begin(slot_candidate(P.dm, hint, x, y));
+            mode = MODE_TRAV;
+        }
+    };
+
     for (;;) {
-        // ---- lanes without a walker take the next pixel of the launch (begin_sample_kernel) ----
+        // ---- lanes without a walker take the next item of the launch (begin_sample_kernel) ----
         const unsigned long long need = __ballot(mode == MODE_REFILL);
         if (need) {
             const uint32_t needed = (uint32_t)__popcll(need), avail = pool_end - pool_next;
-            // Pixels are reserved 64 at a time (one atomic on the shared cursor per 64 pixels: same-address atomics
-            // serialise in L2).  A reservation is private to its wave, so near the end of the launch the pixels a wave
-            // holds back would start only when ITS lanes come free while other waves idle: within `tail_margin` pixels
+            // Items are reserved 64 at a time (one atomic on the shared cursor per 64 items: same-address atomics
+            // serialise in L2).  A reservation is private to its wave, so near the end of the launch the items a wave
+            // holds back would start only when ITS lanes come free while other waves idle: within `tail_margin` items
             // of the end a wave reserves in small chunks.
             uint32_t fresh_base = 0, chunk = 64u;
             if (needed > avail) {
-                if (P.tail_chunk > 0 && last_base + tail_margin >= n_slots) chunk = (needed - avail + (uint32_t)P.tail_chunk - 1u) / (uint32_t)P.tail_chunk * (uint32_t)P.tail_chunk;
+                if (P.tail_chunk > 0 && last_base + tail_margin >= n_items) chunk = (needed - avail + (uint32_t)P.tail_chunk - 1u) / (uint32_t)P.tail_chunk * (uint32_t)P.tail_chunk;
                 if (lane == 0) fresh_base = atomicAdd(P.cursor, chunk);
                 fresh_base = __shfl(fresh_base, 0);
                 last_base = fresh_base;
@@ -671,7 +738,7 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
                 pool_next += needed;
             }
             if (mode == MODE_REFILL) {
-                if (s2 >= n_slots) {
+                if (s2 >= n_items) {
                     mode = MODE_DONE;
                     if (P.dbg && !dbg_out) {
                         dbg_out = true;
@@ -680,43 +747,39 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
                         atomicMax(P.dbg + 2, t);
                     }
                 } else {
-                    int p = (int)s2;
+                    int p = (int)(handed ? s2 % n_slots : s2);
                     if (tiled) {
                         const int tiles_x = P.st.width >> 3, tile = p >> 6, in_tile = p & 63;
                         p = ((tile / tiles_x) * 8 + (in_tile >> 3)) * P.st.width + (tile % tiles_x) * 8 + (in_tile & 7);
                     }
-                    if (P.first_sample) {
-                        Pcg r0;
-                        pcg_seed_pixel(r0, p, P.st.width);
-                        P.rng[p] = r0.state;
-                        P.sol[3 * (size_t)p] = 0.0f; P.sol[3 * (size_t)p + 1] = 0.0f; P.sol[3 * (size_t)p + 2] = 0.0f;
-                        P.hint0[p] = 0;
+                    if (!handed) {
+                        // (a launch of several samples per pixel has these set before it starts: its items of a pixel may arrive in any order)
+                        if (P.first_sample) {
+                            Pcg r0;
+                            pcg_seed_pixel(r0, p, P.st.width);
+                            st_px(P.rng + p, r0.state);
+                            st_px(P.sol + 3 * (size_t)p, 0.0f); st_px(P.sol + 3 * (size_t)p + 1, 0.0f); st_px(P.sol + 3 * (size_t)p + 2, 0.0f);
+                            st_px(P.hint0 + p, (int32_t)0);
+                        }
+                        P.cur_depth[p] = 0;
                     }
-                    P.cur_depth[p] = 0;
                     const int px = p % P.st.width, py = p / P.st.width;
                     const int tile = (py >> 3) * ((P.st.width + 7) >> 3) + (px >> 3);
                     const bool active = (tile % P.shard_count) == P.shard_index && (P.mask == nullptr || P.mask[p] != 0);
                     if (active) {
-                        eval_point(P.probe, px, py, P.st.width, P.st.height, x, y);
-                        pid = (uint32_t)p;
-                        on_n = false; thp = 1.0f; nx = 0.0f; ny = 0.0f; depth = 0;
-                        hint = P.hint0[p];
-                        rng.state = P.rng[p];
-                        left = P.n_samples;
-                        ++c_started;
-                        if (!has_d) {
-                            T.best = Closest{WOST_INF, -1};
-                            mode = MODE_WAIT;
-                        } else if (P.d0_valid) {
-                            // the evaluation point of a pixel is the same for every sample: its query is cached
-                            T.best = Closest{P.d0_d2[p], hint};
-                            mode = MODE_WAIT;
-                        } else {
-                            T = trav_begin(slot_candidate(P.dm, hint, x, y));
-                            mode = MODE_TRAV;
+                        bool start = true;
+                        sidx = 0;
+                        if (handed) {
+                            const uint32_t old = __hip_atomic_fetch_add(P.pstate + p, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            start = (old >> 16) == (old & 0xffffu);     // nobody is walking this pixel: its next sample is this lane's
+                            sidx = old & 0xffffu;
+                        }
+                        if (start) {
+                            pid = (uint32_t)p;
+                            begin_walk();
                         }
                     }
-                    // inactive pixel (mask, other shard): the lane asks again on the next trip
+                    // inactive pixel (mask, other shard) or a credit left with the pixel's walker: the lane asks again on the next trip
                 }
             }
         }
@@ -734,8 +797,8 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
             float R_B = 0.0f;
             if (act) {
                 ++c_steps;
-                if (has_d && depth == 0 && !P.d0_valid && left == P.n_samples) P.d0_d2[pid] = T.best.d2;   // the pixel's first walk of the launch
-                status = separate_finish<EMISSIVE, TREE, SOURCE>(P, pid, on_n, x, y, thp, nx, ny, depth, T.best, hint, R_B, rng, stk);
+                if (has_d && depth == 0 && !P.d0_valid && sidx == 0) st_px(P.d0_d2 + pid, T.best.d2);   // the pixel's first walk of the launch
+                status = separate_finish<EMISSIVE, TREE, SOURCE>(P, pid, on_n, x, y, thp, nx, ny, depth, T.best, hint, R_B, rng, stk, rofs);
                 if (status == SEP_ABSORBED) ++c_abs;
             }
             const bool keep = act && status == SEP_KEEP;
@@ -813,7 +876,7 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
                 bool ended = !keep;
                 if (keep) {
                     const auto raw = [&](int j) { return (float)rawv[j]; };
-                    const SampleOut o = sample_step<TREE>(P, pid, on_n, x, y, thp, nx, ny, R_B, depth, guiding, rng, raw, stk);
+                    const SampleOut o = sample_step<TREE>(P, pid, on_n, x, y, thp, nx, ny, R_B, depth, guiding, rng, raw, stk, rofs);
                     if (o.guided_step) ++c_guided;
                     if (o.dropped) {
                         ended = true;
@@ -828,20 +891,18 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
                     }
                 }
                 if (ended) {
-                    P.rng[pid] = rng.state;
-                    if (--left > 0) {
-                        // the next sample of the same pixel starts right away (guiding phase: nothing is trained in
-                        // between, and the pixel's random stream simply continues)
-                        const int px = (int)pid % P.st.width, py = (int)pid / P.st.width;
-                        eval_point(P.probe, px, py, P.st.width, P.st.height, x, y);
-                        on_n = false; thp = 1.0f; nx = 0.0f; ny = 0.0f; depth = 0;
-                        P.cur_depth[pid] = 0;
-                        hint = P.hint0[pid];
-                        T.best = has_d ? Closest{P.d0_d2[pid], hint} : Closest{WOST_INF, -1};
-                        ++c_started;
-                        mode = MODE_WAIT;
-                    } else {
-                        mode = MODE_REFILL;
+                    st_px(P.rng + pid, rng.state);
+                    mode = MODE_REFILL;
+                    if (handed) {
+                        // the sample is complete: every store of the pixel's state has left this CU before the state word says so
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        const uint32_t old = __hip_atomic_fetch_add(P.pstate + pid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((old >> 16) > (old & 0xffffu) + 1u) {
+                            // items that arrived meanwhile left their credit: the pixel's next sample starts right away, here
+                            // (guiding phase, or a training launch of several samples: the pixel's random stream simply continues)
+                            sidx = (old & 0xffffu) + 1u;
+                            begin_walk();
+                        }
                     }
                 } else if (has_d) {
                     T = trav_begin(slot_candidate(P.dm, hint, x, y));
@@ -897,7 +958,8 @@ struct TrainSet {
 struct TParams {
     GAabb box;
     const uint32_t *cur_depth;
-    const float *rec;
+    const float *rec;          // column 0 of the record set to gather
+    size_t rec_ld;
     int32_t n_pixels;
     uint32_t train_offset, train_stride;
     int32_t n_train_pixels;
@@ -907,7 +969,7 @@ struct TParams {
 
 __device__ __forceinline__ bool record_valid(const TParams &T, int slot, uint32_t pid, float out[kRecFields])
 {
-    for (int f = 0; f < kRecFields; ++f) out[f] = T.rec[((size_t)slot * kRecFields + f) * (size_t)T.n_pixels + pid];
+    for (int f = 0; f < kRecFields; ++f) out[f] = T.rec[((size_t)slot * kRecFields + f) * T.rec_ld + pid];
     if (!aabb_contains(T.box, out[3], out[4])) return false;
     // |solution / thp| per channel, 0 where the throughput vanished
     for (int c = 0; c < 3; ++c) {
@@ -1018,7 +1080,7 @@ struct wost_guided {
     std::vector<void *> allocs;
     GQueue q[2]{};
     uint32_t *counts = nullptr;        // [2]
-    uint32_t *host_counts = nullptr;   // pinned [4]
+    uint32_t *host_counts = nullptr;   // pinned [32]: [1 + j] = size of the training set of record set j
     uint32_t *depth_counts = nullptr;  // pinned [max_depth]: queue size after every depth, copied back without waiting
     std::vector<hipEvent_t> depth_events;
     uint64_t *rng = nullptr;
@@ -1027,6 +1089,7 @@ struct wost_guided {
     int32_t *hint0 = nullptr;
     float *d0_d2 = nullptr;            // fused sample kernel: cached query of every evaluation point
     uint32_t *cursor = nullptr;        // fused sample kernel: next pixel slot of the launch
+    uint32_t *pstate = nullptr;        // fused sample kernel, several samples per launch: arrived / complete counts per pixel
     unsigned long long *dbg = nullptr; // fused sample kernel: WOST_GUIDED_DEBUG timeline
     GStatsDev *stats = nullptr;
     uint32_t *block_sums = nullptr;
@@ -1042,6 +1105,19 @@ struct wost_guided {
     void *frame_user = nullptr;
     int32_t frame_spp_every = 0, frame_spp_until = 0, frame_time_every = 0;
     EventRing net_events;              // timing of the network-evaluating launches
+    // opt-in pipelined training order (wost_guided_set_option "pipeline"): the training pass of sample k runs on its own
+    // stream while sample k + 1 walks with a frozen copy of the weights of pass k - 1
+    int pipeline = 0;
+    // opt-in "train_group" S: a training launch walks S samples of every pixel back to back (one record set per sample) and the S
+    // training passes follow the launch: the drain of the longest walks is paid once per S samples; S = 1 is the reference's order
+    int train_group = 1;
+    int rec_sets = 1;                     // record sets rec / cur_depth are allocated for
+    std::vector<TrainSet> ts_more;        // training-set arrays of the sets 1 .. (pipelined groups train while the next group walks)
+    hipStream_t train_stream = nullptr;
+    void *snap[2] = {nullptr, nullptr};   // frozen inference images, used alternately
+    hipEvent_t ev_ts = nullptr;           // the training set of a sample is complete (walk stream)
+    hipEvent_t ev_train[2] = {nullptr, nullptr};   // training pass k is complete and its weights are in snap[k % 2] (training stream)
+    EventRing train_events;               // device time of the training passes in that mode
 };
 
 static uint32_t host_pcg_next(wost_guided *g)
@@ -1079,6 +1155,11 @@ static void guided_free(wost_guided *g)
     if (g->depth_counts) (void)hipHostFree(g->depth_counts);
     for (hipEvent_t e : g->depth_events) (void)hipEventDestroy(e);
     g->net_events.destroy();
+    g->train_events.destroy();
+    if (g->ev_ts) (void)hipEventDestroy(g->ev_ts);
+    for (hipEvent_t e : g->ev_train)
+        if (e) (void)hipEventDestroy(e);
+    if (g->train_stream) (void)hipStreamDestroy(g->train_stream);
     if (g->net) wost_net_destroy(g->net);
     if (g->scene) wost_destroy(g->scene);
     delete g;
@@ -1137,7 +1218,7 @@ int wost_guided_create(const wost_scene_desc *scene, const wost_guided_settings 
     GA(g->counts, 2); GA(g->rng, N); GA(g->sol, 3 * N); GA(g->field, 3 * N);
     GA(g->rec, (size_t)kMaxTrainDepth * kRecFields * N);
     GA(g->net_in, 2 * N); GA(g->net_out, 33 * N); GA(g->cur_depth, N); GA(g->hint0, N); GA(g->stats, kStatCopies);
-    GA(g->dbg, 4); GA(g->d0_d2, N); GA(g->cursor, 1);
+    GA(g->dbg, 4); GA(g->d0_d2, N); GA(g->cursor, 1); GA(g->pstate, N);
     // sized for offset 0 (the largest set); the offset of a solve may be drawn per solve (run_guided)
     g->n_train_pixels = (int)((N + (size_t)s->train_pixel_stride - 1) / (size_t)s->train_pixel_stride);
     g->n_train_blocks = (g->n_train_pixels + 255) / 256;
@@ -1153,7 +1234,7 @@ int wost_guided_create(const wost_scene_desc *scene, const wost_guided_settings 
     GA(g->ts.xy, 2 * M); GA(g->ts.dir, 2 * M); GA(g->ts.sol, 3 * M); GA(g->ts.li, M); GA(g->ts.pdf, M); GA(g->ts.nrm, 2 * M);
     GA(g->ts.onn, M);
 #undef GA
-    if (e == hipSuccess) e = hipHostMalloc((void **)&g->host_counts, 4 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&g->host_counts, 32 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc((void **)&g->depth_counts, (size_t)std::max(1, s->max_depth) * sizeof(uint32_t));
     for (int d = 0; e == hipSuccess && d < s->max_depth; ++d) {
         hipEvent_t ev = nullptr;
@@ -1200,6 +1281,23 @@ int wost_guided_set_sync(wost_guided_handle h, wost_sync_fn fn, void *user)
     h->sync = fn;
     h->sync_user = user;
     return WOST_OK;
+}
+
+int wost_guided_set_option(wost_guided_handle h, const char *key, double value)
+{
+    if (!h || !key) return set_error(WOST_ERR_INVALID, "null argument");
+    const std::string k(key);
+    if (k == "pipeline") {
+        if (!(value == 0.0 || value == 1.0)) return set_error(WOST_ERR_INVALID, "pipeline is 0 or 1");
+        h->pipeline = (int)value;
+        return WOST_OK;
+    }
+    if (k == "train_group") {
+        if (!(value >= 1.0 && value <= 16.0 && value == (double)(int)value)) return set_error(WOST_ERR_INVALID, "train_group is an integer in 1..16");
+        h->train_group = (int)value;
+        return WOST_OK;
+    }
+    return set_error(WOST_ERR_INVALID, "unknown option '" + k + "'");
 }
 
 int wost_guided_scene(wost_guided_handle h, wost_handle *scene)
@@ -1264,12 +1362,17 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     G_TRY(hipMemsetAsync(g->stats, 0, kStatCopies * sizeof(GStatsDev), stream));
     if (g->sync) {
         // shared network: the summed gradients are divided by the number of ranks (include/wost.h)
-        // (WOST_SYNC_RANKS_I64_HOST was added to the callback's ops in library version 0.2: a callback written against 0.1 that
-        // refuses it keeps the old behaviour -- the summed gradient is used undivided -- instead of failing the solve)
+        // (WOST_SYNC_RANKS_I64_HOST was added to the callback's ops in library version 0.2: a callback written against 0.1
+        // answers WOST_SYNC_UNSUPPORTED and keeps the old behaviour -- the summed gradient is used undivided; any other
+        // non-zero return is a failure and ends the solve)
         int64_t ranks = 1;
-        if (g->sync(g->sync_user, WOST_SYNC_RANKS_I64_HOST, &ranks, 1) != 0 || ranks < 1) {
-            fprintf(stderr, "wost: the sync callback does not answer WOST_SYNC_RANKS_I64_HOST; shared gradients stay undivided\n");
+        const int src = g->sync(g->sync_user, WOST_SYNC_RANKS_I64_HOST, &ranks, 1);
+        if (src == WOST_SYNC_UNSUPPORTED) {
+            fprintf(stderr, "wost: the sync callback does not know WOST_SYNC_RANKS_I64_HOST; shared gradients stay undivided\n");
             ranks = 1;
+        } else if (src != 0 || ranks < 1) {
+            // a genuine failure (or a nonsensical answer) must not train on: the other ranks would step with another gradient
+            return set_error(WOST_ERR_DEVICE, "sync callback failed (rank count)");
         }
         net_set_gradient_divisor(g->net, (float)ranks);
     } else {
@@ -1278,7 +1381,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     GParams P{};
     P.dm = v.dm; P.nm = v.nm; P.st = v.st; P.probe = v.probe; P.src = v.src; P.box = g->box; P.mask = v.mask;
     P.rng = g->rng; P.sol = g->sol; P.cur_depth = g->cur_depth; P.rec = g->rec; P.hint0 = g->hint0;
-    P.net_in = g->net_in; P.net_out = g->net_out; P.net_ld = (size_t)N; P.stats = g->stats; P.n_pixels = N; P.stack_stride = 256;
+    P.rec_ld = (size_t)N; P.net_in = g->net_in; P.net_out = g->net_out; P.net_ld = (size_t)N; P.stats = g->stats; P.n_pixels = N; P.stack_stride = 256;
     P.max_train_depth = s.max_train_depth;
     // prepareSolve (integrator.cu:126): trainPixelOffset = stride <= 1 ? 0 : sampler.get1D() * stride, one draw per
     // solve from the integrator's host sampler; a caller-fixed offset (>= 0) overrides the draw
@@ -1302,6 +1405,18 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     // WOST_GUIDED_FUSED=0 keeps the one-launch-per-depth path for comparison (same field, same records).
     bool fused = false, fused_half = false;
     FusedNet F{};
+    // the members of F that describe the network's shape; false when the fused kernel does not exist for it
+    auto fused_shape = [](const NetLayout *L, FusedNet &Fn) {
+        if (!(L && L->n_levels == 8 && L->n_features == 4 && L->enc == 32 && L->n_neurons == 64 && L->n_hidden == 3 && L->n_out_padded == 48 &&
+              L->n_out == 33))
+            return false;
+        Fn.n_frag = L->n_mlp / 4;
+        Fn.n_mlp = L->n_mlp;
+        for (int l = 0; l < 4; ++l) { Fn.w_off[l] = L->w_off[l]; Fn.w_off4[l] = L->w_off[l] / 4; }
+        for (int l = 0; l < 8; ++l) { Fn.scale[l] = L->scale[l]; Fn.res[l] = (uint32_t)L->res[l]; }
+        for (int l = 0; l <= 8; ++l) Fn.off[l] = L->level_off[l];
+        return true;
+    };
     {
         const char *env = std::getenv("WOST_GUIDED_FUSED");
         HalfNetView hv{};
@@ -1317,15 +1432,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
             F.frag32 = fv.frag;
             F.grid32 = fv.grid;
         }
-        if (L && L->n_levels == 8 && L->n_features == 4 && L->enc == 32 && L->n_neurons == 64 && L->n_hidden == 3 && L->n_out_padded == 48 &&
-            L->n_out == 33) {
-            fused = true;
-            F.n_frag = L->n_mlp / 4;
-            F.n_mlp = L->n_mlp;
-            for (int l = 0; l < 4; ++l) { F.w_off[l] = L->w_off[l]; F.w_off4[l] = L->w_off[l] / 4; }
-            for (int l = 0; l < 8; ++l) { F.scale[l] = L->scale[l]; F.res[l] = (uint32_t)L->res[l]; }
-            for (int l = 0; l <= 8; ++l) F.off[l] = L->level_off[l];
-        }
+        fused = fused_shape(L, F);
     }
     P.d0_d2 = g->d0_d2; P.cursor = g->cursor; P.stack_words = stack_words;
     P.wait_weight = 4; P.trav_burst = 10;     // measured on config 4 (a sweep over both constants)
@@ -1347,14 +1454,223 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         if (lds_fused > (size_t)max_lds) fused = false;
     }
 
+    // one launch of the fused sample kernel on `st` with the network image `Fn` and the launch state in P
+    auto launch_walk = [&](const FusedNet &Fn, hipStream_t st) -> int {
+        G_TRY(hipMemsetAsync(g->cursor, 0, sizeof(uint32_t), st));
+        P.pstate = g->pstate;
+        if (P.n_samples > 1) {
+            // several samples of every pixel in one launch: the pixel state words start at zero, and what a one-sample launch
+            // sets on the fly is set before the launch
+            G_TRY(hipMemsetAsync(g->pstate, 0, (size_t)N * sizeof(uint32_t), st));
+            if (P.first_sample) {
+                hipLaunchKernelGGL(guided_init_kernel, dim3((N + 255) / 256), dim3(256), 0, st, P);
+                ++launches;
+            }
+            if (P.training) G_TRY(hipMemsetAsync(g->cur_depth, 0, (size_t)N * (size_t)P.n_samples * sizeof(uint32_t), st));
+            launches += 2;
+        }
+        const unsigned gridf = (unsigned)std::min<size_t>(256, ((size_t)N + n_fused_threads - 1) / n_fused_threads);
+#define LAUNCH_FUSED(E, T)                                                                                                      \
+    do {                                                                                                                        \
+        auto kfn = v.src.rgb ? (fused_half ? guided_sample_kernel<E, T, true, true> : guided_sample_kernel<E, T, true, false>)    \
+                             : (fused_half ? guided_sample_kernel<E, T, false, true> : guided_sample_kernel<E, T, false, false>); \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused); \
+        hipLaunchKernelGGL(kfn, dim3(gridf), dim3(n_fused_threads), lds_fused, st, P, Fn);                                       \
+    } while (0)
+        if (emissive) { if (tree) LAUNCH_FUSED(true, true); else LAUNCH_FUSED(true, false); }
+        else          { if (tree) LAUNCH_FUSED(false, true); else LAUNCH_FUSED(false, false); }
+#undef LAUNCH_FUSED
+        ++launches;
+        G_TRY(hipGetLastError());
+        return WOST_OK;
+    };
+    // the training set of record set j of the launch that has just walked, in (pixel, record) order, into `ts`; its size
+    // arrives in host_counts[1 + j]
+    auto enqueue_train_set = [&](hipStream_t st, int j, const TrainSet &ts) -> int {
+        TParams T{};
+        T.box = g->box; T.cur_depth = g->cur_depth + (size_t)j * (size_t)N; T.rec = g->rec + (size_t)j * (size_t)N; T.rec_ld = P.rec_ld; T.n_pixels = N;
+        T.train_offset = train_offset; T.train_stride = (uint32_t)s.train_pixel_stride;
+        T.n_train_pixels = n_train_pixels; T.block_sums = g->block_sums; T.ts = ts;
+        hipLaunchKernelGGL((train_set_kernel<false>), dim3(n_train_blocks), dim3(256), 0, st, T);
+        hipLaunchKernelGGL(train_scan_kernel, dim3(1), dim3(256), 0, st, g->block_sums, n_train_blocks);
+        hipLaunchKernelGGL((train_set_kernel<true>), dim3(n_train_blocks), dim3(256), 0, st, T);
+        launches += 3;
+        G_TRY(hipGetLastError());
+        G_TRY(hipMemcpyAsync(g->host_counts + 1 + j, g->block_sums + n_train_blocks, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        return WOST_OK;
+    };
+    // trainStep (:618-668): up to batches_per_spp Adam steps on the n entries of the training set `ts`
+    auto train_passes = [&](size_t n, hipStream_t st, const TrainSet &ts) -> int {
+        g->last_train_n = (uint32_t)n;
+        train_samples += n;
+        const size_t bs = (size_t)s.batch_size;
+        size_t n_batches = std::min<size_t>(n / bs + 1, (size_t)s.batches_per_spp);
+        if (g->sync) {
+            // shared network: every rank must take the same number of steps -- the smallest
+            // number of full batches any rank has
+            size_t usable = 0;
+            for (size_t it = 0; it < n_batches; ++it) {
+                size_t local = std::min(n - it * bs, bs);
+                local -= local % 128;
+                if (local < (size_t)s.min_batch_size) break;
+                ++usable;
+            }
+            int64_t vmin = (int64_t)usable;
+            if (g->sync(g->sync_user, WOST_SYNC_MIN_I64_HOST, &vmin, 1) != 0)
+                return set_error(WOST_ERR_DEVICE, "sync callback failed (batch count)");
+            n_batches = (size_t)std::max<int64_t>(vmin, 0);
+        }
+        for (size_t it = 0; it < n_batches; ++it) {
+            size_t local = std::min(n - it * bs, bs);
+            local -= local % 128;
+            if (local < (size_t)s.min_batch_size) break;
+            const size_t o = it * bs;
+            float *raw = nullptr, *dl = nullptr;
+            int rc = net_forward_train_dev(g->net, ts.xy + 2 * o, (int)local, st, &raw, &dl);
+            if (rc != WOST_OK) return rc;
+            launch_vmm_loss_gradients(st, raw, ts.dir + 2 * o, ts.li + o, ts.pdf + o, ts.onn + o,
+                                      ts.nrm + 2 * o, (int)local, s.loss_scale, dl, nullptr);
+            rc = net_backward_update_dev(g->net, ts.xy + 2 * o, (int)local, s.loss_scale, g->sync ? 0 : 1, st);
+            if (rc != WOST_OK) return rc;
+            if (g->sync) {
+                // sum the fixed-point gradients of all ranks (integer sums: the same network
+                // everywhere, bit for bit), then step
+                G_TRY(hipStreamSynchronize(st));
+                uint64_t count = 0;
+                void *gbuf = net_gradient_buffer(g->net, &count);
+                if (g->sync(g->sync_user, WOST_SYNC_SUM_I64_DEVICE, gbuf, count) != 0)
+                    return set_error(WOST_ERR_DEVICE, "sync callback failed (gradient all-reduce)");
+                rc = net_apply_update_dev(g->net, s.loss_scale, st);
+                if (rc != WOST_OK) return rc;
+            }
+            ++launches;      // the loss-gradient kernel; the network's own launches are counted by the network
+        }
+        return WOST_OK;
+    };
+
     bool d0_valid = false;
     // ctor state (integrator.cu:1158-1160), prepareSolve (:125-126)
     bool training = true;
     float uniform_fraction = s.uniform_fraction_training;
     int max_guided_depth = s.max_guided_depth_training;
+    const bool dbg = std::getenv("WOST_GUIDED_DEBUG") != nullptr;
 
-    for (int sample = 0; sample < s.spp; ++sample) {
-        if (sample == s.train_spp_count) {       // :991-996
+    // ---- opt-in training orders (never the parity mode) ---------------------------------------------------------------
+    // "train_group" S: a training launch walks S samples of every pixel (each with its own record set), then the S training
+    // passes follow.  "pipeline" 1: the passes of group g run on a second stream while group g + 1 walks with a frozen copy
+    // of the weights that the passes of group g - 1 left.  The estimator is unbiased for ANY network state (a step's
+    // direction and its one-sample MIS density come from the same weights, and a training record carries the density it was
+    // drawn with): the only change is that the network a sample sees is a few training passes older.  Both need the fused
+    // sample kernel; a solve with intermediate frames keeps the reference's order.
+    const int n_trained = std::min(s.spp, s.train_spp_count);
+    const bool reordered = fused && n_trained > 0 && !g->frame_fn && !dbg && (g->pipeline || g->train_group > 1);
+    const int group = reordered ? std::min(std::max(g->train_group, 1), n_trained) : 1;
+    if (group > g->rec_sets) {
+        // one record set per sample of a training launch (201 MB each at 1024^2: sized for 288 GB of HBM)
+        float *rec = nullptr;
+        uint32_t *cd = nullptr;
+        G_TRY(galloc(g, &rec, (size_t)kMaxTrainDepth * kRecFields * (size_t)N * group));
+        G_TRY(galloc(g, &cd, (size_t)N * group));
+        g->rec = rec; g->cur_depth = cd; g->rec_sets = group;
+        P.rec = g->rec; P.cur_depth = g->cur_depth;
+    }
+    P.rec_ld = (size_t)N * (size_t)g->rec_sets;
+    int sample0 = 0;
+    if (reordered && g->pipeline) {
+        const size_t snap_bytes = net_snapshot_bytes(g->net);
+        if (snap_bytes == 0) return set_error(WOST_ERR_UNSUPPORTED, "pipelined training needs a network image");
+        if (!g->train_stream) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // lo = least urgent: the training fills what the walk leaves idle
+            G_TRY(hipStreamCreateWithPriority(&g->train_stream, hipStreamNonBlocking, lo));
+            G_TRY(hipEventCreateWithFlags(&g->ev_ts, hipEventDisableTiming));
+            for (hipEvent_t &e : g->ev_train) G_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            G_TRY(g->train_events.init(64));
+            for (void *&p : g->snap) {
+                uint8_t *q = nullptr;
+                G_TRY(galloc(g, &q, snap_bytes));
+                p = q;
+            }
+        }
+        // the passes of a group read their training sets while the next group walks over the record sets: one array set per sample
+        while ((int)g->ts_more.size() + 1 < group) {
+            TrainSet t{};
+            const size_t M = (size_t)g->n_train_pixels * kMaxTrainDepth;
+            G_TRY(galloc(g, &t.xy, 2 * M)); G_TRY(galloc(g, &t.dir, 2 * M)); G_TRY(galloc(g, &t.sol, 3 * M)); G_TRY(galloc(g, &t.li, M));
+            G_TRY(galloc(g, &t.pdf, M)); G_TRY(galloc(g, &t.nrm, 2 * M)); G_TRY(galloc(g, &t.onn, M));
+            g->ts_more.push_back(t);
+        }
+        auto ts_of = [&](int j) -> const TrainSet & { return j == 0 ? g->ts : g->ts_more[(size_t)j - 1]; };
+        hipStream_t B = g->train_stream;
+        FusedNet Fs[2] = {F, F};
+        for (int k = 0; k < 2; ++k) {
+            int rc = net_snapshot_dev(g->net, g->snap[k], stream);      // both copies start as the weights the solve starts with
+            if (rc != WOST_OK) return rc;
+            bool half = false;
+            HalfNetView hv{};
+            F32NetView fv{};
+            rc = net_snapshot_views(g->net, g->snap[k], &half, &hv, &fv);
+            if (rc != WOST_OK || half != fused_half) return set_error(WOST_ERR_UNSUPPORTED, "pipelined training: no view of the network image");
+            if (half) Fs[k].image = hv.image;
+            else { Fs[k].frag32 = fv.frag; Fs[k].grid32 = fv.grid; }
+        }
+        const int n_groups = (n_trained + group - 1) / group;
+        auto size_of = [&](int k) { return std::min(group, n_trained - k * group); };
+        P.training = 1; P.uniform_fraction = uniform_fraction; P.max_guided_depth = max_guided_depth; P.dbg = nullptr;
+        auto walk = [&](int k) -> int {
+            P.first_sample = k == 0;
+            P.d0_valid = k > 0 ? 1 : 0;
+            P.n_samples = size_of(k);
+            return launch_walk(Fs[k & 1], stream);
+        };
+        auto train_sets = [&](int k) -> int {
+            for (int j = 0; j < size_of(k); ++j) {
+                const int rc = enqueue_train_set(stream, j, ts_of(j));
+                if (rc != WOST_OK) return rc;
+            }
+            return WOST_OK;
+        };
+        // (the training stream starts behind whatever the walk stream has been given so far)
+        G_TRY(hipEventRecord(g->ev_ts, stream));
+        G_TRY(hipStreamWaitEvent(B, g->ev_ts, 0));
+        int rc = walk(0);
+        if (rc == WOST_OK) rc = train_sets(0);
+        if (rc != WOST_OK) return rc;
+        G_TRY(hipEventRecord(g->ev_ts, stream));
+        for (int k = 0; k < n_groups; ++k) {
+            if (k + 1 < n_groups) {
+                // walk(k + 1) reads snap[(k + 1) % 2] = the weights after the passes of group k - 1
+                if (k >= 1) G_TRY(hipStreamWaitEvent(stream, g->ev_train[(k - 1) & 1], 0));
+                rc = walk(k + 1);
+                if (rc != WOST_OK) return rc;
+            }
+            G_TRY(hipEventSynchronize(g->ev_ts));          // the training sets of group k are complete; their sizes have arrived
+            size_t n_of[16];
+            for (int j = 0; j < size_of(k); ++j) n_of[j] = g->host_counts[1 + j];
+            G_TRY(hipStreamWaitEvent(B, g->ev_ts, 0));
+            const size_t ev = g->train_events.begin(B);
+            for (int j = 0; j < size_of(k) && rc == WOST_OK; ++j) rc = train_passes(n_of[j], B, ts_of(j));
+            if (rc == WOST_OK) rc = net_snapshot_dev(g->net, g->snap[k & 1], B);
+            g->train_events.end(ev, B);
+            if (rc != WOST_OK) return rc;
+            G_TRY(hipEventRecord(g->ev_train[k & 1], B));
+            if (k + 1 < n_groups) {
+                G_TRY(hipStreamWaitEvent(stream, g->ev_train[k & 1], 0));     // the arrays of the training sets are free again
+                rc = train_sets(k + 1);
+                if (rc != WOST_OK) return rc;
+                G_TRY(hipEventRecord(g->ev_ts, stream));
+            }
+        }
+        // what follows (the guiding phase, the resolve) reads the network's own images
+        G_TRY(hipStreamWaitEvent(stream, g->ev_train[(n_groups - 1) & 1], 0));
+        G_TRY(hipStreamSynchronize(B));
+        train_ms += g->train_events.drain();
+        sample0 = n_trained;
+        d0_valid = true;
+    }
+
+    for (int sample = sample0; sample < s.spp; ++sample) {
+        if (sample >= s.train_spp_count && training) {       // :991-996
             training = false;
             uniform_fraction = s.uniform_fraction_guiding;
             max_guided_depth = s.max_guided_depth_guiding;
@@ -1366,7 +1682,9 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         // both paths give the same results and could alternate within a solve; the fused one is used whenever it exists
         const bool fused_now = fused;
         if (fused_now) {
-            if (!training) {
+            if (training) {
+                n_run = std::min(group, s.train_spp_count - sample);      // 1 unless "train_group" asks for more
+            } else {
                 // nothing is trained between the remaining samples: one launch runs them all, up to the next
                 // intermediate frame the caller asked for
                 int last = s.spp - 1;
@@ -1387,27 +1705,14 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
             P.n_samples = n_run;
             P.d0_valid = d0_valid ? 1 : 0;
             P.max_guided_depth = max_guided_depth;
-            G_TRY(hipMemsetAsync(g->cursor, 0, sizeof(uint32_t), stream));
-            const bool dbg = std::getenv("WOST_GUIDED_DEBUG") != nullptr;
             P.dbg = dbg ? g->dbg : nullptr;
             if (dbg) {
                 const unsigned long long init[4] = {~0ull, ~0ull, 0ull, 0ull};
                 G_TRY(hipMemcpyAsync(g->dbg, init, sizeof(init), hipMemcpyHostToDevice, stream));
                 G_TRY(hipStreamSynchronize(stream));
             }
-            const unsigned gridf = (unsigned)std::min<size_t>(256, ((size_t)N + n_fused_threads - 1) / n_fused_threads);
-#define LAUNCH_FUSED(E, T)                                                                                                      \
-    do {                                                                                                                        \
-        auto kfn = v.src.rgb ? (fused_half ? guided_sample_kernel<E, T, true, true> : guided_sample_kernel<E, T, true, false>)    \
-                             : (fused_half ? guided_sample_kernel<E, T, false, true> : guided_sample_kernel<E, T, false, false>); \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused); \
-        hipLaunchKernelGGL(kfn, dim3(gridf), dim3(n_fused_threads), lds_fused, stream, P, F);                                    \
-    } while (0)
-            if (emissive) { if (tree) LAUNCH_FUSED(true, true); else LAUNCH_FUSED(true, false); }
-            else          { if (tree) LAUNCH_FUSED(false, true); else LAUNCH_FUSED(false, false); }
-#undef LAUNCH_FUSED
-            ++launches;
-            G_TRY(hipGetLastError());
+            const int rcw = launch_walk(F, stream);
+            if (rcw != WOST_OK) return rcw;
             if (dbg) {
                 unsigned long long t[4];
                 G_TRY(hipMemcpy(t, g->dbg, sizeof(t), hipMemcpyDeviceToHost));
@@ -1486,61 +1791,12 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         if (training) {
             G_TRY(hipStreamSynchronize(stream));     // the walk phase ends here; train_ms counts the training only
             const auto t0 = std::chrono::high_resolution_clock::now();
-            TParams T{};
-            T.box = g->box; T.cur_depth = g->cur_depth; T.rec = g->rec; T.n_pixels = N;
-            T.train_offset = train_offset; T.train_stride = (uint32_t)s.train_pixel_stride;
-            T.n_train_pixels = n_train_pixels; T.block_sums = g->block_sums; T.ts = g->ts;
-            hipLaunchKernelGGL((train_set_kernel<false>), dim3(n_train_blocks), dim3(256), 0, stream, T);
-            hipLaunchKernelGGL(train_scan_kernel, dim3(1), dim3(256), 0, stream, g->block_sums, n_train_blocks);
-            hipLaunchKernelGGL((train_set_kernel<true>), dim3(n_train_blocks), dim3(256), 0, stream, T);
-            launches += 3;
-            G_TRY(hipMemcpyAsync(g->host_counts + 1, g->block_sums + n_train_blocks, sizeof(uint32_t),
-                                 hipMemcpyDeviceToHost, stream));
-            G_TRY(hipStreamSynchronize(stream));
-            const size_t n = g->host_counts[1];
-            g->last_train_n = (uint32_t)n;
-            train_samples += n;
-            const size_t bs = (size_t)s.batch_size;
-            size_t n_batches = std::min<size_t>(n / bs + 1, (size_t)s.batches_per_spp);
-            if (g->sync) {
-                // shared network: every rank must take the same number of steps -- the smallest
-                // number of full batches any rank has
-                size_t usable = 0;
-                for (size_t it = 0; it < n_batches; ++it) {
-                    size_t local = std::min(n - it * bs, bs);
-                    local -= local % 128;
-                    if (local < (size_t)s.min_batch_size) break;
-                    ++usable;
-                }
-                int64_t v = (int64_t)usable;
-                if (g->sync(g->sync_user, WOST_SYNC_MIN_I64_HOST, &v, 1) != 0)
-                    return set_error(WOST_ERR_DEVICE, "sync callback failed (batch count)");
-                n_batches = (size_t)std::max<int64_t>(v, 0);
-            }
-            for (size_t it = 0; it < n_batches; ++it) {
-                size_t local = std::min(n - it * bs, bs);
-                local -= local % 128;
-                if (local < (size_t)s.min_batch_size) break;
-                const size_t o = it * bs;
-                float *raw = nullptr, *dl = nullptr;
-                int rc = net_forward_train_dev(g->net, g->ts.xy + 2 * o, (int)local, stream, &raw, &dl);
+            for (int j = 0; j < n_run; ++j) {        // (one record set per sample of the launch; one unless "train_group" is set)
+                int rc = enqueue_train_set(stream, j, g->ts);
                 if (rc != WOST_OK) return rc;
-                launch_vmm_loss_gradients(stream, raw, g->ts.dir + 2 * o, g->ts.li + o, g->ts.pdf + o, g->ts.onn + o,
-                                          g->ts.nrm + 2 * o, (int)local, s.loss_scale, dl, nullptr);
-                rc = net_backward_update_dev(g->net, g->ts.xy + 2 * o, (int)local, s.loss_scale, g->sync ? 0 : 1, stream);
+                G_TRY(hipStreamSynchronize(stream));
+                rc = train_passes((size_t)g->host_counts[1 + j], stream, g->ts);
                 if (rc != WOST_OK) return rc;
-                if (g->sync) {
-                    // sum the fixed-point gradients of all ranks (integer sums: the same network
-                    // everywhere, bit for bit), then step
-                    G_TRY(hipStreamSynchronize(stream));
-                    uint64_t count = 0;
-                    void *gbuf = net_gradient_buffer(g->net, &count);
-                    if (g->sync(g->sync_user, WOST_SYNC_SUM_I64_DEVICE, gbuf, count) != 0)
-                        return set_error(WOST_ERR_DEVICE, "sync callback failed (gradient all-reduce)");
-                    rc = net_apply_update_dev(g->net, s.loss_scale, stream);
-                    if (rc != WOST_OK) return rc;
-                }
-                ++launches;      // the loss-gradient kernel; the network's own launches are counted by the network
             }
             G_TRY(hipStreamSynchronize(stream));
             train_ms += std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();

@@ -1729,6 +1729,49 @@ int net_half_view(wost_net *h, HalfNetView *out)
     return WOST_OK;
 }
 
+size_t net_snapshot_bytes(wost_net *h)
+{
+    if (!h) return 0;
+    if (h->precision == 16 && h->inference_h) return half_image_entries(h->L) * sizeof(uint2);
+    if (h->use_mfma && h->inference_f && h->L.dims == 2) return (size_t)h->n_params * sizeof(float);    // fragments, then the grid
+    return 0;
+}
+
+int net_snapshot_dev(wost_net *h, void *dst, hipStream_t stream)
+{
+    if (!h || !dst) return set_error(WOST_ERR_INVALID, "null argument");
+    if (h->precision == 16 && h->inference_h) {
+        NET_TRY(hipMemcpyAsync(dst, h->inference_h, half_image_entries(h->L) * sizeof(uint2), hipMemcpyDeviceToDevice, stream));
+    } else if (h->use_mfma && h->inference_f && h->L.dims == 2) {
+        float *d = reinterpret_cast<float *>(dst);
+        NET_TRY(hipMemcpyAsync(d, h->inference_f, (size_t)h->L.n_mlp * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        NET_TRY(hipMemcpyAsync(d + h->L.n_mlp, h->inference + h->L.n_mlp, (size_t)(h->n_params - h->L.n_mlp) * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    } else {
+        return set_error(WOST_ERR_UNSUPPORTED, "this network has no image to copy");
+    }
+    h->n_launches += 1;
+    return WOST_OK;
+}
+
+int net_snapshot_views(wost_net *h, const void *snap, bool *half, HalfNetView *hv, F32NetView *fv)
+{
+    if (!h || !snap || !half || !hv || !fv) return set_error(WOST_ERR_INVALID, "null argument");
+    if (h->precision == 16 && h->inference_h) {
+        *half = true;
+        hv->L = h->L;
+        hv->image = reinterpret_cast<const uint2 *>(snap);
+        return WOST_OK;
+    }
+    if (h->use_mfma && h->inference_f && h->L.dims == 2) {
+        *half = false;
+        fv->L = h->L;
+        fv->frag = reinterpret_cast<const float *>(snap);
+        fv->grid = fv->frag + h->L.n_mlp;
+        return WOST_OK;
+    }
+    return WOST_ERR_UNSUPPORTED;
+}
+
 int net_optimizer_steps(const wost_net *h) { return h->step; }
 uint64_t net_launch_count(const wost_net *h) { return h->n_launches; }
 void net_set_gradient_divisor(wost_net *h, float ranks) { h->grad_div = ranks > 0.0f ? ranks : 1.0f; }

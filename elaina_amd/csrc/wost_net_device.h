@@ -57,6 +57,15 @@ struct F32NetView {
 // WOST_ERR_UNSUPPORTED unless the network has the reference's shape (the MFMA kernels)
 int net_f32_view(wost_net_handle h, F32NetView *out);
 
+// A frozen copy of what the views above point at (the pipelined training order of the guided solve: a sample walks with the
+// weights of an earlier training pass while the optimizer rewrites the network's own images on another stream).
+// net_snapshot_bytes: size of one copy (0: the network offers neither view); net_snapshot_dev copies the current inference
+// weights into `dst` on `stream`; net_snapshot_views points the views at a copy (the layout members are filled as by the
+// view calls; *half tells which of the two is valid).
+size_t net_snapshot_bytes(wost_net_handle h);
+int net_snapshot_dev(wost_net_handle h, void *dst, hipStream_t stream);
+int net_snapshot_views(wost_net_handle h, const void *snap, bool *half, HalfNetView *hv, F32NetView *fv);
+
 // one level of the DenseGrid encoding of (x, y), fp32 (tiny-cuda-nn grid.h semantics as restated by the oracle): the
 // arithmetic of net_forward_mfma_kernel, which calls this function
 __device__ __forceinline__ float4 f32_encode_level(const float *grid, float sc, uint32_t res, uint32_t lo, uint32_t n_level, float x, float y)

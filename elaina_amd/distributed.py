@@ -104,6 +104,7 @@ def assemble_field(field, world, rank, width, height, mode="auto"):
 
 
 SYNC_SUM_I64_DEVICE, SYNC_MIN_I64_HOST, SYNC_RANKS_I64_HOST = 0, 1, 2      # wost_sync_fn ops (include/wost.h)
+SYNC_UNSUPPORTED = 2       # what a callback returns for an op it does not know (0 = done, anything else = failed)
 
 
 def make_network_sync(grad, synchronize=None):
@@ -111,8 +112,9 @@ def make_network_sync(grad, synchronize=None):
     int64 fixed-point gradient tensor the library accumulates into (wost_net_set_gradient_buffer); before every
     Adam step it is summed over the ranks -- integers, so every rank ends with the same bits whatever the order --
     once per training pass the ranks agree on the number of full batches (MIN), and once per solve the library
-    asks for the number of ranks (it divides the summed gradient by it).  Returns f(op, data_ptr, count) -> 0 / 1;
-    an unknown op is an error (never a silent MIN)."""
+    asks for the number of ranks (it divides the summed gradient by it).  Returns f(op, data_ptr, count) -> 0 on
+    success, SYNC_UNSUPPORTED (2) for an op it does not know (never a silent MIN), 1 for a failure -- the library
+    ends the solve on a failure and only tolerates "unsupported" for the rank-count op."""
     import ctypes as C
     import torch
     import torch.distributed as dist
@@ -132,7 +134,7 @@ def make_network_sync(grad, synchronize=None):
                 v[0] = int(t.item())
             else:
                 print("network sync: unknown op %d" % op)
-                return 1
+                return SYNC_UNSUPPORTED
             return 0
         except Exception as e:     # never let an exception cross the C boundary
             print("network sync failed: %r" % (e,))

@@ -220,6 +220,11 @@ class GuidedIntegrator:
         except Exception:
             pass
 
+    def set_option(self, key, value):
+        """wost_guided_set_option: "pipeline" 1 = the pipelined training order (sample k + 1 walks with the weights of training
+        pass k - 1 while pass k trains on a second stream; statistically equivalent, never the parity mode)"""
+        _check(self.lib.wost_guided_set_option(self._handle, key.encode(), float(value)), "wost_guided_set_option")
+
     def solve(self):
         """returns wall milliseconds like the reference; the field is in self.solution"""
         field = np.zeros((self.n_pixels, 3), dtype=np.float32)

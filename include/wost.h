@@ -307,12 +307,16 @@ int wost_guided_solve_sharded(wost_guided_handle h, int32_t shard_index, int32_t
  * int64[1]); the summed gradient is divided by it before the Adam step, so that a shared step is
  * the step of ONE batch of ranks x batch_size samples (each rank normalises its loss gradient by
  * its own batch) and the L2 term and epsilon keep their weight for any rank count.  (The op exists since library
- * version 0.2, wost_version(); a callback that refuses it gets the summed gradient undivided, with a warning on stderr.)
+ * version 0.2, wost_version(); a callback written against 0.1 answers it with WOST_SYNC_UNSUPPORTED and gets the summed
+ * gradient undivided, with a warning on stderr.)
  * The divisor belongs to the solve: afterwards wost_net_train_step on the same network is a plain single-rank step.
- * Return 0 on success. */
+ * Return 0 on success, WOST_SYNC_UNSUPPORTED for an op the callback does not know, any other value for a failure:
+ * a failure of ANY op -- or a rank count below 1 -- fails the solve with WOST_ERR_DEVICE (a rank that trained on while
+ * another one failed would let the "shared" weights diverge silently). */
 #define WOST_SYNC_SUM_I64_DEVICE 0
 #define WOST_SYNC_MIN_I64_HOST 1
 #define WOST_SYNC_RANKS_I64_HOST 2
+#define WOST_SYNC_UNSUPPORTED 2      /* return value of a callback for an unknown op */
 typedef int (*wost_sync_fn)(void *user, int op, void *data, uint64_t count);
 int wost_guided_set_sync(wost_guided_handle h, wost_sync_fn fn, void *user);
 /* Intermediate frames (saveSppMetrics* / saveTimeMetrics* of GuidedIntegratorSettings, reference
@@ -329,6 +333,19 @@ int wost_guided_set_frame_callback(wost_guided_handle h, wost_frame_fn fn, void 
  * Copies min(n, capacity) entries; any output array may be NULL. */
 int wost_guided_train_set(wost_guided_handle h, int32_t capacity, int32_t *n, float *xy, float *dir,
                           float *solution, float *dir_pdf, float *normal, uint8_t *on_neumann);
+/* Options of a guided handle; unknown keys -> WOST_ERR_INVALID.
+ * "pipeline" (0 default / 1): the PIPELINED training order.  The reference trains between the samples
+ * (integrator/guided/integrator.cu:968-1094: walk of sample k, trainStep on its records, walk of sample k + 1 with the new
+ * weights); with "pipeline" 1 sample k + 1 walks with a frozen copy of the weights that the training pass of sample k - 1
+ * left while the pass of sample k runs on a second stream -- no barrier between walking and training.  The estimator
+ * stays unbiased for any network state (direction and one-sample-MIS density of a sample come from the same copy, the
+ * training records carry the density they were drawn with); the field differs from the exact order's statistically, so
+ * this is never the parity mode: default off, and a solve with intermediate frames falls back to the exact order.
+ * "train_group" (1 default .. 16): a training launch walks that many samples of every pixel back to back, each with its own
+ * record set, and their training passes follow the launch (with "pipeline" 1: on the second stream, while the next group
+ * walks): the drain of a sample's longest walks is paid once per group.  The same statistical contract as "pipeline";
+ * 1 = the reference's order (a training pass between any two samples). */
+int wost_guided_set_option(wost_guided_handle h, const char *key, double value);
 int wost_guided_destroy(wost_guided_handle h);
 
 /* Tuning knobs ("steps_per_round", "block_size", "refill", "thin_waves", ...; scheduling only,

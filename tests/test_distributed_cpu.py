@@ -174,7 +174,7 @@ def _eight_worker(rank, world, port, w, h, spp, depth, q):
     assert sync(D.SYNC_MIN_I64_HOST, C.cast(C.pointer(v), C.c_void_p), 1) == 0
     n = C.c_int64(0)
     assert sync(D.SYNC_RANKS_I64_HOST, C.cast(C.pointer(n), C.c_void_p), 1) == 0
-    assert sync(99, None, 0) == 1
+    assert sync(99, None, 0) == D.SYNC_UNSUPPORTED == 2      # 'op unknown' is told apart from a failure (1)
     if r == 0:
         q.put((reduced.numpy().reshape(-1, 3), gathered.numpy().reshape(-1, 3), int(steps.item()), gfield.numpy().reshape(-1, 3),
                grad.numpy().copy(), v.value, n.value))

@@ -32,6 +32,9 @@ ap.add_argument("--one-shard-of", type=int, default=0,
                 help="single process: run only shard 0 of N (what ONE rank of an N-GPU job does, no reduce)")
 ap.add_argument("--net-precision", type=int, default=32, choices=[32, 16])
 ap.add_argument("--net-train-precision", type=int, default=0, choices=[0, 32, 16])
+ap.add_argument("--pipeline", type=int, default=0, help="1: the pipelined training order (wost_guided_set_option)")
+ap.add_argument("--train-group", type=int, default=1)
+ap.add_argument("--repeat", type=int, default=1, help="solves (fresh integrator each); the last one is reported")
 a = ap.parse_args()
 
 rank, world, local = D.init_process_group(a.backend)
@@ -42,25 +45,34 @@ prob = Problem.load_scene(a.scene)
 st = GuidedIntegratorSettings(frameSize=(a.frame, a.frame), samplesPerPixel=a.spp, trainSppCount=a.train_spp,
                               maxWalkingDepth=a.depth, epsilonShell=1.0, maxGuidedDepthInTrainingPhase=a.guided_depth,
                               maxGuidedDepthInGuidingPhase=a.guided_depth, batchSize=a.batch, minBatchSize=a.min_batch)
-t0 = time.time()
-gi = GuidedIntegrator(prob, st, ((-100.0, -100.0), (600.0, 600.0)), device=device)
-t_create = time.time() - t0
-if a.shared_network and world > 1:
-    gi.share_network()
-if a.net_precision == 16:
-    gi.network.set_option("precision", 16)
-if (a.net_train_precision or a.net_precision) == 16:
-    gi.network.set_option("train_precision", 16)
 field = torch.zeros(a.frame * a.frame * 3, dtype=torch.float32, device="cuda")
 if world > 1:
     import torch.distributed as dist
-    dist.barrier()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-s = gi.solve_sharded(rank, shard_world, field.data_ptr())
-D.reduce_field(field, world)
-torch.cuda.synchronize()
-elapsed = time.perf_counter() - t0
+for rep in range(a.repeat):
+    t0 = time.time()
+    gi = GuidedIntegrator(prob, st, ((-100.0, -100.0), (600.0, 600.0)), device=device)
+    t_create = time.time() - t0
+    if a.shared_network and world > 1:
+        gi.share_network()
+    if a.net_precision == 16:
+        gi.network.set_option("precision", 16)
+    if (a.net_train_precision or a.net_precision) == 16:
+        gi.network.set_option("train_precision", 16)
+    if a.pipeline:
+        gi.set_option("pipeline", a.pipeline)
+    if a.train_group > 1:
+        gi.set_option("train_group", a.train_group)
+    field.zero_()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s = gi.solve_sharded(rank, shard_world, field.data_ptr())
+    D.reduce_field(field, world)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if rep + 1 < a.repeat:
+        gi.close()
 tot = torch.tensor([float(s["walk_steps"]), float(s["guided_steps"]), float(s["train_samples"]), float(s["optimizer_steps"])],
                    dtype=torch.float64, device="cuda")
 mx = torch.tensor([elapsed, s["train_ms"] / 1e3], dtype=torch.float64, device="cuda")
@@ -77,7 +89,7 @@ if rank == 0:
     print(json.dumps({
         "networks_identical": bool((pmin == pmax).all().item()), "shared_network": bool(a.shared_network and world > 1),
         "workload": "%s guided %dx%d %d spp (train %d) depth %d" % (a.scene, a.frame, a.frame, a.spp, a.train_spp, a.depth),
-        "n_gpus": world, "shard": "%d of %d" % (rank, shard_world), "solve_s": float(mx[0]), "train_s": float(mx[1]), "create_s": t_create,
+        "pipeline": a.pipeline, "train_group": a.train_group, "n_gpus": world, "shard": "%d of %d" % (rank, shard_world), "solve_s": float(mx[0]), "train_s": float(mx[1]), "create_s": t_create,
         "walk_steps": int(tot[0]), "walk_steps_per_s": float(tot[0]) / float(mx[0]), "guided_steps": int(tot[1]),
         "train_samples": int(tot[2]), "optimizer_steps_all_ranks": int(tot[3]), "kernel_launches": s["kernel_launches"],
         "mean": float(field.mean().item()),
