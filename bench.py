@@ -62,6 +62,9 @@ def parse_args(argv=None):
     ap.add_argument("--net-precision", type=int, default=32, choices=[32, 16],
                     help="guided: 32 = fp32 network (bit-exact mode, default), 16 = the reference's half-precision network "
                          "(inference and the training passes on f16 MFMAs; fp32 master weights)")
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1],
+                    help="guided configs: 1 = training passes on a second stream (wost_guided_set_option; opt-in, never the parity mode)")
+    ap.add_argument("--train-group", type=int, default=1, help="guided configs: samples per training launch (opt-in, never the parity mode)")
     ap.add_argument("--net-train-precision", type=int, default=0, choices=[0, 32, 16],
                     help="guided: precision of the training passes alone (0 = follow --net-precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,18 +197,21 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
     field = torch.zeros(frame * frame * 3, dtype=torch.float32, device=env.dev)
     stream = torch.cuda.current_stream(env.dev)
 
-    exchange_ms = [0.0]
+    # the one exchange of a pass, timed with events on the stream -- no host synchronisation inside a timed pass, so N-GPU
+    # `value` / ms_per_step are measured like the one-GPU ones -- and read back only for the timed passes
+    exchange_events = []
 
-    def one_pass(integ):
+    def one_pass(integ, timed=False):
         field.zero_()
         st = integ.solve_sharded(env.rank, env.world, field.data_ptr(), stream.cuda_stream)
         if env.world > 1:
-            # the one exchange of the solve, timed on its own (it waits for the slowest rank's shard: rank imbalance shows here)
-            torch.cuda.synchronize()
-            t = time.perf_counter()
+            e0, e1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else (None, None)
+            if timed:
+                e0.record(stream)
             env.D.assemble_field(field, env.world, env.rank, frame, frame)
-            torch.cuda.synchronize()
-            exchange_ms[0] += (time.perf_counter() - t) * 1e3
+            if timed:
+                e1.record(stream)
+                exchange_events.append((e0, e1))
         return st
 
     # time-to-1spp (cold first pass of a fresh handle, then steady state), outside the timed region
@@ -223,12 +229,15 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
 
     for _ in range(warmup):
         one_pass(it)
+    if env.world > 1 and warmup == 0:
+        env.D.assemble_field(torch.zeros_like(field), env.world, env.rank, frame, frame)      # a warm communicator before the timed passes
+    torch.cuda.synchronize()
     env.barrier()
     t0 = time.perf_counter()
     steps_local, kernel_ms, launches = 0, 0.0, 0
     sched = {"visits": 0, "trav_trips": 0, "step_trips": 0}
     for _ in range(steps):
-        st = one_pass(it)
+        st = one_pass(it, timed=True)
         steps_local += st["walk_steps"]
         kernel_ms += st["kernel_ms"]
         launches += st["kernel_launches"]
@@ -254,7 +263,9 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
     }
     if env.world > 1:
         # per-rank figures of the timed passes, so that an N-GPU record shows imbalance at a glance
-        mine = torch.tensor([kernel_ms / steps, float(steps_local) / steps, exchange_ms[0] / (steps + warmup + (4 if one_spp else 0))],
+        # (the event pair brackets the collective on this rank's stream: it includes the wait for the slowest rank's shard)
+        exchange_ms = sum(a.elapsed_time(b) for a, b in exchange_events)
+        mine = torch.tensor([kernel_ms / steps, float(steps_local) / steps, exchange_ms / max(len(exchange_events), 1)],
                             dtype=torch.float64, device=env.dev)
         allr = [torch.zeros_like(mine) for _ in range(env.world)]
         env.dist.all_gather(allr, mine)
@@ -279,7 +290,7 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
     return res
 
 
-def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, precision=None):
+def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, precision=None, order=None):
     """timed solves of the guided integrator (training included: it is part of the path)"""
     torch = env.torch
     from elaina_amd import Problem
@@ -300,6 +311,12 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
             gi.network.set_option("precision", 16)
         if (args.net_train_precision or precision or args.net_precision) == 16:
             gi.network.set_option("train_precision", 16)
+        # opt-in training orders (never the parity mode): (pipeline, train_group) of wost_guided_set_option
+        pipeline, group = order if order else (args.pipeline, args.train_group)
+        if pipeline:
+            gi.set_option("pipeline", pipeline)
+        if group > 1:
+            gi.set_option("train_group", group)
         field.zero_()
         env.barrier()
         t0 = time.perf_counter()
@@ -367,15 +384,20 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
         "guided_steps_per_pass": guided_steps / steps, "optimizer_steps_per_pass": opt_steps / steps,
         "train_samples_per_pass": train_samples / steps, "kernel_launches_per_pass": launches / steps / max(env.world, 1),
         "shared_network": bool(args.shared_network and env.world > 1),
+        "training_order": ("the reference's: a training pass between any two samples (the parity mode)" if not (pipeline or group > 1) else
+                           "reordered (opt-in, statistically gated): %d samples per training launch%s" %
+                           (group, ", their passes on a second stream while the next group walks" if pipeline else "")),
         "network_precision": ("f16 inference (v_mfma_f32_16x16x32_f16), " if half else "fp32 inference (v_mfma_f32_16x16x4_f32), ") +
                              ("f16 training passes, fp32 master weights" if half_train else "fp32 training"),
         "roofline": {"bound": "valu", "kernel": "guided_sample_kernel", "counters": sample_kernel,
                      "what": "the dominant kernel of this configuration (one launch per sample: walk, network inference on the matrix "
-                             "cores and mixture sampling in one wave); the network-only probe is roofline_mfma"},
+                             "cores and mixture sampling in one wave); the network-only figure is mfma_probe_of_net_forward_kernel (a kernel the solve does not launch)"},
         "training_step": {"ms": (train_s / max(opt_steps / max(env.world, 1), 1.0)) * 1e3 if opt_steps else None,
                           "achieved": train_tf, "peak": train_peak, "unit": "TFLOP/s", "frac": (train_tf / train_peak) if train_tf else None,
                           "flop_per_sample": 3.0 * FLOP_PER_POINT, "samples_per_step": train_samples / max(opt_steps, 1.0)},
-        "roofline_mfma": {"bound": "mfma", "kernel": ("net_forward_h_kernel" if half else "net_forward_mfma_kernel") +
+        # the key says what it is: measured on the solve's own inference launches (the per-depth path), or a PROBE of the network
+        # kernel on a short per-depth pass -- the fused solve evaluates the network inside guided_sample_kernel and launches no such kernel
+        ("roofline_mfma" if infer_s > 0 else "mfma_probe_of_net_forward_kernel"): {"bound": "mfma", "kernel": ("net_forward_h_kernel" if half else "net_forward_mfma_kernel") +
                           (" (inference launches, HIP events)" if infer_s > 0 else
                            " (inference launches of a 6-spp pass of the per-depth path, HIP events; the solve itself evaluates the network inside guided_sample_kernel)"),
                           "achieved": infer_tf, "peak": peak_tf, "unit": "TFLOP/s",
@@ -385,6 +407,9 @@ def run_guided(env, scene, frame, spp, train_spp, depth, steps, warmup, args, pr
                           "probe": None if (infer_s > 0 or probe is None) else {"points": probe_points, "kernel_s": probe_s}},
     }
     return {"out": out, "field": field, "problem": problem, "depth": depth, "eps": eps}
+
+
+REORDERED = (0, 16)      # (pipeline, train_group) of the configs.*_pipelined entries
 
 
 def run_guiding_gain(env):
@@ -409,17 +434,21 @@ def run_guiding_gain(env):
     ref, u = uniform(8192), uniform(128)
     out = {"scene": "bright disc (r 3) + dark disc (r 14) in a reflecting box, 128x128, depth 128, eps 0.05",
            "reference": "uniform integrator, 8192 spp", "rmse_uniform_128spp": float(np.sqrt(np.mean((u - ref) ** 2)))}
-    for prec in (32, 16):
+    for prec, order in ((32, None), (16, None), (16, REORDERED)):
         st = GuidedIntegratorSettings(frameSize=(w, w), samplesPerPixel=128, trainSppCount=64, maxWalkingDepth=depth, epsilonShell=eps,
                                       batchSize=65536, minBatchSize=8192)
         g = GuidedIntegrator(p, st, BRIGHT_DISC_AABB, device=env.local)
         if prec == 16:
             g.network.set_option("precision", 16)
             g.network.set_option("train_precision", 16)
+        if order:
+            g.set_option("pipeline", order[0])
+            g.set_option("train_group", order[1])
         g.solve()
         r = float(np.sqrt(np.mean((g.solution - ref) ** 2)))
-        out["rmse_guided_f%d_64+64spp" % prec] = r
-        out["ratio_f%d" % prec] = r / out["rmse_uniform_128spp"]
+        tag = "f%d%s" % (prec, "_pipelined" if order else "")
+        out["rmse_guided_%s_64+64spp" % tag] = r
+        out["ratio_%s" % tag] = r / out["rmse_uniform_128spp"]
         g.close()
     return out
 
@@ -625,8 +654,12 @@ def main():
         line.update({"value": o["value"], "ms_per_step": o["ms_per_step"],
                      "config": {"workload": o["workload"], "parallelism": "pixel-tiles x%d" % env.world,
                                 "walk_steps_per_pass": o["walk_steps_per_pass"], "config": args.config},
-                     "guided": {k: o[k] for k in o if k not in ("workload", "value", "ms_per_step", "walk_steps_per_pass", "roofline_mfma", "roofline")},
-                     "roofline": o["roofline"], "roofline_mfma": o["roofline_mfma"]})
+                     "guided": {k: o[k] for k in o if k not in ("workload", "value", "ms_per_step", "walk_steps_per_pass", "roofline_mfma",
+                                                                "mfma_probe_of_net_forward_kernel", "roofline")},
+                     "roofline": o["roofline"]})
+        for k in ("roofline_mfma", "mfma_probe_of_net_forward_kernel"):
+            if k in o:
+                line[k] = o[k]
         if env.rank == 0:
             f = r["field"].cpu().numpy()
             line["field_mean"] = float(f.mean())
@@ -660,6 +693,12 @@ def main():
             if uniform_field is not None:
                 e4h["rel_l2_vs_uniform_field"] = rel_l2(r4h["field"].cpu().numpy(), uniform_field.cpu().numpy())
             extras["cfg4_f16"] = e4h
+            # the same in the opt-in reordered training order (sixteen samples per training launch; cfg4 / cfg4_f16 above stay exact-order)
+            r4p = run_guided(env, "ladybug", 1024, 256, 256, 0, 1, 0, args, precision=16, order=REORDERED)
+            e4p = r4p["out"]
+            if uniform_field is not None:
+                e4p["rel_l2_vs_uniform_field"] = rel_l2(r4p["field"].cpu().numpy(), uniform_field.cpu().numpy())
+            extras["cfg4_f16_pipelined"] = e4p
             extras["uniform3d"] = run_uniform3d(env, args)
             extras["guided3d"] = run_guided3d(env, args)
             extras["neumann2d"] = run_neumann2d(env, args)
@@ -678,7 +717,8 @@ def main():
                     "reference": "ladybug 1024x1024, uniform integrator, 4096 spp",
                     "rel_l2_uniform_256spp": rel_l2(uniform_field.cpu().numpy(), refn),
                     "rel_l2_guided_256spp": rel_l2(r4["field"].cpu().numpy(), refn),
-                    "rel_l2_guided_f16_256spp": rel_l2(r4h["field"].cpu().numpy(), refn)}
+                    "rel_l2_guided_f16_256spp": rel_l2(r4h["field"].cpu().numpy(), refn),
+                    "rel_l2_guided_f16_pipelined_256spp": rel_l2(r4p["field"].cpu().numpy(), refn)}
         else:
             r5 = run_guided(env, "ladybug", 2048, 1024, 256, 0, 1, 0, args)
             extras["cfg5"] = r5["out"]

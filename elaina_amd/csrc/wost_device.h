@@ -438,6 +438,9 @@ __device__ __forceinline__ Closest closest_point_flat(const DevMesh &m, float qx
 // to vertices within rmax; +inf when there is none.  Test = FCPW isSilhouetteVertex.
 __device__ __forceinline__ float closest_silhouette_flat(const DevMesh &m, float qx, float qy, float rmax)
 {
+#ifdef WOST_EXP_NO_SIL
+    return WOST_INF;      // developer experiment: what the silhouette loop costs (a convex box seen from inside has none)
+#endif
     float best2 = rmax * rmax;
     bool found = false;
     for (int v = 0; v < m.n_sil; ++v) {

@@ -486,9 +486,31 @@ struct SampleOut {
     float x, y, thp, nx, ny;
 };
 
-template <bool TREE, class RAW>
+// The mixture of a walker, as sample_step uses it.  MixRegs: built by the walker's lane from the raw network outputs, in
+// registers (the per-depth sample_kernel).  MixCol: prepared by the lanes of the network unit and left in the lane's LDS
+// column (guided_sample_kernel).  Same arithmetic, same bits.
+template <class RAW>
+struct MixRegs {
+    const RAW &raw;
+    Vmm m;
+    __device__ __forceinline__ explicit MixRegs(const RAW &r) : raw(r) {}
+    __device__ __forceinline__ float logit() const { return raw(32); }
+    __device__ __forceinline__ void prepare() { m.build(raw); }
+    __device__ __forceinline__ void sample(Pcg &rng, float &ox, float &oy) const { m.sample(rng, ox, oy); }
+    __device__ __forceinline__ void pdf_pair(float ax, float ay, float bx, float by, bool two, float &pa, float &pb) const { m.pdf_pair(ax, ay, bx, by, two, pa, pb); }
+};
+struct MixCol {
+    const LdsColumn &col;
+    __device__ __forceinline__ explicit MixCol(const LdsColumn &c) : col(c) {}
+    __device__ __forceinline__ float logit() const { return vmm_col(col, 40); }
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ void sample(Pcg &rng, float &ox, float &oy) const { vmm_col_sample(col, rng, ox, oy); }
+    __device__ __forceinline__ void pdf_pair(float ax, float ay, float bx, float by, bool two, float &pa, float &pb) const { vmm_col_pdf_pair(col, ax, ay, bx, by, two, pa, pb); }
+};
+
+template <bool TREE, class MIX>
 __device__ __forceinline__ SampleOut sample_step(const GParams &P, uint32_t pid, bool on_n, float x, float y, float thp, float nx, float ny,
-                                                 float R_B, int depth, bool guiding, Pcg &rng, const RAW &raw, const LdsColumn &stk, uint32_t rofs = 0u)
+                                                 float R_B, int depth, bool guiding, Pcg &rng, MIX &m, const LdsColumn &stk, uint32_t rofs = 0u)
 {
     SampleOut o{false, false, false, x, y, thp, nx, ny};
     const bool record = is_training_pixel(P, pid) && depth < P.max_train_depth;
@@ -496,7 +518,7 @@ __device__ __forceinline__ SampleOut sample_step(const GParams &P, uint32_t pid,
     if (!guiding) {
         uniform_direction(on_n, nx, ny, rng, dirx, diry, pdf, alpha);
     } else {
-        const float sel = 1 / (1.f + det_expf(-raw(32)));                 // logistic (functors.h:182)
+        const float sel = 1 / (1.f + det_expf(-m.logit()));               // logistic (functors.h:182)
         const bool inside = aabb_contains(P.box, x, y);
         // the draw precedes the box test and is skipped for uniform fraction 0 (:518)
         bool to_guided = (P.uniform_fraction == 0.0f) || (pcg_next_float(rng) < sel);
@@ -504,9 +526,8 @@ __device__ __forceinline__ SampleOut sample_step(const GParams &P, uint32_t pid,
         o.dropped = to_guided && !(P.uniform_fraction < 1.0f);            // kernel never launched (:1031)
         // the mixture is needed by both branches inside the box: for the sample and its pdf,
         // or for the MIS weight of a uniform sample
-        Vmm m;
         const bool use_vmm = inside && !o.dropped;
-        if (use_vmm) m.build(raw);
+        if (use_vmm) m.prepare();
         float uniform_pdf = 0.0f;
         if (to_guided) {
             if (!o.dropped) {
@@ -577,7 +598,8 @@ __global__ __launch_bounds__(256) void sample_kernel(GParams P)
             raw32 = rp[32 * ld];
         }
         const auto raw = [&](int j) { return j < 8 ? r0[j & 7] : j < 16 ? r1[j & 7] : j < 24 ? r2[j & 7] : j < 32 ? r3[j & 7] : raw32; };
-        const SampleOut o = sample_step<TREE>(P, pid, on_n, x, y, thp, nx, ny, R_B, P.depth, P.guiding != 0, rng, raw, stk);
+        MixRegs<decltype(raw)> mix(raw);
+        const SampleOut o = sample_step<TREE>(P, pid, on_n, x, y, thp, nx, ny, R_B, P.depth, P.guiding != 0, rng, mix, stk);
         P.rng[pid] = rng.state;
         guided_step = o.guided_step;
         if (o.dropped) {
@@ -623,16 +645,24 @@ __global__ __launch_bounds__(256) void guided_init_kernel(GParams P)
 // tail_kernel, and the network arithmetic is that of net_forward_h_kernel (same device functions): the field,
 // the training records and hence the trained weights are bit-identical to the one-launch-per-depth path.
 // waves per CU sharing one copy of the weight fragments: 12 with the f16 fragments (26 KB), 10 with the fp32 ones (53 KB)
-constexpr int fused_threads(bool half) { return half ? 768 : 640; }
-// per wave: 64 network inputs (x, y), then 16 x 48 outputs (f16 / fp32; the fp32 unit stages its encoding in the same words)
-constexpr int fused_xch_words(bool half) { return half ? 128 + 16 * 48 / 2 : 128 + 16 * 48; }
-constexpr int kStageStride = 32 + 2;     // fp32 unit: staged encoding rows, padded like net_forward_mfma_kernel's
+#ifndef WOST_FUSED_THREADS_H
+#define WOST_FUSED_THREADS_H 768
+#endif
+constexpr int fused_threads(bool half) { return half ? WOST_FUSED_THREADS_H : 640; }
+// per wave, beside the lanes' columns: which lane the k-th point of the wave's network batch belongs to (64 bytes)
+constexpr int fused_xch_words(bool) { return 16; }
+// LDS fence + barrier between lanes of ONE wave that hand data to each other through LDS
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 template <bool EMISSIVE, bool TREE, bool SOURCE, bool HALF>
 __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GParams P, FusedNet F)
 {
     constexpr int kFusedThreads = fused_threads(HALF), kXchWords = fused_xch_words(HALF);
-    extern __shared__ uint32_t lds_all[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
     __shared__ float s_scale[8];
     __shared__ uint32_t s_res[8], s_off[9];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -642,9 +672,7 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
     uint2 *wf = reinterpret_cast<uint2 *>(wbase);               // HALF
     float *wf32 = reinterpret_cast<float *>(wbase);             // fp32
     const uint32_t w_words = HALF ? 2u * F.n_frag : F.n_mlp;
-    float *xch_xy = reinterpret_cast<float *>(wbase + w_words) + (size_t)wave * kXchWords;
-    _Float16 *xch_out = reinterpret_cast<_Float16 *>(xch_xy + 128);
-    float *xch_out32 = xch_xy + 128;
+    uint8_t *xch_own = reinterpret_cast<uint8_t *>(wbase + w_words + (size_t)wave * kXchWords);
     if (HALF) {
         for (uint32_t e = threadIdx.x; e < F.n_frag; e += kFusedThreads) wf[e] = F.image[e];
     } else {
@@ -804,26 +832,33 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
             const bool keep = act && status == SEP_KEEP;
             const bool guiding = keep && depth < P.max_guided_depth;
             // ---- the network for the lanes that need it: all 64 lanes take part (matrix instructions) ----
-            typedef typename std::conditional<HALF, _Float16, float>::type raw_t;
-            raw_t rawv[33];
-#pragma unroll
-            for (int j = 0; j < 33; ++j) rawv[j] = (raw_t)0.0f;
+            // Everything the network and the mixture exchange between lanes goes through the LDS COLUMNS of the walkers' lanes: a lane
+            // in the step phase has finished its query, so its traversal stack is empty and its column (at least kVmmColWords deep)
+            // is free.  The walker's lane leaves its input there; the sixteen-point unit writes the point's mixture back -- prepared,
+            // four lanes per point: lane (i, g) owns the lobes g and 4 + g (vmm_lobe: two exponentials, the normalised mean, log I0)
+            // and their weights -- and sample_step reads one lobe at a time (MixCol).  Forty registers of mixture per lane, and the
+            // eight lobes computed by one lane in sixteen of a wave's 64, were what this kernel spilled and waited for.
             const unsigned long long bal = __ballot(guiding);
             if (bal) {
                 const int n_need = __popcll(bal);
                 const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+                float *col0 = reinterpret_cast<float *>(lds_all + (size_t)wave * P.stack_words * 64);     // entry e of lane L at col0[e * 64 + L]
                 if (guiding) {
                     float ix, iy;
                     normalize_coord(P.box, x, y, ix, iy);
-                    xch_xy[2 * rank] = ix;
-                    xch_xy[2 * rank + 1] = iy;
+                    col0[lane] = ix;
+                    col0[64 + lane] = iy;
+                    xch_own[rank] = (uint8_t)lane;
                     ++c_net;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
                 for (int u = 0; 16 * u < n_need; ++u) {
                     const int q = 16 * u + li;
-                    const float qx = q < n_need ? xch_xy[2 * q] : 0.5f, qy = q < n_need ? xch_xy[2 * q + 1] : 0.5f;
+                    const bool qv = q < n_need;
+                    float *ocol = col0 + (qv ? (int)xch_own[q] : lane);      // the column of the point's walker (never written when !qv)
+                    const float qx = qv ? ocol[0] : 0.5f, qy = qv ? ocol[64] : 0.5f;
+                    VmmLobe lobe[2];
+                    float logit = 0.0f;
                     if (HALF) {
                         h4_t enc[2], out[3];
 #pragma unroll
@@ -832,51 +867,74 @@ __global__ __launch_bounds__(fused_threads(HALF)) void guided_sample_kernel(GPar
                             enc[h] = half_encode_level(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], qx, qy);
                         }
                         half_mlp_unit(wf, F.w_off4, lane, enc, out);
+                        // lane (i, g) receives the outputs 16 rt + 4 g + c of point i: the lobes g (rt = 0) and 4 + g (rt = 1), whole
 #pragma unroll
-                        for (int rt = 0; rt < 3; ++rt) {
-                            union { h4_t h; uint2 u; } o;
-                            o.h = out[rt];
-                            *reinterpret_cast<uint2 *>(xch_out + li * 48 + 16 * rt + 4 * lg) = o.u;
-                        }
+                        for (int h = 0; h < 2; ++h) lobe[h] = vmm_lobe((float)out[h][0], (float)out[h][1], (float)out[h][2], (float)out[h][3]);
+                        logit = (float)out[2][0];      // (output 32 in the lanes g = 0)
                     } else {
-                        // the encoding goes through LDS once (point-major rows), as in net_forward_mfma_kernel: the
-                        // matrix instruction wants feature 4 s + g of point i in lane (i, g)
+                        // the encoding goes through LDS once, as in net_forward_mfma_kernel: the matrix instruction wants feature
+                        // 4 s + g of point i in lane (i, g), the lane has computed the features 4 lv .. 4 lv + 3 of its two levels
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const int lv = lg + 4 * h;
                             const float4 f = f32_encode_level(F.grid32, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], qx, qy);
-                            float2 *st = reinterpret_cast<float2 *>(xch_out32 + li * kStageStride + lv * 4);
-                            st[0] = float2{f.x, f.y};
-                            st[1] = float2{f.z, f.w};
+                            if (qv) {
+                                ocol[(4 * lv + 0) * 64] = f.x; ocol[(4 * lv + 1) * 64] = f.y; ocol[(4 * lv + 2) * 64] = f.z; ocol[(4 * lv + 3) * 64] = f.w;
+                            }
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
+                        wave_lds_sync();
                         float b0[8], out[12];
 #pragma unroll
-                        for (int s_ = 0; s_ < 8; ++s_) b0[s_] = xch_out32[li * kStageStride + 4 * s_ + lg];
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
+                        for (int s_ = 0; s_ < 8; ++s_) b0[s_] = qv ? ocol[(4 * s_ + lg) * 64] : 0.0f;
+                        wave_lds_sync();
                         f32_mlp_unit(wf32, F.w_off, lane, b0, out);
+                        // out[4 rt + c] = output 16 rt + 4 c + g: component g of the lobes 4 rt + c -- turned lobe-major through the column
+                        if (qv) {
 #pragma unroll
-                        for (int rt = 0; rt < 3; ++rt)
+                            for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) xch_out32[li * 48 + 16 * rt + 4 * c + lg] = out[4 * rt + c];
+                                for (int c = 0; c < 4; ++c) ocol[(4 * (4 * rt + c) + lg) * 64] = out[4 * rt + c];
+                            if (lg == 0) ocol[32 * 64] = out[8];
+                        }
+                        wave_lds_sync();
+                        float r[2][4];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) r[h][c] = ocol[(4 * (lg + 4 * h) + c) * 64];
+                        logit = ocol[32 * 64];
+                        wave_lds_sync();
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) lobe[h] = vmm_lobe(r[h][0], r[h][1], r[h][2], r[h][3]);
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (guiding && (rank >> 4) == u) {
+                    if (qv) {
 #pragma unroll
-                        for (int j = 0; j < 33; ++j) rawv[j] = HALF ? (raw_t)xch_out[(rank & 15) * 48 + j] : (raw_t)xch_out32[(rank & 15) * 48 + j];
+                        for (int h = 0; h < 2; ++h) {
+                            const int k = lg + 4 * h;
+                            ocol[k * 64] = lobe[h].lambda; ocol[(8 + k) * 64] = lobe[h].kappa; ocol[(16 + k) * 64] = lobe[h].lb;
+                            ocol[(24 + k) * 64] = lobe[h].mux; ocol[(32 + k) * 64] = lobe[h].muy;
+                        }
+                        if (lg == 0) ocol[40 * 64] = logit;
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                    wave_lds_sync();
+                    // the weights lambda / sum: the sum over the eight lobes in their order (Vmm::finish), by each of the point's four lanes
+                    float total = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) total += ocol[k * 64];
+                    const float w0 = lobe[0].lambda / total, w1 = lobe[1].lambda / total;
+                    wave_lds_sync();
+                    if (qv) {
+                        ocol[lg * 64] = w0;
+                        ocol[(4 + lg) * 64] = w1;
+                    }
+                    wave_lds_sync();
                 }
             }
             if (act) {
                 bool ended = !keep;
                 if (keep) {
-                    const auto raw = [&](int j) { return (float)rawv[j]; };
-                    const SampleOut o = sample_step<TREE>(P, pid, on_n, x, y, thp, nx, ny, R_B, depth, guiding, rng, raw, stk, rofs);
+                    MixCol mix(stk);
+                    const SampleOut o = sample_step<TREE>(P, pid, on_n, x, y, thp, nx, ny, R_B, depth, guiding, rng, mix, stk, rofs);
                     if (o.guided_step) ++c_guided;
                     if (o.dropped) {
                         ended = true;
@@ -1434,7 +1492,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         }
         fused = fused_shape(L, F);
     }
-    P.d0_d2 = g->d0_d2; P.cursor = g->cursor; P.stack_words = stack_words;
+    P.d0_d2 = g->d0_d2; P.cursor = g->cursor; P.stack_words = std::max(stack_words, kVmmColWords);      // the fused kernel's columns also hold a walker's mixture
     P.wait_weight = 4; P.trav_burst = 10;     // measured on config 4 (a sweep over both constants)
     if (const char *w = std::getenv("WOST_GUIDED_WAIT_WEIGHT")) P.wait_weight = std::max(1, std::atoi(w));
     if (const char *w = std::getenv("WOST_GUIDED_TRAV_BURST")) P.trav_burst = std::max(1, std::atoi(w));
@@ -1442,7 +1500,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
     if (const char *w = std::getenv("WOST_GUIDED_TAIL_CHUNK")) P.tail_chunk = std::max(0, std::atoi(w));
     if (const char *w = std::getenv("WOST_GUIDED_TAIL_MARGIN")) P.tail_margin_pct = std::max(0, std::atoi(w));
     const int n_fused_threads = fused_threads(fused_half);
-    const size_t lds_fused = ((size_t)stack_words * n_fused_threads + (size_t)(n_fused_threads / 64) * fused_xch_words(fused_half) +
+    const size_t lds_fused = ((size_t)P.stack_words * n_fused_threads + (size_t)(n_fused_threads / 64) * fused_xch_words(fused_half) +
                               (fused_half ? (size_t)2 * F.n_frag : (size_t)F.n_mlp)) * sizeof(uint32_t);
     if (fused) {
         // the stack columns grow with the depth of the trees: when the fused kernel's LDS no longer fits a block (the fp32

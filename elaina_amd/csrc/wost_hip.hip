@@ -1425,7 +1425,12 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         // duration of such a launch is the latency of its slowest wave, and a wave is as slow as the
         // longest query among its walkers (config 2's last three launches: 13.1 -> 8.9 ms; with 2 or
         // 4 lanes per walker the extra waves cost more than they save: 9.2 -> 11.8 ms).
-        const unsigned resident_threads = (unsigned)(c->n_cus * (ntree ? 4 : 6) * 4 * 64);
+        // blocks a CU holds: the register bound of the instantiation (launch bounds: 6 waves per SIMD, 4 with the tree queries), and
+        // no more than fit its 160 KB of LDS -- with the wave task pools a block asks for about 64 KB (two per CU, not four)
+        const unsigned blocks_by_regs = (unsigned)((ntree ? 4 : 6) * 4 * 64 / bs);
+        const unsigned blocks_by_lds = (unsigned)std::max<size_t>(1, (size_t)160 * 1024 / std::max<size_t>(lds_round, 1));
+        const unsigned blocks_per_cu = std::max(1u, std::min(blocks_by_regs, blocks_by_lds));
+        const unsigned resident_threads = (unsigned)c->n_cus * blocks_per_cu * (unsigned)bs;
         rp.lane_shift = 0;
         if (c->thin_waves) {
             while (rp.lane_shift < 6 && ((uint64_t)n_active << (rp.lane_shift + 1)) <= resident_threads) ++rp.lane_shift;
@@ -1436,7 +1441,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         // Worth it when regeneration cannot keep the lanes busy (measured on config 2's frame:
         // 1 spp 3.5 -> 3.0 ms, 4 spp 8.3 -> 7.9 ms, 8 spp 13.0 -> 13.5 ms) and the queue is larger
         // than one residency; the 16-bit lane counters bound spp * max_depth.
-        const unsigned resident = (unsigned)(c->n_cus * (ntree ? 4 : 6) * 4 * 64 / bs);
+        const unsigned resident = (unsigned)c->n_cus * blocks_per_cu;
         const bool has_src = c->src.rgb != nullptr;
         const bool can_refill = (int64_t)c->settings.spp * c->settings.max_depth < 65535 && launches == 0 && !has_src;
         const bool refill = can_refill && (c->refill == 1 || (c->refill == -1 && c->settings.spp <= 4 && grid > resident));

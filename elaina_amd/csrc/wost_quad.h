@@ -127,6 +127,11 @@ __device__ __forceinline__ bool quad_visit(const DevMesh &m, float qx, float qy,
         const int nv = (int)(key < 0x80000000u) + (int)(k1 < 0x80000000u) + (int)(k2 < 0x80000000u) + (int)(k3 < 0x80000000u);
         // the sorted valid keys but the nearest go on the stack far to near: rank nv-1 at sp, ..., rank 1 at sp+nv-2
         if (valid && rank >= 1) stk.put(T.sp + nv - 1 - rank, key);
+        // the entries one lane of the quad has written are read by the other three (quad_pop, the next visit): an LDS fence
+        // inside the wave, so that the compiler cannot move a later load above these stores (the hardware keeps a wave's LDS
+        // operations in order: no instruction is spent)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         T.sp += max(nv - 1, 0);
         if (kmin < 0x80000000u) {
             T.pos = 4 * T.pos + (int)(kmin & 3u);

@@ -128,6 +128,27 @@ __device__ __forceinline__ float vm_rejection_sample(float kappa, double proposa
     }
 }
 
+// one lobe of the mixture from its four raw network outputs (train.h:60-79, distribution.h:150-165): everything that
+// does not depend on the other lobes.  A function of its own so that the lanes of a wave can prepare different lobes of
+// the same point (guided_sample_kernel) -- the arithmetic per lobe is the same wherever it runs.
+struct VmmLobe {
+    float lambda, kappa, mux, muy, lb;
+};
+__device__ __forceinline__ VmmLobe vmm_lobe(float r0, float r1, float x, float y)
+{
+    VmmLobe l;
+    l.lambda = det_expf(fmaxf(fminf(r0, 15.0f), -10.0f));
+    l.kappa = det_expf(fmaxf(fminf(r1, 15.0f), -10.0f));
+    // Eigen's normalized() (Eigen/src/Core/Dot.h, the library behind mu_original.normalized(),
+    // distribution.h:160): v / sqrt(z) when z = |v|^2 > 0, else v unchanged -- a zero vector
+    // stays zero instead of becoming NaN (half-precision outputs do underflow to exact zeros)
+    const float z = x * x + y * y, nn = sqrtf(z);
+    l.mux = z > 0.0f ? x / nn : x;
+    l.muy = z > 0.0f ? y / nn : y;
+    l.lb = log_bessel(l.kappa, 0);
+    return l;
+}
+
 // VMM<2,8>: lambda = exp(clamp(x,-10,15)), kappa likewise, mu = normalize(x,y), weights lambda/sum
 struct Vmm {
     // register vectors (constant indices after unrolling), not arrays: the struct must not end up in scratch
@@ -140,21 +161,20 @@ struct Vmm {
     __device__ __forceinline__ void build(F d)
     {
         f32x8 lambda;
-        float total = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            lambda[k] = det_expf(fmaxf(fminf(d(4 * k), 15.0f), -10.0f));
-            kap[k] = det_expf(fmaxf(fminf(d(4 * k + 1), 15.0f), -10.0f));
-            // Eigen's normalized() (Eigen/src/Core/Dot.h, the library behind mu_original.normalized(),
-            // distribution.h:160): v / sqrt(z) when z = |v|^2 > 0, else v unchanged -- a zero vector
-            // stays zero instead of becoming NaN (half-precision outputs do underflow to exact zeros)
-            const float x = d(4 * k + 2), y = d(4 * k + 3);
-            const float z = x * x + y * y, nn = sqrtf(z);
-            mux[k] = z > 0.0f ? x / nn : x;
-            muy[k] = z > 0.0f ? y / nn : y;
-            total += lambda[k];
-            lb[k] = log_bessel(kap[k], 0);
+            const VmmLobe l = vmm_lobe(d(4 * k), d(4 * k + 1), d(4 * k + 2), d(4 * k + 3));
+            lambda[k] = l.lambda; kap[k] = l.kappa; mux[k] = l.mux; muy[k] = l.muy; lb[k] = l.lb;
         }
+        finish(lambda);
+    }
+
+    // the mixture from lobes that vmm_lobe has already prepared (kap, mux, muy, lb set by the caller): the weights
+    __device__ __forceinline__ void finish(const f32x8 &lambda)
+    {
+        float total = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) total += lambda[k];
 #pragma unroll
         for (int k = 0; k < 8; ++k) weight[k] = lambda[k] / total;
     }
@@ -212,5 +232,53 @@ struct Vmm {
         oy = pmy * vx + py * vy;
     }
 };
+
+// ---- the same mixture kept in a lane's LDS column instead of forty registers ------------------------------------------
+// (guided_sample_kernel: the lanes of a 16-point unit prepare the lobes, four lanes per point, and leave them in the column
+// of the walker's lane.)  Entries: weight[k] at k, kappa at 8 + k, log I0(kappa) at 16 + k, mean at 24 + k / 32 + k, the
+// selection logit at 40.  Rolled loops over the lobes, one lobe's five values live at a time; the arithmetic and its order
+// are Vmm's (pdf sums ascend in k, the pick subtracts the weights in turn), so the results are the same bits.
+constexpr int kVmmColWords = 41;
+
+template <class COL>
+__device__ __forceinline__ float vmm_col(const COL &c, int e)
+{
+    return __uint_as_float(c.get(e));
+}
+
+template <class COL>
+__device__ __forceinline__ void vmm_col_pdf_pair(const COL &c, float ax, float ay, float bx, float by, bool two, float &pa, float &pb)
+{
+    pa = 0.0f;
+    pb = 0.0f;
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+        const float w = vmm_col(c, k), kap = vmm_col(c, 8 + k), lb = vmm_col(c, 16 + k), mx = vmm_col(c, 24 + k), my = vmm_col(c, 32 + k);
+        pa += w * vm_eval_lb(kap, lb, ax * mx + ay * my);
+        if (two) pb += w * vm_eval_lb(kap, lb, bx * mx + by * my);
+    }
+}
+
+template <class COL>
+__device__ __forceinline__ void vmm_col_sample(const COL &c, Pcg &rng, float &ox, float &oy)
+{
+    float u = pcg_next_float(rng);
+    int pick = 0;
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+        const float w = vmm_col(c, k);
+        if (u < w) { pick = k; break; }
+        u -= w;
+    }
+    const float pk = vmm_col(c, 8 + pick), pmx = vmm_col(c, 24 + pick), pmy = vmm_col(c, 32 + pick);
+    const float theta = vm_rejection_sample(pk, vm_proposal_r(pk), rng);
+    float vx, vy;
+    det_sincosf(theta, &vx, &vy);
+    float px = -pmy, py = pmx;   // frameFromTangent(mu): N = normalize(-mu.y, mu.x), T = mu
+    const float pz = px * px + py * py, pl = sqrtf(pz);
+    if (pz > 0.0f) { px /= pl; py /= pl; }      // Eigen normalized(): a zero vector stays zero
+    ox = pmx * vx + px * vy;
+    oy = pmy * vx + py * vy;
+}
 
 }  // namespace wost

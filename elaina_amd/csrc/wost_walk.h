@@ -131,9 +131,11 @@ __device__ __forceinline__ void uniform_direction(bool on_n, float nx, float ny,
                                                   float &pdf, float &alpha)
 {
     const float u = pcg_next_float(rng);
+    // ONE evaluation of the sine / cosine kernel for both kinds of lane (phi = pi u is the angle 2 pi (u / 2), and u / 2 is exact):
+    // written as two calls in the two branches, a wave that holds walkers of both kinds ran the kernel twice
+    float lc, ls;
+    sincos_2pi(on_n ? u * 0.5f : u, lc, ls);
     if (on_n) {
-        float lc, ls;
-        sincos_2pi(u * 0.5f, lc, ls);               // phi = pi * u
         const float qx = -ny, qy = nx;              // frameFromNormal: T = -normalize(-n.y, n.x)
         const float ql = sqrtf(dot2(qx, qy, qx, qy));
         const float tx = -(qx / ql), ty = -(qy / ql);
@@ -142,7 +144,8 @@ __device__ __forceinline__ void uniform_direction(bool on_n, float nx, float ny,
         pdf = (float)(1.0 / 3.14159265358979323846);
         alpha = 0.5f;
     } else {
-        sincos_2pi(u, dirx, diry);
+        dirx = lc;
+        diry = ls;
         pdf = 1.0f / WOST_2PI;
         alpha = 1.0f;
     }

@@ -456,7 +456,8 @@ void read_exr(const fs::path &path, int *width, int *height, std::vector<float> 
     if (!f.is_open()) throw std::runtime_error("cannot open " + path.string());
     std::vector<uint8_t> b((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     size_t pos = 0;
-    auto need = [&](size_t n) { if (pos + n > b.size()) throw std::runtime_error("exr: truncated file: " + path.string()); };
+    // (written so that neither an offset near 2^64 taken from the file nor a huge count can wrap the comparison)
+    auto need = [&](size_t n) { if (pos > b.size() || n > b.size() - pos) throw std::runtime_error("exr: truncated file: " + path.string()); };
     auto i32 = [&]() { need(4); int32_t v; std::memcpy(&v, &b[pos], 4); pos += 4; return v; };
     auto str = [&]() { std::string s; for (;;) { need(1); const char c = (char)b[pos++]; if (!c) break; s.push_back(c); if (s.size() > 255) throw std::runtime_error("exr: bad string"); } return s; };
     if (i32() != 20000630) throw std::runtime_error("not an OpenEXR file: " + path.string());
@@ -503,7 +504,9 @@ void read_exr(const fs::path &path, int *width, int *height, std::vector<float> 
     std::vector<uint64_t> offs((size_t)n_blocks);
     std::memcpy(offs.data(), &b[pos], (size_t)n_blocks * 8);
     rgb->assign((size_t)w * h * 3, 0.0f);
+    const size_t table_end = pos + (size_t)n_blocks * 8;      // the blocks lie behind the header and the offset table
     for (int64_t k = 0; k < n_blocks; ++k) {
+        if (offs[(size_t)k] < (uint64_t)table_end || offs[(size_t)k] >= (uint64_t)b.size()) throw std::runtime_error("exr: block offset outside the file: " + path.string());
         pos = (size_t)offs[(size_t)k];
         const int32_t y = i32(), nbytes = i32();
         if (nbytes < 0 || y < y0 || y > y1) throw std::runtime_error("exr: bad block");
@@ -541,6 +544,88 @@ void read_exr(const fs::path &path, int *width, int *height, std::vector<float> 
     *height = (int)h;
 }
 
+// Radiance RGBE picture (.hdr; stb_image's stbi__hdr_load is what the reference's Image::loadImage reaches for it,
+// core/texture.cu:26-71): text header up to an empty line, "-Y h +X w", then flat RGBE pixels or the run-length scan lines
+// of the "new" format (2 2 hi lo, then the four channels one after the other).  value = mantissa * 2^(e - 136), all four
+// bytes zero-exponent = black: exact arithmetic, so the decoded floats are the reference's.  Rows top to bottom.
+void read_hdr(const fs::path &path, int *width, int *height, std::vector<float> *rgb)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) throw std::runtime_error("cannot open " + path.string());
+    const std::vector<uint8_t> b((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    size_t pos = 0;
+    auto line = [&]() {
+        std::string l;
+        while (pos < b.size() && b[pos] != '\n') {
+            l.push_back((char)b[pos++]);
+            if (l.size() > 1024) throw std::runtime_error("hdr: header line too long: " + path.string());
+        }
+        if (pos >= b.size()) throw std::runtime_error("hdr: truncated header: " + path.string());
+        ++pos;
+        return l;
+    };
+    const std::string magic = line();
+    if (magic != "#?RADIANCE" && magic != "#?RGBE") throw std::runtime_error("not a Radiance picture: " + path.string());
+    bool rgbe = false;
+    for (;;) {
+        const std::string l = line();
+        if (l.empty()) break;
+        if (l == "FORMAT=32-bit_rle_rgbe") rgbe = true;
+    }
+    if (!rgbe) throw std::runtime_error("hdr: only FORMAT=32-bit_rle_rgbe is read: " + path.string());
+    const std::string res = line();
+    long h = 0, w = 0;
+    if (std::sscanf(res.c_str(), "-Y %ld +X %ld", &h, &w) != 2 || w <= 0 || h <= 0 || w > (1 << 24) || h > (1 << 24))
+        throw std::runtime_error("hdr: only the -Y h +X w orientation is read: " + path.string());
+    std::vector<uint8_t> px((size_t)w * h * 4);
+    auto need = [&](size_t n) { if (pos > b.size() || n > b.size() - pos) throw std::runtime_error("hdr: truncated file: " + path.string()); };
+    bool flat = w < 8 || w >= 32768;
+    if (!flat) {
+        need(4);
+        flat = b[pos] != 2 || b[pos + 1] != 2 || (b[pos + 2] & 0x80);      // no scan-line marker: flat pixels throughout
+    }
+    if (flat) {
+        need(px.size());
+        std::memcpy(px.data(), &b[pos], px.size());
+    } else {
+        std::vector<uint8_t> scan((size_t)w * 4);
+        for (long y = 0; y < h; ++y) {
+            need(4);
+            if (b[pos] != 2 || b[pos + 1] != 2 || (((long)b[pos + 2] << 8) | b[pos + 3]) != w) throw std::runtime_error("hdr: bad scan line: " + path.string());
+            pos += 4;
+            for (int ch = 0; ch < 4; ++ch) {
+                long i = 0;
+                while (i < w) {
+                    need(1);
+                    int count = b[pos++];
+                    if (count > 128) {
+                        count -= 128;
+                        need(1);
+                        const uint8_t v = b[pos++];
+                        if (count == 0 || i + count > w) throw std::runtime_error("hdr: bad run: " + path.string());
+                        for (int k = 0; k < count; ++k) scan[(size_t)(i++) * 4 + ch] = v;
+                    } else {
+                        if (count == 0 || i + count > w) throw std::runtime_error("hdr: bad run: " + path.string());
+                        need((size_t)count);
+                        for (int k = 0; k < count; ++k) scan[(size_t)(i++) * 4 + ch] = b[pos++];
+                    }
+                }
+            }
+            std::memcpy(&px[(size_t)y * w * 4], scan.data(), scan.size());
+        }
+    }
+    rgb->assign((size_t)w * h * 3, 0.0f);
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        const uint8_t *q = &px[4 * i];
+        if (q[3] != 0) {
+            const float f1 = std::ldexp(1.0f, (int)q[3] - (128 + 8));
+            (*rgb)[3 * i] = (float)q[0] * f1; (*rgb)[3 * i + 1] = (float)q[1] * f1; (*rgb)[3 * i + 2] = (float)q[2] * f1;
+        }
+    }
+    *width = (int)w;
+    *height = (int)h;
+}
+
 // A mask image of any format the build can read: a pixel is on when any of R, G, B is non-zero; rows bottom to top
 // (the reference loads it flipped vertically, core/problem.cu:216-242).
 void read_mask_image(const fs::path &path, int *width, int *height, std::vector<uint8_t> *mask)
@@ -565,7 +650,12 @@ void read_mask_image(const fs::path &path, int *width, int *height, std::vector<
         bool file_is_bottom_up = false;
         if (head[0] == 0x76 && head[1] == 0x2f && head[2] == 0x31 && head[3] == 0x01) read_exr(path, &w, &h, &rgb);
         else if (head[0] == 'P' && (head[1] == 'F' || head[1] == 'f')) { read_pfm(path, &w, &h, &rgb); file_is_bottom_up = true; }
-        else throw std::runtime_error("mask image: only PNG, OpenEXR and PFM files are read here (no JPEG / Radiance decoder in this build): " + path.string());
+        else if (head[0] == '#' && head[1] == '?') read_hdr(path, &w, &h, &rgb);
+        // OUT OF SCOPE, stated: the lossy formats stb_image also decodes (JPEG above all).  A mask is "any non-zero byte", which a
+        // lossy codec's ringing next to every edge decides by the last bit of ITS inverse transform: no second decoder reproduces
+        // stb_image's there, and stb_image is absent from the reference checkout (ext/ is empty) -- convert such masks to PNG
+        else throw std::runtime_error("mask image: PNG, OpenEXR, PFM and Radiance .hdr files are read here; JPEG and the other lossy or "
+                                      "palette formats of stb_image are out of scope (convert the mask to PNG): " + path.string());
         mask->assign((size_t)w * h, 0);
         for (int y = 0; y < h; ++y)
             for (int x = 0; x < w; ++x) {

@@ -28,6 +28,8 @@ void read_png(const fs::path &path, int *width, int *height, std::vector<uint8_t
 // ZIP, HALF or FLOAT channels R G B (or Y).  JPEG and Radiance .hdr have no decoder in this build.
 void read_pfm(const fs::path &path, int *width, int *height, std::vector<float> *rgb);
 void read_exr(const fs::path &path, int *width, int *height, std::vector<float> *rgb);
+// Radiance RGBE (.hdr), flat or run-length scan lines, rows top to bottom
+void read_hdr(const fs::path &path, int *width, int *height, std::vector<float> *rgb);
 float half_to_float(uint16_t h);
 
 // mask_path of the scene configuration (reference core/problem.cu:216-242): any format above, by content; a pixel is on when

@@ -415,7 +415,9 @@ def test_bench_guided_config_two_ranks():
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["n_gpus"] == 2 and r["config"]["config"] == 4 and r["field_finite"]
-    assert r["guided"]["guided_steps_per_pass"] > 0 and r["roofline_mfma"]["bound"] == "mfma" and r["roofline_mfma"]["achieved"] > 0
+    # (the fused solve launches no network kernel of its own: the matrix-core figure is a probe and its key says so)
+    mf = r.get("roofline_mfma") or r["mfma_probe_of_net_forward_kernel"]
+    assert r["guided"]["guided_steps_per_pass"] > 0 and mf["bound"] == "mfma" and mf["achieved"] > 0
     assert r["roofline"]["kernel"] == "guided_sample_kernel" and r["guided"]["training_step"]["achieved"] > 0
 
 

@@ -550,6 +550,50 @@ def test_gpu_full_frame_guided_properties(ladybug):
     ui.close()
 
 
+# the walk steps of BASELINE config 4 at its real size: deterministic arithmetic makes the count a known answer per precision
+CONFIG4_WALK_STEPS = {32: 1_892_816_878, 16: 1_892_874_274}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [32, 16])
+def test_gpu_config4_at_full_size(ladybug, precision):
+    """BASELINE config 4 as it is benchmarked -- ladybug, 1024^2, 256 samples, all of them trained, the reference's batch sizes --
+    under pytest, not only in bench.py: the walk-step count is a known answer (every walk, record, batch and Adam step is
+    deterministic: fp32 bit-exact against the oracle on smaller frames, the half-precision mode reproducible), two solves give the
+    same field and the same network, every walk is accounted for, 256 x 5 Adam steps were taken, and the field agrees with the
+    uniform integrator's (bit-exact against the oracle) up to the Monte-Carlo noise of 256 samples"""
+    from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    aabb = ((-100.0, -100.0), (600.0, 600.0))
+    n = 1024 * 1024
+
+    def run():
+        st = GuidedIntegratorSettings(frameSize=(1024, 1024), samplesPerPixel=256, trainSppCount=256, maxWalkingDepth=64, epsilonShell=1.0)
+        gi = GuidedIntegrator(ladybug, st, aabb)
+        if precision == 16:
+            gi.network.set_option("precision", 16)
+            gi.network.set_option("train_precision", 16)
+        gi.solve()
+        out = gi.solution.copy(), dict(gi.last_stats), gi.network.params()
+        gi.close()
+        return out
+
+    f1, s1, p1 = run()
+    f2, s2, p2 = run()
+    assert np.array_equal(f1, f2) and np.array_equal(p1, p2) and s1["walk_steps"] == s2["walk_steps"]
+    assert s1["walk_steps"] == CONFIG4_WALK_STEPS[precision]
+    assert s1["walks_started"] == 256 * n and s1["walks_absorbed"] + s1["walks_truncated"] == s1["walks_started"]
+    assert s1["optimizer_steps"] == 256 * 5 and s1["guided_steps"] > 0.5 * s1["walk_steps"]
+    assert np.isfinite(f1).all()
+    ui = UniformIntegrator(ladybug, UniformIntegratorSettings((1024, 1024), 256, 64, 1.0))
+    ui.solve()
+    u = ui.solution
+    assert abs(float(f1.mean()) - float(u.mean())) < 1e-3 * float(u.mean())
+    rel = float(np.linalg.norm(f1 - u) / np.linalg.norm(u))
+    assert rel < 0.05, rel          # two independent 256-sample estimates of one field (measured 0.035)
+    ui.close()
+
+
 # ---- BASELINE config 5: the 2048 x 2048 frame, one shard of 8 ---------------------------------------
 def _band_of_shard_mask(w, h, rows, shard, shards):
     """mask that keeps only the pixels of `rows` evaluation rows around the middle which shard
@@ -856,3 +900,131 @@ def test_gpu_random_scenes_match_the_oracle():
                          timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "fuzz guided 200..229: 0 mismatches" in out.stdout, out.stdout[-3000:]
+
+
+# ---- the opt-in training orders (wost_guided_set_option "train_group", "pipeline"): never the parity mode ----------------
+REORDERED = [(0, 4), (1, 1), (1, 4)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [32, 16])
+def test_gpu_reordered_training_keeps_the_guiding_gain(precision):
+    """The reordered training orders change WHEN the network learns (a sample sees weights that are a few training passes
+    older), not what is estimated: on the bright-disc scene every order must stay unbiased, keep the variance reduction the
+    exact order shows (RMSE <= 0.8 x the uniform integrator's at equal samples, not worse than 1.1 x the exact order's),
+    take the same number of Adam steps, account for every walk, and be reproducible bit for bit."""
+    from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    from elaina_amd.scenes import BRIGHT_DISC_AABB, bright_disc_scene
+    p = bright_disc_scene()
+    w, depth, eps = 128, 128, 0.05
+    it = UniformIntegrator(p, UniformIntegratorSettings((w, w), 8192, depth, eps))
+    it.solve()
+    ref = it.solution.copy()
+    it.close()
+    it = UniformIntegrator(p, UniformIntegratorSettings((w, w), 128, depth, eps))
+    it.solve()
+    rmse_u = float(np.sqrt(np.mean((it.solution - ref) ** 2)))
+    it.close()
+
+    def run(pipeline, group):
+        st = GuidedIntegratorSettings(frameSize=(w, w), samplesPerPixel=128, trainSppCount=64, maxWalkingDepth=depth, epsilonShell=eps,
+                                      batchSize=65536, minBatchSize=8192)
+        g = GuidedIntegrator(p, st, BRIGHT_DISC_AABB)
+        if precision == 16:
+            g.network.set_option("precision", 16)
+            g.network.set_option("train_precision", 16)
+        g.set_option("pipeline", pipeline)
+        g.set_option("train_group", group)
+        g.solve()
+        out = (g.solution.copy(), g.network.params(), dict(g.last_stats))
+        g.close()
+        return out
+
+    exact_f, exact_p, exact_s = run(0, 1)
+    rmse_exact = float(np.sqrt(np.mean((exact_f - ref) ** 2)))
+    assert rmse_exact <= 0.8 * rmse_u
+    for pipeline, group in REORDERED:
+        f, prm, s = run(pipeline, group)
+        f2, prm2, _ = run(pipeline, group)
+        assert np.array_equal(f, f2) and np.array_equal(prm, prm2), (pipeline, group)          # reproducible
+        assert not np.array_equal(f, exact_f)                                                   # another order of learning
+        assert s["optimizer_steps"] == exact_s["optimizer_steps"] > 0
+        assert s["walks_started"] == w * w * 128 and s["walks_absorbed"] + s["walks_truncated"] == s["walks_started"]
+        rmse = float(np.sqrt(np.mean((f - ref) ** 2)))
+        assert rmse <= 0.8 * rmse_u and rmse <= 1.1 * rmse_exact, (pipeline, group, rmse, rmse_exact, rmse_u)
+        assert abs(float(f.mean()) - float(ref.mean())) < 0.01 * float(ref.mean())
+
+
+@pytest.mark.gpu
+def test_gpu_reordered_training_is_unbiased_on_the_analytic_problem(oracle):
+    """u = y on the unit square (mixed boundary): every training order reproduces it; options are validated"""
+    from elaina_amd.capi import WostError
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    prob = laplace_box()
+    w = h = 64
+    exact = eval_ys(prob, w, h).reshape(-1)
+    errs = {}
+    for pipeline, group in [(0, 1)] + REORDERED + [(1, 16)]:
+        st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=48, trainSppCount=30, maxWalkingDepth=48, epsilonShell=EPS,
+                                      batchSize=4096, minBatchSize=1024)
+        gi = GuidedIntegrator(prob, st, AABB, seed=3)
+        gi.set_option("pipeline", pipeline)
+        gi.set_option("train_group", group)       # 30 trained samples: the last group of 4 / 16 is a short one
+        gi.solve()
+        e = gi.solution[:, 0] - exact
+        assert gi.last_stats["optimizer_steps"] > 0 and gi.last_stats["guided_steps"] > 0
+        assert gi.last_stats["walks_started"] == w * h * 48
+        assert abs(float(e.mean())) < 4e-3, (pipeline, group, float(e.mean()))
+        errs[(pipeline, group)] = float(np.sqrt((e ** 2).mean()))
+        gi.close()
+    # (with groups of 16 on a second stream none of the 30 trained samples sees a trained network: unbiased all the same, only noisier)
+    assert max(v for k, v in errs.items() if k != (1, 16)) < 1.25 * errs[(0, 1)] and errs[(1, 16)] < 2.0 * errs[(0, 1)], errs
+    gi = GuidedIntegrator(prob, GuidedIntegratorSettings(frameSize=(8, 8), samplesPerPixel=1, trainSppCount=1, maxWalkingDepth=8,
+                                                          epsilonShell=EPS), AABB)
+    for key, val in (("pipeline", 2), ("train_group", 0), ("train_group", 17), ("train_group", 1.5), ("no_such_option", 1)):
+        with pytest.raises(WostError):
+            gi.set_option(key, val)
+    gi.close()
+
+
+@pytest.mark.gpu
+def test_gpu_sync_callback_failures_end_the_solve():
+    """wost_sync_fn: 0 = done, WOST_SYNC_UNSUPPORTED (2) = op unknown (tolerated for the rank-count op only: a callback
+    written against library 0.1), anything else = failure -- of ANY op -- and the solve ends with an error instead of
+    training on with a gradient the other ranks do not share"""
+    import ctypes as C
+    from elaina_amd import capi
+    from elaina_amd.capi import WostError
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    prob = laplace_box()
+    st = GuidedIntegratorSettings(frameSize=(32, 32), samplesPerPixel=2, trainSppCount=2, maxWalkingDepth=16, epsilonShell=EPS,
+                                  batchSize=1024, minBatchSize=512)
+
+    def solve_with(answers):
+        calls = []
+
+        def sync(user, op, data, count):
+            calls.append(op)
+            rc = answers.get(op, 0)
+            if op == capi.SYNC_RANKS_I64_HOST and rc == 0:
+                C.cast(data, C.POINTER(C.c_int64))[0] = answers.get("ranks", 1)
+            return rc
+
+        gi = GuidedIntegrator(prob, st, AABB, seed=2)
+        fn = capi.SYNC_FN(sync)
+        capi._check(gi.lib.wost_guided_set_sync(gi._handle, fn, None), "wost_guided_set_sync")
+        try:
+            gi.solve()
+            return gi.last_stats, calls
+        finally:
+            gi.close()
+
+    s, calls = solve_with({})
+    assert s["optimizer_steps"] > 0 and calls[0] == capi.SYNC_RANKS_I64_HOST and capi.SYNC_SUM_I64_DEVICE in calls
+    s, _ = solve_with({capi.SYNC_RANKS_I64_HOST: capi.SYNC_UNSUPPORTED})          # a 0.1 callback: undivided gradients, with a warning
+    assert s["optimizer_steps"] > 0
+    for bad in ({capi.SYNC_RANKS_I64_HOST: 1}, {"ranks": 0}, {capi.SYNC_MIN_I64_HOST: 1}, {capi.SYNC_SUM_I64_DEVICE: 1},
+                {capi.SYNC_SUM_I64_DEVICE: capi.SYNC_UNSUPPORTED}):
+        with pytest.raises(WostError, match="sync callback failed"):
+            solve_with(bad)

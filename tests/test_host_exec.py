@@ -318,8 +318,9 @@ def _write_exr(path, img, compression, half):
 
 def test_mask_images_of_every_readable_format(tmp_path):
     """mask_path goes through Image::loadImage in the reference (core/problem.cu:216-242, core/texture.cu:26-80): PNG, OpenEXR
-    (uncompressed, ZIPS, ZIP; half and float) and PFM (colour and grey, both byte orders) give the same mask here; JPEG and
-    Radiance files are refused with a message"""
+    (uncompressed, ZIPS, ZIP; half and float), PFM (colour and grey, both byte orders) and Radiance .hdr (flat pixels and
+    run-length scan lines) give the same mask here; JPEG -- lossy: the mask would hang on the last bit of stb_image's own inverse
+    transform -- is out of scope and refused with a message that says so"""
     rng = np.random.default_rng(3)
     exe = _exe()
     w, h = 41, 35
@@ -355,9 +356,43 @@ def test_mask_images_of_every_readable_format(tmp_path):
     assert out.returncode == 0
     got = subprocess.run([exe, "--readmask", str(tmp_path / "img" / "grad.exr"), str(tmp_path / "m.raw")], capture_output=True, text=True)
     assert got.returncode == 0 and got.stdout.split() == ["5", "3"], got.stderr
+    # Radiance RGBE: mantissa bytes and a shared exponent; a pixel is black exactly when its exponent byte is zero
+    mant, ex = np.frexp(img.max(-1))
+    e8 = np.where(img.max(-1) > 1e-32, ex + 128, 0).astype(np.int32)
+    scale = np.where(e8 > 0, np.ldexp(1.0, 8 - ex.astype(np.int32)), 0.0)
+    rgbe = np.concatenate([np.minimum(np.floor(img * scale[..., None]), 255), e8[..., None]], -1).astype(np.uint8)
+    rgbe[on & (rgbe[..., :3].max(-1) == 0)] = (0, 0, 1, 100)     # (a mantissa that rounded to zero would switch the pixel off)
+    head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y %d +X %d\n" % (h, w)
+    open(tmp_path / "flat.hdr", "wb").write(head + rgbe.tobytes())
+    assert np.array_equal(mask_of("flat.hdr"), want)
+
+    def rle(row):      # one channel of a scan line: runs of >= 3 equal bytes as runs, the rest as literals
+        out, i = bytearray(), 0
+        while i < len(row):
+            j = i
+            while j < len(row) and j - i < 127 and row[j] == row[i]:
+                j += 1
+            if j - i >= 3:
+                out += bytes([128 + j - i, row[i]])
+                i = j
+            else:
+                k = i
+                while k < len(row) and k - i < 127 and not (k + 2 < len(row) and row[k] == row[k + 1] == row[k + 2]):
+                    k += 1
+                k = max(k, i + 1)
+                out += bytes([k - i]) + bytes(row[i:k])
+                i = k
+        return bytes(out)
+
+    body = b"".join(bytes([2, 2, w >> 8, w & 255]) + b"".join(rle(rgbe[y, :, c].tolist()) for c in range(4)) for y in range(h))
+    open(tmp_path / "rle.hdr", "wb").write(head.replace(b"#?RADIANCE", b"#?RGBE") + body)
+    assert np.array_equal(mask_of("rle.hdr"), want)
+    open(tmp_path / "cut.hdr", "wb").write((head + body)[:200])
+    bad = subprocess.run([exe, "--readmask", str(tmp_path / "cut.hdr"), str(tmp_path / "m.raw")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "hdr" in bad.stderr
     open(tmp_path / "x.jpg", "wb").write(b"\xff\xd8\xff\xe0" + b"\0" * 64)
     bad = subprocess.run([exe, "--readmask", str(tmp_path / "x.jpg"), str(tmp_path / "m.raw")], capture_output=True, text=True)
-    assert bad.returncode == 1 and "only PNG, OpenEXR and PFM" in bad.stderr
+    assert bad.returncode == 1 and "out of scope" in bad.stderr and "PNG" in bad.stderr
     open(tmp_path / "cut.exr", "wb").write(open(tmp_path / "m_3_1.exr", "rb").read()[:300])
     bad = subprocess.run([exe, "--readmask", str(tmp_path / "cut.exr"), str(tmp_path / "m.raw")], capture_output=True, text=True)
     assert bad.returncode == 1 and "exr" in bad.stderr

@@ -1,0 +1,12 @@
+#!/bin/bash
+# guiding-phase walk of config 4 (64 guiding samples, untrained network) with the current build; LIBS = variant names
+export TMPDIR=/tmp
+mkdir -p gpurun_out/split
+for v in ${LIBS:-default}; do
+  lib=elaina_amd/lib/variants/$v/libwost_hip.so
+  [ $v = default ] && lib=elaina_amd/lib/libwost_hip.so
+  for prec in ${PRECS:-16 32}; do
+    echo "== $v f$prec" | tee -a gpurun_out/split/split.txt
+    WOST_LIB=$lib python tools/gpu_guided_bench.py --net-precision $prec --spp 64 --train-spp 0 --repeat 3 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a gpurun_out/split/split.txt
+  done
+done
