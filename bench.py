@@ -478,7 +478,7 @@ def icosphere(subdiv, radius):
     return (np.asarray(verts) * radius).astype(np.float32), np.asarray(f, np.int32)
 
 
-def run_uniform3d(env, args):
+def run_uniform3d(env, args, only=None):
     """SURVEY 8 f.3, the 3-D uniform integrator, synthetic scenes (the reference ships no 3-D data): (a) a Dirichlet
     icosphere of 1280 triangles with the harmonic boundary values x y + z, the slice z = 0.1 (tools/probes/bench3d.py's scene); (b) a Dirichlet ball
     inside a zero-flux Neumann shell of 1280 triangles (silhouette and ray queries on the tree).  One timed solve each
@@ -495,14 +495,19 @@ def run_uniform3d(env, args):
     shell = {"d_verts": Vi, "d_tris": Ti, "d_colors": np.repeat(Vi[:, :1], 6, axis=1).astype(np.float32), "n_verts": V, "n_tris": T,
              "n_colors": np.zeros((len(V), 6), np.float32), "probe": (0.7, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0)),
              "dirichlet_intensity": 1.0, "neumann_intensity": 1.0}
-    for name, sd, frame, spp in (("dirichlet_icosphere_1280", ball, 512, 64), ("neumann_shell_1280", shell, 512, 16)):
+    # (the 512^2 frames of the earlier rounds hold fewer walkers than the chip has lanes at six waves per SIMD -- latency-bound;
+    # the 1024^2 frames, a million walkers, are the full-chip figure)
+    for name, sd, frame, spp in (("dirichlet_icosphere_1280", ball, 512, 64), ("neumann_shell_1280", shell, 512, 16),
+                                 ("dirichlet_icosphere_1280_1024", ball, 1024, 16), ("neumann_shell_1280_1024", shell, 1024, 4)):
+        if only is not None and name not in only:
+            continue
         it = UniformIntegrator3(Problem3.from_dict(sd), UniformIntegratorSettings((frame, frame), spp, 64, 2e-3), device=env.local)
         it.solve()
         it.solve()
         st = it.last_stats
         e = {"workload": "%s %dx%d %d spp depth 64 eps 2e-3" % (name, frame, frame, spp), "walk_steps": float(st["walk_steps"]),
              "kernel_ms": float(st["kernel_ms"]), "value": st["walk_steps"] / (st["kernel_ms"] * 1e-3), "unit": "walk-steps/s"}
-        if name.startswith("dirichlet") and not args.no_cpu_baseline:
+        if name == "dirichlet_icosphere_1280" and not args.no_cpu_baseline:
             from oracle.oracle import Oracle
             b, e_ = band_of(frame, 4)
             ref = Oracle().solve3(sd, frame, frame, spp, 64, 2e-3, pixel_begin=b, pixel_end=e_, threads=os.cpu_count() or 1)
@@ -510,9 +515,11 @@ def run_uniform3d(env, args):
             e["rel_l2_band"] = "rows %d..%d" % (b // frame, e_ // frame)
         it.close()
         # what binds walk3_kernel on this scene: VALU figures of the committed PMC pass (tools/gpu_round.sh, stage pmc3d)
-        cc = committed_counters("walk3_valu", ("scenes", "source"))
-        if cc and cc.get("scenes") and name in cc["scenes"]:
-            e["roofline"] = dict(cc["scenes"][name], bound="valu", kernel="walk3_kernel", stale=cc["stale"], measured_on_sources=cc["measured_on_sources"],
+        big = name.endswith("_1024")
+        cc = committed_counters("walk3_valu_1024" if big else "walk3_valu", ("scenes", "source"))
+        name_cc = name[:-5] if big else name
+        if cc and cc.get("scenes") and name_cc in cc["scenes"]:
+            e["roofline"] = dict(cc["scenes"][name_cc], bound="valu", kernel="walk3_kernel", stale=cc["stale"], measured_on_sources=cc["measured_on_sources"],
                                  source=cc["source"])
         out[name] = e
     return out
@@ -586,6 +593,28 @@ def run_guided3d(env, args):
                      "ms_per_step": dt * 1e3, "value": g["walk_steps"] / dt, "unit": "walk-steps/s",
                      "field_finite": bool(np.isfinite(gi.solution).all())}
         gi.close()
+        if not args.no_cpu_baseline:
+            # a band of the frame against the oracle: four rows (a mask switches the other pixels off on both sides), the network
+            # frozen at its initial weights -- the trained solve above has no pixel-local restatement, every pixel trains the one network
+            from oracle.oracle import Oracle, default_net_config3 as oracle_cfg3, guided_settings3
+            b, e_ = band_of(frame, 4)
+            band = dict(sd, mask=np.zeros(frame * frame, np.uint8))
+            band["mask"][b:e_] = 1
+            stb = GuidedIntegratorSettings(frameSize=(frame, frame), samplesPerPixel=spp, trainSppCount=0, maxWalkingDepth=64, epsilonShell=2e-3)
+            gb = GuidedIntegrator3(Problem3.from_dict(band), stb, ((-1.1, -1.1, -1.1), (1.1, 1.1, 1.1)), network_config=default_net_config3(), seed=7,
+                                   device=env.local)
+            p0 = gb.network.params()
+            gb.solve()
+            gs = guided_settings3(frame, frame, spp, 64, 2e-3, (-1.1, -1.1, -1.1), (1.1, 1.1, 1.1), train_spp_count=0)
+            ref = Oracle().solve_guided3(band, gs, oracle_cfg3(), p0.copy(), threads=os.cpu_count() or 1, dump_spp=-1)
+            out[name]["rel_l2_vs_oracle"] = rel_l2(gb.solution[b:e_], ref["field"][b:e_])
+            out[name]["rel_l2_band"] = "rows %d..%d, frozen network, %d walk steps (oracle: %d)" % (b // frame, e_ // frame, gb.last_stats["walk_steps"],
+                                                                                                     ref["walk_steps"])
+            gb.close()
+        cc = committed_counters("guided3d_valu", ("scenes", "source"))
+        if cc and cc.get("scenes") and name in cc["scenes"]:
+            out[name]["roofline"] = dict(cc["scenes"][name], bound="valu", stale=cc["stale"], measured_on_sources=cc["measured_on_sources"],
+                                         source=cc["source"])
     return out
 
 

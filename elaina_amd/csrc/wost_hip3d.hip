@@ -2601,7 +2601,8 @@ int wost3_vmm_loss_gradients(int device, const float *raw, const float *dir, con
 //                       MIS (reflection about the Neumann normal), the walker's ray, throughput, training record
 // and after every trained sample the ordered training set, the loss gradients (vmm3_loss_gradients_kernel) and the Adam
 // steps.  One thread per pixel / queue entry; per-pixel arithmetic and draw order are those of the CPU restatement the tests
-// compare with (tests/test_guided_3d.py): bit-exact.  Scenes with a source term are refused (not built for this integrator).
+// compare with (tests/test_guided_3d.py): bit-exact, the source term (sampleSource, :277-364 with DIM == 3) included.  From the first
+// depth that needs no network on, g3_tail_kernel takes every walker that is left to its end in one launch.
 namespace wost {
 
 constexpr int kRec3Fields = 15;      // sol rgb, pos xyz, dir xyz, pdf, thp, normal xyz, onNeumann
@@ -2620,6 +2621,7 @@ struct G3Params {
     DevMesh3 dm, nm;
     DevSettings st;
     DevProbe3 probe;
+    DevSource3 src;
     const uint8_t *mask;
     G3Box box;
     int32_t n_pixels, shard_index, shard_count;
@@ -2722,15 +2724,12 @@ __global__ __launch_bounds__(256) void g3_begin_kernel(G3Params P)
 }
 
 // separateEvaluationPoint + handleBoundary + sampleNeumann (guided/integrator.cu:153-249, 252-274, 367-494 with DIM == 3)
-template <bool EMISSIVE, bool NTREE>
-__global__ __launch_bounds__(256) void g3_separate_kernel(G3Params P)
+// for the walker of pixel p at `depth` (live: it has an evaluation point queued); every lane of the wave takes part (the tree
+// queries are answered by the wave).  Returns whether the walker stays (out of the shell, R_B stored) and its position.
+template <bool EMISSIVE, bool NTREE, bool SOURCE>
+__device__ __forceinline__ bool g3_separate_body(const G3Params &P, int depth, int p, bool live, const WavePool3 &W, const LdsColumn &stk, V3 &x_out)
 {
-    extern __shared__ uint32_t lds_stack[];
-    const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
     const bool pooled = P.pool_cap > 0;
-    const WavePool3 W = g3_pools(P, lds_stack);
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = p < P.n_pixels && P.state[p] == 1;
     g3_count(live, &g3_stats(P.stats)->steps);
     bool keep = false, absorbed = false;
     V3 x = v3(0.0f, 0.0f, 0.0f);
@@ -2765,7 +2764,7 @@ __global__ __launch_bounds__(256) void g3_separate_kernel(G3Params P)
         rng = Pcg{P.rng[p], 1};
         if (has_d) {
             P.whint[p] = cp.slot;
-            if (P.depth == 0) P.hint0[p] = cp.slot;
+            if (depth == 0) P.hint0[p] = cp.slot;
             const float4 a = P.dm.tri[3 * (size_t)cp.slot], b = P.dm.tri[3 * (size_t)cp.slot + 1], c = P.dm.tri[3 * (size_t)cp.slot + 2];
             const V3 p0 = v3(a.x, a.y, a.z), e0 = v3(b.x, b.y, b.z) - p0, e1 = v3(c.x, c.y, c.z) - p0;
             const int side = tri_side(p0, cross3(e0, e1), x);
@@ -2801,6 +2800,51 @@ __global__ __launch_bounds__(256) void g3_separate_kernel(G3Params P)
             if (!isinf(R_B)) {
                 keep = true;
                 P.wrb[p] = R_B;
+                if (SOURCE) {
+                    // sampleSource (guided/integrator.cu:277-364, templated on DIM): the uniform 3-D step's restatement (step3_b),
+                    // the contribution recorded like a Neumann one (recordSourceContribution)
+                    V3 sdir;
+                    float dir_pdf, salpha = 1.0f;
+                    {
+                        const float u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
+                        float c, s;
+                        sincos_2pi(u2, c, s);
+                        if (on_n) {
+                            const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+                            sdir = frame_to_world(nn, r * c, r * s, z);
+                            dir_pdf = 1.0f / WOST_2PI;
+                            salpha = 0.5f;
+                        } else {
+                            const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
+                            sdir = v3(r * c, r * s, z);
+                            dir_pdf = 1.0f / WOST_4PI;
+                        }
+                    }
+                    float dist = R_B;
+                    if (P.nm.n_tris > 0) {
+                        float t;
+                        int hi;
+                        if (ray_closest3<NTREE>(P.nm, v3(x.x + eps * sdir.x, x.y + eps * sdir.y, x.z + eps * sdir.z), sdir, dist, t, hi, stk)) dist = fminf(t, dist);
+                    }
+                    const float g1 = pcg_next_float(rng), g2 = pcg_next_float(rng);
+                    float gc, gs;
+                    sincos_2pi(g2, gc, gs);
+                    float r = (1.0f + sqrtf(1.0f - cbrt01(g1 * g1)) * gc) * R_B / 2.0f;
+                    r = fmaxf(1e-4f, r);
+                    if (r > R_B) r = R_B / 2.0f;
+                    if (r <= dist) {
+                        float f[3], col[3];
+                        source3_eval(P.src, v3(x.x + r * sdir.x, x.y + r * sdir.y, x.z + r * sdir.z), f);
+                        const float norm = R_B * R_B / 6.0f;
+                        const float c1 = (1.0f / WOST_4PI) / (r * r), c2 = dir_pdf / (r * r);
+                        float *sl = P.sol + 3 * (size_t)p;
+                        for (int k = 0; k < 3; ++k) {
+                            col[k] = thp * f[k] * norm * c1 / c2 / salpha;
+                            sl[k] = col[k] + sl[k];
+                        }
+                        if (train_px) g3_record_solution(P, pid, col);
+                    }
+                }
                 if (P.nm.n_tris > 0) {      // sampleNeumann: three draws whether or not the boundary emits
                     const float u0 = pcg_next_float(rng), u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
                     if (EMISSIVE) {
@@ -2853,6 +2897,20 @@ __global__ __launch_bounds__(256) void g3_separate_kernel(G3Params P)
         P.state[p] = keep ? 2 : 0;
     }
     g3_count(absorbed, &g3_stats(P.stats)->absorbed);
+    x_out = x;
+    return keep;
+}
+
+template <bool EMISSIVE, bool NTREE, bool SOURCE>
+__global__ __launch_bounds__(256) void g3_separate_kernel(G3Params P)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
+    const WavePool3 W = g3_pools(P, lds_stack);
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < P.n_pixels && P.state[p] == 1;
+    V3 x;
+    const bool keep = g3_separate_body<EMISSIVE, NTREE, SOURCE>(P, P.depth, p, live, W, stk, x);
     const uint32_t s = block_push(keep, P.q_count);
     if (keep) {
         P.q_pid[s] = (uint32_t)p;
@@ -2862,21 +2920,17 @@ __global__ __launch_bounds__(256) void g3_separate_kernel(G3Params P)
     }
 }
 
+
 // handleOutShellPoint + handleGuidedSampling / handleUniformSampling, or oneStepWalk beyond the guided depths
 // (guided/integrator.cu:497-526, 671-880, 883-965 with DIM == 3)
+// for the walker of pixel `pid` (live: out of the shell, R_B stored) at `depth`; raw = its 41 network outputs when `guiding`
 template <bool NTREE>
-__global__ __launch_bounds__(256) void g3_sample_kernel(G3Params P)
+__device__ __forceinline__ void g3_sample_body(const G3Params &P, int depth, bool guiding, uint32_t pid, bool live, const float *raw, const WavePool3 &W,
+                                               const LdsColumn &stk)
 {
-    extern __shared__ uint32_t lds_stack[];
-    const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
     const bool pooled = NTREE && P.pool_cap > 0;
-    const WavePool3 W = g3_pools(P, lds_stack);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_in = *P.q_count;
-    const bool live = i < n_in;
     bool guided = false, hit = false, moved = false;
     // (the walker's ray is answered by the wave for all its walkers, ray_closest3_wave: the step is cut in two around it)
-    uint32_t pid = 0;
     size_t p = 0;
     V3 x = v3(0.0f, 0.0f, 0.0f), nn = x, dir = x, cur = x;
     float thp = 0.0f, R_B = 0.0f, pdf = 0.0f, alpha = 1.0f;
@@ -2884,13 +2938,12 @@ __global__ __launch_bounds__(256) void g3_sample_kernel(G3Params P)
     const float eps = P.st.eps;
     Pcg rng{0, 1};
     if (live) {
-        pid = P.q_pid[i];
         p = pid;
         x = v3(P.wx[3 * p], P.wx[3 * p + 1], P.wx[3 * p + 2]);
         nn = v3(P.wn[3 * p], P.wn[3 * p + 1], P.wn[3 * p + 2]);
         thp = P.wthp[p]; R_B = P.wrb[p];
         on_n = P.won[p] != 0;
-        record = g3_training_pixel(P, pid) && P.depth < P.max_train_depth;
+        record = g3_training_pixel(P, pid) && depth < P.max_train_depth;
         rng = Pcg{P.rng[p], 1};
         auto uniform_dir = [&]() {
             const float u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
@@ -2908,10 +2961,9 @@ __global__ __launch_bounds__(256) void g3_sample_kernel(G3Params P)
                 alpha = 1.0f;
             }
         };
-        if (!P.guiding) {
+        if (!guiding) {
             uniform_dir();
         } else {
-            const float *raw = P.net_out + 41 * (size_t)i;
             const float sel = 1 / (1.f + det_expf(-raw[40]));
             const bool inside = g3_box_contains(P.box, x);
             bool to_guided = (P.uniform_fraction == 0) || (pcg_next_float(rng) < sel);
@@ -3000,9 +3052,42 @@ __global__ __launch_bounds__(256) void g3_sample_kernel(G3Params P)
     GStats3Dev *st = g3_stats(P.stats);
     g3_count(guided, &st->guided);
     g3_count(hit, &st->nhits);
-    g3_count(moved && P.depth == P.st.max_depth - 1, &st->truncated);
-    g3_count(live && P.guiding, &st->net_points);
+    g3_count(moved && depth == P.st.max_depth - 1, &st->truncated);
+    g3_count(live && guiding, &st->net_points);
 }
+
+template <bool NTREE>
+__global__ __launch_bounds__(256) void g3_sample_kernel(G3Params P)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
+    const WavePool3 W = g3_pools(P, lds_stack);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < *P.q_count;
+    g3_sample_body<NTREE>(P, P.depth, P.guiding != 0, live ? P.q_pid[i] : 0u, live, P.net_out + 41 * (size_t)i, W, stk);
+}
+
+// The unguided tail of a sample: from depth >= maxGuidedDepth on nothing needs the network, yet a launch pair per depth over a
+// frame that holds a handful of walkers cost what its slowest tree query costs (most of the ~2000 launches of a 16-sample
+// solve).  Here every walker that is left runs to its end in ONE launch -- the same bodies, depth after depth, the tree queries
+// still answered by the wave -- with its state where the bodies keep it (a thread reads back its own stores).
+template <bool EMISSIVE, bool NTREE, bool SOURCE>
+__global__ __launch_bounds__(256) void g3_tail_kernel(G3Params P)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
+    const WavePool3 W = g3_pools(P, lds_stack);
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool mine = p < P.n_pixels;
+    for (int depth = P.depth; depth < P.st.max_depth; ++depth) {
+        const bool live = mine && P.state[p] == 1;
+        if (!__ballot(live)) break;       // (wave-uniform: the queries are the wave's)
+        V3 x;
+        const bool keep = g3_separate_body<EMISSIVE, NTREE, SOURCE>(P, depth, p, live, W, stk, x);
+        g3_sample_body<NTREE>(P, depth, false, (uint32_t)(mine ? p : 0), keep, nullptr, W, stk);
+    }
+}
+
 
 // ---- the training set of a pass, in (pixel, record) order (train.h:423-471) ------------------------------------------------
 struct T3Params {
@@ -3178,7 +3263,8 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
     P.pool_offset = stack_words * 256;
     if (P.pool_cap && lds + (size_t)4 * (2 * (size_t)P.pool_cap + kPool3OwnerWords) * sizeof(uint32_t) + 8 > 64 * 1024) P.pool_cap = 0;
     if (P.pool_cap) lds += (size_t)4 * (2 * (size_t)P.pool_cap + kPool3OwnerWords) * sizeof(uint32_t) + 8;
-    P.dm = c->dm.view; P.nm = c->nm.view; P.st = c->dst; P.probe = c->probe; P.mask = c->mask; P.box = g->box;
+    P.dm = c->dm.view; P.nm = c->nm.view; P.st = c->dst; P.probe = c->probe; P.mask = c->mask; P.box = g->box; P.src = c->src;
+    const bool has_src = c->src.rgb != nullptr;
     P.n_pixels = N; P.shard_index = shard_index; P.shard_count = shard_count;
     P.rng = g->rng; P.sol = g->sol; P.cur_depth = g->cur_depth; P.rec = g->rec; P.state = g->state; P.wx = g->wx; P.wn = g->wn;
     P.wthp = g->wthp; P.wrb = g->wrb; P.won = g->won; P.whint = g->whint; P.hint0 = g->hint0;
@@ -3219,28 +3305,30 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
         P.training = training ? 1 : 0; P.uniform_fraction = uniform_fraction; P.first_sample = sample == 0 ? 1 : 0;
         hipLaunchKernelGGL(g3_begin_kernel, dim3(grid_px), dim3(256), 0, stream, P);
         ++launches;
-        // The host looks at the length of a depth's queue only every fourth depth: walkers only ever leave within a sample, so the
-        // last length it has seen bounds the grids of the depths in between (their kernels read the true length on the device),
-        // and a round trip per depth was a fifth of the solve's wall time.
-        uint32_t n_upper = (uint32_t)N;
+        // No host round trip inside a sample: the launches of a depth are sized for the frame (their kernels read the true length of
+        // the queue on the device; a block beyond it ends at once), and from the first depth that needs no network on, ONE launch
+        // takes every walker that is left to its end (g3_tail_kernel).  A round trip per depth -- later one every fourth depth --
+        // and the launch pairs of the late depths, whose few walkers cost a launch what its slowest tree query costs, were most
+        // of the solve's wall time (about 2000 launches per 16-sample solve).
+        const uint32_t n_upper = (uint32_t)N;
         for (int depth = 0; depth < s.max_depth; ++depth) {
             P.depth = depth; P.guiding = depth < max_guided_depth ? 1 : 0;
+            if (!P.guiding) {
+#define G3_LAUNCH(K, E, T)                                                                                              \
+    do {                                                                                                                \
+        if (has_src) hipLaunchKernelGGL((K<E, T, true>), dim3(grid_px), dim3(256), lds, stream, P);                       \
+        else hipLaunchKernelGGL((K<E, T, false>), dim3(grid_px), dim3(256), lds, stream, P);                              \
+    } while (0)
+                if (ntree) { if (emissive) G3_LAUNCH(g3_tail_kernel, true, true); else G3_LAUNCH(g3_tail_kernel, false, true); }
+                else       { if (emissive) G3_LAUNCH(g3_tail_kernel, true, false); else G3_LAUNCH(g3_tail_kernel, false, false); }
+                ++launches;
+                break;
+            }
             W3_TRY(hipMemsetAsync(g->q_count, 0, sizeof(uint32_t), stream));
-            if (ntree) {
-                if (emissive) hipLaunchKernelGGL((g3_separate_kernel<true, true>), dim3(grid_px), dim3(256), lds, stream, P);
-                else hipLaunchKernelGGL((g3_separate_kernel<false, true>), dim3(grid_px), dim3(256), lds, stream, P);
-            } else {
-                if (emissive) hipLaunchKernelGGL((g3_separate_kernel<true, false>), dim3(grid_px), dim3(256), lds, stream, P);
-                else hipLaunchKernelGGL((g3_separate_kernel<false, false>), dim3(grid_px), dim3(256), lds, stream, P);
-            }
+            if (ntree) { if (emissive) G3_LAUNCH(g3_separate_kernel, true, true); else G3_LAUNCH(g3_separate_kernel, false, true); }
+            else       { if (emissive) G3_LAUNCH(g3_separate_kernel, true, false); else G3_LAUNCH(g3_separate_kernel, false, false); }
             ++launches;
-            if ((depth & 3) == 0) {
-                W3_TRY(hipMemcpyAsync(g->host_word, g->q_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                W3_TRY(hipStreamSynchronize(stream));
-                n_upper = g->host_word[0];
-                if (n_upper == 0) break;
-            }
-            if (P.guiding) {
+            {
                 const int rc = net_inference_dev(g->net, g->net_in, g->q_count, (int)n_upper, g->net_out, true, stream, 0);
                 if (rc != WOST_OK) return rc;
             }
@@ -3319,8 +3407,6 @@ int wost3_guided_create(const wost3_scene_desc *scene, const wost3_guided_settin
         s->batches_per_spp < 0 || s->train_spp_count < 0)
         return set_error(WOST_ERR_INVALID, "bad guided settings");
     if (net->n_output != 41) return set_error(WOST_ERR_INVALID, "the 3-D guiding network has 41 outputs (8 x (lambda, kappa, mean vector) + selection logit)");
-    if (scene->source.nx > 0 || scene->source.ny > 0 || scene->source.nz > 0)
-        return set_error(WOST_ERR_UNSUPPORTED, "the 3-D guided integrator has no source term in this build");
     wost_settings us{s->width, s->height, s->spp, s->max_depth, s->eps_shell};
     wost3_handle sc = nullptr;
     int rc = wost3_create(scene, &us, device, &sc);

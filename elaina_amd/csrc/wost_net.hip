@@ -442,7 +442,10 @@ __device__ __forceinline__ void mfma_layer_h(const uint2 *wf, int lane, const h4
         }
 }
 
-// the reference's network shape only: 8 levels x 4 features -> 64 -> 64 -> 64 -> 48 (33 used)
+// the reference's network shape only: 8 levels x 4 features -> 64 -> 64 -> 64 -> 48 (33 used with two inputs, 41 with three).
+// DIMS = 2: weights AND grid in LDS; DIMS = 3: the dense 3-D grid is far larger than LDS (a million entries) -- only the weight
+// fragments are staged, the eight corner gathers of a level go to L2.
+template <int DIMS>
 __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayout L, const float *params, const uint2 *fragh, const float *xy, int n,
                                                                        const uint32_t *n_dev, float *out, size_t out_ldp, size_t out_ldf, uint2 *enc_out)
 {
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
     __shared__ uint32_t s_res[kNetMaxLevels], s_off[kNetMaxLevels + 1];
     // weights and the whole grid (15 384 entries x 8 bytes in half precision): 150 KB of the CU's 160 KB, one block per CU;
     // every gather of the encoding is an LDS read
-    const uint32_t n_image = L.n_mlp / 4 + L.level_off[L.n_levels];
+    const uint32_t n_image = L.n_mlp / 4 + (DIMS == 2 ? L.level_off[L.n_levels] : 0u);
     for (uint32_t e = threadIdx.x; e < n_image; e += kHalfFwdThreads) lds_h[e] = fragh[e];
     if (threadIdx.x <= (unsigned)L.n_levels) {
         s_off[threadIdx.x] = L.level_off[threadIdx.x];
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
     if (n_dev) n = (int)*n_dev;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int n_tiles = (n + 16 * kHalfSub - 1) / (16 * kHalfSub);
-    const uint2 *grid = lds_h + L.n_mlp / 4;
+    const uint2 *grid = (DIMS == 2 ? lds_h : fragh) + L.n_mlp / 4;
     const uint2 *w0 = lds_h + L.w_off[0] / 4, *w1 = lds_h + L.w_off[1] / 4, *w2 = lds_h + L.w_off[2] / 4, *w3 = lds_h + L.w_off[3] / 4;
     for (int tile = blockIdx.x * (kHalfFwdThreads / 64) + wave; tile < n_tiles; tile += gridDim.x * (kHalfFwdThreads / 64)) {
         asm volatile("" ::: "memory");      // the weight fragments are re-read from LDS per tile, not parked in registers
@@ -475,11 +478,13 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
         for (int u = 0; u < kHalfSub; ++u) {
             pt[u] = (tile * kHalfSub + u) * 16 + i;
             valid[u] = pt[u] < n;
-            const float x = valid[u] ? xy[2 * (size_t)pt[u]] : 0.5f, y = valid[u] ? xy[2 * (size_t)pt[u] + 1] : 0.5f;
+            const float x = valid[u] ? xy[DIMS * (size_t)pt[u]] : 0.5f, y = valid[u] ? xy[DIMS * (size_t)pt[u] + 1] : 0.5f;
+            const float z = (DIMS == 3 && valid[u]) ? xy[DIMS * (size_t)pt[u] + 2] : 0.5f;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int lv = g + 4 * h;
-                b[u][h] = half_encode_level(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], x, y);
+                b[u][h] = DIMS == 3 ? half_encode_level3(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], x, y, z)
+                                    : half_encode_level(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], x, y);
                 if (enc_out) {
                     // training: the encoding goes to the fused backward kernel as it stands (wost_net_half.h)
                     union { h4_t h; uint2 u; } e;
@@ -1348,12 +1353,13 @@ static int launch_forward_h(wost_net *h, const float *p, const uint2 *image, con
                             size_t ldp, size_t ldf, uint2 *enc_out, hipStream_t stream)
 {
     const NetLayout &L = h->L;
-    const size_t lds = half_image_entries(L) * sizeof(uint2);
+    const size_t lds = (L.dims == 2 ? half_image_entries(L) : (size_t)L.n_mlp / 4) * sizeof(uint2);
     const int n_tiles = (n + 16 * kHalfSub - 1) / (16 * kHalfSub);
-    // one block per CU (the image takes 150 KB of LDS), walking over the tiles
+    // one block per CU (two inputs: the image takes 150 KB of LDS), walking over the tiles
     const unsigned grid = (unsigned)std::max(1, std::min((n_tiles + kHalfFwdThreads / 64 - 1) / (kHalfFwdThreads / 64), 256));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(net_forward_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(net_forward_h_kernel, dim3(grid), dim3(kHalfFwdThreads), lds, stream, L, p, image, xy_dev, n, n_dev, out_dev, ldp, ldf, enc_out);
+    auto kfn = L.dims == 2 ? net_forward_h_kernel<2> : net_forward_h_kernel<3>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(kHalfFwdThreads), lds, stream, L, p, image, xy_dev, n, n_dev, out_dev, ldp, ldf, enc_out);
     ++h->n_launches;
     NET_TRY(hipGetLastError());
     return WOST_OK;
@@ -1723,7 +1729,7 @@ int net_f32_view(wost_net *h, F32NetView *out)
 int net_half_view(wost_net *h, HalfNetView *out)
 {
     if (!h || !out) return set_error(WOST_ERR_INVALID, "null argument");
-    if (h->precision != 16 || !h->inference_h) return WOST_ERR_UNSUPPORTED;      // a probe, as above
+    if (h->precision != 16 || !h->inference_h || h->L.dims != 2) return WOST_ERR_UNSUPPORTED;      // a probe, as above
     out->L = h->L;
     out->image = h->inference_h;
     return WOST_OK;
@@ -1946,10 +1952,10 @@ int wost_net_set_option(wost_net_handle h, const char *key, double value)
         if (value != 16 && value != 32) return set_error(WOST_ERR_INVALID, "precision must be 32 (fp32, default) or 16 (half-precision inference)");
         if (value == 16) {
             const NetLayout &L = h->L;
-            if (!(L.dims == 2 && L.enc == 32 && L.n_neurons == 64 && L.n_hidden == 3 && L.n_out_padded == 48 && L.n_features == 4 && L.n_levels == 8))
-                return set_error(WOST_ERR_UNSUPPORTED, "half-precision inference is built for the reference's 2-D network shape only");
+            if (!(L.enc == 32 && L.n_neurons == 64 && L.n_hidden == 3 && L.n_out_padded == 48 && L.n_features == 4 && L.n_levels == 8))
+                return set_error(WOST_ERR_UNSUPPORTED, "half-precision inference is built for the reference's network shape only (8 levels x 4 features, 3 x 64, two or three inputs)");
             NET_TRY(hipSetDevice(h->device));
-            if (half_image_entries(L) * sizeof(uint2) > 158 * 1024)
+            if (L.dims == 2 && half_image_entries(L) * sizeof(uint2) > 158 * 1024)
                 return set_error(WOST_ERR_UNSUPPORTED, "half-precision network: weights and grid must fit into 158 KB of LDS");
             if (!h->inference_h) NET_TRY(hipMalloc((void **)&h->inference_h, half_image_entries(L) * sizeof(uint2)));
             h->precision = 16;
@@ -1965,10 +1971,10 @@ int wost_net_set_option(wost_net_handle h, const char *key, double value)
         if (value != 16 && value != 32) return set_error(WOST_ERR_INVALID, "train_precision must be 32 (fp32, default) or 16 (half-precision training passes)");
         if (value == 16) {
             const NetLayout &L = h->L;
-            if (!(L.dims == 2 && L.enc == 32 && L.n_neurons == 64 && L.n_hidden == 3 && L.n_out_padded == 48 && L.n_features == 4 && L.n_levels == 8))
-                return set_error(WOST_ERR_UNSUPPORTED, "half-precision training is built for the reference's 2-D network shape only");
+            if (!(L.enc == 32 && L.n_neurons == 64 && L.n_hidden == 3 && L.n_out_padded == 48 && L.n_features == 4 && L.n_levels == 8))
+                return set_error(WOST_ERR_UNSUPPORTED, "half-precision training is built for the reference's network shape only (8 levels x 4 features, 3 x 64, two or three inputs)");
             NET_TRY(hipSetDevice(h->device));
-            if (half_image_entries(L) * sizeof(uint2) > 158 * 1024)
+            if (L.dims == 2 && half_image_entries(L) * sizeof(uint2) > 158 * 1024)
                 return set_error(WOST_ERR_UNSUPPORTED, "half-precision network: weights and grid must fit into 158 KB of LDS");
             if (!h->params_h) NET_TRY(hipMalloc((void **)&h->params_h, half_image_entries(L) * sizeof(uint2)));
             if (!h->params_hb) NET_TRY(hipMalloc((void **)&h->params_hb, (size_t)L.n_mlp / 4 * sizeof(uint2)));

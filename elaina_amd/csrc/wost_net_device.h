@@ -193,6 +193,34 @@ __device__ __forceinline__ h4_t half_encode_level(const uint2 *grid, float sc, u
     return h4_t{(_Float16)f.x, (_Float16)f.y, (_Float16)f.z, (_Float16)f.w};
 }
 
+// the same for three inputs (GuidedIntegrator<3> in the reference's network precision, integrator/guided/integrator.h:54): the eight
+// corners of the cell as in f32_encode_level3 -- weight of corner k = (wx wy) wz, dense index in 64 bits -- on the f16 grid
+__device__ __forceinline__ h4_t half_encode_level3(const uint2 *grid, float sc, uint32_t res, uint32_t lo, uint32_t n_level, float x, float y, float z)
+{
+    float px = __builtin_fmaf(sc, x, 0.5f), py = __builtin_fmaf(sc, y, 0.5f), pz = __builtin_fmaf(sc, z, 0.5f);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    px -= fx;
+    py -= fy;
+    pz -= fz;
+    const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy, iz = (uint32_t)(int)fz;
+    union { uint2 u; h4_t h; } c[8];
+    float w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t cx = ix + (k & 1), cy = iy + ((k >> 1) & 1), cz = iz + ((k >> 2) & 1);
+        w[k] = (((k & 1) ? px : 1.0f - px) * ((k & 2) ? py : 1.0f - py)) * ((k & 4) ? pz : 1.0f - pz);
+        const uint32_t idx = (uint32_t)(((unsigned long long)cx + (unsigned long long)cy * res + (unsigned long long)cz * res * res) % n_level);
+        c[k].u = grid[lo + idx];
+    }
+    float4 f = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        f.x += w[k] * (float)c[k].h[0]; f.y += w[k] * (float)c[k].h[1];
+        f.z += w[k] * (float)c[k].h[2]; f.w += w[k] * (float)c[k].h[3];
+    }
+    return h4_t{(_Float16)f.x, (_Float16)f.y, (_Float16)f.z, (_Float16)f.w};
+}
+
 // The four matrices on one 16-point unit, reference network shape (32 -> 64 -> 64 -> 64 -> 48).  Lane l = (i = l & 15,
 // g = l >> 4) supplies in[h] = the encoding of levels g + 4h of point i and receives out[rt][c] = output
 // 16 rt + 4 g + c of point i, rounded to f16 like the network's outputs.  `wf` = the fragment part of the image

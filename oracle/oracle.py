@@ -615,12 +615,13 @@ class Oracle:
         self.lib.wo_net3_n_params.restype = C.c_uint64
         return int(self.lib.wo_net3_n_params(C.byref(cfg)))
 
-    def net3_forward(self, cfg, params, xyz):
+    def net3_forward(self, cfg, params, xyz, want_acts=False):
         p = np.ascontiguousarray(params, dtype=np.float32)
         x = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
         out = np.zeros((len(x), cfg.n_output_padded), dtype=np.float32)
-        self.lib.wo_net3_forward(C.byref(cfg), _fp(p), _fp(x), len(x), _fp(out), None)
-        return out
+        acts = np.zeros((len(x), cfg.n_levels * cfg.n_features + cfg.n_hidden_layers * cfg.n_neurons), dtype=np.float32) if want_acts else None
+        self.lib.wo_net3_forward(C.byref(cfg), _fp(p), _fp(x), len(x), _fp(out), _fp(acts) if want_acts else None)
+        return (out, acts) if want_acts else out
 
     def net3_backward(self, cfg, params, xyz, dl_dout):
         p = np.ascontiguousarray(params, dtype=np.float32)

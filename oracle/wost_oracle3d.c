@@ -854,7 +854,8 @@ int wo3_vmm_loss_gradients(const float *raw, const float *dir, const float *li, 
  * oneStepWalk, :968-1094 the sample loop), guided/parameters.h:26-33 (3 inputs, 8 x 5 + 1 = 41 outputs padded to 48), train.h:149-155
  * (normalizeSpatialCoord with the diagonal of the 3-D box), :423-471 (training data), :492-553 (loss gradients, wo3_vmm_loss_gradients
  * above).  The same free choices as in 2-D make it deterministic: training set in (pixel, record) order, the fp32 network of
- * wost_net.c with three inputs.  The source term is not restated here (a scene with one is refused). */
+ * wost_net.c with three inputs.  The source term (sampleSource, guided/integrator.cu:277-364, templated on DIM) follows the uniform
+ * 3-D step's restatement, its contribution recorded like a Neumann one (recordSourceContribution, guided.h:59-68). */
 typedef struct {
     float sol[3];
     v3 p, d, n;
@@ -959,7 +960,6 @@ int wo3_solve_guided(const wo3_scene *sc, const wo3_guided_settings *gs, const w
                      float *field_rgb, wo_guided_stats *stats, int dump_spp, wo3_train_dump *dump)
 {
     if (!sc || !gs || !nc || !params || !field_rgb) return -1;
-    if (sc->source.nx > 0) return -3;      /* the 3-D guided solve has no source term here */
     if (nc->n_output != 41 || nc->n_output_padded < 41) return -1;
     const int W = gs->width, H = gs->height, N = W * H;
     pmesh3 dm, nm;
@@ -1047,6 +1047,48 @@ int wo3_solve_guided(const wo3_scene *sc, const wo3_guided_settings *gs, const w
                 if (isinf(R_B)) { q->state = 0; continue; }
                 q->R_B = R_B;
                 q->state = 2;
+                if (sc->source.nx > 0) {                        /* sampleSource (guided/integrator.cu:277-364 with DIM == 3) */
+                    v3 sdir;
+                    float dir_pdf, salpha = 1.0f;
+                    {
+                        const float u1 = wo_pcg_next_float(&q->rng), u2 = wo_pcg_next_float(&q->rng);
+                        float c, s;
+                        wo_sincos_2pi(u2, &c, &s);
+                        if (q->on_n) {
+                            const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+                            sdir = frame_to_world(q->nn, r * c, r * s, z);
+                            dir_pdf = 1.0f / WO_2PI;
+                            salpha = 0.5f;
+                        } else {
+                            const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
+                            sdir = (v3){ r * c, r * s, z };
+                            dir_pdf = 1.0f / WO_4PI;
+                        }
+                    }
+                    float dist = R_B;
+                    if (has_n) {
+                        float t; int hi;
+                        const v3 o = { q->x.x + eps * sdir.x, q->x.y + eps * sdir.y, q->x.z + eps * sdir.z };
+                        if (ray_closest3(&nm, o, sdir, dist, &t, &hi)) dist = fminf(t, dist);
+                    }
+                    const float g1 = wo_pcg_next_float(&q->rng), g2 = wo_pcg_next_float(&q->rng);
+                    float gc, gs;
+                    wo_sincos_2pi(g2, &gc, &gs);
+                    float r = (1.0f + sqrtf(1.0f - cbrt01(g1 * g1)) * gc) * R_B / 2.0f;
+                    r = fmaxf(1e-4f, r);
+                    if (r > R_B) r = R_B / 2.0f;
+                    if (r <= dist) {
+                        float f[3], col[3];
+                        wo3_source_eval(&sc->source, q->x.x + r * sdir.x, q->x.y + r * sdir.y, q->x.z + r * sdir.z, f);
+                        const float norm = R_B * R_B / 6.0f;
+                        const float c1 = (1.0f / WO_4PI) / (r * r), c2 = dir_pdf / (r * r);
+                        for (int c = 0; c < 3; ++c) {
+                            col[c] = q->thp * f[c] * norm * c1 / c2 / salpha;
+                            q->sol[c] = col[c] + q->sol[c];
+                        }
+                        if (train_px) record_solution3(q, col, 1);
+                    }
+                }
                 if (has_n) {                                    /* sampleNeumann: three draws in 3-D */
                     const float u0 = wo_pcg_next_float(&q->rng), u1 = wo_pcg_next_float(&q->rng), u2 = wo_pcg_next_float(&q->rng);
                     float pdf;

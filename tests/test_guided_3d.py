@@ -237,8 +237,8 @@ def test_gpu_trained_solve_matches_oracle_3d(orc):
 
 @pytest.mark.gpu
 def test_gpu_guided3_shards_and_refusals(orc):
-    """wost3_guided_solve_sharded: with a frozen network the shards' fields add up to the full frame; a source term and a
-    2-D shaped network are refused"""
+    """wost3_guided_solve_sharded: with a frozen network the shards' fields add up to the full frame; a 2-D shaped network
+    is refused"""
     import torch
     from elaina_amd import capi
     from elaina_amd.guided import GuidedIntegratorSettings
@@ -260,6 +260,136 @@ def test_gpu_guided3_shards_and_refusals(orc):
     gi.close()
     with pytest.raises(capi.WostError):
         GuidedIntegrator3(Problem3.from_dict(sd), st, AABB3, network_config=capi.NetConfig(4, 4, 8, 1.405, 64, 3, 33, 8e-3, 0.9, 0.99, 1e-15, 1e-6, 0.95))
-    src = dict(sd, source={"rgb": np.ones((3, 3, 3, 3), np.float32), "index_scale": (2.0, 2.0, 2.0), "index_offset": (0.0, 0.0, 0.0)})
-    with pytest.raises(capi.WostError):
-        GuidedIntegrator3(Problem3.from_dict(src), st, AABB3, network_config=_hip_cfg(_cfg()))
+
+
+@pytest.mark.gpu
+def test_gpu_guided3_source_term_matches_oracle(orc):
+    """sampleSource of the guided integrator in 3-D (guided/integrator.cu:277-364 is templated on DIM): a Poisson problem on the
+    mixed cube -- a dense-grid source, Dirichlet u = z on two faces, an EMISSIVE Neumann face among the four others -- with a
+    frozen network and with training (records collect the source contributions, recordSourceContribution): fields, counters,
+    training set and trained weights bit for bit; and the sign / scale against the analytic solution of -laplace u = f"""
+    sd = cube_scene3(n=3, d_faces=(4, 5), n_faces=(0, 1, 2, 3), value=lambda x, y, z: z, flux=lambda x, y, z, f: 0.3 * (f - 1.5))
+    rng = np.random.default_rng(4)
+    sd["source"] = {"rgb": rng.uniform(-1, 1, (5, 4, 6, 3)).astype(np.float32), "index_scale": (5.0, 3.0, 4.0), "index_offset": (0.0, 0.0, 0.0),
+                    "intensity": 0.7}
+    p = _rand_params3(orc, _cfg(), seed=3, wscale=0.3, gscale=1.0)
+    gi, ref = _gpu_and_oracle3(orc, sd, 36, 28, 3, 48, 0, params=p)
+    assert np.array_equal(gi.solution, ref["field"]), float(np.abs(gi.solution - ref["field"]).max())
+    for k in COUNTERS:
+        assert gi.last_stats[k] == ref[k], k
+    gi.close()
+    gi, ref = _gpu_and_oracle3(orc, sd, 30, 24, 6, 48, 4, batch=512, min_batch=128)
+    for k in COUNTERS + ("train_samples", "optimizer_steps"):
+        assert gi.last_stats[k] == ref[k], k
+    assert ref["optimizer_steps"] >= 4
+    ts, to = gi.train_set(), ref["train_set"]
+    for k in ("xyz", "dir", "solution", "dir_pdf", "normal", "on_neumann"):
+        assert np.array_equal(ts[k], to[k]), k
+    assert np.array_equal(gi.solution, ref["field"]) and np.array_equal(gi.network.params(), ref["params"])
+    gi.close()
+    # -laplace u = f with f = 6 constant, u = z (1 - z) * 3 + z on the cube with zero flux on the sides: u(z = 1/2) = 3/4 + 1/2
+    sd = mixed_cube()
+    sd["source"] = {"rgb": np.full((2, 2, 2, 3), 6.0, np.float32), "index_scale": (1.0, 1.0, 1.0), "index_offset": (0.0, 0.0, 0.0), "intensity": 1.0}
+    gi, ref = _gpu_and_oracle3(orc, sd, 24, 24, 48, 64, 0, params=p)
+    assert np.array_equal(gi.solution, ref["field"])
+    trunc = ref["walks_truncated"] / ref["walks_started"]
+    assert abs(float(gi.solution[:, 0].mean()) - 1.25) < 0.06 + 1.5 * trunc, float(gi.solution[:, 0].mean())
+    gi.close()
+
+
+# ---- the reference's network precision with three inputs ("precision" / "train_precision" 16, integrator/guided/integrator.h:54) ----
+def _half_network3_numpy(orc, cfg, p, x):
+    """the half-precision three-input network in numpy: grid values rounded to f16, the oracle's fp32 trilinear interpolation,
+    then per layer f16 inputs and weights, fp32 accumulation, ReLU, f16 (tests/test_guided_network.py does the same for two inputs)"""
+    n_mlp = 64 * 32 + 2 * 64 * 64 + 48 * 64
+    ph = p.copy()
+    ph[n_mlp:] = p[n_mlp:].astype(np.float16).astype(np.float32)
+    a = orc.net3_forward(cfg, ph, x, want_acts=True)[1][:, :32].astype(np.float16).astype(np.float32)
+    off = 0
+    for no, ni, relu in [(64, 32, True), (64, 64, True), (64, 64, True), (48, 64, False)]:
+        w = p[off:off + no * ni].reshape(no, ni).astype(np.float16).astype(np.float32)
+        off += no * ni
+        z = (a.astype(np.float64) @ w.T.astype(np.float64)).astype(np.float32)
+        a = (np.maximum(z, 0.0) if relu else z).astype(np.float16).astype(np.float32)
+    return a[:, :41]
+
+
+@pytest.mark.gpu
+def test_gpu_net3_half_precision_inference_and_training(orc):
+    """the three-input network of the reference's shape (eight levels) in half precision: inference equal to the numpy
+    restatement up to the summation order inside the matrix instruction and close to the fp32 network; training passes
+    (f16 forward / backward / weight gradients, fp32 master weights) reproducible bit for bit, close to the fp32 gradient, and
+    a regression learns"""
+    from elaina_amd.guided import GuidingNetwork
+    cfg = default_net_config3()
+    p = _rand_params3(orc, cfg, seed=13, wscale=0.2, gscale=0.4)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0.0, 1.0, (5000, 3)).astype(np.float32)
+    net = GuidingNetwork(_hip_cfg(cfg), seed=3, dims=3)
+    net.set_params(p)
+    fp32 = net.inference(x)
+    assert np.array_equal(fp32, orc.net3_forward(cfg, p, x)[:, :41])
+    net.set_option("precision", 16)
+    half = net.inference(x)
+    emu = _half_network3_numpy(orc, cfg, p, x)
+    scale = float(np.sqrt(np.mean(fp32 ** 2)))
+    assert np.abs(half - emu).max() <= 4e-3 * scale and np.mean(half == emu) > 0.9
+    assert float(np.sqrt(np.mean((half - fp32) ** 2))) / scale < 5e-3
+    assert np.array_equal(half, half.astype(np.float16).astype(np.float32))
+    net.set_option("precision", 32)
+    assert np.array_equal(net.inference(x), fp32)
+    # one training step in both precisions from the same weights: the gradients agree, the half-precision one is reproducible
+    dl = (rng.normal(size=(len(x), 41)) * 0.01).astype(np.float32)
+    net.train_step(x, dl, 128.0, apply_update=False)
+    g32 = net.gradients().copy()
+    net.set_option("train_precision", 16)
+    net.train_step(x, dl, 128.0, apply_update=False)
+    g16 = net.gradients().copy()
+    net.train_step(x, dl, 128.0, apply_update=False)
+    assert np.array_equal(net.gradients(), g16)
+    n_mlp = 64 * 32 + 2 * 64 * 64 + 48 * 64
+    for sl in (slice(0, n_mlp), slice(n_mlp, None)):
+        ref = g32[sl]
+        assert float(np.linalg.norm(g16[sl] - ref)) < 0.08 * float(np.linalg.norm(ref)) + 1e-9
+    # a regression through the half-precision passes: the loss falls
+    target = lambda q: np.stack([np.sin(3 * q[:, 0]) * q[:, 1], q[:, 2] ** 2] + [0.1 * q[:, 0]] * 39, 1).astype(np.float32)
+    net.set_option("precision", 16)
+    first = last = None
+    for it in range(60):
+        xb = rng.uniform(0, 1, (8192, 3)).astype(np.float32)
+        pred = net.inference(xb, use_inference_params=False)
+        loss = float(np.mean((pred - target(xb)) ** 2))
+        first = loss if first is None else first
+        last = loss
+        net.train_step(xb, (2.0 * (pred - target(xb)) / pred.size * 128.0).astype(np.float32), loss_scale=128.0)
+    assert last < 0.3 * first, (first, last)
+    net.close()
+
+
+@pytest.mark.gpu
+def test_gpu_guided3_half_precision_solve_is_unbiased_and_reproducible(orc):
+    """GuidedIntegrator<3> with the half-precision network (inference and training passes): two solves give the same field and the
+    same network, the harmonic check u = z on the mixed cube holds as in fp32, and the field differs from the fp32 mode's"""
+    from elaina_amd.guided import GuidedIntegratorSettings
+    from elaina_amd.integrator3d import GuidedIntegrator3, Problem3
+    sd = mixed_cube()
+    out = {}
+    for prec in (32, 16, 16):
+        st = GuidedIntegratorSettings(frameSize=(40, 40), samplesPerPixel=24, trainSppCount=12, maxWalkingDepth=64, epsilonShell=EPS,
+                                      batchSize=2048, minBatchSize=512)
+        gi = GuidedIntegrator3(Problem3.from_dict(sd), st, AABB3, network_config=_hip_cfg(default_net_config3()), seed=7)
+        if prec == 16:
+            gi.network.set_option("precision", 16)
+            gi.network.set_option("train_precision", 16)
+        gi.solve()
+        assert gi.last_stats["optimizer_steps"] > 0 and gi.last_stats["guided_steps"] > 0
+        out.setdefault(prec, []).append((gi.solution.copy(), gi.network.params(), dict(gi.last_stats)))
+        gi.close()
+    (f16a, p16a, s16), (f16b, p16b, _) = out[16]
+    f32, _, s32 = out[32][0]
+    assert np.array_equal(f16a, f16b) and np.array_equal(p16a, p16b) and not np.array_equal(f16a, f32)
+    for f, s in ((f16a, s16), (f32, s32)):
+        trunc = s["walks_truncated"] / s["walks_started"]
+        assert abs(float(f[:, 0].mean()) - 0.5) < 0.02 + 0.5 * trunc
+    r16, r32 = float(np.sqrt(np.mean((f16a[:, 0] - 0.5) ** 2))), float(np.sqrt(np.mean((f32[:, 0] - 0.5) ** 2)))
+    assert r16 < 1.25 * r32

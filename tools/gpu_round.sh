@@ -2,8 +2,8 @@
 # one GPU-box trip: gpu tests, smoke, bench, rocprof kernel trace + PMC passes of the bench command.
 # TAG names the output directory under gpurun_out/; STAGES selects what runs (default: all).
 export TMPDIR=/tmp
-TAG=${TAG:-r03}
-STAGES=${STAGES:-"tests smoke micro bench trace pmc pmc_guided pmc3d"}
+TAG=${TAG:-r04}
+STAGES=${STAGES:-"tests smoke micro bench trace pmc pmc_guided pmc3d pmc3d_1024 pmc_guided3d"}
 mkdir -p gpurun_out/$TAG
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 if has tests; then
@@ -71,5 +71,42 @@ if has pmc3d; then
   done
   python3 tools/pmc_derive_3d.py gpurun_out/$TAG/pmc_summary_3d.txt gpurun_out/$TAG/kernel_stats_3d.csv gpurun_out/$TAG/walk3_valu.json "$A3"
   rm -rf gpurun_out/$TAG/trace3d
+fi
+# the same two scenes at 1024^2 (a million walkers: the full-chip frames)
+if has pmc3d_1024; then
+  A3="tools/probes/bench3d_only.py"
+  export BENCH3D_FRAME=1024
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/trace3d -- python3 $A3 > gpurun_out/$TAG/bench3d_1024_trace.log 2>&1
+  f=$(find gpurun_out/$TAG/trace3d -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/$TAG/kernel_stats_3d_1024.csv
+  rm -f gpurun_out/$TAG/pmc_summary_3d_1024.txt
+  i=0
+  for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+             "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/$TAG/p3d$i -- python3 $A3 > gpurun_out/$TAG/p3d$i.log 2>&1
+    f=$(find gpurun_out/$TAG/p3d$i -name '*counter_collection.csv' | head -1)
+    [ -n "$f" ] && PMC_NAME_WIDTH=90 python3 tools/pmc_summary.py "$f" walk3_kernel | tee -a gpurun_out/$TAG/pmc_summary_3d_1024.txt
+    rm -rf gpurun_out/$TAG/p3d$i
+  done
+  python3 tools/pmc_derive_3d.py gpurun_out/$TAG/pmc_summary_3d_1024.txt gpurun_out/$TAG/kernel_stats_3d_1024.csv gpurun_out/$TAG/walk3_valu_1024.json "BENCH3D_FRAME=1024 $A3"
+  rm -rf gpurun_out/$TAG/trace3d
+  unset BENCH3D_FRAME
+fi
+# GuidedIntegrator<3> on the two bench scenes (256^2, 16 spp, 8 trained): kernel trace + PMC passes of its walk kernels
+if has pmc_guided3d; then
+  AG="tools/probes/bench3d_guided_only.py"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/traceg3 -- python3 $AG > gpurun_out/$TAG/guided3d_trace.log 2>&1
+  f=$(find gpurun_out/$TAG/traceg3 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/$TAG/kernel_stats_guided3d.csv
+  rm -f gpurun_out/$TAG/pmc_summary_guided3d.txt
+  i=0
+  for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/$TAG/pg3$i -- python3 $AG > gpurun_out/$TAG/pg3$i.log 2>&1
+    f=$(find gpurun_out/$TAG/pg3$i -name '*counter_collection.csv' | head -1)
+    [ -n "$f" ] && PMC_NAME_WIDTH=90 python3 tools/pmc_summary.py "$f" g3_ | tee -a gpurun_out/$TAG/pmc_summary_guided3d.txt
+    rm -rf gpurun_out/$TAG/pg3$i
+  done
+  python3 tools/pmc_derive_guided3d.py gpurun_out/$TAG/pmc_summary_guided3d.txt gpurun_out/$TAG/kernel_stats_guided3d.csv gpurun_out/$TAG/guided3d_valu.json "$AG"
+  rm -rf gpurun_out/$TAG/traceg3
 fi
 rm -rf gpurun_out/$TAG/pmc[0-9] gpurun_out/$TAG/trace
