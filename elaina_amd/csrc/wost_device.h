@@ -40,6 +40,7 @@ struct DevMesh {
     const DevFlatSeg *flat;  // [n_segs] original order
     const float *flatCol;    // [n_segs*12]
     const DevSilVertex *sil; // [n_sil] one per mesh vertex
+    const float4 *silN;      // [n_sil] the unit normals of the vertex's two segments (prev.nx, prev.ny, next.nx, next.ny; zeros where there is none)
     const float4 *cones;     // [n_nodes * 5]: SNCH cones of the children: ax[4] ay[4] cos[4] sin[4] rad[4]
     const int2 *segVerts;    // [slots] vertex ids of the slot's segment
     int32_t n_segs;
@@ -444,19 +445,42 @@ __device__ __forceinline__ float closest_silhouette_flat(const DevMesh &m, float
     float best2 = rmax * rmax;
     bool found = false;
     if (m.n_sil == 4) {
-        // The Neumann boundary of every shipped scene is a four-vertex box.  The loop below fetches one vertex per trip with a
-        // scalar load the trip waits for -- four dependent round trips per walk step, 4.5 % of config 2 (EXPERIMENTS 16) -- to find,
-        // nearly always, that no vertex lies within R_D.  Here the four vertices come with ONE load and the loop's own first test
-        // (`d2 > best2`: skip) is evaluated for all of them: when it skips every vertex for every lane of the wave, the loop would
-        // return +inf for each of them, and so does this.  Otherwise the loop runs as ever (same arithmetic, same result).
-        bool close = false;
+        // The Neumann boundary of every shipped scene is a four-vertex box.  The loop below fetches one vertex per trip, then its two
+        // segments' records, with scalar loads each trip waits for; it costs 3-4 % of config 2 (a build without it: EXPERIMENTS 16)
+        // although nearly every test ends with "farther than R_D" or "not a silhouette".  Here the four vertices and the normals of
+        // their segments come with TWO loads that wait for nothing, and the loop's body runs on them unrolled: the same tests in the
+        // same order on the same numbers, so the same result.
+#ifdef WOST_EXP_SIL_FAST_ALWAYS
+        return WOST_INF;      // developer experiment: the cost of everything below
+#endif
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const DevSilVertex sv = m.sil[v];
+            const float4 nn = m.silN[v];
+            if (sv.prev < 0 && sv.next < 0) continue;
             const float vx = qx - sv.x, vy = qy - sv.y;
-            close = close || !(dot2(vx, vy, vx, vy) > best2);
+            const float d2 = dot2(vx, vy, vx, vy);
+            if (d2 > best2) continue;
+            bool is_sil = (sv.prev < 0 || sv.next < 0);
+            if (!is_sil) {
+                const float d = sqrtf(d2);
+                if (d <= WOST_SIL_PRECISION) {
+                    const float det = cross2(nn.x, nn.y, nn.z, nn.w);
+                    is_sil = (-det > WOST_SIL_PRECISION);
+                } else {
+                    const float ux = vx / d, uy = vy / d;
+                    const float dot0 = dot2(ux, uy, nn.x, nn.y);
+                    const float dot1 = dot2(ux, uy, nn.z, nn.w);
+                    if (fabsf(dot0) <= WOST_SIL_PRECISION || fabsf(dot1) <= WOST_SIL_PRECISION) is_sil = false;
+                    else is_sil = (dot0 * dot1 < 0.0f);
+                }
+            }
+            if (is_sil && (d2 < best2 || !found)) {
+                best2 = d2;
+                found = true;
+            }
         }
-        if (!__ballot(close)) return WOST_INF;
+        return found ? sqrtf(best2) : WOST_INF;
     }
     for (int v = 0; v < m.n_sil; ++v) {
         const DevSilVertex sv = m.sil[v];
@@ -514,31 +538,45 @@ __device__ __forceinline__ bool seg_ray(const DevFlatSeg &s, float ox, float oy,
     return true;
 }
 
-// the four-segment boundary of every shipped scene: the four records with loads that do not wait for one another, the hit tests
-// of the loops below for all of them; true when no lane of the wave hits anything -- the loops would find nothing either
-__device__ __forceinline__ bool ray_misses_box_flat(const DevMesh &m, float ox, float oy, float dx, float dy, float tmax)
+// The four-segment boundary of every shipped scene (a box): the loops below unrolled -- the four records fetched with loads that
+// do not wait for one another, the same tests in the same order, the division only for a segment that is hit.
+template <bool ANY_HIT>
+__device__ __forceinline__ bool ray_box_flat(const DevMesh &m, float ox, float oy, float dx, float dy, float tmax, float &t_out, int &idx_out)
 {
-    bool any = false;
+    float4 a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float4 *>(&m.flat[i]);      // ax ay ex ey
+    bool hit = false;
+    float bt = WOST_INF;
+    int bi = -1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float4 a = *reinterpret_cast<const float4 *>(&m.flat[i]);      // ax ay ex ey
         float uv, dv;
-        any = any || seg_ray_hits(a.x, a.y, a.z, a.w, ox, oy, dx, dy, tmax, uv, dv);
+        if (seg_ray_hits(a[i].x, a[i].y, a[i].z, a[i].w, ox, oy, dx, dy, tmax, uv, dv)) {
+            if (ANY_HIT) {
+                hit = true;
+            } else {
+                const float t = uv / dv;
+                if (!hit || t < bt) {
+                    bt = t;
+                    bi = i;
+                    hit = true;
+                }
+            }
+        }
     }
-    return !__ballot(any);
+    t_out = bt;
+    idx_out = bi;
+    return hit;
 }
 
 __device__ __forceinline__ bool ray_closest_flat(const DevMesh &m, float ox, float oy, float dx, float dy, float tmax,
                                                  float &t_out, int &idx_out)
 {
+    if (m.n_segs == 4) return ray_box_flat<false>(m, ox, oy, dx, dy, tmax, t_out, idx_out);
     bool hit = false;
     float bt = WOST_INF;
     int bi = -1;
-    if (m.n_segs == 4 && ray_misses_box_flat(m, ox, oy, dx, dy, tmax)) {
-        t_out = bt;
-        idx_out = bi;
-        return false;
-    }
     for (int i = 0; i < m.n_segs; ++i) {
         const DevFlatSeg s = m.flat[i];
         float t;
@@ -558,7 +596,11 @@ __device__ __forceinline__ bool ray_closest_flat(const DevMesh &m, float ox, flo
 __device__ __forceinline__ bool ray_any_flat(const DevMesh &m, float ox, float oy, float dx, float dy, float tmax)
 {
     bool hit = false;
-    if (m.n_segs == 4 && ray_misses_box_flat(m, ox, oy, dx, dy, tmax)) return false;
+    if (m.n_segs == 4) {
+        float t;
+        int i;
+        return ray_box_flat<true>(m, ox, oy, dx, dy, tmax, t, i);
+    }
     for (int i = 0; i < m.n_segs; ++i) {
         const DevFlatSeg s = m.flat[i];
         float t;

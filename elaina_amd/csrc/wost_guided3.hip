@@ -72,7 +72,18 @@ struct G3Params {
     // the tree queries of a wave's walkers through its task pools (closest_triangle_pool & co.): pool_cap tasks per pool and wave,
     // pool_offset words into the block's LDS (behind the stack columns); pool_cap = 0: one descent per thread
     int32_t pool_cap, pool_offset;
+    // small frames: one walker per 2^lane_shift lanes of the walk kernels -- a frame of 256^2 fills a quarter of the chip's lanes with
+    // one walker per lane, and a wave's 64 queries through its pools take as long as they take; spread over more waves the same
+    // queries run on more CUs at once (the lanes without a walker work on the other lanes' tree nodes)
+    int32_t lane_shift;
 };
+
+// the walker (pixel or queue entry) of this thread, or -1
+__device__ __forceinline__ int g3_item(const G3Params &P)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    return (tid & ((1u << P.lane_shift) - 1u)) == 0u ? (int)(tid >> P.lane_shift) : -1;
+}
 
 // the task pools of this wave (8-byte LDS atomics: from an 8-byte boundary, whatever static words precede the dynamic segment)
 __device__ __forceinline__ WavePool3 g3_pools(const G3Params &P, uint32_t *lds)
@@ -334,10 +345,10 @@ __global__ __launch_bounds__(256) void g3_separate_kernel(G3Params P)
     extern __shared__ uint32_t lds_stack[];
     const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
     const WavePool3 W = g3_pools(P, lds_stack);
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = p < P.n_pixels && P.state[p] == 1;
+    const int p = g3_item(P);
+    const bool live = p >= 0 && p < P.n_pixels && P.state[p] == 1;
     V3 x;
-    const bool keep = g3_separate_body<EMISSIVE, NTREE, SOURCE>(P, P.depth, p, live, W, stk, x);
+    const bool keep = g3_separate_body<EMISSIVE, NTREE, SOURCE>(P, P.depth, live ? p : 0, live, W, stk, x);
     const uint32_t s = block_push(keep, P.q_count);
     if (keep) {
         P.q_pid[s] = (uint32_t)p;
@@ -489,9 +500,9 @@ __global__ __launch_bounds__(256) void g3_sample_kernel(G3Params P)
     extern __shared__ uint32_t lds_stack[];
     const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
     const WavePool3 W = g3_pools(P, lds_stack);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < *P.q_count;
-    g3_sample_body<NTREE>(P, P.depth, P.guiding != 0, live ? P.q_pid[i] : 0u, live, P.net_out + 41 * (size_t)i, W, stk);
+    const int i = g3_item(P);
+    const bool live = i >= 0 && (uint32_t)i < *P.q_count;
+    g3_sample_body<NTREE>(P, P.depth, P.guiding != 0, live ? P.q_pid[i] : 0u, live, P.net_out + 41 * (size_t)(live ? i : 0), W, stk);
 }
 
 // The unguided tail of a sample: from depth >= maxGuidedDepth on nothing needs the network, yet a launch pair per depth over a
@@ -504,13 +515,13 @@ __global__ __launch_bounds__(256) void g3_tail_kernel(G3Params P)
     extern __shared__ uint32_t lds_stack[];
     const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
     const WavePool3 W = g3_pools(P, lds_stack);
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = p < P.n_pixels;
+    const int p = g3_item(P);
+    const bool mine = p >= 0 && p < P.n_pixels;
     for (int depth = P.depth; depth < P.st.max_depth; ++depth) {
         const bool live = mine && P.state[p] == 1;
         if (!__ballot(live)) break;       // (wave-uniform: the queries are the wave's)
         V3 x;
-        const bool keep = g3_separate_body<EMISSIVE, NTREE, SOURCE>(P, depth, p, live, W, stk, x);
+        const bool keep = g3_separate_body<EMISSIVE, NTREE, SOURCE>(P, depth, mine ? p : 0, live, W, stk, x);
         g3_sample_body<NTREE>(P, depth, false, (uint32_t)(mine ? p : 0), keep, nullptr, W, stk);
     }
 }
@@ -716,7 +727,17 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
     const int n_train_pixels = (int)(((size_t)N - train_offset + (size_t)s.train_pixel_stride - 1) / (size_t)s.train_pixel_stride);
     const int n_train_blocks = (n_train_pixels + 255) / 256;
     W3_TRY(hipMemsetAsync(g->stats, 0, kStat3Copies * sizeof(GStats3Dev), stream));
-    const unsigned grid_px = (unsigned)((N + 255) / 256);
+    // walkers per lane of the walk kernels: spread out while the frame leaves lanes of the chip idle (about three blocks per CU fit)
+    {
+        int n_cus = 256;
+        (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, g->device);
+        const uint64_t resident = (uint64_t)n_cus * 3 * 256;
+        P.lane_shift = 0;
+        while (P.pool_cap > 0 && P.lane_shift < 3 && (((uint64_t)N << (P.lane_shift + 1)) * 2 <= resident * 3)) ++P.lane_shift;
+        if (const char *w = std::getenv("WOST3_G_SHIFT")) P.lane_shift = std::min(4, std::max(0, std::atoi(w)));
+    }
+    const unsigned grid_px = (unsigned)((((uint64_t)N << P.lane_shift) + 255) / 256);      // walk kernels (begin / train-set / resolve: one thread per pixel)
+    const unsigned grid_pix = (unsigned)((N + 255) / 256);
     uint32_t launches = 0;
     uint64_t train_samples = 0;
     double train_ms = 0.0;
@@ -732,7 +753,7 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
             max_guided_depth = s.max_guided_depth_guiding;
         }
         P.training = training ? 1 : 0; P.uniform_fraction = uniform_fraction; P.first_sample = sample == 0 ? 1 : 0;
-        hipLaunchKernelGGL(g3_begin_kernel, dim3(grid_px), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL(g3_begin_kernel, dim3(grid_pix), dim3(256), 0, stream, P);
         ++launches;
         // No host round trip inside a sample: the launches of a depth are sized for the frame (their kernels read the true length of
         // the queue on the device; a block beyond it ends at once), and from the first depth that needs no network on, ONE launch
@@ -761,7 +782,7 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
                 const int rc = net_inference_dev(g->net, g->net_in, g->q_count, (int)n_upper, g->net_out, true, stream, 0);
                 if (rc != WOST_OK) return rc;
             }
-            const unsigned grid_q = (n_upper + 255u) / 256u;
+            const unsigned grid_q = (unsigned)((((uint64_t)n_upper << P.lane_shift) + 255u) / 256u);
             if (ntree) hipLaunchKernelGGL((g3_sample_kernel<true>), dim3(grid_q), dim3(256), lds, stream, P);
             else hipLaunchKernelGGL((g3_sample_kernel<false>), dim3(grid_q), dim3(256), lds, stream, P);
             ++launches;

@@ -945,6 +945,16 @@ static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
     HIP_TRY(upload(s.allocs, reinterpret_cast<const DevFlatSeg *>(t.flat.data()), t.flat.size(), &v.flat));
     HIP_TRY(upload(s.allocs, t.flatCol.data(), t.flatCol.size(), &v.flatCol));
     HIP_TRY(upload(s.allocs, reinterpret_cast<const DevSilVertex *>(t.sil.data()), t.sil.size(), &v.sil));
+    {
+        // the normals of every vertex's two segments beside it: the flat silhouette test of a small boundary reads them with the vertex
+        std::vector<float> sn(t.sil.size() * 4, 0.0f);
+        for (size_t k = 0; k < t.sil.size(); ++k) {
+            const SilVertex &sv = t.sil[k];
+            if (sv.prev >= 0) { sn[4 * k] = t.flat[(size_t)sv.prev].nx; sn[4 * k + 1] = t.flat[(size_t)sv.prev].ny; }
+            if (sv.next >= 0) { sn[4 * k + 2] = t.flat[(size_t)sv.next].nx; sn[4 * k + 3] = t.flat[(size_t)sv.next].ny; }
+        }
+        HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(sn.data()), t.sil.size(), &v.silN));
+    }
     HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(t.cones.data()), t.cones.size() / 4, &v.cones));
     {
         // closest_point_wave: the occupied slots, compact; the operands are those of the leaf-level node records

@@ -341,10 +341,12 @@ int wost_guided_train_set(wost_guided_handle h, int32_t capacity, int32_t *n, fl
  * stays unbiased for any network state (direction and one-sample-MIS density of a sample come from the same copy, the
  * training records carry the density they were drawn with); the field differs from the exact order's statistically, so
  * this is never the parity mode: default off, and a solve with intermediate frames falls back to the exact order.
- * "train_group" (1 default .. 16): a training launch walks that many samples of every pixel back to back, each with its own
- * record set, and their training passes follow the launch (with "pipeline" 1: on the second stream, while the next group
- * walks): the drain of a sample's longest walks is paid once per group.  The same statistical contract as "pipeline";
- * 1 = the reference's order (a training pass between any two samples). */
+ * "train_group" (1 default .. 16): a training launch walks up to that many samples of every pixel, each with its own record
+ * set, and their training passes follow the launch (with "pipeline" 1: on the second stream, while the next group walks): the
+ * drain of a sample's longest walks is paid once per group.  The groups grow with the training -- the launch that starts at
+ * sample s covers min(S, max(1, s / 2)) samples, never more than half of what has been trained before it -- so the first
+ * samples, from which the network learns fastest, keep the reference's order.  The same statistical contract as "pipeline";
+ * 1 = the reference's order throughout (a training pass between any two samples). */
 int wost_guided_set_option(wost_guided_handle h, const char *key, double value);
 int wost_guided_destroy(wost_guided_handle h);
 
