@@ -188,7 +188,9 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
     problem = Problem.load_scene(scene)
     depth = depth or problem.default_max_depth
     eps = problem.default_eps
+    t_create = time.perf_counter()
     it = UniformIntegrator(problem, UniformIntegratorSettings((frame, frame), spp, depth, eps), device=env.local)
+    create_ms = (time.perf_counter() - t_create) * 1e3
     if args.steps_per_round:
         it.set_option("steps_per_round", args.steps_per_round)
     for kv in args.opt:
@@ -276,6 +278,9 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
                                                  "what": "one %s of the %d-byte field (waits for the slowest rank)" % (
                                                      "all-gather of disjoint shards" if field.numel() * 4 >= env.D.GATHER_THRESHOLD_BYTES
                                                      else "all-reduce of zero-padded frames", field.numel() * 4)}}
+    # wost_create: the trees of both meshes (2-D: host builder csrc/lbvh_build.cpp, a top-down sweep; 3-D meshes are built by
+    # kernels, configs.mesh_build3), uploads, the frame's buffers -- outside the solve timer like the reference's build_bvh
+    out["create_ms"] = create_ms
     if t1:
         out["time_to_1spp_ms"] = {"cold": t1[0], "steady": sorted(t1[1:])[len(t1[1:]) // 2]}
     if sched["trav_trips"] and steps_local:
@@ -525,6 +530,21 @@ def run_uniform3d(env, args, only=None):
     return out
 
 
+def run_mesh_build3(env):
+    """Problem<3>::build_bvh on the device (csrc/wost_build3.hip): a bumpy sphere of 81 920 triangles in shuffled index order, the
+    device build against the host builder kept as its checker -- differing bytes per array, fastest of five builds each"""
+    import numpy as np
+    from elaina_amd.integrator3d import mesh_build_check
+    rng = np.random.default_rng(4)
+    V, T = icosphere(6, 1.0)
+    V = (V.astype(np.float64) * (1.0 + 0.15 * np.sin(3 * V[:, :1] + 1.0) * np.cos(4 * V[:, 1:2] + 2.0))).astype(np.float32)
+    T = np.ascontiguousarray(rng.permutation(T), np.int32)
+    diff, compared, host_ms, dev_ms = mesh_build_check(V, T, None, repeat=5, device=env.local)
+    return {"workload": "bumpy icosphere, %d triangles, %d vertices" % (len(T), len(V)), "device_build_ms": dev_ms, "host_build_ms": host_ms,
+            "bytes_compared": compared, "differing_bytes": sum(diff.values()),
+            "what": "wall clock of one mesh build, uploads and the final wait included; wost3_create builds on the device"}
+
+
 def run_neumann2d(env, args):
     """A Neumann boundary too large for the flat loops (its silhouette and ray queries on the tree, answered by the wave:
     wost_coop.h): the non-convex closed curve r(t) = 100 (1 + .2 sin 7t + .05 sin 31t) in 3000 segments, zero flux, around a
@@ -563,8 +583,8 @@ def run_neumann2d(env, args):
 
 
 def run_guided3d(env, args):
-    """GuidedIntegrator<3> on the two 3-D bench scenes at 256^2, 16 spp (8 of them trained), depth 64: the whole solve (walks,
-    network inference per depth, training), as walk-steps per second of wall time."""
+    """GuidedIntegrator<3> on the two 3-D bench scenes at 256^2, 16 spp (8 of them trained) and at 1024^2, 4 spp (2 trained), depth 64:
+    the whole solve (walks, network inference per depth, training), as walk-steps per second of wall time."""
     import numpy as np
     from elaina_amd.guided import GuidedIntegratorSettings
     from elaina_amd.integrator3d import GuidedIntegrator3, Problem3, default_net_config3
@@ -577,8 +597,10 @@ def run_guided3d(env, args):
     shell = {"d_verts": Vi, "d_tris": Ti, "d_colors": np.repeat(Vi[:, :1], 6, axis=1).astype(np.float32), "n_verts": V, "n_tris": T,
              "n_colors": np.zeros((len(V), 6), np.float32), "probe": (0.7, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0)),
              "dirichlet_intensity": 1.0, "neumann_intensity": 1.0}
-    frame, spp = 256, 16
-    for name, sd in (("dirichlet_icosphere_1280", ball), ("neumann_shell_1280", shell)):
+    # (256^2 = 65 536 walkers is a quarter of the chip's lanes at one wave per SIMD: latency-bound; the 1024^2 frames are the
+    # full-chip figure, as for the uniform integrator)
+    for name, sd, frame, spp in (("dirichlet_icosphere_1280", ball, 256, 16), ("neumann_shell_1280", shell, 256, 16),
+                                 ("dirichlet_icosphere_1280_1024", ball, 1024, 4), ("neumann_shell_1280_1024", shell, 1024, 4)):
         st = GuidedIntegratorSettings(frameSize=(frame, frame), samplesPerPixel=spp, trainSppCount=spp // 2, maxWalkingDepth=64, epsilonShell=2e-3)
         gi = GuidedIntegrator3(Problem3.from_dict(sd), st, ((-1.1, -1.1, -1.1), (1.1, 1.1, 1.1)), network_config=default_net_config3(), seed=7,
                                device=env.local)
@@ -593,6 +615,8 @@ def run_guided3d(env, args):
                      "ms_per_step": dt * 1e3, "value": g["walk_steps"] / dt, "unit": "walk-steps/s",
                      "field_finite": bool(np.isfinite(gi.solution).all())}
         gi.close()
+        if frame != 256:
+            continue
         if not args.no_cpu_baseline:
             # a band of the frame against the oracle: four rows (a mask switches the other pixels off on both sides), the network
             # frozen at its initial weights -- the trained solve above has no pixel-local restatement, every pixel trains the one network
@@ -730,6 +754,7 @@ def main():
             extras["cfg4_f16_pipelined"] = e4p
             extras["uniform3d"] = run_uniform3d(env, args)
             extras["guided3d"] = run_guided3d(env, args)
+            extras["mesh_build3"] = run_mesh_build3(env)
             extras["neumann2d"] = run_neumann2d(env, args)
             extras["guiding_gain"] = run_guiding_gain(env)
             if uniform_field is not None:

@@ -164,7 +164,7 @@ EXPORTS = [
     "wost_net_create", "wost_net_destroy", "wost_net_n_params", "wost_net_get_params",
     "wost_net_set_params", "wost_net_set_gradient_buffer", "wost_net_inference", "wost_net_train_step", "wost_net_set_option",
     "wost_guided_create", "wost_guided_set_sync", "wost_guided_set_frame_callback", "wost_guided_network", "wost_guided_scene", "wost_guided_query_network", "wost_guided_solve", "wost_guided_solve_sharded", "wost_guided_train_set", "wost_guided_set_option", "wost_guided_destroy",
-    "wost3_create", "wost3_solve", "wost3_solve_sharded", "wost3_closest_point", "wost3_closest_silhouette", "wost3_ray_intersect",
+    "wost3_create", "wost3_solve", "wost3_solve_sharded", "wost3_closest_point", "wost3_closest_silhouette", "wost3_ray_intersect", "wost3_mesh_build_check",
     "wost3_render_sdf", "wost3_render_source", "wost3_destroy", "wost3_vmf_eval", "wost3_vmf_sample", "wost3_vmm_pdf_sample", "wost3_vmm_loss_gradients",
     "wost3_net_create", "wost3_guided_create", "wost3_guided_destroy", "wost3_guided_network", "wost3_guided_solve", "wost3_guided_solve_sharded",
     "wost3_guided_query_network", "wost3_guided_train_set", "wost3_guided_scene",
@@ -239,6 +239,7 @@ def load():
     L.wost3_closest_point.argtypes = [C.c_void_p, C.c_int, fp, C.c_int32, ip, fp, fp, ip]
     L.wost3_closest_silhouette.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_int32, fp]
     L.wost3_ray_intersect.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, C.c_int32, ip, fp, ip]
+    L.wost3_mesh_build_check.argtypes = [C.POINTER(Mesh3Desc), C.c_int, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.wost3_render_sdf.argtypes = [C.c_void_p, C.c_int, fp]
     L.wost3_render_source.argtypes = [C.c_void_p, fp]
     L.wost3_destroy.argtypes = [C.c_void_p]

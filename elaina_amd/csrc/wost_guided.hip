@@ -1590,11 +1590,19 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
             local -= local % 128;
             if (local < (size_t)s.min_batch_size) break;
             const size_t o = it * bs;
-            float *raw = nullptr, *dl = nullptr;
-            int rc = net_forward_train_dev(g->net, ts.xy + 2 * o, (int)local, st, &raw, &dl);
-            if (rc != WOST_OK) return rc;
-            launch_vmm_loss_gradients(st, raw, ts.dir + 2 * o, ts.li + o, ts.pdf + o, ts.onn + o,
-                                      ts.nrm + 2 * o, (int)local, s.loss_scale, dl, nullptr);
+            // forward + loss gradient in one launch where the network trains in half precision, else the two launches
+            int rc = net_forward_loss_dev(g->net, ts.xy + 2 * o, (int)local, st, ts.dir + 2 * o, ts.li + o, ts.pdf + o, ts.onn + o, ts.nrm + 2 * o,
+                                          s.loss_scale);
+            if (rc == WOST_ERR_UNSUPPORTED) {
+                float *raw = nullptr, *dl = nullptr;
+                rc = net_forward_train_dev(g->net, ts.xy + 2 * o, (int)local, st, &raw, &dl);
+                if (rc != WOST_OK) return rc;
+                launch_vmm_loss_gradients(st, raw, ts.dir + 2 * o, ts.li + o, ts.pdf + o, ts.onn + o,
+                                          ts.nrm + 2 * o, (int)local, s.loss_scale, dl, nullptr);
+                ++launches;      // the loss-gradient kernel; the network's own launches are counted by the network
+            } else if (rc != WOST_OK) {
+                return rc;
+            }
             rc = net_backward_update_dev(g->net, ts.xy + 2 * o, (int)local, s.loss_scale, g->sync ? 0 : 1, st);
             if (rc != WOST_OK) return rc;
             if (g->sync) {
@@ -1608,7 +1616,6 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
                 rc = net_apply_update_dev(g->net, s.loss_scale, st);
                 if (rc != WOST_OK) return rc;
             }
-            ++launches;      // the loss-gradient kernel; the network's own launches are counted by the network
         }
         return WOST_OK;
     };
@@ -1774,6 +1781,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
                 if (const char *w = std::getenv("WOST_GUIDED_SAMPLES_PER_LAUNCH")) cap = std::max(1, std::atoi(w));
                 n_run = std::min(n_run, cap);
             }
+            n_run = (int)std::min<uint64_t>((uint64_t)n_run, std::max<uint64_t>(1, 0xffffffffull / (uint64_t)std::max(N, 1)));      // (items of a launch are counted in 32 bits)
             P.n_samples = n_run;
             P.d0_valid = d0_valid ? 1 : 0;
             P.max_guided_depth = max_guided_depth;

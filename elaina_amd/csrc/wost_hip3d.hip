@@ -126,137 +126,188 @@ __device__ __forceinline__ bool step3_a(const Walk3Params &P, Lane3 &L, Closest 
     return false;
 }
 
-// B: the star radius, the source and Neumann samples (their rays inline), the direction of the step.  true = no boundary
-// at all (the walk ends); else the walker's ray starts at `cur` along `dir` and is at most R_B long.
+// B: the star radius, the source and Neumann samples, the direction of the step -- in three parts around the two rays those
+// samples ask for (the source sample's line to the boundary, the boundary sample's shadow ray), so that the kernel can answer
+// them by the wave like the walker's own ray (step3_b answers them on the spot).  The draws of a lane keep their order.
+struct Step3B {
+    float R_B;
+    V3 sdir;                 // source sample: direction, its density, the boundary factor
+    float dir_pdf, salpha;
+    int oi;                  // boundary sample: triangle, density, the point, its distance, the shadow ray (o, rd, cd)
+    float pdf, r, cd;
+    V3 sp, o, rd;
+};
+
+// B0: the radius; the direction of the source sample.  true = no boundary at all (the walk ends)
+template <bool SOURCE>
+__device__ __forceinline__ bool step3_b0(const Walk3Params &P, Lane3 &L, float R_D, float R_N, Step3B &B)
+{
+    float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
+    R_B *= WOST_R_B_SHRINK;
+    B.R_B = R_B;
+    if (isinf(R_B)) return true;
+    // ---- sampleSource (reference integrator/uniform/integrator.cu:235-316, DIM == 3) ----
+    if (SOURCE) {
+        B.salpha = 1.0f;
+        const float u1 = pcg_next_float(L.rng), u2 = pcg_next_float(L.rng);
+        float c, s;
+        sincos_2pi(u2, c, s);
+        if (L.on_n) {
+            const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+            B.sdir = frame_to_world(L.nn, r * c, r * s, z);
+            B.dir_pdf = 1.0f / WOST_2PI;
+            B.salpha = 0.5f;
+        } else {
+            const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
+            B.sdir = v3(r * c, r * s, z);
+            B.dir_pdf = 1.0f / WOST_4PI;
+        }
+    }
+    return false;
+}
+// the source sample's line: from p + eps sdir along sdir, at most R_B long (asked for when the scene has a Neumann mesh)
+__device__ __forceinline__ V3 step3_source_origin(const Walk3Params &P, const Lane3 &L, const Step3B &B)
+{
+    const float eps = P.st.eps;
+    return v3(L.p.x + eps * B.sdir.x, L.p.y + eps * B.sdir.y, L.p.z + eps * B.sdir.z);
+}
+
+// B1: the source sample with its line answered (hit, t); the boundary sample.  true = the shadow ray (B.o, B.rd, B.cd - eps) is asked for
 template <bool EMISSIVE, bool SOURCE, bool NTREE>
-__device__ __forceinline__ bool step3_b(const Walk3Params &P, Lane3 &L, float R_D, float R_N, const LdsColumn &stk, float &R_B_out, V3 &dir_out, V3 &cur_out)
+__device__ __forceinline__ bool step3_b1(const Walk3Params &P, Lane3 &L, Step3B &B, bool src_hit, float src_t)
 {
     const bool has_n = P.nm.n_tris > 0;
-    const float eps = P.st.eps;
-    V3 &p = L.p;
-    float &thp = L.thp;
-    bool &on_n = L.on_n;
-    V3 &nn = L.nn;
+    const float eps = P.st.eps, R_B = B.R_B;
+    const V3 p = L.p;
+    const float thp = L.thp;
     float (&sol)[3] = L.sol;
     Pcg &rng = L.rng;
     PROF3_T0();
-            float R_B = fmaxf(WOST_R_B_FLOOR, fminf(R_D, R_N));
-            R_B *= WOST_R_B_SHRINK;
-            if (isinf(R_B)) return true;
-            // ---- sampleSource (reference integrator/uniform/integrator.cu:235-316, DIM == 3) ----
-            if (SOURCE) {
-                V3 sdir;
-                float dir_pdf, salpha = 1.0f;
-                {
-                    const float u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
-                    float c, s;
-                    sincos_2pi(u2, c, s);
-                    if (on_n) {
-                        const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
-                        sdir = frame_to_world(nn, r * c, r * s, z);
-                        dir_pdf = 1.0f / WOST_2PI;
-                        salpha = 0.5f;
-                    } else {
-                        const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
-                        sdir = v3(r * c, r * s, z);
-                        dir_pdf = 1.0f / WOST_4PI;
-                    }
-                }
-                // how far the straight line stays inside the star-shaped region (:279-292)
-                float dist = R_B;
-                if (has_n) {
-                    float t;
-                    int hi;
-                    if (ray_closest3<NTREE>(P.nm, v3(p.x + eps * sdir.x, p.y + eps * sdir.y, p.z + eps * sdir.z), sdir, dist, t, hi, stk)) dist = fminf(t, dist);
-                }
-                // HarmonicGreenBall<3>::sample (util/green.h:101-116): closed form, two draws
-                const float g1 = pcg_next_float(rng), g2 = pcg_next_float(rng);
-                float gc, gs;
-                sincos_2pi(g2, gc, gs);
-                float r = (1.0f + sqrtf(1.0f - cbrt01(g1 * g1)) * gc) * R_B / 2.0f;
-                r = fmaxf(1e-4f, r);                                            // ELAINA_GREEN_FUNC_R_CLAMP
-                if (r > R_B) r = R_B / 2.0f;
-                if (r <= dist) {
-                    float f[3];
-                    source3_eval(P.src, v3(p.x + r * sdir.x, p.y + r * sdir.y, p.z + r * sdir.z), f);
-                    const float norm = R_B * R_B / 6.0f;
-                    const float c1 = (1.0f / WOST_4PI) / (r * r), c2 = dir_pdf / (r * r);     // conditionalSampleSpherePDF<3>
+    if (SOURCE) {
+        // how far the straight line stays inside the star-shaped region (:279-292)
+        float dist = R_B;
+        if (has_n && src_hit) dist = fminf(src_t, dist);
+        const V3 sdir = B.sdir;
+        // HarmonicGreenBall<3>::sample (util/green.h:101-116): closed form, two draws
+        const float g1 = pcg_next_float(rng), g2 = pcg_next_float(rng);
+        float gc, gs;
+        sincos_2pi(g2, gc, gs);
+        float r = (1.0f + sqrtf(1.0f - cbrt01(g1 * g1)) * gc) * R_B / 2.0f;
+        r = fmaxf(1e-4f, r);                                            // ELAINA_GREEN_FUNC_R_CLAMP
+        if (r > R_B) r = R_B / 2.0f;
+        if (r <= dist) {
+            float f[3];
+            source3_eval(P.src, v3(p.x + r * sdir.x, p.y + r * sdir.y, p.z + r * sdir.z), f);
+            const float norm = R_B * R_B / 6.0f;
+            const float c1 = (1.0f / WOST_4PI) / (r * r), c2 = B.dir_pdf / (r * r);     // conditionalSampleSpherePDF<3>
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float col = thp * f[k] * norm * c1 / c2 / salpha;
-                        sol[k] = col + sol[k];
-                    }
+            for (int k = 0; k < 3; ++k) {
+                const float col = thp * f[k] * norm * c1 / c2 / B.salpha;
+                sol[k] = col + sol[k];
+            }
+        }
+    }
+    PROF3(1);
+    // ---- sampleNeumann: three draws whether or not the boundary emits ----
+    bool shadow = false;
+    if (has_n) {
+        const float u0 = pcg_next_float(rng), u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
+        if (EMISSIVE) {
+            float pdf;
+            const int oi = (NTREE && P.nm.obox_levels > 0) ? sample_in_sphere3_tree(P.nm, p, R_B, u0, pdf) : sample_in_sphere3_flat(P.nm, p, R_B, u0, pdf);
+            if (oi != -1 && pdf > 0) {
+                const DevTri &S = P.nm.flat[oi];
+                const V3 s0 = ld3(S.p0), s1 = ld3(S.p1), s2 = ld3(S.p2);
+                const float su = sqrtf(u1), b1 = u2 * su, b0 = 1.0f - su, b2 = 1.0f - b0 - b1;
+                const V3 sp = v3((s0.x * b0 + s1.x * b1) + s2.x * b2, (s0.y * b0 + s1.y * b1) + s2.y * b2,
+                                 (s0.z * b0 + s1.z * b1) + s2.z * b2);
+                const V3 rv = sp - p;
+                const float r = sqrtf(dot3(rv, rv));
+                if (r < R_B && r > 0) {
+                    V3 o = p;
+                    if (L.on_n) o = v3(p.x + eps * L.nn.x, p.y + eps * L.nn.y, p.z + eps * L.nn.z);
+                    V3 rd = sp - o;
+                    const float cd = sqrtf(dot3(rd, rd));
+                    if (cd > 0) { rd.x /= cd; rd.y /= cd; rd.z /= cd; }
+                    B.oi = oi; B.pdf = pdf; B.r = r; B.cd = cd; B.sp = sp; B.o = o; B.rd = rd;
+                    shadow = true;
                 }
             }
-            PROF3(1);
-            // ---- sampleNeumann: three draws whether or not the boundary emits ----
-            if (has_n) {
-                const float u0 = pcg_next_float(rng), u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
-                if (EMISSIVE) {
-                    float pdf;
-                    const int oi = (NTREE && P.nm.obox_levels > 0) ? sample_in_sphere3_tree(P.nm, p, R_B, u0, pdf) : sample_in_sphere3_flat(P.nm, p, R_B, u0, pdf);
-                    if (oi != -1 && pdf > 0) {
-                        const DevTri S = P.nm.flat[oi];
-                        const V3 s0 = ld3(S.p0), s1 = ld3(S.p1), s2 = ld3(S.p2);
-                        const float su = sqrtf(u1), b1 = u2 * su, b0 = 1.0f - su, b2 = 1.0f - b0 - b1;
-                        const V3 sp = v3((s0.x * b0 + s1.x * b1) + s2.x * b2, (s0.y * b0 + s1.y * b1) + s2.y * b2,
-                                         (s0.z * b0 + s1.z * b1) + s2.z * b2);
-                        const V3 rv = sp - p;
-                        const float r = sqrtf(dot3(rv, rv));
-                        if (r < R_B && r > 0) {
-                            V3 o = p;
-                            if (on_n) o = v3(p.x + eps * nn.x, p.y + eps * nn.y, p.z + eps * nn.z);
-                            V3 rd = sp - o;
-                            const float cd = sqrtf(dot3(rd, rd));
-                            if (cd > 0) { rd.x /= cd; rd.y /= cd; rd.z /= cd; }
-                            if (!ray_any3<NTREE>(P.nm, o, rd, cd - eps, stk)) {
-                                int side = tri_side(s0, ld3(S.nraw), p);
-                                float uu, vv;
-                                tri_uv(s0, s1 - s0, s2 - s0, sp, uu, vv);
-                                if (on_n) {
-                                    const float dn = dot3(ld3(S.n), nn);
-                                    side = (0.0f < dn) - (dn < 0.0f);
-                                }
-                                if (side != 0) {
-                                    float col[3];
-                                    const int32_t *tv = P.nm.flatVerts + 3 * (size_t)oi;
-                                    surface_color3(P.nm.colors, tv[0], tv[1], tv[2], side, uu, vv, col);
-                                    const float alpha = on_n ? 0.5f : 1.0f;
-                                    const float G = (1.0f / r - 1.0f / R_B) / WOST_4PI;
+        }
+    }
+    return shadow;
+}
+
+// B2: the boundary sample when its shadow ray found nothing (`lit`); the direction of the step.  The walker's ray starts at
+// `cur` along `dir` and is at most B.R_B long.
+template <bool EMISSIVE>
+__device__ __forceinline__ void step3_b2(const Walk3Params &P, Lane3 &L, const Step3B &B, bool lit, V3 &dir_out, V3 &cur_out)
+{
+    const float eps = P.st.eps;
+    const V3 p = L.p;
+    const bool on_n = L.on_n;
+    const V3 nn = L.nn;
+    float (&sol)[3] = L.sol;
+    PROF3_T0();
+    if (EMISSIVE && lit) {
+        const DevTri &S = P.nm.flat[B.oi];
+        const V3 s0 = ld3(S.p0), s1 = ld3(S.p1), s2 = ld3(S.p2);
+        int side = tri_side(s0, ld3(S.nraw), p);
+        float uu, vv;
+        tri_uv(s0, s1 - s0, s2 - s0, B.sp, uu, vv);
+        if (on_n) {
+            const float dn = dot3(ld3(S.n), nn);
+            side = (0.0f < dn) - (dn < 0.0f);
+        }
+        if (side != 0) {
+            float col[3];
+            const int32_t *tv = P.nm.flatVerts + 3 * (size_t)B.oi;
+            surface_color3(P.nm.colors, tv[0], tv[1], tv[2], side, uu, vv, col);
+            const float alpha = on_n ? 0.5f : 1.0f;
+            const float G = (1.0f / B.r - 1.0f / B.R_B) / WOST_4PI;
 #pragma unroll
-                                    for (int k = 0; k < 3; ++k) {
-                                        col[k] *= P.st.neumann_intensity;
-                                        col[k] *= thp * G / alpha / pdf;
-                                        sol[k] = -col[k] + sol[k];
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
+            for (int k = 0; k < 3; ++k) {
+                col[k] *= P.st.neumann_intensity;
+                col[k] *= L.thp * G / alpha / B.pdf;
+                sol[k] = -col[k] + sol[k];
             }
-            PROF3(2);
-            // ---- oneStepWalk ----
-            V3 dir, cur = p;
-            float pdf, alpha = 1.0f;
-            {
-                const float u1 = pcg_next_float(rng), u2 = pcg_next_float(rng);
-                float c, s;
-                sincos_2pi(u2, c, s);
-                if (on_n) {
-                    const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
-                    dir = frame_to_world(nn, r * c, r * s, z);
-                    pdf = 1.0f / WOST_2PI;
-                    alpha = 0.5f;
-                    cur = v3(p.x + eps * nn.x, p.y + eps * nn.y, p.z + eps * nn.z);
-                } else {
-                    const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
-                    dir = v3(r * c, r * s, z);
-                    pdf = 1.0f / WOST_4PI;
-                }
-            }
-    (void)pdf; (void)alpha;
-    R_B_out = R_B; dir_out = dir; cur_out = cur;
+        }
+    }
+    PROF3(2);
+    // ---- oneStepWalk ----
+    V3 dir, cur = p;
+    {
+        const float u1 = pcg_next_float(L.rng), u2 = pcg_next_float(L.rng);
+        float c, s;
+        sincos_2pi(u2, c, s);
+        if (on_n) {
+            const float z = u1, r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+            dir = frame_to_world(nn, r * c, r * s, z);
+            cur = v3(p.x + eps * nn.x, p.y + eps * nn.y, p.z + eps * nn.z);
+        } else {
+            const float z = 1 - 2 * u1, r = sqrtf(1 - z * z);
+            dir = v3(r * c, r * s, z);
+        }
+    }
+    dir_out = dir; cur_out = cur;
+}
+
+// B with both rays answered by the lane itself.  true = no boundary at all (the walk ends)
+template <bool EMISSIVE, bool SOURCE, bool NTREE>
+__device__ __forceinline__ bool step3_b(const Walk3Params &P, Lane3 &L, float R_D, float R_N, const LdsColumn &stk, float &R_B_out, V3 &dir_out, V3 &cur_out)
+{
+    Step3B B;
+    if (step3_b0<SOURCE>(P, L, R_D, R_N, B)) return true;
+    bool src_hit = false;
+    float src_t = 0.0f;
+    if (SOURCE && P.nm.n_tris > 0) {
+        int hi;
+        src_hit = ray_closest3<NTREE>(P.nm, step3_source_origin(P, L, B), B.sdir, B.R_B, src_t, hi, stk);
+    }
+    bool lit = step3_b1<EMISSIVE, SOURCE, NTREE>(P, L, B, src_hit, src_t);
+    if (EMISSIVE && lit) lit = !ray_any3<NTREE>(P.nm, B.o, B.rd, B.cd - P.st.eps, stk);
+    step3_b2<EMISSIVE>(P, L, B, lit, dir_out, cur_out);
+    R_B_out = B.R_B;
     return false;
 }
 
@@ -486,7 +537,33 @@ __global__ __launch_bounds__(kWalk3Threads, WOST3_WAVES) void walk3_kernel(Walk3
                     mid = !ended;
                 }
                 const float R_N = closest_silhouette3_wave(P.nm, L.p, R_D, mid, W, stk);
-                if (mid) {
+                // part B around the rays of its samples, those answered by the wave as well (a lane's shadow ray through a tree
+                // of its own was the longest wait of an emissive step)
+                if ((EMISSIVE || SOURCE) && P.coop > 1) {
+                    Step3B B;
+                    B.sdir = B.o = B.rd = v3(0.0f, 0.0f, 0.0f);
+                    B.R_B = B.cd = 0.0f;
+                    if (mid) {
+                        ended = step3_b0<SOURCE>(P, L, R_D, R_N, B);
+                        go = !ended;
+                    }
+                    bool src_hit = false, lit = false;
+                    float src_t = 0.0f;
+                    if (SOURCE) {
+                        int shi;
+                        src_hit = ray_closest3_wave(P.nm, step3_source_origin(P, L, B), B.sdir, B.R_B, go, src_t, shi, W, stk, P.ray_slot_trigger);
+                    }
+                    if (go) lit = step3_b1<EMISSIVE, SOURCE, NTREE>(P, L, B, src_hit, src_t);
+                    if (EMISSIVE) {
+                        float st;
+                        int shi;
+                        const bool occluded = ray_closest3_wave(P.nm, B.o, B.rd, B.cd - P.st.eps, lit, st, shi, W, stk, P.ray_slot_trigger);
+                        lit = lit && !occluded;
+                    }
+                    if (go) step3_b2<EMISSIVE>(P, L, B, lit, dir, cur);
+                    R_B = B.R_B;
+                } else if (mid) {
+                    // (WOST3_COOP=1: the rays of the samples by the lane itself, as in rounds 3)
                     ended = step3_b<EMISSIVE, SOURCE, NTREE>(P, L, R_D, R_N, stk, R_B, dir, cur);
                     go = !ended;
                 }
@@ -620,339 +697,9 @@ __global__ __launch_bounds__(256) void ray3_kernel(DevMesh3 m, const float *o, c
     out_idx[i] = idx;
 }
 
-// ---- host: LBVH over triangles ----------------------------------------------------------------------
-
-static inline uint32_t part1by2(uint32_t x)
-{
-    x &= 0x3ff;
-    x = (x | (x << 16)) & 0x030000FF;
-    x = (x | (x << 8)) & 0x0300F00F;
-    x = (x | (x << 4)) & 0x030C30C3;
-    x = (x | (x << 2)) & 0x09249249;
-    return x;
-}
-static inline float hdot3(const float *a, const float *b) { return std::fmaf(a[0], b[0], std::fmaf(a[1], b[1], a[2] * b[2])); }
-
-// returns 0, or -1 on an index out of range
-static int build_mesh3(const wost3_mesh_desc &d, HostMesh3 *out)
-{
-    HostMesh3 &h = *out;
-    h = HostMesh3();
-    h.n_tris = d.n_tris;
-    if (d.n_tris <= 0) return 0;
-    if (!d.verts || !d.tris || d.n_verts <= 0) return -1;
-    const int n = d.n_tris;
-    h.flat.resize(n);
-    std::vector<float> cen((size_t)n * 3);
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int t = 0; t < n; ++t) {
-        const int32_t *iv = d.tris + 3 * (size_t)t;
-        for (int k = 0; k < 3; ++k)
-            if (iv[k] < 0 || iv[k] >= d.n_verts) return -1;
-        DevTri &T = h.flat[t];
-        for (int c = 0; c < 3; ++c) {
-            T.p0[c] = d.verts[3 * (size_t)iv[0] + c]; T.p1[c] = d.verts[3 * (size_t)iv[1] + c]; T.p2[c] = d.verts[3 * (size_t)iv[2] + c];
-            lo[c] = std::min(lo[c], std::min(T.p0[c], std::min(T.p1[c], T.p2[c])));
-            hi[c] = std::max(hi[c], std::max(T.p0[c], std::max(T.p1[c], T.p2[c])));
-            cen[3 * (size_t)t + c] = (float)(((double)T.p0[c] + T.p1[c] + T.p2[c]) / 3.0);
-        }
-        // e0, e1, nraw = cross3(e0, e1), unit normal, area: the triangle record of DESIGN.md 2.3
-        float e0[3], e1[3];
-        for (int c = 0; c < 3; ++c) { e0[c] = T.p1[c] - T.p0[c]; e1[c] = T.p2[c] - T.p0[c]; }
-        T.nraw[0] = std::fmaf(e0[1], e1[2], -(e0[2] * e1[1]));
-        T.nraw[1] = std::fmaf(e0[2], e1[0], -(e0[0] * e1[2]));
-        T.nraw[2] = std::fmaf(e0[0], e1[1], -(e0[1] * e1[0]));
-        const float l = std::sqrt(hdot3(T.nraw, T.nraw));
-        T.area = 0.5f * l;
-        for (int c = 0; c < 3; ++c) T.n[c] = l > 0.0f ? T.nraw[c] / l : 0.0f;
-    }
-    if (d.colors) {
-        h.colors.assign(d.colors, d.colors + (size_t)d.n_verts * 6);
-        for (float c : h.colors)
-            if (c != 0.0f) h.emissive = true;
-    }
-    // edges: the first two incident triangles in index order, direction of the first
-    std::vector<int32_t> edge_of;
-    {
-        struct Key { int a, b, t, k; };
-        std::vector<Key> keys;
-        keys.reserve((size_t)n * 3);
-        for (int t = 0; t < n; ++t)
-            for (int k = 0; k < 3; ++k) {
-                const int a = d.tris[3 * (size_t)t + k], b = d.tris[3 * (size_t)t + (k + 1) % 3];
-                keys.push_back(Key{std::min(a, b), std::max(a, b), t, k});
-            }
-        std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) {
-            if (x.a != y.a) return x.a < y.a;
-            if (x.b != y.b) return x.b < y.b;
-            return x.t < y.t;
-        });
-        edge_of.assign((size_t)n * 3, -1);        // the edge record of side k of triangle t
-        for (size_t i = 0; i < keys.size();) {
-            size_t j = i;
-            while (j < keys.size() && keys[j].a == keys[i].a && keys[j].b == keys[i].b) ++j;
-            const int t0 = keys[i].t, k0 = keys[i].k;
-            const int a = d.tris[3 * (size_t)t0 + k0], b = d.tris[3 * (size_t)t0 + (k0 + 1) % 3];
-            if (a != b) {
-                DevEdge3 E{};
-                for (int c = 0; c < 3; ++c) { E.pa[c] = d.verts[3 * (size_t)a + c]; E.pb[c] = d.verts[3 * (size_t)b + c]; }
-                E.t0 = t0;
-                E.t1 = (j - i >= 2) ? keys[i + 1].t : -1;
-                for (size_t q = i; q < j; ++q) edge_of[3 * (size_t)keys[q].t + keys[q].k] = (int32_t)h.edges.size();
-                h.edges.push_back(E);
-            }
-            i = j;
-        }
-        h.n_edges = (int32_t)h.edges.size();
-    }
-    h.flatVerts.assign(d.tris, d.tris + (size_t)n * 3);
-    // Morton order of the centroids, leaves of 4, implicit complete 4-ary tree (lbvh.h in 3-D)
-    std::vector<int32_t> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    {
-        std::vector<uint32_t> code(n);
-        for (int t = 0; t < n; ++t) {
-            uint32_t q[3];
-            for (int c = 0; c < 3; ++c) {
-                const double s = hi[c] > lo[c] ? 1023.0 / ((double)hi[c] - lo[c]) : 0.0;
-                q[c] = (uint32_t)std::min(1023.0, std::max(0.0, ((double)cen[3 * (size_t)t + c] - lo[c]) * s));
-            }
-            code[t] = part1by2(q[0]) | (part1by2(q[1]) << 1) | (part1by2(q[2]) << 2);
-        }
-        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return code[a] < code[b]; });
-    }
-    const int n_leaves = (n + 3) / 4;
-    int levels = 1, cap = 4;
-    while (cap < n_leaves) { cap *= 4; ++levels; }
-    h.levels = levels;
-    h.first_leaf = (cap - 1) / 3;
-    const size_t n_slots = (size_t)cap * 4;
-    h.tri.assign(n_slots * 12, 1.0e18f);
-    h.triOrig.assign(n_slots, kFarIndex);
-    h.triVerts.assign(n_slots * 3, 0);
-    std::vector<char> edge_listed(h.edges.size(), 0);
-    h.slotEdges.assign(n_slots * 3 * 16, 0.0f);
-    for (int k = 0; k < n; ++k) {
-        const int o = order[k];
-        for (int c = 0; c < 3; ++c) {
-            const int32_t e = edge_of[3 * (size_t)o + c];
-            if (e >= 0 && !edge_listed[e]) {
-                edge_listed[e] = 1;
-                const DevEdge3 &E = h.edges[e];
-                float *r = &h.slotEdges[(3 * (size_t)k + c) * 16];
-                for (int x = 0; x < 3; ++x) {
-                    r[x] = E.pa[x]; r[4 + x] = E.pb[x];
-                    r[8 + x] = h.flat[E.t0].n[x];
-                    r[12 + x] = E.t1 >= 0 ? h.flat[E.t1].n[x] : 0.0f;
-                }
-                r[3] = E.t1 >= 0 ? 1.0f : 2.0f;
-            }
-        }
-        const DevTri &T = h.flat[o];
-        float *r = &h.tri[(size_t)k * 12];
-        for (int c = 0; c < 3; ++c) { r[c] = T.p0[c]; r[4 + c] = T.p1[c]; r[8 + c] = T.p2[c]; }
-        r[3] = r[7] = r[11] = 0.0f;
-        h.triOrig[k] = o;
-        for (int c = 0; c < 3; ++c) h.triVerts[3 * (size_t)k + c] = d.tris[3 * (size_t)o + c];
-    }
-    // boxes bottom-up, padded (pruning slack)
-    float ext = 0.0f;
-    for (int c = 0; c < 3; ++c) ext = std::max(ext, std::max(std::fabs(lo[c]), std::fabs(hi[c])));
-    const float pad = ext * 0x1p-18f + 1e-30f;
-    h.ext = ext;
-    const int n_nodes = h.first_leaf + cap;
-    std::vector<float> nb((size_t)n_nodes * 6);
-    std::vector<char> empty(n_nodes, 1);
-    for (int g = 0; g < n_nodes; ++g)
-        for (int c = 0; c < 3; ++c) { nb[6 * (size_t)g + c] = INFINITY; nb[6 * (size_t)g + 3 + c] = -INFINITY; }
-    for (int k = 0; k < n; ++k) {
-        const int g = h.first_leaf + k / 4;
-        const DevTri &T = h.flat[order[k]];
-        for (int c = 0; c < 3; ++c) {
-            nb[6 * (size_t)g + c] = std::min(nb[6 * (size_t)g + c], std::min(T.p0[c], std::min(T.p1[c], T.p2[c])));
-            nb[6 * (size_t)g + 3 + c] = std::max(nb[6 * (size_t)g + 3 + c], std::max(T.p0[c], std::max(T.p1[c], T.p2[c])));
-        }
-        empty[g] = 0;
-    }
-    for (int g = h.first_leaf - 1; g >= 0; --g)
-        for (int j = 1; j <= 4; ++j) {
-            const int c4 = 4 * g + j;
-            if (empty[c4]) continue;
-            for (int c = 0; c < 3; ++c) {
-                nb[6 * (size_t)g + c] = std::min(nb[6 * (size_t)g + c], nb[6 * (size_t)c4 + c]);
-                nb[6 * (size_t)g + 3 + c] = std::max(nb[6 * (size_t)g + 3 + c], nb[6 * (size_t)c4 + 3 + c]);
-            }
-            empty[g] = 0;
-        }
-    if (h.emissive && n > WOST3_FLAT_MAX) {
-        size_t prev_off = 0, prev_n = 0;
-        for (int l = 0; l < 12; ++l) {
-            const size_t run = (size_t)4 << (2 * l), n_runs = ((size_t)n + run - 1) / run;
-            h.obox_off[l] = (int32_t)(h.obox.size() / 8);
-            for (size_t r = 0; r < n_runs; ++r) {
-                float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-                if (l == 0) {
-                    for (size_t i = r * 4; i < std::min<size_t>(r * 4 + 4, (size_t)n); ++i)
-                        for (int c = 0; c < 3; ++c) {
-                            const DevTri &T = h.flat[i];
-                            blo[c] = std::min(blo[c], std::min(T.p0[c], std::min(T.p1[c], T.p2[c])));
-                            bhi[c] = std::max(bhi[c], std::max(T.p0[c], std::max(T.p1[c], T.p2[c])));
-                        }
-                    for (int c = 0; c < 3; ++c) { blo[c] -= pad; bhi[c] += pad; }
-                } else {
-                    for (size_t c4 = r * 4; c4 < std::min(r * 4 + 4, prev_n); ++c4)
-                        for (int c = 0; c < 3; ++c) {
-                            blo[c] = std::min(blo[c], h.obox[(prev_off + c4) * 8 + c]);
-                            bhi[c] = std::max(bhi[c], h.obox[(prev_off + c4) * 8 + 4 + c]);
-                        }
-                }
-                h.obox.insert(h.obox.end(), {blo[0], blo[1], blo[2], 0.0f, bhi[0], bhi[1], bhi[2], 0.0f});
-            }
-            prev_off = (size_t)h.obox_off[l];
-            prev_n = n_runs;
-            h.obox_levels = l + 1;
-            if (n_runs <= 1) break;
-        }
-    }
-    // inner nodes (levels 0 .. levels-1) store the boxes of their four children; a leaf (level == levels) stores the
-    // boxes of its four triangles
-    h.nodes.assign((size_t)n_nodes * 24, 0.0f);
-    for (int g = h.first_leaf; g < n_nodes; ++g) {
-        float *nd = &h.nodes[(size_t)g * 24];
-        for (int j = 0; j < 4; ++j) {
-            const int k = 4 * (g - h.first_leaf) + j;
-            for (int c = 0; c < 3; ++c) {
-                if (k < n) {
-                    const DevTri &T = h.flat[order[k]];
-                    nd[4 * c + j] = std::min(T.p0[c], std::min(T.p1[c], T.p2[c])) - pad;
-                    nd[12 + 4 * c + j] = std::max(T.p0[c], std::max(T.p1[c], T.p2[c])) + pad;
-                } else {
-                    nd[4 * c + j] = nd[12 + 4 * c + j] = 1.0e18f;
-                }
-            }
-        }
-    }
-    for (int g = 0; g < h.first_leaf; ++g)
-        for (int j = 0; j < 4; ++j) {
-            const int c4 = 4 * g + 1 + j;
-            float *nd = &h.nodes[(size_t)g * 24];
-            for (int c = 0; c < 3; ++c) {
-                nd[4 * c + j] = empty[c4] ? 1.0e18f : nb[6 * (size_t)c4 + c] - pad;
-                nd[12 + 4 * c + j] = empty[c4] ? 1.0e18f : nb[6 * (size_t)c4 + 3 + c] + pad;
-            }
-        }
-    // normal cones of the children of every inner node (cone3_may_hold_silhouette): the normals of both triangles of
-    // every edge of the subtree's triangles, the end points of those edges; a boundary edge is always a silhouette
-    {
-        struct Acc { std::vector<double> nrm, pts; bool open = false; };
-        std::vector<Acc> acc(n_nodes);
-        for (int k = 0; k < n; ++k) {
-            Acc &a = acc[h.first_leaf + k / 4];
-            const int o = order[k];
-            for (int c = 0; c < 3; ++c) {
-                const int32_t e = edge_of[3 * (size_t)o + c];
-                if (e < 0) continue;
-                const DevEdge3 &E = h.edges[e];
-                if (E.t1 < 0) a.open = true;
-                for (int t : {E.t0, E.t1}) {
-                    if (t < 0) continue;
-                    const DevTri &T = h.flat[t];
-                    if (hdot3(T.n, T.n) > 0.0f) a.nrm.insert(a.nrm.end(), {T.n[0], T.n[1], T.n[2]});
-                }
-                a.pts.insert(a.pts.end(), {E.pa[0], E.pa[1], E.pa[2], E.pb[0], E.pb[1], E.pb[2]});
-            }
-        }
-        for (int g = h.first_leaf - 1; g >= 1; --g)
-            for (int j = 1; j <= 4; ++j) {
-                const Acc &c = acc[4 * g + j];
-                acc[g].nrm.insert(acc[g].nrm.end(), c.nrm.begin(), c.nrm.end());
-                acc[g].pts.insert(acc[g].pts.end(), c.pts.begin(), c.pts.end());
-                acc[g].open = acc[g].open || c.open;
-            }
-        h.cones.assign((size_t)n_nodes * 24, 0.0f);
-        for (int g = 0; g < h.first_leaf; ++g)
-            for (int j = 0; j < 4; ++j) {
-                const Acc &a = acc[4 * g + 1 + j];
-                const float *nd = &h.nodes[(size_t)g * 24];
-                float *cn = &h.cones[(size_t)g * 24];
-                cn[12 + j] = -1.0f;                                             // cannot prune
-                cn[0 + j] = 1.0f;
-                if (a.open || a.nrm.empty()) continue;
-                double ax[3] = {0.0, 0.0, 0.0};
-                for (size_t i = 0; i < a.nrm.size(); i += 3)
-                    for (int c = 0; c < 3; ++c) ax[c] += a.nrm[i + c];
-                const double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-                if (!(al > 1e-9 * (double)(a.nrm.size() / 3))) continue;
-                for (int c = 0; c < 3; ++c) ax[c] /= al;
-                double cmin = 1.0;
-                for (size_t i = 0; i < a.nrm.size(); i += 3) {
-                    const double l = std::sqrt(a.nrm[i] * a.nrm[i] + a.nrm[i + 1] * a.nrm[i + 1] + a.nrm[i + 2] * a.nrm[i + 2]);
-                    cmin = std::min(cmin, (ax[0] * a.nrm[i] + ax[1] * a.nrm[i + 1] + ax[2] * a.nrm[i + 2]) / l);
-                }
-                const double half = std::acos(std::max(-1.0, std::min(1.0, cmin))) + 1e-4;
-                if (half >= 0.5 * M_PI - 1e-3) continue;
-                // the centre the kernel uses: the middle of the child's box, in the kernel's float arithmetic
-                float cf[3];
-                for (int c = 0; c < 3; ++c) cf[c] = 0.5f * (nd[4 * c + j] + nd[12 + 4 * c + j]);
-                double rad = 0.0;
-                for (size_t i = 0; i < a.pts.size(); i += 3)
-                    rad = std::max(rad, std::sqrt((a.pts[i] - cf[0]) * (a.pts[i] - cf[0]) + (a.pts[i + 1] - cf[1]) * (a.pts[i + 1] - cf[1]) +
-                                                  (a.pts[i + 2] - cf[2]) * (a.pts[i + 2] - cf[2])));
-                cn[0 + j] = (float)ax[0]; cn[4 + j] = (float)ax[1]; cn[8 + j] = (float)ax[2];
-                cn[12 + j] = (float)std::cos(half); cn[16 + j] = (float)std::sin(half);
-                cn[20 + j] = (float)(rad * (1.0 + 1e-6) + (double)pad + 2.0 * (double)WOST_SIL_PRECISION);
-            }
-    }
-    return 0;
-}
-
 }  // namespace wost
 
 using namespace wost;
-
-static int upload_mesh3(const wost3_mesh_desc &d, DeviceMesh3 &s)
-{
-    if (d.n_tris < 0 || d.n_verts < 0) return set_error(WOST_ERR_INVALID, "negative mesh size");
-    if (build_mesh3(d, &s.host) != 0) return set_error(WOST_ERR_INVALID, "mesh: triangle index out of range or null arrays");
-    const HostMesh3 &h = s.host;
-    DevMesh3 &v = s.view;
-    v = DevMesh3{};
-    v.n_tris = h.n_tris;
-    if (h.n_tris == 0) return WOST_OK;
-    v.n_edges = h.n_edges; v.levels = h.levels; v.first_leaf = h.first_leaf; v.emissive = h.emissive ? 1 : 0;
-    v.huge2 = 4096.0f * h.ext * h.ext;        // 64 extents
-    W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.nodes.data()), h.nodes.size() / 4, &v.nodes));
-    W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.tri.data()), h.tri.size() / 4, &v.tri));
-    W3_TRY(upload3(s.allocs, h.triOrig.data(), h.triOrig.size(), &v.triOrig));
-    {
-        std::vector<int32_t> inv((size_t)std::max(h.n_tris, 1), 0);
-        for (size_t k = 0; k < h.triOrig.size(); ++k)
-            if (h.triOrig[k] != kFarIndex) inv[(size_t)h.triOrig[k]] = (int32_t)k;
-        W3_TRY(upload3(s.allocs, inv.data(), inv.size(), &v.slotOfOrig));
-    }
-    W3_TRY(upload3(s.allocs, h.triVerts.data(), h.triVerts.size(), &v.triVerts));
-    W3_TRY(upload3(s.allocs, h.colors.data(), h.colors.size(), &v.colors));
-    W3_TRY(upload3(s.allocs, h.flat.data(), h.flat.size(), &v.flat));
-    W3_TRY(upload3(s.allocs, h.edges.data(), h.edges.size(), &v.edges));
-    W3_TRY(upload3(s.allocs, h.flatVerts.data(), h.flatVerts.size(), &v.flatVerts));
-    W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.cones.data()), h.cones.size() / 4, &v.cones));
-    W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.slotEdges.data()), h.slotEdges.size() / 4, &v.slotEdges));
-    W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(h.obox.data()), h.obox.size() / 4, &v.obox));
-    if (!h.obox.empty()) {
-        const size_t n4 = (h.flat.size() + 3) / 4 * 4;
-        std::vector<float> areas(n4, 0.0f), tri(n4 * 12, 1.0e18f);
-        for (size_t i = 0; i < h.flat.size(); ++i) {
-            const DevTri &T = h.flat[i];
-            areas[i] = T.area;
-            for (int c = 0; c < 3; ++c) { tri[12 * i + c] = T.p0[c]; tri[12 * i + 4 + c] = T.p1[c]; tri[12 * i + 8 + c] = T.p2[c]; }
-        }
-        W3_TRY(upload3(s.allocs, areas.data(), areas.size(), &v.areas));
-        W3_TRY(upload3(s.allocs, reinterpret_cast<const float4 *>(tri.data()), n4 * 3, &v.sampTri));
-    }
-    for (int l = 0; l < 12; ++l) v.obox_off[l] = h.obox_off[l];
-    v.obox_levels = h.obox_levels;
-    return WOST_OK;
-}
 
 static void destroy3(wost3_context *c)
 {
@@ -1000,12 +747,12 @@ static int run_solve3(wost3_context *c, int32_t pixel_begin, int32_t pixel_end, 
         const bool ntree = c->nm.view.n_tris > WOST3_FLAT_MAX;
         // Neumann mesh on the tree: its silhouette and ray queries are answered by the wave as a whole, through task pools in LDS
         // behind the stack columns (developer knobs: WOST3_COOP=0 for the per-lane queries, WOST3_POOL_CAP, WOST3_RAY_TRIGGER)
-        P.coop = ntree ? 1 : 0;
+        P.coop = ntree ? 2 : 0;          // 2: the rays of the source and boundary samples through the pools as well (1: by the lane)
         P.pool_cap = 512;
         P.ray_slot_trigger = 32;
         P.cp_slot_trigger = 64;
         if (const char *w = std::getenv("WOST3_CP_TRIGGER")) P.cp_slot_trigger = std::min(64, std::max(1, std::atoi(w)));
-        if (const char *w = std::getenv("WOST3_COOP")) P.coop = (ntree && std::atoi(w) != 0) ? 1 : 0;
+        if (const char *w = std::getenv("WOST3_COOP")) P.coop = ntree ? std::max(0, std::min(2, std::atoi(w))) : 0;
         if (const char *w = std::getenv("WOST3_POOL_CAP")) P.pool_cap = std::min(4096, std::max(96, std::atoi(w)));     // (64 roots must fit)
         if (const char *w = std::getenv("WOST3_RAY_TRIGGER")) P.ray_slot_trigger = std::min(64, std::max(1, std::atoi(w)));
         if (c->nm.view.levels > 11) P.coop = 0;      // (node and slot indices of a task: 26 bits, 4^(levels + 1) slots)

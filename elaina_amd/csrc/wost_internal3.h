@@ -70,6 +70,8 @@ struct wost3_context {
     } while (0)
 
 namespace wost {
+// wost_build3.hip: the mesh of `d` built on the current device (records, Morton order, tree, cones) into s.view
+int upload_mesh3(const wost3_mesh_desc &d, DeviceMesh3 &s);
 // wost_vmm3.hip: dL/draw of the 3-D mixture loss for n training samples, all pointers on the device (rows of 41 floats)
 void launch_vmm3_loss_gradients(hipStream_t stream, const float *raw, const float *dir, const float *li, const float *dir_pdf,
                                 const unsigned char *on_neumann, const float *normal, int n, float loss_scale, float *dl_draw, float *likelihood);

@@ -29,6 +29,7 @@
 #include "wost_internal.h"
 #include "wost_math.h"
 #include "wost_net_device.h"
+#include "wost_vmm_device.h"
 
 namespace wost {
 
@@ -445,9 +446,27 @@ __device__ __forceinline__ void mfma_layer_h(const uint2 *wf, int lane, const h4
 // the reference's network shape only: 8 levels x 4 features -> 64 -> 64 -> 64 -> 48 (33 used with two inputs, 41 with three).
 // DIMS = 2: weights AND grid in LDS; DIMS = 3: the dense 3-D grid is far larger than LDS (a million entries) -- only the weight
 // fragments are staged, the eight corner gathers of a level go to L2.
-template <int DIMS>
+__device__ __forceinline__ _Float16 sat_h(float v);
+
+// LOSS = true (training forward of the guided solve, two inputs): the mixture's loss gradient (reference distribution.h:201-264 +
+// train.h:492-553, the arithmetic of vmm_loss_gradients_kernel) is taken right here instead of by a kernel of its own that reads the raw
+// outputs back.  Lane (i, g) of a unit holds the outputs of the lobes g and 4 + g of point i whole; lambda, the lobe densities of the
+// sample's direction and of its mirror image travel between the four lanes of a point by wave shuffles, every sum runs in lobe order as
+// in the one-thread-per-sample kernel -- the same numbers -- and what leaves the kernel is dL/dout as the backward kernel wants it:
+// f16 chain tiles, scaled and saturated like net_train_h_kernel does it itself (`dl_h`: [unit][3 tiles][64 lanes], 96 bytes per point
+// instead of 132 out + 132 back).
+struct LossArgs {
+    const float *dir, *li, *dir_pdf, *normal;
+    const uint8_t *on_neumann;
+    float scale;       // loss_scale / n
+    float dscale;      // the extra power-of-two scale of the f16 deltas (net_train_h_kernel)
+    uint2 *dl_h;
+};
+
+template <int DIMS, bool LOSS>
 __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayout L, const float *params, const uint2 *fragh, const float *xy, int n,
-                                                                       const uint32_t *n_dev, float *out, size_t out_ldp, size_t out_ldf, uint2 *enc_out)
+                                                                       const uint32_t *n_dev, float *out, size_t out_ldp, size_t out_ldf, uint2 *enc_out,
+                                                                       LossArgs la)
 {
     extern __shared__ uint2 lds_h[];
     __shared__ float s_scale[kNetMaxLevels];
@@ -507,16 +526,123 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
                                                          h4_t{(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f});
         }
         mfma_layer_h<4, 3>(w3, lane, b, acc);
+        if (!LOSS) {
 #pragma unroll
-        for (int u = 0; u < kHalfSub; ++u)
+            for (int u = 0; u < kHalfSub; ++u)
 #pragma unroll
-            for (int rt = 0; rt < 3; ++rt)
+                for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int o = 16 * rt + 4 * g + c;
-                    // the network's outputs are half-precision numbers in the reference
-                    if (valid[u] && o < L.n_out) out[(size_t)pt[u] * out_ldp + o * out_ldf] = (float)(_Float16)acc[u][rt][c];
+                    for (int c = 0; c < 4; ++c) {
+                        const int o = 16 * rt + 4 * g + c;
+                        // the network's outputs are half-precision numbers in the reference
+                        if (valid[u] && o < L.n_out) out[(size_t)pt[u] * out_ldp + o * out_ldf] = (float)(_Float16)acc[u][rt][c];
+                    }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kHalfSub; ++u) {
+                // ---- vmm_loss_gradients_kernel for point pt[u], its eight lobes on the four lanes (i, 0..3) ----
+                const float eps = 1e-5f;  // M_EPSILON
+                const int t = valid[u] ? pt[u] : 0;
+                const float wx = la.dir[2 * (size_t)t], wy = la.dir[2 * (size_t)t + 1];
+                const bool on_n = la.on_neumann && la.on_neumann[t] != 0;
+                float rx = 0.0f, ry = 0.0f;
+                if (on_n) {
+                    const float nx = la.normal[2 * (size_t)t], ny = la.normal[2 * (size_t)t + 1];
+                    const float dd = wx * nx + wy * ny;
+                    rx = wx - 2 * dd * nx;
+                    ry = wy - 2 * dd * ny;
                 }
+                // own lobes h = 0, 1 (lobe index g + 4 h): the raw outputs as the separate kernel reads them (f16 numbers)
+                float lam_o[2], kap_o[2], ox_o[2], oy_o[2], mux_o[2], muy_o[2], pk_o[2], pkr_o[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float r0 = (float)(_Float16)acc[u][h][0], r1 = (float)(_Float16)acc[u][h][1];
+                    lam_o[h] = det_expf(fmaxf(fminf(r0, 15.0f), -10.0f));
+                    kap_o[h] = det_expf(fmaxf(fminf(r1, 15.0f), -10.0f));
+                    ox_o[h] = (float)(_Float16)acc[u][h][2];
+                    oy_o[h] = (float)(_Float16)acc[u][h][3];
+                    const float z = ox_o[h] * ox_o[h] + oy_o[h] * oy_o[h], nn = sqrtf(z);
+                    mux_o[h] = z > 0.0f ? ox_o[h] / nn : ox_o[h];
+                    muy_o[h] = z > 0.0f ? oy_o[h] / nn : oy_o[h];
+                    const float lb = log_bessel(kap_o[h], 0);
+                    pk_o[h] = vm_eval_lb(kap_o[h], lb, wx * mux_o[h] + wy * muy_o[h]);
+                    pkr_o[h] = on_n ? vm_eval_lb(kap_o[h], lb, rx * mux_o[h] + ry * muy_o[h]) : 0.0f;
+                }
+                // all eight lobes' lambda, density and mirrored density in every lane of the point
+                float lambda[8], pk[8], pkr[8];
+#pragma unroll
+                for (int gp = 0; gp < 4; ++gp)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int src = i + 16 * gp, k = gp + 4 * h;
+                        lambda[k] = __shfl(lam_o[h], src);
+                        pk[k] = __shfl(pk_o[h], src);
+                        pkr[k] = __shfl(pkr_o[h], src);
+                    }
+                float total = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) total += lambda[k];
+                float probability = 0.0f;
+#pragma unroll
+                for (int sg = 0; sg < 8; ++sg) {
+                    const float w = lambda[sg] / total;
+                    probability += w * pk[sg];
+                    if (on_n) probability += w * pkr[sg];
+                }
+                const float Li = la.li[t];
+                const float dirPdf = la.dir_pdf[t] + eps;
+                const float guidePdf = probability + eps;
+                const float prefix = -Li / dirPdf / guidePdf * la.scale;
+                float gr[3][4];
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gr[tt][c] = 0.0f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int sg = g + 4 * h;
+                    const float w = lambda[sg] / total;
+                    const float vm = pk[sg], vmr = pkr[sg];
+                    float dF_dlambda = (vm + vmr) * (total - lambda[sg]) / (total * total);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (k == sg) continue;
+                        const float wk = lambda[k] / total;
+                        dF_dlambda -= wk / total * pk[k];
+                        if (on_n) dF_dlambda -= wk / total * pkr[k];
+                    }
+                    float dF_dkappa = w * (vm * vm_dlog_dkappa(kap_o[h], wx * mux_o[h] + wy * muy_o[h]));
+                    if (on_n) dF_dkappa += w * (vmr * vm_dlog_dkappa(kap_o[h], rx * mux_o[h] + ry * muy_o[h]));
+                    const float n2 = ox_o[h] * ox_o[h] + oy_o[h] * oy_o[h];
+                    float denom = n2 * sqrtf(n2);
+                    if (denom < eps) denom = eps;
+                    float dF_dx = w * vm * kap_o[h] * oy_o[h] * (-ox_o[h] * wy + oy_o[h] * wx) / denom;
+                    if (on_n) dF_dx += w * vmr * kap_o[h] * oy_o[h] * (-ox_o[h] * ry + oy_o[h] * rx) / denom;
+                    float dF_dy = w * vm * kap_o[h] * ox_o[h] * (ox_o[h] * wy - oy_o[h] * wx) / denom;
+                    if (on_n) dF_dy += w * vmr * kap_o[h] * ox_o[h] * (ox_o[h] * ry - oy_o[h] * rx) / denom;
+                    gr[h][0] = prefix * dF_dlambda * lambda[sg];
+                    gr[h][1] = prefix * dF_dkappa * kap_o[h];
+                    gr[h][2] = prefix * dF_dx;
+                    gr[h][3] = prefix * dF_dy;
+                }
+                if (g == 0) {
+                    const float uni = on_n ? (float)(1.0 / VM_PI_D) : 1.0f / VM_2PI;
+                    const float sgm = 1.0f / (1.0f + det_expf(-(float)(_Float16)acc[u][2][0]));
+                    gr[2][0] = la.scale * (-0.2f) * Li * (guidePdf - uni) / (dirPdf * dirPdf) * (sgm * (1 - sgm));
+                }
+                // the deltas as net_train_h_kernel takes them: scaled, saturated, f16; zero for the points beyond n
+                const size_t unit = (size_t)(tile * kHalfSub + u);
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt) {
+                    union { h4_t h; uint2 v; } d;
+                    float v4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v4[c] = valid[u] ? gr[tt][c] * la.dscale : 0.0f;
+                    d.h = h4_t{sat_h(v4[0]), sat_h(v4[1]), sat_h(v4[2]), sat_h(v4[3])};
+                    la.dl_h[(unit * 3 + tt) * 64 + lane] = d.v;
+                }
+            }
+        }
     }
 }
 
@@ -1328,6 +1454,7 @@ struct wost_net {
     uint2 *params_h = nullptr, *params_hb = nullptr;   // f16 fragments of the training weights and of their transposes
     float *train_partial = nullptr;                    // per-block sums of the matrix gradients (net_train_h_kernel), 256 rows
     bool fused_backward = true;      // net_backward_wgrad_kernel (WOST_NET_FUSED=0: backward and weight gradients apart)
+    bool dl_is_half = false;         // the training forward has left dL/dout as f16 chain tiles in d_dl (net_forward_loss_dev)
     int step = 0;
     uint64_t n_launches = 0;           // kernels and fills issued by the *_dev entry points (wost_guided_stats.kernel_launches)
     uint32_t *param_steps = nullptr;   // Adam steps taken by each parameter (tiny-cuda-nn adam_step)
@@ -1350,16 +1477,16 @@ struct wost_net {
 static size_t half_image_entries(const NetLayout &L) { return (size_t)L.n_mlp / 4 + L.level_off[L.n_levels]; }
 
 static int launch_forward_h(wost_net *h, const float *p, const uint2 *image, const float *xy_dev, int n, const uint32_t *n_dev, float *out_dev,
-                            size_t ldp, size_t ldf, uint2 *enc_out, hipStream_t stream)
+                            size_t ldp, size_t ldf, uint2 *enc_out, hipStream_t stream, const LossArgs *loss = nullptr)
 {
     const NetLayout &L = h->L;
     const size_t lds = (L.dims == 2 ? half_image_entries(L) : (size_t)L.n_mlp / 4) * sizeof(uint2);
     const int n_tiles = (n + 16 * kHalfSub - 1) / (16 * kHalfSub);
     // one block per CU (two inputs: the image takes 150 KB of LDS), walking over the tiles
     const unsigned grid = (unsigned)std::max(1, std::min((n_tiles + kHalfFwdThreads / 64 - 1) / (kHalfFwdThreads / 64), 256));
-    auto kfn = L.dims == 2 ? net_forward_h_kernel<2> : net_forward_h_kernel<3>;
+    auto kfn = L.dims == 2 ? (loss ? net_forward_h_kernel<2, true> : net_forward_h_kernel<2, false>) : net_forward_h_kernel<3, false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(kHalfFwdThreads), lds, stream, L, p, image, xy_dev, n, n_dev, out_dev, ldp, ldf, enc_out);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(kHalfFwdThreads), lds, stream, L, p, image, xy_dev, n, n_dev, out_dev, ldp, ldf, enc_out, loss ? *loss : LossArgs{});
     ++h->n_launches;
     NET_TRY(hipGetLastError());
     return WOST_OK;
@@ -1501,6 +1628,55 @@ int net_forward_train_dev(wost_net *h, const float *xy_dev, int n, hipStream_t s
     return WOST_OK;
 }
 
+// The training forward of the guided solve with the mixture's loss gradient taken inside it (half-precision training, two inputs):
+// one launch instead of forward + vmm_loss_gradients_kernel, dL/dout handed to net_backward_update_dev as f16 tiles.
+// WOST_ERR_UNSUPPORTED (no error recorded) when the network does not train that way: the caller takes the two launches.
+int net_forward_loss_dev(wost_net *h, const float *xy_dev, int n, hipStream_t stream, const float *dir, const float *li, const float *dir_pdf,
+                         const uint8_t *on_neumann, const float *normal, float loss_scale)
+{
+    if (h->train_precision != 16 || h->L.dims != 2 || h->L.n_out != 33) return WOST_ERR_UNSUPPORTED;
+    if (const char *e = std::getenv("WOST_NET_FUSED_LOSS"))
+        if (std::atoi(e) == 0) return WOST_ERR_UNSUPPORTED;
+    int rc = ensure_points(h, (size_t)std::max(n, 64));
+    if (rc != WOST_OK) return rc;
+    int k = 0;
+    while (k < 10 && (n >> (k + 10)) > 0) ++k;          // the deltas' extra scale, as net_backward_update_dev chooses it
+    LossArgs la{dir, li, dir_pdf, normal, on_neumann, loss_scale / (float)n, (float)(1 << k), reinterpret_cast<uint2 *>(h->d_dl)};
+    rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, h->d_out, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream, &la);
+    if (rc != WOST_OK) return rc;
+    if (const char *e = std::getenv("WOST_NET_FUSED_LOSS"))
+        if (std::atoi(e) == 3) {
+            // developer check: the same launch again into a second buffer, the two compared word by word
+            const size_t words = (size_t)((n + 31) / 32 * 2) * 3 * 64 * 2;
+            uint32_t *second = nullptr;
+            std::vector<uint32_t> a(words), b(words);
+            NET_TRY(hipMalloc((void **)&second, words * 4));
+            NET_TRY(hipMemsetAsync(second, 0xee, words * 4, stream));
+            LossArgs lb = la;
+            lb.dl_h = reinterpret_cast<uint2 *>(second);
+            rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, h->d_out, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream, &lb);
+            NET_TRY(hipStreamSynchronize(stream));
+            NET_TRY(hipMemcpy(a.data(), h->d_dl, words * 4, hipMemcpyDeviceToHost));
+            NET_TRY(hipMemcpy(b.data(), second, words * 4, hipMemcpyDeviceToHost));
+            (void)hipFree(second);
+            size_t diff = 0, first = words;
+            for (size_t i = 0; i < words; ++i)
+                if (a[i] != b[i]) { if (first == words) first = i; ++diff; }
+            if (diff) {
+                const size_t unit = first / (3 * 64 * 2), tt = first / 128 % 3, lane = first / 2 % 64;
+                std::fprintf(stderr, "fused loss twice: n %d, %zu of %zu words differ, first at word %zu = unit %zu tile %zu lane %zu (%08x vs %08x)\n", n, diff, words,
+                             first, unit, tt, lane, a[first], b[first]);
+                size_t shown = 0;
+                for (size_t i = first; i < words && shown < 24; ++i)
+                    if (a[i] != b[i]) { std::fprintf(stderr, "   word %zu unit %zu tile %zu lane %zu half-pair %zu: %08x vs %08x\n", i, i / 384, i / 128 % 3, i / 2 % 64, i % 2, a[i], b[i]); ++shown; }
+            } else {
+                std::fprintf(stderr, "fused loss twice: n %d, all %zu words equal\n", n, words);
+            }
+        }
+    h->dl_is_half = true;
+    return WOST_OK;
+}
+
 int net_apply_update_dev(wost_net *h, float loss_scale, hipStream_t stream);
 
 int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_scale, int apply_update, hipStream_t stream)
@@ -1518,7 +1694,9 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
         int k = 0;
         while (k < 10 && (n >> (k + 10)) > 0) ++k;          // 2^k ~ n / 512, between 1 and 1024
         hipLaunchKernelGGL(net_train_h_kernel, dim3(gridb), dim3(kHalfThreads), lds, stream, L, h->params_h, h->params_hb,
-                           reinterpret_cast<const uint2 *>(h->d_acts), h->d_dl, n, (float)(1 << k), h->d_denc, h->train_partial);
+                           reinterpret_cast<const uint2 *>(h->d_acts), h->d_dl, n, (float)(1 << k), h->d_denc, h->train_partial,
+                           h->dl_is_half ? reinterpret_cast<const uint2 *>(h->d_dl) : nullptr);
+        h->dl_is_half = false;
         hipLaunchKernelGGL(net_train_h_reduce_kernel, dim3((L.n_mlp + 255) / 256, (gridb + 15) / 16), dim3(256), 0, stream, L, h->train_partial, (int)gridb,
                            h->grad);
         h->n_launches += 2;

@@ -164,6 +164,25 @@ class UniformIntegrator3:
             pass
 
 
+MESH_BUILD_ARRAYS = ("nodes", "tri", "triOrig", "slotOfOrig", "triVerts", "colors", "flat", "flatVerts", "edges", "slotEdges", "cones", "obox",
+                     "areas", "sampTri", "scalars")
+
+
+def mesh_build_check(verts, tris, colors=None, repeat=1, device=0):
+    """wost3_mesh_build_check: the device build of a triangle mesh against the host builder kept as its checker ->
+    ({array: differing bytes}, bytes compared, host ms, device ms)"""
+    keep = []
+    verts = np.ascontiguousarray(verts, np.float32)
+    tris = np.ascontiguousarray(tris, np.int32)
+    colors = None if colors is None else np.ascontiguousarray(colors, np.float32)
+    m = _mesh3(keep, verts, tris, colors)
+    host_ms, dev_ms = C.c_double(0.0), C.c_double(0.0)
+    mism = (C.c_int64 * 16)()
+    lib = capi.load()
+    _check(lib.wost3_mesh_build_check(C.byref(m), device, repeat, C.byref(host_ms), C.byref(dev_ms), mism), "wost3_mesh_build_check")
+    return {k: int(mism[i]) for i, k in enumerate(MESH_BUILD_ARRAYS)}, int(mism[15]), host_ms.value, dev_ms.value
+
+
 def vmf_eval(kappa, cos_theta, device=0):
     """VMF::eval(cosTheta) (reference util/vmf.h:27-32) for pairs (kappa, cos_theta)"""
     lib = capi.load()

@@ -408,6 +408,14 @@ int wost3_closest_silhouette(wost3_handle h, int which_mesh, const float *pts, c
 /* lbvh::ray_intersect on triangles: closest hit (flag, t, triangle) */
 int wost3_ray_intersect(wost3_handle h, int which_mesh, const float *origins, const float *dirs, const float *tmax, int32_t n,
                         int32_t *out_hit, float *out_t, int32_t *out_idx);
+/* Problem<3>::build_bvh (core/problem.cu:31-37, 48-54: the reference builds its trees on the device).  wost3_create builds
+ * every mesh with HIP kernels (csrc/wost_build3.hip); this developer / test entry builds `mesh` with those kernels AND with the
+ * host builder kept as their checker, `repeat` times, and compares the two uploaded meshes byte for byte:
+ * mismatch[0..13] = differing bytes of nodes, tri, triOrig, slotOfOrig, triVerts, colors, flat, flatVerts, edges, slotEdges,
+ * cones, obox, areas, sampTri; [14] = differing scalars (the arrays are not compared then); [15] = bytes compared.
+ * host_ms / device_ms (either may be NULL) = the fastest wall-clock time of each build, uploads and the final wait included. */
+int wost3_mesh_build_check(const wost3_mesh_desc *mesh, int device, int32_t repeat, double *host_ms, double *device_ms,
+                           int64_t *mismatch);
 /* VMF (reference util/vmf.h:21-70), the lobe of the 3-D guided integrator's mixture (that integrator is not built; this is
  * its distribution layer, batch entry points over HOST arrays like wost_vonmises_*): eval(cosTheta) for n (kappa,
  * cos_theta) pairs; sample(sampler, mu): per point a PCG32 stream setSeed(seed[i], 1) and per_point consecutive unit

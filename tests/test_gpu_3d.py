@@ -208,6 +208,18 @@ def test_3d_neumann_mesh_of_hundreds_of_triangles(oracle, case):
     assert ref["neumann_hits"] > 0
 
 
+@pytest.mark.parametrize("case", ["zero_flux", "emissive"])
+def test_3d_source_term_inside_a_tree_sized_neumann_shell(oracle, case):
+    """the source sample's line to the boundary and the boundary sample's shadow ray, both answered by the wave through its task
+    pools on a 1280-triangle shell (walk3_kernel<EMISSIVE, SOURCE, NTREE>, part B in three stages): the oracle's field and counters"""
+    sd = _shell_scene(2, 3, flux=(lambda x, y, z: 0.3 * y) if case == "emissive" else None)
+    rng = np.random.default_rng(9)
+    sd["source"] = {"rgb": rng.uniform(0, 2, (6, 5, 4, 3)).astype(np.float32), "index_scale": (2.0, 2.5, 3.0),
+                    "index_offset": (2.0, 2.5, 3.0), "intensity": 0.8}
+    ref = _same_solve(oracle, sd, 14, 12, 6, 64, 2e-3)
+    assert ref["neumann_hits"] > 0 and np.any(ref["field"] != 0)
+
+
 @pytest.mark.parametrize("case", ["ball", "cube_with_reflecting_walls", "emissive_walls_and_mask"])
 def test_3d_source_term_matches_oracle(oracle, case):
     """sampleSource in 3-D (dense grid, trilinear; HarmonicGreenBall<3>::sample): bit-exact against the oracle, whose
@@ -255,6 +267,7 @@ def test_3d_debug_channels_match_oracle(oracle):
 
 
 @pytest.mark.parametrize("knobs", [{"WOST3_WAVE": "0", "WOST3_COOP": "0"}, {"WOST3_WAVE": "0", "WOST3_COOP": "1"}, {"WOST3_WAVE": "1", "WOST3_COOP": "0"},
+                                   {"WOST3_WAVE": "0", "WOST3_COOP": "2"}, {"WOST3_COOP": "1"},
                                    {"WOST3_POOL_CAP": "96"}, {"WOST3_POOL_CAP": "200", "WOST3_RAY_TRIGGER": "1", "WOST3_CP_TRIGGER": "1"}])
 def test_3d_wave_cooperative_queries_and_their_fallbacks_match_oracle(oracle, monkeypatch, knobs):
     """the tree queries of a walk answered by the wave through its LDS task pools (closest_triangle_pool, closest_silhouette3_wave,

@@ -152,17 +152,32 @@ def guided3d(oracle, seed):
 
 
 def main():
+    """fuzz_far_trees.py MODE [FIRST [COUNT [SECONDS [LOG]]]]: seeds FIRST .. FIRST + COUNT - 1; with SECONDS > 0 the run stops at the
+    first seed that starts after that many seconds (the summary line names the seeds that ran); LOG = a file that receives one line
+    per seed as it finishes (a run that is cut off still leaves its record)"""
+    import time
     mode = sys.argv[1]
     first, count = int(sys.argv[2]) if len(sys.argv) > 2 else 0, int(sys.argv[3]) if len(sys.argv) > 3 else 40
+    seconds = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+    log = open(sys.argv[5], "a") if len(sys.argv) > 5 else None
     run = {"guided2d": guided2d, "uniform3d": uniform3d, "guided3d": guided3d}[mode]
     oracle = Oracle()
-    bad = 0
+    bad, done, t0 = 0, 0, time.time()
     for seed in range(first, first + count):
+        if seconds > 0 and time.time() - t0 > seconds:
+            break
         ok, what, feat, diff = run(oracle, seed)
+        done += 1
+        if log:
+            log.write("%s seed %d %s %.1fs\n" % (mode, seed, "ok" if ok else "MISMATCH", time.time() - t0))
+            log.flush()
         if not ok:
             bad += 1
             print("seed %d MISMATCH (%s): %s" % (seed, mode, what), feat, diff, flush=True)
-    print("fuzz far trees %s %d..%d: %d mismatches" % (mode, first, first + count - 1, bad), flush=True)
+    print("fuzz far trees %s %d..%d: %d mismatches" % (mode, first, first + done - 1, bad), flush=True)
+    if log:
+        log.write("fuzz far trees %s %d..%d: %d mismatches\n" % (mode, first, first + done - 1, bad))
+        log.close()
 
 
 if __name__ == "__main__":
