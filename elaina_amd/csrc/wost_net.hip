@@ -464,6 +464,9 @@ struct LossArgs {
 };
 
 template <int DIMS, bool LOSS>
+#ifdef WOST_FWD_H_VGPR
+__attribute__((amdgpu_waves_per_eu(WOST_FWD_H_VGPR, WOST_FWD_H_VGPR)))
+#endif
 __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayout L, const float *params, const uint2 *fragh, const float *xy, int n,
                                                                        const uint32_t *n_dev, float *out, size_t out_ldp, size_t out_ldf, uint2 *enc_out,
                                                                        LossArgs la)
@@ -526,6 +529,14 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
                                                          h4_t{(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f});
         }
         mfma_layer_h<4, 3>(w3, lane, b, acc);
+#ifdef WOST_LOSS_FENCE
+        if (LOSS) {
+            // (developer build: nothing of the loss arithmetic scheduled into the matrix instructions -- did not change the finding of EXPERIMENTS 17)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         if (!LOSS) {
 #pragma unroll
             for (int u = 0; u < kHalfSub; ++u)
@@ -1635,8 +1646,12 @@ int net_forward_loss_dev(wost_net *h, const float *xy_dev, int n, hipStream_t st
                          const uint8_t *on_neumann, const float *normal, float loss_scale)
 {
     if (h->train_precision != 16 || h->L.dims != 2 || h->L.n_out != 33) return WOST_ERR_UNSUPPORTED;
-    if (const char *e = std::getenv("WOST_NET_FUSED_LOSS"))
-        if (std::atoi(e) == 0) return WOST_ERR_UNSUPPORTED;
+    // OFF unless WOST_NET_FUSED_LOSS asks for it (1: on, 3: on, launched three times and compared): the kernel is 2.6 % of config 4
+    // faster than the two launches and gives the same numbers -- except that now and then a few 16-point units of a launch come out
+    // slightly different (three launches on the same inputs, any one of them the odd one out), which the solve's run-to-run
+    // reproducibility does not tolerate.  What was ruled out is in EXPERIMENTS 17; the cause was not found.
+    const char *fused = std::getenv("WOST_NET_FUSED_LOSS");
+    if (!fused || std::atoi(fused) == 0) return WOST_ERR_UNSUPPORTED;
     int rc = ensure_points(h, (size_t)std::max(n, 64));
     if (rc != WOST_OK) return rc;
     int k = 0;
@@ -1646,32 +1661,35 @@ int net_forward_loss_dev(wost_net *h, const float *xy_dev, int n, hipStream_t st
     if (rc != WOST_OK) return rc;
     if (const char *e = std::getenv("WOST_NET_FUSED_LOSS"))
         if (std::atoi(e) == 3) {
-            // developer check: the same launch again into a second buffer, the two compared word by word
+            // developer check: the same launch twice more into other buffers, the three compared word by word (which one is the odd one out)
             const size_t words = (size_t)((n + 31) / 32 * 2) * 3 * 64 * 2;
-            uint32_t *second = nullptr;
-            std::vector<uint32_t> a(words), b(words);
-            NET_TRY(hipMalloc((void **)&second, words * 4));
-            NET_TRY(hipMemsetAsync(second, 0xee, words * 4, stream));
-            LossArgs lb = la;
-            lb.dl_h = reinterpret_cast<uint2 *>(second);
-            rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, h->d_out, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream, &lb);
-            NET_TRY(hipStreamSynchronize(stream));
-            NET_TRY(hipMemcpy(a.data(), h->d_dl, words * 4, hipMemcpyDeviceToHost));
-            NET_TRY(hipMemcpy(b.data(), second, words * 4, hipMemcpyDeviceToHost));
-            (void)hipFree(second);
-            size_t diff = 0, first = words;
-            for (size_t i = 0; i < words; ++i)
-                if (a[i] != b[i]) { if (first == words) first = i; ++diff; }
-            if (diff) {
-                const size_t unit = first / (3 * 64 * 2), tt = first / 128 % 3, lane = first / 2 % 64;
-                std::fprintf(stderr, "fused loss twice: n %d, %zu of %zu words differ, first at word %zu = unit %zu tile %zu lane %zu (%08x vs %08x)\n", n, diff, words,
-                             first, unit, tt, lane, a[first], b[first]);
-                size_t shown = 0;
-                for (size_t i = first; i < words && shown < 24; ++i)
-                    if (a[i] != b[i]) { std::fprintf(stderr, "   word %zu unit %zu tile %zu lane %zu half-pair %zu: %08x vs %08x\n", i, i / 384, i / 128 % 3, i / 2 % 64, i % 2, a[i], b[i]); ++shown; }
-            } else {
-                std::fprintf(stderr, "fused loss twice: n %d, all %zu words equal\n", n, words);
+            uint32_t *extra = nullptr;
+            std::vector<uint32_t> r[3];
+            for (auto &v : r) v.resize(words);
+            NET_TRY(hipMalloc((void **)&extra, 2 * words * 4));
+            NET_TRY(hipMemsetAsync(extra, 0xee, 2 * words * 4, stream));
+            for (int k = 0; k < 2; ++k) {
+                LossArgs lb = la;
+                lb.dl_h = reinterpret_cast<uint2 *>(extra + k * words);
+                rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, h->d_out, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream, &lb);
             }
+            NET_TRY(hipStreamSynchronize(stream));
+            NET_TRY(hipMemcpy(r[0].data(), h->d_dl, words * 4, hipMemcpyDeviceToHost));
+            NET_TRY(hipMemcpy(r[1].data(), extra, words * 4, hipMemcpyDeviceToHost));
+            NET_TRY(hipMemcpy(r[2].data(), extra + words, words * 4, hipMemcpyDeviceToHost));
+            (void)hipFree(extra);
+            size_t odd[4] = {0, 0, 0, 0}, shown = 0;
+            for (size_t i = 0; i < words; ++i) {
+                const uint32_t a0 = r[0][i], a1 = r[1][i], a2 = r[2][i];
+                if (a0 == a1 && a1 == a2) continue;
+                const int which = a1 == a2 ? 0 : a0 == a2 ? 1 : a0 == a1 ? 2 : 3;
+                ++odd[which];
+                if (shown++ < 40)
+                    std::fprintf(stderr, "   word %zu unit %zu tile %zu lane %zu (i %zu g %zu) pair %zu: %08x %08x %08x odd %d\n", i, i / 384, i / 128 % 3, i / 2 % 64,
+                                 i / 2 % 16, i / 2 % 64 / 16, i % 2, a0, a1, a2, which);
+            }
+            std::fprintf(stderr, "fused loss three times: n %d, odd one out: first %zu, second %zu, third %zu, all differ %zu words of %zu\n", n, odd[0], odd[1], odd[2],
+                         odd[3], words);
         }
     h->dl_is_half = true;
     return WOST_OK;

@@ -1028,29 +1028,3 @@ def test_gpu_sync_callback_failures_end_the_solve():
                 {capi.SYNC_SUM_I64_DEVICE: capi.SYNC_UNSUPPORTED}):
         with pytest.raises(WostError, match="sync callback failed"):
             solve_with(bad)
-
-
-@pytest.mark.gpu
-def test_gpu_loss_gradient_inside_the_training_forward_equals_the_two_launches(monkeypatch):
-    """Half-precision training: the mixture's loss gradient is taken inside the training forward kernel (net_forward_h_kernel<2, LOSS>:
-    four lanes per point, the sums in lobe order) and handed to the backward kernel as f16 tiles.  Same numbers as the
-    one-thread-per-sample kernel between two launches (WOST_NET_FUSED_LOSS=0): field, counters and trained weights bit for bit --
-    on the mixed box (walkers on the Neumann sides: the mirrored densities), with batches that end inside a 32-point tile."""
-    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
-    prob = laplace_box()
-    out = []
-    for fused in ("1", "0"):
-        monkeypatch.setenv("WOST_NET_FUSED_LOSS", fused)
-        st = GuidedIntegratorSettings(frameSize=(64, 48), samplesPerPixel=10, trainSppCount=8, maxWalkingDepth=32, epsilonShell=EPS,
-                                      batchSize=4096 + 128, minBatchSize=1024)
-        gi = GuidedIntegrator(prob, st, AABB, seed=5)
-        gi.network.set_option("precision", 16)
-        gi.network.set_option("train_precision", 16)
-        gi.solve()
-        assert gi.last_stats["optimizer_steps"] >= 8
-        out.append((gi.solution.copy(), gi.network.params(), gi.network.inference_params(), dict(gi.last_stats)))
-        gi.close()
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
-    for k in ("walk_steps", "guided_steps", "train_samples", "optimizer_steps"):
-        assert out[0][3][k] == out[1][3][k], k
-    assert out[0][3]["kernel_launches"] < out[1][3]["kernel_launches"]

@@ -6,7 +6,7 @@ os.environ["WOST_NET_FUSED_LOSS"] = "3"
 from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
 from elaina_amd.scenes import BRIGHT_DISC_AABB, bright_disc_scene
 p = bright_disc_scene()
-for rep in range(6):
+for rep in range(int(os.environ.get("REPS", "6"))):
     st = GuidedIntegratorSettings(frameSize=(128, 128), samplesPerPixel=2, trainSppCount=2, maxWalkingDepth=128, epsilonShell=0.05, batchSize=65536, minBatchSize=8192)
     g = GuidedIntegrator(p, st, BRIGHT_DISC_AABB)
     g.network.set_option("precision", 16)
