@@ -395,7 +395,10 @@ __global__ __launch_bounds__(NT) void net_forward_mfma_kernel(NetLayout L, const
 // g and g + 4 of its point: nothing is exchanged between lanes.
 constexpr int kHalfSub = 2;       // 16-point groups per wave iteration
 constexpr int kHalfThreads = 256;      // training kernel (wost_net_half.h): one wave per SIMD, the accumulators take the registers
-constexpr int kHalfFwdThreads = 1024;  // forward kernel: sixteen waves share the LDS image, four per SIMD hide each other's latencies
+#ifndef WOST_HALF_FWD_THREADS
+#define WOST_HALF_FWD_THREADS 1024
+#endif
+constexpr int kHalfFwdThreads = WOST_HALF_FWD_THREADS;  // forward kernel: sixteen waves share the LDS image, four per SIMD hide each other's latencies
 
 // fragh[(w_off[layer] / 4) + (rt * KT + kt) * 64 + lane] = W[16 rt + i][16 kt + 4g .. 4g + 3], KT = n_i / 16
 // followed by the grid, entry by entry (4 features, 8 bytes): the image net_forward_h_kernel keeps in LDS
@@ -464,9 +467,6 @@ struct LossArgs {
 };
 
 template <int DIMS, bool LOSS>
-#ifdef WOST_FWD_H_VGPR
-__attribute__((amdgpu_waves_per_eu(WOST_FWD_H_VGPR, WOST_FWD_H_VGPR)))
-#endif
 __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayout L, const float *params, const uint2 *fragh, const float *xy, int n,
                                                                        const uint32_t *n_dev, float *out, size_t out_ldp, size_t out_ldf, uint2 *enc_out,
                                                                        LossArgs la)
@@ -521,6 +521,8 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
         for (int layer = 0; layer < 3; ++layer) {
             if (layer == 0) mfma_layer_h<2, 4>(w0, lane, b, acc);
             else mfma_layer_h<4, 4>(layer == 1 ? w1 : w2, lane, b, acc);
+            mfma_settle(acc);
+            mfma_hold(b);
 #pragma unroll
             for (int u = 0; u < kHalfSub; ++u)
 #pragma unroll
@@ -529,14 +531,8 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
                                                          h4_t{(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f});
         }
         mfma_layer_h<4, 3>(w3, lane, b, acc);
-#ifdef WOST_LOSS_FENCE
-        if (LOSS) {
-            // (developer build: nothing of the loss arithmetic scheduled into the matrix instructions -- did not change the finding of EXPERIMENTS 17)
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 7");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#endif
+        mfma_settle3(acc);
+        mfma_hold(b);
         if (!LOSS) {
 #pragma unroll
             for (int u = 0; u < kHalfSub; ++u)
@@ -549,6 +545,17 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
                         if (valid[u] && o < L.n_out) out[(size_t)pt[u] * out_ldp + o * out_ldf] = (float)(_Float16)acc[u][rt][c];
                     }
         } else {
+            if (out) {      // (developer check of EXPERIMENTS 17: the raw outputs as well)
+#pragma unroll
+                for (int u = 0; u < kHalfSub; ++u)
+#pragma unroll
+                    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int o = 16 * rt + 4 * g + c;
+                            if (valid[u] && o < L.n_out) out[(size_t)pt[u] * out_ldp + o * out_ldf] = (float)(_Float16)acc[u][rt][c];
+                        }
+            }
 #pragma unroll
             for (int u = 0; u < kHalfSub; ++u) {
                 // ---- vmm_loss_gradients_kernel for point pt[u], its eight lobes on the four lanes (i, 0..3) ----
@@ -1657,7 +1664,8 @@ int net_forward_loss_dev(wost_net *h, const float *xy_dev, int n, hipStream_t st
     int k = 0;
     while (k < 10 && (n >> (k + 10)) > 0) ++k;          // the deltas' extra scale, as net_backward_update_dev chooses it
     LossArgs la{dir, li, dir_pdf, normal, on_neumann, loss_scale / (float)n, (float)(1 << k), reinterpret_cast<uint2 *>(h->d_dl)};
-    rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, h->d_out, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream, &la);
+    const bool check3 = std::atoi(fused) == 3;
+    rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, check3 ? h->d_out : nullptr, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream, &la);
     if (rc != WOST_OK) return rc;
     if (const char *e = std::getenv("WOST_NET_FUSED_LOSS"))
         if (std::atoi(e) == 3) {
@@ -1666,14 +1674,46 @@ int net_forward_loss_dev(wost_net *h, const float *xy_dev, int n, hipStream_t st
             uint32_t *extra = nullptr;
             std::vector<uint32_t> r[3];
             for (auto &v : r) v.resize(words);
+            const size_t n_raw = (size_t)n * h->L.n_out;
+            float *raw2 = nullptr;
             NET_TRY(hipMalloc((void **)&extra, 2 * words * 4));
+            NET_TRY(hipMalloc((void **)&raw2, 2 * n_raw * 4));
             NET_TRY(hipMemsetAsync(extra, 0xee, 2 * words * 4, stream));
             for (int k = 0; k < 2; ++k) {
                 LossArgs lb = la;
                 lb.dl_h = reinterpret_cast<uint2 *>(extra + k * words);
-                rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, h->d_out, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream, &lb);
+                rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, raw2 + k * n_raw, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream, &lb);
             }
             NET_TRY(hipStreamSynchronize(stream));
+            {
+                std::vector<float> o0(n_raw), o1(n_raw), o2(n_raw);
+                NET_TRY(hipMemcpy(o0.data(), h->d_out, n_raw * 4, hipMemcpyDeviceToHost));
+                NET_TRY(hipMemcpy(o1.data(), raw2, n_raw * 4, hipMemcpyDeviceToHost));
+                NET_TRY(hipMemcpy(o2.data(), raw2 + n_raw, n_raw * 4, hipMemcpyDeviceToHost));
+                (void)hipFree(raw2);
+                size_t bad_vals = 0, bad_pts = 0, last_pt = (size_t)-1, shown = 0;
+                for (size_t i = 0; i < n_raw; ++i)
+                    if (std::memcmp(&o0[i], &o1[i], 4) != 0 || std::memcmp(&o1[i], &o2[i], 4) != 0) {
+                        ++bad_vals;
+                        const size_t pt = i / h->L.n_out;
+                        if (pt != last_pt) { ++bad_pts; last_pt = pt; if (shown++ < 12) std::fprintf(stderr, "   raw outputs differ at point %zu (unit %zu, i %zu), output %zu: %g %g %g\n", pt, pt / 16, pt % 16, i % h->L.n_out, o0[i], o1[i], o2[i]); }
+                    }
+                std::fprintf(stderr, "raw network outputs of the three launches: %zu values in %zu points differ; units:", bad_vals, bad_pts);
+                {
+                    size_t last_unit = (size_t)-1;
+                    int n_out_here = 0;
+                    for (size_t i = 0; i < n_raw; ++i)
+                        if (std::memcmp(&o0[i], &o1[i], 4) != 0 || std::memcmp(&o1[i], &o2[i], 4) != 0) {
+                            const size_t unit = i / h->L.n_out / 16;
+                            if (unit != last_unit) {
+                                const int odd = std::memcmp(&o1[i], &o2[i], 4) == 0 ? 0 : std::memcmp(&o0[i], &o2[i], 4) == 0 ? 1 : std::memcmp(&o0[i], &o1[i], 4) == 0 ? 2 : 3;
+                                if (n_out_here++ < 40) std::fprintf(stderr, " %zu(launch %d)", unit, odd);
+                                last_unit = unit;
+                            }
+                        }
+                    std::fprintf(stderr, "\n");
+                }
+            }
             NET_TRY(hipMemcpy(r[0].data(), h->d_dl, words * 4, hipMemcpyDeviceToHost));
             NET_TRY(hipMemcpy(r[1].data(), extra, words * 4, hipMemcpyDeviceToHost));
             NET_TRY(hipMemcpy(r[2].data(), extra + words, words * 4, hipMemcpyDeviceToHost));

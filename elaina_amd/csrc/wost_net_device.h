@@ -38,6 +38,39 @@ __device__ __forceinline__ f32x4_t mfma_k32(h4_t a0, h4_t a1, h4_t b0, h4_t b1, 
                                                   acc, 0, 0, 0);
 }
 
+// Every accumulator of a layer passes through one of these before anything reads it: all matrix instructions of the layer issued,
+// then four idle states.  Without it hipcc (ROCm 7.2) schedules the conversions of the first accumulators between the last
+// v_mfma_f32_16x16x32_f16 of the layer with the wait states of its gfx950 table, and on MI355X a whole 16-point unit then comes
+// out a percent different now and then -- three launches of one kernel on the same inputs, any one of them the odd one out, about
+// one unit in 3 000 with the loss arithmetic behind the network and one in several millions without (what made config 4 in half
+// precision differ between two runs).  With the statement: 0 differing values in 120 launches (EXPERIMENTS 17).
+#ifdef WOST_MFMA_SETTLE_OFF     // (developer builds: the unpadded kernels of EXPERIMENTS 17)
+#define WOST_MFMA_SETTLE ""
+#else
+#define WOST_MFMA_SETTLE "s_nop 15"
+#endif
+__device__ __forceinline__ void mfma_settle(f32x4_t &a) { asm volatile(WOST_MFMA_SETTLE : "+v"(a)); }
+__device__ __forceinline__ void mfma_settle(f32x4_t (&a)[2]) { asm volatile(WOST_MFMA_SETTLE : "+v"(a[0]), "+v"(a[1])); }
+__device__ __forceinline__ void mfma_settle(f32x4_t (&a)[3]) { asm volatile(WOST_MFMA_SETTLE : "+v"(a[0]), "+v"(a[1]), "+v"(a[2])); }
+__device__ __forceinline__ void mfma_settle(f32x4_t (&a)[4]) { asm volatile(WOST_MFMA_SETTLE : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); }
+__device__ __forceinline__ void mfma_settle(f32x4_t (&a)[2][4])
+{
+    asm volatile(WOST_MFMA_SETTLE : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]));
+}
+__device__ __forceinline__ void mfma_settle3(f32x4_t (&a)[4]) { asm volatile(WOST_MFMA_SETTLE : "+v"(a[0]), "+v"(a[1]), "+v"(a[2])); }
+__device__ __forceinline__ void mfma_settle3(f32x4_t (&a)[2][4])
+{
+    asm volatile(WOST_MFMA_SETTLE : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]));
+}
+// the operands of a layer held until the same point (nothing may overwrite one while a matrix instruction of the layer can still read it)
+__device__ __forceinline__ void mfma_hold(const h4_t (&b)[2]) { asm volatile("" :: "v"(b[0]), "v"(b[1])); }
+__device__ __forceinline__ void mfma_hold(const h4_t (&b)[3]) { asm volatile("" :: "v"(b[0]), "v"(b[1]), "v"(b[2])); }
+__device__ __forceinline__ void mfma_hold(const h4_t (&b)[4]) { asm volatile("" :: "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3])); }
+__device__ __forceinline__ void mfma_hold(const h4_t (&b)[2][4])
+{
+    asm volatile("" :: "v"(b[0][0]), "v"(b[0][1]), "v"(b[0][2]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][1]), "v"(b[1][2]), "v"(b[1][3]));
+}
+
 // The half-precision image of the inference weights ("precision" 16): MFMA fragments of the four matrices
 // (n_mlp / 4 entries of 8 bytes, layout of fragment_mlp_h_kernel), then the grid entry by entry (4 features in f16).
 // Refreshed by the network after every optimizer step.
@@ -247,6 +280,8 @@ __device__ __forceinline__ void half_mlp_unit(const uint2 *wf, const uint32_t (&
                     acc[rt] = mfma_k32(a0.h, a1.h, b[kt], b[kt + 1], acc[rt]);
                 }
             }
+        mfma_settle(acc);
+        mfma_hold(b);
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) b[rt] = __builtin_elementwise_max(__builtin_convertvector(acc[rt], h4_t), zero);
     }
@@ -262,6 +297,8 @@ __device__ __forceinline__ void half_mlp_unit(const uint2 *wf, const uint32_t (&
             a1.u = w3[(rt * 4 + kt + 1) * 64 + lane];
             acc[rt] = mfma_k32(a0.h, a1.h, b[kt], b[kt + 1], acc[rt]);
         }
+    mfma_settle3(acc);
+    mfma_hold(b);
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt) out[rt] = __builtin_convertvector(acc[rt], h4_t);
 }

@@ -75,7 +75,8 @@ __device__ __forceinline__ _Float16 sat_h(float v) { return (_Float16)__builtin_
 
 __device__ __forceinline__ h4_t turn_h(h4_t x, h4_t ident)
 {
-    const f32x4_t z = __builtin_amdgcn_mfma_f32_16x16x16f16(x, ident, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+    f32x4_t z = __builtin_amdgcn_mfma_f32_16x16x16f16(x, ident, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+    mfma_settle(z);
     return h4_t{(_Float16)z[0], (_Float16)z[1], (_Float16)z[2], (_Float16)z[3]};
 }
 
@@ -96,6 +97,8 @@ __device__ __forceinline__ void hidden_h(const uint2 *wf, int lane, const h4_t (
             a1.u = wf[(rt * KT + kt + 1) * 64 + lane];
             acc[rt] = mfma_k32(a0.h, a1.h, in[kt], in[kt + 1], acc[rt]);
         }
+    mfma_settle(acc);
+    mfma_hold(in);
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) out[rt] = relu_pack(acc[rt]);
 }
@@ -104,11 +107,19 @@ __device__ __forceinline__ void hidden_h(const uint2 *wf, int lane, const h4_t (
 template <int RT, int KT>
 __device__ __forceinline__ void wgrad_h(const h4_t (&d)[4], const h4_t (&a)[KT], h4_t ident, f32x4_t (&gacc)[RT][KT])
 {
+    // the transposes: all their matrix instructions, then the conversions (mfma_settle)
     h4_t td[RT], ta[KT];
+    f32x4_t zd[RT], za[KT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) td[rt] = turn_h(d[rt], ident);
+    for (int rt = 0; rt < RT; ++rt) zd[rt] = __builtin_amdgcn_mfma_f32_16x16x16f16(d[rt], ident, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) ta[kt] = turn_h(a[kt], ident);
+    for (int kt = 0; kt < KT; ++kt) za[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[kt], ident, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+    mfma_settle(zd);
+    mfma_settle(za);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) td[rt] = h4_t{(_Float16)zd[rt][0], (_Float16)zd[rt][1], (_Float16)zd[rt][2], (_Float16)zd[rt][3]};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) ta[kt] = h4_t{(_Float16)za[kt][0], (_Float16)za[kt][1], (_Float16)za[kt][2], (_Float16)za[kt][3]};
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -139,6 +150,8 @@ __device__ __forceinline__ void back_h(const uint2 *wb, int lane, const h4_t (&d
             acc[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, d[RT - 1], acc[kt], 0, 0, 0);
         }
     }
+    mfma_settle(acc);
+    mfma_hold(d);
 }
 
 // delta of the hidden layer whose activations are a: relu'(a) * acc, saturated, f16

@@ -3,7 +3,7 @@
 # TAG names the output directory under gpurun_out/; STAGES selects what runs (default: all).
 export TMPDIR=/tmp
 TAG=${TAG:-r04}
-STAGES=${STAGES:-"tests smoke micro bench trace pmc pmc_guided pmc3d pmc3d_1024 pmc_guided3d"}
+STAGES=${STAGES:-"tests smoke micro bench trace pmc pmc_guided pmc3d pmc3d_1024 pmc_guided3d build3"}
 mkdir -p gpurun_out/$TAG
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 if has tests; then
@@ -108,5 +108,12 @@ if has pmc_guided3d; then
   done
   python3 tools/pmc_derive_guided3d.py gpurun_out/$TAG/pmc_summary_guided3d.txt gpurun_out/$TAG/kernel_stats_guided3d.csv gpurun_out/$TAG/guided3d_valu.json "$AG"
   rm -rf gpurun_out/$TAG/traceg3
+fi
+# the triangle LBVH built on the device (81 920 triangles, five builds each way): kernel trace of the build kernels
+if has build3; then
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/traceb3 -- python3 tools/probes/build3_only.py > gpurun_out/$TAG/build3_trace.log 2>&1
+  f=$(find gpurun_out/$TAG/traceb3 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/$TAG/kernel_stats_build3.csv
+  grep mesh gpurun_out/$TAG/build3_trace.log | tail -1
+  rm -rf gpurun_out/$TAG/traceb3
 fi
 rm -rf gpurun_out/$TAG/pmc[0-9] gpurun_out/$TAG/trace
