@@ -396,9 +396,9 @@ __global__ __launch_bounds__(NT) void net_forward_mfma_kernel(NetLayout L, const
 constexpr int kHalfSub = 2;       // 16-point groups per wave iteration
 constexpr int kHalfThreads = 256;      // training kernel (wost_net_half.h): one wave per SIMD, the accumulators take the registers
 #ifndef WOST_HALF_FWD_THREADS
-#define WOST_HALF_FWD_THREADS 1024
+#define WOST_HALF_FWD_THREADS 512
 #endif
-constexpr int kHalfFwdThreads = WOST_HALF_FWD_THREADS;  // forward kernel: sixteen waves share the LDS image, four per SIMD hide each other's latencies
+constexpr int kHalfFwdThreads = WOST_HALF_FWD_THREADS;  // forward kernel: eight waves share the LDS image, two per SIMD (four per SIMD: EXPERIMENTS 17)
 
 // fragh[(w_off[layer] / 4) + (rt * KT + kt) * 64 + lane] = W[16 rt + i][16 kt + 4g .. 4g + 3], KT = n_i / 16
 // followed by the grid, entry by entry (4 features, 8 bytes): the image net_forward_h_kernel keeps in LDS

@@ -39,13 +39,20 @@ __device__ __forceinline__ f32x4_t mfma_k32(h4_t a0, h4_t a1, h4_t b0, h4_t b1, 
 }
 
 // Every accumulator of a layer passes through one of these before anything reads it: all matrix instructions of the layer issued,
-// then four idle states.  Without it hipcc (ROCm 7.2) schedules the conversions of the first accumulators between the last
-// v_mfma_f32_16x16x32_f16 of the layer with the wait states of its gfx950 table, and on MI355X a whole 16-point unit then comes
-// out a percent different now and then -- three launches of one kernel on the same inputs, any one of them the odd one out, about
-// one unit in 3 000 with the loss arithmetic behind the network and one in several millions without (what made config 4 in half
-// precision differ between two runs).  With the statement: 0 differing values in 120 launches (EXPERIMENTS 17).
+// then sixteen idle states, the layer's operands held until then (mfma_hold).  hipcc (ROCm 7.2) otherwise schedules the conversions
+// of the first accumulators between the last v_mfma_f32_16x16x32_f16 of the layer, and on MI355X, with four waves of a SIMD issuing
+// such layers side by side, a whole 16-point unit then comes out a percent different now and then: three launches of one kernel on
+// the same inputs, any one of them the odd one out (EXPERIMENTS 17: what made config 4 in half precision differ between two runs).
+// Measured: idle states BETWEEN the matrix instructions or in front of them make it far worse, this statement behind them 30 x better,
+// two waves per SIMD instead of four (net_forward_h_kernel's block of 512) remove what was left; one wave per SIMD
+// (net_train_h_kernel) never showed it.
+#define WOST_NOP16 "s_nop 15\n\t"
 #ifdef WOST_MFMA_SETTLE_OFF     // (developer builds: the unpadded kernels of EXPERIMENTS 17)
 #define WOST_MFMA_SETTLE ""
+#elif defined(WOST_MFMA_SETTLE_64)
+#define WOST_MFMA_SETTLE WOST_NOP16 WOST_NOP16 WOST_NOP16 "s_nop 15"
+#elif defined(WOST_MFMA_SETTLE_128)
+#define WOST_MFMA_SETTLE WOST_NOP16 WOST_NOP16 WOST_NOP16 WOST_NOP16 WOST_NOP16 WOST_NOP16 WOST_NOP16 "s_nop 15"
 #else
 #define WOST_MFMA_SETTLE "s_nop 15"
 #endif
