@@ -674,6 +674,9 @@ def main():
                                 "walk_steps_per_pass": o["walk_steps_per_pass"], "config": args.config}})
         if "time_to_1spp_ms" in o:
             line["time_to_1spp_ms"] = o["time_to_1spp_ms"]
+        if "create_ms" in o:
+            # wost_create of the workload's scene (2-D trees: host builder; outside the timed passes like the reference's loadConfig / build_bvh)
+            line["create_ms"] = o["create_ms"]
         if "scheduler" in o:
             line["scheduler"] = o["scheduler"]
         if "ranks" in o:
