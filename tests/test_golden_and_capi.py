@@ -111,6 +111,12 @@ def test_guided_and_network_entry_points_reject_bad_arguments(ladybug):
             GuidingNetwork()
         with pytest.raises(capi.WostError, match="no HIP device"):
             GuidedIntegrator(ladybug, GuidedIntegratorSettings(frameSize=(8, 8), samplesPerPixel=1), ((0, 0), (1, 1)))
+        # the triangle trees are built on the device: no host fallback behind wost3_create, and the build check says so too
+        import numpy as np
+        from elaina_amd.integrator3d import mesh_build_check
+        with pytest.raises(capi.WostError, match="no HIP device"):
+            mesh_build_check(np.asarray([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.asarray([[0, 1, 2]], np.int32))
+    assert lib.wost3_mesh_build_check(None, 0, 1, None, None, None) == -1
     # settings the device code does not cover are refused up front
     bad = GuidedIntegratorSettings(frameSize=(8, 8), samplesPerPixel=1, maxTrainDepth=7)
     with pytest.raises(capi.WostError, match="max_train_depth|no HIP device"):
