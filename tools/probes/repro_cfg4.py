@@ -23,7 +23,7 @@ def run(prec, tprec, train):
 
 cases = ((16, 16, spp), (16, 32, spp), (32, 16, spp), (16, 16, 0), (16, 16, spp))
 if os.environ.get("ONLY_F16"):
-    cases = ((32, 16, spp),) * int(os.environ["ONLY_F16"]) + ((16, 16, spp),) * int(os.environ.get("BOTH_F16", "0"))
+    cases = ((32, 16, spp),) * int(os.environ["ONLY_F16"]) + ((16, 16, spp),) * int(os.environ.get("BOTH_F16", "0")) + ((16, 32, spp),) * int(os.environ.get("INF_F16", "0"))
 for prec, tprec, train in cases:
     a, b = run(prec, tprec, train), run(prec, tprec, train)
     d = np.abs(a[0] - b[0])
