@@ -19,7 +19,8 @@ the line also carries "configs": one pass each of config 3 and config 4 (both ne
 (uniform3d, guided3d), a 2-D scene with a Neumann boundary on the tree (neumann2d), the guiding gain and the variance check
 (--no-extras skips them); at N > 1 it carries one pass of config 5.
 
-Prints ONE JSON line on rank 0.
+Rank 0 prints the JSON line (the headline alone as soon as it is measured when extras follow -- marked "partial" -- and the
+complete line last).
 """
 import argparse
 import json
@@ -28,6 +29,7 @@ import subprocess
 import sys
 import time
 
+T_START = time.time()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -70,6 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the selected config (no \"configs\" object)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--budget-s", type=float, default=170.0, help="wall-clock seconds from process start after which no further extra starts")
     ap.add_argument("--no-1spp", action="store_true", help="skip the time-to-1spp probe (profiling runs)")
     ap.add_argument("--steps-per-round", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="key=value passed to wost_set_option")
@@ -722,45 +725,45 @@ def main():
             line["field_finite"] = bool(np.isfinite(f).all())
 
     # ---- one pass each of the other single-GPU configurations (driver-run evidence for configs 3, 4, 5) ----
+    # The headline is printed as soon as it is measured (a run that is cut off keeps it) and again, complete, at the end; the
+    # extras run most important first inside a wall-clock budget (--budget-s, counted from process start): one that would start
+    # past it is named in "skipped" instead of run.
     extras = {}
-    if not args.no_extras and args.config == 2 and not (args.scene or args.frame or args.spp):
+    want_extras = not args.no_extras and args.config == 2 and not (args.scene or args.frame or args.spp)
+    if env.rank == 0 and want_extras:
+        print(json.dumps(dict(line, partial="headline only; the complete line follows")), flush=True)
+    wall, skipped = {}, []
+
+    if want_extras:
         if env.world == 1:
-            r3 = run_uniform(env, "fille", 1024, 256, 0, 1, 0, args, one_spp=True)
-            e3 = r3["out"]
-            if not args.no_cpu_baseline:
-                from oracle.oracle import Oracle
-                b, e = band_of(1024, 8)
-                ref = Oracle().solve(r3["problem"].as_dict(), 1024, 1024, 256, r3["depth"], r3["eps"], pixel_begin=b, pixel_end=e,
-                                     threads=os.cpu_count() or 1)
-                e3["rel_l2_vs_oracle"] = rel_l2(r3["field"].cpu().numpy().reshape(-1, 3)[b:e], ref["field"])
-                e3["rel_l2_band"] = "rows %d..%d" % (b // 1024, e // 1024)
-            r3["it"].close()
-            extras["cfg3"] = e3
-            r4 = run_guided(env, "ladybug", 1024, 256, 256, 0, 1, 0, args)
-            e4 = r4["out"]
-            if uniform_field is not None:
-                # the guided estimator is unbiased: its field agrees with the uniform integrator's
-                # (bit-exact against the oracle above) up to the Monte-Carlo noise of 256 spp
-                e4["rel_l2_vs_uniform_field"] = rel_l2(r4["field"].cpu().numpy(), uniform_field.cpu().numpy())
-            extras["cfg4"] = e4
-            # the same configuration with the reference's half-precision network (tolerance-gated mode)
-            r4h = run_guided(env, "ladybug", 1024, 256, 256, 0, 1, 0, args, precision=16)
-            e4h = r4h["out"]
-            if uniform_field is not None:
-                e4h["rel_l2_vs_uniform_field"] = rel_l2(r4h["field"].cpu().numpy(), uniform_field.cpu().numpy())
-            extras["cfg4_f16"] = e4h
-            # the same in the opt-in reordered training order (sixteen samples per training launch; cfg4 / cfg4_f16 above stay exact-order)
-            r4p = run_guided(env, "ladybug", 1024, 256, 256, 0, 1, 0, args, precision=16, order=REORDERED)
-            e4p = r4p["out"]
-            if uniform_field is not None:
-                e4p["rel_l2_vs_uniform_field"] = rel_l2(r4p["field"].cpu().numpy(), uniform_field.cpu().numpy())
-            extras["cfg4_f16_pipelined"] = e4p
-            extras["uniform3d"] = run_uniform3d(env, args)
-            extras["guided3d"] = run_guided3d(env, args)
-            extras["mesh_build3"] = run_mesh_build3(env)
-            extras["neumann2d"] = run_neumann2d(env, args)
-            extras["guiding_gain"] = run_guiding_gain(env)
-            if uniform_field is not None:
+            fields = {}
+
+            def cfg3():
+                r3 = run_uniform(env, "fille", 1024, 256, 0, 1, 0, args, one_spp=True)
+                e3 = r3["out"]
+                if not args.no_cpu_baseline:
+                    from oracle.oracle import Oracle
+                    b, e = band_of(1024, 4)
+                    ref = Oracle().solve(r3["problem"].as_dict(), 1024, 1024, 256, r3["depth"], r3["eps"], pixel_begin=b, pixel_end=e,
+                                         threads=os.cpu_count() or 1)
+                    e3["rel_l2_vs_oracle"] = rel_l2(r3["field"].cpu().numpy().reshape(-1, 3)[b:e], ref["field"])
+                    e3["rel_l2_band"] = "rows %d..%d" % (b // 1024, e // 1024)
+                r3["it"].close()
+                return e3
+
+            def cfg4(tag, **kw):
+                def run():
+                    r4 = run_guided(env, "ladybug", 1024, 256, 256, 0, 1, 0, args, **kw)
+                    e4 = r4["out"]
+                    fields[tag] = r4["field"].cpu().numpy()
+                    if uniform_field is not None:
+                        # the guided estimator is unbiased: its field agrees with the uniform integrator's
+                        # (bit-exact against the oracle above) up to the Monte-Carlo noise of 256 spp
+                        e4["rel_l2_vs_uniform_field"] = rel_l2(fields[tag], uniform_field.cpu().numpy())
+                    return e4
+                return run
+
+            def variance_check():
                 # SURVEY 8c, guided gate: against a 4096-spp field of the uniform integrator (bit-exact against the
                 # oracle at any spp) the guided estimator must not be noisier than the uniform one at equal spp
                 from elaina_amd import UniformIntegrator, UniformIntegratorSettings
@@ -770,17 +773,43 @@ def main():
                 env.torch.cuda.synchronize()
                 itr.close()
                 refn = ref.cpu().numpy()
-                extras["variance_check"] = {
-                    "reference": "ladybug 1024x1024, uniform integrator, 4096 spp",
-                    "rel_l2_uniform_256spp": rel_l2(uniform_field.cpu().numpy(), refn),
-                    "rel_l2_guided_256spp": rel_l2(r4["field"].cpu().numpy(), refn),
-                    "rel_l2_guided_f16_256spp": rel_l2(r4h["field"].cpu().numpy(), refn),
-                    "rel_l2_guided_f16_pipelined_256spp": rel_l2(r4p["field"].cpu().numpy(), refn)}
+                out = {"reference": "ladybug 1024x1024, uniform integrator, 4096 spp",
+                       "rel_l2_uniform_256spp": rel_l2(uniform_field.cpu().numpy(), refn)}
+                for tag, key in (("cfg4", "guided"), ("cfg4_f16", "guided_f16"), ("cfg4_f16_pipelined", "guided_f16_pipelined")):
+                    if tag in fields:
+                        out["rel_l2_%s_256spp" % key] = rel_l2(fields[tag], refn)
+                return out
+
+            todo = [("cfg3", cfg3), ("cfg4", cfg4("cfg4")),
+                    # the same configuration with the reference's half-precision network (tolerance-gated mode)
+                    ("cfg4_f16", cfg4("cfg4_f16", precision=16)),
+                    # the same in the opt-in reordered training order (sixteen samples per training launch; cfg4 / cfg4_f16 stay exact-order)
+                    ("cfg4_f16_pipelined", cfg4("cfg4_f16_pipelined", precision=16, order=REORDERED)),
+                    ("uniform3d", lambda: run_uniform3d(env, args)), ("guided3d", lambda: run_guided3d(env, args)),
+                    ("neumann2d", lambda: run_neumann2d(env, args)), ("mesh_build3", lambda: run_mesh_build3(env)),
+                    ("guiding_gain", lambda: run_guiding_gain(env))]
+            if uniform_field is not None:
+                todo.append(("variance_check", variance_check))
         else:
-            r5 = run_guided(env, "ladybug", 2048, 1024, 256, 0, 1, 0, args)
-            extras["cfg5"] = r5["out"]
-            r5h = run_guided(env, "ladybug", 2048, 1024, 256, 0, 1, 0, args, precision=16)
-            extras["cfg5_f16"] = r5h["out"]
+            todo = [("cfg5", lambda: run_guided(env, "ladybug", 2048, 1024, 256, 0, 1, 0, args)["out"]),
+                    ("cfg5_f16", lambda: run_guided(env, "ladybug", 2048, 1024, 256, 0, 1, 0, args, precision=16)["out"])]
+        for name, fn in todo:
+            go = time.time() - T_START <= args.budget_s
+            if env.world > 1:
+                # every rank takes rank 0's decision, or a skipped collective would hang the others
+                flag = env.torch.tensor([1 if go else 0], device="cuda")
+                env.dist.broadcast(flag, 0)
+                go = bool(int(flag.item()))
+            if not go:
+                skipped.append(name)
+                continue
+            t0 = time.time()
+            extras[name] = fn()
+            wall[name] = round(time.time() - t0, 1)
+            print("bench extra %s: %.1f s (%.0f s since start)" % (name, wall[name], time.time() - T_START), file=sys.stderr, flush=True)
+        extras["wall_s"] = wall
+        if skipped:
+            extras["skipped"] = {"names": skipped, "why": "would have started past --budget-s %g of wall clock" % args.budget_s}
     if env.rank == 0:
         if extras:
             line["configs"] = extras

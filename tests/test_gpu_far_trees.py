@@ -1,29 +1,54 @@
 """Tree-sized boundary meshes FAR from the origin (the class of scene the ray / box rounding bug of round 3, c5eaca1, came from):
 
 * tools/fuzz/fuzz_far_trees.py -- Neumann meshes of 5 000 .. 30 000 primitives, closed and open, emissive and not, the whole
-  scene 10 .. 300 scene sizes away -- through the guided 2-D, the uniform 3-D and the guided 3-D kernels, 40 seeds each,
-  bit for bit against the oracle;
+  scene 10 .. 300 scene sizes away -- through the guided 2-D, the uniform 3-D and the guided 3-D kernels, 40 seeds each with a
+  frozen network and 10 seeds each with trainSppCount >= 2 (records, Adam / EMA steps, the trained network's walks), bit for bit
+  against the oracle.  The oracle half of every seed (fields, counters, final parameters) is the committed fixture
+  tests/golden/far_trees_<mode>.npz, written in the build container by `fuzz_far_trees.py golden <mode>`; the GPU box regenerates
+  the scene from the seed, runs HIP and compares -- none of the oracle's CPU time (10 - 17 s a guided seed) inside the GPU suite;
 * the batch ray queries (ray_kernel / ray3_kernel behind wost_ray_intersect / wost3_ray_intersect) with origins ON the mesh
   at 1 .. 10^4 mesh extents from the origin against BRUTE FORCE: the oracle's ray queries are plain loops over every
   primitive (oracle/wost_oracle.c ray_closest, wost_oracle3d.c ray_closest3), no tree of its own that could share a flaw.
 """
 import os
-import subprocess
 import sys
 
 import numpy as np
 import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "tools", "fuzz"))
+
+MODES = ["guided2d", "uniform3d", "guided3d", "guided2d_train", "guided3d_train"]
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_far_tree_fixtures_hold_every_seed(mode):
+    """(CPU) the fixture is there, holds the seeds the mode asks for, and -- spot check, seed 0 of the cheap mode -- is what the
+    oracle computes today"""
+    import fuzz_far_trees as F
+    g = np.load(F.golden_path(mode))
+    n = int(g["count"])
+    assert n == F.DEFAULT_COUNT[mode] and str(g["mode"]) == mode
+    for seed in range(n):
+        c = F.CASES[mode](seed) if seed < 2 else None
+        assert g["field_%d" % seed].dtype == np.float32 and g["counters_%d" % seed].dtype == np.uint64
+        if c is not None:
+            assert g["field_%d" % seed].shape == (c["w"] * c["h"], 3) and len(g["counters_%d" % seed]) == len(c["keys"])
+    if mode == "uniform3d":
+        from oracle.oracle import Oracle
+        c = F.CASES[mode](0)
+        r = F.oracle_run(Oracle(), c)
+        assert np.array_equal(r["field"], g["field_0"], equal_nan=True) and np.array_equal(r["counters"], g["counters_0"])
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["guided2d", "uniform3d", "guided3d"])
+@pytest.mark.parametrize("mode", MODES)
 def test_gpu_tree_sized_neumann_meshes_far_from_the_origin(mode):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz", "fuzz_far_trees.py"), mode, "0", "40"], capture_output=True,
-                         text=True, timeout=2400, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-3000:]
-    assert "fuzz far trees %s 0..39: 0 mismatches" % mode in out.stdout, out.stdout[-3000:]
+    import fuzz_far_trees as F
+    bad, n = F.check_golden(mode)
+    assert n == F.DEFAULT_COUNT[mode]
+    assert not bad, bad[:5]
 
 
 @pytest.mark.gpu

@@ -9,7 +9,18 @@ integrator, HIP against the oracle bit for bit (fields and counters).
   solve   small frames and few samples (the oracle answers every query on the CPU), a frozen random network with pronounced
           lobes for the guided integrators (training on scenes of this size is the business of the other fuzzers).
 
-usage: fuzz_far_trees.py <guided2d | uniform3d | guided3d> [first seed] [count]"""
+  trained the *_train modes run the guided integrators with trainSppCount >= 2 on the same class of scene: training records, the
+          Adam / EMA steps and the trained network's walks (rows a26 - a27), the final parameters compared as well.
+
+Every mode is a pair of halves over one `case` (scene + settings + initial parameters, all from the seed): oracle_run() needs no
+GPU, hip_run() needs no oracle.  `golden` writes the oracle half of the seeds to tests/golden/far_trees_<mode>.npz in the build
+container; tests/test_gpu_far_trees.py runs the HIP half on the GPU box against that file -- the same seeds, none of the oracle's
+CPU time inside the GPU suite.
+
+usage: fuzz_far_trees.py <mode> [first seed] [count [seconds [log]]]       both halves live (needs GPU + oracle)
+       fuzz_far_trees.py golden <mode> [count]                             write the fixture (oracle only)
+       fuzz_far_trees.py check <mode>                                      HIP against the fixture (GPU only)
+modes: guided2d uniform3d guided3d guided2d_train guided3d_train"""
 import os
 import sys
 
@@ -19,7 +30,6 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..",
 sys.path.insert(0, os.path.dirname(__file__))
 import bench  # noqa: E402
 from fuzz_parity import polyline  # noqa: E402
-from oracle.oracle import Oracle, default_net_config, default_net_config3, guided_settings, guided_settings3  # noqa: E402
 
 COUNTERS = ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated", "neumann_hits")
 
@@ -52,32 +62,6 @@ def rand_params(n, n_mlp, rng, wscale=0.3, gscale=1.0):
     return p
 
 
-def guided2d(oracle, seed):
-    from elaina_amd import Problem
-    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
-    rng = np.random.default_rng(70_000 + seed)
-    kw, scale, off, feat = scene2d(rng)
-    p = Problem(**kw)
-    w, h, spp, depth = 16, 12, int(rng.choice([2, 3])), int(rng.choice([12, 32]))
-    eps = scale * 10.0 ** rng.uniform(-3.5, -2)
-    aabb = ((float(off[0] - 1.3 * scale), float(off[1] - 1.3 * scale)), (float(off[0] + 1.3 * scale), float(off[1] + 1.3 * scale)))
-    uf = float(rng.choice([0.0, 0.5]))
-    st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=0, maxWalkingDepth=depth, epsilonShell=eps,
-                                  uniformFractionInTrainingPhase=uf, uniformFractionInGuidingPhase=uf)
-    gi = GuidedIntegrator(p, st, aabb, seed=7)
-    cfg = default_net_config()
-    prm = rand_params(gi.network.n_params, gi.network.n_mlp_params, rng)
-    gi.network.set_params(prm)
-    gi.solve()
-    gs = guided_settings(w, h, spp, depth, eps, aabb[0], aabb[1], train_spp_count=0, uniform_fraction=(uf, uf))
-    ref = oracle.solve_guided(p.as_dict(), gs, cfg, prm.copy(), threads=os.cpu_count() or 8, dump_spp=-1)
-    s = gi.last_stats
-    keys = COUNTERS + ("guided_steps",)
-    ok = all(s[k] == ref[k] for k in keys) and np.array_equal(gi.solution, ref["field"], equal_nan=True)
-    gi.close()
-    return ok, "scale %.3g frame %dx%d spp %d depth %d uf %g" % (scale, w, h, spp, depth, uf), feat, {k: (s[k], ref[k]) for k in keys if s[k] != ref[k]}
-
-
 def scene3d(rng):
     scale = 10.0 ** rng.uniform(-1, 2)
     subdiv = int(rng.choice([4, 4, 5]))                    # 5 120 / 20 480 triangles
@@ -107,48 +91,214 @@ def scene3d(rng):
     return sd, scale, off, feat
 
 
-def uniform3d(oracle, seed):
-    from elaina_amd import UniformIntegratorSettings
-    from elaina_amd.integrator3d import Problem3, UniformIntegrator3
+def net_counts(cfg, dims):
+    """(n_params, n_mlp_params) of the guiding network: the layout of oracle/wost_net.c layout_d restated on the host in fp32
+    (checked against the library's own count on both sides: Oracle.net*_n_params when a fixture is written, wost_net_n_params
+    when HIP runs)"""
+    f32 = np.float32
+    log2s = np.log2(f32(cfg.per_level_scale), dtype=f32)
+    entries = 0
+    for i in range(cfg.n_levels):
+        scale = f32(np.exp2(f32(i) * log2s, dtype=f32) * f32(cfg.base_resolution)) - f32(1.0)
+        res = int(np.ceil(scale)) + 1
+        entries += (res ** dims + 7) // 8 * 8
+    enc = cfg.n_levels * cfg.n_features
+    n_mlp = cfg.n_neurons * enc + (cfg.n_hidden_layers - 1) * cfg.n_neurons * cfg.n_neurons + cfg.n_output_padded * cfg.n_neurons
+    return n_mlp + entries * cfg.n_features, n_mlp
+
+
+class NetCfg:
+    """the network configuration as plain numbers (data/ladybug/n.json:49-81 of the reference + guided/parameters.h:16-33); both
+    libraries' NetConfig structs are made from it, so neither half of a case imports the other's"""
+    def __init__(self, n_output, n_levels=8):
+        self.n_levels, self.n_features, self.base_resolution, self.per_level_scale = n_levels, 4, 8, 1.4049999713897705
+        self.n_neurons, self.n_hidden_layers, self.n_output, self.n_output_padded = 64, 3, n_output, 48
+        self.learning_rate, self.beta1, self.beta2 = 0.00800000037997961, 0.8999999761581421, 0.9900000095367432
+        self.epsilon, self.l2_reg, self.ema_decay = 1.0000000036274937e-15, 9.999999974752427e-07, 0.949999988079071
+
+    def oracle(self):
+        from oracle.oracle import NetConfig
+        return NetConfig(self.n_levels, self.n_features, self.base_resolution, self.per_level_scale, self.n_neurons, self.n_hidden_layers,
+                         self.n_output, self.n_output_padded, self.learning_rate, self.beta1, self.beta2, self.epsilon, self.l2_reg,
+                         self.ema_decay)
+
+    def hip(self):
+        from elaina_amd import capi
+        return capi.NetConfig(self.n_levels, self.n_features, self.base_resolution, self.per_level_scale, self.n_neurons,
+                              self.n_hidden_layers, self.n_output, self.learning_rate, self.beta1, self.beta2, self.epsilon, self.l2_reg,
+                              self.ema_decay)
+
+
+GUIDED_KEYS = COUNTERS + ("guided_steps",)
+TRAIN_KEYS = GUIDED_KEYS + ("train_samples", "optimizer_steps")
+
+
+def case_guided2d(seed, train=False):
+    rng = np.random.default_rng((75_000 if train else 70_000) + seed)
+    kw, scale, off, feat = scene2d(rng)
+    c = dict(dims=2, scene=kw, scale=scale, feat=feat, w=16, h=12, spp=int(rng.choice([2, 3])), depth=int(rng.choice([12, 32])))
+    c["eps"] = scale * 10.0 ** rng.uniform(-3.5, -2)
+    c["aabb"] = ((float(off[0] - 1.3 * scale), float(off[1] - 1.3 * scale)), (float(off[0] + 1.3 * scale), float(off[1] + 1.3 * scale)))
+    uf = float(rng.choice([0.0, 0.5]))
+    c["uf"], c["train"], c["keys"], c["cfg"] = (uf, uf), 0, GUIDED_KEYS, NetCfg(33)
+    if train:
+        c.update(w=24, h=16, spp=int(rng.choice([3, 4])), train=int(rng.choice([2, 3])), keys=TRAIN_KEYS,
+                 uf=(float(rng.choice([0.5, 1.0])), float(rng.choice([0.0, 0.5]))), batch=(512, 128))
+    n, n_mlp = net_counts(c["cfg"], 2)
+    c["params"] = rand_params(n, n_mlp, rng, *((0.15, 0.5) if train else (0.3, 1.0)))
+    c["what"] = "scale %.3g frame %dx%d spp %d train %d depth %d uf %g %g" % (scale, c["w"], c["h"], c["spp"], c["train"], c["depth"], *c["uf"])
+    return c
+
+
+def case_uniform3d(seed):
     rng = np.random.default_rng(80_000 + seed)
     sd, scale, off, feat = scene3d(rng)
-    w, h, spp, depth = 12, 8, int(rng.choice([1, 2])), int(rng.choice([8, 24]))
-    eps = scale * 10.0 ** rng.uniform(-3.5, -2)
-    it = UniformIntegrator3(Problem3.from_dict(sd), UniformIntegratorSettings((w, h), spp, depth, eps))
-    it.solve()
-    ref = oracle.solve3(sd, w, h, spp, depth, eps, threads=os.cpu_count() or 8)
-    s = it.last_stats
-    ok = all(s[k] == ref[k] for k in COUNTERS) and np.array_equal(it.solution.reshape(-1, 3), ref["field"], equal_nan=True)
-    it.close()
-    return ok, "scale %.3g frame %dx%d spp %d depth %d" % (scale, w, h, spp, depth), feat, {k: (s[k], ref[k]) for k in COUNTERS if s[k] != ref[k]}
+    c = dict(dims=3, scene=sd, scale=scale, feat=feat, w=12, h=8, spp=int(rng.choice([1, 2])), depth=int(rng.choice([8, 24])), keys=COUNTERS,
+             params=None, train=0)
+    c["eps"] = scale * 10.0 ** rng.uniform(-3.5, -2)
+    c["what"] = "scale %.3g frame %dx%d spp %d depth %d" % (scale, c["w"], c["h"], c["spp"], c["depth"])
+    return c
 
 
-def guided3d(oracle, seed):
-    from elaina_amd import capi
-    from elaina_amd.guided import GuidedIntegratorSettings
-    from elaina_amd.integrator3d import GuidedIntegrator3, Problem3
-    rng = np.random.default_rng(90_000 + seed)
+def case_guided3d(seed, train=False):
+    rng = np.random.default_rng((95_000 if train else 90_000) + seed)
     sd, scale, off, feat = scene3d(rng)
-    w, h, spp, depth = 10, 8, 2, int(rng.choice([8, 20]))
-    eps = scale * 10.0 ** rng.uniform(-3.5, -2)
-    aabb = (tuple(float(o - 1.3 * scale) for o in off), tuple(float(o + 1.3 * scale) for o in off))
+    c = dict(dims=3, scene=sd, scale=scale, feat=feat, w=10, h=8, spp=2, depth=int(rng.choice([8, 20])))
+    c["eps"] = scale * 10.0 ** rng.uniform(-3.5, -2)
+    c["aabb"] = (tuple(float(o - 1.3 * scale) for o in off), tuple(float(o + 1.3 * scale) for o in off))
     uf = float(rng.choice([0.0, 0.5]))
-    cfg = default_net_config3(n_levels=4)                # four levels keep the dense 3-D grid small; the code path is the same for eight
-    hip_cfg = capi.NetConfig(cfg.n_levels, cfg.n_features, cfg.base_resolution, cfg.per_level_scale, cfg.n_neurons, cfg.n_hidden_layers,
-                             cfg.n_output, cfg.learning_rate, cfg.beta1, cfg.beta2, cfg.epsilon, cfg.l2_reg, cfg.ema_decay)
-    st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=0, maxWalkingDepth=depth, epsilonShell=eps,
-                                  uniformFractionInTrainingPhase=uf, uniformFractionInGuidingPhase=uf)
-    gi = GuidedIntegrator3(Problem3.from_dict(sd), st, aabb, network_config=hip_cfg, seed=7)
-    prm = rand_params(gi.network.n_params, gi.network.n_mlp_params, rng)
-    gi.network.set_params(prm)
+    # four levels keep the dense 3-D grid small; the code path is the same for eight
+    c["uf"], c["train"], c["keys"], c["cfg"] = (uf, uf), 0, GUIDED_KEYS, NetCfg(41, n_levels=4)
+    if train:
+        c.update(w=16, h=12, spp=int(rng.choice([3, 4])), train=int(rng.choice([2, 3])), keys=TRAIN_KEYS,
+                 uf=(float(rng.choice([0.5, 1.0])), float(rng.choice([0.0, 0.5]))), batch=(256, 128))
+    n, n_mlp = net_counts(c["cfg"], 3)
+    c["params"] = rand_params(n, n_mlp, rng, *((0.15, 0.5) if train else (0.3, 1.0)))
+    c["what"] = "scale %.3g frame %dx%d spp %d train %d depth %d uf %g %g" % (scale, c["w"], c["h"], c["spp"], c["train"], c["depth"], *c["uf"])
+    return c
+
+
+CASES = {"guided2d": case_guided2d, "uniform3d": case_uniform3d, "guided3d": case_guided3d,
+         "guided2d_train": lambda seed: case_guided2d(seed, True), "guided3d_train": lambda seed: case_guided3d(seed, True)}
+DEFAULT_COUNT = {"guided2d": 40, "uniform3d": 40, "guided3d": 40, "guided2d_train": 10, "guided3d_train": 10}
+
+
+def _result(c, field, stats, params):
+    """what the two halves are compared on: the field (bits), the counters, and for a trained case the final parameters"""
+    r = {"field": np.ascontiguousarray(field, np.float32).reshape(-1, 3).copy(), "counters": np.asarray([stats[k] for k in c["keys"]], np.uint64)}
+    if c["train"]:
+        r["params"] = np.ascontiguousarray(params, np.float32).copy()
+    return r
+
+
+def oracle_run(oracle, c):
+    from oracle.oracle import guided_settings, guided_settings3
+    threads = os.cpu_count() or 8
+    if c["params"] is None:
+        ref = oracle.solve3(c["scene"], c["w"], c["h"], c["spp"], c["depth"], c["eps"], threads=threads)
+        return _result(c, ref["field"], ref, None)
+    cfg = c["cfg"].oracle()
+    n = (oracle.net_n_params if c["dims"] == 2 else oracle.net3_n_params)(cfg)
+    assert n == c["params"].size, (n, c["params"].size)
+    kw = dict(train_spp_count=c["train"], uniform_fraction=c["uf"])
+    if c["train"]:
+        kw.update(batch_size=c["batch"][0], min_batch_size=c["batch"][1])
+    prm = c["params"].copy()
+    if c["dims"] == 2:
+        from elaina_amd import Problem
+        gs = guided_settings(c["w"], c["h"], c["spp"], c["depth"], c["eps"], c["aabb"][0], c["aabb"][1], **kw)
+        ref = oracle.solve_guided(Problem(**c["scene"]).as_dict(), gs, cfg, prm, threads=threads, dump_spp=-1)
+    else:
+        gs = guided_settings3(c["w"], c["h"], c["spp"], c["depth"], c["eps"], c["aabb"][0], c["aabb"][1], **kw)
+        ref = oracle.solve_guided3(c["scene"], gs, cfg, prm, threads=threads, dump_spp=-1)
+    return _result(c, ref["field"], ref, prm)
+
+
+def hip_run(c):
+    from elaina_amd import UniformIntegratorSettings
+    if c["params"] is None:
+        from elaina_amd.integrator3d import Problem3, UniformIntegrator3
+        it = UniformIntegrator3(Problem3.from_dict(c["scene"]), UniformIntegratorSettings((c["w"], c["h"]), c["spp"], c["depth"], c["eps"]))
+        it.solve()
+        r = _result(c, it.solution, it.last_stats, None)
+        it.close()
+        return r
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    kw = dict(frameSize=(c["w"], c["h"]), samplesPerPixel=c["spp"], trainSppCount=c["train"], maxWalkingDepth=c["depth"], epsilonShell=c["eps"],
+              uniformFractionInTrainingPhase=c["uf"][0], uniformFractionInGuidingPhase=c["uf"][1])
+    if c["train"]:
+        kw.update(batchSize=c["batch"][0], minBatchSize=c["batch"][1])
+    st = GuidedIntegratorSettings(**kw)
+    if c["dims"] == 2:
+        from elaina_amd import Problem
+        gi = GuidedIntegrator(Problem(**c["scene"]), st, c["aabb"], seed=7)
+    else:
+        from elaina_amd.integrator3d import GuidedIntegrator3, Problem3
+        gi = GuidedIntegrator3(Problem3.from_dict(c["scene"]), st, c["aabb"], network_config=c["cfg"].hip(), seed=7)
+    assert (gi.network.n_params, gi.network.n_mlp_params) == net_counts(c["cfg"], c["dims"])
+    gi.network.set_params(c["params"])
     gi.solve()
-    gs = guided_settings3(w, h, spp, depth, eps, aabb[0], aabb[1], train_spp_count=0, uniform_fraction=(uf, uf))
-    ref = oracle.solve_guided3(sd, gs, cfg, prm.copy(), threads=os.cpu_count() or 8, dump_spp=-1)
-    s = gi.last_stats
-    keys = COUNTERS + ("guided_steps",)
-    ok = all(s[k] == ref[k] for k in keys) and np.array_equal(gi.solution, ref["field"], equal_nan=True)
+    r = _result(c, gi.solution, gi.last_stats, gi.network.params() if c["train"] else None)
     gi.close()
-    return ok, "scale %.3g frame %dx%d spp %d depth %d uf %g" % (scale, w, h, spp, depth, uf), feat, {k: (s[k], ref[k]) for k in keys if s[k] != ref[k]}
+    return r
+
+
+def same(c, a, b):
+    """the mismatch description of two results, or None"""
+    diff = {k: (int(x), int(y)) for k, x, y in zip(c["keys"], a["counters"], b["counters"]) if x != y}
+    if not np.array_equal(a["field"], b["field"], equal_nan=True):
+        diff["field"] = int((a["field"].view(np.uint32) != b["field"].view(np.uint32)).sum())
+    if c["train"] and not np.array_equal(a["params"], b["params"], equal_nan=True):
+        diff["params"] = int((a["params"].view(np.uint32) != b["params"].view(np.uint32)).sum())
+    return diff or None
+
+
+def golden_path(mode):
+    return os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", "tests", "golden", "far_trees_%s.npz" % mode))
+
+
+def write_golden(mode, count):
+    """the oracle half of seeds 0 .. count-1 -> tests/golden/far_trees_<mode>.npz (fields are a few KB per seed; a trained case
+    keeps its final parameters as 64-bit sums of their bit patterns per 1024-parameter block, plus the first 256 values)"""
+    import time
+    from oracle.oracle import Oracle
+    oracle = Oracle()
+    out = {"count": np.asarray(count), "mode": np.asarray(mode)}
+    t0 = time.time()
+    for seed in range(count):
+        c = CASES[mode](seed)
+        r = oracle_run(oracle, c)
+        out["field_%d" % seed], out["counters_%d" % seed] = r["field"], r["counters"]
+        if c["train"]:
+            out["params_sums_%d" % seed], out["params_head_%d" % seed] = param_sums(r["params"]), r["params"][:256].copy()
+        print("%s seed %d: %s %s counters %s (%.1fs)" % (mode, seed, c["what"], c["feat"], r["counters"].tolist(), time.time() - t0), flush=True)
+    np.savez_compressed(golden_path(mode), **out)
+    print("wrote %s (%d bytes)" % (golden_path(mode), os.path.getsize(golden_path(mode))))
+
+
+def param_sums(p):
+    bits = np.ascontiguousarray(p, np.float32).view(np.uint32).astype(np.uint64)
+    pad = (-len(bits)) % 1024
+    return np.concatenate([bits, np.zeros(pad, np.uint64)]).reshape(-1, 1024).sum(1)
+
+
+def check_golden(mode, seeds=None):
+    """the HIP half of the fixture's seeds against the fixture: the list of (seed, what, features, differences)"""
+    g = np.load(golden_path(mode))
+    bad = []
+    for seed in (range(int(g["count"])) if seeds is None else seeds):
+        c = CASES[mode](seed)
+        r = hip_run(c)
+        ref = {"field": g["field_%d" % seed], "counters": g["counters_%d" % seed]}
+        diff = {k: (int(x), int(y)) for k, x, y in zip(c["keys"], r["counters"], ref["counters"]) if x != y}
+        if not np.array_equal(r["field"], ref["field"], equal_nan=True):
+            diff["field"] = int((r["field"].view(np.uint32) != ref["field"].view(np.uint32)).sum())
+        if c["train"] and not (np.array_equal(param_sums(r["params"]), g["params_sums_%d" % seed]) and
+                               np.array_equal(r["params"][:256], g["params_head_%d" % seed], equal_nan=True)):
+            diff["params"] = int((param_sums(r["params"]) != g["params_sums_%d" % seed]).sum())
+        if diff:
+            bad.append((seed, c["what"], c["feat"], diff))
+    return bad, int(g["count"]) if seeds is None else len(list(seeds))
 
 
 def main():
@@ -157,23 +307,32 @@ def main():
     per seed as it finishes (a run that is cut off still leaves its record)"""
     import time
     mode = sys.argv[1]
-    first, count = int(sys.argv[2]) if len(sys.argv) > 2 else 0, int(sys.argv[3]) if len(sys.argv) > 3 else 40
+    if mode == "golden":
+        return write_golden(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else DEFAULT_COUNT[sys.argv[2]])
+    if mode == "check":
+        bad, n = check_golden(sys.argv[2])
+        for b in bad:
+            print("seed %d MISMATCH (%s): %s" % (b[0], sys.argv[2], b[1]), b[2], b[3], flush=True)
+        print("fuzz far trees %s against the fixture, %d seeds: %d mismatches" % (sys.argv[2], n, len(bad)), flush=True)
+        return
+    from oracle.oracle import Oracle
+    first, count = int(sys.argv[2]) if len(sys.argv) > 2 else 0, int(sys.argv[3]) if len(sys.argv) > 3 else DEFAULT_COUNT[mode]
     seconds = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
     log = open(sys.argv[5], "a") if len(sys.argv) > 5 else None
-    run = {"guided2d": guided2d, "uniform3d": uniform3d, "guided3d": guided3d}[mode]
     oracle = Oracle()
     bad, done, t0 = 0, 0, time.time()
     for seed in range(first, first + count):
         if seconds > 0 and time.time() - t0 > seconds:
             break
-        ok, what, feat, diff = run(oracle, seed)
+        c = CASES[mode](seed)
+        diff = same(c, hip_run(c), oracle_run(oracle, c))
         done += 1
         if log:
-            log.write("%s seed %d %s %.1fs\n" % (mode, seed, "ok" if ok else "MISMATCH", time.time() - t0))
+            log.write("%s seed %d %s %.1fs\n" % (mode, seed, "ok" if diff is None else "MISMATCH", time.time() - t0))
             log.flush()
-        if not ok:
+        if diff is not None:
             bad += 1
-            print("seed %d MISMATCH (%s): %s" % (seed, mode, what), feat, diff, flush=True)
+            print("seed %d MISMATCH (%s): %s" % (seed, mode, c["what"]), c["feat"], diff, flush=True)
     print("fuzz far trees %s %d..%d: %d mismatches" % (mode, first, first + done - 1, bad), flush=True)
     if log:
         log.write("fuzz far trees %s %d..%d: %d mismatches\n" % (mode, first, first + done - 1, bad))

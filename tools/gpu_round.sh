@@ -2,12 +2,13 @@
 # one GPU-box trip: gpu tests, smoke, bench, rocprof kernel trace + PMC passes of the bench command.
 # TAG names the output directory under gpurun_out/; STAGES selects what runs (default: all).
 export TMPDIR=/tmp
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 STAGES=${STAGES:-"tests smoke micro bench trace pmc pmc_guided pmc3d pmc3d_1024 pmc_guided3d build3"}
 mkdir -p gpurun_out/$TAG
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 if has tests; then
-  python -m pytest tests -x -q -m gpu -rs 2>&1 | tail -25 | tee gpurun_out/$TAG/pytest_gpu.log
+  # the whole log with the slowest tests named: the driver's limit for this command is 1 200 s, ours 600 s
+  python -m pytest tests -x -q -m gpu -rs --durations=40 > gpurun_out/$TAG/pytest_gpu.log 2>&1; tail -60 gpurun_out/$TAG/pytest_gpu.log
   # a green run with skipped GPU tests is a broken environment, not a pass
   if grep -qE '[0-9]+ skipped' gpurun_out/$TAG/pytest_gpu.log; then echo "GPU TESTS WERE SKIPPED" | tee -a gpurun_out/$TAG/pytest_gpu.log; fi
 fi
