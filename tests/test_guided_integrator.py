@@ -904,10 +904,10 @@ def test_gpu_random_scenes_match_the_oracle():
     assert "fuzz guided 3..4: 0 mismatches" in out.stdout, out.stdout[-3000:]
     # the half-precision mode has no bit-exact oracle: on such scenes its fused launch must equal its own per-depth path
     # (fields, counters and the trained weights)
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz", "fuzz_guided.py"), "200", "30", "half"], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz", "fuzz_guided.py"), "200", "16", "half"], capture_output=True, text=True,
                          timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "fuzz guided 200..229: 0 mismatches" in out.stdout, out.stdout[-3000:]
+    assert "fuzz guided 200..215: 0 mismatches" in out.stdout, out.stdout[-3000:]
 
 
 # ---- the opt-in training orders (wost_guided_set_option "train_group", "pipeline"): never the parity mode ----------------
