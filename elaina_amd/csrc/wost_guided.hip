@@ -1211,6 +1211,18 @@ static hipError_t galloc(wost_guided *g, T **p, size_t count)
     return e;
 }
 
+// release one buffer of galloc before the handle goes (a buffer that is replaced by a larger one)
+static void gfree_one(wost_guided *g, void *p)
+{
+    if (!p) return;
+    for (size_t i = 0; i < g->allocs.size(); ++i)
+        if (g->allocs[i] == p) {
+            g->allocs.erase(g->allocs.begin() + (long)i);
+            (void)hipFree(p);
+            return;
+        }
+}
+
 static void guided_free(wost_guided *g)
 {
     if (!g) return;
@@ -1646,6 +1658,12 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         // one record set per sample of a training launch (201 MB each at 1024^2: sized for 288 GB of HBM)
         float *rec = nullptr;
         uint32_t *cd = nullptr;
+        // (the smaller set goes first: nothing on the device uses it between two solves, and group 16 would otherwise hold
+        // 3.2 GB next to the 201 MB it replaces until the handle is destroyed)
+        G_TRY(hipStreamSynchronize(stream));
+        gfree_one(g, g->rec);
+        gfree_one(g, g->cur_depth);
+        g->rec = nullptr; g->cur_depth = nullptr; g->rec_sets = 0;
         G_TRY(galloc(g, &rec, (size_t)kMaxTrainDepth * kRecFields * (size_t)N * group));
         G_TRY(galloc(g, &cd, (size_t)N * group));
         g->rec = rec; g->cur_depth = cd; g->rec_sets = group;
@@ -1679,6 +1697,12 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         }
         auto ts_of = [&](int j) -> const TrainSet & { return j == 0 ? g->ts : g->ts_more[(size_t)j - 1]; };
         hipStream_t B = g->train_stream;
+        // an error return below must not leave training passes in flight on the second stream behind the caller's back
+        struct DrainOnError {
+            hipStream_t s;
+            bool armed;
+            ~DrainOnError() { if (armed) (void)hipStreamSynchronize(s); }
+        } drain{B, true};
         FusedNet Fs[2] = {F, F};
         for (int k = 0; k < 2; ++k) {
             int rc = net_snapshot_dev(g->net, g->snap[k], stream);      // both copies start as the weights the solve starts with
@@ -1743,6 +1767,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
         // what follows (the guiding phase, the resolve) reads the network's own images
         G_TRY(hipStreamWaitEvent(stream, g->ev_train[(n_groups - 1) & 1], 0));
         G_TRY(hipStreamSynchronize(B));
+        drain.armed = false;
         train_ms += g->train_events.drain();
         sample0 = n_trained;
         d0_valid = true;
@@ -1781,6 +1806,7 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
                 if (const char *w = std::getenv("WOST_GUIDED_SAMPLES_PER_LAUNCH")) cap = std::max(1, std::atoi(w));
                 n_run = std::min(n_run, cap);
             }
+            n_run = std::min(n_run, 0xffff);      // a pixel's state word counts the samples of a launch in 16 bits (arrived << 16 | complete)
             n_run = (int)std::min<uint64_t>((uint64_t)n_run, std::max<uint64_t>(1, 0xffffffffull / (uint64_t)std::max(N, 1)));      // (items of a launch are counted in 32 bits)
             P.n_samples = n_run;
             P.d0_valid = d0_valid ? 1 : 0;

@@ -577,13 +577,16 @@ void read_hdr(const fs::path &path, int *width, int *height, std::vector<float> 
     long h = 0, w = 0;
     if (std::sscanf(res.c_str(), "-Y %ld +X %ld", &h, &w) != 2 || w <= 0 || h <= 0 || w > (1 << 24) || h > (1 << 24))
         throw std::runtime_error("hdr: only the -Y h +X w orientation is read: " + path.string());
-    std::vector<uint8_t> px((size_t)w * h * 4);
     auto need = [&](size_t n) { if (pos > b.size() || n > b.size() - pos) throw std::runtime_error("hdr: truncated file: " + path.string()); };
     bool flat = w < 8 || w >= 32768;
     if (!flat) {
         need(4);
         flat = b[pos] != 2 || b[pos + 1] != 2 || (b[pos + 2] & 0x80);      // no scan-line marker: flat pixels throughout
     }
+    // before anything is allocated from the header's numbers (each up to 2^24): the file must be able to hold the picture -- flat
+    // pixels whole, a run-length coded one at least its scan-line markers and two bytes per channel run (a run covers <= 127 pixels)
+    need(flat ? (size_t)w * (size_t)h * 4 : (size_t)h * (4 + 4 * 2 * (((size_t)w + 126) / 127)));
+    std::vector<uint8_t> px((size_t)w * h * 4);
     if (flat) {
         need(px.size());
         std::memcpy(px.data(), &b[pos], px.size());

@@ -390,6 +390,10 @@ def test_mask_images_of_every_readable_format(tmp_path):
     open(tmp_path / "cut.hdr", "wb").write((head + body)[:200])
     bad = subprocess.run([exe, "--readmask", str(tmp_path / "cut.hdr"), str(tmp_path / "m.raw")], capture_output=True, text=True)
     assert bad.returncode == 1 and "hdr" in bad.stderr
+    # a hundred bytes that claim 2^24 x 2^24 pixels: the clean "truncated file", not an allocation of 2^50 bytes
+    open(tmp_path / "huge.hdr", "wb").write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 16777216 +X 16777216\n" + b"\2\2\0\0" * 8)
+    bad = subprocess.run([exe, "--readmask", str(tmp_path / "huge.hdr"), str(tmp_path / "m.raw")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "truncated file" in bad.stderr
     open(tmp_path / "x.jpg", "wb").write(b"\xff\xd8\xff\xe0" + b"\0" * 64)
     bad = subprocess.run([exe, "--readmask", str(tmp_path / "x.jpg"), str(tmp_path / "m.raw")], capture_output=True, text=True)
     assert bad.returncode == 1 and "out of scope" in bad.stderr and "PNG" in bad.stderr
