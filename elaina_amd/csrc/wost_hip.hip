@@ -645,254 +645,6 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
 
 
 // ------------------------------------------------------------------------------------------
-// the walk round with TWO walkers per lane (round 5): lane fill
-// ------------------------------------------------------------------------------------------
-// walk_round_kernel's lanes idle in two ways: a lane whose query is finished waits for the wave's next step trip while the
-// others descend (traversal trips ran at 60 % fill on config 2), and a lane in mid-descent sits out the step trips (54 %).
-// Here a lane owns two queue slots -- two pixels, each with its own PCG stream, so interleaving them changes no number -- and
-// ONE descent at a time: while walker A waits for its step, the lane descends for walker B.  The record of the walker that is
-// not being stepped stays in registers (the walk state proper; x0 / y0 / the cached depth-0 query / the pixel index are re-read
-// from the input queue when a walk ends, once per ~7 steps); the traversal context (query point, Trav, stack column) exists
-// once.  A step trip serves, per lane, one walker with a finished query -- the older one first; the record to step is brought
-// into the registers the step code is compiled on by one swap of the two records.
-// Same step code (step_finish), same visits (trav_visit<false>), same queue records: the field, the counters and the queue
-// contents after a round are those of walk_round_kernel for any split of the work.  Ordinary launches only: flat Neumann
-// meshes, no source term, no refill / slack / thin waves (the host keeps walk_round_kernel and walk_quad_kernel for those).
-#ifndef WOST_PAIR_WAVES
-#define WOST_PAIR_WAVES 4       // waves per SIMD the pair kernel is compiled for: 128 registers for two records and one descent
-#endif
-struct PairRec {
-    float px, py;
-    Pcg rng;
-    uint32_t sample, depth;
-    bool on_n;
-    float nx, ny;
-    int32_t hint;
-    float thp;
-    float sr, sg, sb;
-};
-
-__device__ __forceinline__ void load_pair_rec(const WalkQueue &q, uint32_t slot, PairRec &R)
-{
-    R.px = q.px[slot]; R.py = q.py[slot];
-    R.rng.state = q.rng[slot]; R.rng.inc = 1;
-    const uint32_t m = q.meta[slot];
-    R.sample = META_SAMPLE(m); R.depth = META_DEPTH(m); R.on_n = META_ONN(m) != 0;
-    R.nx = q.nx[slot]; R.ny = q.ny[slot];
-    R.hint = q.hint[slot];
-    R.thp = q.thp[slot];
-    R.sr = q.sr[slot]; R.sg = q.sg[slot]; R.sb = q.sb[slot];
-}
-
-template <class T>
-__device__ __forceinline__ void swap_if(bool c, T &a, T &b)
-{
-    const T x = a, y = b;
-    a = c ? y : x;
-    b = c ? x : y;
-}
-
-__device__ __forceinline__ void swap_pair_recs(bool c, PairRec &A, PairRec &B)
-{
-    swap_if(c, A.px, B.px); swap_if(c, A.py, B.py);
-    swap_if(c, A.rng.state, B.rng.state);
-    swap_if(c, A.sample, B.sample); swap_if(c, A.depth, B.depth); swap_if(c, A.on_n, B.on_n);
-    swap_if(c, A.nx, B.nx); swap_if(c, A.ny, B.ny);
-    swap_if(c, A.hint, B.hint);
-    swap_if(c, A.thp, B.thp);
-    swap_if(c, A.sr, B.sr); swap_if(c, A.sg, B.sg); swap_if(c, A.sb, B.sb);
-}
-
-template <bool NEUMANN_EMISSIVE>
-__global__ __launch_bounds__(256, WOST_PAIR_WAVES) void walk_pair_kernel(RoundParams P)
-{
-    extern __shared__ uint32_t lds_stack[];
-    const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_in = *P.count_in;
-    const uint32_t half = (n_in + 1u) >> 1;      // record 0 <- slot tid, record 1 <- slot tid + half
-    const bool valid0 = tid < half, valid1 = tid + half < n_in;
-    // a walker is READY (its position has no query yet), in TRAVersal (at most one of the two), WAITs with a finished query
-    // for the step, is DONE for this round, or FAR (its query starts beyond the plain visits' range: left untouched for the
-    // slack launch, like walk_round_kernel's MODE_FAR)
-    enum { M_TRAV = 1, M_READY = 2, M_WAIT = 3, M_DONE = 4, M_FAR = 6 };
-    PairRec R0{}, R1{};
-    int m0 = M_DONE, m1 = M_DONE;
-    const uint32_t spp = (uint32_t)P.st.spp;
-    if (valid0) {
-        load_pair_rec(P.in, tid, R0);
-        m0 = R0.sample < spp ? M_READY : M_DONE;
-    }
-    if (valid1) {
-        load_pair_rec(P.in, tid + half, R1);
-        m1 = R1.sample < spp ? M_READY : M_DONE;
-    }
-    bool sw = false;             // the records are exchanged: R0 holds slot tid + half
-    int tb = 0;                  // the record T belongs to (in traversal, or the last one that was); the result of a WAITing
-    Closest bestp{WOST_INF, -1}; // record is T.best when it is record tb, bestp otherwise
-    float qx = 0.0f, qy = 0.0f;
-    Trav T = trav_begin(Closest{WOST_INF, -1});
-    LaneStats S{0, 0, 0, 0};
-    const bool has_d = P.dm.n_segs > 0;
-    int budget = 2 * P.steps_per_round;
-    uint32_t trav_trips = 0, step_trips = 0;
-    for (;;) {
-        // ---- the lane's descent is free and a walker is READY: start its query ----
-        {
-            const bool idle = m0 != M_TRAV && m1 != M_TRAV && budget > 0;
-            const bool start0 = idle && m0 == M_READY;
-            const bool start1 = idle && !start0 && m1 == M_READY;
-            if (__ballot(start0 || start1)) {
-                if (start0 || start1) {
-                    const int r = start1 ? 1 : 0;
-                    const int mo = start1 ? m0 : m1;
-                    if (mo == M_WAIT && tb != r) bestp = T.best;      // the other walker's result leaves T
-                    const float px = start1 ? R1.px : R0.px, py = start1 ? R1.py : R0.py;
-                    const uint32_t depth = start1 ? R1.depth : R0.depth;
-                    const int32_t hint = start1 ? R1.hint : R0.hint;
-                    int nm;
-                    if (!has_d || depth == 0) {
-                        // depth 0 starts at the same point for every sample of the pixel: cached by init_kernel
-                        const uint32_t slot = (r == 1) != sw ? tid + half : tid;
-                        S.a += 1u + ((depth == 0) ? 0x10000u : 0u);
-                        T.best = Closest{P.in.d0_d2[slot], P.in.d0_slot[slot]};
-                        nm = M_WAIT;
-                    } else {
-                        T = trav_begin(slot_candidate(P.dm, hint, px, py));
-                        if (T.best.d2 > P.dm.far2) {
-                            nm = M_FAR;
-                        } else {
-                            S.a += 1u;
-                            qx = px; qy = py;
-                            nm = M_TRAV;
-                        }
-                    }
-                    tb = r;
-                    m0 = start1 ? m0 : nm;
-                    m1 = start1 ? nm : m1;
-                }
-            }
-        }
-        const int n_trav = __popcll(__ballot(m0 == M_TRAV || m1 == M_TRAV));
-        const bool waits = m0 == M_WAIT || m1 == M_WAIT;
-        const int n_wait = __popcll(__ballot(waits));
-        if (n_trav + n_wait == 0) break;
-        if (n_wait * P.wait_weight >= n_trav * 8) {
-            // ---- step trip: one waiting walker per lane, the one whose query finished first ----
-            ++step_trips;
-            if (waits) {
-                const int other = tb ^ 1;
-                const int m_other = other ? m1 : m0;
-                const int s = m_other == M_WAIT ? other : tb;
-                const bool ex = s == 1;      // the step code runs on R0
-                swap_pair_recs(ex, R0, R1);
-                swap_if(ex, m0, m1);
-                tb = ex ? tb ^ 1 : tb;
-                sw = ex ? !sw : sw;
-                const Closest cp = tb == 0 ? T.best : bestp;
-                Lane L;
-                L.px = R0.px; L.py = R0.py; L.rng = R0.rng; L.sample = R0.sample; L.depth = R0.depth; L.on_n = R0.on_n;
-                L.nx = R0.nx; L.ny = R0.ny; L.hint = R0.hint; L.thp = R0.thp; L.sr = R0.sr; L.sg = R0.sg; L.sb = R0.sb;
-                const uint32_t status = step_finish<NEUMANN_EMISSIVE, false, false>(P.dm, P.nm, P.st, L, cp, stk, P.src);
-                R0.px = L.px; R0.py = L.py; R0.rng = L.rng; R0.depth = L.depth; R0.on_n = L.on_n;
-                R0.nx = L.nx; R0.ny = L.ny; R0.hint = L.hint; R0.thp = L.thp; R0.sr = L.sr; R0.sg = L.sg; R0.sb = L.sb;
-                S.b += ((status >> 1) & 1u) | (((status >> 2) & 1u) << 16);
-                S.c += (status >> 3) & 1u;
-                if ((status & STEP_ENDED) != 0u) {
-                    // next sample of this pixel starts right away (generateEvaluationPoints, reference integrator.cu:90-99)
-                    const uint32_t slot = sw ? tid + half : tid;
-                    R0.sample++;
-                    R0.px = P.in.x0[slot]; R0.py = P.in.y0[slot];
-                    R0.depth = 0; R0.on_n = false; R0.nx = 0.0f; R0.ny = 0.0f;
-                    R0.thp = 1.0f;
-                    R0.hint = P.in.d0_slot[slot];
-                }
-                --budget;
-                m0 = R0.sample < spp ? M_READY : M_DONE;
-            }
-        } else {
-            // ---- traversal trip: every descending lane visits up to three nodes ----
-            ++trav_trips;
-            bool trav = m0 == M_TRAV || m1 == M_TRAV;
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                if (trav) {
-                    S.visits++;
-                    if (!trav_visit<false>(P.dm, qx, qy, T, stk)) trav = false;
-                }
-            }
-            if (!trav) {
-                m0 = m0 == M_TRAV ? M_WAIT : m0;
-                m1 = m1 == M_TRAV ? M_WAIT : m1;
-            }
-        }
-    }
-    // ---- the records back in slot order ----
-    swap_pair_recs(sw, R0, R1);
-    swap_if(sw, m0, m1);
-    // ---- resolve finished pixels (reference integrator.cu:616-620), compact the survivors: the strayed ones from the far end ----
-    const bool alive0 = valid0 && R0.sample < spp, alive1 = valid1 && R1.sample < spp;
-    const float sppf = (float)P.st.spp;
-    uint32_t pix0 = 0, pix1 = 0;
-    if (valid0) pix0 = P.in.pix[tid];
-    if (valid1) pix1 = P.in.pix[tid + half];
-    if (valid0 && !alive0) {
-        float *f = P.field + 3 * (size_t)((int32_t)pix0 - P.field_base);
-        f[0] = R0.sr / sppf; f[1] = R0.sg / sppf; f[2] = R0.sb / sppf;
-    }
-    if (valid1 && !alive1) {
-        float *f = P.field + 3 * (size_t)((int32_t)pix1 - P.field_base);
-        f[0] = R1.sr / sppf; f[1] = R1.sg / sppf; f[2] = R1.sb / sppf;
-    }
-    const bool far0 = m0 == M_FAR, far1 = m1 == M_FAR;
-    uint32_t s0 = block_push(alive0 && !far0, P.count_out);
-    __syncthreads();      // block_push reuses its shared words
-    uint32_t s1 = block_push(alive1 && !far1, P.count_out);
-    __syncthreads();
-    const uint32_t k0 = block_push(alive0 && far0, P.count_far);
-    __syncthreads();
-    const uint32_t k1 = block_push(alive1 && far1, P.count_far);
-    if (far0) s0 = P.out_capacity - 1u - k0;
-    if (far1) s1 = P.out_capacity - 1u - k1;
-    auto store = [&](uint32_t s, uint32_t from, uint32_t pix, const PairRec &R) {
-        const WalkQueue &q = P.out;
-        q.pix[s] = pix;
-        q.x0[s] = P.in.x0[from]; q.y0[s] = P.in.y0[from];
-        q.px[s] = R.px; q.py[s] = R.py;
-        q.rng[s] = R.rng.state;
-        q.meta[s] = META_PACK(R.sample, R.depth, R.on_n ? 1 : 0);
-        q.nx[s] = R.nx; q.ny[s] = R.ny;
-        q.hint[s] = R.hint;
-        q.thp[s] = R.thp;
-        q.sr[s] = R.sr; q.sg[s] = R.sg; q.sb[s] = R.sb;
-        q.d0_d2[s] = P.in.d0_d2[from]; q.d0_slot[s] = P.in.d0_slot[from];
-    };
-    if (alive0) store(s0, tid, pix0, R0);
-    if (alive1) store(s1, tid + half, pix1, R1);
-    // ---- statistics: wave reduction, one atomic per counter per wave ----
-    const int lane = threadIdx.x & 63;
-    uint32_t v[6] = {S.a & 0xffffu, S.a >> 16, S.b & 0xffffu, S.b >> 16, S.c, S.visits};
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        uint32_t x = v[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-        v[k] = x;
-    }
-    if (lane == 0) {
-        StatsDev *st = my_stats(P.stats);
-        if (v[0]) atomicAdd(&st->steps, (unsigned long long)v[0]);
-        if (v[1]) atomicAdd(&st->started, (unsigned long long)v[1]);
-        if (v[2]) atomicAdd(&st->absorbed, (unsigned long long)v[2]);
-        if (v[3]) atomicAdd(&st->truncated, (unsigned long long)v[3]);
-        if (v[4]) atomicAdd(&st->nhits, (unsigned long long)v[4]);
-        if (v[5]) atomicAdd(&st->inner_visits, (unsigned long long)v[5]);
-        atomicAdd(&st->trav_trips, (unsigned long long)trav_trips);
-        atomicAdd(&st->step_trips, (unsigned long long)step_trips);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // the walk round of an under-filled launch: four lanes per walker (wost_quad.h)
 // ------------------------------------------------------------------------------------------
 // Same rounds, same queue records, same per-walker arithmetic as walk_round_kernel -- and so the same field, counters
@@ -1314,8 +1066,6 @@ struct wost_context {
     int refill = -1;       // -1 = automatic (few samples per pixel), 0 = never, 1 = always
     int quad = -1;         // four lanes per walker in under-filled launches: -1 = automatic, 0 = never, 1 = every ordinary round
     double quad_fill = 1.0;   // automatic: when 4 x walkers <= quad_fill x resident lanes
-    int pair = -1;         // two walkers per lane (walk_pair_kernel): -1 = automatic, 0 = never, 1 = every ordinary round it can serve
-    double pair_fill = 1.0;   // automatic: when walkers / 2 >= pair_fill x the lanes the pair kernel keeps resident
     int coop = 1;             // a Neumann mesh on the tree: its silhouette and ray queries by the wave as a whole (wost_coop.h); 0 = per lane
     int pool_cap = 0;         // ... tasks per pool and wave; 0 = automatic: 128 per level of the Neumann tree (a deeper tree keeps more tasks in flight)
     int ray_slot_trigger = 32;
@@ -1493,12 +1243,6 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "quad") {
         if (value != -1 && value != 0 && value != 1) return fail(WOST_ERR_INVALID, "quad must be -1 (auto), 0 or 1");
         h->quad = (int)value;
-    } else if (k == "pair") {
-        if (value != -1 && value != 0 && value != 1) return fail(WOST_ERR_INVALID, "pair must be -1, 0 or 1");
-        h->pair = (int)value;
-    } else if (k == "pair_fill") {
-        if (!(value > 0) || value > 64) return fail(WOST_ERR_INVALID, "pair_fill must be in (0, 64]");
-        h->pair_fill = value;
     } else if (k == "quad_fill") {
         if (!(value > 0) || value > 64) return fail(WOST_ERR_INVALID, "quad_fill must be in (0, 64]");
         h->quad_fill = value;
@@ -1698,7 +1442,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         const unsigned blocks_per_cu = std::max(1u, std::min(blocks_by_regs, blocks_by_lds));
         const unsigned resident_threads = (unsigned)c->n_cus * blocks_per_cu * (unsigned)bs;
         rp.lane_shift = 0;
-        if (c->thin_waves && c->pair != 1) {      // ("pair" 1 = every ordinary round on the pair kernel: tests)
+        if (c->thin_waves) {
             while (rp.lane_shift < 6 && ((uint64_t)n_active << (rp.lane_shift + 1)) <= resident_threads) ++rp.lane_shift;
             if (rp.lane_shift < 4) rp.lane_shift = 0;
         }
@@ -1721,7 +1465,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         }
         // Under-filled launch: four lanes per walker (walk_quad_kernel).  Such a launch lasts as long as its longest chain of
         // dependent node visits; sharing a descent between the lanes of a quad halves that chain.
-        const bool quad = !refill && n_active > 0 && c->pair != 1 &&
+        const bool quad = !refill && n_active > 0 &&
                           (c->quad == 1 || (c->quad == -1 && 4.0 * (double)n_active <= c->quad_fill * (double)resident_threads));
         // (the last strayed walkers can outlive the ordinary queue: then only their launch runs)
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
@@ -1734,18 +1478,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
             launch_quad(has_src, ntree, emissive, grid, bs, (size_t)stack_depth * (bs / 4) * sizeof(uint32_t), stream, rp);
             HIP_TRY(hipGetLastError());
         } else if (n_active > 0) {
-            // Full launches: two walkers per lane (walk_pair_kernel) -- a lane descends for one while the other waits for its
-            // step.  Flat Neumann meshes without a source term only; 16-bit lane counters hold both walkers' steps.
-            const unsigned pair_resident = (unsigned)c->n_cus * (unsigned)(WOST_PAIR_WAVES * 4 * 64);
-            const bool can_pair = !ntree && !has_src && !refill && rp.lane_shift == 0 && bs == 256 && 2 * (int64_t)rp.steps_per_round <= 32767;
-            const bool pair = can_pair && (c->pair == 1 || (c->pair == -1 && (double)(n_active / 2) >= c->pair_fill * (double)pair_resident));
-            if (pair) {
-                const unsigned pgrid = (unsigned)(((n_active + 1u) / 2u + bs - 1) / bs);
-                if (emissive) hipLaunchKernelGGL((walk_pair_kernel<true>), dim3(pgrid), dim3(bs), lds, stream, rp);
-                else hipLaunchKernelGGL((walk_pair_kernel<false>), dim3(pgrid), dim3(bs), lds, stream, rp);
-            } else {
-                launch_round<false>(has_src, refill, ntree, emissive, grid, bs, lds_round, stream, rp);
-            }
+            launch_round<false>(has_src, refill, ntree, emissive, grid, bs, lds_round, stream, rp);
             HIP_TRY(hipGetLastError());
         }
         if (pending_far > 0) HIP_TRY(hipStreamWaitEvent(stream, c->far_ev1, 0));

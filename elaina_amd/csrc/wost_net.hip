@@ -393,7 +393,11 @@ __global__ __launch_bounds__(NT) void net_forward_mfma_kernel(NetLayout L, const
 // and receives D[r = 16 rt + 4g + c][point i], so the accumulators of row tile rt ARE the B
 // operand of k-tile kt = rt of the next layer, and lane (i, g) encodes exactly the grid levels
 // g and g + 4 of its point: nothing is exchanged between lanes.
+#ifdef WOST_H_SUB1                 // (developer builds of EXPERIMENTS 17/19: bisecting the run-to-run difference in place)
+constexpr int kHalfSub = 1;
+#else
 constexpr int kHalfSub = 2;       // 16-point groups per wave iteration
+#endif
 constexpr int kHalfThreads = 256;      // training kernel (wost_net_half.h): one wave per SIMD, the accumulators take the registers
 #ifndef WOST_HALF_FWD_THREADS
 #define WOST_HALF_FWD_THREADS 512
@@ -476,7 +480,11 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
     __shared__ uint32_t s_res[kNetMaxLevels], s_off[kNetMaxLevels + 1];
     // weights and the whole grid (15 384 entries x 8 bytes in half precision): 150 KB of the CU's 160 KB, one block per CU;
     // every gather of the encoding is an LDS read
+#ifdef WOST_H_GRID_GLOBAL
+    const uint32_t n_image = L.n_mlp / 4;
+#else
     const uint32_t n_image = L.n_mlp / 4 + (DIMS == 2 ? L.level_off[L.n_levels] : 0u);
+#endif
     for (uint32_t e = threadIdx.x; e < n_image; e += kHalfFwdThreads) lds_h[e] = fragh[e];
     if (threadIdx.x <= (unsigned)L.n_levels) {
         s_off[threadIdx.x] = L.level_off[threadIdx.x];
@@ -489,8 +497,17 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
     if (n_dev) n = (int)*n_dev;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int n_tiles = (n + 16 * kHalfSub - 1) / (16 * kHalfSub);
+#ifdef WOST_H_GRID_GLOBAL
+    const uint2 *grid = fragh + L.n_mlp / 4;
+#else
     const uint2 *grid = (DIMS == 2 ? lds_h : fragh) + L.n_mlp / 4;
-    const uint2 *w0 = lds_h + L.w_off[0] / 4, *w1 = lds_h + L.w_off[1] / 4, *w2 = lds_h + L.w_off[2] / 4, *w3 = lds_h + L.w_off[3] / 4;
+#endif
+#ifdef WOST_H_W_GLOBAL
+    const uint2 *wimg = fragh;
+#else
+    const uint2 *wimg = lds_h;
+#endif
+    const uint2 *w0 = wimg + L.w_off[0] / 4, *w1 = wimg + L.w_off[1] / 4, *w2 = wimg + L.w_off[2] / 4, *w3 = wimg + L.w_off[3] / 4;
     for (int tile = blockIdx.x * (kHalfFwdThreads / 64) + wave; tile < n_tiles; tile += gridDim.x * (kHalfFwdThreads / 64)) {
         asm volatile("" ::: "memory");      // the weight fragments are re-read from LDS per tile, not parked in registers
         int pt[kHalfSub];
@@ -516,6 +533,9 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
             }
         }
         f32x4_t acc[kHalfSub][4];
+#ifdef WOST_H_FENCE
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15" ::: "memory");
+#endif
         // ---- hidden layers: ReLU, the accumulators of row tile rt become the B operand of k-tile rt
 #pragma unroll
         for (int layer = 0; layer < 3; ++layer) {
@@ -1712,6 +1732,16 @@ int net_forward_loss_dev(wost_net *h, const float *xy_dev, int n, hipStream_t st
                             }
                         }
                     std::fprintf(stderr, "\n");
+                }
+                {
+                    // which units: do the two units of a wave's tile (2u, 2u + 1: one weight fragment serves both) fail together?
+                    std::vector<char> bad_unit((n + 15) / 16 + 1, 0);
+                    for (size_t i = 0; i < n_raw; ++i)
+                        if (std::memcmp(&o0[i], &o1[i], 4) != 0 || std::memcmp(&o1[i], &o2[i], 4) != 0) bad_unit[i / h->L.n_out / 16] = 1;
+                    size_t units = 0, with_partner = 0;
+                    for (size_t u = 0; u < bad_unit.size(); ++u)
+                        if (bad_unit[u]) { ++units; with_partner += bad_unit[u ^ 1] ? 1 : 0; }
+                    std::fprintf(stderr, "TRIPLE %s: %zu units differ, %zu of them together with the other unit of their tile\n", units ? "BAD" : "CLEAN", units, with_partner);
                 }
             }
             NET_TRY(hipMemcpy(r[0].data(), h->d_dl, words * 4, hipMemcpyDeviceToHost));

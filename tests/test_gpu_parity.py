@@ -173,36 +173,6 @@ def test_kernel_variants_do_not_change_results(oracle, ladybug, opts):
     _assert_same_solve(oracle, ladybug, 56, 48, 6, 32, 1.0, ref=_cached_ref(oracle, ladybug, "variants", 56, 48, 6, 32, 1.0), **opts)
 
 
-@pytest.mark.parametrize("opts", [
-    {"pair": 1}, {"pair": 1, "steps_per_round": 1}, {"pair": 1, "steps_per_round": 5}, {"pair": 1, "wait_weight": 1},
-    {"pair": 1, "wait_weight": 64, "steps_per_round": 40}, {"pair": 0},
-])
-def test_pair_kernel_matches_oracle(oracle, ladybug, opts):
-    """two walkers per lane (walk_pair_kernel, forced: the automatic choice takes it for full launches only): same bits, same
-    counters as the oracle -- an odd number of walkers (the last lane holds one), rounds of one step (every walker is re-queued
-    between its steps), and the scheduler's extremes"""
-    _assert_same_solve(oracle, ladybug, 57, 47, 6, 32, 1.0, ref=_cached_ref(oracle, ladybug, "pair", 57, 47, 6, 32, 1.0), **opts)
-
-
-def test_pair_kernel_with_mask_emissive_boundary_and_strays(oracle, ladybug, fille):
-    from elaina_amd import Problem
-    w, h = 37, 29
-    mask = (np.random.default_rng(0).uniform(size=w * h) > 0.3).astype(np.uint8)
-    p = Problem(d_verts=ladybug.d_verts, d_segs=ladybug.d_segs, d_colors=ladybug.d_colors, n_verts=ladybug.n_verts,
-                n_segs=ladybug.n_segs, probe=ladybug.probe, mask=mask)
-    _assert_same_solve(oracle, p, w, h, 5, 32, 1.0, pair=1)
-    _assert_same_solve(oracle, fille, 48, 40, 4, 128, 1.0, pair=1)
-    flux = lambda x, y, side: -1.0 if side == 2 else 1.0
-    pe = box_problem(0.0, 100.0, 25, d_sides=(1, 3), n_sides=(0, 2), value=lambda x, y: y, flux=flux, probe=(40.0, 50.0, 50.0, 0.0, 1.0))
-    _assert_same_solve(oracle, pe, 16, 16, 64, 512, 0.25, pair=1)
-    # an open scene seen from afar: most walks stray beyond the plain visits' range and pass through the slack launches
-    po = Problem(d_verts=ladybug.d_verts, d_segs=ladybug.d_segs, d_colors=ladybug.d_colors,
-                 probe=(3.0 * ladybug.probe[0], ladybug.probe[1], ladybug.probe[2], ladybug.probe[3], ladybug.probe[4]))
-    _assert_same_solve(oracle, po, 40, 24, 4, 32, 1.0, pair=1)
-    # one walker only, and none
-    _assert_same_solve(oracle, ladybug, 1, 1, 9, 32, 1.0, pair=1)
-
-
 def test_ground_truth_sample_count(oracle, ladybug):
     """the reference's ground-truth configuration runs 65 536 samples per pixel (data/ladybug/gt.json): a pixel's sample
     counter, the per-launch 16-bit statistics and hundreds of rounds, on a frame (5 x 4) the oracle finishes in seconds"""
