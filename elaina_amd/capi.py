@@ -168,7 +168,7 @@ EXPORTS = [
     "wost3_render_sdf", "wost3_render_source", "wost3_destroy", "wost3_vmf_eval", "wost3_vmf_sample", "wost3_vmm_pdf_sample", "wost3_vmm_loss_gradients",
     "wost3_net_create", "wost3_guided_create", "wost3_guided_destroy", "wost3_guided_network", "wost3_guided_solve", "wost3_guided_solve_sharded",
     "wost3_guided_query_network", "wost3_guided_train_set", "wost3_guided_scene",
-    "wost_last_error", "wost_version",
+    "wost_last_error", "wost_version", "wost_mesh_build_check",
 ]
 
 _lib = None
@@ -240,6 +240,7 @@ def load():
     L.wost3_closest_silhouette.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_int32, fp]
     L.wost3_ray_intersect.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, C.c_int32, ip, fp, ip]
     L.wost3_mesh_build_check.argtypes = [C.POINTER(Mesh3Desc), C.c_int, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.wost_mesh_build_check.argtypes = [C.POINTER(MeshDesc), C.c_int, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.wost3_render_sdf.argtypes = [C.c_void_p, C.c_int, fp]
     L.wost3_render_source.argtypes = [C.c_void_p, fp]
     L.wost3_destroy.argtypes = [C.c_void_p]

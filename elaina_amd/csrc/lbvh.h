@@ -78,8 +78,9 @@ struct HostTree {
     float aabb[4] = {0, 0, 0, 0}; // lox, loy, hix, hiy of the mesh
 };
 
-// Oriented box {cx cy ux uy hl hw} around n points (x y pairs), padded by obb_pad (lbvh_build.cpp).
-void fit_obb(const double *P, size_t n, double obb_pad, float out[6]);
+// Oriented box {cx cy ux uy hl hw} around n points (x y pairs) with the moments `sums` (lbvh_fit.h), padded by obb_pad (lbvh_build.cpp).
+struct FitSums;
+void fit_obb(const float *P, size_t n, const FitSums &sums, double obb_pad, float out[6]);
 
 // Returns 0 on success, negative on invalid input (index out of range).
 // refine: true = perimeter-weighted (SAH) top-down assignment of the Morton-ordered segments

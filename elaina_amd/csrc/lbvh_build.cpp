@@ -3,6 +3,7 @@
 // part of the arithmetic contract of the queries and must round exactly as specified
 // in DESIGN.md ("segment record").
 #include "lbvh.h"
+#include "lbvh_fit.h"
 
 #include <algorithm>
 #include <cmath>
@@ -25,47 +26,25 @@ static inline uint32_t part1by1(uint32_t x)
 
 static inline float dot2(float ax, float ay, float bx, float by) { return std::fmaf(ax, bx, ay * by); }
 
-// Oriented box around n points (x0 y0 x1 y1 ...): the tightest (by half perimeter) of the PCA axis
-// and 16 fixed directions, measured in the frame of the fp32 axis it will be stored with, inflated by
-// a relative 1e-6 plus `pad`.  out = cx cy ux uy hl hw.
-void fit_obb(const double *P, size_t n, double obb_pad, float out[6])
+// Oriented box around n points (x0 y0 x1 y1 ..., fp32 coordinates): the tightest (by half perimeter) of the principal axis of
+// their moments `sums` and the sixteen fixed directions, measured in the frame of the fp32 axis it will be stored with,
+// inflated by a relative 1e-6 plus `pad`.  out = cx cy ux uy hl hw.  The arithmetic is lbvh_fit.h's: the device builder
+// (wost_build2.hip) computes the same bits.
+void fit_obb(const float *P, size_t n, const FitSums &sums, double obb_pad, float out[6])
 {
-    double mx = 0, my = 0;
-    for (size_t i = 0; i < n; ++i) { mx += P[2 * i]; my += P[2 * i + 1]; }
-    mx /= (double)n; my /= (double)n;
-    double sxx = 0, sxy = 0, syy = 0;
-    for (size_t i = 0; i < n; ++i) {
-        const double x = P[2 * i] - mx, y = P[2 * i + 1] - my;
-        sxx += x * x; sxy += x * y; syy += y * y;
-    }
-    const double pca = 0.5 * std::atan2(2.0 * sxy, sxx - syy);
     double best = std::numeric_limits<double>::infinity();
-    float b_cx = 0, b_cy = 0, b_ux = 1, b_uy = 0, b_hl = 0, b_hw = 0;
-    const int n_ang = 16;
-    for (int a = -1; a < n_ang; ++a) {
-        const double ang = (a < 0) ? pca : M_PI * (double)a / n_ang;
-        // the axis as it will be stored (fp32); extents are measured in THAT frame
-        const float uxf = (float)std::cos(ang), uyf = (float)std::sin(ang);
-        const double ux = uxf, uy = uyf, n2 = ux * ux + uy * uy;
-        double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
-        for (size_t i = 0; i < n; ++i) {
-            const double u = P[2 * i] * ux + P[2 * i + 1] * uy;
-            const double v = -P[2 * i] * uy + P[2 * i + 1] * ux;
-            umin = std::min(umin, u); umax = std::max(umax, u);
-            vmin = std::min(vmin, v); vmax = std::max(vmax, v);
-        }
-        const double score = (umax - umin) + (vmax - vmin);
+    for (int a = -1; a < kFitDirs; ++a) {
+        float uxf, uyf;
+        if (a < 0) fit_pca_axis(sums, uxf, uyf);
+        else { uxf = fit_dir(a).c; uyf = fit_dir(a).s; }
+        FitExtent e = fit_extent_empty();
+        for (size_t i = 0; i < n; ++i) fit_extent_add(e, uxf, uyf, P[2 * i], P[2 * i + 1]);
+        const double score = fit_score(e);
         if (score < best) {
             best = score;
-            const double uc = 0.5 * (umin + umax), vc = 0.5 * (vmin + vmax);
-            b_cx = (float)((uc * ux - vc * uy) / n2);
-            b_cy = (float)((uc * uy + vc * ux) / n2);
-            b_ux = uxf; b_uy = uyf;
-            b_hl = (float)(0.5 * (umax - umin) * (1.0 + 1e-6) + obb_pad);
-            b_hw = (float)(0.5 * (vmax - vmin) * (1.0 + 1e-6) + obb_pad);
+            fit_box(e, uxf, uyf, obb_pad, out);
         }
     }
-    out[0] = b_cx; out[1] = b_cy; out[2] = b_ux; out[3] = b_uy; out[4] = b_hl; out[5] = b_hw;
 }
 
 int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_t *segs,
@@ -328,22 +307,27 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
     {
         const int n_all = t->first_leaf + cap;   // nodes that have children (leaves included)
         t->nodes.assign((size_t)n_all * 24, 0.0f);
-        // endpoints under every node, gathered bottom-up (leaves first)
-        std::vector<std::vector<double>> pts(n_all);
+        // endpoints under every node, gathered bottom-up (leaves first), and their moments on the 2^20 grid of the mesh's box
+        std::vector<std::vector<float>> pts(n_all);
+        std::vector<FitSums> sums(n_all, FitSums{0, 0, 0, 0, 0, 0});
+        const double grid = fit_grid_scale(lox, loy, hix, hiy);
         for (int k = 0; k < cap; ++k) {
-            std::vector<double> &P = pts[t->first_leaf + k];
+            std::vector<float> &P = pts[t->first_leaf + k];
             for (int j = 0; j < kLeafSize; ++j) {
                 const int o = slot_of[(size_t)k * kLeafSize + j];
                 if (o < 0) continue;
-                const int i0 = segs[2 * o], i1 = segs[2 * o + 1];
-                P.push_back(verts[2 * i0]); P.push_back(verts[2 * i0 + 1]);
-                P.push_back(verts[2 * i1]); P.push_back(verts[2 * i1 + 1]);
+                for (int e = 0; e < 2; ++e) {
+                    const int v = segs[2 * o + e];
+                    P.push_back(verts[2 * v]); P.push_back(verts[2 * v + 1]);
+                    fit_add_point(sums[t->first_leaf + k], verts[2 * v], verts[2 * v + 1], lox, loy, grid);
+                }
             }
         }
         for (int g = t->first_leaf - 1; g >= 1; --g)
             for (int j = 1; j <= kArity; ++j) {
-                const std::vector<double> &C = pts[kArity * g + j];
+                const std::vector<float> &C = pts[kArity * g + j];
                 pts[g].insert(pts[g].end(), C.begin(), C.end());
+                fit_add_sums(sums[g], sums[kArity * g + j]);
             }
         const char *e_pad = getenv("WOST_OBB_PAD_LOG2");   // developer knob: absolute pad = ext * 2^-k
         const double obb_pad = (double)ext * std::ldexp(1.0, -(e_pad ? atoi(e_pad) : 21)) + 1e-30;
@@ -355,14 +339,14 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
         // inner levels: fit an oriented box around the endpoints of each child subtree
         for (int g = 0; g < t->first_leaf; ++g) {
             for (int j = 0; j < kArity; ++j) {
-                const std::vector<double> &P = pts[kArity * g + 1 + j];
+                const std::vector<float> &P = pts[kArity * g + 1 + j];
                 const size_t n = P.size() / 2;
                 if (n == 0) {
                     set_child(g, j, kFarCoord, kFarCoord, 1.0f, 0.0f, 0.0f, 0.0f);
                     continue;
                 }
                 float ob[6];
-                fit_obb(P.data(), n, obb_pad, ob);
+                fit_obb(P.data(), n, sums[kArity * g + 1 + j], obb_pad, ob);
                 set_child(g, j, ob[0], ob[1], ob[2], ob[3], ob[4], ob[5]);
             }
         }
@@ -389,12 +373,16 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
             t->segVerts[2 * k] = segs[2 * o];
             t->segVerts[2 * k + 1] = segs[2 * o + 1];
         }
-        // per node (heap index): angles of the relevant normals, "has an open end", vertices
-        struct Acc { std::vector<double> ang; bool open = false; std::vector<double> pts; };
+        // per node (heap index): the normals its cone must cover -- those of its segments and of the segments that share a
+        // vertex with them --, "has an open end", the end points
+        struct Acc { std::vector<float> nrm; ConeSums cs{0, 0, 0, 0}; std::vector<float> pts; };
         std::vector<Acc> acc(n_all);
         auto add_seg_normal = [&](Acc &a, int sidx) {
             const FlatSeg &s = t->flat[sidx];
-            if (s.len > 0.0f) a.ang.push_back(std::atan2((double)s.ny, (double)s.nx));
+            if (s.len > 0.0f) {
+                a.nrm.push_back(s.nx); a.nrm.push_back(s.ny);
+                cone_add_normal(a.cs, s.nx, s.ny);
+            }
         };
         for (int k = 0; k < cap; ++k) {
             Acc &a = acc[t->first_leaf + k];
@@ -405,7 +393,7 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
                 for (int e = 0; e < 2; ++e) {
                     const int v = segs[2 * o + e];
                     a.pts.push_back(verts[2 * v]); a.pts.push_back(verts[2 * v + 1]);
-                    if (vprev[v] < 0 || vnext[v] < 0) a.open = true;
+                    if (vprev[v] < 0 || vnext[v] < 0) a.cs.open = 1;
                     if (vprev[v] >= 0) add_seg_normal(a, vprev[v]);
                     if (vnext[v] >= 0) add_seg_normal(a, vnext[v]);
                 }
@@ -414,32 +402,28 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
         for (int g = t->first_leaf - 1; g >= 1; --g)
             for (int j = 1; j <= kArity; ++j) {
                 const Acc &c = acc[kArity * g + j];
-                acc[g].ang.insert(acc[g].ang.end(), c.ang.begin(), c.ang.end());
+                acc[g].nrm.insert(acc[g].nrm.end(), c.nrm.begin(), c.nrm.end());
                 acc[g].pts.insert(acc[g].pts.end(), c.pts.begin(), c.pts.end());
-                acc[g].open = acc[g].open || c.open;
+                cone_add_sums(acc[g].cs, c.cs);
             }
         auto set_cone = [&](int parent, int j, float ax, float ay, float ch, float sh, float rad) {
             float *cn = &t->cones[(size_t)parent * 20];
             cn[0 + j] = ax; cn[4 + j] = ay; cn[8 + j] = ch; cn[12 + j] = sh; cn[16 + j] = rad;
         };
-        const double two_pi = 2.0 * M_PI;
         auto fit = [&](int parent, int j, Acc &a, float cx, float cy) {
             double rad = 0.0;
-            for (size_t i = 0; i + 1 < a.pts.size(); i += 2)
-                rad = std::max(rad, std::hypot(a.pts[i] - (double)cx, a.pts[i + 1] - (double)cy));
-            // padded by more than the silhouette test's absolute precision (10^-3): a query within that distance of a
-            // vertex takes the test's near branch, which the cone argument does not cover -- it must count as inside
-            const float radf = (float)(rad * (1.0 + 1e-6) + (double)ext * 0x1p-18 + 2.0e-3);
-            if (a.open || a.ang.empty()) { set_cone(parent, j, 1.0f, 0.0f, -1.0f, 0.0f, radf); return; }
-            std::sort(a.ang.begin(), a.ang.end());
-            double gap = a.ang.front() + two_pi - a.ang.back(), gap_end = a.ang.front() + two_pi;
-            for (size_t i = 1; i < a.ang.size(); ++i)
-                if (a.ang[i] - a.ang[i - 1] > gap) { gap = a.ang[i] - a.ang[i - 1]; gap_end = a.ang[i]; }
-            const double arc = two_pi - gap;              // smallest arc containing every normal
-            const double half = 0.5 * arc + 1e-4;        // padded
-            if (half >= 0.5 * M_PI - 1e-3) { set_cone(parent, j, 1.0f, 0.0f, -1.0f, 0.0f, radf); return; }
-            const double mid = gap_end + 0.5 * arc;       // arc starts where the largest gap ends
-            set_cone(parent, j, (float)std::cos(mid), (float)std::sin(mid), (float)std::cos(half), (float)std::sin(half), radf);
+            for (size_t i = 0; i + 1 < a.pts.size(); i += 2) {
+                const double dx = (double)a.pts[i] - (double)cx, dy = (double)a.pts[i + 1] - (double)cy;
+                rad = std::max(rad, std::sqrt(dx * dx + dy * dy));
+            }
+            const float radf = cone_radius(rad, ext);
+            double ax, ay;
+            if (!cone_axis(a.cs, ax, ay)) { set_cone(parent, j, 1.0f, 0.0f, -1.0f, 0.0f, radf); return; }
+            double cmin = 1.0;
+            for (size_t i = 0; i + 1 < a.nrm.size(); i += 2) cmin = std::min(cmin, cone_cos_to(ax, ay, a.nrm[i], a.nrm[i + 1]));
+            float c4[4];
+            if (!cone_finish(ax, ay, cmin, c4)) { set_cone(parent, j, 1.0f, 0.0f, -1.0f, 0.0f, radf); return; }
+            set_cone(parent, j, c4[0], c4[1], c4[2], c4[3], radf);
         };
         for (int g = 0; g < t->first_leaf; ++g)
             for (int j = 0; j < kArity; ++j) {

@@ -644,9 +644,15 @@ __global__ __launch_bounds__(256) void guided_init_kernel(GParams P)
 // Per pixel the arithmetic and the order of the random draws are those of separate_kernel / sample_kernel /
 // tail_kernel, and the network arithmetic is that of net_forward_h_kernel (same device functions): the field,
 // the training records and hence the trained weights are bit-identical to the one-launch-per-depth path.
-// waves per CU sharing one copy of the weight fragments: 12 with the f16 fragments (26 KB), 10 with the fp32 ones (53 KB)
+// waves per CU sharing one copy of the weight fragments: 8 with the f16 fragments (26 KB), 10 with the fp32 ones (53 KB).
+// Half precision: TWO waves per SIMD, not the three that fit.  With three or four waves of a SIMD running the f16 matrix-instruction
+// network side by side (weights read from LDS, gathers in between) a 16-point unit now and then comes out a percent different --
+// three launches of net_forward_h_kernel on the same inputs differ in every triple at 768 threads, in none at 512 (EXPERIMENTS 17,
+// 20: bisected in place; the standalone chain tools/micro/mfma_chain.hip does not show it, and what exactly the hardware does is
+// not known) -- and a guided solve in half precision stopped being reproducible run to run about once in 36 solves.  Two waves per
+// SIMD never showed it in any experiment; they cost this kernel its third wave's latency hiding.
 #ifndef WOST_FUSED_THREADS_H
-#define WOST_FUSED_THREADS_H 768
+#define WOST_FUSED_THREADS_H 512
 #endif
 constexpr int fused_threads(bool half) { return half ? WOST_FUSED_THREADS_H : 640; }
 // per wave, beside the lanes' columns: which lane the k-th point of the wave's network batch belongs to (64 bytes)

@@ -29,6 +29,7 @@
 
 #include "../../include/wost.h"
 #include "lbvh.h"
+#include "wost_build2.h"
 #include "wost_device.h"
 #include "wost_internal.h"
 #include "wost_walk.h"
@@ -904,7 +905,13 @@ static hipError_t upload(std::vector<void *> &allocs, const T *src, size_t count
     return e;
 }
 
-static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
+// the run boxes over consecutive ORIGINAL indices and the sampler's compact copies (an emissive boundary on the tree only):
+// a function of the flat records alone
+static int upload_run_boxes(const std::vector<FlatSeg> &flat_recs, DeviceMeshStorage &s);
+
+// the host builder's tree (lbvh_build.cpp), uploaded array by array: the checker of the device build, small meshes,
+// WOST_HOST_BUILD=1 and the tree-quality knobs
+static int upload_mesh_host(const wost_mesh_desc &d, DeviceMeshStorage &s)
 {
     if (d.n_segs < 0 || d.n_verts < 0) return fail(WOST_ERR_INVALID, "negative mesh size");
     // developer knobs for tree-quality experiments (defaults: refined, minimal depth)
@@ -980,23 +987,31 @@ static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
         HIP_TRY(upload(s.allocs, reinterpret_cast<const int2 *>(id.data()), hl.size(), &v.scanId));
     }
     HIP_TRY(upload(s.allocs, reinterpret_cast<const int2 *>(t.segVerts.data()), t.segVerts.size() / 2, &v.segVerts));
+    if (v.emissive && t.n_segs > WOST_FLAT_MAX) return upload_run_boxes(t.flat, s);
+    return WOST_OK;
+}
+
+static int upload_run_boxes(const std::vector<FlatSeg> &flat_recs, DeviceMeshStorage &s)
+{
+    DevMesh &v = s.view;
+    const int n_segs = (int)flat_recs.size();
     // boxes over runs of consecutive original indices, for the index-ordered sampling of emissive Neumann meshes
     // (sample_in_sphere_tree); padded like the tree's boxes, so that rounding never hides a segment the flat loop takes
-    if (v.emissive && t.n_segs > WOST_FLAT_MAX) {
+    {
         float ext = 0.0f;
-        for (const FlatSeg &f : t.flat) ext = std::max(ext, std::max(std::max(std::fabs(f.ax), std::fabs(f.ay)), std::max(std::fabs(f.ax + f.ex), std::fabs(f.ay + f.ey))));
+        for (const FlatSeg &f : flat_recs) ext = std::max(ext, std::max(std::max(std::fabs(f.ax), std::fabs(f.ay)), std::max(std::fabs(f.ax + f.ex), std::fabs(f.ay + f.ey))));
         const float pad = ext * 0x1p-18f + 1e-30f;
         std::vector<float> ob;
         int levels = 0;
         size_t prev_off = 0, prev_n = 0;
         for (int l = 0; l < 12; ++l) {
-            const size_t run = (size_t)4 << (2 * l), n_runs = ((size_t)t.n_segs + run - 1) / run;
+            const size_t run = (size_t)4 << (2 * l), n_runs = ((size_t)n_segs + run - 1) / run;
             v.obox_off[l] = (int32_t)(ob.size() / 4);
             for (size_t r = 0; r < n_runs; ++r) {
                 float lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
                 if (l == 0) {
-                    for (size_t i = r * 4; i < std::min<size_t>(r * 4 + 4, (size_t)t.n_segs); ++i) {
-                        const FlatSeg &f = t.flat[i];
+                    for (size_t i = r * 4; i < std::min<size_t>(r * 4 + 4, (size_t)n_segs); ++i) {
+                        const FlatSeg &f = flat_recs[i];
                         lo[0] = std::min(lo[0], std::min(f.ax, f.ax + f.ex)); hi[0] = std::max(hi[0], std::max(f.ax, f.ax + f.ex));
                         lo[1] = std::min(lo[1], std::min(f.ay, f.ay + f.ey)); hi[1] = std::max(hi[1], std::max(f.ay, f.ay + f.ey));
                     }
@@ -1016,16 +1031,41 @@ static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
         }
         v.obox_levels = levels;
         HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(ob.data()), ob.size() / 4, &v.obox));
-        const size_t n4 = (t.flat.size() + 3) / 4 * 4;
+        const size_t n4 = (flat_recs.size() + 3) / 4 * 4;
         std::vector<float> lens(n4, 0.0f), hl(n4, 0.0f), box(n4 * 4, 1.0e18f);
-        for (size_t i = 0; i < t.flat.size(); ++i) {
-            const FlatSeg &f = t.flat[i];
+        for (size_t i = 0; i < flat_recs.size(); ++i) {
+            const FlatSeg &f = flat_recs[i];
             lens[i] = f.len; hl[i] = f.hl;
             box[4 * i] = f.cx; box[4 * i + 1] = f.cy; box[4 * i + 2] = f.ux; box[4 * i + 3] = f.uy;
         }
         HIP_TRY(upload(s.allocs, lens.data(), lens.size(), &v.lens));
         HIP_TRY(upload(s.allocs, hl.data(), hl.size(), &v.sampHl));
         HIP_TRY(upload(s.allocs, reinterpret_cast<const float4 *>(box.data()), n4, &v.sampBox));
+    }
+    return WOST_OK;
+}
+
+// Problem<2>::build_bvh: on the device (wost_build2.hip) for every mesh worth the launches; the host builder for the small ones
+// (a four-segment Neumann box is done before the first kernel would start), behind WOST_HOST_BUILD=1, and for the tree-quality
+// knobs.  Both give the same arrays bit for bit (wost_mesh_build_check, tests/test_gpu_build2.py).
+static int upload_mesh(const wost_mesh_desc &d, DeviceMeshStorage &s)
+{
+    if (d.n_segs < 0 || d.n_verts < 0) return fail(WOST_ERR_INVALID, "negative mesh size");
+    const char *e_host = getenv("WOST_HOST_BUILD");
+    const bool knobs = getenv("WOST_TREE_REFINE") || getenv("WOST_TREE_EXTRA_LEVELS");
+    int min_segs = 512;
+    if (const char *e = getenv("WOST_DEVICE_BUILD_MIN")) min_segs = std::max(1, atoi(e));
+    if ((e_host && atoi(e_host) != 0) || knobs || d.n_segs < min_segs) return upload_mesh_host(d, s);
+    DeviceTree2 t;
+    const int rc = build_tree_device(d, t);
+    if (rc != WOST_OK) return rc;
+    s.view = t.view;
+    if (t.alloc) s.allocs.push_back(t.alloc);
+    if (s.view.emissive && d.n_segs > WOST_FLAT_MAX) {
+        // (rare: an emissive boundary on the tree) the run boxes are built on the host from the flat records
+        std::vector<FlatSeg> flat_recs((size_t)d.n_segs);
+        HIP_TRY(hipMemcpy(flat_recs.data(), s.view.flat, flat_recs.size() * sizeof(FlatSeg), hipMemcpyDeviceToHost));
+        return upload_run_boxes(flat_recs, s);
     }
     return WOST_OK;
 }
@@ -1124,10 +1164,93 @@ static void destroy_ctx(wost_context *c)
     delete c;
 }
 
+namespace {
+template <class T>
+int64_t differing_bytes2(const T *a, const T *b, size_t count, int64_t *compared)
+{
+    if (count == 0) return 0;
+    const size_t bytes = count * sizeof(T);
+    if (!a || !b) return (a || b) ? (int64_t)bytes : 0;
+    std::vector<unsigned char> ha(bytes), hb(bytes);
+    if (hipMemcpy(ha.data(), a, bytes, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(hb.data(), b, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+        return (int64_t)bytes;
+    int64_t diff = 0;
+    for (size_t i = 0; i < bytes; ++i) diff += ha[i] != hb[i];
+    *compared += (int64_t)bytes;
+    return diff;
+}
+}  // namespace
+
 extern "C" {
 
 // 0.2: the sync callback of a shared guiding network is also asked for the number of ranks (WOST_SYNC_RANKS_I64_HOST)
 const char *wost_version(void) { return "wost-hip 0.2 (gfx950)"; }
+
+
+int wost_mesh_build_check(const wost_mesh_desc *mesh, int device, int32_t repeat, double *host_ms, double *device_ms, int64_t *mismatch)
+{
+    if (!mesh || !mismatch) return fail(WOST_ERR_INVALID, "null argument");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(WOST_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n_dev) return fail(WOST_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    if (mesh->n_segs < 0 || mesh->n_verts < 0) return fail(WOST_ERR_INVALID, "negative mesh size");
+    struct Owned {
+        DeviceMeshStorage m;
+        ~Owned()
+        {
+            for (void *p : m.allocs) (void)hipFree(p);
+        }
+    };
+    using clock = std::chrono::steady_clock;
+    double best_host = 1e300, best_dev = 1e300;
+    Owned a, b;
+    for (int r = 0; r < std::max(1, repeat); ++r) {
+        Owned ha, hb;
+        HIP_TRY(hipDeviceSynchronize());
+        auto t0 = clock::now();
+        int rc = upload_mesh_host(*mesh, ha.m);
+        HIP_TRY(hipDeviceSynchronize());
+        auto t1 = clock::now();
+        if (rc != WOST_OK) return rc;
+        DeviceTree2 t;
+        rc = build_tree_device(*mesh, t);
+        if (t.alloc) hb.m.allocs.push_back(t.alloc);
+        hb.m.view = t.view;
+        HIP_TRY(hipDeviceSynchronize());
+        auto t2 = clock::now();
+        if (rc != WOST_OK) return rc;
+        best_host = std::min(best_host, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        best_dev = std::min(best_dev, std::chrono::duration<double, std::milli>(t2 - t1).count());
+        std::swap(a.m, ha.m);
+        std::swap(b.m, hb.m);
+    }
+    if (host_ms) *host_ms = best_host;
+    if (device_ms) *device_ms = best_dev;
+    const DevMesh &x = a.m.view, &y = b.m.view;
+    for (int i = 0; i < 16; ++i) mismatch[i] = 0;
+    const int64_t scalars = (x.n_segs != y.n_segs) + (x.n_sil != y.n_sil) + (x.levels != y.levels) + (x.first_leaf != y.first_leaf) + (x.emissive != y.emissive) +
+                            (std::memcmp(&x.far2, &y.far2, 4) != 0) + (std::memcmp(&x.huge2, &y.huge2, 4) != 0) + (x.n_scan != y.n_scan);
+    mismatch[14] = scalars;
+    if (x.n_segs == 0 || scalars) return WOST_OK;
+    const size_t cap = 3 * (size_t)x.first_leaf + 1, n_all = (size_t)x.first_leaf + cap, n_slots = cap * 4, n = (size_t)x.n_segs, nv = (size_t)x.n_sil;
+    int64_t *cmp = &mismatch[15];
+    mismatch[0] = differing_bytes2(x.nodes, y.nodes, n_all * 6, cmp);
+    mismatch[1] = differing_bytes2(x.cones, y.cones, n_all * 5, cmp);
+    mismatch[2] = differing_bytes2(x.segA, y.segA, n_slots, cmp);
+    mismatch[3] = differing_bytes2(x.segInv, y.segInv, n_slots, cmp);
+    mismatch[4] = differing_bytes2(x.segOrig, y.segOrig, n_slots, cmp);
+    mismatch[5] = differing_bytes2(x.segCol, y.segCol, n_slots * 12, cmp);
+    mismatch[6] = differing_bytes2(x.segVerts, y.segVerts, n_slots, cmp);
+    mismatch[7] = differing_bytes2(x.flat, y.flat, n, cmp);
+    mismatch[8] = differing_bytes2(x.flatCol, y.flatCol, n * 12, cmp);
+    mismatch[9] = differing_bytes2(x.sil, y.sil, nv, cmp);
+    mismatch[10] = differing_bytes2(x.silN, y.silN, nv, cmp);
+    mismatch[11] = differing_bytes2(x.scanBox, y.scanBox, (size_t)x.n_scan, cmp);
+    mismatch[12] = differing_bytes2(x.scanHl, y.scanHl, (size_t)x.n_scan, cmp);
+    mismatch[13] = differing_bytes2(x.scanId, y.scanId, (size_t)x.n_scan, cmp);
+    return WOST_OK;
+}
 
 const char *wost_last_error(void) { return g_last_error.c_str(); }
 

@@ -468,6 +468,7 @@ struct LossArgs {
     float scale;       // loss_scale / n
     float dscale;      // the extra power-of-two scale of the f16 deltas (net_train_h_kernel)
     uint2 *dl_h;
+    uint2 *dbg;        // (WOST_H_DUMP builds, EXPERIMENTS 17: the hidden activations of every layer, [unit][3 layers][4 tiles][64 lanes])
 };
 
 template <int DIMS, bool LOSS>
@@ -522,8 +523,12 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int lv = g + 4 * h;
+#ifdef WOST_H_NO_GATHER     // (bisecting builds: a stand-in encoding without a single LDS gather -- wrong numbers, the same in every launch)
+                b[u][h] = h4_t{(_Float16)(x * 0.25f), (_Float16)(y * 0.25f), (_Float16)(x * y), (_Float16)(0.125f * (float)lv)};
+#else
                 b[u][h] = DIMS == 3 ? half_encode_level3(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], x, y, z)
                                     : half_encode_level(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], x, y);
+#endif
                 if (enc_out) {
                     // training: the encoding goes to the fused backward kernel as it stands (wost_net_half.h)
                     union { h4_t h; uint2 u; } e;
@@ -549,6 +554,18 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
                 for (int rt = 0; rt < 4; ++rt)
                     b[u][rt] = __builtin_elementwise_max(__builtin_convertvector(acc[u][rt], h4_t),
                                                          h4_t{(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f});
+#ifdef WOST_H_DUMP
+            if (LOSS && la.dbg) {
+#pragma unroll
+                for (int u = 0; u < kHalfSub; ++u)
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+                        union { h4_t h; uint2 v; } d;
+                        d.h = b[u][rt];
+                        la.dbg[(((size_t)(tile * kHalfSub + u) * 3 + layer) * 4 + rt) * 64 + lane] = d.v;
+                    }
+            }
+#endif
         }
         mfma_layer_h<4, 3>(w3, lane, b, acc);
         mfma_settle3(acc);
@@ -1699,12 +1716,119 @@ int net_forward_loss_dev(wost_net *h, const float *xy_dev, int n, hipStream_t st
             NET_TRY(hipMalloc((void **)&extra, 2 * words * 4));
             NET_TRY(hipMalloc((void **)&raw2, 2 * n_raw * 4));
             NET_TRY(hipMemsetAsync(extra, 0xee, 2 * words * 4, stream));
+#ifdef WOST_H_DUMP
+            const size_t n_units_d = (size_t)((n + 31) / 32 * 2), dump_words = n_units_d * 3 * 4 * 64;
+            uint2 *dump = nullptr;
+            NET_TRY(hipMalloc((void **)&dump, 3 * dump_words * sizeof(uint2)));
+            {
+                // (the first launch above ran without a dump: it is repeated here into slot 0, the comparison below is among these three)
+                LossArgs l0 = la;
+                l0.dbg = dump;
+                rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, h->d_out, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream, &l0);
+            }
+#endif
             for (int k = 0; k < 2; ++k) {
                 LossArgs lb = la;
+#ifdef WOST_H_DUMP
+                lb.dbg = dump + (size_t)(k + 1) * dump_words;
+#endif
                 lb.dl_h = reinterpret_cast<uint2 *>(extra + k * words);
                 rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, raw2 + k * n_raw, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream, &lb);
             }
             NET_TRY(hipStreamSynchronize(stream));
+#ifdef WOST_H_DUMP
+            {
+                // where the three launches part: per differing unit the first layer and the tiles (16 hidden features each) that differ,
+                // which launch is the odd one, and whether the odd values are explained by ONE operand of the layer's matrix
+                // instructions having been another fragment of the weight image
+                std::vector<uint2> d(3 * dump_words), enc(n_units_d * 2 * 64), img(h->L.n_mlp / 4);
+                NET_TRY(hipMemcpy(d.data(), dump, d.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+                NET_TRY(hipMemcpy(enc.data(), h->d_acts, enc.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+                NET_TRY(hipMemcpy(img.data(), h->params_h, img.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+                (void)hipFree(dump);
+                auto half4 = [](uint2 v, float *o) { union { uint2 u; h4_t hh; } x; x.u = v; for (int c = 0; c < 4; ++c) o[c] = (float)x.hh[c]; };
+                size_t shown = 0, bad_units = 0;
+                size_t hist[3][5] = {{0}};
+                for (size_t u = 0; u < n_units_d; ++u) {
+                    int first_layer = -1;
+                    unsigned tiles = 0;
+                    int odd = -1;
+                    for (int layer = 0; layer < 3 && first_layer < 0; ++layer)
+                        for (int rt = 0; rt < 4; ++rt)
+                            for (int l = 0; l < 64; ++l) {
+                                const size_t i = ((u * 3 + layer) * 4 + rt) * 64 + l;
+                                const uint2 a = d[i], b2 = d[dump_words + i], c2 = d[2 * dump_words + i];
+                                const bool ab = a.x == b2.x && a.y == b2.y, bc = b2.x == c2.x && b2.y == c2.y;
+                                if (ab && bc) continue;
+                                first_layer = layer;
+                                tiles |= 1u << rt;
+                                odd = bc ? 0 : (a.x == c2.x && a.y == c2.y) ? 1 : ab ? 2 : 3;
+                            }
+                    if (first_layer < 0) continue;
+                    ++bad_units;
+                    hist[first_layer][__builtin_popcount(tiles)]++;
+                    if (shown++ >= 6) continue;
+                    std::fprintf(stderr, "DUMP unit %zu (unit %zu of its tile): first differing layer %d, tiles mask %x, odd launch %d\n", u, u & 1, first_layer, tiles, odd);
+                    // the layer's inputs (identical in the three launches: the layer before did not differ) and its weight fragments
+                    const int KT = first_layer == 0 ? 2 : 4;
+                    float in[4][64][4];
+                    for (int kt = 0; kt < KT; ++kt)
+                        for (int l = 0; l < 64; ++l)
+                            half4(first_layer == 0 ? enc[(u * 2 + kt) * 64 + l] : d[((u * 3 + first_layer - 1) * 4 + kt) * 64 + l], in[kt][l]);
+                    const uint2 *wf = img.data() + h->L.w_off[first_layer] / 4;
+                    const int good = odd == 0 ? 1 : 0, oddl = odd < 3 ? odd : 0;
+                    for (int rt = 0; rt < 4; ++rt) {
+                        if (!(tiles & (1u << rt))) continue;
+                        // out[row 16 rt + 4 g + c][point i] = sum_kt sum_g' sum_c' W[16 rt + i'][16 kt + 4 g' + c'] ... evaluated per lane of the D layout:
+                        // lane (i, g) holds rows 16 rt + 4 g + c of point i; fragment (rt, kt) lane (i', g') = W[16 rt + i'][16 kt + 4 g' .. + 3]
+                        auto eval = [&](int sub_rt, int sub_kt, int with_rt, int with_kt, float *out /*[64][4]*/) {
+                            for (int l = 0; l < 64; ++l) {
+                                const int i = l & 15, g = l >> 4;
+                                for (int c = 0; c < 4; ++c) {
+                                    const int row = 4 * g + c;      // row inside the tile
+                                    double acc = 0.0;
+                                    for (int kt = 0; kt < KT; ++kt) {
+                                        int frt = rt, fkt = kt;
+                                        if (rt == sub_rt && kt == sub_kt) { frt = with_rt; fkt = with_kt; }
+                                        for (int gp = 0; gp < 4; ++gp) {
+                                            float w4[4];
+                                            half4(wf[(frt * KT + fkt) * 64 + 16 * gp + row], w4);      // W[16 frt + row][16 fkt + 4 gp + c']
+                                            for (int cp = 0; cp < 4; ++cp) acc += (double)w4[cp] * (double)in[kt][16 * gp + i][cp];
+                                        }
+                                    }
+                                    out[l * 4 + c] = (float)acc;
+                                }
+                            }
+                        };
+                        std::vector<float> ref(256), got_good(256), got_odd(256), alt(256);
+                        for (int l = 0; l < 64; ++l) {
+                            half4(d[(size_t)good * dump_words + ((u * 3 + first_layer) * 4 + rt) * 64 + l], &got_good[l * 4]);
+                            half4(d[(size_t)oddl * dump_words + ((u * 3 + first_layer) * 4 + rt) * 64 + l], &got_odd[l * 4]);
+                        }
+                        eval(-1, -1, 0, 0, ref.data());
+                        auto dist = [&](const std::vector<float> &a, const std::vector<float> &b2) {
+                            double s2 = 0.0;
+                            for (int k = 0; k < 256; ++k) { const double x = std::max(a[k], 0.0f) - b2[k]; s2 += x * x; }
+                            return std::sqrt(s2 / 256.0);
+                        };
+                        std::fprintf(stderr, "   tile %d: rms(host - good launch) %.3g, rms(host - odd launch) %.3g;", rt, dist(ref, got_good), dist(ref, got_odd));
+                        double best = 1e30;
+                        int b_kt = -1, b_rt = -1, b_wkt = -1;
+                        for (int skt = 0; skt < KT; ++skt)
+                            for (int wrt = 0; wrt < 4; ++wrt)
+                                for (int wkt = 0; wkt < KT; ++wkt) {
+                                    if (wrt == rt && wkt == skt) continue;
+                                    eval(rt, skt, wrt, wkt, alt.data());
+                                    const double e = dist(alt, got_odd);
+                                    if (e < best) { best = e; b_kt = skt; b_rt = wrt; b_wkt = wkt; }
+                                }
+                        std::fprintf(stderr, " best single-fragment substitution: fragment (rt %d, kt %d) read as (rt %d, kt %d): rms %.3g\n", rt, b_kt, b_rt, b_wkt, best);
+                    }
+                }
+                std::fprintf(stderr, "DUMP: %zu units differ; first differing layer x number of tiles (1..4): L0 %zu %zu %zu %zu | L1 %zu %zu %zu %zu | L2 %zu %zu %zu %zu\n", bad_units,
+                             hist[0][1], hist[0][2], hist[0][3], hist[0][4], hist[1][1], hist[1][2], hist[1][3], hist[1][4], hist[2][1], hist[2][2], hist[2][3], hist[2][4]);
+            }
+#endif
             {
                 std::vector<float> o0(n_raw), o1(n_raw), o2(n_raw);
                 NET_TRY(hipMemcpy(o0.data(), h->d_out, n_raw * 4, hipMemcpyDeviceToHost));

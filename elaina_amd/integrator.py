@@ -167,3 +167,24 @@ class UniformIntegrator:
             self.close()
         except Exception:
             pass
+
+
+MESH_BUILD_ARRAYS2 = ("nodes", "cones", "segA", "segInv", "segOrig", "segCol", "segVerts", "flat", "flatCol", "sil", "silN", "scanBox", "scanHl", "scanId",
+                      "scalars")
+
+
+def mesh_build_check(verts, segs, colors=None, repeat=1, device=0):
+    """wost_mesh_build_check: the device build of a segment mesh (csrc/wost_build2.hip) against the host builder kept as its
+    checker -> ({array: differing bytes}, bytes compared, host ms, device ms)"""
+    import ctypes as C
+    from . import capi
+    lib = capi.load()
+    v = np.ascontiguousarray(verts, np.float32)
+    s_ = np.ascontiguousarray(segs, np.int32)
+    c = None if colors is None else np.ascontiguousarray(colors, np.float32)
+    m = capi.MeshDesc(len(v), len(s_), v.ctypes.data_as(C.POINTER(C.c_float)), s_.ctypes.data_as(C.POINTER(C.c_int32)),
+                      None if c is None else c.ctypes.data_as(C.POINTER(C.c_float)))
+    host_ms, dev_ms = C.c_double(0.0), C.c_double(0.0)
+    mism = (C.c_int64 * 16)()
+    capi._check(lib.wost_mesh_build_check(C.byref(m), device, repeat, C.byref(host_ms), C.byref(dev_ms), mism), "wost_mesh_build_check")
+    return {k: int(mism[i]) for i, k in enumerate(MESH_BUILD_ARRAYS2)}, int(mism[15]), host_ms.value, dev_ms.value

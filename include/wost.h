@@ -480,6 +480,13 @@ int wost3_guided_train_set(wost3_guided_handle h, int32_t capacity, int32_t *n, 
 
 const char *wost_last_error(void);
 const char *wost_version(void);
+/* Problem<2>::build_bvh (core/problem.cu:31-37, 48-54: the reference builds its trees on the device).  wost_create builds every
+ * mesh of 512 segments or more with HIP kernels (csrc/wost_build2.hip); this developer / test entry builds `mesh` with those kernels
+ * AND with the host builder kept as their checker (csrc/lbvh_build.cpp), `repeat` times, and compares the two uploaded trees byte
+ * for byte: mismatch[0..13] = differing bytes of nodes, cones, segA, segInv, segOrig, segCol, segVerts, flat, flatCol, sil, silN,
+ * scanBox, scanHl, scanId; [14] = differing scalars (the arrays are not compared then); [15] = bytes compared.
+ * host_ms / device_ms (either may be NULL) = the fastest wall-clock time of each build, uploads and the final wait included. */
+int wost_mesh_build_check(const wost_mesh_desc *mesh, int device, int32_t repeat, double *host_ms, double *device_ms, int64_t *mismatch);
 
 #ifdef __cplusplus
 }

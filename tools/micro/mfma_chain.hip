@@ -10,7 +10,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/micro/mfma_chain.hip -o tools/micro/mfma_chain
 //   ./mfma_chain [launches per configuration = 20000] [points = 524288]
 //
-// Configurations: block size 1024 / 512 / 256 (four / two / one wave per SIMD; LDS padded to 150 KB so that one block owns a CU
+// Configurations: block size 1024 / 768 / 512 / 256 (four / three / two / one wave per SIMD; LDS padded to 150 KB so that one block owns a CU
 // like the production kernel) x MODE:
 //   0 plain          the chain as the compiler schedules it
 //   1 settle         all accumulators of a layer through one asm statement with s_nop 15 behind the layer, operands held (production)
@@ -19,6 +19,8 @@
 //   4 schedbarrier   __builtin_amdgcn_sched_barrier(0) behind each layer, no idle states
 //   5 nolds          weight fragments from global memory (L1/L2), nothing in LDS
 //   6 tail           MODE 0 plus ~200 VALU instructions of transcendental arithmetic on the outputs (the shape of the fused-loss tail)
+//   7 gather         MODE 0 plus sixteen data-dependent 8-byte LDS gathers per lane and tile over the whole 150 KB (the shape of the grid
+//                    encoding: bank conflicts, LDS returns of uneven latency next to the matrix instructions)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -104,6 +106,8 @@ __global__ __launch_bounds__(THREADS) void chain_kernel(const uint2 *fragh, cons
     extern __shared__ uint2 lds_h[];
     if (MODE != 5) {
         for (uint32_t e = threadIdx.x; e < kNMlp / 4; e += THREADS) lds_h[e] = fragh[e];
+        if (MODE == 7)
+            for (uint32_t e = kNMlp / 4 + threadIdx.x; e < 150 * 1024 / 8; e += THREADS) lds_h[e] = uint2{0u, 0u};
         __syncthreads();
     }
     const uint2 *img = MODE == 5 ? fragh : lds_h;
@@ -122,6 +126,25 @@ __global__ __launch_bounds__(THREADS) void chain_kernel(const uint2 *fragh, cons
                 Frag f;
                 f.u = in[((size_t)unit[u] * 2 + t) * 64 + lane];
                 b[u][t] = f.h;
+            }
+        }
+        if (MODE == 7) {
+            // the gathered words are zeros (the image beyond the weights is cleared by the block before the loop): OR-ed into the inputs
+            // they change nothing, but the chain cannot start before they have arrived
+            uint32_t z = 0;
+            uint32_t a = (uint32_t)lane * 2654435761u + (uint32_t)tile * 40503u;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                a = a * 1664525u + 1013904223u;
+                const uint2 w = lds_h[kNMlp / 4 + (a >> 8) % (uint32_t)(150 * 1024 / 8 - kNMlp / 4)];
+                z |= w.x | w.y;
+            }
+#pragma unroll
+            for (int u = 0; u < kSub; ++u) {
+                Frag f;
+                f.h = b[u][0];
+                f.u.x |= z;
+                b[u][0] = f.h;
             }
         }
         f32x4_t acc[kSub][4];
@@ -313,10 +336,12 @@ int main(int argc, char **argv)
 #define RUN3(MODE, NAME)                                                                                      \
     if (only_mode < 0 || only_mode == MODE) {                                                                 \
         run<1024, MODE>(NAME, d_frag, d_in, d_expect, n_units, launches, d_bad, d_first, lds);                \
+        run<768, MODE>(NAME, d_frag, d_in, d_expect, n_units, launches, d_bad, d_first, lds);                 \
         run<512, MODE>(NAME, d_frag, d_in, d_expect, n_units, launches, d_bad, d_first, lds);                 \
         run<256, MODE>(NAME, d_frag, d_in, d_expect, n_units, launches, d_bad, d_first, lds);                 \
     }
     RUN3(0, "plain")
+    RUN3(7, "gather")
     RUN3(6, "tail")
     RUN3(1, "settle")
     RUN3(2, "agpr")
