@@ -548,6 +548,21 @@ def run_mesh_build3(env):
             "what": "wall clock of one mesh build, uploads and the final wait included; wost3_create builds on the device"}
 
 
+def run_mesh_build2(env):
+    """Problem<2>::build_bvh on the device (csrc/wost_build2.hip): the Dirichlet trees of the two BASELINE scenes, the device build
+    against the host builder kept as its checker -- differing bytes over all arrays, fastest of five builds each way"""
+    from elaina_amd import Problem
+    from elaina_amd.integrator import mesh_build_check
+    out = {}
+    for name in ("ladybug", "fille"):
+        p = Problem.load_scene(name)
+        diff, compared, host_ms, dev_ms = mesh_build_check(p.d_verts, p.d_segs, p.d_colors, repeat=5, device=env.local)
+        out[name] = {"segments": int(len(p.d_segs)), "device_build_ms": dev_ms, "host_build_ms": host_ms, "bytes_compared": compared,
+                     "differing_bytes": sum(diff.values())}
+    out["what"] = "wall clock of one tree build, uploads and the final wait included; wost_create builds on the device"
+    return out
+
+
 def run_neumann2d(env, args):
     """A Neumann boundary too large for the flat loops (its silhouette and ray queries on the tree, answered by the wave:
     wost_coop.h): the non-convex closed curve r(t) = 100 (1 + .2 sin 7t + .05 sin 31t) in 3000 segments, zero flux, around a
@@ -662,7 +677,7 @@ def main():
         if "time_to_1spp_ms" in o:
             line["time_to_1spp_ms"] = o["time_to_1spp_ms"]
         if "create_ms" in o:
-            # wost_create of the workload's scene (2-D trees: host builder; outside the timed passes like the reference's loadConfig / build_bvh)
+            # wost_create of the workload's scene (trees built on the device since round 5; outside the timed passes like the reference's loadConfig / build_bvh)
             line["create_ms"] = o["create_ms"]
         if "scheduler" in o:
             line["scheduler"] = o["scheduler"]
@@ -770,7 +785,8 @@ def main():
                     # the same in the opt-in reordered training order (sixteen samples per training launch; cfg4 / cfg4_f16 stay exact-order)
                     ("cfg4_f16_pipelined", cfg4("cfg4_f16_pipelined", precision=16, order=REORDERED)),
                     ("uniform3d", lambda: run_uniform3d(env, args)), ("guided3d", lambda: run_guided3d(env, args)),
-                    ("neumann2d", lambda: run_neumann2d(env, args)), ("mesh_build3", lambda: run_mesh_build3(env)),
+                    ("neumann2d", lambda: run_neumann2d(env, args)), ("mesh_build2", lambda: run_mesh_build2(env)),
+                    ("mesh_build3", lambda: run_mesh_build3(env)),
                     ("guiding_gain", lambda: run_guiding_gain(env))]
             if uniform_field is not None:
                 todo.append(("variance_check", variance_check))

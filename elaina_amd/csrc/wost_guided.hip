@@ -644,15 +644,12 @@ __global__ __launch_bounds__(256) void guided_init_kernel(GParams P)
 // Per pixel the arithmetic and the order of the random draws are those of separate_kernel / sample_kernel /
 // tail_kernel, and the network arithmetic is that of net_forward_h_kernel (same device functions): the field,
 // the training records and hence the trained weights are bit-identical to the one-launch-per-depth path.
-// waves per CU sharing one copy of the weight fragments: 8 with the f16 fragments (26 KB), 10 with the fp32 ones (53 KB).
-// Half precision: TWO waves per SIMD, not the three that fit.  With three or four waves of a SIMD running the f16 matrix-instruction
-// network side by side (weights read from LDS, gathers in between) a 16-point unit now and then comes out a percent different --
-// three launches of net_forward_h_kernel on the same inputs differ in every triple at 768 threads, in none at 512 (EXPERIMENTS 17,
-// 20: bisected in place; the standalone chain tools/micro/mfma_chain.hip does not show it, and what exactly the hardware does is
-// not known) -- and a guided solve in half precision stopped being reproducible run to run about once in 36 solves.  Two waves per
-// SIMD never showed it in any experiment; they cost this kernel its third wave's latency hiding.
+// waves per CU sharing one copy of the weight fragments: 12 with the f16 fragments (26 KB), 10 with the fp32 ones (53 KB)
+// (Round 5 tried two waves per SIMD here against the half-precision run-to-run difference: 18 of 20 full-size solve pairs identical at
+// 512 threads, 17 of 20 at 768 -- not this kernel.  The difference was the training forward's first tile after a light kernel:
+// wost_net.hip net_forward_h_kernel, EXPERIMENTS 20; with that fixed, 25 of 25 pairs are identical.)
 #ifndef WOST_FUSED_THREADS_H
-#define WOST_FUSED_THREADS_H 512
+#define WOST_FUSED_THREADS_H 768
 #endif
 constexpr int fused_threads(bool half) { return half ? WOST_FUSED_THREADS_H : 640; }
 // per wave, beside the lanes' columns: which lane the k-th point of the wave's network batch belongs to (64 bytes)
@@ -1608,19 +1605,11 @@ static int run_guided(wost_guided *g, int shard_index, int shard_count, float *f
             local -= local % 128;
             if (local < (size_t)s.min_batch_size) break;
             const size_t o = it * bs;
-            // forward + loss gradient in one launch where the network trains in half precision, else the two launches
-            int rc = net_forward_loss_dev(g->net, ts.xy + 2 * o, (int)local, st, ts.dir + 2 * o, ts.li + o, ts.pdf + o, ts.onn + o, ts.nrm + 2 * o,
-                                          s.loss_scale);
-            if (rc == WOST_ERR_UNSUPPORTED) {
-                float *raw = nullptr, *dl = nullptr;
-                rc = net_forward_train_dev(g->net, ts.xy + 2 * o, (int)local, st, &raw, &dl);
-                if (rc != WOST_OK) return rc;
-                launch_vmm_loss_gradients(st, raw, ts.dir + 2 * o, ts.li + o, ts.pdf + o, ts.onn + o,
-                                          ts.nrm + 2 * o, (int)local, s.loss_scale, dl, nullptr);
-                ++launches;      // the loss-gradient kernel; the network's own launches are counted by the network
-            } else if (rc != WOST_OK) {
-                return rc;
-            }
+            float *raw = nullptr, *dl = nullptr;
+            int rc = net_forward_train_dev(g->net, ts.xy + 2 * o, (int)local, st, &raw, &dl);
+            if (rc != WOST_OK) return rc;
+            launch_vmm_loss_gradients(st, raw, ts.dir + 2 * o, ts.li + o, ts.pdf + o, ts.onn + o, ts.nrm + 2 * o, (int)local, s.loss_scale, dl, nullptr);
+            ++launches;      // the loss-gradient kernel; the network's own launches are counted by the network
             rc = net_backward_update_dev(g->net, ts.xy + 2 * o, (int)local, s.loss_scale, g->sync ? 0 : 1, st);
             if (rc != WOST_OK) return rc;
             if (g->sync) {

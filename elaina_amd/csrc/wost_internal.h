@@ -40,10 +40,6 @@ int net_inference_dev(wost_net_handle h, const float *xy_dev, const uint32_t *co
                       bool use_inference_params, hipStream_t stream, size_t feature_stride = 0);
 int net_forward_train_dev(wost_net_handle h, const float *xy_dev, int n, hipStream_t stream, float **out_dev,
                           float **dl_dev);
-// training forward + mixture loss gradient in one launch (half-precision training only; WOST_ERR_UNSUPPORTED otherwise: fall back to
-// net_forward_train_dev + launch_vmm_loss_gradients); net_backward_update_dev then takes dL/dout from it
-int net_forward_loss_dev(wost_net_handle h, const float *xy_dev, int n, hipStream_t stream, const float *dir, const float *li,
-                         const float *dir_pdf, const uint8_t *on_neumann, const float *normal, float loss_scale);
 int net_backward_update_dev(wost_net_handle h, const float *xy_dev, int n, float loss_scale, int apply_update,
                             hipStream_t stream);
 int net_apply_update_dev(wost_net_handle h, float loss_scale, hipStream_t stream);

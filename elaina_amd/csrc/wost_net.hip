@@ -393,11 +393,7 @@ __global__ __launch_bounds__(NT) void net_forward_mfma_kernel(NetLayout L, const
 // and receives D[r = 16 rt + 4g + c][point i], so the accumulators of row tile rt ARE the B
 // operand of k-tile kt = rt of the next layer, and lane (i, g) encodes exactly the grid levels
 // g and g + 4 of its point: nothing is exchanged between lanes.
-#ifdef WOST_H_SUB1                 // (developer builds of EXPERIMENTS 17/19: bisecting the run-to-run difference in place)
-constexpr int kHalfSub = 1;
-#else
 constexpr int kHalfSub = 2;       // 16-point groups per wave iteration
-#endif
 constexpr int kHalfThreads = 256;      // training kernel (wost_net_half.h): one wave per SIMD, the accumulators take the registers
 #ifndef WOST_HALF_FWD_THREADS
 #define WOST_HALF_FWD_THREADS 512
@@ -453,39 +449,17 @@ __device__ __forceinline__ void mfma_layer_h(const uint2 *wf, int lane, const h4
 // the reference's network shape only: 8 levels x 4 features -> 64 -> 64 -> 64 -> 48 (33 used with two inputs, 41 with three).
 // DIMS = 2: weights AND grid in LDS; DIMS = 3: the dense 3-D grid is far larger than LDS (a million entries) -- only the weight
 // fragments are staged, the eight corner gathers of a level go to L2.
-__device__ __forceinline__ _Float16 sat_h(float v);
 
-// LOSS = true (training forward of the guided solve, two inputs): the mixture's loss gradient (reference distribution.h:201-264 +
-// train.h:492-553, the arithmetic of vmm_loss_gradients_kernel) is taken right here instead of by a kernel of its own that reads the raw
-// outputs back.  Lane (i, g) of a unit holds the outputs of the lobes g and 4 + g of point i whole; lambda, the lobe densities of the
-// sample's direction and of its mirror image travel between the four lanes of a point by wave shuffles, every sum runs in lobe order as
-// in the one-thread-per-sample kernel -- the same numbers -- and what leaves the kernel is dL/dout as the backward kernel wants it:
-// f16 chain tiles, scaled and saturated like net_train_h_kernel does it itself (`dl_h`: [unit][3 tiles][64 lanes], 96 bytes per point
-// instead of 132 out + 132 back).
-struct LossArgs {
-    const float *dir, *li, *dir_pdf, *normal;
-    const uint8_t *on_neumann;
-    float scale;       // loss_scale / n
-    float dscale;      // the extra power-of-two scale of the f16 deltas (net_train_h_kernel)
-    uint2 *dl_h;
-    uint2 *dbg;        // (WOST_H_DUMP builds, EXPERIMENTS 17: the hidden activations of every layer, [unit][3 layers][4 tiles][64 lanes])
-};
-
-template <int DIMS, bool LOSS>
+template <int DIMS>
 __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayout L, const float *params, const uint2 *fragh, const float *xy, int n,
-                                                                       const uint32_t *n_dev, float *out, size_t out_ldp, size_t out_ldf, uint2 *enc_out,
-                                                                       LossArgs la)
+                                                                       const uint32_t *n_dev, float *out, size_t out_ldp, size_t out_ldf, uint2 *enc_out)
 {
     extern __shared__ uint2 lds_h[];
     __shared__ float s_scale[kNetMaxLevels];
     __shared__ uint32_t s_res[kNetMaxLevels], s_off[kNetMaxLevels + 1];
     // weights and the whole grid (15 384 entries x 8 bytes in half precision): 150 KB of the CU's 160 KB, one block per CU;
     // every gather of the encoding is an LDS read
-#ifdef WOST_H_GRID_GLOBAL
-    const uint32_t n_image = L.n_mlp / 4;
-#else
     const uint32_t n_image = L.n_mlp / 4 + (DIMS == 2 ? L.level_off[L.n_levels] : 0u);
-#endif
     for (uint32_t e = threadIdx.x; e < n_image; e += kHalfFwdThreads) lds_h[e] = fragh[e];
     if (threadIdx.x <= (unsigned)L.n_levels) {
         s_off[threadIdx.x] = L.level_off[threadIdx.x];
@@ -498,18 +472,22 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
     if (n_dev) n = (int)*n_dev;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int n_tiles = (n + 16 * kHalfSub - 1) / (16 * kHalfSub);
-#ifdef WOST_H_GRID_GLOBAL
-    const uint2 *grid = fragh + L.n_mlp / 4;
-#else
     const uint2 *grid = (DIMS == 2 ? lds_h : fragh) + L.n_mlp / 4;
-#endif
-#ifdef WOST_H_W_GLOBAL
-    const uint2 *wimg = fragh;
+    const uint2 *w0 = lds_h + L.w_off[0] / 4, *w1 = lds_h + L.w_off[1] / 4, *w2 = lds_h + L.w_off[2] / 4, *w3 = lds_h + L.w_off[3] / 4;
+    // A wave's FIRST tile is computed twice: first in its turn, then once more behind the wave's last tile, the second result
+    // overwriting the first.  Measured (EXPERIMENTS 20): when this kernel follows a DIFFERENT kernel on the device, the first tile a
+    // wave computes -- and only that one: 37 of 37 deviating units in 3 840 full-size launches -- now and then comes out with a whole
+    // 16-point unit a percent off; the same launch behind a launch of itself never does (0 of 3 840).  What the first pass of a
+    // wave through this code finds different (instruction cache, leftover state) is not known; its last pass finds what all the
+    // others found, and the stores are idempotent.  One tile in nine at full size.
+    const int tile_first = blockIdx.x * (kHalfFwdThreads / 64) + wave, tile_step = gridDim.x * (kHalfFwdThreads / 64);
+#ifdef WOST_H_NO_REDO      // (developer builds: the kernel of rounds 1-4)
+    const bool redo_first = false;
 #else
-    const uint2 *wimg = lds_h;
+    const bool redo_first = tile_first < n_tiles;
 #endif
-    const uint2 *w0 = wimg + L.w_off[0] / 4, *w1 = wimg + L.w_off[1] / 4, *w2 = wimg + L.w_off[2] / 4, *w3 = wimg + L.w_off[3] / 4;
-    for (int tile = blockIdx.x * (kHalfFwdThreads / 64) + wave; tile < n_tiles; tile += gridDim.x * (kHalfFwdThreads / 64)) {
+    for (int tile_it = tile_first; tile_it < n_tiles || (redo_first && tile_it < n_tiles + tile_step); tile_it += tile_step) {
+        const int tile = tile_it < n_tiles ? tile_it : tile_first;
         asm volatile("" ::: "memory");      // the weight fragments are re-read from LDS per tile, not parked in registers
         int pt[kHalfSub];
         bool valid[kHalfSub];
@@ -523,12 +501,8 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int lv = g + 4 * h;
-#ifdef WOST_H_NO_GATHER     // (bisecting builds: a stand-in encoding without a single LDS gather -- wrong numbers, the same in every launch)
-                b[u][h] = h4_t{(_Float16)(x * 0.25f), (_Float16)(y * 0.25f), (_Float16)(x * y), (_Float16)(0.125f * (float)lv)};
-#else
                 b[u][h] = DIMS == 3 ? half_encode_level3(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], x, y, z)
                                     : half_encode_level(grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], x, y);
-#endif
                 if (enc_out) {
                     // training: the encoding goes to the fused backward kernel as it stands (wost_net_half.h)
                     union { h4_t h; uint2 u; } e;
@@ -538,9 +512,6 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
             }
         }
         f32x4_t acc[kHalfSub][4];
-#ifdef WOST_H_FENCE
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15" ::: "memory");
-#endif
         // ---- hidden layers: ReLU, the accumulators of row tile rt become the B operand of k-tile rt
 #pragma unroll
         for (int layer = 0; layer < 3; ++layer) {
@@ -554,150 +525,20 @@ __global__ __launch_bounds__(kHalfFwdThreads) void net_forward_h_kernel(NetLayou
                 for (int rt = 0; rt < 4; ++rt)
                     b[u][rt] = __builtin_elementwise_max(__builtin_convertvector(acc[u][rt], h4_t),
                                                          h4_t{(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f});
-#ifdef WOST_H_DUMP
-            if (LOSS && la.dbg) {
-#pragma unroll
-                for (int u = 0; u < kHalfSub; ++u)
-#pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) {
-                        union { h4_t h; uint2 v; } d;
-                        d.h = b[u][rt];
-                        la.dbg[(((size_t)(tile * kHalfSub + u) * 3 + layer) * 4 + rt) * 64 + lane] = d.v;
-                    }
-            }
-#endif
         }
         mfma_layer_h<4, 3>(w3, lane, b, acc);
         mfma_settle3(acc);
         mfma_hold(b);
-        if (!LOSS) {
 #pragma unroll
-            for (int u = 0; u < kHalfSub; ++u)
+        for (int u = 0; u < kHalfSub; ++u)
 #pragma unroll
-                for (int rt = 0; rt < 3; ++rt)
+            for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int o = 16 * rt + 4 * g + c;
-                        // the network's outputs are half-precision numbers in the reference
-                        if (valid[u] && o < L.n_out) out[(size_t)pt[u] * out_ldp + o * out_ldf] = (float)(_Float16)acc[u][rt][c];
-                    }
-        } else {
-            if (out) {      // (developer check of EXPERIMENTS 17: the raw outputs as well)
-#pragma unroll
-                for (int u = 0; u < kHalfSub; ++u)
-#pragma unroll
-                    for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int o = 16 * rt + 4 * g + c;
-                            if (valid[u] && o < L.n_out) out[(size_t)pt[u] * out_ldp + o * out_ldf] = (float)(_Float16)acc[u][rt][c];
-                        }
-            }
-#pragma unroll
-            for (int u = 0; u < kHalfSub; ++u) {
-                // ---- vmm_loss_gradients_kernel for point pt[u], its eight lobes on the four lanes (i, 0..3) ----
-                const float eps = 1e-5f;  // M_EPSILON
-                const int t = valid[u] ? pt[u] : 0;
-                const float wx = la.dir[2 * (size_t)t], wy = la.dir[2 * (size_t)t + 1];
-                const bool on_n = la.on_neumann && la.on_neumann[t] != 0;
-                float rx = 0.0f, ry = 0.0f;
-                if (on_n) {
-                    const float nx = la.normal[2 * (size_t)t], ny = la.normal[2 * (size_t)t + 1];
-                    const float dd = wx * nx + wy * ny;
-                    rx = wx - 2 * dd * nx;
-                    ry = wy - 2 * dd * ny;
+                for (int c = 0; c < 4; ++c) {
+                    const int o = 16 * rt + 4 * g + c;
+                    // the network's outputs are half-precision numbers in the reference
+                    if (valid[u] && o < L.n_out) out[(size_t)pt[u] * out_ldp + o * out_ldf] = (float)(_Float16)acc[u][rt][c];
                 }
-                // own lobes h = 0, 1 (lobe index g + 4 h): the raw outputs as the separate kernel reads them (f16 numbers)
-                float lam_o[2], kap_o[2], ox_o[2], oy_o[2], mux_o[2], muy_o[2], pk_o[2], pkr_o[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float r0 = (float)(_Float16)acc[u][h][0], r1 = (float)(_Float16)acc[u][h][1];
-                    lam_o[h] = det_expf(fmaxf(fminf(r0, 15.0f), -10.0f));
-                    kap_o[h] = det_expf(fmaxf(fminf(r1, 15.0f), -10.0f));
-                    ox_o[h] = (float)(_Float16)acc[u][h][2];
-                    oy_o[h] = (float)(_Float16)acc[u][h][3];
-                    const float z = ox_o[h] * ox_o[h] + oy_o[h] * oy_o[h], nn = sqrtf(z);
-                    mux_o[h] = z > 0.0f ? ox_o[h] / nn : ox_o[h];
-                    muy_o[h] = z > 0.0f ? oy_o[h] / nn : oy_o[h];
-                    const float lb = log_bessel(kap_o[h], 0);
-                    pk_o[h] = vm_eval_lb(kap_o[h], lb, wx * mux_o[h] + wy * muy_o[h]);
-                    pkr_o[h] = on_n ? vm_eval_lb(kap_o[h], lb, rx * mux_o[h] + ry * muy_o[h]) : 0.0f;
-                }
-                // all eight lobes' lambda, density and mirrored density in every lane of the point
-                float lambda[8], pk[8], pkr[8];
-#pragma unroll
-                for (int gp = 0; gp < 4; ++gp)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int src = i + 16 * gp, k = gp + 4 * h;
-                        lambda[k] = __shfl(lam_o[h], src);
-                        pk[k] = __shfl(pk_o[h], src);
-                        pkr[k] = __shfl(pkr_o[h], src);
-                    }
-                float total = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) total += lambda[k];
-                float probability = 0.0f;
-#pragma unroll
-                for (int sg = 0; sg < 8; ++sg) {
-                    const float w = lambda[sg] / total;
-                    probability += w * pk[sg];
-                    if (on_n) probability += w * pkr[sg];
-                }
-                const float Li = la.li[t];
-                const float dirPdf = la.dir_pdf[t] + eps;
-                const float guidePdf = probability + eps;
-                const float prefix = -Li / dirPdf / guidePdf * la.scale;
-                float gr[3][4];
-#pragma unroll
-                for (int tt = 0; tt < 3; ++tt)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) gr[tt][c] = 0.0f;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int sg = g + 4 * h;
-                    const float w = lambda[sg] / total;
-                    const float vm = pk[sg], vmr = pkr[sg];
-                    float dF_dlambda = (vm + vmr) * (total - lambda[sg]) / (total * total);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if (k == sg) continue;
-                        const float wk = lambda[k] / total;
-                        dF_dlambda -= wk / total * pk[k];
-                        if (on_n) dF_dlambda -= wk / total * pkr[k];
-                    }
-                    float dF_dkappa = w * (vm * vm_dlog_dkappa(kap_o[h], wx * mux_o[h] + wy * muy_o[h]));
-                    if (on_n) dF_dkappa += w * (vmr * vm_dlog_dkappa(kap_o[h], rx * mux_o[h] + ry * muy_o[h]));
-                    const float n2 = ox_o[h] * ox_o[h] + oy_o[h] * oy_o[h];
-                    float denom = n2 * sqrtf(n2);
-                    if (denom < eps) denom = eps;
-                    float dF_dx = w * vm * kap_o[h] * oy_o[h] * (-ox_o[h] * wy + oy_o[h] * wx) / denom;
-                    if (on_n) dF_dx += w * vmr * kap_o[h] * oy_o[h] * (-ox_o[h] * ry + oy_o[h] * rx) / denom;
-                    float dF_dy = w * vm * kap_o[h] * ox_o[h] * (ox_o[h] * wy - oy_o[h] * wx) / denom;
-                    if (on_n) dF_dy += w * vmr * kap_o[h] * ox_o[h] * (ox_o[h] * ry - oy_o[h] * rx) / denom;
-                    gr[h][0] = prefix * dF_dlambda * lambda[sg];
-                    gr[h][1] = prefix * dF_dkappa * kap_o[h];
-                    gr[h][2] = prefix * dF_dx;
-                    gr[h][3] = prefix * dF_dy;
-                }
-                if (g == 0) {
-                    const float uni = on_n ? (float)(1.0 / VM_PI_D) : 1.0f / VM_2PI;
-                    const float sgm = 1.0f / (1.0f + det_expf(-(float)(_Float16)acc[u][2][0]));
-                    gr[2][0] = la.scale * (-0.2f) * Li * (guidePdf - uni) / (dirPdf * dirPdf) * (sgm * (1 - sgm));
-                }
-                // the deltas as net_train_h_kernel takes them: scaled, saturated, f16; zero for the points beyond n
-                const size_t unit = (size_t)(tile * kHalfSub + u);
-#pragma unroll
-                for (int tt = 0; tt < 3; ++tt) {
-                    union { h4_t h; uint2 v; } d;
-                    float v4[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v4[c] = valid[u] ? gr[tt][c] * la.dscale : 0.0f;
-                    d.h = h4_t{sat_h(v4[0]), sat_h(v4[1]), sat_h(v4[2]), sat_h(v4[3])};
-                    la.dl_h[(unit * 3 + tt) * 64 + lane] = d.v;
-                }
-            }
-        }
     }
 }
 
@@ -1509,7 +1350,6 @@ struct wost_net {
     uint2 *params_h = nullptr, *params_hb = nullptr;   // f16 fragments of the training weights and of their transposes
     float *train_partial = nullptr;                    // per-block sums of the matrix gradients (net_train_h_kernel), 256 rows
     bool fused_backward = true;      // net_backward_wgrad_kernel (WOST_NET_FUSED=0: backward and weight gradients apart)
-    bool dl_is_half = false;         // the training forward has left dL/dout as f16 chain tiles in d_dl (net_forward_loss_dev)
     int step = 0;
     uint64_t n_launches = 0;           // kernels and fills issued by the *_dev entry points (wost_guided_stats.kernel_launches)
     uint32_t *param_steps = nullptr;   // Adam steps taken by each parameter (tiny-cuda-nn adam_step)
@@ -1532,16 +1372,16 @@ struct wost_net {
 static size_t half_image_entries(const NetLayout &L) { return (size_t)L.n_mlp / 4 + L.level_off[L.n_levels]; }
 
 static int launch_forward_h(wost_net *h, const float *p, const uint2 *image, const float *xy_dev, int n, const uint32_t *n_dev, float *out_dev,
-                            size_t ldp, size_t ldf, uint2 *enc_out, hipStream_t stream, const LossArgs *loss = nullptr)
+                            size_t ldp, size_t ldf, uint2 *enc_out, hipStream_t stream)
 {
     const NetLayout &L = h->L;
     const size_t lds = (L.dims == 2 ? half_image_entries(L) : (size_t)L.n_mlp / 4) * sizeof(uint2);
     const int n_tiles = (n + 16 * kHalfSub - 1) / (16 * kHalfSub);
     // one block per CU (two inputs: the image takes 150 KB of LDS), walking over the tiles
     const unsigned grid = (unsigned)std::max(1, std::min((n_tiles + kHalfFwdThreads / 64 - 1) / (kHalfFwdThreads / 64), 256));
-    auto kfn = L.dims == 2 ? (loss ? net_forward_h_kernel<2, true> : net_forward_h_kernel<2, false>) : net_forward_h_kernel<3, false>;
+    auto kfn = L.dims == 2 ? net_forward_h_kernel<2> : net_forward_h_kernel<3>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(kHalfFwdThreads), lds, stream, L, p, image, xy_dev, n, n_dev, out_dev, ldp, ldf, enc_out, loss ? *loss : LossArgs{});
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(kHalfFwdThreads), lds, stream, L, p, image, xy_dev, n, n_dev, out_dev, ldp, ldf, enc_out);
     ++h->n_launches;
     NET_TRY(hipGetLastError());
     return WOST_OK;
@@ -1638,10 +1478,90 @@ static int ensure_points(wost_net *h, size_t n)
     return WOST_OK;
 }
 
+// WOST_NET_CHECK3=1 (developer self check, EXPERIMENTS 20): the half-precision training kernels of every Adam step launched three times
+// on the same inputs, the three results compared word by word on the device; the counts go to stderr when the network is destroyed
+__global__ void check3_kernel(const uint32_t *a, const uint32_t *b, const uint32_t *c, size_t n, unsigned long long *out, uint32_t *log)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t x = a[i], y = b[i], z = c[i];
+    if (x == y && y == z) return;
+    const unsigned long long k = atomicAdd(&out[0], 1ull);
+    atomicAdd(&out[1 + (y == z ? 0 : x == z ? 1 : x == y ? 2 : 3)], 1ull);
+    if (log && k < 65536ull) log[k] = (uint32_t)i;
+}
+struct Check3 {
+    bool on = false, asked = false;
+    unsigned long long *dev = nullptr;       // [kernel 0 forward / 1 train][words differing, odd launch 0 1 2, all differ] + launches with a difference
+    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    unsigned long long steps = 0;
+    uint32_t *log = nullptr;                 // word indices of the forward kernel's first 65 536 differing words
+    int n_out = 33;
+};
+static Check3 g_check3;
+static bool check3_on()
+{
+    if (!g_check3.asked) {
+        g_check3.asked = true;
+        const char *e = std::getenv("WOST_NET_CHECK3");
+        g_check3.on = e && std::atoi(e) != 0;
+        if (g_check3.on && (hipMalloc((void **)&g_check3.log, 65536 * 4) != hipSuccess || hipMalloc((void **)&g_check3.dev, 16 * sizeof(unsigned long long)) != hipSuccess ||
+                            hipMemset(g_check3.dev, 0, 16 * sizeof(unsigned long long)) != hipSuccess))
+            g_check3.on = false;
+    }
+    return g_check3.on;
+}
+static void *check3_scratch(int k, size_t bytes)
+{
+    if (g_check3.scratch_bytes[k] < bytes) {
+        if (g_check3.scratch[k]) (void)hipFree(g_check3.scratch[k]);
+        g_check3.scratch[k] = nullptr;
+        if (hipMalloc(&g_check3.scratch[k], bytes) != hipSuccess) return nullptr;
+        g_check3.scratch_bytes[k] = bytes;
+    }
+    return g_check3.scratch[k];
+}
+static void check3_compare(int kernel, const void *a, const void *b, const void *c, size_t bytes, hipStream_t stream)
+{
+    const size_t words = bytes / 4;
+    hipLaunchKernelGGL(check3_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const uint32_t *>(a),
+                       reinterpret_cast<const uint32_t *>(b), reinterpret_cast<const uint32_t *>(c), words, g_check3.dev + 8 * kernel, kernel == 0 ? g_check3.log : nullptr);
+}
+static void check3_report()
+{
+    if (!g_check3.on || !g_check3.dev) return;
+    unsigned long long v[16];
+    if (hipMemcpy(v, g_check3.dev, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return;
+    std::fprintf(stderr, "CHECK3 after %llu training steps: forward words differing %llu (odd launch 0/1/2/all: %llu %llu %llu %llu); train kernel words differing %llu (%llu %llu %llu %llu)\n",
+                 g_check3.steps, v[0], v[1], v[2], v[3], v[4], v[8], v[9], v[10], v[11], v[12]);
+    // where in the launch the forward kernel's differing units lie: a wave takes the tiles blockIdx * waves + wave + k * (256 * waves), k = 0, 1, ...
+    const size_t n_log = (size_t)std::min<unsigned long long>(v[0], 65536ull);
+    if (n_log) {
+        std::vector<uint32_t> idx(n_log);
+        if (hipMemcpy(idx.data(), g_check3.log, n_log * 4, hipMemcpyDeviceToHost) != hipSuccess) return;
+        const int waves = kHalfFwdThreads / 64;
+        std::vector<char> seen;
+        size_t hist[16] = {0}, units = 0;
+        for (uint32_t w : idx) {
+            const size_t unit = (size_t)w / (size_t)g_check3.n_out / 16;
+            if (seen.size() <= unit) seen.resize(unit + 1, 0);
+            if (seen[unit]) continue;
+            seen[unit] = 1;      // (a unit that fails in two different steps is counted once: rare)
+            ++units;
+            hist[std::min<size_t>(15, unit / 2 / (size_t)(256 * waves))]++;
+        }
+        std::fprintf(stderr, "CHECK3 forward: %zu distinct units among the first %zu differing words; by the wave's iteration k: ", units, n_log);
+        for (int k = 0; k < 16; ++k) std::fprintf(stderr, "%zu ", hist[k]);
+        std::fprintf(stderr, "\n");
+    }
+}
+
 static void net_free(wost_net *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    check3_report();
     for (float *p : {h->params, h->inference, h->params_t, h->inference_t, h->params_f, h->inference_f, h->params_fb, h->m1, h->m2, h->ema_raw, h->d_xy, h->d_out, h->d_dl, h->d_acts, h->d_deltas, h->d_denc})
         if (p) (void)hipFree(p);
     if (h->grad && h->grad_owned) (void)hipFree(h->grad);
@@ -1672,220 +1592,32 @@ int net_forward_train_dev(wost_net *h, const float *xy_dev, int n, hipStream_t s
     if (rc != WOST_OK) return rc;
     if (h->train_precision == 16) {
         // the inference kernel on the training weights; the f16 encoding of every point (64 bytes) is kept
+        if (check3_on() && h->L.dims == 2 && std::atoi(std::getenv("WOST_NET_CHECK3")) == 2) {
+            // variant 2: a discarded launch in front (is it the launch that follows OTHER kernels that differs, whatever it computes?)
+            const size_t ob = (size_t)n * h->L.n_out * 4, eb = (size_t)((n + 31) / 32 * 2) * 2 * 64 * 8;
+            float *o3 = (float *)check3_scratch(3, ob);
+            uint2 *e1 = (uint2 *)check3_scratch(2, eb);
+            if (o3 && e1) (void)launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, o3, (size_t)h->L.n_out, 1, e1, stream);
+        }
         rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, h->d_out, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream);
         if (rc != WOST_OK) return rc;
+        if (check3_on() && h->L.dims == 2) {
+            const size_t ob = (size_t)n * h->L.n_out * 4, eb = (size_t)((n + 31) / 32 * 2) * 2 * 64 * 8;
+            float *o1 = (float *)check3_scratch(0, ob), *o2 = (float *)check3_scratch(1, ob);
+            uint2 *e1 = (uint2 *)check3_scratch(2, eb);
+            if (o1 && o2 && e1) {
+                (void)launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, o1, (size_t)h->L.n_out, 1, e1, stream);
+                (void)launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, o2, (size_t)h->L.n_out, 1, e1, stream);
+                check3_compare(0, h->d_out, o1, o2, ob, stream);
+                ++g_check3.steps;
+            }
+        }
     } else {
         rc = launch_forward(h, false, xy_dev, n, nullptr, h->d_out, h->d_acts, stream);
         if (rc != WOST_OK) return rc;
     }
     *out_dev = h->d_out;
     *dl_dev = h->d_dl;
-    return WOST_OK;
-}
-
-// The training forward of the guided solve with the mixture's loss gradient taken inside it (half-precision training, two inputs):
-// one launch instead of forward + vmm_loss_gradients_kernel, dL/dout handed to net_backward_update_dev as f16 tiles.
-// WOST_ERR_UNSUPPORTED (no error recorded) when the network does not train that way: the caller takes the two launches.
-int net_forward_loss_dev(wost_net *h, const float *xy_dev, int n, hipStream_t stream, const float *dir, const float *li, const float *dir_pdf,
-                         const uint8_t *on_neumann, const float *normal, float loss_scale)
-{
-    if (h->train_precision != 16 || h->L.dims != 2 || h->L.n_out != 33) return WOST_ERR_UNSUPPORTED;
-    // OFF unless WOST_NET_FUSED_LOSS asks for it (1: on, 3: on, launched three times and compared): the kernel is 2.6 % of config 4
-    // faster than the two launches and gives the same numbers -- except that now and then a few 16-point units of a launch come out
-    // slightly different (three launches on the same inputs, any one of them the odd one out), which the solve's run-to-run
-    // reproducibility does not tolerate.  What was ruled out is in EXPERIMENTS 17; the cause was not found.
-    const char *fused = std::getenv("WOST_NET_FUSED_LOSS");
-    if (!fused || std::atoi(fused) == 0) return WOST_ERR_UNSUPPORTED;
-    int rc = ensure_points(h, (size_t)std::max(n, 64));
-    if (rc != WOST_OK) return rc;
-    int k = 0;
-    while (k < 10 && (n >> (k + 10)) > 0) ++k;          // the deltas' extra scale, as net_backward_update_dev chooses it
-    LossArgs la{dir, li, dir_pdf, normal, on_neumann, loss_scale / (float)n, (float)(1 << k), reinterpret_cast<uint2 *>(h->d_dl)};
-    const bool check3 = std::atoi(fused) == 3;
-    rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, check3 ? h->d_out : nullptr, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream, &la);
-    if (rc != WOST_OK) return rc;
-    if (const char *e = std::getenv("WOST_NET_FUSED_LOSS"))
-        if (std::atoi(e) == 3) {
-            // developer check: the same launch twice more into other buffers, the three compared word by word (which one is the odd one out)
-            const size_t words = (size_t)((n + 31) / 32 * 2) * 3 * 64 * 2;
-            uint32_t *extra = nullptr;
-            std::vector<uint32_t> r[3];
-            for (auto &v : r) v.resize(words);
-            const size_t n_raw = (size_t)n * h->L.n_out;
-            float *raw2 = nullptr;
-            NET_TRY(hipMalloc((void **)&extra, 2 * words * 4));
-            NET_TRY(hipMalloc((void **)&raw2, 2 * n_raw * 4));
-            NET_TRY(hipMemsetAsync(extra, 0xee, 2 * words * 4, stream));
-#ifdef WOST_H_DUMP
-            const size_t n_units_d = (size_t)((n + 31) / 32 * 2), dump_words = n_units_d * 3 * 4 * 64;
-            uint2 *dump = nullptr;
-            NET_TRY(hipMalloc((void **)&dump, 3 * dump_words * sizeof(uint2)));
-            {
-                // (the first launch above ran without a dump: it is repeated here into slot 0, the comparison below is among these three)
-                LossArgs l0 = la;
-                l0.dbg = dump;
-                rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, h->d_out, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream, &l0);
-            }
-#endif
-            for (int k = 0; k < 2; ++k) {
-                LossArgs lb = la;
-#ifdef WOST_H_DUMP
-                lb.dbg = dump + (size_t)(k + 1) * dump_words;
-#endif
-                lb.dl_h = reinterpret_cast<uint2 *>(extra + k * words);
-                rc = launch_forward_h(h, h->params, h->params_h, xy_dev, n, nullptr, raw2 + k * n_raw, (size_t)h->L.n_out, 1, reinterpret_cast<uint2 *>(h->d_acts), stream, &lb);
-            }
-            NET_TRY(hipStreamSynchronize(stream));
-#ifdef WOST_H_DUMP
-            {
-                // where the three launches part: per differing unit the first layer and the tiles (16 hidden features each) that differ,
-                // which launch is the odd one, and whether the odd values are explained by ONE operand of the layer's matrix
-                // instructions having been another fragment of the weight image
-                std::vector<uint2> d(3 * dump_words), enc(n_units_d * 2 * 64), img(h->L.n_mlp / 4);
-                NET_TRY(hipMemcpy(d.data(), dump, d.size() * sizeof(uint2), hipMemcpyDeviceToHost));
-                NET_TRY(hipMemcpy(enc.data(), h->d_acts, enc.size() * sizeof(uint2), hipMemcpyDeviceToHost));
-                NET_TRY(hipMemcpy(img.data(), h->params_h, img.size() * sizeof(uint2), hipMemcpyDeviceToHost));
-                (void)hipFree(dump);
-                auto half4 = [](uint2 v, float *o) { union { uint2 u; h4_t hh; } x; x.u = v; for (int c = 0; c < 4; ++c) o[c] = (float)x.hh[c]; };
-                size_t shown = 0, bad_units = 0;
-                size_t hist[3][5] = {{0}};
-                for (size_t u = 0; u < n_units_d; ++u) {
-                    int first_layer = -1;
-                    unsigned tiles = 0;
-                    int odd = -1;
-                    for (int layer = 0; layer < 3 && first_layer < 0; ++layer)
-                        for (int rt = 0; rt < 4; ++rt)
-                            for (int l = 0; l < 64; ++l) {
-                                const size_t i = ((u * 3 + layer) * 4 + rt) * 64 + l;
-                                const uint2 a = d[i], b2 = d[dump_words + i], c2 = d[2 * dump_words + i];
-                                const bool ab = a.x == b2.x && a.y == b2.y, bc = b2.x == c2.x && b2.y == c2.y;
-                                if (ab && bc) continue;
-                                first_layer = layer;
-                                tiles |= 1u << rt;
-                                odd = bc ? 0 : (a.x == c2.x && a.y == c2.y) ? 1 : ab ? 2 : 3;
-                            }
-                    if (first_layer < 0) continue;
-                    ++bad_units;
-                    hist[first_layer][__builtin_popcount(tiles)]++;
-                    if (shown++ >= 6) continue;
-                    std::fprintf(stderr, "DUMP unit %zu (unit %zu of its tile): first differing layer %d, tiles mask %x, odd launch %d\n", u, u & 1, first_layer, tiles, odd);
-                    // the layer's inputs (identical in the three launches: the layer before did not differ) and its weight fragments
-                    const int KT = first_layer == 0 ? 2 : 4;
-                    float in[4][64][4];
-                    for (int kt = 0; kt < KT; ++kt)
-                        for (int l = 0; l < 64; ++l)
-                            half4(first_layer == 0 ? enc[(u * 2 + kt) * 64 + l] : d[((u * 3 + first_layer - 1) * 4 + kt) * 64 + l], in[kt][l]);
-                    const uint2 *wf = img.data() + h->L.w_off[first_layer] / 4;
-                    const int good = odd == 0 ? 1 : 0, oddl = odd < 3 ? odd : 0;
-                    for (int rt = 0; rt < 4; ++rt) {
-                        if (!(tiles & (1u << rt))) continue;
-                        // out[row 16 rt + 4 g + c][point i] = sum_kt sum_g' sum_c' W[16 rt + i'][16 kt + 4 g' + c'] ... evaluated per lane of the D layout:
-                        // lane (i, g) holds rows 16 rt + 4 g + c of point i; fragment (rt, kt) lane (i', g') = W[16 rt + i'][16 kt + 4 g' .. + 3]
-                        auto eval = [&](int sub_rt, int sub_kt, int with_rt, int with_kt, float *out /*[64][4]*/) {
-                            for (int l = 0; l < 64; ++l) {
-                                const int i = l & 15, g = l >> 4;
-                                for (int c = 0; c < 4; ++c) {
-                                    const int row = 4 * g + c;      // row inside the tile
-                                    double acc = 0.0;
-                                    for (int kt = 0; kt < KT; ++kt) {
-                                        int frt = rt, fkt = kt;
-                                        if (rt == sub_rt && kt == sub_kt) { frt = with_rt; fkt = with_kt; }
-                                        for (int gp = 0; gp < 4; ++gp) {
-                                            float w4[4];
-                                            half4(wf[(frt * KT + fkt) * 64 + 16 * gp + row], w4);      // W[16 frt + row][16 fkt + 4 gp + c']
-                                            for (int cp = 0; cp < 4; ++cp) acc += (double)w4[cp] * (double)in[kt][16 * gp + i][cp];
-                                        }
-                                    }
-                                    out[l * 4 + c] = (float)acc;
-                                }
-                            }
-                        };
-                        std::vector<float> ref(256), got_good(256), got_odd(256), alt(256);
-                        for (int l = 0; l < 64; ++l) {
-                            half4(d[(size_t)good * dump_words + ((u * 3 + first_layer) * 4 + rt) * 64 + l], &got_good[l * 4]);
-                            half4(d[(size_t)oddl * dump_words + ((u * 3 + first_layer) * 4 + rt) * 64 + l], &got_odd[l * 4]);
-                        }
-                        eval(-1, -1, 0, 0, ref.data());
-                        auto dist = [&](const std::vector<float> &a, const std::vector<float> &b2) {
-                            double s2 = 0.0;
-                            for (int k = 0; k < 256; ++k) { const double x = std::max(a[k], 0.0f) - b2[k]; s2 += x * x; }
-                            return std::sqrt(s2 / 256.0);
-                        };
-                        std::fprintf(stderr, "   tile %d: rms(host - good launch) %.3g, rms(host - odd launch) %.3g;", rt, dist(ref, got_good), dist(ref, got_odd));
-                        double best = 1e30;
-                        int b_kt = -1, b_rt = -1, b_wkt = -1;
-                        for (int skt = 0; skt < KT; ++skt)
-                            for (int wrt = 0; wrt < 4; ++wrt)
-                                for (int wkt = 0; wkt < KT; ++wkt) {
-                                    if (wrt == rt && wkt == skt) continue;
-                                    eval(rt, skt, wrt, wkt, alt.data());
-                                    const double e = dist(alt, got_odd);
-                                    if (e < best) { best = e; b_kt = skt; b_rt = wrt; b_wkt = wkt; }
-                                }
-                        std::fprintf(stderr, " best single-fragment substitution: fragment (rt %d, kt %d) read as (rt %d, kt %d): rms %.3g\n", rt, b_kt, b_rt, b_wkt, best);
-                    }
-                }
-                std::fprintf(stderr, "DUMP: %zu units differ; first differing layer x number of tiles (1..4): L0 %zu %zu %zu %zu | L1 %zu %zu %zu %zu | L2 %zu %zu %zu %zu\n", bad_units,
-                             hist[0][1], hist[0][2], hist[0][3], hist[0][4], hist[1][1], hist[1][2], hist[1][3], hist[1][4], hist[2][1], hist[2][2], hist[2][3], hist[2][4]);
-            }
-#endif
-            {
-                std::vector<float> o0(n_raw), o1(n_raw), o2(n_raw);
-                NET_TRY(hipMemcpy(o0.data(), h->d_out, n_raw * 4, hipMemcpyDeviceToHost));
-                NET_TRY(hipMemcpy(o1.data(), raw2, n_raw * 4, hipMemcpyDeviceToHost));
-                NET_TRY(hipMemcpy(o2.data(), raw2 + n_raw, n_raw * 4, hipMemcpyDeviceToHost));
-                (void)hipFree(raw2);
-                size_t bad_vals = 0, bad_pts = 0, last_pt = (size_t)-1, shown = 0;
-                for (size_t i = 0; i < n_raw; ++i)
-                    if (std::memcmp(&o0[i], &o1[i], 4) != 0 || std::memcmp(&o1[i], &o2[i], 4) != 0) {
-                        ++bad_vals;
-                        const size_t pt = i / h->L.n_out;
-                        if (pt != last_pt) { ++bad_pts; last_pt = pt; if (shown++ < 12) std::fprintf(stderr, "   raw outputs differ at point %zu (unit %zu, i %zu), output %zu: %g %g %g\n", pt, pt / 16, pt % 16, i % h->L.n_out, o0[i], o1[i], o2[i]); }
-                    }
-                std::fprintf(stderr, "raw network outputs of the three launches: %zu values in %zu points differ; units:", bad_vals, bad_pts);
-                {
-                    size_t last_unit = (size_t)-1;
-                    int n_out_here = 0;
-                    for (size_t i = 0; i < n_raw; ++i)
-                        if (std::memcmp(&o0[i], &o1[i], 4) != 0 || std::memcmp(&o1[i], &o2[i], 4) != 0) {
-                            const size_t unit = i / h->L.n_out / 16;
-                            if (unit != last_unit) {
-                                const int odd = std::memcmp(&o1[i], &o2[i], 4) == 0 ? 0 : std::memcmp(&o0[i], &o2[i], 4) == 0 ? 1 : std::memcmp(&o0[i], &o1[i], 4) == 0 ? 2 : 3;
-                                if (n_out_here++ < 40) std::fprintf(stderr, " %zu(launch %d)", unit, odd);
-                                last_unit = unit;
-                            }
-                        }
-                    std::fprintf(stderr, "\n");
-                }
-                {
-                    // which units: do the two units of a wave's tile (2u, 2u + 1: one weight fragment serves both) fail together?
-                    std::vector<char> bad_unit((n + 15) / 16 + 1, 0);
-                    for (size_t i = 0; i < n_raw; ++i)
-                        if (std::memcmp(&o0[i], &o1[i], 4) != 0 || std::memcmp(&o1[i], &o2[i], 4) != 0) bad_unit[i / h->L.n_out / 16] = 1;
-                    size_t units = 0, with_partner = 0;
-                    for (size_t u = 0; u < bad_unit.size(); ++u)
-                        if (bad_unit[u]) { ++units; with_partner += bad_unit[u ^ 1] ? 1 : 0; }
-                    std::fprintf(stderr, "TRIPLE %s: %zu units differ, %zu of them together with the other unit of their tile\n", units ? "BAD" : "CLEAN", units, with_partner);
-                }
-            }
-            NET_TRY(hipMemcpy(r[0].data(), h->d_dl, words * 4, hipMemcpyDeviceToHost));
-            NET_TRY(hipMemcpy(r[1].data(), extra, words * 4, hipMemcpyDeviceToHost));
-            NET_TRY(hipMemcpy(r[2].data(), extra + words, words * 4, hipMemcpyDeviceToHost));
-            (void)hipFree(extra);
-            size_t odd[4] = {0, 0, 0, 0}, shown = 0;
-            for (size_t i = 0; i < words; ++i) {
-                const uint32_t a0 = r[0][i], a1 = r[1][i], a2 = r[2][i];
-                if (a0 == a1 && a1 == a2) continue;
-                const int which = a1 == a2 ? 0 : a0 == a2 ? 1 : a0 == a1 ? 2 : 3;
-                ++odd[which];
-                if (shown++ < 40)
-                    std::fprintf(stderr, "   word %zu unit %zu tile %zu lane %zu (i %zu g %zu) pair %zu: %08x %08x %08x odd %d\n", i, i / 384, i / 128 % 3, i / 2 % 64,
-                                 i / 2 % 16, i / 2 % 64 / 16, i % 2, a0, a1, a2, which);
-            }
-            std::fprintf(stderr, "fused loss three times: n %d, odd one out: first %zu, second %zu, third %zu, all differ %zu words of %zu\n", n, odd[0], odd[1], odd[2],
-                         odd[3], words);
-        }
-    h->dl_is_half = true;
     return WOST_OK;
 }
 
@@ -1906,9 +1638,18 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
         int k = 0;
         while (k < 10 && (n >> (k + 10)) > 0) ++k;          // 2^k ~ n / 512, between 1 and 1024
         hipLaunchKernelGGL(net_train_h_kernel, dim3(gridb), dim3(kHalfThreads), lds, stream, L, h->params_h, h->params_hb,
-                           reinterpret_cast<const uint2 *>(h->d_acts), h->d_dl, n, (float)(1 << k), h->d_denc, h->train_partial,
-                           h->dl_is_half ? reinterpret_cast<const uint2 *>(h->d_dl) : nullptr);
-        h->dl_is_half = false;
+                           reinterpret_cast<const uint2 *>(h->d_acts), h->d_dl, n, (float)(1 << k), h->d_denc, h->train_partial);
+        if (check3_on() && L.dims == 2) {
+            const size_t db = (size_t)n * L.enc * 4, pb = (size_t)gridb * L.n_mlp * 4;
+            float *d1 = (float *)check3_scratch(0, db), *d2 = (float *)check3_scratch(1, db), *p1 = (float *)check3_scratch(2, pb), *p2 = (float *)check3_scratch(3, pb);
+            if (d1 && d2 && p1 && p2) {
+                for (int rep = 0; rep < 2; ++rep)
+                    hipLaunchKernelGGL(net_train_h_kernel, dim3(gridb), dim3(kHalfThreads), lds, stream, L, h->params_h, h->params_hb,
+                                       reinterpret_cast<const uint2 *>(h->d_acts), h->d_dl, n, (float)(1 << k), rep ? d2 : d1, rep ? p2 : p1);
+                check3_compare(1, h->d_denc, d1, d2, db, stream);
+                check3_compare(1, h->train_partial, p1, p2, pb, stream);
+            }
+        }
         hipLaunchKernelGGL(net_train_h_reduce_kernel, dim3((L.n_mlp + 255) / 256, (gridb + 15) / 16), dim3(256), 0, stream, L, h->train_partial, (int)gridb,
                            h->grad);
         h->n_launches += 2;

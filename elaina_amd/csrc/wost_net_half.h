@@ -184,9 +184,8 @@ __device__ __forceinline__ void flush_h(const f32x4_t (&gacc)[RT][KT], int lane,
 // deltas while they are f16 (loss scale 128 / batch 524 288 ~ 2e-4 sits at the f16 subnormal edge;
 // chosen by the host from the batch size, divided out before anything leaves the kernel);
 // denc: level-major, [8 levels][n points][4 features]; partial: one row of n_mlp block sums per block
-// dl_h != nullptr: dL/dout arrives as f16 chain tiles already ([unit][3][64 lanes], scaled and saturated: net_forward_h_kernel<.., LOSS>)
 __global__ __launch_bounds__(kHalfThreads, 1) void net_train_h_kernel(NetLayout L, const uint2 *fragh, const uint2 *fragb, const uint2 *enc, const float *dl,
-                                                                        int n, float dscale, float *denc, float *partial, const uint2 *dl_h)
+                                                                        int n, float dscale, float *denc, float *partial)
 {
     extern __shared__ uint2 lds_h[];
     const uint32_t nf = L.n_mlp / 4;
@@ -214,18 +213,13 @@ __global__ __launch_bounds__(kHalfThreads, 1) void net_train_h_kernel(NetLayout 
     // the inputs of a unit (2 encoding tiles, 12 values of dL/dout per lane) are fetched one unit ahead:
     // with one wave per SIMD nothing else hides the memory latency
     const int stride = gridDim.x * (kHalfThreads / 64);
-    uint2 enc_next[2], dlh_next[3];
+    uint2 enc_next[2];
     float dl_next[3][4];
     auto fetch = [&](int unit) {
         const int pt = unit * 16 + i;
         const int u = unit < n_units ? unit : n_units - 1;
 #pragma unroll
         for (int h = 0; h < 2; ++h) enc_next[h] = enc[((size_t)u * 2 + h) * 64 + lane];
-        if (dl_h) {
-#pragma unroll
-            for (int t = 0; t < 3; ++t) dlh_next[t] = dl_h[((size_t)u * 3 + t) * 64 + lane];
-            return;
-        }
         // addresses clamped instead of branches: all twelve loads in flight at once
         const float *row = dl + (size_t)(pt < n ? pt : n - 1) * L.n_out;
 #pragma unroll
@@ -251,21 +245,12 @@ __global__ __launch_bounds__(kHalfThreads, 1) void net_train_h_kernel(NetLayout 
             e.u = enc_next[h];
             a0[h] = e.h;
         }
-        if (dl_h) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                HalfFrag f;
-                f.u = dlh_next[t];
-                d[t] = f.h;
-            }
-        } else {
+        for (int t = 0; t < 3; ++t) {
+            float v[4];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                float v[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = (valid && 16 * t + 4 * g + c < L.n_out) ? dl_next[t][c] * dscale : 0.0f;
-                d[t] = h4_t{sat_h(v[0]), sat_h(v[1]), sat_h(v[2]), sat_h(v[3])};
-            }
+            for (int c = 0; c < 4; ++c) v[c] = (valid && 16 * t + 4 * g + c < L.n_out) ? dl_next[t][c] * dscale : 0.0f;
+            d[t] = h4_t{sat_h(v[0]), sat_h(v[1]), sat_h(v[2]), sat_h(v[3])};
         }
         fetch(unit + stride);
         asm volatile("" ::: "memory");      // keeps the loads up here, ahead of the unit's arithmetic

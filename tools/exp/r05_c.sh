@@ -1,4 +1,5 @@
 #!/bin/bash
+# (a record: ran at commit 45cb138, whose wost_net.hip still had the fused-loss kernel, its three-launch check and the -D variants used here)
 # round 5, trip c: the half-precision run-to-run difference bisected in place -- the fused-loss forward launched three times on the
 # same inputs (WOST_NET_FUSED_LOSS=3, tools/probes/repro_probe3.py), clean / bad triples per build variant
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (a record: ran at commit 45cb138, whose wost_net.hip still had the fused-loss kernel, its three-launch check and the -D variants used here)
 # round 5, trip e: the half-precision difference at three waves per SIMD (blocks of 768: every triple differs) bisected in place,
 # and the standalone chain at 768 threads / with LDS gathers beside it
 export TMPDIR=/tmp
