@@ -592,7 +592,7 @@ def run_neumann2d(env, args):
          "unit": "walk-steps/s"}
     if not args.no_cpu_baseline:
         from oracle.oracle import Oracle
-        b, e_ = band_of(frame, 4)
+        b, e_ = band_of(frame, 1)
         ref = Oracle().solve(p.as_dict(), frame, frame, spp, depth, eps, pixel_begin=b, pixel_end=e_, threads=os.cpu_count() or 1)
         e["rel_l2_vs_oracle"] = rel_l2(it.solution.reshape(-1, 3)[b:e_], ref["field"])
         e["rel_l2_band"] = "rows %d..%d" % (b // frame, e_ // frame)

@@ -1764,6 +1764,16 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
                 lv = end;
                 continue;
             }
+            // levels of which not even ONE feature fits a block's LDS (three inputs: 32^3 cells and up) add straight to global memory: all
+            // of them and all their features in ONE launch -- a launch per level and feature slice (round 4: sixteen of a step's twenty-odd
+            // launches) walks all n points again each time for the same atomics
+            if (level_bytes(lv, 1) > big) {
+                int end_g = lv;
+                while (end_g < L.n_levels && level_bytes(end_g, 1) > big) ++end_g;
+                launch(lv, end_g, 0, L.n_features, 0, 0);
+                lv = end_g;
+                continue;
+            }
             // this level alone exceeds the group budget: whole if it fits one block per CU, else feature slices
             int slices = 1;
             while (slices < L.n_features && level_bytes(lv, (L.n_features + slices - 1) / slices) > big) ++slices;
