@@ -223,6 +223,9 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
     t1 = None
     if one_spp:
         it1 = UniformIntegrator(problem, UniformIntegratorSettings((frame, frame), 1, depth, eps), device=env.local)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            it1.set_option(k, float(v))
         t1 = []
         for _ in range(4):
             torch.cuda.synchronize()

@@ -326,19 +326,27 @@ struct B2Sums {
     FitSums fit;
     ConeSums cone;
 };
+// extents of a node's end points along the sixteen FIXED candidate directions: minima and maxima, so a node's are the union of its
+// children's -- made bottom-up with the sums, not by a sweep of the node's segments per direction (which was 17 sweeps per child, a
+// quarter of the whole build); only the principal axis, a different one for every node, still needs its own sweep
+struct B2Fixed {
+    FitExtent e[kFitDirs];
+};
 __device__ __forceinline__ void b2_add_seg_normal(ConeSums &c, const DevFlatSeg *flat, int s)
 {
     if (flat[s].len > 0.0f) cone_add_normal(c, flat[s].nx, flat[s].ny);
 }
 __global__ __launch_bounds__(256) void b2_leaf_kernel(B2Shape S, const int32_t *slot_of, const DevFlatSeg *flat, const float *flatCol, const float *verts, const int32_t *segs,
                                                       const int32_t *vprev, const int32_t *vnext, const B2Meta *meta, float4 *segA, float *segInv, int32_t *segOrig, float *segCol,
-                                                      int2 *segVerts, float *nodes, float *cones, B2Sums *sums)
+                                                      int2 *segVerts, float *nodes, float *cones, B2Sums *sums, B2Fixed *fixed)
 {
     const int L = blockIdx.x * blockDim.x + threadIdx.x;
     if (L >= S.cap || meta->bad) return;
     const float lox = b2_dec(meta->lo[0]), loy = b2_dec(meta->lo[1]), hix = b2_dec(meta->hi[0]), hiy = b2_dec(meta->hi[1]);
     const double grid = fit_grid_scale(lox, loy, hix, hiy);
     B2Sums a{};
+    B2Fixed fx;
+    for (int d = 0; d < kFitDirs; ++d) fx.e[d] = fit_extent_empty();
     float *nd = nodes + (size_t)(S.first_leaf + L) * 24;
     float *cn = cones + (size_t)(S.first_leaf + L) * 20;
     for (int j = 0; j < kLeafSize; ++j) {
@@ -366,25 +374,36 @@ __global__ __launch_bounds__(256) void b2_leaf_kernel(B2Shape S, const int32_t *
         for (int e = 0; e < 2; ++e) {
             const int v = segs[2 * o + e];
             fit_add_point(a.fit, verts[2 * v], verts[2 * v + 1], lox, loy, grid);
+            for (int d = 0; d < kFitDirs; ++d) fit_extent_add(fx.e[d], fit_dir(d).c, fit_dir(d).s, verts[2 * v], verts[2 * v + 1]);
             if (vprev[v] < 0 || vnext[v] < 0) a.cone.open = 1;
             if (vprev[v] >= 0) b2_add_seg_normal(a.cone, flat, vprev[v]);
             if (vnext[v] >= 0) b2_add_seg_normal(a.cone, flat, vnext[v]);
         }
     }
     sums[S.first_leaf + L] = a;
+    fixed[S.first_leaf + L] = fx;
 }
-__global__ __launch_bounds__(256) void b2_inner_sums_kernel(int level_first, int level_count, const B2Meta *meta, B2Sums *sums)
+__global__ __launch_bounds__(256) void b2_inner_sums_kernel(int level_first, int level_count, const B2Meta *meta, B2Sums *sums, B2Fixed *fixed)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= level_count || meta->bad) return;
     const int g = level_first + p;
     B2Sums a{};
+    B2Fixed fx;
+    for (int d = 0; d < kFitDirs; ++d) fx.e[d] = fit_extent_empty();
     for (int j = 1; j <= kArity; ++j) {
         const B2Sums c = sums[kArity * g + j];
         fit_add_sums(a.fit, c.fit);
         cone_add_sums(a.cone, c.cone);
+        for (int d = 0; d < kFitDirs; ++d) {
+            const FitExtent ce = fixed[kArity * g + j].e[d];
+            FitExtent &e = fx.e[d];
+            e.umin = fmin(e.umin, ce.umin); e.umax = fmax(e.umax, ce.umax);
+            e.vmin = fmin(e.vmin, ce.vmin); e.vmax = fmax(e.vmax, ce.vmax);
+        }
     }
     sums[g] = a;
+    fixed[g] = fx;
 }
 
 __device__ __forceinline__ double b2_shfl_xor(double v, int m)
@@ -406,7 +425,7 @@ __device__ __forceinline__ void b2_child_span(const B2Shape &S, int c4, long lon
 
 // ---- the oriented box of every child of every inner node, one wave per child (lbvh_build.cpp fit_obb) -------------------------
 __global__ __launch_bounds__(256) void b2_obb_kernel(B2Shape S, const int32_t *slot_of, const float *verts, const int32_t *segs, const B2Meta *meta, const B2Sums *sums,
-                                                     double obb_pad_rel, float *nodes)
+                                                     const B2Fixed *fixed, double obb_pad_rel, float *nodes)
 {
     const long long w = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -428,17 +447,21 @@ __global__ __launch_bounds__(256) void b2_obb_kernel(B2Shape S, const int32_t *s
         if (a < 0) fit_pca_axis(fs, uxf, uyf);
         else { uxf = fit_dir(a).c; uyf = fit_dir(a).s; }
         FitExtent e = fit_extent_empty();
-        for (long long k = s0 + lane; k < s1; k += 64) {
-            const int o = slot_of[k];
-            if (o < 0) continue;
-            for (int q = 0; q < 2; ++q) {
-                const int v = segs[2 * o + q];
-                fit_extent_add(e, uxf, uyf, verts[2 * v], verts[2 * v + 1]);
+        if (a < 0) {
+            for (long long k = s0 + lane; k < s1; k += 64) {
+                const int o = slot_of[k];
+                if (o < 0) continue;
+                for (int q = 0; q < 2; ++q) {
+                    const int v = segs[2 * o + q];
+                    fit_extent_add(e, uxf, uyf, verts[2 * v], verts[2 * v + 1]);
+                }
             }
-        }
-        for (int m = 32; m >= 1; m >>= 1) {
-            e.umin = fmin(e.umin, b2_shfl_xor(e.umin, m)); e.umax = fmax(e.umax, b2_shfl_xor(e.umax, m));
-            e.vmin = fmin(e.vmin, b2_shfl_xor(e.vmin, m)); e.vmax = fmax(e.vmax, b2_shfl_xor(e.vmax, m));
+            for (int m = 32; m >= 1; m >>= 1) {
+                e.umin = fmin(e.umin, b2_shfl_xor(e.umin, m)); e.umax = fmax(e.umax, b2_shfl_xor(e.umax, m));
+                e.vmin = fmin(e.vmin, b2_shfl_xor(e.vmin, m)); e.vmax = fmax(e.vmax, b2_shfl_xor(e.vmax, m));
+            }
+        } else {
+            e = fixed[c4].e[a];      // the union of the children's extents along this direction (minima and maxima: exact)
         }
         const double score = fit_score(e);
         if (score < best) {
@@ -592,7 +615,7 @@ int build_tree_device(const wost_mesh_desc &d, DeviceTree2 &out_tree)
                  t_pre = tmp.take((size_t)n * 16), t_suf = tmp.take((size_t)n * 16), t_rb = tmp.take(max_ranges * 4), t_re = tmp.take(max_ranges * 4),
                  t_rb2 = tmp.take(max_ranges * 4), t_re2 = tmp.take(max_ranges * 4), t_split = tmp.take(max_ranges * 4), t_axis = tmp.take(max_ranges * 4),
                  t_c0 = tmp.take(max_ranges * 8), t_c1 = tmp.take(max_ranges * 8), t_o0 = tmp.take(max_ranges * 4), t_o1 = tmp.take(max_ranges * 4),
-                 t_slot_of = tmp.take(n_slots * 4), t_flag = tmp.take(n_slots * 4), t_dst = tmp.take(n_slots * 4), t_sums = tmp.take((size_t)S.n_all * sizeof(B2Sums)),
+                 t_slot_of = tmp.take(n_slots * 4), t_flag = tmp.take(n_slots * 4), t_dst = tmp.take(n_slots * 4), t_sums = tmp.take((size_t)S.n_all * sizeof(B2Sums)), t_fixed = tmp.take((size_t)S.n_all * sizeof(B2Fixed)),
                  t_rp = tmp.take(std::max(std::max(sort_a, sort_b), std::max(scan_c, scan_d)));
     B2_TRY(hipMalloc((void **)&out.base, out.size));
     B2_TRY(hipMalloc((void **)&tmp.base, tmp.size));
@@ -681,21 +704,22 @@ int build_tree_device(const wost_mesh_desc &d, DeviceTree2 &out_tree)
     // ---- leaves, sums bottom-up, boxes, cones, the scan copies ----
     float *nodes = out.at<float>(o_nodes), *cones = out.at<float>(o_cones);
     B2Sums *sums = tmp.at<B2Sums>(t_sums);
+    B2Fixed *fixed = tmp.at<B2Fixed>(t_fixed);
     B2_TRY(hipMemsetAsync(nodes, 0, (size_t)S.n_all * 96, st));
     B2_TRY(hipMemsetAsync(cones, 0, (size_t)S.n_all * 80, st));
     hipLaunchKernelGGL(b2_leaf_kernel, b2_grid(S.cap), dim3(256), 0, st, S, slot_of, flat, flatCol, verts, segs, vprev, vnext, meta, out.at<float4>(o_segA),
-                       out.at<float>(o_segInv), out.at<int32_t>(o_segOrig), out.at<float>(o_segCol), out.at<int2>(o_segVerts), nodes, cones, sums);
+                       out.at<float>(o_segInv), out.at<int32_t>(o_segOrig), out.at<float>(o_segCol), out.at<int2>(o_segVerts), nodes, cones, sums, fixed);
     {
         int first = S.first_leaf, count = S.cap;
         for (int l = S.levels - 1; l >= 0; --l) {
             count /= kArity;
             first -= count;
-            hipLaunchKernelGGL(b2_inner_sums_kernel, b2_grid(count), dim3(256), 0, st, first, count, meta, sums);
+            hipLaunchKernelGGL(b2_inner_sums_kernel, b2_grid(count), dim3(256), 0, st, first, count, meta, sums, fixed);
         }
     }
     const char *e_pad = getenv("WOST_OBB_PAD_LOG2");   // developer knob: absolute pad = ext * 2^-k
     const double obb_pad_rel = std::ldexp(1.0, -(e_pad ? atoi(e_pad) : 21));
-    hipLaunchKernelGGL(b2_obb_kernel, b2_grid(256ll * S.first_leaf), dim3(256), 0, st, S, slot_of, verts, segs, meta, sums, obb_pad_rel, nodes);
+    hipLaunchKernelGGL(b2_obb_kernel, b2_grid(256ll * S.first_leaf), dim3(256), 0, st, S, slot_of, verts, segs, meta, sums, fixed, obb_pad_rel, nodes);
     hipLaunchKernelGGL(b2_cone_kernel, b2_grid(256ll * S.first_leaf), dim3(256), 0, st, S, slot_of, flat, verts, segs, vprev, vnext, meta, sums, nodes, cones);
     int32_t *flag = tmp.at<int32_t>(t_flag), *dst = tmp.at<int32_t>(t_dst);
     hipLaunchKernelGGL(b2_occupied_kernel, b2_grid((long long)n_slots), dim3(256), 0, st, slot_of, (long long)n_slots, flag);

@@ -3,7 +3,7 @@
 # TAG names the output directory under gpurun_out/; STAGES selects what runs (default: all).
 export TMPDIR=/tmp
 TAG=${TAG:-r05}
-STAGES=${STAGES:-"tests smoke micro bench trace pmc pmc_guided pmc3d pmc3d_1024 pmc_guided3d build3"}
+STAGES=${STAGES:-"tests smoke micro bench trace pmc pmc_guided pmc3d pmc3d_1024 pmc_guided3d build3 build2"}
 mkdir -p gpurun_out/$TAG
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 if has tests; then
@@ -116,5 +116,12 @@ if has build3; then
   f=$(find gpurun_out/$TAG/traceb3 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/$TAG/kernel_stats_build3.csv
   grep mesh gpurun_out/$TAG/build3_trace.log | tail -1
   rm -rf gpurun_out/$TAG/traceb3
+fi
+# the segment LBVH built on the device (ladybug, fille; five builds each way): kernel trace of the build kernels
+if has build2; then
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/traceb2 -- python3 tools/probes/build2_only.py > gpurun_out/$TAG/build2_trace.log 2>&1
+  f=$(find gpurun_out/$TAG/traceb2 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/$TAG/kernel_stats_build2.csv
+  grep mesh_build2 gpurun_out/$TAG/build2_trace.log | tail -1
+  rm -rf gpurun_out/$TAG/traceb2
 fi
 rm -rf gpurun_out/$TAG/pmc[0-9] gpurun_out/$TAG/trace
