@@ -25,6 +25,10 @@
 #include <cstdint>
 #include <vector>
 
+#ifndef WOST_NODE_FLOATS
+#define WOST_NODE_FLOATS 24      // see wost_device.h
+#endif
+
 namespace wost {
 
 constexpr int kLeafSize = 4;

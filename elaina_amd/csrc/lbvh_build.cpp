@@ -306,7 +306,7 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
     // ---- oriented child boxes for every node -------------------------------------------
     {
         const int n_all = t->first_leaf + cap;   // nodes that have children (leaves included)
-        t->nodes.assign((size_t)n_all * 24, 0.0f);
+        t->nodes.assign((size_t)n_all * WOST_NODE_FLOATS, 0.0f);
         // endpoints under every node, gathered bottom-up (leaves first), and their moments on the 2^20 grid of the mesh's box
         std::vector<std::vector<float>> pts(n_all);
         std::vector<FitSums> sums(n_all, FitSums{0, 0, 0, 0, 0, 0});
@@ -333,7 +333,7 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
         const double obb_pad = (double)ext * std::ldexp(1.0, -(e_pad ? atoi(e_pad) : 21)) + 1e-30;
         t->obb_pad = obb_pad;
         auto set_child = [&](int parent, int j, float cx, float cy, float ux, float uy, float hl, float hw) {
-            float *nd = &t->nodes[(size_t)parent * 24];
+            float *nd = &t->nodes[(size_t)parent * WOST_NODE_FLOATS];
             nd[0 + j] = cx; nd[4 + j] = cy; nd[8 + j] = ux; nd[12 + j] = uy; nd[16 + j] = hl; nd[20 + j] = hw;
         };
         // inner levels: fit an oriented box around the endpoints of each child subtree
@@ -427,7 +427,7 @@ int build_tree(int32_t n_verts, const float *verts, int32_t n_segs, const int32_
         };
         for (int g = 0; g < t->first_leaf; ++g)
             for (int j = 0; j < kArity; ++j) {
-                const float *nd = &t->nodes[(size_t)g * 24];
+                const float *nd = &t->nodes[(size_t)g * WOST_NODE_FLOATS];
                 fit(g, j, acc[kArity * g + 1 + j], nd[0 + j], nd[4 + j]);
             }
         // last level: the "children" are single segments; their candidates are their two

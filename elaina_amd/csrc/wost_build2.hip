@@ -251,12 +251,28 @@ __global__ __launch_bounds__(256) void b2_cost_min_kernel(const int32_t *rb, con
                                                           int axis, unsigned long long *best_cost)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    for (int special = (axis == 0 ? 1 : 0); special >= 0; --special) {
-        double cost;
-        uint32_t ord, r;
-        if (b2_candidate(rb, re, rid, pre, suf_rev, n, cap_side, k, special != 0, cost, ord, r) && cost < INFINITY)
-            atomicMin(&best_cost[r], (unsigned long long)__double_as_longlong(cost));      // costs are not negative: their patterns order like the numbers
+    // costs are not negative: their bit patterns order like the numbers.  The lanes of a wave mostly belong to ONE range (the top
+    // levels' ranges are thousands of items long): their minimum goes to memory as one atomic, not sixty-four on the same word
+    unsigned long long mine = ~0ull;
+    uint32_t r = 0xffffffffu;
+    if (k < n) {
+        r = rid[k];
+        for (int special = (axis == 0 ? 1 : 0); special >= 0; --special) {
+            double cost;
+            uint32_t ord, r2;
+            if (b2_candidate(rb, re, rid, pre, suf_rev, n, cap_side, k, special != 0, cost, ord, r2) && cost < INFINITY)
+                mine = min(mine, (unsigned long long)__double_as_longlong(cost));
+        }
+    }
+    const uint32_t r0 = __shfl(r, 0);
+    if (__all(r == r0 || k >= n)) {
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned int lo = __shfl_xor((unsigned int)(mine & 0xffffffffull), m), hi = __shfl_xor((unsigned int)(mine >> 32), m);
+            mine = min(mine, ((unsigned long long)hi << 32) | lo);
+        }
+        if ((threadIdx.x & 63) == 0 && mine != ~0ull && r0 != 0xffffffffu) atomicMin(&best_cost[r0], mine);
+    } else if (mine != ~0ull) {
+        atomicMin(&best_cost[r], mine);
     }
 }
 __global__ __launch_bounds__(256) void b2_cost_arg_kernel(const int32_t *rb, const int32_t *re, const uint32_t *rid, const float4 *pre, const float4 *suf_rev, int n, int cap_side,
@@ -347,7 +363,7 @@ __global__ __launch_bounds__(256) void b2_leaf_kernel(B2Shape S, const int32_t *
     B2Sums a{};
     B2Fixed fx;
     for (int d = 0; d < kFitDirs; ++d) fx.e[d] = fit_extent_empty();
-    float *nd = nodes + (size_t)(S.first_leaf + L) * 24;
+    float *nd = nodes + (size_t)(S.first_leaf + L) * WOST_NODE_FLOATS;
     float *cn = cones + (size_t)(S.first_leaf + L) * 20;
     for (int j = 0; j < kLeafSize; ++j) {
         const size_t k = (size_t)L * kLeafSize + j;
@@ -431,7 +447,7 @@ __global__ __launch_bounds__(256) void b2_obb_kernel(B2Shape S, const int32_t *s
     const int lane = threadIdx.x & 63;
     if (w >= 4ll * S.first_leaf || meta->bad) return;
     const int g = (int)(w >> 2), j = (int)(w & 3), c4 = 4 * g + 1 + j;
-    float *nd = nodes + (size_t)g * 24;
+    float *nd = nodes + (size_t)g * WOST_NODE_FLOATS;
     const FitSums fs = sums[c4].fit;
     if (fs.n == 0) {
         if (lane == 0) { nd[0 + j] = kFarCoord; nd[4 + j] = kFarCoord; nd[8 + j] = 1.0f; nd[12 + j] = 0.0f; nd[16 + j] = 0.0f; nd[20 + j] = 0.0f; }
@@ -481,7 +497,7 @@ __global__ __launch_bounds__(256) void b2_cone_kernel(B2Shape S, const int32_t *
     if (w >= 4ll * S.first_leaf || meta->bad) return;
     const int g = (int)(w >> 2), j = (int)(w & 3), c4 = 4 * g + 1 + j;
     float *cn = cones + (size_t)g * 20;
-    const float *nd = nodes + (size_t)g * 24;
+    const float *nd = nodes + (size_t)g * WOST_NODE_FLOATS;
     const float cx = nd[0 + j], cy = nd[4 + j];
     long long s0, s1;
     b2_child_span(S, c4, s0, s1);
@@ -528,7 +544,7 @@ __global__ __launch_bounds__(256) void b2_scan_copy_kernel(B2Shape S, const int3
 {
     const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (k < S.n_slots && slot_of[k] >= 0) {
-        const float *nd = nodes + ((size_t)S.first_leaf + k / 4) * 24 + (k & 3);
+        const float *nd = nodes + ((size_t)S.first_leaf + k / 4) * WOST_NODE_FLOATS + (k & 3);
         const int d = dst[k];
         scanBox[d] = float4{nd[0], nd[4], nd[8], nd[12]};
         scanHl[d] = nd[16];
@@ -597,7 +613,7 @@ int build_tree_device(const wost_mesh_desc &d, DeviceTree2 &out_tree)
     while ((1ll << rid_bits) < 2ll * S.cap) ++rid_bits;
 
     B2Buffer out, tmp;
-    const size_t o_nodes = out.take((size_t)S.n_all * 24 * 4), o_cones = out.take((size_t)S.n_all * 20 * 4), o_segA = out.take(n_slots * 16), o_segInv = out.take(n_slots * 4),
+    const size_t o_nodes = out.take((size_t)S.n_all * WOST_NODE_FLOATS * 4), o_cones = out.take((size_t)S.n_all * 20 * 4), o_segA = out.take(n_slots * 16), o_segInv = out.take(n_slots * 4),
                  o_segOrig = out.take(n_slots * 4), o_segCol = out.take(n_slots * 48), o_segVerts = out.take(n_slots * 8), o_flat = out.take((size_t)n * sizeof(DevFlatSeg)),
                  o_flatCol = out.take((size_t)n * 48), o_sil = out.take((size_t)nv * sizeof(DevSilVertex)), o_silN = out.take((size_t)nv * 16),
                  o_scanBox = out.take(n_scan_pad * 16), o_scanHl = out.take(n_scan_pad * 4), o_scanId = out.take(n_scan_pad * 8);
@@ -705,7 +721,7 @@ int build_tree_device(const wost_mesh_desc &d, DeviceTree2 &out_tree)
     float *nodes = out.at<float>(o_nodes), *cones = out.at<float>(o_cones);
     B2Sums *sums = tmp.at<B2Sums>(t_sums);
     B2Fixed *fixed = tmp.at<B2Fixed>(t_fixed);
-    B2_TRY(hipMemsetAsync(nodes, 0, (size_t)S.n_all * 96, st));
+    B2_TRY(hipMemsetAsync(nodes, 0, (size_t)S.n_all * WOST_NODE_FLOATS * 4, st));
     B2_TRY(hipMemsetAsync(cones, 0, (size_t)S.n_all * 80, st));
     hipLaunchKernelGGL(b2_leaf_kernel, b2_grid(S.cap), dim3(256), 0, st, S, slot_of, flat, flatCol, verts, segs, vprev, vnext, meta, out.at<float4>(o_segA),
                        out.at<float>(o_segInv), out.at<int32_t>(o_segOrig), out.at<float>(o_segCol), out.at<int2>(o_segVerts), nodes, cones, sums, fixed);

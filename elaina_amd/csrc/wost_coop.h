@@ -28,7 +28,7 @@ __device__ __forceinline__ float closest_silhouette_wave(const DevMesh &m, float
         [&](uint32_t g, int owner, bool leaf, bool (&v)[4], uint32_t (&key)[4]) {
             const float x = oq[owner], y = oq[64 + owner];
             const float bd = __uint_as_float(obest[owner]) * kSlack;
-            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 4u * WOST_NODE_FLOATS));
             const float4 CX = nd[0], CY = nd[1], UX = nd[2], UY = nd[3], HL = nd[4], HW = nd[5];
             const float d0 = obb_d2(CX.x, CY.x, UX.x, UY.x, HL.x, HW.x, x, y), d1 = obb_d2(CX.y, CY.y, UX.y, UY.y, HL.y, HW.y, x, y);
             const float d2 = obb_d2(CX.z, CY.z, UX.z, UY.z, HL.z, HW.z, x, y), d3 = obb_d2(CX.w, CY.w, UX.w, UY.w, HL.w, HW.w, x, y);
@@ -101,7 +101,7 @@ __device__ __forceinline__ bool ray_closest_wave(const DevMesh &m, float ox, flo
         [&](uint32_t g, int owner, bool leaf, bool (&v)[4], uint32_t (&key)[4]) {
             const float rx = of[owner], ry = of[64 + owner], rdx = of[128 + owner], rdy = of[192 + owner];
             const float lim = __uint_as_float(obound[owner]);
-            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+            const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 4u * WOST_NODE_FLOATS));
             const float4 CX = nd[0], CY = nd[1], UX = nd[2], UY = nd[3], HL = nd[4], HW = nd[5];
             const float e0 = CX.x >= 1.0e17f ? WOST_INF : ray_obb_entry(CX.x, CY.x, UX.x, UY.x, HL.x, HW.x, rx, ry, rdx, rdy, lim);
             const float e1 = CX.y >= 1.0e17f ? WOST_INF : ray_obb_entry(CX.y, CY.y, UX.y, UY.y, HL.y, HW.y, rx, ry, rdx, rdy, lim);

@@ -18,6 +18,11 @@ namespace wost {
 #define WOST_SIL_PRECISION 1e-3f
 #define WOST_FAR_INDEX 0x7fffffff
 #define WOST_INF __builtin_inff()
+// floats between the child records of consecutive nodes: 24 (the six operand vectors, 96 bytes) or, as an experiment, 32 -- one node per
+// 128-byte line, never two lines per fetch, a third more memory (EXPERIMENTS 22)
+#ifndef WOST_NODE_FLOATS
+#define WOST_NODE_FLOATS 24
+#endif
 
 // ---- device views ----------------------------------------------------------------------
 struct DevFlatSeg {
@@ -282,7 +287,7 @@ __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy,
 {
     const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
     // 96-byte nodes; the byte offset stays below 4 GiB
-    const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+    const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 4u * WOST_NODE_FLOATS));
     const float4 CX = nd[0], CY = nd[1], UX = nd[2], UY = nd[3], HL = nd[4], HW = nd[5];
     // plain scalar fp32: on gfx950 a packed v_pk_fma_f32 costs two v_fma_f32 (tools/micro/op_rate.hip,
     // profiles/r02_micro_*), has no |x| source modifier and needs hazard nops; the scalar form
@@ -307,7 +312,7 @@ __device__ __forceinline__ bool trav_visit(const DevMesh &m, float qx, float qy,
         const uint32_t nn = level_first(m.levels + 1);
         uint32_t g2 = g + (nn >> 1);
         g2 = g2 >= nn ? g2 - nn : g2;
-        const float4 *n2 = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g2, 96u));
+        const float4 *n2 = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g2, 4u * WOST_NODE_FLOATS));
         const float acc = n2[0].x + n2[1].x + n2[2].x + n2[3].x + n2[4].x + n2[5].x;
         if (acc == 12345.678f) T.best_orig = 0;
     }
@@ -374,7 +379,7 @@ __device__ __forceinline__ Closest closest_point(const DevMesh &m, float qx, flo
 // distance of q to the segment stored in `slot` (seed of a query: temporal hint)
 __device__ __forceinline__ Closest slot_candidate(const DevMesh &m, int32_t slot, float qx, float qy)
 {
-    const float *nd = reinterpret_cast<const float *>(m.nodes + 6 * (size_t)(m.first_leaf + (slot >> 2))) + (slot & 3);
+    const float *nd = reinterpret_cast<const float *>(m.nodes + (WOST_NODE_FLOATS / 4) * (size_t)(m.first_leaf + (slot >> 2))) + (slot & 3);
     return Closest{obb_d2(nd[0], nd[4], nd[8], nd[12], nd[16], 0.0f, qx, qy), slot};
 }
 
@@ -803,7 +808,7 @@ __device__ __forceinline__ float closest_silhouette_tree(const DevMesh &m, float
     Trav T = trav_begin(Closest{best2 * kSlack, -1});
     for (;;) {
         const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
-        const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+        const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 4u * WOST_NODE_FLOATS));
         const float4 CX = nd[0], CY = nd[1], UX = nd[2], UY = nd[3], HL = nd[4], HW = nd[5];
         bool more;
         if (T.level == m.levels) {
@@ -904,7 +909,7 @@ __device__ __forceinline__ bool ray_tree(const DevMesh &m, float ox, float oy, f
     Trav T = trav_begin(Closest{tmax, -1});
     for (;;) {
         const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
-        const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u));
+        const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 4u * WOST_NODE_FLOATS));
         const float4 CX = nd[0], CY = nd[1], UX = nd[2], UY = nd[3], HL = nd[4], HW = nd[5];
         const float lim = T.best.d2;
         const float e0 = CX.x >= 1.0e17f ? WOST_INF : ray_obb_entry(CX.x, CY.x, UX.x, UY.x, HL.x, HW.x, ox, oy, dx, dy, lim);

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
     // lane's query to completion in lock step, each trip of the loop runs ONE of two bodies
     // -- "visit one node" or "finish a step and start the next query" -- whichever more lanes
     // of the wave are ready for (weighted), while the lanes of the other kind accumulate.
-    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5, MODE_FAR = 6, MODE_HUGE = 7, MODE_PUSH = 8 };
+    enum { MODE_TRAV = 1, MODE_WAIT = 3, MODE_DONE = 4, MODE_REFILL = 5, MODE_FAR = 6, MODE_HUGE = 7 };
     const bool has_d = P.dm.n_segs > 0;
     int mode = alive ? MODE_WAIT : MODE_DONE;
     bool fresh = true;   // first trip: no finished step yet, only start the query
@@ -440,22 +440,6 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
     const LdsColumn stk{stack, (uint32_t)P.stack_stride};
     for (;;) {
         if (REFILL) {
-            // lanes whose pixel has used up the steps a refill launch gives it (RoundParams::steps_per_round, "refill_steps"): the
-            // walker goes to the output queue -- one atomic per wave and trip -- for the rounds that follow, whose few walkers get
-            // four lanes each; the lane takes the next pixel.  A long walk is a chain of dependent queries: here it would hold a lane
-            // of a full wave to the end of the launch
-            const unsigned long long pushm = __ballot(mode == MODE_PUSH);
-            if (pushm) {
-                const int lane_ = threadIdx.x & 63;
-                uint32_t base = 0;
-                if (lane_ == 0) base = atomicAdd(P.count_out, (uint32_t)__popcll(pushm));
-                base = __shfl(base, 0);
-                if (mode == MODE_PUSH) {
-                    store_lane(P.out, base + (uint32_t)__popcll(pushm & ((1ull << lane_) - 1ull)), L, pix);
-                    open = false;
-                    mode = MODE_REFILL;
-                }
-            }
             // lanes whose pixel is complete: write it, then take the next unread input slot
             const unsigned long long need = __ballot(mode == MODE_REFILL);
             if (need) {
@@ -491,7 +475,6 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
                         open = true;
                         alive = L.sample < (uint32_t)P.st.spp;
                         fresh = true;
-                        budget = P.steps_per_round;       // per pixel in a refill launch
                         mode = alive ? MODE_WAIT : MODE_REFILL;
                     } else {
                         mode = MODE_DONE;
@@ -502,7 +485,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
         const int n_trav = __popcll(__ballot(mode == MODE_TRAV));
         const int n_wait = __popcll(__ballot(mode == MODE_WAIT));
         if (n_trav + n_wait == 0) {
-            if (REFILL && __ballot(mode == MODE_REFILL || mode == MODE_PUSH)) continue;
+            if (REFILL && __ballot(mode == MODE_REFILL)) continue;
             break;
         }
         if (n_wait * P.wait_weight >= n_trav * 8) {
@@ -564,7 +547,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
                         }
                     }
                 } else {
-                    mode = REFILL ? (alive ? MODE_PUSH : MODE_REFILL) : MODE_DONE;
+                    mode = (REFILL && !alive) ? MODE_REFILL : MODE_DONE;
                 }
             }
             if (SLACK) {
@@ -986,7 +969,7 @@ static int upload_mesh_host(const wost_mesh_desc &d, DeviceMeshStorage &s)
         std::vector<int32_t> id;
         for (size_t k = 0; k < t.segOrig.size(); ++k) {
             if (t.segOrig[k] == kFarIndex) continue;
-            const float *nd = &t.nodes[((size_t)t.first_leaf + k / 4) * 24] + (k & 3);
+            const float *nd = &t.nodes[((size_t)t.first_leaf + k / 4) * WOST_NODE_FLOATS] + (k & 3);
             box.insert(box.end(), {nd[0], nd[4], nd[8], nd[12]});
             hl.push_back(nd[16]);
             id.push_back((int32_t)k);
@@ -1121,7 +1104,6 @@ struct wost_context {
     int trav_burst = 3;
     int time_kernels = 1;
     int refill = -1;       // -1 = automatic (few samples per pixel), 0 = never, 1 = always
-    int refill_steps = 0;  // steps a pixel gets in a refill launch before its walker is handed to the rounds that follow (0 = no limit)
     int quad = -1;         // four lanes per walker in under-filled launches: -1 = automatic, 0 = never, 1 = every ordinary round
     double quad_fill = 1.0;   // automatic: when 4 x walkers <= quad_fill x resident lanes
     int coop = 1;             // a Neumann mesh on the tree: its silhouette and ray queries by the wave as a whole (wost_coop.h); 0 = per lane
@@ -1253,7 +1235,7 @@ int wost_mesh_build_check(const wost_mesh_desc *mesh, int device, int32_t repeat
     if (x.n_segs == 0 || scalars) return WOST_OK;
     const size_t cap = 3 * (size_t)x.first_leaf + 1, n_all = (size_t)x.first_leaf + cap, n_slots = cap * 4, n = (size_t)x.n_segs, nv = (size_t)x.n_sil;
     int64_t *cmp = &mismatch[15];
-    mismatch[0] = differing_bytes2(x.nodes, y.nodes, n_all * 6, cmp);
+    mismatch[0] = differing_bytes2(x.nodes, y.nodes, n_all * (WOST_NODE_FLOATS / 4), cmp);
     mismatch[1] = differing_bytes2(x.cones, y.cones, n_all * 5, cmp);
     mismatch[2] = differing_bytes2(x.segA, y.segA, n_slots, cmp);
     mismatch[3] = differing_bytes2(x.segInv, y.segInv, n_slots, cmp);
@@ -1378,9 +1360,6 @@ int wost_set_option(wost_handle h, const char *key, double value)
         if (value < 0 || value >= (1 << 20)) return fail(WOST_ERR_INVALID, "spp must be in 0..2^20-1");
         h->settings.spp = (int32_t)value;
         h->dst.spp = (int32_t)value;
-    } else if (k == "refill_steps") {
-        if (value < 0 || value > 32767) return fail(WOST_ERR_INVALID, "refill_steps must be in 0..32767");
-        h->refill_steps = (int)value;
     } else if (k == "refill") {
         if (value != -1 && value != 0 && value != 1) return fail(WOST_ERR_INVALID, "refill must be -1 (auto), 0 or 1");
         h->refill = (int)value;
@@ -1605,7 +1584,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
             c->host_count[1] = grid * (unsigned)bs;      // first unread slot (pinned staging word)
             HIP_TRY(hipMemcpyAsync(c->cursor, c->host_count + 1, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             rp.cursor = c->cursor;
-            rp.steps_per_round = c->refill_steps > 0 ? c->refill_steps : 0x7fffffff;
+            rp.steps_per_round = 0x7fffffff;
         }
         // Under-filled launch: four lanes per walker (walk_quad_kernel).  Such a launch lasts as long as its longest chain of
         // dependent node visits; sharing a descent between the lanes of a quad halves that chain.

@@ -90,7 +90,7 @@ template <bool SLACK>
 __device__ __forceinline__ bool quad_visit(const DevMesh &m, float qx, float qy, Trav &T, const QuadColumn &stk, int j)
 {
     const uint32_t g = level_first(T.level) + (uint32_t)T.pos;
-    const float *nd = reinterpret_cast<const float *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 96u)) + j;
+    const float *nd = reinterpret_cast<const float *>(reinterpret_cast<const char *>(m.nodes) + __umul24(g, 4u * WOST_NODE_FLOATS)) + j;
     const float cx = nd[0], cy = nd[4], ux = nd[8], uy = nd[12], hl = nd[16], hw = nd[20];
     const float bd = T.best.d2;
     const bool at_leaf = T.level == m.levels;

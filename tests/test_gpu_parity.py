@@ -445,17 +445,6 @@ def test_refill_launch_matches_oracle(oracle, scene, spp, depth):
     _assert_same_solve(oracle, p, 96, 80, spp, depth, 1.0, refill=1)
 
 
-@pytest.mark.parametrize("steps", [1, 3, 16])
-def test_refill_launch_with_a_step_limit_hands_long_walks_to_the_rounds(oracle, ladybug, fille, steps):
-    """"refill_steps": a pixel gets that many steps in the refill launch, then its walker goes to the output queue (one atomic per
-    wave and trip) and the ordinary rounds -- thin waves, quads -- finish it: same per-pixel arithmetic, still bit-exact; with one
-    step per pixel nearly every walker is handed over, with sixteen the long walks only"""
-    ref = None
-    for opts in ({"refill": 1, "refill_steps": steps}, {"refill": 1, "refill_steps": steps, "block_size": 64, "quad": 0}):
-        ref = _assert_same_solve(oracle, ladybug, 96, 80, 2, 64, 1.0, ref=ref, **opts)
-    _assert_same_solve(oracle, fille, 64, 48, 1, 128, 1.0, refill=1, refill_steps=steps)
-
-
 def test_refill_launch_with_mask_and_mixed_boundaries(oracle):
     from conftest import box_problem, wiggly_problem
     p = box_problem(d_sides=(0, 2), n_sides=(1, 3), value=lambda x, y: y, flux=lambda x, y, s: 0.3 * (s - 2))
