@@ -37,7 +37,9 @@ _GPU_ORDER = [
     ("test_gpu_far_trees.py", ("",)),
 ]
 # the long statistical / fuzz / multi-process tests go behind everything else whatever file they are in
-_GPU_LAST = ("test_random_scenes", "test_gpu_random_scenes", "test_3d_random_scenes", "test_gpu_tree_sized", "test_gpu_guiding_reduces",
+# (the half-precision mode's run-to-run checks too: they are strict -- two solves, same bits -- and a box that misbehaves there must not
+# cost the parity tests behind them under -x; the fp32 case of the same test, the parity mode, stays in the first rank)
+_GPU_LAST = ("test_gpu_config4_at_full_size[16]", "test_gpu_half_precision_training_kernels_repeat", "test_random_scenes", "test_gpu_random_scenes", "test_3d_random_scenes", "test_gpu_tree_sized", "test_gpu_guiding_reduces",
              "test_gpu_reordered_training", "test_gpu_half_precision_network_mode_is_unbiased", "test_gpu_guided_on_ladybug_agrees",
              "test_gpu_full_frame_guided_properties", "test_bench_", "test_gpu_two_ranks", "test_ground_truth_sample_count",
              "test_gpu_guided3_half_precision_solve_is_unbiased")
