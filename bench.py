@@ -264,7 +264,9 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
     out = {
         "workload": "%s uniform %dx%d grid %d spp depth %d eps %g" % (scene, frame, frame, spp, depth, eps),
         "value": total_steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "walk_steps_per_pass": total_steps / steps,
-        "roofline": {"bound": "valu", "hbm_formula": "98 B x walk steps / kernel time (SURVEY 8d)",
+        "roofline": {"bound": "hbm", "hbm_formula": "98 B x walk steps / kernel time (SURVEY 8d)",
+                     "what_binds": "not HBM: the walker state stays in registers inside a launch (traffic = 8 % of the algorithmic bytes); VALU pipes 99 % busy at 41 % "
+                                   "lane efficiency, and per-lane node fetches of an L1-resident tree (EXPERIMENTS 6, 18, 19)",
                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                      "kernel": "walk_round_kernel", "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
                      "algorithmic_bytes_per_walk_step": BYTES_PER_STEP},
@@ -695,8 +697,8 @@ def main():
             roof["traffic_unit"] = "HBM bytes per launch (profiles/walk_round_traffic.json)"
             roof["traffic_stale"] = tr["stale"] if tr else None
             roof["valu"] = valu_block() if args.config == 2 else None
-            # "bound" is what the counters say binds the kernel (VALU issue); achieved/peak/frac stay the
-            # SURVEY 8(d) HBM formula so that rounds remain comparable
+            # achieved / peak / frac are the SURVEY 8(d) HBM formula (rounds remain comparable); "what_binds" and "valu" say what the counters
+            # say binds the kernel instead
             line["roofline"] = roof
             if not args.no_cpu_baseline:
                 # the host baseline is a reported figure at N = 1 only; at N > 1 a short band of the
