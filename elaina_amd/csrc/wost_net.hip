@@ -1188,6 +1188,205 @@ __global__ __launch_bounds__(kGridGradBlock, 2) void grid_grad_plan_kernel(NetLa
                     plan.q1[g], 1, grad, acc, plan.replicas[g]);
 }
 
+// ---- three inputs: ALL levels of a step's grid gradient in one launch, through spatial bins ------------------------------------
+// The trilinear grids of GuidedIntegrator<3> do not fit LDS (up to 2^19 entries a level), and round 4 / 5 added their upper levels
+// straight to global memory: 128 sixty-four-bit atomics per point that queue on the cells the walkers share -- 1.5 ms of a 2-ms
+// training step at 2 x 10^5 points, 7 to 10 ms at 5 x 10^5 (profiles/r05_ab_grid_grad_launches.txt).  Here the points are first
+// put into bins^3 boxes of the unit cube (count, table, scatter: any order inside a box, the sums are integers).  All points of a
+// box touch, on level l, a sub-grid of at most floor(scale_l / bins) + 3 cells per axis: with 8 boxes per axis the sub-grids of all
+// eight levels of the reference's network are 4 205 entries x 4 features = 135 KB of accumulators.  A block takes up to `chunk`
+// points of ONE box, adds them up in LDS and flushes what is not zero with one global atomic per entry and feature.
+struct GridBin3Plan {
+    int32_t bins, chunk, n_acc;            // boxes per axis (a power of two); points per block; accumulator entries (x n_features)
+    int32_t ext[kNetMaxLevels], acc_off[kNetMaxLevels + 1];
+};
+// counts[0 .. nb): points per box; then [nb .. 2 nb): scatter cursors; [2 nb]: ticket of the count kernel; after that, written by
+// the last block of the count kernel: start[nb + 1] (first point of a box in `order`) and first_block[nb + 1]
+__device__ __forceinline__ int grid_bin3_of(const float *q3, int bins)
+{
+    int b[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) b[a] = max(0, min(bins - 1, (int)(q3[a] * (float)bins)));
+    return b[0] + bins * (b[1] + bins * b[2]);
+}
+constexpr int kBin3CountPoints = 4096;      // points of a count / scatter block
+__global__ __launch_bounds__(1024) void grid_bin3_count_kernel(const float *xyz, int n, int bins, int chunk, uint32_t *tab)
+{
+    extern __shared__ uint32_t s_cnt[];
+    const int nb = bins * bins * bins;
+    for (int b = threadIdx.x; b < nb; b += 1024) s_cnt[b] = 0;
+    __syncthreads();
+    const int p0 = blockIdx.x * kBin3CountPoints;
+    for (int p = p0 + threadIdx.x; p < min(n, p0 + kBin3CountPoints); p += 1024) atomicAdd(&s_cnt[grid_bin3_of(xyz + 3 * (size_t)p, bins)], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += 1024)
+        if (s_cnt[b]) atomicAdd(&tab[b], s_cnt[b]);
+    __threadfence();
+    __syncthreads();
+    __shared__ uint32_t s_last;
+    if (threadIdx.x == 0) s_last = atomicAdd(&tab[2 * nb], 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // the table, by the block that finished last: one thread per box group, two running sums (nb <= 4096: four boxes a thread)
+    uint32_t *start = tab + 2 * nb + 1, *first_block = start + nb + 1;
+    const int per = (nb + 1023) / 1024;
+    uint32_t pts = 0, blks = 0;
+    for (int k = 0; k < per; ++k) {
+        const int b = threadIdx.x * per + k;
+        if (b < nb) {
+            const uint32_t c = __hip_atomic_load(&tab[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pts += c;
+            blks += (c + chunk - 1) / chunk;
+        }
+    }
+    uint32_t *s_p = s_cnt, *s_b = s_cnt + 1024;      // (nb >= 512 words of LDS are there: the launch asks for max(nb, 2048))
+    s_p[threadIdx.x] = pts;
+    s_b[threadIdx.x] = blks;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t a = threadIdx.x >= (unsigned)d ? s_p[threadIdx.x - d] : 0u, c = threadIdx.x >= (unsigned)d ? s_b[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_p[threadIdx.x] += a;
+        s_b[threadIdx.x] += c;
+        __syncthreads();
+    }
+    uint32_t run_p = s_p[threadIdx.x] - pts, run_b = s_b[threadIdx.x] - blks;
+    for (int k = 0; k < per; ++k) {
+        const int b = threadIdx.x * per + k;
+        if (b < nb) {
+            const uint32_t c = __hip_atomic_load(&tab[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            start[b] = run_p;
+            first_block[b] = run_b;
+            run_p += c;
+            run_b += (c + chunk - 1) / chunk;
+        }
+    }
+    if (threadIdx.x == 1023) {
+        start[nb] = s_p[1023];
+        first_block[nb] = s_b[1023];
+    }
+}
+__global__ __launch_bounds__(1024) void grid_bin3_scatter_kernel(const float *xyz, int n, int bins, uint32_t *tab, uint32_t *order)
+{
+    extern __shared__ uint32_t s_cnt[];        // [nb] counts of this block's points, then [nb] their first slot
+    const int nb = bins * bins * bins;
+    uint32_t *s_at = s_cnt + nb;
+    for (int b = threadIdx.x; b < nb; b += 1024) s_cnt[b] = 0;
+    __syncthreads();
+    const int p0 = blockIdx.x * kBin3CountPoints, p1 = min(n, p0 + kBin3CountPoints);
+    int mine[kBin3CountPoints / 1024];
+#pragma unroll
+    for (int k = 0; k < kBin3CountPoints / 1024; ++k) {
+        const int p = p0 + threadIdx.x + 1024 * k;
+        mine[k] = p < p1 ? grid_bin3_of(xyz + 3 * (size_t)p, bins) : -1;
+        if (mine[k] >= 0) atomicAdd(&s_cnt[mine[k]], 1u);
+    }
+    __syncthreads();
+    const uint32_t *start = tab + 2 * nb + 1;
+    for (int b = threadIdx.x; b < nb; b += 1024) s_at[b] = s_cnt[b] ? start[b] + atomicAdd(&tab[nb + b], s_cnt[b]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kBin3CountPoints / 1024; ++k)
+        if (mine[k] >= 0) order[atomicAdd(&s_at[mine[k]], 1u)] = (uint32_t)(p0 + threadIdx.x + 1024 * k);
+}
+__global__ __launch_bounds__(kGridGradBlock) void grid_bin3_accumulate_kernel(NetLayout L, const float *xyz, const float *denc, size_t ld_point, size_t ld_level,
+                                                                               GridBin3Plan plan, const uint32_t *tab, const uint32_t *order, fx_t *grad)
+{
+    extern __shared__ fx_t acc[];
+    __shared__ float s_scale[kNetMaxLevels];
+    __shared__ uint32_t s_res[kNetMaxLevels], s_off[kNetMaxLevels + 1];
+    __shared__ int s_lo[kNetMaxLevels][3];
+    __shared__ int s_box, s_from, s_to;
+    const int bins = plan.bins, nb = bins * bins * bins, nf = L.n_features, n_lv = L.n_levels;
+    const uint32_t *start = tab + 2 * nb + 1, *first_block = start + nb + 1;
+    if ((uint32_t)blockIdx.x >= first_block[nb]) return;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = nb;                   // the last box whose first block is <= this one (empty boxes share a first block with
+        while (hi - lo > 1) {                  // the next box: the last of them is the one that has blocks)
+            const int mid = (lo + hi) >> 1;
+            if (first_block[mid] <= (uint32_t)blockIdx.x) lo = mid;
+            else hi = mid;
+        }
+        s_box = lo;
+        s_from = (int)(start[lo] + ((uint32_t)blockIdx.x - first_block[lo]) * (uint32_t)plan.chunk);
+        s_to = (int)min(start[lo + 1], (uint32_t)s_from + (uint32_t)plan.chunk);
+    }
+    if (threadIdx.x <= (unsigned)n_lv) {
+        s_off[threadIdx.x] = L.level_off[threadIdx.x];
+        if (threadIdx.x < (unsigned)n_lv) {
+            s_scale[threadIdx.x] = L.scale[threadIdx.x];
+            s_res[threadIdx.x] = (uint32_t)L.res[threadIdx.x];
+        }
+    }
+    for (int e = threadIdx.x; e < plan.n_acc * nf; e += kGridGradBlock) acc[e] = 0;
+    __syncthreads();
+    if (threadIdx.x < (unsigned)(3 * n_lv)) {
+        // the first cell of the box on every level: positions of the box are >= b / bins (exact: bins is a power of two), the cell
+        // index floor(fma(scale, x, 0.5)) is monotone in x
+        const int lv = threadIdx.x / 3, a = threadIdx.x % 3;
+        const int b = a == 0 ? s_box % bins : (a == 1 ? (s_box / bins) % bins : s_box / (bins * bins));
+        s_lo[lv][a] = (int)floorf(__builtin_fmaf(s_scale[lv], (float)b / (float)bins, 0.5f));
+    }
+    __syncthreads();
+    fx_t *gG = grad + L.n_mlp;
+    const int from = s_from, n_pts = s_to - s_from;
+    for (int item = threadIdx.x; item < n_pts * n_lv; item += kGridGradBlock) {
+        const int lv = item % n_lv;
+        const uint32_t p = order[from + item / n_lv];
+        const float s = s_scale[lv];
+        const uint32_t res = s_res[lv], lo = s_off[lv], n_level = s_off[lv + 1] - lo;
+        const float *q3 = xyz + 3 * (size_t)p;
+        float pf[3];
+        int pi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = __builtin_fmaf(s, q3[a], 0.5f), fl = floorf(v);
+            pf[a] = v - fl;
+            pi[a] = (int)fl;
+        }
+        const float *d = denc + (size_t)p * ld_point + (size_t)lv * ld_level;
+        float dv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dv[q] = q < nf ? d[q] : 0.0f;
+        const int ext = plan.ext[lv], cells = ext * ext * ext;
+        const int lx = pi[0] - s_lo[lv][0], ly = pi[1] - s_lo[lv][1], lz = pi[2] - s_lo[lv][2];
+        // (a point outside its box's sub-grid -- not met; it would take rounding the table does not allow for -- adds to global memory)
+        const bool inside = lx >= 0 && ly >= 0 && lz >= 0 && lx + 1 < ext && ly + 1 < ext && lz + 1 < ext;
+        fx_t *a_lv = acc + (size_t)plan.acc_off[lv] * nf;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float w = (((k & 1) ? pf[0] : 1.0f - pf[0]) * ((k & 2) ? pf[1] : 1.0f - pf[1])) * ((k & 4) ? pf[2] : 1.0f - pf[2]);
+            if (inside) {
+                const int cell = (lx + (k & 1)) + ext * ((ly + ((k >> 1) & 1)) + ext * (lz + ((k >> 2) & 1)));
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < nf) fx_add(a_lv + q * cells + cell, to_fx(w * dv[q]));
+            } else {
+                const uint32_t idx = (uint32_t)(((unsigned long long)((uint32_t)pi[0] + (k & 1)) + (unsigned long long)((uint32_t)pi[1] + ((k >> 1) & 1)) * res +
+                                                 (unsigned long long)((uint32_t)pi[2] + ((k >> 2) & 1)) * res * res) % n_level);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < nf) fx_add(gG + (size_t)(lo + idx) * nf + q, to_fx(w * dv[q]));
+            }
+        }
+    }
+    __syncthreads();
+    for (int lv = 0; lv < n_lv; ++lv) {
+        const int ext = plan.ext[lv], cells = ext * ext * ext;
+        const uint32_t res = s_res[lv], lo = s_off[lv], n_level = s_off[lv + 1] - lo;
+        const fx_t *a_lv = acc + (size_t)plan.acc_off[lv] * nf;
+        for (int e = threadIdx.x; e < cells * nf; e += kGridGradBlock) {
+            const fx_t v = a_lv[e];
+            if (v == 0) continue;
+            const int q = e / cells, cell = e % cells;
+            const uint32_t cx = (uint32_t)(s_lo[lv][0] + cell % ext), cy = (uint32_t)(s_lo[lv][1] + (cell / ext) % ext), cz = (uint32_t)(s_lo[lv][2] + cell / (ext * ext));
+            const uint32_t idx = (uint32_t)(((unsigned long long)cx + (unsigned long long)cy * res + (unsigned long long)cz * res * res) % n_level);
+            fx_add(gG + (size_t)(lo + idx) * nf + q, v);
+        }
+    }
+}
+
 // dW[r][k] += sum_p delta[p][r] * input[p][k] for one layer: a block owns a chunk of points,
 // thread t owns the (r, k) pairs {t, t + 256, ...}; per pair four fmaf chains over the 4-point
 // groups taken round robin, added as ((c0 + c1) + c2) + c3 -- the order of the MFMA kernel.
@@ -1359,6 +1558,7 @@ struct wost_net {
     // scratch (grown on demand)
     float *d_xy = nullptr, *d_out = nullptr, *d_dl = nullptr, *d_acts = nullptr, *d_deltas = nullptr, *d_denc = nullptr;
     unsigned long long *d_mask = nullptr;   // MFMA path: signs of the hidden activations, 4 words per point
+    uint32_t *d_bin_order = nullptr, *d_bin_tab = nullptr;   // three inputs: the points of a training step by spatial box (grid_bin3_*)
     size_t cap_points = 0;
 };
 
@@ -1474,6 +1674,8 @@ static int ensure_points(wost_net *h, size_t n)
     NET_TRY(hipMalloc((void **)&h->d_denc, n * (size_t)L.enc * sizeof(float)));
     if (h->d_mask) { (void)hipFree(h->d_mask); h->d_mask = nullptr; }
     NET_TRY(hipMalloc((void **)&h->d_mask, n * 4 * sizeof(unsigned long long)));
+    if (h->d_bin_order) { (void)hipFree(h->d_bin_order); h->d_bin_order = nullptr; }
+    if (L.dims == 3) NET_TRY(hipMalloc((void **)&h->d_bin_order, n * sizeof(uint32_t)));
     h->cap_points = n;
     return WOST_OK;
 }
@@ -1566,6 +1768,8 @@ static void net_free(wost_net *h)
         if (p) (void)hipFree(p);
     if (h->grad && h->grad_owned) (void)hipFree(h->grad);
     if (h->d_mask) (void)hipFree(h->d_mask);
+    if (h->d_bin_order) (void)hipFree(h->d_bin_order);
+    if (h->d_bin_tab) (void)hipFree(h->d_bin_tab);
     if (h->param_steps) (void)hipFree(h->param_steps);
     if (h->lr_table) (void)hipFree(h->lr_table);
     if (h->inference_h) (void)hipFree(h->inference_h);
@@ -1755,6 +1959,42 @@ int net_backward_update_dev(wost_net *h, const float *xy_dev, int n, float loss_
             ++h->n_launches;
         }
         int lv = planned && plan.n_groups > 0 ? L.n_levels : 0;
+        // three inputs: every level in one launch through spatial boxes (WOST_GRID_GRAD_BINS=0: the launches per level group below)
+        if (L.dims == 3 && !(std::getenv("WOST_GRID_GRAD_BINS") && std::atoi(std::getenv("WOST_GRID_GRAD_BINS")) == 0) && h->d_bin_order &&
+            (size_t)n <= h->cap_points) {
+            GridBin3Plan bp{};
+            const size_t lds_cap = 152 * 1024;
+            for (int bins : {8, 16}) {
+                int total = 0;
+                for (int l = 0; l < L.n_levels; ++l) {
+                    bp.ext[l] = (int)std::floor(L.scale[l] / (float)bins) + 3;
+                    bp.acc_off[l] = total;
+                    total += bp.ext[l] * bp.ext[l] * bp.ext[l];
+                }
+                bp.acc_off[L.n_levels] = bp.n_acc = total;
+                bp.bins = (size_t)total * L.n_features * sizeof(fx_t) <= lds_cap ? bins : 0;
+                if (bp.bins) break;
+            }
+            if (bp.bins) {
+                const int nb = bp.bins * bp.bins * bp.bins;
+                bp.chunk = 2048;
+                if (const char *w = std::getenv("WOST_GRID_GRAD_BIN_CHUNK")) bp.chunk = std::max(64, std::atoi(w));
+                if (!h->d_bin_tab) NET_TRY(hipMalloc((void **)&h->d_bin_tab, (2 * 4096 + 1 + 2 * 4097) * sizeof(uint32_t)));
+                NET_TRY(hipMemsetAsync(h->d_bin_tab, 0, (2 * (size_t)nb + 1) * sizeof(uint32_t), stream));
+                const unsigned gc = (unsigned)((n + kBin3CountPoints - 1) / kBin3CountPoints);
+                hipLaunchKernelGGL(grid_bin3_count_kernel, dim3(gc), dim3(1024), (size_t)std::max(nb, 2048) * sizeof(uint32_t), stream, xy_dev, n, bp.bins,
+                                   bp.chunk, h->d_bin_tab);
+                hipLaunchKernelGGL(grid_bin3_scatter_kernel, dim3(gc), dim3(1024), 2 * (size_t)nb * sizeof(uint32_t), stream, xy_dev, n, bp.bins, h->d_bin_tab,
+                                   h->d_bin_order);
+                const size_t acc_bytes = (size_t)bp.n_acc * L.n_features * sizeof(fx_t);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(grid_bin3_accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
+                const size_t ld_point = half ? (size_t)L.n_features : (size_t)L.enc, ld_level = half ? (size_t)n * L.n_features : (size_t)L.n_features;
+                hipLaunchKernelGGL(grid_bin3_accumulate_kernel, dim3((unsigned)(n / bp.chunk + nb + 1)), dim3(kGridGradBlock), acc_bytes, stream, L, xy_dev, h->d_denc,
+                                   ld_point, ld_level, bp, h->d_bin_tab, h->d_bin_order, h->grad);
+                h->n_launches += 4;
+                lv = L.n_levels;
+            }
+        }
         while (lv < L.n_levels) {
             int end = lv;
             size_t bytes = 0;
