@@ -13,6 +13,7 @@
 
 #include "../../include/wost.h"
 #include "wost_internal3.h"
+#include "wost_net_device.h"
 #include "wost_vmm3_device.h"
 
 // =====================================================================================================================
@@ -68,6 +69,7 @@ struct G3Params {
     GStats3Dev *stats;
     int32_t training, train_offset, train_stride, max_train_depth;
     int32_t depth, guiding, first_sample, stack_stride;
+    int32_t max_guided_depth;      // (g3_fused_kernel: the depths below it ask the network)
     float uniform_fraction;
     // the tree queries of a wave's walkers through its task pools (closest_triangle_pool & co.): pool_cap tasks per pool and wave,
     // pool_offset words into the block's LDS (behind the stack columns); pool_cap = 0: one descent per thread
@@ -527,6 +529,125 @@ __global__ __launch_bounds__(256) void g3_tail_kernel(G3Params P)
 }
 
 
+// ---- a whole sample in ONE launch ------------------------------------------------------------------------------------------------
+// The launches per depth above cost a 16-sample solve ~700 launches, each as long as the slowest wave of its depth, and the walkers a
+// round trip through the queue and the network's buffers.  Here a wave keeps its walkers from the evaluation point to the end of the
+// walk -- g3_tail_kernel's loop from depth 0 -- and evaluates the network ITSELF for those that stay at a guided depth: the walkers
+// that need it are ranked (ballot), sixteen of them make a unit of the matrix instructions, lane (i, g) of a unit interpolates the
+// levels g and g + 4 of point i (f32_encode_level3, the arithmetic of net_forward_mfma_kernel), the features are turned to the operand
+// layout through 2 KB of LDS, and the four matrices run on up to four units at once with every weight fragment fetched once
+// (f32_mlp_units: the fragments stay in global memory / L2 -- the block's LDS belongs to the stack columns and the task pools of the
+// tree queries).  The 41 outputs go to the pixel's row of net_out; the walker's lane reads them back after a work-group fence (one
+// CU, one L1).  Same bodies, same draws, same matrices in the same order: bit-identical to the launches per depth
+// (tests/test_guided_3d.py compares both with the oracle and with each other).  fp32 inference on the MFMA path only; any other
+// network (half precision, a shape the MFMA kernels do not cover) keeps the launches per depth.
+struct G3Net {
+    const float *frag, *grid;
+    uint32_t w_off[4];
+    float scale[8];
+    uint32_t res[8], off[9];
+    int32_t xch_offset;       // words into the block's LDS: per wave [3][64] inputs, [64] pixel of rank r, [32][16] features of a unit
+};
+constexpr int kG3XchWords = 3 * 64 + 64 + 32 * 16;
+
+template <int NU>
+__device__ __forceinline__ void g3_net_units(const G3Params &P, const G3Net &F, const float *s_scale, const uint32_t *s_res, const uint32_t *s_off, int u0, int n_need,
+                                             const float *xin, const uint32_t *xpid, float *ubuf)
+{
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    float b[NU][16];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int q = 16 * (u0 + u) + li;
+        const bool qv = q < n_need;
+        const float qx = qv ? xin[q] : 0.5f, qy = qv ? xin[64 + q] : 0.5f, qz = qv ? xin[128 + q] : 0.5f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int lv = lg + 4 * h;
+            float4 f = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (qv) f = f32_encode_level3(F.grid, s_scale[lv], s_res[lv], s_off[lv], s_off[lv + 1] - s_off[lv], qx, qy, qz);
+            ubuf[(4 * lv + 0) * 16 + li] = f.x; ubuf[(4 * lv + 1) * 16 + li] = f.y; ubuf[(4 * lv + 2) * 16 + li] = f.z; ubuf[(4 * lv + 3) * 16 + li] = f.w;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) b[u][s_] = qv ? ubuf[(4 * s_ + lg) * 16 + li] : 0.0f;
+        wave_lds_fence();
+    }
+    // (the fragments do not change inside the launch: without this the compiler loads all 208 words of a lane once, in front of the depth
+    // loop, and keeps them in accumulation registers -- one wave per SIMD, where the tree queries want their latency hidden)
+    const float *frag = F.frag;
+    asm volatile("" : "+s"(frag));
+    f32_mlp_units<NU>(frag, F.w_off, lane, b);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int q = 16 * (u0 + u) + li;
+        if (q < n_need) {
+            float *o = P.net_out + 41 * (size_t)xpid[q];
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (16 * rt + 4 * c + lg < 41) o[16 * rt + 4 * c + lg] = b[u][4 * rt + c];      // b[4 rt + c] = output 16 rt + 4 c + g
+        }
+    }
+}
+
+template <bool EMISSIVE, bool NTREE, bool SOURCE>
+__global__ __launch_bounds__(256, 2) void g3_fused_kernel(G3Params P, G3Net F)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
+    const WavePool3 W = g3_pools(P, lds_stack);
+    const int lane = threadIdx.x & 63;
+    uint32_t *xw = lds_stack + F.xch_offset + (threadIdx.x >> 6) * kG3XchWords;
+    float *xin = reinterpret_cast<float *>(xw);
+    uint32_t *xpid = xw + 192;
+    float *ubuf = reinterpret_cast<float *>(xw + 256);
+    __shared__ float s_scale[8];
+    __shared__ uint32_t s_res[8], s_off[9];
+    if (threadIdx.x < 9) {
+        s_off[threadIdx.x] = F.off[threadIdx.x];
+        if (threadIdx.x < 8) {
+            s_scale[threadIdx.x] = F.scale[threadIdx.x];
+            s_res[threadIdx.x] = F.res[threadIdx.x];
+        }
+    }
+    __syncthreads();
+    const int p = g3_item(P);
+    const bool mine = p >= 0 && p < P.n_pixels;
+    for (int depth = 0; depth < P.st.max_depth; ++depth) {
+        const bool live = mine && P.state[p] == 1;
+        if (!__ballot(live)) break;       // (wave-uniform: the queries are the wave's)
+        V3 x;
+        const bool keep = g3_separate_body<EMISSIVE, NTREE, SOURCE>(P, depth, mine ? p : 0, live, W, stk, x);
+        const bool guiding = depth < P.max_guided_depth;
+        if (guiding) {
+            const unsigned long long bal = __ballot(keep);
+            if (bal) {
+                const int n_need = __popcll(bal);
+                if (keep) {
+                    const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+                    float in3[3];
+                    g3_normalize(P.box, x, in3);
+                    xin[rank] = in3[0]; xin[64 + rank] = in3[1]; xin[128 + rank] = in3[2];
+                    xpid[rank] = (uint32_t)p;
+                }
+                wave_lds_fence();
+                if (n_need > 16) {
+                    g3_net_units<4>(P, F, s_scale, s_res, s_off, 0, n_need, xin, xpid, ubuf);
+                } else {
+                    g3_net_units<1>(P, F, s_scale, s_res, s_off, 0, n_need, xin, xpid, ubuf);
+                }
+                // the outputs were stored by other lanes of this wave: complete, and visible in this CU's L1, before they are read
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                wave_lds_fence();
+            }
+        }
+        g3_sample_body<NTREE>(P, depth, guiding, (uint32_t)(mine ? p : 0), keep, P.net_out + 41 * (size_t)(mine ? p : 0), W, stk);
+    }
+}
+
+
 // ---- the training set of a pass, in (pixel, record) order (train.h:423-471) ------------------------------------------------
 struct T3Params {
     G3Params G;
@@ -746,6 +867,27 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
     bool training = true;
     float uniform_fraction = s.uniform_fraction_training;
     int max_guided_depth = s.max_guided_depth_training;
+    // One launch per sample (g3_fused_kernel) when the network offers its fp32 MFMA fragments and the frame leaves lanes of the chip idle
+    // (lane_shift > 0: up to 147 456 walkers): such a solve is bound by its launches -- 30 per sample, each as long as its slowest wave
+    // (icosphere 256^2, 16 samples: 62.9 -> 49.0 ms).  A frame that fills the chip is bound by throughput, and there the launches per
+    // depth win: their network and sampling kernels run on the compacted queue of the walkers that are left, the fused kernel's waves
+    // keep their dead lanes (1024^2, 4 samples: 84 -> 94 ms on the icosphere, 181 -> 230 ms in the shell).  WOST3_G_FUSED=0 / 1: never / always.
+    G3Net Fn{};
+    bool fused = false;
+    {
+        F32NetView fv{};
+        const char *env = std::getenv("WOST3_G_FUSED");
+        const bool want = env ? env[0] != '0' : P.lane_shift > 0;
+        if (want && net_f32_view3(g->net, &fv) == WOST_OK && fv.L.n_levels == 8 && fv.L.n_features == 4 && fv.L.n_out == 41) {
+            Fn.frag = fv.frag; Fn.grid = fv.grid;
+            for (int l = 0; l < 4; ++l) Fn.w_off[l] = fv.L.w_off[l];
+            for (int l = 0; l < 8; ++l) { Fn.scale[l] = fv.L.scale[l]; Fn.res[l] = (uint32_t)fv.L.res[l]; }
+            for (int l = 0; l <= 8; ++l) Fn.off[l] = fv.L.level_off[l];
+            Fn.xch_offset = (int32_t)((lds + 3) / 4);
+            fused = true;
+        }
+    }
+    const size_t lds_fused = ((size_t)Fn.xch_offset + 4 * (size_t)kG3XchWords) * sizeof(uint32_t);
     for (int sample = 0; sample < s.spp; ++sample) {
         if (sample == s.train_spp_count) {      // :991-996
             training = false;
@@ -761,7 +903,20 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
         // and the launch pairs of the late depths, whose few walkers cost a launch what its slowest tree query costs, were most
         // of the solve's wall time (about 2000 launches per 16-sample solve).
         const uint32_t n_upper = (uint32_t)N;
-        for (int depth = 0; depth < s.max_depth; ++depth) {
+        if (fused) {
+            P.max_guided_depth = max_guided_depth;
+#define G3_FUSED(E, T)                                                                                                                      \
+    do {                                                                                                                                    \
+        auto kfn = has_src ? g3_fused_kernel<E, T, true> : g3_fused_kernel<E, T, false>;                                                      \
+        if (lds_fused > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused); \
+        hipLaunchKernelGGL(kfn, dim3(grid_px), dim3(256), lds_fused, stream, P, Fn);                                                         \
+    } while (0)
+            if (ntree) { if (emissive) G3_FUSED(true, true); else G3_FUSED(false, true); }
+            else       { if (emissive) G3_FUSED(true, false); else G3_FUSED(false, false); }
+#undef G3_FUSED
+            ++launches;
+        }
+        for (int depth = 0; depth < s.max_depth && !fused; ++depth) {
             P.depth = depth; P.guiding = depth < max_guided_depth ? 1 : 0;
             if (!P.guiding) {
 #define G3_LAUNCH(K, E, T)                                                                                              \

@@ -2107,6 +2107,16 @@ int net_f32_view(wost_net *h, F32NetView *out)
     return WOST_OK;
 }
 
+int net_f32_view3(wost_net *h, F32NetView *out)
+{
+    if (!h || !out) return set_error(WOST_ERR_INVALID, "null argument");
+    if (!h->use_mfma || !h->inference_f || h->L.dims != 3 || h->precision != 32) return WOST_ERR_UNSUPPORTED;      // a probe, as above
+    out->L = h->L;
+    out->frag = h->inference_f;
+    out->grid = h->inference + h->L.n_mlp;
+    return WOST_OK;
+}
+
 int net_half_view(wost_net *h, HalfNetView *out)
 {
     if (!h || !out) return set_error(WOST_ERR_INVALID, "null argument");

@@ -94,8 +94,9 @@ struct F32NetView {
     NetLayout L;
     const float *frag, *grid;
 };
-// WOST_ERR_UNSUPPORTED unless the network has the reference's shape (the MFMA kernels)
+// WOST_ERR_UNSUPPORTED unless the network has the reference's shape (the MFMA kernels); net_f32_view: two inputs, net_f32_view3: three
 int net_f32_view(wost_net_handle h, F32NetView *out);
+int net_f32_view3(wost_net_handle h, F32NetView *out);
 
 // A frozen copy of what the views above point at (the pipelined training order of the guided solve: a sample walks with the
 // weights of an earlier training pass while the optimizer rewrites the network's own images on another stream).
@@ -200,6 +201,66 @@ __device__ __forceinline__ void f32_mlp_unit(const float *wf, const uint32_t (&w
     for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[4 * rt + c] = acc[rt][c];
+}
+
+// The same for NU units at once with the fragments in GLOBAL memory (the fused GuidedIntegrator<3> kernel, whose LDS belongs to the tree
+// queries): every fragment is fetched once for all units -- a wave of 64 points reads the 53 KB of matrices once, not four times --
+// and D k-steps ahead of the matrix instructions that use it (left to itself the compiler issues all 208 loads of the pass first:
+// 256 + 256 registers and scratch).  Per unit the instructions and their order are those of f32_mlp_unit: same bits.
+template <int NU, int D, int S, int RT>
+__device__ __forceinline__ void f32_mlp_layer(const float *w, int lane, const float (&b)[NU][16], f32x4_t (&acc)[NU][4])
+{
+    float ring[D][RT];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) ring[d][rt] = d < S ? w[(rt * S + d) * 64 + lane] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[u][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        float cur[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) cur[rt] = ring[s % D][rt];
+        if (s + D < S) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) ring[s % D][rt] = w[(rt * S + s + D) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) acc[u][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[rt], b[u][s], acc[u][rt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// b[u][0 .. 7]: in, the features 4 s + g of point i of unit u in lane (i, g); out: b[u][4 rt + c] = output 16 rt + 4 c + g, rt < 3
+template <int NU>
+__device__ __forceinline__ void f32_mlp_units(const float *wf, const uint32_t (&w_off)[4], int lane, float (&b)[NU][16])
+{
+    constexpr int D = NU >= 4 ? 2 : 4;
+    f32x4_t acc[NU][4];
+#pragma unroll
+    for (int layer = 0; layer < 3; ++layer) {
+        if (layer == 0) f32_mlp_layer<NU, D, 8, 4>(wf + w_off[0], lane, b, acc);
+        else f32_mlp_layer<NU, D, 16, 4>(wf + w_off[layer], lane, b, acc);
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) b[u][4 * rt + c] = fmaxf(acc[u][rt][c], 0.0f);
+    }
+    f32_mlp_layer<NU, D, 16, 3>(wf + w_off[3], lane, b, acc);
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[u][4 * rt + c] = acc[u][rt][c];
 }
 
 // one level of the DenseGrid encoding of (x, y) in the half-precision network: grid values as stored (f16),

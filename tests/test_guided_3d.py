@@ -157,10 +157,10 @@ def test_gpu_net3_inference_and_training_match_oracle(orc, n_levels):
 
 
 def _gpu_and_oracle3(orc, sd, w, h, spp, depth, train_spp, uf=(0.5, 0.5), mgd=(10, 10), batch=1024, min_batch=256, params=None,
-                     stride=1, offset=0, dump=True):
+                     stride=1, offset=0, dump=True, cfg=None, ref=None):
     from elaina_amd.guided import GuidedIntegratorSettings
     from elaina_amd.integrator3d import GuidedIntegrator3, Problem3
-    cfg = _cfg()
+    cfg = cfg or _cfg()
     st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=train_spp, maxWalkingDepth=depth, epsilonShell=EPS,
                                   uniformFractionInTrainingPhase=uf[0], uniformFractionInGuidingPhase=uf[1],
                                   maxGuidedDepthInTrainingPhase=mgd[0], maxGuidedDepthInGuidingPhase=mgd[1], batchSize=batch,
@@ -170,6 +170,8 @@ def _gpu_and_oracle3(orc, sd, w, h, spp, depth, train_spp, uf=(0.5, 0.5), mgd=(1
         gi.network.set_params(params)
     p0 = gi.network.params()
     gi.solve()
+    if ref is not None:      # (the oracle's half of this solve has been computed already)
+        return gi, ref
     gs = guided_settings3(w, h, spp, depth, EPS, AABB3[0], AABB3[1], train_spp_count=train_spp, uniform_fraction=uf, max_guided_depth=mgd,
                           batch_size=batch, min_batch_size=min_batch, train_pixel_stride=stride, train_pixel_offset=offset)
     dump_spp = min(train_spp, spp) - 1 if (dump and train_spp > 0) else -1
@@ -233,6 +235,56 @@ def test_gpu_trained_solve_matches_oracle_3d(orc):
     raw = gi.queryNetwork((0.5, 0.29, 0.5))
     assert raw.shape == (41,) and np.isfinite(raw).all()
     gi.close()
+
+
+def _with_env(env, fn):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+FUSED_MODES = [({}, "one launch per sample, walkers spread over the lanes (a small frame)"),
+               ({"WOST3_G_SHIFT": "0", "WOST3_G_FUSED": "1"}, "one launch per sample, 64 walkers per wave: four units of the matrices at once"),
+               ({"WOST3_G_FUSED": "0"}, "the launches per depth")]
+
+
+@pytest.mark.gpu
+def test_gpu_guided3_reference_network_fused_and_per_depth(orc):
+    """the reference's eight-level network (the shape the MFMA kernels and g3_fused_kernel cover; the tests above use four levels
+    = the scalar kernels and the launches per depth): a frozen random network and a trained solve with an emissive Neumann face,
+    each through the fused kernel (spread walkers: one unit; 64 walkers per wave: four units) and through the launches per
+    depth -- all equal to the oracle bit for bit, and the fused solves take a few launches per sample"""
+    cfg = default_net_config3()
+    sd = mixed_cube()
+    p = _rand_params3(orc, cfg, seed=3, wscale=0.3, gscale=1.0)
+    ref = None
+    for env, what in FUSED_MODES:
+        gi, ref = _with_env(env, lambda: _gpu_and_oracle3(orc, sd, 40, 32, 3, 48, 0, params=p, cfg=cfg, ref=ref))
+        assert np.array_equal(gi.solution, ref["field"]), (what, float(np.abs(gi.solution - ref["field"]).max()))
+        for k in COUNTERS:
+            assert gi.last_stats[k] == ref[k], (what, k)
+        assert gi.last_stats["guided_steps"] > 1000
+        if env.get("WOST3_G_FUSED") != "0":
+            assert gi.last_stats["kernel_launches"] <= 3 * 2 + 2, gi.last_stats["kernel_launches"]
+        gi.close()
+    sd = cube_scene3(n=3, d_faces=(4, 5), n_faces=(0, 1, 2, 3), value=lambda x, y, z: z, flux=lambda x, y, z, f: 0.3 * (f - 1.5))
+    ref = None
+    for env, what in FUSED_MODES:
+        gi, ref = _with_env(env, lambda: _gpu_and_oracle3(orc, sd, 30, 24, 5, 48, 3, batch=512, min_batch=128, stride=2, offset=1, cfg=cfg, ref=ref))
+        for k in COUNTERS + ("train_samples", "optimizer_steps"):
+            assert gi.last_stats[k] == ref[k], (what, k)
+        assert ref["optimizer_steps"] >= 3
+        assert np.array_equal(gi.solution, ref["field"]), what
+        assert np.array_equal(gi.network.params(), ref["params"]), what
+        gi.close()
 
 
 @pytest.mark.gpu
