@@ -848,13 +848,15 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
     const int n_train_pixels = (int)(((size_t)N - train_offset + (size_t)s.train_pixel_stride - 1) / (size_t)s.train_pixel_stride);
     const int n_train_blocks = (n_train_pixels + 255) / 256;
     W3_TRY(hipMemsetAsync(g->stats, 0, kStat3Copies * sizeof(GStats3Dev), stream));
-    // walkers per lane of the walk kernels: spread out while the frame leaves lanes of the chip idle (about three blocks per CU fit)
+    // walkers per lane of the walk kernels: spread out while all blocks of the frame are still resident at once (two blocks per CU: the
+    // stack columns and the task pools take 46 to 64 KB of LDS).  Round 4 spread as far as 1.5 x three blocks per CU: a frame of 256^2
+    // then ran its blocks in two rounds, each as long as its longest walk (the shell scene, 16 samples: 118 -> 89 ms with one round)
     {
         int n_cus = 256;
         (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, g->device);
-        const uint64_t resident = (uint64_t)n_cus * 3 * 256;
+        const uint64_t resident = (uint64_t)n_cus * 2 * 256;
         P.lane_shift = 0;
-        while (P.pool_cap > 0 && P.lane_shift < 3 && (((uint64_t)N << (P.lane_shift + 1)) * 2 <= resident * 3)) ++P.lane_shift;
+        while (P.pool_cap > 0 && P.lane_shift < 3 && ((uint64_t)N << (P.lane_shift + 1)) <= resident) ++P.lane_shift;
         if (const char *w = std::getenv("WOST3_G_SHIFT")) P.lane_shift = std::min(4, std::max(0, std::atoi(w)));
     }
     const unsigned grid_px = (unsigned)((((uint64_t)N << P.lane_shift) + 255) / 256);      // walk kernels (begin / train-set / resolve: one thread per pixel)
