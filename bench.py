@@ -607,7 +607,8 @@ def run_neumann2d(env, args):
 
 def run_guided3d(env, args):
     """GuidedIntegrator<3> on the two 3-D bench scenes at 256^2, 16 spp (8 of them trained) and at 1024^2, 4 spp (2 trained), depth 64:
-    the whole solve (walks, network inference per depth, training), as walk-steps per second of wall time."""
+    the whole solve (walks, network inference, training), as walk-steps per second of wall time.  (The roofline counters of the 256^2
+    entries come from one profiled run of all four solves: g3_fused_kernel is the 256^2 frames', g3_separate / g3_sample / g3_tail the 1024^2 frames'.)"""
     import numpy as np
     from elaina_amd.guided import GuidedIntegratorSettings
     from elaina_amd.integrator3d import GuidedIntegrator3, Problem3, default_net_config3
@@ -635,7 +636,8 @@ def run_guided3d(env, args):
         g = gi.last_stats
         out[name] = {"workload": "%s guided %dx%d %d spp (train %d) depth 64 eps 2e-3" % (name, frame, frame, spp, spp // 2),
                      "walk_steps": float(g["walk_steps"]), "guided_steps": float(g["guided_steps"]), "optimizer_steps": float(g["optimizer_steps"]),
-                     "ms_per_step": dt * 1e3, "value": g["walk_steps"] / dt, "unit": "walk-steps/s",
+                     "ms_per_step": dt * 1e3, "value": g["walk_steps"] / dt, "unit": "walk-steps/s", "kernel_launches": float(g["kernel_launches"]),
+                     "form": "one launch per sample (g3_fused_kernel)" if frame == 256 else "launches per depth (the frame fills the chip)",
                      "field_finite": bool(np.isfinite(gi.solution).all())}
         gi.close()
         if frame != 256:

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""VALU figures of the guided 3-D walk kernels (g3_separate_kernel, g3_sample_kernel, g3_tail_kernel) per bench scene from PMC
+"""VALU figures of the guided 3-D walk kernels (g3_fused_kernel; g3_separate_kernel, g3_sample_kernel, g3_tail_kernel) per bench scene from PMC
 summaries of tools/probes/bench3d_guided_only.py.  Usage: pmc_derive_guided3d.py pmc_summary.txt kernel_stats.csv out.json "<command>"
 The Dirichlet icosphere runs the instantiations with NTREE = false, the Neumann shell those with NTREE = true (template
-arguments EMISSIVE, NTREE, SOURCE of g3_separate / g3_tail; NTREE of g3_sample)."""
+arguments EMISSIVE, NTREE, SOURCE of g3_fused / g3_separate / g3_tail; NTREE of g3_sample).  The 256^2 scenes run g3_fused_kernel (one launch
+per sample), the 1024^2 scenes of the same command the launches per depth."""
 import csv
 import json
 import os
@@ -16,7 +17,7 @@ summary, stats_csv, out_path, cmd = sys.argv[1:5]
 
 
 def scene_of(name):
-    m = re.search(r"g3_(separate|tail)_kernel<(\w+), (\w+), (\w+)>", name) or re.search(r"g3_(sample)_kernel<()(\w+)>", name)
+    m = re.search(r"g3_(separate|tail|fused)_kernel<(\w+), (\w+), (\w+)>", name) or re.search(r"g3_(sample)_kernel<()(\w+)>", name)
     if not m:
         return None, None
     return ("neumann_shell_1280" if m.group(3) == "true" else "dirichlet_icosphere_1280"), "g3_%s_kernel" % m.group(1)
@@ -36,7 +37,7 @@ try:
 except Exception:
     rows = []
 total_ns = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
-out = {"kernels": "g3_separate_kernel / g3_sample_kernel / g3_tail_kernel", "source_id": source_id(), "scenes": {},
+out = {"kernels": "g3_fused_kernel (256^2) / g3_separate_kernel / g3_sample_kernel / g3_tail_kernel (1024^2)", "source_id": source_id(), "scenes": {},
        "source": "rocprofv3 --pmc passes of `%s` (tools/gpu_round.sh, stage pmc_guided3d): pipe_busy = 4 SQ_ACTIVE_INST_VALU / (1024 SIMDs x "
                  "GRBM_GUI_ACTIVE / 8), lane_efficiency = SQ_THREAD_CYCLES_VALU / (64 SQ_INSTS_VALU), wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES; "
                  "share_of_gpu_time from the kernel trace of the same command (both scenes, network and training kernels included)" % cmd}
