@@ -52,6 +52,22 @@ def test_gpu_tree_sized_neumann_meshes_far_from_the_origin(mode):
 
 
 @pytest.mark.gpu
+def test_gpu_guided3_forms_agree_on_far_tree_sized_meshes():
+    """tools/fuzz/fuzz_g3_forms.py: the same scenes with the reference's eight-level network (the shape g3_fused_kernel and the MFMA
+    kernels cover; the oracle-backed seeds above use four levels), frozen and training, frames of 80 .. 51 200 pixels -- one launch per
+    sample with spread walkers, with 64 walkers per wave, and the launches per depth agree bit for bit (eight seeds here; 200 once
+    under gpurun: profiles/r05_ag_fuzz_g3_forms.txt)"""
+    import fuzz_g3_forms as G
+    bad = []
+    for seed in range(8):
+        c = G.case(seed)
+        d = G.run_forms(c)
+        if d:
+            bad.append((seed, d, c["what"]))
+    assert not bad, bad[:3]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extents", [1.0, 100.0, 1e3, 1e4])
 def test_gpu_rays_from_points_on_a_fine_mesh_far_from_the_origin_2d(oracle, extents):
     """30 000 segments; the mesh centre `extents` mesh sizes from the origin (at 10^4 one ulp of a coordinate is five segment
