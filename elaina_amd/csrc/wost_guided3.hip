@@ -65,6 +65,10 @@ struct G3Params {
     int32_t *whint, *hint0;
     // the queue of a depth
     uint32_t *q_pid, *q_count;
+    // the launches per depth: the walkers that are still alive, compacted (written by g3_sample_kernel for the next depth's
+    // g3_separate_kernel / the tail; l_pid == nullptr: every pixel in pixel order, as at depth 0 and in g3_fused_kernel)
+    const uint32_t *l_pid, *l_count;
+    uint32_t *l_next_pid, *l_next_count;
     float *net_in, *net_out;
     GStats3Dev *stats;
     int32_t training, train_offset, train_stride, max_train_depth;
@@ -347,8 +351,15 @@ __global__ __launch_bounds__(256) void g3_separate_kernel(G3Params P)
     extern __shared__ uint32_t lds_stack[];
     const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
     const WavePool3 W = g3_pools(P, lds_stack);
-    const int p = g3_item(P);
-    const bool live = p >= 0 && p < P.n_pixels && P.state[p] == 1;
+    const int i = g3_item(P);
+    int p = i;
+    bool live;
+    if (P.l_pid) {
+        live = i >= 0 && (uint32_t)i < *P.l_count;
+        p = live ? (int)P.l_pid[i] : 0;
+    } else {
+        live = p >= 0 && p < P.n_pixels && P.state[p] == 1;
+    }
     V3 x;
     const bool keep = g3_separate_body<EMISSIVE, NTREE, SOURCE>(P, P.depth, live ? p : 0, live, W, stk, x);
     const uint32_t s = block_push(keep, P.q_count);
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(256) void g3_separate_kernel(G3Params P)
 // (guided/integrator.cu:497-526, 671-880, 883-965 with DIM == 3)
 // for the walker of pixel `pid` (live: out of the shell, R_B stored) at `depth`; raw = its 41 network outputs when `guiding`
 template <bool NTREE>
-__device__ __forceinline__ void g3_sample_body(const G3Params &P, int depth, bool guiding, uint32_t pid, bool live, const float *raw, const WavePool3 &W,
+__device__ __forceinline__ bool g3_sample_body(const G3Params &P, int depth, bool guiding, uint32_t pid, bool live, const float *raw, const WavePool3 &W,
                                                const LdsColumn &stk)
 {
     const bool pooled = NTREE && P.pool_cap > 0;
@@ -494,6 +505,7 @@ __device__ __forceinline__ void g3_sample_body(const G3Params &P, int depth, boo
     g3_count(hit, &st->nhits);
     g3_count(moved && depth == P.st.max_depth - 1, &st->truncated);
     g3_count(live && guiding, &st->net_points);
+    return moved;      // the walker goes on to the next depth
 }
 
 template <bool NTREE>
@@ -504,7 +516,12 @@ __global__ __launch_bounds__(256) void g3_sample_kernel(G3Params P)
     const WavePool3 W = g3_pools(P, lds_stack);
     const int i = g3_item(P);
     const bool live = i >= 0 && (uint32_t)i < *P.q_count;
-    g3_sample_body<NTREE>(P, P.depth, P.guiding != 0, live ? P.q_pid[i] : 0u, live, P.net_out + 41 * (size_t)(live ? i : 0), W, stk);
+    const uint32_t pid = live ? P.q_pid[i] : 0u;
+    const bool moved = g3_sample_body<NTREE>(P, P.depth, P.guiding != 0, pid, live, P.net_out + 41 * (size_t)(live ? i : 0), W, stk);
+    if (P.l_next_pid) {
+        const uint32_t s = block_push(moved, P.l_next_count);
+        if (moved) P.l_next_pid[s] = pid;
+    }
 }
 
 // The unguided tail of a sample: from depth >= maxGuidedDepth on nothing needs the network, yet a launch pair per depth over a
@@ -517,8 +534,13 @@ __global__ __launch_bounds__(256) void g3_tail_kernel(G3Params P)
     extern __shared__ uint32_t lds_stack[];
     const LdsColumn stk{lds_stack + threadIdx.x, (uint32_t)P.stack_stride};
     const WavePool3 W = g3_pools(P, lds_stack);
-    const int p = g3_item(P);
-    const bool mine = p >= 0 && p < P.n_pixels;
+    const int i = g3_item(P);
+    int p = i;
+    bool mine = p >= 0 && p < P.n_pixels;
+    if (P.l_pid) {      // the walkers that reached this depth, compacted
+        mine = i >= 0 && (uint32_t)i < *P.l_count;
+        p = mine ? (int)P.l_pid[i] : 0;
+    }
     for (int depth = P.depth; depth < P.st.max_depth; ++depth) {
         const bool live = mine && P.state[p] == 1;
         if (!__ballot(live)) break;       // (wave-uniform: the queries are the wave's)
@@ -773,7 +795,7 @@ struct wost3_guided {
     std::vector<void *> allocs;
     uint64_t *rng = nullptr;
     float *sol = nullptr, *rec = nullptr, *wx = nullptr, *wn = nullptr, *wthp = nullptr, *wrb = nullptr, *net_in = nullptr, *net_out = nullptr, *field = nullptr;
-    uint32_t *cur_depth = nullptr, *q_pid = nullptr, *q_count = nullptr, *block_sums = nullptr;
+    uint32_t *cur_depth = nullptr, *q_pid = nullptr, *q_count = nullptr, *block_sums = nullptr, *l_pid = nullptr;
     int32_t *state = nullptr, *whint = nullptr, *hint0 = nullptr;
     uint8_t *won = nullptr, *t_onn = nullptr;
     float *t_x = nullptr, *t_dir = nullptr, *t_sol = nullptr, *t_li = nullptr, *t_pdf = nullptr, *t_nrm = nullptr;
@@ -829,7 +851,8 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
     P.n_pixels = N; P.shard_index = shard_index; P.shard_count = shard_count;
     P.rng = g->rng; P.sol = g->sol; P.cur_depth = g->cur_depth; P.rec = g->rec; P.state = g->state; P.wx = g->wx; P.wn = g->wn;
     P.wthp = g->wthp; P.wrb = g->wrb; P.won = g->won; P.whint = g->whint; P.hint0 = g->hint0;
-    P.q_pid = g->q_pid; P.q_count = g->q_count; P.net_in = g->net_in; P.net_out = g->net_out; P.stats = g->stats;
+    // (counters: [1] the queue, [0] and [2] the live lists written at even / odd depths)
+    P.q_pid = g->q_pid; P.q_count = g->q_count + 1; P.net_in = g->net_in; P.net_out = g->net_out; P.stats = g->stats;
     P.max_train_depth = s.max_train_depth; P.stack_stride = 256;
     uint32_t train_offset = 0;
     if (s.train_pixel_stride > 1) {
@@ -851,10 +874,11 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
     // walkers per lane of the walk kernels: spread out while all blocks of the frame are still resident at once (two blocks per CU: the
     // stack columns and the task pools take 46 to 64 KB of LDS).  Round 4 spread as far as 1.5 x three blocks per CU: a frame of 256^2
     // then ran its blocks in two rounds, each as long as its longest walk (the shell scene, 16 samples: 118 -> 89 ms with one round)
+    uint64_t resident = 0;
     {
         int n_cus = 256;
         (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, g->device);
-        const uint64_t resident = (uint64_t)n_cus * 2 * 256;
+        resident = (uint64_t)n_cus * 2 * 256;
         P.lane_shift = 0;
         while (P.pool_cap > 0 && P.lane_shift < 3 && ((uint64_t)N << (P.lane_shift + 1)) <= resident) ++P.lane_shift;
         if (const char *w = std::getenv("WOST3_G_SHIFT")) P.lane_shift = std::min(4, std::max(0, std::atoi(w)));
@@ -869,17 +893,18 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
     bool training = true;
     float uniform_fraction = s.uniform_fraction_training;
     int max_guided_depth = s.max_guided_depth_training;
-    // One launch per sample (g3_fused_kernel) when the network offers its fp32 MFMA fragments and the frame leaves lanes of the chip idle
-    // (lane_shift > 0: up to 147 456 walkers): such a solve is bound by its launches -- 30 per sample, each as long as its slowest wave
-    // (icosphere 256^2, 16 samples: 62.9 -> 49.0 ms).  A frame that fills the chip is bound by throughput, and there the launches per
-    // depth win: their network and sampling kernels run on the compacted queue of the walkers that are left, the fused kernel's waves
-    // keep their dead lanes (1024^2, 4 samples: 84 -> 94 ms on the icosphere, 181 -> 230 ms in the shell).  WOST3_G_FUSED=0 / 1: never / always.
+    // One launch per sample (g3_fused_kernel) when the network offers its fp32 MFMA fragments and the frame has at most 1.5 walkers per
+    // resident lane (196 608 on MI355X): such a solve is bound by its launches -- 30 per sample, each as long as its slowest wave.  A
+    // larger frame is bound by throughput, and there the launches per depth win: all their kernels run on compacted lists of the walkers
+    // that are left, the fused kernel's waves keep their dead lanes.  8 samples, 4 trained, fused / per depth in ms
+    // (tools/probes/g3_forms_by_frame.py): icosphere 256^2 25 / 35, 362^2 30 / 44, 512^2 53 / 58, 724^2 120 / 91, 1024^2 212 / 158; shell
+    // 44 / 52, 70 / 82, 132 / 105, 223 / 174, 457 / 301.  WOST3_G_FUSED=0 / 1: never / always.
     G3Net Fn{};
     bool fused = false;
     {
         F32NetView fv{};
         const char *env = std::getenv("WOST3_G_FUSED");
-        const bool want = env ? env[0] != '0' : P.lane_shift > 0;
+        const bool want = env ? env[0] != '0' : 2 * (uint64_t)N <= 3 * resident;
         if (want && net_f32_view3(g->net, &fv) == WOST_OK && fv.L.n_levels == 8 && fv.L.n_features == 4 && fv.L.n_out == 41) {
             Fn.frag = fv.frag; Fn.grid = fv.grid;
             for (int l = 0; l < 4; ++l) Fn.w_off[l] = fv.L.w_off[l];
@@ -920,6 +945,9 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
         }
         for (int depth = 0; depth < s.max_depth && !fused; ++depth) {
             P.depth = depth; P.guiding = depth < max_guided_depth ? 1 : 0;
+            // the walkers that reached this depth: the list the previous depth's sample kernel wrote (depth 0: every pixel)
+            P.l_pid = depth > 0 ? g->l_pid + (size_t)((depth - 1) & 1) * N : nullptr;
+            P.l_count = depth > 0 ? g->q_count + 2 * ((depth - 1) & 1) : nullptr;
             if (!P.guiding) {
 #define G3_LAUNCH(K, E, T)                                                                                              \
     do {                                                                                                                \
@@ -931,12 +959,14 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
                 ++launches;
                 break;
             }
-            W3_TRY(hipMemsetAsync(g->q_count, 0, sizeof(uint32_t), stream));
+            // the queue's counter and that of the live list this depth's sample kernel writes: two adjacent words
+            W3_TRY(hipMemsetAsync(g->q_count + (depth & 1), 0, 2 * sizeof(uint32_t), stream));
+            P.l_next_pid = g->l_pid + (size_t)(depth & 1) * N; P.l_next_count = g->q_count + 2 * (depth & 1);
             if (ntree) { if (emissive) G3_LAUNCH(g3_separate_kernel, true, true); else G3_LAUNCH(g3_separate_kernel, false, true); }
             else       { if (emissive) G3_LAUNCH(g3_separate_kernel, true, false); else G3_LAUNCH(g3_separate_kernel, false, false); }
             ++launches;
             {
-                const int rc = net_inference_dev(g->net, g->net_in, g->q_count, (int)n_upper, g->net_out, true, stream, 0);
+                const int rc = net_inference_dev(g->net, g->net_in, P.q_count, (int)n_upper, g->net_out, true, stream, 0);
                 if (rc != WOST_OK) return rc;
             }
             const unsigned grid_q = (unsigned)((((uint64_t)n_upper << P.lane_shift) + 255u) / 256u);
@@ -1038,7 +1068,7 @@ int wost3_guided_create(const wost3_scene_desc *scene, const wost3_guided_settin
     hipError_t e = hipSuccess;
 #define G3A(p, n) if (e == hipSuccess) e = g3_alloc(g, &g->p, (n))
     G3A(rng, N); G3A(sol, 3 * N); G3A(cur_depth, N); G3A(rec, (size_t)kMaxTrainDepth3 * kRec3Fields * N); G3A(state, N); G3A(wx, 3 * N); G3A(wn, 3 * N);
-    G3A(wthp, N); G3A(wrb, N); G3A(won, N); G3A(whint, N); G3A(hint0, N); G3A(q_pid, N); G3A(q_count, 4); G3A(net_in, 3 * N); G3A(net_out, 41 * N);
+    G3A(wthp, N); G3A(wrb, N); G3A(won, N); G3A(whint, N); G3A(hint0, N); G3A(q_pid, N); G3A(l_pid, 2 * N); G3A(q_count, 4); G3A(net_in, 3 * N); G3A(net_out, 41 * N);
     G3A(field, 3 * N); G3A(stats, kStat3Copies); G3A(block_sums, N / 256 + 4);
     G3A(t_x, 3 * cap); G3A(t_dir, 3 * cap); G3A(t_sol, 3 * cap); G3A(t_li, cap); G3A(t_pdf, cap); G3A(t_nrm, 3 * cap); G3A(t_onn, cap);
 #undef G3A
