@@ -550,7 +550,6 @@ __global__ __launch_bounds__(256) void g3_tail_kernel(G3Params P)
     }
 }
 
-
 // ---- a whole sample in ONE launch ------------------------------------------------------------------------------------------------
 // The launches per depth above cost a 16-sample solve ~700 launches, each as long as the slowest wave of its depth, and the walkers a
 // round trip through the queue and the network's buffers.  Here a wave keeps its walkers from the evaluation point to the end of the
@@ -954,6 +953,8 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
         if (has_src) hipLaunchKernelGGL((K<E, T, true>), dim3(grid_px), dim3(256), lds, stream, P);                       \
         else hipLaunchKernelGGL((K<E, T, false>), dim3(grid_px), dim3(256), lds, stream, P);                              \
     } while (0)
+                // (the tail starts on the compacted list of the walkers that are left and keeps them to their end: launches of a few depths
+                // with the survivors compacted in between were measured and lose -- EXPERIMENTS 23 -- the tail waits for its steps, not for lanes)
                 if (ntree) { if (emissive) G3_LAUNCH(g3_tail_kernel, true, true); else G3_LAUNCH(g3_tail_kernel, false, true); }
                 else       { if (emissive) G3_LAUNCH(g3_tail_kernel, true, false); else G3_LAUNCH(g3_tail_kernel, false, false); }
                 ++launches;

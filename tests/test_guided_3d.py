@@ -253,7 +253,8 @@ def _with_env(env, fn):
 
 FUSED_MODES = [({}, "one launch per sample, walkers spread over the lanes (a small frame)"),
                ({"WOST3_G_SHIFT": "0", "WOST3_G_FUSED": "1"}, "one launch per sample, 64 walkers per wave: four units of the matrices at once"),
-               ({"WOST3_G_FUSED": "0"}, "the launches per depth")]
+               ({"WOST3_G_FUSED": "0"}, "the launches per depth"),
+               ({"WOST3_G_FUSED": "0", "WOST3_G_SHIFT": "0"}, "the launches per depth, 64 walkers per wave")]
 
 
 @pytest.mark.gpu

@@ -1,7 +1,7 @@
 """GuidedIntegrator<3> in its three forms against each other on random far, tree-sized scenes (the scenes of fuzz_far_trees.py) with the
 reference's EIGHT-level network -- the shape g3_fused_kernel and the MFMA kernels cover, which the oracle-backed fuzzers avoid (four
 levels keep the oracle's dense grid small): one launch per sample with the walkers spread over the lanes, one launch per sample with
-64 walkers per wave (four units of the matrices at once), and the launches per depth.  Frozen and training solves, frames from 80 to
+64 walkers per wave (four units of the matrices at once), and the launches per depth (walkers spread; 64 per wave).  Frozen and training solves, frames from 80 to
 51 200 pixels; fields, counters and (trained) final parameters must agree bit for bit.  GPU only, no oracle.
 
 usage: fuzz_g3_forms.py [first seed] [count [seconds]]"""

@@ -15,10 +15,10 @@ Vi, Ti = bench.icosphere(2, 0.45)
 shell = {"d_verts": Vi, "d_tris": Ti, "d_colors": np.repeat(Vi[:, :1], 6, axis=1).astype(np.float32), "n_verts": V, "n_tris": T,
          "n_colors": np.zeros((len(V), 6), np.float32), "probe": (0.7, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0)),
          "dirichlet_intensity": 1.0, "neumann_intensity": 1.0}
-for frame in (256, 362, 512, 724, 1024):
+for frame in [int(f) for f in os.environ.get("G3_FRAMES", "256 362 512 724 1024").split()]:
     row = {}
     for name, sd in (("icosphere", ball), ("shell", shell)):
-        for form in ("1", "0"):
+        for form in os.environ.get("G3_FORMS", "1 0").split():
             os.environ["WOST3_G_FUSED"] = form
             st = GuidedIntegratorSettings(frameSize=(frame, frame), samplesPerPixel=8, trainSppCount=4, maxWalkingDepth=64, epsilonShell=2e-3)
             gi = GuidedIntegrator3(Problem3.from_dict(sd), st, ((-1.1, -1.1, -1.1), (1.1, 1.1, 1.1)), network_config=default_net_config3(), seed=7)
