@@ -126,12 +126,17 @@ def _hip_cfg(cfg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_levels", [4, 8])
-def test_gpu_net3_inference_and_training_match_oracle(orc, n_levels):
+@pytest.mark.parametrize("n_levels,scale", [(4, None), (8, None), (8, 1.45), (8, 0)])
+def test_gpu_net3_inference_and_training_match_oracle(orc, n_levels, scale, monkeypatch):
     """four levels: the scalar kernels; eight (the reference's network shape): the matrix-core kernels with the trilinear encoding
-    (f32_encode_level3) -- both the oracle's numbers bit for bit"""
+    (f32_encode_level3) -- both the oracle's numbers bit for bit.  The grid gradient goes through spatial boxes (grid_bin3_*): 8^3 of
+    them with the reference's per-level scale, 16^3 with 1.45 (the finest level's sub-grid of an eighth of the cube no longer fits
+    LDS), and (scale 0 here: WOST_GRID_GRAD_BINS=0) through the launches per level group that remain for grids no box size fits"""
     from elaina_amd.guided import GuidingNetwork
-    cfg = default_net_config3(n_levels=n_levels)
+    if scale == 0:
+        monkeypatch.setenv("WOST_GRID_GRAD_BINS", "0")
+        scale = None
+    cfg = default_net_config3(n_levels=n_levels) if scale is None else default_net_config3(n_levels=n_levels, per_level_scale=scale)
     net = GuidingNetwork(_hip_cfg(cfg), seed=3, dims=3)
     assert net.n_params == orc.net3_n_params(cfg)
     p = _rand_params3(orc, cfg, seed=11)
