@@ -161,6 +161,43 @@ def test_gpu_net3_inference_and_training_match_oracle(orc, n_levels, scale, monk
     net.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_features,n_levels", [(2, 8), (8, 3)])
+def test_gpu_net3_grid_gradient_with_other_feature_counts(orc, n_features, n_levels):
+    """the three-input grid gradient through spatial boxes is written for any number of features per level (the reference uses four):
+    two and eight features on the scalar kernels, 20 000 points so that a box's points fill several blocks -- gradients and two Adam
+    steps against the oracle bit for bit"""
+    from elaina_amd.guided import GuidingNetwork
+    from oracle.oracle import NetConfig
+    cfg = NetConfig(n_levels, n_features, 8, 1.4049999713897705, 64, 3, 41, 48, 0.00800000037997961, 0.8999999761581421, 0.9900000095367432,
+                    1.0000000036274937e-15, 9.999999974752427e-07, 0.949999988079071)
+    net = GuidingNetwork(_hip_cfg(cfg), seed=3, dims=3)
+    n = orc.net3_n_params(cfg)
+    assert net.n_params == n
+    rng = np.random.default_rng(21)
+    n_mlp = 64 * (n_features * n_levels) + 2 * 64 * 64 + 48 * 64
+    p = rng.uniform(-0.25, 0.25, n).astype(np.float32)
+    p[n_mlp:] = rng.uniform(-0.5, 0.5, n - n_mlp).astype(np.float32)
+    net.set_params(p)
+    # most points in one corner of the cube (one box holds thousands), the rest everywhere, a few outside
+    x = np.concatenate([rng.uniform(0.0, 0.12, (12000, 3)), rng.uniform(-0.02, 1.02, (8000, 3))]).astype(np.float32)
+    assert np.array_equal(net.inference(x), orc.net3_forward(cfg, p, x)[:, :41])
+    state = orc.net_optimizer_state(cfg)
+    for k in state:
+        state[k] = np.zeros(len(p), state[k].dtype)
+    po = p.copy()
+    for step in (1, 2):
+        dl = rng.normal(size=(len(x), 41)).astype(np.float32)
+        dl48 = np.zeros((len(x), 48), np.float32)
+        dl48[:, :41] = dl
+        g = orc.net3_backward(cfg, po, x, dl48)
+        net.train_step(x, dl, 128.0, apply_update=True)
+        assert np.array_equal(net.gradients(), g)
+        inf = orc.net3_optimizer_step(cfg, po, state, g, step, 128.0)
+        assert np.array_equal(net.params(), po) and np.array_equal(net.inference_params(), inf)
+    net.close()
+
+
 def _gpu_and_oracle3(orc, sd, w, h, spp, depth, train_spp, uf=(0.5, 0.5), mgd=(10, 10), batch=1024, min_batch=256, params=None,
                      stride=1, offset=0, dump=True, cfg=None, ref=None):
     from elaina_amd.guided import GuidedIntegratorSettings
