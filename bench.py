@@ -269,6 +269,10 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
                                    "lane efficiency, and per-lane node fetches of an L1-resident tree (EXPERIMENTS 6, 18, 19)",
                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                      "kernel": "walk_round_kernel", "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
+                     "launches_what": "the round launches on the solve's stream, HIP events around each: walk_round_kernel and, for the last rounds, its "
+                                      "four-lanes-per-walker twin walk_quad_kernel (config 2: 11 + 4 per pass); in a rocprofv3 --kernel-trace --stats summary "
+                                      "of the same command compare with (sum of both kernels' TotalDurationNs) / (sum of their Calls), the SLACK instantiation "
+                                      "<..., true> left out (it runs beside them on the side stream)",
                      "algorithmic_bytes_per_walk_step": BYTES_PER_STEP},
     }
     if env.world > 1:
