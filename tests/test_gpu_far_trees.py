@@ -3,7 +3,9 @@
 * tools/fuzz/fuzz_far_trees.py -- Neumann meshes of 5 000 .. 30 000 primitives, closed and open, emissive and not, the whole
   scene 10 .. 300 scene sizes away -- through the guided 2-D, the uniform 3-D and the guided 3-D kernels, 40 seeds each with a
   frozen network and 10 seeds each with trainSppCount >= 2 (records, Adam / EMA steps, the trained network's walks), bit for bit
-  against the oracle.  The oracle half of every seed (fields, counters, final parameters) is the committed fixture
+  against the oracle; the guided 3-D kernels once more with the reference's EIGHT-level network (guided3d_l8: 24 seeds frozen,
+  guided3d_l8_train: 8 seeds training) -- the matrix-core network kernels, the grid gradient through spatial boxes and
+  g3_fused_kernel (a sample in one launch), which the four-level seeds do not reach.  The oracle half of every seed (fields, counters, final parameters) is the committed fixture
   tests/golden/far_trees_<mode>.npz, written in the build container by `fuzz_far_trees.py golden <mode>`; the GPU box regenerates
   the scene from the seed, runs HIP and compares -- none of the oracle's CPU time (10 - 17 s a guided seed) inside the GPU suite;
 * the batch ray queries (ray_kernel / ray3_kernel behind wost_ray_intersect / wost3_ray_intersect) with origins ON the mesh
@@ -19,7 +21,7 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(ROOT, "tools", "fuzz"))
 
-MODES = ["guided2d", "uniform3d", "guided3d", "guided2d_train", "guided3d_train"]
+MODES = ["guided2d", "uniform3d", "guided3d", "guided2d_train", "guided3d_train", "guided3d_l8", "guided3d_l8_train"]
 
 
 @pytest.mark.parametrize("mode", MODES)

@@ -20,7 +20,7 @@ CPU time inside the GPU suite.
 usage: fuzz_far_trees.py <mode> [first seed] [count [seconds [log]]]       both halves live (needs GPU + oracle)
        fuzz_far_trees.py golden <mode> [count]                             write the fixture (oracle only)
        fuzz_far_trees.py check <mode>                                      HIP against the fixture (GPU only)
-modes: guided2d uniform3d guided3d guided2d_train guided3d_train"""
+modes: guided2d uniform3d guided3d guided2d_train guided3d_train guided3d_l8 guided3d_l8_train"""
 import os
 import sys
 
@@ -160,15 +160,18 @@ def case_uniform3d(seed):
     return c
 
 
-def case_guided3d(seed, train=False):
-    rng = np.random.default_rng((95_000 if train else 90_000) + seed)
+def case_guided3d(seed, train=False, n_levels=4):
+    rng = np.random.default_rng((95_000 if train else 90_000) + seed + (0 if n_levels == 4 else 3_000))
     sd, scale, off, feat = scene3d(rng)
     c = dict(dims=3, scene=sd, scale=scale, feat=feat, w=10, h=8, spp=2, depth=int(rng.choice([8, 20])))
     c["eps"] = scale * 10.0 ** rng.uniform(-3.5, -2)
     c["aabb"] = (tuple(float(o - 1.3 * scale) for o in off), tuple(float(o + 1.3 * scale) for o in off))
     uf = float(rng.choice([0.0, 0.5]))
-    # four levels keep the dense 3-D grid small; the code path is the same for eight
-    c["uf"], c["train"], c["keys"], c["cfg"] = (uf, uf), 0, GUIDED_KEYS, NetCfg(41, n_levels=4)
+    # four levels keep the dense 3-D grid small and run the scalar network kernels with the launches per depth; eight levels (the
+    # *_l8 modes, the reference's network) run the matrix-core kernels and, on these small frames, g3_fused_kernel: a sample in one launch
+    c["uf"], c["train"], c["keys"], c["cfg"] = (uf, uf), 0, GUIDED_KEYS, NetCfg(41, n_levels=n_levels)
+    if n_levels == 8:
+        c.update(w=14, h=11, spp=3)
     if train:
         c.update(w=16, h=12, spp=int(rng.choice([3, 4])), train=int(rng.choice([2, 3])), keys=TRAIN_KEYS,
                  uf=(float(rng.choice([0.5, 1.0])), float(rng.choice([0.0, 0.5]))), batch=(256, 128))
@@ -179,8 +182,9 @@ def case_guided3d(seed, train=False):
 
 
 CASES = {"guided2d": case_guided2d, "uniform3d": case_uniform3d, "guided3d": case_guided3d,
-         "guided2d_train": lambda seed: case_guided2d(seed, True), "guided3d_train": lambda seed: case_guided3d(seed, True)}
-DEFAULT_COUNT = {"guided2d": 40, "uniform3d": 40, "guided3d": 40, "guided2d_train": 10, "guided3d_train": 10}
+         "guided2d_train": lambda seed: case_guided2d(seed, True), "guided3d_train": lambda seed: case_guided3d(seed, True),
+         "guided3d_l8": lambda seed: case_guided3d(seed, False, 8), "guided3d_l8_train": lambda seed: case_guided3d(seed, True, 8)}
+DEFAULT_COUNT = {"guided2d": 40, "uniform3d": 40, "guided3d": 40, "guided2d_train": 10, "guided3d_train": 10, "guided3d_l8": 24, "guided3d_l8_train": 8}
 
 
 def _result(c, field, stats, params):
