@@ -331,6 +331,21 @@ def test_gpu_guided3_reference_network_fused_and_per_depth(orc):
 
 
 @pytest.mark.gpu
+def test_gpu_guided3_forms_agree_on_a_frame_that_fills_the_chip():
+    """tools/probes/g3_forms_equal_at_size.py: the bench's shell scene at 724^2, two trained + two guided samples -- the live lists of the
+    launches per depth hold hundreds of thousands of walkers written by thousands of blocks (the other tests' frames are small); field,
+    counters and trained parameters equal to those of the one-launch-per-sample form bit for bit"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "g3_forms_equal_at_size.py")], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, FRAME="724", SPP="4"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "fields equal True, parameters equal True, counters equal" in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.gpu
 def test_gpu_guided3_shards_and_refusals(orc):
     """wost3_guided_solve_sharded: with a frozen network the shards' fields add up to the full frame; a 2-D shaped network
     is refused"""
