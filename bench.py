@@ -19,8 +19,8 @@ the line also carries "configs": one pass each of config 3 and config 4 (both ne
 (uniform3d, guided3d), a 2-D scene with a Neumann boundary on the tree (neumann2d), the guiding gain and the variance check
 (--no-extras skips them); at N > 1 it carries one pass of config 5.
 
-Rank 0 prints the JSON line (the headline alone as soon as it is measured when extras follow -- marked "partial" -- and the
-complete line last).
+Rank 0 prints ONE JSON line on stdout, the complete one; when extras follow the headline it also goes to stderr, marked
+"partial", as soon as it is measured (a run that is cut off keeps it in the log).
 """
 import argparse
 import json
@@ -260,19 +260,35 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
     env.reduce(mx, env.dist.ReduceOp.MAX)
     elapsed = float(mx[0].item())
     total_steps = float(tot[0].item())
-    ach = (steps_local * BYTES_PER_STEP) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    # The dominant kernel launch of the last timed pass, priced by SURVEY 8(d): 98 algorithmic bytes per walk step x the walk steps
+    # THAT launch took / its duration (HIP events around it on the solve's stream, wost_last_launches).  Since round 6 a full-frame
+    # solve is one persistent launch of walk_round_kernel (resident lanes take whole pixels, longest expected chain first) plus a
+    # few rounds of what it leaves; other launches run beside those rounds on streams of their own, so the solve's kernel time is
+    # the union of the spans on the solve's stream ("solve" below), not a sum over kernels.
+    ll = it.last_launches()
+    real = [l for l in ll if l["kind"] != 4 and l["ms"] > 0]
+    dom = max(real, key=lambda l: l["ms"]) if real else None
+    ach = dom["steps"] * BYTES_PER_STEP / (dom["ms"] * 1e-3) / 1e9 if dom else 0.0
+    ach_solve = (steps_local * BYTES_PER_STEP) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     out = {
         "workload": "%s uniform %dx%d grid %d spp depth %d eps %g" % (scene, frame, frame, spp, depth, eps),
         "value": total_steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "walk_steps_per_pass": total_steps / steps,
-        "roofline": {"bound": "hbm", "hbm_formula": "98 B x walk steps / kernel time (SURVEY 8d)",
-                     "what_binds": "not HBM: the walker state stays in registers inside a launch (traffic = 8 % of the algorithmic bytes); VALU pipes 99 % busy at 41 % "
-                                   "lane efficiency, and per-lane node fetches of an L1-resident tree (EXPERIMENTS 6, 18, 19)",
+        "roofline": {"bound": "hbm", "hbm_formula": "98 B x walk steps of the launch / its duration (SURVEY 8d)",
+                     "what_binds": "the HBM formula is the contract's yardstick, not what limits this kernel: the walker state stays in registers inside a launch "
+                                   "(traffic << algorithmic bytes); the VALU pipes are what is busy -- see valu_frac, valu",
                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                     "kernel": "walk_round_kernel", "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
-                     "launches_what": "the round launches on the solve's stream, HIP events around each: walk_round_kernel and, for the last rounds, its "
-                                      "four-lanes-per-walker twin walk_quad_kernel (config 2: 11 + 4 per pass); in a rocprofv3 --kernel-trace --stats summary "
-                                      "of the same command compare with (sum of both kernels' TotalDurationNs) / (sum of their Calls), the SLACK instantiation "
-                                      "<..., true> left out (it runs beside them on the side stream)",
+                     "kernel": "walk_round_kernel",
+                     "launch": ({"kind": dom["kind_name"], "walkers": dom["walkers"], "grid": dom["grid"], "ms": dom["ms"], "walk_steps": dom["steps"],
+                                 "share_of_the_pass": dom["steps"] / max(st["walk_steps"], 1)} if dom else None),
+                     "launches": launches, "avg_launch_ms": (dom["ms"] if dom else 0.0),
+                     "launches_what": "avg_launch_ms = the duration of the dominant launch (one per pass: in a rocprofv3 --kernel-trace --stats summary of the same command "
+                                      "the walk_round_kernel instantiation <.., true, false, false> -- REFILL -- has one call per pass, compare its average); "
+                                      "`launches` counts the launches on the solve's stream over the timed passes",
+                     "solve": {"achieved": ach_solve, "frac": ach_solve / HBM_PEAK_GBS, "kernel_ms_per_pass": kernel_ms / max(steps, 1),
+                               "what": "98 B x all walk steps of a pass / the union of the launch spans on the solve's stream (launches beside it included "
+                                       "through the spans they overlap and the wait at the end)"},
+                     "pass_launches": [{"kind": l["kind_name"], "walkers": l["walkers"], "beside": l["walkers_beside"], "ms": round(l["ms"], 3),
+                                        "walk_steps": l.get("steps")} for l in ll],
                      "algorithmic_bytes_per_walk_step": BYTES_PER_STEP},
     }
     if env.world > 1:
@@ -290,8 +306,9 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
                                                  "what": "one %s of the %d-byte field (waits for the slowest rank)" % (
                                                      "all-gather of disjoint shards" if field.numel() * 4 >= env.D.GATHER_THRESHOLD_BYTES
                                                      else "all-reduce of zero-padded frames", field.numel() * 4)}}
-    # wost_create: the trees of both meshes (2-D: host builder csrc/lbvh_build.cpp, a top-down sweep; 3-D meshes are built by
-    # kernels, configs.mesh_build3), uploads, the frame's buffers -- outside the solve timer like the reference's build_bvh
+    # wost_create: the trees of both meshes (built by kernels in both dimensions: csrc/wost_build2.hip since round 5, wost_build3.hip;
+    # configs.mesh_build2 / mesh_build3 time them against the host builders kept as their checkers), uploads, the frame's buffers
+    # -- outside the solve timer like the reference's build_bvh
     out["create_ms"] = create_ms
     if t1:
         out["time_to_1spp_ms"] = {"cold": t1[0], "steady": sorted(t1[1:])[len(t1[1:]) // 2]}
@@ -703,6 +720,14 @@ def main():
             roof["traffic_unit"] = "HBM bytes per launch (profiles/walk_round_traffic.json)"
             roof["traffic_stale"] = tr["stale"] if tr else None
             roof["valu"] = valu_block() if args.config == 2 else None
+            v = roof["valu"]
+            if v and v.get("lane_instr_per_step") and roof.get("launch"):
+                # the VALU roofline of the same launch: 1024 SIMDs x 16 lanes x 2.4 GHz lane-instructions per second / the lane
+                # instructions a walk step takes (counters of the committed PMC passes) = the walk steps per second the chip could
+                # make if every lane of every VALU instruction were useful
+                peak_steps = 1024 * 16 * 2.4e9 / v["lane_instr_per_step"]
+                roof["valu_frac"] = (roof["launch"]["walk_steps"] / (roof["launch"]["ms"] * 1e-3)) / peak_steps
+                roof["valu_peak_walk_steps_per_s"] = peak_steps
             # achieved / peak / frac are the SURVEY 8(d) HBM formula (rounds remain comparable); "what_binds" and "valu" say what the counters
             # say binds the kernel instead
             line["roofline"] = roof
@@ -741,7 +766,8 @@ def main():
     extras = {}
     want_extras = not args.no_extras and args.config == 2 and not (args.scene or args.frame or args.spp)
     if env.rank == 0 and want_extras:
-        print(json.dumps(dict(line, partial="headline only; the complete line follows")), flush=True)
+        # (on stderr: stdout carries exactly one JSON line, the complete one)
+        print(json.dumps(dict(line, partial="headline only; the complete line follows on stdout")), file=sys.stderr, flush=True)
     wall, skipped = {}, []
 
     if want_extras:

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libwost_hip.so")
 HOST_EXE = os.path.join(LIB_DIR, "elaina-exec")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 
-SOURCES = ["wost_hip.hip", "wost_hip3d.hip", "wost_build2.hip", "wost_build3.hip", "wost_vmm3.hip", "wost_guided3.hip", "wost_vmm.hip", "wost_net.hip", "wost_guided.hip", "lbvh_build.cpp"]
+SOURCES = ["wost_hip.hip", "wost_order.hip", "wost_hip3d.hip", "wost_build2.hip", "wost_build3.hip", "wost_vmm3.hip", "wost_guided3.hip", "wost_vmm.hip", "wost_net.hip", "wost_guided.hip", "lbvh_build.cpp"]
 
 # -ffp-contract=off is part of the arithmetic contract (DESIGN.md "deterministic math")
 HIPCC_FLAGS = [

@@ -150,6 +150,19 @@ class GuidedStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class LaunchInfo(C.Structure):
+    """wost_launch_info (include/wost.h)"""
+    _fields_ = [("kind", C.c_int32), ("walkers", C.c_uint32), ("walkers_beside", C.c_uint32), ("grid", C.c_uint32),
+                ("ms", C.c_double), ("walk_steps_done", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+LAUNCH_ROUND, LAUNCH_QUAD, LAUNCH_ONE, LAUNCH_PERSISTENT, LAUNCH_WAIT = 0, 1, 2, 3, 4
+LAUNCH_NAMES = {0: "round", 1: "quad round", 2: "one launch", 3: "persistent", 4: "wait"}
+
+
 # wost_sync_fn (include/wost.h): int (*)(void *user, int op, void *data, uint64_t count)
 SYNC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64)
 SYNC_SUM_I64_DEVICE, SYNC_MIN_I64_HOST, SYNC_RANKS_I64_HOST = 0, 1, 2
@@ -159,7 +172,7 @@ FRAME_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_double, C.PO
 
 EXPORTS = [
     "wost_create", "wost_solve", "wost_solve_sharded", "wost_render_sdf", "wost_render_source", "wost_closest_point",
-    "wost_closest_silhouette", "wost_ray_intersect", "wost_set_option", "wost_destroy",
+    "wost_closest_silhouette", "wost_ray_intersect", "wost_set_option", "wost_last_launches", "wost_destroy",
     "wost_vonmises_eval", "wost_vonmises_sample", "wost_vmm_pdf_sample", "wost_vmm_loss_gradients",
     "wost_net_create", "wost_net_destroy", "wost_net_n_params", "wost_net_get_params",
     "wost_net_set_params", "wost_net_set_gradient_buffer", "wost_net_inference", "wost_net_train_step", "wost_net_set_option",
@@ -206,6 +219,7 @@ def load():
     L.wost_closest_silhouette.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_int32, fp]
     L.wost_ray_intersect.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, C.c_int32, ip, fp, ip]
     L.wost_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    L.wost_last_launches.argtypes = [C.c_void_p, C.POINTER(LaunchInfo), C.c_int32, C.POINTER(C.c_int32)]
     u64p = C.POINTER(C.c_uint64)
     L.wost_vonmises_eval.argtypes = [C.c_int, fp, fp, C.c_int32, fp, fp, fp, fp]
     L.wost_vonmises_sample.argtypes = [C.c_int, fp, u64p, C.c_int32, C.c_int32, fp]

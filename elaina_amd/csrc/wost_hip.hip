@@ -30,6 +30,7 @@
 #include "../../include/wost.h"
 #include "lbvh.h"
 #include "wost_build2.h"
+#include "wost_order.h"
 #include "wost_device.h"
 #include "wost_internal.h"
 #include "wost_walk.h"
@@ -53,9 +54,11 @@ struct WalkQueue {
     float *sr, *sg, *sb;  // running solution of the pixel
     float *d0_d2;      // cached closest-point result of the evaluation point (depth 0 of
     int32_t *d0_slot;  //   every sample starts at the same point)
+    float *est;        // written when a persistent launch hands a pixel over mid-way: walk steps the pixel is expected to need still
+                       //   (not part of a walker's state: no kernel loads it back; the host orders the next launch by it)
 };
 
-static const int kQueueWords = 16 + 1;  // rng counts twice
+static const int kQueueWords = 17 + 1;  // rng counts twice
 
 // Atomics on one cache line are served one by one by its L2 channel (about 10 ns each: the eight
 // counters of the 16 384 waves of a round cost over a millisecond), so the counters exist in
@@ -85,6 +88,15 @@ struct RoundParams {
     int32_t trav_burst;    // node visits per scheduling decision in the traversal phase
     int32_t lane_shift;    // one walker per 2^lane_shift lanes (0 = every lane)
     uint32_t *cursor;      // REFILL launches: next unread slot of the input queue
+    const uint32_t *order; // the k-th walker of the launch is input slot order[k] (wost_order.h); nullptr = slot k
+    int32_t reserve;       // REFILL launches: input slots a wave reserves per atomic on the cursor; 0 = exactly those it needs
+    int32_t leave_dry;     // REFILL launches: 1 = a wave that finds the input queue dry finishes the steps in flight and hands its
+                           //   walkers to the output queue (the host repacks them: rounds); 0 = it stays until its last pixel is done
+    uint32_t *count_long;  // ... and counts the pixels it hands over that are expected to need long_steps walk steps or more
+    float long_steps;
+    // walk_quad_kernel, the launch of the long remainders: the first thin_count walkers sit four to a wave (sixteen to a workgroup)
+    // in the first thin_blocks workgroups, the others sixteen to a wave behind them; thin_blocks == 0: lane_shift for all
+    uint32_t thin_blocks, thin_count;
     // walkers that the plain kernel cannot serve exactly (a closest-point query that starts beyond dm.far2) leave the launch
     // at that point and are queued from the TOP of the output queue downwards: slot out_capacity - 1 - k, k from *count_far
     uint32_t *count_far;
@@ -379,6 +391,17 @@ __device__ __forceinline__ void store_lane(const WalkQueue &q, uint32_t s, const
     q.d0_d2[s] = L.d0_d2; q.d0_slot[s] = L.d0_slot;
 }
 
+// walkers order[0 .. n) of `in` (0 .. n without an order) copied to slots 0 .. n of `out`
+__global__ __launch_bounds__(256) void gather_walkers_kernel(WalkQueue in, const uint32_t *order, uint32_t n, WalkQueue out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Lane L;
+    uint32_t pix;
+    load_lane(in, order ? order[i] : i, L, pix);
+    store_lane(out, i, L, pix);
+}
+
 // REFILL = false: one thread per queue slot, the round ends after steps_per_round steps and the
 // survivors are compacted (the throughput path: with many samples per pixel a slot keeps itself
 // busy by regenerating).  REFILL = true: a fixed number of resident threads; a lane whose pixel
@@ -409,7 +432,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
     uint32_t pix = 0;
     bool alive = false;
     if (valid) {
-        load_lane(P.in, slot, L, pix);
+        load_lane(P.in, P.order ? P.order[slot] : slot, L, pix);
         alive = L.sample < (uint32_t)P.st.spp;
     }
     bool open = valid;            // this lane holds a pixel whose result has not been written
@@ -445,21 +468,28 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
             if (need) {
                 // slots come from a wave-private reservation of 64 (one atomic on the shared cursor
                 // per 64 pixels, not per refill: same-address atomics serialise in L2)
+                // (many samples per pixel: a refill is rare -- config 2: one per wave and 30 walk steps -- and unread slots
+                // parked in 6 000 private reservations would be a fifth of the frame when the cursor runs dry: reserve = 0 takes
+                // exactly the slots needed)
                 const int lane_ = threadIdx.x & 63;
                 const uint32_t needed = (uint32_t)__popcll(need), avail = pool_end - pool_next;
                 uint32_t fresh_base = 0;
+                const uint32_t want = P.reserve > 0 ? (uint32_t)P.reserve : needed - min(needed, avail);
                 if (needed > avail) {
-                    if (lane_ == 0) fresh_base = atomicAdd(P.cursor, 64u);
+                    if (lane_ == 0) fresh_base = atomicAdd(P.cursor, want);
                     fresh_base = __shfl(fresh_base, 0);
                 }
                 const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane_) - 1ull));
                 const uint32_t s2 = rank < avail ? pool_next + rank : fresh_base + (rank - avail);
                 if (needed > avail) {
                     pool_next = fresh_base + (needed - avail);
-                    pool_end = fresh_base + 64u;
+                    pool_end = fresh_base + want;
                 } else {
                     pool_next += needed;
                 }
+                // the queue is dry: with leave_dry the wave stops here -- no new step starts (budget 0), queries in flight finish
+                // their step, pixels still open go to the output queue at the end of the kernel like the survivors of a round
+                if (P.leave_dry && __ballot(mode == MODE_REFILL && s2 >= n_in)) budget = 0;
                 if (mode == MODE_REFILL) {
                     if (open) {       // (a walker that left for the slack launch is not resolved here: `open` is false)
                         float *f = P.field + 3 * (size_t)((int32_t)pix - P.field_base);
@@ -471,7 +501,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
                     wide[4] += S.c; wide[5] += S.visits;
                     S = LaneStats{0, 0, 0, 0};
                     if (s2 < n_in) {
-                        load_lane(P.in, s2, L, pix);
+                        load_lane(P.in, P.order ? P.order[s2] : s2, L, pix);
                         open = true;
                         alive = L.sample < (uint32_t)P.st.spp;
                         fresh = true;
@@ -604,6 +634,17 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
         if (far) s = P.out_capacity - 1u - k;
     }
     if (alive && open) store_lane(P.out, s, L, pix);
+    if (REFILL && P.leave_dry) {
+        // a persistent launch hands its open pixels to the rounds: how many walk steps a pixel still needs is known well by now --
+        // its samples so far took S.a steps (the lane's counters restart with every pixel it takes), the rest will take about as
+        // many each.  The host starts the longest remainders at once, four lanes to a walker, beside the rounds of the others.
+        const float done = (float)L.sample, left = (float)((uint32_t)P.st.spp - L.sample);
+        const float est = left * ((float)max(S.a & 0xffffu, 4u) / fmaxf(done, 1.0f));
+        const bool is_long = alive && open && !far && est >= P.long_steps;
+        if (alive && open && !far) P.out.est[s] = est;
+        const unsigned long long lb = __ballot(is_long);
+        if (lane == 0 && lb) atomicAdd(P.count_long, (uint32_t)__popcll(lb));
+    }
     // ---- statistics: wave reduction, one atomic per counter per wave -----------------------
     uint32_t v[7] = {(S.a & 0xffffu) + wide[0], (S.a >> 16) + wide[1], (S.b & 0xffffu) + wide[2], (S.b >> 16) + wide[3],
                      S.c + wide[4], S.visits + wide[5], 0u};
@@ -662,15 +703,25 @@ __global__ __launch_bounds__(256, 4) void walk_quad_kernel(RoundParams P)
     // lane_shift > 0 (the very last rounds): only every 2^shift-th quad holds a walker, down to one walker per wave -- such a
     // wave never waits for another walker's query
     const uint32_t quad_id = tid >> 2;
-    const uint32_t slot = quad_id >> P.lane_shift;
     const uint32_t n_in = *P.count_in;
-    const bool valid = slot < n_in && (quad_id & ((1u << P.lane_shift) - 1u)) == 0u;
+    uint32_t slot = quad_id >> P.lane_shift;
+    bool valid = slot < n_in && (quad_id & ((1u << P.lane_shift) - 1u)) == 0u;
+    if (P.thin_blocks > 0u) {
+        const uint32_t quads_per_block = blockDim.x >> 2;
+        if (blockIdx.x < P.thin_blocks) {
+            slot = quad_id >> 2;
+            valid = slot < P.thin_count && (quad_id & 3u) == 0u;
+        } else {
+            slot = P.thin_count + (quad_id - P.thin_blocks * quads_per_block);
+            valid = slot < n_in;
+        }
+    }
     Lane L;
     LaneStats S{0, 0, 0, 0};
     uint32_t pix = 0;
     bool alive = false;
     if (valid) {
-        load_lane(P.in, slot, L, pix);
+        load_lane(P.in, P.order ? P.order[slot] : slot, L, pix);
         alive = L.sample < (uint32_t)P.st.spp;
     }
     const bool open = valid;
@@ -1104,6 +1155,27 @@ struct wost_context {
     int trav_burst = 3;
     int time_kernels = 1;
     int refill = -1;       // -1 = automatic (few samples per pixel), 0 = never, 1 = always
+    int persist = -1;      // many samples per pixel, more walkers than resident lanes: the first launch is persistent (lanes take pixels,
+                           //   longest expected chain first, until none is left; the rest of the solve runs in rounds): -1 = automatic, 0, 1
+    int persist_order = 1; // ... in the order of wost_order.h (0: queue order; comparison runs)
+    int few_order = 1;     // the one-launch path of few samples per pixel in that order too (config 2's frame at 1 / 2 / 4 spp: 2.64 -> 2.48, 4.09 -> 3.55, 6.79 -> 5.68 ms)
+    int resident_blocks = 0;  // blocks of a one-launch / persistent launch; 0 = as many as the chip holds (tests: a few blocks drain a small frame)
+    // what a persistent launch hands over (run_solve): the pixels expected to need `long_steps` walk steps or more run to their end at
+    // once, four lanes to a walker, on a stream of higher priority beside the rounds of the others (0 = none do); the first round
+    // takes the others in the order of their expected remainders (tail_sort), so that a wave's walkers finish together
+    int long_steps = 1024;
+    int long_cap = 32768;
+    int tail_sort = 1;
+    void *long_mem = nullptr;
+    WalkQueue long_queue{};
+    int long_thin = 2048;         // ... the first long_thin of them four to a wave, the others sixteen
+    // Their stream has the highest priority: they are the critical path of the solve's end, and the runtime keeps the hardware
+    // queues of a priority level apart from those of the others -- a stream of ordinary priority can land on the hardware queue
+    // of the caller's stream (four queues per level), and then the launch meant to run BESIDE the rounds runs behind them (seen
+    // in bench.py, which makes a second handle first: the solve waited 27 ms for it).
+    hipStream_t long_stream = nullptr;
+    hipEvent_t long_ev0 = nullptr, long_ev1 = nullptr;
+    WalkOrder order;
     int quad = -1;         // four lanes per walker in under-filled launches: -1 = automatic, 0 = never, 1 = every ordinary round
     double quad_fill = 1.0;   // automatic: when 4 x walkers <= quad_fill x resident lanes
     int coop = 1;             // a Neumann mesh on the tree: its silhouette and ray queries by the wave as a whole (wost_coop.h); 0 = per lane
@@ -1113,6 +1185,8 @@ struct wost_context {
     hipStream_t far_stream = nullptr;          // the launches that take strayed walkers through the SLACK kernel (run_solve)
     hipEvent_t far_ev0 = nullptr, far_ev1 = nullptr;
     int n_cus = 256;
+    StatsDev *host_stats = nullptr;            // pinned: the counters as they stood after each launch (last_launches)
+    std::vector<wost_launch_info> last_launches;
 };
 
 namespace wost {
@@ -1138,6 +1212,7 @@ static void carve_queue(void *mem, size_t n, WalkQueue &q)
     q.sr = (float *)take(n * 4); q.sg = (float *)take(n * 4); q.sb = (float *)take(n * 4);
     q.d0_d2 = (float *)take(n * 4);
     q.d0_slot = (int32_t *)take(n * 4);
+    q.est = (float *)take(n * 4);
 }
 
 static void destroy_ctx(wost_context *c)
@@ -1154,10 +1229,16 @@ static void destroy_ctx(wost_context *c)
     if (c->stats) (void)hipFree(c->stats);
     if (c->field) (void)hipFree(c->field);
     if (c->cursor) (void)hipFree(c->cursor);
+    order_free(c->order);
+    if (c->long_mem) (void)hipFree(c->long_mem);
+    if (c->long_stream) (void)hipStreamDestroy(c->long_stream);
+    if (c->long_ev0) (void)hipEventDestroy(c->long_ev0);
+    if (c->long_ev1) (void)hipEventDestroy(c->long_ev1);
     if (c->far_stream) (void)hipStreamDestroy(c->far_stream);
     if (c->far_ev0) (void)hipEventDestroy(c->far_ev0);
     if (c->far_ev1) (void)hipEventDestroy(c->far_ev1);
     if (c->host_count) (void)hipHostFree(c->host_count);
+    if (c->host_stats) (void)hipHostFree(c->host_stats);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1315,16 +1396,24 @@ int wost_create(const wost_scene_desc *scene, const wost_settings *settings, int
         HIP_TRY_C(hipMalloc(&c->queue_mem[i], qbytes));
         carve_queue(c->queue_mem[i], c->n_pixels, c->queue[i]);
     }
-    HIP_TRY_C(hipMalloc((void **)&c->counts, 4 * sizeof(uint32_t)));   // two queue counts, the far count
+    HIP_TRY_C(hipMalloc((void **)&c->counts, 12 * sizeof(uint32_t)));   // two queue counts, the far count and its input copy; [4..7]: the hand-over of a persistent launch
     HIP_TRY_C(hipMalloc((void **)&c->stats, kStatCopies * sizeof(StatsDev)));
     HIP_TRY_C(hipMalloc((void **)&c->cursor, sizeof(uint32_t)));
     HIP_TRY_C(hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device));
     HIP_TRY_C(hipMalloc((void **)&c->field, c->n_pixels * 3 * sizeof(float)));
-    HIP_TRY_C(hipHostMalloc((void **)&c->host_count, 4 * sizeof(uint32_t)));
+    HIP_TRY_C(hipHostMalloc((void **)&c->host_count, 8 * sizeof(uint32_t)));
+    HIP_TRY_C(hipHostMalloc((void **)&c->host_stats, kStatCopies * sizeof(StatsDev)));
     HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY_C(hipStreamCreateWithFlags(&c->far_stream, hipStreamNonBlocking));
     HIP_TRY_C(hipEventCreateWithFlags(&c->far_ev0, hipEventDisableTiming));
     HIP_TRY_C(hipEventCreateWithFlags(&c->far_ev1, hipEventDisableTiming));
+    {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        HIP_TRY_C(hipStreamCreateWithPriority(&c->long_stream, hipStreamNonBlocking, greatest));
+    }
+    HIP_TRY_C(hipEventCreateWithFlags(&c->long_ev0, hipEventDisableTiming));
+    HIP_TRY_C(hipEventCreateWithFlags(&c->long_ev1, hipEventDisableTiming));
     HIP_TRY_C(hipEventCreate(&c->ev0));
     HIP_TRY_C(hipEventCreate(&c->ev1));
 #undef HIP_TRY_C
@@ -1363,6 +1452,29 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "refill") {
         if (value != -1 && value != 0 && value != 1) return fail(WOST_ERR_INVALID, "refill must be -1 (auto), 0 or 1");
         h->refill = (int)value;
+    } else if (k == "persist") {
+        if (value != -1 && value != 0 && value != 1) return fail(WOST_ERR_INVALID, "persist must be -1 (auto), 0 or 1");
+        h->persist = (int)value;
+    } else if (k == "persist_order") {
+        h->persist_order = value != 0;
+    } else if (k == "few_order") {
+        h->few_order = value != 0;
+    } else if (k == "long_steps") {
+        if (value < 0 || value > 65528 || ((int)value & 7)) return fail(WOST_ERR_INVALID, "long_steps must be a multiple of 8 in 0..65528 (0 = no pixel runs beside the rounds)");
+        h->long_steps = (int)value;
+    } else if (k == "long_cap") {
+        if (value < 1 || value > (1 << 20)) return fail(WOST_ERR_INVALID, "long_cap must be in 1..2^20");
+        h->long_cap = (int)value;
+        if (h->long_mem) (void)hipFree(h->long_mem);
+        h->long_mem = nullptr;
+    } else if (k == "long_thin") {
+        if (value < 0 || value > (1 << 20)) return fail(WOST_ERR_INVALID, "long_thin must be in 0..2^20");
+        h->long_thin = (int)value;
+    } else if (k == "tail_sort") {
+        h->tail_sort = value != 0;
+    } else if (k == "resident_blocks") {
+        if (value < 0 || value > 65535) return fail(WOST_ERR_INVALID, "resident_blocks must be in 0..65535 (0 = what the chip holds)");
+        h->resident_blocks = (int)value;
     } else if (k == "quad") {
         if (value != -1 && value != 0 && value != 1) return fail(WOST_ERR_INVALID, "quad must be -1 (auto), 0 or 1");
         h->quad = (int)value;
@@ -1421,11 +1533,12 @@ static void launch_round(bool has_src, bool refill, bool ntree, bool emissive, u
 }
 
 // the quad instantiation (four lanes per walker) for an ordinary launch
+template <bool SLACK = false>
 static void launch_quad(bool has_src, bool ntree, bool emissive, unsigned grid, int bs, size_t lds, hipStream_t stream, const RoundParams &rp)
 {
 #define WOST_QUAD_CASE(E, T, S)                                                                                                  \
     if (emissive == E && ntree == T && has_src == S) {                                                                           \
-        hipLaunchKernelGGL((walk_quad_kernel<E, T, S, false>), dim3(grid), dim3(bs), lds, stream, rp);                          \
+        hipLaunchKernelGGL((walk_quad_kernel<E, T, S, SLACK>), dim3(grid), dim3(bs), lds, stream, rp);                          \
         return;                                                                                                                  \
     }
     WOST_QUAD_CASE(false, false, false) WOST_QUAD_CASE(true, false, false) WOST_QUAD_CASE(false, true, false) WOST_QUAD_CASE(true, true, false)
@@ -1437,7 +1550,7 @@ static WalkQueue queue_from(const WalkQueue &q, size_t k)
 {
     WalkQueue r = q;
     r.pix += k; r.x0 += k; r.y0 += k; r.px += k; r.py += k; r.rng += k; r.meta += k; r.nx += k; r.ny += k; r.hint += k; r.thp += k;
-    r.sr += k; r.sg += k; r.sb += k; r.d0_d2 += k; r.d0_slot += k;
+    r.sr += k; r.sg += k; r.sb += k; r.d0_d2 += k; r.d0_slot += k; r.est += k;
     return r;
 }
 
@@ -1455,7 +1568,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     // and pop 1 per inner level: 3L+1 entries
     const int stack_depth = 3 * levels_any + 1;
     const size_t lds = (size_t)stack_depth * bs * sizeof(uint32_t);
-    HIP_TRY(hipMemsetAsync(c->counts, 0, 4 * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(c->counts, 0, 12 * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(c->stats, 0, kStatCopies * sizeof(StatsDev), stream));
 
     const int tiles_x = (c->settings.width + 7) / 8, tiles_y = (c->settings.height + 7) / 8;
@@ -1486,14 +1599,19 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
     double kernel_ms = 0.0;
     uint32_t launches = 0;
     int cur = 0;
+    c->last_launches.clear();
     const bool emissive = c->nm.view.n_segs > 0 && c->nm.view.emissive;
     const bool ntree = c->nm.view.n_segs > WOST_FLAT_MAX;
     uint32_t pending_far = 0;     // walkers at the far end of queue[cur] that the previous launch could not serve (see below)
+    bool handed_over = false;     // the previous launch was persistent: queue[cur] holds what it handed over, with estimates
+    bool long_pending = false;    // the launch of the long remainders is under way on long_stream
     while (n_active > 0 || pending_far > 0) {
         const int nxt = cur ^ 1;
         HIP_TRY(hipMemsetAsync(c->counts + nxt, 0, sizeof(uint32_t), stream));
         HIP_TRY(hipMemsetAsync(c->counts + 2, 0, sizeof(uint32_t), stream));
         RoundParams rp{};
+        rp.count_long = c->counts + 4;
+        rp.long_steps = c->long_steps > 0 ? (float)c->long_steps : WOST_INF;
         rp.dm = c->dm.view;
         rp.nm = c->nm.view;
         rp.st = c->dst;
@@ -1532,24 +1650,100 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         }
         // developer experiment: extra LDS per block lowers the number of resident blocks (occupancy sensitivity)
         const size_t lds_round = lds + lds_pools + (getenv("WOST_EXP_LDS_PAD") ? (size_t)atoi(getenv("WOST_EXP_LDS_PAD")) : 0);
+        const bool has_src = c->src.rgb != nullptr;
+        // blocks a CU holds: the register bound of the instantiation (launch bounds: 6 waves per SIMD, 4 with the tree queries), and
+        // no more than fit its 160 KB of LDS -- with the wave task pools a block asks for about 64 KB (two per CU, not four)
+        const unsigned blocks_by_regs = (unsigned)((ntree ? 4 : 6) * 4 * 64 / bs);
+        const unsigned blocks_by_lds = (unsigned)std::max<size_t>(1, (size_t)160 * 1024 / std::max<size_t>(lds_round, 1));
+        const unsigned blocks_per_cu = std::max(1u, std::min(blocks_by_regs, blocks_by_lds));
+        const unsigned resident_threads = (unsigned)c->n_cus * blocks_per_cu * (unsigned)bs;
+        if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
+        // What a persistent launch handed over: one partly solved pixel per lane, each with an estimate of the walk steps it still
+        // needs (config 2: 387 000 pixels, 12 % of the solve's steps; half of them need 650 steps more, a few thousand over 1 500),
+        // and the walkers that strayed beyond the plain visits' range during that launch, parked since with most of their samples
+        // ahead of them.  In rounds the few long ones add launch after launch of a nearly empty chip (16 of the 52 ms that followed
+        // the persistent launch), so they start NOW and run to their end -- four lanes to a walker, exact at any distance (SLACK: no
+        // walker leaves such a launch), the longest a thousand or two four to a wave, the others sixteen -- on streams of their own
+        // beside the rounds of the rest; and the first round takes the rest sorted by estimate: the walkers of a wave finish
+        // together and the wave leaves, instead of a third of the lanes of every wave idling behind finished pixels.
+        uint32_t n_round = n_active;        // walkers of this iteration's ordinary launch
+        uint32_t beside_far = 0;            // strayed walkers that joined the long remainders
+        if (handed_over && (n_active > 0 || pending_far > 0)) {
+            const bool beside = c->long_steps > 0;
+            const uint32_t n_far = (beside && pending_far <= 1024u && pending_far <= (uint32_t)c->long_cap) ? pending_far : 0u;
+            const uint32_t n_long = beside ? std::min<uint32_t>(std::min<uint32_t>(c->host_count[4], (uint32_t)c->long_cap - n_far), n_active) : 0u;
+            const uint32_t *ord = nullptr;
+            if (n_active > 0 && (n_long > 0 || c->tail_sort)) {
+                if (c->order.cap < c->n_pixels) HIP_TRY((hipError_t)order_alloc(c->order, c->n_pixels));
+                HIP_TRY((hipError_t)order_by_estimate(c->order, c->queue[cur].est, n_active, stream, &ord));
+                rp.order = ord + n_long;
+            }
+            const uint32_t n_beside = n_far + n_long;
+            if (n_beside > 0) {
+                if (!c->long_mem) {
+                    HIP_TRY(hipMalloc(&c->long_mem, (size_t)c->long_cap * 4 * kQueueWords));
+                    carve_queue(c->long_mem, (size_t)c->long_cap, c->long_queue);
+                }
+                // the strayed first (most of a pixel ahead of them as a rule), then the long remainders, longest first
+                if (n_far > 0) {
+                    hipLaunchKernelGGL(gather_walkers_kernel, dim3((n_far + 255) / 256), dim3(256), 0, stream, queue_from(c->queue[cur], c->n_pixels - n_far),
+                                       (const uint32_t *)nullptr, n_far, c->long_queue);
+                    HIP_TRY(hipGetLastError());
+                    pending_far = 0;
+                    beside_far = n_far;
+                }
+                if (n_long > 0) {
+                    hipLaunchKernelGGL(gather_walkers_kernel, dim3((n_long + 255) / 256), dim3(256), 0, stream, c->queue[cur], ord, n_long, queue_from(c->long_queue, n_far));
+                    HIP_TRY(hipGetLastError());
+                }
+                const uint32_t n_thin = std::min<uint32_t>(n_beside, (uint32_t)std::max(c->long_thin, 0));
+                c->host_count[5] = n_beside;
+                c->host_count[6] = n_active - n_long;
+                HIP_TRY(hipMemcpyAsync(c->counts + 5, c->host_count + 5, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipEventRecord(c->long_ev0, stream));
+                HIP_TRY(hipStreamWaitEvent(c->long_stream, c->long_ev0, 0));
+                RoundParams lp = rp;
+                lp.in = c->long_queue;
+                lp.order = nullptr;
+                lp.count_in = c->counts + 5;
+                lp.count_out = c->counts + 8;       // (nothing comes out: every walker runs to the end of its pixel)
+                lp.count_far = c->counts + 8;
+                lp.steps_per_round = 0x7fffffff;
+                lp.stack_stride = stack_depth;
+                lp.lane_shift = 0;
+                const uint32_t quads_per_block = (uint32_t)bs / 4u;
+                lp.thin_count = n_thin;
+                lp.thin_blocks = (n_thin * 4u + quads_per_block - 1u) / quads_per_block;
+                const unsigned lgrid = lp.thin_blocks + (n_beside - n_thin + quads_per_block - 1u) / quads_per_block;
+                if (lp.thin_blocks == 0u) lp.thin_count = 0u;
+                launch_quad<true>(has_src, ntree, emissive, lgrid, bs, (size_t)stack_depth * (bs / 4) * sizeof(uint32_t), c->long_stream, lp);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(c->long_ev1, c->long_stream));
+                long_pending = true;
+                rp.count_in = c->counts + 6;
+                n_round = n_active - n_long;
+            }
+        }
         // Walkers that left the previous launch at a query beyond the plain kernel's range wait at the far end of its output queue,
         // which is this launch's input queue.  The SLACK instantiation takes them through max_depth steps -- the walk that strayed
         // ends within that many -- on a stream of its own, next to this launch, and appends them to the same output queue (both
         // kernels only read the input queue and claim output slots from one counter).
-        if (pending_far > 0) {
-            c->host_count[3] = pending_far;
+        const uint32_t far_now = pending_far;
+        if (far_now > 0) {
+            c->host_count[3] = far_now;
             HIP_TRY(hipMemcpyAsync(c->counts + 3, c->host_count + 3, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             HIP_TRY(hipEventRecord(c->far_ev0, stream));                      // the counters are ready
             HIP_TRY(hipStreamWaitEvent(c->far_stream, c->far_ev0, 0));
             RoundParams fp = rp;
-            fp.in = queue_from(c->queue[cur], c->n_pixels - pending_far);
+            fp.order = nullptr;
+            fp.in = queue_from(c->queue[cur], c->n_pixels - far_now);
             fp.count_in = c->counts + 3;
             fp.steps_per_round = std::max(1, c->settings.max_depth);
             // a few strayed walkers (leaks of a closed scene): one per wave -- a query from very far away is a scan of the whole
             // mesh by the 64 lanes (closest_point_wave), and the launch lasts as long as its slowest wave; many (an open scene:
             // every walk that misses the boundary strays): every lane loaded
-            fp.lane_shift = pending_far <= 4096u ? 6 : 0;
-            launch_round<true>(c->src.rgb != nullptr, false, ntree, emissive, (unsigned)((((uint64_t)pending_far << fp.lane_shift) + bs - 1) / bs), bs, lds_round, c->far_stream, fp);
+            fp.lane_shift = far_now <= 4096u ? 6 : 0;
+            launch_round<true>(has_src, false, ntree, emissive, (unsigned)((((uint64_t)far_now << fp.lane_shift) + bs - 1) / bs), bs, lds_round, c->far_stream, fp);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->far_ev1, c->far_stream));
             // (not counted in `launches`: kernel_ms / kernel_launches stays the average duration of the ordinary launches)
@@ -1558,26 +1752,28 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         // duration of such a launch is the latency of its slowest wave, and a wave is as slow as the
         // longest query among its walkers (config 2's last three launches: 13.1 -> 8.9 ms; with 2 or
         // 4 lanes per walker the extra waves cost more than they save: 9.2 -> 11.8 ms).
-        // blocks a CU holds: the register bound of the instantiation (launch bounds: 6 waves per SIMD, 4 with the tree queries), and
-        // no more than fit its 160 KB of LDS -- with the wave task pools a block asks for about 64 KB (two per CU, not four)
-        const unsigned blocks_by_regs = (unsigned)((ntree ? 4 : 6) * 4 * 64 / bs);
-        const unsigned blocks_by_lds = (unsigned)std::max<size_t>(1, (size_t)160 * 1024 / std::max<size_t>(lds_round, 1));
-        const unsigned blocks_per_cu = std::max(1u, std::min(blocks_by_regs, blocks_by_lds));
-        const unsigned resident_threads = (unsigned)c->n_cus * blocks_per_cu * (unsigned)bs;
         rp.lane_shift = 0;
         if (c->thin_waves) {
-            while (rp.lane_shift < 6 && ((uint64_t)n_active << (rp.lane_shift + 1)) <= resident_threads) ++rp.lane_shift;
+            while (rp.lane_shift < 6 && ((uint64_t)n_round << (rp.lane_shift + 1)) <= resident_threads) ++rp.lane_shift;
             if (rp.lane_shift < 4) rp.lane_shift = 0;
         }
-        unsigned grid = (unsigned)((((uint64_t)n_active << rp.lane_shift) + bs - 1) / bs);
+        unsigned grid = (unsigned)((((uint64_t)n_round << rp.lane_shift) + bs - 1) / bs);
         // REFILL launch: as many resident threads as the chip holds, each draining the input queue.
         // Worth it when regeneration cannot keep the lanes busy (measured on config 2's frame:
         // 1 spp 3.5 -> 3.0 ms, 4 spp 8.3 -> 7.9 ms, 8 spp 13.0 -> 13.5 ms) and the queue is larger
         // than one residency; the 16-bit lane counters bound spp * max_depth.
-        const unsigned resident = (unsigned)c->n_cus * blocks_per_cu;
-        const bool has_src = c->src.rgb != nullptr;
+        const unsigned resident = c->resident_blocks > 0 ? std::min((unsigned)c->resident_blocks, (unsigned)c->n_cus * blocks_per_cu) : (unsigned)c->n_cus * blocks_per_cu;
         const bool can_refill = (int64_t)c->settings.spp * c->settings.max_depth < 65535 && launches == 0 && !has_src;
-        const bool refill = can_refill && (c->refill == 1 || (c->refill == -1 && c->settings.spp <= 4 && grid > resident));
+        const bool few = can_refill && (c->refill == 1 || (c->refill == -1 && c->settings.spp <= 4 && grid > resident));
+        // PERSISTENT first launch (many samples per pixel, more walkers than resident lanes): the same resident threads, but the
+        // lanes take whole pixels -- all of a pixel's samples, the pixels in the order of wost_order.h, longest expected chain first
+        // -- until the input queue is dry; then every wave hands what it holds to the output queue and the rest of the solve runs
+        // in rounds.  No lane idles behind a finished pixel and no launch ends while pixels are unread (in rounds, config 2 spent
+        // 108 of its 252 ms in launches where a third of the lanes had finished their pixel, EXPERIMENTS 25); what the rounds
+        // get is the remainder of one pixel per lane.
+        const bool persist = can_refill && !few && c->refill != 1 &&
+                             (c->persist == 1 || (c->persist == -1 && c->settings.spp > 4 && n_active > resident_threads));
+        const bool refill = few || persist;
         if (refill) {
             rp.lane_shift = 0;
             grid = std::min((unsigned)((n_active + bs - 1) / bs), resident);
@@ -1585,40 +1781,76 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
             HIP_TRY(hipMemcpyAsync(c->cursor, c->host_count + 1, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             rp.cursor = c->cursor;
             rp.steps_per_round = 0x7fffffff;
+            rp.reserve = 64;
+            if (persist ? c->persist_order : c->few_order) {
+                if (c->order.cap < c->n_pixels) HIP_TRY((hipError_t)order_alloc(c->order, c->n_pixels));
+                HIP_TRY((hipError_t)order_by_distance(c->order, c->queue[cur].d0_d2, n_active, stream, &rp.order));
+            }
+            if (persist) {
+                rp.reserve = 0;
+                rp.leave_dry = 1;
+            }
         }
         // Under-filled launch: four lanes per walker (walk_quad_kernel).  Such a launch lasts as long as its longest chain of
         // dependent node visits; sharing a descent between the lanes of a quad halves that chain.
-        const bool quad = !refill && n_active > 0 &&
-                          (c->quad == 1 || (c->quad == -1 && 4.0 * (double)n_active <= c->quad_fill * (double)resident_threads));
+        const bool quad = !refill && n_round > 0 &&
+                          (c->quad == 1 || (c->quad == -1 && 4.0 * (double)n_round <= c->quad_fill * (double)resident_threads));
         // (the last strayed walkers can outlive the ordinary queue: then only their launch runs)
-        if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
         if (quad) {
             // few walkers: fewer quads per wave (16 -> 4 -> 1), as long as the waves still fit the chip
             rp.lane_shift = 0;
-            while (rp.lane_shift < 4 && ((uint64_t)n_active << (2 + rp.lane_shift + 2)) <= resident_threads) rp.lane_shift += 2;
+            while (rp.lane_shift < 4 && ((uint64_t)n_round << (2 + rp.lane_shift + 2)) <= resident_threads) rp.lane_shift += 2;
             rp.stack_stride = stack_depth;      // entries per (contiguous) quad column
-            grid = (unsigned)((((uint64_t)n_active << (2 + rp.lane_shift)) + bs - 1) / bs);
+            grid = (unsigned)((((uint64_t)n_round << (2 + rp.lane_shift)) + bs - 1) / bs);
             launch_quad(has_src, ntree, emissive, grid, bs, (size_t)stack_depth * (bs / 4) * sizeof(uint32_t), stream, rp);
             HIP_TRY(hipGetLastError());
-        } else if (n_active > 0) {
+        } else if (n_round > 0) {
             launch_round<false>(has_src, refill, ntree, emissive, grid, bs, lds_round, stream, rp);
             HIP_TRY(hipGetLastError());
         }
-        if (pending_far > 0) HIP_TRY(hipStreamWaitEvent(stream, c->far_ev1, 0));
+        if (far_now > 0) HIP_TRY(hipStreamWaitEvent(stream, c->far_ev1, 0));
         if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev1, stream));
         HIP_TRY(hipMemcpyAsync(c->host_count, c->counts + nxt, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(c->host_count + 2, c->counts + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (persist) HIP_TRY(hipMemcpyAsync(c->host_count + 4, c->counts + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (c->time_kernels) HIP_TRY(hipMemcpyAsync(c->host_stats, c->stats, kStatCopies * sizeof(StatsDev), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        handed_over = persist;
         if (c->time_kernels) {
             float ms = 0.0f;
             HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
             kernel_ms += ms;
-            if (getenv("WOST_TRACE_LAUNCHES")) fprintf(stderr, "launch %d: walkers %d (+ %u strayed) grid %u %.3f ms -> %u left, %u strayed\n", launches, n_active, pending_far, grid, ms, c->host_count[0], c->host_count[2]);
+            wost_launch_info li{};
+            li.kind = persist ? WOST_LAUNCH_PERSISTENT : (refill ? WOST_LAUNCH_ONE : (quad ? WOST_LAUNCH_QUAD : WOST_LAUNCH_ROUND));
+            li.walkers = n_round;
+            li.walkers_beside = n_active - n_round + far_now + beside_far;
+            li.grid = n_round > 0 ? grid : 0u;
+            li.ms = ms;
+            for (int k = 0; k < kStatCopies; ++k) li.walk_steps_done += c->host_stats[k].steps;
+            c->last_launches.push_back(li);
+            if (getenv("WOST_TRACE_LAUNCHES")) fprintf(stderr, "launch %d: walkers %u of %u (+ %u strayed) grid %u %.3f ms -> %u left, %u strayed%s\n", launches, n_round, n_active, far_now, grid, ms, c->host_count[0], c->host_count[2], persist ? " (persistent)" : "");
         }
-        if (n_active > 0) ++launches;
+        if (n_round > 0) ++launches;
         pending_far = c->host_count[2];
         n_active = c->host_count[0];
         cur = nxt;
+    }
+    if (long_pending) {
+        // the long remainders may outlast the rounds: what is left of their launch counts as kernel time of the solve
+        if (c->time_kernels) HIP_TRY(hipEventRecord(c->ev0, stream));
+        HIP_TRY(hipStreamWaitEvent(stream, c->long_ev1, 0));
+        if (c->time_kernels) {
+            HIP_TRY(hipEventRecord(c->ev1, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            kernel_ms += ms;
+            wost_launch_info li{};
+            li.kind = WOST_LAUNCH_WAIT;
+            li.ms = ms;
+            c->last_launches.push_back(li);
+            if (getenv("WOST_TRACE_LAUNCHES")) fprintf(stderr, "waited %.3f ms for the launch of the long remainders\n", ms);
+        }
     }
     std::vector<StatsDev> copies(kStatCopies);
     HIP_TRY(hipMemcpyAsync(copies.data(), c->stats, kStatCopies * sizeof(StatsDev), hipMemcpyDeviceToHost, stream));
@@ -1713,6 +1945,14 @@ int wost_solve_sharded(wost_handle h, int32_t shard_index, int32_t shard_count, 
     // NULL is the legacy default stream, which is also torch's default stream
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return run_solve(h, 0, (int32_t)h->n_pixels, shard_index, shard_count, field_rgb_dev, 0, s, stats);
+}
+
+int wost_last_launches(wost_handle h, wost_launch_info *out, int32_t capacity, int32_t *count)
+{
+    if (!h || !count || (capacity > 0 && !out) || capacity < 0) return fail(WOST_ERR_INVALID, "null argument");
+    *count = (int32_t)h->last_launches.size();
+    for (int32_t i = 0; i < std::min(*count, capacity); ++i) out[i] = h->last_launches[(size_t)i];
+    return WOST_OK;
 }
 
 int wost_render_sdf(wost_handle h, int which_mesh, float *out_dist)

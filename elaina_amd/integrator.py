@@ -157,6 +157,23 @@ class UniformIntegrator:
     def set_option(self, key, value):
         _check(self.lib.wost_set_option(self._handle, key.encode(), float(value)), "wost_set_option")
 
+    def last_launches(self):
+        """the launches of the last solve, in order (wost_last_launches): dicts of kind / walkers / walkers_beside / grid / ms /
+        walk_steps_done plus "steps" = the walk steps counted between the end of the previous launch and the end of this one"""
+        n = C.c_int32(0)
+        _check(self.lib.wost_last_launches(self._handle, None, 0, C.byref(n)), "wost_last_launches")
+        buf = (capi.LaunchInfo * max(n.value, 1))()
+        _check(self.lib.wost_last_launches(self._handle, buf, n.value, C.byref(n)), "wost_last_launches")
+        out, prev = [], 0
+        for i in range(n.value):
+            d = buf[i].as_dict()
+            d["kind_name"] = capi.LAUNCH_NAMES.get(d["kind"], str(d["kind"]))
+            if d["kind"] != capi.LAUNCH_WAIT:
+                d["steps"] = d["walk_steps_done"] - prev
+                prev = d["walk_steps_done"]
+            out.append(d)
+        return out
+
     def close(self):
         if self._handle:
             self.lib.wost_destroy(self._handle)

@@ -350,8 +350,36 @@ int wost_guided_train_set(wost_guided_handle h, int32_t capacity, int32_t *n, fl
 int wost_guided_set_option(wost_guided_handle h, const char *key, double value);
 int wost_guided_destroy(wost_guided_handle h);
 
+/* The launches of the last wost_solve / wost_solve_sharded of this handle, in order (bench.py prices the dominant one against
+ * the roofline; the reference has no counterpart: its solveImpl issues 2 + 5 * depth full-frame launches per sample,
+ * integrator/uniform/integrator.cu:529-623).  Writes min(*count, capacity) records. */
+typedef struct wost_launch_info {
+    int32_t kind;             /* WOST_LAUNCH_* */
+    uint32_t walkers;         /* walkers (pixels in flight) the launch started with                                      */
+    uint32_t walkers_beside;  /* walkers started with it on other streams: long remainders, strayed walkers               */
+    uint32_t grid;            /* workgroups                                                                              */
+    double ms;                /* HIP events around it on the solve's stream (what ran beside it ends inside later spans) */
+    uint64_t walk_steps_done; /* walk steps of the solve counted when the launch had ended (cumulative, all streams)      */
+} wost_launch_info;
+enum {
+    WOST_LAUNCH_ROUND = 0,       /* walk_round_kernel: every walker up to steps_per_round steps, then compaction          */
+    WOST_LAUNCH_QUAD = 1,        /* walk_quad_kernel: the same with four lanes per walker (under-filled launches)         */
+    WOST_LAUNCH_ONE = 2,         /* few samples per pixel: resident lanes drain the queue, the whole solve in one launch   */
+    WOST_LAUNCH_PERSISTENT = 3,  /* many samples per pixel: resident lanes take whole pixels, longest expected chain first,
+                                    until none is unread; what they hold then goes to rounds                              */
+    WOST_LAUNCH_WAIT = 4         /* no launch: the time the solve waited at its end for what ran beside the rounds         */
+};
+int wost_last_launches(wost_handle h, wost_launch_info *out, int32_t capacity, int32_t *count);
+
 /* Tuning knobs ("steps_per_round", "block_size", "refill", "thin_waves", ...; scheduling only,
  * never the result); unknown keys -> WOST_ERR_INVALID.
+ * "persist" (-1 automatic / 0 / 1): the persistent first launch of a solve with many samples per pixel and more walkers than
+ * resident lanes (WOST_LAUNCH_PERSISTENT); "persist_order" 0: in queue order instead of longest-first; "long_steps" (a multiple
+ * of 8, default 1024; 0 = none): pixels that launch hands over with at least that many walk steps expected still run to their
+ * end beside the rounds of the others, the first "long_thin" (2048) of them four to a wave, at most "long_cap" (32768);
+ * "tail_sort" (1): the first round after it takes its walkers in the order of their expected remainders; "few_order" (1): the
+ * one-launch path of few samples per pixel takes the pixels longest-first too; "resident_blocks": workgroups of those launches
+ * (0 = what the chip holds).
  * "spp" changes samplesPerPixel of an existing handle (a pixel's first k samples do not depend on
  * the total, so solving with spp = k reproduces the state of a longer solve after k samples: the
  * host mirror uses this for saveSppMetrics frames). */

@@ -558,6 +558,63 @@ def test_refill_launch_open_scene_every_walk_strays(oracle):
     assert np.isfinite(a).all()
 
 
+@pytest.mark.parametrize("scene,spp,depth,opts", [
+    ("ladybug", 24, 64, {"resident_blocks": 2}), ("ladybug", 24, 64, {"resident_blocks": 3, "block_size": 64}),
+    ("ladybug", 24, 64, {"resident_blocks": 5, "persist_order": 0}), ("ladybug", 24, 64, {}),
+    ("fille", 9, 128, {"resident_blocks": 4, "steps_per_round": 16}), ("fille", 9, 128, {"resident_blocks": 1, "quad": 1}),
+    # what the persistent launch hands over: the longest remainders beside the rounds (every pixel, none, a capped number), the rest sorted or not
+    ("ladybug", 24, 64, {"resident_blocks": 6, "long_steps": 8}), ("ladybug", 24, 64, {"resident_blocks": 6, "long_steps": 64, "long_cap": 37}),
+    ("ladybug", 24, 64, {"resident_blocks": 6, "long_steps": 0, "tail_sort": 0}), ("ladybug", 24, 64, {"resident_blocks": 6, "long_steps": 48, "tail_sort": 0}),
+    ("fille", 9, 128, {"resident_blocks": 8, "long_steps": 40, "steps_per_round": 8}),
+    ("fille", 9, 128, {"resident_blocks": 8, "long_steps": 16, "long_thin": 5}), ("ladybug", 24, 64, {"resident_blocks": 6, "long_steps": 8, "long_thin": 0}),
+])
+def test_persistent_first_launch_matches_oracle(oracle, scene, spp, depth, opts):
+    """The persistent first launch of a many-sample solve (round 6): a few resident blocks take the pixels of the frame one by
+    one, longest expected chain first, and when none is unread every wave hands the pixels it holds -- mid-pixel, mid-walk --
+    to the rounds.  A pixel's arithmetic does not depend on the lane that runs it or on where a launch ends: same bits, same
+    counters (the steps in flight when the queue runs dry are counted once)."""
+    from elaina_amd import Problem
+    p = Problem.load_scene(scene)
+    _assert_same_solve(oracle, p, 96, 80, spp, depth, 1.0, ref=_cached_ref(oracle, p, "persist-" + scene, 96, 80, spp, depth, 1.0), persist=1, **opts)
+
+
+def test_persistent_first_launch_with_mask_mixed_boundaries_and_strays(oracle):
+    from conftest import box_problem, wiggly_problem
+    from elaina_amd import Problem
+    p = box_problem(d_sides=(0, 2), n_sides=(1, 3), value=lambda x, y: y, flux=lambda x, y, s: 0.3 * (s - 2))
+    mask = (np.arange(70 * 50) % 3 != 0).astype(np.uint8)
+    p.mask = mask
+    ref = _assert_same_solve(oracle, p, 70, 50, 12, 32, 1e-3, persist=1, resident_blocks=2)
+    assert np.all(ref["field"][mask == 0] == 0)
+    _assert_same_solve(oracle, wiggly_problem(emissive=True), 48, 48, 7, 24, 0.05, persist=1, resident_blocks=3)
+    # an open polyline seen from afar: most walks stray beyond the plain visits' range, and a resident lane hands a strayed walker
+    # to the slack launch and takes the next pixel
+    t = np.linspace(0.0, 1.0, 301)
+    verts = np.stack([100.0 * t, 20.0 * np.sin(9.0 * t) + 5.0 * np.cos(31.0 * t)], 1).astype(np.float32)
+    segs = np.stack([np.arange(300), np.arange(300) + 1], 1).astype(np.int32)
+    cols = np.random.default_rng(5).uniform(0.0, 1.0, size=(301, 6)).astype(np.float32)
+    q = Problem(d_verts=verts, d_segs=segs, d_colors=cols, probe=(300.0, 50.0, 0.0, 0.0, 1.0))
+    _assert_same_solve(oracle, q, 64, 64, 6, 12, 0.5, persist=1, resident_blocks=2)
+
+
+def test_persistent_first_launch_is_chosen_for_a_full_frame_of_many_samples(ladybug):
+    """1024^2 walkers on 393 216 resident lanes, 16 samples each: the automatic choice is one persistent launch plus the rounds of
+    what it leaves; with persist = 0 the solve runs in rounds only.  Same field, same counters."""
+    from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+    it = UniformIntegrator(ladybug, UniformIntegratorSettings((1024, 1024), 16, 64, 1.0))
+    it.solve()
+    a, sa = it.solution.copy(), dict(it.last_stats)
+    it.set_option("persist", 0)
+    it.solve()
+    sb = dict(it.last_stats)
+    assert np.array_equal(a, it.solution)
+    # (not the node visits: the long remainders run with the visits that are exact at any distance, which prune a little less)
+    for k in ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated", "neumann_hits"):
+        assert sa[k] == sb[k], k
+    assert sa["walks_started"] == 16 * 1024 * 1024
+    it.close()
+
+
 def _with_source(problem, lo, hi, cells=24, seed=9, intensity=0.7):
     """attach a smooth random RGB source grid covering [lo, hi]^2 (and a margin of zero outside)"""
     rng = np.random.default_rng(seed)

@@ -2,7 +2,7 @@
 # one GPU-box trip: gpu tests, smoke, bench, rocprof kernel trace + PMC passes of the bench command.
 # TAG names the output directory under gpurun_out/; STAGES selects what runs (default: all).
 export TMPDIR=/tmp
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 STAGES=${STAGES:-"tests smoke micro bench trace pmc pmc_guided pmc3d pmc3d_1024 pmc_guided3d build3 build2"}
 mkdir -p gpurun_out/$TAG
 has() { [[ " $STAGES " == *" $1 "* ]]; }

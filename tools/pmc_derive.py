@@ -19,11 +19,17 @@ for line in open(summary):
     # template argument and a millionth of the counts
     if m and (m.group(1) not in tot or float(m.group(3)) > tot[m.group(1)][1]):
         tot[m.group(1)] = (int(m.group(2)), float(m.group(3)))
+# the counters above are those of the instantiation with the largest sums: since round 6 the persistent first launch of the solve
+# (one call per pass); the walk steps THAT launch took come from the bench line of the traced run (roofline.launch.walk_steps;
+# the launch ends when the pixel queue runs dry, so its share of the pass varies by a fraction of a percent between runs)
 steps = None
 try:
     for line in open(bench_log):
         if line.startswith("{"):
-            steps = json.loads(line)["config"]["walk_steps_per_pass"]
+            j = json.loads(line)
+            steps = j["config"]["walk_steps_per_pass"]
+            if j.get("roofline", {}).get("launch"):
+                steps = j["roofline"]["launch"]["walk_steps"]
 except Exception:
     pass
 if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
