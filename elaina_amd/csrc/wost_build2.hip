@@ -599,6 +599,11 @@ int build_tree_device(const wost_mesh_desc &d, DeviceTree2 &out_tree)
     if (!d.verts || !d.segs || d.n_verts <= 0) return set_error(WOST_ERR_INVALID, "mesh: segment index out of range or null arrays");
     if (d.n_segs > (1 << 26)) return set_error(WOST_ERR_UNSUPPORTED, "mesh: more than 2^26 segments");
     const int n = d.n_segs, nv = d.n_verts;
+    // an index out of range is refused HERE, before any launch: the kernels below leave their outputs unwritten when the code
+    // kernel reports it, and the sorts and gathers that follow would read stale keys as positions (round-5 advisor finding);
+    // the indices are in host memory, the loop is O(n)
+    for (int i = 0; i < 2 * n; ++i)
+        if (d.segs[i] < 0 || d.segs[i] >= nv) return set_error(WOST_ERR_INVALID, "mesh: segment index out of range or null arrays");
     B2Shape S{};
     S.n = n; S.nv = nv;
     const int n_leaves = (n + kLeafSize - 1) / kLeafSize;

@@ -914,6 +914,20 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
         }
     }
     const size_t lds_fused = ((size_t)Fn.xch_offset + 4 * (size_t)kG3XchWords) * sizeof(uint32_t);
+    if (fused && lds_fused > 48 * 1024) {
+        // the stack columns and pools were sized against 64 KB, the exchange area comes on top (up to 76 KB): ask once, before the
+        // sample loop, and take the launches per depth -- which need no more than `lds` -- when the device refuses
+        hipError_t e = hipSuccess;
+#define G3_ATTR(E, T) (has_src ? hipFuncSetAttribute(reinterpret_cast<const void *>(g3_fused_kernel<E, T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused) \
+                               : hipFuncSetAttribute(reinterpret_cast<const void *>(g3_fused_kernel<E, T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused))
+        if (ntree) e = emissive ? G3_ATTR(true, true) : G3_ATTR(false, true);
+        else e = emissive ? G3_ATTR(true, false) : G3_ATTR(false, false);
+#undef G3_ATTR
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            fused = false;
+        }
+    }
     for (int sample = 0; sample < s.spp; ++sample) {
         if (sample == s.train_spp_count) {      // :991-996
             training = false;
@@ -934,7 +948,6 @@ static int run_guided3(wost3_guided *g, int shard_index, int shard_count, float 
 #define G3_FUSED(E, T)                                                                                                                      \
     do {                                                                                                                                    \
         auto kfn = has_src ? g3_fused_kernel<E, T, true> : g3_fused_kernel<E, T, false>;                                                      \
-        if (lds_fused > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused); \
         hipLaunchKernelGGL(kfn, dim3(grid_px), dim3(256), lds_fused, stream, P, Fn);                                                         \
     } while (0)
             if (ntree) { if (emissive) G3_FUSED(true, true); else G3_FUSED(false, true); }

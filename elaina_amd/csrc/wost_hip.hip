@@ -595,10 +595,13 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
         } else {
             // ---- traversal phase: every traversing lane visits one node ----
             ++trav_trips;
-            if (P.trav_burst == 3) {
+#ifndef WOST_TRAV_BURST
+#define WOST_TRAV_BURST 3       // the burst the kernel is unrolled for (the handle's default trav_burst must equal it)
+#endif
+            if (P.trav_burst == WOST_TRAV_BURST) {
                 // the default burst, unrolled: no loop counter, and the compiler may start a visit's node load early
 #pragma unroll
-                for (int b = 0; b < 3; ++b) {
+                for (int b = 0; b < WOST_TRAV_BURST; ++b) {
                     if (mode == MODE_TRAV) {
                         S.visits++;
                         WOST_TRACK_VISIT_PRE();
@@ -1153,6 +1156,7 @@ struct wost_context {
     int wait_weight = 8;
     bool wait_weight_set = false;   // by wost_set_option: otherwise steps with tree queries on the Neumann side use weight 1
     int trav_burst = 3;
+    bool trav_burst_set = false;    // by wost_set_option: otherwise the persistent launch runs bursts of 5 with wait weight 6
     int time_kernels = 1;
     int refill = -1;       // -1 = automatic (few samples per pixel), 0 = never, 1 = always
     int persist = -1;      // many samples per pixel, more walkers than resident lanes: the first launch is persistent (lanes take pixels,
@@ -1445,6 +1449,7 @@ int wost_set_option(wost_handle h, const char *key, double value)
     } else if (k == "trav_burst") {
         if (value < 1 || value > 16) return fail(WOST_ERR_INVALID, "trav_burst must be in 1..16");
         h->trav_burst = (int)value;
+        h->trav_burst_set = true;
     } else if (k == "spp") {
         if (value < 0 || value >= (1 << 20)) return fail(WOST_ERR_INVALID, "spp must be in 0..2^20-1");
         h->settings.spp = (int32_t)value;
@@ -1789,6 +1794,10 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
             if (persist) {
                 rp.reserve = 0;
                 rp.leave_dry = 1;
+                // every lane holds a live walker throughout: longer traversal bursts and an earlier step trip pay here (config 2
+                // 222 -> 217 ms, config 3 327 -> 317, profiles/r06_i_burst_variants.txt), in rounds they do not
+                if (!c->trav_burst_set) rp.trav_burst = 5;
+                if (!c->wait_weight_set && !ntree) rp.wait_weight = 6;
             }
         }
         // Under-filled launch: four lanes per walker (walk_quad_kernel).  Such a launch lasts as long as its longest chain of

@@ -116,6 +116,27 @@ def test_gpu_device_tree_build_rejects_an_index_out_of_range():
 
 
 @pytest.mark.gpu
+def test_gpu_create_refuses_an_index_out_of_range_before_any_launch():
+    """wost_create builds its trees on the device (no host builder in front of it, unlike wost_mesh_build_check): a 2 000-segment
+    mesh with one bad index must come back as an error, twice in one process (the second build finds the first one's buffers in
+    the allocator), and a good mesh must still build and solve afterwards"""
+    from elaina_amd import Problem, UniformIntegrator, UniformIntegratorSettings
+    from elaina_amd.capi import WostError
+    V, S = _curve(2000, 1)
+    cols = np.random.default_rng(3).uniform(0, 1, (len(V), 6)).astype(np.float32)
+    for bad in (len(V), -1):
+        for _ in range(2):
+            Sb = S.copy()
+            Sb[1234, 1] = bad
+            with pytest.raises(WostError, match="out of range"):
+                UniformIntegrator(Problem(d_verts=V, d_segs=Sb, d_colors=cols, probe=(1.0, 0.0, 0.0, 0.0, 1.0)), UniformIntegratorSettings((16, 16), 2, 8, 1e-2))
+    it = UniformIntegrator(Problem(d_verts=V, d_segs=S, d_colors=cols, probe=(1.0, 0.0, 0.0, 0.0, 1.0)), UniformIntegratorSettings((16, 16), 2, 8, 1e-2))
+    it.solve()
+    assert np.isfinite(it.solution).all()
+    it.close()
+
+
+@pytest.mark.gpu
 def test_gpu_device_tree_build_of_the_shipped_scenes_takes_milliseconds():
     """wost_create's tree build of the BASELINE scenes (61 476 / 153 000 segments) -- fastest of five builds each way"""
     for name in ("ladybug", "fille"):

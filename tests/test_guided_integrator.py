@@ -705,6 +705,60 @@ def test_gpu_config5_frame_shard_trained_solve(ladybug):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", [32, 16])
+def test_gpu_config5_sample_count_with_the_phase_switch_on_a_thin_shard(ladybug, precision):
+    """BASELINE config 5's own sample count -- 1024 samples per pixel, the first 256 trained, then the switch to the guiding phase
+    (reference integrator/guided/integrator.cu:991-996: uniformFraction and maxGuidedDepth change, training stops) -- on its 2048^2
+    frame, for shard 0 of 64 (65 536 pixels: what keeps this inside the driver's clock).  Counters across the switch, an Adam pass
+    after every trained sample and none after, reproducibility (field and network twice), and agreement with the uniform
+    integrator's 1024-sample solve of the same pixels within Monte-Carlo noise."""
+    from elaina_amd import UniformIntegrator, UniformIntegratorSettings
+    from elaina_amd.distributed import owned_mask
+    from elaina_amd.guided import GuidedIntegrator, GuidedIntegratorSettings
+    import torch
+    w = h = 2048
+    spp, trained, shards = 1024, 256, 64
+    aabb = ((-100.0, -100.0), (600.0, 600.0))
+    st = GuidedIntegratorSettings(frameSize=(w, h), samplesPerPixel=spp, trainSppCount=trained, maxWalkingDepth=64, epsilonShell=1.0)
+    runs = []
+    for _ in range(2):
+        gi = GuidedIntegrator(ladybug, st, aabb, seed=11)
+        if precision == 16:
+            gi.network.set_option("precision", 16)
+            gi.network.set_option("train_precision", 16)
+        p_init = gi.network.params()
+        field = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+        s = gi.solve_sharded(0, shards, field.data_ptr())
+        torch.cuda.synchronize()
+        runs.append((field.cpu().numpy().reshape(-1, 3), gi.network.params(), dict(s)))
+        gi.close()
+    (f0, p0, s0), (f1, p1, s1) = runs
+    assert np.array_equal(f0, f1) and np.array_equal(p0, p1)
+    assert not np.array_equal(p0, p_init)
+    own = owned_mask(w, h, 0, shards)
+    n_own = int(own.sum())
+    assert n_own == w * h // shards and s0["walks_started"] == n_own * spp
+    assert s0["walks_absorbed"] + s0["walks_truncated"] == s0["walks_started"]
+    # every trained sample is followed by at least one Adam step (65 536 pixels leave at least minBatchSize records), at most five
+    # (batchesPerSpp), and the 768 guiding samples by none
+    assert trained <= s0["optimizer_steps"] <= 5 * trained
+    assert s0["train_samples"] >= 65536 * trained and s0["guided_steps"] > 0
+    for k in ("walk_steps", "train_samples", "optimizer_steps", "guided_steps", "walks_truncated"):
+        assert s0[k] == s1[k], k
+    assert not f0[~own].any() and np.isfinite(f0).all()
+    ui = UniformIntegrator(ladybug, UniformIntegratorSettings((w, h), spp, 64, 1.0))
+    uf = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    ui.solve_sharded(0, shards, uf.data_ptr())
+    torch.cuda.synchronize()
+    u = uf.cpu().numpy().reshape(-1, 3)
+    ui.close()
+    # two unbiased 1024-sample estimates of the same pixels
+    assert abs(float(f0[own].mean()) - float(u[own].mean())) < 5e-4 * max(1.0, abs(float(u[own].mean())))
+    rel = np.linalg.norm(f0[own] - u[own]) / np.linalg.norm(u[own])
+    assert rel < 0.05, rel
+
+
+@pytest.mark.gpu
 def test_gpu_train_pixel_offset_is_drawn_like_the_reference(oracle):
     """trainPixelStride > 1: prepareSolve draws trainPixelOffset = get1D() * stride from the integrator's host
     sampler, seeded setSeed(42) with sequence 1 in resetNetwork (reference integrator/guided/integrator.cu:126,
