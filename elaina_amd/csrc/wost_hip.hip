@@ -413,7 +413,13 @@ __global__ __launch_bounds__(256) void gather_walkers_kernel(WalkQueue in, const
 // probe looks at the scene from afar) stops there, untouched, and goes to the far end of the output queue; the host runs those
 // few walkers through the SLACK = true instantiation -- node visits exact at any distance (trav_visit<true>), which costs this
 // kernel a quarter of its throughput: more visits and, above all, registers -- for the length of a walk and returns them.
-template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, bool REFILL = false, bool SOURCE = false, bool SLACK = false>
+// PERSIST (with REFILL): the persistent first launch of a many-sample solve.  The same code, minus the state that only the
+// few-samples form needs: no wave-private reservation (a refill is rare: exactly the slots needed, one atomic per refill), no
+// 32-bit totals of the lane counters (a lane adds its counters to the statistics when its pixel is complete: six atomics per
+// pixel).  Eight registers fewer -- the instantiation wants 98 where six waves per SIMD allow 80, and what it spilled was not
+// only cold: the PCG state went through scratch at every step (a build with 96 registers and five waves per SIMD was 7 % faster
+// than the spilling one at the same five waves, profiles/r06_o_*).
+template <bool NEUMANN_EMISSIVE, bool NEUMANN_TREE, bool REFILL = false, bool SOURCE = false, bool SLACK = false, bool PERSIST = false>
 #ifndef WOST_ROUND_WAVES
 #define WOST_ROUND_WAVES 6      // waves per SIMD the round kernel is compiled for (tuning builds override it)
 #endif
@@ -472,20 +478,28 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
                 // parked in 6 000 private reservations would be a fifth of the frame when the cursor runs dry: reserve = 0 takes
                 // exactly the slots needed)
                 const int lane_ = threadIdx.x & 63;
-                const uint32_t needed = (uint32_t)__popcll(need), avail = pool_end - pool_next;
-                uint32_t fresh_base = 0;
-                const uint32_t want = P.reserve > 0 ? (uint32_t)P.reserve : needed - min(needed, avail);
-                if (needed > avail) {
-                    if (lane_ == 0) fresh_base = atomicAdd(P.cursor, want);
-                    fresh_base = __shfl(fresh_base, 0);
-                }
+                const uint32_t needed = (uint32_t)__popcll(need);
                 const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane_) - 1ull));
-                const uint32_t s2 = rank < avail ? pool_next + rank : fresh_base + (rank - avail);
-                if (needed > avail) {
-                    pool_next = fresh_base + (needed - avail);
-                    pool_end = fresh_base + want;
+                uint32_t s2;
+                if (PERSIST) {
+                    uint32_t fresh_base = 0;
+                    if (lane_ == 0) fresh_base = atomicAdd(P.cursor, needed);
+                    s2 = __shfl(fresh_base, 0) + rank;
                 } else {
-                    pool_next += needed;
+                    const uint32_t avail = pool_end - pool_next;
+                    uint32_t fresh_base = 0;
+                    const uint32_t want = P.reserve > 0 ? (uint32_t)P.reserve : needed - min(needed, avail);
+                    if (needed > avail) {
+                        if (lane_ == 0) fresh_base = atomicAdd(P.cursor, want);
+                        fresh_base = __shfl(fresh_base, 0);
+                    }
+                    s2 = rank < avail ? pool_next + rank : fresh_base + (rank - avail);
+                    if (needed > avail) {
+                        pool_next = fresh_base + (needed - avail);
+                        pool_end = fresh_base + want;
+                    } else {
+                        pool_next += needed;
+                    }
                 }
                 // the queue is dry: with leave_dry the wave stops here -- no new step starts (budget 0), queries in flight finish
                 // their step, pixels still open go to the output queue at the end of the kernel like the survivors of a round
@@ -497,8 +511,18 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
                         f[0] = L.sr / spp; f[1] = L.sg / spp; f[2] = L.sb / spp;
                     }
                     open = false;
-                    wide[0] += S.a & 0xffffu; wide[1] += S.a >> 16; wide[2] += S.b & 0xffffu; wide[3] += S.b >> 16;
-                    wide[4] += S.c; wide[5] += S.visits;
+                    if (PERSIST) {
+                        StatsDev *sd = my_stats(P.stats);
+                        if (S.a & 0xffffu) atomicAdd(&sd->steps, (unsigned long long)(S.a & 0xffffu));
+                        if (S.a >> 16) atomicAdd(&sd->started, (unsigned long long)(S.a >> 16));
+                        if (S.b & 0xffffu) atomicAdd(&sd->absorbed, (unsigned long long)(S.b & 0xffffu));
+                        if (S.b >> 16) atomicAdd(&sd->truncated, (unsigned long long)(S.b >> 16));
+                        if (S.c) atomicAdd(&sd->nhits, (unsigned long long)S.c);
+                        if (S.visits) atomicAdd(&sd->inner_visits, (unsigned long long)S.visits);
+                    } else {
+                        wide[0] += S.a & 0xffffu; wide[1] += S.a >> 16; wide[2] += S.b & 0xffffu; wide[3] += S.b >> 16;
+                        wide[4] += S.c; wide[5] += S.visits;
+                    }
                     S = LaneStats{0, 0, 0, 0};
                     if (s2 < n_in) {
                         load_lane(P.in, P.order ? P.order[s2] : s2, L, pix);
@@ -598,7 +622,7 @@ __global__ __launch_bounds__(256, NEUMANN_TREE ? 4 : WOST_ROUND_WAVES) void walk
 #ifndef WOST_TRAV_BURST
 #define WOST_TRAV_BURST 3       // the burst the kernel is unrolled for (the handle's default trav_burst must equal it)
 #endif
-            if (P.trav_burst == WOST_TRAV_BURST) {
+            if (!PERSIST && P.trav_burst == WOST_TRAV_BURST) {
                 // the default burst, unrolled: no loop counter, and the compiler may start a visit's node load early
 #pragma unroll
                 for (int b = 0; b < WOST_TRAV_BURST; ++b) {
@@ -1509,8 +1533,18 @@ int wost_set_option(wost_handle h, const char *key, double value)
 // the instantiation of the round kernel for a launch
 template <bool SLACK>
 static void launch_round(bool has_src, bool refill, bool ntree, bool emissive, unsigned grid, int bs, size_t lds_round, hipStream_t stream,
-                         const RoundParams &rp)
+                         const RoundParams &rp, bool persist = false)
 {
+    if (!SLACK && persist && refill && !has_src) {
+        if (ntree) {
+            if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true, true, false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+            else hipLaunchKernelGGL((walk_round_kernel<false, true, true, false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+        } else {
+            if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, false, true, false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+            else hipLaunchKernelGGL((walk_round_kernel<false, false, true, false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
+        }
+        return;
+    }
     if (has_src) {
         // problems with a source term: the SOURCE instantiations (one extra stage per step)
         if (ntree) {
@@ -1814,7 +1848,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
             launch_quad(has_src, ntree, emissive, grid, bs, (size_t)stack_depth * (bs / 4) * sizeof(uint32_t), stream, rp);
             HIP_TRY(hipGetLastError());
         } else if (n_round > 0) {
-            launch_round<false>(has_src, refill, ntree, emissive, grid, bs, lds_round, stream, rp);
+            launch_round<false>(has_src, refill, ntree, emissive, grid, bs, lds_round, stream, rp, persist);
             HIP_TRY(hipGetLastError());
         }
         if (far_now > 0) HIP_TRY(hipStreamWaitEvent(stream, c->far_ev1, 0));
