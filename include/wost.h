@@ -476,7 +476,8 @@ int wost3_destroy(wost3_handle h);
  * 8 x (lambda, kappa, mean vector) + selection logit = 41 outputs padded to 48), train.h:289-353 (3-D records) -- on the
  * scene types of the 3-D uniform integrator above.  The network is the one of wost3_net_create: the DenseGrid encoding
  * with three inputs (trilinear, res^3 entries per level), otherwise the configuration of data/ladybug/n.json:49-81; fp32.
- * Scenes with a source term are refused (WOST_ERR_UNSUPPORTED). */
+ * Scenes with a source term are solved like the others (sampleSourceImpl with DIM == 3, integrator.cu:277-364; the
+ * dense-grid stand-in for nanovdb of wost3_source_desc): tests/test_guided_3d.py::test_gpu_guided3_source_term_matches_oracle. */
 int wost3_net_create(int device, const wost_net_config *cfg, uint64_t seed, wost_net_handle *out);   /* inputs: 3 floats per point */
 typedef struct wost3_guided_settings {
     int32_t width, height, spp, max_depth;
