@@ -35,6 +35,7 @@ ap.add_argument("--net-train-precision", type=int, default=0, choices=[0, 32, 16
 ap.add_argument("--pipeline", type=int, default=0, help="1: the pipelined training order (wost_guided_set_option)")
 ap.add_argument("--train-group", type=int, default=1)
 ap.add_argument("--opt", action="append", default=[], help="key=value passed to wost_guided_set_option")
+ap.add_argument("--net-opt", action="append", default=[], help="key=value passed to wost_net_set_option")
 ap.add_argument("--repeat", type=int, default=1, help="solves (fresh integrator each); the last one is reported")
 a = ap.parse_args()
 
@@ -66,6 +67,9 @@ for rep in range(a.repeat):
     for kv in a.opt:
         k, v = kv.split("=")
         gi.set_option(k, float(v))
+    for kv in a.net_opt:
+        k, v = kv.split("=")
+        gi.network.set_option(k, float(v))
     field.zero_()
     if world > 1:
         dist.barrier()
@@ -96,7 +100,7 @@ if rank == 0:
         "pipeline": a.pipeline, "train_group": a.train_group, "n_gpus": world, "shard": "%d of %d" % (rank, shard_world), "solve_s": float(mx[0]), "train_s": float(mx[1]), "create_s": t_create,
         "walk_steps": int(tot[0]), "walk_steps_per_s": float(tot[0]) / float(mx[0]), "guided_steps": int(tot[1]),
         "train_samples": int(tot[2]), "optimizer_steps_all_ranks": int(tot[3]), "kernel_launches": s["kernel_launches"],
-        "mean": float(field.mean().item()), "field_crc": int(torch.frombuffer(bytearray(field.cpu().numpy().tobytes()), dtype=torch.int32).to(torch.int64).sum().item()), "opts": a.opt,
+        "mean": float(field.mean().item()), "field_crc": int(torch.frombuffer(bytearray(field.cpu().numpy().tobytes()), dtype=torch.int32).to(torch.int64).sum().item()), "opts": a.opt + a.net_opt, "params_crc": int(torch.frombuffer(bytearray(gi.network.params().tobytes()), dtype=torch.int32).to(torch.int64).sum().item()),
     }))
 if world > 1:
     dist.barrier()
