@@ -273,6 +273,11 @@ def run_uniform(env, scene, frame, spp, depth, steps, warmup, args, one_spp=True
     out = {
         "workload": "%s uniform %dx%d grid %d spp depth %d eps %g" % (scene, frame, frame, spp, depth, eps),
         "value": total_steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "walk_steps_per_pass": total_steps / steps,
+        # the unit of work is the reference's (one item consumed from the evaluation-point queue at one depth); the depth-0 steps among
+        # them make no closest-point query here: every sample of a pixel starts at the same point, whose query is answered once per pixel
+        "walk_step_note": "%.1f %% of the counted walk steps are depth-0 steps (= walks started), whose closest-point query is cached per pixel; "
+                          "same field and same count as the oracle, which repeats the query like the reference" % (
+                              100.0 * st["walks_started"] / max(st["walk_steps"], 1)),
         "roofline": {"bound": "hbm", "hbm_formula": "98 B x walk steps of the launch / its duration (SURVEY 8d)",
                      "what_binds": "the HBM formula is the contract's yardstick, not what limits this kernel: the walker state stays in registers inside a launch "
                                    "(traffic << algorithmic bytes); the VALU pipes are what is busy -- see valu_frac, valu",
@@ -701,7 +706,7 @@ def main():
         o = r["out"]
         line.update({"value": o["value"], "ms_per_step": o["ms_per_step"],
                      "config": {"workload": o["workload"], "parallelism": "pixel-tiles x%d" % env.world,
-                                "walk_steps_per_pass": o["walk_steps_per_pass"], "config": args.config}})
+                                "walk_steps_per_pass": o["walk_steps_per_pass"], "config": args.config, "walk_step_note": o.get("walk_step_note")}})
         if "time_to_1spp_ms" in o:
             line["time_to_1spp_ms"] = o["time_to_1spp_ms"]
         if "create_ms" in o:
