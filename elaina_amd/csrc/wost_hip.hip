@@ -1673,7 +1673,9 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         // a step that answers its Neumann queries on the tree is long and divergent: served when eight ninths of the
         // busy lanes wait (tools/probes/bench2d_wiggly.py: 3.87 -> 4.40 x 10^8 walk-steps/s on 3000 segments)
         rp.wait_weight = (ntree && !c->wait_weight_set) ? 1 : c->wait_weight;
-        rp.trav_burst = c->trav_burst;
+        // bursts of five visits unless the caller chose (round 6: + 1-2 % in rounds and shards as well as in the persistent launch,
+        // profiles/r06_v_*; a Neumann mesh on the tree keeps the three its step scheduling was tuned with)
+        rp.trav_burst = (c->trav_burst_set || ntree) ? c->trav_burst : 5;
         // a Neumann mesh on the tree: the task pools of every wave behind the stack columns (wost_coop.h)
         rp.coop = (ntree && c->coop && c->nm.view.levels <= 11) ? 1 : 0;
         rp.pool_cap = c->pool_cap > 0 ? c->pool_cap : std::min(1024, std::max(384, 128 * c->nm.view.levels));

@@ -612,6 +612,19 @@ def test_persistent_first_launch_is_chosen_for_a_full_frame_of_many_samples(lady
     for k in ("walk_steps", "walks_started", "walks_absorbed", "walks_truncated", "neumann_hits"):
         assert sa[k] == sb[k], k
     assert sa["walks_started"] == 16 * 1024 * 1024
+    # the launches of the two solves as wost_last_launches reports them: rounds only now; before, one persistent launch that took
+    # most of the steps, then rounds (and a wait for what ran beside them); the steps of the launches add up to the solve's
+    from elaina_amd import capi
+    rounds_only = it.last_launches()
+    assert all(l["kind"] in (capi.LAUNCH_ROUND, capi.LAUNCH_QUAD) for l in rounds_only)
+    assert rounds_only[-1]["walk_steps_done"] == sb["walk_steps"]
+    it.set_option("persist", -1)
+    it.solve()
+    ll = it.last_launches()
+    assert ll[0]["kind"] == capi.LAUNCH_PERSISTENT and ll[0]["walkers"] == 1024 * 1024 and ll[0]["steps"] > 0.7 * sa["walk_steps"]
+    assert all(l["kind"] != capi.LAUNCH_PERSISTENT for l in ll[1:])
+    assert sum(l.get("steps", 0) for l in ll) <= sa["walk_steps"]          # (what ran beside the last round ends inside the wait)
+    assert len([l for l in ll if l["kind"] != capi.LAUNCH_WAIT]) == it.last_stats["kernel_launches"] < len(rounds_only)
     it.close()
 
 
