@@ -69,7 +69,7 @@ def main():
     for seed in range(first, first + count):
         rng = np.random.default_rng(seed)
         p, scale, feat = random_problem(rng)
-        w, h, spp, depth = int(rng.choice([8, 24, 40])), int(rng.choice([8, 16, 24])), int(rng.choice([1, 3, 6])), int(rng.choice([4, 24, 64]))
+        w, h, spp, depth = int(rng.choice([8, 24, 40])), int(rng.choice([8, 16, 24])), int(rng.choice([1, 3, 6, 19])), int(rng.choice([4, 24, 64]))
         eps = scale * 10.0 ** rng.uniform(-4, -1.5)
         if rng.uniform() < 0.2:
             feat.append('mask')
@@ -86,6 +86,15 @@ def main():
                     "coop": int(rng.choice([0, 1, 1])), "pool_cap": int(rng.choice([96, 200, 384])), "ray_slot_trigger": int(rng.choice([1, 32, 64]))}
             feat.append(str(opts))
             for k, v in opts.items():
+                it.set_option(k, v)
+        if rng.uniform() < 0.35 and p.source is None and 'refill' not in feat:
+            # the persistent first launch of round 6 on a frame a few resident blocks drain: pixels taken longest-first (or in queue order),
+            # the hand-over with long remainders beside the rounds (every pixel long, none, a capped number, all thin or none), sorted or not
+            popts = {"persist": 1, "resident_blocks": int(rng.choice([1, 2, 3, 7])), "persist_order": int(rng.choice([0, 1, 1])),
+                     "long_steps": int(rng.choice([0, 8, 24, 64, 1024])), "long_cap": int(rng.choice([5, 64, 32768])), "long_thin": int(rng.choice([0, 3, 2048])),
+                     "tail_sort": int(rng.choice([0, 1]))}
+            feat.append(str(popts))
+            for k, v in popts.items():
                 it.set_option(k, v)
         it.solve()
         ref = oracle.solve(p.as_dict(), w, h, spp, depth, eps, threads=os.cpu_count() or 8)
