@@ -821,7 +821,21 @@ def main():
                         out["rel_l2_%s_256spp" % key] = rel_l2(fields[tag], refn)
                 return out
 
-            todo = [("cfg3", cfg3), ("cfg4", cfg4("cfg4")),
+            def cfg2_rounds():
+                """the headline configuration as it ran until round 5: rounds only (wost_set_option persist 0) -- one pass, the same field"""
+                import copy
+                a2 = copy.copy(args)
+                a2.opt = list(args.opt) + ["persist=0"]
+                r2 = run_uniform(env, "ladybug", 1024, 256, 0, 1, 0, a2, one_spp=False)
+                e2 = {k: r2["out"][k] for k in ("workload", "value", "ms_per_step")}
+                e2["launches"] = r2["out"]["roofline"]["launches"]
+                e2["what"] = "config 2 in rounds only (persist = 0): what the persistent first launch of round 6 replaced"
+                if uniform_field is not None:
+                    e2["field_identical_to_the_headline_solve"] = bool((r2["field"] == uniform_field).all().item())
+                r2["it"].close()
+                return e2
+
+            todo = [("cfg3", cfg3), ("cfg2_rounds_only", cfg2_rounds), ("cfg4", cfg4("cfg4")),
                     # the same configuration with the reference's half-precision network (tolerance-gated mode)
                     ("cfg4_f16", cfg4("cfg4_f16", precision=16)),
                     # the same in the opt-in reordered training order (sixteen samples per training launch; cfg4 / cfg4_f16 stay exact-order)
