@@ -12,7 +12,10 @@
 //     registers, then compacts the still-unfinished slots into the other queue with
 //     ballot/popcount + one atomic per wave, and resolves finished pixels into the field.
 //   * the per-lane LBVH traversal stack lives in LDS (one column per lane, bank = lane).
-//   * with few samples per pixel the REFILL instantiation drains the queue in ONE launch;
+//   * with few samples per pixel the REFILL instantiation drains the queue in ONE launch; with many, and more walkers
+//     than resident lanes, the first launch is PERSISTENT: lanes take whole pixels, longest expected chain first
+//     (wost_order.h), until none is unread, and hand what they hold to a few rounds -- the remainders expected to be
+//     long run to their end beside those rounds, four lanes to a walker (run_solve);
 //     problems with a source term use the SOURCE instantiations (wost_walk.h).
 //   * no managed memory, no CPU fallback.
 #include <hip/hip_runtime.h>
