@@ -621,7 +621,7 @@ def test_persistent_first_launch_is_chosen_for_a_full_frame_of_many_samples(lady
     it.set_option("persist", -1)
     it.solve()
     ll = it.last_launches()
-    assert ll[0]["kind"] == capi.LAUNCH_PERSISTENT and ll[0]["walkers"] == 1024 * 1024 and ll[0]["steps"] > 0.7 * sa["walk_steps"]
+    assert ll[0]["kind"] == capi.LAUNCH_PERSISTENT and ll[0]["walkers"] == 1024 * 1024 and ll[0]["steps"] > 0.5 * sa["walk_steps"]
     assert all(l["kind"] != capi.LAUNCH_PERSISTENT for l in ll[1:])
     assert sum(l.get("steps", 0) for l in ll) <= sa["walk_steps"]          # (what ran beside the last round ends inside the wait)
     assert len([l for l in ll if l["kind"] != capi.LAUNCH_WAIT]) == it.last_stats["kernel_launches"]
