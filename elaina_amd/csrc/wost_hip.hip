@@ -1538,15 +1538,15 @@ template <bool SLACK>
 static void launch_round(bool has_src, bool refill, bool ntree, bool emissive, unsigned grid, int bs, size_t lds_round, hipStream_t stream,
                          const RoundParams &rp, bool persist = false)
 {
-    if (!SLACK && persist && refill && !has_src) {
-        if (ntree) {
-            if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, true, true, false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-            else hipLaunchKernelGGL((walk_round_kernel<false, true, true, false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-        } else {
-            if (emissive) hipLaunchKernelGGL((walk_round_kernel<true, false, true, false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-            else hipLaunchKernelGGL((walk_round_kernel<false, false, true, false, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);
-        }
-        return;
+    if (!SLACK && persist && refill) {
+#define WOST_PERSIST_CASE(E, T, S)                                                                                                           \
+    if (emissive == E && ntree == T && has_src == S) {                                                                                       \
+        hipLaunchKernelGGL((walk_round_kernel<E, T, true, S, false, true>), dim3(grid), dim3(bs), lds_round, stream, rp);                    \
+        return;                                                                                                                              \
+    }
+        WOST_PERSIST_CASE(false, false, false) WOST_PERSIST_CASE(true, false, false) WOST_PERSIST_CASE(false, true, false) WOST_PERSIST_CASE(true, true, false)
+        WOST_PERSIST_CASE(false, false, true) WOST_PERSIST_CASE(true, false, true) WOST_PERSIST_CASE(false, true, true) WOST_PERSIST_CASE(true, true, true)
+#undef WOST_PERSIST_CASE
     }
     if (has_src) {
         // problems with a source term: the SOURCE instantiations (one extra stage per step)
@@ -1807,7 +1807,9 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         // 1 spp 3.5 -> 3.0 ms, 4 spp 8.3 -> 7.9 ms, 8 spp 13.0 -> 13.5 ms) and the queue is larger
         // than one residency; the 16-bit lane counters bound spp * max_depth.
         const unsigned resident = c->resident_blocks > 0 ? std::min((unsigned)c->resident_blocks, (unsigned)c->n_cus * blocks_per_cu) : (unsigned)c->n_cus * blocks_per_cu;
-        const bool can_refill = (int64_t)c->settings.spp * c->settings.max_depth < 65535 && launches == 0 && !has_src;
+        // (the one-launch form of few samples has no instantiation with a source term; the persistent launch has)
+        const bool can_persist = (int64_t)c->settings.spp * c->settings.max_depth < 65535 && launches == 0;
+        const bool can_refill = can_persist && !has_src;
         const bool few = can_refill && (c->refill == 1 || (c->refill == -1 && c->settings.spp <= 4 && grid > resident));
         // PERSISTENT first launch (many samples per pixel, more walkers than resident lanes): the same resident threads, but the
         // lanes take whole pixels -- all of a pixel's samples, the pixels in the order of wost_order.h, longest expected chain first
@@ -1815,7 +1817,7 @@ static int run_solve(wost_context *c, int32_t pixel_begin, int32_t pixel_end, in
         // in rounds.  No lane idles behind a finished pixel and no launch ends while pixels are unread (in rounds, config 2 spent
         // 108 of its 252 ms in launches where a third of the lanes had finished their pixel, EXPERIMENTS 25); what the rounds
         // get is the remainder of one pixel per lane.
-        const bool persist = can_refill && !few && c->refill != 1 &&
+        const bool persist = can_persist && !few && c->refill != 1 &&
                              (c->persist == 1 || (c->persist == -1 && c->settings.spp > 4 && n_active > resident_threads));
         const bool refill = few || persist;
         if (refill) {

@@ -652,6 +652,10 @@ def test_source_term_matches_oracle(oracle, ladybug):
     lb = _with_source(copy.copy(ladybug), -100.0, 600.0, cells=40, intensity=1e-3)
     _assert_same_solve(oracle, lb, 64, 48, 3, 64, 1.0)
     _assert_same_solve(oracle, _with_source(wiggly_problem(emissive=True), -130.0, 130.0, intensity=1e-3), 40, 40, 2, 24, 0.05)
+    # the persistent first launch with a source term (round 6): a few resident blocks take the pixels, the hand-over with long remainders
+    _assert_same_solve(oracle, mixed, 48, 40, 14, 32, 1e-3, persist=1, resident_blocks=2, long_steps=16)
+    _assert_same_solve(oracle, lb, 64, 48, 9, 64, 1.0, persist=1, resident_blocks=3, block_size=64)
+    _assert_same_solve(oracle, _with_source(wiggly_problem(emissive=True), -130.0, 130.0, intensity=1e-3), 40, 40, 7, 24, 0.05, persist=1, resident_blocks=2, long_steps=8)
 
 
 def test_render_source_matches_oracle(oracle):

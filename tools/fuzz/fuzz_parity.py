@@ -87,7 +87,7 @@ def main():
             feat.append(str(opts))
             for k, v in opts.items():
                 it.set_option(k, v)
-        if rng.uniform() < 0.35 and p.source is None and 'refill' not in feat:
+        if rng.uniform() < 0.35 and 'refill' not in feat:
             # the persistent first launch of round 6 on a frame a few resident blocks drain: pixels taken longest-first (or in queue order),
             # the hand-over with long remainders beside the rounds (every pixel long, none, a capped number, all thin or none), sorted or not
             popts = {"persist": 1, "resident_blocks": int(rng.choice([1, 2, 3, 7])), "persist_order": int(rng.choice([0, 1, 1])),
