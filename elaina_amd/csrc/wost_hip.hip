@@ -1447,6 +1447,18 @@ int wost_create(const wost_scene_desc *scene, const wost_settings *settings, int
     HIP_TRY_C(hipEventCreateWithFlags(&c->long_ev1, hipEventDisableTiming));
     HIP_TRY_C(hipEventCreate(&c->ev0));
     HIP_TRY_C(hipEventCreate(&c->ev1));
+    {
+        // the order of a persistent / one-launch solve: its buffers and the first use of its sort kernels (their code objects load
+        // then: 2.5 ms) belong here, beside the tree builds, not inside the first solve -- time-to-1spp of a fresh handle
+        HIP_TRY_C((hipError_t)order_alloc(c->order, c->n_pixels));
+        const uint32_t n_warm = (uint32_t)std::min<size_t>(c->n_pixels, 1024);
+        const uint32_t *unused = nullptr;
+        HIP_TRY_C(hipMemsetAsync(c->queue[0].d0_d2, 0, n_warm * sizeof(float), c->stream));
+        HIP_TRY_C(hipMemsetAsync(c->queue[0].est, 0, n_warm * sizeof(float), c->stream));
+        HIP_TRY_C((hipError_t)order_by_distance(c->order, c->queue[0].d0_d2, n_warm, c->stream, &unused));
+        HIP_TRY_C((hipError_t)order_by_estimate(c->order, c->queue[0].est, n_warm, c->stream, &unused));
+        HIP_TRY_C(hipStreamSynchronize(c->stream));
+    }
 #undef HIP_TRY_C
     *out = c;
     return WOST_OK;
